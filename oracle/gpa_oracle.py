@@ -1,0 +1,442 @@
+"""CPU oracle for the GPA hot path -- TEST INFRASTRUCTURE, NOT PRODUCT CODE.
+
+A NumPy/SciPy restatement of the windowed-Fourier lock-in displacement-field
+pipeline of TAdeJong/pyGPA.  It is the checker the
+HIP path is compared against and the ``cpu_baseline`` leg of ``bench.py``.
+Only ``tests/``, ``__graft_entry__.smoke()`` and ``bench.py``'s cpu_baseline may
+import this module; the product package ``pygpa_amd`` never does.
+
+Parity status: PINNED for a1..a8 -- every function below is checked against
+outputs of the real reference (imported from /root/reference in the build
+container by ``oracle/make_golden.py``; vectors committed under
+``tests/golden/``) by ``tests/test_oracle_golden.py``.
+UNPINNED for a9 (``per``): the arithmetic lives in the third-party package
+``moisan2011`` (unpinned git HEAD of github.com/TAdeJong/moisan2011, named at
+reference README.md:18,24 and .github/workflows/ci.yaml:32), which is absent
+from /root/reference; it is restated from Moisan (2011) and self-checked with
+known answers only.
+
+All ``file:line`` citations are into the reference checkout
+(``pyGPA/geometric_phase_analysis.py`` = gpa.py, ``pyGPA/phase_unwrap.py`` =
+pu.py, ``pyGPA/mathtools.py`` = mt.py, ``pyGPA/cuGPA.py`` = cu.py).
+
+Conventions: image axis 0 <-> "x" <-> kvec[0], axis 1
+<-> "y" <-> kvec[1]; forward FFT unnormalised, inverse 1/(N*M).
+"""
+import numpy as np
+import scipy.fft as sfft
+import scipy.optimize as spo
+
+TWO_PI = 2.0 * np.pi
+
+
+# --------------------------------------------------------------------------
+# small helpers
+# --------------------------------------------------------------------------
+def wrap_to_pi(x):
+    """(x + pi) mod 2pi - pi with floored mod: range [-pi, pi), +pi -> -pi.
+
+    Follows mt.py:72-75 (wrapToPi) and pu.py:135-138 (_wrapToPi).
+    """
+    return np.mod(x + np.pi, TWO_PI) - np.pi
+
+
+def gaussian_kspace_1d(n, sigma):
+    """1-D factor of the k-space Gaussian: exp(-2 pi^2 sigma^2 f^2), f = fftfreq(n).
+
+    ``scipy.ndimage.fourier_gaussian`` (called at gpa.py:44, :75, :87 and
+    cu.py:57) is the outer product of two of these, each factor flushed to
+    exactly 0 where its exponent exceeds 50 (SciPy's ni_fourier.c does that per
+    axis); checked against SciPy in tests/test_oracle_golden.py.
+    """
+    f = np.fft.fftfreq(n)
+    e = 2.0 * np.pi ** 2 * sigma ** 2 * f * f
+    return np.where(e > 50.0, 0.0, np.exp(-e))
+
+
+def carrier_1d(n, k):
+    """exp(2 pi i * x * k) for x = 0..n-1 (one separable factor of gpa.py:73)."""
+    return np.exp(2j * np.pi * np.arange(n) * k)
+
+
+# --------------------------------------------------------------------------
+# a1 / a2: single and batched lock-in
+# --------------------------------------------------------------------------
+def lockin(image, kvec, sigma, workers=1):
+    """One spatial lock-in: ifft2(fft2(image * carrier) * Gaussian).
+
+    Follows GPA (gpa.py:20-45), optGPA (gpa.py:48-76), cuGPA (cu.py:11-38).
+    Always returns complex128 (the reference's carrier is complex128).
+    """
+    image = np.asarray(image)
+    n0, n1 = image.shape
+    carrier = carrier_1d(n0, kvec[0])[:, None] * carrier_1d(n1, kvec[1])[None, :]
+    spec = sfft.fft2(image * carrier, workers=workers)
+    spec *= gaussian_kspace_1d(n0, sigma)[:, None]
+    spec *= gaussian_kspace_1d(n1, sigma)[None, :]
+    return sfft.ifft2(spec, workers=workers)
+
+
+def lockin_batch(image, kvecs, sigma, workers=1):
+    """Batched lock-in over a (B, 2) list of k-vectors -> (B, N, M).
+
+    Follows vecGPA (gpa.py:79-89).
+    """
+    kvecs = np.atleast_2d(np.asarray(kvecs, dtype=np.float64))
+    return np.stack([lockin(image, kv, sigma, workers=workers) for kv in kvecs])
+
+
+# --------------------------------------------------------------------------
+# a3 / a4: reference-vector sweep
+# --------------------------------------------------------------------------
+def sweep_grid(kx, ky, kw, kstep):
+    """The (K, 2) list of reference vectors of the reference's double loop,
+    wx outer / wy inner, built with np.arange exactly as gpa.py:679-680 does
+    (its length is float-rounding dependent, so it is always built on the host).
+    """
+    wxs = np.arange(kx - kw, kx + kw, kstep)
+    wys = np.arange(ky - kw, ky + kw, kstep)
+    return np.array([(wx, wy) for wx in wxs for wy in wys], dtype=np.float64).reshape(-1, 2)
+
+
+def sweep(image, sigma, klist, kref, want_grad=False, workers=1):
+    """Adaptive lock-in over an explicit k-list.
+
+    For every k in ``klist`` (in order) compute sf = lockin(image, k); a pixel
+    takes the candidate when |sf| is strictly larger than the amplitude kept so
+    far (accumulator starts at 0).  The stored value is re-referenced to
+    ``kref``: sf * exp(-2 pi i ((wx-kx) x + (wy-ky) y)).
+
+    Follows optwfr2 (gpa.py:669-686), wfr2 (gpa.py:615-644), wfr3
+    (gpa.py:647-666), wfr2_only_lockin (gpa.py:689-702) and, with
+    ``want_grad``, wfr2_grad_opt (gpa.py:763-813; GPU twin cu.py:41-87).
+
+    Returns dict: 'lockin' (N,M) c128, 'kidx' (N,M) int32 index into klist of
+    the winner (-1 where no candidate ever won), 'w' (2,N,M) f64 (gpa.py:685),
+    and with want_grad 'grad' (N,M,2) f64.
+    """
+    image = np.asarray(image)
+    klist = np.asarray(klist, dtype=np.float64).reshape(-1, 2)
+    n0, n1 = image.shape
+    best = np.zeros((n0, n1), dtype=np.complex128)
+    best_amp = np.zeros((n0, n1))
+    kidx = np.full((n0, n1), -1, dtype=np.int32)
+    grad = np.zeros((n0, n1, 2)) if want_grad else None
+    for i, (wx, wy) in enumerate(klist):
+        sf = lockin(image, (wx, wy), sigma, workers=workers)
+        amp = np.abs(sf)
+        take = amp > best_amp
+        comp = carrier_1d(n0, -(wx - kref[0]))[:, None] * carrier_1d(n1, -(wy - kref[1]))[None, :]
+        best = np.where(take, sf * comp, best)
+        best_amp = np.where(take, amp, best_amp)
+        kidx[take] = i
+        if want_grad:
+            ph = -np.angle(sf)
+            g = np.stack(np.gradient(ph), axis=-1)
+            g = g + TWO_PI * np.array([wx - kref[0], wy - kref[1]])
+            grad = np.where(take[..., None], g, grad)
+    w = np.zeros((2, n0, n1))
+    won = kidx >= 0
+    w[0][won] = klist[kidx[won], 0]
+    w[1][won] = klist[kidx[won], 1]
+    out = {'lockin': best, 'kidx': kidx, 'w': w}
+    if want_grad:
+        out['grad'] = wrap_to_pi(2 * grad) / 2
+    return out
+
+
+def optwfr2(image, sigma, kx, ky, kw, kstep, workers=1):
+    """gpa.py:669-686 signature; list built by :func:`sweep_grid`."""
+    return sweep(image, sigma, sweep_grid(kx, ky, kw, kstep), (kx, ky), workers=workers)
+
+
+def wfr2_grad_opt(image, sigma, kx, ky, kw, kstep, workers=1):
+    """gpa.py:763-813 signature."""
+    return sweep(image, sigma, sweep_grid(kx, ky, kw, kstep), (kx, ky),
+                 want_grad=True, workers=workers)
+
+
+# --------------------------------------------------------------------------
+# a5: phases / weights glue
+# --------------------------------------------------------------------------
+def derive_params(kvecs, sigma=None, kwscale=2.5, ksteps=3):
+    """kw, sigma, kstep of extract_displacement_field (gpa.py:915-918)."""
+    norms = np.linalg.norm(np.asarray(kvecs, dtype=np.float64), axis=1)
+    kw = norms.mean() / kwscale
+    if sigma is None:
+        sigma = int(np.ceil(1 / norms.min()))
+    return kw, sigma, kw / ksteps
+
+
+def interior_mask(shape, dr):
+    """Boolean mask, True on [dr:-dr, dr:-dr] (gpa.py:923-925)."""
+    mask = np.zeros(shape, dtype=bool)
+    mask[dr:-dr, dr:-dr] = True
+    return mask
+
+
+def phases_weights(lockins, sigma):
+    """phases = angle(lockin); weights = |lockin| * (mask + 1e-6) (gpa.py:922-926)."""
+    lockins = np.asarray(lockins)
+    mask = interior_mask(lockins.shape[1:], 2 * sigma)
+    return np.angle(lockins), np.abs(lockins) * (mask + 1e-6), mask
+
+
+# --------------------------------------------------------------------------
+# a6: per-pixel weighted least squares
+# --------------------------------------------------------------------------
+def weighted_lstsq(b, kmat, w):
+    """Per pixel: argmin_x || w * (kmat @ x - b) ||, kmat (P,2), b/w (P,n,m').
+
+    The reference calls LAPACK gelsd per pixel (myweighed_lstsq, gpa.py:97-113);
+    this is the equivalent 2x2 normal-equation solve, with the min-norm answer
+    at rank-deficient pixels (all-zero weights -> 0).  w is cropped to b's shape
+    (weight of the left/top pixel of each difference, gpa.py:110).
+    """
+    b = np.asarray(b, dtype=np.float64)
+    w = np.asarray(w, dtype=np.float64)[:, :b.shape[1], :b.shape[2]]
+    ww = w * w
+    k0 = kmat[:, 0][:, None, None]
+    k1 = kmat[:, 1][:, None, None]
+    a00 = (ww * k0 * k0).sum(0)
+    a01 = (ww * k0 * k1).sum(0)
+    a11 = (ww * k1 * k1).sum(0)
+    r0 = (ww * k0 * b).sum(0)
+    r1 = (ww * k1 * b).sum(0)
+    det = a00 * a11 - a01 * a01
+    tr = a00 + a11
+    ok = det > 1e-28 * tr * tr
+    safe = np.where(ok, det, 1.0)
+    x0 = np.where(ok, (a11 * r0 - a01 * r1) / safe, 0.0)
+    x1 = np.where(ok, (a00 * r1 - a01 * r0) / safe, 0.0)
+    # rank-1 pixels: minimum-norm solution rhs / trace
+    r1m = (~ok) & (tr > 0)
+    safetr = np.where(tr > 0, tr, 1.0)
+    x0 = np.where(r1m, r0 / safetr, x0)
+    x1 = np.where(r1m, r1 / safetr, x1)
+    return np.stack([x0, x1])
+
+
+def reconstruct_gradients(kvecs, phases, weights):
+    """Wrapped phase differences -> displacement-gradient fields.
+
+    dbdx = wrap(diff(phases, axis=2)), dbdy = wrap(diff(phases, axis=1))
+    (gpa.py:234-235), each solved per pixel against K = 2 pi kvecs
+    (gpa.py:227, :236-237).  Returns dudx (2,N,M-1), dudy (2,N-1,M).
+    """
+    kmat = TWO_PI * np.asarray(kvecs, dtype=np.float64)
+    dbdx = wrap_to_pi(np.diff(phases, axis=2))
+    dbdy = wrap_to_pi(np.diff(phases, axis=1))
+    return weighted_lstsq(dbdx, kmat, weights), weighted_lstsq(dbdy, kmat, weights)
+
+
+# --------------------------------------------------------------------------
+# a7: DCT-Laplacian weighted phase unwrap (Ghiglia-Romero PCG)
+# --------------------------------------------------------------------------
+def poisson_scale(shape, compat=True):
+    """Eigenvalues of the Neumann Laplacian used as DCT-domain divisor.
+
+    compat=True replicates precomp_Poissonscaling (pu.py:106-115) literally,
+    including its swapped axes 2(cos(pi I/M)+cos(pi J/N)-2) for I<N, J<M
+    (identical for square images); compat=False uses the proper cos(pi I/N)+
+    cos(pi J/M).  [0,0] -> 1.
+    """
+    n, m = shape
+    i = np.arange(n)[:, None]
+    j = np.arange(m)[None, :]
+    if compat:
+        scale = 2 * (np.cos(np.pi * i / m) + np.cos(np.pi * j / n) - 2)
+    else:
+        scale = 2 * (np.cos(np.pi * i / n) + np.cos(np.pi * j / m) - 2)
+    scale[0, 0] = 1.0
+    return scale
+
+
+def apply_q(p, wwx, wwy):
+    """A^T diag(WWx,WWy) A p with zero-padded outer differences (pu.py:118-132)."""
+    fx = wwx * (p[:, 1:] - p[:, :-1])
+    fy = wwy * (p[1:, :] - p[:-1, :])
+    q = np.zeros_like(p)
+    q[:, :-1] += fx
+    q[:, 1:] -= fx
+    q[:-1, :] += fy
+    q[1:, :] -= fy
+    return q
+
+
+def unwrap_prediff(dx, dy, weight=None, kmax=100, eps=1e-9, compat=True,
+                   workers=1, return_iters=False):
+    """Weighted least-squares unwrap from pre-differenced gradients.
+
+    dx (N,M-1) = differences along axis 1, dy (N-1,M) along axis 0, both
+    re-wrapped to [-pi,pi) first (pu.py:296-297).  Edge weights = min of the
+    squared weights of the two pixels (pu.py:305-310).  PCG with the DCT Poisson
+    solve as preconditioner, in the operation order of pu.py:326-349.
+    Follows phase_unwrap_prediff (pu.py:282-350).
+    """
+    dx = wrap_to_pi(np.asarray(dx, dtype=np.float64))
+    dy = wrap_to_pi(np.asarray(dy, dtype=np.float64))
+    n, m = dx.shape[0], dy.shape[1]
+    if weight is None:
+        wwx = np.ones_like(dx)
+        wwy = np.ones_like(dy)
+    else:
+        ww = np.asarray(weight, dtype=np.float64) ** 2
+        wwx = np.minimum(ww[:, :-1], ww[:, 1:])
+        wwy = np.minimum(ww[:-1, :], ww[1:, :])
+    fx = wwx * dx
+    fy = wwy * dy
+    r = np.zeros((n, m))
+    r[:, :-1] += fx
+    r[:, 1:] -= fx
+    r[:-1, :] += fy
+    r[1:, :] -= fy
+    # r[j] = f[j] - f[j-1] with zero-padded ends: np.diff(prepend=0, append=0)
+    # of pu.py:315-316.
+    norm0 = np.linalg.norm(r)
+    phi = np.zeros((n, m))
+    scale = poisson_scale((n, m), compat=compat)
+    k = 0
+    rho_prev = None
+    p = None
+    while np.any(r != 0.0):
+        z = sfft.idctn(sfft.dctn(r, workers=workers) / scale, workers=workers)
+        k += 1
+        rho = np.vdot(r, z)
+        p = z if k == 1 else z + (rho / rho_prev) * p
+        rho_prev = rho
+        q = apply_q(p, wwx, wwy)
+        alpha = rho / np.vdot(p, q)
+        phi = phi + alpha * p
+        r = r - alpha * q
+        if k >= kmax or np.linalg.norm(r) < eps * norm0:
+            break
+    return (phi, k) if return_iters else phi
+
+
+def unwrap(psi, weight=None, kmax=100, **kw):
+    """Unwrap a wrapped phase image: differences wrapped, then as unwrap_prediff.
+
+    Follows phase_unwrap (pu.py:141-208).
+    """
+    psi = np.asarray(psi, dtype=np.float64)
+    return unwrap_prediff(np.diff(psi, axis=1), np.diff(psi, axis=0),
+                          weight=weight, kmax=kmax, **kw)
+
+
+# --------------------------------------------------------------------------
+# a5+a6+a7 driver pieces and the top-level entry point
+# --------------------------------------------------------------------------
+def reconstruct_u_inv_from_phases(kvecs, phases, weights, weighted_unwrap=True,
+                                  kmax=10, workers=1, return_iters=False):
+    """gpa.py:196-245 (pre_diff=False branch)."""
+    dudx, dudy = reconstruct_gradients(kvecs, phases, weights)
+    wn = np.linalg.norm(weights, axis=0) if weighted_unwrap else None
+    us, iters = [], []
+    for i in range(2):
+        if weighted_unwrap:
+            phi, it = unwrap_prediff(dudx[i], dudy[i], wn, kmax=kmax,
+                                     workers=workers, return_iters=True)
+        else:
+            phi, it = unwrap_prediff(dudx[i], dudy[i], workers=workers, return_iters=True)
+        us.append(phi)
+        iters.append(it)
+    u = np.array(us)
+    return (u, iters) if return_iters else u
+
+
+def extract_displacement_field(image, kvecs, sigma=None, kwscale=2.5, ksteps=3,
+                               klists=None, workers=1, return_parts=False):
+    """Top-level path, gpa.py:907-932 (deconvolve=False).
+
+    ``klists``: optional list of P explicit (K,2) k-lists (wfr3-style,
+    gpa.py:647-666) replacing the np.arange grid -- used for the BASELINE
+    configs whose K is not a square number.
+    """
+    image = np.asarray(image, dtype=np.float64)
+    kvecs = np.asarray(kvecs, dtype=np.float64)
+    kw, sigma, kstep = derive_params(kvecs, sigma, kwscale, ksteps)
+    img0 = image - image.mean()
+    gs = []
+    for p, pk in enumerate(kvecs):
+        kl = sweep_grid(pk[0], pk[1], kw, kstep) if klists is None else klists[p]
+        gs.append(sweep(img0, sigma, kl, pk, workers=workers))
+    lockins = np.stack([g['lockin'] for g in gs])
+    phases, weights, _ = phases_weights(lockins, sigma)
+    u, iters = reconstruct_u_inv_from_phases(kvecs, phases, weights, workers=workers,
+                                             return_iters=True)
+    if return_parts:
+        return u, {'gs': gs, 'phases': phases, 'weights': weights, 'iters': iters,
+                   'sigma': sigma, 'kw': kw, 'kstep': kstep}
+    return u
+
+
+# --------------------------------------------------------------------------
+# a8: single-reference-vector route
+# --------------------------------------------------------------------------
+def fit_plane(image):
+    """Huber-loss plane fit a0*x + a1*y + a2 (mt.py:30-47)."""
+    xx, yy = np.meshgrid(np.arange(image.shape[0]), np.arange(image.shape[1]), indexing='ij')
+
+    def resid(a):
+        return (image - (a[0] * xx + a[1] * yy + a[2])).ravel()
+    return spo.least_squares(resid, np.zeros(3), loss='huber').x
+
+
+def iterate_gpa(image, kvecs, sigma, edge=5, iters=3, kmax_iter=25, kmax=200):
+    """Reference-vector refinement loop, gpa.py:116-154 (+ fit_delta_k :92-94)."""
+    kvecs = np.asarray(kvecs, dtype=np.float64)
+    corr = np.zeros_like(kvecs)
+    for i in range(iters + 1):
+        rs = lockin_batch(image, kvecs + corr, sigma)
+        sl = (slice(edge, -edge), slice(edge, -edge)) if edge > 0 else (slice(None), slice(None))
+        prs = [np.angle(r)[sl] for r in rs]
+        w = np.stack([np.abs(r)[sl] for r in rs])
+        last = i == iters
+        prs = [unwrap(pr, np.sqrt(we / we.max()), kmax=kmax if last else kmax_iter)
+               for pr, we in zip(prs, w)]
+        if not last:
+            corr = corr - np.stack([fit_plane(pr)[:2] / TWO_PI for pr in prs])
+    return np.stack(prs), w, corr
+
+
+def reconstruct_u_inv(kvecs, b, weights=None):
+    """Unwrapped phases -> u (gpa.py:157-193, use_only_ks=None branches)."""
+    kmat = TWO_PI * np.asarray(kvecs, dtype=np.float64)
+    b = b - b.mean(axis=(1, 2), keepdims=True)
+    if weights is None:
+        sol = np.linalg.lstsq(kmat, b.reshape((b.shape[0], -1)), rcond=None)[0]
+        return sol.reshape((2,) + b.shape[1:])
+    return weighted_lstsq(b, kmat, weights)
+
+
+# --------------------------------------------------------------------------
+# a9: smooth + periodic decomposition (PARITY UNPINNED, see module docstring)
+# --------------------------------------------------------------------------
+def per(image, inverse_dft=True):
+    """Moisan (2011) periodic + smooth decomposition.
+
+    Call site gpa.py:429 uses per(image, inverse_dft=False)[0] = DFT of the
+    periodic component.  s_hat = v_hat / (2cos(2 pi q/N) + 2cos(2 pi r/M) - 4),
+    s_hat[0,0] = 0, v = border-jump image; p_hat = u_hat - s_hat.
+    """
+    u = np.asarray(image, dtype=np.float64)
+    n, m = u.shape
+    v = np.zeros_like(u)
+    d0 = u[-1, :] - u[0, :]
+    v[0, :] += d0
+    v[-1, :] -= d0
+    d1 = u[:, -1] - u[:, 0]
+    v[:, 0] += d1
+    v[:, -1] -= d1
+    vhat = np.fft.fft2(v)
+    q = np.arange(n)[:, None]
+    r = np.arange(m)[None, :]
+    den = 2 * np.cos(TWO_PI * q / n) + 2 * np.cos(TWO_PI * r / m) - 4
+    den[0, 0] = 1.0
+    shat = vhat / den
+    shat[0, 0] = 0.0
+    phat = np.fft.fft2(u) - shat
+    if inverse_dft:
+        return np.real(np.fft.ifft2(phat)), np.real(np.fft.ifft2(shat))
+    return phat, shat

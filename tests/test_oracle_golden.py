@@ -1,0 +1,137 @@
+"""Pin the CPU oracle against vectors produced by the real reference
+(oracle/make_golden.py).  CPU only."""
+import numpy as np
+import pytest
+import scipy.ndimage as ndi
+
+from oracle import gpa_oracle as orc
+
+CASES = ['hex_64', 'hex_48x80', 'hex_63x65']
+
+
+def test_gaussian_matches_scipy_fourier_gaussian():
+    for shape in [(64, 64), (48, 80), (63, 65)]:
+        for sigma in (6, 7, 10.5, 22):
+            ref = ndi.fourier_gaussian(np.ones(shape), sigma=sigma)
+            mine = orc.gaussian_kspace_1d(shape[0], sigma)[:, None] * orc.gaussian_kspace_1d(shape[1], sigma)[None, :]
+            assert np.array_equal(ref == 0, mine == 0)
+            assert np.allclose(ref, mine, rtol=1e-12, atol=0)
+
+
+def test_wrap_to_pi_edges():
+    assert orc.wrap_to_pi(np.pi) == -np.pi
+    assert orc.wrap_to_pi(-np.pi) == -np.pi
+    assert orc.wrap_to_pi(3 * np.pi) == -np.pi
+
+
+@pytest.mark.parametrize('name', CASES)
+def test_a1_a2_lockin(golden, name):
+    g = golden(name)
+    img0 = g['image'] - g['image'].mean()
+    sigma = int(g['sigma'])
+    a = orc.lockin(img0, g['kvecs'][0], sigma)
+    assert np.allclose(a, g['a1_GPA'], rtol=1e-10, atol=1e-12)
+    b = orc.lockin(img0, g['kvecs'][1], sigma)
+    assert np.allclose(b, g['a1_optGPA'], rtol=1e-10, atol=1e-12)
+    if 'a2_vecGPA' in g:
+        c = orc.lockin_batch(img0, g['kvecs'], sigma)
+        assert np.allclose(c, g['a2_vecGPA'], rtol=1e-10, atol=1e-12)
+
+
+@pytest.mark.parametrize('name', CASES)
+def test_a3_sweep(golden, name):
+    g = golden(name)
+    img0 = g['image'] - g['image'].mean()
+    sigma = int(g['sigma'])
+    for p, pk in enumerate(g['kvecs']):
+        klist = orc.sweep_grid(pk[0], pk[1], float(g['kw']), float(g['kstep']))
+        assert np.array_equal(klist, g['a3_klists'][p])       # host-built list is bit-identical
+        res = orc.sweep(img0, sigma, klist, pk)
+        assert np.array_equal(res['kidx'], g['a3_kidx'][p])    # index work: bit-exact
+        assert np.allclose(res['lockin'], g['a3_lockin'][p], rtol=1e-10, atol=1e-12)
+        if 'a3_w' in g:
+            assert np.array_equal(res['w'], g['a3_w'][p])
+
+
+@pytest.mark.parametrize('name', CASES)
+def test_a4_grad(golden, name):
+    g = golden(name)
+    img0 = g['image'] - g['image'].mean()
+    pk = g['kvecs'][0]
+    res = orc.wfr2_grad_opt(img0, int(g['sigma']), pk[0], pk[1], float(g['kw']), float(g['kstep']))
+    d = orc.wrap_to_pi(2 * (res['grad'] - g['a4_grad0'])) / 2   # compare modulo the pi-periodic wrap
+    assert np.abs(d).max() < 1e-8
+
+
+@pytest.mark.parametrize('name', CASES)
+def test_a5_a6_reconstruct(golden, name):
+    g = golden(name)
+    phases, weights, mask = orc.phases_weights(g['a3_lockin'], int(g['sigma']))
+    assert np.array_equal(mask, g['a5_mask'])                  # mask: bit-exact
+    assert np.array_equal(phases, g['a5_phases'])
+    assert np.array_equal(weights, g['a5_weights'])
+    dudx, dudy = orc.reconstruct_gradients(g['kvecs'], phases, weights)
+    assert np.allclose(dudx, g['a6_dudx'], rtol=1e-8, atol=1e-10)
+    assert np.allclose(dudy, g['a6_dudy'], rtol=1e-8, atol=1e-10)
+
+
+@pytest.mark.parametrize('name', CASES)
+def test_a7_unwrap(golden, name):
+    g = golden(name)
+    wn = np.linalg.norm(g['a5_weights'], axis=0)
+    dudx, dudy = g['a6_dudx'], g['a6_dudy']
+    for kmax in (1, 3, 10, 100):
+        phi = orc.unwrap_prediff(dudx[0], dudy[0], wn, kmax=kmax)
+        ref = g['a7_phi_w_kmax%d' % kmax]
+        assert np.allclose(phi, ref, rtol=1e-7, atol=1e-8 * np.abs(ref).max()), kmax
+    phi = orc.unwrap_prediff(dudx[0], dudy[0])
+    assert np.allclose(phi, g['a7_phi_unweighted'], rtol=1e-8, atol=1e-9)
+    w0 = g['a5_weights'][0]
+    psi = orc.unwrap(g['a5_phases'][0], np.sqrt(w0 / w0.max()), kmax=10)
+    ref = g['a7_psi_unwrap_kmax10']
+    assert np.allclose(psi, ref, rtol=1e-7, atol=1e-8 * np.abs(ref).max())
+
+
+@pytest.mark.parametrize('name', CASES + ['hex_128_noise'])
+def test_full_driver(golden, name):
+    g = golden(name)
+    u, parts = orc.extract_displacement_field(g['image'], g['kvecs'], return_parts=True)
+    assert parts['sigma'] == int(g['sigma'])
+    for p in range(3):
+        assert np.array_equal(parts['gs'][p]['kidx'], g['a3_kidx'][p])
+    assert np.allclose(u, g['u'], rtol=1e-6, atol=1e-7 * np.abs(g['u']).max())
+
+
+def test_a8_iterate(golden):
+    g = golden('iterate_64')
+    prs, w, corr = orc.iterate_gpa(g['image'] - g['image'].mean(), g['start_ks'], int(g['sigma']))
+    assert np.allclose(corr, g['corr'], rtol=1e-5, atol=1e-8)
+    assert np.allclose(w, g['w'], rtol=1e-6, atol=1e-9)
+    assert np.allclose(prs, g['prs'], rtol=1e-5, atol=1e-6)
+    assert np.allclose(orc.reconstruct_u_inv(g['start_ks'] + corr, prs, w), g['u_weighted'], atol=1e-5)
+    assert np.allclose(orc.reconstruct_u_inv(g['start_ks'] + corr, prs), g['u_global'], atol=1e-5)
+
+
+def test_reference_unwrap_ramp(golden):
+    """The reference's own test input (tests/test_phase_unwrap.py) at 64^2."""
+    g = golden('unwrap_ramp_64')
+    for kmax in (1, 5, 30):
+        phi = orc.unwrap(g['psi'], np.ones_like(g['psi']), kmax=kmax)
+        assert np.allclose(phi, g['ref_kmax%d' % kmax])
+        assert np.allclose(phi - phi.mean(), g['psi0'] - g['psi0'].mean())
+        assert np.allclose(orc.unwrap(g['psi'], None, kmax=kmax), phi)
+    assert np.allclose(orc.unwrap(g['psi'], g['gaussian_weight']), g['ref_gaussian'])
+
+
+def test_a9_per_known_answers():
+    rng = np.random.default_rng(0)
+    img = rng.normal(size=(32, 40)) + np.linspace(0, 3, 40)[None, :]
+    p, s = orc.per(img)
+    assert np.allclose(p + s, img)
+    assert abs(s.mean()) < 1e-12
+    tile = np.cos(2 * np.pi * np.arange(32) / 32)[:, None] * np.cos(2 * np.pi * 3 * np.arange(40) / 40)[None, :]
+    ptile, stile = orc.per(tile)
+    assert np.abs(stile).max() < 1e-9 * 1e3 or np.abs(stile).max() < 0.2   # near-periodic image: small smooth part
+    phat, shat = orc.per(img, inverse_dft=False)
+    assert np.allclose(phat + shat, np.fft.fft2(img))
+    assert shat[0, 0] == 0
