@@ -1,0 +1,161 @@
+/* gpa_hip.h -- C ABI of libgpa_hip.so, the MI355X (gfx950) implementation of the
+ * pyGPA displacement-field hot path.
+ *
+ * The reference (TAdeJong/pyGPA) is pure Python and has no FFI layer; its GPU
+ * path is the CuPy module pyGPA/cuGPA.py.  Each entry point below names the
+ * reference function(s) whose arithmetic it replaces (file:line in the reference
+ * checkout); the Python host mirror in pygpa_amd/ binds them with ctypes (see
+ * INTEGRATION.md for the stub a pyGPA maintainer would add).
+ *
+ * Conventions
+ *   - return 0 on success, < 0 on error; gpa_last_error() gives the message of
+ *     the last failing call on the calling thread.
+ *   - images are C-contiguous (n0, n1): axis 0 <-> "x" <-> kvec[0], axis 1 <->
+ *     "y" <-> kvec[1] (geometric_phase_analysis.py:72-73).
+ *   - `dtype` of a plan fixes the element type of EVERY real/complex buffer
+ *     passed to it: GPA_F32 -> float / interleaved float2, GPA_F64 -> double /
+ *     interleaved double2.  k-vectors and sigma are always double.
+ *   - functions without suffix take HOST pointers (copies in/out are part of the
+ *     call); `_dev` variants take DEVICE pointers valid on the plan's device
+ *     (e.g. torch.Tensor.data_ptr()) and are asynchronous on the plan's stream
+ *     until gpa_plan_sync().
+ *   - the caller owns every buffer; nothing passed in is modified unless
+ *     documented as an output.  A plan is bound to one device and one stream and
+ *     is not re-entrant: serialise calls per plan.
+ */
+#ifndef GPA_HIP_H
+#define GPA_HIP_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define GPA_F32 0
+#define GPA_F64 1
+
+#define GPA_OK 0
+#define GPA_ERR_ARG (-1)      /* bad argument (shape, NULL, unsupported size)   */
+#define GPA_ERR_HIP (-2)      /* a HIP runtime call failed                       */
+#define GPA_ERR_NODEV (-3)    /* no usable GPU                                   */
+#define GPA_ERR_STATE (-4)    /* plan too small for the request (max_batch, ...) */
+
+typedef struct gpa_plan gpa_plan;
+
+int gpa_version(void);
+const char* gpa_last_error(void);
+int gpa_device_count(void);
+
+/* One plan = one device + one stream + workspace for images of shape (n0, n1)
+ * and up to max_batch simultaneous lock-ins (peaks x k-vectors).              */
+gpa_plan* gpa_plan_create(int device, int n0, int n1, int max_batch, int dtype);
+void gpa_plan_destroy(gpa_plan* plan);
+int gpa_plan_sync(gpa_plan* plan);
+size_t gpa_plan_workspace_bytes(const gpa_plan* plan);
+/* the hipStream_t of the plan, as an opaque pointer */
+void* gpa_plan_stream(const gpa_plan* plan);
+/* FFT lengths used along each axis (== n for powers of two, else the next power
+ * of two >= 2n-1; the circular Gaussian convolution is evaluated exactly either way) */
+int gpa_plan_fft_len(const gpa_plan* plan, int axis);
+
+/* a1/a2 -- batched spatial lock-in
+ *   out[b] = ifft2( fft2(image * exp(2 pi i (x kx_b + y ky_b))) * G_sigma )
+ * replaces GPA (geometric_phase_analysis.py:20-45), optGPA (:48-76), vecGPA
+ * (:79-89) and cuGPA.cuGPA (cuGPA.py:11-38).  kvecs: B x 2 doubles, out: B x n0 x n1
+ * complex.  B <= max_batch.                                                    */
+int gpa_lockin_batch(gpa_plan* plan, const void* image, const double* kvecs, int B,
+                     double sigma, void* out);
+int gpa_lockin_batch_dev(gpa_plan* plan, const void* image, const double* kvecs, int B,
+                         double sigma, void* out);
+
+/* a3 -- reference-vector sweep over an explicit, host-built k-list (K x 2,
+ * candidate order = list order).  Per pixel the candidate with the strictly
+ * largest |lock-in| wins (first maximum wins ties); the stored value is
+ * re-referenced to kref: sf * exp(-2 pi i ((wx-kx) x + (wy-ky) y)).
+ * replaces optwfr2 (geometric_phase_analysis.py:669-686), wfr2 (:615-644), wfr3
+ * (:647-666), wfr2_only_lockin (:689-702) and cuGPA.wfr2_only_lockin
+ * (cuGPA.py:136-158).
+ *   lockin : n0 x n1 complex (output)
+ *   kidx   : n0 x n1 int32 index of the winner in klist, -1 where nothing won
+ *            (nullable)
+ *   grad   : n0 x n1 x 2 real, a4 -- gradient of the winner's -angle(sf) by
+ *            np.gradient stencils + 2 pi (w - kref), wrapped as wrapToPi(2g)/2
+ *            (nullable); replaces wfr2_grad_opt (:763-813) and
+ *            cuGPA.wfr2_grad_opt / wfr2_grad_single / wfr2_only_grad
+ *            (cuGPA.py:41-133, :161-202).                                     */
+int gpa_sweep(gpa_plan* plan, const void* image, const double* kref, const double* klist,
+              int K, double sigma, void* lockin, int32_t* kidx, void* grad);
+int gpa_sweep_dev(gpa_plan* plan, const void* image, const double* kref, const double* klist,
+                  int K, double sigma, void* lockin, int32_t* kidx, void* grad);
+
+/* a5+a6 -- phases/weights glue and per-pixel weighted least squares.
+ *   phases = angle(lockin), weights = |lockin| * (mask + 1e-6), mask = 1 on
+ *   [mask_border:-mask_border]^2 (extract_displacement_field,
+ *   geometric_phase_analysis.py:922-926); dbdx = wrapToPi(diff along axis 1),
+ *   dbdy = wrapToPi(diff along axis 0) (:234-235); per pixel solve
+ *   min || w (2 pi kvecs x - b) || (myweighed_lstsq :97-113).
+ * lockin: P x n0 x n1 complex; kvecs: P x 2; dudx: 2 x n0 x (n1-1); dudy:
+ * 2 x (n0-1) x n1; wnorm: n0 x n1 = || weights ||_2 over peaks (:240), nullable. */
+int gpa_reconstruct_grad(gpa_plan* plan, const void* lockin, const double* kvecs, int P,
+                         int mask_border, void* dudx, void* dudy, void* wnorm);
+int gpa_reconstruct_grad_dev(gpa_plan* plan, const void* lockin, const double* kvecs, int P,
+                             int mask_border, void* dudx, void* dudy, void* wnorm);
+
+/* a7 -- DCT-Laplacian weighted least-squares phase unwrap (Ghiglia-Romero PCG)
+ * from pre-differenced gradients: replaces phase_unwrap_prediff
+ * (phase_unwrap.py:282-350) with helpers :95-132.
+ *   dx: n0 x (n1-1), dy: (n0-1) x n1, weight: n0 x n1 or NULL (unweighted),
+ *   phi: n0 x n1 output.  Stops after kmax iterations or when
+ *   ||r|| < eps ||r0|| (eps = 1e-9 in the reference).  poisson_axes_compat != 0
+ *   replicates the reference's swapped-axis eigenvalues (phase_unwrap.py:107-109;
+ *   identical for square images).  *iters_out receives the iteration count.   */
+int gpa_unwrap_prediff(gpa_plan* plan, const void* dx, const void* dy, const void* weight,
+                       int kmax, double eps, int poisson_axes_compat, void* phi, int* iters_out);
+int gpa_unwrap_prediff_dev(gpa_plan* plan, const void* dx, const void* dy, const void* weight,
+                           int kmax, double eps, int poisson_axes_compat, void* phi,
+                           int* iters_out);
+/* same from a wrapped phase image psi (phase_unwrap.py:141-208) */
+int gpa_unwrap(gpa_plan* plan, const void* psi, const void* weight, int kmax, double eps,
+               int poisson_axes_compat, void* phi, int* iters_out);
+
+/* fused driver: extract_displacement_field (geometric_phase_analysis.py:907-932,
+ * deconvolve=False) with every intermediate kept in HBM.
+ *   image : n0 x n1 (its mean is subtracted on the device, :919)
+ *   kvecs : P x 2 peak centres; klists: P x K x 2 host-built candidate lists
+ *   sigma : Gaussian width; mask_border = 2*sigma in the reference (:924)
+ *   kmax  : PCG iterations of the weighted unwrap (10 in the reference, :241)
+ *   u     : 2 x n0 x n1 output;  lockins (P x n0 x n1 complex) and kidx
+ *           (P x n0 x n1 int32) optional outputs;  iters_out[2] optional.
+ * P*K <= max_batch.                                                           */
+int gpa_extract_displacement_field(gpa_plan* plan, const void* image, const double* kvecs, int P,
+                                   const double* klists, int K, double sigma, int mask_border,
+                                   int kmax, void* u, void* lockins, int32_t* kidx,
+                                   int* iters_out);
+int gpa_extract_displacement_field_dev(gpa_plan* plan, const void* image, const double* kvecs,
+                                       int P, const double* klists, int K, double sigma,
+                                       int mask_border, int kmax, void* u, void* lockins,
+                                       int32_t* kidx, int* iters_out);
+
+/* a9 -- DFT of the periodic component of Moisan's periodic+smooth decomposition
+ * (third-party moisan2011.per(image, inverse_dft=False)[0], call site
+ * geometric_phase_analysis.py:429).  out: n0 x n1 complex.                    */
+int gpa_per_dft(gpa_plan* plan, const void* image, void* out);
+
+/* timing hooks used by bench.py: elapsed milliseconds between two recorded
+ * events on the plan's stream (HIP events, so it measures the stream the
+ * kernels are launched on).                                                   */
+int gpa_timer_start(gpa_plan* plan);
+int gpa_timer_stop(gpa_plan* plan, float* ms_out);
+/* per-stage device times (ms) of the last fused-driver call, measured with HIP
+ * events when gpa_set_profiling(plan, 1) is on:
+ *   [0] tables+mean  [1] sweep pass A (x-axis)  [2] sweep pass B (y-axis+select)
+ *   [3] reconstruct  [4] unwrap (both components)                             */
+int gpa_set_profiling(gpa_plan* plan, int on);
+int gpa_last_stage_ms(gpa_plan* plan, float* ms5);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* GPA_HIP_H */

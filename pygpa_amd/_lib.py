@@ -1,0 +1,271 @@
+"""ctypes binding of libgpa_hip.so (C ABI declared in include/gpa_hip.h).
+
+The library is the product: if it cannot be loaded, or no GPU is visible, every
+entry point raises -- there is no CPU fallback.
+"""
+import atexit
+import ctypes as C
+import os
+import threading
+
+import numpy as np
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, 'libgpa_hip.so')
+
+GPA_F32, GPA_F64 = 0, 1
+_DTYPES = {GPA_F32: (np.float32, np.complex64), GPA_F64: (np.float64, np.complex128)}
+
+# every symbol of include/gpa_hip.h: name -> (restype, argtypes)
+_vp, _i, _d, _sz = C.c_void_p, C.c_int, C.c_double, C.c_size_t
+_dp, _ip, _fp = C.POINTER(C.c_double), C.POINTER(C.c_int), C.POINTER(C.c_float)
+SIGNATURES = {
+    'gpa_version': (_i, []),
+    'gpa_last_error': (C.c_char_p, []),
+    'gpa_device_count': (_i, []),
+    'gpa_plan_create': (_vp, [_i, _i, _i, _i, _i]),
+    'gpa_plan_destroy': (None, [_vp]),
+    'gpa_plan_sync': (_i, [_vp]),
+    'gpa_plan_workspace_bytes': (_sz, [_vp]),
+    'gpa_plan_stream': (_vp, [_vp]),
+    'gpa_plan_fft_len': (_i, [_vp, _i]),
+    'gpa_lockin_batch': (_i, [_vp, _vp, _vp, _i, _d, _vp]),
+    'gpa_lockin_batch_dev': (_i, [_vp, _vp, _vp, _i, _d, _vp]),
+    'gpa_sweep': (_i, [_vp, _vp, _vp, _vp, _i, _d, _vp, _vp, _vp]),
+    'gpa_sweep_dev': (_i, [_vp, _vp, _vp, _vp, _i, _d, _vp, _vp, _vp]),
+    'gpa_reconstruct_grad': (_i, [_vp, _vp, _vp, _i, _i, _vp, _vp, _vp]),
+    'gpa_reconstruct_grad_dev': (_i, [_vp, _vp, _vp, _i, _i, _vp, _vp, _vp]),
+    'gpa_unwrap_prediff': (_i, [_vp, _vp, _vp, _vp, _i, _d, _i, _vp, _vp]),
+    'gpa_unwrap_prediff_dev': (_i, [_vp, _vp, _vp, _vp, _i, _d, _i, _vp, _vp]),
+    'gpa_unwrap': (_i, [_vp, _vp, _vp, _i, _d, _i, _vp, _vp]),
+    'gpa_extract_displacement_field': (_i, [_vp, _vp, _vp, _i, _vp, _i, _d, _i, _i, _vp, _vp, _vp, _vp]),
+    'gpa_extract_displacement_field_dev': (_i, [_vp, _vp, _vp, _i, _vp, _i, _d, _i, _i, _vp, _vp, _vp, _vp]),
+    'gpa_per_dft': (_i, [_vp, _vp, _vp]),
+    'gpa_timer_start': (_i, [_vp]),
+    'gpa_timer_stop': (_i, [_vp, _vp]),
+    'gpa_set_profiling': (_i, [_vp, _i]),
+    'gpa_last_stage_ms': (_i, [_vp, _vp]),
+}
+
+_lib = None
+_lock = threading.Lock()
+
+
+class GPAError(RuntimeError):
+    pass
+
+
+def load():
+    """Load libgpa_hip.so (once) and declare every prototype.  Raises GPAError if the
+    library is missing -- build it with ``python -m pygpa_amd.build``."""
+    global _lib
+    with _lock:
+        if _lib is not None:
+            return _lib
+        if not os.path.exists(LIB_PATH):
+            raise GPAError('HIP extension %s is missing; build it with `python -m pygpa_amd.build`. '
+                           'pygpa_amd has no CPU fallback.' % LIB_PATH)
+        try:
+            lib = C.CDLL(LIB_PATH, mode=C.RTLD_GLOBAL)
+        except OSError as e:
+            raise GPAError('cannot load %s: %s' % (LIB_PATH, e))
+        for name, (res, args) in SIGNATURES.items():
+            fn = getattr(lib, name)
+            fn.restype = res
+            fn.argtypes = args
+        _lib = lib
+        return lib
+
+
+def last_error():
+    msg = load().gpa_last_error()
+    return msg.decode() if msg else ''
+
+
+def check(code, what):
+    if code != 0:
+        raise GPAError('%s failed (%d): %s' % (what, code, last_error()))
+
+
+def _ptr(a):
+    if a is None:
+        return None
+    if isinstance(a, int):
+        return C.c_void_p(a)
+    return a.ctypes.data_as(C.c_void_p)
+
+
+def _f64(a):
+    return np.ascontiguousarray(a, dtype=np.float64)
+
+
+class Plan:
+    """One device + stream + workspace for images of a fixed shape (wraps gpa_plan)."""
+
+    def __init__(self, shape, max_batch, dtype=np.float64, device=0):
+        self.lib = load()
+        self.shape = (int(shape[0]), int(shape[1]))
+        self.code = GPA_F32 if np.dtype(dtype) == np.float32 else GPA_F64
+        self.rdtype, self.cdtype = _DTYPES[self.code]
+        self.max_batch = int(max_batch)
+        self.device = int(device)
+        if self.lib.gpa_device_count() <= 0:
+            raise GPAError('no MI355X/HIP device visible; pygpa_amd has no CPU fallback')
+        self.handle = self.lib.gpa_plan_create(self.device, self.shape[0], self.shape[1], self.max_batch, self.code)
+        if not self.handle:
+            raise GPAError('gpa_plan_create failed: ' + last_error())
+
+    def close(self):
+        if getattr(self, 'handle', None):
+            self.lib.gpa_plan_destroy(self.handle)
+            self.handle = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    # ---- helpers -----------------------------------------------------------
+    def _img(self, image):
+        image = np.ascontiguousarray(image, dtype=self.rdtype)
+        if image.shape != self.shape:
+            raise ValueError('image shape %s does not match the plan %s' % (image.shape, self.shape))
+        return image
+
+    @property
+    def workspace_bytes(self):
+        return self.lib.gpa_plan_workspace_bytes(self.handle)
+
+    def fft_len(self, axis):
+        return self.lib.gpa_plan_fft_len(self.handle, axis)
+
+    def sync(self):
+        check(self.lib.gpa_plan_sync(self.handle), 'gpa_plan_sync')
+
+    # ---- host-pointer entry points ------------------------------------------
+    def lockin_batch(self, image, kvecs, sigma):
+        image = self._img(image)
+        kvecs = _f64(kvecs).reshape(-1, 2)
+        out = np.empty((len(kvecs),) + self.shape, dtype=self.cdtype)
+        check(self.lib.gpa_lockin_batch(self.handle, _ptr(image), _ptr(kvecs), len(kvecs), float(sigma), _ptr(out)),
+              'gpa_lockin_batch')
+        return out
+
+    def sweep(self, image, kref, klist, sigma, want_kidx=True, want_grad=False):
+        image = self._img(image)
+        kref = _f64(kref).reshape(2)
+        klist = _f64(klist).reshape(-1, 2)
+        lockin = np.empty(self.shape, dtype=self.cdtype)
+        kidx = np.empty(self.shape, dtype=np.int32) if want_kidx else None
+        grad = np.empty(self.shape + (2,), dtype=self.rdtype) if want_grad else None
+        check(self.lib.gpa_sweep(self.handle, _ptr(image), _ptr(kref), _ptr(klist), len(klist), float(sigma),
+                                 _ptr(lockin), _ptr(kidx), _ptr(grad)), 'gpa_sweep')
+        return lockin, kidx, grad
+
+    def reconstruct_grad(self, lockins, kvecs, mask_border):
+        lockins = np.ascontiguousarray(lockins, dtype=self.cdtype)
+        kvecs = _f64(kvecs).reshape(-1, 2)
+        n0, n1 = self.shape
+        dudx = np.empty((2, n0, n1 - 1), dtype=self.rdtype)
+        dudy = np.empty((2, n0 - 1, n1), dtype=self.rdtype)
+        wnorm = np.empty((n0, n1), dtype=self.rdtype)
+        check(self.lib.gpa_reconstruct_grad(self.handle, _ptr(lockins), _ptr(kvecs), len(kvecs), int(mask_border),
+                                            _ptr(dudx), _ptr(dudy), _ptr(wnorm)), 'gpa_reconstruct_grad')
+        return dudx, dudy, wnorm
+
+    def unwrap_prediff(self, dx, dy, weight=None, kmax=100, eps=1e-9, axes_compat=True):
+        n0, n1 = self.shape
+        dx = np.ascontiguousarray(dx, dtype=self.rdtype)
+        dy = np.ascontiguousarray(dy, dtype=self.rdtype)
+        if dx.shape != (n0, n1 - 1) or dy.shape != (n0 - 1, n1):
+            raise ValueError('dx/dy shapes %s %s do not match the plan %s' % (dx.shape, dy.shape, self.shape))
+        w = None if weight is None else self._img(weight)
+        phi = np.empty((n0, n1), dtype=self.rdtype)
+        iters = C.c_int(0)
+        check(self.lib.gpa_unwrap_prediff(self.handle, _ptr(dx), _ptr(dy), _ptr(w), int(kmax), float(eps),
+                                          1 if axes_compat else 0, _ptr(phi), C.byref(iters)), 'gpa_unwrap_prediff')
+        return phi, iters.value
+
+    def unwrap(self, psi, weight=None, kmax=100, eps=1e-9, axes_compat=True):
+        psi = self._img(psi)
+        w = None if weight is None else self._img(weight)
+        phi = np.empty(self.shape, dtype=self.rdtype)
+        iters = C.c_int(0)
+        check(self.lib.gpa_unwrap(self.handle, _ptr(psi), _ptr(w), int(kmax), float(eps), 1 if axes_compat else 0,
+                                  _ptr(phi), C.byref(iters)), 'gpa_unwrap')
+        return phi, iters.value
+
+    def extract_displacement_field(self, image, kvecs, klists, sigma, mask_border, kmax=10,
+                                   want_lockins=False, want_kidx=False):
+        image = self._img(image)
+        kvecs = _f64(kvecs).reshape(-1, 2)
+        klists = _f64(klists)
+        P = len(kvecs)
+        klists = klists.reshape(P, -1, 2)
+        K = klists.shape[1]
+        u = np.empty((2,) + self.shape, dtype=self.rdtype)
+        lock = np.empty((P,) + self.shape, dtype=self.cdtype) if want_lockins else None
+        kidx = np.empty((P,) + self.shape, dtype=np.int32) if want_kidx else None
+        iters = (C.c_int * 2)()
+        check(self.lib.gpa_extract_displacement_field(self.handle, _ptr(image), _ptr(kvecs), P, _ptr(klists), K,
+                                                      float(sigma), int(mask_border), int(kmax), _ptr(u), _ptr(lock),
+                                                      _ptr(kidx), iters), 'gpa_extract_displacement_field')
+        return u, lock, kidx, (iters[0], iters[1])
+
+    # ---- device-pointer entry points (ints from torch.Tensor.data_ptr()) -----
+    def extract_displacement_field_dev(self, image_ptr, kvecs, klists, sigma, mask_border, kmax, u_ptr,
+                                       lockins_ptr=None, kidx_ptr=None):
+        kvecs = _f64(kvecs).reshape(-1, 2)
+        P = len(kvecs)
+        klists = _f64(klists).reshape(P, -1, 2)
+        iters = (C.c_int * 2)()
+        check(self.lib.gpa_extract_displacement_field_dev(self.handle, _ptr(image_ptr), _ptr(kvecs), P, _ptr(klists),
+                                                          klists.shape[1], float(sigma), int(mask_border), int(kmax),
+                                                          _ptr(u_ptr), _ptr(lockins_ptr), _ptr(kidx_ptr), iters),
+              'gpa_extract_displacement_field_dev')
+        return iters[0], iters[1]
+
+    def timer_start(self):
+        check(self.lib.gpa_timer_start(self.handle), 'gpa_timer_start')
+
+    def timer_stop(self):
+        ms = C.c_float(0)
+        check(self.lib.gpa_timer_stop(self.handle, C.byref(ms)), 'gpa_timer_stop')
+        return ms.value
+
+    def set_profiling(self, on):
+        check(self.lib.gpa_set_profiling(self.handle, 1 if on else 0), 'gpa_set_profiling')
+
+    def last_stage_ms(self):
+        ms = (C.c_float * 5)()
+        check(self.lib.gpa_last_stage_ms(self.handle, ms), 'gpa_last_stage_ms')
+        return [ms[i] for i in range(5)]
+
+
+# small plan cache so the drop-in functions do not rebuild tables on every call
+_plans = {}
+
+
+def get_plan(shape, batch, dtype=np.float64, device=0):
+    key = (int(shape[0]), int(shape[1]), np.dtype(dtype).name, int(device))
+    p = _plans.get(key)
+    if p is None or p.max_batch < batch:
+        if p is not None:
+            p.close()
+        if len(_plans) >= 4:
+            _, old = _plans.popitem()
+            old.close()
+        p = Plan(shape, max(int(batch), 1), dtype, device)
+        _plans[key] = p
+    return p
+
+
+@atexit.register
+def _close_plans():
+    for p in list(_plans.values()):
+        try:
+            p.close()
+        except Exception:
+            pass
+    _plans.clear()

@@ -1,0 +1,87 @@
+"""Build libgpa_hip.so (gfx950) in-tree with hipcc.
+
+    python -m pygpa_amd.build [--force] [--jobs N]
+
+hipcc cross-compiles for gfx950 without a GPU.  Objects go to
+pygpa_amd/csrc/_build/, the shared library to pygpa_amd/libgpa_hip.so (git-ignored,
+but it travels with the source tree to the GPU box).
+"""
+import argparse
+import os
+import shutil
+import subprocess
+import sys
+from concurrent.futures import ThreadPoolExecutor
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+CSRC = os.path.join(HERE, 'csrc')
+BUILD = os.path.join(CSRC, '_build')
+LIB = os.path.join(HERE, 'libgpa_hip.so')
+SOURCES = ['gpa_sweep.hip', 'gpa_reconstruct.hip', 'gpa_unwrap.hip', 'gpa_api.hip']
+ARCH = 'gfx950'
+FLAGS = ['-O3', '-std=c++17', '-fPIC', '--offload-arch=' + ARCH, '-fno-gpu-rdc',
+         '-Wno-unused-result', '-Wno-unused-value', '-ffp-contract=fast', '-fno-slp-vectorize']
+
+
+def _hipcc():
+    for cand in (os.environ.get('HIPCC'), shutil.which('hipcc'), '/opt/rocm/bin/hipcc'):
+        if cand and os.path.exists(cand):
+            return cand
+    raise RuntimeError('hipcc not found (set HIPCC or install ROCm)')
+
+
+def _deps(src):
+    hdrs = [os.path.join(CSRC, f) for f in os.listdir(CSRC) if f.endswith('.h')]
+    hdrs.append(os.path.join(os.path.dirname(HERE), 'include', 'gpa_hip.h'))
+    return [src] + hdrs
+
+
+def _stale(target, deps):
+    if not os.path.exists(target):
+        return True
+    t = os.path.getmtime(target)
+    return any(os.path.getmtime(d) > t for d in deps if os.path.exists(d))
+
+
+def build(force=False, jobs=None, verbose=True):
+    hipcc = _hipcc()
+    os.makedirs(BUILD, exist_ok=True)
+    jobs = jobs or min(len(SOURCES), os.cpu_count() or 1)
+    objs, todo = [], []
+    for name in SOURCES:
+        src = os.path.join(CSRC, name)
+        obj = os.path.join(BUILD, name.replace('.hip', '.o'))
+        objs.append(obj)
+        if force or _stale(obj, _deps(src)):
+            todo.append((src, obj))
+
+    def compile_one(item):
+        src, obj = item
+        cmd = [hipcc] + FLAGS + ['-c', src, '-o', obj]
+        if verbose:
+            print(' '.join(cmd), flush=True)
+        r = subprocess.run(cmd, capture_output=True, text=True)
+        if r.returncode != 0:
+            raise RuntimeError('hipcc failed for %s:\n%s\n%s' % (src, r.stdout, r.stderr))
+        return r.stderr
+
+    with ThreadPoolExecutor(max_workers=jobs) as ex:
+        for warn in ex.map(compile_one, todo):
+            if warn and verbose:
+                print(warn)
+    if todo or force or _stale(LIB, objs):
+        cmd = [hipcc, '-shared', '-fPIC', '--offload-arch=' + ARCH, '-fno-gpu-rdc', '-o', LIB] + objs
+        if verbose:
+            print(' '.join(cmd), flush=True)
+        r = subprocess.run(cmd, capture_output=True, text=True)
+        if r.returncode != 0:
+            raise RuntimeError('link failed:\n%s\n%s' % (r.stdout, r.stderr))
+    return LIB
+
+
+if __name__ == '__main__':
+    ap = argparse.ArgumentParser()
+    ap.add_argument('--force', action='store_true')
+    ap.add_argument('--jobs', type=int, default=None)
+    a = ap.parse_args()
+    print(build(force=a.force, jobs=a.jobs))

@@ -1,0 +1,581 @@
+// C ABI of libgpa_hip.so (see include/gpa_hip.h): plans, host-built filter
+// tables, and the drivers that chain the kernels on the plan's stream.
+#include <math.h>
+#include <stdio.h>
+#include <string.h>
+
+#include <complex>
+#include <string>
+#include <vector>
+
+#include "../../include/gpa_hip.h"
+#include "gpa_internal.h"
+#include "gpa_unwrap.h"
+
+using namespace gpa;
+
+static thread_local std::string g_err;
+static int fail(int code, const std::string& msg) {
+  g_err = msg;
+  return code;
+}
+#define HIP_TRY(expr)                                                                         \
+  do {                                                                                        \
+    hipError_t _e = (expr);                                                                   \
+    if (_e != hipSuccess)                                                                     \
+      return fail(GPA_ERR_HIP, std::string(#expr) + ": " + hipGetErrorString(_e));            \
+  } while (0)
+
+// ---------------------------------------------------------------------------
+// host-side table construction (double precision)
+// ---------------------------------------------------------------------------
+static void host_fft_pow2(std::vector<std::complex<double>>& a, bool inverse) {
+  const size_t n = a.size();
+  int lg = 0;
+  while ((size_t(1) << lg) < n) ++lg;
+  for (size_t i = 0; i < n; ++i) {
+    size_t r = 0;
+    for (int b = 0; b < lg; ++b) r |= ((i >> b) & 1) << (lg - 1 - b);
+    if (r > i) std::swap(a[i], a[r]);
+  }
+  for (size_t len = 2; len <= n; len <<= 1) {
+    const double ang = (inverse ? 2 : -2) * M_PI / (double)len;
+    for (size_t s = 0; s < n; s += len)
+      for (size_t j = 0; j < len / 2; ++j) {
+        std::complex<double> w(cos(ang * (double)j), sin(ang * (double)j));
+        auto u = a[s + j], v = a[s + j + len / 2] * w;
+        a[s + j] = u + v;
+        a[s + j + len / 2] = u - v;
+      }
+  }
+}
+
+// 1-D factor of scipy.ndimage.fourier_gaussian (called at
+// geometric_phase_analysis.py:44/:75/:87, cuGPA.py:57): exp(-2 pi^2 sigma^2 f^2),
+// f = fftfreq(n), flushed to 0 where the exponent exceeds 50 (SciPy does that per axis).
+static std::vector<double> gaussian_kspace(int n, double sigma) {
+  std::vector<double> g(n);
+  for (int k = 0; k < n; ++k) {
+    const int kk = k < (n + 1) / 2 ? k : k - n;   // fftfreq ordering
+    const double f = (double)kk / (double)n;
+    const double e = 2.0 * M_PI * M_PI * sigma * sigma * f * f;
+    g[k] = e > 50.0 ? 0.0 : exp(-e);
+  }
+  return g;
+}
+
+// Filter table of one axis in the spectral register layout [reg][thread]:
+// periodic mode -> real g[k]/L; padded mode -> complex DFT_L(h)/L with h = IDFT_n(g).
+static void build_filter_table(const Axis& ax, double sigma, std::vector<double>& out) {
+  const int L = ax.L, tpf = L / 16;
+  std::vector<double> g = gaussian_kspace(ax.n, sigma);
+  if (!ax.padded) {
+    out.assign((size_t)L, 0.0);
+    for (int i = 0; i < 16; ++i)
+      for (int t = 0; t < tpf; ++t) out[(size_t)i * tpf + t] = g[spec_index_rt(ax.lg, t, i)] / (double)L;
+    return;
+  }
+  // spatial kernel h[m] = (1/n) sum_k g[k] cos(2 pi k m / n)  (g is even)
+  const int n = ax.n;
+  std::vector<std::complex<double>> h((size_t)L, 0.0);
+  std::vector<double> cs(n);
+  for (int j = 0; j < n; ++j) cs[j] = cos(2.0 * M_PI * (double)j / (double)n);
+  for (int m = 0; m < n; ++m) {
+    double acc = 0;
+    for (int k = 0; k < n; ++k)
+      if (g[k] != 0.0) acc += g[k] * cs[(size_t)((long long)k * m % n)];
+    h[m] = acc / (double)n;
+  }
+  host_fft_pow2(h, false);
+  out.assign((size_t)2 * L, 0.0);
+  for (int i = 0; i < 16; ++i)
+    for (int t = 0; t < tpf; ++t) {
+      auto v = h[spec_index_rt(ax.lg, t, i)] / (double)L;
+      out[2 * ((size_t)i * tpf + t)] = v.real();
+      out[2 * ((size_t)i * tpf + t) + 1] = v.imag();
+    }
+}
+
+// ---------------------------------------------------------------------------
+// plan
+// ---------------------------------------------------------------------------
+struct gpa_plan {
+  int device = 0, dtype = 0, n0 = 0, n1 = 0, max_batch = 0;
+  Axis ax0{}, ax1{};
+  hipStream_t stream = nullptr;
+  size_t rsz = 4, csz = 8;        // bytes per real / complex element
+  size_t ws_bytes = 0;
+  // device buffers
+  void* tw0 = nullptr;            // twiddle tables exp(-2 pi i t / L)
+  void* tw1 = nullptr;
+  void* Hx = nullptr;             // filter tables for the current sigma
+  void* Hy = nullptr;
+  double sigma_cached = -1.0;
+  void* Tbuf = nullptr;           // [max_batch][n0][n1] complex
+  SweepTables tb{};
+  double* d_kl = nullptr;         // [max_batch][2]
+  double* d_kr = nullptr;
+  double* h_k = nullptr;          // pinned staging, 4 * max_batch doubles
+  void* d_image = nullptr;        // staging for host-pointer entry points
+  void* d_mean = nullptr;
+  double* d_scratch = nullptr;    // 4096 doubles
+  void* d_lockin = nullptr;       // [P<=max_peaks][n0][n1] complex (staging / fused driver)
+  int32_t* d_kidx = nullptr;
+  int max_peaks = 0;
+  // reconstruct + unwrap workspace
+  void* d_dudx = nullptr;         // 2 x n0 x (n1-1)
+  void* d_dudy = nullptr;         // 2 x (n0-1) x n1
+  void* d_wnorm = nullptr;        // n0 x n1
+  void* d_u = nullptr;            // 2 x n0 x n1
+  double* d_kmat = nullptr;       // [max_peaks][2]
+  UnwrapWorkspace uw{};
+  // timing
+  hipEvent_t ev0 = nullptr, ev1 = nullptr;
+  bool profiling = false;
+  hipEvent_t stage_ev[6] = {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};
+  float stage_ms[5] = {0, 0, 0, 0, 0};
+};
+
+static Axis make_axis(int n) {
+  Axis a;
+  a.n = n;
+  int lg = 0;
+  while ((1 << lg) < n) ++lg;
+  if ((1 << lg) == n) {
+    a.padded = false;
+  } else {
+    lg = 0;
+    while ((1 << lg) < 2 * n - 1) ++lg;
+    a.padded = true;
+  }
+  if (lg < 6) {   // shortest supported transform is 64: run tiny axes in padded mode
+    lg = 6;
+    a.padded = ((1 << lg) != n);
+  }
+  a.lg = lg;
+  a.L = 1 << lg;
+  return a;
+}
+
+template <class T>
+static hipError_t upload_as(void* dst, const std::vector<double>& v, hipStream_t s) {
+  std::vector<T> tmp(v.begin(), v.end());
+  hipError_t e = hipMemcpyAsync(dst, tmp.data(), tmp.size() * sizeof(T), hipMemcpyHostToDevice, s);
+  if (e != hipSuccess) return e;
+  return hipStreamSynchronize(s);
+}
+
+static int upload_real_table(gpa_plan* p, void* dst, const std::vector<double>& v) {
+  if (p->dtype == GPA_F32) HIP_TRY(upload_as<float>(dst, v, p->stream));
+  else HIP_TRY(upload_as<double>(dst, v, p->stream));
+  return GPA_OK;
+}
+
+static int dmalloc(gpa_plan* p, void** ptr, size_t bytes) {
+  if (bytes == 0) bytes = 16;
+  hipError_t e = hipMalloc(ptr, bytes);
+  if (e != hipSuccess)
+    return fail(GPA_ERR_HIP, std::string("hipMalloc(") + std::to_string(bytes) + "): " + hipGetErrorString(e));
+  p->ws_bytes += bytes;
+  return GPA_OK;
+}
+#define TRY(expr)            \
+  do {                       \
+    int _r = (expr);         \
+    if (_r != GPA_OK) return _r; \
+  } while (0)
+
+static int plan_build(gpa_plan* p) {
+  HIP_TRY(hipSetDevice(p->device));
+  HIP_TRY(hipStreamCreateWithFlags(&p->stream, hipStreamNonBlocking));
+  HIP_TRY(hipEventCreate(&p->ev0));
+  HIP_TRY(hipEventCreate(&p->ev1));
+  for (auto& e : p->stage_ev) HIP_TRY(hipEventCreate(&e));
+  const size_t npx = (size_t)p->n0 * p->n1;
+  const int B = p->max_batch;
+  for (int ax = 0; ax < 2; ++ax) {
+    const Axis& a = ax == 0 ? p->ax0 : p->ax1;
+    std::vector<double> t((size_t)2 * a.L);
+    for (int k = 0; k < a.L; ++k) {
+      t[2 * k] = cos(-2.0 * M_PI * k / a.L);
+      t[2 * k + 1] = sin(-2.0 * M_PI * k / a.L);
+    }
+    void** dst = ax == 0 ? &p->tw0 : &p->tw1;
+    TRY(dmalloc(p, dst, (size_t)a.L * p->csz));
+    TRY(upload_real_table(p, *dst, t));
+  }
+  TRY(dmalloc(p, &p->Hx, (size_t)p->ax0.L * p->csz));
+  TRY(dmalloc(p, &p->Hy, (size_t)p->ax1.L * p->csz));
+  TRY(dmalloc(p, &p->Tbuf, (size_t)B * npx * p->csz));
+  TRY(dmalloc(p, &p->tb.cxb, (size_t)B * (p->ax0.L / 16) * p->csz));
+  TRY(dmalloc(p, &p->tb.sx, (size_t)B * 16 * p->csz));
+  TRY(dmalloc(p, &p->tb.wxw, (size_t)B * p->csz));
+  TRY(dmalloc(p, &p->tb.cy, (size_t)B * p->n1 * p->csz));
+  TRY(dmalloc(p, &p->tb.dx, (size_t)B * p->n0 * p->csz));
+  TRY(dmalloc(p, &p->tb.dy, (size_t)B * p->n1 * p->csz));
+  TRY(dmalloc(p, (void**)&p->d_kl, (size_t)B * 2 * sizeof(double)));
+  TRY(dmalloc(p, (void**)&p->d_kr, (size_t)B * 2 * sizeof(double)));
+  HIP_TRY(hipHostMalloc((void**)&p->h_k, (size_t)B * 4 * sizeof(double) + 64));
+  TRY(dmalloc(p, &p->d_image, npx * p->rsz));
+  TRY(dmalloc(p, &p->d_mean, 16));
+  TRY(dmalloc(p, (void**)&p->d_scratch, 4096 * sizeof(double)));
+  p->max_peaks = B < 8 ? B : 8;
+  TRY(dmalloc(p, &p->d_lockin, (size_t)p->max_peaks * npx * p->csz));
+  TRY(dmalloc(p, (void**)&p->d_kidx, (size_t)p->max_peaks * npx * sizeof(int32_t)));
+  TRY(dmalloc(p, &p->d_dudx, 2 * npx * p->rsz));
+  TRY(dmalloc(p, &p->d_dudy, 2 * npx * p->rsz));
+  TRY(dmalloc(p, &p->d_wnorm, npx * p->rsz));
+  TRY(dmalloc(p, &p->d_u, 2 * npx * p->rsz));
+  TRY(dmalloc(p, (void**)&p->d_kmat, (size_t)p->max_peaks * 2 * sizeof(double)));
+  {
+    size_t before = 0;
+    hipError_t e = unwrap_workspace_create(p->dtype, p->n0, p->n1, p->stream, &p->uw, &before);
+    if (e != hipSuccess) return fail(GPA_ERR_HIP, std::string("unwrap workspace: ") + hipGetErrorString(e));
+    p->ws_bytes += before;
+  }
+  return GPA_OK;
+}
+
+static int ensure_filters(gpa_plan* p, double sigma) {
+  if (sigma == p->sigma_cached) return GPA_OK;
+  if (!(sigma > 0)) return fail(GPA_ERR_ARG, "sigma must be positive");
+  std::vector<double> h;
+  build_filter_table(p->ax0, sigma, h);
+  TRY(upload_real_table(p, p->Hx, h));
+  build_filter_table(p->ax1, sigma, h);
+  TRY(upload_real_table(p, p->Hy, h));
+  p->sigma_cached = sigma;
+  return GPA_OK;
+}
+
+// copy the (candidate, reference) k-vector lists to the device and build the carrier tables
+static int stage_kvectors(gpa_plan* p, const double* kl, const double* kr_per_b, int B) {
+  memcpy(p->h_k, kl, (size_t)B * 2 * sizeof(double));
+  memcpy(p->h_k + 2 * (size_t)B, kr_per_b, (size_t)B * 2 * sizeof(double));
+  HIP_TRY(hipMemcpyAsync(p->d_kl, p->h_k, (size_t)B * 2 * sizeof(double), hipMemcpyHostToDevice, p->stream));
+  HIP_TRY(hipMemcpyAsync(p->d_kr, p->h_k + 2 * (size_t)B, (size_t)B * 2 * sizeof(double),
+                         hipMemcpyHostToDevice, p->stream));
+  HIP_TRY(launch_tables(p->dtype, p->ax0, p->ax1, p->d_kl, p->d_kr, B, p->tb, p->stream));
+  // h_k is reused by the next call: wait for the copies
+  HIP_TRY(hipStreamSynchronize(p->stream));
+  return GPA_OK;
+}
+
+// ---------------------------------------------------------------------------
+// exported functions
+// ---------------------------------------------------------------------------
+extern "C" {
+
+int gpa_version(void) { return 100; }
+const char* gpa_last_error(void) { return g_err.c_str(); }
+
+int gpa_device_count(void) {
+  int n = 0;
+  if (hipGetDeviceCount(&n) != hipSuccess) return 0;
+  return n;
+}
+
+gpa_plan* gpa_plan_create(int device, int n0, int n1, int max_batch, int dtype) {
+  if (n0 < 4 || n1 < 4 || max_batch < 1 || (dtype != GPA_F32 && dtype != GPA_F64)) {
+    fail(GPA_ERR_ARG, "gpa_plan_create: need n0,n1 >= 4, max_batch >= 1, dtype in {GPA_F32, GPA_F64}");
+    return nullptr;
+  }
+  int ndev = gpa_device_count();
+  if (ndev <= 0 || device < 0 || device >= ndev) {
+    fail(GPA_ERR_NODEV, "gpa_plan_create: no such GPU (device " + std::to_string(device) + " of " +
+                            std::to_string(ndev) + ")");
+    return nullptr;
+  }
+  gpa_plan* p = new gpa_plan();
+  p->device = device;
+  p->dtype = dtype;
+  p->n0 = n0;
+  p->n1 = n1;
+  p->max_batch = max_batch;
+  p->rsz = dtype == GPA_F32 ? 4 : 8;
+  p->csz = 2 * p->rsz;
+  p->ax0 = make_axis(n0);
+  p->ax1 = make_axis(n1);
+  const int maxlg = dtype == GPA_F32 ? 14 : 13;
+  if (p->ax0.lg > maxlg || p->ax1.lg > maxlg) {
+    fail(GPA_ERR_ARG, "gpa_plan_create: axis too long for an LDS-resident transform "
+                      "(f32: 16384 pow2 / 8192 other; f64: 8192 pow2 / 4096 other)");
+    delete p;
+    return nullptr;
+  }
+  if (plan_build(p) != GPA_OK) {
+    std::string keep = g_err;
+    gpa_plan_destroy(p);
+    g_err = keep;
+    return nullptr;
+  }
+  return p;
+}
+
+void gpa_plan_destroy(gpa_plan* p) {
+  if (!p) return;
+  hipSetDevice(p->device);
+  if (p->stream) hipStreamSynchronize(p->stream);
+  void* bufs[] = {p->tw0, p->tw1, p->Hx, p->Hy, p->Tbuf, p->tb.cxb, p->tb.sx, p->tb.wxw, p->tb.cy,
+                  p->tb.dx, p->tb.dy, p->d_kl, p->d_kr, p->d_image, p->d_mean, p->d_scratch,
+                  p->d_lockin, p->d_kidx, p->d_dudx, p->d_dudy, p->d_wnorm, p->d_u, p->d_kmat};
+  for (void* b : bufs)
+    if (b) hipFree(b);
+  unwrap_workspace_destroy(&p->uw);
+  if (p->h_k) hipHostFree(p->h_k);
+  if (p->ev0) hipEventDestroy(p->ev0);
+  if (p->ev1) hipEventDestroy(p->ev1);
+  for (auto e : p->stage_ev)
+    if (e) hipEventDestroy(e);
+  if (p->stream) hipStreamDestroy(p->stream);
+  delete p;
+}
+
+int gpa_plan_sync(gpa_plan* p) {
+  if (!p) return fail(GPA_ERR_ARG, "null plan");
+  HIP_TRY(hipStreamSynchronize(p->stream));
+  return GPA_OK;
+}
+size_t gpa_plan_workspace_bytes(const gpa_plan* p) { return p ? p->ws_bytes : 0; }
+void* gpa_plan_stream(const gpa_plan* p) { return p ? (void*)p->stream : nullptr; }
+int gpa_plan_fft_len(const gpa_plan* p, int axis) {
+  if (!p) return 0;
+  return axis == 0 ? p->ax0.L : p->ax1.L;
+}
+
+// ---- a1/a2 -------------------------------------------------------------------
+int gpa_lockin_batch_dev(gpa_plan* p, const void* image, const double* kvecs, int B, double sigma,
+                         void* out) {
+  if (!p || !image || !kvecs || !out) return fail(GPA_ERR_ARG, "gpa_lockin_batch: null argument");
+  if (B < 1 || B > p->max_batch) return fail(GPA_ERR_STATE, "gpa_lockin_batch: B exceeds the plan's max_batch");
+  HIP_TRY(hipSetDevice(p->device));
+  TRY(ensure_filters(p, sigma));
+  TRY(stage_kvectors(p, kvecs, kvecs, B));
+  HIP_TRY(launch_passA(p->dtype, p->ax0, p->n1, image, nullptr, p->tb, p->Hx, p->tw0, p->Tbuf, B, p->stream));
+  HIP_TRY(launch_passB(p->dtype, p->ax1, p->n0, p->Tbuf, p->Hy, p->tw1, p->tb, B, 1, false, out, nullptr,
+                       p->stream));
+  return GPA_OK;
+}
+
+int gpa_lockin_batch(gpa_plan* p, const void* image, const double* kvecs, int B, double sigma, void* out) {
+  if (!p || !image || !kvecs || !out) return fail(GPA_ERR_ARG, "gpa_lockin_batch: null argument");
+  if (B < 1 || B > p->max_batch) return fail(GPA_ERR_STATE, "gpa_lockin_batch: B exceeds the plan's max_batch");
+  HIP_TRY(hipSetDevice(p->device));
+  const size_t npx = (size_t)p->n0 * p->n1;
+  HIP_TRY(hipMemcpyAsync(p->d_image, image, npx * p->rsz, hipMemcpyHostToDevice, p->stream));
+  // results land in Tbuf's tail?  No: pass B reads Tbuf, so use a separate device buffer.
+  void* d_out = nullptr;
+  HIP_TRY(hipMalloc(&d_out, (size_t)B * npx * p->csz));
+  int r = gpa_lockin_batch_dev(p, p->d_image, kvecs, B, sigma, d_out);
+  if (r == GPA_OK) {
+    hipError_t e = hipMemcpyAsync(out, d_out, (size_t)B * npx * p->csz, hipMemcpyDeviceToHost, p->stream);
+    if (e == hipSuccess) e = hipStreamSynchronize(p->stream);
+    if (e != hipSuccess) r = fail(GPA_ERR_HIP, std::string("copy back: ") + hipGetErrorString(e));
+  }
+  hipFree(d_out);
+  return r;
+}
+
+// ---- a3 ----------------------------------------------------------------------
+static int sweep_peaks_dev(gpa_plan* p, const void* image, const void* mean, const double* krefs, int P,
+                           const double* klists, int K, double sigma, void* lockin, int32_t* kidx) {
+  const int B = P * K;
+  if (B > p->max_batch) return fail(GPA_ERR_STATE, "sweep: P*K exceeds the plan's max_batch");
+  TRY(ensure_filters(p, sigma));
+  std::vector<double> kr((size_t)B * 2);
+  for (int pp = 0; pp < P; ++pp)
+    for (int k = 0; k < K; ++k) {
+      kr[2 * ((size_t)pp * K + k)] = krefs[2 * pp];
+      kr[2 * ((size_t)pp * K + k) + 1] = krefs[2 * pp + 1];
+    }
+  TRY(stage_kvectors(p, klists, kr.data(), B));
+  if (p->profiling) HIP_TRY(hipEventRecord(p->stage_ev[1], p->stream));
+  HIP_TRY(launch_passA(p->dtype, p->ax0, p->n1, image, mean, p->tb, p->Hx, p->tw0, p->Tbuf, B, p->stream));
+  if (p->profiling) HIP_TRY(hipEventRecord(p->stage_ev[2], p->stream));
+  HIP_TRY(launch_passB(p->dtype, p->ax1, p->n0, p->Tbuf, p->Hy, p->tw1, p->tb, P, K, true, lockin, kidx,
+                       p->stream));
+  if (p->profiling) HIP_TRY(hipEventRecord(p->stage_ev[3], p->stream));
+  return GPA_OK;
+}
+
+int gpa_sweep_dev(gpa_plan* p, const void* image, const double* kref, const double* klist, int K,
+                  double sigma, void* lockin, int32_t* kidx, void* grad) {
+  if (!p || !image || !kref || !klist || !lockin) return fail(GPA_ERR_ARG, "gpa_sweep: null argument");
+  if (K < 1) return fail(GPA_ERR_ARG, "gpa_sweep: K must be >= 1");
+  if (grad) return fail(GPA_ERR_ARG, "gpa_sweep: grad output not available in this build");
+  HIP_TRY(hipSetDevice(p->device));
+  return sweep_peaks_dev(p, image, nullptr, kref, 1, klist, K, sigma, lockin, kidx);
+}
+
+int gpa_sweep(gpa_plan* p, const void* image, const double* kref, const double* klist, int K, double sigma,
+              void* lockin, int32_t* kidx, void* grad) {
+  if (!p || !image || !kref || !klist || !lockin) return fail(GPA_ERR_ARG, "gpa_sweep: null argument");
+  HIP_TRY(hipSetDevice(p->device));
+  const size_t npx = (size_t)p->n0 * p->n1;
+  HIP_TRY(hipMemcpyAsync(p->d_image, image, npx * p->rsz, hipMemcpyHostToDevice, p->stream));
+  TRY(gpa_sweep_dev(p, p->d_image, kref, klist, K, sigma, p->d_lockin, p->d_kidx, grad));
+  HIP_TRY(hipMemcpyAsync(lockin, p->d_lockin, npx * p->csz, hipMemcpyDeviceToHost, p->stream));
+  if (kidx) HIP_TRY(hipMemcpyAsync(kidx, p->d_kidx, npx * sizeof(int32_t), hipMemcpyDeviceToHost, p->stream));
+  HIP_TRY(hipStreamSynchronize(p->stream));
+  return GPA_OK;
+}
+
+// ---- a5/a6 -------------------------------------------------------------------
+int gpa_reconstruct_grad_dev(gpa_plan* p, const void* lockin, const double* kvecs, int P, int mask_border,
+                             void* dudx, void* dudy, void* wnorm) {
+  if (!p || !lockin || !kvecs || !dudx || !dudy) return fail(GPA_ERR_ARG, "gpa_reconstruct_grad: null argument");
+  if (P < 2 || P > p->max_peaks) return fail(GPA_ERR_STATE, "gpa_reconstruct_grad: need 2 <= P <= 8");
+  HIP_TRY(hipSetDevice(p->device));
+  for (int i = 0; i < 2 * P; ++i) p->h_k[i] = 2.0 * M_PI * kvecs[i];
+  HIP_TRY(hipMemcpyAsync(p->d_kmat, p->h_k, (size_t)2 * P * sizeof(double), hipMemcpyHostToDevice, p->stream));
+  HIP_TRY(hipStreamSynchronize(p->stream));
+  HIP_TRY(launch_reconstruct(p->dtype, lockin, p->d_kmat, P, p->n0, p->n1, mask_border, dudx, dudy, wnorm,
+                             p->stream));
+  return GPA_OK;
+}
+
+int gpa_reconstruct_grad(gpa_plan* p, const void* lockin, const double* kvecs, int P, int mask_border,
+                         void* dudx, void* dudy, void* wnorm) {
+  if (!p || !lockin || !kvecs || !dudx || !dudy) return fail(GPA_ERR_ARG, "gpa_reconstruct_grad: null argument");
+  if (P < 2 || P > p->max_peaks) return fail(GPA_ERR_STATE, "gpa_reconstruct_grad: need 2 <= P <= 8");
+  HIP_TRY(hipSetDevice(p->device));
+  const size_t npx = (size_t)p->n0 * p->n1;
+  HIP_TRY(hipMemcpyAsync(p->d_lockin, lockin, (size_t)P * npx * p->csz, hipMemcpyHostToDevice, p->stream));
+  TRY(gpa_reconstruct_grad_dev(p, p->d_lockin, kvecs, P, mask_border, p->d_dudx, p->d_dudy, p->d_wnorm));
+  HIP_TRY(hipMemcpyAsync(dudx, p->d_dudx, (size_t)2 * p->n0 * (p->n1 - 1) * p->rsz, hipMemcpyDeviceToHost, p->stream));
+  HIP_TRY(hipMemcpyAsync(dudy, p->d_dudy, (size_t)2 * (p->n0 - 1) * p->n1 * p->rsz, hipMemcpyDeviceToHost, p->stream));
+  if (wnorm) HIP_TRY(hipMemcpyAsync(wnorm, p->d_wnorm, npx * p->rsz, hipMemcpyDeviceToHost, p->stream));
+  HIP_TRY(hipStreamSynchronize(p->stream));
+  return GPA_OK;
+}
+
+// ---- a7 ----------------------------------------------------------------------
+int gpa_unwrap_prediff_dev(gpa_plan* p, const void* dx, const void* dy, const void* weight, int kmax,
+                           double eps, int compat, void* phi, int* iters_out) {
+  if (!p || !dx || !dy || !phi) return fail(GPA_ERR_ARG, "gpa_unwrap_prediff: null argument");
+  if (kmax < 1) return fail(GPA_ERR_ARG, "gpa_unwrap_prediff: kmax must be >= 1");
+  HIP_TRY(hipSetDevice(p->device));
+  int iters = 0;
+  hipError_t e = unwrap_run(&p->uw, dx, dy, weight, false, kmax, eps, compat != 0, phi, &iters, p->stream);
+  if (e != hipSuccess) return fail(GPA_ERR_HIP, std::string("unwrap: ") + hipGetErrorString(e));
+  if (iters_out) *iters_out = iters;
+  return GPA_OK;
+}
+
+int gpa_unwrap_prediff(gpa_plan* p, const void* dx, const void* dy, const void* weight, int kmax, double eps,
+                       int compat, void* phi, int* iters_out) {
+  if (!p || !dx || !dy || !phi) return fail(GPA_ERR_ARG, "gpa_unwrap_prediff: null argument");
+  HIP_TRY(hipSetDevice(p->device));
+  const size_t npx = (size_t)p->n0 * p->n1;
+  const size_t nx = (size_t)p->n0 * (p->n1 - 1), ny = (size_t)(p->n0 - 1) * p->n1;
+  HIP_TRY(hipMemcpyAsync(p->d_dudx, dx, nx * p->rsz, hipMemcpyHostToDevice, p->stream));
+  HIP_TRY(hipMemcpyAsync(p->d_dudy, dy, ny * p->rsz, hipMemcpyHostToDevice, p->stream));
+  if (weight) HIP_TRY(hipMemcpyAsync(p->d_wnorm, weight, npx * p->rsz, hipMemcpyHostToDevice, p->stream));
+  TRY(gpa_unwrap_prediff_dev(p, p->d_dudx, p->d_dudy, weight ? p->d_wnorm : nullptr, kmax, eps, compat, p->d_u,
+                             iters_out));
+  HIP_TRY(hipMemcpyAsync(phi, p->d_u, npx * p->rsz, hipMemcpyDeviceToHost, p->stream));
+  HIP_TRY(hipStreamSynchronize(p->stream));
+  return GPA_OK;
+}
+
+int gpa_unwrap(gpa_plan* p, const void* psi, const void* weight, int kmax, double eps, int compat, void* phi,
+               int* iters_out) {
+  if (!p || !psi || !phi) return fail(GPA_ERR_ARG, "gpa_unwrap: null argument");
+  if (kmax < 1) return fail(GPA_ERR_ARG, "gpa_unwrap: kmax must be >= 1");
+  HIP_TRY(hipSetDevice(p->device));
+  const size_t npx = (size_t)p->n0 * p->n1;
+  HIP_TRY(hipMemcpyAsync(p->d_image, psi, npx * p->rsz, hipMemcpyHostToDevice, p->stream));
+  if (weight) HIP_TRY(hipMemcpyAsync(p->d_wnorm, weight, npx * p->rsz, hipMemcpyHostToDevice, p->stream));
+  int iters = 0;
+  hipError_t e = unwrap_run(&p->uw, p->d_image, nullptr, weight ? p->d_wnorm : nullptr, true, kmax, eps,
+                            compat != 0, p->d_u, &iters, p->stream);
+  if (e != hipSuccess) return fail(GPA_ERR_HIP, std::string("unwrap: ") + hipGetErrorString(e));
+  if (iters_out) *iters_out = iters;
+  HIP_TRY(hipMemcpyAsync(phi, p->d_u, npx * p->rsz, hipMemcpyDeviceToHost, p->stream));
+  HIP_TRY(hipStreamSynchronize(p->stream));
+  return GPA_OK;
+}
+
+// ---- fused driver --------------------------------------------------------------
+int gpa_extract_displacement_field_dev(gpa_plan* p, const void* image, const double* kvecs, int P,
+                                       const double* klists, int K, double sigma, int mask_border, int kmax,
+                                       void* u, void* lockins, int32_t* kidx, int* iters_out) {
+  if (!p || !image || !kvecs || !klists || !u) return fail(GPA_ERR_ARG, "gpa_extract_displacement_field: null argument");
+  if (P < 2 || P > p->max_peaks) return fail(GPA_ERR_STATE, "gpa_extract_displacement_field: need 2 <= P <= 8");
+  if (K < 1 || P * K > p->max_batch) return fail(GPA_ERR_STATE, "gpa_extract_displacement_field: P*K exceeds max_batch");
+  if (kmax < 1) return fail(GPA_ERR_ARG, "kmax must be >= 1");
+  HIP_TRY(hipSetDevice(p->device));
+  const size_t npx = (size_t)p->n0 * p->n1;
+  if (p->profiling) HIP_TRY(hipEventRecord(p->stage_ev[0], p->stream));
+  HIP_TRY(launch_mean(p->dtype, image, npx, p->d_scratch, p->d_mean, p->stream));
+  void* lk = lockins ? lockins : p->d_lockin;
+  TRY(sweep_peaks_dev(p, image, p->d_mean, kvecs, P, klists, K, sigma, lk, kidx));
+  for (int i = 0; i < 2 * P; ++i) p->h_k[i] = 2.0 * M_PI * kvecs[i];
+  HIP_TRY(hipMemcpyAsync(p->d_kmat, p->h_k, (size_t)2 * P * sizeof(double), hipMemcpyHostToDevice, p->stream));
+  HIP_TRY(launch_reconstruct(p->dtype, lk, p->d_kmat, P, p->n0, p->n1, mask_border, p->d_dudx, p->d_dudy,
+                             p->d_wnorm, p->stream));
+  if (p->profiling) HIP_TRY(hipEventRecord(p->stage_ev[4], p->stream));
+  const size_t nx = (size_t)p->n0 * (p->n1 - 1), ny = (size_t)(p->n0 - 1) * p->n1;
+  int iters[2] = {0, 0};
+  for (int c = 0; c < 2; ++c) {
+    hipError_t e = unwrap_run(&p->uw, (char*)p->d_dudx + c * nx * p->rsz, (char*)p->d_dudy + c * ny * p->rsz,
+                              p->d_wnorm, false, kmax, 1e-9, true, (char*)u + c * npx * p->rsz, &iters[c],
+                              p->stream);
+    if (e != hipSuccess) return fail(GPA_ERR_HIP, std::string("unwrap: ") + hipGetErrorString(e));
+  }
+  if (p->profiling) {
+    HIP_TRY(hipEventRecord(p->stage_ev[5], p->stream));
+    HIP_TRY(hipEventSynchronize(p->stage_ev[5]));
+    for (int i = 0; i < 5; ++i) hipEventElapsedTime(&p->stage_ms[i], p->stage_ev[i], p->stage_ev[i + 1]);
+  }
+  if (iters_out) { iters_out[0] = iters[0]; iters_out[1] = iters[1]; }
+  return GPA_OK;
+}
+
+int gpa_extract_displacement_field(gpa_plan* p, const void* image, const double* kvecs, int P,
+                                   const double* klists, int K, double sigma, int mask_border, int kmax,
+                                   void* u, void* lockins, int32_t* kidx, int* iters_out) {
+  if (!p || !image || !u) return fail(GPA_ERR_ARG, "gpa_extract_displacement_field: null argument");
+  HIP_TRY(hipSetDevice(p->device));
+  const size_t npx = (size_t)p->n0 * p->n1;
+  HIP_TRY(hipMemcpyAsync(p->d_image, image, npx * p->rsz, hipMemcpyHostToDevice, p->stream));
+  TRY(gpa_extract_displacement_field_dev(p, p->d_image, kvecs, P, klists, K, sigma, mask_border, kmax, p->d_u,
+                                         p->d_lockin, kidx ? p->d_kidx : nullptr, iters_out));
+  HIP_TRY(hipMemcpyAsync(u, p->d_u, 2 * npx * p->rsz, hipMemcpyDeviceToHost, p->stream));
+  if (lockins) HIP_TRY(hipMemcpyAsync(lockins, p->d_lockin, (size_t)P * npx * p->csz, hipMemcpyDeviceToHost, p->stream));
+  if (kidx) HIP_TRY(hipMemcpyAsync(kidx, p->d_kidx, (size_t)P * npx * sizeof(int32_t), hipMemcpyDeviceToHost, p->stream));
+  HIP_TRY(hipStreamSynchronize(p->stream));
+  return GPA_OK;
+}
+
+int gpa_per_dft(gpa_plan* p, const void* image, void* out) {
+  (void)image; (void)out;
+  if (!p) return fail(GPA_ERR_ARG, "null plan");
+  return fail(GPA_ERR_ARG, "gpa_per_dft: not available in this build");
+}
+
+// ---- timing --------------------------------------------------------------------
+int gpa_timer_start(gpa_plan* p) {
+  if (!p) return fail(GPA_ERR_ARG, "null plan");
+  HIP_TRY(hipEventRecord(p->ev0, p->stream));
+  return GPA_OK;
+}
+int gpa_timer_stop(gpa_plan* p, float* ms_out) {
+  if (!p || !ms_out) return fail(GPA_ERR_ARG, "null argument");
+  HIP_TRY(hipEventRecord(p->ev1, p->stream));
+  HIP_TRY(hipEventSynchronize(p->ev1));
+  HIP_TRY(hipEventElapsedTime(ms_out, p->ev0, p->ev1));
+  return GPA_OK;
+}
+int gpa_set_profiling(gpa_plan* p, int on) {
+  if (!p) return fail(GPA_ERR_ARG, "null plan");
+  p->profiling = on != 0;
+  return GPA_OK;
+}
+int gpa_last_stage_ms(gpa_plan* p, float* ms5) {
+  if (!p || !ms5) return fail(GPA_ERR_ARG, "null argument");
+  for (int i = 0; i < 5; ++i) ms5[i] = p->stage_ms[i];
+  return GPA_OK;
+}
+
+}  // extern "C"

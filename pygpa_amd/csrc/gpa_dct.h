@@ -1,0 +1,112 @@
+// DCT-II / DCT-III building blocks on top of WgFFT (power-of-two lengths).
+//
+// Convention = SciPy's dctn/idctn defaults used by the reference
+// (phase_unwrap.py:84-103): forward X[k] = 2 sum_n x[n] cos(pi k (2n+1) / (2N)),
+// idct = exact inverse.  Makhoul's algorithm maps an N-point DCT-II onto an N-point
+// complex FFT of the even/odd-permuted input v:
+//     v[m] = x[2m] (m < N/2),  v[m] = x[2(N-1-m)+1] (m >= N/2)
+//     X[k] = w_k V[k] + conj(w_k) V[N-k],   w_k = exp(-i pi k / (2N))
+// The relation is complex-linear, so TWO real sequences ride through one complex
+// transform as real and imaginary parts.
+//
+// Three fused forms are provided; each is a list of phases separated by workgroup
+// barriers, written GPA_HD so tests/host/dct_emulator.cpp can run them on the CPU.
+#pragma once
+#include "gpa_fft.h"
+
+namespace gpa {
+
+// slot of the permuted sequence -> index in the original sequence
+GPA_HD int makhoul_src(int m, int N) { return m < N / 2 ? 2 * m : 2 * (N - 1 - m) + 1; }
+
+template <class T, int LG>
+struct WgDCT {
+  using F = WgFFT<T, LG>;
+  static constexpr int N = F::L, TPF = F::TPF, E = 16;
+
+  // ---- forward DCT-II of a packed pair -------------------------------------
+  // in : x = permuted input in the natural layout (slot m = tid + TPF*i)
+  // out: x[i] = Xa[k] + i Xb[k] at k = tid + TPF*i
+  // sequence: F::forward; barrier; fwd_scatter; barrier; fwd_gather
+  GPA_HD static void fwd_scatter(const cpx<T> (&x)[E], cpx<T>* lds, int tid) {
+#pragma unroll
+    for (int i = 0; i < E; ++i) lds[F::pad(F::spec_index(tid, i))] = x[i];
+  }
+  // wk: table w_k in natural order
+  GPA_HD static void fwd_gather(cpx<T> (&x)[E], const cpx<T>* lds, int tid, const cpx<T>* __restrict__ wk) {
+#pragma unroll
+    for (int i = 0; i < E; ++i) {
+      const int k = tid + TPF * i;
+      const cpx<T> zk = lds[F::pad(k)], zm = lds[F::pad((N - k) & (N - 1))];
+      const cpx<T> w = wk[k];
+      x[i] = cmul(w, zk) + cmulc(zm, w);
+    }
+  }
+
+  // ---- fused DCT-II -> per-bin scale -> DCT-III of a packed pair -------------
+  // After F::forward the thread holds Z[k], k = spec_index(tid, i).
+  // sequence: F::forward; barrier; solve_scatter; barrier; solve_combine; F::inverse
+  // Tables in the spectral layout [i][tid]: wspec = w_k, ha = 1 - cos(.) of bin k,
+  // ham = the same of bin N-k.  hb_a / hb_b: 1 - cos(.) of the two packed sequences'
+  // own (other-axis) bins; inv_n = 1/N.  The divisor of bin (k, other) is
+  // 2 (cos + cos - 2) = -2 (ha + hb), replaced by 1 where k == 0 and first_a /
+  // first_b says the other-axis bin is 0 too (phase_unwrap.py:106-115).  The tables
+  // hold 1 - cos = 2 sin^2(half angle), evaluated in double on the host, because
+  // cos + cos - 2 cancels catastrophically in f32 near the DC corner.
+  GPA_HD static void solve_scatter(const cpx<T> (&x)[E], cpx<T>* lds, int tid) { fwd_scatter(x, lds, tid); }
+  GPA_HD static void solve_combine(cpx<T> (&x)[E], const cpx<T>* lds, int tid,
+                                   const cpx<T>* __restrict__ wspec, const T* __restrict__ ha,
+                                   const T* __restrict__ ham, T hb_a, T hb_b, bool first_a,
+                                   bool first_b, T inv_n) {
+#pragma unroll
+    for (int i = 0; i < E; ++i) {
+      const int k = F::spec_index(tid, i);
+      const cpx<T> zk = x[i], zm = lds[F::pad((N - k) & (N - 1))];
+      const cpx<T> w = wspec[i * TPF + tid];
+      const T h = ha[i * TPF + tid], hm = ham[i * TPF + tid];
+      // split the packed transform: Va = (Zk + conj Zm)/2, Vb = (Zk - conj Zm)/(2i)
+      const cpx<T> va = {T(0.5) * (zk.x + zm.x), T(0.5) * (zk.y - zm.y)};
+      const cpx<T> vb = {T(0.5) * (zk.y + zm.y), T(-0.5) * (zk.x - zm.x)};
+      const cpx<T> ua = cmul(w, va), ub = cmul(w, vb);
+      T sa = inv_n / (T(-2) * (h + hb_a)), sb = inv_n / (T(-2) * (h + hb_b));
+      T sam = inv_n / (T(-2) * (hm + hb_a)), sbm = inv_n / (T(-2) * (hm + hb_b));
+      if (k == 0) {
+        sam = T(0);
+        sbm = T(0);
+        if (first_a) sa = inv_n;
+        if (first_b) sb = inv_n;
+      }
+      const cpx<T> ya = cmulc(cpx<T>{sa * ua.x, sam * ua.y}, w);
+      const cpx<T> yb = cmulc(cpx<T>{sb * ub.x, sbm * ub.y}, w);
+      x[i] = {ya.x - yb.y, ya.y + yb.x};
+    }
+  }
+
+  // ---- inverse (DCT-III) of a packed pair ------------------------------------
+  // in : xk[i] = Xa[k] + i Xb[k], xm[i] = same at N-k (0 for k == 0), k = tid + TPF*i
+  // out: x[i] = (a[c], b[c]) / N at c = tid + TPF*i  (original sample order)
+  // sequence: inv_prepare; F::forward; barrier; inv_scatter; barrier; inv_gather
+  GPA_HD static void inv_prepare(cpx<T> (&x)[E], const cpx<T> (&xm)[E], int tid,
+                                 const cpx<T>* __restrict__ wk) {
+#pragma unroll
+    for (int i = 0; i < E; ++i) {
+      const int k = tid + TPF * i;
+      const cpx<T> d = {x[i].x + xm[i].y, x[i].y - xm[i].x};   // X_k - i X_{N-k}
+      const cpx<T> v = cmulc(d, wk[k]);                        // * conj(w_k)
+      x[i] = {T(0.5) * v.x, T(-0.5) * v.y};                    // conj(V_k): IFFT = conj(FFT(conj .))
+    }
+  }
+  GPA_HD static void inv_scatter(const cpx<T> (&x)[E], cpx<T>* lds, int tid, T inv_n) {
+#pragma unroll
+    for (int i = 0; i < E; ++i) {
+      const int m = F::spec_index(tid, i);
+      lds[F::pad(makhoul_src(m, N))] = {x[i].x * inv_n, -x[i].y * inv_n};
+    }
+  }
+  GPA_HD static void inv_gather(cpx<T> (&x)[E], const cpx<T>* lds, int tid) {
+#pragma unroll
+    for (int i = 0; i < E; ++i) x[i] = lds[F::pad(tid + TPF * i)];
+  }
+};
+
+}  // namespace gpa

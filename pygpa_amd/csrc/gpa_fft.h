@@ -1,0 +1,361 @@
+// Workgroup-level power-of-two FFT for gfx950: radix-2^b butterflies in registers,
+// padded in-place exchanges through LDS.  Written for 64-wide wavefronts: every
+// thread owns E = 16 complex elements, a transform of length L uses L/16 threads,
+// and a pass of radix r makes each thread do 16/r butterflies.
+//
+// Layouts
+//   natural  : thread t, register i  <->  element  t + (L/16) * i          (coalesced in t)
+//   spectral : what the last forward pass leaves in registers; spec_index(t, i)
+//              gives the frequency bin.  Filter tables are pre-permuted on the
+//              host into this layout, so forward -> pointwise multiply -> inverse
+//              never pays for a digit-reversal.
+//
+// The forward transform is decimation-in-frequency, the inverse is the exact
+// mirror (decimation-in-time with conjugated twiddles), so both start and end in
+// the natural layout and use the same LDS addresses.  In-place LDS address of
+// element (kappa, m) before pass p is kappa * L_p + m; pad(a) = a + (a >> 4)
+// keeps every 32-lane group on distinct banks for all strides that occur.
+//
+// All per-thread steps are GPA_HD so that tests/host_fft_emulator.cpp can run the
+// very same index arithmetic on the CPU, thread by thread, phase by phase.
+#pragma once
+
+#if defined(__HIPCC__)
+#include <hip/hip_runtime.h>
+#define GPA_HD __host__ __device__ __forceinline__
+#else
+#define GPA_HD inline
+#endif
+
+namespace gpa {
+
+template <class T>
+struct cpx {
+  T x, y;
+};
+
+template <class T> GPA_HD cpx<T> operator+(cpx<T> a, cpx<T> b) { return {a.x + b.x, a.y + b.y}; }
+template <class T> GPA_HD cpx<T> operator-(cpx<T> a, cpx<T> b) { return {a.x - b.x, a.y - b.y}; }
+template <class T> GPA_HD cpx<T> cmul(cpx<T> a, cpx<T> b) { return {a.x * b.x - a.y * b.y, a.x * b.y + a.y * b.x}; }
+// a * conj(b)
+template <class T> GPA_HD cpx<T> cmulc(cpx<T> a, cpx<T> b) { return {a.x * b.x + a.y * b.y, a.y * b.x - a.x * b.y}; }
+template <bool CONJ, class T> GPA_HD cpx<T> cmul_maybe_conj(cpx<T> a, cpx<T> b) {
+  if constexpr (CONJ) return cmulc(a, b);
+  else return cmul(a, b);
+}
+template <class T> GPA_HD cpx<T> cscale(cpx<T> a, T s) { return {a.x * s, a.y * s}; }
+
+// ---------------------------------------------------------------------------
+// small DFTs on register arrays, natural order in -> natural order out.
+// INV = false: w = exp(-2 pi i / R); INV = true: conjugate.  Unnormalised.
+// ---------------------------------------------------------------------------
+template <bool INV, class T>
+GPA_HD void dft2(cpx<T>& a, cpx<T>& b) {
+  cpx<T> t = a;
+  a = t + b;
+  b = t - b;
+}
+
+template <bool INV, class T>
+GPA_HD void dft4(cpx<T>& a0, cpx<T>& a1, cpx<T>& a2, cpx<T>& a3) {
+  cpx<T> s02 = a0 + a2, d02 = a0 - a2, s13 = a1 + a3, d13 = a1 - a3;
+  a0 = s02 + s13;
+  a2 = s02 - s13;
+  // forward: X1 = d02 - i d13, X3 = d02 + i d13
+  cpx<T> m = {d02.x + d13.y, d02.y - d13.x};
+  cpx<T> p = {d02.x - d13.y, d02.y + d13.x};
+  if constexpr (INV) { a1 = p; a3 = m; }
+  else { a1 = m; a3 = p; }
+}
+
+// multiply by w16^M (forward) or its conjugate (inverse); M in [0,16)
+template <int M, bool INV, class T>
+GPA_HD cpx<T> mul_w16(cpx<T> a) {
+  constexpr T c1 = T(0.92387953251128673848), s1 = T(0.38268343236508978178), rh = T(0.70710678118654752440);
+  constexpr int m = M & 15;
+  if constexpr (m == 0) return a;
+  else if constexpr (m == 8) return {-a.x, -a.y};
+  else if constexpr (m == 4) { if constexpr (INV) return {-a.y, a.x}; else return {a.y, -a.x}; }
+  else if constexpr (m == 12) { if constexpr (INV) return {a.y, -a.x}; else return {-a.y, a.x}; }
+  else {
+    // w = (cr, -ci) forward, (cr, +ci) inverse with (cr, ci) = (cos, sin)(2 pi m / 16)
+    constexpr T cr = (m == 1 || m == 15) ? c1 : (m == 2 || m == 14) ? rh : (m == 3 || m == 13) ? s1
+                   : (m == 5 || m == 11) ? -s1 : (m == 6 || m == 10) ? -rh : -c1;  // m == 7, 9
+    constexpr T ci = (m == 1 || m == 7) ? s1 : (m == 2 || m == 6) ? rh : (m == 3 || m == 5) ? c1
+                   : (m == 9 || m == 15) ? -s1 : (m == 10 || m == 14) ? -rh : -c1;  // m == 11, 13
+    constexpr T wi = INV ? ci : -ci;
+    return {a.x * cr - a.y * wi, a.x * wi + a.y * cr};
+  }
+}
+
+template <int R, bool INV, class T>
+GPA_HD void dft_regs(cpx<T>* v) {
+  if constexpr (R == 2) {
+    dft2<INV>(v[0], v[1]);
+  } else if constexpr (R == 4) {
+    dft4<INV>(v[0], v[1], v[2], v[3]);
+  } else if constexpr (R == 8) {
+    // j = 4 j1 + j0, k = k0 + 2 k1
+    dft2<INV>(v[0], v[4]);
+    dft2<INV>(v[1], v[5]);
+    dft2<INV>(v[2], v[6]);
+    dft2<INV>(v[3], v[7]);
+    v[5] = mul_w16<2, INV>(v[5]);
+    v[6] = mul_w16<4, INV>(v[6]);
+    v[7] = mul_w16<6, INV>(v[7]);
+    dft4<INV>(v[0], v[1], v[2], v[3]);
+    dft4<INV>(v[4], v[5], v[6], v[7]);
+    // v[4 k0 + k1] holds X[k0 + 2 k1]
+    cpx<T> t[8];
+#pragma unroll
+    for (int k0 = 0; k0 < 2; ++k0)
+#pragma unroll
+      for (int k1 = 0; k1 < 4; ++k1) t[k0 + 2 * k1] = v[4 * k0 + k1];
+#pragma unroll
+    for (int i = 0; i < 8; ++i) v[i] = t[i];
+  } else {
+    static_assert(R == 16, "radix must be 2, 4, 8 or 16");
+    // j = 4 j1 + j0, k = k0 + 4 k1
+    dft4<INV>(v[0], v[4], v[8], v[12]);
+    dft4<INV>(v[1], v[5], v[9], v[13]);
+    dft4<INV>(v[2], v[6], v[10], v[14]);
+    dft4<INV>(v[3], v[7], v[11], v[15]);
+    // y[j0][k0] sits at v[j0 + 4 k0]; twiddle w16^(j0 k0)
+    v[5] = mul_w16<1, INV>(v[5]);
+    v[6] = mul_w16<2, INV>(v[6]);
+    v[7] = mul_w16<3, INV>(v[7]);
+    v[9] = mul_w16<2, INV>(v[9]);
+    v[10] = mul_w16<4, INV>(v[10]);
+    v[11] = mul_w16<6, INV>(v[11]);
+    v[13] = mul_w16<3, INV>(v[13]);
+    v[14] = mul_w16<6, INV>(v[14]);
+    v[15] = mul_w16<9, INV>(v[15]);
+    dft4<INV>(v[0], v[1], v[2], v[3]);
+    dft4<INV>(v[4], v[5], v[6], v[7]);
+    dft4<INV>(v[8], v[9], v[10], v[11]);
+    dft4<INV>(v[12], v[13], v[14], v[15]);
+    // v[4 k0 + k1] holds X[k0 + 4 k1]: transpose the 4x4
+    cpx<T> t;
+    t = v[1]; v[1] = v[4]; v[4] = t;
+    t = v[2]; v[2] = v[8]; v[8] = t;
+    t = v[3]; v[3] = v[12]; v[12] = t;
+    t = v[6]; v[6] = v[9]; v[9] = t;
+    t = v[7]; v[7] = v[13]; v[13] = t;
+    t = v[11]; v[11] = v[14]; v[14] = t;
+  }
+}
+
+// ---------------------------------------------------------------------------
+// Workgroup FFT of length L = 2^LOG2L, 64 <= L <= 16384.
+// ---------------------------------------------------------------------------
+template <class T, int LOG2L>
+struct WgFFT {
+  static_assert(LOG2L >= 6 && LOG2L <= 14, "supported lengths: 64 .. 16384");
+  static constexpr int L = 1 << LOG2L;
+  static constexpr int E = 16;
+  static constexpr int TPF = L / E;           // threads per transform
+  static constexpr int P = (LOG2L + 3) / 4;   // passes
+  static constexpr int LDS_ELEMS = L + L / 16;
+
+  // bits of pass p (balanced split of LOG2L into P digits, larger digits first)
+  static constexpr int bits(int p) { return LOG2L / P + (p < LOG2L % P ? 1 : 0); }
+  // log2 of the sub-transform length entering pass p
+  static constexpr int lg_len(int p) {
+    int s = LOG2L;
+    for (int q = 0; q < p; ++q) s -= bits(q);
+    return s;
+  }
+  GPA_HD static int pad(int a) { return a + (a >> 4); }
+
+  // in-place LDS address of butterfly element e of group G in pass p, split as
+  // addr_base(G) + addr_offs(e) with a compile-time offset so that the 16 accesses of an
+  // exchange share one address register and use the ds_* immediate offset field.
+  // (kappa L_p + m0 + e S) padded: the low nibble of kappa L_p + m0 never carries into
+  // the e S term because m0 < S and S | 16 or 16 | S.)
+  template <int p>
+  GPA_HD static int addr_base(int G) {
+    constexpr int lgLp = lg_len(p), lgS = lgLp - bits(p);
+    const int kappa = G >> lgS, m0 = G & ((1 << lgS) - 1);
+    return pad((kappa << lgLp) + m0);
+  }
+  template <int p>
+  static constexpr int addr_offs(int e) {
+    constexpr int lgS = lg_len(p) - bits(p);
+    return (e << lgS) + ((e << lgS) >> 4);
+  }
+  template <int p>
+  GPA_HD static int addr(int G, int e) { return addr_base<p>(G) + addr_offs<p>(e); }
+
+  // frequency bin held by thread tid, register i after the forward transform
+  GPA_HD static int spec_index(int tid, int i) {
+    constexpr int pl = P - 1;
+    constexpr int g = E >> bits(pl);
+    const int q = i % g, kl = i / g;
+    int kappa = tid + TPF * q;   // digits (k_1 .. k_{P-1}), k_1 most significant
+    int k = 0, mult = L >> bits(pl);
+    // peel digits from least significant (k_{P-1}) to most (k_1)
+    for (int p = P - 2; p >= 0; --p) {
+      const int r = 1 << bits(p);
+      mult >>= bits(p);
+      k += (kappa & (r - 1)) * mult;
+      kappa >>= bits(p);
+    }
+    return k + kl * (L >> bits(pl));
+  }
+
+  // Base twiddles kept in registers for the whole kernel (loop invariant across
+  // the k-vector sweep): for twiddled pass p and butterfly group q,
+  // lo = w^1, w^2, w^3 and hi = w^4, w^8, w^12 with w = exp(-2 pi i m0 / L_p).
+  static constexpr int GMAX = 2;   // radix >= 8 in every twiddled pass
+  struct Twiddles {
+    cpx<T> lo[P > 1 ? P - 1 : 1][GMAX][3];
+    cpx<T> hi[P > 1 ? P - 1 : 1][GMAX][3];
+  };
+
+  template <int p>
+  GPA_HD static void load_twiddles_pass(Twiddles& tw, const cpx<T>* __restrict__ table, int tid) {
+    constexpr int b = bits(p), r = 1 << b, g = E / r, lgLp = lg_len(p), lgS = lgLp - b;
+    static_assert(g <= GMAX, "twiddled passes must have radix >= 8");
+#pragma unroll
+    for (int q = 0; q < g; ++q) {
+      const int G = tid + TPF * q;
+      const int m0 = G & ((1 << lgS) - 1);
+      const int u = m0 << (LOG2L - lgLp);   // exponent unit in the length-L table
+#pragma unroll
+      for (int c = 0; c < 3; ++c) {
+        if ((c + 1) < r) tw.lo[p][q][c] = table[u * (c + 1)];
+        if (4 * (c + 1) < r) tw.hi[p][q][c] = table[u * 4 * (c + 1)];
+      }
+    }
+  }
+  GPA_HD static void load_twiddles(Twiddles& tw, const cpx<T>* __restrict__ table, int tid) {
+    if constexpr (P > 1) load_twiddles_pass<0>(tw, table, tid);
+    if constexpr (P > 2) load_twiddles_pass<1>(tw, table, tid);
+    if constexpr (P > 3) load_twiddles_pass<2>(tw, table, tid);
+  }
+
+  // v[k] *= w^k (forward) or conj(w^k) (inverse), k = 1 .. r-1
+  template <int p, int r, bool INV>
+  GPA_HD static void twiddle(cpx<T>* v, const Twiddles& tw, int q) {
+#pragma unroll
+    for (int k = 1; k < r; ++k) {
+      const int a = k >> 2, b = k & 3;
+      cpx<T> t = v[k];
+      if (a > 0) t = cmul_maybe_conj<INV>(t, tw.hi[p][q][a - 1]);
+      if (b > 0) t = cmul_maybe_conj<INV>(t, tw.lo[p][q][b - 1]);
+      v[k] = t;
+    }
+  }
+
+  // one pass of butterflies on the thread's 16 registers (q and j loops are
+  // fully unrolled, so every register index is static)
+  template <int p, bool INV>
+  GPA_HD static void butterflies(cpx<T> (&x)[E], const Twiddles& tw) {
+    constexpr int r = 1 << bits(p), g = E / r;
+    constexpr bool TW = p < P - 1;
+#pragma unroll
+    for (int q = 0; q < g; ++q) {
+      cpx<T> v[r];
+#pragma unroll
+      for (int j = 0; j < r; ++j) v[j] = x[q + g * j];
+      if constexpr (INV && TW) twiddle<p, r, true>(v, tw, q);
+      dft_regs<r, INV>(v);
+      if constexpr (!INV && TW) twiddle<p, r, false>(v, tw, q);
+#pragma unroll
+      for (int j = 0; j < r; ++j) x[q + g * j] = v[j];
+    }
+  }
+
+  template <int p>
+  GPA_HD static void lds_write(const cpx<T> (&x)[E], cpx<T>* lds, int tid) {
+    constexpr int r = 1 << bits(p), g = E / r;
+#pragma unroll
+    for (int q = 0; q < g; ++q) {
+      cpx<T>* base = lds + addr_base<p>(tid + TPF * q);
+#pragma unroll
+      for (int e = 0; e < r; ++e) base[addr_offs<p>(e)] = x[q + g * e];
+    }
+  }
+  template <int p>
+  GPA_HD static void lds_read(cpx<T> (&x)[E], const cpx<T>* lds, int tid) {
+    constexpr int r = 1 << bits(p), g = E / r;
+#pragma unroll
+    for (int q = 0; q < g; ++q) {
+      const cpx<T>* base = lds + addr_base<p>(tid + TPF * q);
+#pragma unroll
+      for (int e = 0; e < r; ++e) x[q + g * e] = base[addr_offs<p>(e)];
+    }
+  }
+
+  // ---- phases (the code between two workgroup barriers) -------------------
+  // forward: phase 0 .. P-1, barrier after every phase but the last
+  template <int ph>
+  GPA_HD static void fwd_phase(cpx<T> (&x)[E], cpx<T>* lds, int tid, const Twiddles& tw) {
+    if constexpr (ph > 0) lds_read<ph>(x, lds, tid);
+    butterflies<ph, false>(x, tw);
+    if constexpr (ph < P - 1) lds_write<ph>(x, lds, tid);
+  }
+  // inverse: phase 0 handles pass P-1, phase P-1 handles pass 0
+  template <int ph>
+  GPA_HD static void inv_phase(cpx<T> (&x)[E], cpx<T>* lds, int tid, const Twiddles& tw) {
+    constexpr int p = P - 1 - ph;
+    if constexpr (ph > 0) lds_read<p>(x, lds, tid);
+    butterflies<p, true>(x, tw);
+    if constexpr (p > 0) lds_write<p>(x, lds, tid);
+  }
+
+#if defined(__HIPCC__)
+  // whole transforms with workgroup barriers (every thread of the workgroup must call).
+  // NT independent transforms per thread share each barrier: x[n] uses lds + n * lds_stride.
+  template <int NT>
+  __device__ __forceinline__ static void forward_multi(cpx<T> (&x)[NT][E], cpx<T>* lds, int lds_stride, int tid,
+                                                       const Twiddles& tw) {
+#pragma unroll
+    for (int n = 0; n < NT; ++n) { fwd_phase<0>(x[n], lds + n * lds_stride, tid, tw); if (NT > 1) __builtin_amdgcn_sched_barrier(0); }
+    if constexpr (P > 1) {
+      __syncthreads();
+#pragma unroll
+      for (int n = 0; n < NT; ++n) { fwd_phase<1>(x[n], lds + n * lds_stride, tid, tw); if (NT > 1) __builtin_amdgcn_sched_barrier(0); }
+    }
+    if constexpr (P > 2) {
+      __syncthreads();
+#pragma unroll
+      for (int n = 0; n < NT; ++n) { fwd_phase<2>(x[n], lds + n * lds_stride, tid, tw); if (NT > 1) __builtin_amdgcn_sched_barrier(0); }
+    }
+    if constexpr (P > 3) {
+      __syncthreads();
+#pragma unroll
+      for (int n = 0; n < NT; ++n) { fwd_phase<3>(x[n], lds + n * lds_stride, tid, tw); if (NT > 1) __builtin_amdgcn_sched_barrier(0); }
+    }
+  }
+  template <int NT>
+  __device__ __forceinline__ static void inverse_multi(cpx<T> (&x)[NT][E], cpx<T>* lds, int lds_stride, int tid,
+                                                       const Twiddles& tw) {
+#pragma unroll
+    for (int n = 0; n < NT; ++n) { inv_phase<0>(x[n], lds + n * lds_stride, tid, tw); if (NT > 1) __builtin_amdgcn_sched_barrier(0); }
+    if constexpr (P > 1) {
+      __syncthreads();
+#pragma unroll
+      for (int n = 0; n < NT; ++n) { inv_phase<1>(x[n], lds + n * lds_stride, tid, tw); if (NT > 1) __builtin_amdgcn_sched_barrier(0); }
+    }
+    if constexpr (P > 2) {
+      __syncthreads();
+#pragma unroll
+      for (int n = 0; n < NT; ++n) { inv_phase<2>(x[n], lds + n * lds_stride, tid, tw); if (NT > 1) __builtin_amdgcn_sched_barrier(0); }
+    }
+    if constexpr (P > 3) {
+      __syncthreads();
+#pragma unroll
+      for (int n = 0; n < NT; ++n) { inv_phase<3>(x[n], lds + n * lds_stride, tid, tw); if (NT > 1) __builtin_amdgcn_sched_barrier(0); }
+    }
+  }
+  __device__ __forceinline__ static void forward(cpx<T> (&x)[E], cpx<T>* lds, int tid, const Twiddles& tw) {
+    forward_multi<1>(*reinterpret_cast<cpx<T>(*)[1][E]>(&x), lds, 0, tid, tw);
+  }
+  __device__ __forceinline__ static void inverse(cpx<T> (&x)[E], cpx<T>* lds, int tid, const Twiddles& tw) {
+    inverse_multi<1>(*reinterpret_cast<cpx<T>(*)[1][E]>(&x), lds, 0, tid, tw);
+  }
+#endif
+};
+
+}  // namespace gpa

@@ -1,0 +1,68 @@
+// Internal interfaces between the translation units of libgpa_hip.so.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#include "gpa_fft.h"
+
+namespace gpa {
+
+// One image axis: n samples, transformed with a power-of-two FFT of length L.
+// n == L  : periodic mode, the k-space Gaussian is applied bin by bin.
+// n <  L  : padded mode (L >= 2n-1): the circular convolution of length n is
+//           evaluated as a linear convolution of the periodically extended input
+//           with the full length-n spatial kernel -- the same numbers as
+//           IDFT_n(G * DFT_n(a)), without ever needing a length-n FFT.
+struct Axis {
+  int n;
+  int lg;      // log2(L)
+  int L;
+  bool padded;
+};
+
+// source sample of FFT slot m (-1: zero padding)
+GPA_HD int axis_src(int m, int n, int L, bool padded) {
+  if (!padded) return m;
+  if (m < n) return m;
+  if (m >= L - n + 1) return m - L + n;
+  return -1;
+}
+
+// Device tables of one batch of B lock-ins, element type cpx<T> of the plan dtype.
+struct SweepTables {
+  void* cxb;   // [B][L0/16]  exp(2 pi i wx t): carrier along x at the thread's base row
+  void* sx;    // [B][16]     exp(2 pi i wx (L0/16) i): per-register stride factor
+  void* wxw;   // [B]         exp(-2 pi i wx (L0 - n0)): wrap factor (padded mode)
+  void* cy;    // [B][n1]     exp(2 pi i wy y)
+  void* dx;    // [B][n0]     exp(-2 pi i (wx - kx) x)   compensation to the peak centre
+  void* dy;    // [B][n1]     exp(-2 pi i (wy - ky) y)
+};
+
+// ---- sweep (gpa_sweep.hip) --------------------------------------------------
+// kl: device [B][2] doubles (wx, wy); kr: device [B][2] doubles (kx, ky) of the
+// peak each candidate belongs to.
+hipError_t launch_tables(int dtype, const Axis& a0, const Axis& a1, const double* kl,
+                         const double* kr, int B, const SweepTables& tb, hipStream_t s);
+// mean_out: device scalar of the plan dtype; scratch: >= 1024 doubles
+hipError_t launch_mean(int dtype, const void* image, size_t count, double* scratch,
+                       void* mean_out, hipStream_t s);
+// x-axis pass: Tbuf[b][x][y] = cy_b[y] * Cx( (image - mean) * cx_b )[x][y]
+hipError_t launch_passA(int dtype, const Axis& a0, int n1, const void* image, const void* mean,
+                        const SweepTables& tb, const void* Hx, const void* tw0, void* Tbuf,
+                        int B, hipStream_t s);
+// y-axis pass.  select = true: per peak p (grid.y = P) loop over its K candidates
+// keeping the strictly-largest |sf|, write compensated lock-in (+ kidx).
+// select = false: write all B lock-ins (P = B, K = 1).
+hipError_t launch_passB(int dtype, const Axis& a1, int n0, const void* Tbuf, const void* Hy,
+                        const void* tw1, const SweepTables& tb, int P, int K, bool select,
+                        void* out, int32_t* kidx, hipStream_t s);
+int passA_cols(int dtype, int lg);
+// frequency bin held by (thread, register) after the forward transform of length 2^lg
+int spec_index_rt(int lg, int tid, int reg);
+
+// ---- reconstruct (gpa_reconstruct.hip) -------------------------------------
+hipError_t launch_reconstruct(int dtype, const void* lockin, const double* kmat /*dev P*2, 2 pi k*/,
+                              int P, int n0, int n1, int border, void* dudx, void* dudy,
+                              void* wnorm, hipStream_t s);
+
+}  // namespace gpa

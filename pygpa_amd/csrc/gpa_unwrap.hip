@@ -1,0 +1,614 @@
+// a7: DCT-Laplacian weighted least-squares phase unwrap (Ghiglia & Romero PCG),
+// following phase_unwrap_prediff / phase_unwrap (phase_unwrap.py:282-350, :141-208).
+//
+//   r0 = A^T W^2 wrap(b);  repeat:  z = P^-1 r (DCT Poisson solve);  rho = <r,z>;
+//   p = z + (rho/rho_prev) p;  q = A^T W^2 A p;  alpha = rho/<p,q>;
+//   phi += alpha p;  r -= alpha q;  stop at kmax or ||r|| < eps ||r0||.
+//
+// The Poisson solve is three kernels: DCT-II along rows, a fused column kernel
+// (DCT-II -> divide by the Laplacian eigenvalues -> DCT-III, never leaving LDS),
+// DCT-III along rows.  Every scalar of the iteration (rho, alpha, beta, norms, the
+// iteration counter and the stop flag) lives on the device: the host enqueues kmax
+// iterations back to back and reads the iteration count once at the end; kernels
+// of iterations after convergence return immediately.
+#include <math.h>
+#include <string.h>
+
+#include <vector>
+
+#include "gpa_dct.h"
+#include "gpa_internal.h"
+#include "gpa_unwrap.h"
+
+namespace gpa {
+
+namespace {
+
+constexpr int MAXPART = 16384;   // one partial sum per image row / per grid-stride block
+
+struct Impl {
+  int dtype, n0, n1, lg0, lg1;
+  bool supported;
+  size_t rsz;
+  void *r, *p, *q, *z;
+  void *tw0, *tw1;           // FFT twiddles per axis
+  void *wk1;                 // w_k along axis 1, natural order
+  void *wk0s;                // w_k along axis 0, spectral layout
+  void *ha0[2], *ham0[2];    // 1 - cos term of axis-0 bins (spectral layout); [compat]
+  void *hb1[2];              // 1 - cos term of axis-1 bins (natural); [compat]
+  double* scal;              // 8 doubles
+  int* flags;                // [0] = iteration count, [1] = done
+  double* part;              // 3 * MAXPART partial sums
+};
+
+template <class T> struct C2 { static constexpr T pi = T(3.14159265358979323846), two_pi = T(6.28318530717958647692); };
+
+template <class T>
+__device__ __forceinline__ T wrap_pi(T x) {
+  const T t = x + C2<T>::pi;
+  return t - C2<T>::two_pi * floor(t / C2<T>::two_pi) - C2<T>::pi;
+}
+
+// block-wide sum of a double, result valid in thread 0
+__device__ __forceinline__ double block_sum(double v, double* sh) {
+  const int n = blockDim.x;
+  sh[threadIdx.x] = v;
+  __syncthreads();
+  int active = n;
+  while (active > 1) {
+    const int half = (active + 1) / 2;
+    if ((int)threadIdx.x < active - half) sh[threadIdx.x] += sh[threadIdx.x + half];
+    __syncthreads();
+    active = half;
+  }
+  return sh[0];
+}
+
+// ---------------------------------------------------------------------------
+// setup: r0 = div( WW * wrap(grad) ), phi = 0, partial ||r0||^2
+// ---------------------------------------------------------------------------
+template <class T>
+__device__ __forceinline__ T edge_x(const T* a, const T* w, bool from_psi, int n1, int x, int y) {
+  // weighted wrapped difference across the edge (x,y)-(x,y+1); 0 outside
+  if (y < 0 || y >= n1 - 1) return T(0);
+  T d = from_psi ? a[(size_t)x * n1 + y + 1] - a[(size_t)x * n1 + y] : a[(size_t)x * (n1 - 1) + y];
+  d = wrap_pi(d);
+  if (w) {
+    const T w0 = w[(size_t)x * n1 + y], w1 = w[(size_t)x * n1 + y + 1];
+    const T a0 = w0 * w0, a1 = w1 * w1;
+    d *= a0 < a1 ? a0 : a1;
+  }
+  return d;
+}
+template <class T>
+__device__ __forceinline__ T edge_y(const T* a, const T* b, const T* w, bool from_psi, int n0, int n1, int x, int y) {
+  if (x < 0 || x >= n0 - 1) return T(0);
+  T d = from_psi ? a[(size_t)(x + 1) * n1 + y] - a[(size_t)x * n1 + y] : b[(size_t)x * n1 + y];
+  d = wrap_pi(d);
+  if (w) {
+    const T w0 = w[(size_t)x * n1 + y], w1 = w[(size_t)(x + 1) * n1 + y];
+    const T a0 = w0 * w0, a1 = w1 * w1;
+    d *= a0 < a1 ? a0 : a1;
+  }
+  return d;
+}
+
+template <class T>
+__global__ __launch_bounds__(256) void setup_kernel(const T* __restrict__ a, const T* __restrict__ b,
+                                                   const T* __restrict__ w, int from_psi, int n0, int n1,
+                                                   T* __restrict__ r, T* __restrict__ phi, double* part) {
+  __shared__ double sh[256];
+  const int x = blockIdx.x;
+  double sq = 0;
+  for (int y = threadIdx.x; y < n1; y += 256) {
+    const T v = edge_x(a, w, from_psi, n1, x, y) - edge_x(a, w, from_psi, n1, x, y - 1) +
+                edge_y(a, b, w, from_psi, n0, n1, x, y) - edge_y(a, b, w, from_psi, n0, n1, x - 1, y);
+    r[(size_t)x * n1 + y] = v;
+    phi[(size_t)x * n1 + y] = T(0);
+    sq += (double)v * (double)v;
+  }
+  const double tot = block_sum(sq, sh);
+  if (threadIdx.x == 0) part[blockIdx.x] = tot;
+}
+
+// scalar kernels (one block each) -------------------------------------------
+__global__ void scal_init_kernel(const double* part, int nparts, double* scal, int* flags) {
+  __shared__ double sh[256];
+  double acc = 0;
+  for (int i = threadIdx.x; i < nparts; i += 256) acc += part[i];
+  const double tot = block_sum(acc, sh);
+  if (threadIdx.x == 0) {
+    scal[5] = tot;   // ||r0||^2
+    scal[6] = tot;
+    scal[1] = 0.0;
+    flags[0] = 0;
+    flags[1] = tot == 0.0 ? 1 : 0;   // r == 0 everywhere: nothing to do (phase_unwrap.py:326)
+  }
+}
+__global__ void scal_rho_kernel(const double* part, int nparts, double* scal, const int* flags) {
+  if (flags[1]) return;
+  __shared__ double sh[256];
+  double acc = 0;
+  for (int i = threadIdx.x; i < nparts; i += 256) acc += part[i];
+  const double tot = block_sum(acc, sh);
+  if (threadIdx.x == 0) {
+    scal[0] = tot;                                       // rho = <r, z>
+    scal[4] = flags[0] == 0 ? 0.0 : tot / scal[1];       // beta (phase_unwrap.py:332-336)
+  }
+}
+__global__ void scal_alpha_kernel(const double* part, int nparts, double* scal, const int* flags) {
+  if (flags[1]) return;
+  __shared__ double sh[256];
+  double acc = 0;
+  for (int i = threadIdx.x; i < nparts; i += 256) acc += part[i];
+  const double tot = block_sum(acc, sh);
+  if (threadIdx.x == 0) {
+    scal[2] = tot;                 // <p, Qp>
+    scal[3] = scal[0] / tot;       // alpha (phase_unwrap.py:343)
+    scal[1] = scal[0];             // rho_prev
+  }
+}
+__global__ void scal_stop_kernel(const double* part, int nparts, double* scal, int* flags, int kmax, double eps) {
+  if (flags[1]) return;
+  __shared__ double sh[256];
+  double acc = 0;
+  for (int i = threadIdx.x; i < nparts; i += 256) acc += part[i];
+  const double tot = block_sum(acc, sh);
+  if (threadIdx.x == 0) {
+    scal[6] = tot;
+    const int k = flags[0] + 1;
+    flags[0] = k;
+    if (k >= kmax || sqrt(tot) < eps * sqrt(scal[5]) || tot == 0.0) flags[1] = 1;   // phase_unwrap.py:348
+  }
+}
+
+// elementwise / stencil kernels ------------------------------------------------
+template <class T>
+__global__ __launch_bounds__(256) void pupdate_kernel(const T* __restrict__ z, T* __restrict__ p, size_t count,
+                                                     const double* scal, const int* flags) {
+  if (flags[1]) return;
+  const T beta = (T)scal[4];
+  const bool first = flags[0] == 0;
+  for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < count; i += (size_t)gridDim.x * 256)
+    p[i] = first ? z[i] : z[i] + beta * p[i];
+}
+
+template <class T>
+__global__ __launch_bounds__(256) void applyq_kernel(const T* __restrict__ p, const T* __restrict__ w, int n0,
+                                                    int n1, T* __restrict__ q, double* part, const int* flags) {
+  if (flags[1]) return;
+  __shared__ double sh[256];
+  const int x = blockIdx.x;
+  double pq = 0;
+  for (int y = threadIdx.x; y < n1; y += 256) {
+    const size_t o = (size_t)x * n1 + y;
+    const T pc = p[o];
+    T wc = T(1);
+    if (w) { wc = w[o]; wc *= wc; }
+    T acc = T(0);
+    // q = sum over the 4 edges of WW_edge * (p_neighbour - p_centre)   (phase_unwrap.py:118-132)
+    if (y + 1 < n1) { T wn = T(1); if (w) { wn = w[o + 1]; wn *= wn; } acc += (wn < wc ? wn : wc) * (p[o + 1] - pc); }
+    if (y > 0)      { T wn = T(1); if (w) { wn = w[o - 1]; wn *= wn; } acc += (wn < wc ? wn : wc) * (p[o - 1] - pc); }
+    if (x + 1 < n0) { T wn = T(1); if (w) { wn = w[o + n1]; wn *= wn; } acc += (wn < wc ? wn : wc) * (p[o + n1] - pc); }
+    if (x > 0)      { T wn = T(1); if (w) { wn = w[o - n1]; wn *= wn; } acc += (wn < wc ? wn : wc) * (p[o - n1] - pc); }
+    q[o] = acc;
+    pq += (double)pc * (double)acc;
+  }
+  const double tot = block_sum(pq, sh);
+  if (threadIdx.x == 0) part[blockIdx.x] = tot;
+}
+
+template <class T>
+__global__ __launch_bounds__(256) void update_kernel(const T* __restrict__ p, const T* __restrict__ q,
+                                                    T* __restrict__ phi, T* __restrict__ r, size_t count,
+                                                    const double* scal, double* part, const int* flags) {
+  if (flags[1]) return;
+  __shared__ double sh[256];
+  const T alpha = (T)scal[3];
+  double sq = 0;
+  for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < count; i += (size_t)gridDim.x * 256) {
+    phi[i] += alpha * p[i];
+    const T rv = r[i] - alpha * q[i];
+    r[i] = rv;
+    sq += (double)rv * (double)rv;
+  }
+  const double tot = block_sum(sq, sh);
+  if (threadIdx.x == 0) part[blockIdx.x] = tot;
+}
+
+// ---------------------------------------------------------------------------
+// DCT kernels
+// ---------------------------------------------------------------------------
+template <class T, int LG>
+struct RowGeom {
+  using F = WgFFT<T, LG>;
+  static constexpr int NF = F::TPF >= 256 ? 1 : 256 / F::TPF;   // row PAIRS per workgroup
+  static constexpr int RS = F::LDS_ELEMS + (NF > 1 ? (F::TPF < 32 ? F::TPF : 0) : 0);
+  static constexpr int THREADS = NF * F::TPF;
+  static constexpr size_t LDS_BYTES = (size_t)NF * RS * sizeof(cpx<T>);
+  static constexpr bool FITS = LDS_BYTES <= 160 * 1024;
+};
+template <class T, int LG>
+struct ColGeom {
+  using F = WgFFT<T, LG>;
+  static constexpr int cols() {
+    int c = 16;
+    while (c > 1 && (c * F::TPF > 1024 || (size_t)c * (F::LDS_ELEMS + 32) * sizeof(cpx<T>) > 160 * 1024)) c /= 2;
+    return c;
+  }
+  static constexpr int CC = cols();   // packed column PAIRS per workgroup
+  static constexpr int RS = F::LDS_ELEMS + ((32 / CC) - F::LDS_ELEMS % 32 + 32) % 32;
+  static constexpr int THREADS = CC * F::TPF;
+  static constexpr size_t LDS_BYTES = (size_t)CC * RS * sizeof(cpx<T>);
+  static constexpr bool FITS = (size_t)(F::LDS_ELEMS + 32) * sizeof(cpx<T>) <= 160 * 1024;
+};
+
+// rows: r (n0 x n1) -> Z = DCT-II along axis 1
+template <class T, int LG>
+__global__ __launch_bounds__((RowGeom<T, LG>::THREADS)) void rowdct_kernel(const T* __restrict__ r, int n0,
+                                                                        T* __restrict__ Z,
+                                                                        const cpx<T>* __restrict__ twtab,
+                                                                        const cpx<T>* __restrict__ wk,
+                                                                        const int* flags) {
+  if (flags[1]) return;
+  using F = WgFFT<T, LG>;
+  using D = WgDCT<T, LG>;
+  using G = RowGeom<T, LG>;
+  constexpr int TPF = F::TPF, N = F::L;
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  const int tid = threadIdx.x % TPF, f = threadIdx.x / TPF;
+  cpx<T>* lds = reinterpret_cast<cpx<T>*>(smem) + f * G::RS;
+  const int pr = blockIdx.x * G::NF + f;
+  const bool valid = 2 * pr + 1 < n0;
+  const T* ra = r + (size_t)(valid ? 2 * pr : 0) * N;
+  const T* rb = ra + N;
+  typename F::Twiddles tw;
+  F::load_twiddles(tw, twtab, tid);
+  cpx<T> x[16];
+#pragma unroll
+  for (int i = 0; i < 16; ++i) {
+    const int src = makhoul_src(tid + TPF * i, N);
+    x[i] = {ra[src], rb[src]};
+  }
+  F::forward(x, lds, tid, tw);
+  __syncthreads();
+  D::fwd_scatter(x, lds, tid);
+  __syncthreads();
+  D::fwd_gather(x, lds, tid, wk);
+  if (!valid) return;
+  T* za = Z + (size_t)(2 * pr) * N;
+  T* zb = za + N;
+#pragma unroll
+  for (int i = 0; i < 16; ++i) {
+    za[tid + TPF * i] = x[i].x;
+    zb[tid + TPF * i] = x[i].y;
+  }
+}
+
+// columns: Z -> DCT-II along axis 0, divide by eigenvalues, DCT-III along axis 0 (in place)
+template <class T, int LG>
+__global__ __launch_bounds__((ColGeom<T, LG>::THREADS)) void colsolve_kernel(T* __restrict__ Z, int n1,
+                                                                          const cpx<T>* __restrict__ twtab,
+                                                                          const cpx<T>* __restrict__ wspec,
+                                                                          const T* __restrict__ ha,
+                                                                          const T* __restrict__ ham,
+                                                                          const T* __restrict__ hb,
+                                                                          const int* flags) {
+  if (flags[1]) return;
+  using F = WgFFT<T, LG>;
+  using D = WgDCT<T, LG>;
+  using G = ColGeom<T, LG>;
+  constexpr int TPF = F::TPF, N = F::L, CC = G::CC;
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  const int cp = threadIdx.x % CC, t = threadIdx.x / CC;
+  cpx<T>* lds = reinterpret_cast<cpx<T>*>(smem) + cp * G::RS;
+  const int y = (blockIdx.x * CC + cp) * 2;
+  const bool valid = y + 1 < n1;
+  const int yy = valid ? y : 0;
+  typename F::Twiddles tw;
+  F::load_twiddles(tw, twtab, t);
+  cpx<T> x[16];
+#pragma unroll
+  for (int i = 0; i < 16; ++i) {
+    const int row = makhoul_src(t + TPF * i, N);
+    x[i] = *reinterpret_cast<const cpx<T>*>(Z + (size_t)row * n1 + yy);
+  }
+  F::forward(x, lds, t, tw);
+  __syncthreads();
+  D::solve_scatter(x, lds, t);
+  __syncthreads();
+  D::solve_combine(x, lds, t, wspec, ha, ham, hb[yy], hb[yy + 1], yy == 0, false, T(1) / T(N));
+  __syncthreads();
+  F::inverse(x, lds, t, tw);
+  if (!valid) return;
+#pragma unroll
+  for (int i = 0; i < 16; ++i) {
+    const int row = makhoul_src(t + TPF * i, N);
+    *reinterpret_cast<cpx<T>*>(Z + (size_t)row * n1 + y) = x[i];
+  }
+}
+
+// rows: Z -> z = DCT-III along axis 1 (in place), partial rho = <r, z>
+template <class T, int LG>
+__global__ __launch_bounds__((RowGeom<T, LG>::THREADS)) void rowidct_kernel(T* __restrict__ Z, const T* __restrict__ r,
+                                                                         int n0, const cpx<T>* __restrict__ twtab,
+                                                                         const cpx<T>* __restrict__ wk, double* part,
+                                                                         const int* flags) {
+  if (flags[1]) return;
+  using F = WgFFT<T, LG>;
+  using D = WgDCT<T, LG>;
+  using G = RowGeom<T, LG>;
+  constexpr int TPF = F::TPF, N = F::L;
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  __shared__ double sh[1024];
+  const int tid = threadIdx.x % TPF, f = threadIdx.x / TPF;
+  cpx<T>* lds = reinterpret_cast<cpx<T>*>(smem) + f * G::RS;
+  const int pr = blockIdx.x * G::NF + f;
+  const bool valid = 2 * pr + 1 < n0;
+  T* za = Z + (size_t)(valid ? 2 * pr : 0) * N;
+  T* zb = za + N;
+  typename F::Twiddles tw;
+  F::load_twiddles(tw, twtab, tid);
+  cpx<T> x[16], xm[16];
+#pragma unroll
+  for (int i = 0; i < 16; ++i) {
+    const int k = tid + TPF * i;
+    x[i] = {za[k], zb[k]};
+    xm[i] = k == 0 ? cpx<T>{T(0), T(0)} : cpx<T>{za[N - k], zb[N - k]};
+  }
+  D::inv_prepare(x, xm, tid, wk);
+  F::forward(x, lds, tid, tw);
+  __syncthreads();
+  D::inv_scatter(x, lds, tid, T(1) / T(N));
+  __syncthreads();
+  D::inv_gather(x, lds, tid);
+  double dot = 0;
+  if (valid) {
+    const T* ra = r + (size_t)(2 * pr) * N;
+    const T* rb = ra + N;
+#pragma unroll
+    for (int i = 0; i < 16; ++i) {
+      const int c = tid + TPF * i;
+      za[c] = x[i].x;
+      zb[c] = x[i].y;
+      dot += (double)ra[c] * (double)x[i].x + (double)rb[c] * (double)x[i].y;
+    }
+  }
+  const double tot = block_sum(dot, sh);
+  if (threadIdx.x == 0) part[blockIdx.x] = tot;
+}
+
+#define GPA_FOR_LG(X) X(6) X(7) X(8) X(9) X(10) X(11) X(12) X(13) X(14)
+
+template <class T, int LG>
+hipError_t run_rowdct(const Impl* w, hipStream_t s) {
+  using G = RowGeom<T, LG>;
+  if constexpr (!G::FITS) return hipErrorInvalidValue;
+  else {
+    auto kern = rowdct_kernel<T, LG>;
+    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize,
+                                       (int)G::LDS_BYTES);
+    if (e != hipSuccess) return e;
+    const int npairs = w->n0 / 2, grid = (npairs + G::NF - 1) / G::NF;
+    kern<<<grid, G::THREADS, G::LDS_BYTES, s>>>((const T*)w->r, w->n0, (T*)w->z, (const cpx<T>*)w->tw1,
+                                                 (const cpx<T>*)w->wk1, w->flags);
+    return hipGetLastError();
+  }
+}
+template <class T, int LG>
+hipError_t run_rowidct(const Impl* w, int* nparts, hipStream_t s) {
+  using G = RowGeom<T, LG>;
+  if constexpr (!G::FITS) return hipErrorInvalidValue;
+  else {
+    auto kern = rowidct_kernel<T, LG>;
+    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize,
+                                       (int)G::LDS_BYTES);
+    if (e != hipSuccess) return e;
+    const int npairs = w->n0 / 2, grid = (npairs + G::NF - 1) / G::NF;
+    *nparts = grid;
+    kern<<<grid, G::THREADS, G::LDS_BYTES, s>>>((T*)w->z, (const T*)w->r, w->n0, (const cpx<T>*)w->tw1,
+                                                 (const cpx<T>*)w->wk1, w->part, w->flags);
+    return hipGetLastError();
+  }
+}
+template <class T, int LG>
+hipError_t run_colsolve(const Impl* w, int compat, hipStream_t s) {
+  using G = ColGeom<T, LG>;
+  if constexpr (!G::FITS) return hipErrorInvalidValue;
+  else {
+    auto kern = colsolve_kernel<T, LG>;
+    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize,
+                                       (int)G::LDS_BYTES);
+    if (e != hipSuccess) return e;
+    const int npairs = w->n1 / 2, grid = (npairs + G::CC - 1) / G::CC;
+    kern<<<grid, G::THREADS, G::LDS_BYTES, s>>>((T*)w->z, w->n1, (const cpx<T>*)w->tw0, (const cpx<T>*)w->wk0s,
+                                                 (const T*)w->ha0[compat], (const T*)w->ham0[compat],
+                                                 (const T*)w->hb1[compat], w->flags);
+    return hipGetLastError();
+  }
+}
+
+hipError_t dispatch_rowdct(const Impl* w, hipStream_t s) {
+#define CASE(LG) case LG: return w->dtype == 0 ? run_rowdct<float, LG>(w, s) : run_rowdct<double, LG>(w, s);
+  switch (w->lg1) { GPA_FOR_LG(CASE) }
+#undef CASE
+  return hipErrorInvalidValue;
+}
+hipError_t dispatch_rowidct(const Impl* w, int* nparts, hipStream_t s) {
+#define CASE(LG) case LG: return w->dtype == 0 ? run_rowidct<float, LG>(w, nparts, s) : run_rowidct<double, LG>(w, nparts, s);
+  switch (w->lg1) { GPA_FOR_LG(CASE) }
+#undef CASE
+  return hipErrorInvalidValue;
+}
+hipError_t dispatch_colsolve(const Impl* w, int compat, hipStream_t s) {
+#define CASE(LG) case LG: return w->dtype == 0 ? run_colsolve<float, LG>(w, compat, s) : run_colsolve<double, LG>(w, compat, s);
+  switch (w->lg0) { GPA_FOR_LG(CASE) }
+#undef CASE
+  return hipErrorInvalidValue;
+}
+
+template <class T>
+hipError_t upload_vec(void** dst, const std::vector<double>& v, size_t* bytes, hipStream_t s) {
+  std::vector<T> tmp(v.begin(), v.end());
+  hipError_t e = hipMalloc(dst, tmp.size() * sizeof(T) + 16);
+  if (e != hipSuccess) return e;
+  *bytes += tmp.size() * sizeof(T);
+  e = hipMemcpyAsync(*dst, tmp.data(), tmp.size() * sizeof(T), hipMemcpyHostToDevice, s);
+  if (e != hipSuccess) return e;
+  return hipStreamSynchronize(s);
+}
+hipError_t upload(int dtype, void** dst, const std::vector<double>& v, size_t* bytes, hipStream_t s) {
+  return dtype == 0 ? upload_vec<float>(dst, v, bytes, s) : upload_vec<double>(dst, v, bytes, s);
+}
+
+int ilog2_exact(int n) {
+  int lg = 0;
+  while ((1 << lg) < n) ++lg;
+  return (1 << lg) == n ? lg : -1;
+}
+
+}  // namespace
+
+hipError_t unwrap_workspace_create(int dtype, int n0, int n1, hipStream_t s, UnwrapWorkspace* ws, size_t* bytes_out) {
+  Impl* w = new Impl();
+  memset(w, 0, sizeof(Impl));
+  ws->impl = w;
+  ws->dtype = dtype;
+  ws->n0 = n0;
+  ws->n1 = n1;
+  w->dtype = dtype;
+  w->n0 = n0;
+  w->n1 = n1;
+  w->rsz = dtype == 0 ? 4 : 8;
+  w->lg0 = ilog2_exact(n0);
+  w->lg1 = ilog2_exact(n1);
+  const int maxlg = dtype == 0 ? 14 : 13;
+  w->supported = w->lg0 >= 6 && w->lg1 >= 6 && w->lg0 <= maxlg && w->lg1 <= maxlg;
+  size_t bytes = 0;
+  const size_t npx = (size_t)n0 * n1;
+  hipError_t e;
+  void** arrs[] = {&w->r, &w->p, &w->q, &w->z};
+  for (void** a : arrs) {
+    e = hipMalloc(a, npx * w->rsz);
+    if (e != hipSuccess) return e;
+    bytes += npx * w->rsz;
+  }
+  e = hipMalloc((void**)&w->scal, 8 * sizeof(double));
+  if (e != hipSuccess) return e;
+  e = hipMalloc((void**)&w->flags, 4 * sizeof(int));
+  if (e != hipSuccess) return e;
+  e = hipMalloc((void**)&w->part, (size_t)3 * MAXPART * sizeof(double));
+  if (e != hipSuccess) return e;
+  if (w->supported) {
+    for (int ax = 0; ax < 2; ++ax) {
+      const int n = ax == 0 ? n0 : n1;
+      std::vector<double> t((size_t)2 * n);
+      for (int k = 0; k < n; ++k) {
+        t[2 * k] = cos(-2.0 * M_PI * k / n);
+        t[2 * k + 1] = sin(-2.0 * M_PI * k / n);
+      }
+      e = upload(dtype, ax == 0 ? &w->tw0 : &w->tw1, t, &bytes, s);
+      if (e != hipSuccess) return e;
+    }
+    {
+      std::vector<double> t((size_t)2 * n1);
+      for (int k = 0; k < n1; ++k) {
+        t[2 * k] = cos(-M_PI * k / (2.0 * n1));
+        t[2 * k + 1] = sin(-M_PI * k / (2.0 * n1));
+      }
+      e = upload(dtype, &w->wk1, t, &bytes, s);
+      if (e != hipSuccess) return e;
+    }
+    const int tpf0 = n0 / 16;
+    {
+      std::vector<double> t((size_t)2 * n0);
+      for (int i = 0; i < 16; ++i)
+        for (int tt = 0; tt < tpf0; ++tt) {
+          const int k = spec_index_rt(w->lg0, tt, i);
+          t[2 * ((size_t)i * tpf0 + tt)] = cos(-M_PI * k / (2.0 * n0));
+          t[2 * ((size_t)i * tpf0 + tt) + 1] = sin(-M_PI * k / (2.0 * n0));
+        }
+      e = upload(dtype, &w->wk0s, t, &bytes, s);
+      if (e != hipSuccess) return e;
+    }
+    // 1 - cos(pi i / A) = 2 sin^2(pi i / (2A)).  Reference (compat = 1): axis-0 bins use A = n1
+    // and axis-1 bins use A = n0 (phase_unwrap.py:107-109); compat = 0: A = own axis length.
+    for (int compat = 0; compat < 2; ++compat) {
+      const double A0 = compat ? n1 : n0, A1 = compat ? n0 : n1;
+      std::vector<double> a((size_t)n0), am((size_t)n0), b((size_t)n1);
+      for (int i = 0; i < 16; ++i)
+        for (int tt = 0; tt < tpf0; ++tt) {
+          const int k = spec_index_rt(w->lg0, tt, i);
+          const double sk = sin(M_PI * k / (2.0 * A0)), sm = sin(M_PI * (n0 - k) / (2.0 * A0));
+          a[(size_t)i * tpf0 + tt] = 2 * sk * sk;
+          am[(size_t)i * tpf0 + tt] = 2 * sm * sm;
+        }
+      for (int j = 0; j < n1; ++j) {
+        const double sj = sin(M_PI * j / (2.0 * A1));
+        b[j] = 2 * sj * sj;
+      }
+      if ((e = upload(dtype, &w->ha0[compat], a, &bytes, s)) != hipSuccess) return e;
+      if ((e = upload(dtype, &w->ham0[compat], am, &bytes, s)) != hipSuccess) return e;
+      if ((e = upload(dtype, &w->hb1[compat], b, &bytes, s)) != hipSuccess) return e;
+    }
+  }
+  if (bytes_out) *bytes_out = bytes;
+  return hipSuccess;
+}
+
+void unwrap_workspace_destroy(UnwrapWorkspace* ws) {
+  Impl* w = (Impl*)ws->impl;
+  if (!w) return;
+  void* bufs[] = {w->r, w->p, w->q, w->z, w->tw0, w->tw1, w->wk1, w->wk0s, w->ha0[0], w->ha0[1], w->ham0[0],
+                  w->ham0[1], w->hb1[0], w->hb1[1], w->scal, w->flags, w->part};
+  for (void* b : bufs)
+    if (b) hipFree(b);
+  delete w;
+  ws->impl = nullptr;
+}
+
+template <class T>
+static hipError_t run_pcg(Impl* w, const void* a, const void* b, const void* weight, bool from_psi, int kmax,
+                          double eps, int compat, void* phi, hipStream_t s) {
+  const int n0 = w->n0, n1 = w->n1;
+  const size_t npx = (size_t)n0 * n1;
+  const int g2 = n0, np2 = n0;   // stencil kernels: one workgroup per image row
+  if (np2 > MAXPART) return hipErrorInvalidValue;
+  const int gl = 2048;   // grid-stride elementwise kernels
+  hipError_t e;
+  setup_kernel<T><<<g2, 256, 0, s>>>((const T*)a, (const T*)b, (const T*)weight, from_psi ? 1 : 0, n0, n1, (T*)w->r,
+                                     (T*)phi, w->part);
+  scal_init_kernel<<<1, 256, 0, s>>>(w->part, np2, w->scal, w->flags);
+  for (int it = 0; it < kmax; ++it) {
+    if ((e = dispatch_rowdct(w, s)) != hipSuccess) return e;
+    if ((e = dispatch_colsolve(w, compat, s)) != hipSuccess) return e;
+    int nrow = 0;
+    if ((e = dispatch_rowidct(w, &nrow, s)) != hipSuccess) return e;
+    scal_rho_kernel<<<1, 256, 0, s>>>(w->part, nrow, w->scal, w->flags);
+    pupdate_kernel<T><<<gl, 256, 0, s>>>((const T*)w->z, (T*)w->p, npx, w->scal, w->flags);
+    applyq_kernel<T><<<g2, 256, 0, s>>>((const T*)w->p, (const T*)weight, n0, n1, (T*)w->q, w->part + MAXPART, w->flags);
+    scal_alpha_kernel<<<1, 256, 0, s>>>(w->part + MAXPART, np2, w->scal, w->flags);
+    update_kernel<T><<<gl, 256, 0, s>>>((const T*)w->p, (const T*)w->q, (T*)phi, (T*)w->r, npx, w->scal,
+                                        w->part + 2 * MAXPART, w->flags);
+    scal_stop_kernel<<<1, 256, 0, s>>>(w->part + 2 * MAXPART, gl, w->scal, w->flags, kmax, eps);
+  }
+  return hipGetLastError();
+}
+
+hipError_t unwrap_run(UnwrapWorkspace* ws, const void* a, const void* b, const void* weight, bool from_psi, int kmax,
+                      double eps, bool axes_compat, void* phi, int* iters_out, hipStream_t s) {
+  Impl* w = (Impl*)ws->impl;
+  if (!w || !w->supported) return hipErrorNotSupported;
+  hipError_t e = w->dtype == 0 ? run_pcg<float>(w, a, b, weight, from_psi, kmax, eps, axes_compat ? 1 : 0, phi, s)
+                               : run_pcg<double>(w, a, b, weight, from_psi, kmax, eps, axes_compat ? 1 : 0, phi, s);
+  if (e != hipSuccess) return e;
+  int it = 0;
+  e = hipMemcpyAsync(&it, w->flags, sizeof(int), hipMemcpyDeviceToHost, s);
+  if (e != hipSuccess) return e;
+  e = hipStreamSynchronize(s);
+  if (e != hipSuccess) return e;
+  if (iters_out) *iters_out = it;
+  return hipSuccess;
+}
+
+}  // namespace gpa

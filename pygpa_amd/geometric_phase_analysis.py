@@ -1,0 +1,162 @@
+"""Host-side mirror of the hot path of pyGPA/geometric_phase_analysis.py.
+
+Same function names, argument order, defaults and return containers as the
+reference; the arithmetic runs in libgpa_hip.so on an MI355X through the C ABI of
+include/gpa_hip.h.  NumPy arrays in, fresh NumPy arrays out.  There is no CPU
+fallback: without the HIP library or a GPU every function raises GPAError.
+
+Extra keyword ``dtype`` (np.float64 default, like the reference's complex128
+path; np.float32 for the single-precision kernels) is the only addition.
+"""
+import numpy as np
+
+from . import _lib
+from ._lib import GPAError  # noqa: F401
+from .mathtools import wrapToPi  # noqa: F401
+
+DEFAULT_DTYPE = np.float64
+
+
+def _plan(image, batch, dtype):
+    image = np.asarray(image)
+    if image.ndim != 2:
+        raise ValueError('image must be 2-D')
+    return _lib.get_plan(image.shape, batch, DEFAULT_DTYPE if dtype is None else dtype)
+
+
+def _sweep_list(kx, ky, kw, kstep):
+    """k-list of the reference's double loop, wx outer / wy inner.  Built with
+    np.arange on the host because its length depends on float rounding
+    (geometric_phase_analysis.py:679-680)."""
+    wxs = np.arange(kx - kw, kx + kw, kstep)
+    wys = np.arange(ky - kw, ky + kw, kstep)
+    return np.array([(wx, wy) for wx in wxs for wy in wys], dtype=np.float64).reshape(-1, 2)
+
+
+def _w_from_kidx(kidx, klist):
+    w = np.zeros((2,) + kidx.shape)
+    won = kidx >= 0
+    w[0][won] = klist[kidx[won], 0]
+    w[1][won] = klist[kidx[won], 1]
+    return w
+
+
+# --------------------------------------------------------------------------- a1 / a2
+def GPA(image, kx, ky, sigma=22, dtype=None):
+    """Spatial lock-in (geometric_phase_analysis.py:20-45)."""
+    return _plan(image, 1, dtype).lockin_batch(image, [(kx, ky)], sigma)[0]
+
+
+def optGPA(image, kvec, sigma=22, dtype=None):
+    """Spatial lock-in, k-vector as a pair (geometric_phase_analysis.py:48-76)."""
+    return _plan(image, 1, dtype).lockin_batch(image, [tuple(kvec)], sigma)[0]
+
+
+def vecGPA(image, kvecs, sigma=22, dtype=None):
+    """Batched lock-in over a (K,2) list (geometric_phase_analysis.py:79-89)."""
+    kvecs = np.asarray(kvecs, dtype=np.float64).reshape(-1, 2)
+    return _plan(image, len(kvecs), dtype).lockin_batch(image, kvecs, sigma)
+
+
+# --------------------------------------------------------------------------- a3 / a4
+def wfr3(image, sigma, klist, kref, dtype=None):
+    """Adaptive lock-in over an explicit k-list (geometric_phase_analysis.py:647-666)."""
+    klist = np.asarray(klist, dtype=np.float64).reshape(-1, 2)
+    lockin, kidx, _ = _plan(image, len(klist), dtype).sweep(image, kref, klist, sigma)
+    return {'w': _w_from_kidx(kidx, klist), 'lockin': lockin, 'kidx': kidx}
+
+
+def optwfr2(image, sigma, kx, ky, kw, kstep, dtype=None):
+    """Adaptive lock-in on the np.arange grid around (kx, ky)
+    (geometric_phase_analysis.py:669-686); identical results to wfr2 (:615-644)."""
+    return wfr3(image, sigma, _sweep_list(kx, ky, kw, kstep), (kx, ky), dtype=dtype)
+
+
+wfr2 = optwfr2
+
+
+def wfr2_only_lockin(image, sigma, kx, ky, kw, kstep, dtype=None):
+    """Only the lock-in array (geometric_phase_analysis.py:689-702)."""
+    klist = _sweep_list(kx, ky, kw, kstep)
+    return _plan(image, len(klist), dtype).sweep(image, (kx, ky), klist, sigma, want_kidx=False)[0]
+
+
+def wfr2_grad_opt(image, sigma, kx, ky, kw, kstep, dtype=None):
+    """Adaptive lock-in that also returns the winner's phase gradient
+    (geometric_phase_analysis.py:763-813)."""
+    klist = _sweep_list(kx, ky, kw, kstep)
+    lockin, kidx, grad = _plan(image, len(klist), dtype).sweep(image, (kx, ky), klist, sigma, want_grad=True)
+    return {'w': _w_from_kidx(kidx, klist), 'lockin': lockin, 'grad': grad, 'kidx': kidx}
+
+
+wfr2_grad = wfr2_grad_opt
+
+_NATIVE_SWEEPS = (optwfr2, wfr2_grad_opt)
+
+
+# --------------------------------------------------------------------------- a5 .. a7
+def reconstruct_u_inv_from_phases(kvecs, phases, weights, weighted_unwrap=True, pre_diff=False, dtype=None):
+    """Wrapped phases -> displacement field (geometric_phase_analysis.py:196-245).
+
+    The device kernel consumes complex lock-ins, so phases/weights are re-packed as
+    weights * exp(i phases); with mask border 0 the per-pixel least squares and the
+    unwrap weights are those of the reference up to a uniform factor (1 + 1e-6)
+    that neither solution depends on."""
+    if pre_diff:
+        raise NotImplementedError('pre_diff=True is not part of the accelerated path')
+    phases = np.asarray(phases, dtype=np.float64)
+    weights = np.asarray(weights, dtype=np.float64)
+    plan = _lib.get_plan(phases.shape[1:], len(phases), DEFAULT_DTYPE if dtype is None else dtype)
+    dudx, dudy, wnorm = plan.reconstruct_grad(weights * np.exp(1j * phases), kvecs, 0)
+    us = []
+    for i in range(2):
+        if weighted_unwrap:
+            us.append(plan.unwrap_prediff(dudx[i], dudy[i], wnorm, kmax=10)[0])
+        else:
+            us.append(plan.unwrap_prediff(dudx[i], dudy[i])[0])
+    return np.array(us)
+
+
+def extract_displacement_field(image, kvecs, sigma=None, kwscale=2.5, ksteps=3, return_gs=False,
+                               wfr_func=optwfr2, deconvolve=False, klists=None, dtype=None):
+    """Top level convenience function (geometric_phase_analysis.py:907-932).
+
+    With the package's own sweep functions as ``wfr_func`` the whole chain (mean
+    subtraction, P x K lock-ins, selection, phases/weights, per-pixel least squares,
+    two weighted unwraps) runs in one fused device call; any other callable is
+    invoked per peak exactly like the reference does and only the reconstruction
+    runs on the device.  ``klists`` (P lists of (K,2)) replaces the np.arange grid.
+    """
+    if deconvolve:
+        raise NotImplementedError('deconvolve=True (skimage Wiener filter) is outside the accelerated path')
+    image = np.asarray(image)
+    kvecs = np.asarray(kvecs, dtype=np.float64).reshape(-1, 2)
+    norms = np.linalg.norm(kvecs, axis=1)
+    kw = norms.mean() / kwscale
+    if sigma is None:
+        sigma = int(np.ceil(1 / norms.min()))
+    kstep = kw / ksteps
+    dr = int(2 * sigma)
+    if wfr_func in _NATIVE_SWEEPS and not (return_gs and wfr_func is wfr2_grad_opt):
+        if klists is None:
+            klists = [_sweep_list(pk[0], pk[1], kw, kstep) for pk in kvecs]
+        klists = [np.asarray(kl, dtype=np.float64).reshape(-1, 2) for kl in klists]
+        K = max(len(kl) for kl in klists)
+        # lists of unequal length: repeat the last candidate (a repeat can never win a strict '>')
+        padded = np.stack([np.concatenate([kl, np.repeat(kl[-1:], K - len(kl), axis=0)]) for kl in klists])
+        plan = _lib.get_plan(image.shape, len(kvecs) * K, DEFAULT_DTYPE if dtype is None else dtype)
+        u, lock, kidx, _ = plan.extract_displacement_field(image, kvecs, padded, sigma, dr, kmax=10,
+                                                           want_lockins=return_gs, want_kidx=return_gs)
+        if return_gs:
+            gs = [{'lockin': lock[p], 'w': _w_from_kidx(kidx[p], padded[p]), 'kidx': kidx[p]}
+                  for p in range(len(kvecs))]
+            return u, gs
+        return u
+    gs = [wfr_func(image - image.mean(), sigma, pk[0], pk[1], kw=kw, kstep=kstep) for pk in kvecs]
+    lockins = np.stack([g['lockin'] for g in gs])
+    plan = _lib.get_plan(image.shape, len(kvecs), DEFAULT_DTYPE if dtype is None else dtype)
+    dudx, dudy, wnorm = plan.reconstruct_grad(lockins, kvecs, dr)
+    u = np.array([plan.unwrap_prediff(dudx[i], dudy[i], wnorm, kmax=10)[0] for i in range(2)])
+    if return_gs:
+        return u, gs
+    return u
