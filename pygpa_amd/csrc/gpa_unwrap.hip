@@ -120,6 +120,7 @@ __global__ void scal_init_kernel(const double* part, int nparts, double* scal, i
   if (threadIdx.x == 0) {
     scal[5] = tot;   // ||r0||^2
     scal[6] = tot;
+    scal[7] = tot;   // smallest ||r||^2 seen
     scal[1] = 0.0;
     flags[0] = 0;
     flags[1] = tot == 0.0 ? 1 : 0;   // r == 0 everywhere: nothing to do (phase_unwrap.py:326)
@@ -159,6 +160,11 @@ __global__ void scal_stop_kernel(const double* part, int nparts, double* scal, i
     const int k = flags[0] + 1;
     flags[0] = k;
     if (k >= kmax || sqrt(tot) < eps * sqrt(scal[5]) || tot == 0.0) flags[1] = 1;   // phase_unwrap.py:348
+    // breakdown guard (not in the reference, which iterates in f64 only): once the
+    // residual has bottomed out at the working precision CG loses conjugacy and the
+    // residual grows again; stop instead of iterating into garbage.
+    if (!(tot == tot) || tot > 1e4 * scal[7]) flags[1] = 1;
+    if (tot < scal[7]) scal[7] = tot;
   }
 }
 
@@ -575,6 +581,9 @@ static hipError_t run_pcg(Impl* w, const void* a, const void* b, const void* wei
   const int g2 = n0, np2 = n0;   // stencil kernels: one workgroup per image row
   if (np2 > MAXPART) return hipErrorInvalidValue;
   const int gl = 2048;   // grid-stride elementwise kernels
+  // the residual of an f32 iteration cannot fall below a few ulps of ||r0||
+  const double eps_floor = sizeof(T) == 4 ? 4e-6 : 0.0;
+  if (eps < eps_floor) eps = eps_floor;
   hipError_t e;
   setup_kernel<T><<<g2, 256, 0, s>>>((const T*)a, (const T*)b, (const T*)weight, from_psi ? 1 : 0, n0, n1, (T*)w->r,
                                      (T*)phi, w->part);
