@@ -118,6 +118,9 @@ struct gpa_plan {
   double* h_k = nullptr;          // pinned staging, 4 * max_batch doubles
   void* d_image = nullptr;        // staging for host-pointer entry points
   void* d_mean = nullptr;
+  void* d_sf = nullptr;           // [K][n0][n1] complex, grown on demand (a4 gradient path)
+  size_t sf_bytes = 0;
+  void* d_grad = nullptr;         // n0 x n1 x 2 staging for the host-pointer a4 call
   double* d_scratch = nullptr;    // 4096 doubles
   void* d_lockin = nullptr;       // [P<=max_peaks][n0][n1] complex (staging / fused driver)
   int32_t* d_kidx = nullptr;
@@ -318,7 +321,7 @@ void gpa_plan_destroy(gpa_plan* p) {
   if (p->stream) hipStreamSynchronize(p->stream);
   void* bufs[] = {p->tw0, p->tw1, p->Hx, p->Hy, p->Tbuf, p->tb.cxb, p->tb.sx, p->tb.wxw, p->tb.cy,
                   p->tb.dx, p->tb.dy, p->d_kl, p->d_kr, p->d_image, p->d_mean, p->d_scratch,
-                  p->d_lockin, p->d_kidx, p->d_dudx, p->d_dudy, p->d_wnorm, p->d_u, p->d_kmat};
+                  p->d_lockin, p->d_kidx, p->d_dudx, p->d_dudy, p->d_wnorm, p->d_u, p->d_kmat, p->d_sf, p->d_grad};
   for (void* b : bufs)
     if (b) hipFree(b);
   unwrap_workspace_destroy(&p->uw);
@@ -402,9 +405,24 @@ int gpa_sweep_dev(gpa_plan* p, const void* image, const double* kref, const doub
                   double sigma, void* lockin, int32_t* kidx, void* grad) {
   if (!p || !image || !kref || !klist || !lockin) return fail(GPA_ERR_ARG, "gpa_sweep: null argument");
   if (K < 1) return fail(GPA_ERR_ARG, "gpa_sweep: K must be >= 1");
-  if (grad) return fail(GPA_ERR_ARG, "gpa_sweep: grad output not available in this build");
   HIP_TRY(hipSetDevice(p->device));
-  return sweep_peaks_dev(p, image, nullptr, kref, 1, klist, K, sigma, lockin, kidx);
+  if (!grad) return sweep_peaks_dev(p, image, nullptr, kref, 1, klist, K, sigma, lockin, kidx);
+  // a4: every candidate's lock-in is needed around the winner, so all K go to HBM once
+  if (K > p->max_batch) return fail(GPA_ERR_STATE, "gpa_sweep: K exceeds the plan's max_batch");
+  const size_t npx = (size_t)p->n0 * p->n1, need = (size_t)K * npx * p->csz;
+  if (p->sf_bytes < need) {
+    if (p->d_sf) { HIP_TRY(hipStreamSynchronize(p->stream)); HIP_TRY(hipFree(p->d_sf)); p->ws_bytes -= p->sf_bytes; p->d_sf = nullptr; p->sf_bytes = 0; }
+    TRY(dmalloc(p, &p->d_sf, need));
+    p->sf_bytes = need;
+  }
+  TRY(ensure_filters(p, sigma));
+  std::vector<double> kr((size_t)K * 2);
+  for (int k = 0; k < K; ++k) { kr[2 * k] = kref[0]; kr[2 * k + 1] = kref[1]; }
+  TRY(stage_kvectors(p, klist, kr.data(), K));
+  HIP_TRY(launch_passA(p->dtype, p->ax0, p->n1, image, nullptr, p->tb, p->Hx, p->tw0, p->Tbuf, K, p->stream));
+  HIP_TRY(launch_passB(p->dtype, p->ax1, p->n0, p->Tbuf, p->Hy, p->tw1, p->tb, K, 1, false, p->d_sf, nullptr, p->stream));
+  HIP_TRY(launch_gradselect(p->dtype, p->d_sf, K, p->n0, p->n1, p->d_kl, p->d_kr, p->tb, lockin, kidx, grad, p->stream));
+  return GPA_OK;
 }
 
 int gpa_sweep(gpa_plan* p, const void* image, const double* kref, const double* klist, int K, double sigma,
@@ -413,7 +431,9 @@ int gpa_sweep(gpa_plan* p, const void* image, const double* kref, const double* 
   HIP_TRY(hipSetDevice(p->device));
   const size_t npx = (size_t)p->n0 * p->n1;
   HIP_TRY(hipMemcpyAsync(p->d_image, image, npx * p->rsz, hipMemcpyHostToDevice, p->stream));
-  TRY(gpa_sweep_dev(p, p->d_image, kref, klist, K, sigma, p->d_lockin, p->d_kidx, grad));
+  if (grad && !p->d_grad) TRY(dmalloc(p, &p->d_grad, 2 * npx * p->rsz));
+  TRY(gpa_sweep_dev(p, p->d_image, kref, klist, K, sigma, p->d_lockin, p->d_kidx, grad ? p->d_grad : nullptr));
+  if (grad) HIP_TRY(hipMemcpyAsync(grad, p->d_grad, 2 * npx * p->rsz, hipMemcpyDeviceToHost, p->stream));
   HIP_TRY(hipMemcpyAsync(lockin, p->d_lockin, npx * p->csz, hipMemcpyDeviceToHost, p->stream));
   if (kidx) HIP_TRY(hipMemcpyAsync(kidx, p->d_kidx, npx * sizeof(int32_t), hipMemcpyDeviceToHost, p->stream));
   HIP_TRY(hipStreamSynchronize(p->stream));

@@ -266,87 +266,91 @@ struct WgFFT {
     }
   }
 
-  template <int p>
+  // LS = element stride of this transform's LDS image: LS transforms of neighbouring
+  // lanes are interleaved element by element (address = LS * padded index + lane slot),
+  // which keeps every lane group on distinct banks when LS columns sit side by side
+  // in the thread index.
+  template <int p, int LS = 1>
   GPA_HD static void lds_write(const cpx<T> (&x)[E], cpx<T>* lds, int tid) {
     constexpr int r = 1 << bits(p), g = E / r;
 #pragma unroll
     for (int q = 0; q < g; ++q) {
-      cpx<T>* base = lds + addr_base<p>(tid + TPF * q);
+      cpx<T>* base = lds + LS * addr_base<p>(tid + TPF * q);
 #pragma unroll
-      for (int e = 0; e < r; ++e) base[addr_offs<p>(e)] = x[q + g * e];
+      for (int e = 0; e < r; ++e) base[LS * addr_offs<p>(e)] = x[q + g * e];
     }
   }
-  template <int p>
+  template <int p, int LS = 1>
   GPA_HD static void lds_read(cpx<T> (&x)[E], const cpx<T>* lds, int tid) {
     constexpr int r = 1 << bits(p), g = E / r;
 #pragma unroll
     for (int q = 0; q < g; ++q) {
-      const cpx<T>* base = lds + addr_base<p>(tid + TPF * q);
+      const cpx<T>* base = lds + LS * addr_base<p>(tid + TPF * q);
 #pragma unroll
-      for (int e = 0; e < r; ++e) x[q + g * e] = base[addr_offs<p>(e)];
+      for (int e = 0; e < r; ++e) x[q + g * e] = base[LS * addr_offs<p>(e)];
     }
   }
 
   // ---- phases (the code between two workgroup barriers) -------------------
   // forward: phase 0 .. P-1, barrier after every phase but the last
-  template <int ph>
+  template <int ph, int LS = 1>
   GPA_HD static void fwd_phase(cpx<T> (&x)[E], cpx<T>* lds, int tid, const Twiddles& tw) {
-    if constexpr (ph > 0) lds_read<ph>(x, lds, tid);
+    if constexpr (ph > 0) lds_read<ph, LS>(x, lds, tid);
     butterflies<ph, false>(x, tw);
-    if constexpr (ph < P - 1) lds_write<ph>(x, lds, tid);
+    if constexpr (ph < P - 1) lds_write<ph, LS>(x, lds, tid);
   }
   // inverse: phase 0 handles pass P-1, phase P-1 handles pass 0
-  template <int ph>
+  template <int ph, int LS = 1>
   GPA_HD static void inv_phase(cpx<T> (&x)[E], cpx<T>* lds, int tid, const Twiddles& tw) {
     constexpr int p = P - 1 - ph;
-    if constexpr (ph > 0) lds_read<p>(x, lds, tid);
+    if constexpr (ph > 0) lds_read<p, LS>(x, lds, tid);
     butterflies<p, true>(x, tw);
-    if constexpr (p > 0) lds_write<p>(x, lds, tid);
+    if constexpr (p > 0) lds_write<p, LS>(x, lds, tid);
   }
 
 #if defined(__HIPCC__)
   // whole transforms with workgroup barriers (every thread of the workgroup must call).
   // NT independent transforms per thread share each barrier: x[n] uses lds + n * lds_stride.
-  template <int NT>
+  template <int NT, int LS = 1>
   __device__ __forceinline__ static void forward_multi(cpx<T> (&x)[NT][E], cpx<T>* lds, int lds_stride, int tid,
                                                        const Twiddles& tw) {
 #pragma unroll
-    for (int n = 0; n < NT; ++n) { fwd_phase<0>(x[n], lds + n * lds_stride, tid, tw); if (NT > 1) __builtin_amdgcn_sched_barrier(0); }
+    for (int n = 0; n < NT; ++n) { fwd_phase<0, LS>(x[n], lds + n * lds_stride, tid, tw); if (NT > 1) __builtin_amdgcn_sched_barrier(0); }
     if constexpr (P > 1) {
       __syncthreads();
 #pragma unroll
-      for (int n = 0; n < NT; ++n) { fwd_phase<1>(x[n], lds + n * lds_stride, tid, tw); if (NT > 1) __builtin_amdgcn_sched_barrier(0); }
+      for (int n = 0; n < NT; ++n) { fwd_phase<1, LS>(x[n], lds + n * lds_stride, tid, tw); if (NT > 1) __builtin_amdgcn_sched_barrier(0); }
     }
     if constexpr (P > 2) {
       __syncthreads();
 #pragma unroll
-      for (int n = 0; n < NT; ++n) { fwd_phase<2>(x[n], lds + n * lds_stride, tid, tw); if (NT > 1) __builtin_amdgcn_sched_barrier(0); }
+      for (int n = 0; n < NT; ++n) { fwd_phase<2, LS>(x[n], lds + n * lds_stride, tid, tw); if (NT > 1) __builtin_amdgcn_sched_barrier(0); }
     }
     if constexpr (P > 3) {
       __syncthreads();
 #pragma unroll
-      for (int n = 0; n < NT; ++n) { fwd_phase<3>(x[n], lds + n * lds_stride, tid, tw); if (NT > 1) __builtin_amdgcn_sched_barrier(0); }
+      for (int n = 0; n < NT; ++n) { fwd_phase<3, LS>(x[n], lds + n * lds_stride, tid, tw); if (NT > 1) __builtin_amdgcn_sched_barrier(0); }
     }
   }
-  template <int NT>
+  template <int NT, int LS = 1>
   __device__ __forceinline__ static void inverse_multi(cpx<T> (&x)[NT][E], cpx<T>* lds, int lds_stride, int tid,
                                                        const Twiddles& tw) {
 #pragma unroll
-    for (int n = 0; n < NT; ++n) { inv_phase<0>(x[n], lds + n * lds_stride, tid, tw); if (NT > 1) __builtin_amdgcn_sched_barrier(0); }
+    for (int n = 0; n < NT; ++n) { inv_phase<0, LS>(x[n], lds + n * lds_stride, tid, tw); if (NT > 1) __builtin_amdgcn_sched_barrier(0); }
     if constexpr (P > 1) {
       __syncthreads();
 #pragma unroll
-      for (int n = 0; n < NT; ++n) { inv_phase<1>(x[n], lds + n * lds_stride, tid, tw); if (NT > 1) __builtin_amdgcn_sched_barrier(0); }
+      for (int n = 0; n < NT; ++n) { inv_phase<1, LS>(x[n], lds + n * lds_stride, tid, tw); if (NT > 1) __builtin_amdgcn_sched_barrier(0); }
     }
     if constexpr (P > 2) {
       __syncthreads();
 #pragma unroll
-      for (int n = 0; n < NT; ++n) { inv_phase<2>(x[n], lds + n * lds_stride, tid, tw); if (NT > 1) __builtin_amdgcn_sched_barrier(0); }
+      for (int n = 0; n < NT; ++n) { inv_phase<2, LS>(x[n], lds + n * lds_stride, tid, tw); if (NT > 1) __builtin_amdgcn_sched_barrier(0); }
     }
     if constexpr (P > 3) {
       __syncthreads();
 #pragma unroll
-      for (int n = 0; n < NT; ++n) { inv_phase<3>(x[n], lds + n * lds_stride, tid, tw); if (NT > 1) __builtin_amdgcn_sched_barrier(0); }
+      for (int n = 0; n < NT; ++n) { inv_phase<3, LS>(x[n], lds + n * lds_stride, tid, tw); if (NT > 1) __builtin_amdgcn_sched_barrier(0); }
     }
   }
   __device__ __forceinline__ static void forward(cpx<T> (&x)[E], cpx<T>* lds, int tid, const Twiddles& tw) {

@@ -56,6 +56,10 @@ hipError_t launch_passA(int dtype, const Axis& a0, int n1, const void* image, co
 hipError_t launch_passB(int dtype, const Axis& a1, int n0, const void* Tbuf, const void* Hy,
                         const void* tw1, const SweepTables& tb, int P, int K, bool select,
                         void* out, int32_t* kidx, hipStream_t s);
+// a4: per-pixel best-of-K select over stored lock-ins sf[K][n0][n1] + phase gradient of the winner
+hipError_t launch_gradselect(int dtype, const void* sf, int K, int n0, int n1, const double* kl,
+                             const double* kr, const SweepTables& tb, void* lockin, int32_t* kidx,
+                             void* grad, hipStream_t s);
 int passA_cols(int dtype, int lg);
 // frequency bin held by (thread, register) after the forward transform of length 2^lg
 int spec_index_rt(int lg, int tid, int reg);

@@ -125,11 +125,11 @@ struct PassAGeom {
   // and leave 256 VGPRs per lane (8 waves per CU) instead of forcing 128 on 16 waves
   static constexpr int NT = (sizeof(T) == 4 && C >= 2) ? 2 : 1;
   static constexpr int CT = C / NT;   // columns side by side in the thread index
-  // LDS elements between the regions of neighbouring columns; the +32/CT rotates
-  // the bank phase so the CT columns a 32-lane group touches never collide
-  static constexpr int RS = F::LDS_ELEMS + ((32 / CT) - F::LDS_ELEMS % 32 + 32) % 32;
+  // LDS: one region per transform-of-a-thread (n), inside which the CT columns that sit
+  // side by side in the thread index are interleaved element by element
+  static constexpr int REGION = CT * F::LDS_ELEMS;
   static constexpr int THREADS = CT * F::TPF;
-  static constexpr size_t LDS_BYTES = (size_t)C * RS * sizeof(cpx<T>);
+  static constexpr size_t LDS_BYTES = (size_t)NT * REGION * sizeof(cpx<T>);
   static constexpr bool FITS = (size_t)(F::LDS_ELEMS + 32) * sizeof(cpx<T>) <= 160 * 1024;
 };
 
@@ -164,18 +164,23 @@ __global__ __launch_bounds__((PassAGeom<T, LG>::THREADS)) void passA_kernel(
   constexpr int CT = G::CT, NT = G::NT, TPF = F::TPF, L = F::L;
   extern __shared__ __attribute__((aligned(16))) char smem[];
   // thread -> (column slot c, transform thread t); transform n of the thread handles
-  // column  tile*C + n*CT + c,  LDS region n*CT + c
+  // column  tile*C + c*NT + n  (a thread's columns are adjacent: one 16-byte store per row)
   const int c = threadIdx.x % CT, t = threadIdx.x / CT;
-  cpx<T>* lds = reinterpret_cast<cpx<T>*>(smem) + c * G::RS;
-  constexpr int LDS_NSTRIDE = CT * G::RS;
-  const int y0 = blockIdx.x * G::C + c;
+  cpx<T>* lds = reinterpret_cast<cpx<T>*>(smem) + c;
+  constexpr int LDS_NSTRIDE = G::REGION;
+  // XCD-aware tile order: workgroups b, b+8, b+16, ... share an XCD (round-robin
+  // dispatch), so give each XCD a contiguous run of column tiles -- the tiles that
+  // share a 128-byte line of the output then meet in one L2 and leave it as whole lines.
+  int tile = blockIdx.x;
+  if ((gridDim.x & 7) == 0) tile = (blockIdx.x & 7) * (gridDim.x >> 3) + (blockIdx.x >> 3);
+  const int y0 = tile * G::C + c * NT;
   const T m = mean ? *mean : T(0);
 
   T val[NT][16];
   unsigned wrapmask = 0;
 #pragma unroll
   for (int n = 0; n < NT; ++n) {
-    const int y = y0 + n * CT;
+    const int y = y0 + n;
 #pragma unroll
     for (int i = 0; i < 16; ++i) {
       const int slot = t + TPF * i;
@@ -199,7 +204,7 @@ __global__ __launch_bounds__((PassAGeom<T, LG>::THREADS)) void passA_kernel(
 #pragma unroll
       for (int n = 0; n < NT; ++n) x[n][i] = {val[n][i] * ph.x, val[n][i] * ph.y};
     }
-    F::template forward_multi<NT>(x, lds, LDS_NSTRIDE, t, tw);
+    F::template forward_multi<NT, CT>(x, lds, LDS_NSTRIDE, t, tw);
     {
       // keep the filter table out of the registers across the lock-in loop: it is
       // re-read from L1/L2 every iteration (the asm makes the pointer opaque to LICM)
@@ -212,16 +217,36 @@ __global__ __launch_bounds__((PassAGeom<T, LG>::THREADS)) void passA_kernel(
         for (int n = 0; n < NT; ++n) x[n][i] = hmul(x[n][i], h);
       }
     }
-    F::template inverse_multi<NT>(x, lds, LDS_NSTRIDE, t, tw);
-#pragma unroll
-    for (int n = 0; n < NT; ++n) {
-      const int y = y0 + n * CT;
-      if (y < n1) {
-        const cpx<T> cyv = cy[(size_t)b * n1 + y];
+    F::template inverse_multi<NT, CT>(x, lds, LDS_NSTRIDE, t, tw);
+    bool paired = false;
+    if constexpr (NT == 2) {
+      // two adjacent columns of one row go out as a single 2-complex (16 B for f32) store
+      // when the row pitch keeps that store naturally aligned
+      if (y0 + 1 < n1 && (n1 & 1) == 0) {
+        paired = true;
+        const cpx<T> cy0 = cy[(size_t)b * n1 + y0], cy1 = cy[(size_t)b * n1 + y0 + 1];
 #pragma unroll
         for (int i = 0; i < 16; ++i) {
           const int slot = t + TPF * i;
-          if (!PADDED || slot < n0) Tout[((size_t)b * n0 + slot) * n1 + y] = cmul(x[n][i], cyv);
+          if (!PADDED || slot < n0) {
+            struct alignas(2 * sizeof(cpx<T>)) Pair { cpx<T> a, b; };
+            Pair pr = {cmul(x[0][i], cy0), cmul(x[1][i], cy1)};
+            *reinterpret_cast<Pair*>(&Tout[((size_t)b * n0 + slot) * n1 + y0]) = pr;
+          }
+        }
+      }
+    }
+    if (!paired) {
+#pragma unroll
+      for (int n = 0; n < NT; ++n) {
+        const int y = y0 + n;
+        if (y < n1) {
+          const cpx<T> cyv = cy[(size_t)b * n1 + y];
+#pragma unroll
+          for (int i = 0; i < 16; ++i) {
+            const int slot = t + TPF * i;
+            if (!PADDED || slot < n0) Tout[((size_t)b * n0 + slot) * n1 + y] = cmul(x[n][i], cyv);
+          }
         }
       }
     }
@@ -309,6 +334,67 @@ __global__ __launch_bounds__((PassBGeom<T, LG>::THREADS)) void passB_kernel(
       }
     }
   }
+}
+
+// ---------------------------------------------------------------------------
+// a4: select + phase-gradient of the winning candidate (wfr2_grad_opt,
+// geometric_phase_analysis.py:803-812).  Input: all K lock-ins of one peak, sf[k][x][y].
+// grad = np.gradient(-angle(sf_winner)) (central differences, one-sided at the borders)
+//        + 2 pi (w - kref), finally wrapToPi(2 g) / 2.
+// ---------------------------------------------------------------------------
+template <class T>
+__device__ __forceinline__ T neg_angle(cpx<T> v) { return -atan2(v.y, v.x); }
+
+template <class T>
+__global__ __launch_bounds__(256) void gradselect_kernel(const cpx<T>* __restrict__ sf, int K, int n0, int n1,
+                                                        const double* __restrict__ kl, const double* __restrict__ kr,
+                                                        const cpx<T>* __restrict__ dx, const cpx<T>* __restrict__ dy,
+                                                        cpx<T>* __restrict__ lockin, int32_t* __restrict__ kidx,
+                                                        T* __restrict__ grad) {
+  const int y = blockIdx.x * 256 + threadIdx.x, x = blockIdx.y;
+  if (y >= n1) return;
+  const size_t npx = (size_t)n0 * n1, o = (size_t)x * n1 + y;
+  T ba = T(0);
+  int bi = -1;
+  for (int k = 0; k < K; ++k) {
+    const cpx<T> v = sf[k * npx + o];
+    const T a = v.x * v.x + v.y * v.y;
+    if (a > ba) { ba = a; bi = k; }
+  }
+  cpx<T> out = {T(0), T(0)};
+  T g0 = T(0), g1 = T(0);
+  if (bi >= 0) {
+    const cpx<T>* pl = sf + bi * npx;
+    out = cmul(pl[o], cmul(dx[(size_t)bi * n0 + x], dy[(size_t)bi * n1 + y]));
+    const T c = neg_angle(pl[o]);
+    const T xm = x > 0 ? neg_angle(pl[o - n1]) : c, xp = x + 1 < n0 ? neg_angle(pl[o + n1]) : c;
+    const T ym = y > 0 ? neg_angle(pl[o - 1]) : c, yp = y + 1 < n1 ? neg_angle(pl[o + 1]) : c;
+    g0 = (x > 0 && x + 1 < n0) ? T(0.5) * (xp - xm) : (xp - xm);
+    g1 = (y > 0 && y + 1 < n1) ? T(0.5) * (yp - ym) : (yp - ym);
+    const T two_pi = T(6.28318530717958647692), pi = T(3.14159265358979323846);
+    g0 += (T)(6.28318530717958647692 * (kl[2 * bi] - kr[2 * bi]));
+    g1 += (T)(6.28318530717958647692 * (kl[2 * bi + 1] - kr[2 * bi + 1]));
+    // wrapToPi(2 g) / 2 with the floored modulo of mathtools.py:72-75
+    T t0 = T(2) * g0 + pi, t1 = T(2) * g1 + pi;
+    g0 = T(0.5) * (t0 - two_pi * floor(t0 / two_pi) - pi);
+    g1 = T(0.5) * (t1 - two_pi * floor(t1 / two_pi) - pi);
+  }
+  lockin[o] = out;
+  if (kidx) kidx[o] = bi;
+  grad[2 * o] = g0;
+  grad[2 * o + 1] = g1;
+}
+
+hipError_t launch_gradselect(int dtype, const void* sf, int K, int n0, int n1, const double* kl, const double* kr,
+                             const SweepTables& tb, void* lockin, int32_t* kidx, void* grad, hipStream_t s) {
+  dim3 grid((n1 + 255) / 256, n0);
+  if (dtype == 0)
+    gradselect_kernel<float><<<grid, 256, 0, s>>>((const cpx<float>*)sf, K, n0, n1, kl, kr, (const cpx<float>*)tb.dx,
+                                                  (const cpx<float>*)tb.dy, (cpx<float>*)lockin, kidx, (float*)grad);
+  else
+    gradselect_kernel<double><<<grid, 256, 0, s>>>((const cpx<double>*)sf, K, n0, n1, kl, kr, (const cpx<double>*)tb.dx,
+                                                   (const cpx<double>*)tb.dy, (cpx<double>*)lockin, kidx, (double*)grad);
+  return hipGetLastError();
 }
 
 // ---------------------------------------------------------------------------

@@ -1,0 +1,81 @@
+"""The reference's own hot-path tests, restated against the drop-in modules
+(pygpa_amd.geometric_phase_analysis / cuGPA / phase_unwrap).  GPU only."""
+import numpy as np
+import pytest
+
+import pygpa_amd.cuGPA as cuGPA
+import pygpa_amd.geometric_phase_analysis as GPA
+import pygpa_amd.phase_unwrap as pu
+from pygpa_amd.synthetic import hex_kvecs, gaussian_bump_displacement, hex_moire
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope='module')
+def testset():
+    shape = (512, 512)
+    ks = hex_kvecs(0.1, 7.0)
+    u = gaussian_bump_displacement(shape)
+    original = hex_moire(shape, ks)
+    deformed = hex_moire(shape, ks, u)
+    noise = hex_moire(shape, ks, None, noise=1.0, seed=0) - original
+    return original, deformed, noise, ks, u
+
+
+def test_displacement_field(testset):
+    """reference tests/test_geometric_phase_analysis.py:61-66 and tests/test_cuGPA.py:46-52"""
+    original, deformed, noise, ks, u_true = testset
+    for kw in (dict(), dict(wfr_func=GPA.wfr2_grad_opt)):
+        u = -GPA.extract_displacement_field(deformed + noise, ks, **kw)
+        assert u.shape == u_true.shape
+        assert np.all(np.abs(u - u_true)[:, 20:-20, 20:-20] < 0.9)
+    u32 = -GPA.extract_displacement_field(deformed + noise, ks, dtype=np.float32)
+    assert np.all(np.abs(u32 - u_true)[:, 20:-20, 20:-20] < 0.9)
+
+
+def test_wfr2_variants_lockin(testset):
+    """reference tests/test_geometric_phase_analysis.py:82-97 and tests/test_cuGPA.py:68-82"""
+    original, deformed, noise, ks, _ = testset
+    kw = np.linalg.norm(ks, axis=1).mean() / 2.5
+    sigma = int(np.ceil(1 / np.linalg.norm(ks, axis=1).min()))
+    kstep = kw / 3
+    img0 = deformed - deformed.mean()
+    for f1, f2 in [(GPA.optwfr2, GPA.wfr2), (GPA.optwfr2, cuGPA.wfr2_grad_opt), (GPA.wfr2_grad_opt, cuGPA.wfr2_grad_opt)]:
+        for pk in ks:
+            g1 = f1(img0, sigma, pk[0], pk[1], kw=kw, kstep=kstep)
+            g2 = f2(img0, sigma, pk[0], pk[1], kw=kw, kstep=kstep)
+            assert np.allclose(g1['lockin'], g2['lockin'])
+    g = cuGPA.wfr2_only_lockin(img0, sigma, ks[0], kw, kstep)
+    assert np.allclose(g, GPA.optwfr2(img0, sigma, ks[0][0], ks[0][1], kw, kstep)['lockin'])
+    gs = cuGPA.wfr2_grad_single(img0, sigma, ks[0][0], ks[0][1], kw, kstep)
+    assert 'w' not in gs and gs['lockin'].dtype == np.complex64
+
+
+@pytest.mark.parametrize('kmax', [1, 7, 30])
+def test_equivalent_phase_unwrap_variants(kmax):
+    """reference tests/test_phase_unwrap.py:11-31, :49-75 (N = 256 linear ramp)"""
+    N = 256
+    xx, yy = np.meshgrid(np.arange(N), np.arange(N), indexing='ij')
+    psi0 = (yy + xx) / (4 * np.sqrt(2))
+    psi = pu._wrapToPi(psi0)
+    weight = np.ones_like(psi)
+    res = pu.phase_unwrap_ref(psi=psi, weight=weight, kmax=kmax)
+    assert np.allclose(res - res.mean(), psi0 - psi0.mean())
+    assert np.allclose(res, pu.phase_unwrap(psi=psi, weight=weight, kmax=kmax))
+    assert np.allclose(res, pu.phase_unwrap(psi=psi, weight=None, kmax=kmax))
+    dx = np.diff(psi, axis=1)
+    dy = np.diff(psi, axis=0)
+    res_pd = pu.phase_unwrap_ref_prediff(dx=dx, dy=dy, weight=weight, kmax=kmax)
+    assert np.allclose(res_pd - res_pd.mean(), psi0 - psi0.mean())
+    assert np.allclose(res_pd, pu.phase_unwrap_prediff(dx=dx, dy=dy, weight=None, kmax=kmax))
+    assert np.allclose(res_pd, res)
+
+
+def test_equivalent_phase_unwrap_gaussian_weight():
+    """reference tests/test_phase_unwrap.py:34-46"""
+    N = 256
+    xx, yy = np.meshgrid(np.arange(N), np.arange(N), indexing='ij')
+    psi0 = (yy + xx) / (4 * np.sqrt(2))
+    psi = pu._wrapToPi(psi0)
+    gaussian = np.exp(-((xx - N // 2) ** 2 + (yy - N // 2) ** 2) / (0.3 * N ** 2))
+    assert np.allclose(pu.phase_unwrap(psi=psi, weight=None), pu.phase_unwrap(psi=psi, weight=gaussian))

@@ -1,0 +1,222 @@
+"""GPU parity tests: the HIP path (through the C ABI) against the golden vectors made
+by the real reference and against the CPU oracle.  Run with `-m gpu` on an MI355X.
+
+Stated tolerances (relative to the largest magnitude of the compared array):
+    f64 path: 1e-11 for lock-ins / gradients, 1e-9 for PCG outputs
+    f32 path: 2e-6 for lock-ins, 2e-5 for gradients, 2e-5 for PCG outputs
+Index / mask outputs (kidx, 'w') are compared bit-exactly; a mismatch is tolerated
+only where the two candidates' amplitudes tie to rounding (kidx_mismatch_is_tie)."""
+import numpy as np
+import pytest
+
+from conftest import kidx_mismatch_is_tie
+from oracle import gpa_oracle as orc
+from pygpa_amd import _lib
+from pygpa_amd.synthetic import hex_kvecs, gaussian_bump_displacement, hex_moire, explicit_klists
+
+pytestmark = pytest.mark.gpu
+
+TOL = {
+    np.float64: dict(lock=1e-11, grad=1e-11, pcg=1e-9, tie=1e-12),
+    np.float32: dict(lock=2e-6, grad=2e-5, pcg=2e-5, tie=2e-6),
+}
+DTYPES = [np.float64, np.float32]
+FULL_CASES = ['hex_64', 'hex_48x80', 'hex_63x65']
+
+
+def rel(a, b):
+    return float(np.abs(a - b).max() / max(np.abs(b).max(), 1e-300))
+
+
+def check_kidx(kidx, ref_kidx, img0, klist, sigma, tie_tol):
+    bad = kidx != ref_kidx
+    if not bad.any():
+        return
+    amps = np.abs(orc.lockin_batch(img0, klist, sigma))
+    assert np.all(kidx_mismatch_is_tie(amps, kidx, ref_kidx, tie_tol)[bad]), \
+        '%d kidx mismatches that are not amplitude ties' % int(bad.sum())
+
+
+@pytest.mark.parametrize('dtype', DTYPES)
+@pytest.mark.parametrize('name', FULL_CASES)
+def test_a1_a2_lockin(golden, name, dtype):
+    g = golden(name)
+    img0 = g['image'] - g['image'].mean()
+    plan = _lib.Plan(img0.shape, 3, dtype)
+    out = plan.lockin_batch(img0, g['kvecs'][:2], int(g['sigma']))
+    assert out.dtype == (np.complex128 if dtype is np.float64 else np.complex64)
+    assert rel(out[0], g['a1_GPA']) < TOL[dtype]['lock']
+    assert rel(out[1], g['a1_optGPA']) < TOL[dtype]['lock']
+    if 'a2_vecGPA' in g:
+        out3 = plan.lockin_batch(img0, g['kvecs'], int(g['sigma']))
+        assert rel(out3, g['a2_vecGPA']) < TOL[dtype]['lock']
+    plan.close()
+
+
+@pytest.mark.parametrize('dtype', DTYPES)
+@pytest.mark.parametrize('name', FULL_CASES)
+def test_a3_sweep(golden, name, dtype):
+    g = golden(name)
+    img0 = g['image'] - g['image'].mean()
+    sigma = int(g['sigma'])
+    K = g['a3_klists'].shape[1]
+    plan = _lib.Plan(img0.shape, K, dtype)
+    for p in range(3):
+        lock, kidx, _ = plan.sweep(img0, g['kvecs'][p], g['a3_klists'][p], sigma)
+        check_kidx(kidx, g['a3_kidx'][p], img0, g['a3_klists'][p], sigma, TOL[dtype]['tie'])
+        same = kidx == g['a3_kidx'][p]
+        assert rel(lock[same], g['a3_lockin'][p][same]) < TOL[dtype]['lock']
+        if dtype is np.float64:
+            assert np.array_equal(kidx, g['a3_kidx'][p])          # index work: bit-exact in f64
+    plan.close()
+
+
+@pytest.mark.parametrize('dtype', DTYPES)
+@pytest.mark.parametrize('name', FULL_CASES)
+def test_a5_a6_reconstruct(golden, name, dtype):
+    g = golden(name)
+    plan = _lib.Plan(g['image'].shape, 3, dtype)
+    dudx, dudy, wn = plan.reconstruct_grad(g['a3_lockin'], g['kvecs'], 2 * int(g['sigma']))
+    assert rel(dudx, g['a6_dudx']) < TOL[dtype]['grad']
+    assert rel(dudy, g['a6_dudy']) < TOL[dtype]['grad']
+    assert rel(wn, np.linalg.norm(g['a5_weights'], axis=0)) < TOL[dtype]['lock']
+    plan.close()
+
+
+@pytest.mark.parametrize('dtype', DTYPES)
+def test_a7_unwrap_golden(golden, dtype):
+    g = golden('hex_64')
+    plan = _lib.Plan(g['image'].shape, 1, dtype)
+    wn = np.linalg.norm(g['a5_weights'], axis=0)
+    for kmax in (1, 3, 10, 100):
+        phi, it = plan.unwrap_prediff(g['a6_dudx'][0], g['a6_dudy'][0], wn, kmax=kmax)
+        assert rel(phi, g['a7_phi_w_kmax%d' % kmax]) < TOL[dtype]['pcg'], kmax
+        if dtype is np.float64:
+            assert it == min(kmax, 15)      # the reference converges in 15 iterations on this case
+    phi, it = plan.unwrap_prediff(g['a6_dudx'][0], g['a6_dudy'][0])
+    assert rel(phi, g['a7_phi_unweighted']) < TOL[dtype]['pcg']
+    w0 = g['a5_weights'][0]
+    psi, _ = plan.unwrap(g['a5_phases'][0], np.sqrt(w0 / w0.max()), kmax=10)
+    assert rel(psi, g['a7_psi_unwrap_kmax10']) < TOL[dtype]['pcg']
+    plan.close()
+
+
+@pytest.mark.parametrize('dtype', DTYPES)
+def test_reference_unwrap_ramp(golden, dtype):
+    """The reference's own unwrap test (tests/test_phase_unwrap.py) at 64^2 against its outputs."""
+    g = golden('unwrap_ramp_64')
+    plan = _lib.Plan(g['psi'].shape, 1, dtype)
+    atol = 1e-8 if dtype is np.float64 else 2e-4
+    for kmax in (1, 5, 30):
+        phi, _ = plan.unwrap(g['psi'], np.ones_like(g['psi']), kmax=kmax)
+        assert np.allclose(phi, g['ref_kmax%d' % kmax], atol=atol)
+        assert np.allclose(phi - phi.mean(), g['psi0'] - g['psi0'].mean(), atol=atol)
+        phi_u, _ = plan.unwrap(g['psi'], None, kmax=kmax)
+        assert np.allclose(phi_u, phi, atol=atol)
+    phi, _ = plan.unwrap(g['psi'], g['gaussian_weight'])
+    assert np.allclose(phi, g['ref_gaussian'], atol=10 * atol)
+    plan.close()
+
+
+@pytest.mark.parametrize('dtype', DTYPES)
+@pytest.mark.parametrize('name', ['hex_64', 'hex_128_noise'])
+def test_fused_driver_golden(golden, name, dtype):
+    g = golden(name)
+    sigma = int(g['sigma'])
+    K = g['a3_klists'].shape[1]
+    plan = _lib.Plan(g['image'].shape, 3 * K, dtype)
+    u, lock, kidx, iters = plan.extract_displacement_field(g['image'], g['kvecs'], g['a3_klists'], sigma, 2 * sigma,
+                                                            kmax=10, want_lockins=True, want_kidx=True)
+    img0 = g['image'] - g['image'].mean()
+    for p in range(3):
+        check_kidx(kidx[p], g['a3_kidx'][p], img0, g['a3_klists'][p], sigma, TOL[dtype]['tie'])
+    assert rel(u, g['u']) < TOL[dtype]['pcg']
+    if dtype is np.float64:
+        assert np.array_equal(kidx, g['a3_kidx'])
+        assert iters == (10, 10)
+    plan.close()
+
+
+@pytest.mark.parametrize('dtype', DTYPES)
+@pytest.mark.parametrize('shape', [(256, 512), (200, 300), (1024, 1024)])
+def test_sweep_vs_oracle_larger(shape, dtype):
+    kvecs = hex_kvecs(0.1, 7.0)
+    img = hex_moire(shape, kvecs, gaussian_bump_displacement(shape), noise=0.2, seed=11)
+    img0 = img - img.mean()
+    kw, sigma, _ = orc.derive_params(kvecs)
+    klist = explicit_klists(kvecs, kw, 3, 3)[1]
+    ref = orc.sweep(img0, sigma, klist, kvecs[1], workers=8)
+    plan = _lib.Plan(shape, len(klist), dtype)
+    lock, kidx, _ = plan.sweep(img0, kvecs[1], klist, sigma)
+    check_kidx(kidx, ref['kidx'], img0, klist, sigma, TOL[dtype]['tie'])
+    same = kidx == ref['kidx']
+    assert same.mean() > 0.999
+    assert rel(lock[same], ref['lockin'][same]) < TOL[dtype]['lock']
+    plan.close()
+
+
+@pytest.mark.parametrize('dtype', DTYPES)
+def test_driver_vs_oracle_512(dtype):
+    """Config-1-sized image: recovered displacement within the reference test's 0.9 px bar
+    (tests/test_geometric_phase_analysis.py:61-66) and equal to the oracle."""
+    shape = (512, 512)
+    kvecs = hex_kvecs(0.1, 7.0)
+    u_true = gaussian_bump_displacement(shape)
+    img = hex_moire(shape, kvecs, u_true, noise=0.3, seed=3)
+    u_ref, parts = orc.extract_displacement_field(img, kvecs, return_parts=True, workers=8)
+    import pygpa_amd.geometric_phase_analysis as GPA
+    u = GPA.extract_displacement_field(img, kvecs, dtype=dtype)
+    assert rel(u, u_ref) < (1e-8 if dtype is np.float64 else 5e-4)
+    assert np.all(np.abs(-u - u_true)[:, 20:-20, 20:-20] < 0.9)
+
+
+def test_full_size_properties_4096():
+    """BASELINE size (4096^2, f32): properties that need no oracle run at full size."""
+    n = 4096
+    kvecs = hex_kvecs(0.1, 7.0)
+    img = hex_moire((n, n), kvecs, gaussian_bump_displacement((n, n)), noise=0.1, seed=2, dtype=np.float32)
+    kw, sigma, _ = orc.derive_params(kvecs)
+    klists = np.stack(explicit_klists(kvecs, kw, 2, 2))
+    plan = _lib.Plan((n, n), 12, np.float32)
+    # (1) linearity of the lock-in
+    a = plan.lockin_batch(img, kvecs[:1], sigma)[0]
+    b = plan.lockin_batch(2.5 * img, kvecs[:1], sigma)[0]
+    assert rel(b, 2.5 * a) < 1e-5
+    # (2) a sweep over a single candidate equal to kref is the plain lock-in
+    lock, kidx, _ = plan.sweep(img, kvecs[0], kvecs[:1], sigma)
+    assert np.array_equal(kidx, np.zeros_like(kidx))
+    assert rel(lock, a) < 1e-6
+    # (3) one row/column block against the oracle (full 2-D oracle at 4096^2 takes seconds)
+    ref = orc.lockin(img.astype(np.float64), kvecs[0], sigma, workers=8)
+    assert rel(a, ref) < 5e-6
+    # (4) the driver is invariant to an image offset (mean subtraction, reference :919) and
+    #     reproducible run to run (deterministic reductions)
+    u1, _, k1, it1 = plan.extract_displacement_field(img, kvecs, klists, sigma, 2 * sigma, want_kidx=True)
+    u2, _, k2, it2 = plan.extract_displacement_field(img, kvecs, klists, sigma, 2 * sigma, want_kidx=True)
+    assert np.array_equal(u1, u2) and np.array_equal(k1, k2)
+    u3, _, k3, _ = plan.extract_displacement_field(img + np.float32(0.5), kvecs, klists, sigma, 2 * sigma, want_kidx=True)
+    assert (k3 != k1).mean() < 1e-4
+    assert rel(u3, u1) < 1e-2
+    assert np.isfinite(u1).all()
+    plan.close()
+
+
+@pytest.mark.parametrize('dtype', DTYPES)
+@pytest.mark.parametrize('name', FULL_CASES)
+def test_a4_grad(golden, name, dtype):
+    g = golden(name)
+    img0 = g['image'] - g['image'].mean()
+    sigma = int(g['sigma'])
+    K = g['a3_klists'].shape[1]
+    plan = _lib.Plan(img0.shape, K, dtype)
+    lock, kidx, grad = plan.sweep(img0, g['kvecs'][0], g['a3_klists'][0], sigma, want_grad=True)
+    check_kidx(kidx, g['a3_kidx'][0], img0, g['a3_klists'][0], sigma, TOL[dtype]['tie'])
+    same = kidx == g['a3_kidx'][0]
+    assert rel(lock[same], g['a3_lockin'][0][same]) < TOL[dtype]['lock']
+    # compare modulo the pi-periodic wrap of wrapToPi(2 g) / 2; the phase of a weak
+    # lock-in is ill-conditioned, so weigh the f32 comparison by the local amplitude
+    d = orc.wrap_to_pi(2 * (grad.astype(np.float64) - g['a4_grad0'])) / 2
+    amp = np.abs(g['a3_lockin'][0])
+    ok = same & (amp > 1e-3 * amp.max())
+    assert np.abs(d[ok]).max() < (1e-9 if dtype is np.float64 else 2e-3)
+    plan.close()
