@@ -115,6 +115,8 @@ struct gpa_plan {
   SweepTables tb{};
   double* d_kl = nullptr;         // [max_batch][2]
   double* d_kr = nullptr;
+  double* d_pw = nullptr;         // [max_batch] distinct wx values (x-planes)
+  int last_planes = 0;
   double* h_k = nullptr;          // pinned staging, 4 * max_batch doubles
   void* d_image = nullptr;        // staging for host-pointer entry points
   void* d_mean = nullptr;
@@ -213,12 +215,16 @@ static int plan_build(gpa_plan* p) {
   TRY(dmalloc(p, &p->tb.cxb, (size_t)B * (p->ax0.L / 16) * p->csz));
   TRY(dmalloc(p, &p->tb.sx, (size_t)B * 16 * p->csz));
   TRY(dmalloc(p, &p->tb.wxw, (size_t)B * p->csz));
-  TRY(dmalloc(p, &p->tb.cy, (size_t)B * p->n1 * p->csz));
+  TRY(dmalloc(p, &p->tb.cyb, (size_t)B * (p->ax1.L / 16) * p->csz));
+  TRY(dmalloc(p, &p->tb.sy, (size_t)B * 16 * p->csz));
+  TRY(dmalloc(p, &p->tb.wyw, (size_t)B * p->csz));
+  TRY(dmalloc(p, (void**)&p->tb.planeof, (size_t)B * sizeof(int)));
+  TRY(dmalloc(p, (void**)&p->d_pw, (size_t)B * sizeof(double)));
   TRY(dmalloc(p, &p->tb.dx, (size_t)B * p->n0 * p->csz));
   TRY(dmalloc(p, &p->tb.dy, (size_t)B * p->n1 * p->csz));
   TRY(dmalloc(p, (void**)&p->d_kl, (size_t)B * 2 * sizeof(double)));
   TRY(dmalloc(p, (void**)&p->d_kr, (size_t)B * 2 * sizeof(double)));
-  HIP_TRY(hipHostMalloc((void**)&p->h_k, (size_t)B * 4 * sizeof(double) + 64));
+  HIP_TRY(hipHostMalloc((void**)&p->h_k, (size_t)B * 6 * sizeof(double) + 64));
   TRY(dmalloc(p, &p->d_image, npx * p->rsz));
   TRY(dmalloc(p, &p->d_mean, 16));
   TRY(dmalloc(p, (void**)&p->d_scratch, 4096 * sizeof(double)));
@@ -251,16 +257,33 @@ static int ensure_filters(gpa_plan* p, double sigma) {
   return GPA_OK;
 }
 
-// copy the (candidate, reference) k-vector lists to the device and build the carrier tables
-static int stage_kvectors(gpa_plan* p, const double* kl, const double* kr_per_b, int B) {
-  memcpy(p->h_k, kl, (size_t)B * 2 * sizeof(double));
-  memcpy(p->h_k + 2 * (size_t)B, kr_per_b, (size_t)B * 2 * sizeof(double));
-  HIP_TRY(hipMemcpyAsync(p->d_kl, p->h_k, (size_t)B * 2 * sizeof(double), hipMemcpyHostToDevice, p->stream));
-  HIP_TRY(hipMemcpyAsync(p->d_kr, p->h_k + 2 * (size_t)B, (size_t)B * 2 * sizeof(double),
-                         hipMemcpyHostToDevice, p->stream));
-  HIP_TRY(launch_tables(p->dtype, p->ax0, p->ax1, p->d_kl, p->d_kr, B, p->tb, p->stream));
+// copy the (candidate, reference) k-vector lists to the device, map the candidates onto
+// x-planes (one per distinct wx, see SweepTables) and build the carrier tables.
+// Returns the number of x-planes in *planes_out.
+static int stage_kvectors(gpa_plan* p, const double* kl, const double* kr_per_b, int B, int* planes_out) {
+  double* h_kl = p->h_k;
+  double* h_kr = p->h_k + 2 * (size_t)B;
+  double* h_pw = p->h_k + 4 * (size_t)B;
+  int* h_po = reinterpret_cast<int*>(p->h_k + 5 * (size_t)B);
+  memcpy(h_kl, kl, (size_t)B * 2 * sizeof(double));
+  memcpy(h_kr, kr_per_b, (size_t)B * 2 * sizeof(double));
+  int Bx = 0;
+  for (int b = 0; b < B; ++b) {
+    int found = -1;
+    for (int q = 0; q < Bx; ++q)
+      if (memcmp(&h_pw[q], &kl[2 * b], sizeof(double)) == 0) { found = q; break; }
+    if (found < 0) { h_pw[Bx] = kl[2 * b]; found = Bx++; }
+    h_po[b] = found;
+  }
+  HIP_TRY(hipMemcpyAsync(p->d_kl, h_kl, (size_t)B * 2 * sizeof(double), hipMemcpyHostToDevice, p->stream));
+  HIP_TRY(hipMemcpyAsync(p->d_kr, h_kr, (size_t)B * 2 * sizeof(double), hipMemcpyHostToDevice, p->stream));
+  HIP_TRY(hipMemcpyAsync(p->d_pw, h_pw, (size_t)Bx * sizeof(double), hipMemcpyHostToDevice, p->stream));
+  HIP_TRY(hipMemcpyAsync(p->tb.planeof, h_po, (size_t)B * sizeof(int), hipMemcpyHostToDevice, p->stream));
+  HIP_TRY(launch_tables(p->dtype, p->ax0, p->ax1, p->d_kl, p->d_kr, B, p->d_pw, Bx, p->tb, p->stream));
   // h_k is reused by the next call: wait for the copies
   HIP_TRY(hipStreamSynchronize(p->stream));
+  p->last_planes = Bx;
+  *planes_out = Bx;
   return GPA_OK;
 }
 
@@ -319,7 +342,7 @@ void gpa_plan_destroy(gpa_plan* p) {
   if (!p) return;
   hipSetDevice(p->device);
   if (p->stream) hipStreamSynchronize(p->stream);
-  void* bufs[] = {p->tw0, p->tw1, p->Hx, p->Hy, p->Tbuf, p->tb.cxb, p->tb.sx, p->tb.wxw, p->tb.cy,
+  void* bufs[] = {p->tw0, p->tw1, p->Hx, p->Hy, p->Tbuf, p->tb.cxb, p->tb.sx, p->tb.wxw, p->tb.cyb, p->tb.sy, p->tb.wyw, p->tb.planeof, p->d_pw,
                   p->tb.dx, p->tb.dy, p->d_kl, p->d_kr, p->d_image, p->d_mean, p->d_scratch,
                   p->d_lockin, p->d_kidx, p->d_dudx, p->d_dudy, p->d_wnorm, p->d_u, p->d_kmat, p->d_sf, p->d_grad};
   for (void* b : bufs)
@@ -353,8 +376,9 @@ int gpa_lockin_batch_dev(gpa_plan* p, const void* image, const double* kvecs, in
   if (B < 1 || B > p->max_batch) return fail(GPA_ERR_STATE, "gpa_lockin_batch: B exceeds the plan's max_batch");
   HIP_TRY(hipSetDevice(p->device));
   TRY(ensure_filters(p, sigma));
-  TRY(stage_kvectors(p, kvecs, kvecs, B));
-  HIP_TRY(launch_passA(p->dtype, p->ax0, p->n1, image, nullptr, p->tb, p->Hx, p->tw0, p->Tbuf, B, p->stream));
+  int Bx = 0;
+  TRY(stage_kvectors(p, kvecs, kvecs, B, &Bx));
+  HIP_TRY(launch_passA(p->dtype, p->ax0, p->n1, image, nullptr, p->tb, p->Hx, p->tw0, p->Tbuf, Bx, p->stream));
   HIP_TRY(launch_passB(p->dtype, p->ax1, p->n0, p->Tbuf, p->Hy, p->tw1, p->tb, B, 1, false, out, nullptr,
                        p->stream));
   return GPA_OK;
@@ -391,9 +415,10 @@ static int sweep_peaks_dev(gpa_plan* p, const void* image, const void* mean, con
       kr[2 * ((size_t)pp * K + k)] = krefs[2 * pp];
       kr[2 * ((size_t)pp * K + k) + 1] = krefs[2 * pp + 1];
     }
-  TRY(stage_kvectors(p, klists, kr.data(), B));
+  int Bx = 0;
+  TRY(stage_kvectors(p, klists, kr.data(), B, &Bx));
   if (p->profiling) HIP_TRY(hipEventRecord(p->stage_ev[1], p->stream));
-  HIP_TRY(launch_passA(p->dtype, p->ax0, p->n1, image, mean, p->tb, p->Hx, p->tw0, p->Tbuf, B, p->stream));
+  HIP_TRY(launch_passA(p->dtype, p->ax0, p->n1, image, mean, p->tb, p->Hx, p->tw0, p->Tbuf, Bx, p->stream));
   if (p->profiling) HIP_TRY(hipEventRecord(p->stage_ev[2], p->stream));
   HIP_TRY(launch_passB(p->dtype, p->ax1, p->n0, p->Tbuf, p->Hy, p->tw1, p->tb, P, K, true, lockin, kidx,
                        p->stream));
@@ -418,8 +443,9 @@ int gpa_sweep_dev(gpa_plan* p, const void* image, const double* kref, const doub
   TRY(ensure_filters(p, sigma));
   std::vector<double> kr((size_t)K * 2);
   for (int k = 0; k < K; ++k) { kr[2 * k] = kref[0]; kr[2 * k + 1] = kref[1]; }
-  TRY(stage_kvectors(p, klist, kr.data(), K));
-  HIP_TRY(launch_passA(p->dtype, p->ax0, p->n1, image, nullptr, p->tb, p->Hx, p->tw0, p->Tbuf, K, p->stream));
+  int Bx = 0;
+  TRY(stage_kvectors(p, klist, kr.data(), K, &Bx));
+  HIP_TRY(launch_passA(p->dtype, p->ax0, p->n1, image, nullptr, p->tb, p->Hx, p->tw0, p->Tbuf, Bx, p->stream));
   HIP_TRY(launch_passB(p->dtype, p->ax1, p->n0, p->Tbuf, p->Hy, p->tw1, p->tb, K, 1, false, p->d_sf, nullptr, p->stream));
   HIP_TRY(launch_gradselect(p->dtype, p->d_sf, K, p->n0, p->n1, p->d_kl, p->d_kr, p->tb, lockin, kidx, grad, p->stream));
   return GPA_OK;

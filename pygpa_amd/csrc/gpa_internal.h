@@ -29,27 +29,42 @@ GPA_HD int axis_src(int m, int n, int L, bool padded) {
 }
 
 // Device tables of one batch of B lock-ins, element type cpx<T> of the plan dtype.
+// Carriers are factored as  exp(2 pi i w (t + (L/16) i)) = base[t] * stride[i]  (times a
+// wrap factor for the periodically extended slots of padded mode), so a thread needs one
+// table load plus 16 wave-uniform scalars per lock-in.
+//
+// x-planes: pass A's output depends on the candidate only through wx (cy[y] is a
+// per-column scalar that commutes with the x-axis filter).  The B candidates are
+// therefore mapped onto Bx <= B "x-planes", one per DISTINCT wx; pass A computes and
+// stores one complex plane per x-plane and pass B multiplies cy in on load.  A 4x4
+// candidate grid needs 4 planes per peak instead of 16, the reference's 7x7 grid 7
+// instead of 49.
 struct SweepTables {
-  void* cxb;   // [B][L0/16]  exp(2 pi i wx t): carrier along x at the thread's base row
-  void* sx;    // [B][16]     exp(2 pi i wx (L0/16) i): per-register stride factor
-  void* wxw;   // [B]         exp(-2 pi i wx (L0 - n0)): wrap factor (padded mode)
-  void* cy;    // [B][n1]     exp(2 pi i wy y)
+  void* cxb;   // [Bx][L0/16] exp(2 pi i wx t): carrier along x at the thread's base row
+  void* sx;    // [Bx][16]    exp(2 pi i wx (L0/16) i): per-register stride factor
+  void* wxw;   // [Bx]        exp(-2 pi i wx (L0 - n0)): wrap factor (padded mode)
+  void* cyb;   // [B][L1/16]  the same three for the y carrier of every candidate
+  void* sy;    // [B][16]
+  void* wyw;   // [B]
   void* dx;    // [B][n0]     exp(-2 pi i (wx - kx) x)   compensation to the peak centre
   void* dy;    // [B][n1]     exp(-2 pi i (wy - ky) y)
+  int* planeof;   // [B] x-plane of each candidate
 };
 
 // ---- sweep (gpa_sweep.hip) --------------------------------------------------
 // kl: device [B][2] doubles (wx, wy); kr: device [B][2] doubles (kx, ky) of the
 // peak each candidate belongs to.
+// pw: device [Bx] doubles, the distinct wx values
 hipError_t launch_tables(int dtype, const Axis& a0, const Axis& a1, const double* kl,
-                         const double* kr, int B, const SweepTables& tb, hipStream_t s);
+                         const double* kr, int B, const double* pw, int Bx, const SweepTables& tb,
+                         hipStream_t s);
 // mean_out: device scalar of the plan dtype; scratch: >= 1024 doubles
 hipError_t launch_mean(int dtype, const void* image, size_t count, double* scratch,
                        void* mean_out, hipStream_t s);
-// x-axis pass: Tbuf[b][x][y] = cy_b[y] * Cx( (image - mean) * cx_b )[x][y]
+// x-axis pass over the Bx x-planes: Tbuf[plane][x][y] = Cx( (image - mean) * cx_plane )[x][y]
 hipError_t launch_passA(int dtype, const Axis& a0, int n1, const void* image, const void* mean,
                         const SweepTables& tb, const void* Hx, const void* tw0, void* Tbuf,
-                        int B, hipStream_t s);
+                        int Bx, hipStream_t s);
 // y-axis pass.  select = true: per peak p (grid.y = P) loop over its K candidates
 // keeping the strictly-largest |sf|, write compensated lock-in (+ kidx).
 // select = false: write all B lock-ins (P = B, K = 1).

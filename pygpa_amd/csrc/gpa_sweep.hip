@@ -2,8 +2,8 @@
 //
 // A lock-in is  sf = ifft2( fft2(img * cx (x) cy) * Gx (x) Gy ).  Carrier and
 // Gaussian are both separable, so it is computed as two 1-D circular filters
-//     pass A (x axis, column tiles):  T  = cy[y] * Cx( img * cx )           (complex, to HBM)
-//     pass B (y axis, rows)        :  sf = Cy( T )  -> per-pixel best-of-K  (stays in registers)
+//     pass A (x axis, column tiles):  T  = Cx( img * cx )                   (complex, to HBM)
+//     pass B (y axis, rows)        :  sf = Cy( cy * T )  -> per-pixel best-of-K  (stays in registers)
 // each filter being  forward FFT -> table multiply -> inverse FFT  entirely in
 // registers + LDS.  HBM sees the real image once, T once each way, and the winning
 // lock-in once: 4 reals per lock-in per pixel instead of the 8 a 2-D FFT pair costs.
@@ -29,37 +29,46 @@ __device__ __forceinline__ cpx<T> unit_phasor(double cycles) {
 
 template <class T>
 __global__ void tables_kernel(const double* __restrict__ kl, const double* __restrict__ kr,
-                              int n0, int n1, int L0, cpx<T>* cxb, cpx<T>* sx, cpx<T>* wxw,
-                              cpx<T>* cy, cpx<T>* dx, cpx<T>* dy) {
+                              const double* __restrict__ pw, int B, int Bx, int n0, int n1, int L0, int L1,
+                              cpx<T>* cxb, cpx<T>* sx, cpx<T>* wxw, cpx<T>* cyb, cpx<T>* sy, cpx<T>* wyw,
+                              cpx<T>* dx, cpx<T>* dy) {
   const int b = blockIdx.y;
   const int j = blockIdx.x * blockDim.x + threadIdx.x;
-  const double wx = kl[2 * b], wy = kl[2 * b + 1], kx = kr[2 * b], ky = kr[2 * b + 1];
-  const int tpf = L0 / 16;
-  if (j < tpf) cxb[(size_t)b * tpf + j] = unit_phasor<T>(wx * j);
-  if (j < 16) sx[b * 16 + j] = unit_phasor<T>(wx * (double)tpf * j);
-  if (j == 0) wxw[b] = unit_phasor<T>(-wx * (double)(L0 - n0));
-  if (j < n1) {
-    cy[(size_t)b * n1 + j] = unit_phasor<T>(wy * j);
-    dy[(size_t)b * n1 + j] = unit_phasor<T>(-(wy - ky) * j);
+  if (b < Bx) {   // x carrier of x-plane b
+    const double wx = pw[b];
+    const int tpf = L0 / 16;
+    if (j < tpf) cxb[(size_t)b * tpf + j] = unit_phasor<T>(wx * j);
+    if (j < 16) sx[b * 16 + j] = unit_phasor<T>(wx * (double)tpf * j);
+    if (j == 0) wxw[b] = unit_phasor<T>(-wx * (double)(L0 - n0));
   }
-  if (j < n0) dx[(size_t)b * n0 + j] = unit_phasor<T>(-(wx - kx) * j);
+  if (b < B) {    // y carrier and compensation phasors of candidate b
+    const double wx = kl[2 * b], wy = kl[2 * b + 1], kx = kr[2 * b], ky = kr[2 * b + 1];
+    const int tpf = L1 / 16;
+    if (j < tpf) cyb[(size_t)b * tpf + j] = unit_phasor<T>(wy * j);
+    if (j < 16) sy[b * 16 + j] = unit_phasor<T>(wy * (double)tpf * j);
+    if (j == 0) wyw[b] = unit_phasor<T>(-wy * (double)(L1 - n1));
+    if (j < n1) dy[(size_t)b * n1 + j] = unit_phasor<T>(-(wy - ky) * j);
+    if (j < n0) dx[(size_t)b * n0 + j] = unit_phasor<T>(-(wx - kx) * j);
+  }
 }
 
 hipError_t launch_tables(int dtype, const Axis& a0, const Axis& a1, const double* kl,
-                         const double* kr, int B, const SweepTables& tb, hipStream_t s) {
+                         const double* kr, int B, const double* pw, int Bx, const SweepTables& tb,
+                         hipStream_t s) {
   int len = a0.n > a1.n ? a0.n : a1.n;
   if (len < a0.L / 16) len = a0.L / 16;
+  if (len < a1.L / 16) len = a1.L / 16;
   if (len < 16) len = 16;
-  dim3 grid((len + 255) / 256, B);
+  dim3 grid((len + 255) / 256, B > Bx ? B : Bx);
   if (dtype == 0)
-    tables_kernel<float><<<grid, 256, 0, s>>>(kl, kr, a0.n, a1.n, a0.L, (cpx<float>*)tb.cxb,
-                                              (cpx<float>*)tb.sx, (cpx<float>*)tb.wxw,
-                                              (cpx<float>*)tb.cy, (cpx<float>*)tb.dx,
+    tables_kernel<float><<<grid, 256, 0, s>>>(kl, kr, pw, B, Bx, a0.n, a1.n, a0.L, a1.L, (cpx<float>*)tb.cxb,
+                                              (cpx<float>*)tb.sx, (cpx<float>*)tb.wxw, (cpx<float>*)tb.cyb,
+                                              (cpx<float>*)tb.sy, (cpx<float>*)tb.wyw, (cpx<float>*)tb.dx,
                                               (cpx<float>*)tb.dy);
   else
-    tables_kernel<double><<<grid, 256, 0, s>>>(kl, kr, a0.n, a1.n, a0.L, (cpx<double>*)tb.cxb,
-                                               (cpx<double>*)tb.sx, (cpx<double>*)tb.wxw,
-                                               (cpx<double>*)tb.cy, (cpx<double>*)tb.dx,
+    tables_kernel<double><<<grid, 256, 0, s>>>(kl, kr, pw, B, Bx, a0.n, a1.n, a0.L, a1.L, (cpx<double>*)tb.cxb,
+                                               (cpx<double>*)tb.sx, (cpx<double>*)tb.wxw, (cpx<double>*)tb.cyb,
+                                               (cpx<double>*)tb.sy, (cpx<double>*)tb.wyw, (cpx<double>*)tb.dx,
                                                (cpx<double>*)tb.dy);
   return hipGetLastError();
 }
@@ -157,7 +166,7 @@ template <class T, int LG, bool PADDED>
 __global__ __launch_bounds__((PassAGeom<T, LG>::THREADS)) void passA_kernel(
     const T* __restrict__ image, const T* __restrict__ mean, int n0, int n1,
     const cpx<T>* __restrict__ cxb, const cpx<T>* __restrict__ sx, const cpx<T>* __restrict__ wxw,
-    const cpx<T>* __restrict__ cy, const typename HType<PADDED, T>::type* __restrict__ H,
+    const typename HType<PADDED, T>::type* __restrict__ H,
     const cpx<T>* __restrict__ twtab, cpx<T>* __restrict__ Tout, int B, int bchunk) {
   using F = WgFFT<T, LG>;
   using G = PassAGeom<T, LG>;
@@ -224,13 +233,12 @@ __global__ __launch_bounds__((PassAGeom<T, LG>::THREADS)) void passA_kernel(
       // when the row pitch keeps that store naturally aligned
       if (y0 + 1 < n1 && (n1 & 1) == 0) {
         paired = true;
-        const cpx<T> cy0 = cy[(size_t)b * n1 + y0], cy1 = cy[(size_t)b * n1 + y0 + 1];
 #pragma unroll
         for (int i = 0; i < 16; ++i) {
           const int slot = t + TPF * i;
           if (!PADDED || slot < n0) {
             struct alignas(2 * sizeof(cpx<T>)) Pair { cpx<T> a, b; };
-            Pair pr = {cmul(x[0][i], cy0), cmul(x[1][i], cy1)};
+            Pair pr = {x[0][i], x[1][i]};
             *reinterpret_cast<Pair*>(&Tout[((size_t)b * n0 + slot) * n1 + y0]) = pr;
           }
         }
@@ -241,11 +249,10 @@ __global__ __launch_bounds__((PassAGeom<T, LG>::THREADS)) void passA_kernel(
       for (int n = 0; n < NT; ++n) {
         const int y = y0 + n;
         if (y < n1) {
-          const cpx<T> cyv = cy[(size_t)b * n1 + y];
 #pragma unroll
           for (int i = 0; i < 16; ++i) {
             const int slot = t + TPF * i;
-            if (!PADDED || slot < n0) Tout[((size_t)b * n0 + slot) * n1 + y] = cmul(x[n][i], cyv);
+            if (!PADDED || slot < n0) Tout[((size_t)b * n0 + slot) * n1 + y] = x[n][i];
           }
         }
       }
@@ -260,7 +267,8 @@ template <class T, int LG, bool PADDED, bool SELECT>
 __global__ __launch_bounds__((PassBGeom<T, LG>::THREADS)) void passB_kernel(
     const cpx<T>* __restrict__ Tin, int n0, int n1,
     const typename HType<PADDED, T>::type* __restrict__ H, const cpx<T>* __restrict__ twtab,
-    const cpx<T>* __restrict__ dx, const cpx<T>* __restrict__ dy, int K,
+    const int* __restrict__ planeof, const cpx<T>* __restrict__ cyb, const cpx<T>* __restrict__ sy,
+    const cpx<T>* __restrict__ wyw, const cpx<T>* __restrict__ dx, const cpx<T>* __restrict__ dy, int K,
     cpx<T>* __restrict__ out, int32_t* __restrict__ kidx) {
   using F = WgFFT<T, LG>;
   using G = PassBGeom<T, LG>;
@@ -283,15 +291,20 @@ __global__ __launch_bounds__((PassBGeom<T, LG>::THREADS)) void passB_kernel(
   const int nk = SELECT ? K : 1;
   for (int k = 0; k < nk; ++k) {
     const int b = SELECT ? p * K + k : p;
-    const cpx<T>* src = Tin + ((size_t)b * n0 + (valid ? row : 0)) * n1;
+    // the x-plane of this candidate (shared by every candidate with the same wx: re-reads hit L2)
+    const cpx<T>* src = Tin + ((size_t)planeof[b] * n0 + (valid ? row : 0)) * n1;
+    const cpx<T> cbase = cyb[(size_t)b * TPF + tid];
     cpx<T> x[16];
 #pragma unroll
     for (int i = 0; i < 16; ++i) {
+      cpx<T> ph = cmul(cbase, sy[b * 16 + i]);   // exp(2 pi i wy y) at y = tid + TPF*i
       if constexpr (PADDED) {
-        const int ys = axis_src(tid + TPF * i, n1, L, true);
-        x[i] = ys >= 0 ? src[ys] : cpx<T>{T(0), T(0)};
+        const int slot = tid + TPF * i;
+        const int ys = axis_src(slot, n1, L, true);
+        if (slot >= n1) ph = cmul(ph, wyw[b]);
+        x[i] = ys >= 0 ? cmul(src[ys], ph) : cpx<T>{T(0), T(0)};
       } else {
-        x[i] = src[tid + TPF * i];   // rows past the image reuse row 0; their results are dropped
+        x[i] = cmul(src[tid + TPF * i], ph);   // rows past the image reuse row 0; their results are dropped
       }
     }
     F::forward(x, lds, tid, tw);
@@ -421,7 +434,7 @@ static hipError_t run_passA(const Axis& a0, int n1, const void* image, const voi
     dim3 grid(tiles, (B + bchunk - 1) / bchunk);
     kern<<<grid, G::THREADS, G::LDS_BYTES, s>>>(
         (const T*)image, (const T*)mean, a0.n, n1, (const cpx<T>*)tb.cxb, (const cpx<T>*)tb.sx,
-        (const cpx<T>*)tb.wxw, (const cpx<T>*)tb.cy,
+        (const cpx<T>*)tb.wxw,
         (const typename HType<PADDED, T>::type*)Hx, (const cpx<T>*)tw0, (cpx<T>*)Tbuf, B, bchunk);
     return hipGetLastError();
   }
@@ -442,7 +455,8 @@ static hipError_t run_passB(const Axis& a1, int n0, const void* Tbuf, const void
     dim3 grid((n0 + G::NF - 1) / G::NF, P);
     kern<<<grid, G::THREADS, G::LDS_BYTES, s>>>(
         (const cpx<T>*)Tbuf, n0, a1.n, (const typename HType<PADDED, T>::type*)Hy,
-        (const cpx<T>*)tw1, (const cpx<T>*)tb.dx, (const cpx<T>*)tb.dy, K, (cpx<T>*)out, kidx);
+        (const cpx<T>*)tw1, tb.planeof, (const cpx<T>*)tb.cyb, (const cpx<T>*)tb.sy, (const cpx<T>*)tb.wyw,
+        (const cpx<T>*)tb.dx, (const cpx<T>*)tb.dy, K, (cpx<T>*)out, kidx);
     return hipGetLastError();
   }
 }
