@@ -28,9 +28,11 @@ struct WgDCT {
   // in : x = permuted input in the natural layout (slot m = tid + TPF*i)
   // out: x[i] = Xa[k] + i Xb[k] at k = tid + TPF*i
   // sequence: F::forward; barrier; fwd_scatter; barrier; fwd_gather
+  // LS: element stride of the LDS image (see WgFFT::lds_write)
+  template <int LS = 1>
   GPA_HD static void fwd_scatter(const cpx<T> (&x)[E], cpx<T>* lds, int tid) {
 #pragma unroll
-    for (int i = 0; i < E; ++i) lds[F::pad(F::spec_index(tid, i))] = x[i];
+    for (int i = 0; i < E; ++i) lds[LS * F::pad(F::spec_index(tid, i))] = x[i];
   }
   // wk: table w_k in natural order
   GPA_HD static void fwd_gather(cpx<T> (&x)[E], const cpx<T>* lds, int tid, const cpx<T>* __restrict__ wk) {
@@ -53,7 +55,9 @@ struct WgDCT {
   // first_b says the other-axis bin is 0 too (phase_unwrap.py:106-115).  The tables
   // hold 1 - cos = 2 sin^2(half angle), evaluated in double on the host, because
   // cos + cos - 2 cancels catastrophically in f32 near the DC corner.
-  GPA_HD static void solve_scatter(const cpx<T> (&x)[E], cpx<T>* lds, int tid) { fwd_scatter(x, lds, tid); }
+  template <int LS = 1>
+  GPA_HD static void solve_scatter(const cpx<T> (&x)[E], cpx<T>* lds, int tid) { fwd_scatter<LS>(x, lds, tid); }
+  template <int LS = 1>
   GPA_HD static void solve_combine(cpx<T> (&x)[E], const cpx<T>* lds, int tid,
                                    const cpx<T>* __restrict__ wspec, const T* __restrict__ ha,
                                    const T* __restrict__ ham, T hb_a, T hb_b, bool first_a,
@@ -61,7 +65,7 @@ struct WgDCT {
 #pragma unroll
     for (int i = 0; i < E; ++i) {
       const int k = F::spec_index(tid, i);
-      const cpx<T> zk = x[i], zm = lds[F::pad((N - k) & (N - 1))];
+      const cpx<T> zk = x[i], zm = lds[LS * F::pad((N - k) & (N - 1))];
       const cpx<T> w = wspec[i * TPF + tid];
       const T h = ha[i * TPF + tid], hm = ham[i * TPF + tid];
       // split the packed transform: Va = (Zk + conj Zm)/2, Vb = (Zk - conj Zm)/(2i)

@@ -30,7 +30,7 @@ struct Impl {
   int dtype, n0, n1, lg0, lg1;
   bool supported;
   size_t rsz;
-  void *r, *p, *q, *z;
+  void *r, *p, *p2, *q, *z;   // p / p2: double-buffered search direction
   void *tw0, *tw1;           // FFT twiddles per axis
   void *wk1;                 // w_k along axis 1, natural order
   void *wk0s;                // w_k along axis 0, spectral layout
@@ -204,6 +204,90 @@ __global__ __launch_bounds__(256) void applyq_kernel(const T* __restrict__ p, co
   if (threadIdx.x == 0) part[blockIdx.x] = tot;
 }
 
+// fused  p <- z + beta p  and  q = A^T W^2 A p  (phase_unwrap.py:332-342, :118-132).
+// p is double-buffered (pin -> pout) so a row's neighbours can be recomputed from z and
+// the OLD p while other workgroups are already writing the new one.  One workgroup per
+// image row, 4 pixels per thread (16-byte accesses); partial <p, q> per row.
+template <class T>
+struct alignas(4 * sizeof(T)) Vec4 { T v[4]; };
+
+constexpr int PQ_ROWS = 16;   // rows per workgroup band of pq_kernel
+
+template <class T>
+__global__ __launch_bounds__(256) void pq_kernel(const T* __restrict__ z, const T* __restrict__ pin,
+                                                T* __restrict__ pout, const T* __restrict__ w, int n0, int n1,
+                                                T* __restrict__ q, double* part, const double* scal,
+                                                const int* flags) {
+  if (flags[1]) return;
+  __shared__ double sh[256];
+  const bool first = flags[0] == 0;                  // first iteration: p = z (pin is uninitialised)
+  const T beta = first ? T(0) : (T)scal[4];
+  auto comb = [&](T zv, T pv) { return first ? zv : zv + beta * pv; };
+  // a workgroup owns a band of PQ_ROWS rows x 1024 columns and slides down it with the
+  // previous / current / next row in registers: every row of z, p, w is read once
+  // (plus a 2-row halo per band) instead of three times by three different workgroups.
+  const int y0 = (blockIdx.x * 256 + threadIdx.x) * 4;
+  const int x0 = blockIdx.y * PQ_ROWS;
+  const int x1 = x0 + PQ_ROWS < n0 ? x0 + PQ_ROWS : n0;
+  double pq = 0;
+  if (y0 < n1) {
+    auto load_p = [&](int x, Vec4<T>& out) {
+      const size_t o = (size_t)x * n1 + y0;
+      const Vec4<T> a = *reinterpret_cast<const Vec4<T>*>(z + o);
+      if (first) { out = a; return; }
+      const Vec4<T> b = *reinterpret_cast<const Vec4<T>*>(pin + o);
+#pragma unroll
+      for (int j = 0; j < 4; ++j) out.v[j] = a.v[j] + beta * b.v[j];
+    };
+    auto load_w = [&](int x, Vec4<T>& out) {
+      if (!w) {
+#pragma unroll
+        for (int j = 0; j < 4; ++j) out.v[j] = T(1);
+        return;
+      }
+      out = *reinterpret_cast<const Vec4<T>*>(w + (size_t)x * n1 + y0);
+#pragma unroll
+      for (int j = 0; j < 4; ++j) out.v[j] *= out.v[j];
+    };
+    const bool hasl = y0 > 0, hasr = y0 + 4 < n1;
+    Vec4<T> pu, pc, pd, wu, wc, wd;
+#pragma unroll
+    for (int j = 0; j < 4; ++j) pu.v[j] = wu.v[j] = T(0);
+    if (x0 > 0) { load_p(x0 - 1, pu); load_w(x0 - 1, wu); }
+    load_p(x0, pc);
+    load_w(x0, wc);
+    for (int x = x0; x < x1; ++x) {
+      const bool up = x > 0, dn = x + 1 < n0;
+      if (dn) { load_p(x + 1, pd); load_w(x + 1, wd); }
+      const size_t o = (size_t)x * n1 + y0;
+      const T pl = hasl ? comb(z[o - 1], pin[o - 1]) : T(0), pr = hasr ? comb(z[o + 4], pin[o + 4]) : T(0);
+      T wl = T(1), wr = T(1);
+      if (w) { if (hasl) { wl = w[o - 1]; wl *= wl; } if (hasr) { wr = w[o + 4]; wr *= wr; } }
+      Vec4<T> qv;
+#pragma unroll
+      for (int j = 0; j < 4; ++j) {
+        const T c = pc.v[j], wj = wc.v[j];
+        T acc = T(0);
+        // q = sum over the 4 edges of min(w^2, w_nb^2) * (p_nb - p)   (phase_unwrap.py:118-132)
+        if (j < 3) { const T wn = wc.v[j + 1]; acc += (wn < wj ? wn : wj) * (pc.v[j + 1] - c); }
+        else if (hasr) acc += (wr < wj ? wr : wj) * (pr - c);
+        if (j > 0) { const T wn = wc.v[j - 1]; acc += (wn < wj ? wn : wj) * (pc.v[j - 1] - c); }
+        else if (hasl) acc += (wl < wj ? wl : wj) * (pl - c);
+        if (dn) { const T wn = wd.v[j]; acc += (wn < wj ? wn : wj) * (pd.v[j] - c); }
+        if (up) { const T wn = wu.v[j]; acc += (wn < wj ? wn : wj) * (pu.v[j] - c); }
+        qv.v[j] = acc;
+        pq += (double)c * (double)acc;
+      }
+      *reinterpret_cast<Vec4<T>*>(pout + o) = pc;
+      *reinterpret_cast<Vec4<T>*>(q + o) = qv;
+      pu = pc; wu = wc;
+      pc = pd; wc = wd;
+    }
+  }
+  const double tot = block_sum(pq, sh);
+  if (threadIdx.x == 0) part[blockIdx.y * gridDim.x + blockIdx.x] = tot;
+}
+
 template <class T>
 __global__ __launch_bounds__(256) void update_kernel(const T* __restrict__ p, const T* __restrict__ q,
                                                     T* __restrict__ phi, T* __restrict__ r, size_t count,
@@ -242,10 +326,15 @@ struct ColGeom {
     while (c > 1 && (c * F::TPF > 1024 || (size_t)c * (F::LDS_ELEMS + 32) * sizeof(cpx<T>) > 160 * 1024)) c /= 2;
     return c;
   }
-  static constexpr int CC = cols();   // packed column PAIRS per workgroup
-  static constexpr int RS = F::LDS_ELEMS + ((32 / CC) - F::LDS_ELEMS % 32 + 32) % 32;
-  static constexpr int THREADS = CC * F::TPF;
-  static constexpr size_t LDS_BYTES = (size_t)CC * RS * sizeof(cpx<T>);
+  static constexpr int CC = cols();   // packed column PAIRS (complex transforms) per workgroup
+  // as in pass A of the sweep: two transforms per f32 thread (adjacent pairs = 4 real
+  // columns = one 16-byte access per row), the CT pairs that sit side by side in the
+  // thread index interleaved element by element in LDS
+  static constexpr int NT = (sizeof(T) == 4 && CC >= 2) ? 2 : 1;
+  static constexpr int CT = CC / NT;
+  static constexpr int REGION = CT * F::LDS_ELEMS;
+  static constexpr int THREADS = CT * F::TPF;
+  static constexpr size_t LDS_BYTES = (size_t)NT * REGION * sizeof(cpx<T>);
   static constexpr bool FITS = (size_t)(F::LDS_ELEMS + 32) * sizeof(cpx<T>) <= 160 * 1024;
 };
 
@@ -304,33 +393,46 @@ __global__ __launch_bounds__((ColGeom<T, LG>::THREADS)) void colsolve_kernel(T* 
   using F = WgFFT<T, LG>;
   using D = WgDCT<T, LG>;
   using G = ColGeom<T, LG>;
-  constexpr int TPF = F::TPF, N = F::L, CC = G::CC;
+  constexpr int TPF = F::TPF, N = F::L, CT = G::CT, NT = G::NT;
   extern __shared__ __attribute__((aligned(16))) char smem[];
-  const int cp = threadIdx.x % CC, t = threadIdx.x / CC;
-  cpx<T>* lds = reinterpret_cast<cpx<T>*>(smem) + cp * G::RS;
-  const int y = (blockIdx.x * CC + cp) * 2;
-  const bool valid = y + 1 < n1;
-  const int yy = valid ? y : 0;
+  const int c = threadIdx.x % CT, t = threadIdx.x / CT;
+  cpx<T>* lds = reinterpret_cast<cpx<T>*>(smem) + c;
+  // XCD-aware tile order (see passA_kernel): neighbouring column tiles meet in one L2
+  int tile = blockIdx.x;
+  if ((gridDim.x & 7) == 0) tile = (blockIdx.x & 7) * (gridDim.x >> 3) + (blockIdx.x >> 3);
+  const int y0 = (tile * G::CC + c * NT) * 2;       // first real column of this thread
+  const bool valid = y0 + 2 * NT - 1 < n1;          // n1 is a power of two >= 64: tiles are never ragged
+  const int yy = valid ? y0 : 0;
   typename F::Twiddles tw;
   F::load_twiddles(tw, twtab, t);
-  cpx<T> x[16];
+  cpx<T> x[NT][16];
+  struct alignas(NT * sizeof(cpx<T>)) Vec { cpx<T> v[NT]; };
 #pragma unroll
   for (int i = 0; i < 16; ++i) {
     const int row = makhoul_src(t + TPF * i, N);
-    x[i] = *reinterpret_cast<const cpx<T>*>(Z + (size_t)row * n1 + yy);
+    const Vec q = *reinterpret_cast<const Vec*>(Z + (size_t)row * n1 + yy);
+#pragma unroll
+    for (int n = 0; n < NT; ++n) x[n][i] = q.v[n];
   }
-  F::forward(x, lds, t, tw);
+  F::template forward_multi<NT, CT>(x, lds, G::REGION, t, tw);
   __syncthreads();
-  D::solve_scatter(x, lds, t);
+#pragma unroll
+  for (int n = 0; n < NT; ++n) D::template solve_scatter<CT>(x[n], lds + n * G::REGION, t);
   __syncthreads();
-  D::solve_combine(x, lds, t, wspec, ha, ham, hb[yy], hb[yy + 1], yy == 0, false, T(1) / T(N));
+#pragma unroll
+  for (int n = 0; n < NT; ++n)
+    D::template solve_combine<CT>(x[n], lds + n * G::REGION, t, wspec, ha, ham, hb[yy + 2 * n], hb[yy + 2 * n + 1],
+                                  yy + 2 * n == 0, false, T(1) / T(N));
   __syncthreads();
-  F::inverse(x, lds, t, tw);
+  F::template inverse_multi<NT, CT>(x, lds, G::REGION, t, tw);
   if (!valid) return;
 #pragma unroll
   for (int i = 0; i < 16; ++i) {
     const int row = makhoul_src(t + TPF * i, N);
-    *reinterpret_cast<cpx<T>*>(Z + (size_t)row * n1 + y) = x[i];
+    Vec q;
+#pragma unroll
+    for (int n = 0; n < NT; ++n) q.v[n] = x[n][i];
+    *reinterpret_cast<Vec*>(Z + (size_t)row * n1 + y0) = q;
   }
 }
 
@@ -493,7 +595,7 @@ hipError_t unwrap_workspace_create(int dtype, int n0, int n1, hipStream_t s, Unw
   size_t bytes = 0;
   const size_t npx = (size_t)n0 * n1;
   hipError_t e;
-  void** arrs[] = {&w->r, &w->p, &w->q, &w->z};
+  void** arrs[] = {&w->r, &w->p, &w->p2, &w->q, &w->z};
   for (void** a : arrs) {
     e = hipMalloc(a, npx * w->rsz);
     if (e != hipSuccess) return e;
@@ -565,7 +667,7 @@ hipError_t unwrap_workspace_create(int dtype, int n0, int n1, hipStream_t s, Unw
 void unwrap_workspace_destroy(UnwrapWorkspace* ws) {
   Impl* w = (Impl*)ws->impl;
   if (!w) return;
-  void* bufs[] = {w->r, w->p, w->q, w->z, w->tw0, w->tw1, w->wk1, w->wk0s, w->ha0[0], w->ha0[1], w->ham0[0],
+  void* bufs[] = {w->r, w->p, w->p2, w->q, w->z, w->tw0, w->tw1, w->wk1, w->wk0s, w->ha0[0], w->ha0[1], w->ham0[0],
                   w->ham0[1], w->hb1[0], w->hb1[1], w->scal, w->flags, w->part};
   for (void* b : bufs)
     if (b) hipFree(b);
@@ -580,6 +682,9 @@ static hipError_t run_pcg(Impl* w, const void* a, const void* b, const void* wei
   const size_t npx = (size_t)n0 * n1;
   const int g2 = n0, np2 = n0;   // stencil kernels: one workgroup per image row
   if (np2 > MAXPART) return hipErrorInvalidValue;
+  const dim3 gpq((n1 + 1023) / 1024, (n0 + PQ_ROWS - 1) / PQ_ROWS);
+  const int npq = gpq.x * gpq.y;
+  if (npq > MAXPART) return hipErrorInvalidValue;
   const int gl = 2048;   // grid-stride elementwise kernels
   // the residual of an f32 iteration cannot fall below a few ulps of ||r0||
   const double eps_floor = sizeof(T) == 4 ? 4e-6 : 0.0;
@@ -594,10 +699,13 @@ static hipError_t run_pcg(Impl* w, const void* a, const void* b, const void* wei
     int nrow = 0;
     if ((e = dispatch_rowidct(w, &nrow, s)) != hipSuccess) return e;
     scal_rho_kernel<<<1, 256, 0, s>>>(w->part, nrow, w->scal, w->flags);
-    pupdate_kernel<T><<<gl, 256, 0, s>>>((const T*)w->z, (T*)w->p, npx, w->scal, w->flags);
-    applyq_kernel<T><<<g2, 256, 0, s>>>((const T*)w->p, (const T*)weight, n0, n1, (T*)w->q, w->part + MAXPART, w->flags);
-    scal_alpha_kernel<<<1, 256, 0, s>>>(w->part + MAXPART, np2, w->scal, w->flags);
-    update_kernel<T><<<gl, 256, 0, s>>>((const T*)w->p, (const T*)w->q, (T*)phi, (T*)w->r, npx, w->scal,
+    // n1 is a power of two >= 64 here, so rows are 16-byte aligned multiples of 4 pixels
+    T* pin = (T*)((it & 1) ? w->p2 : w->p);
+    T* pout = (T*)((it & 1) ? w->p : w->p2);
+    pq_kernel<T><<<gpq, 256, 0, s>>>((const T*)w->z, pin, pout, (const T*)weight, n0, n1, (T*)w->q, w->part + MAXPART,
+                                     w->scal, w->flags);
+    scal_alpha_kernel<<<1, 256, 0, s>>>(w->part + MAXPART, npq, w->scal, w->flags);
+    update_kernel<T><<<gl, 256, 0, s>>>((const T*)pout, (const T*)w->q, (T*)phi, (T*)w->r, npx, w->scal,
                                         w->part + 2 * MAXPART, w->flags);
     scal_stop_kernel<<<1, 256, 0, s>>>(w->part + 2 * MAXPART, gl, w->scal, w->flags, kmax, eps);
   }

@@ -10,7 +10,7 @@ blocks = re.split(r'remark: [^\n]*Function Name: ', r.stderr)[1:]
 for b in blocks:
     name = b.split()[0]
     dn = subprocess.run(['c++filt', name], capture_output=True, text=True).stdout.strip()
-    short = re.sub(r'\(.*', '', dn).replace('void gpa::', '').replace('(anonymous namespace)::', '')
+    short = re.sub(r'\(.*', '', dn.replace('(anonymous namespace)::', '')).replace('void gpa::', '')
     if not re.search(pat, short):
         continue
     g = lambda k: (re.search(k + r': (\d+)', b) or [0, -1])[1]
