@@ -17,7 +17,8 @@
 namespace gpa {
 
 // slot of the permuted sequence -> index in the original sequence
-GPA_HD int makhoul_src(int m, int N) { return m < N / 2 ? 2 * m : 2 * (N - 1 - m) + 1; }
+// (valid for odd N too: the first ceil(N/2) slots take the even samples)
+GPA_HD int makhoul_src(int m, int N) { return m < (N + 1) / 2 ? 2 * m : 2 * (N - 1 - m) + 1; }
 
 template <class T, int LG>
 struct WgDCT {
@@ -111,6 +112,45 @@ struct WgDCT {
 #pragma unroll
     for (int i = 0; i < E; ++i) x[i] = lds[F::pad(tid + TPF * i)];
   }
+};
+
+
+// ---------------------------------------------------------------------------
+// DFT of ARBITRARY length n on the power-of-two workgroup FFT (Bluestein / chirp-z):
+//   X[k] = conj(c_k) * sum_m (x[m] conj(c_m)) c_{k-m},   c_m = exp(i pi m^2 / n)
+// i.e. chirp multiply -> circular convolution of length L >= 2n-1 -> chirp multiply.
+// The convolution is forward FFT -> table multiply -> inverse FFT, exactly the shape of
+// the lock-in filters, so it never leaves registers + LDS.  Tables (built in double on
+// the host): chirp[m] = c_m (m < n), bspec = FFT_L(b)/L in the spectral layout with
+// b[m] = b[L-m] = c_m.
+// ---------------------------------------------------------------------------
+template <class T, int LG>
+struct WgBluestein {
+  using F = WgFFT<T, LG>;
+  static constexpr int L = F::L, TPF = F::TPF, E = 16;
+
+#if defined(__HIPCC__)
+  // in : x[i] = sample at slot tid + TPF*i (must be 0 for slots >= n), natural layout
+  // out: x[i] = X[k] at k = slot (< n); garbage for slots >= n
+  // every thread of the workgroup must call (contains barriers)
+  __device__ __forceinline__ static void dft(cpx<T> (&x)[E], cpx<T>* lds, int tid, int n,
+                                             const cpx<T>* __restrict__ chirp, const cpx<T>* __restrict__ bspec,
+                                             const typename F::Twiddles& tw) {
+    cpx<T> ch[E];
+#pragma unroll
+    for (int i = 0; i < E; ++i) {
+      const int slot = tid + TPF * i;
+      ch[i] = slot < n ? chirp[slot] : cpx<T>{T(0), T(0)};
+      x[i] = cmulc(x[i], ch[i]);
+    }
+    F::forward(x, lds, tid, tw);
+#pragma unroll
+    for (int i = 0; i < E; ++i) x[i] = cmul(x[i], bspec[i * TPF + tid]);
+    F::inverse(x, lds, tid, tw);
+#pragma unroll
+    for (int i = 0; i < E; ++i) x[i] = cmulc(x[i], ch[i]);
+  }
+#endif
 };
 
 }  // namespace gpa

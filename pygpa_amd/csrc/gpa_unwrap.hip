@@ -39,6 +39,14 @@ struct Impl {
   double* scal;              // 8 doubles
   int* flags;                // [0] = iteration count, [1] = done
   double* part;              // 3 * MAXPART partial sums
+  // generic sizes (any n0, n1 >= 2): DCTs through Bluestein DFTs of length n on FFTs of length Lb
+  bool generic;
+  int lgb0, lgb1;            // log2 of the Bluestein FFT lengths
+  void *btw0, *btw1;         // twiddles of those FFTs
+  void *chirp0, *chirp1;     // c_m = exp(i pi m^2 / n)
+  void *bspec0, *bspec1;     // FFT_L(b)/L, spectral layout
+  void *gwk0, *gwk1;         // w_k = exp(-i pi k / (2n)), natural order
+  void *gha0[2], *gham0[2];  // 1 - cos term of axis-0 bins k and n0-k, natural order; [compat]
 };
 
 template <class T> struct C2 { static constexpr T pi = T(3.14159265358979323846), two_pi = T(6.28318530717958647692); };
@@ -318,12 +326,19 @@ struct RowGeom {
   static constexpr size_t LDS_BYTES = (size_t)NF * RS * sizeof(cpx<T>);
   static constexpr bool FITS = LDS_BYTES <= 160 * 1024;
 };
+#ifndef GPA_COL_LDS_BUDGET
+#define GPA_COL_LDS_BUDGET (80 * 1024)
+#endif
+constexpr size_t COL_LDS_BUDGET = GPA_COL_LDS_BUDGET;
+
 template <class T, int LG>
 struct ColGeom {
   using F = WgFFT<T, LG>;
   static constexpr int cols() {
     int c = 16;
-    while (c > 1 && (c * F::TPF > 1024 || (size_t)c * (F::LDS_ELEMS + 32) * sizeof(cpx<T>) > 160 * 1024)) c /= 2;
+    // budget half the LDS per workgroup: the kernel is one load -> transform -> store chain
+    // per workgroup, so two resident workgroups per CU are what overlaps memory with math
+    while (c > 1 && (c * F::TPF > 1024 || (size_t)c * (F::LDS_ELEMS + 32) * sizeof(cpx<T>) > COL_LDS_BUDGET)) c /= 2;
     return c;
   }
   static constexpr int CC = cols();   // packed column PAIRS (complex transforms) per workgroup
@@ -486,6 +501,210 @@ __global__ __launch_bounds__((RowGeom<T, LG>::THREADS)) void rowidct_kernel(T* _
   if (threadIdx.x == 0) part[blockIdx.x] = tot;
 }
 
+// ---------------------------------------------------------------------------
+// generic-size DCT kernels (Bluestein).  Same data flow as the power-of-two kernels,
+// everything in the natural layout; 4 FFTs of length L >= 2n-1 per column instead of 2 of
+// length n, so roughly 4-8x the arithmetic -- the price of accepting any image size.
+// ---------------------------------------------------------------------------
+template <class T, int LG>
+struct GenGeom {
+  using F = WgFFT<T, LG>;
+  static constexpr int NF = F::TPF >= 256 ? 1 : 256 / F::TPF;   // transforms per workgroup
+  static constexpr int RS = F::LDS_ELEMS + (NF > 1 ? (F::TPF < 32 ? F::TPF : 0) : 0);
+  static constexpr int THREADS = NF * F::TPF;
+  static constexpr size_t LDS_BYTES = (size_t)NF * RS * sizeof(cpx<T>);
+  static constexpr bool FITS = LDS_BYTES <= 160 * 1024;
+};
+
+// rows: r (n0 x n) -> Z = DCT-II along axis 1; two rows per complex transform
+template <class T, int LG>
+__global__ __launch_bounds__((GenGeom<T, LG>::THREADS)) void g_rowdct_kernel(
+    const T* __restrict__ r, int n0, int n, T* __restrict__ Z, const cpx<T>* __restrict__ twtab,
+    const cpx<T>* __restrict__ chirp, const cpx<T>* __restrict__ bspec, const cpx<T>* __restrict__ wk,
+    const int* flags) {
+  if (flags[1]) return;
+  using F = WgFFT<T, LG>;
+  using B = WgBluestein<T, LG>;
+  using G = GenGeom<T, LG>;
+  constexpr int TPF = F::TPF;
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  const int tid = threadIdx.x % TPF, f = threadIdx.x / TPF;
+  cpx<T>* lds = reinterpret_cast<cpx<T>*>(smem) + f * G::RS;
+  const int pr = blockIdx.x * G::NF + f;
+  const int xa = 2 * pr, xb = 2 * pr + 1;
+  const bool va = xa < n0, vb = xb < n0;
+  const T* ra = r + (size_t)(va ? xa : 0) * n;
+  const T* rb = r + (size_t)(vb ? xb : 0) * n;
+  typename F::Twiddles tw;
+  F::load_twiddles(tw, twtab, tid);
+  cpx<T> x[16];
+#pragma unroll
+  for (int i = 0; i < 16; ++i) {
+    const int slot = tid + TPF * i;
+    if (slot < n) {
+      const int src = makhoul_src(slot, n);
+      x[i] = {va ? ra[src] : T(0), vb ? rb[src] : T(0)};
+    } else {
+      x[i] = {T(0), T(0)};
+    }
+  }
+  B::dft(x, lds, tid, n, chirp, bspec, tw);
+  __syncthreads();
+#pragma unroll
+  for (int i = 0; i < 16; ++i) {
+    const int slot = tid + TPF * i;
+    if (slot < n) lds[F::pad(slot)] = x[i];
+  }
+  __syncthreads();
+#pragma unroll
+  for (int i = 0; i < 16; ++i) {
+    const int k = tid + TPF * i;
+    if (k < n) {
+      const cpx<T> zm = lds[F::pad(k == 0 ? 0 : n - k)];
+      const cpx<T> w = wk[k];
+      const cpx<T> X = cmul(w, x[i]) + cmulc(zm, w);
+      if (va) Z[(size_t)xa * n + k] = X.x;
+      if (vb) Z[(size_t)xb * n + k] = X.y;
+    }
+  }
+}
+
+// rows: Z -> z = DCT-III along axis 1 (in place), partial <r, z>
+template <class T, int LG>
+__global__ __launch_bounds__((GenGeom<T, LG>::THREADS)) void g_rowidct_kernel(
+    T* __restrict__ Z, const T* __restrict__ r, int n0, int n, const cpx<T>* __restrict__ twtab,
+    const cpx<T>* __restrict__ chirp, const cpx<T>* __restrict__ bspec, const cpx<T>* __restrict__ wk,
+    double* part, const int* flags) {
+  if (flags[1]) return;
+  using F = WgFFT<T, LG>;
+  using B = WgBluestein<T, LG>;
+  using G = GenGeom<T, LG>;
+  constexpr int TPF = F::TPF;
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  __shared__ double sh[1024];
+  const int tid = threadIdx.x % TPF, f = threadIdx.x / TPF;
+  cpx<T>* lds = reinterpret_cast<cpx<T>*>(smem) + f * G::RS;
+  const int pr = blockIdx.x * G::NF + f;
+  const int xa = 2 * pr, xb = 2 * pr + 1;
+  const bool va = xa < n0, vb = xb < n0;
+  T* za = Z + (size_t)(va ? xa : 0) * n;
+  T* zb = Z + (size_t)(vb ? xb : 0) * n;
+  typename F::Twiddles tw;
+  F::load_twiddles(tw, twtab, tid);
+  cpx<T> x[16];
+  const T inv_n = T(1) / T(n);
+#pragma unroll
+  for (int i = 0; i < 16; ++i) {
+    const int k = tid + TPF * i;
+    x[i] = {T(0), T(0)};
+    if (k < n) {
+      const cpx<T> X = {va ? za[k] : T(0), vb ? zb[k] : T(0)};
+      const cpx<T> Xm = k == 0 ? cpx<T>{T(0), T(0)} : cpx<T>{va ? za[n - k] : T(0), vb ? zb[n - k] : T(0)};
+      const cpx<T> d = {X.x + Xm.y, X.y - Xm.x};     // X_k - i X_{n-k}
+      const cpx<T> v = cmulc(d, wk[k]);              // V_k = conj(w_k) (.) / 2
+      x[i] = {T(0.5) * v.x, T(-0.5) * v.y};          // conj(V_k): IDFT = conj(DFT(conj .))
+    }
+  }
+  B::dft(x, lds, tid, n, chirp, bspec, tw);
+  __syncthreads();
+#pragma unroll
+  for (int i = 0; i < 16; ++i) {
+    const int m = tid + TPF * i;
+    if (m < n) lds[F::pad(makhoul_src(m, n))] = {x[i].x * inv_n, -x[i].y * inv_n};
+  }
+  __syncthreads();
+  double dot = 0;
+#pragma unroll
+  for (int i = 0; i < 16; ++i) {
+    const int c = tid + TPF * i;
+    if (c < n) {
+      const cpx<T> v = lds[F::pad(c)];
+      if (va) { za[c] = v.x; dot += (double)r[(size_t)xa * n + c] * (double)v.x; }
+      if (vb) { zb[c] = v.y; dot += (double)r[(size_t)xb * n + c] * (double)v.y; }
+    }
+  }
+  const double tot = block_sum(dot, sh);
+  if (threadIdx.x == 0) part[blockIdx.x] = tot;
+}
+
+// columns: DCT-II along axis 0 -> divide by eigenvalues -> DCT-III along axis 0, in place;
+// two adjacent columns per complex transform, NF transforms per workgroup
+template <class T, int LG>
+__global__ __launch_bounds__((GenGeom<T, LG>::THREADS)) void g_colsolve_kernel(
+    T* __restrict__ Z, int n, int n1, const cpx<T>* __restrict__ twtab, const cpx<T>* __restrict__ chirp,
+    const cpx<T>* __restrict__ bspec, const cpx<T>* __restrict__ wk, const T* __restrict__ ha,
+    const T* __restrict__ ham, const T* __restrict__ hb, const int* flags) {
+  if (flags[1]) return;
+  using F = WgFFT<T, LG>;
+  using B = WgBluestein<T, LG>;
+  using G = GenGeom<T, LG>;
+  constexpr int TPF = F::TPF, NF = G::NF;
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  // column-pair index fastest in the thread index: neighbouring lanes read neighbouring columns
+  const int f = threadIdx.x % NF, tid = threadIdx.x / NF;
+  cpx<T>* lds = reinterpret_cast<cpx<T>*>(smem) + f * G::RS;
+  const int ya = (blockIdx.x * NF + f) * 2, yb = ya + 1;
+  const bool va = ya < n1, vb = yb < n1;
+  typename F::Twiddles tw;
+  F::load_twiddles(tw, twtab, tid);
+  cpx<T> x[16];
+#pragma unroll
+  for (int i = 0; i < 16; ++i) {
+    const int slot = tid + TPF * i;
+    x[i] = {T(0), T(0)};
+    if (slot < n) {
+      const size_t row = (size_t)makhoul_src(slot, n) * n1;
+      x[i] = {va ? Z[row + ya] : T(0), vb ? Z[row + yb] : T(0)};
+    }
+  }
+  B::dft(x, lds, tid, n, chirp, bspec, tw);
+  __syncthreads();
+#pragma unroll
+  for (int i = 0; i < 16; ++i) {
+    const int slot = tid + TPF * i;
+    if (slot < n) lds[F::pad(slot)] = x[i];
+  }
+  __syncthreads();
+  const T inv_n = T(1) / T(n);
+  const T hba = va ? hb[ya] : T(1), hbb = vb ? hb[yb] : T(1);
+#pragma unroll
+  for (int i = 0; i < 16; ++i) {
+    const int k = tid + TPF * i;
+    if (k < n) {
+      const cpx<T> zk = x[i], zm = lds[F::pad(k == 0 ? 0 : n - k)];
+      const cpx<T> w = wk[k];
+      const T h = ha[k], hm = ham[k];
+      const cpx<T> qa = {T(0.5) * (zk.x + zm.x), T(0.5) * (zk.y - zm.y)};
+      const cpx<T> qb = {T(0.5) * (zk.y + zm.y), T(-0.5) * (zk.x - zm.x)};
+      const cpx<T> ua = cmul(w, qa), ub = cmul(w, qb);
+      T sa = inv_n / (T(-2) * (h + hba)), sb = inv_n / (T(-2) * (h + hbb));
+      T sam = inv_n / (T(-2) * (hm + hba)), sbm = inv_n / (T(-2) * (hm + hbb));
+      if (k == 0) {
+        sam = T(0);
+        sbm = T(0);
+        if (ya == 0) sa = inv_n;
+      }
+      const cpx<T> pa = cmulc(cpx<T>{sa * ua.x, sam * ua.y}, w);
+      const cpx<T> pb = cmulc(cpx<T>{sb * ub.x, sbm * ub.y}, w);
+      // V'_k of the packed pair, conjugated for the conj-DFT-conj inverse
+      x[i] = {pa.x - pb.y, -(pa.y + pb.x)};
+    } else {
+      x[i] = {T(0), T(0)};
+    }
+  }
+  __syncthreads();
+  B::dft(x, lds, tid, n, chirp, bspec, tw);
+#pragma unroll
+  for (int i = 0; i < 16; ++i) {
+    const int slot = tid + TPF * i;
+    if (slot < n) {
+      const size_t row = (size_t)makhoul_src(slot, n) * n1;
+      if (va) Z[row + ya] = x[i].x;
+      if (vb) Z[row + yb] = -x[i].y;
+    }
+  }
+}
+
 #define GPA_FOR_LG(X) X(6) X(7) X(8) X(9) X(10) X(11) X(12) X(13) X(14)
 
 template <class T, int LG>
@@ -555,6 +774,96 @@ hipError_t dispatch_colsolve(const Impl* w, int compat, hipStream_t s) {
   return hipErrorInvalidValue;
 }
 
+template <class T, int LG>
+hipError_t run_g_rowdct(const Impl* w, hipStream_t s) {
+  using G = GenGeom<T, LG>;
+  if constexpr (!G::FITS) return hipErrorInvalidValue;
+  else {
+    auto kern = g_rowdct_kernel<T, LG>;
+    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize,
+                                       (int)G::LDS_BYTES);
+    if (e != hipSuccess) return e;
+    const int npairs = (w->n0 + 1) / 2, grid = (npairs + G::NF - 1) / G::NF;
+    kern<<<grid, G::THREADS, G::LDS_BYTES, s>>>((const T*)w->r, w->n0, w->n1, (T*)w->z, (const cpx<T>*)w->btw1,
+                                                 (const cpx<T>*)w->chirp1, (const cpx<T>*)w->bspec1,
+                                                 (const cpx<T>*)w->gwk1, w->flags);
+    return hipGetLastError();
+  }
+}
+template <class T, int LG>
+hipError_t run_g_rowidct(const Impl* w, int* nparts, hipStream_t s) {
+  using G = GenGeom<T, LG>;
+  if constexpr (!G::FITS) return hipErrorInvalidValue;
+  else {
+    auto kern = g_rowidct_kernel<T, LG>;
+    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize,
+                                       (int)G::LDS_BYTES);
+    if (e != hipSuccess) return e;
+    const int npairs = (w->n0 + 1) / 2, grid = (npairs + G::NF - 1) / G::NF;
+    *nparts = grid;
+    kern<<<grid, G::THREADS, G::LDS_BYTES, s>>>((T*)w->z, (const T*)w->r, w->n0, w->n1, (const cpx<T>*)w->btw1,
+                                                 (const cpx<T>*)w->chirp1, (const cpx<T>*)w->bspec1,
+                                                 (const cpx<T>*)w->gwk1, w->part, w->flags);
+    return hipGetLastError();
+  }
+}
+template <class T, int LG>
+hipError_t run_g_colsolve(const Impl* w, int compat, hipStream_t s) {
+  using G = GenGeom<T, LG>;
+  if constexpr (!G::FITS) return hipErrorInvalidValue;
+  else {
+    auto kern = g_colsolve_kernel<T, LG>;
+    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize,
+                                       (int)G::LDS_BYTES);
+    if (e != hipSuccess) return e;
+    const int npairs = (w->n1 + 1) / 2, grid = (npairs + G::NF - 1) / G::NF;
+    kern<<<grid, G::THREADS, G::LDS_BYTES, s>>>((T*)w->z, w->n0, w->n1, (const cpx<T>*)w->btw0,
+                                                 (const cpx<T>*)w->chirp0, (const cpx<T>*)w->bspec0,
+                                                 (const cpx<T>*)w->gwk0, (const T*)w->gha0[compat],
+                                                 (const T*)w->gham0[compat], (const T*)w->hb1[compat], w->flags);
+    return hipGetLastError();
+  }
+}
+hipError_t dispatch_g_rowdct(const Impl* w, hipStream_t s) {
+#define CASE(LG) case LG: return w->dtype == 0 ? run_g_rowdct<float, LG>(w, s) : run_g_rowdct<double, LG>(w, s);
+  switch (w->lgb1) { GPA_FOR_LG(CASE) }
+#undef CASE
+  return hipErrorInvalidValue;
+}
+hipError_t dispatch_g_rowidct(const Impl* w, int* nparts, hipStream_t s) {
+#define CASE(LG) case LG: return w->dtype == 0 ? run_g_rowidct<float, LG>(w, nparts, s) : run_g_rowidct<double, LG>(w, nparts, s);
+  switch (w->lgb1) { GPA_FOR_LG(CASE) }
+#undef CASE
+  return hipErrorInvalidValue;
+}
+hipError_t dispatch_g_colsolve(const Impl* w, int compat, hipStream_t s) {
+#define CASE(LG) case LG: return w->dtype == 0 ? run_g_colsolve<float, LG>(w, compat, s) : run_g_colsolve<double, LG>(w, compat, s);
+  switch (w->lgb0) { GPA_FOR_LG(CASE) }
+#undef CASE
+  return hipErrorInvalidValue;
+}
+
+// host-side radix-2 FFT in double, for the Bluestein kernel spectra
+void host_fft(std::vector<double>& re, std::vector<double>& im) {
+  const size_t n = re.size();
+  int lg = 0;
+  while ((size_t(1) << lg) < n) ++lg;
+  for (size_t i = 0; i < n; ++i) {
+    size_t r = 0;
+    for (int b = 0; b < lg; ++b) r |= ((i >> b) & 1) << (lg - 1 - b);
+    if (r > i) { std::swap(re[i], re[r]); std::swap(im[i], im[r]); }
+  }
+  for (size_t len = 2; len <= n; len <<= 1)
+    for (size_t s0 = 0; s0 < n; s0 += len)
+      for (size_t j = 0; j < len / 2; ++j) {
+        const double ang = -2.0 * M_PI * (double)j / (double)len, wr = cos(ang), wi = sin(ang);
+        const size_t a = s0 + j, b = s0 + j + len / 2;
+        const double vr = re[b] * wr - im[b] * wi, vi = re[b] * wi + im[b] * wr;
+        re[b] = re[a] - vr; im[b] = im[a] - vi;
+        re[a] += vr; im[a] += vi;
+      }
+}
+
 template <class T>
 hipError_t upload_vec(void** dst, const std::vector<double>& v, size_t* bytes, hipStream_t s) {
   std::vector<T> tmp(v.begin(), v.end());
@@ -591,7 +900,12 @@ hipError_t unwrap_workspace_create(int dtype, int n0, int n1, hipStream_t s, Unw
   w->lg0 = ilog2_exact(n0);
   w->lg1 = ilog2_exact(n1);
   const int maxlg = dtype == 0 ? 14 : 13;
-  w->supported = w->lg0 >= 6 && w->lg1 >= 6 && w->lg0 <= maxlg && w->lg1 <= maxlg;
+  const bool pow2ok = w->lg0 >= 6 && w->lg1 >= 6 && w->lg0 <= maxlg && w->lg1 <= maxlg;
+  auto blue_lg = [](int n) { int lg = 6; while ((1 << lg) < 2 * n - 1) ++lg; return lg; };
+  w->lgb0 = blue_lg(n0);
+  w->lgb1 = blue_lg(n1);
+  w->generic = !pow2ok;
+  w->supported = pow2ok || (n0 >= 2 && n1 >= 2 && w->lgb0 <= maxlg && w->lgb1 <= maxlg);
   size_t bytes = 0;
   const size_t npx = (size_t)n0 * n1;
   hipError_t e;
@@ -607,7 +921,48 @@ hipError_t unwrap_workspace_create(int dtype, int n0, int n1, hipStream_t s, Unw
   if (e != hipSuccess) return e;
   e = hipMalloc((void**)&w->part, (size_t)3 * MAXPART * sizeof(double));
   if (e != hipSuccess) return e;
-  if (w->supported) {
+  if (w->supported && w->generic) {
+    for (int ax = 0; ax < 2; ++ax) {
+      const int n = ax == 0 ? n0 : n1, lgb = ax == 0 ? w->lgb0 : w->lgb1, L = 1 << lgb, tpf = L / 16;
+      std::vector<double> t((size_t)2 * L), ch((size_t)2 * n), wkv((size_t)2 * n);
+      for (int k = 0; k < L; ++k) { t[2 * k] = cos(-2.0 * M_PI * k / L); t[2 * k + 1] = sin(-2.0 * M_PI * k / L); }
+      std::vector<double> bre((size_t)L, 0.0), bim((size_t)L, 0.0);
+      for (int m = 0; m < n; ++m) {
+        const long long mm = ((long long)m * m) % (2LL * n);     // c_m = exp(i pi m^2 / n), argument reduced exactly
+        const double cr = cos(M_PI * (double)mm / n), ci = sin(M_PI * (double)mm / n);
+        ch[2 * m] = cr; ch[2 * m + 1] = ci;
+        bre[m] = cr; bim[m] = ci;
+        if (m > 0) { bre[L - m] = cr; bim[L - m] = ci; }
+        wkv[2 * m] = cos(-M_PI * m / (2.0 * n)); wkv[2 * m + 1] = sin(-M_PI * m / (2.0 * n));
+      }
+      host_fft(bre, bim);
+      std::vector<double> bs((size_t)2 * L);
+      for (int i = 0; i < 16; ++i)
+        for (int tt = 0; tt < tpf; ++tt) {
+          const int k = spec_index_rt(lgb, tt, i);
+          bs[2 * ((size_t)i * tpf + tt)] = bre[k] / L;
+          bs[2 * ((size_t)i * tpf + tt) + 1] = bim[k] / L;
+        }
+      if ((e = upload(dtype, ax == 0 ? &w->btw0 : &w->btw1, t, &bytes, s)) != hipSuccess) return e;
+      if ((e = upload(dtype, ax == 0 ? &w->chirp0 : &w->chirp1, ch, &bytes, s)) != hipSuccess) return e;
+      if ((e = upload(dtype, ax == 0 ? &w->bspec0 : &w->bspec1, bs, &bytes, s)) != hipSuccess) return e;
+      if ((e = upload(dtype, ax == 0 ? &w->gwk0 : &w->gwk1, wkv, &bytes, s)) != hipSuccess) return e;
+    }
+    for (int compat = 0; compat < 2; ++compat) {
+      const double A0 = compat ? n1 : n0, A1 = compat ? n0 : n1;
+      std::vector<double> a((size_t)n0), am((size_t)n0), b((size_t)n1);
+      for (int k = 0; k < n0; ++k) {
+        const double sk = sin(M_PI * k / (2.0 * A0)), sm = sin(M_PI * (n0 - k) / (2.0 * A0));
+        a[k] = 2 * sk * sk;
+        am[k] = 2 * sm * sm;
+      }
+      for (int j = 0; j < n1; ++j) { const double sj = sin(M_PI * j / (2.0 * A1)); b[j] = 2 * sj * sj; }
+      if ((e = upload(dtype, &w->gha0[compat], a, &bytes, s)) != hipSuccess) return e;
+      if ((e = upload(dtype, &w->gham0[compat], am, &bytes, s)) != hipSuccess) return e;
+      if ((e = upload(dtype, &w->hb1[compat], b, &bytes, s)) != hipSuccess) return e;
+    }
+  }
+  if (w->supported && !w->generic) {
     for (int ax = 0; ax < 2; ++ax) {
       const int n = ax == 0 ? n0 : n1;
       std::vector<double> t((size_t)2 * n);
@@ -668,7 +1023,8 @@ void unwrap_workspace_destroy(UnwrapWorkspace* ws) {
   Impl* w = (Impl*)ws->impl;
   if (!w) return;
   void* bufs[] = {w->r, w->p, w->p2, w->q, w->z, w->tw0, w->tw1, w->wk1, w->wk0s, w->ha0[0], w->ha0[1], w->ham0[0],
-                  w->ham0[1], w->hb1[0], w->hb1[1], w->scal, w->flags, w->part};
+                  w->ham0[1], w->hb1[0], w->hb1[1], w->scal, w->flags, w->part, w->btw0, w->btw1, w->chirp0, w->chirp1,
+                  w->bspec0, w->bspec1, w->gwk0, w->gwk1, w->gha0[0], w->gha0[1], w->gham0[0], w->gham0[1]};
   for (void* b : bufs)
     if (b) hipFree(b);
   delete w;
@@ -693,19 +1049,34 @@ static hipError_t run_pcg(Impl* w, const void* a, const void* b, const void* wei
   setup_kernel<T><<<g2, 256, 0, s>>>((const T*)a, (const T*)b, (const T*)weight, from_psi ? 1 : 0, n0, n1, (T*)w->r,
                                      (T*)phi, w->part);
   scal_init_kernel<<<1, 256, 0, s>>>(w->part, np2, w->scal, w->flags);
+  const bool vec4 = !w->generic && (n1 % 4) == 0;   // pq_kernel needs 16-byte aligned rows
   for (int it = 0; it < kmax; ++it) {
-    if ((e = dispatch_rowdct(w, s)) != hipSuccess) return e;
-    if ((e = dispatch_colsolve(w, compat, s)) != hipSuccess) return e;
     int nrow = 0;
-    if ((e = dispatch_rowidct(w, &nrow, s)) != hipSuccess) return e;
+    if (w->generic) {
+      if ((e = dispatch_g_rowdct(w, s)) != hipSuccess) return e;
+      if ((e = dispatch_g_colsolve(w, compat, s)) != hipSuccess) return e;
+      if ((e = dispatch_g_rowidct(w, &nrow, s)) != hipSuccess) return e;
+    } else {
+      if ((e = dispatch_rowdct(w, s)) != hipSuccess) return e;
+      if ((e = dispatch_colsolve(w, compat, s)) != hipSuccess) return e;
+      if ((e = dispatch_rowidct(w, &nrow, s)) != hipSuccess) return e;
+    }
     scal_rho_kernel<<<1, 256, 0, s>>>(w->part, nrow, w->scal, w->flags);
-    // n1 is a power of two >= 64 here, so rows are 16-byte aligned multiples of 4 pixels
-    T* pin = (T*)((it & 1) ? w->p2 : w->p);
-    T* pout = (T*)((it & 1) ? w->p : w->p2);
-    pq_kernel<T><<<gpq, 256, 0, s>>>((const T*)w->z, pin, pout, (const T*)weight, n0, n1, (T*)w->q, w->part + MAXPART,
-                                     w->scal, w->flags);
-    scal_alpha_kernel<<<1, 256, 0, s>>>(w->part + MAXPART, npq, w->scal, w->flags);
-    update_kernel<T><<<gl, 256, 0, s>>>((const T*)pout, (const T*)w->q, (T*)phi, (T*)w->r, npx, w->scal,
+    T* pcur;
+    if (vec4) {
+      T* pin = (T*)((it & 1) ? w->p2 : w->p);
+      pcur = (T*)((it & 1) ? w->p : w->p2);
+      pq_kernel<T><<<gpq, 256, 0, s>>>((const T*)w->z, pin, pcur, (const T*)weight, n0, n1, (T*)w->q,
+                                       w->part + MAXPART, w->scal, w->flags);
+      scal_alpha_kernel<<<1, 256, 0, s>>>(w->part + MAXPART, npq, w->scal, w->flags);
+    } else {
+      pcur = (T*)w->p;
+      pupdate_kernel<T><<<gl, 256, 0, s>>>((const T*)w->z, pcur, npx, w->scal, w->flags);
+      applyq_kernel<T><<<g2, 256, 0, s>>>((const T*)pcur, (const T*)weight, n0, n1, (T*)w->q, w->part + MAXPART,
+                                          w->flags);
+      scal_alpha_kernel<<<1, 256, 0, s>>>(w->part + MAXPART, np2, w->scal, w->flags);
+    }
+    update_kernel<T><<<gl, 256, 0, s>>>((const T*)pcur, (const T*)w->q, (T*)phi, (T*)w->r, npx, w->scal,
                                         w->part + 2 * MAXPART, w->flags);
     scal_stop_kernel<<<1, 256, 0, s>>>(w->part + 2 * MAXPART, gl, w->scal, w->flags, kmax, eps);
   }

@@ -33,6 +33,19 @@ def test_displacement_field(testset):
     assert np.all(np.abs(u32 - u_true)[:, 20:-20, 20:-20] < 0.9)
 
 
+def test_displacement_field_500():
+    """the reference's own image size (500^2, not a power of two): padded-mode lock-ins + Bluestein unwrap"""
+    shape = (500, 500)
+    ks = hex_kvecs(0.1, 7.0)
+    u_true = gaussian_bump_displacement(shape)
+    deformed = hex_moire(shape, ks, u_true, noise=0.5, seed=4)
+    u = -GPA.extract_displacement_field(deformed, ks)
+    assert np.all(np.abs(u - u_true)[:, 20:-20, 20:-20] < 0.9)
+    from oracle import gpa_oracle as orc
+    u_ref = -orc.extract_displacement_field(deformed, ks, workers=8)
+    assert np.abs(u - u_ref).max() < 1e-7 * np.abs(u_ref).max()
+
+
 def test_wfr2_variants_lockin(testset):
     """reference tests/test_geometric_phase_analysis.py:82-97 and tests/test_cuGPA.py:68-82"""
     original, deformed, noise, ks, _ = testset
