@@ -103,6 +103,13 @@ int gpa_reconstruct_grad(gpa_plan* plan, const void* lockin, const double* kvecs
 int gpa_reconstruct_grad_dev(gpa_plan* plan, const void* lockin, const double* kvecs, int P,
                              int mask_border, void* dudx, void* dudy, void* wnorm);
 
+/* a8 helper -- per-pixel weighted least squares on given right-hand sides:
+ * minimise || w (2 pi kvecs x - b) || per pixel; the weighted branch of reconstruct_u_inv
+ * (geometric_phase_analysis.py:188 -> myweighed_lstsq :97-113).  b, weights: P x n0 x n1
+ * (host), out: 2 x n0 x n1.                                                    */
+int gpa_weighted_lstsq(gpa_plan* plan, const void* b, const void* weights, const double* kvecs, int P,
+                       void* out);
+
 /* a7 -- DCT-Laplacian weighted least-squares phase unwrap (Ghiglia-Romero PCG)
  * from pre-differenced gradients: replaces phase_unwrap_prediff
  * (phase_unwrap.py:282-350) with helpers :95-132.

@@ -35,6 +35,7 @@ SIGNATURES = {
     'gpa_sweep_dev': (_i, [_vp, _vp, _vp, _vp, _i, _d, _vp, _vp, _vp]),
     'gpa_reconstruct_grad': (_i, [_vp, _vp, _vp, _i, _i, _vp, _vp, _vp]),
     'gpa_reconstruct_grad_dev': (_i, [_vp, _vp, _vp, _i, _i, _vp, _vp, _vp]),
+    'gpa_weighted_lstsq': (_i, [_vp, _vp, _vp, _vp, _i, _vp]),
     'gpa_unwrap_prediff': (_i, [_vp, _vp, _vp, _vp, _i, _d, _i, _vp, _vp]),
     'gpa_unwrap_prediff_dev': (_i, [_vp, _vp, _vp, _vp, _i, _d, _i, _vp, _vp]),
     'gpa_unwrap': (_i, [_vp, _vp, _vp, _i, _d, _i, _vp, _vp]),
@@ -174,6 +175,17 @@ class Plan:
                                             _ptr(dudx), _ptr(dudy), _ptr(wnorm)), 'gpa_reconstruct_grad')
         return dudx, dudy, wnorm
 
+    def weighted_lstsq(self, b, weights, kvecs):
+        b = np.ascontiguousarray(b, dtype=self.rdtype)
+        weights = np.ascontiguousarray(weights, dtype=self.rdtype)
+        kvecs = _f64(kvecs).reshape(-1, 2)
+        if b.shape != (len(kvecs),) + self.shape or weights.shape != b.shape:
+            raise ValueError('b / weights must have shape (P,) + plan shape')
+        out = np.empty((2,) + self.shape, dtype=self.rdtype)
+        check(self.lib.gpa_weighted_lstsq(self.handle, _ptr(b), _ptr(weights), _ptr(kvecs), len(kvecs), _ptr(out)),
+              'gpa_weighted_lstsq')
+        return out
+
     def unwrap_prediff(self, dx, dy, weight=None, kmax=100, eps=1e-9, axes_compat=True):
         n0, n1 = self.shape
         dx = np.ascontiguousarray(dx, dtype=self.rdtype)
@@ -251,11 +263,10 @@ def get_plan(shape, batch, dtype=np.float64, device=0):
     key = (int(shape[0]), int(shape[1]), np.dtype(dtype).name, int(device))
     p = _plans.get(key)
     if p is None or p.max_batch < batch:
-        if p is not None:
-            p.close()
-        if len(_plans) >= 4:
-            _, old = _plans.popitem()
-            old.close()
+        # evicted plans are only dropped from the cache: a caller may still hold one, and
+        # Plan.__del__ releases the device memory with the last reference
+        if len(_plans) >= 4 and key not in _plans:
+            _plans.pop(next(iter(_plans)))
         p = Plan(shape, max(int(batch), 1), dtype, device)
         _plans[key] = p
     return p

@@ -495,6 +495,22 @@ int gpa_reconstruct_grad(gpa_plan* p, const void* lockin, const double* kvecs, i
   return GPA_OK;
 }
 
+int gpa_weighted_lstsq(gpa_plan* p, const void* b, const void* weights, const double* kvecs, int P, void* out) {
+  if (!p || !b || !weights || !kvecs || !out) return fail(GPA_ERR_ARG, "gpa_weighted_lstsq: null argument");
+  if (P < 2 || P > p->max_peaks) return fail(GPA_ERR_STATE, "gpa_weighted_lstsq: need 2 <= P <= 8 (and P <= max_batch)");
+  HIP_TRY(hipSetDevice(p->device));
+  const size_t npx = (size_t)p->n0 * p->n1;
+  // staging: b in d_lockin (P complex planes hold 2P real ones), weights in Tbuf
+  HIP_TRY(hipMemcpyAsync(p->d_lockin, b, (size_t)P * npx * p->rsz, hipMemcpyHostToDevice, p->stream));
+  HIP_TRY(hipMemcpyAsync(p->Tbuf, weights, (size_t)P * npx * p->rsz, hipMemcpyHostToDevice, p->stream));
+  for (int i = 0; i < 2 * P; ++i) p->h_k[i] = 2.0 * M_PI * kvecs[i];
+  HIP_TRY(hipMemcpyAsync(p->d_kmat, p->h_k, (size_t)2 * P * sizeof(double), hipMemcpyHostToDevice, p->stream));
+  HIP_TRY(launch_wlstsq(p->dtype, p->d_lockin, p->Tbuf, p->d_kmat, P, npx, p->d_u, p->stream));
+  HIP_TRY(hipMemcpyAsync(out, p->d_u, 2 * npx * p->rsz, hipMemcpyDeviceToHost, p->stream));
+  HIP_TRY(hipStreamSynchronize(p->stream));
+  return GPA_OK;
+}
+
 // ---- a7 ----------------------------------------------------------------------
 int gpa_unwrap_prediff_dev(gpa_plan* p, const void* dx, const void* dy, const void* weight, int kmax,
                            double eps, int compat, void* phi, int* iters_out) {

@@ -84,4 +84,7 @@ hipError_t launch_reconstruct(int dtype, const void* lockin, const double* kmat 
                               int P, int n0, int n1, int border, void* dudx, void* dudy,
                               void* wnorm, hipStream_t s);
 
+hipError_t launch_wlstsq(int dtype, const void* b, const void* w, const double* kmat, int P, size_t npx,
+                         void* out, hipStream_t s);
+
 }  // namespace gpa

@@ -111,6 +111,40 @@ __global__ __launch_bounds__(256) void reconstruct_kernel(const cpx<T>* __restri
   }
 }
 
+// per-pixel weighted least squares on given right-hand sides b (P x n0 x n1), the weighted
+// branch of reconstruct_u_inv (geometric_phase_analysis.py:188 -> myweighed_lstsq :97-113)
+template <class T>
+__global__ __launch_bounds__(256) void wlstsq_kernel(const T* __restrict__ b, const T* __restrict__ w,
+                                                    const double* __restrict__ kmat, int P, size_t npx,
+                                                    T* __restrict__ out) {
+  const size_t o = (size_t)blockIdx.x * 256 + threadIdx.x;
+  if (o >= npx) return;
+  T wv[MAXP], wmax = T(0);
+  for (int p = 0; p < P; ++p) { wv[p] = w[p * npx + o]; const T a = wv[p] < T(0) ? -wv[p] : wv[p]; wmax = a > wmax ? a : wmax; }
+  const T ws = wmax > T(0) ? T(1) / wmax : T(0);
+  T a00 = 0, a01 = 0, a11 = 0, r0 = 0, r1 = 0;
+  for (int p = 0; p < P; ++p) {
+    const T k0 = (T)kmat[2 * p], k1 = (T)kmat[2 * p + 1], wn = wv[p] * ws, ww = wn * wn, bv = b[p * npx + o];
+    a00 += ww * k0 * k0; a01 += ww * k0 * k1; a11 += ww * k1 * k1;
+    r0 += ww * k0 * bv; r1 += ww * k1 * bv;
+  }
+  T s0, s1;
+  solve2(a00, a01, a11, r0, r1, s0, s1);
+  out[o] = s0;
+  out[npx + o] = s1;
+}
+
+hipError_t launch_wlstsq(int dtype, const void* b, const void* w, const double* kmat, int P, size_t npx, void* out,
+                         hipStream_t s) {
+  if (P > MAXP) return hipErrorInvalidValue;
+  const unsigned grid = (unsigned)((npx + 255) / 256);
+  if (dtype == 0)
+    wlstsq_kernel<float><<<grid, 256, 0, s>>>((const float*)b, (const float*)w, kmat, P, npx, (float*)out);
+  else
+    wlstsq_kernel<double><<<grid, 256, 0, s>>>((const double*)b, (const double*)w, kmat, P, npx, (double*)out);
+  return hipGetLastError();
+}
+
 hipError_t launch_reconstruct(int dtype, const void* lockin, const double* kmat, int P, int n0, int n1,
                               int border, void* dudx, void* dudy, void* wnorm, hipStream_t s) {
   if (P > MAXP) return hipErrorInvalidValue;

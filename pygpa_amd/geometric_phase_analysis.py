@@ -12,7 +12,7 @@ import numpy as np
 
 from . import _lib
 from ._lib import GPAError  # noqa: F401
-from .mathtools import wrapToPi  # noqa: F401
+from .mathtools import wrapToPi, fit_plane  # noqa: F401
 
 DEFAULT_DTYPE = np.float64
 
@@ -92,6 +92,60 @@ def wfr2_grad_opt(image, sigma, kx, ky, kw, kstep, dtype=None):
 wfr2_grad = wfr2_grad_opt
 
 _NATIVE_SWEEPS = (optwfr2, wfr2_grad_opt)
+
+
+# --------------------------------------------------------------------------- a8
+def fit_delta_k(phases):
+    """Plane-fit slope of an unwrapped phase map as a k-vector correction
+    (geometric_phase_analysis.py:92-94)."""
+    return fit_plane(phases)[:2] / (2 * np.pi)
+
+
+def iterate_GPA(image, kvecs, sigma, edge=5, iters=3, kmax_iter=25, kmax=200, verbose=False, dtype=None):
+    """Iterate GPA, refining the reference vectors towards the extracted average
+    (geometric_phase_analysis.py:116-154).  Lock-ins and weighted unwraps run on the
+    device, the 3-parameter Huber plane fit on the host as in the reference.
+
+    Returns (prs, w, corr) like the reference."""
+    from . import phase_unwrap as _pu
+    image = np.asarray(image)
+    kvecs = np.asarray(kvecs, dtype=np.float64).reshape(-1, 2)
+    corr = np.zeros_like(kvecs)
+    plan = _plan(image, len(kvecs), dtype)
+    for i in range(iters + 1):
+        rs = plan.lockin_batch(image, kvecs + corr, sigma)
+        sl = (slice(edge, -edge), slice(edge, -edge)) if edge > 0 else (slice(None), slice(None))
+        prs = [np.angle(r)[sl] for r in rs]
+        w = np.stack([np.abs(r)[sl] for r in rs])
+        last = i == iters
+        prs = [_pu.phase_unwrap(r, np.sqrt(we / we.max()), kmax=kmax if last else kmax_iter, dtype=dtype)
+               for r, we in zip(prs, w)]
+        if not last:
+            delta_ks = np.stack([fit_delta_k(pr) for pr in prs])
+            if verbose:
+                print(delta_ks)
+            corr -= delta_ks
+    return np.stack(prs), w, corr
+
+
+def reconstruct_u_inv(kvecs, b, weights=None, use_only_ks=None, dtype=None):
+    """Unwrapped phases -> displacement field (geometric_phase_analysis.py:157-193).
+    The weighted per-pixel solve runs on the device; the two global solves are one small
+    matrix product on the host, as in the reference."""
+    kvecs = np.asarray(kvecs, dtype=np.float64).reshape(-1, 2)
+    K = 2 * np.pi * kvecs
+    b = np.asarray(b, dtype=np.float64)
+    b = b - b.mean(axis=(1, 2), keepdims=True)
+    if use_only_ks is not None:
+        assert len(use_only_ks) == 2
+        idx = list(use_only_ks)
+        us = np.linalg.inv(K[idx]) @ b[idx].reshape((2, -1))
+        return us.reshape((2,) + b[0].shape)
+    if weights is None:
+        us = np.linalg.pinv(K) @ b.reshape((len(kvecs), -1))
+        return us.reshape((2,) + b[0].shape)
+    plan = _lib.get_plan(b.shape[1:], len(kvecs), DEFAULT_DTYPE if dtype is None else dtype)
+    return plan.weighted_lstsq(b, weights, kvecs)
 
 
 # --------------------------------------------------------------------------- a5 .. a7

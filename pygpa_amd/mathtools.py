@@ -5,3 +5,18 @@ import numpy as np
 def wrapToPi(x):
     """Wrap to [-pi, pi) with floored modulo (reference pyGPA/mathtools.py:72-75)."""
     return (x + np.pi) % (2 * np.pi) - np.pi
+
+
+def fit_plane(image, verbose=False):
+    """Huber-loss plane fit a[0]*x + a[1]*y + a[2] through `image` (reference
+    pyGPA/mathtools.py:30-47).  A 3-parameter robust fit: host-side SciPy in the reference
+    and here ("Huber fit is host-side SciPy (stays on host)")."""
+    import scipy.optimize as spo
+    lxx, lyy = np.meshgrid(np.arange(image.shape[0]), np.arange(image.shape[1]), indexing='ij')
+
+    def resid(x):
+        return (image - (x[0] * lxx + x[1] * lyy + x[2])).ravel()
+    res = spo.least_squares(resid, np.zeros(3), loss='huber')
+    if verbose:
+        print(res.message)
+    return res.x

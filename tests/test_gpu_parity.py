@@ -223,3 +223,19 @@ def test_a4_grad(golden, name, dtype):
     ok = same & (amp > 1e-3 * amp.max())
     assert np.abs(d[ok]).max() < (1e-9 if dtype is np.float64 else 2e-3)
     plan.close()
+
+
+def test_a8_iterate_gpa(golden):
+    """iterate_GPA / reconstruct_u_inv against the reference's outputs (64^2 image, unwraps on
+    the 54^2 cropped maps -> Bluestein path, kmax_iter = 25, final kmax = 200)."""
+    import pygpa_amd.geometric_phase_analysis as GPA
+    g = golden('iterate_64')
+    prs, w, corr = GPA.iterate_GPA(g['image'] - g['image'].mean(), g['start_ks'], int(g['sigma']))
+    assert np.allclose(corr, g['corr'], rtol=1e-5, atol=1e-8)
+    assert np.allclose(w, g['w'], rtol=1e-8, atol=1e-10)
+    assert np.allclose(prs, g['prs'], rtol=1e-5, atol=1e-6)
+    assert np.abs(g['start_ks'] + corr - g['true_ks']).max() < 5e-4
+    uw = GPA.reconstruct_u_inv(g['start_ks'] + g['corr'], g['prs'], weights=g['w'])
+    assert np.allclose(uw, g['u_weighted'], atol=1e-9)
+    ug = GPA.reconstruct_u_inv(g['start_ks'] + g['corr'], g['prs'])
+    assert np.allclose(ug, g['u_global'], atol=1e-9)
