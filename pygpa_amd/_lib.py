@@ -186,6 +186,12 @@ class Plan:
               'gpa_weighted_lstsq')
         return out
 
+    def per_dft(self, image):
+        image = self._img(image)
+        out = np.empty(self.shape, dtype=self.cdtype)
+        check(self.lib.gpa_per_dft(self.handle, _ptr(image), _ptr(out)), 'gpa_per_dft')
+        return out
+
     def unwrap_prediff(self, dx, dy, weight=None, kmax=100, eps=1e-9, axes_compat=True):
         n0, n1 = self.shape
         dx = np.ascontiguousarray(dx, dtype=self.rdtype)

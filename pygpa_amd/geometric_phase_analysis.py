@@ -94,6 +94,18 @@ wfr2_grad = wfr2_grad_opt
 _NATIVE_SWEEPS = (optwfr2, wfr2_grad_opt)
 
 
+# --------------------------------------------------------------------------- a9
+def per(image, inverse_dft=False, dtype=None):
+    """DFT of the periodic component of Moisan's periodic + smooth decomposition -- the
+    only thing the reference takes from the third-party moisan2011.per, at
+    geometric_phase_analysis.py:429 (`pd, _ = per(image, inverse_dft=False)`).
+    Returns (p_hat, None); the smooth part is not computed.  Parity of this function is
+    unpinned (moisan2011 is not part of the reference checkout): restated from Moisan (2011)."""
+    if inverse_dft:
+        raise NotImplementedError('only inverse_dft=False (the reference call site) is provided')
+    return _plan(image, 1, dtype).per_dft(image), None
+
+
 # --------------------------------------------------------------------------- a8
 def fit_delta_k(phases):
     """Plane-fit slope of an unwrapped phase map as a k-vector correction

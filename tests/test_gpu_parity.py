@@ -239,3 +239,22 @@ def test_a8_iterate_gpa(golden):
     assert np.allclose(uw, g['u_weighted'], atol=1e-9)
     ug = GPA.reconstruct_u_inv(g['start_ks'] + g['corr'], g['prs'])
     assert np.allclose(ug, g['u_global'], atol=1e-9)
+
+
+@pytest.mark.parametrize('dtype', DTYPES)
+@pytest.mark.parametrize('shape', [(64, 64), (48, 80), (63, 65), (500, 500)])
+def test_a9_per_dft(shape, dtype):
+    """periodic-component DFT (arbitrary-size 2-D DFT via Bluestein) against the oracle's
+    restatement of Moisan (2011) and its known answers."""
+    import pygpa_amd.geometric_phase_analysis as GPA
+    rng = np.random.default_rng(5)
+    img = rng.normal(size=shape) + np.linspace(0, 3, shape[1])[None, :] + np.linspace(-1, 0, shape[0])[:, None] ** 2
+    img = img - img.mean()          # as the call site does (geometric_phase_analysis.py:428)
+    phat, _ = GPA.per(img, inverse_dft=False, dtype=dtype)
+    ref, sref = orc.per(img, inverse_dft=False)
+    # f32: a chirp-z DFT carries ~1e-5 of the largest bin as error (f64: 1e-11)
+    tol = 1e-10 if dtype is np.float64 else 5e-5   # the oracle's own 2cos+2cos-4 cancels to ~1e-11 near DC
+    assert rel(phat, ref) < tol
+    # known answers: mean(p) = mean(image) (= 0 here); p + s = image
+    assert abs(phat[0, 0]) < tol * np.abs(ref).max()
+    assert rel(phat + sref, np.fft.fft2(img)) < tol
