@@ -145,6 +145,15 @@ int gpa_extract_displacement_field_dev(gpa_plan* plan, const void* image, const 
                                        int mask_border, int kmax, void* u, void* lockins,
                                        int32_t* kidx, int* iters_out);
 
+/* tile stage of the multi-GPU path: sweep + phases/weights + per-pixel least squares of
+ * extract_displacement_field (:919-926, :234-237) WITHOUT the unwrap; the gradient tiles of all
+ * ranks are stitched and unwrapped once globally.  The image is used
+ * as given (the caller subtracts the mean of the WHOLE image from its tiles).  Host pointers;
+ * dudx: 2 x n0 x (n1-1), dudy: 2 x (n0-1) x n1, wnorm: n0 x n1.                  */
+int gpa_extract_gradients(gpa_plan* plan, const void* image, const double* kvecs, int P,
+                          const double* klists, int K, double sigma, int mask_border, void* dudx,
+                          void* dudy, void* wnorm);
+
 /* a9 -- DFT of the periodic component of Moisan's periodic+smooth decomposition
  * (third-party moisan2011.per(image, inverse_dft=False)[0], call site
  * geometric_phase_analysis.py:429).  out: n0 x n1 complex.                    */

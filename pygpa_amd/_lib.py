@@ -41,6 +41,7 @@ SIGNATURES = {
     'gpa_unwrap': (_i, [_vp, _vp, _vp, _i, _d, _i, _vp, _vp]),
     'gpa_extract_displacement_field': (_i, [_vp, _vp, _vp, _i, _vp, _i, _d, _i, _i, _vp, _vp, _vp, _vp]),
     'gpa_extract_displacement_field_dev': (_i, [_vp, _vp, _vp, _i, _vp, _i, _d, _i, _i, _vp, _vp, _vp, _vp]),
+    'gpa_extract_gradients': (_i, [_vp, _vp, _vp, _i, _vp, _i, _d, _i, _vp, _vp, _vp]),
     'gpa_per_dft': (_i, [_vp, _vp, _vp]),
     'gpa_timer_start': (_i, [_vp]),
     'gpa_timer_stop': (_i, [_vp, _vp]),
@@ -230,6 +231,20 @@ class Plan:
                                                       float(sigma), int(mask_border), int(kmax), _ptr(u), _ptr(lock),
                                                       _ptr(kidx), iters), 'gpa_extract_displacement_field')
         return u, lock, kidx, (iters[0], iters[1])
+
+    def extract_gradients(self, image, kvecs, klists, sigma, mask_border):
+        image = self._img(image)
+        kvecs = _f64(kvecs).reshape(-1, 2)
+        P = len(kvecs)
+        klists = _f64(klists).reshape(P, -1, 2)
+        n0, n1 = self.shape
+        dudx = np.empty((2, n0, n1 - 1), dtype=self.rdtype)
+        dudy = np.empty((2, n0 - 1, n1), dtype=self.rdtype)
+        wnorm = np.empty((n0, n1), dtype=self.rdtype)
+        check(self.lib.gpa_extract_gradients(self.handle, _ptr(image), _ptr(kvecs), P, _ptr(klists), klists.shape[1],
+                                             float(sigma), int(mask_border), _ptr(dudx), _ptr(dudy), _ptr(wnorm)),
+              'gpa_extract_gradients')
+        return dudx, dudy, wnorm
 
     # ---- device-pointer entry points (ints from torch.Tensor.data_ptr()) -----
     def extract_displacement_field_dev(self, image_ptr, kvecs, klists, sigma, mask_border, kmax, u_ptr,

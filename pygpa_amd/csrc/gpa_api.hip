@@ -613,6 +613,29 @@ int gpa_extract_displacement_field(gpa_plan* p, const void* image, const double*
   return GPA_OK;
 }
 
+int gpa_extract_gradients(gpa_plan* p, const void* image, const double* kvecs, int P, const double* klists, int K,
+                          double sigma, int mask_border, void* dudx, void* dudy, void* wnorm) {
+  if (!p || !image || !kvecs || !klists || !dudx || !dudy || !wnorm)
+    return fail(GPA_ERR_ARG, "gpa_extract_gradients: null argument");
+  if (P < 2 || P > p->max_peaks) return fail(GPA_ERR_STATE, "gpa_extract_gradients: need 2 <= P <= 8");
+  if (K < 1 || P * K > p->max_batch) return fail(GPA_ERR_STATE, "gpa_extract_gradients: P*K exceeds max_batch");
+  HIP_TRY(hipSetDevice(p->device));
+  const size_t npx = (size_t)p->n0 * p->n1;
+  HIP_TRY(hipMemcpyAsync(p->d_image, image, npx * p->rsz, hipMemcpyHostToDevice, p->stream));
+  // no mean subtraction here: a tile must be offset by the mean of the WHOLE image
+  // (geometric_phase_analysis.py:919), which only the caller knows
+  TRY(sweep_peaks_dev(p, p->d_image, nullptr, kvecs, P, klists, K, sigma, p->d_lockin, nullptr));
+  for (int i = 0; i < 2 * P; ++i) p->h_k[i] = 2.0 * M_PI * kvecs[i];
+  HIP_TRY(hipMemcpyAsync(p->d_kmat, p->h_k, (size_t)2 * P * sizeof(double), hipMemcpyHostToDevice, p->stream));
+  HIP_TRY(launch_reconstruct(p->dtype, p->d_lockin, p->d_kmat, P, p->n0, p->n1, mask_border, p->d_dudx, p->d_dudy,
+                             p->d_wnorm, p->stream));
+  HIP_TRY(hipMemcpyAsync(dudx, p->d_dudx, (size_t)2 * p->n0 * (p->n1 - 1) * p->rsz, hipMemcpyDeviceToHost, p->stream));
+  HIP_TRY(hipMemcpyAsync(dudy, p->d_dudy, (size_t)2 * (p->n0 - 1) * p->n1 * p->rsz, hipMemcpyDeviceToHost, p->stream));
+  HIP_TRY(hipMemcpyAsync(wnorm, p->d_wnorm, npx * p->rsz, hipMemcpyDeviceToHost, p->stream));
+  HIP_TRY(hipStreamSynchronize(p->stream));
+  return GPA_OK;
+}
+
 int gpa_per_dft(gpa_plan* p, const void* image, void* out) {
   if (!p || !image || !out) return fail(GPA_ERR_ARG, "gpa_per_dft: null argument");
   HIP_TRY(hipSetDevice(p->device));

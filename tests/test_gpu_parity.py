@@ -258,3 +258,17 @@ def test_a9_per_dft(shape, dtype):
     # known answers: mean(p) = mean(image) (= 0 here); p + s = image
     assert abs(phat[0, 0]) < tol * np.abs(ref).max()
     assert rel(phat + sref, np.fft.fft2(img)) < tol
+
+
+def test_tiled_path_device_vs_oracle():
+    """tile-sharded path (pygpa_amd/distributed.py), one rank: device stages against the oracle
+    run on the SAME tiling (2 x 2 tiles of 128 x 192 -> 104 x 136 windows: padded lock-ins,
+    global 128 x 192 unwrap on the Bluestein/pow2 mix)."""
+    from pygpa_amd import distributed as D
+    from test_distributed import _case, _oracle_compute
+    img, kvecs, klists = _case()
+    u_ref = D.extract_displacement_field_tiled(img, kvecs, (2, 2), klists=klists, halo=20, compute=_oracle_compute())
+    u = D.extract_displacement_field_tiled(img, kvecs, (2, 2), klists=klists, halo=20)
+    assert rel(u, u_ref) < 1e-8
+    u32 = D.extract_displacement_field_tiled(img, kvecs, (2, 2), klists=klists, halo=20, dtype=np.float32)
+    assert rel(u32, u_ref) < 5e-4
