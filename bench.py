@@ -48,7 +48,7 @@ def algorithmic_bytes(n0, n1, P, K, s, iters):
     return {'passA': a, 'passB': b, 'reconstruct': rec, 'unwrap': unw, 'total': a + b + rec + unw}
 
 
-def cpu_baseline(kvecs, sigma, K_side, kmax, sample=1024):
+def cpu_baseline(kvecs, sigma, knx, kny, kmax, sample=1024):
     """Time the CPU oracle (NumPy/SciPy port of the reference path) on a bounded
     sample of the same workload: a sample x sample image, same P x K, same kmax."""
     from oracle import gpa_oracle as orc
@@ -57,13 +57,13 @@ def cpu_baseline(kvecs, sigma, K_side, kmax, sample=1024):
     shape = (sample, sample)
     img = hex_moire(shape, kvecs, gaussian_bump_displacement(shape), noise=0.1, seed=7)
     kw = np.linalg.norm(kvecs, axis=1).mean() / 2.5
-    klists = explicit_klists(kvecs, kw, K_side, K_side)
+    klists = explicit_klists(kvecs, kw, knx, kny)
     t = time.perf_counter()
     orc.extract_displacement_field(img, kvecs, sigma=sigma, klists=klists, workers=cores)
     dt = time.perf_counter() - t
     return {'value': round(sample * sample / dt / 1e6, 4), 'unit': 'Mpixels/s', 'cores': cores, 'kind': 'port',
             'sample': '%dx%d image, 3 peaks x %d k-vectors + weighted unwrap kmax=%d, oracle/gpa_oracle.py with '
-                      'scipy.fft workers=%d, %.1f s' % (sample, sample, K_side * K_side, kmax, cores, dt)}
+                      'scipy.fft workers=%d, %.1f s' % (sample, sample, knx * kny, kmax, cores, dt)}
 
 
 def main():
@@ -73,6 +73,7 @@ def main():
     ap.add_argument('--warmup', type=int, default=3)
     ap.add_argument('--size', type=int, default=4096)
     ap.add_argument('--kside', type=int, default=4, help='k-vectors per peak = kside^2')
+    ap.add_argument('--kgrid', default=None, help='NXxNY candidate grid per peak (e.g. 4x2 for BASELINE config 2)')
     ap.add_argument('--dtype', default='f32', choices=['f32', 'f64'])
     ap.add_argument('--kmax', type=int, default=10)
     ap.add_argument('--no-cpu', action='store_true', help='skip the CPU baseline leg')
@@ -96,14 +97,15 @@ def main():
     dev = torch.device('cuda', local_rank if world > 1 else 0)
 
     n = args.size
-    P, K = 3, args.kside * args.kside
+    knx, kny = (int(v) for v in args.kgrid.split('x')) if args.kgrid else (args.kside, args.kside)
+    P, K = 3, knx * kny
     np_dt = np.float32 if args.dtype == 'f32' else np.float64
     t_dt = torch.float32 if args.dtype == 'f32' else torch.float64
     s = 4 if args.dtype == 'f32' else 8
     kvecs = hex_kvecs(0.1, 7.0)
     sigma = int(np.ceil(1 / np.linalg.norm(kvecs, axis=1).min()))
     kw = np.linalg.norm(kvecs, axis=1).mean() / 2.5
-    klists = np.stack(explicit_klists(kvecs, kw, args.kside, args.kside))
+    klists = np.stack(explicit_klists(kvecs, kw, knx, kny))
 
     # every rank owns one tile of a (world * n) x n synthetic image
     u_true = gaussian_bump_displacement((n, n))
@@ -185,7 +187,7 @@ def main():
                          'algorithmic_bytes_per_launch': dom_bytes, 'kernel_ms': round(float(stage[dom]), 4)},
         }
         if world == 1 and not args.no_cpu:
-            out['cpu_baseline'] = cpu_baseline(kvecs, sigma, args.kside, args.kmax)
+            out['cpu_baseline'] = cpu_baseline(kvecs, sigma, knx, kny, args.kmax)
         print(json.dumps(out), flush=True)
     plan.close()
     if world > 1:

@@ -268,9 +268,21 @@ __global__ __launch_bounds__(256) void pq_kernel(const T* __restrict__ z, const 
       const bool up = x > 0, dn = x + 1 < n0;
       if (dn) { load_p(x + 1, pd); load_w(x + 1, wd); }
       const size_t o = (size_t)x * n1 + y0;
-      const T pl = hasl ? comb(z[o - 1], pin[o - 1]) : T(0), pr = hasr ? comb(z[o + 4], pin[o + 4]) : T(0);
-      T wl = T(1), wr = T(1);
-      if (w) { if (hasl) { wl = w[o - 1]; wl *= wl; } if (hasr) { wr = w[o + 4]; wr *= wr; } }
+      // left / right neighbours come from the adjacent lanes' registers; only the two
+      // lanes at the ends of a wavefront have to go to memory
+      const int lane = threadIdx.x & 63;
+      T pl = __shfl_up(pc.v[3], 1), pr = __shfl_down(pc.v[0], 1);
+      T wl = __shfl_up(wc.v[3], 1), wr = __shfl_down(wc.v[0], 1);
+      if (lane == 0 && hasl) {
+        pl = comb(z[o - 1], pin[o - 1]);
+        wl = T(1);
+        if (w) { wl = w[o - 1]; wl *= wl; }
+      }
+      if (lane == 63 && hasr) {
+        pr = comb(z[o + 4], pin[o + 4]);
+        wr = T(1);
+        if (w) { wr = w[o + 4]; wr *= wr; }
+      }
       Vec4<T> qv;
 #pragma unroll
       for (int j = 0; j < 4; ++j) {
