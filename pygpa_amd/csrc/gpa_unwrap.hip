@@ -57,20 +57,42 @@ __device__ __forceinline__ T wrap_pi(T x) {
   return t - C2<T>::two_pi * floor(t / C2<T>::two_pi) - C2<T>::pi;
 }
 
-// block-wide sum of a double, result valid in thread 0
-__device__ __forceinline__ double block_sum(double v, double* sh) {
-  const int n = blockDim.x;
-  sh[threadIdx.x] = v;
-  __syncthreads();
-  int active = n;
-  while (active > 1) {
-    const int half = (active + 1) / 2;
-    if ((int)threadIdx.x < active - half) sh[threadIdx.x] += sh[threadIdx.x + half];
-    __syncthreads();
-    active = half;
-  }
-  return sh[0];
+// block-wide sum of a double (deterministic: fixed shuffle tree per wavefront, then a fixed
+// order over the wavefronts); the result is returned to every thread.  sh: >= 17 doubles.
+__device__ __forceinline__ double wave_sum(double v) {
+#pragma unroll
+  for (int off = 32; off > 0; off >>= 1) v += __shfl_down(v, off);
+  return v;
 }
+__device__ __forceinline__ double block_sum(double v, double* sh) {
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, nw = (blockDim.x + 63) >> 6;
+  v = wave_sum(v);
+  __syncthreads();   // sh may still be read from a previous call
+  if (lane == 0) sh[wave] = v;
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    double t = 0;
+    for (int i = 0; i < nw; ++i) t += sh[i];
+    sh[16] = t;
+  }
+  __syncthreads();
+  return sh[16];
+}
+
+// sum of n partial sums written by an EARLIER kernel, computed identically (same order) by
+// every workgroup that needs it: a consumer-side reduction that costs no launch
+__device__ __forceinline__ double reduce_partials(const double* __restrict__ part, int n, double* sh) {
+  double acc = 0;
+  for (int i = threadIdx.x; i < n; i += blockDim.x) acc += part[i];
+  return block_sum(acc, sh);
+}
+
+// Scalars of the fused power-of-two path (single writer = block 0 of the named kernel;
+// values a kernel both reads and replaces are double-buffered by iteration parity):
+//   scal[5] = ||r0||^2                    (scal_init_kernel)
+//   scal[8 + (it & 1)]  = rho of iteration it            (pq_kernel)
+//   scal[10 + (it & 1)] = smallest ||r||^2 up to it      (colsolve_kernel)
+//   flags[0] = completed updates k, flags[1] = done      (colsolve_kernel / final kernel)
 
 // ---------------------------------------------------------------------------
 // setup: r0 = div( WW * wrap(grad) ), phi = 0, partial ||r0||^2
@@ -129,6 +151,8 @@ __global__ void scal_init_kernel(const double* part, int nparts, double* scal, i
     scal[5] = tot;   // ||r0||^2
     scal[6] = tot;
     scal[7] = tot;   // smallest ||r||^2 seen
+    scal[10] = tot;
+    scal[11] = tot;
     scal[1] = 0.0;
     flags[0] = 0;
     flags[1] = tot == 0.0 ? 1 : 0;   // r == 0 everywhere: nothing to do (phase_unwrap.py:326)
@@ -224,12 +248,22 @@ constexpr int PQ_ROWS = 16;   // rows per workgroup band of pq_kernel
 template <class T>
 __global__ __launch_bounds__(256) void pq_kernel(const T* __restrict__ z, const T* __restrict__ pin,
                                                 T* __restrict__ pout, const T* __restrict__ w, int n0, int n1,
-                                                T* __restrict__ q, double* part, const double* scal,
-                                                const int* flags) {
+                                                T* __restrict__ q, double* part, double* scal,
+                                                const int* flags, const double* part_rho, int nrho, int it) {
   if (flags[1]) return;
   __shared__ double sh[256];
-  const bool first = flags[0] == 0;                  // first iteration: p = z (pin is uninitialised)
-  const T beta = first ? T(0) : (T)scal[4];
+  bool first;
+  T beta;
+  if (it >= 0) {
+    // fused path: rho = <r, z> from rowidct's partial sums, beta = rho / rho_previous
+    const double rho = reduce_partials(part_rho, nrho, sh);
+    first = it == 0;                                 // first iteration: p = z (pin is uninitialised)
+    beta = first ? T(0) : (T)(rho / scal[8 + ((it - 1) & 1)]);
+    if (blockIdx.x == 0 && blockIdx.y == 0 && threadIdx.x == 0) scal[8 + (it & 1)] = rho;
+  } else {
+    first = flags[0] == 0;
+    beta = first ? T(0) : (T)scal[4];
+  }
   auto comb = [&](T zv, T pv) { return first ? zv : zv + beta * pv; };
   // a workgroup owns a band of PQ_ROWS rows x 1024 columns and slides down it with the
   // previous / current / next row in registers: every row of z, p, w is read once
@@ -407,6 +441,106 @@ __global__ __launch_bounds__((RowGeom<T, LG>::THREADS)) void rowdct_kernel(const
   }
 }
 
+// fused path: apply the pending update of the previous iteration (alpha from the pq
+// kernel's partial sums), then DCT-II along axis 1 of the new residual
+//   r -= alpha q;  phi += alpha p;  partial ||r||^2;  Z = DCT(r)
+template <class T, int LG>
+__global__ __launch_bounds__((RowGeom<T, LG>::THREADS)) void rowdct_fused_kernel(
+    T* __restrict__ r, const T* __restrict__ q, const T* __restrict__ p, T* __restrict__ phi, int n0,
+    T* __restrict__ Z, const cpx<T>* __restrict__ twtab, const cpx<T>* __restrict__ wk, const int* flags,
+    const double* part_pq, int npq, double* part_norm, const double* scal, int it) {
+  if (flags[1]) return;
+  using F = WgFFT<T, LG>;
+  using D = WgDCT<T, LG>;
+  using G = RowGeom<T, LG>;
+  constexpr int TPF = F::TPF, N = F::L;
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  __shared__ double sh[RowGeom<T, LG>::THREADS];
+  const int tid = threadIdx.x % TPF, f = threadIdx.x / TPF;
+  cpx<T>* lds = reinterpret_cast<cpx<T>*>(smem) + f * G::RS;
+  const int pr = blockIdx.x * G::NF + f;
+  const bool valid = 2 * pr + 1 < n0;
+  const size_t oa = (size_t)(valid ? 2 * pr : 0) * N, ob = oa + N;
+  typename F::Twiddles tw;
+  F::load_twiddles(tw, twtab, tid);
+  cpx<T> x[16];
+  if (it > 0) {
+    const double pq = reduce_partials(part_pq, npq, sh);
+    const T alpha = (T)(scal[8 + ((it - 1) & 1)] / pq);   // phase_unwrap.py:343
+    // elementwise update with coalesced 16-byte accesses (4 consecutive pixels per thread and
+    // step); the new residual is also parked in LDS so the even/odd-permuted DCT input does
+    // not have to come back from memory with stride-2 accesses
+    double sq = 0;
+    for (int c0 = 4 * tid; c0 < N; c0 += 4 * TPF) {
+      Vec4<T> ra = *reinterpret_cast<const Vec4<T>*>(r + oa + c0), rb = *reinterpret_cast<const Vec4<T>*>(r + ob + c0);
+      const Vec4<T> qa = *reinterpret_cast<const Vec4<T>*>(q + oa + c0), qb = *reinterpret_cast<const Vec4<T>*>(q + ob + c0);
+      const Vec4<T> pa = *reinterpret_cast<const Vec4<T>*>(p + oa + c0), pb = *reinterpret_cast<const Vec4<T>*>(p + ob + c0);
+      Vec4<T> fa = *reinterpret_cast<const Vec4<T>*>(phi + oa + c0), fb = *reinterpret_cast<const Vec4<T>*>(phi + ob + c0);
+#pragma unroll
+      for (int j = 0; j < 4; ++j) {
+        ra.v[j] -= alpha * qa.v[j];
+        rb.v[j] -= alpha * qb.v[j];
+        fa.v[j] += alpha * pa.v[j];
+        fb.v[j] += alpha * pb.v[j];
+        sq += (double)ra.v[j] * (double)ra.v[j] + (double)rb.v[j] * (double)rb.v[j];
+        lds[F::pad(c0 + j)] = {ra.v[j], rb.v[j]};
+      }
+      if (valid) {
+        *reinterpret_cast<Vec4<T>*>(r + oa + c0) = ra;
+        *reinterpret_cast<Vec4<T>*>(r + ob + c0) = rb;
+        *reinterpret_cast<Vec4<T>*>(phi + oa + c0) = fa;
+        *reinterpret_cast<Vec4<T>*>(phi + ob + c0) = fb;
+      }
+    }
+    if (!valid) sq = 0;
+    const double tot = block_sum(sq, sh);   // (contains the barrier that publishes the LDS staging)
+    if (threadIdx.x == 0) part_norm[blockIdx.x] = tot;
+#pragma unroll
+    for (int i = 0; i < 16; ++i) x[i] = lds[F::pad(makhoul_src(tid + TPF * i, N))];
+    __syncthreads();
+  } else {
+#pragma unroll
+    for (int i = 0; i < 16; ++i) {
+      const int src = makhoul_src(tid + TPF * i, N);
+      x[i] = {r[oa + src], r[ob + src]};
+    }
+  }
+  F::forward(x, lds, tid, tw);
+  __syncthreads();
+  D::fwd_scatter(x, lds, tid);
+  __syncthreads();
+  D::fwd_gather(x, lds, tid, wk);
+  if (!valid) return;
+  T* za = Z + oa;
+  T* zb = Z + ob;
+#pragma unroll
+  for (int i = 0; i < 16; ++i) {
+    za[tid + TPF * i] = x[i].x;
+    zb[tid + TPF * i] = x[i].y;
+  }
+}
+
+// fused path, after the last iteration: the update that no further row kernel will apply
+template <class T>
+__global__ __launch_bounds__(256) void final_update_kernel(const T* __restrict__ p, const T* __restrict__ q,
+                                                          T* __restrict__ phi, T* __restrict__ r, size_t count,
+                                                          const double* scal, const double* part_pq, int npq,
+                                                          int it, const int* flags) {
+  if (flags[1]) return;
+  __shared__ double sh[256];
+  const double pq = reduce_partials(part_pq, npq, sh);
+  const T alpha = (T)(scal[8 + ((it - 1) & 1)] / pq);
+  for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < count; i += (size_t)gridDim.x * 256) {
+    phi[i] += alpha * p[i];
+    r[i] -= alpha * q[i];
+  }
+}
+__global__ void final_count_kernel(int* flags, int kmax) {
+  if (flags[1]) return;
+  flags[0] = kmax;
+  flags[1] = 1;
+}
+
 // columns: Z -> DCT-II along axis 0, divide by eigenvalues, DCT-III along axis 0 (in place)
 template <class T, int LG>
 __global__ __launch_bounds__((ColGeom<T, LG>::THREADS)) void colsolve_kernel(T* __restrict__ Z, int n1,
@@ -415,7 +549,9 @@ __global__ __launch_bounds__((ColGeom<T, LG>::THREADS)) void colsolve_kernel(T* 
                                                                           const T* __restrict__ ha,
                                                                           const T* __restrict__ ham,
                                                                           const T* __restrict__ hb,
-                                                                          const int* flags) {
+                                                                          int* flags, const double* part_norm,
+                                                                          int nnorm, int it, double eps,
+                                                                          double* scal) {
   if (flags[1]) return;
   using F = WgFFT<T, LG>;
   using D = WgDCT<T, LG>;
@@ -440,6 +576,22 @@ __global__ __launch_bounds__((ColGeom<T, LG>::THREADS)) void colsolve_kernel(T* 
     const Vec q = *reinterpret_cast<const Vec*>(Z + (size_t)row * n1 + yy);
 #pragma unroll
     for (int n = 0; n < NT; ++n) x[n][i] = q.v[n];
+  }
+  if (it > 0) {
+    // (placed after the tile loads have been issued so its latency hides behind them)
+    // fused path: the update of iteration it-1 was applied by this iteration's row kernel;
+    // every workgroup evaluates the reference's stopping test (phase_unwrap.py:348) on it
+    __shared__ double shn[ColGeom<T, LG>::THREADS];
+    const double tot = reduce_partials(part_norm, nnorm, shn);
+    const double best = scal[10 + ((it - 1) & 1)];
+    const bool stop = sqrt(tot) < eps * sqrt(scal[5]) || tot == 0.0 || !(tot == tot) || tot > 1e4 * best;
+    if (blockIdx.x == 0 && threadIdx.x == 0) {
+      flags[0] = it;                                   // updates completed
+      scal[6] = tot;
+      scal[10 + (it & 1)] = tot < best ? tot : best;
+      if (stop) flags[1] = 1;
+    }
+    if (stop) return;
   }
   F::template forward_multi<NT, CT>(x, lds, G::REGION, t, tw);
   __syncthreads();
@@ -851,7 +1003,8 @@ hipError_t run_rowidct(const Impl* w, int* nparts, hipStream_t s) {
   }
 }
 template <class T, int LG>
-hipError_t run_colsolve(const Impl* w, int compat, hipStream_t s) {
+hipError_t run_colsolve(const Impl* w, int compat, hipStream_t s, const double* part_norm = nullptr, int nnorm = 0,
+                        int it = 0, double eps = 0.0) {
   using G = ColGeom<T, LG>;
   if constexpr (!G::FITS) return hipErrorInvalidValue;
   else {
@@ -862,7 +1015,25 @@ hipError_t run_colsolve(const Impl* w, int compat, hipStream_t s) {
     const int npairs = w->n1 / 2, grid = (npairs + G::CC - 1) / G::CC;
     kern<<<grid, G::THREADS, G::LDS_BYTES, s>>>((T*)w->z, w->n1, (const cpx<T>*)w->tw0, (const cpx<T>*)w->wk0s,
                                                  (const T*)w->ha0[compat], (const T*)w->ham0[compat],
-                                                 (const T*)w->hb1[compat], w->flags);
+                                                 (const T*)w->hb1[compat], w->flags, part_norm, nnorm, it, eps, w->scal);
+    return hipGetLastError();
+  }
+}
+template <class T, int LG>
+hipError_t run_rowdct_fused(const Impl* w, const void* q, const void* p, void* phi, const double* part_pq, int npq,
+                            double* part_norm, int it, int* nnorm, hipStream_t s) {
+  using G = RowGeom<T, LG>;
+  if constexpr (!G::FITS) return hipErrorInvalidValue;
+  else {
+    auto kern = rowdct_fused_kernel<T, LG>;
+    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize,
+                                       (int)G::LDS_BYTES);
+    if (e != hipSuccess) return e;
+    const int npairs = w->n0 / 2, grid = (npairs + G::NF - 1) / G::NF;
+    *nnorm = grid;
+    kern<<<grid, G::THREADS, G::LDS_BYTES, s>>>((T*)w->r, (const T*)q, (const T*)p, (T*)phi, w->n0, (T*)w->z,
+                                                 (const cpx<T>*)w->tw1, (const cpx<T>*)w->wk1, w->flags, part_pq, npq,
+                                                 part_norm, w->scal, it);
     return hipGetLastError();
   }
 }
@@ -879,9 +1050,19 @@ hipError_t dispatch_rowidct(const Impl* w, int* nparts, hipStream_t s) {
 #undef CASE
   return hipErrorInvalidValue;
 }
-hipError_t dispatch_colsolve(const Impl* w, int compat, hipStream_t s) {
-#define CASE(LG) case LG: return w->dtype == 0 ? run_colsolve<float, LG>(w, compat, s) : run_colsolve<double, LG>(w, compat, s);
+hipError_t dispatch_colsolve(const Impl* w, int compat, hipStream_t s, const double* part_norm = nullptr,
+                             int nnorm = 0, int it = 0, double eps = 0.0) {
+#define CASE(LG) case LG: return w->dtype == 0 ? run_colsolve<float, LG>(w, compat, s, part_norm, nnorm, it, eps) \
+                                               : run_colsolve<double, LG>(w, compat, s, part_norm, nnorm, it, eps);
   switch (w->lg0) { GPA_FOR_LG(CASE) }
+#undef CASE
+  return hipErrorInvalidValue;
+}
+hipError_t dispatch_rowdct_fused(const Impl* w, const void* q, const void* p, void* phi, const double* part_pq, int npq,
+                                 double* part_norm, int it, int* nnorm, hipStream_t s) {
+#define CASE(LG) case LG: return w->dtype == 0 ? run_rowdct_fused<float, LG>(w, q, p, phi, part_pq, npq, part_norm, it, nnorm, s) \
+                                               : run_rowdct_fused<double, LG>(w, q, p, phi, part_pq, npq, part_norm, it, nnorm, s);
+  switch (w->lg1) { GPA_FOR_LG(CASE) }
 #undef CASE
   return hipErrorInvalidValue;
 }
@@ -1027,7 +1208,7 @@ hipError_t unwrap_workspace_create(int dtype, int n0, int n1, hipStream_t s, Unw
     if (e != hipSuccess) return e;
     bytes += npx * w->rsz;
   }
-  e = hipMalloc((void**)&w->scal, 8 * sizeof(double));
+  e = hipMalloc((void**)&w->scal, 16 * sizeof(double));
   if (e != hipSuccess) return e;
   e = hipMalloc((void**)&w->flags, 4 * sizeof(int));
   if (e != hipSuccess) return e;
@@ -1162,6 +1343,31 @@ static hipError_t run_pcg(Impl* w, const void* a, const void* b, const void* wei
                                      (T*)phi, w->part);
   scal_init_kernel<<<1, 256, 0, s>>>(w->part, np2, w->scal, w->flags);
   const bool vec4 = !w->generic && (n1 % 4) == 0;   // pq_kernel needs 16-byte aligned rows
+  if (vec4) {
+    // fused power-of-two path: 4 kernels per iteration, no scalar kernels.  The phi / r update
+    // of iteration it-1 rides in the row-DCT kernel of iteration it; the stopping test is
+    // evaluated by the column kernel from that kernel's partial norms.
+    double* part_rho = w->part;
+    double* part_pq = w->part + MAXPART;
+    double* part_norm = w->part + 2 * MAXPART;
+    int nnorm = 0;
+    T* pprev = nullptr;
+    for (int it = 0; it < kmax; ++it) {
+      if ((e = dispatch_rowdct_fused(w, w->q, pprev, phi, part_pq, npq, part_norm, it, &nnorm, s)) != hipSuccess) return e;
+      if ((e = dispatch_colsolve(w, compat, s, part_norm, nnorm, it, eps)) != hipSuccess) return e;
+      int nrow = 0;
+      if ((e = dispatch_rowidct(w, &nrow, s)) != hipSuccess) return e;
+      T* pin = (T*)((it & 1) ? w->p2 : w->p);
+      T* pout = (T*)((it & 1) ? w->p : w->p2);
+      pq_kernel<T><<<gpq, 256, 0, s>>>((const T*)w->z, pin, pout, (const T*)weight, n0, n1, (T*)w->q, part_pq, w->scal,
+                                       w->flags, part_rho, nrow, it);
+      pprev = pout;
+    }
+    final_update_kernel<T><<<gl, 256, 0, s>>>((const T*)pprev, (const T*)w->q, (T*)phi, (T*)w->r, npx, w->scal, part_pq,
+                                              npq, kmax, w->flags);
+    final_count_kernel<<<1, 1, 0, s>>>(w->flags, kmax);
+    return hipGetLastError();
+  }
   for (int it = 0; it < kmax; ++it) {
     int nrow = 0;
     if (w->generic) {
@@ -1179,7 +1385,7 @@ static hipError_t run_pcg(Impl* w, const void* a, const void* b, const void* wei
       T* pin = (T*)((it & 1) ? w->p2 : w->p);
       pcur = (T*)((it & 1) ? w->p : w->p2);
       pq_kernel<T><<<gpq, 256, 0, s>>>((const T*)w->z, pin, pcur, (const T*)weight, n0, n1, (T*)w->q,
-                                       w->part + MAXPART, w->scal, w->flags);
+                                       w->part + MAXPART, w->scal, w->flags, nullptr, 0, -1);
       scal_alpha_kernel<<<1, 256, 0, s>>>(w->part + MAXPART, npq, w->scal, w->flags);
     } else {
       pcur = (T*)w->p;
