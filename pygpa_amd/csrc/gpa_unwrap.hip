@@ -123,22 +123,60 @@ __device__ __forceinline__ T edge_y(const T* a, const T* b, const T* w, bool fro
   return d;
 }
 
+constexpr int SETUP_ROWS = 16;   // rows per workgroup band of setup_kernel
+
+// One thread per column, sliding down a band of SETUP_ROWS rows: every weighted edge value
+// is computed once (right edge and down edge of the thread's own pixel); the left edge
+// comes from the neighbouring lane, the upper edge from the previous row's registers.
 template <class T>
 __global__ __launch_bounds__(256) void setup_kernel(const T* __restrict__ a, const T* __restrict__ b,
                                                    const T* __restrict__ w, int from_psi, int n0, int n1,
                                                    T* __restrict__ r, T* __restrict__ phi, double* part) {
   __shared__ double sh[256];
-  const int x = blockIdx.x;
+  const int y = blockIdx.x * 256 + threadIdx.x;
+  const int x0 = blockIdx.y * SETUP_ROWS;
+  const int x1 = x0 + SETUP_ROWS < n0 ? x0 + SETUP_ROWS : n0;
+  const int lane = threadIdx.x & 63;
   double sq = 0;
-  for (int y = threadIdx.x; y < n1; y += 256) {
-    const T v = edge_x(a, w, from_psi, n1, x, y) - edge_x(a, w, from_psi, n1, x, y - 1) +
-                edge_y(a, b, w, from_psi, n0, n1, x, y) - edge_y(a, b, w, from_psi, n0, n1, x - 1, y);
-    r[(size_t)x * n1 + y] = v;
-    phi[(size_t)x * n1 + y] = T(0);
-    sq += (double)v * (double)v;
+  const bool act = y < n1;
+  const int yc = act ? y : n1 - 1;
+  auto ww = [&](int x, int yy) { const T t = w ? w[(size_t)x * n1 + yy] : T(1); return t * t; };
+  T fy_up = T(0), wc = T(0);
+  if (act) {
+    wc = ww(x0, yc);
+    if (x0 > 0) fy_up = edge_y(a, b, w, from_psi, n0, n1, x0 - 1, yc);
+  }
+  for (int x = x0; x < x1; ++x) {
+    // own right edge (x,y)-(x,y+1) and own down edge (x,y)-(x+1,y)
+    T fx = T(0), fy = T(0), wd = T(0);
+    if (act) {
+      if (yc + 1 < n1) {
+        T d = from_psi ? a[(size_t)x * n1 + yc + 1] - a[(size_t)x * n1 + yc] : a[(size_t)x * (n1 - 1) + yc];
+        d = wrap_pi(d);
+        if (w) { const T wr = ww(x, yc + 1); d *= wr < wc ? wr : wc; }
+        fx = d;
+      }
+      if (x + 1 < n0) {
+        T d = from_psi ? a[(size_t)(x + 1) * n1 + yc] - a[(size_t)x * n1 + yc] : b[(size_t)x * n1 + yc];
+        d = wrap_pi(d);
+        wd = ww(x + 1, yc);
+        if (w) d *= wd < wc ? wd : wc;
+        fy = d;
+      }
+    }
+    T fx_left = __shfl_up(fx, 1);
+    if (lane == 0) fx_left = (act && yc > 0) ? edge_x(a, w, from_psi, n1, x, yc - 1) : T(0);
+    if (act) {
+      const T v = fx - fx_left + fy - fy_up;
+      r[(size_t)x * n1 + yc] = v;
+      phi[(size_t)x * n1 + yc] = T(0);
+      sq += (double)v * (double)v;
+    }
+    fy_up = fy;
+    wc = wd;
   }
   const double tot = block_sum(sq, sh);
-  if (threadIdx.x == 0) part[blockIdx.x] = tot;
+  if (threadIdx.x == 0) part[blockIdx.y * gridDim.x + blockIdx.x] = tot;
 }
 
 // scalar kernels (one block each) -------------------------------------------
@@ -1339,9 +1377,12 @@ static hipError_t run_pcg(Impl* w, const void* a, const void* b, const void* wei
   const double eps_floor = sizeof(T) == 4 ? 4e-6 : 0.0;
   if (eps < eps_floor) eps = eps_floor;
   hipError_t e;
-  setup_kernel<T><<<g2, 256, 0, s>>>((const T*)a, (const T*)b, (const T*)weight, from_psi ? 1 : 0, n0, n1, (T*)w->r,
-                                     (T*)phi, w->part);
-  scal_init_kernel<<<1, 256, 0, s>>>(w->part, np2, w->scal, w->flags);
+  const dim3 gsu((n1 + 255) / 256, (n0 + SETUP_ROWS - 1) / SETUP_ROWS);
+  const int nsu = gsu.x * gsu.y;
+  if (nsu > MAXPART) return hipErrorInvalidValue;
+  setup_kernel<T><<<gsu, 256, 0, s>>>((const T*)a, (const T*)b, (const T*)weight, from_psi ? 1 : 0, n0, n1, (T*)w->r,
+                                      (T*)phi, w->part);
+  scal_init_kernel<<<1, 256, 0, s>>>(w->part, nsu, w->scal, w->flags);
   const bool vec4 = !w->generic && (n1 % 4) == 0;   // pq_kernel needs 16-byte aligned rows
   if (vec4) {
     // fused power-of-two path: 4 kernels per iteration, no scalar kernels.  The phi / r update
