@@ -134,6 +134,9 @@ struct gpa_plan {
   void* d_u = nullptr;            // 2 x n0 x n1
   double* d_kmat = nullptr;       // [max_peaks][2]
   UnwrapWorkspace uw{};
+  UnwrapWorkspace uw2{};          // second workspace + stream: the two components of u unwrap concurrently
+  hipStream_t stream2 = nullptr;
+  hipEvent_t ev_fork = nullptr, ev_join = nullptr;
   BlueAxis bx0{}, bx1{};          // Bluestein tables for gpa_per_dft, built on first use
   // timing
   hipEvent_t ev0 = nullptr, ev1 = nullptr;
@@ -349,6 +352,10 @@ void gpa_plan_destroy(gpa_plan* p) {
   for (void* b : bufs)
     if (b) hipFree(b);
   unwrap_workspace_destroy(&p->uw);
+  unwrap_workspace_destroy(&p->uw2);
+  if (p->stream2) { hipStreamSynchronize(p->stream2); hipStreamDestroy(p->stream2); }
+  if (p->ev_fork) hipEventDestroy(p->ev_fork);
+  if (p->ev_join) hipEventDestroy(p->ev_join);
   blue_axis_destroy(&p->bx0);
   blue_axis_destroy(&p->bx1);
   if (p->h_k) hipHostFree(p->h_k);
@@ -582,10 +589,29 @@ int gpa_extract_displacement_field_dev(gpa_plan* p, const void* image, const dou
   if (p->profiling) HIP_TRY(hipEventRecord(p->stage_ev[4], p->stream));
   const size_t nx = (size_t)p->n0 * (p->n1 - 1), ny = (size_t)(p->n0 - 1) * p->n1;
   int iters[2] = {0, 0};
-  for (int c = 0; c < 2; ++c) {
-    hipError_t e = unwrap_run(&p->uw, (char*)p->d_dudx + c * nx * p->rsz, (char*)p->d_dudy + c * ny * p->rsz,
-                              p->d_wnorm, false, kmax, 1e-9, true, (char*)u + c * npx * p->rsz, &iters[c],
-                              p->stream);
+  if (!p->stream2) {
+    // the two displacement components are independent solves: give the second one its own
+    // workspace and stream so the latency-bound kernels of one fill the gaps of the other
+    HIP_TRY(hipStreamCreateWithFlags(&p->stream2, hipStreamNonBlocking));
+    HIP_TRY(hipEventCreateWithFlags(&p->ev_fork, hipEventDisableTiming));
+    HIP_TRY(hipEventCreateWithFlags(&p->ev_join, hipEventDisableTiming));
+    size_t b2 = 0;
+    hipError_t e2 = unwrap_workspace_create(p->dtype, p->n0, p->n1, p->stream2, &p->uw2, &b2);
+    if (e2 != hipSuccess) return fail(GPA_ERR_HIP, std::string("second unwrap workspace: ") + hipGetErrorString(e2));
+    p->ws_bytes += b2;
+  }
+  HIP_TRY(hipEventRecord(p->ev_fork, p->stream));
+  HIP_TRY(hipStreamWaitEvent(p->stream2, p->ev_fork, 0));
+  {
+    hipError_t e = unwrap_enqueue(&p->uw, p->d_dudx, p->d_dudy, p->d_wnorm, false, kmax, 1e-9, true, u, p->stream);
+    if (e == hipSuccess)
+      e = unwrap_enqueue(&p->uw2, (char*)p->d_dudx + nx * p->rsz, (char*)p->d_dudy + ny * p->rsz, p->d_wnorm, false,
+                         kmax, 1e-9, true, (char*)u + npx * p->rsz, p->stream2);
+    if (e != hipSuccess) return fail(GPA_ERR_HIP, std::string("unwrap: ") + hipGetErrorString(e));
+    HIP_TRY(hipEventRecord(p->ev_join, p->stream2));
+    HIP_TRY(hipStreamWaitEvent(p->stream, p->ev_join, 0));
+    e = unwrap_finish(&p->uw2, &iters[1], p->stream2);
+    if (e == hipSuccess) e = unwrap_finish(&p->uw, &iters[0], p->stream);
     if (e != hipSuccess) return fail(GPA_ERR_HIP, std::string("unwrap: ") + hipGetErrorString(e));
   }
   if (p->profiling) {

@@ -39,4 +39,10 @@ hipError_t per_pack(int dtype, const void* image, int n0, int n1, void* Z, void*
 hipError_t per_combine(int dtype, const void* Uhat, const void* D0, const void* D1, int n0, int n1, void* out,
                        hipStream_t s);
 
+// the two halves of unwrap_run, for callers that overlap several unwraps on different streams:
+// enqueue everything without synchronising, then fetch the iteration count (synchronises s)
+hipError_t unwrap_enqueue(UnwrapWorkspace* ws, const void* a, const void* b, const void* weight, bool from_psi,
+                          int kmax, double eps, bool axes_compat, void* phi, hipStream_t s);
+hipError_t unwrap_finish(UnwrapWorkspace* ws, int* iters_out, hipStream_t s);
+
 }  // namespace gpa

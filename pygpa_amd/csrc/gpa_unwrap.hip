@@ -1442,20 +1442,31 @@ static hipError_t run_pcg(Impl* w, const void* a, const void* b, const void* wei
   return hipGetLastError();
 }
 
-hipError_t unwrap_run(UnwrapWorkspace* ws, const void* a, const void* b, const void* weight, bool from_psi, int kmax,
-                      double eps, bool axes_compat, void* phi, int* iters_out, hipStream_t s) {
+hipError_t unwrap_enqueue(UnwrapWorkspace* ws, const void* a, const void* b, const void* weight, bool from_psi,
+                          int kmax, double eps, bool axes_compat, void* phi, hipStream_t s) {
   Impl* w = (Impl*)ws->impl;
   if (!w || !w->supported) return hipErrorNotSupported;
-  hipError_t e = w->dtype == 0 ? run_pcg<float>(w, a, b, weight, from_psi, kmax, eps, axes_compat ? 1 : 0, phi, s)
-                               : run_pcg<double>(w, a, b, weight, from_psi, kmax, eps, axes_compat ? 1 : 0, phi, s);
-  if (e != hipSuccess) return e;
+  return w->dtype == 0 ? run_pcg<float>(w, a, b, weight, from_psi, kmax, eps, axes_compat ? 1 : 0, phi, s)
+                       : run_pcg<double>(w, a, b, weight, from_psi, kmax, eps, axes_compat ? 1 : 0, phi, s);
+}
+
+hipError_t unwrap_finish(UnwrapWorkspace* ws, int* iters_out, hipStream_t s) {
+  Impl* w = (Impl*)ws->impl;
+  if (!w || !w->supported) return hipErrorNotSupported;
   int it = 0;
-  e = hipMemcpyAsync(&it, w->flags, sizeof(int), hipMemcpyDeviceToHost, s);
+  hipError_t e = hipMemcpyAsync(&it, w->flags, sizeof(int), hipMemcpyDeviceToHost, s);
   if (e != hipSuccess) return e;
   e = hipStreamSynchronize(s);
   if (e != hipSuccess) return e;
   if (iters_out) *iters_out = it;
   return hipSuccess;
+}
+
+hipError_t unwrap_run(UnwrapWorkspace* ws, const void* a, const void* b, const void* weight, bool from_psi, int kmax,
+                      double eps, bool axes_compat, void* phi, int* iters_out, hipStream_t s) {
+  hipError_t e = unwrap_enqueue(ws, a, b, weight, from_psi, kmax, eps, axes_compat, phi, s);
+  if (e != hipSuccess) return e;
+  return unwrap_finish(ws, iters_out, s);
 }
 
 // ---------------------------------------------------------------------------
