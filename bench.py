@@ -77,6 +77,8 @@ def main():
     ap.add_argument('--dtype', default='f32', choices=['f32', 'f64'])
     ap.add_argument('--kmax', type=int, default=10)
     ap.add_argument('--no-cpu', action='store_true', help='skip the CPU baseline leg')
+    ap.add_argument('--inflight', type=int, default=1,
+                    help='images in flight per GPU (one plan each): 1 = strictly one after the other')
     args = ap.parse_args()
 
     import torch   # first: libgpa_hip.so then binds to the HIP runtime torch already loaded
@@ -111,34 +113,53 @@ def main():
     u_true = gaussian_bump_displacement((n, n))
     img = hex_moire((n, n), kvecs, u_true, noise=0.1, seed=100 + rank, dtype=np_dt)
     d_img = torch.from_numpy(img).to(dev)
-    d_u = torch.empty((2, n, n), dtype=t_dt, device=dev)
-    d_all = torch.empty((world, 2, n, n), dtype=t_dt, device=dev) if world > 1 else None
+    depth = max(1, args.inflight)
+    # one plan (workspace + streams) per image in flight: consecutive steps are independent
+    # images, so the VALU-bound sweep of step i+1 overlaps the bandwidth-bound unwrap of step i
+    plans = [_lib.Plan((n, n), P * K, np_dt, device=dev.index) for _ in range(depth)]
+    d_us = [torch.empty((2, n, n), dtype=t_dt, device=dev) for _ in range(depth)]
+    d_alls = [torch.empty((world, 2, n, n), dtype=t_dt, device=dev) for _ in range(depth)] if world > 1 else None
+    gathered = [None] * depth
+    plan = plans[0]
+    d_u = d_us[0]
 
-    plan = _lib.Plan((n, n), P * K, np_dt, device=dev.index)
+    def gather(j):
+        # stitch the tiles' fields of the step that ran on plan j (RCCL all_gather over xGMI)
+        plans[j].sync()
+        dist.all_gather_into_tensor(d_alls[j], d_us[j])
+        ev = torch.cuda.Event()
+        ev.record()
+        gathered[j] = ev
 
-    def step():
-        it = plan.extract_displacement_field_dev(d_img.data_ptr(), kvecs, klists, sigma, 2 * sigma, args.kmax,
-                                                 d_u.data_ptr())
+    def run(nsteps):
+        for i in range(nsteps):
+            j = i % depth
+            if gathered[j] is not None:        # the collective that reads d_us[j] must be done before it is rewritten
+                gathered[j].synchronize()
+                gathered[j] = None
+            plans[j].extract_displacement_field_async(d_img.data_ptr(), kvecs, klists, sigma, 2 * sigma, args.kmax,
+                                                      d_us[j].data_ptr())
+            if world > 1 and i >= depth - 1:
+                gather((i - (depth - 1)) % depth)
         if world > 1:
-            dist.all_gather_into_tensor(d_all, d_u)
-        return it
+            for i in range(max(0, nsteps - (depth - 1)), nsteps):
+                gather(i % depth)
 
     def fence():
-        plan.sync()
+        for pl in plans:
+            pl.sync()
         torch.cuda.synchronize()
         if world > 1:
             dist.barrier()
             torch.cuda.synchronize()
 
-    iters = (args.kmax, args.kmax)
-    for _ in range(args.warmup):
-        iters = step()
+    run(args.warmup)
     fence()
     t0 = time.perf_counter()
-    for _ in range(args.steps):
-        iters = step()
+    run(args.steps)
     fence()
     dt = time.perf_counter() - t0
+    iters = plan.last_iters()
     if world > 1:
         t = torch.tensor([dt], dtype=torch.float64, device=dev)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
@@ -179,7 +200,8 @@ def main():
             'config': {'workload': '%dx%d synthetic hex moire per GPU, 3 Bragg peaks x %d k-vectors, sigma=%d, '
                                    'weighted DCT-PCG unwrap kmax=%d (BASELINE.json configs[2])' % (n, n, K, sigma, args.kmax),
                        'image': [n, n], 'peaks': P, 'kvectors_per_peak': K, 'unwrap_iters': list(iters),
-                       'sharding': 'one image tile per rank' + (', RCCL all_gather of u' if world > 1 else '')},
+                       'sharding': 'one image tile per rank' + (', RCCL all_gather of u' if world > 1 else ''),
+                       'images_in_flight_per_gpu': depth},
             'algorithmic_GBps_whole_step': round(ab['total'] / (ms_per_step * 1e-3) / 1e9, 1),
             'stage_ms': {names[i]: round(float(stage[i]), 4) for i in range(5)},
             'roofline': {'bound': 'hbm', 'kernel': names[dom], 'achieved': round(achieved, 1), 'peak': HBM_PEAK_GBS,
@@ -189,7 +211,8 @@ def main():
         if world == 1 and not args.no_cpu:
             out['cpu_baseline'] = cpu_baseline(kvecs, sigma, knx, kny, args.kmax)
         print(json.dumps(out), flush=True)
-    plan.close()
+    for pl in plans:
+        pl.close()
     if world > 1:
         dist.barrier()
         dist.destroy_process_group()

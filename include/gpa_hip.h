@@ -145,6 +145,16 @@ int gpa_extract_displacement_field_dev(gpa_plan* plan, const void* image, const 
                                        int mask_border, int kmax, void* u, void* lockins,
                                        int32_t* kidx, int* iters_out);
 
+/* Asynchronous form of the fused driver (device pointers): enqueues everything on the plan's
+ * streams and returns without waiting, so that several plans (one per image in flight) overlap
+ * on the GPU -- the VALU-bound sweep of one image runs beside the bandwidth-bound unwrap of
+ * another.  Calls on ONE plan still execute in order.  gpa_plan_sync() waits for completion,
+ * gpa_last_iters() (which synchronises) returns the two PCG iteration counts of the last call. */
+int gpa_extract_displacement_field_async(gpa_plan* plan, const void* image, const double* kvecs, int P,
+                                         const double* klists, int K, double sigma, int mask_border,
+                                         int kmax, void* u, void* lockins, int32_t* kidx);
+int gpa_last_iters(gpa_plan* plan, int* iters2);
+
 /* tile stage of the multi-GPU path: sweep + phases/weights + per-pixel least squares of
  * extract_displacement_field (:919-926, :234-237) WITHOUT the unwrap; the gradient tiles of all
  * ranks are stitched and unwrapped once globally.  The image is used

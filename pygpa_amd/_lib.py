@@ -41,6 +41,8 @@ SIGNATURES = {
     'gpa_unwrap': (_i, [_vp, _vp, _vp, _i, _d, _i, _vp, _vp]),
     'gpa_extract_displacement_field': (_i, [_vp, _vp, _vp, _i, _vp, _i, _d, _i, _i, _vp, _vp, _vp, _vp]),
     'gpa_extract_displacement_field_dev': (_i, [_vp, _vp, _vp, _i, _vp, _i, _d, _i, _i, _vp, _vp, _vp, _vp]),
+    'gpa_extract_displacement_field_async': (_i, [_vp, _vp, _vp, _i, _vp, _i, _d, _i, _i, _vp, _vp, _vp]),
+    'gpa_last_iters': (_i, [_vp, _vp]),
     'gpa_extract_gradients': (_i, [_vp, _vp, _vp, _i, _vp, _i, _d, _i, _vp, _vp, _vp]),
     'gpa_per_dft': (_i, [_vp, _vp, _vp]),
     'gpa_timer_start': (_i, [_vp]),
@@ -258,6 +260,22 @@ class Plan:
                                                           _ptr(u_ptr), _ptr(lockins_ptr), _ptr(kidx_ptr), iters),
               'gpa_extract_displacement_field_dev')
         return iters[0], iters[1]
+
+    def extract_displacement_field_async(self, image_ptr, kvecs, klists, sigma, mask_border, kmax, u_ptr,
+                                         lockins_ptr=None, kidx_ptr=None):
+        """enqueue only; pair with sync() / last_iters()"""
+        kvecs = _f64(kvecs).reshape(-1, 2)
+        P = len(kvecs)
+        klists = _f64(klists).reshape(P, -1, 2)
+        check(self.lib.gpa_extract_displacement_field_async(self.handle, _ptr(image_ptr), _ptr(kvecs), P, _ptr(klists),
+                                                            klists.shape[1], float(sigma), int(mask_border), int(kmax),
+                                                            _ptr(u_ptr), _ptr(lockins_ptr), _ptr(kidx_ptr)),
+              'gpa_extract_displacement_field_async')
+
+    def last_iters(self):
+        it = (C.c_int * 2)()
+        check(self.lib.gpa_last_iters(self.handle, it), 'gpa_last_iters')
+        return it[0], it[1]
 
     def timer_start(self):
         check(self.lib.gpa_timer_start(self.handle), 'gpa_timer_start')

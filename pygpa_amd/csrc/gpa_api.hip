@@ -117,6 +117,8 @@ struct gpa_plan {
   double* d_kr = nullptr;
   double* d_pw = nullptr;         // [max_batch] distinct wx values (x-planes)
   int last_planes = 0;
+  std::vector<double> staged_kl, staged_kr, staged_kmat;   // what the device tables currently hold
+  int* h_iters = nullptr;         // pinned: iteration counts of the last (possibly asynchronous) driver call
   double* h_k = nullptr;          // pinned staging, 4 * max_batch doubles
   void* d_image = nullptr;        // staging for host-pointer entry points
   void* d_mean = nullptr;
@@ -228,7 +230,8 @@ static int plan_build(gpa_plan* p) {
   TRY(dmalloc(p, &p->tb.dy, (size_t)B * p->n1 * p->csz));
   TRY(dmalloc(p, (void**)&p->d_kl, (size_t)B * 2 * sizeof(double)));
   TRY(dmalloc(p, (void**)&p->d_kr, (size_t)B * 2 * sizeof(double)));
-  HIP_TRY(hipHostMalloc((void**)&p->h_k, (size_t)B * 6 * sizeof(double) + 64));
+  HIP_TRY(hipHostMalloc((void**)&p->h_k, ((size_t)B * 6 + 32) * sizeof(double)));
+  HIP_TRY(hipHostMalloc((void**)&p->h_iters, 4 * sizeof(int)));
   TRY(dmalloc(p, &p->d_image, npx * p->rsz));
   TRY(dmalloc(p, &p->d_mean, 16));
   TRY(dmalloc(p, (void**)&p->d_scratch, 4096 * sizeof(double)));
@@ -265,6 +268,17 @@ static int ensure_filters(gpa_plan* p, double sigma) {
 // x-planes (one per distinct wx, see SweepTables) and build the carrier tables.
 // Returns the number of x-planes in *planes_out.
 static int stage_kvectors(gpa_plan* p, const double* kl, const double* kr_per_b, int B, int* planes_out) {
+  // same candidates as the previous call (a sequence of images analysed with one k-list):
+  // the carrier tables on the device are still valid, nothing to copy and nothing to wait for
+  if ((int)p->staged_kl.size() == 2 * B && memcmp(p->staged_kl.data(), kl, (size_t)B * 2 * sizeof(double)) == 0 &&
+      memcmp(p->staged_kr.data(), kr_per_b, (size_t)B * 2 * sizeof(double)) == 0) {
+    *planes_out = p->last_planes;
+    return GPA_OK;
+  }
+  // the pinned staging buffer may still feed copies of an earlier asynchronous call
+  HIP_TRY(hipStreamSynchronize(p->stream));
+  p->staged_kl.assign(kl, kl + 2 * (size_t)B);
+  p->staged_kr.assign(kr_per_b, kr_per_b + 2 * (size_t)B);
   double* h_kl = p->h_k;
   double* h_kr = p->h_k + 2 * (size_t)B;
   double* h_pw = p->h_k + 4 * (size_t)B;
@@ -288,6 +302,19 @@ static int stage_kvectors(gpa_plan* p, const double* kl, const double* kr_per_b,
   HIP_TRY(hipStreamSynchronize(p->stream));
   p->last_planes = Bx;
   *planes_out = Bx;
+  return GPA_OK;
+}
+
+// 2 pi kvecs for the per-pixel solves, re-staged only when the peaks change
+static int stage_kmat(gpa_plan* p, const double* kvecs, int P) {
+  std::vector<double> km((size_t)2 * P);
+  for (int i = 0; i < 2 * P; ++i) km[i] = 2.0 * M_PI * kvecs[i];
+  if (km == p->staged_kmat) return GPA_OK;
+  HIP_TRY(hipStreamSynchronize(p->stream));
+  p->staged_kmat = km;
+  double* h = p->h_k + 6 * (size_t)p->max_batch;
+  memcpy(h, km.data(), km.size() * sizeof(double));
+  HIP_TRY(hipMemcpyAsync(p->d_kmat, h, km.size() * sizeof(double), hipMemcpyHostToDevice, p->stream));
   return GPA_OK;
 }
 
@@ -359,6 +386,7 @@ void gpa_plan_destroy(gpa_plan* p) {
   blue_axis_destroy(&p->bx0);
   blue_axis_destroy(&p->bx1);
   if (p->h_k) hipHostFree(p->h_k);
+  if (p->h_iters) hipHostFree(p->h_iters);
   if (p->ev0) hipEventDestroy(p->ev0);
   if (p->ev1) hipEventDestroy(p->ev1);
   for (auto e : p->stage_ev)
@@ -370,6 +398,7 @@ void gpa_plan_destroy(gpa_plan* p) {
 int gpa_plan_sync(gpa_plan* p) {
   if (!p) return fail(GPA_ERR_ARG, "null plan");
   HIP_TRY(hipStreamSynchronize(p->stream));
+  if (p->stream2) HIP_TRY(hipStreamSynchronize(p->stream2));
   return GPA_OK;
 }
 size_t gpa_plan_workspace_bytes(const gpa_plan* p) { return p ? p->ws_bytes : 0; }
@@ -482,9 +511,7 @@ int gpa_reconstruct_grad_dev(gpa_plan* p, const void* lockin, const double* kvec
   if (!p || !lockin || !kvecs || !dudx || !dudy) return fail(GPA_ERR_ARG, "gpa_reconstruct_grad: null argument");
   if (P < 2 || P > p->max_peaks) return fail(GPA_ERR_STATE, "gpa_reconstruct_grad: need 2 <= P <= 8");
   HIP_TRY(hipSetDevice(p->device));
-  for (int i = 0; i < 2 * P; ++i) p->h_k[i] = 2.0 * M_PI * kvecs[i];
-  HIP_TRY(hipMemcpyAsync(p->d_kmat, p->h_k, (size_t)2 * P * sizeof(double), hipMemcpyHostToDevice, p->stream));
-  HIP_TRY(hipStreamSynchronize(p->stream));
+  TRY(stage_kmat(p, kvecs, P));
   HIP_TRY(launch_reconstruct(p->dtype, lockin, p->d_kmat, P, p->n0, p->n1, mask_border, dudx, dudy, wnorm,
                              p->stream));
   return GPA_OK;
@@ -513,8 +540,7 @@ int gpa_weighted_lstsq(gpa_plan* p, const void* b, const void* weights, const do
   // staging: b in d_lockin (P complex planes hold 2P real ones), weights in Tbuf
   HIP_TRY(hipMemcpyAsync(p->d_lockin, b, (size_t)P * npx * p->rsz, hipMemcpyHostToDevice, p->stream));
   HIP_TRY(hipMemcpyAsync(p->Tbuf, weights, (size_t)P * npx * p->rsz, hipMemcpyHostToDevice, p->stream));
-  for (int i = 0; i < 2 * P; ++i) p->h_k[i] = 2.0 * M_PI * kvecs[i];
-  HIP_TRY(hipMemcpyAsync(p->d_kmat, p->h_k, (size_t)2 * P * sizeof(double), hipMemcpyHostToDevice, p->stream));
+  TRY(stage_kmat(p, kvecs, P));
   HIP_TRY(launch_wlstsq(p->dtype, p->d_lockin, p->Tbuf, p->d_kmat, P, npx, p->d_u, p->stream));
   HIP_TRY(hipMemcpyAsync(out, p->d_u, 2 * npx * p->rsz, hipMemcpyDeviceToHost, p->stream));
   HIP_TRY(hipStreamSynchronize(p->stream));
@@ -569,9 +595,9 @@ int gpa_unwrap(gpa_plan* p, const void* psi, const void* weight, int kmax, doubl
 }
 
 // ---- fused driver --------------------------------------------------------------
-int gpa_extract_displacement_field_dev(gpa_plan* p, const void* image, const double* kvecs, int P,
-                                       const double* klists, int K, double sigma, int mask_border, int kmax,
-                                       void* u, void* lockins, int32_t* kidx, int* iters_out) {
+// enqueue the whole driver on the plan's streams without any host synchronisation
+static int extract_enqueue(gpa_plan* p, const void* image, const double* kvecs, int P, const double* klists, int K,
+                           double sigma, int mask_border, int kmax, void* u, void* lockins, int32_t* kidx) {
   if (!p || !image || !kvecs || !klists || !u) return fail(GPA_ERR_ARG, "gpa_extract_displacement_field: null argument");
   if (P < 2 || P > p->max_peaks) return fail(GPA_ERR_STATE, "gpa_extract_displacement_field: need 2 <= P <= 8");
   if (K < 1 || P * K > p->max_batch) return fail(GPA_ERR_STATE, "gpa_extract_displacement_field: P*K exceeds max_batch");
@@ -582,13 +608,11 @@ int gpa_extract_displacement_field_dev(gpa_plan* p, const void* image, const dou
   HIP_TRY(launch_mean(p->dtype, image, npx, p->d_scratch, p->d_mean, p->stream));
   void* lk = lockins ? lockins : p->d_lockin;
   TRY(sweep_peaks_dev(p, image, p->d_mean, kvecs, P, klists, K, sigma, lk, kidx));
-  for (int i = 0; i < 2 * P; ++i) p->h_k[i] = 2.0 * M_PI * kvecs[i];
-  HIP_TRY(hipMemcpyAsync(p->d_kmat, p->h_k, (size_t)2 * P * sizeof(double), hipMemcpyHostToDevice, p->stream));
+  TRY(stage_kmat(p, kvecs, P));
   HIP_TRY(launch_reconstruct(p->dtype, lk, p->d_kmat, P, p->n0, p->n1, mask_border, p->d_dudx, p->d_dudy,
                              p->d_wnorm, p->stream));
   if (p->profiling) HIP_TRY(hipEventRecord(p->stage_ev[4], p->stream));
   const size_t nx = (size_t)p->n0 * (p->n1 - 1), ny = (size_t)(p->n0 - 1) * p->n1;
-  int iters[2] = {0, 0};
   if (!p->stream2) {
     // the two displacement components are independent solves: give the second one its own
     // workspace and stream so the latency-bound kernels of one fill the gaps of the other
@@ -602,24 +626,41 @@ int gpa_extract_displacement_field_dev(gpa_plan* p, const void* image, const dou
   }
   HIP_TRY(hipEventRecord(p->ev_fork, p->stream));
   HIP_TRY(hipStreamWaitEvent(p->stream2, p->ev_fork, 0));
-  {
-    hipError_t e = unwrap_enqueue(&p->uw, p->d_dudx, p->d_dudy, p->d_wnorm, false, kmax, 1e-9, true, u, p->stream);
-    if (e == hipSuccess)
-      e = unwrap_enqueue(&p->uw2, (char*)p->d_dudx + nx * p->rsz, (char*)p->d_dudy + ny * p->rsz, p->d_wnorm, false,
-                         kmax, 1e-9, true, (char*)u + npx * p->rsz, p->stream2);
-    if (e != hipSuccess) return fail(GPA_ERR_HIP, std::string("unwrap: ") + hipGetErrorString(e));
-    HIP_TRY(hipEventRecord(p->ev_join, p->stream2));
-    HIP_TRY(hipStreamWaitEvent(p->stream, p->ev_join, 0));
-    e = unwrap_finish(&p->uw2, &iters[1], p->stream2);
-    if (e == hipSuccess) e = unwrap_finish(&p->uw, &iters[0], p->stream);
-    if (e != hipSuccess) return fail(GPA_ERR_HIP, std::string("unwrap: ") + hipGetErrorString(e));
-  }
-  if (p->profiling) {
-    HIP_TRY(hipEventRecord(p->stage_ev[5], p->stream));
-    HIP_TRY(hipEventSynchronize(p->stage_ev[5]));
+  hipError_t e = unwrap_enqueue(&p->uw, p->d_dudx, p->d_dudy, p->d_wnorm, false, kmax, 1e-9, true, u, p->stream);
+  if (e == hipSuccess)
+    e = unwrap_enqueue(&p->uw2, (char*)p->d_dudx + nx * p->rsz, (char*)p->d_dudy + ny * p->rsz, p->d_wnorm, false,
+                       kmax, 1e-9, true, (char*)u + npx * p->rsz, p->stream2);
+  if (e == hipSuccess) e = unwrap_fetch_iters(&p->uw, &p->h_iters[0], p->stream);
+  if (e == hipSuccess) e = unwrap_fetch_iters(&p->uw2, &p->h_iters[1], p->stream2);
+  if (e != hipSuccess) return fail(GPA_ERR_HIP, std::string("unwrap: ") + hipGetErrorString(e));
+  HIP_TRY(hipEventRecord(p->ev_join, p->stream2));
+  HIP_TRY(hipStreamWaitEvent(p->stream, p->ev_join, 0));
+  if (p->profiling) HIP_TRY(hipEventRecord(p->stage_ev[5], p->stream));
+  return GPA_OK;
+}
+
+int gpa_extract_displacement_field_async(gpa_plan* p, const void* image, const double* kvecs, int P,
+                                         const double* klists, int K, double sigma, int mask_border, int kmax,
+                                         void* u, void* lockins, int32_t* kidx) {
+  return extract_enqueue(p, image, kvecs, P, klists, K, sigma, mask_border, kmax, u, lockins, kidx);
+}
+
+int gpa_last_iters(gpa_plan* p, int* iters2) {
+  if (!p || !iters2) return fail(GPA_ERR_ARG, "null argument");
+  HIP_TRY(hipStreamSynchronize(p->stream));
+  iters2[0] = p->h_iters[0];
+  iters2[1] = p->h_iters[1];
+  return GPA_OK;
+}
+
+int gpa_extract_displacement_field_dev(gpa_plan* p, const void* image, const double* kvecs, int P,
+                                       const double* klists, int K, double sigma, int mask_border, int kmax,
+                                       void* u, void* lockins, int32_t* kidx, int* iters_out) {
+  TRY(extract_enqueue(p, image, kvecs, P, klists, K, sigma, mask_border, kmax, u, lockins, kidx));
+  HIP_TRY(hipStreamSynchronize(p->stream));
+  if (p->profiling)
     for (int i = 0; i < 5; ++i) hipEventElapsedTime(&p->stage_ms[i], p->stage_ev[i], p->stage_ev[i + 1]);
-  }
-  if (iters_out) { iters_out[0] = iters[0]; iters_out[1] = iters[1]; }
+  if (iters_out) { iters_out[0] = p->h_iters[0]; iters_out[1] = p->h_iters[1]; }
   return GPA_OK;
 }
 
@@ -651,8 +692,7 @@ int gpa_extract_gradients(gpa_plan* p, const void* image, const double* kvecs, i
   // no mean subtraction here: a tile must be offset by the mean of the WHOLE image
   // (geometric_phase_analysis.py:919), which only the caller knows
   TRY(sweep_peaks_dev(p, p->d_image, nullptr, kvecs, P, klists, K, sigma, p->d_lockin, nullptr));
-  for (int i = 0; i < 2 * P; ++i) p->h_k[i] = 2.0 * M_PI * kvecs[i];
-  HIP_TRY(hipMemcpyAsync(p->d_kmat, p->h_k, (size_t)2 * P * sizeof(double), hipMemcpyHostToDevice, p->stream));
+  TRY(stage_kmat(p, kvecs, P));
   HIP_TRY(launch_reconstruct(p->dtype, p->d_lockin, p->d_kmat, P, p->n0, p->n1, mask_border, p->d_dudx, p->d_dudy,
                              p->d_wnorm, p->stream));
   HIP_TRY(hipMemcpyAsync(dudx, p->d_dudx, (size_t)2 * p->n0 * (p->n1 - 1) * p->rsz, hipMemcpyDeviceToHost, p->stream));

@@ -44,5 +44,7 @@ hipError_t per_combine(int dtype, const void* Uhat, const void* D0, const void* 
 hipError_t unwrap_enqueue(UnwrapWorkspace* ws, const void* a, const void* b, const void* weight, bool from_psi,
                           int kmax, double eps, bool axes_compat, void* phi, hipStream_t s);
 hipError_t unwrap_finish(UnwrapWorkspace* ws, int* iters_out, hipStream_t s);
+// asynchronous copy of the iteration count into (pinned) host memory, no synchronisation
+hipError_t unwrap_fetch_iters(UnwrapWorkspace* ws, int* host_pinned, hipStream_t s);
 
 }  // namespace gpa

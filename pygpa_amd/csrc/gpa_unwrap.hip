@@ -1462,6 +1462,12 @@ hipError_t unwrap_finish(UnwrapWorkspace* ws, int* iters_out, hipStream_t s) {
   return hipSuccess;
 }
 
+hipError_t unwrap_fetch_iters(UnwrapWorkspace* ws, int* host_pinned, hipStream_t s) {
+  Impl* w = (Impl*)ws->impl;
+  if (!w || !w->supported) return hipErrorNotSupported;
+  return hipMemcpyAsync(host_pinned, w->flags, sizeof(int), hipMemcpyDeviceToHost, s);
+}
+
 hipError_t unwrap_run(UnwrapWorkspace* ws, const void* a, const void* b, const void* weight, bool from_psi, int kmax,
                       double eps, bool axes_compat, void* phi, int* iters_out, hipStream_t s) {
   hipError_t e = unwrap_enqueue(ws, a, b, weight, from_psi, kmax, eps, axes_compat, phi, s);
