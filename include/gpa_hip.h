@@ -164,6 +164,17 @@ int gpa_extract_gradients(gpa_plan* plan, const void* image, const double* kvecs
                           const double* klists, int K, double sigma, int mask_border, void* dudx,
                           void* dudy, void* wnorm);
 
+/* f-1 -- Lawler-Fujita undistortion.
+ * gpa_invert_u_overlap: fixed-point inverse of a displacement field, `iters` rounds of cubic-
+ *   spline resampling with mode='nearest' on the grid extended by `edge` pixels; replaces
+ *   invert_u_overlap (geometric_phase_analysis.py:262-300).  u: 2 x n0 x n1 (host),
+ *   out: 2 x (n0+2 edge) x (n1+2 edge).
+ * gpa_undistort_image: out = deformed resampled at r + invert_u_overlap(-u)(r) with
+ *   scipy.ndimage.map_coordinates' defaults (order 3, mode='constant', cval=0); replaces
+ *   undistort_image (:935-974).  deformed, out: n0 x n1.                          */
+int gpa_invert_u_overlap(gpa_plan* plan, const void* u, int iters, int edge, void* out);
+int gpa_undistort_image(gpa_plan* plan, const void* deformed, const void* u, void* out);
+
 /* a9 -- DFT of the periodic component of Moisan's periodic+smooth decomposition
  * (third-party moisan2011.per(image, inverse_dft=False)[0], call site
  * geometric_phase_analysis.py:429).  out: n0 x n1 complex.                    */

@@ -6,7 +6,7 @@ HIP path is compared against and the ``cpu_baseline`` leg of ``bench.py``.
 Only ``tests/``, ``__graft_entry__.smoke()`` and ``bench.py``'s cpu_baseline may
 import this module; the product package ``pygpa_amd`` never does.
 
-Parity status: PINNED for a1..a8 -- every function below is checked against
+Parity status: PINNED for a1..a8 and f-1 (Lawler-Fujita) -- every function below is checked against
 outputs of the real reference (imported from /root/reference in the build
 container by ``oracle/make_golden.py``; vectors committed under
 ``tests/golden/``) by ``tests/test_oracle_golden.py``.
@@ -408,6 +408,35 @@ def reconstruct_u_inv(kvecs, b, weights=None):
         sol = np.linalg.lstsq(kmat, b.reshape((b.shape[0], -1)), rcond=None)[0]
         return sol.reshape((2,) + b.shape[1:])
     return weighted_lstsq(b, kmat, weights)
+
+
+# --------------------------------------------------------------------------
+# f-1: Lawler-Fujita undistortion
+# --------------------------------------------------------------------------
+def invert_u_overlap(us, iters=35, edge=0, mode='nearest'):
+    """Fixed-point inversion of a displacement field: u_it(r) <- u(r + u_it(r)), `iters` rounds of
+    cubic-spline resampling (scipy.ndimage.map_coordinates, order 3) on the grid extended by
+    `edge` pixels; the last round is called with cval=nan.  Follows invert_u_overlap
+    (gpa.py:262-300)."""
+    import scipy.ndimage as ndi
+    us = np.asarray(us, dtype=np.float64)
+    xx, yy = np.mgrid[-edge:us.shape[1] + edge, -edge:us.shape[2] + edge]
+    u_it = [ndi.map_coordinates(u, [xx, yy], mode=mode) for u in us]
+    for _ in range(iters - 1):
+        u_it = [ndi.map_coordinates(u, [xx + u_it[0], yy + u_it[1]], mode=mode) for u in us]
+    u_it = [ndi.map_coordinates(u, [xx + u_it[0], yy + u_it[1]], mode=mode, cval=np.nan) for u in us]
+    return np.stack(u_it)
+
+
+def undistort_image(deformed, u):
+    """Resample `deformed` at r + u_inv(r), u_inv = invert_u_overlap(-u); the resampling uses
+    map_coordinates' defaults (order 3, mode='constant', cval=0).  Follows undistort_image
+    (gpa.py:935-974)."""
+    import scipy.ndimage as ndi
+    u = np.asarray(u, dtype=np.float64)
+    u_inv = invert_u_overlap(-u)
+    xx, yy = np.mgrid[:u.shape[1], :u.shape[2]]
+    return ndi.map_coordinates(np.asarray(deformed, dtype=np.float64), [xx + u_inv[0], yy + u_inv[1]])
 
 
 # --------------------------------------------------------------------------

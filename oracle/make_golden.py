@@ -224,6 +224,24 @@ def make_unwrap_ramp(pu):
     print('unwrap_ramp_64 done')
 
 
+def make_warp_case(GPA):
+    """f-1: invert_u_overlap / undistort_image of the reference on a 96 x 80 field."""
+    from pygpa_amd.synthetic import hex_kvecs, gaussian_bump_displacement, hex_moire
+    shape = (96, 80)
+    ks = hex_kvecs(0.12, 7.0)
+    u = 0.4 * gaussian_bump_displacement(shape)
+    u[1] = 0.6 * u[0].T[:shape[0], :shape[1]] if shape[0] == shape[1] else 0.5 * np.roll(u[0], 7, axis=1)
+    deformed = hex_moire(shape, ks, u)
+    original = hex_moire(shape, ks, None)
+    out = dict(u=u, deformed=deformed, original=original)
+    out['u_inv'] = GPA.invert_u_overlap(-u)
+    out['u_inv_edge4_it5'] = GPA.invert_u_overlap(-u, iters=5, edge=4)
+    out['reconstructed'] = GPA.undistort_image(deformed, u)
+    np.savez_compressed(os.path.join(OUT, 'warp_96x80.npz'), **out)
+    err = np.abs(out['reconstructed'] - original)[12:-12, 12:-12].max() / np.abs(original).max()
+    print('warp_96x80     reconstruction error (interior, rel. to max) = %.3e' % err)
+
+
 def main():
     os.makedirs(OUT, exist_ok=True)
     GPA, pu = _import_reference()
@@ -234,6 +252,7 @@ def main():
     make_case(GPA, pu, 'hex_128_noise', (128, 128), 0.1, 7.0, noise=0.5, seed=3, full=False, grad=False)
     make_iterate_case(GPA, pu)
     make_unwrap_ramp(pu)
+    make_warp_case(GPA)
 
 
 if __name__ == '__main__':

@@ -44,6 +44,8 @@ SIGNATURES = {
     'gpa_extract_displacement_field_async': (_i, [_vp, _vp, _vp, _i, _vp, _i, _d, _i, _i, _vp, _vp, _vp]),
     'gpa_last_iters': (_i, [_vp, _vp]),
     'gpa_extract_gradients': (_i, [_vp, _vp, _vp, _i, _vp, _i, _d, _i, _vp, _vp, _vp]),
+    'gpa_invert_u_overlap': (_i, [_vp, _vp, _i, _i, _vp]),
+    'gpa_undistort_image': (_i, [_vp, _vp, _vp, _vp]),
     'gpa_per_dft': (_i, [_vp, _vp, _vp]),
     'gpa_timer_start': (_i, [_vp]),
     'gpa_timer_stop': (_i, [_vp, _vp]),
@@ -187,6 +189,23 @@ class Plan:
         out = np.empty((2,) + self.shape, dtype=self.rdtype)
         check(self.lib.gpa_weighted_lstsq(self.handle, _ptr(b), _ptr(weights), _ptr(kvecs), len(kvecs), _ptr(out)),
               'gpa_weighted_lstsq')
+        return out
+
+    def invert_u_overlap(self, us, iters=35, edge=0):
+        us = np.ascontiguousarray(us, dtype=self.rdtype)
+        if us.shape != (2,) + self.shape:
+            raise ValueError('us must have shape (2,) + plan shape')
+        out = np.empty((2, self.shape[0] + 2 * edge, self.shape[1] + 2 * edge), dtype=self.rdtype)
+        check(self.lib.gpa_invert_u_overlap(self.handle, _ptr(us), int(iters), int(edge), _ptr(out)), 'gpa_invert_u_overlap')
+        return out
+
+    def undistort_image(self, deformed, u):
+        deformed = self._img(deformed)
+        u = np.ascontiguousarray(u, dtype=self.rdtype)
+        if u.shape != (2,) + self.shape:
+            raise ValueError('u must have shape (2,) + plan shape')
+        out = np.empty(self.shape, dtype=self.rdtype)
+        check(self.lib.gpa_undistort_image(self.handle, _ptr(deformed), _ptr(u), _ptr(out)), 'gpa_undistort_image')
         return out
 
     def per_dft(self, image):

@@ -87,4 +87,9 @@ hipError_t launch_reconstruct(int dtype, const void* lockin, const double* kmat 
 hipError_t launch_wlstsq(int dtype, const void* b, const void* w, const double* kmat, int P, size_t npx,
                          void* out, hipStream_t s);
 
+// ---- f-1 Lawler-Fujita (gpa_warp.hip); both synchronise the stream before returning -----------
+hipError_t warp_invert_u(int dtype, const void* d_u, int n0, int n1, double scale, int iters, int edge, void* d_out,
+                         hipStream_t s);
+hipError_t warp_image(int dtype, const void* d_img, const void* d_uinv, int n0, int n1, void* d_out, hipStream_t s);
+
 }  // namespace gpa

@@ -226,3 +226,23 @@ def extract_displacement_field(image, kvecs, sigma=None, kwscale=2.5, ksteps=3, 
     if return_gs:
         return u, gs
     return u
+
+
+# --------------------------------------------------------------------------- f-1
+def invert_u_overlap(us, iters=35, edge=0, mode='nearest', dtype=None):
+    """Numerical inverse of the displacement `us` (geometric_phase_analysis.py:262-300):
+    u_it(r + us(r)) = r, by `iters` rounds of cubic-spline resampling on the grid extended by
+    `edge` pixels.  Only mode='nearest' (the reference's default) is provided."""
+    if mode != 'nearest':
+        raise NotImplementedError("only mode='nearest' is provided")
+    us = np.asarray(us)
+    plan = _lib.get_plan(us.shape[1:], 1, DEFAULT_DTYPE if dtype is None else dtype)
+    return plan.invert_u_overlap(us, iters=iters, edge=edge)
+
+
+def undistort_image(deformed, u, dtype=None):
+    """Reconstruct an undistorted image from `deformed` and the displacement field `u`
+    (Lawler-Fujita, geometric_phase_analysis.py:935-974)."""
+    deformed = np.asarray(deformed)
+    plan = _lib.get_plan(deformed.shape, 1, DEFAULT_DTYPE if dtype is None else dtype)
+    return plan.undistort_image(deformed, u)

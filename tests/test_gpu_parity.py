@@ -272,3 +272,45 @@ def test_tiled_path_device_vs_oracle():
     assert rel(u, u_ref) < 1e-8
     u32 = D.extract_displacement_field_tiled(img, kvecs, (2, 2), klists=klists, halo=20, dtype=np.float32)
     assert rel(u32, u_ref) < 5e-4
+
+
+@pytest.mark.parametrize('dtype', DTYPES)
+def test_f1_lawler_fujita_golden(golden, dtype):
+    """invert_u_overlap / undistort_image against the reference's outputs (96 x 80 field):
+    scipy.ndimage.map_coordinates semantics (spline prefilter, mode='nearest' with its
+    12-sample edge padding, mode='constant' for the final resampling) restated on the device."""
+    import pygpa_amd.geometric_phase_analysis as GPA
+    g = golden('warp_96x80')
+    tol = 1e-10 if dtype is np.float64 else 2e-4
+    u_inv = GPA.invert_u_overlap(-g['u'], dtype=dtype)
+    assert np.abs(u_inv - g['u_inv']).max() < tol * max(1.0, np.abs(g['u_inv']).max())
+    u_e = GPA.invert_u_overlap(-g['u'], iters=5, edge=4, dtype=dtype)
+    assert u_e.shape == g['u_inv_edge4_it5'].shape
+    assert np.abs(u_e - g['u_inv_edge4_it5']).max() < tol * max(1.0, np.abs(g['u_inv_edge4_it5']).max())
+    rec = GPA.undistort_image(g['deformed'], g['u'], dtype=dtype)
+    # mode='constant' is discontinuous where r + u_inv leaves [0, n-1]: in f32 a sample a few
+    # ulps from that border may land on the other side, so compare away from it
+    xx, yy = np.mgrid[:rec.shape[0], :rec.shape[1]]
+    cx, cy = xx + g['u_inv'][0], yy + g['u_inv'][1]
+    margin = 0.0 if dtype is np.float64 else 1e-3
+    ok = (cx >= margin) & (cx <= rec.shape[0] - 1 - margin) & (cy >= margin) & (cy <= rec.shape[1] - 1 - margin)
+    ok |= (cx < -margin) | (cx > rec.shape[0] - 1 + margin) | (cy < -margin) | (cy > rec.shape[1] - 1 + margin)
+    d = np.abs(rec - g['reconstructed'])
+    assert d[ok].max() < (1e-9 if dtype is np.float64 else 5e-4) * np.abs(g['reconstructed']).max()
+    assert ok.mean() > 0.98
+
+
+def test_f1_reconstruction_like_reference():
+    """reference tests/test_geometric_phase_analysis.py:73-78: undistorting with the true
+    displacement recovers the undeformed lattice within 2 % of its maximum"""
+    import pygpa_amd.geometric_phase_analysis as GPA
+    shape = (512, 512)
+    ks = hex_kvecs(0.1, 7.0)
+    u = gaussian_bump_displacement(shape)
+    original = hex_moire(shape, ks)
+    deformed = hex_moire(shape, ks, u)
+    u_inv = GPA.invert_u_overlap(-u)
+    assert u_inv.shape == u.shape
+    rec = GPA.undistort_image(deformed, u)
+    assert np.all(np.abs(rec - original)[2:-2, 2:-2] / np.abs(original).max() < 0.02)
+    assert rel(rec, orc.undistort_image(deformed, u)) < 1e-9

@@ -135,3 +135,10 @@ def test_a9_per_known_answers():
     phat, shat = orc.per(img, inverse_dft=False)
     assert np.allclose(phat + shat, np.fft.fft2(img))
     assert shat[0, 0] == 0
+
+
+def test_f1_lawler_fujita(golden):
+    g = golden('warp_96x80')
+    assert np.allclose(orc.invert_u_overlap(-g['u']), g['u_inv'], rtol=0, atol=1e-12, equal_nan=True)
+    assert np.allclose(orc.invert_u_overlap(-g['u'], iters=5, edge=4), g['u_inv_edge4_it5'], rtol=0, atol=1e-12, equal_nan=True)
+    assert np.allclose(orc.undistort_image(g['deformed'], g['u']), g['reconstructed'], rtol=0, atol=1e-12)
