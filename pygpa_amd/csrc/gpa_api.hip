@@ -2,6 +2,7 @@
 // tables, and the drivers that chain the kernels on the plan's stream.
 #include <math.h>
 #include <stdio.h>
+#include <stdlib.h>
 #include <string.h>
 
 #include <complex>
@@ -627,6 +628,10 @@ static int extract_enqueue(gpa_plan* p, const void* image, const double* kvecs, 
   HIP_TRY(hipEventRecord(p->ev_fork, p->stream));
   HIP_TRY(hipStreamWaitEvent(p->stream2, p->ev_fork, 0));
   hipError_t e = unwrap_enqueue(&p->uw, p->d_dudx, p->d_dudy, p->d_wnorm, false, kmax, 1e-9, true, u, p->stream);
+  if (getenv("GPA_SERIAL_UNWRAP")) {   // diagnostic: run the second component after the first (clean per-kernel timings)
+    HIP_TRY(hipEventRecord(p->ev_fork, p->stream));
+    HIP_TRY(hipStreamWaitEvent(p->stream2, p->ev_fork, 0));
+  }
   if (e == hipSuccess)
     e = unwrap_enqueue(&p->uw2, (char*)p->d_dudx + nx * p->rsz, (char*)p->d_dudy + ny * p->rsz, p->d_wnorm, false,
                        kmax, 1e-9, true, (char*)u + npx * p->rsz, p->stream2);

@@ -16,6 +16,16 @@
 
 namespace gpa {
 
+// 1/x: the f32 device path uses the hardware reciprocal (1 ulp, one instruction) instead of
+// the ~10-instruction IEEE division; it only scales the CG preconditioner, whose exactness
+// does not enter the fixed point of the iteration.
+template <class T> GPA_HD T fast_recip(T x) {
+#if defined(__HIP_DEVICE_COMPILE__)
+  if constexpr (sizeof(T) == 4) return __builtin_amdgcn_rcpf(x);
+#endif
+  return T(1) / x;
+}
+
 // slot of the permuted sequence -> index in the original sequence
 // (valid for odd N too: the first ceil(N/2) slots take the even samples)
 GPA_HD int makhoul_src(int m, int N) { return m < (N + 1) / 2 ? 2 * m : 2 * (N - 1 - m) + 1; }
@@ -73,8 +83,9 @@ struct WgDCT {
       const cpx<T> va = {T(0.5) * (zk.x + zm.x), T(0.5) * (zk.y - zm.y)};
       const cpx<T> vb = {T(0.5) * (zk.y + zm.y), T(-0.5) * (zk.x - zm.x)};
       const cpx<T> ua = cmul(w, va), ub = cmul(w, vb);
-      T sa = inv_n / (T(-2) * (h + hb_a)), sb = inv_n / (T(-2) * (h + hb_b));
-      T sam = inv_n / (T(-2) * (hm + hb_a)), sbm = inv_n / (T(-2) * (hm + hb_b));
+      const T cn = T(-0.5) * inv_n;   // 1 / (2 (cos + cos - 2)) / N = cn / (ha + hb)
+      T sa = cn * fast_recip(h + hb_a), sb = cn * fast_recip(h + hb_b);
+      T sam = cn * fast_recip(hm + hb_a), sbm = cn * fast_recip(hm + hb_b);
       if (k == 0) {
         sam = T(0);
         sbm = T(0);

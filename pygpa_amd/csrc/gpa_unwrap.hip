@@ -411,7 +411,7 @@ struct RowGeom {
   static constexpr bool FITS = LDS_BYTES <= 160 * 1024;
 };
 #ifndef GPA_COL_LDS_BUDGET
-#define GPA_COL_LDS_BUDGET (80 * 1024)
+#define GPA_COL_LDS_BUDGET (160 * 1024)
 #endif
 constexpr size_t COL_LDS_BUDGET = GPA_COL_LDS_BUDGET;
 

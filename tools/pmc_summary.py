@@ -5,7 +5,7 @@ acc = collections.defaultdict(lambda: collections.defaultdict(list))
 for d in sys.argv[1:]:
     for f in glob.glob(os.path.join(d, '**', '*counter_collection.csv'), recursive=True):
         for r in csv.DictReader(open(f)):
-            name = r['Kernel_Name'].split('(')[0].replace('void gpa::', '').replace('(anonymous namespace)::', '').replace('gpa::', '')
+            name = r['Kernel_Name'].replace('(anonymous namespace)::', '').split('(')[0].replace('void gpa::', '').replace('gpa::', '')
             acc[name][r['Counter_Name']].append(float(r['Counter_Value']))
 for name in sorted(acc):
     print(name)
