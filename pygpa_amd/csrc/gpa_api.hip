@@ -254,8 +254,8 @@ static int plan_build(gpa_plan* p) {
 }
 
 static int ensure_filters(gpa_plan* p, double sigma) {
-  if (sigma == p->sigma_cached) return GPA_OK;
   if (!(sigma > 0)) return fail(GPA_ERR_ARG, "sigma must be positive");
+  if (sigma == p->sigma_cached) return GPA_OK;
   std::vector<double> h;
   build_filter_table(p->ax0, sigma, h);
   TRY(upload_real_table(p, p->Hx, h));

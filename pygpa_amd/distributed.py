@@ -51,10 +51,21 @@ def _dist():
     return torch, dist
 
 
+def _initialized():
+    """True when a torch.distributed process group exists.  torch is not imported here: a
+    process that never imported torch.distributed cannot have a group (and the first import
+    of torch on a cold machine takes minutes)."""
+    import sys
+    d = sys.modules.get('torch.distributed')
+    return d is not None and d.is_available() and d.is_initialized()
+
+
 def _all_gather_np(arr, group=None):
     """all_gather of equally shaped NumPy arrays -> list over ranks (RCCL needs device tensors)"""
+    if not _initialized():
+        return [arr]
     torch, dist = _dist()
-    if not dist.is_initialized() or dist.get_world_size(group) == 1:
+    if dist.get_world_size(group) == 1:
         return [arr]
     t = torch.from_numpy(np.ascontiguousarray(arr))
     on_gpu = dist.get_backend(group) == 'nccl'
@@ -86,9 +97,10 @@ def extract_displacement_field_tiled(image, kvecs, grid, sigma=None, kwscale=2.5
                                      halo=None, kmax=10, dtype=np.float64, device=0, group=None, compute=None):
     """Tile-sharded `extract_displacement_field`.  Every rank passes the same full `image`
     (or at least its own windows' pixels) and receives the full (2, N, M) field."""
-    torch, dist = _dist()
-    world = dist.get_world_size(group) if dist.is_initialized() else 1
-    rank = dist.get_rank(group) if dist.is_initialized() else 0
+    world, rank = 1, 0
+    if _initialized():
+        _, dist = _dist()
+        world, rank = dist.get_world_size(group), dist.get_rank(group)
     image = np.asarray(image)
     kvecs = np.asarray(kvecs, dtype=np.float64).reshape(-1, 2)
     norms = np.linalg.norm(kvecs, axis=1)

@@ -314,3 +314,88 @@ def test_f1_reconstruction_like_reference():
     rec = GPA.undistort_image(deformed, u)
     assert np.all(np.abs(rec - original)[2:-2, 2:-2] / np.abs(original).max() < 0.02)
     assert rel(rec, orc.undistort_image(deformed, u)) < 1e-9
+
+
+class DeviceArray:
+    """a device buffer through the HIP runtime itself (ctypes), so the test needs no torch"""
+    _hip = None
+
+    def __init__(self, host):
+        import ctypes as C
+        if DeviceArray._hip is None:
+            _lib.load()
+            DeviceArray._hip = C.CDLL('libamdhip64.so')
+        self.host = np.ascontiguousarray(host)
+        p = C.c_void_p()
+        assert self._hip.hipMalloc(C.byref(p), C.c_size_t(self.host.nbytes)) == 0
+        self.ptr = p.value
+        assert self._hip.hipMemcpy(C.c_void_p(self.ptr), self.host.ctypes.data_as(C.c_void_p), C.c_size_t(self.host.nbytes), 1) == 0
+
+    def get(self):
+        import ctypes as C
+        out = np.empty_like(self.host)
+        assert self._hip.hipMemcpy(out.ctypes.data_as(C.c_void_p), C.c_void_p(self.ptr), C.c_size_t(out.nbytes), 2) == 0
+        return out
+
+    def __del__(self):
+        import ctypes as C
+        try:
+            self._hip.hipFree(C.c_void_p(self.ptr))
+        except Exception:
+            pass
+
+
+def test_async_driver_and_plan_reuse():
+    """gpa_extract_displacement_field_async on two plans (device pointers via torch), results equal
+    to the synchronous host-pointer call; repeated calls with the same k-lists reuse the staged
+    tables; changing the k-lists re-stages them."""
+    shape = (256, 256)
+    kvecs = hex_kvecs(0.1, 7.0)
+    img = hex_moire(shape, kvecs, gaussian_bump_displacement(shape), noise=0.1, seed=8)
+    kw, sigma, _ = orc.derive_params(kvecs)
+    kl_a = np.stack(explicit_klists(kvecs, kw, 2, 2))
+    kl_b = np.stack(explicit_klists(kvecs, kw, 3, 3))
+    ref = {}
+    plan = _lib.Plan(shape, 27, np.float64)
+    for name, kl in (('a', kl_a), ('b', kl_b)):
+        ref[name] = plan.extract_displacement_field(img, kvecs, kl, sigma, 2 * sigma)[0]
+    plans = [_lib.Plan(shape, 27, np.float64) for _ in range(2)]
+    d_img = DeviceArray(img)
+    outs = [DeviceArray(np.zeros((2,) + shape)) for _ in range(2)]
+    for rnd, (name, kl) in enumerate((('a', kl_a), ('a', kl_a), ('b', kl_b), ('a', kl_a))):
+        for j in range(2):
+            plans[j].extract_displacement_field_async(d_img.ptr, kvecs, kl, sigma, 2 * sigma, 10, outs[j].ptr)
+        for j in range(2):
+            plans[j].sync()
+            assert plans[j].last_iters() == (10, 10)
+            assert np.array_equal(outs[j].get(), ref[name]), (rnd, j)
+    for p in plans + [plan]:
+        p.close()
+
+
+def test_error_paths_and_extreme_shapes():
+    """argument checking at the C ABI and very oblong images"""
+    with pytest.raises(_lib.GPAError):
+        _lib.Plan((2, 64), 1, np.float32)                 # axis shorter than 4
+    with pytest.raises(_lib.GPAError):
+        _lib.Plan((64, 20000), 1, np.float32)             # axis too long for an LDS-resident transform
+    plan = _lib.Plan((64, 64), 2, np.float32)
+    img = np.zeros((64, 64), dtype=np.float32)
+    with pytest.raises(_lib.GPAError):
+        plan.lockin_batch(img, np.zeros((3, 2)), 5.0)     # more k-vectors than max_batch
+    with pytest.raises(_lib.GPAError):
+        plan.lockin_batch(img, np.zeros((1, 2)), -1.0)    # sigma must be positive
+    with pytest.raises(ValueError):
+        plan.lockin_batch(np.zeros((32, 64)), np.zeros((1, 2)), 5.0)
+    # an all-zero image: every |sf| is 0, nothing ever wins (kidx = -1, lock-in 0) as in the reference
+    lock, kidx, _ = plan.sweep(img, (0.1, 0.0), np.array([[0.1, 0.0], [0.12, 0.0]]), 5.0)
+    assert np.all(kidx == -1) and np.all(lock == 0)
+    plan.close()
+    # 16384 x 64 (f32) and 8192 x 100 (f64, padded second axis) against the oracle
+    for shape, dt, tol in (((16384, 64), np.float32, 5e-6), ((8192, 100), np.float64, 1e-10)):
+        rng = np.random.default_rng(1)
+        im = rng.normal(size=shape)
+        p2 = _lib.Plan(shape, 1, dt)
+        out = p2.lockin_batch(im, [(0.05, 0.11)], 6.0)[0]
+        assert rel(out, orc.lockin(im, (0.05, 0.11), 6.0, workers=8)) < tol
+        p2.close()
