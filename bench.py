@@ -77,32 +77,35 @@ def main():
     ap.add_argument('--dtype', default='f32', choices=['f32', 'f64'])
     ap.add_argument('--kmax', type=int, default=10)
     ap.add_argument('--no-cpu', action='store_true', help='skip the CPU baseline leg')
+    ap.add_argument('--force-torch', action='store_true', help='use the torch buffer path at N = 1 too (test aid)')
     ap.add_argument('--inflight', type=int, default=1,
                     help='images in flight per GPU (one plan each): 1 = strictly one after the other')
     args = ap.parse_args()
 
-    import torch   # first: libgpa_hip.so then binds to the HIP runtime torch already loaded
-    import torch.distributed as dist
-    from pygpa_amd import _lib
-    from pygpa_amd.synthetic import hex_kvecs, gaussian_bump_displacement, hex_moire, explicit_klists
-
     world = int(os.environ.get('WORLD_SIZE', '1'))
     rank = int(os.environ.get('RANK', '0'))
     local_rank = int(os.environ.get('LOCAL_RANK', '0'))
-    if world > 1:
+    torch = dist = None
+    use_torch = world > 1 or args.force_torch
+    if use_torch:
+        # torch is plumbing for the multi-GPU run only (process group + RCCL); it is imported
+        # BEFORE libgpa_hip.so so that both share the HIP runtime torch ships.  A single-GPU run
+        # does not need it (and its first import on a cold machine takes minutes).
+        import torch
+        import torch.distributed as dist
         os.environ.setdefault('MASTER_ADDR', '127.0.0.1')
         os.environ.setdefault('HSA_ENABLE_IPC_MODE_LEGACY', '0')
         torch.cuda.set_device(local_rank)
-        dist.init_process_group('nccl', rank=rank, world_size=world, device_id=torch.device('cuda', local_rank))
-    else:
-        torch.cuda.set_device(0)
-    dev = torch.device('cuda', local_rank if world > 1 else 0)
+        if world > 1:
+            dist.init_process_group('nccl', rank=rank, world_size=world, device_id=torch.device('cuda', local_rank))
+    from pygpa_amd import _lib
+    from pygpa_amd.synthetic import hex_kvecs, gaussian_bump_displacement, hex_moire, explicit_klists
+    dev_index = local_rank if world > 1 else 0
 
     n = args.size
     knx, kny = (int(v) for v in args.kgrid.split('x')) if args.kgrid else (args.kside, args.kside)
     P, K = 3, knx * kny
     np_dt = np.float32 if args.dtype == 'f32' else np.float64
-    t_dt = torch.float32 if args.dtype == 'f32' else torch.float64
     s = 4 if args.dtype == 'f32' else 8
     kvecs = hex_kvecs(0.1, 7.0)
     sigma = int(np.ceil(1 / np.linalg.norm(kvecs, axis=1).min()))
@@ -112,21 +115,28 @@ def main():
     # every rank owns one tile of a (world * n) x n synthetic image
     u_true = gaussian_bump_displacement((n, n))
     img = hex_moire((n, n), kvecs, u_true, noise=0.1, seed=100 + rank, dtype=np_dt)
-    d_img = torch.from_numpy(img).to(dev)
     depth = max(1, args.inflight)
-    # one plan (workspace + streams) per image in flight: consecutive steps are independent
-    # images, so the VALU-bound sweep of step i+1 overlaps the bandwidth-bound unwrap of step i
-    plans = [_lib.Plan((n, n), P * K, np_dt, device=dev.index) for _ in range(depth)]
-    d_us = [torch.empty((2, n, n), dtype=t_dt, device=dev) for _ in range(depth)]
-    d_alls = [torch.empty((world, 2, n, n), dtype=t_dt, device=dev) for _ in range(depth)] if world > 1 else None
+    # one plan (workspace + streams) per image in flight
+    plans = [_lib.Plan((n, n), P * K, np_dt, device=dev_index) for _ in range(depth)]
+    if use_torch:
+        dev = torch.device('cuda', dev_index)
+        t_dt = torch.float32 if args.dtype == 'f32' else torch.float64
+        t_img = torch.from_numpy(img).to(dev)
+        t_us = [torch.empty((2, n, n), dtype=t_dt, device=dev) for _ in range(depth)]
+        d_alls = [torch.empty((world, 2, n, n), dtype=t_dt, device=dev) for _ in range(depth)] if world > 1 else None
+        img_ptr, u_ptrs = t_img.data_ptr(), [t.data_ptr() for t in t_us]
+    else:
+        bufs = [_lib.DeviceBuffer(img.nbytes)] + [_lib.DeviceBuffer(2 * img.nbytes) for _ in range(depth)]
+        bufs[0].upload(img)
+        img_ptr, u_ptrs = bufs[0].ptr, [b.ptr for b in bufs[1:]]
+        t_us = d_alls = None
     gathered = [None] * depth
     plan = plans[0]
-    d_u = d_us[0]
 
     def gather(j):
         # stitch the tiles' fields of the step that ran on plan j (RCCL all_gather over xGMI)
         plans[j].sync()
-        dist.all_gather_into_tensor(d_alls[j], d_us[j])
+        dist.all_gather_into_tensor(d_alls[j], t_us[j])
         ev = torch.cuda.Event()
         ev.record()
         gathered[j] = ev
@@ -134,11 +144,10 @@ def main():
     def run(nsteps):
         for i in range(nsteps):
             j = i % depth
-            if gathered[j] is not None:        # the collective that reads d_us[j] must be done before it is rewritten
+            if gathered[j] is not None:        # the collective that reads t_us[j] must be done before it is rewritten
                 gathered[j].synchronize()
                 gathered[j] = None
-            plans[j].extract_displacement_field_async(d_img.data_ptr(), kvecs, klists, sigma, 2 * sigma, args.kmax,
-                                                      d_us[j].data_ptr())
+            plans[j].extract_displacement_field_async(img_ptr, kvecs, klists, sigma, 2 * sigma, args.kmax, u_ptrs[j])
             if world > 1 and i >= depth - 1:
                 gather((i - (depth - 1)) % depth)
         if world > 1:
@@ -148,7 +157,8 @@ def main():
     def fence():
         for pl in plans:
             pl.sync()
-        torch.cuda.synchronize()
+        if use_torch:
+            torch.cuda.synchronize()
         if world > 1:
             dist.barrier()
             torch.cuda.synchronize()
@@ -161,7 +171,7 @@ def main():
     dt = time.perf_counter() - t0
     iters = plan.last_iters()
     if world > 1:
-        t = torch.tensor([dt], dtype=torch.float64, device=dev)
+        t = torch.tensor([dt], dtype=torch.float64, device=torch.device('cuda', dev_index))
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         dt = float(t.item())
 
@@ -170,7 +180,7 @@ def main():
     stage = np.zeros(5)
     nprof = 5
     for _ in range(nprof):
-        plan.extract_displacement_field_dev(d_img.data_ptr(), kvecs, klists, sigma, 2 * sigma, args.kmax, d_u.data_ptr())
+        plan.extract_displacement_field_dev(img_ptr, kvecs, klists, sigma, 2 * sigma, args.kmax, u_ptrs[0])
         stage += np.array(plan.last_stage_ms())
     stage /= nprof
     plan.set_profiling(False)

@@ -313,6 +313,44 @@ class Plan:
         return [ms[i] for i in range(5)]
 
 
+class DeviceBuffer:
+    """A raw device allocation through the HIP runtime (hipMalloc / hipMemcpy via ctypes) for
+    callers of the `_dev` / `_async` entry points that do not want torch for it."""
+    _hip = None
+
+    def __init__(self, nbytes):
+        load()
+        if DeviceBuffer._hip is None:
+            DeviceBuffer._hip = C.CDLL('libamdhip64.so')   # already mapped as a dependency of libgpa_hip.so
+        p = C.c_void_p()
+        rc = self._hip.hipMalloc(C.byref(p), C.c_size_t(int(nbytes)))
+        if rc != 0 or not p.value:
+            raise GPAError('hipMalloc(%d) failed (%d)' % (nbytes, rc))
+        self.ptr, self.nbytes = p.value, int(nbytes)
+
+    def upload(self, host):
+        host = np.ascontiguousarray(host)
+        if self._hip.hipMemcpy(C.c_void_p(self.ptr), host.ctypes.data_as(C.c_void_p), C.c_size_t(host.nbytes), 1) != 0:
+            raise GPAError('hipMemcpy H2D failed')
+
+    def download(self, shape, dtype):
+        out = np.empty(shape, dtype=dtype)
+        if self._hip.hipMemcpy(out.ctypes.data_as(C.c_void_p), C.c_void_p(self.ptr), C.c_size_t(out.nbytes), 2) != 0:
+            raise GPAError('hipMemcpy D2H failed')
+        return out
+
+    def free(self):
+        if getattr(self, 'ptr', None):
+            self._hip.hipFree(C.c_void_p(self.ptr))
+            self.ptr = None
+
+    def __del__(self):
+        try:
+            self.free()
+        except Exception:
+            pass
+
+
 # small plan cache so the drop-in functions do not rebuild tables on every call
 _plans = {}
 
