@@ -58,12 +58,20 @@ def cpu_baseline(kvecs, sigma, knx, kny, kmax, sample=1024):
     img = hex_moire(shape, kvecs, gaussian_bump_displacement(shape), noise=0.1, seed=7)
     kw = np.linalg.norm(kvecs, axis=1).mean() / 2.5
     klists = explicit_klists(kvecs, kw, knx, kny)
-    t = time.perf_counter()
-    orc.extract_displacement_field(img, kvecs, sigma=sigma, klists=klists, workers=cores)
-    dt = time.perf_counter() - t
-    return {'value': round(sample * sample / dt / 1e6, 4), 'unit': 'Mpixels/s', 'cores': cores, 'kind': 'port',
-            'sample': '%dx%d image, 3 peaks x %d k-vectors + weighted unwrap kmax=%d, oracle/gpa_oracle.py with '
-                      'scipy.fft workers=%d, %.1f s' % (sample, sample, knx * kny, kmax, cores, dt)}
+    # (i) reference-faithful threading: pyGPA runs single-threaded pocketfft and a serial per-pixel
+    # solve; (ii) best effort: scipy.fft on every host core.  The faster one is the baseline.
+    runs = {}
+    for w in sorted({1, cores}):
+        t = time.perf_counter()
+        orc.extract_displacement_field(img, kvecs, sigma=sigma, klists=klists, workers=w)
+        runs[w] = time.perf_counter() - t
+    best = min(runs, key=runs.get)
+    dt = runs[best]
+    return {'value': round(sample * sample / dt / 1e6, 4), 'unit': 'Mpixels/s', 'cores': best, 'kind': 'port',
+            'sample': '%dx%d image, 3 peaks x %d k-vectors + weighted unwrap kmax=%d, oracle/gpa_oracle.py; '
+                      % (sample, sample, knx * kny, kmax) +
+                      ', '.join('scipy.fft workers=%d: %.1f s' % (w, runs[w]) for w in sorted(runs)) +
+                      ' (host has %d cores)' % cores}
 
 
 def main():
