@@ -281,13 +281,14 @@ __global__ __launch_bounds__(256) void applyq_kernel(const T* __restrict__ p, co
 template <class T>
 struct alignas(4 * sizeof(T)) Vec4 { T v[4]; };
 
-constexpr int PQ_ROWS = 16;   // rows per workgroup band of pq_kernel
+constexpr int PQ_ROWS = 16;   // rows per workgroup band of pq_kernel (large images; fewer for small ones)
 
 template <class T>
 __global__ __launch_bounds__(256) void pq_kernel(const T* __restrict__ z, const T* __restrict__ pin,
                                                 T* __restrict__ pout, const T* __restrict__ w, int n0, int n1,
                                                 T* __restrict__ q, double* part, double* scal,
-                                                const int* flags, const double* part_rho, int nrho, int it) {
+                                                const int* flags, const double* part_rho, int nrho, int it,
+                                                int band) {
   if (flags[1]) return;
   __shared__ double sh[256];
   bool first;
@@ -307,8 +308,8 @@ __global__ __launch_bounds__(256) void pq_kernel(const T* __restrict__ z, const 
   // previous / current / next row in registers: every row of z, p, w is read once
   // (plus a 2-row halo per band) instead of three times by three different workgroups.
   const int y0 = (blockIdx.x * 256 + threadIdx.x) * 4;
-  const int x0 = blockIdx.y * PQ_ROWS;
-  const int x1 = x0 + PQ_ROWS < n0 ? x0 + PQ_ROWS : n0;
+  const int x0 = blockIdx.y * band;
+  const int x1 = x0 + band < n0 ? x0 + band : n0;
   double pq = 0;
   if (y0 < n1) {
     auto load_p = [&](int x, Vec4<T>& out) {
@@ -410,20 +411,17 @@ struct RowGeom {
   static constexpr size_t LDS_BYTES = (size_t)NF * RS * sizeof(cpx<T>);
   static constexpr bool FITS = LDS_BYTES <= 160 * 1024;
 };
-#ifndef GPA_COL_LDS_BUDGET
-#define GPA_COL_LDS_BUDGET (160 * 1024)
-#endif
-constexpr size_t COL_LDS_BUDGET = GPA_COL_LDS_BUDGET;
-
 template <class T, int LG>
 struct ColGeom {
   using F = WgFFT<T, LG>;
   static constexpr int cols() {
+    // as many column pairs as LDS and 1024 threads allow (wide tiles = long row segments) ...
     int c = 16;
-    // budget half the LDS per workgroup: the kernel is one load -> transform -> store chain
-    // per workgroup, so two resident workgroups per CU are what overlaps memory with math
-    while (c > 1 && (c * F::TPF > 1024 || (size_t)c * (F::LDS_ELEMS + 32) * sizeof(cpx<T>) > COL_LDS_BUDGET)) c /= 2;
-    return c;
+    while (c > 1 && (c * F::TPF > 1024 || (size_t)c * (F::LDS_ELEMS + 32) * sizeof(cpx<T>) > 160 * 1024)) c /= 2;
+    // ... but a (square) image of side N has only N/2 pairs: keep >= 512 workgroups in flight
+    // on the 256 CUs, small images are cache resident and do not care about segment length
+    const int want = LG >= 12 ? 16 : (LG == 11 ? 2 : 1);
+    return c < want ? c : want;
   }
   static constexpr int CC = cols();   // packed column PAIRS (complex transforms) per workgroup
   // as in pass A of the sweep: two transforms per f32 thread (adjacent pairs = 4 real
@@ -1369,7 +1367,11 @@ static hipError_t run_pcg(Impl* w, const void* a, const void* b, const void* wei
   const size_t npx = (size_t)n0 * n1;
   const int g2 = n0, np2 = n0;   // stencil kernels: one workgroup per image row
   if (np2 > MAXPART) return hipErrorInvalidValue;
-  const dim3 gpq((n1 + 1023) / 1024, (n0 + PQ_ROWS - 1) / PQ_ROWS);
+  // band height of the stencil kernel: 16 rows for large images, fewer when that would leave
+  // less than ~2048 workgroups (small images are latency-, not bandwidth-bound)
+  int band = PQ_ROWS;
+  while (band > 4 && (size_t)((n1 + 1023) / 1024) * ((n0 + band - 1) / band) < 2048) band /= 2;
+  const dim3 gpq((n1 + 1023) / 1024, (n0 + band - 1) / band);
   const int npq = gpq.x * gpq.y;
   if (npq > MAXPART) return hipErrorInvalidValue;
   const int gl = 2048;   // grid-stride elementwise kernels
@@ -1401,7 +1403,7 @@ static hipError_t run_pcg(Impl* w, const void* a, const void* b, const void* wei
       T* pin = (T*)((it & 1) ? w->p2 : w->p);
       T* pout = (T*)((it & 1) ? w->p : w->p2);
       pq_kernel<T><<<gpq, 256, 0, s>>>((const T*)w->z, pin, pout, (const T*)weight, n0, n1, (T*)w->q, part_pq, w->scal,
-                                       w->flags, part_rho, nrow, it);
+                                       w->flags, part_rho, nrow, it, band);
       pprev = pout;
     }
     final_update_kernel<T><<<gl, 256, 0, s>>>((const T*)pprev, (const T*)w->q, (T*)phi, (T*)w->r, npx, w->scal, part_pq,
@@ -1426,7 +1428,7 @@ static hipError_t run_pcg(Impl* w, const void* a, const void* b, const void* wei
       T* pin = (T*)((it & 1) ? w->p2 : w->p);
       pcur = (T*)((it & 1) ? w->p : w->p2);
       pq_kernel<T><<<gpq, 256, 0, s>>>((const T*)w->z, pin, pcur, (const T*)weight, n0, n1, (T*)w->q,
-                                       w->part + MAXPART, w->scal, w->flags, nullptr, 0, -1);
+                                       w->part + MAXPART, w->scal, w->flags, nullptr, 0, -1, band);
       scal_alpha_kernel<<<1, 256, 0, s>>>(w->part + MAXPART, npq, w->scal, w->flags);
     } else {
       pcur = (T*)w->p;
