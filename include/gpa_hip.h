@@ -175,6 +175,29 @@ int gpa_extract_gradients(gpa_plan* plan, const void* image, const double* kvecs
 int gpa_invert_u_overlap(gpa_plan* plan, const void* u, int iters, int edge, void* out);
 int gpa_undistort_image(gpa_plan* plan, const void* deformed, const void* u, void* out);
 
+/* f-2 -- phase gradient -> Jacobian -> lattice properties.
+ * gpa_phasegradient2J: J[n,m,i,j] = (per-pixel weighted least squares of grads[:,n,m,j] against
+ *   2 pi kvecs)_i / nmperpixel; replaces phasegradient2J (property_extract.py:69-101).
+ *   dks == NULL is iso_ref=False; with dks (P x 2, = calc_diff_from_isotropic(kvecs)) the
+ *   gradients are taken relative to the isotropic lattice: K = 2 pi (kvecs + dks) and
+ *   g <- wrapToPi(g - 2 pi dk) (:87-92).  grads: P x n0 x n1 x 2 (the `grad` output of
+ *   gpa_sweep per peak), weights: P x n0 x n1, J: n0 x n1 x 2 x 2.
+ * gpa_props_from_jac: (angle [deg], aniangle [deg, mod 180], alpha, kappa) per pixel from the 2x2
+ *   Jacobian (+ identity when add_identity != 0, i.e. phasegradient2Jac :104-111); replaces
+ *   props_from_Jac (:137-178).  Needs no plan: jac is npx x 2 x 2 for any number of pixels,
+ *   props 4 x npx.
+ * The _dev variants take device pointers and run asynchronously (on the plan's stream, or on
+ * the given hipStream_t for gpa_props_from_jac_dev).                                        */
+int gpa_phasegradient2J(gpa_plan* plan, const double* kvecs, int P, const void* grads,
+                        const void* weights, double nmperpixel, const double* dks, void* J);
+int gpa_phasegradient2J_dev(gpa_plan* plan, const double* kvecs, int P, const void* grads,
+                            const void* weights, double nmperpixel, const double* dks, void* J);
+int gpa_props_from_jac(int device, int dtype, size_t npx, const void* jac, int add_identity,
+                       double refangle, double refscale, int diff, void* props);
+int gpa_props_from_jac_dev(int device, int dtype, size_t npx, const void* jac, int add_identity,
+                           double refangle, double refscale, int diff, void* props,
+                           void* stream);
+
 /* a9 -- DFT of the periodic component of Moisan's periodic+smooth decomposition
  * (third-party moisan2011.per(image, inverse_dft=False)[0], call site
  * geometric_phase_analysis.py:429).  out: n0 x n1 complex.                    */

@@ -6,7 +6,7 @@ HIP path is compared against and the ``cpu_baseline`` leg of ``bench.py``.
 Only ``tests/``, ``__graft_entry__.smoke()`` and ``bench.py``'s cpu_baseline may
 import this module; the product package ``pygpa_amd`` never does.
 
-Parity status: PINNED for a1..a8 and f-1 (Lawler-Fujita) -- every function below is checked against
+Parity status: PINNED for a1..a8, f-1 (Lawler-Fujita) and f-2 (Jacobian / lattice properties) -- every function below is checked against
 outputs of the real reference (imported from /root/reference in the build
 container by ``oracle/make_golden.py``; vectors committed under
 ``tests/golden/``) by ``tests/test_oracle_golden.py``.
@@ -437,6 +437,60 @@ def undistort_image(deformed, u):
     u_inv = invert_u_overlap(-u)
     xx, yy = np.mgrid[:u.shape[1], :u.shape[2]]
     return ndi.map_coordinates(np.asarray(deformed, dtype=np.float64), [xx + u_inv[0], yy + u_inv[1]])
+
+
+# --------------------------------------------------------------------------
+# f-2: phase gradient -> Jacobian -> lattice properties
+# --------------------------------------------------------------------------
+def calc_diff_from_isotropic(ani_ks, symmetry=6):
+    """dks such that ani_ks + dks is an isotropic lattice of the mean radius at the periodic-mean
+    angle (geometric_phase_analysis.py:303-322)."""
+    ani_ks = np.asarray(ani_ks, dtype=np.float64)
+    period = TWO_PI / symmetry
+    ang = np.arctan2(ani_ks[:, 1], ani_ks[:, 0])
+    dt = np.angle(np.exp(1j * TWO_PI / period * ang).mean()) * period / TWO_PI
+    r = np.linalg.norm(ani_ks, axis=1).mean()
+    th = dt + period * np.arange(symmetry)
+    ks_hex = r * np.stack([np.cos(th), np.sin(th)], axis=-1)
+    alldiffs = ks_hex - ani_ks[:, None]
+    argmins = np.linalg.norm(alldiffs, axis=-1).argmin(axis=1)
+    return alldiffs[np.arange(len(ani_ks)), argmins]
+
+
+def phasegradient2J(kvecs, grads, weights, nmperpixel, iso_ref=False):
+    """J (N,M,2,2) from the sweep's phase gradients (P,N,M,2) by the per-pixel weighted least
+    squares (property_extract.py:69-101, sort=0)."""
+    kvecs = np.asarray(kvecs, dtype=np.float64)
+    grads = np.asarray(grads, dtype=np.float64)
+    if iso_ref:
+        dks = calc_diff_from_isotropic(kvecs)
+        kmat = TWO_PI * (kvecs + dks)
+        grads = wrap_to_pi(grads - TWO_PI * dks[:, None, None, :])
+    else:
+        kmat = TWO_PI * kvecs
+    dudx = weighted_lstsq(grads[..., 0], kmat, weights)
+    dudy = weighted_lstsq(grads[..., 1], kmat, weights)
+    J = np.stack([dudx, dudy], axis=-1) / nmperpixel
+    return np.moveaxis(J, 0, -2)
+
+
+def props_from_jac(jac, refangle=0., refscale=1., diff=False):
+    """(angle, aniangle, alpha, kappa) of a lattice from the Jacobian of its transformation, by
+    the sign-normalised SVD of property_extract.py:137-178."""
+    u, s, v = np.linalg.svd(np.asarray(jac, dtype=np.float64))
+    signs = np.sign(u[..., None, [0, 1], [0, 1]])
+    v = signs * v
+    u = np.swapaxes(signs * u, -1, -2)
+    u_p = np.swapaxes(u @ v, -1, -2)
+    angle = np.rad2deg(np.arctan2(u_p[..., 1, 0], u_p[..., 0, 0]))
+    aniangle = np.rad2deg(np.arctan2(u[..., 1, 0], u[..., 0, 0]))
+    if diff:
+        aniangle = aniangle + 90
+        alpha = s[..., 0]
+    else:
+        alpha = s[..., 1]
+    kappa = s[..., 0] / s[..., 1]
+    return np.array([angle + refangle, aniangle % 180, alpha * refscale, kappa])
 
 
 # --------------------------------------------------------------------------

@@ -242,6 +242,34 @@ def make_warp_case(GPA):
     print('warp_96x80     reconstruction error (interior, rel. to max) = %.3e' % err)
 
 
+def make_props_case(GPA):
+    """f-2: phasegradient2J (iso_ref=False) and props_from_Jac of the reference."""
+    import pyGPA.property_extract as pe
+    g = dict(np.load(os.path.join(OUT, 'hex_64.npz')))
+    img0 = g['image'] - g['image'].mean()
+    sigma, kw, kstep, kvecs = int(g['sigma']), float(g['kw']), float(g['kstep']), g['kvecs']
+    gs = [GPA.wfr2_grad_opt(img0, sigma, pk[0], pk[1], kw=kw, kstep=kstep) for pk in kvecs]
+    grads = np.stack([x['grad'] for x in gs])
+    weights = np.stack([np.abs(x['lockin']) for x in gs])
+    J = pe.phasegradient2J(kvecs, grads, weights, nmperpixel=0.5, iso_ref=False)
+    # iso_ref=True needs latticegen.transformations.rotate (absent here).  calc_diff_from_isotropic
+    # (geometric_phase_analysis.py:309-322) enumerates all `symmetry` rotations of one vector, so its
+    # result does not depend on the handedness of rotate(); a plain 2-D rotation stands in for it.
+    def rot(v, a):
+        return np.array([[np.cos(a), -np.sin(a)], [np.sin(a), np.cos(a)]]) @ v
+    GPA.rotate = rot
+    aniks = kvecs * np.array([1.04, 0.97])     # slightly anisotropic reference lattice
+    J_iso = pe.phasegradient2J(aniks, grads, weights, nmperpixel=0.5, iso_ref=True)
+    dks = GPA.calc_diff_from_isotropic(aniks)
+    rng = np.random.default_rng(11)
+    jac_rand = rng.normal(size=(40, 30, 2, 2)) + 1.5 * np.eye(2)
+    out = dict(grads=grads, weights=weights, kvecs=kvecs, J=J, aniks=aniks, J_iso=J_iso, dks=dks,
+               props=pe.props_from_Jac(np.eye(2) + J), props_diff=pe.props_from_Jac(np.eye(2) + J, refangle=3.0, refscale=2.0, diff=True),
+               jac_rand=jac_rand, props_rand=pe.props_from_Jac(jac_rand))
+    np.savez_compressed(os.path.join(OUT, 'props_64.npz'), **out)
+    print('props_64       done, mean twist-like angle %.3f deg' % out['props'][0].mean())
+
+
 def main():
     os.makedirs(OUT, exist_ok=True)
     GPA, pu = _import_reference()
@@ -253,6 +281,7 @@ def main():
     make_iterate_case(GPA, pu)
     make_unwrap_ramp(pu)
     make_warp_case(GPA)
+    make_props_case(GPA)
 
 
 if __name__ == '__main__':

@@ -46,6 +46,10 @@ SIGNATURES = {
     'gpa_extract_gradients': (_i, [_vp, _vp, _vp, _i, _vp, _i, _d, _i, _vp, _vp, _vp]),
     'gpa_invert_u_overlap': (_i, [_vp, _vp, _i, _i, _vp]),
     'gpa_undistort_image': (_i, [_vp, _vp, _vp, _vp]),
+    'gpa_phasegradient2J': (_i, [_vp, _vp, _i, _vp, _vp, _d, _vp, _vp]),
+    'gpa_phasegradient2J_dev': (_i, [_vp, _vp, _i, _vp, _vp, _d, _vp, _vp]),
+    'gpa_props_from_jac': (_i, [_i, _i, _sz, _vp, _i, _d, _d, _i, _vp]),
+    'gpa_props_from_jac_dev': (_i, [_i, _i, _sz, _vp, _i, _d, _d, _i, _vp, _vp]),
     'gpa_per_dft': (_i, [_vp, _vp, _vp]),
     'gpa_timer_start': (_i, [_vp]),
     'gpa_timer_stop': (_i, [_vp, _vp]),
@@ -208,6 +212,18 @@ class Plan:
         check(self.lib.gpa_undistort_image(self.handle, _ptr(deformed), _ptr(u), _ptr(out)), 'gpa_undistort_image')
         return out
 
+    def phasegradient2J(self, kvecs, grads, weights, nmperpixel, dks=None):
+        kvecs = _f64(kvecs).reshape(-1, 2)
+        grads = np.ascontiguousarray(grads, dtype=self.rdtype)
+        weights = np.ascontiguousarray(weights, dtype=self.rdtype)
+        if grads.shape != (len(kvecs),) + self.shape + (2,) or weights.shape != grads.shape[:-1]:
+            raise ValueError('grads must be (P,) + plan shape + (2,), weights (P,) + plan shape')
+        dks = None if dks is None else _f64(dks).reshape(len(kvecs), 2)
+        J = np.empty(self.shape + (2, 2), dtype=self.rdtype)
+        check(self.lib.gpa_phasegradient2J(self.handle, _ptr(kvecs), len(kvecs), _ptr(grads), _ptr(weights),
+                                           float(nmperpixel), _ptr(dks), _ptr(J)), 'gpa_phasegradient2J')
+        return J
+
     def per_dft(self, image):
         image = self._img(image)
         out = np.empty(self.shape, dtype=self.cdtype)
@@ -366,6 +382,22 @@ def get_plan(shape, batch, dtype=np.float64, device=0):
         p = Plan(shape, max(int(batch), 1), dtype, device)
         _plans[key] = p
     return p
+
+
+def props_from_jac(jac, add_identity=False, refangle=0., refscale=1., diff=False, dtype=np.float64, device=0):
+    """Plan-free f-2 entry: jac (..., 2, 2) -> props (4, ...)."""
+    dtype = np.dtype(dtype)
+    if dtype not in (np.dtype(np.float32), np.dtype(np.float64)):
+        raise ValueError('dtype must be float32 or float64')
+    jac = np.ascontiguousarray(jac, dtype=dtype)
+    if jac.shape[-2:] != (2, 2):
+        raise ValueError('jac must have shape (..., 2, 2)')
+    lead = jac.shape[:-2]
+    props = np.empty((4,) + lead, dtype=dtype)
+    check(load().gpa_props_from_jac(int(device), 0 if dtype == np.float32 else 1, jac.size // 4, _ptr(jac),
+                                    int(bool(add_identity)), float(refangle), float(refscale), int(bool(diff)),
+                                    _ptr(props)), 'gpa_props_from_jac')
+    return props
 
 
 @atexit.register

@@ -762,6 +762,71 @@ int gpa_per_dft(gpa_plan* p, const void* image, void* out) {
   return GPA_OK;
 }
 
+// ---- f-2 -------------------------------------------------------------------------
+int gpa_phasegradient2J_dev(gpa_plan* p, const double* kvecs, int P, const void* grads, const void* weights,
+                            double nmperpixel, const double* dks, void* J) {
+  if (!p || !kvecs || !grads || !weights || !J) return fail(GPA_ERR_ARG, "gpa_phasegradient2J: null argument");
+  if (P < 2 || P > p->max_peaks) return fail(GPA_ERR_STATE, "gpa_phasegradient2J: need 2 <= P <= 8 (and P <= max_batch)");
+  if (!(nmperpixel > 0.0)) return fail(GPA_ERR_ARG, "gpa_phasegradient2J: nmperpixel must be positive");
+  HIP_TRY(hipSetDevice(p->device));
+  double kiso[16];
+  for (int i = 0; i < 2 * P; ++i) kiso[i] = kvecs[i] + (dks ? dks[i] : 0.0);
+  TRY(stage_kmat(p, kiso, P));
+  HIP_TRY(launch_jacobian(p->dtype, grads, weights, p->d_kmat, P, (size_t)p->n0 * p->n1, nmperpixel, dks, J, p->stream));
+  return GPA_OK;
+}
+
+int gpa_phasegradient2J(gpa_plan* p, const double* kvecs, int P, const void* grads, const void* weights,
+                        double nmperpixel, const double* dks, void* J) {
+  if (!p || !kvecs || !grads || !weights || !J) return fail(GPA_ERR_ARG, "gpa_phasegradient2J: null argument");
+  if (P < 2 || P > p->max_peaks) return fail(GPA_ERR_STATE, "gpa_phasegradient2J: need 2 <= P <= 8 (and P <= max_batch)");
+  HIP_TRY(hipSetDevice(p->device));
+  const size_t npx = (size_t)p->n0 * p->n1;
+  void* d_J = nullptr;
+  HIP_TRY(hipMalloc(&d_J, 4 * npx * p->rsz));
+  int rc = GPA_OK;
+  hipError_t e = hipMemcpyAsync(p->d_lockin, grads, (size_t)P * npx * 2 * p->rsz, hipMemcpyHostToDevice, p->stream);
+  if (e == hipSuccess) e = hipMemcpyAsync(p->Tbuf, weights, (size_t)P * npx * p->rsz, hipMemcpyHostToDevice, p->stream);
+  if (e == hipSuccess) rc = gpa_phasegradient2J_dev(p, kvecs, P, p->d_lockin, p->Tbuf, nmperpixel, dks, d_J);
+  if (e == hipSuccess && rc == GPA_OK) e = hipMemcpyAsync(J, d_J, 4 * npx * p->rsz, hipMemcpyDeviceToHost, p->stream);
+  if (e == hipSuccess) e = hipStreamSynchronize(p->stream);
+  hipFree(d_J);
+  if (e != hipSuccess) return fail(GPA_ERR_HIP, std::string("gpa_phasegradient2J: ") + hipGetErrorString(e));
+  return rc;
+}
+
+int gpa_props_from_jac_dev(int device, int dtype, size_t npx, const void* jac, int add_identity, double refangle,
+                           double refscale, int diff, void* props, void* stream) {
+  if (!jac || !props) return fail(GPA_ERR_ARG, "gpa_props_from_jac: null argument");
+  if (dtype != GPA_F32 && dtype != GPA_F64) return fail(GPA_ERR_ARG, "gpa_props_from_jac: dtype must be GPA_F32 or GPA_F64");
+  if (npx == 0) return GPA_OK;
+  HIP_TRY(hipSetDevice(device));
+  HIP_TRY(launch_props(dtype, jac, npx, add_identity, refangle, refscale, diff, props, (hipStream_t)stream));
+  return GPA_OK;
+}
+
+int gpa_props_from_jac(int device, int dtype, size_t npx, const void* jac, int add_identity, double refangle,
+                       double refscale, int diff, void* props) {
+  if (!jac || !props) return fail(GPA_ERR_ARG, "gpa_props_from_jac: null argument");
+  if (dtype != GPA_F32 && dtype != GPA_F64) return fail(GPA_ERR_ARG, "gpa_props_from_jac: dtype must be GPA_F32 or GPA_F64");
+  if (npx == 0) return GPA_OK;
+  int ndev = 0;
+  if (hipGetDeviceCount(&ndev) != hipSuccess || ndev < 1) return fail(GPA_ERR_NODEV, "gpa_props_from_jac: no HIP device");
+  HIP_TRY(hipSetDevice(device));
+  const size_t bytes = 4 * npx * (dtype == GPA_F32 ? 4 : 8);
+  void *d_j = nullptr, *d_p = nullptr;
+  HIP_TRY(hipMalloc(&d_j, bytes));
+  hipError_t e = hipMalloc(&d_p, bytes);
+  int rc = GPA_OK;
+  if (e == hipSuccess) e = hipMemcpy(d_j, jac, bytes, hipMemcpyHostToDevice);
+  if (e == hipSuccess) rc = gpa_props_from_jac_dev(device, dtype, npx, d_j, add_identity, refangle, refscale, diff, d_p, nullptr);
+  if (e == hipSuccess && rc == GPA_OK) e = hipMemcpy(props, d_p, bytes, hipMemcpyDeviceToHost);
+  hipFree(d_j);
+  hipFree(d_p);
+  if (e != hipSuccess) return fail(GPA_ERR_HIP, std::string("gpa_props_from_jac: ") + hipGetErrorString(e));
+  return rc;
+}
+
 // ---- timing --------------------------------------------------------------------
 int gpa_timer_start(gpa_plan* p) {
   if (!p) return fail(GPA_ERR_ARG, "null plan");

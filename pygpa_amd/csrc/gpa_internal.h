@@ -87,6 +87,12 @@ hipError_t launch_reconstruct(int dtype, const void* lockin, const double* kmat 
 hipError_t launch_wlstsq(int dtype, const void* b, const void* w, const double* kmat, int P, size_t npx,
                          void* out, hipStream_t s);
 
+// f-2: grads (P x npx x 2) + weights (P x npx) -> J (npx x 2 x 2); Jac (+I) -> props (4 x npx)
+hipError_t launch_jacobian(int dtype, const void* grads, const void* w, const double* kmat, int P, size_t npx,
+                           double nmperpixel, const double* dks /*host P x 2 or null*/, void* J, hipStream_t s);
+hipError_t launch_props(int dtype, const void* jac, size_t npx, int add_identity, double refangle, double refscale,
+                        int diff, void* out, hipStream_t s);
+
 // ---- f-1 Lawler-Fujita (gpa_warp.hip); both synchronise the stream before returning -----------
 hipError_t warp_invert_u(int dtype, const void* d_u, int n0, int n1, double scale, int iters, int edge, void* d_out,
                          hipStream_t s);

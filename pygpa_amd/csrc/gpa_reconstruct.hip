@@ -173,6 +173,103 @@ hipError_t launch_wlstsq(int dtype, const void* b, const void* w, const double* 
   return hipGetLastError();
 }
 
+// ---- f-2: phase gradients -> Jacobian -> lattice properties --------------------------------
+// J[n,m,i,j] = (per-pixel weighted lstsq of grads[:, n, m, j])_i / nmperpixel: phasegradient2J with
+// iso_ref=False (property_extract.py:69-101).  One thread per pixel, both solves share the normal
+// matrix; grads are read as (d/dx, d/dy) pairs, J leaves as one 4-element store.
+template <class T> struct alignas(2 * sizeof(T)) Pair2 { T x, y; };
+template <class T> struct alignas(4 * sizeof(T)) Quad { T a, b, c, d; };
+
+// shift.on: gradients are taken relative to the isotropic lattice kvecs + dks, g <- wrapToPi(g - 2 pi dk)
+// (iso_ref=True, :87-92); kmat then already holds 2 pi (kvecs + dks).
+struct GradShift { double v[2 * MAXP]; int on; };
+
+template <class T>
+__global__ __launch_bounds__(256) void jacobian_kernel(const Pair2<T>* __restrict__ grads, const T* __restrict__ w,
+                                                      const double* __restrict__ kmat, int P, size_t npx,
+                                                      T inv_nm, GradShift shift, Quad<T>* __restrict__ J) {
+  const size_t o = (size_t)blockIdx.x * 256 + threadIdx.x;
+  if (o >= npx) return;
+  T wv[MAXP], wmax = T(0);
+  for (int p = 0; p < P; ++p) { wv[p] = w[p * npx + o]; const T a = wv[p] < T(0) ? -wv[p] : wv[p]; wmax = a > wmax ? a : wmax; }
+  const T ws = wmax > T(0) ? T(1) / wmax : T(0);
+  T a00 = 0, a01 = 0, a11 = 0, rx0 = 0, rx1 = 0, ry0 = 0, ry1 = 0;
+  for (int p = 0; p < P; ++p) {
+    const T k0 = (T)kmat[2 * p], k1 = (T)kmat[2 * p + 1], wn = wv[p] * ws, ww = wn * wn;
+    Pair2<T> g = grads[p * npx + o];
+    if (shift.on) {
+      g.x = wrap_to_pi(g.x - (T)shift.v[2 * p]);
+      g.y = wrap_to_pi(g.y - (T)shift.v[2 * p + 1]);
+    }
+    a00 += ww * k0 * k0; a01 += ww * k0 * k1; a11 += ww * k1 * k1;
+    rx0 += ww * k0 * g.x; rx1 += ww * k1 * g.x;
+    ry0 += ww * k0 * g.y; ry1 += ww * k1 * g.y;
+  }
+  T ux0, ux1, uy0, uy1;
+  solve2(a00, a01, a11, rx0, rx1, ux0, ux1);   // d u_i / d axis 0
+  solve2(a00, a01, a11, ry0, ry1, uy0, uy1);   // d u_i / d axis 1
+  J[o] = Quad<T>{ux0 * inv_nm, uy0 * inv_nm, ux1 * inv_nm, uy1 * inv_nm};
+}
+
+// (angle, aniangle, alpha, kappa) per pixel from the 2x2 Jacobian of the lattice transformation:
+// props_from_Jac (property_extract.py:137-178).  The reference takes a LAPACK SVD and normalises
+// the signs of U; for a 2x2 matrix the same quantities come in closed form from
+//   E,H = (a+d)/2, (c-b)/2   (rotation part),   F,G = (a-d)/2, (c+b)/2   (shear part):
+//   s0,s1 = Q+R, |Q-R| with Q=|(E,H)|, R=|(F,G)|; U = rot((atan2(H,E)+atan2(G,F))/2);
+//   U V^T = rot(atan2(H,E)) for det>0 and the reflection of angle -atan2(G,F) for det<0.
+template <class T>
+__global__ __launch_bounds__(256) void props_kernel(const Quad<T>* __restrict__ jac, size_t npx, T ident,
+                                                   T refangle, T refscale, int diff, T* __restrict__ out) {
+  const size_t o = (size_t)blockIdx.x * 256 + threadIdx.x;
+  if (o >= npx) return;
+  const Quad<T> j = jac[o];
+  T a = j.a + ident, b = j.b, c = j.c, d = j.d + ident;
+  // scale by the largest entry: the squares below must not leave the range of T
+  const T m = fmax(fmax(fabs(a), fabs(b)), fmax(fabs(c), fabs(d)));
+  const T im = m > T(0) ? T(1) / m : T(0);
+  a *= im; b *= im; c *= im; d *= im;
+  const T E = T(0.5) * (a + d), F = T(0.5) * (a - d), G = T(0.5) * (c + b), H = T(0.5) * (c - b);
+  const T Q = sqrt(E * E + H * H), R = sqrt(F * F + G * G);
+  const T s0 = Q + R, s1 = fabs(Q - R);
+  const T a1 = atan2(G, F), a2 = atan2(H, E);
+  const T deg = T(180) / Consts<T>::pi;
+  const T angle = (Q >= R ? a2 : -a1) * deg;
+  T ani = T(-0.5) * (a1 + a2) * deg + (diff ? T(90) : T(0));
+  ani -= T(180) * floor(ani / T(180));
+  out[o] = angle + refangle;
+  out[npx + o] = ani;
+  out[2 * npx + o] = (diff ? s0 : s1) * m * refscale;
+  out[3 * npx + o] = s0 / s1;
+}
+
+hipError_t launch_jacobian(int dtype, const void* grads, const void* w, const double* kmat, int P, size_t npx,
+                           double nmperpixel, const double* dks, void* J, hipStream_t s) {
+  if (P > MAXP || P < 2) return hipErrorInvalidValue;
+  const unsigned grid = (unsigned)((npx + 255) / 256);
+  GradShift shift{};
+  shift.on = dks != nullptr;
+  for (int i = 0; dks && i < 2 * P; ++i) shift.v[i] = 6.283185307179586476925 * dks[i];
+  if (dtype == 0)
+    jacobian_kernel<float><<<grid, 256, 0, s>>>((const Pair2<float>*)grads, (const float*)w, kmat, P, npx,
+                                                (float)(1.0 / nmperpixel), shift, (Quad<float>*)J);
+  else
+    jacobian_kernel<double><<<grid, 256, 0, s>>>((const Pair2<double>*)grads, (const double*)w, kmat, P, npx,
+                                                 1.0 / nmperpixel, shift, (Quad<double>*)J);
+  return hipGetLastError();
+}
+
+hipError_t launch_props(int dtype, const void* jac, size_t npx, int add_identity, double refangle, double refscale,
+                        int diff, void* out, hipStream_t s) {
+  const unsigned grid = (unsigned)((npx + 255) / 256);
+  if (dtype == 0)
+    props_kernel<float><<<grid, 256, 0, s>>>((const Quad<float>*)jac, npx, add_identity ? 1.f : 0.f, (float)refangle,
+                                             (float)refscale, diff, (float*)out);
+  else
+    props_kernel<double><<<grid, 256, 0, s>>>((const Quad<double>*)jac, npx, add_identity ? 1.0 : 0.0, refangle,
+                                              refscale, diff, (double*)out);
+  return hipGetLastError();
+}
+
 template <class T>
 static hipError_t launch_reconstruct_t(const void* lockin, const double* kmat, int P, int n0, int n1, int border,
                                        void* dudx, void* dudy, void* wnorm, hipStream_t s) {

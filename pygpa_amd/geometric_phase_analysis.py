@@ -12,7 +12,7 @@ import numpy as np
 
 from . import _lib
 from ._lib import GPAError  # noqa: F401
-from .mathtools import wrapToPi, fit_plane  # noqa: F401
+from .mathtools import wrapToPi, fit_plane, periodic_average  # noqa: F401
 
 DEFAULT_DTYPE = np.float64
 
@@ -92,6 +92,25 @@ def wfr2_grad_opt(image, sigma, kx, ky, kw, kstep, dtype=None):
 wfr2_grad = wfr2_grad_opt
 
 _NATIVE_SWEEPS = (optwfr2, wfr2_grad_opt)
+
+
+# ------------------------------------------------------------- k-vector helpers (host, P x 2)
+def average_lattice_vector(ks, symmetry=6):
+    """Mean-radius vector at the periodic-mean angle (geometric_phase_analysis.py:303-306)."""
+    ks = np.asarray(ks, dtype=np.float64)
+    dt = periodic_average(np.arctan2(ks[:, 1], ks[:, 0]), period=2 * np.pi / symmetry)
+    return np.linalg.norm(ks, axis=1).mean() * np.array([np.cos(dt), np.sin(dt)])
+
+
+def calc_diff_from_isotropic(ani_ks, symmetry=6):
+    """dks such that ani_ks + dks is an isotropic lattice (geometric_phase_analysis.py:309-322)."""
+    ani_ks = np.asarray(ani_ks, dtype=np.float64)
+    k_hex = average_lattice_vector(ani_ks, symmetry=symmetry)
+    th = np.arctan2(k_hex[1], k_hex[0]) + 2 * np.pi / symmetry * np.arange(symmetry)
+    ks_hex = np.linalg.norm(k_hex) * np.stack([np.cos(th), np.sin(th)], axis=-1)
+    alldiffs = ks_hex - ani_ks[:, None]
+    argmins = np.linalg.norm(alldiffs, axis=-1).argmin(axis=1)
+    return alldiffs[np.arange(len(ani_ks)), argmins]
 
 
 # --------------------------------------------------------------------------- a9

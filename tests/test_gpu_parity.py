@@ -399,3 +399,73 @@ def test_error_paths_and_extreme_shapes():
         out = p2.lockin_batch(im, [(0.05, 0.11)], 6.0)[0]
         assert rel(out, orc.lockin(im, (0.05, 0.11), 6.0, workers=8)) < tol
         p2.close()
+
+
+# ---- f-2: phase gradient -> Jacobian -> lattice properties -------------------------------------
+def _pdiff(x, y, period):
+    return (np.asarray(x) - y + period / 2) % period - period / 2
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize('dtype', DTYPES)
+def test_f2_jacobian_and_props_golden(golden, dtype):
+    from pygpa_amd import property_extract as pe
+    g = golden('props_64')
+    f32 = dtype == np.float32
+    J = pe.phasegradient2J(g['kvecs'], g['grads'], g['weights'], 0.5, iso_ref=False, dtype=dtype)
+    assert J.shape == g['J'].shape and J.dtype == dtype
+    scale = np.abs(g['J']).max()
+    assert np.abs(J - g['J']).max() <= (2e-5 if f32 else 1e-11) * scale
+    J_iso = pe.phasegradient2J(g['aniks'], g['grads'], g['weights'], 0.5, dtype=dtype)      # iso_ref=True default
+    assert np.abs(J_iso - g['J_iso']).max() <= (2e-5 if f32 else 1e-11) * np.abs(g['J_iso']).max()
+    # properties of the reference's own J: angles in degrees, alpha, kappa
+    for props, ref in ((pe.props_from_J(g['J'], dtype=dtype), g['props']),
+                       (pe.props_from_Jac(np.eye(2) + g['J'], 3.0, 2.0, True, dtype=dtype), g['props_diff']),
+                       (pe.props_from_Jac(g['jac_rand'], dtype=dtype), g['props_rand'])):
+        assert props.shape == ref.shape
+        kap = ref[3]
+        # the anisotropy direction is ill-conditioned as kappa -> 1 (error ~ eps / (kappa - 1))
+        tol_ani = (2e-5 if f32 else 1e-11) * (1 + 1 / (kap - 1)) * 57.3
+        assert np.all(np.abs(_pdiff(props[0], ref[0], 360)) <= (1e-4 if f32 else 1e-10))
+        assert np.all(np.abs(_pdiff(props[1], ref[1], 180)) <= tol_ani)
+        assert np.allclose(props[2], ref[2], rtol=1e-5 if f32 else 1e-12, atol=(2e-6 if f32 else 1e-13) * np.abs(ref[2] * kap).max())
+        assert np.allclose(props[3], ref[3], rtol=(2e-5 if f32 else 1e-11) * kap.max())
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize('dtype', DTYPES)
+def test_f2_props_vs_oracle_random(dtype):
+    """props_from_jac against the oracle's LAPACK SVD on random Jacobians of both orientations
+    (det > 0 and det < 0), away from the degenerate kappa = 1 and singular cases."""
+    rng = np.random.default_rng(5)
+    jac = rng.normal(size=(300, 200, 2, 2))
+    ref = orc.props_from_jac(jac)
+    ok = (ref[3] > 1.05) & (ref[3] < 1e3)
+    props = _lib.props_from_jac(jac, dtype=dtype)
+    f32 = dtype == np.float32
+    assert (np.linalg.det(jac)[ok] < 0).any() and (np.linalg.det(jac)[ok] > 0).any()
+    assert np.abs(_pdiff(props[0], ref[0], 360))[ok].max() <= (0.05 if f32 else 1e-8)
+    assert np.abs(_pdiff(props[1], ref[1], 180))[ok].max() <= (0.02 if f32 else 1e-8)
+    assert np.allclose(props[2][ok], ref[2][ok], rtol=2e-3 if f32 else 1e-9)
+    assert np.allclose(props[3][ok], ref[3][ok], rtol=2e-3 if f32 else 1e-9)
+
+
+@pytest.mark.gpu
+def test_f2_fused_from_sweep_vs_oracle():
+    """calc_props_from_phasegradient on the device sweep's own gradients against the oracle chain."""
+    from pygpa_amd import geometric_phase_analysis as GPA, property_extract as pe
+    n = 192
+    kvecs = hex_kvecs(0.11, 4.0)
+    img = hex_moire((n, n), kvecs, gaussian_bump_displacement((n, n)))
+    img0 = img - img.mean()
+    gs = [GPA.wfr2_grad_opt(img0, 12, k[0], k[1], kw=0.02, kstep=0.01) for k in kvecs]
+    grads = np.stack([x['grad'] for x in gs])
+    weights = np.stack([np.abs(x['lockin']) for x in gs])
+    props = pe.calc_props_from_phasegradient(kvecs, grads, weights, nmperpixel=1.0)
+    J_ref = orc.phasegradient2J(kvecs, grads, weights, 1.0, iso_ref=True)
+    _, theta_0, _ = pe.get_initial_props(kvecs)
+    ref = orc.props_from_jac(np.eye(2) + J_ref, refangle=theta_0)
+    assert np.abs(_pdiff(props[0], ref[0], 360)).max() < 1e-9
+    assert np.allclose(props[2], ref[2], rtol=1e-11) and np.allclose(props[3], ref[3], rtol=1e-10)
+    well = ref[3] > 1.001
+    assert np.abs(_pdiff(props[1], ref[1], 180))[well].max() < 1e-6

@@ -142,3 +142,17 @@ def test_f1_lawler_fujita(golden):
     assert np.allclose(orc.invert_u_overlap(-g['u']), g['u_inv'], rtol=0, atol=1e-12, equal_nan=True)
     assert np.allclose(orc.invert_u_overlap(-g['u'], iters=5, edge=4), g['u_inv_edge4_it5'], rtol=0, atol=1e-12, equal_nan=True)
     assert np.allclose(orc.undistort_image(g['deformed'], g['u']), g['reconstructed'], rtol=0, atol=1e-12)
+
+
+def test_f2_properties(golden):
+    g = golden('props_64')
+    J = orc.phasegradient2J(g['kvecs'], g['grads'], g['weights'], 0.5)
+    assert np.allclose(J, g['J'], rtol=1e-8, atol=1e-10)
+    assert np.allclose(orc.calc_diff_from_isotropic(g['aniks']), g['dks'], rtol=0, atol=1e-14)
+    J_iso = orc.phasegradient2J(g['aniks'], g['grads'], g['weights'], 0.5, iso_ref=True)
+    assert np.allclose(J_iso, g['J_iso'], rtol=1e-8, atol=1e-10)
+    iso = g['aniks'] + g['dks']
+    assert np.allclose(np.linalg.norm(iso, axis=1), np.linalg.norm(iso, axis=1)[0])
+    assert np.allclose(orc.props_from_jac(np.eye(2) + g['J']), g['props'], rtol=1e-12, atol=1e-12)
+    assert np.allclose(orc.props_from_jac(np.eye(2) + g['J'], 3.0, 2.0, True), g['props_diff'], rtol=1e-12, atol=1e-12)
+    assert np.allclose(orc.props_from_jac(g['jac_rand']), g['props_rand'], rtol=1e-12, atol=1e-12)
