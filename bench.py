@@ -126,41 +126,47 @@ def main():
     depth = max(1, args.inflight)
     # one plan (workspace + streams) per image in flight
     plans = [_lib.Plan((n, n), P * K, np_dt, device=dev_index) for _ in range(depth)]
+    # u buffers: with N > 1 at least two, so that the all_gather of step i (RCCL, torch's stream) overlaps
+    # the kernels of step i + 1 (plan streams), which write the other buffer
+    nb = depth if world == 1 else max(2, depth)
     if use_torch:
         dev = torch.device('cuda', dev_index)
         t_dt = torch.float32 if args.dtype == 'f32' else torch.float64
         t_img = torch.from_numpy(img).to(dev)
-        t_us = [torch.empty((2, n, n), dtype=t_dt, device=dev) for _ in range(depth)]
-        d_alls = [torch.empty((world, 2, n, n), dtype=t_dt, device=dev) for _ in range(depth)] if world > 1 else None
+        t_us = [torch.empty((2, n, n), dtype=t_dt, device=dev) for _ in range(nb)]
+        d_alls = [torch.empty((world, 2, n, n), dtype=t_dt, device=dev) for _ in range(nb)] if world > 1 else None
         img_ptr, u_ptrs = t_img.data_ptr(), [t.data_ptr() for t in t_us]
     else:
-        bufs = [_lib.DeviceBuffer(img.nbytes)] + [_lib.DeviceBuffer(2 * img.nbytes) for _ in range(depth)]
+        bufs = [_lib.DeviceBuffer(img.nbytes)] + [_lib.DeviceBuffer(2 * img.nbytes) for _ in range(nb)]
         bufs[0].upload(img)
         img_ptr, u_ptrs = bufs[0].ptr, [b.ptr for b in bufs[1:]]
         t_us = d_alls = None
-    gathered = [None] * depth
+    gathered = [None] * nb
     plan = plans[0]
 
-    def gather(j):
-        # stitch the tiles' fields of the step that ran on plan j (RCCL all_gather over xGMI)
-        plans[j].sync()
+    def gather(pj, j):
+        # stitch the tiles' fields of the step that ran on plan pj into buffer j (RCCL all_gather over xGMI);
+        # asynchronous on torch's stream, the event guards the reuse of u buffer j
+        plans[pj].sync()
         dist.all_gather_into_tensor(d_alls[j], t_us[j])
         ev = torch.cuda.Event()
         ev.record()
         gathered[j] = ev
 
     def run(nsteps):
+        pending = []
         for i in range(nsteps):
-            j = i % depth
+            j, pj = i % nb, i % depth
             if gathered[j] is not None:        # the collective that reads t_us[j] must be done before it is rewritten
                 gathered[j].synchronize()
                 gathered[j] = None
-            plans[j].extract_displacement_field_async(img_ptr, kvecs, klists, sigma, 2 * sigma, args.kmax, u_ptrs[j])
-            if world > 1 and i >= depth - 1:
-                gather((i - (depth - 1)) % depth)
-        if world > 1:
-            for i in range(max(0, nsteps - (depth - 1)), nsteps):
-                gather(i % depth)
+            plans[pj].extract_displacement_field_async(img_ptr, kvecs, klists, sigma, 2 * sigma, args.kmax, u_ptrs[j])
+            if world > 1:
+                pending.append((pj, j))
+                if len(pending) > depth - 1:
+                    gather(*pending.pop(0))
+        for pj, j in pending:
+            gather(pj, j)
 
     def fence():
         for pl in plans:

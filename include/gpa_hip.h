@@ -164,6 +164,21 @@ int gpa_extract_gradients(gpa_plan* plan, const void* image, const double* kvecs
                           const double* klists, int K, double sigma, int mask_border, void* dudx,
                           void* dudy, void* wnorm);
 
+/* device-resident tile stage (BASELINE configs 4-5): the window [r0, r0+n0) x [c0, c0+n1) of a
+ * larger image that lives on the device (row pitch image_pitch, in elements) is analysed like
+ * gpa_extract_gradients with `mean` (of the whole image, e.g. from gpa_mean_dev) subtracted, and
+ * the interior rectangle [i0, i0+t0) x [j0, j0+t1) (window coordinates) of dudx / dudy / wnorm is
+ * written to dx / dy / wn: 2 planes each for dx, dy (plane stride *_plane, row pitch *_pitch,
+ * elements), clipped to the one-short last column / row of the window's difference fields.  The
+ * destinations may be compact per-tile buffers (to be all-gathered) or the stitched fields of the
+ * whole image.  Asynchronous on the plan's stream (gpa_plan_sync).                            */
+int gpa_mean_dev(gpa_plan* plan, const void* data, size_t count, double* mean_out);
+int gpa_tile_gradients_dev(gpa_plan* plan, const void* image, size_t image_pitch, int r0, int c0,
+                           double mean, const double* kvecs, int P, const double* klists, int K,
+                           double sigma, int mask_border, int i0, int j0, int t0, int t1, void* dx,
+                           size_t dx_pitch, size_t dx_plane, void* dy, size_t dy_pitch,
+                           size_t dy_plane, void* wn, size_t wn_pitch);
+
 /* f-1 -- Lawler-Fujita undistortion.
  * gpa_invert_u_overlap: fixed-point inverse of a displacement field, `iters` rounds of cubic-
  *   spline resampling with mode='nearest' on the grid extended by `edge` pixels; replaces

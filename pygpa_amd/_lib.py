@@ -44,6 +44,9 @@ SIGNATURES = {
     'gpa_extract_displacement_field_async': (_i, [_vp, _vp, _vp, _i, _vp, _i, _d, _i, _i, _vp, _vp, _vp]),
     'gpa_last_iters': (_i, [_vp, _vp]),
     'gpa_extract_gradients': (_i, [_vp, _vp, _vp, _i, _vp, _i, _d, _i, _vp, _vp, _vp]),
+    'gpa_mean_dev': (_i, [_vp, _vp, _sz, _dp]),
+    'gpa_tile_gradients_dev': (_i, [_vp, _vp, _sz, _i, _i, _d, _vp, _i, _vp, _i, _d, _i, _i, _i, _i, _i,
+                                    _vp, _sz, _sz, _vp, _sz, _sz, _vp, _sz]),
     'gpa_invert_u_overlap': (_i, [_vp, _vp, _i, _i, _vp]),
     'gpa_undistort_image': (_i, [_vp, _vp, _vp, _vp]),
     'gpa_phasegradient2J': (_i, [_vp, _vp, _i, _vp, _vp, _d, _vp, _vp]),
@@ -284,6 +287,32 @@ class Plan:
         return dudx, dudy, wnorm
 
     # ---- device-pointer entry points (ints from torch.Tensor.data_ptr()) -----
+    def mean_dev(self, ptr, count):
+        out = C.c_double(0.0)
+        check(self.lib.gpa_mean_dev(self.handle, _ptr(int(ptr)), int(count), C.byref(out)), 'gpa_mean_dev')
+        return out.value
+
+    def tile_gradients_dev(self, image_ptr, image_pitch, r0, c0, mean, kvecs, klists, sigma, mask_border,
+                           interior, dx, dy, wn):
+        """interior = (i0, j0, t0, t1); dx, dy = (ptr, pitch, plane), wn = (ptr, pitch); element units."""
+        kvecs = _f64(kvecs).reshape(-1, 2)
+        P = len(kvecs)
+        klists = _f64(klists).reshape(P, -1, 2)
+        i0, j0, t0, t1 = (int(v) for v in interior)
+        check(self.lib.gpa_tile_gradients_dev(self.handle, _ptr(int(image_ptr)), int(image_pitch), int(r0), int(c0),
+                                              float(mean), _ptr(kvecs), P, _ptr(klists), klists.shape[1], float(sigma),
+                                              int(mask_border), i0, j0, t0, t1, _ptr(int(dx[0])), int(dx[1]), int(dx[2]),
+                                              _ptr(int(dy[0])), int(dy[1]), int(dy[2]), _ptr(int(wn[0])), int(wn[1])),
+              'gpa_tile_gradients_dev')
+
+    def unwrap_prediff_dev(self, dx_ptr, dy_ptr, weight_ptr, phi_ptr, kmax=100, eps=1e-9, axes_compat=True):
+        iters = C.c_int(0)
+        check(self.lib.gpa_unwrap_prediff_dev(self.handle, _ptr(int(dx_ptr)), _ptr(int(dy_ptr)),
+                                              _ptr(None if weight_ptr is None else int(weight_ptr)), int(kmax), float(eps),
+                                              int(bool(axes_compat)), _ptr(int(phi_ptr)), C.byref(iters)),
+              'gpa_unwrap_prediff_dev')
+        return iters.value
+
     def extract_displacement_field_dev(self, image_ptr, kvecs, klists, sigma, mask_border, kmax, u_ptr,
                                        lockins_ptr=None, kidx_ptr=None):
         kvecs = _f64(kvecs).reshape(-1, 2)

@@ -7,6 +7,7 @@
 
 #include <complex>
 #include <string>
+#include <limits>
 #include <vector>
 
 #include "../../include/gpa_hip.h"
@@ -123,6 +124,8 @@ struct gpa_plan {
   double* h_k = nullptr;          // pinned staging, 4 * max_batch doubles
   void* d_image = nullptr;        // staging for host-pointer entry points
   void* d_mean = nullptr;
+  void* d_tile_mean = nullptr;    // whole-image mean of the tile path (gpa_tile_gradients_dev)
+  double tile_mean = std::numeric_limits<double>::quiet_NaN();
   void* d_sf = nullptr;           // [K][n0][n1] complex, grown on demand (a4 gradient path)
   size_t sf_bytes = 0;
   void* d_grad = nullptr;         // n0 x n1 x 2 staging for the host-pointer a4 call
@@ -235,6 +238,7 @@ static int plan_build(gpa_plan* p) {
   HIP_TRY(hipHostMalloc((void**)&p->h_iters, 4 * sizeof(int)));
   TRY(dmalloc(p, &p->d_image, npx * p->rsz));
   TRY(dmalloc(p, &p->d_mean, 16));
+  TRY(dmalloc(p, &p->d_tile_mean, 16));
   TRY(dmalloc(p, (void**)&p->d_scratch, 4096 * sizeof(double)));
   p->max_peaks = B < 8 ? B : 8;
   TRY(dmalloc(p, &p->d_lockin, (size_t)p->max_peaks * npx * p->csz));
@@ -375,7 +379,7 @@ void gpa_plan_destroy(gpa_plan* p) {
   hipSetDevice(p->device);
   if (p->stream) hipStreamSynchronize(p->stream);
   void* bufs[] = {p->tw0, p->tw1, p->Hx, p->Hy, p->Tbuf, p->tb.cxb, p->tb.sx, p->tb.wxw, p->tb.cyb, p->tb.sy, p->tb.wyw, p->tb.planeof, p->d_pw,
-                  p->tb.dx, p->tb.dy, p->d_kl, p->d_kr, p->d_image, p->d_mean, p->d_scratch,
+                  p->tb.dx, p->tb.dy, p->d_kl, p->d_kr, p->d_image, p->d_mean, p->d_tile_mean, p->d_scratch,
                   p->d_lockin, p->d_kidx, p->d_dudx, p->d_dudy, p->d_wnorm, p->d_u, p->d_kmat, p->d_sf, p->d_grad};
   for (void* b : bufs)
     if (b) hipFree(b);
@@ -704,6 +708,68 @@ int gpa_extract_gradients(gpa_plan* p, const void* image, const double* kvecs, i
   HIP_TRY(hipMemcpyAsync(dudy, p->d_dudy, (size_t)2 * (p->n0 - 1) * p->n1 * p->rsz, hipMemcpyDeviceToHost, p->stream));
   HIP_TRY(hipMemcpyAsync(wnorm, p->d_wnorm, npx * p->rsz, hipMemcpyDeviceToHost, p->stream));
   HIP_TRY(hipStreamSynchronize(p->stream));
+  return GPA_OK;
+}
+
+int gpa_mean_dev(gpa_plan* p, const void* data, size_t count, double* mean_out) {
+  if (!p || !data || !mean_out || count == 0) return fail(GPA_ERR_ARG, "gpa_mean_dev: null argument");
+  HIP_TRY(hipSetDevice(p->device));
+  HIP_TRY(launch_mean(p->dtype, data, count, p->d_scratch, p->d_mean, p->stream));
+  double buf = 0.0;
+  HIP_TRY(hipMemcpyAsync(&buf, p->d_mean, p->rsz, hipMemcpyDeviceToHost, p->stream));
+  HIP_TRY(hipStreamSynchronize(p->stream));
+  *mean_out = p->dtype == GPA_F32 ? (double)*reinterpret_cast<float*>(&buf) : buf;
+  return GPA_OK;
+}
+
+int gpa_tile_gradients_dev(gpa_plan* p, const void* image, size_t image_pitch, int r0, int c0, double mean,
+                           const double* kvecs, int P, const double* klists, int K, double sigma, int mask_border,
+                           int i0, int j0, int t0, int t1, void* dx, size_t dx_pitch, size_t dx_plane, void* dy,
+                           size_t dy_pitch, size_t dy_plane, void* wn, size_t wn_pitch) {
+  if (!p || !image || !kvecs || !klists || !dx || !dy || !wn)
+    return fail(GPA_ERR_ARG, "gpa_tile_gradients_dev: null argument");
+  if (P < 2 || P > p->max_peaks) return fail(GPA_ERR_STATE, "gpa_tile_gradients_dev: need 2 <= P <= 8");
+  if (K < 1 || P * K > p->max_batch) return fail(GPA_ERR_STATE, "gpa_tile_gradients_dev: P*K exceeds max_batch");
+  const int n0 = p->n0, n1 = p->n1;
+  if (r0 < 0 || c0 < 0 || (size_t)c0 + n1 > image_pitch || i0 < 0 || j0 < 0 || t0 < 1 || t1 < 1 || i0 + t0 > n0 ||
+      j0 + t1 > n1)
+    return fail(GPA_ERR_ARG, "gpa_tile_gradients_dev: window / interior rectangle out of range");
+  HIP_TRY(hipSetDevice(p->device));
+  const size_t rsz = p->rsz;
+  hipStream_t st = p->stream;
+  // window -> plan image; the mean of the WHOLE image (geometric_phase_analysis.py:919) is subtracted by pass A
+  HIP_TRY(hipMemcpy2DAsync(p->d_image, (size_t)n1 * rsz, (const char*)image + ((size_t)r0 * image_pitch + c0) * rsz,
+                           image_pitch * rsz, (size_t)n1 * rsz, n0, hipMemcpyDeviceToDevice, st));
+  if (!(mean == p->tile_mean)) {   // tiles of one image share the mean: staged once (d_tile_mean is not d_mean,
+    HIP_TRY(hipStreamSynchronize(st));   // which the fused driver recomputes per call)
+    if (p->dtype == GPA_F32) {
+      *reinterpret_cast<float*>(p->h_k) = (float)mean;
+    } else {
+      p->h_k[0] = mean;
+    }
+    // h_k is pinned and also stages k-vectors: the copy must have left it before stage_kvectors rewrites it
+    HIP_TRY(hipMemcpyAsync(p->d_tile_mean, p->h_k, rsz, hipMemcpyHostToDevice, st));
+    HIP_TRY(hipStreamSynchronize(st));
+    p->tile_mean = mean;
+  }
+  TRY(sweep_peaks_dev(p, p->d_image, p->d_tile_mean, kvecs, P, klists, K, sigma, p->d_lockin, nullptr));
+  TRY(stage_kmat(p, kvecs, P));
+  HIP_TRY(launch_reconstruct(p->dtype, p->d_lockin, p->d_kmat, P, n0, n1, mask_border, p->d_dudx, p->d_dudy,
+                             p->d_wnorm, st));
+  // interiors -> destination; the difference fields are one column / row short of the window
+  const int wx = std::min(t1, n1 - 1 - j0), hy = std::min(t0, n0 - 1 - i0);
+  for (int c = 0; c < 2; ++c) {
+    if (wx > 0)
+      HIP_TRY(hipMemcpy2DAsync((char*)dx + c * dx_plane * rsz, dx_pitch * rsz,
+                               (const char*)p->d_dudx + (((size_t)c * n0 + i0) * (n1 - 1) + j0) * rsz,
+                               (size_t)(n1 - 1) * rsz, (size_t)wx * rsz, t0, hipMemcpyDeviceToDevice, st));
+    if (hy > 0)
+      HIP_TRY(hipMemcpy2DAsync((char*)dy + c * dy_plane * rsz, dy_pitch * rsz,
+                               (const char*)p->d_dudy + (((size_t)c * (n0 - 1) + i0) * n1 + j0) * rsz, (size_t)n1 * rsz,
+                               (size_t)t1 * rsz, hy, hipMemcpyDeviceToDevice, st));
+  }
+  HIP_TRY(hipMemcpy2DAsync(wn, wn_pitch * rsz, (const char*)p->d_wnorm + ((size_t)i0 * n1 + j0) * rsz, (size_t)n1 * rsz,
+                           (size_t)t1 * rsz, t0, hipMemcpyDeviceToDevice, st));
   return GPA_OK;
 }
 

@@ -24,7 +24,7 @@ namespace gpa {
 
 namespace {
 
-constexpr int MAXPART = 16384;   // one partial sum per image row / per grid-stride block
+constexpr int MAXPART = 65536;   // one partial sum per image row / per grid-stride block
 
 struct Impl {
   int dtype, n0, n1, lg0, lg1;

@@ -13,6 +13,12 @@ The reference has no tiling; the semantics are this build's:
   3. all_gather #1 stitches the gradient tiles; the weighted unwrap is a global solve, so
      component c of u is unwrapped once by rank c % world on the stitched fields;
   4. all_gather #2 distributes the two components.
+With the default compute (libgpa_hip.so) everything between the upload of the image and the download
+of u stays in HBM: windows are cut on the device, tile interiors are written by 2-D device copies into
+compact per-rank buffers (N > 1, all-gathered as device tensors) or straight into the stitched fields
+(N = 1), and the global unwrap reads them in place (`gpa_tile_gradients_dev`,
+`gpa_unwrap_prediff_dev`).  The `compute=` hook (host arrays) exists for the oracle and the gloo tests.
+
 Inside a tile the lock-in wraps around the WINDOW instead of the image, so results differ from
 the whole-image reference near window borders; the halo keeps that out of the interiors
 (tests compare against the oracle run on the same tiling, and tile interiors against the
@@ -27,22 +33,53 @@ def window_start(i, tile, halo, n):
     return int(min(max(i * tile - halo, 0), n - (tile + 2 * halo)))
 
 
-def tile_plan(shape, grid, halo):
-    """list of (tile index, window slices, interior offset inside the window)"""
-    n0, n1 = shape
-    g0, g1 = grid
-    if n0 % g0 or n1 % g1:
-        raise ValueError('image shape %s is not divisible by the tile grid %s' % (shape, grid))
-    t0, t1 = n0 // g0, n1 // g1
-    if t0 + 2 * halo > n0 or t1 + 2 * halo > n1:
-        raise ValueError('tile + 2*halo exceeds the image')
+def _axis_tiles(n, g, halo, W):
+    """(origin, size, window start) of the tiles along one axis.  g tiles of n / g pixels in windows of
+    n / g + 2 halo (W None), or windows of exactly W pixels (e.g. a power of two, which the lock-in
+    FFTs run natively instead of zero-padded to >= 2 W) around ceil(n / g) pixel tiles, g derived from
+    W when None; the last tile may be shorter."""
+    if W is None:
+        if n % g:
+            raise ValueError('axis length %d is not divisible into %d tiles' % (n, g))
+        t = n // g
+        if t + 2 * halo > n:
+            raise ValueError('tile + 2*halo exceeds the image')
+        return [(i * t, t, window_start(i, t, halo, n)) for i in range(g)], t, t + 2 * halo
+    if W > n:
+        raise ValueError('window %d exceeds the axis length %d' % (W, n))
+    if W == n:
+        return [(0, n, 0)], n, W
+    if W <= 2 * halo:
+        raise ValueError('window %d leaves no interior with halo %d' % (W, halo))
+    if g is None:
+        g = -(-n // (W - 2 * halo))
+    t = -(-n // g)
+    if t + 2 * halo > W:
+        raise ValueError('%d tiles of %d pixels + 2*halo do not fit windows of %d' % (g, t, W))
     out = []
-    for i in range(g0):
-        for j in range(g1):
-            s0, s1 = window_start(i, t0, halo, n0), window_start(j, t1, halo, n1)
-            out.append(((i, j), (slice(s0, s0 + t0 + 2 * halo), slice(s1, s1 + t1 + 2 * halo)),
-                        (i * t0 - s0, j * t1 - s1)))
-    return out, (t0, t1)
+    for i in range(g):
+        o, size = i * t, min(t, n - i * t)
+        if size <= 0:
+            break
+        out.append((o, size, int(min(max(o - (W - size) // 2, 0), n - W))))
+    return out, t, W
+
+
+def tile_plan(shape, grid, halo, window=None):
+    """Tiles of the image and the windows they are computed in.
+
+    Returns (tiles, (t0, t1), (w0, w1)): tiles is a list of ((i, j), window slices, offset of the tile
+    inside its window, tile size); (t0, t1) the largest tile, (w0, w1) the common window shape.
+    Tile (i, j) covers image[i*t0 : i*t0 + size0, j*t1 : j*t1 + size1]."""
+    g0, g1 = grid if grid is not None else (None, None)
+    W0, W1 = window if window is not None else (None, None)
+    a0, t0, w0 = _axis_tiles(shape[0], g0, halo, W0)
+    a1, t1, w1 = _axis_tiles(shape[1], g1, halo, W1)
+    out = []
+    for i, (o0, z0, s0) in enumerate(a0):
+        for j, (o1, z1, s1) in enumerate(a1):
+            out.append(((i, j), (slice(s0, s0 + w0), slice(s1, s1 + w1)), (o0 - s0, o1 - s1), (z0, z1)))
+    return out, (t0, t1), (w0, w1)
 
 
 def _dist():
@@ -93,8 +130,96 @@ def default_compute(window_shape, image_shape, nbatch, dtype, device):
     return gradients, unwrap
 
 
-def extract_displacement_field_tiled(image, kvecs, grid, sigma=None, kwscale=2.5, ksteps=3, klists=None,
-                                     halo=None, kmax=10, dtype=np.float64, device=0, group=None, compute=None):
+def _tiled_device(image, kvecs, klists, sigma, halo, kmax, dtype, device, group, tiles, tshape, wshape, world, rank,
+                  use_torch):
+    """Device-resident tile pipeline (module docstring): numpy image in, numpy (2, N, M) out."""
+    from . import _lib
+    dtype = np.dtype(dtype)
+    rsz = dtype.itemsize
+    n0, n1 = image.shape
+    t0, t1 = tshape
+    npx = n0 * n1
+    P, K = klists.shape[:2]
+    border = 2 * int(sigma)
+    plan_w = _lib.get_plan(wshape, P * K, dtype, device)
+    img = np.ascontiguousarray(image, dtype=dtype)
+    if not use_torch:
+        d_img = _lib.DeviceBuffer(img.nbytes)
+        d_img.upload(img)
+        mean = plan_w.mean_dev(d_img.ptr, npx)
+        gdx = _lib.DeviceBuffer(2 * n0 * (n1 - 1) * rsz)
+        gdy = _lib.DeviceBuffer(2 * (n0 - 1) * n1 * rsz)
+        gw = _lib.DeviceBuffer(npx * rsz)
+        for (i, j), (w0, w1), (o0, o1), (z0, z1) in tiles:
+            gi, gj = i * t0, j * t1
+            plan_w.tile_gradients_dev(d_img.ptr, n1, w0.start, w1.start, mean, kvecs, klists, sigma, border,
+                                      (o0, o1, z0, z1),
+                                      (gdx.ptr + (gi * (n1 - 1) + gj) * rsz, n1 - 1, n0 * (n1 - 1)),
+                                      (gdy.ptr + (gi * n1 + gj) * rsz, n1, (n0 - 1) * n1),
+                                      (gw.ptr + (gi * n1 + gj) * rsz, n1))
+        plan_w.sync()
+        d_img.free()
+        plan_g = _lib.get_plan(image.shape, 1, dtype, device)
+        d_u = _lib.DeviceBuffer(2 * npx * rsz)
+        for c in range(2):
+            plan_g.unwrap_prediff_dev(gdx.ptr + c * n0 * (n1 - 1) * rsz, gdy.ptr + c * (n0 - 1) * n1 * rsz, gw.ptr,
+                                      d_u.ptr + c * npx * rsz, kmax=kmax)
+        u = d_u.download((2, n0, n1), dtype)
+        for b in (gdx, gdy, gw, d_u):
+            b.free()
+        return u
+
+    torch, dist = _dist()
+    dev = torch.device('cuda', device)
+    t_dt = torch.float32 if dtype == np.float32 else torch.float64
+    multi = world > 1
+    t_img = torch.from_numpy(img).to(dev)
+    per_rank = (len(tiles) + world - 1) // world
+    local = torch.zeros((per_rank, 5, t0, t1), dtype=t_dt, device=dev)
+    torch.cuda.synchronize(dev)          # the plans run on their own streams
+    mean = plan_w.mean_dev(t_img.data_ptr(), npx)
+    plane = t0 * t1
+    for slot, idx in enumerate(range(rank, len(tiles), world)):
+        _, (w0, w1), (o0, o1), (z0, z1) = tiles[idx]
+        base = local[slot].data_ptr()
+        plan_w.tile_gradients_dev(t_img.data_ptr(), n1, w0.start, w1.start, mean, kvecs, klists, sigma, border,
+                                  (o0, o1, z0, z1), (base, t1, plane), (base + 2 * plane * rsz, t1, plane),
+                                  (base + 4 * plane * rsz, t1))
+    plan_w.sync()
+    # --- collective 1 (RCCL all_gather over xGMI): compact gradient tiles of every rank
+    if multi:
+        gathered = torch.empty((world,) + tuple(local.shape), dtype=t_dt, device=dev)
+        dist.all_gather_into_tensor(gathered, local, group=group)
+    else:
+        gathered = local[None]
+    full = torch.empty((5, n0, n1), dtype=t_dt, device=dev)
+    for idx, ((i, j), _, _, (z0, z1)) in enumerate(tiles):
+        full[:, i * t0:i * t0 + z0, j * t1:j * t1 + z1] = gathered[idx % world, idx // world, :, :z0, :z1]
+    del gathered, local, t_img
+    # --- global unwrap, one component per rank; collective 2 distributes the components
+    mine = torch.zeros((2, n0, n1), dtype=t_dt, device=dev)
+    todo = [c for c in range(2) if c % world == rank]
+    if todo:
+        w = full[4]
+        plan_g = _lib.get_plan(image.shape, 1, dtype, device)
+        for c in todo:
+            dx = full[c, :, :-1].contiguous()
+            dy = full[2 + c, :-1, :]
+            torch.cuda.synchronize(dev)
+            plan_g.unwrap_prediff_dev(dx.data_ptr(), dy.data_ptr(), w.data_ptr(), mine[c].data_ptr(), kmax=kmax)
+    torch.cuda.synchronize(dev)
+    if multi:
+        parts = torch.empty((world, 2, n0, n1), dtype=t_dt, device=dev)
+        dist.all_gather_into_tensor(parts, mine, group=group)
+        u = torch.stack([parts[c % world, c] for c in range(2)])
+    else:
+        u = mine
+    return u.cpu().numpy()
+
+
+def extract_displacement_field_tiled(image, kvecs, grid=None, sigma=None, kwscale=2.5, ksteps=3, klists=None,
+                                     halo=None, kmax=10, dtype=np.float64, device=0, group=None, compute=None,
+                                     window=None, _force_torch=False):
     """Tile-sharded `extract_displacement_field`.  Every rank passes the same full `image`
     (or at least its own windows' pixels) and receives the full (2, N, M) field."""
     world, rank = 1, 0
@@ -116,10 +241,10 @@ def extract_displacement_field_tiled(image, kvecs, grid, sigma=None, kwscale=2.5
         halo = 3 * int(sigma)
     if halo < 2 * sigma + 1:
         raise ValueError('halo must be at least 2*sigma + 1')
-    tiles, (t0, t1) = tile_plan(image.shape, grid, halo)
-    wshape = (t0 + 2 * halo, t1 + 2 * halo)
+    tiles, (t0, t1), wshape = tile_plan(image.shape, grid, halo, window)
     if compute is None:
-        compute = default_compute(wshape, image.shape, len(kvecs) * K, dtype, device)
+        return _tiled_device(image, kvecs, klists, sigma, halo, kmax, dtype, device, group, tiles, (t0, t1), wshape,
+                             world, rank, world > 1 or _force_torch)
     gradients, unwrap = compute
 
     # --- local stage: my tiles (round robin), interiors of dudx (2), dudy (2), wnorm (1)
@@ -127,23 +252,23 @@ def extract_displacement_field_tiled(image, kvecs, grid, sigma=None, kwscale=2.5
     local = np.zeros((per_rank, 5, t0, t1), dtype=dtype)
     mean = image.mean()      # the driver subtracts the IMAGE mean (geometric_phase_analysis.py:919)
     for slot, idx in enumerate(range(rank, len(tiles), world)):
-        _, (w0, w1), (o0, o1) = tiles[idx]
+        _, (w0, w1), (o0, o1), (z0, z1) = tiles[idx]
         dudx, dudy, wn = gradients(np.ascontiguousarray(image[w0, w1] - mean), kvecs, klists, sigma, 2 * int(sigma))
         # pad the difference fields to the window shape so interiors can be cut uniformly
         dx = np.zeros((2,) + wshape, dtype=dtype)
         dy = np.zeros((2,) + wshape, dtype=dtype)
         dx[:, :, :-1] = dudx
         dy[:, :-1, :] = dudy
-        local[slot, 0:2] = dx[:, o0:o0 + t0, o1:o1 + t1]
-        local[slot, 2:4] = dy[:, o0:o0 + t0, o1:o1 + t1]
-        local[slot, 4] = wn[o0:o0 + t0, o1:o1 + t1]
+        local[slot, 0:2, :z0, :z1] = dx[:, o0:o0 + z0, o1:o1 + z1]
+        local[slot, 2:4, :z0, :z1] = dy[:, o0:o0 + z0, o1:o1 + z1]
+        local[slot, 4, :z0, :z1] = wn[o0:o0 + z0, o1:o1 + z1]
 
     # --- collective 1: stitch the gradient tiles
     gathered = _all_gather_np(local, group)
     n0, n1 = image.shape
     full = np.zeros((5, n0, n1), dtype=dtype)
-    for idx, ((i, j), _, _) in enumerate(tiles):
-        full[:, i * t0:(i + 1) * t0, j * t1:(j + 1) * t1] = gathered[idx % world][idx // world]
+    for idx, ((i, j), _, _, (z0, z1)) in enumerate(tiles):
+        full[:, i * t0:i * t0 + z0, j * t1:j * t1 + z1] = gathered[idx % world][idx // world][:, :z0, :z1]
 
     # --- global unwrap, one component per rank; collective 2 distributes them
     mine = np.zeros((2, n0, n1), dtype=dtype)

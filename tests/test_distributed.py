@@ -44,13 +44,17 @@ def _case():
     return img, kvecs, explicit_klists(kvecs, kw, 2, 2)
 
 
-def _worker(rank, world, port, out_path):
+TILINGS = {'grid': dict(grid=(2, 2)), 'window': dict(grid=None, window=(64, 128))}
+
+
+def _worker(rank, world, port, out_path, tiling='grid'):
     sys.path.insert(0, ROOT)
     import torch.distributed as dist
     from pygpa_amd import distributed as D
     dist.init_process_group('gloo', init_method='tcp://127.0.0.1:%d' % port, rank=rank, world_size=world)
     img, kvecs, klists = _case()
-    u = D.extract_displacement_field_tiled(img, kvecs, (2, 2), klists=klists, halo=20, compute=_oracle_compute())
+    u = D.extract_displacement_field_tiled(img, kvecs, klists=klists, halo=20, compute=_oracle_compute(),
+                                           **TILINGS[tiling])
     np.save(out_path % rank, u)
     dist.barrier()
     dist.destroy_process_group()
@@ -58,11 +62,11 @@ def _worker(rank, world, port, out_path):
 
 def test_tile_plan_windows():
     from pygpa_amd import distributed as D
-    tiles, (t0, t1) = D.tile_plan((128, 192), (2, 3), 10)
-    assert (t0, t1) == (64, 64) and len(tiles) == 6
+    tiles, (t0, t1), wshape = D.tile_plan((128, 192), (2, 3), 10)
+    assert (t0, t1) == (64, 64) and len(tiles) == 6 and wshape == (84, 84)
     seen = np.zeros((128, 192), dtype=int)
-    for (i, j), (w0, w1), (o0, o1) in tiles:
-        assert w0.stop - w0.start == 84 and w1.stop - w1.start == 84
+    for (i, j), (w0, w1), (o0, o1), (z0, z1) in tiles:
+        assert w0.stop - w0.start == 84 and w1.stop - w1.start == 84 and (z0, z1) == (64, 64)
         assert 0 <= w0.start and w0.stop <= 128 and 0 <= w1.start and w1.stop <= 192
         assert w0.start + o0 == i * 64 and w1.start + o1 == j * 64
         seen[i * 64:(i + 1) * 64, j * 64:(j + 1) * 64] += 1
@@ -71,16 +75,40 @@ def test_tile_plan_windows():
         D.tile_plan((100, 100), (3, 3), 4)
 
 
-def test_tiled_world2_matches_world1(tmp_path):
+@pytest.mark.parametrize('shape,window,halo', [((300, 520), (128, 256), 12), ((256, 256), (256, 128), 20),
+                                               ((1000, 130), (64, 128), 8)])
+def test_tile_plan_explicit_windows(shape, window, halo):
+    """windows of a prescribed (power-of-two) shape: every pixel in exactly one tile, every tile at
+    least `halo` away from its window's edges unless that edge is the image's"""
+    from pygpa_amd import distributed as D
+    tiles, (t0, t1), wshape = D.tile_plan(shape, None, halo, window)
+    assert wshape == window
+    seen = np.zeros(shape, dtype=int)
+    for (i, j), (w0, w1), (o0, o1), (z0, z1) in tiles:
+        assert (w0.stop - w0.start, w1.stop - w1.start) == window
+        assert 0 <= w0.start and w0.stop <= shape[0] and 0 <= w1.start and w1.stop <= shape[1]
+        assert w0.start + o0 == i * t0 and w1.start + o1 == j * t1 and 0 < z0 <= t0 and 0 < z1 <= t1
+        for o, z, w, n in ((o0, z0, w0, shape[0]), (o1, z1, w1, shape[1])):
+            assert o >= halo or w.start == 0
+            assert (w.stop - w.start) - (o + z) >= halo or w.stop == n
+        seen[i * t0:i * t0 + z0, j * t1:j * t1 + z1] += 1
+    assert np.all(seen == 1)
+    with pytest.raises(ValueError):
+        D.tile_plan(shape, None, 64, (64, 64))
+
+
+@pytest.mark.parametrize('tiling', ['grid', 'window'])
+def test_tiled_world2_matches_world1(tmp_path, tiling):
     import torch.multiprocessing as mp
     from oracle import gpa_oracle as orc
     from pygpa_amd import distributed as D
     img, kvecs, klists = _case()
     # single process, no process group: the reference result of the SAME tiling
-    u1 = D.extract_displacement_field_tiled(img, kvecs, (2, 2), klists=klists, halo=20, compute=_oracle_compute())
+    u1 = D.extract_displacement_field_tiled(img, kvecs, klists=klists, halo=20, compute=_oracle_compute(),
+                                            **TILINGS[tiling])
     port = _free_port()
     out = str(tmp_path / 'u_rank%d.npy')
-    mp.spawn(_worker, args=(2, port, out), nprocs=2, join=True)
+    mp.spawn(_worker, args=(2, port, out, tiling), nprocs=2, join=True)
     for r in range(2):
         ur = np.load(out % r)
         assert np.array_equal(ur, u1), 'rank %d result differs from the single-process run' % r

@@ -6,6 +6,8 @@ Stated tolerances (relative to the largest magnitude of the compared array):
     f32 path: 2e-6 for lock-ins, 2e-5 for gradients, 2e-5 for PCG outputs
 Index / mask outputs (kidx, 'w') are compared bit-exactly; a mismatch is tolerated
 only where the two candidates' amplitudes tie to rounding (kidx_mismatch_is_tie)."""
+import os
+
 import numpy as np
 import pytest
 
@@ -469,3 +471,46 @@ def test_f2_fused_from_sweep_vs_oracle():
     assert np.allclose(props[2], ref[2], rtol=1e-11) and np.allclose(props[3], ref[3], rtol=1e-10)
     well = ref[3] > 1.001
     assert np.abs(_pdiff(props[1], ref[1], 180))[well].max() < 1e-6
+
+
+@pytest.mark.gpu
+def test_tiled_explicit_pow2_windows_vs_oracle():
+    """Power-of-two windows (native FFT lengths) around derived tiles, device-resident path against the
+    oracle on the same tiling."""
+    import test_distributed as TD
+    from pygpa_amd import distributed as D
+    img, kvecs, klists = TD._case()
+    u_ref = D.extract_displacement_field_tiled(img, kvecs, klists=klists, halo=20, window=(64, 128), compute=TD._oracle_compute())
+    u = D.extract_displacement_field_tiled(img, kvecs, klists=klists, halo=20, window=(64, 128))
+    assert rel(u, u_ref) < 1e-8
+    u32 = D.extract_displacement_field_tiled(img, kvecs, klists=klists, halo=20, window=(64, 128), dtype=np.float32)
+    assert rel(u32, u_ref) < 5e-4
+
+
+@pytest.mark.gpu
+def test_tiled_device_resident_equals_host_staged():
+    """The device-resident tile pipeline (2-D device copies into the stitched fields) and the
+    host-staged one (`compute=default_compute`) run the same kernels on the same windows."""
+    from pygpa_amd import distributed as D
+    kvecs = hex_kvecs(0.1, 7.0)
+    img = hex_moire((192, 256), kvecs, gaussian_bump_displacement((192, 256)), noise=0.05, seed=3)
+    klists = explicit_klists(kvecs, 0.04, 3, 3)
+    for dtype in DTYPES:
+        u_dev = D.extract_displacement_field_tiled(img, kvecs, (2, 2), klists=klists, halo=24, dtype=dtype)
+        comp = D.default_compute((96 + 48, 128 + 48), img.shape, 27, dtype, 0)
+        u_host = D.extract_displacement_field_tiled(img, kvecs, (2, 2), klists=klists, halo=24, dtype=dtype, compute=comp)
+        # the whole-image mean is reduced on the device in one path and by NumPy in the other
+        assert np.abs(u_dev - u_host).max() <= (5e-4 if dtype == np.float32 else 1e-9)
+
+
+@pytest.mark.gpu
+@pytest.mark.skipif(not os.environ.get('GPA_TEST_TORCH'), reason='imports torch (minutes on a cold box); set GPA_TEST_TORCH=1')
+def test_tiled_device_resident_torch_buffers():
+    """Same pipeline on torch device tensors (the N > 1 code path, collectives skipped at world 1)."""
+    from pygpa_amd import distributed as D
+    kvecs = hex_kvecs(0.1, 7.0)
+    img = hex_moire((192, 256), kvecs, gaussian_bump_displacement((192, 256)), noise=0.05, seed=3)
+    klists = explicit_klists(kvecs, 0.04, 3, 3)
+    u_dev = D.extract_displacement_field_tiled(img, kvecs, (2, 2), klists=klists, halo=24)
+    u_t = D.extract_displacement_field_tiled(img, kvecs, (2, 2), klists=klists, halo=24, _force_torch=True)
+    assert np.abs(u_dev - u_t).max() <= 1e-12
