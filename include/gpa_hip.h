@@ -213,6 +213,16 @@ int gpa_props_from_jac_dev(int device, int dtype, size_t npx, const void* jac, i
                            double refangle, double refscale, int diff, void* props,
                            void* stream);
 
+/* f-4 -- robust plane fit a0*x + a1*y + a2 (x = row, y = column index) through an n0 x n1 map:
+ * the minimiser of the Huber cost that fit_plane (mathtools.py:30-47, scipy least_squares with
+ * loss='huber', f_scale 1, start at 0) approaches, by iteratively reweighted least squares with the
+ * per-iteration sums reduced on the device.  Stops when the plane changes by <= tol (sum of the
+ * three coefficient changes in centred unit coordinates) or after max_iter passes.             */
+int gpa_fit_plane(gpa_plan* plan, const void* image, int max_iter, double tol, double* coef3,
+                  int* iters_out);
+int gpa_fit_plane_dev(gpa_plan* plan, const void* image, int max_iter, double tol, double* coef3,
+                      int* iters_out);
+
 /* a9 -- DFT of the periodic component of Moisan's periodic+smooth decomposition
  * (third-party moisan2011.per(image, inverse_dft=False)[0], call site
  * geometric_phase_analysis.py:429).  out: n0 x n1 complex.                    */

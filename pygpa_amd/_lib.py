@@ -11,7 +11,8 @@ import threading
 import numpy as np
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, 'libgpa_hip.so')
+# GPA_HIP_LIB selects another build of the same library (performance experiments, tools/variant.sh)
+LIB_PATH = os.environ.get('GPA_HIP_LIB') or os.path.join(_HERE, 'libgpa_hip.so')
 
 GPA_F32, GPA_F64 = 0, 1
 _DTYPES = {GPA_F32: (np.float32, np.complex64), GPA_F64: (np.float64, np.complex128)}
@@ -53,6 +54,8 @@ SIGNATURES = {
     'gpa_phasegradient2J_dev': (_i, [_vp, _vp, _i, _vp, _vp, _d, _vp, _vp]),
     'gpa_props_from_jac': (_i, [_i, _i, _sz, _vp, _i, _d, _d, _i, _vp]),
     'gpa_props_from_jac_dev': (_i, [_i, _i, _sz, _vp, _i, _d, _d, _i, _vp, _vp]),
+    'gpa_fit_plane': (_i, [_vp, _vp, _i, _d, _dp, _ip]),
+    'gpa_fit_plane_dev': (_i, [_vp, _vp, _i, _d, _dp, _ip]),
     'gpa_per_dft': (_i, [_vp, _vp, _vp]),
     'gpa_timer_start': (_i, [_vp]),
     'gpa_timer_stop': (_i, [_vp, _vp]),
@@ -226,6 +229,14 @@ class Plan:
         check(self.lib.gpa_phasegradient2J(self.handle, _ptr(kvecs), len(kvecs), _ptr(grads), _ptr(weights),
                                            float(nmperpixel), _ptr(dks), _ptr(J)), 'gpa_phasegradient2J')
         return J
+
+    def fit_plane(self, image, max_iter=200, tol=1e-12):
+        image = self._img(image)
+        coef = (C.c_double * 3)()
+        iters = C.c_int(0)
+        check(self.lib.gpa_fit_plane(self.handle, _ptr(image), int(max_iter), float(tol), coef, C.byref(iters)),
+              'gpa_fit_plane')
+        return np.array(coef[:]), iters.value
 
     def per_dft(self, image):
         image = self._img(image)

@@ -893,6 +893,58 @@ int gpa_props_from_jac(int device, int dtype, size_t npx, const void* jac, int a
   return rc;
 }
 
+// ---- f-4 -------------------------------------------------------------------------
+static bool solve3(const double* m /*uu uv u vv v 1*/, const double* b, double* x) {
+  const double A[3][3] = {{m[0], m[1], m[2]}, {m[1], m[3], m[4]}, {m[2], m[4], m[5]}};
+  const double det = A[0][0] * (A[1][1] * A[2][2] - A[1][2] * A[2][1]) - A[0][1] * (A[1][0] * A[2][2] - A[1][2] * A[2][0]) +
+                     A[0][2] * (A[1][0] * A[2][1] - A[1][1] * A[2][0]);
+  if (!(fabs(det) > 0.0)) return false;
+  for (int c = 0; c < 3; ++c) {
+    double M[3][3];
+    for (int i = 0; i < 3; ++i)
+      for (int j = 0; j < 3; ++j) M[i][j] = j == c ? b[i] : A[i][j];
+    x[c] = (M[0][0] * (M[1][1] * M[2][2] - M[1][2] * M[2][1]) - M[0][1] * (M[1][0] * M[2][2] - M[1][2] * M[2][0]) +
+            M[0][2] * (M[1][0] * M[2][1] - M[1][1] * M[2][0])) / det;
+  }
+  return true;
+}
+
+int gpa_fit_plane_dev(gpa_plan* p, const void* image, int max_iter, double tol, double* coef, int* iters_out) {
+  if (!p || !image || !coef) return fail(GPA_ERR_ARG, "gpa_fit_plane: null argument");
+  if (max_iter < 1 || !(tol >= 0.0)) return fail(GPA_ERR_ARG, "gpa_fit_plane: need max_iter >= 1, tol >= 0");
+  HIP_TRY(hipSetDevice(p->device));
+  const int n0 = p->n0, n1 = p->n1;
+  // centred, unit-scaled coordinates keep the normal matrix well conditioned
+  const double cx = 0.5 * (n0 - 1), cy = 0.5 * (n1 - 1), sx = 0.5 * n0, sy = 0.5 * n1;
+  double c[3] = {0.0, 0.0, 0.0};   // start at the zero plane like the reference (x0 = [0, 0, 0])
+  double sums[10];
+  int it = 0;
+  for (; it < max_iter; ++it) {
+    HIP_TRY(launch_huber_moments(p->dtype, image, n0, n1, c, cx, cy, sx, sy, p->d_scratch, p->stream));
+    HIP_TRY(hipMemcpyAsync(sums, p->d_scratch + 2560, sizeof(sums), hipMemcpyDeviceToHost, p->stream));
+    HIP_TRY(hipStreamSynchronize(p->stream));
+    double nc[3];
+    if (!solve3(sums, sums + 6, nc)) return fail(GPA_ERR_STATE, "gpa_fit_plane: singular normal equations");
+    // change of the fitted plane over the image, in units of the data
+    const double step = fabs(nc[0] - c[0]) + fabs(nc[1] - c[1]) + fabs(nc[2] - c[2]);
+    c[0] = nc[0]; c[1] = nc[1]; c[2] = nc[2];
+    if (step <= tol) { ++it; break; }
+  }
+  // back to pixel indices: a0 x + a1 y + a2
+  coef[0] = c[0] / sx;
+  coef[1] = c[1] / sy;
+  coef[2] = c[2] - c[0] * cx / sx - c[1] * cy / sy;
+  if (iters_out) *iters_out = it;
+  return GPA_OK;
+}
+
+int gpa_fit_plane(gpa_plan* p, const void* image, int max_iter, double tol, double* coef, int* iters_out) {
+  if (!p || !image || !coef) return fail(GPA_ERR_ARG, "gpa_fit_plane: null argument");
+  HIP_TRY(hipSetDevice(p->device));
+  HIP_TRY(hipMemcpyAsync(p->d_image, image, (size_t)p->n0 * p->n1 * p->rsz, hipMemcpyHostToDevice, p->stream));
+  return gpa_fit_plane_dev(p, p->d_image, max_iter, tol, coef, iters_out);
+}
+
 // ---- timing --------------------------------------------------------------------
 int gpa_timer_start(gpa_plan* p) {
   if (!p) return fail(GPA_ERR_ARG, "null plan");

@@ -93,6 +93,10 @@ hipError_t launch_jacobian(int dtype, const void* grads, const void* w, const do
 hipError_t launch_props(int dtype, const void* jac, size_t npx, int add_identity, double refangle, double refscale,
                         int diff, void* out, hipStream_t s);
 
+// f-4: one IRLS pass of the Huber plane fit; ten sums at scratch + 2560 (scratch >= 2570 doubles)
+hipError_t launch_huber_moments(int dtype, const void* img, int n0, int n1, const double* coef, double cx, double cy,
+                                double sx, double sy, double* scratch, hipStream_t s);
+
 // ---- f-1 Lawler-Fujita (gpa_warp.hip); both synchronise the stream before returning -----------
 hipError_t warp_invert_u(int dtype, const void* d_u, int n0, int n1, double scale, int iters, int edge, void* d_out,
                          hipStream_t s);

@@ -270,6 +270,74 @@ hipError_t launch_props(int dtype, const void* jac, size_t npx, int add_identity
   return hipGetLastError();
 }
 
+// ---- f-4: robust plane fit (mathtools.py:30-47) -----------------------------------------------
+// The reference minimises sum rho_huber(r^2) of r = image - (a0 x + a1 y + a2) with
+// scipy.optimize.least_squares(loss='huber', f_scale=1).  That cost is convex; its minimiser is the
+// fixed point of iteratively reweighted least squares with w = 1 for |r| <= 1 and 1/|r| beyond.
+// One pass over the image per iteration accumulates the weighted normal equations in centred, scaled
+// coordinates (u = (x - cx) / sx, v = (y - cy) / sy) in double; the 3x3 solve is the host's.
+// sums: 0..5 = w*(uu, uv, u, vv, v, 1), 6..8 = w*(u z, v z, z), 9 = cost = sum 0.5 rho
+template <class T>
+__global__ __launch_bounds__(256) void huber_moments_kernel(const T* __restrict__ img, int n0, int n1, double a0,
+                                                           double a1, double a2, double cx, double cy, double isx,
+                                                           double isy, double* __restrict__ part) {
+  double acc[10];
+#pragma unroll
+  for (int k = 0; k < 10; ++k) acc[k] = 0.0;
+  const size_t npx = (size_t)n0 * n1;
+  for (size_t o = (size_t)blockIdx.x * 256 + threadIdx.x; o < npx; o += (size_t)gridDim.x * 256) {
+    const int x = (int)(o / n1), y = (int)(o - (size_t)x * n1);
+    const double u = (x - cx) * isx, v = (y - cy) * isy, z = (double)img[o];
+    const double r = z - (a0 * u + a1 * v + a2), ar = fabs(r);
+    const double w = ar <= 1.0 ? 1.0 : 1.0 / ar;
+    acc[0] += w * u * u; acc[1] += w * u * v; acc[2] += w * u; acc[3] += w * v * v; acc[4] += w * v; acc[5] += w;
+    acc[6] += w * u * z; acc[7] += w * v * z; acc[8] += w * z;
+    acc[9] += ar <= 1.0 ? 0.5 * r * r : ar - 0.5;
+  }
+  __shared__ double sh[256];
+  for (int k = 0; k < 10; ++k) {
+    sh[threadIdx.x] = acc[k];
+    __syncthreads();
+    for (int s = 128; s > 0; s >>= 1) {
+      if (threadIdx.x < s) sh[threadIdx.x] += sh[threadIdx.x + s];
+      __syncthreads();
+    }
+    if (threadIdx.x == 0) part[(size_t)k * gridDim.x + blockIdx.x] = sh[0];
+    __syncthreads();
+  }
+}
+
+__global__ __launch_bounds__(256) void huber_final_kernel(const double* __restrict__ part, int nparts,
+                                                         double* __restrict__ out) {
+  __shared__ double sh[256];
+  for (int k = 0; k < 10; ++k) {
+    double a = 0.0;
+    for (int i = threadIdx.x; i < nparts; i += 256) a += part[(size_t)k * nparts + i];
+    sh[threadIdx.x] = a;
+    __syncthreads();
+    for (int s = 128; s > 0; s >>= 1) {
+      if (threadIdx.x < s) sh[threadIdx.x] += sh[threadIdx.x + s];
+      __syncthreads();
+    }
+    if (threadIdx.x == 0) out[k] = sh[0];
+    __syncthreads();
+  }
+}
+
+// scratch: >= 10 * 256 + 10 doubles; the ten sums land at scratch + 2560
+hipError_t launch_huber_moments(int dtype, const void* img, int n0, int n1, const double* coef, double cx, double cy,
+                                double sx, double sy, double* scratch, hipStream_t s) {
+  const int nparts = 256;
+  if (dtype == 0)
+    huber_moments_kernel<float><<<nparts, 256, 0, s>>>((const float*)img, n0, n1, coef[0], coef[1], coef[2], cx, cy,
+                                                       1.0 / sx, 1.0 / sy, scratch);
+  else
+    huber_moments_kernel<double><<<nparts, 256, 0, s>>>((const double*)img, n0, n1, coef[0], coef[1], coef[2], cx, cy,
+                                                        1.0 / sx, 1.0 / sy, scratch);
+  huber_final_kernel<<<1, 256, 0, s>>>(scratch, nparts, scratch + 10 * nparts);
+  return hipGetLastError();
+}
+
 template <class T>
 static hipError_t launch_reconstruct_t(const void* lockin, const double* kmat, int P, int n0, int n1, int border,
                                        void* dudx, void* dudy, void* wnorm, hipStream_t s) {

@@ -427,7 +427,10 @@ struct ColGeom {
   // as in pass A of the sweep: two transforms per f32 thread (adjacent pairs = 4 real
   // columns = one 16-byte access per row), the CT pairs that sit side by side in the
   // thread index interleaved element by element in LDS
-  static constexpr int NT = (sizeof(T) == 4 && CC >= 2) ? 2 : 1;
+#ifndef GPA_COL_NT
+#define GPA_COL_NT 2
+#endif
+  static constexpr int NT = (sizeof(T) == 4 && CC >= 2) ? GPA_COL_NT : 1;
   static constexpr int CT = CC / NT;
   static constexpr int REGION = CT * F::LDS_ELEMS;
   static constexpr int THREADS = CT * F::TPF;

@@ -135,7 +135,7 @@ def fit_delta_k(phases):
 def iterate_GPA(image, kvecs, sigma, edge=5, iters=3, kmax_iter=25, kmax=200, verbose=False, dtype=None):
     """Iterate GPA, refining the reference vectors towards the extracted average
     (geometric_phase_analysis.py:116-154).  Lock-ins and weighted unwraps run on the
-    device, the 3-parameter Huber plane fit on the host as in the reference.
+    device, including the 3-parameter Huber plane fit (gpa_fit_plane).
 
     Returns (prs, w, corr) like the reference."""
     from . import phase_unwrap as _pu

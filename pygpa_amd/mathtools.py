@@ -7,19 +7,21 @@ def wrapToPi(x):
     return (x + np.pi) % (2 * np.pi) - np.pi
 
 
-def fit_plane(image, verbose=False):
-    """Huber-loss plane fit a[0]*x + a[1]*y + a[2] through `image` (reference
-    pyGPA/mathtools.py:30-47).  A 3-parameter robust fit: host-side SciPy in the reference
-    and here ("Huber fit is host-side SciPy (stays on host)")."""
-    import scipy.optimize as spo
-    lxx, lyy = np.meshgrid(np.arange(image.shape[0]), np.arange(image.shape[1]), indexing='ij')
-
-    def resid(x):
-        return (image - (x[0] * lxx + x[1] * lyy + x[2])).ravel()
-    res = spo.least_squares(resid, np.zeros(3), loss='huber')
+def fit_plane(image, verbose=False, dtype=None):
+    """Huber-loss plane fit a[0]*x + a[1]*y + a[2] through `image` (x, y = row, column index;
+    reference pyGPA/mathtools.py:30-47).  The reference runs scipy.optimize.least_squares with
+    loss='huber'; here the same convex cost is minimised by iteratively reweighted least squares
+    whose per-pass sums are reduced on the device (gpa_fit_plane, include/gpa_hip.h)."""
+    from . import _lib
+    image = np.asarray(image)
+    if image.ndim != 2:
+        raise ValueError('image must be 2-D')
+    if dtype is None:
+        dtype = np.float32 if image.dtype == np.float32 else np.float64
+    coef, iters = _lib.get_plan(image.shape, 1, dtype).fit_plane(image)
     if verbose:
-        print(res.message)
-    return res.x
+        print('IRLS Huber plane fit: %d passes' % iters)
+    return coef
 
 
 def periodic_average(X, period=2 * np.pi, weights=1., **kwargs):

@@ -514,3 +514,26 @@ def test_tiled_device_resident_torch_buffers():
     u_dev = D.extract_displacement_field_tiled(img, kvecs, (2, 2), klists=klists, halo=24)
     u_t = D.extract_displacement_field_tiled(img, kvecs, (2, 2), klists=klists, halo=24, _force_torch=True)
     assert np.abs(u_dev - u_t).max() <= 1e-12
+
+
+# ---- f-4: Huber plane fit ------------------------------------------------------------------------
+@pytest.mark.gpu
+@pytest.mark.parametrize('dtype', DTYPES)
+def test_f4_fit_plane_vs_scipy(dtype):
+    """gpa_fit_plane (IRLS, device reductions) against the reference's scipy least_squares(loss='huber')
+    on a noisy tilted phase map with an outlier patch and a bump; SciPy stops at ftol = 1e-8."""
+    from pygpa_amd import mathtools
+    rng = np.random.default_rng(0)
+    n0, n1 = 200, 240
+    x, y = np.meshgrid(np.arange(n0), np.arange(n1), indexing='ij')
+    img = 0.013 * x - 0.021 * y + 0.4 + 0.3 * rng.normal(size=(n0, n1))
+    img[50:90, 60:120] += 6.0
+    img += 3 * np.exp(-((x - 150) ** 2 + (y - 50) ** 2) / 300.)
+    ref = orc.fit_plane(img)
+    got = mathtools.fit_plane(img.astype(dtype))
+    # slopes in rad/pixel, offset in rad; f32 only rounds the input image
+    assert np.allclose(got[:2], ref[:2], rtol=0, atol=1e-6 * np.abs(ref[:2]).max() + (1e-8 if dtype == np.float32 else 0))
+    assert abs(got[2] - ref[2]) < (1e-5 if dtype == np.float32 else 1e-6)
+    # an exact plane is recovered exactly, in one or two passes
+    coef, iters = _lib.get_plan((n0, n1), 1, np.float64).fit_plane(0.5 * x - 0.25 * y + 3.0)
+    assert np.allclose(coef, [0.5, -0.25, 3.0], rtol=1e-12, atol=1e-10) and iters <= 60
