@@ -228,6 +228,19 @@ int gpa_fit_plane_dev(gpa_plan* plan, const void* image, int max_iter, double to
  * geometric_phase_analysis.py:429).  out: n0 x n1 complex.                    */
 int gpa_per_dft(gpa_plan* plan, const void* image, void* out);
 
+/* f-3 -- Bragg-peak candidates, the array work of extract_primary_ks
+ * (geometric_phase_analysis.py:427-437): smooth = gaussian_filter(|fftshift(per_dft(image - mean))|,
+ * sigma) minus, when dog_sigma > 0, the same with dog_sigma (scipy.ndimage.gaussian_filter
+ * semantics: truncate 4, mode 'reflect'); peaks = skimage.feature.peak_local_max(smooth,
+ * threshold_rel=threshold_rel) with its defaults (3x3 maxima above max(min, rel*max), 1-pixel
+ * border excluded).  image: n0 x n1 (host).  coords: up to max_out (row, column) pairs in the
+ * fftshift-ed frame, values: their smooth values (plan dtype), in no particular order (sort by
+ * value, then raster index, for skimage's order); *count_out = number found (> max_out means
+ * the arrays hold only a subset: call again with more room).  smooth_out: n0 x n1 or NULL.   */
+int gpa_find_peaks(gpa_plan* plan, const void* image, double sigma, double dog_sigma,
+                   double threshold_rel, int max_out, int32_t* coords, void* values,
+                   int* count_out, void* smooth_out);
+
 /* timing hooks used by bench.py: elapsed milliseconds between two recorded
  * events on the plan's stream (HIP events, so it measures the stream the
  * kernels are launched on).                                                   */

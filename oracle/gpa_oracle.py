@@ -6,7 +6,9 @@ HIP path is compared against and the ``cpu_baseline`` leg of ``bench.py``.
 Only ``tests/``, ``__graft_entry__.smoke()`` and ``bench.py``'s cpu_baseline may
 import this module; the product package ``pygpa_amd`` never does.
 
-Parity status: PINNED for a1..a8, f-1 (Lawler-Fujita) and f-2 (Jacobian / lattice properties) -- every function below is checked against
+Parity status: PINNED for a1..a8, f-1 (Lawler-Fujita), f-2 (Jacobian / lattice properties), f-4 (Huber
+plane fit = the reference's SciPy call) and the driver logic + smoothing of f-3 (peak finding, with
+declared stand-ins for moisan2011.per and skimage.feature.peak_local_max) -- every function below is checked against
 outputs of the real reference (imported from /root/reference in the build
 container by ``oracle/make_golden.py``; vectors committed under
 ``tests/golden/``) by ``tests/test_oracle_golden.py``.
@@ -523,3 +525,134 @@ def per(image, inverse_dft=True):
     if inverse_dft:
         return np.real(np.fft.ifft2(phat)), np.real(np.fft.ifft2(shat))
     return phat, shat
+
+
+# --------------------------------------------------------------------------
+# f-3: peak finding -- extract_primary_ks, gpa.py:397-548.
+# Pinned against the reference's own driver logic with two declared stand-ins for third-party
+# functions that are absent from this image (oracle/make_golden.py): moisan2011.per -> per() above,
+# skimage.feature.peak_local_max -> peak_local_max() below (restated from scikit-image >= 0.19).
+# --------------------------------------------------------------------------
+def peak_local_max(image, threshold_rel):
+    """skimage.feature.peak_local_max(image, threshold_rel=...) with its defaults min_distance=1,
+    exclude_border=True: pixels equal to the maximum of their 3x3 neighbourhood and above
+    max(image.min(), threshold_rel * image.max()), one border pixel excluded, highest first
+    (stable, i.e. raster order among equals); ensure_spacing is a no-op at min_distance 1."""
+    import scipy.ndimage as ndi
+    image = np.asarray(image)
+    thr = max(image.min(), threshold_rel * image.max())
+    mask = (image == ndi.maximum_filter(image, footprint=np.ones((3, 3)), mode='nearest'))
+    if np.all(mask):
+        mask[:] = False
+    mask &= image > thr
+    mask[0, :] = mask[-1, :] = False
+    mask[:, 0] = mask[:, -1] = False
+    coord = np.nonzero(mask)
+    order = np.argsort(-image[coord], kind='stable')
+    return np.transpose(coord)[order]
+
+
+def smoothed_spectrum(image, sigma=1, DoG=True):
+    """|fftshift(per(image - mean))| smoothed by a Gaussian (minus a sigma=50 one), gpa.py:427-434."""
+    import scipy.ndimage as ndi
+    image = np.asarray(image, dtype=np.float64)
+    pd, _ = per(image - image.mean(), inverse_dft=False)
+    fftim = np.abs(np.fft.fftshift(pd))
+    smooth = ndi.gaussian_filter(fftim, sigma=sigma)
+    if DoG:
+        smooth -= ndi.gaussian_filter(fftim, sigma=50)
+    return smooth
+
+
+def fftbounds(n, d=1):
+    """imagetools.py:22-26"""
+    r = np.fft.fftshift(np.fft.fftfreq(n, d))
+    return np.append(r, r[-1] + 1 / (n * d))
+
+
+def remove_negative_duplicates(ks):
+    """mathtools.py:78-94"""
+    if ks.shape[0] == 0:
+        return ks
+    nonneg = np.where(np.sign(ks[:, [0]]) != 0, np.sign(ks[:, [0]]) * ks, np.sign(ks[:, [1]]) * ks)
+    npks = [nonneg[0]]
+    atol = 1e-3 * np.min(np.abs(nonneg), axis=1).mean()
+    for k in nonneg[1:]:
+        if not np.any(np.all(np.isclose(k, npks, atol=atol), axis=1)):
+            npks.append(k)
+    return np.array(npks)
+
+
+def _decrease_threshold(t):
+    """gpa.py:388-394"""
+    if t > 0.001:
+        t = t - 0.1 if t >= 0.2 else t / 2
+    return t
+
+
+def smallest_sum(ks):
+    """gpa.py:538-548"""
+    M = np.ones((3, 3)) - 2 * np.eye(3)
+    sums = M @ ks
+    return sums[np.argmin(np.linalg.norm(sums, axis=1))]
+
+
+def select_closest_to_triangle(ks):
+    """gpa.py:529-535"""
+    from itertools import combinations
+    combis = list(combinations(ks, 3))
+    sums = [np.linalg.norm(smallest_sum(np.array(c))) for c in combis]
+    return np.array(combis[int(np.argmin(sums))])
+
+
+def extract_primary_ks(image, threshold=0.7, pix_norm_range=(2, 200), sigma=1, DoG=True):
+    """gpa.py:397-505 (plotting dropped).  As in the reference, the recursive calls do not pass DoG on
+    (it falls back to its default True)."""
+    image = np.asarray(image, dtype=np.float64)
+    smooth = smoothed_spectrum(image, sigma, DoG)
+    kxs, kys = [fftbounds(n) for n in smooth.shape]
+    center = np.array(smooth.shape) // 2
+    cindices = peak_local_max(smooth, threshold_rel=threshold)
+    coords = cindices - center
+    norms = np.linalg.norm(coords, axis=1)
+    selection = np.logical_and(norms < pix_norm_range[1], norms > pix_norm_range[0])
+    cindices = cindices[selection]
+    coords = coords[selection]
+    all_ks = np.array([kxs[cindices.T[0]], kys[cindices.T[1]]]).T
+    all_ks = remove_negative_duplicates(all_ks)
+    newparams = False
+    if len(all_ks) < 3:
+        newparams = True
+        if len(all_ks) == 0:
+            if threshold > _decrease_threshold(threshold):
+                threshold = _decrease_threshold(threshold)
+            else:
+                newparams = False
+        else:
+            coordsminlength = np.linalg.norm(coords, axis=1).min()
+            top = 0.2 * np.max([smooth[c[0], c[1]] for c in cindices])
+            if coordsminlength < 5 * sigma:
+                sigma = coordsminlength / 6
+            elif threshold > top:
+                threshold = top
+            elif threshold > _decrease_threshold(threshold):
+                threshold = _decrease_threshold(threshold)
+            else:
+                newparams = False
+        if newparams:
+            primary_ks, all_ks = extract_primary_ks(image, threshold=threshold, sigma=sigma, pix_norm_range=pix_norm_range)
+        else:
+            primary_ks = all_ks.copy()
+    if not newparams:
+        primary_ks = all_ks.copy()
+    if len(primary_ks) != 3:
+        if len(primary_ks) > 3:
+            primary_ks = select_closest_to_triangle(all_ks)
+        elif len(all_ks) > 6:
+            primary_ks = select_closest_to_triangle(all_ks)
+        elif threshold > _decrease_threshold(threshold) and not newparams:
+            threshold = _decrease_threshold(threshold)
+            primary_ks, all_ks = extract_primary_ks(image, threshold=threshold, sigma=sigma, pix_norm_range=pix_norm_range)
+        else:
+            primary_ks = all_ks.copy()
+    return primary_ks, all_ks

@@ -270,6 +270,40 @@ def make_props_case(GPA):
     print('props_64       done, mean twist-like angle %.3f deg' % out['props'][0].mean())
 
 
+def make_peaks_case(GPA):
+    """f-3: the reference's extract_primary_ks (gpa.py:397-505) with two declared stand-ins for the
+    third-party functions this image lacks: moisan2011.per -> oracle per (restated from Moisan 2011),
+    skimage.feature.peak_local_max -> oracle peak_local_max (restated from scikit-image >= 0.19).
+    Everything else -- Gaussian / DoG smoothing, radius selection, duplicate removal, the parameter
+    recursion, triangle selection -- is the reference's own code."""
+    from oracle import gpa_oracle as orc
+    from pygpa_amd.synthetic import hex_kvecs, hex_moire, gaussian_bump_displacement
+    GPA.per = orc.per
+    GPA.peak_local_max = lambda image, threshold_rel: orc.peak_local_max(image, threshold_rel)
+    import io, contextlib
+    out = {}
+    cases = {
+        'clean128': (hex_moire((128, 128), hex_kvecs(0.1, 7.0)), dict(DoG=False)),
+        'noisy200x240': (hex_moire((200, 240), hex_kvecs(0.13, 21.0), gaussian_bump_displacement((200, 240)), noise=0.4, seed=4), dict()),
+        'weak96': (hex_moire((96, 96), hex_kvecs(0.21, 40.0), noise=2.5, seed=8), dict(threshold=0.9)),
+    }
+    base = hex_moire((256, 256), hex_kvecs(0.08, 12.0))
+    cases['harmonics256'] = (base + 0.8 * base ** 2 + 0.5 * base ** 3, dict(threshold=0.2))      # > 3: triangle selection
+    cases['aniso160'] = (hex_moire((160, 160), hex_kvecs(0.08, 12.0) * np.array([1.0, 1.3]), noise=0.2, seed=1),
+                         dict(threshold=0.95))                                                      # threshold recursion
+    stripe = np.cos(2 * np.pi * 0.1 * np.arange(128))[:, None] * np.ones((1, 128))
+    cases['stripe128'] = (stripe + 0.01 * np.random.default_rng(0).normal(size=stripe.shape), dict())   # deep recursion
+    for name, (img, kw) in cases.items():
+        with contextlib.redirect_stdout(io.StringIO()):
+            pks, aks = GPA.extract_primary_ks(img, **kw)
+        out[name + '_image'] = img
+        out[name + '_primary'] = pks
+        out[name + '_all'] = aks
+        out[name + '_kw'] = np.array([kw.get('threshold', 0.7), float(kw.get('DoG', True))])
+        print('peaks %-14s primary %d all %d' % (name, len(pks), len(aks)))
+    np.savez_compressed(os.path.join(OUT, 'peaks.npz'), **out)
+
+
 def main():
     os.makedirs(OUT, exist_ok=True)
     GPA, pu = _import_reference()
@@ -282,6 +316,7 @@ def main():
     make_unwrap_ramp(pu)
     make_warp_case(GPA)
     make_props_case(GPA)
+    make_peaks_case(GPA)
 
 
 if __name__ == '__main__':

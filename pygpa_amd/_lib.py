@@ -57,6 +57,7 @@ SIGNATURES = {
     'gpa_fit_plane': (_i, [_vp, _vp, _i, _d, _dp, _ip]),
     'gpa_fit_plane_dev': (_i, [_vp, _vp, _i, _d, _dp, _ip]),
     'gpa_per_dft': (_i, [_vp, _vp, _vp]),
+    'gpa_find_peaks': (_i, [_vp, _vp, _d, _d, _d, _i, _vp, _vp, _ip, _vp]),
     'gpa_timer_start': (_i, [_vp]),
     'gpa_timer_stop': (_i, [_vp, _vp]),
     'gpa_set_profiling': (_i, [_vp, _i]),
@@ -237,6 +238,27 @@ class Plan:
         check(self.lib.gpa_fit_plane(self.handle, _ptr(image), int(max_iter), float(tol), coef, C.byref(iters)),
               'gpa_fit_plane')
         return np.array(coef[:]), iters.value
+
+    def find_peaks(self, image, sigma, dog_sigma, threshold_rel, want_smooth=False, max_out=4096):
+        """peak_local_max candidates of the smoothed spectrum: (coords (n, 2) int, values (n,)) sorted like
+        skimage (highest first, raster order among equals) [, smooth]."""
+        image = self._img(image)
+        smooth = np.empty(self.shape, dtype=self.rdtype) if want_smooth else None
+        while True:
+            coords = np.empty((max_out, 2), dtype=np.int32)
+            vals = np.empty(max_out, dtype=self.rdtype)
+            count = C.c_int(0)
+            check(self.lib.gpa_find_peaks(self.handle, _ptr(image), float(sigma), float(dog_sigma), float(threshold_rel),
+                                          int(max_out), _ptr(coords), _ptr(vals), C.byref(count), _ptr(smooth)),
+                  'gpa_find_peaks')
+            if count.value <= max_out:
+                break
+            max_out = count.value
+        n = count.value
+        coords, vals = coords[:n], vals[:n]
+        order = np.lexsort((coords[:, 1], coords[:, 0], -vals))
+        out = (coords[order].astype(np.intp), vals[order])
+        return out + (smooth,) if want_smooth else out
 
     def per_dft(self, image):
         image = self._img(image)

@@ -803,9 +803,8 @@ int gpa_undistort_image(gpa_plan* p, const void* deformed, const void* u, void* 
   return GPA_OK;
 }
 
-int gpa_per_dft(gpa_plan* p, const void* image, void* out) {
-  if (!p || !image || !out) return fail(GPA_ERR_ARG, "gpa_per_dft: null argument");
-  HIP_TRY(hipSetDevice(p->device));
+// periodic-component DFT of the image in p->d_image -> p->d_lockin (plane 0)
+static int per_dft_staged(gpa_plan* p) {
   if (!p->bx0.tw) {
     size_t b = 0;
     hipError_t e = blue_axis_create(p->dtype, p->n0, p->stream, &p->bx0, &b);
@@ -813,8 +812,6 @@ int gpa_per_dft(gpa_plan* p, const void* image, void* out) {
     if (e != hipSuccess) return fail(GPA_ERR_HIP, std::string("gpa_per_dft tables: ") + hipGetErrorString(e));
     p->ws_bytes += b;
   }
-  const size_t npx = (size_t)p->n0 * p->n1;
-  HIP_TRY(hipMemcpyAsync(p->d_image, image, npx * p->rsz, hipMemcpyHostToDevice, p->stream));
   // border-difference vectors live in the (otherwise idle) compensation tables: dy >= n1, dx >= n0 complex
   void* d0 = p->tb.dy;
   void* d1 = p->tb.dx;
@@ -823,8 +820,78 @@ int gpa_per_dft(gpa_plan* p, const void* image, void* out) {
   HIP_TRY(dft_rows_inplace(p->dtype, p->bx1, 1, d0, p->stream));
   HIP_TRY(dft_rows_inplace(p->dtype, p->bx0, 1, d1, p->stream));
   HIP_TRY(per_combine(p->dtype, p->Tbuf, d0, d1, p->n0, p->n1, p->d_lockin, p->stream));
+  return GPA_OK;
+}
+
+int gpa_per_dft(gpa_plan* p, const void* image, void* out) {
+  if (!p || !image || !out) return fail(GPA_ERR_ARG, "gpa_per_dft: null argument");
+  HIP_TRY(hipSetDevice(p->device));
+  const size_t npx = (size_t)p->n0 * p->n1;
+  HIP_TRY(hipMemcpyAsync(p->d_image, image, npx * p->rsz, hipMemcpyHostToDevice, p->stream));
+  TRY(per_dft_staged(p));
   HIP_TRY(hipMemcpyAsync(out, p->d_lockin, npx * p->csz, hipMemcpyDeviceToHost, p->stream));
   HIP_TRY(hipStreamSynchronize(p->stream));
+  return GPA_OK;
+}
+
+// ---- f-3 -------------------------------------------------------------------------
+// scipy.ndimage._filters._gaussian_kernel1d (order 0): exp(-x^2 / 2 sigma^2) / sum, radius int(4 sigma + 0.5)
+static int gaussian_weights(double sigma, std::vector<double>& w) {
+  const int R = (int)(4.0 * sigma + 0.5);
+  w.resize(2 * (size_t)R + 1);
+  double sum = 0.0;
+  for (int k = -R; k <= R; ++k) { w[k + R] = exp(-0.5 / (sigma * sigma) * (double)k * k); sum += w[k + R]; }
+  for (double& v : w) v /= sum;
+  return R;
+}
+
+int gpa_find_peaks(gpa_plan* p, const void* image, double sigma, double dog_sigma, double threshold_rel, int max_out,
+                   int32_t* coords, void* values, int* count_out, void* smooth_out) {
+  if (!p || !image || !coords || !values || !count_out) return fail(GPA_ERR_ARG, "gpa_find_peaks: null argument");
+  if (!(sigma > 0.0) || max_out < 1) return fail(GPA_ERR_ARG, "gpa_find_peaks: need sigma > 0, max_out >= 1");
+  if (p->n0 < 3 || p->n1 < 3) return fail(GPA_ERR_STATE, "gpa_find_peaks: image too small");
+  HIP_TRY(hipSetDevice(p->device));
+  const int n0 = p->n0, n1 = p->n1;
+  const size_t npx = (size_t)n0 * n1;
+  if ((size_t)max_out > npx) max_out = (int)npx;
+  std::vector<double> w1, w2;
+  const int R1 = gaussian_weights(sigma, w1);
+  const int R2 = dog_sigma > 0.0 ? gaussian_weights(dog_sigma, w2) : 0;
+  // d_scratch (4096 doubles): [0, 1024) min/max partials + threshold, [1024, 4096) filter weights
+  if (2 * R1 + 1 > 3072 || 2 * R2 + 1 > 3072) return fail(GPA_ERR_ARG, "gpa_find_peaks: sigma too large (radius > 1535)");
+  hipStream_t st = p->stream;
+  double* d_w = p->d_scratch + 1024;
+  double* d_thr = p->d_scratch + 600;
+  int* d_count = reinterpret_cast<int*>(p->d_scratch + 610);
+  HIP_TRY(hipMemcpyAsync(p->d_image, image, npx * p->rsz, hipMemcpyHostToDevice, st));
+  TRY(per_dft_staged(p));                                                    // p_hat in d_lockin
+  void* fftim = p->d_image;                                                  // the staged image is consumed
+  void* tmp = p->d_wnorm;
+  void* smooth = p->d_u;
+  HIP_TRY(launch_absshift(p->dtype, p->d_lockin, n0, n1, fftim, st));
+  HIP_TRY(hipMemcpyAsync(d_w, w1.data(), w1.size() * sizeof(double), hipMemcpyHostToDevice, st));
+  HIP_TRY(launch_gauss1d(p->dtype, fftim, tmp, n0, n1, 0, d_w, R1, nullptr, st));
+  HIP_TRY(launch_gauss1d(p->dtype, tmp, smooth, n0, n1, 1, d_w, R1, nullptr, st));
+  if (dog_sigma > 0.0) {
+    HIP_TRY(hipStreamSynchronize(st));   // w1 (pageable) and the weight slot are reused
+    HIP_TRY(hipMemcpyAsync(d_w, w2.data(), w2.size() * sizeof(double), hipMemcpyHostToDevice, st));
+    HIP_TRY(launch_gauss1d(p->dtype, fftim, tmp, n0, n1, 0, d_w, R2, nullptr, st));
+    HIP_TRY(launch_gauss1d(p->dtype, tmp, smooth, n0, n1, 1, d_w, R2, smooth, st));
+  }
+  void* d_vals = p->d_dudx;                                                  // 2 npx reals >= max_out values
+  HIP_TRY(launch_localmax(p->dtype, smooth, n0, n1, threshold_rel, p->d_scratch, d_thr, max_out, d_count, p->d_kidx,
+                          d_vals, st));
+  int count = 0;
+  HIP_TRY(hipMemcpyAsync(&count, d_count, sizeof(int), hipMemcpyDeviceToHost, st));
+  HIP_TRY(hipStreamSynchronize(st));
+  const int stored = count < max_out ? count : max_out;
+  if (stored > 0) {
+    HIP_TRY(hipMemcpyAsync(coords, p->d_kidx, (size_t)stored * 2 * sizeof(int32_t), hipMemcpyDeviceToHost, st));
+    HIP_TRY(hipMemcpyAsync(values, d_vals, (size_t)stored * p->rsz, hipMemcpyDeviceToHost, st));
+  }
+  if (smooth_out) HIP_TRY(hipMemcpyAsync(smooth_out, smooth, npx * p->rsz, hipMemcpyDeviceToHost, st));
+  HIP_TRY(hipStreamSynchronize(st));
+  *count_out = count;
   return GPA_OK;
 }
 

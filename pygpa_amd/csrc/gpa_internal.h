@@ -97,6 +97,13 @@ hipError_t launch_props(int dtype, const void* jac, size_t npx, int add_identity
 hipError_t launch_huber_moments(int dtype, const void* img, int n0, int n1, const double* coef, double cx, double cy,
                                 double sx, double sy, double* scratch, hipStream_t s);
 
+// ---- f-3 peak candidates (gpa_peaks.hip) --------------------------------------------------------
+hipError_t launch_absshift(int dtype, const void* phat, int n0, int n1, void* out, hipStream_t s);
+hipError_t launch_gauss1d(int dtype, const void* in, void* out, int n0, int n1, int axis, const double* w, int R,
+                          const void* minuend, hipStream_t s);
+hipError_t launch_localmax(int dtype, const void* smooth, int n0, int n1, double rel, double* part, double* thr,
+                           int max_out, int* count, int32_t* coords, void* vals, hipStream_t s);
+
 // ---- f-1 Lawler-Fujita (gpa_warp.hip); both synchronise the stream before returning -----------
 hipError_t warp_invert_u(int dtype, const void* d_u, int n0, int n1, double scale, int iters, int edge, void* d_out,
                          hipStream_t s);

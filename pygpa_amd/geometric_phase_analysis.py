@@ -12,7 +12,7 @@ import numpy as np
 
 from . import _lib
 from ._lib import GPAError  # noqa: F401
-from .mathtools import wrapToPi, fit_plane, periodic_average  # noqa: F401
+from .mathtools import wrapToPi, fit_plane, periodic_average, remove_negative_duplicates  # noqa: F401
 
 DEFAULT_DTYPE = np.float64
 
@@ -92,6 +92,105 @@ def wfr2_grad_opt(image, sigma, kx, ky, kw, kstep, dtype=None):
 wfr2_grad = wfr2_grad_opt
 
 _NATIVE_SWEEPS = (optwfr2, wfr2_grad_opt)
+
+
+# --------------------------------------------------------------------------- f-3
+def fftbounds(n, d=1):
+    """Frequency bin edges of an fftshift-ed axis (imagetools.py:22-26)."""
+    r = np.fft.fftshift(np.fft.fftfreq(n, d))
+    return np.append(r, r[-1] + 1 / (n * d))
+
+
+def _decrease_threshold(t):
+    """geometric_phase_analysis.py:388-394"""
+    if t > 0.001:
+        t = t - 0.1 if t >= 0.2 else t / 2
+    return t
+
+
+def smallest_sum(ks):
+    """Smallest sum of three k-vectors with one sign flipped (geometric_phase_analysis.py:538-548)."""
+    ks = np.asarray(ks)
+    if len(ks) != 3:
+        return np.nan
+    sums = (np.ones((3, 3)) - 2 * np.eye(3)) @ ks
+    return sums[np.argmin(np.linalg.norm(sums, axis=1))]
+
+
+def select_closest_to_triangle(ks):
+    """The 3 k-vectors that come closest to a triangle (geometric_phase_analysis.py:529-535)."""
+    from itertools import combinations
+    print(f"closest triangle: {ks}")
+    combis = list(combinations(ks, 3))
+    sums = [np.linalg.norm(smallest_sum(combi)) for combi in combis]
+    return np.array(combis[np.argmin(sums)])
+
+
+def extract_primary_ks(image, plot=False, threshold=0.7, pix_norm_range=(2, 200), sigma=1, NMPERPIXEL=1., DoG=True,
+                       dtype=None):
+    """Primary k-vectors of an image from the smoothed Fourier transform of its periodic component
+    (geometric_phase_analysis.py:397-505); returns (primary_ks, all_ks).
+
+    The array work -- smooth + periodic DFT, |fftshift|, Gaussian / difference-of-Gaussians smoothing,
+    peak_local_max -- runs on the device (gpa_find_peaks); the bookkeeping on the handful of peaks and
+    the parameter recursion are the reference's, including that recursive calls fall back to DoG=True.
+    ``plot`` only switches the reference's debug printing here (no figure is drawn)."""
+    image = np.asarray(image)
+    plan = _plan(image, 1, dtype)
+    cindices, vals = plan.find_peaks(image, sigma, 50.0 if DoG else 0.0, threshold)
+    kxs, kys = [fftbounds(n) for n in image.shape]
+    center = np.array(image.shape) // 2
+    coords = cindices - center
+    norms = np.linalg.norm(coords, axis=1)
+    selection = np.logical_and(norms < pix_norm_range[1], norms > pix_norm_range[0])
+    cindices, coords, vals = cindices[selection], coords[selection], vals[selection]
+    all_ks = np.array([kxs[cindices.T[0]], kys[cindices.T[1]]]).T
+    all_ks = remove_negative_duplicates(all_ks)
+    newparams = False
+    if len(all_ks) < 3:
+        newparams = True
+        if len(all_ks) == 0:
+            if threshold > _decrease_threshold(threshold):
+                threshold = _decrease_threshold(threshold)
+            else:
+                print("No ks found at minimum threshold!")
+                newparams = False
+        else:
+            coordsminlength = np.linalg.norm(coords, axis=1).min()
+            if coordsminlength < 5 * sigma:
+                sigma = coordsminlength / 6
+            elif threshold > 0.2 * np.max(vals):
+                threshold = 0.2 * np.max(vals)
+            elif threshold > _decrease_threshold(threshold):
+                threshold = _decrease_threshold(threshold)
+            else:
+                print("Can't find enough ks!")
+                newparams = False
+        if newparams:
+            primary_ks, all_ks = extract_primary_ks(image, plot=False, threshold=threshold, sigma=sigma,
+                                                    pix_norm_range=pix_norm_range, dtype=dtype)
+        else:
+            primary_ks = all_ks.copy()
+    if not newparams:
+        primary_ks = all_ks.copy()
+    if len(primary_ks) != 3:
+        if len(primary_ks) > 3:
+            primary_ks = select_closest_to_triangle(all_ks)
+        elif len(all_ks) > 6:
+            if plot:
+                print("all_ks > 3 but not enough primary_ks, selecting closest to triangle")
+            primary_ks = select_closest_to_triangle(all_ks)
+        elif threshold > _decrease_threshold(threshold) and not newparams:
+            if plot:
+                print(f"pks<3, all_ks < 6, decreasing threshold {threshold:.3f}")
+            threshold = _decrease_threshold(threshold)
+            primary_ks, all_ks = extract_primary_ks(image, plot=False, threshold=threshold, sigma=sigma,
+                                                    pix_norm_range=pix_norm_range, dtype=dtype)
+        else:
+            if plot:
+                print("pks < aks=3", len(all_ks), len(primary_ks))
+            primary_ks = all_ks.copy()
+    return primary_ks, all_ks
 
 
 # ------------------------------------------------------------- k-vector helpers (host, P x 2)

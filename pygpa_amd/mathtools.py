@@ -33,3 +33,18 @@ def periodic_average(X, period=2 * np.pi, weights=1., **kwargs):
 def periodic_difference(X, Y, period=2 * np.pi):
     """Periodic difference X - Y folded into [-period/2, period/2) (mathtools.py:13-17)."""
     return np.angle(np.exp(2j * np.pi / period * (np.asarray(X) - np.asarray(Y)))) * period / (2 * np.pi)
+
+
+def remove_negative_duplicates(ks):
+    """Drop the k-vectors that are negatives of earlier ones, x-coordinate made non-negative (if
+    zero, the y-coordinate) (mathtools.py:78-94)."""
+    ks = np.asarray(ks)
+    if ks.shape[0] == 0:
+        return ks
+    nonneg = np.where(np.sign(ks[:, [0]]) != 0, np.sign(ks[:, [0]]) * ks, np.sign(ks[:, [1]]) * ks)
+    npks = [nonneg[0]]
+    atol = 1e-3 * np.min(np.abs(nonneg), axis=1).mean()
+    for k in nonneg[1:]:
+        if not np.any(np.all(np.isclose(k, npks, atol=atol), axis=1)):
+            npks.append(k)
+    return np.array(npks)

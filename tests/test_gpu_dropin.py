@@ -127,3 +127,20 @@ def test_props_from_J():
     assert np.all(np.abs(periodic_difference(props2[1], psi, period=180)) <= ani_tol)
     assert np.allclose(props2[2], 1.0)
     assert np.allclose(props2[3], kappa)
+
+
+# ---- tests/test_geometric_phase_analysis.py:44-58 (test_extract_primary_ks), seeded draws; the lattice
+# is the sum-of-cosines generator of pygpa_amd.synthetic instead of latticegen.hexlattice_gen
+@pytest.mark.gpu
+def test_extract_primary_ks():
+    import pygpa_amd.geometric_phase_analysis as GPA
+    from pygpa_amd.synthetic import hex_kvecs, hex_moire
+    rng = np.random.default_rng(12)
+    size = 128
+    for _ in range(12):
+        r_k, theta = rng.uniform(0.03, 0.24), rng.uniform(0., 60.)
+        ori_ks = hex_kvecs(r_k, theta, n=6)
+        original = hex_moire((size, size), ori_ks[:3])
+        ext_ks, _ = GPA.extract_primary_ks(original, DoG=False)
+        abs_diffs = np.linalg.norm((ext_ks[None] - ori_ks[:, None]), axis=-1).min(axis=0)
+        assert np.all(abs_diffs < 1.5 / size), (r_k, theta, ext_ks)

@@ -537,3 +537,47 @@ def test_f4_fit_plane_vs_scipy(dtype):
     # an exact plane is recovered exactly, in one or two passes
     coef, iters = _lib.get_plan((n0, n1), 1, np.float64).fit_plane(0.5 * x - 0.25 * y + 3.0)
     assert np.allclose(coef, [0.5, -0.25, 3.0], rtol=1e-12, atol=1e-10) and iters <= 60
+
+
+# ---- f-3: peak finding ---------------------------------------------------------------------------
+PEAK_CASES = ['clean128', 'noisy200x240', 'weak96', 'harmonics256', 'aniso160', 'stripe128']
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize('name', PEAK_CASES)
+def test_f3_extract_primary_ks_golden(golden, name, capsys):
+    """mirror extract_primary_ks (device spectrum / smoothing / local maxima) against the reference's
+    driver output: the k-vectors are grid frequencies, so they must be identical"""
+    import pygpa_amd.geometric_phase_analysis as GPA
+    g = golden('peaks')
+    thr, dog = g[name + '_kw']
+    for dtype in DTYPES:
+        pks, aks = GPA.extract_primary_ks(g[name + '_image'], threshold=float(thr), DoG=bool(dog), dtype=dtype)
+        assert np.array_equal(pks, g[name + '_primary']), dtype
+        assert np.array_equal(aks, g[name + '_all']), dtype
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize('dtype', DTYPES)
+@pytest.mark.parametrize('shape,sigma,dog', [((200, 240), 1.0, 50.0), ((96, 130), 2.5, 0.0), ((64, 64), 0.7, 50.0)])
+def test_f3_smoothed_spectrum_and_candidates(shape, sigma, dog, dtype):
+    """smooth (incl. radius-200 kernel reflected several times over a 64-pixel axis) and the full
+    peak_local_max candidate list against the oracle (SciPy's gaussian_filter / maximum_filter)"""
+    kvecs = hex_kvecs(0.12, 17.0)
+    img = hex_moire(shape, kvecs, noise=0.5, seed=6)
+    plan = _lib.get_plan(shape, 1, dtype)
+    coords, vals, smooth = plan.find_peaks(img, sigma, dog, 0.05, want_smooth=True)
+    ref = orc.smoothed_spectrum(img, sigma, DoG=dog > 0)
+    tol = 2e-5 if dtype == np.float32 else 1e-11
+    assert rel(smooth, ref) < tol
+    ref_c = orc.peak_local_max(ref, 0.05)
+    if dtype == np.float64:
+        # |p_hat(k)| = |p_hat(-k)| up to rounding: the order inside such a pair is not defined
+        assert {tuple(c) for c in coords} == {tuple(c) for c in ref_c}
+        assert np.allclose(vals, ref[tuple(ref_c.T)], rtol=1e-10)
+    else:
+        # f32 rounding may move candidates at the threshold / on near-ties: the strong ones must agree
+        strong = ref[tuple(ref_c.T)] > 0.1 * ref.max()
+        got = {tuple(c) for c in coords}
+        assert all(tuple(c) in got for c in ref_c[strong])
+    assert np.all(np.diff(vals) <= 0)

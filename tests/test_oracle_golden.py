@@ -156,3 +156,17 @@ def test_f2_properties(golden):
     assert np.allclose(orc.props_from_jac(np.eye(2) + g['J']), g['props'], rtol=1e-12, atol=1e-12)
     assert np.allclose(orc.props_from_jac(np.eye(2) + g['J'], 3.0, 2.0, True), g['props_diff'], rtol=1e-12, atol=1e-12)
     assert np.allclose(orc.props_from_jac(g['jac_rand']), g['props_rand'], rtol=1e-12, atol=1e-12)
+
+
+PEAK_CASES = ['clean128', 'noisy200x240', 'weak96', 'harmonics256', 'aniso160', 'stripe128']
+
+
+@pytest.mark.parametrize('name', PEAK_CASES)
+def test_f3_extract_primary_ks(golden, name):
+    """oracle restatement against the reference's driver (run with the declared per / peak_local_max
+    stand-ins, oracle/make_golden.py): identical k-vectors"""
+    g = golden('peaks')
+    thr, dog = g[name + '_kw']
+    pks, aks = orc.extract_primary_ks(g[name + '_image'], threshold=float(thr), DoG=bool(dog))
+    assert np.array_equal(pks, g[name + '_primary'])
+    assert np.array_equal(aks, g[name + '_all'])
