@@ -223,6 +223,13 @@ int gpa_fit_plane(gpa_plan* plan, const void* image, int max_iter, double tol, d
 int gpa_fit_plane_dev(gpa_plan* plan, const void* image, int max_iter, double tol, double* coef3,
                       int* iters_out);
 
+/* gaussian_deconvolve (geometric_phase_analysis.py:892-904) of ONE field: reflect-pad by 2 dr,
+ * Wiener-Hunt deconvolution (skimage.restoration.wiener, Laplacian regulariser, `balance`) with the
+ * Gaussian the lock-ins were smoothed by, crop.  The plan has the PADDED shape
+ * (m0 + 4 dr) x (m1 + 4 dr); data, out: m0 x m1 (host).                                       */
+int gpa_gaussian_deconvolve(gpa_plan* plan, const void* data, int dr, double sigma, double balance,
+                            void* out);
+
 /* a9 -- DFT of the periodic component of Moisan's periodic+smooth decomposition
  * (third-party moisan2011.per(image, inverse_dft=False)[0], call site
  * geometric_phase_analysis.py:429).  out: n0 x n1 complex.                    */

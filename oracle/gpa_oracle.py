@@ -656,3 +656,43 @@ def extract_primary_ks(image, threshold=0.7, pix_norm_range=(2, 200), sigma=1, D
         else:
             primary_ks = all_ks.copy()
     return primary_ks, all_ks
+
+
+# --------------------------------------------------------------------------
+# f-4 (second half): gaussian_deconvolve, gpa.py:892-904, over skimage.restoration.wiener
+# (absent from this image; restated from scikit-image's restoration/deconvolution.py + uft.py).
+# --------------------------------------------------------------------------
+def wiener(image, psf, balance):
+    """skimage.restoration.wiener(image, psf, balance, clip=False, is_real=True) for a real-space psf:
+    irfft2(conj(H) / (|H|^2 + balance |L|^2) * rfft2(image)), H / L the transfer functions (uft.ir2tf)
+    of the psf and of the 3x3 Laplacian stencil, both centred on the origin."""
+    image = np.asarray(image, dtype=np.float64)
+
+    def ir2tf(imp, shape):
+        pad = np.zeros(shape)
+        pad[tuple(slice(0, s) for s in imp.shape)] = imp
+        for axis, size in enumerate(imp.shape):
+            pad = np.roll(pad, shift=-int(np.floor(size / 2)), axis=axis)
+        return np.fft.rfft2(pad)
+    lap = np.zeros((3, 3))
+    lap[1, :] = -1.0
+    lap[:, 1] = -1.0
+    lap[1, 1] = 4.0
+    reg = ir2tf(lap, image.shape)
+    H = ir2tf(np.asarray(psf).real, image.shape)
+    filt = np.conj(H) / (np.abs(H) ** 2 + balance * np.abs(reg) ** 2)
+    return np.fft.irfft2(filt * np.fft.rfft2(image), s=image.shape)
+
+
+def gaussian_deconvolve(data, sigma, dr=20, balance=5000):
+    """gpa.py:892-904: reflect-pad by 2 dr, Wiener-deconvolve with the real-space image of the k-space
+    Gaussian, crop."""
+    import scipy.ndimage as ndi
+    data = np.asarray(data, dtype=np.float64)
+    padding = [(0, 0)] * (data.ndim - 2) + [(2 * dr, 2 * dr), (2 * dr, 2 * dr)]
+    padded = np.pad(data, padding, mode='reflect')
+    kernel = np.fft.fft2(ndi.fourier_gaussian(np.ones(padded.shape[-2:]), sigma=sigma)).real
+    kernel = np.fft.fftshift(kernel)
+    kernel = kernel / kernel.sum()
+    dec = [wiener(p, kernel, balance)[2 * dr:-2 * dr, 2 * dr:-2 * dr] for p in padded.reshape((-1,) + padded.shape[-2:])]
+    return np.reshape(np.stack(dec), data.shape)

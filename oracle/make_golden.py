@@ -304,6 +304,21 @@ def make_peaks_case(GPA):
     np.savez_compressed(os.path.join(OUT, 'peaks.npz'), **out)
 
 
+def make_deconv_case(GPA):
+    """f-4: the reference's gaussian_deconvolve (gpa.py:892-904: padding, kernel construction, cropping)
+    with skimage.restoration.wiener -- absent here -- replaced by the oracle's restatement of it."""
+    from oracle import gpa_oracle as orc
+    GPA.wiener = lambda p, kernel, balance, clip, is_real: orc.wiener(p, kernel, balance)
+    rng = np.random.default_rng(21)
+    x, y = np.meshgrid(np.arange(70), np.arange(91), indexing='ij')
+    data = np.stack([np.sin(x / 9.0) * np.cos(y / 13.0), 0.02 * x - 0.01 * y]) + 0.01 * rng.normal(size=(2, 70, 91))
+    out = dict(data=data, sigma=np.array(3.0), dr=np.array(6), balance=np.array(5000.0),
+               dec=GPA.gaussian_deconvolve(data, 3.0, dr=6, balance=5000),
+               dec_b=GPA.gaussian_deconvolve(data[0], 5.0, dr=10, balance=200))
+    np.savez_compressed(os.path.join(OUT, 'deconv.npz'), **out)
+    print('deconv         done, max |dec - data| = %.3f' % np.abs(out['dec'] - data).max())
+
+
 def main():
     os.makedirs(OUT, exist_ok=True)
     GPA, pu = _import_reference()
@@ -317,6 +332,7 @@ def main():
     make_warp_case(GPA)
     make_props_case(GPA)
     make_peaks_case(GPA)
+    make_deconv_case(GPA)
 
 
 if __name__ == '__main__':

@@ -57,6 +57,7 @@ SIGNATURES = {
     'gpa_fit_plane': (_i, [_vp, _vp, _i, _d, _dp, _ip]),
     'gpa_fit_plane_dev': (_i, [_vp, _vp, _i, _d, _dp, _ip]),
     'gpa_per_dft': (_i, [_vp, _vp, _vp]),
+    'gpa_gaussian_deconvolve': (_i, [_vp, _vp, _i, _d, _d, _vp]),
     'gpa_find_peaks': (_i, [_vp, _vp, _d, _d, _d, _i, _vp, _vp, _ip, _vp]),
     'gpa_timer_start': (_i, [_vp]),
     'gpa_timer_stop': (_i, [_vp, _vp]),
@@ -259,6 +260,16 @@ class Plan:
         order = np.lexsort((coords[:, 1], coords[:, 0], -vals))
         out = (coords[order].astype(np.intp), vals[order])
         return out + (smooth,) if want_smooth else out
+
+    def gaussian_deconvolve(self, data, dr, sigma, balance):
+        """one m0 x m1 field; this plan has the padded shape (m0 + 4 dr, m1 + 4 dr)"""
+        data = np.ascontiguousarray(data, dtype=self.rdtype)
+        if data.shape != (self.shape[0] - 4 * dr, self.shape[1] - 4 * dr):
+            raise ValueError('data shape %s does not match the padded plan %s' % (data.shape, self.shape))
+        out = np.empty(data.shape, dtype=self.rdtype)
+        check(self.lib.gpa_gaussian_deconvolve(self.handle, _ptr(data), int(dr), float(sigma), float(balance), _ptr(out)),
+              'gpa_gaussian_deconvolve')
+        return out
 
     def per_dft(self, image):
         image = self._img(image)

@@ -895,6 +895,39 @@ int gpa_find_peaks(gpa_plan* p, const void* image, double sigma, double dog_sigm
   return GPA_OK;
 }
 
+// ---- f-4 (gaussian_deconvolve) -----------------------------------------------------
+int gpa_gaussian_deconvolve(gpa_plan* p, const void* data, int dr, double sigma, double balance, void* out) {
+  if (!p || !data || !out) return fail(GPA_ERR_ARG, "gpa_gaussian_deconvolve: null argument");
+  if (dr < 0 || !(sigma > 0.0) || !(balance >= 0.0)) return fail(GPA_ERR_ARG, "gpa_gaussian_deconvolve: need dr >= 0, sigma > 0, balance >= 0");
+  const int pad = 2 * dr, n0 = p->n0, n1 = p->n1, m0 = n0 - 2 * pad, m1 = n1 - 2 * pad;
+  if (m0 < 2 || m1 < 2 || pad >= m0 || pad >= m1)
+    return fail(GPA_ERR_STATE, "gpa_gaussian_deconvolve: the plan must have the padded shape (m + 4 dr), with 2 dr < m");
+  HIP_TRY(hipSetDevice(p->device));
+  if (!p->bx0.tw) {
+    size_t b = 0;
+    hipError_t e = blue_axis_create(p->dtype, p->n0, p->stream, &p->bx0, &b);
+    if (e == hipSuccess) e = blue_axis_create(p->dtype, p->n1, p->stream, &p->bx1, &b);
+    if (e != hipSuccess) return fail(GPA_ERR_HIP, std::string("gpa_gaussian_deconvolve tables: ") + hipGetErrorString(e));
+    p->ws_bytes += b;
+  }
+  hipStream_t st = p->stream;
+  // k-space Gaussian factors (doubles) in the idle compensation tables: dx holds >= n0, dy >= n1 complex
+  std::vector<double> gx = gaussian_kspace(n0, sigma), gy = gaussian_kspace(n1, sigma);
+  double* d_gx = reinterpret_cast<double*>(p->tb.dx);
+  double* d_gy = reinterpret_cast<double*>(p->tb.dy);
+  HIP_TRY(hipMemcpyAsync(d_gx, gx.data(), (size_t)n0 * sizeof(double), hipMemcpyHostToDevice, st));
+  HIP_TRY(hipMemcpyAsync(d_gy, gy.data(), (size_t)n1 * sizeof(double), hipMemcpyHostToDevice, st));
+  HIP_TRY(hipMemcpyAsync(p->d_image, data, (size_t)m0 * m1 * p->rsz, hipMemcpyHostToDevice, st));
+  HIP_TRY(launch_deconv_pack(p->dtype, p->d_image, m0, m1, pad, p->Tbuf, st));
+  HIP_TRY(dft2_inplace(p->dtype, p->bx0, p->bx1, p->Tbuf, st));
+  HIP_TRY(launch_deconv_filter(p->dtype, p->Tbuf, n0, n1, d_gx, d_gy, balance, st));
+  HIP_TRY(dft2_inplace(p->dtype, p->bx0, p->bx1, p->Tbuf, st));
+  HIP_TRY(launch_deconv_unpack(p->dtype, p->Tbuf, m0, m1, pad, p->d_wnorm, st));
+  HIP_TRY(hipMemcpyAsync(out, p->d_wnorm, (size_t)m0 * m1 * p->rsz, hipMemcpyDeviceToHost, st));
+  HIP_TRY(hipStreamSynchronize(st));   // gx / gy are pageable host vectors
+  return GPA_OK;
+}
+
 // ---- f-2 -------------------------------------------------------------------------
 int gpa_phasegradient2J_dev(gpa_plan* p, const double* kvecs, int P, const void* grads, const void* weights,
                             double nmperpixel, const double* dks, void* J) {

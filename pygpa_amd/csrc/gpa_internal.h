@@ -104,6 +104,12 @@ hipError_t launch_gauss1d(int dtype, const void* in, void* out, int n0, int n1, 
 hipError_t launch_localmax(int dtype, const void* smooth, int n0, int n1, double rel, double* part, double* thr,
                            int max_out, int* count, int32_t* coords, void* vals, hipStream_t s);
 
+// f-4 gaussian_deconvolve pieces (gpa_peaks.hip); Z: (m0 + 2 pad) x (m1 + 2 pad) complex
+hipError_t launch_deconv_pack(int dtype, const void* data, int m0, int m1, int pad, void* Z, hipStream_t s);
+hipError_t launch_deconv_filter(int dtype, void* Z, int n0, int n1, const double* gx, const double* gy, double balance,
+                                hipStream_t s);
+hipError_t launch_deconv_unpack(int dtype, const void* Z, int m0, int m1, int pad, void* out, hipStream_t s);
+
 // ---- f-1 Lawler-Fujita (gpa_warp.hip); both synchronise the stream before returning -----------
 hipError_t warp_invert_u(int dtype, const void* d_u, int n0, int n1, double scale, int iters, int edge, void* d_out,
                          hipStream_t s);

@@ -129,7 +129,78 @@ __global__ __launch_bounds__(256) void localmax_kernel(const T* __restrict__ s, 
   }
 }
 
+// ---- f-4: gaussian_deconvolve (geometric_phase_analysis.py:892-904) -----------------------------
+// np.pad(mode='reflect') (whole-sample mirror, edge not repeated) of the m0 x m1 field into the
+// n0 x n1 = (m0 + 2 pad) x (m1 + 2 pad) complex work array
+template <class T>
+__global__ __launch_bounds__(256) void deconv_pack_kernel(const T* __restrict__ data, int m0, int m1, int pad,
+                                                         cpx<T>* __restrict__ Z) {
+  const int n0 = m0 + 2 * pad, n1 = m1 + 2 * pad;
+  const size_t o = (size_t)blockIdx.x * 256 + threadIdx.x;
+  if (o >= (size_t)n0 * n1) return;
+  int i = (int)(o / n1) - pad, j = (int)(o - (size_t)(o / n1) * n1) - pad;
+  i = i < 0 ? -i : (i >= m0 ? 2 * (m0 - 1) - i : i);
+  j = j < 0 ? -j : (j >= m1 ? 2 * (m1 - 1) - j : j);
+  Z[o] = {data[(size_t)i * m1 + j], T(0)};
+}
+
+// Z <- conj(Z * W), W = G / (G^2 + balance L^2): the Wiener-Hunt filter of skimage.restoration.wiener
+// for the Gaussian transfer function G = gx[kx] gy[ky] and the Laplacian regulariser
+// L = 4 - 2 cos(2 pi kx / n0) - 2 cos(2 pi ky / n1); conjugated so that a second forward DFT inverts
+template <class T>
+__global__ __launch_bounds__(256) void deconv_filter_kernel(cpx<T>* __restrict__ Z, int n0, int n1,
+                                                           const double* __restrict__ gx,
+                                                           const double* __restrict__ gy, double balance) {
+  const size_t o = (size_t)blockIdx.x * 256 + threadIdx.x;
+  if (o >= (size_t)n0 * n1) return;
+  const int kx = (int)(o / n1), ky = (int)(o - (size_t)kx * n1);
+  const double G = gx[kx] * gy[ky];
+  const double L = 4.0 - 2.0 * cospi(2.0 * kx / (double)n0) - 2.0 * cospi(2.0 * ky / (double)n1);
+  const double den = G * G + balance * L * L;
+  const double W = den > 0.0 ? G / den : 0.0;
+  const cpx<T> z = Z[o];
+  Z[o] = {(T)(z.x * W), (T)(-z.y * W)};
+}
+
+template <class T>
+__global__ __launch_bounds__(256) void deconv_unpack_kernel(const cpx<T>* __restrict__ Z, int m0, int m1, int pad,
+                                                           double scale, T* __restrict__ out) {
+  const size_t o = (size_t)blockIdx.x * 256 + threadIdx.x;
+  if (o >= (size_t)m0 * m1) return;
+  const int i = (int)(o / m1), j = (int)(o - (size_t)i * m1);
+  out[o] = (T)(Z[(size_t)(i + pad) * (m1 + 2 * pad) + (j + pad)].x * scale);
+}
+
 }  // namespace
+
+hipError_t launch_deconv_pack(int dtype, const void* data, int m0, int m1, int pad, void* Z, hipStream_t s) {
+  const unsigned grid = (unsigned)(((size_t)(m0 + 2 * pad) * (m1 + 2 * pad) + 255) / 256);
+  if (dtype == 0)
+    deconv_pack_kernel<float><<<grid, 256, 0, s>>>((const float*)data, m0, m1, pad, (cpx<float>*)Z);
+  else
+    deconv_pack_kernel<double><<<grid, 256, 0, s>>>((const double*)data, m0, m1, pad, (cpx<double>*)Z);
+  return hipGetLastError();
+}
+
+hipError_t launch_deconv_filter(int dtype, void* Z, int n0, int n1, const double* gx, const double* gy, double balance,
+                                hipStream_t s) {
+  const unsigned grid = (unsigned)(((size_t)n0 * n1 + 255) / 256);
+  if (dtype == 0)
+    deconv_filter_kernel<float><<<grid, 256, 0, s>>>((cpx<float>*)Z, n0, n1, gx, gy, balance);
+  else
+    deconv_filter_kernel<double><<<grid, 256, 0, s>>>((cpx<double>*)Z, n0, n1, gx, gy, balance);
+  return hipGetLastError();
+}
+
+hipError_t launch_deconv_unpack(int dtype, const void* Z, int m0, int m1, int pad, void* out, hipStream_t s) {
+  const unsigned grid = (unsigned)(((size_t)m0 * m1 + 255) / 256);
+  const double scale = 1.0 / ((double)(m0 + 2 * pad) * (double)(m1 + 2 * pad));
+  if (dtype == 0)
+    deconv_unpack_kernel<float><<<grid, 256, 0, s>>>((const cpx<float>*)Z, m0, m1, pad, scale, (float*)out);
+  else
+    deconv_unpack_kernel<double><<<grid, 256, 0, s>>>((const cpx<double>*)Z, m0, m1, pad, scale, (double*)out);
+  return hipGetLastError();
+}
 
 hipError_t launch_absshift(int dtype, const void* phat, int n0, int n1, void* out, hipStream_t s) {
   const unsigned grid = (unsigned)(((size_t)n0 * n1 + 255) / 256);

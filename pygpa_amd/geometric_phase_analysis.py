@@ -310,9 +310,8 @@ def extract_displacement_field(image, kvecs, sigma=None, kwscale=2.5, ksteps=3, 
     two weighted unwraps) runs in one fused device call; any other callable is
     invoked per peak exactly like the reference does and only the reconstruction
     runs on the device.  ``klists`` (P lists of (K,2)) replaces the np.arange grid.
+    ``deconvolve=True`` Wiener-deconvolves u with the lock-in Gaussian afterwards (:927-928).
     """
-    if deconvolve:
-        raise NotImplementedError('deconvolve=True (skimage Wiener filter) is outside the accelerated path')
     image = np.asarray(image)
     kvecs = np.asarray(kvecs, dtype=np.float64).reshape(-1, 2)
     norms = np.linalg.norm(kvecs, axis=1)
@@ -331,6 +330,8 @@ def extract_displacement_field(image, kvecs, sigma=None, kwscale=2.5, ksteps=3, 
         plan = _lib.get_plan(image.shape, len(kvecs) * K, DEFAULT_DTYPE if dtype is None else dtype)
         u, lock, kidx, _ = plan.extract_displacement_field(image, kvecs, padded, sigma, dr, kmax=10,
                                                            want_lockins=return_gs, want_kidx=return_gs)
+        if deconvolve:
+            u = gaussian_deconvolve(u, sigma, dr, dtype=dtype)
         if return_gs:
             gs = [{'lockin': lock[p], 'w': _w_from_kidx(kidx[p], padded[p]), 'kidx': kidx[p]}
                   for p in range(len(kvecs))]
@@ -341,9 +342,25 @@ def extract_displacement_field(image, kvecs, sigma=None, kwscale=2.5, ksteps=3, 
     plan = _lib.get_plan(image.shape, len(kvecs), DEFAULT_DTYPE if dtype is None else dtype)
     dudx, dudy, wnorm = plan.reconstruct_grad(lockins, kvecs, dr)
     u = np.array([plan.unwrap_prediff(dudx[i], dudy[i], wnorm, kmax=10)[0] for i in range(2)])
+    if deconvolve:
+        u = gaussian_deconvolve(u, sigma, dr, dtype=dtype)
     if return_gs:
         return u, gs
     return u
+
+
+def gaussian_deconvolve(data, sigma, dr=20, balance=5000, dtype=None):
+    """Deconvolve a stack of fields by the Gaussian of width sigma (geometric_phase_analysis.py:892-904):
+    reflect padding by 2*dr, skimage.restoration.wiener with `balance`, cropping -- on the device
+    (gpa_gaussian_deconvolve), one field at a time like the reference."""
+    data = np.asarray(data)
+    if data.ndim < 2:
+        raise ValueError('data must have at least 2 dimensions')
+    dr = int(dr)
+    m0, m1 = data.shape[-2:]
+    plan = _lib.get_plan((m0 + 4 * dr, m1 + 4 * dr), 1, DEFAULT_DTYPE if dtype is None else dtype)
+    dec = [plan.gaussian_deconvolve(f, dr, sigma, balance) for f in data.reshape((-1, m0, m1))]
+    return np.reshape(np.stack(dec), data.shape)
 
 
 # --------------------------------------------------------------------------- f-1

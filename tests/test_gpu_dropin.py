@@ -31,6 +31,12 @@ def test_displacement_field(testset):
         assert np.all(np.abs(u - u_true)[:, 20:-20, 20:-20] < 0.9)
     u32 = -GPA.extract_displacement_field(deformed + noise, ks, dtype=np.float32)
     assert np.all(np.abs(u32 - u_true)[:, 20:-20, 20:-20] < 0.9)
+    # :66-69: the noise-free image with the Wiener deconvolution of the lock-in Gaussian
+    u2 = -GPA.extract_displacement_field(deformed, ks, deconvolve=True)
+    assert u2.shape == u_true.shape
+    assert np.all(np.abs(u2 - u_true)[:, 20:-20, 20:-20] < 0.05)
+    u1 = -GPA.extract_displacement_field(deformed, ks)
+    assert np.abs(u2 - u_true)[:, 20:-20, 20:-20].max() < np.abs(u1 - u_true)[:, 20:-20, 20:-20].max()
 
 
 def test_displacement_field_500():

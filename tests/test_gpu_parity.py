@@ -581,3 +581,18 @@ def test_f3_smoothed_spectrum_and_candidates(shape, sigma, dog, dtype):
         got = {tuple(c) for c in coords}
         assert all(tuple(c) in got for c in ref_c[strong])
     assert np.all(np.diff(vals) <= 0)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize('dtype', DTYPES)
+def test_f4_gaussian_deconvolve_golden(golden, dtype):
+    """gaussian_deconvolve against the reference's output (its padding / kernel code over the restated
+    skimage Wiener filter): 94 x 115 and 110 x 131 padded shapes -> Bluestein 2-D DFTs"""
+    import pygpa_amd.geometric_phase_analysis as GPA
+    g = golden('deconv')
+    tol = 3e-5 if dtype == np.float32 else 1e-10
+    dec = GPA.gaussian_deconvolve(g['data'], float(g['sigma']), dr=int(g['dr']), balance=float(g['balance']), dtype=dtype)
+    assert dec.shape == g['dec'].shape
+    assert rel(dec, g['dec']) < tol
+    dec_b = GPA.gaussian_deconvolve(g['data'][0], 5.0, dr=10, balance=200, dtype=dtype)
+    assert rel(dec_b, g['dec_b']) < tol

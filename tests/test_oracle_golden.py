@@ -170,3 +170,18 @@ def test_f3_extract_primary_ks(golden, name):
     pks, aks = orc.extract_primary_ks(g[name + '_image'], threshold=float(thr), DoG=bool(dog))
     assert np.array_equal(pks, g[name + '_primary'])
     assert np.array_equal(aks, g[name + '_all'])
+
+
+def test_f4_gaussian_deconvolve(golden):
+    g = golden('deconv')
+    dec = orc.gaussian_deconvolve(g['data'], float(g['sigma']), dr=int(g['dr']), balance=float(g['balance']))
+    assert np.allclose(dec, g['dec'], rtol=1e-12, atol=1e-12)
+    assert np.allclose(orc.gaussian_deconvolve(g['data'][0], 5.0, dr=10, balance=200), g['dec_b'], rtol=1e-12, atol=1e-12)
+    # closed form the device uses: the filter is G / (G^2 + balance L^2) with G the k-space Gaussian itself
+    n0, n1 = g['data'].shape[-2] + 24, g['data'].shape[-1] + 24
+    G = np.outer(orc.gaussian_kspace_1d(n0, 3.0), orc.gaussian_kspace_1d(n1, 3.0))
+    L = 4 - 2 * np.cos(2 * np.pi * np.arange(n0) / n0)[:, None] - 2 * np.cos(2 * np.pi * np.arange(n1) / n1)[None, :]
+    W = G / (G ** 2 + 5000.0 * L ** 2)
+    padded = np.pad(g['data'][0], 12, mode='reflect')
+    direct = np.real(np.fft.ifft2(W * np.fft.fft2(padded)))[12:-12, 12:-12]
+    assert np.allclose(direct, g['dec'][0], rtol=1e-10, atol=1e-11)
