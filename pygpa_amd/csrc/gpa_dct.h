@@ -72,7 +72,14 @@ struct WgDCT {
   GPA_HD static void solve_combine(cpx<T> (&x)[E], const cpx<T>* lds, int tid,
                                    const cpx<T>* __restrict__ wspec, const T* __restrict__ ha,
                                    const T* __restrict__ ham, T hb_a, T hb_b, bool first_a,
-                                   bool first_b, T inv_n) {
+                                   bool first_b, T inv_n, double* rho = nullptr) {
+    // rho (optional): Parseval sum of <input, output> over this thread's bins.  In SciPy's convention
+    // X[k] = 2 Re(w_k V_k) = 2 ua.x and sum_n x y = (1 / 2N) sum_k c_k X_k Y_k with c_0 = 1/2; the output
+    // coefficient is X / lambda = X * (sa N), so the pair's share is c_k c_j ua.x^2 sa up to the factor
+    // 1 / N_other applied by the caller (c_j = 1/2 where the other-axis bin is 0).  Every bin is visited
+    // once as "k" (its mirror visit, the .y part, is not counted).
+    // per-thread sums in T: E same-signed terms each; the caller reduces across threads in double
+    T ra = T(0), rb = T(0);
 #pragma unroll
     for (int i = 0; i < E; ++i) {
       const int k = F::spec_index(tid, i);
@@ -92,10 +99,22 @@ struct WgDCT {
         if (first_a) sa = inv_n;
         if (first_b) sb = inv_n;
       }
-      const cpx<T> ya = cmulc(cpx<T>{sa * ua.x, sam * ua.y}, w);
-      const cpx<T> yb = cmulc(cpx<T>{sb * ub.x, sbm * ub.y}, w);
+      const T pa = sa * ua.x, pb = sb * ub.x;
+      const cpx<T> ya = cmulc(cpx<T>{pa, sam * ua.y}, w);
+      const cpx<T> yb = cmulc(cpx<T>{pb, sbm * ub.y}, w);
       x[i] = {ya.x - yb.y, ya.y + yb.x};
+      if (rho) {
+        const T ck = k == 0 ? T(0.5) : T(1);
+        ra = fma(ck * pa, ua.x, ra);
+        rb = fma(ck * pb, ub.x, rb);
+#if defined(__HIP_DEVICE_COMPILE__)
+        // the two sums are dependent chains through all E iterations: without a fence the scheduler
+        // runs the rest of every iteration first and keeps 2 E operand pairs alive for the chains
+        if ((i & 3) == 3) __builtin_amdgcn_sched_barrier(0);
+#endif
+      }
     }
+    if (rho) *rho += (double)((first_a ? T(0.5) : T(1)) * ra + (first_b ? T(0.5) : T(1)) * rb);
   }
 
   // ---- inverse (DCT-III) of a packed pair ------------------------------------

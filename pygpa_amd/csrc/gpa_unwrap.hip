@@ -581,7 +581,7 @@ __global__ void final_count_kernel(int* flags, int kmax) {
 }
 
 // columns: Z -> DCT-II along axis 0, divide by eigenvalues, DCT-III along axis 0 (in place)
-template <class T, int LG>
+template <class T, int LG, bool RHO>
 __global__ __launch_bounds__((ColGeom<T, LG>::THREADS)) void colsolve_kernel(T* __restrict__ Z, int n1,
                                                                           const cpx<T>* __restrict__ twtab,
                                                                           const cpx<T>* __restrict__ wspec,
@@ -590,7 +590,7 @@ __global__ __launch_bounds__((ColGeom<T, LG>::THREADS)) void colsolve_kernel(T* 
                                                                           const T* __restrict__ hb,
                                                                           int* flags, const double* part_norm,
                                                                           int nnorm, int it, double eps,
-                                                                          double* scal) {
+                                                                          double* scal, double* part_rho) {
   if (flags[1]) return;
   using F = WgFFT<T, LG>;
   using D = WgDCT<T, LG>;
@@ -616,11 +616,11 @@ __global__ __launch_bounds__((ColGeom<T, LG>::THREADS)) void colsolve_kernel(T* 
 #pragma unroll
     for (int n = 0; n < NT; ++n) x[n][i] = q.v[n];
   }
+  __shared__ double shn[ColGeom<T, LG>::THREADS];
   if (it > 0) {
     // (placed after the tile loads have been issued so its latency hides behind them)
     // fused path: the update of iteration it-1 was applied by this iteration's row kernel;
     // every workgroup evaluates the reference's stopping test (phase_unwrap.py:348) on it
-    __shared__ double shn[ColGeom<T, LG>::THREADS];
     const double tot = reduce_partials(part_norm, nnorm, shn);
     const double best = scal[10 + ((it - 1) & 1)];
     const bool stop = sqrt(tot) < eps * sqrt(scal[5]) || tot == 0.0 || !(tot == tot) || tot > 1e4 * best;
@@ -637,25 +637,48 @@ __global__ __launch_bounds__((ColGeom<T, LG>::THREADS)) void colsolve_kernel(T* 
 #pragma unroll
   for (int n = 0; n < NT; ++n) D::template solve_scatter<CT>(x[n], lds + n * G::REGION, t);
   __syncthreads();
+  // fused path: rho = <r, z> of the whole image from the spectra in registers (Parseval), so that the
+  // row kernel that follows need not read r again
+  double rho = 0.0;
 #pragma unroll
   for (int n = 0; n < NT; ++n)
     D::template solve_combine<CT>(x[n], lds + n * G::REGION, t, wspec, ha, ham, hb[yy + 2 * n], hb[yy + 2 * n + 1],
-                                  yy + 2 * n == 0, false, T(1) / T(N));
+                                  yy + 2 * n == 0, false, T(1) / T(N), RHO ? &rho : nullptr);
   __syncthreads();
-  F::template inverse_multi<NT, CT>(x, lds, G::REGION, t, tw);
-  if (!valid) return;
+  // parked in (static) LDS; reduced after the stores, where no transform data is live any more
+  if constexpr (RHO) shn[threadIdx.x] = valid ? rho : 0.0;
+  // the inverse exchanges through the same LDS addresses as the forward transform: recomputed from an
+  // opaque copy of t instead of being kept alive (or spilled) across the solve
+  int ti = t;
+  asm volatile("" : "+v"(ti));
+  F::template inverse_multi<NT, CT>(x, lds, G::REGION, ti, tw);
+  if (valid) {
+    // the store addresses equal the load addresses; recomputed from an opaque copy of t so that the
+    // compiler does not keep 16 64-bit addresses alive (or spilled) across the transforms
+    int ts = t;
+    asm volatile("" : "+v"(ts));
 #pragma unroll
-  for (int i = 0; i < 16; ++i) {
-    const int row = makhoul_src(t + TPF * i, N);
-    Vec q;
+    for (int i = 0; i < 16; ++i) {
+      const int row = makhoul_src(ts + TPF * i, N);
+      Vec q;
 #pragma unroll
-    for (int n = 0; n < NT; ++n) q.v[n] = x[n][i];
-    *reinterpret_cast<Vec*>(Z + (size_t)row * n1 + y0) = q;
+      for (int n = 0; n < NT; ++n) q.v[n] = x[n][i];
+      *reinterpret_cast<Vec*>(Z + (size_t)row * n1 + y0) = q;
+    }
+  }
+  if constexpr (RHO) {
+    __syncthreads();
+    if (threadIdx.x < 64) {
+      double a = 0.0;
+      for (int i = threadIdx.x; i < G::THREADS; i += 64) a += shn[i];
+      a = wave_sum(a);
+      if (threadIdx.x == 0) part_rho[blockIdx.x] = a / (double)n1;
+    }
   }
 }
 
 // rows: Z -> z = DCT-III along axis 1 (in place), partial rho = <r, z>
-template <class T, int LG>
+template <class T, int LG, bool RHO>
 __global__ __launch_bounds__((RowGeom<T, LG>::THREADS)) void rowidct_kernel(T* __restrict__ Z, const T* __restrict__ r,
                                                                          int n0, const cpx<T>* __restrict__ twtab,
                                                                          const cpx<T>* __restrict__ wk, double* part,
@@ -697,11 +720,13 @@ __global__ __launch_bounds__((RowGeom<T, LG>::THREADS)) void rowidct_kernel(T* _
       const int c = tid + TPF * i;
       za[c] = x[i].x;
       zb[c] = x[i].y;
-      dot += (double)ra[c] * (double)x[i].x + (double)rb[c] * (double)x[i].y;
+      if constexpr (RHO) dot += (double)ra[c] * (double)x[i].x + (double)rb[c] * (double)x[i].y;
     }
   }
-  const double tot = block_sum(dot, sh);
-  if (threadIdx.x == 0) part[blockIdx.x] = tot;
+  if constexpr (RHO) {   // (the fused path takes rho from the column kernel's spectra instead)
+    const double tot = block_sum(dot, sh);
+    if (threadIdx.x == 0) part[blockIdx.x] = tot;
+  }
 }
 
 // ---------------------------------------------------------------------------
@@ -1025,12 +1050,12 @@ hipError_t run_rowdct(const Impl* w, hipStream_t s) {
     return hipGetLastError();
   }
 }
-template <class T, int LG>
+template <class T, int LG, bool RHO = true>
 hipError_t run_rowidct(const Impl* w, int* nparts, hipStream_t s) {
   using G = RowGeom<T, LG>;
   if constexpr (!G::FITS) return hipErrorInvalidValue;
   else {
-    auto kern = rowidct_kernel<T, LG>;
+    auto kern = rowidct_kernel<T, LG, RHO>;
     hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize,
                                        (int)G::LDS_BYTES);
     if (e != hipSuccess) return e;
@@ -1043,18 +1068,20 @@ hipError_t run_rowidct(const Impl* w, int* nparts, hipStream_t s) {
 }
 template <class T, int LG>
 hipError_t run_colsolve(const Impl* w, int compat, hipStream_t s, const double* part_norm = nullptr, int nnorm = 0,
-                        int it = 0, double eps = 0.0) {
+                        int it = 0, double eps = 0.0, double* part_rho = nullptr, int* nrho = nullptr) {
   using G = ColGeom<T, LG>;
   if constexpr (!G::FITS) return hipErrorInvalidValue;
   else {
-    auto kern = colsolve_kernel<T, LG>;
+    auto kern = part_rho ? colsolve_kernel<T, LG, true> : colsolve_kernel<T, LG, false>;
     hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize,
                                        (int)G::LDS_BYTES);
     if (e != hipSuccess) return e;
     const int npairs = w->n1 / 2, grid = (npairs + G::CC - 1) / G::CC;
+    if (nrho) *nrho = grid;
     kern<<<grid, G::THREADS, G::LDS_BYTES, s>>>((T*)w->z, w->n1, (const cpx<T>*)w->tw0, (const cpx<T>*)w->wk0s,
                                                  (const T*)w->ha0[compat], (const T*)w->ham0[compat],
-                                                 (const T*)w->hb1[compat], w->flags, part_norm, nnorm, it, eps, w->scal);
+                                                 (const T*)w->hb1[compat], w->flags, part_norm, nnorm, it, eps, w->scal,
+                                                 part_rho);
     return hipGetLastError();
   }
 }
@@ -1089,10 +1116,19 @@ hipError_t dispatch_rowidct(const Impl* w, int* nparts, hipStream_t s) {
 #undef CASE
   return hipErrorInvalidValue;
 }
+// fused path: z only, rho comes from the column kernel
+hipError_t dispatch_rowidct_norho(const Impl* w, hipStream_t s) {
+  int unused = 0;
+#define CASE(LG) case LG: return w->dtype == 0 ? run_rowidct<float, LG, false>(w, &unused, s) : run_rowidct<double, LG, false>(w, &unused, s);
+  switch (w->lg1) { GPA_FOR_LG(CASE) }
+#undef CASE
+  return hipErrorInvalidValue;
+}
 hipError_t dispatch_colsolve(const Impl* w, int compat, hipStream_t s, const double* part_norm = nullptr,
-                             int nnorm = 0, int it = 0, double eps = 0.0) {
-#define CASE(LG) case LG: return w->dtype == 0 ? run_colsolve<float, LG>(w, compat, s, part_norm, nnorm, it, eps) \
-                                               : run_colsolve<double, LG>(w, compat, s, part_norm, nnorm, it, eps);
+                             int nnorm = 0, int it = 0, double eps = 0.0, double* part_rho = nullptr,
+                             int* nrho = nullptr) {
+#define CASE(LG) case LG: return w->dtype == 0 ? run_colsolve<float, LG>(w, compat, s, part_norm, nnorm, it, eps, part_rho, nrho) \
+                                               : run_colsolve<double, LG>(w, compat, s, part_norm, nnorm, it, eps, part_rho, nrho);
   switch (w->lg0) { GPA_FOR_LG(CASE) }
 #undef CASE
   return hipErrorInvalidValue;
@@ -1400,9 +1436,9 @@ static hipError_t run_pcg(Impl* w, const void* a, const void* b, const void* wei
     T* pprev = nullptr;
     for (int it = 0; it < kmax; ++it) {
       if ((e = dispatch_rowdct_fused(w, w->q, pprev, phi, part_pq, npq, part_norm, it, &nnorm, s)) != hipSuccess) return e;
-      if ((e = dispatch_colsolve(w, compat, s, part_norm, nnorm, it, eps)) != hipSuccess) return e;
-      int nrow = 0;
-      if ((e = dispatch_rowidct(w, &nrow, s)) != hipSuccess) return e;
+      int nrow = 0;   // partial sums of rho = <r, z>: one per column workgroup (Parseval, solve_combine)
+      if ((e = dispatch_colsolve(w, compat, s, part_norm, nnorm, it, eps, part_rho, &nrow)) != hipSuccess) return e;
+      if ((e = dispatch_rowidct_norho(w, s)) != hipSuccess) return e;
       T* pin = (T*)((it & 1) ? w->p2 : w->p);
       T* pout = (T*)((it & 1) ? w->p : w->p2);
       pq_kernel<T><<<gpq, 256, 0, s>>>((const T*)w->z, pin, pout, (const T*)weight, n0, n1, (T*)w->q, part_pq, w->scal,
