@@ -25,12 +25,16 @@ namespace gpa {
 namespace {
 
 constexpr int MAXPART = 65536;   // one partial sum per image row / per grid-stride block
+constexpr int RING_MAX = 10;     // search directions kept so that phi is updated once per RING_MAX iterations
+constexpr int SC_ALPHA = 16;     // scal[SC_ALPHA + j % ring] = alpha of iteration j
 
 struct Impl {
   int dtype, n0, n1, lg0, lg1;
   bool supported;
   size_t rsz;
-  void *r, *p, *p2, *q, *z;   // p / p2: double-buffered search direction
+  void *r, *p, *p2, *q, *z;   // p / p2: double-buffered search direction (= ring[0], ring[1])
+  void* ring[10];            // search directions of the last RING iterations (fused path), grown on demand
+  int nring;
   void *tw0, *tw1;           // FFT twiddles per axis
   void *wk1;                 // w_k along axis 1, natural order
   void *wk0s;                // w_k along axis 0, spectral layout
@@ -92,7 +96,9 @@ __device__ __forceinline__ double reduce_partials(const double* __restrict__ par
 //   scal[5] = ||r0||^2                    (scal_init_kernel)
 //   scal[8 + (it & 1)]  = rho of iteration it            (pq_kernel)
 //   scal[10 + (it & 1)] = smallest ||r||^2 up to it      (colsolve_kernel)
+//   scal[16 + (j % ring)] = alpha of iteration j         (rowdct_fused_kernel / final_update_kernel)
 //   flags[0] = completed updates k, flags[1] = done      (colsolve_kernel / final kernel)
+//   flags[2] = updates already applied to phi            (phi_commit_kernel)
 
 // ---------------------------------------------------------------------------
 // setup: r0 = div( WW * wrap(grad) ), phi = 0, partial ||r0||^2
@@ -193,6 +199,7 @@ __global__ void scal_init_kernel(const double* part, int nparts, double* scal, i
     scal[11] = tot;
     scal[1] = 0.0;
     flags[0] = 0;
+    flags[2] = 0;
     flags[1] = tot == 0.0 ? 1 : 0;   // r == 0 everywhere: nothing to do (phase_unwrap.py:326)
   }
 }
@@ -485,9 +492,9 @@ __global__ __launch_bounds__((RowGeom<T, LG>::THREADS)) void rowdct_kernel(const
 //   r -= alpha q;  phi += alpha p;  partial ||r||^2;  Z = DCT(r)
 template <class T, int LG>
 __global__ __launch_bounds__((RowGeom<T, LG>::THREADS)) void rowdct_fused_kernel(
-    T* __restrict__ r, const T* __restrict__ q, const T* __restrict__ p, T* __restrict__ phi, int n0,
-    T* __restrict__ Z, const cpx<T>* __restrict__ twtab, const cpx<T>* __restrict__ wk, const int* flags,
-    const double* part_pq, int npq, double* part_norm, const double* scal, int it) {
+    T* __restrict__ r, const T* __restrict__ q, int n0, T* __restrict__ Z, const cpx<T>* __restrict__ twtab,
+    const cpx<T>* __restrict__ wk, const int* flags, const double* part_pq, int npq, double* part_norm,
+    double* scal, int it, int ring) {
   if (flags[1]) return;
   using F = WgFFT<T, LG>;
   using D = WgDCT<T, LG>;
@@ -505,7 +512,11 @@ __global__ __launch_bounds__((RowGeom<T, LG>::THREADS)) void rowdct_fused_kernel
   cpx<T> x[16];
   if (it > 0) {
     const double pq = reduce_partials(part_pq, npq, sh);
-    const T alpha = (T)(scal[8 + ((it - 1) & 1)] / pq);   // phase_unwrap.py:343
+    const double alpha_d = scal[8 + ((it - 1) & 1)] / pq;   // phase_unwrap.py:343
+    const T alpha = (T)alpha_d;
+    // phi += alpha p is not applied here: alpha is filed for phi_flush_kernel, which adds the kept
+    // search directions of up to `ring` iterations in one pass over phi
+    if (blockIdx.x == 0 && threadIdx.x == 0) scal[SC_ALPHA + (it - 1) % ring] = alpha_d;
     // elementwise update with coalesced 16-byte accesses (4 consecutive pixels per thread and
     // step); the new residual is also parked in LDS so the even/odd-permuted DCT input does
     // not have to come back from memory with stride-2 accesses
@@ -513,22 +524,16 @@ __global__ __launch_bounds__((RowGeom<T, LG>::THREADS)) void rowdct_fused_kernel
     for (int c0 = 4 * tid; c0 < N; c0 += 4 * TPF) {
       Vec4<T> ra = *reinterpret_cast<const Vec4<T>*>(r + oa + c0), rb = *reinterpret_cast<const Vec4<T>*>(r + ob + c0);
       const Vec4<T> qa = *reinterpret_cast<const Vec4<T>*>(q + oa + c0), qb = *reinterpret_cast<const Vec4<T>*>(q + ob + c0);
-      const Vec4<T> pa = *reinterpret_cast<const Vec4<T>*>(p + oa + c0), pb = *reinterpret_cast<const Vec4<T>*>(p + ob + c0);
-      Vec4<T> fa = *reinterpret_cast<const Vec4<T>*>(phi + oa + c0), fb = *reinterpret_cast<const Vec4<T>*>(phi + ob + c0);
 #pragma unroll
       for (int j = 0; j < 4; ++j) {
         ra.v[j] -= alpha * qa.v[j];
         rb.v[j] -= alpha * qb.v[j];
-        fa.v[j] += alpha * pa.v[j];
-        fb.v[j] += alpha * pb.v[j];
         sq += (double)ra.v[j] * (double)ra.v[j] + (double)rb.v[j] * (double)rb.v[j];
         lds[F::pad(c0 + j)] = {ra.v[j], rb.v[j]};
       }
       if (valid) {
         *reinterpret_cast<Vec4<T>*>(r + oa + c0) = ra;
         *reinterpret_cast<Vec4<T>*>(r + ob + c0) = rb;
-        *reinterpret_cast<Vec4<T>*>(phi + oa + c0) = fa;
-        *reinterpret_cast<Vec4<T>*>(phi + ob + c0) = fb;
       }
     }
     if (!valid) sq = 0;
@@ -561,19 +566,40 @@ __global__ __launch_bounds__((RowGeom<T, LG>::THREADS)) void rowdct_fused_kernel
 
 // fused path, after the last iteration: the update that no further row kernel will apply
 template <class T>
-__global__ __launch_bounds__(256) void final_update_kernel(const T* __restrict__ p, const T* __restrict__ q,
-                                                          T* __restrict__ phi, T* __restrict__ r, size_t count,
-                                                          const double* scal, const double* part_pq, int npq,
-                                                          int it, const int* flags) {
+__global__ __launch_bounds__(256) void final_update_kernel(const T* __restrict__ q, T* __restrict__ r, size_t count,
+                                                          double* scal, const double* part_pq, int npq, int it,
+                                                          int ring, const int* flags) {
   if (flags[1]) return;
   __shared__ double sh[256];
   const double pq = reduce_partials(part_pq, npq, sh);
-  const T alpha = (T)(scal[8 + ((it - 1) & 1)] / pq);
-  for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < count; i += (size_t)gridDim.x * 256) {
-    phi[i] += alpha * p[i];
-    r[i] -= alpha * q[i];
+  const double alpha_d = scal[8 + ((it - 1) & 1)] / pq;
+  const T alpha = (T)alpha_d;
+  if (blockIdx.x == 0 && threadIdx.x == 0) scal[SC_ALPHA + (it - 1) % ring] = alpha_d;
+  for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < count; i += (size_t)gridDim.x * 256) r[i] -= alpha * q[i];
+}
+
+// phi += sum_j alpha_j p_j over the updates j in [flags[2], flags[0]) that the iteration has completed
+// but phi has not seen yet, in iteration order (the same additions the reference makes one per
+// iteration, phase_unwrap.py:344, without writing phi back in between).  Runs whether or not the
+// iteration has stopped; phi_commit_kernel then records what was applied.
+template <class T> struct RingPtrs { const T* p[RING_MAX]; };
+template <class T>
+__global__ __launch_bounds__(256) void phi_flush_kernel(RingPtrs<T> ringp, int ring, T* __restrict__ phi, size_t count4,
+                                                       const double* __restrict__ scal, const int* __restrict__ flags) {
+  const int a = flags[2], b = flags[0];
+  if (a >= b) return;
+  for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < count4; i += (size_t)gridDim.x * 256) {
+    Vec4<T> f = reinterpret_cast<const Vec4<T>*>(phi)[i];
+    for (int j = a; j < b; ++j) {
+      const T alpha = (T)scal[SC_ALPHA + j % ring];
+      const Vec4<T> pv = reinterpret_cast<const Vec4<T>*>(ringp.p[j % ring])[i];
+#pragma unroll
+      for (int c = 0; c < 4; ++c) f.v[c] += alpha * pv.v[c];
+    }
+    reinterpret_cast<Vec4<T>*>(phi)[i] = f;
   }
 }
+__global__ void phi_commit_kernel(int* flags) { flags[2] = flags[0]; }
 __global__ void final_count_kernel(int* flags, int kmax) {
   if (flags[1]) return;
   flags[0] = kmax;
@@ -1086,7 +1112,7 @@ hipError_t run_colsolve(const Impl* w, int compat, hipStream_t s, const double* 
   }
 }
 template <class T, int LG>
-hipError_t run_rowdct_fused(const Impl* w, const void* q, const void* p, void* phi, const double* part_pq, int npq,
+hipError_t run_rowdct_fused(const Impl* w, const void* q, int ring, const double* part_pq, int npq,
                             double* part_norm, int it, int* nnorm, hipStream_t s) {
   using G = RowGeom<T, LG>;
   if constexpr (!G::FITS) return hipErrorInvalidValue;
@@ -1097,9 +1123,9 @@ hipError_t run_rowdct_fused(const Impl* w, const void* q, const void* p, void* p
     if (e != hipSuccess) return e;
     const int npairs = w->n0 / 2, grid = (npairs + G::NF - 1) / G::NF;
     *nnorm = grid;
-    kern<<<grid, G::THREADS, G::LDS_BYTES, s>>>((T*)w->r, (const T*)q, (const T*)p, (T*)phi, w->n0, (T*)w->z,
-                                                 (const cpx<T>*)w->tw1, (const cpx<T>*)w->wk1, w->flags, part_pq, npq,
-                                                 part_norm, w->scal, it);
+    kern<<<grid, G::THREADS, G::LDS_BYTES, s>>>((T*)w->r, (const T*)q, w->n0, (T*)w->z, (const cpx<T>*)w->tw1,
+                                                 (const cpx<T>*)w->wk1, w->flags, part_pq, npq, part_norm, w->scal, it,
+                                                 ring);
     return hipGetLastError();
   }
 }
@@ -1133,10 +1159,10 @@ hipError_t dispatch_colsolve(const Impl* w, int compat, hipStream_t s, const dou
 #undef CASE
   return hipErrorInvalidValue;
 }
-hipError_t dispatch_rowdct_fused(const Impl* w, const void* q, const void* p, void* phi, const double* part_pq, int npq,
+hipError_t dispatch_rowdct_fused(const Impl* w, const void* q, int ring, const double* part_pq, int npq,
                                  double* part_norm, int it, int* nnorm, hipStream_t s) {
-#define CASE(LG) case LG: return w->dtype == 0 ? run_rowdct_fused<float, LG>(w, q, p, phi, part_pq, npq, part_norm, it, nnorm, s) \
-                                               : run_rowdct_fused<double, LG>(w, q, p, phi, part_pq, npq, part_norm, it, nnorm, s);
+#define CASE(LG) case LG: return w->dtype == 0 ? run_rowdct_fused<float, LG>(w, q, ring, part_pq, npq, part_norm, it, nnorm, s) \
+                                               : run_rowdct_fused<double, LG>(w, q, ring, part_pq, npq, part_norm, it, nnorm, s);
   switch (w->lg1) { GPA_FOR_LG(CASE) }
 #undef CASE
   return hipErrorInvalidValue;
@@ -1283,7 +1309,10 @@ hipError_t unwrap_workspace_create(int dtype, int n0, int n1, hipStream_t s, Unw
     if (e != hipSuccess) return e;
     bytes += npx * w->rsz;
   }
-  e = hipMalloc((void**)&w->scal, 16 * sizeof(double));
+  w->ring[0] = w->p;
+  w->ring[1] = w->p2;
+  w->nring = 2;
+  e = hipMalloc((void**)&w->scal, (SC_ALPHA + RING_MAX + 6) * sizeof(double));
   if (e != hipSuccess) return e;
   e = hipMalloc((void**)&w->flags, 4 * sizeof(int));
   if (e != hipSuccess) return e;
@@ -1395,6 +1424,8 @@ void unwrap_workspace_destroy(UnwrapWorkspace* ws) {
                   w->bspec0, w->bspec1, w->gwk0, w->gwk1, w->gha0[0], w->gha0[1], w->gham0[0], w->gham0[1]};
   for (void* b : bufs)
     if (b) hipFree(b);
+  for (int j = 2; j < w->nring; ++j)
+    if (w->ring[j]) hipFree(w->ring[j]);
   delete w;
   ws->impl = nullptr;
 }
@@ -1432,22 +1463,37 @@ static hipError_t run_pcg(Impl* w, const void* a, const void* b, const void* wei
     double* part_rho = w->part;
     double* part_pq = w->part + MAXPART;
     double* part_norm = w->part + 2 * MAXPART;
+    // the search directions of the last `ring` iterations stay in HBM (64 MiB each at 4096^2 f32 -- HBM is
+    // plentiful), so phi += alpha p costs one pass over phi per `ring` iterations instead of one per iteration
+    int ring = kmax < RING_MAX ? kmax : RING_MAX;
+    if (ring < 2) ring = 2;
+    while (w->nring < ring) {
+      void* buf = nullptr;
+      if (hipMalloc(&buf, npx * w->rsz) != hipSuccess) { (void)hipGetLastError(); break; }
+      w->ring[w->nring++] = buf;
+    }
+    if (w->nring < ring) ring = w->nring;   // out of memory: flush more often
+    RingPtrs<T> rp;
+    for (int j = 0; j < RING_MAX; ++j) rp.p[j] = (const T*)w->ring[j < ring ? j : 0];
+    auto flush = [&]() {
+      phi_flush_kernel<T><<<gl, 256, 0, s>>>(rp, ring, (T*)phi, npx / 4, w->scal, w->flags);
+      phi_commit_kernel<<<1, 1, 0, s>>>(w->flags);
+    };
     int nnorm = 0;
-    T* pprev = nullptr;
     for (int it = 0; it < kmax; ++it) {
-      if ((e = dispatch_rowdct_fused(w, w->q, pprev, phi, part_pq, npq, part_norm, it, &nnorm, s)) != hipSuccess) return e;
+      if ((e = dispatch_rowdct_fused(w, w->q, ring, part_pq, npq, part_norm, it, &nnorm, s)) != hipSuccess) return e;
       int nrow = 0;   // partial sums of rho = <r, z>: one per column workgroup (Parseval, solve_combine)
       if ((e = dispatch_colsolve(w, compat, s, part_norm, nnorm, it, eps, part_rho, &nrow)) != hipSuccess) return e;
       if ((e = dispatch_rowidct_norho(w, s)) != hipSuccess) return e;
-      T* pin = (T*)((it & 1) ? w->p2 : w->p);
-      T* pout = (T*)((it & 1) ? w->p : w->p2);
+      if (it > 0 && it % ring == 0) flush();   // slot it % ring still holds p of iteration it - ring
+      const T* pin = (const T*)w->ring[(it + ring - 1) % ring];
+      T* pout = (T*)w->ring[it % ring];
       pq_kernel<T><<<gpq, 256, 0, s>>>((const T*)w->z, pin, pout, (const T*)weight, n0, n1, (T*)w->q, part_pq, w->scal,
                                        w->flags, part_rho, nrow, it, band);
-      pprev = pout;
     }
-    final_update_kernel<T><<<gl, 256, 0, s>>>((const T*)pprev, (const T*)w->q, (T*)phi, (T*)w->r, npx, w->scal, part_pq,
-                                              npq, kmax, w->flags);
+    final_update_kernel<T><<<gl, 256, 0, s>>>((const T*)w->q, (T*)w->r, npx, w->scal, part_pq, npq, kmax, ring, w->flags);
     final_count_kernel<<<1, 1, 0, s>>>(w->flags, kmax);
+    flush();
     return hipGetLastError();
   }
   for (int it = 0; it < kmax; ++it) {
