@@ -427,7 +427,10 @@ struct ColGeom {
     while (c > 1 && (c * F::TPF > 1024 || (size_t)c * (F::LDS_ELEMS + 32) * sizeof(cpx<T>) > 160 * 1024)) c /= 2;
     // ... but a (square) image of side N has only N/2 pairs: keep >= 512 workgroups in flight
     // on the 256 CUs, small images are cache resident and do not care about segment length
-    const int want = LG >= 12 ? 16 : (LG == 11 ? 2 : 1);
+#ifndef GPA_COL_WANT
+#define GPA_COL_WANT 16
+#endif
+    const int want = LG >= 12 ? GPA_COL_WANT : (LG == 11 ? 2 : 1);
     return c < want ? c : want;
   }
   static constexpr int CC = cols();   // packed column PAIRS (complex transforms) per workgroup
