@@ -614,10 +614,6 @@ static int extract_enqueue(gpa_plan* p, const void* image, const double* kvecs, 
   void* lk = lockins ? lockins : p->d_lockin;
   TRY(sweep_peaks_dev(p, image, p->d_mean, kvecs, P, klists, K, sigma, lk, kidx));
   TRY(stage_kmat(p, kvecs, P));
-  HIP_TRY(launch_reconstruct(p->dtype, lk, p->d_kmat, P, p->n0, p->n1, mask_border, p->d_dudx, p->d_dudy,
-                             p->d_wnorm, p->stream));
-  if (p->profiling) HIP_TRY(hipEventRecord(p->stage_ev[4], p->stream));
-  const size_t nx = (size_t)p->n0 * (p->n1 - 1), ny = (size_t)(p->n0 - 1) * p->n1;
   if (!p->stream2) {
     // the two displacement components are independent solves: give the second one its own
     // workspace and stream so the latency-bound kernels of one fill the gaps of the other
@@ -629,16 +625,22 @@ static int extract_enqueue(gpa_plan* p, const void* image, const double* kvecs, 
     if (e2 != hipSuccess) return fail(GPA_ERR_HIP, std::string("second unwrap workspace: ") + hipGetErrorString(e2));
     p->ws_bytes += b2;
   }
+  // phases / weights / per-pixel least squares fused with the unwrap's set-up: the gradient fields never
+  // go to HBM, the kernel leaves r0 of both components in the two unwrap workspaces
+  int nparts = 0;
+  HIP_TRY(launch_reconstruct_setup(p->dtype, lk, p->d_kmat, P, p->n0, p->n1, mask_border, p->d_wnorm,
+                                   unwrap_residual_buffer(&p->uw), unwrap_residual_buffer(&p->uw2),
+                                   unwrap_partials_buffer(&p->uw), unwrap_partials_buffer(&p->uw2), &nparts, p->stream));
+  if (p->profiling) HIP_TRY(hipEventRecord(p->stage_ev[4], p->stream));
   HIP_TRY(hipEventRecord(p->ev_fork, p->stream));
   HIP_TRY(hipStreamWaitEvent(p->stream2, p->ev_fork, 0));
-  hipError_t e = unwrap_enqueue(&p->uw, p->d_dudx, p->d_dudy, p->d_wnorm, false, kmax, 1e-9, true, u, p->stream);
+  hipError_t e = unwrap_enqueue_prepared(&p->uw, p->d_wnorm, nparts, kmax, 1e-9, true, u, p->stream);
   if (getenv("GPA_SERIAL_UNWRAP")) {   // diagnostic: run the second component after the first (clean per-kernel timings)
     HIP_TRY(hipEventRecord(p->ev_fork, p->stream));
     HIP_TRY(hipStreamWaitEvent(p->stream2, p->ev_fork, 0));
   }
   if (e == hipSuccess)
-    e = unwrap_enqueue(&p->uw2, (char*)p->d_dudx + nx * p->rsz, (char*)p->d_dudy + ny * p->rsz, p->d_wnorm, false,
-                       kmax, 1e-9, true, (char*)u + npx * p->rsz, p->stream2);
+    e = unwrap_enqueue_prepared(&p->uw2, p->d_wnorm, nparts, kmax, 1e-9, true, (char*)u + npx * p->rsz, p->stream2);
   if (e == hipSuccess) e = unwrap_fetch_iters(&p->uw, &p->h_iters[0], p->stream);
   if (e == hipSuccess) e = unwrap_fetch_iters(&p->uw2, &p->h_iters[1], p->stream2);
   if (e != hipSuccess) return fail(GPA_ERR_HIP, std::string("unwrap: ") + hipGetErrorString(e));

@@ -84,6 +84,12 @@ hipError_t launch_reconstruct(int dtype, const void* lockin, const double* kmat 
                               int P, int n0, int n1, int border, void* dudx, void* dudy,
                               void* wnorm, hipStream_t s);
 
+// fused a5 + a6 + unwrap setup for both components (fused driver): wnorm, r0 of u_x / u_y and
+// *nparts partial sums of ||r0||^2 each
+hipError_t launch_reconstruct_setup(int dtype, const void* lockin, const double* kmat, int P, int n0, int n1,
+                                    int border, void* wnorm, void* r0, void* r1, double* part0, double* part1,
+                                    int* nparts, hipStream_t s);
+
 hipError_t launch_wlstsq(int dtype, const void* b, const void* w, const double* kmat, int P, size_t npx,
                          void* out, hipStream_t s);
 

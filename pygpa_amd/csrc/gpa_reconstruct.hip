@@ -139,6 +139,167 @@ __global__ __launch_bounds__(256) void reconstruct_kernel(const cpx<T>* __restri
   }
 }
 
+// ---- fused driver: a5 + a6 + the unwrap's setup in one pass --------------------------------------
+// reconstruct_kernel followed by the unwrap's setup_kernel (gpa_unwrap.hip) writes the four
+// gradient fields to HBM only for the next kernel to read them back.  Here the weighted, wrapped
+// gradient of every edge is consumed where it is produced: the kernel emits wnorm and, for both
+// displacement components, r0 = div(min(w^2) wrap(grad u_c)) (phase_unwrap.py:326-331 on the
+// weighted-prediff inputs of geometric_phase_analysis.py:234-240) plus the partial sums of ||r0||^2.
+// A wavefront owns 62 columns (lane 0 / lane 63 are a left / right halo column, so every neighbour
+// comes from a lane shuffle); a workgroup slides down FUSED_ROWS rows after one halo row.
+// Arithmetic identical to the two separate kernels (same values, same order).
+constexpr int FUSED_ROWS = 32, FUSED_COLS = 62;
+
+template <class T, int P>
+__global__ __launch_bounds__(256) void reconstruct_setup_kernel(const cpx<T>* __restrict__ lockin,
+                                                               const double* __restrict__ kmat, int n0, int n1,
+                                                               int border, T* __restrict__ wnorm, T* __restrict__ r0,
+                                                               T* __restrict__ r1, double* __restrict__ part0,
+                                                               double* __restrict__ part1) {
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int yw = (blockIdx.x * 4 + wave) * FUSED_COLS + lane - 1;
+  const bool incol = yw >= 0 && yw < n1;
+  const int yc = yw < 0 ? 0 : (yw >= n1 ? n1 - 1 : yw);
+  const bool outcol = incol && lane >= 1 && lane <= FUSED_COLS;
+  const int x0 = blockIdx.y * FUSED_ROWS;
+  const int x1 = x0 + FUSED_ROWS < n0 ? x0 + FUSED_ROWS : n0;
+  const int xs = x0 > 0 ? x0 - 1 : x0;
+  const size_t npx = (size_t)n0 * n1;
+  const bool has_r = incol && yw + 1 < n1;
+  T k0[P], k1[P];
+#pragma unroll
+  for (int p = 0; p < P; ++p) { k0[p] = (T)kmat[2 * p]; k1[p] = (T)kmat[2 * p + 1]; }
+  auto mask_fac = [&](int x, int y) {
+    const bool inside = x >= border && x < n0 - border && y >= border && y < n1 - border;
+    return (inside ? T(1) : T(0)) + T(1e-6);
+  };
+  T phc[P], ampc[P], phn[P], ampn[P];
+  T wsq_c = T(0);
+#pragma unroll
+  for (int p = 0; p < P; ++p) {
+    const cpx<T> c = lockin[p * npx + (size_t)xs * n1 + yc];
+    phc[p] = atan2(c.y, c.x);
+    ampc[p] = sqrt(c.x * c.x + c.y * c.y);
+    phn[p] = T(0);
+    ampn[p] = T(0);
+    const T w = ampc[p] * mask_fac(xs, yc);
+    wsq_c += w * w;
+  }
+  T fyu0 = T(0), fyu1 = T(0);
+  double sq0 = 0, sq1 = 0;
+  for (int x = xs; x < x1; ++x) {
+    const size_t o = (size_t)x * n1 + yc;
+    const bool has_d = x + 1 < n0, outrow = x >= x0;
+    T wsq_n = T(0);
+    if (has_d) {
+      const T mn = mask_fac(x + 1, yc);
+#pragma unroll
+      for (int p = 0; p < P; ++p) {
+        const cpx<T> c = lockin[p * npx + o + n1];
+        phn[p] = atan2(c.y, c.x);
+        ampn[p] = sqrt(c.x * c.x + c.y * c.y);
+        const T w = ampn[p] * mn;
+        wsq_n += w * w;
+      }
+    }
+    // the unwrap weight is wnorm = sqrt(sum w^2) as stored; its square is what setup_kernel uses
+    const T tc = sqrt(wsq_c), tn = sqrt(wsq_n);
+    const T wwc = tc * tc, wwn = tn * tn;
+    const T wwr = __shfl_down(wwc, 1);
+    const T mfac = mask_fac(x, yc);
+    T w[P], bx[P], by[P];
+    T wmax = T(0);
+#pragma unroll
+    for (int p = 0; p < P; ++p) {
+      const T phr = __shfl_down(phc[p], 1);
+      w[p] = ampc[p] * mfac;
+      wmax = w[p] > wmax ? w[p] : wmax;
+      bx[p] = has_r ? wrap_to_pi(phr - phc[p]) : T(0);
+      by[p] = has_d ? wrap_to_pi(phn[p] - phc[p]) : T(0);
+    }
+    const T ws = wmax > T(0) ? T(1) / wmax : T(0);
+    T a00 = 0, a01 = 0, a11 = 0, rx0 = 0, rx1 = 0, ry0 = 0, ry1 = 0;
+#pragma unroll
+    for (int p = 0; p < P; ++p) {
+      const T wn = w[p] * ws, ww = wn * wn;
+      a00 += ww * k0[p] * k0[p];
+      a01 += ww * k0[p] * k1[p];
+      a11 += ww * k1[p] * k1[p];
+      rx0 += ww * k0[p] * bx[p];
+      rx1 += ww * k1[p] * bx[p];
+      ry0 += ww * k0[p] * by[p];
+      ry1 += ww * k1[p] * by[p];
+    }
+    T fx0 = T(0), fx1 = T(0), fy0 = T(0), fy1 = T(0);
+    if (outrow && has_r) {   // (the halo row only supplies its down edges)
+      T s0, s1;
+      solve2(a00, a01, a11, rx0, rx1, s0, s1);
+      const T m = wwr < wwc ? wwr : wwc;
+      fx0 = wrap_to_pi(s0) * m;
+      fx1 = wrap_to_pi(s1) * m;
+    }
+    if (has_d) {
+      T s0, s1;
+      solve2(a00, a01, a11, ry0, ry1, s0, s1);
+      const T m = wwn < wwc ? wwn : wwc;
+      fy0 = wrap_to_pi(s0) * m;
+      fy1 = wrap_to_pi(s1) * m;
+    }
+    const T fxl0 = __shfl_up(fx0, 1), fxl1 = __shfl_up(fx1, 1);
+    if (outrow && outcol) {
+      const T v0 = fx0 - fxl0 + fy0 - fyu0, v1 = fx1 - fxl1 + fy1 - fyu1;
+      wnorm[o] = tc;
+      r0[o] = v0;
+      r1[o] = v1;
+      sq0 += (double)v0 * (double)v0;
+      sq1 += (double)v1 * (double)v1;
+    }
+    fyu0 = fy0;
+    fyu1 = fy1;
+    wsq_c = wsq_n;
+#pragma unroll
+    for (int p = 0; p < P; ++p) { phc[p] = phn[p]; ampc[p] = ampn[p]; }
+  }
+  // deterministic block sums (fixed shuffle tree, then fixed order over the four wavefronts)
+  __shared__ double sh[8];
+#pragma unroll
+  for (int off = 32; off > 0; off >>= 1) { sq0 += __shfl_down(sq0, off); sq1 += __shfl_down(sq1, off); }
+  if (lane == 0) { sh[wave] = sq0; sh[4 + wave] = sq1; }
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    const int blk = blockIdx.y * gridDim.x + blockIdx.x;
+    part0[blk] = ((sh[0] + sh[1]) + sh[2]) + sh[3];
+    part1[blk] = ((sh[4] + sh[5]) + sh[6]) + sh[7];
+  }
+}
+
+template <class T>
+static hipError_t launch_reconstruct_setup_t(const void* lockin, const double* kmat, int P, int n0, int n1, int border,
+                                             void* wnorm, void* r0, void* r1, double* part0, double* part1, int* nparts,
+                                             hipStream_t s) {
+  dim3 grid((n1 + 4 * FUSED_COLS - 1) / (4 * FUSED_COLS), (n0 + FUSED_ROWS - 1) / FUSED_ROWS);
+  *nparts = (int)(grid.x * grid.y);
+#define RS_CASE(PP)                                                                                                   \
+  case PP:                                                                                                            \
+    reconstruct_setup_kernel<T, PP><<<grid, 256, 0, s>>>((const cpx<T>*)lockin, kmat, n0, n1, border, (T*)wnorm,       \
+                                                         (T*)r0, (T*)r1, part0, part1);                              \
+    break;
+  switch (P) {
+    RS_CASE(2) RS_CASE(3) RS_CASE(4) RS_CASE(5) RS_CASE(6) RS_CASE(7) RS_CASE(8)
+    default: return hipErrorInvalidValue;
+  }
+#undef RS_CASE
+  return hipGetLastError();
+}
+
+hipError_t launch_reconstruct_setup(int dtype, const void* lockin, const double* kmat, int P, int n0, int n1,
+                                    int border, void* wnorm, void* r0, void* r1, double* part0, double* part1,
+                                    int* nparts, hipStream_t s) {
+  if (P > MAXP || P < 2) return hipErrorInvalidValue;
+  return dtype == 0 ? launch_reconstruct_setup_t<float>(lockin, kmat, P, n0, n1, border, wnorm, r0, r1, part0, part1, nparts, s)
+                    : launch_reconstruct_setup_t<double>(lockin, kmat, P, n0, n1, border, wnorm, r0, r1, part0, part1, nparts, s);
+}
+
 // per-pixel weighted least squares on given right-hand sides b (P x n0 x n1), the weighted
 // branch of reconstruct_u_inv (geometric_phase_analysis.py:188 -> myweighed_lstsq :97-113)
 template <class T>

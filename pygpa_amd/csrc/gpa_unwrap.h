@@ -43,6 +43,13 @@ hipError_t per_combine(int dtype, const void* Uhat, const void* D0, const void* 
 // enqueue everything without synchronising, then fetch the iteration count (synchronises s)
 hipError_t unwrap_enqueue(UnwrapWorkspace* ws, const void* a, const void* b, const void* weight, bool from_psi,
                           int kmax, double eps, bool axes_compat, void* phi, hipStream_t s);
+// prepared start: the caller has written r0 = div(W^2 wrap(grad)) into unwrap_residual_buffer() and
+// nparts partial sums of ||r0||^2 into unwrap_partials_buffer() (reconstruct_setup_kernel does, fused with
+// the per-pixel least squares that produces the gradients); weight as in unwrap_enqueue
+void* unwrap_residual_buffer(UnwrapWorkspace* ws);
+double* unwrap_partials_buffer(UnwrapWorkspace* ws);
+hipError_t unwrap_enqueue_prepared(UnwrapWorkspace* ws, const void* weight, int nparts, int kmax, double eps,
+                                   bool axes_compat, void* phi, hipStream_t s);
 hipError_t unwrap_finish(UnwrapWorkspace* ws, int* iters_out, hipStream_t s);
 // asynchronous copy of the iteration count into (pinned) host memory, no synchronisation
 hipError_t unwrap_fetch_iters(UnwrapWorkspace* ws, int* host_pinned, hipStream_t s);

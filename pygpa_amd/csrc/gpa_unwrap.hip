@@ -33,6 +33,7 @@ struct Impl {
   bool supported;
   size_t rsz;
   void *r, *p, *p2, *q, *z;   // p / p2: double-buffered search direction (= ring[0], ring[1])
+  int prepared_parts;        // number of partial norms of a prepared r0 (unwrap_enqueue_prepared)
   void* ring[10];            // search directions of the last RING iterations (fused path), grown on demand
   int nring;
   void *tw0, *tw1;           // FFT twiddles per axis
@@ -588,11 +589,14 @@ __global__ __launch_bounds__(256) void final_update_kernel(const T* __restrict__
 template <class T> struct RingPtrs { const T* p[RING_MAX]; };
 template <class T>
 __global__ __launch_bounds__(256) void phi_flush_kernel(RingPtrs<T> ringp, int ring, T* __restrict__ phi, size_t count4,
-                                                       const double* __restrict__ scal, const int* __restrict__ flags) {
+                                                       const double* __restrict__ scal, const int* __restrict__ flags,
+                                                       int init) {
+  // init: phi has not been written yet (prepared start) -- this flush starts from 0 instead of reading it
   const int a = flags[2], b = flags[0];
-  if (a >= b) return;
+  if (a >= b && !init) return;
   for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < count4; i += (size_t)gridDim.x * 256) {
-    Vec4<T> f = reinterpret_cast<const Vec4<T>*>(phi)[i];
+    Vec4<T> f = {T(0), T(0), T(0), T(0)};
+    if (!init) f = reinterpret_cast<const Vec4<T>*>(phi)[i];
     for (int j = a; j < b; ++j) {
       const T alpha = (T)scal[SC_ALPHA + j % ring];
       const Vec4<T> pv = reinterpret_cast<const Vec4<T>*>(ringp.p[j % ring])[i];
@@ -1455,9 +1459,18 @@ static hipError_t run_pcg(Impl* w, const void* a, const void* b, const void* wei
   const dim3 gsu((n1 + 255) / 256, (n0 + SETUP_ROWS - 1) / SETUP_ROWS);
   const int nsu = gsu.x * gsu.y;
   if (nsu > MAXPART) return hipErrorInvalidValue;
-  setup_kernel<T><<<gsu, 256, 0, s>>>((const T*)a, (const T*)b, (const T*)weight, from_psi ? 1 : 0, n0, n1, (T*)w->r,
-                                      (T*)phi, w->part);
-  scal_init_kernel<<<1, 256, 0, s>>>(w->part, nsu, w->scal, w->flags);
+  if (a) {
+    setup_kernel<T><<<gsu, 256, 0, s>>>((const T*)a, (const T*)b, (const T*)weight, from_psi ? 1 : 0, n0, n1, (T*)w->r,
+                                        (T*)phi, w->part);
+    scal_init_kernel<<<1, 256, 0, s>>>(w->part, nsu, w->scal, w->flags);
+  } else {
+    // prepared: r0 and its w->prepared_parts partial norms were written by the producer of the gradients
+    // (reconstruct_setup_kernel).  phi = 0: the fused path's first phi_flush_kernel starts from 0, the
+    // other paths update phi in place and need it cleared
+    const bool fused_path = !w->generic && (n1 % 4) == 0;
+    if (!fused_path && (e = hipMemsetAsync(phi, 0, npx * w->rsz, s)) != hipSuccess) return e;
+    scal_init_kernel<<<1, 256, 0, s>>>(w->part, w->prepared_parts, w->scal, w->flags);
+  }
   const bool vec4 = !w->generic && (n1 % 4) == 0;   // pq_kernel needs 16-byte aligned rows
   if (vec4) {
     // fused power-of-two path: 4 kernels per iteration, no scalar kernels.  The phi / r update
@@ -1478,9 +1491,11 @@ static hipError_t run_pcg(Impl* w, const void* a, const void* b, const void* wei
     if (w->nring < ring) ring = w->nring;   // out of memory: flush more often
     RingPtrs<T> rp;
     for (int j = 0; j < RING_MAX; ++j) rp.p[j] = (const T*)w->ring[j < ring ? j : 0];
+    bool phi_unwritten = a == nullptr;   // prepared start: nobody has zeroed phi
     auto flush = [&]() {
-      phi_flush_kernel<T><<<gl, 256, 0, s>>>(rp, ring, (T*)phi, npx / 4, w->scal, w->flags);
+      phi_flush_kernel<T><<<gl, 256, 0, s>>>(rp, ring, (T*)phi, npx / 4, w->scal, w->flags, phi_unwritten ? 1 : 0);
       phi_commit_kernel<<<1, 1, 0, s>>>(w->flags);
+      phi_unwritten = false;
     };
     int nnorm = 0;
     for (int it = 0; it < kmax; ++it) {
@@ -1538,6 +1553,19 @@ hipError_t unwrap_enqueue(UnwrapWorkspace* ws, const void* a, const void* b, con
   if (!w || !w->supported) return hipErrorNotSupported;
   return w->dtype == 0 ? run_pcg<float>(w, a, b, weight, from_psi, kmax, eps, axes_compat ? 1 : 0, phi, s)
                        : run_pcg<double>(w, a, b, weight, from_psi, kmax, eps, axes_compat ? 1 : 0, phi, s);
+}
+
+void* unwrap_residual_buffer(UnwrapWorkspace* ws) { return ws->impl ? ((Impl*)ws->impl)->r : nullptr; }
+double* unwrap_partials_buffer(UnwrapWorkspace* ws) { return ws->impl ? ((Impl*)ws->impl)->part : nullptr; }
+
+hipError_t unwrap_enqueue_prepared(UnwrapWorkspace* ws, const void* weight, int nparts, int kmax, double eps,
+                                   bool axes_compat, void* phi, hipStream_t s) {
+  Impl* w = (Impl*)ws->impl;
+  if (!w || !w->supported) return hipErrorNotSupported;
+  if (nparts < 1 || nparts > MAXPART) return hipErrorInvalidValue;
+  w->prepared_parts = nparts;
+  return w->dtype == 0 ? run_pcg<float>(w, nullptr, nullptr, weight, false, kmax, eps, axes_compat ? 1 : 0, phi, s)
+                       : run_pcg<double>(w, nullptr, nullptr, weight, false, kmax, eps, axes_compat ? 1 : 0, phi, s);
 }
 
 hipError_t unwrap_finish(UnwrapWorkspace* ws, int* iters_out, hipStream_t s) {
