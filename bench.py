@@ -48,29 +48,30 @@ def algorithmic_bytes(n0, n1, P, K, s, iters):
     return {'passA': a, 'passB': b, 'reconstruct': rec, 'unwrap': unw, 'total': a + b + rec + unw}
 
 
-def cpu_baseline(kvecs, sigma, knx, kny, kmax, sample=1024):
-    """Time the CPU oracle (NumPy/SciPy port of the reference path) on a bounded
-    sample of the same workload: a sample x sample image, same P x K, same kmax."""
+def cpu_baseline(kvecs, sigma, knx, kny, kmax):
+    """Time the CPU oracle (NumPy/SciPy port of the reference path) on bounded samples of the same
+    workload (same P x K, same kmax), about 15-25 s of host work in total."""
     from oracle import gpa_oracle as orc
     from pygpa_amd.synthetic import gaussian_bump_displacement, hex_moire, explicit_klists
     cores = os.cpu_count() or 1
-    shape = (sample, sample)
-    img = hex_moire(shape, kvecs, gaussian_bump_displacement(shape), noise=0.1, seed=7)
     kw = np.linalg.norm(kvecs, axis=1).mean() / 2.5
     klists = explicit_klists(kvecs, kw, knx, kny)
     # (i) reference-faithful threading: pyGPA runs single-threaded pocketfft and a serial per-pixel
-    # solve; (ii) best effort: scipy.fft on every host core.  The faster one is the baseline.
-    runs = {}
-    for w in sorted({1, cores}):
+    # solve (1024^2 sample); (ii) best effort: scipy.fft on every host core (2048^2 sample).
+    # The faster rate is the baseline.
+    runs = []
+    for w, sample in ((1, 1024), (cores, 2048)) if cores > 1 else ((1, 1024),):
+        shape = (sample, sample)
+        img = hex_moire(shape, kvecs, gaussian_bump_displacement(shape), noise=0.1, seed=7)
         t = time.perf_counter()
         orc.extract_displacement_field(img, kvecs, sigma=sigma, klists=klists, workers=w)
-        runs[w] = time.perf_counter() - t
-    best = min(runs, key=runs.get)
-    dt = runs[best]
-    return {'value': round(sample * sample / dt / 1e6, 4), 'unit': 'Mpixels/s', 'cores': best, 'kind': 'port',
-            'sample': '%dx%d image, 3 peaks x %d k-vectors + weighted unwrap kmax=%d, oracle/gpa_oracle.py; '
-                      % (sample, sample, knx * kny, kmax) +
-                      ', '.join('scipy.fft workers=%d: %.1f s' % (w, runs[w]) for w in sorted(runs)) +
+        dt = time.perf_counter() - t
+        runs.append((sample * sample / dt / 1e6, w, sample, dt))
+    rate, w, sample, dt = max(runs)
+    return {'value': round(rate, 4), 'unit': 'Mpixels/s', 'cores': w, 'kind': 'port',
+            'sample': '%dx%d image, 3 peaks x %d k-vectors + weighted unwrap kmax=%d, oracle/gpa_oracle.py, scipy.fft '
+                      'workers=%d: %.1f s; all runs: ' % (sample, sample, knx * kny, kmax, w, dt) +
+                      ', '.join('%d^2 workers=%d %.1f s = %.3f Mpix/s' % (r[2], r[1], r[3], r[0]) for r in runs) +
                       ' (host has %d cores)' % cores}
 
 
