@@ -291,7 +291,9 @@ struct alignas(4 * sizeof(T)) Vec4 { T v[4]; };
 
 constexpr int PQ_ROWS = 16;   // rows per workgroup band of pq_kernel (large images; fewer for small ones)
 
-template <class T>
+// PGIVEN: `z` already holds the search direction p (written by rowidct_p_kernel): no combination with
+// pin, no copy to pout, no beta
+template <class T, bool PGIVEN = false>
 __global__ __launch_bounds__(256) void pq_kernel(const T* __restrict__ z, const T* __restrict__ pin,
                                                 T* __restrict__ pout, const T* __restrict__ w, int n0, int n1,
                                                 T* __restrict__ q, double* part, double* scal,
@@ -301,8 +303,11 @@ __global__ __launch_bounds__(256) void pq_kernel(const T* __restrict__ z, const 
   __shared__ double sh[256];
   bool first;
   T beta;
-  if (it >= 0) {
-    // fused path: rho = <r, z> from rowidct's partial sums, beta = rho / rho_previous
+  if constexpr (PGIVEN) {
+    first = true;
+    beta = T(0);
+  } else if (it >= 0) {
+    // rho = <r, z> from the producer's partial sums, beta = rho / rho_previous
     const double rho = reduce_partials(part_rho, nrho, sh);
     first = it == 0;                                 // first iteration: p = z (pin is uninitialised)
     beta = first ? T(0) : (T)(rho / scal[8 + ((it - 1) & 1)]);
@@ -355,12 +360,12 @@ __global__ __launch_bounds__(256) void pq_kernel(const T* __restrict__ z, const 
       T pl = __shfl_up(pc.v[3], 1), pr = __shfl_down(pc.v[0], 1);
       T wl = __shfl_up(wc.v[3], 1), wr = __shfl_down(wc.v[0], 1);
       if (lane == 0 && hasl) {
-        pl = comb(z[o - 1], pin[o - 1]);
+        if constexpr (PGIVEN) pl = z[o - 1]; else pl = comb(z[o - 1], pin[o - 1]);
         wl = T(1);
         if (w) { wl = w[o - 1]; wl *= wl; }
       }
       if (lane == 63 && hasr) {
-        pr = comb(z[o + 4], pin[o + 4]);
+        if constexpr (PGIVEN) pr = z[o + 4]; else pr = comb(z[o + 4], pin[o + 4]);
         wr = T(1);
         if (w) { wr = w[o + 4]; wr *= wr; }
       }
@@ -379,7 +384,7 @@ __global__ __launch_bounds__(256) void pq_kernel(const T* __restrict__ z, const 
         qv.v[j] = acc;
         pq += (double)c * (double)acc;
       }
-      *reinterpret_cast<Vec4<T>*>(pout + o) = pc;
+      if constexpr (!PGIVEN) *reinterpret_cast<Vec4<T>*>(pout + o) = pc;
       *reinterpret_cast<Vec4<T>*>(q + o) = qv;
       pu = pc; wu = wc;
       pc = pd; wc = wd;
@@ -759,6 +764,60 @@ __global__ __launch_bounds__((RowGeom<T, LG>::THREADS)) void rowidct_kernel(T* _
   if constexpr (RHO) {   // (the fused path takes rho from the column kernel's spectra instead)
     const double tot = block_sum(dot, sh);
     if (threadIdx.x == 0) part[blockIdx.x] = tot;
+  }
+}
+
+// fused path: rows Z -> z = DCT-III along axis 1, and straight on to the new search direction
+// p = z + beta p_prev (phase_unwrap.py:336-340) -- z itself never goes to HBM.  beta = rho / rho_prev with
+// rho from the column kernel's Parseval partial sums.
+template <class T, int LG>
+__global__ __launch_bounds__((RowGeom<T, LG>::THREADS)) void rowidct_p_kernel(
+    const T* __restrict__ Z, const T* __restrict__ pin, T* __restrict__ pout, int n0,
+    const cpx<T>* __restrict__ twtab, const cpx<T>* __restrict__ wk, const int* flags, const double* part_rho,
+    int nrho, double* scal, int it) {
+  if (flags[1]) return;
+  using F = WgFFT<T, LG>;
+  using D = WgDCT<T, LG>;
+  using G = RowGeom<T, LG>;
+  constexpr int TPF = F::TPF, N = F::L;
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  __shared__ double sh[RowGeom<T, LG>::THREADS];
+  const int tid = threadIdx.x % TPF, f = threadIdx.x / TPF;
+  cpx<T>* lds = reinterpret_cast<cpx<T>*>(smem) + f * G::RS;
+  const int pr = blockIdx.x * G::NF + f;
+  const bool valid = 2 * pr + 1 < n0;
+  const size_t oa = (size_t)(valid ? 2 * pr : 0) * N, ob = oa + N;
+  typename F::Twiddles tw;
+  F::load_twiddles(tw, twtab, tid);
+  cpx<T> x[16], xm[16];
+#pragma unroll
+  for (int i = 0; i < 16; ++i) {
+    const int k = tid + TPF * i;
+    x[i] = {Z[oa + k], Z[ob + k]};
+    xm[i] = k == 0 ? cpx<T>{T(0), T(0)} : cpx<T>{Z[oa + N - k], Z[ob + N - k]};
+  }
+  // (after the loads have been issued so its latency hides behind them)
+  const double rho = reduce_partials(part_rho, nrho, sh);
+  const bool first = it == 0;                        // first iteration: p = z (pin is uninitialised)
+  const T beta = first ? T(0) : (T)(rho / scal[8 + ((it - 1) & 1)]);
+  if (blockIdx.x == 0 && threadIdx.x == 0) scal[8 + (it & 1)] = rho;
+  D::inv_prepare(x, xm, tid, wk);
+  F::forward(x, lds, tid, tw);
+  __syncthreads();
+  D::inv_scatter(x, lds, tid, T(1) / T(N));
+  __syncthreads();
+  D::inv_gather(x, lds, tid);
+  if (!valid) return;
+#pragma unroll
+  for (int i = 0; i < 16; ++i) {
+    const int c = tid + TPF * i;
+    T pa = x[i].x, pb = x[i].y;
+    if (!first) {
+      pa += beta * pin[oa + c];
+      pb += beta * pin[ob + c];
+    }
+    pout[oa + c] = pa;
+    pout[ob + c] = pb;
   }
 }
 
@@ -1143,6 +1202,30 @@ hipError_t dispatch_rowdct(const Impl* w, hipStream_t s) {
 #undef CASE
   return hipErrorInvalidValue;
 }
+template <class T, int LG>
+hipError_t run_rowidct_p(const Impl* w, const void* pin, void* pout, const double* part_rho, int nrho, int it,
+                         hipStream_t s) {
+  using G = RowGeom<T, LG>;
+  if constexpr (!G::FITS) return hipErrorInvalidValue;
+  else {
+    auto kern = rowidct_p_kernel<T, LG>;
+    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize,
+                                       (int)G::LDS_BYTES);
+    if (e != hipSuccess) return e;
+    const int npairs = w->n0 / 2, grid = (npairs + G::NF - 1) / G::NF;
+    kern<<<grid, G::THREADS, G::LDS_BYTES, s>>>((const T*)w->z, (const T*)pin, (T*)pout, w->n0, (const cpx<T>*)w->tw1,
+                                                 (const cpx<T>*)w->wk1, w->flags, part_rho, nrho, w->scal, it);
+    return hipGetLastError();
+  }
+}
+hipError_t dispatch_rowidct_p(const Impl* w, const void* pin, void* pout, const double* part_rho, int nrho, int it,
+                              hipStream_t s) {
+#define CASE(LG) case LG: return w->dtype == 0 ? run_rowidct_p<float, LG>(w, pin, pout, part_rho, nrho, it, s) \
+                                               : run_rowidct_p<double, LG>(w, pin, pout, part_rho, nrho, it, s);
+  switch (w->lg1) { GPA_FOR_LG(CASE) }
+#undef CASE
+  return hipErrorInvalidValue;
+}
 hipError_t dispatch_rowidct(const Impl* w, int* nparts, hipStream_t s) {
 #define CASE(LG) case LG: return w->dtype == 0 ? run_rowidct<float, LG>(w, nparts, s) : run_rowidct<double, LG>(w, nparts, s);
   switch (w->lg1) { GPA_FOR_LG(CASE) }
@@ -1502,12 +1585,12 @@ static hipError_t run_pcg(Impl* w, const void* a, const void* b, const void* wei
       if ((e = dispatch_rowdct_fused(w, w->q, ring, part_pq, npq, part_norm, it, &nnorm, s)) != hipSuccess) return e;
       int nrow = 0;   // partial sums of rho = <r, z>: one per column workgroup (Parseval, solve_combine)
       if ((e = dispatch_colsolve(w, compat, s, part_norm, nnorm, it, eps, part_rho, &nrow)) != hipSuccess) return e;
-      if ((e = dispatch_rowidct_norho(w, s)) != hipSuccess) return e;
       if (it > 0 && it % ring == 0) flush();   // slot it % ring still holds p of iteration it - ring
       const T* pin = (const T*)w->ring[(it + ring - 1) % ring];
       T* pout = (T*)w->ring[it % ring];
-      pq_kernel<T><<<gpq, 256, 0, s>>>((const T*)w->z, pin, pout, (const T*)weight, n0, n1, (T*)w->q, part_pq, w->scal,
-                                       w->flags, part_rho, nrow, it, band);
+      if ((e = dispatch_rowidct_p(w, pin, pout, part_rho, nrow, it, s)) != hipSuccess) return e;
+      pq_kernel<T, true><<<gpq, 256, 0, s>>>(pout, nullptr, nullptr, (const T*)weight, n0, n1, (T*)w->q, part_pq,
+                                             w->scal, w->flags, nullptr, 0, it, band);
     }
     final_update_kernel<T><<<gl, 256, 0, s>>>((const T*)w->q, (T*)w->r, npx, w->scal, part_pq, npq, kmax, ring, w->flags);
     final_count_kernel<<<1, 1, 0, s>>>(w->flags, kmax);
