@@ -770,8 +770,13 @@ __global__ __launch_bounds__((RowGeom<T, LG>::THREADS)) void rowidct_kernel(T* _
 // fused path: rows Z -> z = DCT-III along axis 1, and straight on to the new search direction
 // p = z + beta p_prev (phase_unwrap.py:336-340) -- z itself never goes to HBM.  beta = rho / rho_prev with
 // rho from the column kernel's Parseval partial sums.
+// f32, 4096-point rows: 4 waves per SIMD (<= 128 VGPRs; the unconstrained allocation takes 130 and runs at 3):
+// 49 -> 43 us.  Other lengths would spill under that cap (2048: 13 -> 16 us) and keep the default.
 template <class T, int LG>
-__global__ __launch_bounds__((RowGeom<T, LG>::THREADS)) void rowidct_p_kernel(
+#ifndef GPA_IDCTP_COND
+#define GPA_IDCTP_COND (sizeof(T) == 4 && LG == 12)
+#endif
+__global__ __launch_bounds__((RowGeom<T, LG>::THREADS), (GPA_IDCTP_COND ? 4 : 1)) void rowidct_p_kernel(
     const T* __restrict__ Z, const T* __restrict__ pin, T* __restrict__ pout, int n0,
     const cpx<T>* __restrict__ twtab, const cpx<T>* __restrict__ wk, const int* flags, const double* part_rho,
     int nrho, double* scal, int it) {

@@ -1,8 +1,7 @@
 #!/bin/bash
-# usage (GPU box): tools/ab.sh [bench args --] name1 name2 ...   ("base" = the shipped library)
+# usage (GPU box): [BENCH_ARGS=...] tools/ab.sh name1 name2 ...   ("base" = the shipped library)
 # prints Mpix/s + stage_ms of bench.py for each variant built by tools/variant.sh, and serial-unwrap kernel averages
-args=""
-if [[ "$*" == *" -- "* ]]; then args="${*%% -- *}"; set -- ${*##* -- }; fi
+args="$BENCH_ARGS"   # e.g. BENCH_ARGS="--size 2048 --kgrid 4x2" tools/ab.sh base
 for v in "$@"; do
   lib=""; [ "$v" != base ] && lib=$GRAFT_REPO_ROOT/pygpa_amd/variants/libgpa_$v.so
   echo "== $v"
