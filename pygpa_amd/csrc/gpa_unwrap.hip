@@ -499,11 +499,19 @@ __global__ __launch_bounds__((RowGeom<T, LG>::THREADS)) void rowdct_kernel(const
 // fused path: apply the pending update of the previous iteration (alpha from the pq
 // kernel's partial sums), then DCT-II along axis 1 of the new residual
 //   r -= alpha q;  phi += alpha p;  partial ||r||^2;  Z = DCT(r)
+#ifndef GPA_DCTF_WAVES
+#define GPA_DCTF_WAVES 1
+#endif
 template <class T, int LG>
-__global__ __launch_bounds__((RowGeom<T, LG>::THREADS)) void rowdct_fused_kernel(
-    T* __restrict__ r, const T* __restrict__ q, int n0, T* __restrict__ Z, const cpx<T>* __restrict__ twtab,
+__global__ __launch_bounds__((RowGeom<T, LG>::THREADS), GPA_DCTF_WAVES) void rowdct_fused_kernel(
+    T* __restrict__ r, const T* __restrict__ q, int n0, const cpx<T>* __restrict__ twtab,
     const cpx<T>* __restrict__ wk, const int* flags, const double* part_pq, int npq, double* part_norm,
     double* scal, int it, int ring) {
+  // The fused iteration keeps the residual as its row spectrum R = DCT-II_rows(r) (the only consumers of r
+  // are this transform, ||r|| and <r,z>, and the last two follow from the spectra by Parseval):
+  //   it == 0: r (spatial, from the set-up) -> R, in place;
+  //   it  > 0: R -= alpha DCT-II_rows(q)    (linearity; phase_unwrap.py:345), partial ||r||^2 from R.
+  // So the update reads q and R and writes R: three arrays instead of r, q in and r, Z out.
   if (flags[1]) return;
   using F = WgFFT<T, LG>;
   using D = WgDCT<T, LG>;
@@ -519,35 +527,22 @@ __global__ __launch_bounds__((RowGeom<T, LG>::THREADS)) void rowdct_fused_kernel
   typename F::Twiddles tw;
   F::load_twiddles(tw, twtab, tid);
   cpx<T> x[16];
+  T alpha = T(0);
   if (it > 0) {
     const double pq = reduce_partials(part_pq, npq, sh);
     const double alpha_d = scal[8 + ((it - 1) & 1)] / pq;   // phase_unwrap.py:343
-    const T alpha = (T)alpha_d;
+    alpha = (T)alpha_d;
     // phi += alpha p is not applied here: alpha is filed for phi_flush_kernel, which adds the kept
     // search directions of up to `ring` iterations in one pass over phi
     if (blockIdx.x == 0 && threadIdx.x == 0) scal[SC_ALPHA + (it - 1) % ring] = alpha_d;
-    // elementwise update with coalesced 16-byte accesses (4 consecutive pixels per thread and
-    // step); the new residual is also parked in LDS so the even/odd-permuted DCT input does
-    // not have to come back from memory with stride-2 accesses
-    double sq = 0;
+    // q comes in with coalesced 16-byte accesses and is parked in LDS, so that the even/odd-permuted
+    // DCT input does not have to be fetched with stride-2 accesses
     for (int c0 = 4 * tid; c0 < N; c0 += 4 * TPF) {
-      Vec4<T> ra = *reinterpret_cast<const Vec4<T>*>(r + oa + c0), rb = *reinterpret_cast<const Vec4<T>*>(r + ob + c0);
       const Vec4<T> qa = *reinterpret_cast<const Vec4<T>*>(q + oa + c0), qb = *reinterpret_cast<const Vec4<T>*>(q + ob + c0);
 #pragma unroll
-      for (int j = 0; j < 4; ++j) {
-        ra.v[j] -= alpha * qa.v[j];
-        rb.v[j] -= alpha * qb.v[j];
-        sq += (double)ra.v[j] * (double)ra.v[j] + (double)rb.v[j] * (double)rb.v[j];
-        lds[F::pad(c0 + j)] = {ra.v[j], rb.v[j]};
-      }
-      if (valid) {
-        *reinterpret_cast<Vec4<T>*>(r + oa + c0) = ra;
-        *reinterpret_cast<Vec4<T>*>(r + ob + c0) = rb;
-      }
+      for (int j = 0; j < 4; ++j) lds[F::pad(c0 + j)] = {qa.v[j], qb.v[j]};
     }
-    if (!valid) sq = 0;
-    const double tot = block_sum(sq, sh);   // (contains the barrier that publishes the LDS staging)
-    if (threadIdx.x == 0) part_norm[blockIdx.x] = tot;
+    __syncthreads();
 #pragma unroll
     for (int i = 0; i < 16; ++i) x[i] = lds[F::pad(makhoul_src(tid + TPF * i, N))];
     __syncthreads();
@@ -557,19 +552,40 @@ __global__ __launch_bounds__((RowGeom<T, LG>::THREADS)) void rowdct_fused_kernel
       const int src = makhoul_src(tid + TPF * i, N);
       x[i] = {r[oa + src], r[ob + src]};
     }
+    __syncthreads();   // in place: every sample of the two rows is in registers before any bin is written
+  }
+  // the kept spectrum is requested before the transform so that its latency hides behind it
+  cpx<T> rk[16];
+  if (it > 0) {
+#pragma unroll
+    for (int i = 0; i < 16; ++i) rk[i] = {r[oa + tid + TPF * i], r[ob + tid + TPF * i]};
   }
   F::forward(x, lds, tid, tw);
   __syncthreads();
   D::fwd_scatter(x, lds, tid);
   __syncthreads();
   D::fwd_gather(x, lds, tid, wk);
-  if (!valid) return;
-  T* za = Z + oa;
-  T* zb = Z + ob;
+  double sq = 0;
 #pragma unroll
   for (int i = 0; i < 16; ++i) {
-    za[tid + TPF * i] = x[i].x;
-    zb[tid + TPF * i] = x[i].y;
+    const int k = tid + TPF * i;
+    T ra = x[i].x, rb = x[i].y;
+    if (it > 0) {
+      ra = rk[i].x - alpha * ra;
+      rb = rk[i].y - alpha * rb;
+      // sum_n r^2 = (1 / 2N) sum_k c_k R_k^2, c_0 = 1/2 (SciPy's unnormalised DCT-II)
+      const double t = (double)ra * (double)ra + (double)rb * (double)rb;
+      sq += k == 0 ? 0.5 * t : t;
+    }
+    if (valid) {
+      r[oa + k] = ra;
+      r[ob + k] = rb;
+    }
+  }
+  if (it > 0) {
+    if (!valid) sq = 0;
+    const double tot = block_sum(sq, sh);
+    if (threadIdx.x == 0) part_norm[blockIdx.x] = tot / (2.0 * N);
   }
 }
 
@@ -582,9 +598,9 @@ __global__ __launch_bounds__(256) void final_update_kernel(const T* __restrict__
   __shared__ double sh[256];
   const double pq = reduce_partials(part_pq, npq, sh);
   const double alpha_d = scal[8 + ((it - 1) & 1)] / pq;
-  const T alpha = (T)alpha_d;
   if (blockIdx.x == 0 && threadIdx.x == 0) scal[SC_ALPHA + (it - 1) % ring] = alpha_d;
-  for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < count; i += (size_t)gridDim.x * 256) r[i] -= alpha * q[i];
+  // (the residual of the last iteration is not formed: nothing reads it)
+  (void)q; (void)r; (void)count;
 }
 
 // phi += sum_j alpha_j p_j over the updates j in [flags[2], flags[0]) that the iteration has completed
@@ -628,11 +644,13 @@ __global__ __launch_bounds__((ColGeom<T, LG>::THREADS)) void colsolve_kernel(T* 
                                                                           const T* __restrict__ hb,
                                                                           int* flags, const double* part_norm,
                                                                           int nnorm, int it, double eps,
-                                                                          double* scal, double* part_rho) {
+                                                                          double* scal, double* part_rho,
+                                                                          const T* __restrict__ Zin) {
   if (flags[1]) return;
   using F = WgFFT<T, LG>;
   using D = WgDCT<T, LG>;
   using G = ColGeom<T, LG>;
+  const T* Zsrc = Zin ? Zin : Z;   // fused path: reads the kept row spectrum of r, writes the solve to Z
   constexpr int TPF = F::TPF, N = F::L, CT = G::CT, NT = G::NT;
   extern __shared__ __attribute__((aligned(16))) char smem[];
   const int c = threadIdx.x % CT, t = threadIdx.x / CT;
@@ -650,7 +668,7 @@ __global__ __launch_bounds__((ColGeom<T, LG>::THREADS)) void colsolve_kernel(T* 
 #pragma unroll
   for (int i = 0; i < 16; ++i) {
     const int row = makhoul_src(t + TPF * i, N);
-    const Vec q = *reinterpret_cast<const Vec*>(Z + (size_t)row * n1 + yy);
+    const Vec q = *reinterpret_cast<const Vec*>(Zsrc + (size_t)row * n1 + yy);
 #pragma unroll
     for (int n = 0; n < NT; ++n) x[n][i] = q.v[n];
   }
@@ -1165,7 +1183,8 @@ hipError_t run_rowidct(const Impl* w, int* nparts, hipStream_t s) {
 }
 template <class T, int LG>
 hipError_t run_colsolve(const Impl* w, int compat, hipStream_t s, const double* part_norm = nullptr, int nnorm = 0,
-                        int it = 0, double eps = 0.0, double* part_rho = nullptr, int* nrho = nullptr) {
+                        int it = 0, double eps = 0.0, double* part_rho = nullptr, int* nrho = nullptr,
+                        const void* zin = nullptr) {
   using G = ColGeom<T, LG>;
   if constexpr (!G::FITS) return hipErrorInvalidValue;
   else {
@@ -1178,7 +1197,7 @@ hipError_t run_colsolve(const Impl* w, int compat, hipStream_t s, const double* 
     kern<<<grid, G::THREADS, G::LDS_BYTES, s>>>((T*)w->z, w->n1, (const cpx<T>*)w->tw0, (const cpx<T>*)w->wk0s,
                                                  (const T*)w->ha0[compat], (const T*)w->ham0[compat],
                                                  (const T*)w->hb1[compat], w->flags, part_norm, nnorm, it, eps, w->scal,
-                                                 part_rho);
+                                                 part_rho, (const T*)zin);
     return hipGetLastError();
   }
 }
@@ -1194,7 +1213,7 @@ hipError_t run_rowdct_fused(const Impl* w, const void* q, int ring, const double
     if (e != hipSuccess) return e;
     const int npairs = w->n0 / 2, grid = (npairs + G::NF - 1) / G::NF;
     *nnorm = grid;
-    kern<<<grid, G::THREADS, G::LDS_BYTES, s>>>((T*)w->r, (const T*)q, w->n0, (T*)w->z, (const cpx<T>*)w->tw1,
+    kern<<<grid, G::THREADS, G::LDS_BYTES, s>>>((T*)w->r, (const T*)q, w->n0, (const cpx<T>*)w->tw1,
                                                  (const cpx<T>*)w->wk1, w->flags, part_pq, npq, part_norm, w->scal, it,
                                                  ring);
     return hipGetLastError();
@@ -1247,9 +1266,9 @@ hipError_t dispatch_rowidct_norho(const Impl* w, hipStream_t s) {
 }
 hipError_t dispatch_colsolve(const Impl* w, int compat, hipStream_t s, const double* part_norm = nullptr,
                              int nnorm = 0, int it = 0, double eps = 0.0, double* part_rho = nullptr,
-                             int* nrho = nullptr) {
-#define CASE(LG) case LG: return w->dtype == 0 ? run_colsolve<float, LG>(w, compat, s, part_norm, nnorm, it, eps, part_rho, nrho) \
-                                               : run_colsolve<double, LG>(w, compat, s, part_norm, nnorm, it, eps, part_rho, nrho);
+                             int* nrho = nullptr, const void* zin = nullptr) {
+#define CASE(LG) case LG: return w->dtype == 0 ? run_colsolve<float, LG>(w, compat, s, part_norm, nnorm, it, eps, part_rho, nrho, zin) \
+                                               : run_colsolve<double, LG>(w, compat, s, part_norm, nnorm, it, eps, part_rho, nrho, zin);
   switch (w->lg0) { GPA_FOR_LG(CASE) }
 #undef CASE
   return hipErrorInvalidValue;
@@ -1589,7 +1608,7 @@ static hipError_t run_pcg(Impl* w, const void* a, const void* b, const void* wei
     for (int it = 0; it < kmax; ++it) {
       if ((e = dispatch_rowdct_fused(w, w->q, ring, part_pq, npq, part_norm, it, &nnorm, s)) != hipSuccess) return e;
       int nrow = 0;   // partial sums of rho = <r, z>: one per column workgroup (Parseval, solve_combine)
-      if ((e = dispatch_colsolve(w, compat, s, part_norm, nnorm, it, eps, part_rho, &nrow)) != hipSuccess) return e;
+      if ((e = dispatch_colsolve(w, compat, s, part_norm, nnorm, it, eps, part_rho, &nrow, w->r)) != hipSuccess) return e;
       if (it > 0 && it % ring == 0) flush();   // slot it % ring still holds p of iteration it - ring
       const T* pin = (const T*)w->ring[(it + ring - 1) % ring];
       T* pout = (T*)w->ring[it % ring];
@@ -1597,7 +1616,7 @@ static hipError_t run_pcg(Impl* w, const void* a, const void* b, const void* wei
       pq_kernel<T, true><<<gpq, 256, 0, s>>>(pout, nullptr, nullptr, (const T*)weight, n0, n1, (T*)w->q, part_pq,
                                              w->scal, w->flags, nullptr, 0, it, band);
     }
-    final_update_kernel<T><<<gl, 256, 0, s>>>((const T*)w->q, (T*)w->r, npx, w->scal, part_pq, npq, kmax, ring, w->flags);
+    final_update_kernel<T><<<1, 256, 0, s>>>((const T*)w->q, (T*)w->r, npx, w->scal, part_pq, npq, kmax, ring, w->flags);
     final_count_kernel<<<1, 1, 0, s>>>(w->flags, kmax);
     flush();
     return hipGetLastError();
