@@ -11,6 +11,17 @@
 // iteration counter and the stop flag) lives on the device: the host enqueues kmax
 // iterations back to back and reads the iteration count once at the end; kernels
 // of iterations after convergence return immediately.
+//
+// Power-of-two images take the fused path (run_pcg): four kernels per iteration and no vector is moved
+// that does not have to be --
+//   rowdct_fused : R -= alpha DCT_rows(q)   the residual is kept as its row spectrum R; ||r||^2 by Parseval
+//   colsolve     : R -> Z                   column DCT-II / eigenvalue divide / DCT-III; stop test;
+//                                           rho = <r,z> by Parseval from the spectra in registers
+//   rowidct_p    : Z -> p = z + beta p_prev row DCT-III straight into the new search direction
+//   pq           : q = A^T W^2 A p          one sliding-window stencil pass, partial <p,q>
+// and phi += alpha p is applied for up to 10 iterations at once by phi_flush_kernel from the kept search
+// directions.  11 array passes per iteration (+ 1.2 for the flush) instead of the 19 of the plain scheme.
+// Other sizes (Bluestein DCTs) and rows that are not a multiple of 4 pixels take the plain scheme below it.
 #include <math.h>
 #include <string.h>
 
@@ -95,7 +106,7 @@ __device__ __forceinline__ double reduce_partials(const double* __restrict__ par
 // Scalars of the fused power-of-two path (single writer = block 0 of the named kernel;
 // values a kernel both reads and replaces are double-buffered by iteration parity):
 //   scal[5] = ||r0||^2                    (scal_init_kernel)
-//   scal[8 + (it & 1)]  = rho of iteration it            (pq_kernel)
+//   scal[8 + (it & 1)]  = rho of iteration it            (rowidct_p_kernel)
 //   scal[10 + (it & 1)] = smallest ||r||^2 up to it      (colsolve_kernel)
 //   scal[16 + (j % ring)] = alpha of iteration j         (rowdct_fused_kernel / final_update_kernel)
 //   flags[0] = completed updates k, flags[1] = done      (colsolve_kernel / final kernel)
@@ -1252,14 +1263,6 @@ hipError_t dispatch_rowidct_p(const Impl* w, const void* pin, void* pout, const 
 }
 hipError_t dispatch_rowidct(const Impl* w, int* nparts, hipStream_t s) {
 #define CASE(LG) case LG: return w->dtype == 0 ? run_rowidct<float, LG>(w, nparts, s) : run_rowidct<double, LG>(w, nparts, s);
-  switch (w->lg1) { GPA_FOR_LG(CASE) }
-#undef CASE
-  return hipErrorInvalidValue;
-}
-// fused path: z only, rho comes from the column kernel
-hipError_t dispatch_rowidct_norho(const Impl* w, hipStream_t s) {
-  int unused = 0;
-#define CASE(LG) case LG: return w->dtype == 0 ? run_rowidct<float, LG, false>(w, &unused, s) : run_rowidct<double, LG, false>(w, &unused, s);
   switch (w->lg1) { GPA_FOR_LG(CASE) }
 #undef CASE
   return hipErrorInvalidValue;
