@@ -638,3 +638,26 @@ def test_config3_4096_f32_vs_f64():
     assert np.abs(l32 - l64)[same].max() < 2e-5 * np.abs(l64).max()
     # the fp32 PCG stops at its residual floor (8-9 of 10 iterations): tolerance relative to |u| ~ 200 px
     assert rel(u32, u64) < 2e-3
+
+
+@pytest.mark.gpu
+def test_pinned_host_arrays():
+    """page-locked NumPy arrays (pinned_empty) as input and as out=: same numbers as pageable ones"""
+    import gc
+    import pygpa_amd
+    kvecs = hex_kvecs(0.1, 7.0)
+    img = hex_moire((128, 256), kvecs, gaussian_bump_displacement((128, 256)), noise=0.1, seed=3, dtype=np.float32)
+    klists = np.stack(explicit_klists(kvecs, 0.04, 2, 2))
+    plan = _lib.get_plan((128, 256), 12, np.float32)
+    u = plan.extract_displacement_field(img, kvecs, klists, 10, 20, 10)[0]
+    pimg = pygpa_amd.pinned_empty(img.shape, np.float32)
+    pimg[...] = img
+    pu = pygpa_amd.pinned_empty(u.shape, np.float32)
+    got = plan.extract_displacement_field(pimg, kvecs, klists, 10, 20, 10, out=pu)[0]
+    assert got is pu and np.array_equal(pu, u)
+    with pytest.raises(ValueError):
+        plan.extract_displacement_field(pimg, kvecs, klists, 10, 20, 10, out=pu[:, :, ::2])
+    view = pu[1, 5:9]
+    del pu, got, pimg
+    gc.collect()
+    assert np.isfinite(view).all()      # a view keeps the pinned allocation alive
