@@ -108,7 +108,7 @@ __device__ __forceinline__ double reduce_partials(const double* __restrict__ par
 //   scal[5] = ||r0||^2                    (scal_init_kernel)
 //   scal[8 + (it & 1)]  = rho of iteration it            (rowidct_p_kernel)
 //   scal[10 + (it & 1)] = smallest ||r||^2 up to it      (colsolve_kernel)
-//   scal[16 + (j % ring)] = alpha of iteration j         (rowdct_fused_kernel / final_update_kernel)
+//   scal[16 + (j % ring)] = alpha of iteration j         (rowdct_fused_kernel / final_alpha_kernel)
 //   flags[0] = completed updates k, flags[1] = done      (colsolve_kernel / final kernel)
 //   flags[2] = updates already applied to phi            (phi_commit_kernel)
 
@@ -600,18 +600,14 @@ __global__ __launch_bounds__((RowGeom<T, LG>::THREADS), GPA_DCTF_WAVES) void row
   }
 }
 
-// fused path, after the last iteration: the update that no further row kernel will apply
-template <class T>
-__global__ __launch_bounds__(256) void final_update_kernel(const T* __restrict__ q, T* __restrict__ r, size_t count,
-                                                          double* scal, const double* part_pq, int npq, int it,
-                                                          int ring, const int* flags) {
+// fused path, after the last iteration: alpha of that iteration for phi_flush_kernel (no further row
+// kernel will compute it; the residual of the last iteration is not formed, nothing reads it)
+__global__ __launch_bounds__(256) void final_alpha_kernel(double* scal, const double* part_pq, int npq, int it, int ring,
+                                                         const int* flags) {
   if (flags[1]) return;
   __shared__ double sh[256];
   const double pq = reduce_partials(part_pq, npq, sh);
-  const double alpha_d = scal[8 + ((it - 1) & 1)] / pq;
-  if (blockIdx.x == 0 && threadIdx.x == 0) scal[SC_ALPHA + (it - 1) % ring] = alpha_d;
-  // (the residual of the last iteration is not formed: nothing reads it)
-  (void)q; (void)r; (void)count;
+  if (threadIdx.x == 0) scal[SC_ALPHA + (it - 1) % ring] = scal[8 + ((it - 1) & 1)] / pq;
 }
 
 // phi += sum_j alpha_j p_j over the updates j in [flags[2], flags[0]) that the iteration has completed
@@ -1619,7 +1615,7 @@ static hipError_t run_pcg(Impl* w, const void* a, const void* b, const void* wei
       pq_kernel<T, true><<<gpq, 256, 0, s>>>(pout, nullptr, nullptr, (const T*)weight, n0, n1, (T*)w->q, part_pq,
                                              w->scal, w->flags, nullptr, 0, it, band);
     }
-    final_update_kernel<T><<<1, 256, 0, s>>>((const T*)w->q, (T*)w->r, npx, w->scal, part_pq, npq, kmax, ring, w->flags);
+    final_alpha_kernel<<<1, 256, 0, s>>>(w->scal, part_pq, npq, kmax, ring, w->flags);
     final_count_kernel<<<1, 1, 0, s>>>(w->flags, kmax);
     flush();
     return hipGetLastError();
