@@ -1548,6 +1548,11 @@ static hipError_t run_pcg(Impl* w, const void* a, const void* b, const void* wei
                           double eps, int compat, void* phi, hipStream_t s) {
   const int n0 = w->n0, n1 = w->n1;
   const size_t npx = (size_t)n0 * n1;
+  // The reference's preconditioner table uses cos(pi I / M) + cos(pi J / N) with the axis lengths swapped
+  // (phase_unwrap.py:107-109); `compat` reproduces that.  Once one side is at least twice the other that
+  // table has a zero away from the DC bin (I = 2M) and the reference itself returns NaN: there is nothing
+  // to reproduce, and the true Laplacian eigenvalues are used instead.
+  if (compat && (n0 >= 2 * n1 || n1 >= 2 * n0)) compat = 0;
   const int g2 = n0, np2 = n0;   // stencil kernels: one workgroup per image row
   if (np2 > MAXPART) return hipErrorInvalidValue;
   // band height of the stencil kernel: 16 rows for large images, fewer when that would leave

@@ -661,3 +661,66 @@ def test_pinned_host_arrays():
     del pu, got, pimg
     gc.collect()
     assert np.isfinite(view).all()      # a view keeps the pinned allocation alive
+
+
+# ---- randomized shapes / parameters ----------------------------------------------------------------
+def _random_cases(seed, count):
+    rng = np.random.default_rng(seed)
+    sizes = [64, 96, 100, 128, 130, 200, 256, 257, 320]
+    done = 0
+    while done < count:
+        n0, n1 = (int(v) for v in rng.choice(sizes, 2))
+        # the reference's swapped-axis eigenvalue table (phase_unwrap.py:107-109) has a zero away from DC
+        # once one side is at least twice the other (cos(pi I / M) = 1 at I = 2M): its own output is NaN there
+        if max(n0, n1) >= 2 * min(n0, n1):
+            continue
+        done += 1
+        r_k = float(rng.uniform(0.07, 0.2))
+        xi = float(rng.uniform(0.0, 60.0))
+        nx, ny = int(rng.integers(1, 4)), int(rng.integers(1, 4))
+        sigma = int(rng.integers(3, 10))   # (the reference slices its mask with 2*sigma: integers only)
+        yield (n0, n1), r_k, xi, nx, ny, sigma, int(rng.integers(0, 2 ** 31))
+
+
+@pytest.mark.gpu
+def test_random_shapes_driver_vs_oracle():
+    """16 seeded random cases -- power-of-two, even, odd and prime-ish axis lengths mixed freely
+    (padded lock-ins, Bluestein unwraps), random lattice / sigma / candidate grids -- whole fused driver in
+    f64 against the oracle, and the f32 build within its stated tolerance."""
+    for shape, r_k, xi, nx, ny, sigma, seed in _random_cases(2026, 16):
+        kvecs = hex_kvecs(r_k, xi)
+        img = hex_moire(shape, kvecs, 0.4 * gaussian_bump_displacement(shape), noise=0.2, seed=seed % 1000)
+        kw = np.linalg.norm(kvecs, axis=1).mean() / 2.5
+        klists = np.stack(explicit_klists(kvecs, kw, nx, ny))
+        border = 2 * int(sigma)
+        u_ref, parts = orc.extract_displacement_field(img, kvecs, sigma=sigma, klists=klists, return_parts=True)
+        ref_kidx = np.stack([g['kidx'] for g in parts['gs']])
+        tag = (shape, round(r_k, 3), round(xi, 1), nx, ny, sigma)
+        plan = _lib.get_plan(shape, 3 * nx * ny, np.float64)
+        u, _, kidx, iters = plan.extract_displacement_field(img, kvecs, klists, sigma, border, want_kidx=True)
+        for p in range(3):   # bit-exact winners, except where two candidates tie to rounding
+            check_kidx(kidx[p], ref_kidx[p], img - img.mean(), klists[p], sigma, 1e-9)
+        assert rel(u, u_ref) < 1e-7, tag
+        plan32 = _lib.get_plan(shape, 3 * nx * ny, np.float32)
+        u32 = plan32.extract_displacement_field(img, kvecs, klists, sigma, border)[0]
+        assert rel(u32, u_ref) < 5e-3, tag
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize('shape', [(256, 64), (96, 257)])
+def test_unwrap_elongated_images(shape):
+    """aspect ratio >= 2: the reference's swapped-axis preconditioner table has a zero eigenvalue and the
+    reference returns NaN; the device path uses the true eigenvalues (oracle with compat=False)"""
+    rng = np.random.default_rng(4)
+    n0, n1 = shape
+    x, y = np.meshgrid(np.arange(n0), np.arange(n1), indexing='ij')
+    phi_true = 0.21 * x + 0.13 * y + 2.0 * np.sin(x / 17.0) * np.cos(y / 11.0)
+    psi = orc.wrap_to_pi(phi_true + 0.05 * rng.normal(size=shape))
+    weight = 0.5 + rng.random(shape)
+    dx, dy = np.diff(psi, axis=1), np.diff(psi, axis=0)
+    with np.errstate(all='ignore'):
+        assert not np.isfinite(orc.unwrap_prediff(dx, dy, weight, kmax=20, compat=True)).all()
+    ref = orc.unwrap_prediff(dx, dy, weight, kmax=20, compat=False)
+    got, iters = _lib.get_plan(shape, 1, np.float64).unwrap_prediff(dx, dy, weight, kmax=20)
+    assert np.isfinite(got).all()
+    assert rel(got, ref) < 1e-8
