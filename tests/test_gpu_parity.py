@@ -724,3 +724,75 @@ def test_unwrap_elongated_images(shape):
     got, iters = _lib.get_plan(shape, 1, np.float64).unwrap_prediff(dx, dy, weight, kmax=20)
     assert np.isfinite(got).all()
     assert rel(got, ref) < 1e-8
+
+
+@pytest.mark.gpu
+def test_random_shapes_unwrap_and_warp_vs_oracle():
+    """seeded random shapes (2 .. 150 pixels a side, any parity, aspect ratio < 2) through the unwrap
+    family (wrapped phase / pre-differenced, weighted / unweighted) and the Lawler-Fujita resampling,
+    f64 against the oracle"""
+    import pygpa_amd.phase_unwrap as PU
+    import pygpa_amd.geometric_phase_analysis as GPA
+    rng = np.random.default_rng(77)
+    done = 0
+    while done < 14:
+        n0, n1 = (int(v) for v in rng.integers(2, 151, 2))
+        if max(n0, n1) >= 2 * min(n0, n1):
+            continue
+        done += 1
+        shape = (n0, n1)
+        x, y = np.meshgrid(np.arange(n0), np.arange(n1), indexing='ij')
+        phi = rng.uniform(-0.4, 0.4) * x + rng.uniform(-0.4, 0.4) * y + 1.5 * np.sin(x / 9.0 + y / 13.0)
+        psi = orc.wrap_to_pi(phi + 0.03 * rng.normal(size=shape))
+        weight = None if done % 2 else 0.3 + rng.random(shape)
+        kmax = int(rng.integers(3, 25))
+        ref = orc.unwrap(psi, weight=weight, kmax=kmax)
+        got = PU.phase_unwrap(psi, weight=weight, kmax=kmax)
+        assert rel(got, ref) < 1e-8, (shape, kmax)
+        got2 = PU.phase_unwrap_prediff(np.diff(psi, axis=1), np.diff(psi, axis=0), weight=weight, kmax=kmax)
+        assert rel(got2, ref) < 1e-8, (shape, kmax)
+        if min(n0, n1) >= 24:
+            u = np.stack([1.5 * np.sin(x / 19.0) * np.cos(y / 23.0), 1.2 * np.cos(x / 17.0 + y / 29.0)])
+            img = np.cos(0.5 * x) + np.sin(0.37 * y)
+            inv_ref = orc.invert_u_overlap(u, iters=12)
+            inv = GPA.invert_u_overlap(u, iters=12)
+            assert rel(inv, inv_ref) < 1e-9, shape
+            und_ref = orc.undistort_image(img, u)
+            und = GPA.undistort_image(img, u)
+            # mode='constant' jumps to cval where the sampling point leaves [0, n-1]: on the outermost pixel
+            # ring, where u vanishes, that is decided by rounding noise of u_inv -- compare inside it
+            assert rel(und[1:-1, 1:-1], und_ref[1:-1, 1:-1]) < 1e-9, shape
+
+
+@pytest.mark.gpu
+def test_random_shapes_spectral_helpers_vs_oracle():
+    """seeded random shapes through the a9 / f-3 / f-4 entry points (arbitrary-size DFTs, Gaussian
+    smoothing with reflected kernels longer than the image, Wiener deconvolution, Huber plane fit)"""
+    import pygpa_amd.geometric_phase_analysis as GPA
+    from pygpa_amd import mathtools
+    rng = np.random.default_rng(31)
+    for _ in range(8):
+        n0, n1 = (int(v) for v in rng.integers(20, 180, 2))
+        shape = (n0, n1)
+        kvecs = hex_kvecs(float(rng.uniform(0.08, 0.2)), float(rng.uniform(0, 60)))
+        img = hex_moire(shape, kvecs, noise=0.3, seed=int(rng.integers(0, 1000)))
+        plan = _lib.get_plan(shape, 1, np.float64)
+        # a9
+        assert rel(plan.per_dft(img), orc.per(img, inverse_dft=False)[0]) < 1e-10, shape
+        # f-3: smoothed spectrum and candidates
+        sigma = float(rng.uniform(0.6, 3.0))
+        dog = bool(rng.integers(0, 2))
+        coords, vals, smooth = plan.find_peaks(img, sigma, 50.0 if dog else 0.0, 0.1, want_smooth=True)
+        ref = orc.smoothed_spectrum(img, sigma, DoG=dog)
+        assert rel(smooth, ref) < 1e-10, (shape, sigma, dog)
+        assert {tuple(c) for c in coords} == {tuple(c) for c in orc.peak_local_max(ref, 0.1)}, (shape, sigma, dog)
+        # f-4: deconvolution of a smooth field, plane fit of a tilted noisy one
+        dr = int(rng.integers(1, max(2, min(n0, n1) // 5)))
+        x, y = np.meshgrid(np.arange(n0), np.arange(n1), indexing='ij')
+        field = np.sin(x / 11.0) * np.cos(y / 7.0) + 0.01 * rng.normal(size=shape)
+        s2 = float(rng.uniform(1.0, 4.0))
+        assert rel(GPA.gaussian_deconvolve(field, s2, dr=dr, balance=300.0), orc.gaussian_deconvolve(field, s2, dr=dr, balance=300.0)) < 1e-9, (shape, dr)
+        tilted = 0.02 * x - 0.015 * y + 0.3 + 0.2 * rng.normal(size=shape)
+        tilted[: n0 // 4, : n1 // 4] += 5.0
+        got, refp = mathtools.fit_plane(tilted), orc.fit_plane(tilted)
+        assert np.allclose(got[:2], refp[:2], rtol=0, atol=2e-6 * np.abs(refp[:2]).max()) and abs(got[2] - refp[2]) < 2e-5, shape
