@@ -117,7 +117,10 @@ int gpa_weighted_lstsq(gpa_plan* plan, const void* b, const void* weights, const
  *   phi: n0 x n1 output.  Stops after kmax iterations or when
  *   ||r|| < eps ||r0|| (eps = 1e-9 in the reference).  poisson_axes_compat != 0
  *   replicates the reference's swapped-axis eigenvalues (phase_unwrap.py:107-109;
- *   identical for square images).  *iters_out receives the iteration count.   */
+ *   identical for square images; where one side is at least twice the other that
+ *   table is singular and the reference returns NaN -- the true eigenvalues are used
+ *   there).  The f32 build floors eps at 4e-6 (what an f32 recurrence can reach).
+ *   *iters_out receives the iteration count.                                    */
 int gpa_unwrap_prediff(gpa_plan* plan, const void* dx, const void* dy, const void* weight,
                        int kmax, double eps, int poisson_axes_compat, void* phi, int* iters_out);
 int gpa_unwrap_prediff_dev(gpa_plan* plan, const void* dx, const void* dy, const void* weight,
