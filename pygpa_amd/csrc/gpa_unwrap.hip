@@ -23,6 +23,7 @@
 // directions.  11 array passes per iteration (+ 1.2 for the flush) instead of the 19 of the plain scheme.
 // Other sizes (Bluestein DCTs) and rows that are not a multiple of 4 pixels take the plain scheme below it.
 #include <math.h>
+#include <stdlib.h>
 #include <string.h>
 
 #include <vector>
@@ -1564,7 +1565,8 @@ static hipError_t run_pcg(Impl* w, const void* a, const void* b, const void* wei
   if (npq > MAXPART) return hipErrorInvalidValue;
   const int gl = 2048;   // grid-stride elementwise kernels
   // the residual of an f32 iteration cannot fall below a few ulps of ||r0||
-  const double eps_floor = sizeof(T) == 4 ? 4e-6 : 0.0;
+  double eps_floor = sizeof(T) == 4 ? 4e-6 : 0.0;
+  if (const char* ef = getenv("GPA_F32_EPS_FLOOR")) { if (sizeof(T) == 4) eps_floor = atof(ef); }   // diagnostic
   if (eps < eps_floor) eps = eps_floor;
   hipError_t e;
   const dim3 gsu((n1 + 255) / 256, (n0 + SETUP_ROWS - 1) / SETUP_ROWS);
