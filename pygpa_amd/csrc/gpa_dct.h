@@ -73,13 +73,28 @@ struct WgDCT {
                                    const cpx<T>* __restrict__ wspec, const T* __restrict__ ha,
                                    const T* __restrict__ ham, T hb_a, T hb_b, bool first_a,
                                    bool first_b, T inv_n, double* rho = nullptr) {
-    // rho (optional): Parseval sum of <input, output> over this thread's bins.  In SciPy's convention
-    // X[k] = 2 Re(w_k V_k) = 2 ua.x and sum_n x y = (1 / 2N) sum_k c_k X_k Y_k with c_0 = 1/2; the output
-    // coefficient is X / lambda = X * (sa N), so the pair's share is c_k c_j ua.x^2 sa up to the factor
-    // 1 / N_other applied by the caller (c_j = 1/2 where the other-axis bin is 0).  Every bin is visited
-    // once as "k" (its mirror visit, the .y part, is not counted).
-    // per-thread sums in T: E same-signed terms each; the caller reduces across threads in double
-    T ra = T(0), rb = T(0);
+    // rho (optional): this thread's share of <input, output> of the solve, summed over both packed sequences.
+    // The forward / inverse transforms are unnormalised with 1/N folded into the scale, so by the DFT's
+    // Parseval relation  sum_n (a za + b zb) = Re sum_k Z_in[k] conj(Z_out[k])  on the PACKED spectra -- two
+    // FMAs per bin on values that are in registers anyway (the cross terms between the two sequences cancel
+    // between bins k and N-k).  In SciPy's DCT normalisation <r,z> = sum_j c_j / (2 N_other) * (that sum of
+    // column j), c_0 = 1/2: the caller applies 1 / N_other, the factor 1/2 is applied here, and the one
+    // column with c_j = 1/2 (first_a) is corrected by half of its own share, which for that single column is
+    // evaluated from the unpacked spectrum: sum_k c_k X_k^2 / lambda_k with X_k = 2 Re(w_k V_k).
+    T packed = T(0), corr = T(0);
+    if (rho && first_a) {
+#pragma unroll
+      for (int i = 0; i < E; ++i) {
+        const int k = F::spec_index(tid, i);
+        const cpx<T> zk = x[i], zm = lds[LS * F::pad((N - k) & (N - 1))];
+        const cpx<T> w = wspec[i * TPF + tid];
+        const cpx<T> va = {T(0.5) * (zk.x + zm.x), T(0.5) * (zk.y - zm.y)};
+        const T uax = w.x * va.x - w.y * va.y;
+        T sa = T(-0.5) * inv_n * fast_recip(ha[i * TPF + tid] + hb_a);
+        if (k == 0) sa = inv_n;
+        corr += (k == 0 ? T(0.5) : T(1)) * uax * uax * sa;
+      }
+    }
 #pragma unroll
     for (int i = 0; i < E; ++i) {
       const int k = F::spec_index(tid, i);
@@ -99,22 +114,13 @@ struct WgDCT {
         if (first_a) sa = inv_n;
         if (first_b) sb = inv_n;
       }
-      const T pa = sa * ua.x, pb = sb * ub.x;
-      const cpx<T> ya = cmulc(cpx<T>{pa, sam * ua.y}, w);
-      const cpx<T> yb = cmulc(cpx<T>{pb, sbm * ub.y}, w);
-      x[i] = {ya.x - yb.y, ya.y + yb.x};
-      if (rho) {
-        const T ck = k == 0 ? T(0.5) : T(1);
-        ra = fma(ck * pa, ua.x, ra);
-        rb = fma(ck * pb, ub.x, rb);
-#if defined(__HIP_DEVICE_COMPILE__)
-        // the two sums are dependent chains through all E iterations: without a fence the scheduler
-        // runs the rest of every iteration first and keeps 2 E operand pairs alive for the chains
-        if ((i & 3) == 3) __builtin_amdgcn_sched_barrier(0);
-#endif
-      }
+      const cpx<T> ya = cmulc(cpx<T>{sa * ua.x, sam * ua.y}, w);
+      const cpx<T> yb = cmulc(cpx<T>{sb * ub.x, sbm * ub.y}, w);
+      const cpx<T> xn = {ya.x - yb.y, ya.y + yb.x};
+      x[i] = xn;
+      if (rho) packed = fma(zk.x, xn.x, fma(zk.y, xn.y, packed));
     }
-    if (rho) *rho += (double)((first_a ? T(0.5) : T(1)) * ra + (first_b ? T(0.5) : T(1)) * rb);
+    if (rho) *rho += 0.5 * ((double)packed - (double)corr);
   }
 
   // ---- inverse (DCT-III) of a packed pair ------------------------------------

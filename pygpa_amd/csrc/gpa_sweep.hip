@@ -264,7 +264,10 @@ __global__ __launch_bounds__((PassAGeom<T, LG>::THREADS)) void passA_kernel(
 // pass B: y-axis filter on rows, best-of-K select
 // ---------------------------------------------------------------------------
 template <class T, int LG, bool PADDED, bool SELECT>
-__global__ __launch_bounds__((PassBGeom<T, LG>::THREADS)) void passB_kernel(
+#ifndef GPA_F64_WAVES
+#define GPA_F64_WAVES 2   // f64: cap at 256 VGPRs (2 waves/SIMD) instead of 299 at 1 wave: pass B 7.5 -> 5.9 ms
+#endif
+__global__ __launch_bounds__((PassBGeom<T, LG>::THREADS), (sizeof(T) == 8 ? GPA_F64_WAVES : 1)) void passB_kernel(
     const cpx<T>* __restrict__ Tin, int n0, int n1,
     const typename HType<PADDED, T>::type* __restrict__ H, const cpx<T>* __restrict__ twtab,
     const int* __restrict__ planeof, const cpx<T>* __restrict__ cyb, const cpx<T>* __restrict__ sy,

@@ -514,8 +514,11 @@ __global__ __launch_bounds__((RowGeom<T, LG>::THREADS)) void rowdct_kernel(const
 #ifndef GPA_DCTF_WAVES
 #define GPA_DCTF_WAVES 1
 #endif
+#ifndef GPA_F64_WAVES
+#define GPA_F64_WAVES 2   // f64 row kernels: 2 waves/SIMD (256 VGPRs) beat 1 wave with AGPR spill-over
+#endif
 template <class T, int LG>
-__global__ __launch_bounds__((RowGeom<T, LG>::THREADS), GPA_DCTF_WAVES) void rowdct_fused_kernel(
+__global__ __launch_bounds__((RowGeom<T, LG>::THREADS), (sizeof(T) == 8 ? GPA_F64_WAVES : GPA_DCTF_WAVES)) void rowdct_fused_kernel(
     T* __restrict__ r, const T* __restrict__ q, int n0, const cpx<T>* __restrict__ twtab,
     const cpx<T>* __restrict__ wk, const int* flags, const double* part_pq, int npq, double* part_norm,
     double* scal, int it, int ring) {
@@ -802,7 +805,10 @@ template <class T, int LG>
 #ifndef GPA_IDCTP_COND
 #define GPA_IDCTP_COND (sizeof(T) == 4 && LG == 12)
 #endif
-__global__ __launch_bounds__((RowGeom<T, LG>::THREADS), (GPA_IDCTP_COND ? 4 : 1)) void rowidct_p_kernel(
+#ifndef GPA_F64_WAVES
+#define GPA_F64_WAVES 2   // f64 row kernels: 2 waves/SIMD (256 VGPRs) beat 1 wave with AGPR spill-over
+#endif
+__global__ __launch_bounds__((RowGeom<T, LG>::THREADS), (GPA_IDCTP_COND ? 4 : (sizeof(T) == 8 ? GPA_F64_WAVES : 1))) void rowidct_p_kernel(
     const T* __restrict__ Z, const T* __restrict__ pin, T* __restrict__ pout, int n0,
     const cpx<T>* __restrict__ twtab, const cpx<T>* __restrict__ wk, const int* flags, const double* part_rho,
     int nrho, double* scal, int it) {
