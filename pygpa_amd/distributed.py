@@ -277,3 +277,101 @@ def extract_displacement_field_tiled(image, kvecs, grid=None, sigma=None, kwscal
             mine[c] = unwrap(full[c, :, :-1], full[2 + c, :-1, :], full[4], kmax)
     parts = _all_gather_np(mine, group)
     return np.stack([parts[c % world][c] for c in range(2)])
+
+
+# ---------------------------------------------------------------------------------------------------
+# (peak x k-vector) sharding of ONE image: exact strong scaling (option 1)
+# ---------------------------------------------------------------------------------------------------
+def default_ksharded_compute(shape, nbatch, npeaks, dtype, device):
+    """sweep / reconstruct / unwrap callables backed by libgpa_hip.so (host arrays in and out)"""
+    from . import _lib
+    plans = {}
+
+    def plan():
+        if 'p' not in plans:
+            plans['p'] = _lib.Plan(shape, max(nbatch, npeaks), dtype, device)
+        return plans['p']
+
+    def sweep(img0, sigma, klist, kref):
+        lockin, kidx, _ = plan().sweep(img0, kref, klist, sigma)
+        return lockin, kidx
+
+    def reconstruct(lockins, kvecs, border):
+        return plan().reconstruct_grad(lockins, kvecs, border)
+
+    def unwrap(dx, dy, weight, kmax):
+        return plan().unwrap_prediff(dx, dy, weight, kmax=kmax)[0]
+    return sweep, reconstruct, unwrap
+
+
+def extract_displacement_field_ksharded(image, kvecs, sigma=None, kwscale=2.5, ksteps=3, klists=None, kmax=10,
+                                        dtype=np.float64, device=0, group=None, compute=None, _simulate_world=None):
+    """`extract_displacement_field` of one image with the (peak x candidate) lock-ins dealt over the ranks.
+
+    Every lock-in is independent, so rank r runs candidates r, r + N, r + 2N, ... of every peak on the whole
+    (replicated) image and keeps its partial winner per pixel; one all_gather of the partial winners
+    (complex lock-in + global candidate index, P x N x M each) and a local selection -- larger amplitude,
+    then smaller candidate index, which is what the sequential strict '>' of the reference keeps
+    (geometric_phase_analysis.py:683) -- give every rank the lock-ins of the full sweep.  The two unwraps then
+    run on ranks 0 and 1 and a second all_gather distributes u.  Same numbers as one GPU (each candidate
+    is computed by the same kernel), except that amplitudes tying to rounding may resolve differently."""
+    world, rank = 1, 0
+    if _initialized():
+        _, dist = _dist()
+        world, rank = dist.get_world_size(group), dist.get_rank(group)
+    image = np.asarray(image)
+    kvecs = np.asarray(kvecs, dtype=np.float64).reshape(-1, 2)
+    norms = np.linalg.norm(kvecs, axis=1)
+    kw = norms.mean() / kwscale
+    if sigma is None:
+        sigma = int(np.ceil(1 / norms.min()))
+    if klists is None:
+        from .geometric_phase_analysis import _sweep_list
+        klists = [_sweep_list(pk[0], pk[1], kw, kw / ksteps) for pk in kvecs]
+    klists = [np.asarray(k, dtype=np.float64).reshape(-1, 2) for k in klists]
+    P = len(kvecs)
+    K = max(len(k) for k in klists)
+    if compute is None:
+        compute = default_ksharded_compute(image.shape, -(-K // world), P, dtype, device)
+    sweep, reconstruct, unwrap = compute
+    cdtype = np.complex64 if np.dtype(dtype) == np.float32 else np.complex128
+    img0 = image - image.mean()
+
+    # --- local stage: my candidates of every peak
+    def partial_winners(r, w):
+        lock = np.zeros((P,) + image.shape, dtype=cdtype)
+        gidx = np.full((P,) + image.shape, -1, dtype=np.int32)
+        for p in range(P):
+            mine = np.arange(r, len(klists[p]), w)
+            if len(mine) == 0:
+                continue
+            lk, kidx = sweep(img0, sigma, klists[p][mine], kvecs[p])
+            lock[p] = lk
+            gidx[p] = np.where(kidx >= 0, mine[np.maximum(kidx, 0)], -1)
+        return lock, gidx
+
+    if _simulate_world:   # test aid: the ranks' shares one after the other in this process, no collective
+        pw = [partial_winners(r, int(_simulate_world)) for r in range(int(_simulate_world))]
+        locks, gidxs = [x[0] for x in pw], [x[1] for x in pw]
+    else:
+        lock, gidx = partial_winners(rank, world)
+        # --- collective 1: partial winners of every rank
+        locks = _all_gather_np(lock, group)
+        gidxs = _all_gather_np(gidx, group)
+    # --- selection
+    best, bidx = locks[0].copy(), gidxs[0].copy()
+    for lk, gi in zip(locks[1:], gidxs[1:]):
+        a_new, a_old = np.abs(lk), np.abs(best)
+        take = (gi >= 0) & ((bidx < 0) | (a_new > a_old) | ((a_new == a_old) & (gi < bidx)))
+        best = np.where(take, lk, best)
+        bidx = np.where(take, gi, bidx)
+
+    # --- reconstruct (replicated, cheap) and the two unwraps on ranks 0 and 1; collective 2
+    dudx, dudy, wnorm = reconstruct(best, kvecs, 2 * int(sigma))
+    mine_u = np.zeros((2,) + image.shape, dtype=np.dtype(dtype))
+    for c in range(2):
+        if c % world == rank:
+            mine_u[c] = unwrap(dudx[c], dudy[c], wnorm, kmax)
+    parts = _all_gather_np(mine_u, group)
+    u = np.stack([parts[c % world][c] for c in range(2)])
+    return u, best, bidx

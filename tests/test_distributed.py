@@ -116,3 +116,56 @@ def test_tiled_world2_matches_world1(tmp_path, tiling):
     uw = orc.extract_displacement_field(img, kvecs, klists=klists)
     d = (u1 - u1.mean(axis=(1, 2), keepdims=True)) - (uw - uw.mean(axis=(1, 2), keepdims=True))
     assert np.abs(d[:, 24:-24, 24:-24]).max() < 0.05
+
+
+# ---- (peak x k-vector) sharding -------------------------------------------------------------------
+def _oracle_ksharded_compute():
+    from oracle import gpa_oracle as orc
+
+    def sweep(img0, sigma, klist, kref):
+        g = orc.sweep(img0, sigma, klist, kref)
+        return g['lockin'], g['kidx']
+
+    def reconstruct(lockins, kvecs, border):
+        mask = orc.interior_mask(lockins.shape[1:], border)
+        weights = np.abs(lockins) * (mask + 1e-6)
+        dudx, dudy = orc.reconstruct_gradients(kvecs, np.angle(lockins), weights)
+        return dudx, dudy, np.linalg.norm(weights, axis=0)
+
+    def unwrap(dx, dy, weight, kmax):
+        return orc.unwrap_prediff(dx, dy, weight, kmax=kmax)
+    return sweep, reconstruct, unwrap
+
+
+def _kworker(rank, world, port, out_path):
+    sys.path.insert(0, ROOT)
+    import torch.distributed as dist
+    from pygpa_amd import distributed as D
+    from pygpa_amd.synthetic import explicit_klists
+    dist.init_process_group('gloo', init_method='tcp://127.0.0.1:%d' % port, rank=rank, world_size=world)
+    img, kvecs, _ = _case()
+    klists = explicit_klists(kvecs, np.linalg.norm(kvecs, axis=1).mean() / 2.5, 3, 3)
+    u, lock, kidx = D.extract_displacement_field_ksharded(img, kvecs, sigma=6, klists=klists, compute=_oracle_ksharded_compute())
+    np.savez(out_path % rank, u=u, lock=lock, kidx=kidx)
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+@pytest.mark.parametrize('world', [2, 3])
+def test_ksharded_matches_whole_sweep(tmp_path, world):
+    """9 candidates per peak dealt over 2 / 3 ranks (gloo): the gathered selection reproduces the
+    sequential sweep of the oracle exactly -- winners, lock-ins and the displacement field"""
+    import torch.multiprocessing as mp
+    from oracle import gpa_oracle as orc
+    from pygpa_amd.synthetic import explicit_klists
+    img, kvecs, _ = _case()
+    klists = explicit_klists(kvecs, np.linalg.norm(kvecs, axis=1).mean() / 2.5, 3, 3)
+    u_ref, parts = orc.extract_displacement_field(img, kvecs, sigma=6, klists=klists, return_parts=True)
+    port = _free_port()
+    out = str(tmp_path / 'k_rank%d.npz')
+    mp.spawn(_kworker, args=(world, port, out), nprocs=world, join=True)
+    for r in range(world):
+        g = np.load(out % r)
+        assert np.array_equal(g['kidx'], np.stack([x['kidx'] for x in parts['gs']]))
+        assert np.array_equal(g['lock'], np.stack([x['lockin'] for x in parts['gs']]))
+        assert np.array_equal(g['u'], u_ref)

@@ -801,3 +801,25 @@ def test_random_shapes_spectral_helpers_vs_oracle():
         tilted[: n0 // 4, : n1 // 4] += 5.0
         got, refp = mathtools.fit_plane(tilted), orc.fit_plane(tilted)
         assert np.allclose(got[:2], refp[:2], rtol=0, atol=2e-6 * np.abs(refp[:2]).max()) and abs(got[2] - refp[2]) < 2e-5, shape
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize('dtype', DTYPES)
+def test_ksharded_device_equals_fused_driver(dtype):
+    """(peak x k-vector) sharding with the device kernels, 4 simulated ranks in one process: the gathered
+    selection gives the winners and lock-ins of the single-GPU sweep (identical up to amplitude ties) and
+    the same displacement field"""
+    from pygpa_amd import distributed as D
+    shape = (192, 256)
+    kvecs = hex_kvecs(0.11, 9.0)
+    img = hex_moire(shape, kvecs, gaussian_bump_displacement(shape), noise=0.2, seed=11)
+    kw = np.linalg.norm(kvecs, axis=1).mean() / 2.5
+    klists = np.stack(explicit_klists(kvecs, kw, 4, 4))
+    u, lock, kidx = D.extract_displacement_field_ksharded(img, kvecs, sigma=9, klists=list(klists), dtype=dtype, _simulate_world=4)
+    plan = _lib.get_plan(shape, 48, dtype)
+    u1, lock1, kidx1, _ = plan.extract_displacement_field(img, kvecs, klists, 9, 18, want_lockins=True, want_kidx=True)
+    same = kidx == kidx1
+    assert same.mean() > 0.9999
+    # (the fused driver takes the image mean on the device, the sharded path on the host: last-bit differences)
+    assert rel(lock[same], lock1[same]) < (2e-6 if dtype == np.float32 else 1e-12)
+    assert rel(u, u1) < (2e-3 if dtype == np.float32 else 1e-9)
