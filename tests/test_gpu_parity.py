@@ -855,3 +855,22 @@ def test_fused_driver_rectangular_pow2(shape, dtype):
     else:
         d = (u - u.mean(axis=(1, 2), keepdims=True)) - (u_ref - u_ref.mean(axis=(1, 2), keepdims=True))
         assert np.sqrt((d ** 2).mean()) / np.abs(u_ref).max() < 3e-3
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize('dtype', DTYPES)
+def test_fused_unwrap_iteration_counts(dtype):
+    """fused power-of-two unwrap at iteration counts around the search-direction ring (10): 1, 2, 3, 9, 10,
+    11, 19, 20, 21, 35 -- the deferred phi updates must match the oracle's per-iteration updates"""
+    rng = np.random.default_rng(8)
+    shape = (128, 128)
+    x, y = np.meshgrid(np.arange(128), np.arange(128), indexing='ij')
+    psi = orc.wrap_to_pi(0.3 * x - 0.2 * y + 3.0 * np.sin(x / 15.0) * np.cos(y / 21.0) + 0.2 * rng.normal(size=shape))
+    weight = 0.2 + rng.random(shape)
+    plan = _lib.get_plan(shape, 1, dtype)
+    for kmax in (1, 2, 3, 9, 10, 11, 19, 20, 21, 35):
+        ref, it_ref = orc.unwrap(psi, weight=weight, kmax=kmax, return_iters=True)
+        got, it = plan.unwrap(psi, weight, kmax=kmax)
+        # (the f32 build stops at its residual floor, here after 31 iterations)
+        assert it_ref == kmax and (it == kmax or (dtype == np.float32 and it >= 25)), (kmax, it)
+        assert rel(got, ref) < (5e-4 if dtype == np.float32 else 1e-9), kmax
