@@ -874,3 +874,35 @@ def test_fused_unwrap_iteration_counts(dtype):
         # (the f32 build stops at its residual floor, here after 31 iterations)
         assert it_ref == kmax and (it == kmax or (dtype == np.float32 and it >= 25)), (kmax, it)
         assert rel(got, ref) < (5e-4 if dtype == np.float32 else 1e-9), kmax
+
+
+@pytest.mark.gpu
+def test_random_shapes_lockin_sweep_grad_vs_oracle():
+    """seeded random shapes / sigma / candidate lists through the sweep entry points (a1-a4): batched lock-ins,
+    best-of-K with winners bit-exact up to ties, phase gradient of the winner; f64 against the oracle"""
+    rng = np.random.default_rng(int(os.environ.get('GPA_TEST_RANDOM_SEED', '404')))
+    for _ in range(int(os.environ.get('GPA_TEST_RANDOM_CASES', '12'))):
+        n0, n1 = (int(v) for v in rng.integers(16, 300, 2))
+        shape = (n0, n1)
+        r_k = float(rng.uniform(0.06, 0.22))
+        kvecs = hex_kvecs(r_k, float(rng.uniform(0, 60)))
+        img = hex_moire(shape, kvecs, 0.3 * gaussian_bump_displacement(shape), noise=0.3, seed=int(rng.integers(0, 1000)))
+        img0 = img - img.mean()
+        sigma = float(rng.uniform(2.0, 9.0))
+        K = int(rng.integers(1, 12))
+        klist = kvecs[0] + rng.uniform(-0.4, 0.4, (K, 2)) * r_k
+        plan = _lib.get_plan(shape, max(K, 3), np.float64)
+        tag = (shape, round(sigma, 2), K)
+        assert rel(plan.lockin_batch(img0, kvecs, sigma), orc.lockin_batch(img0, kvecs, sigma)) < 1e-11, tag
+        ref = orc.sweep(img0, sigma, klist, kvecs[0], want_grad=True)
+        lock, kidx, grad = plan.sweep(img0, kvecs[0], klist, sigma, want_grad=True)
+        check_kidx(kidx, ref['kidx'], img0, klist, sigma, 1e-9)
+        same = kidx == ref['kidx']
+        assert rel(lock[same], ref['lockin'][same]) < 1e-11, tag
+        # the gradient uses np.gradient of the winner's phase, defined modulo the pi-periodic wrap of
+        # wrapToPi(2 g) / 2; compare where the lock-in is not vanishing
+        gref = orc.wrap_to_pi(2 * ref['grad']) / 2
+        d = orc.wrap_to_pi(2 * (grad - gref)) / 2
+        amp = np.abs(ref['lockin'])
+        ok = same & (amp > 1e-3 * amp.max())
+        assert np.abs(d[ok]).max() < 1e-8, tag
