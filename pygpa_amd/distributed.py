@@ -173,16 +173,21 @@ def _tiled_device(image, kvecs, klists, sigma, halo, kmax, dtype, device, group,
     dev = torch.device('cuda', device)
     t_dt = torch.float32 if dtype == np.float32 else torch.float64
     multi = world > 1
-    t_img = torch.from_numpy(img).to(dev)
     per_rank = (len(tiles) + world - 1) // world
     local = torch.zeros((per_rank, 5, t0, t1), dtype=t_dt, device=dev)
+    # a rank uploads only the windows of its own tiles (1/N of the image plus halos), one after the other;
+    # the mean of the WHOLE image that every tile is offset by (geometric_phase_analysis.py:919) is the host's
+    mean = float(img.mean(dtype=np.float64))
+    t_win = torch.empty(wshape, dtype=t_dt, device=dev)
     torch.cuda.synchronize(dev)          # the plans run on their own streams
-    mean = plan_w.mean_dev(t_img.data_ptr(), npx)
     plane = t0 * t1
     for slot, idx in enumerate(range(rank, len(tiles), world)):
         _, (w0, w1), (o0, o1), (z0, z1) = tiles[idx]
+        plan_w.sync()                    # the previous tile has consumed the window buffer
+        t_win.copy_(torch.from_numpy(np.ascontiguousarray(img[w0, w1])))
+        torch.cuda.synchronize(dev)
         base = local[slot].data_ptr()
-        plan_w.tile_gradients_dev(t_img.data_ptr(), n1, w0.start, w1.start, mean, kvecs, klists, sigma, border,
+        plan_w.tile_gradients_dev(t_win.data_ptr(), wshape[1], 0, 0, mean, kvecs, klists, sigma, border,
                                   (o0, o1, z0, z1), (base, t1, plane), (base + 2 * plane * rsz, t1, plane),
                                   (base + 4 * plane * rsz, t1))
     plan_w.sync()
@@ -195,7 +200,7 @@ def _tiled_device(image, kvecs, klists, sigma, halo, kmax, dtype, device, group,
     full = torch.empty((5, n0, n1), dtype=t_dt, device=dev)
     for idx, ((i, j), _, _, (z0, z1)) in enumerate(tiles):
         full[:, i * t0:i * t0 + z0, j * t1:j * t1 + z1] = gathered[idx % world, idx // world, :, :z0, :z1]
-    del gathered, local, t_img
+    del gathered, local, t_win
     # --- global unwrap, one component per rank; collective 2 distributes the components
     mine = torch.zeros((2, n0, n1), dtype=t_dt, device=dev)
     todo = [c for c in range(2) if c % world == rank]

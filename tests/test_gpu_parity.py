@@ -513,7 +513,7 @@ def test_tiled_device_resident_torch_buffers():
     klists = explicit_klists(kvecs, 0.04, 3, 3)
     u_dev = D.extract_displacement_field_tiled(img, kvecs, (2, 2), klists=klists, halo=24)
     u_t = D.extract_displacement_field_tiled(img, kvecs, (2, 2), klists=klists, halo=24, _force_torch=True)
-    assert np.abs(u_dev - u_t).max() <= 1e-12
+    assert np.abs(u_dev - u_t).max() <= 1e-10   # (image mean taken on the device vs on the host)
 
 
 # ---- f-4: Huber plane fit ------------------------------------------------------------------------
