@@ -25,6 +25,15 @@ __device__ __forceinline__ T wrap_to_pi(T x) {
   return t - Consts<T>::two_pi * floor(t / Consts<T>::two_pi) - Consts<T>::pi;
 }
 
+// the same for the difference of two phases, |x| < 2 pi: floor((x + pi) / 2 pi) is -1, 0 or 1 and follows from
+// two comparisons -- no division, and (like NumPy's exact float modulo) no quotient rounding at the seams
+template <class T>
+__device__ __forceinline__ T wrap_phase_diff(T x) {
+  const T t = x + Consts<T>::pi;
+  const T r = t >= Consts<T>::two_pi ? t - Consts<T>::two_pi : (t < T(0) ? t + Consts<T>::two_pi : t);
+  return r - Consts<T>::pi;
+}
+
 template <class T>
 __device__ __forceinline__ void solve2(T a00, T a01, T a11, T r0, T r1, T& x0, T& x1) {
   const T det = a00 * a11 - a01 * a01, tr = a00 + a11;
@@ -99,8 +108,8 @@ __global__ __launch_bounds__(256) void reconstruct_kernel(const cpx<T>* __restri
       w[p] = ampc[p] * mfac;
       wsq += w[p] * w[p];
       wmax = w[p] > wmax ? w[p] : wmax;
-      bx[p] = has_r ? wrap_to_pi(phr - phc[p]) : T(0);
-      by[p] = has_d ? wrap_to_pi(phn[p] - phc[p]) : T(0);
+      bx[p] = has_r ? wrap_phase_diff(phr - phc[p]) : T(0);
+      by[p] = has_d ? wrap_phase_diff(phn[p] - phc[p]) : T(0);
     }
     if (act) {
       if (wnorm) wnorm[o] = sqrt(wsq);
@@ -214,8 +223,8 @@ __global__ __launch_bounds__(256) void reconstruct_setup_kernel(const cpx<T>* __
       const T phr = __shfl_down(phc[p], 1);
       w[p] = ampc[p] * mfac;
       wmax = w[p] > wmax ? w[p] : wmax;
-      bx[p] = has_r ? wrap_to_pi(phr - phc[p]) : T(0);
-      by[p] = has_d ? wrap_to_pi(phn[p] - phc[p]) : T(0);
+      bx[p] = has_r ? wrap_phase_diff(phr - phc[p]) : T(0);
+      by[p] = has_d ? wrap_phase_diff(phn[p] - phc[p]) : T(0);
     }
     const T ws = wmax > T(0) ? T(1) / wmax : T(0);
     T a00 = 0, a01 = 0, a11 = 0, rx0 = 0, rx1 = 0, ry0 = 0, ry1 = 0;
