@@ -34,6 +34,12 @@ __device__ __forceinline__ T wrap_phase_diff(T x) {
   return r - Consts<T>::pi;
 }
 
+// general argument, fast path for the usual |x| < 2 pi (same arithmetic as wrap_to_pi there)
+template <class T>
+__device__ __forceinline__ T wrap_to_pi_fast(T x) {
+  return fabs(x) < Consts<T>::two_pi ? wrap_phase_diff(x) : wrap_to_pi(x);
+}
+
 template <class T>
 __device__ __forceinline__ void solve2(T a00, T a01, T a11, T r0, T r1, T& x0, T& x1) {
   const T det = a00 * a11 - a01 * a01, tr = a00 + a11;
@@ -244,15 +250,15 @@ __global__ __launch_bounds__(256) void reconstruct_setup_kernel(const cpx<T>* __
       T s0, s1;
       solve2(a00, a01, a11, rx0, rx1, s0, s1);
       const T m = wwr < wwc ? wwr : wwc;
-      fx0 = wrap_to_pi(s0) * m;
-      fx1 = wrap_to_pi(s1) * m;
+      fx0 = wrap_to_pi_fast(s0) * m;
+      fx1 = wrap_to_pi_fast(s1) * m;
     }
     if (has_d) {
       T s0, s1;
       solve2(a00, a01, a11, ry0, ry1, s0, s1);
       const T m = wwn < wwc ? wwn : wwc;
-      fy0 = wrap_to_pi(s0) * m;
-      fy1 = wrap_to_pi(s1) * m;
+      fy0 = wrap_to_pi_fast(s0) * m;
+      fy1 = wrap_to_pi_fast(s1) * m;
     }
     const T fxl0 = __shfl_up(fx0, 1), fxl1 = __shfl_up(fx1, 1);
     if (outrow && outcol) {
