@@ -245,6 +245,7 @@ class Plan:
         skimage (highest first, raster order among equals) [, smooth]."""
         image = self._img(image)
         smooth = np.empty(self.shape, dtype=self.rdtype) if want_smooth else None
+        tried_full = False
         while True:
             coords = np.empty((max_out, 2), dtype=np.int32)
             vals = np.empty(max_out, dtype=self.rdtype)
@@ -252,10 +253,10 @@ class Plan:
             check(self.lib.gpa_find_peaks(self.handle, _ptr(image), float(sigma), float(dog_sigma), float(threshold_rel),
                                           int(max_out), _ptr(coords), _ptr(vals), C.byref(count), _ptr(smooth)),
                   'gpa_find_peaks')
-            if count.value <= max_out:
+            if count.value <= max_out or tried_full:
                 break
-            max_out = count.value
-        n = count.value
+            max_out, tried_full = count.value, True   # (the library caps max_out at its buffer size)
+        n = min(count.value, max_out)
         coords, vals = coords[:n], vals[:n]
         order = np.lexsort((coords[:, 1], coords[:, 0], -vals))
         out = (coords[order].astype(np.intp), vals[order])

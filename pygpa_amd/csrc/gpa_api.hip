@@ -5,6 +5,7 @@
 #include <stdlib.h>
 #include <string.h>
 
+#include <algorithm>
 #include <complex>
 #include <string>
 #include <limits>
@@ -855,7 +856,9 @@ int gpa_find_peaks(gpa_plan* p, const void* image, double sigma, double dog_sigm
   HIP_TRY(hipSetDevice(p->device));
   const int n0 = p->n0, n1 = p->n1;
   const size_t npx = (size_t)n0 * n1;
-  if ((size_t)max_out > npx) max_out = (int)npx;
+  // candidates land in d_kidx (max_peaks * npx ints, two per candidate) and d_dudx (2 npx reals)
+  const size_t cap = std::min((size_t)p->max_peaks * npx / 2, 2 * npx);
+  if ((size_t)max_out > cap) max_out = (int)cap;
   std::vector<double> w1, w2;
   const int R1 = gaussian_weights(sigma, w1);
   const int R2 = dog_sigma > 0.0 ? gaussian_weights(dog_sigma, w2) : 0;
