@@ -1,26 +1,29 @@
 #!/usr/bin/env python
 """Headline benchmark: Mpixels/s of displacement-field extraction on MI355X.
 
-Workload (BASELINE.json config 3): 4096 x 4096 synthetic hex moire, 3 Bragg peaks x
-16 reference k-vectors (explicit 4x4 lists), sigma = 10, weighted DCT-PCG unwrap
-with kmax = 10, fp32.  One "step" = one whole extract_displacement_field call on an
-image already resident in HBM (mean, 48 lock-ins, select, phases/weights, per-pixel
-least squares, two unwraps), through the C ABI of libgpa_hip.so.
-
     python bench.py [--gpus N] [--steps K] [--warmup W] [--size S] [--dtype f32|f64]
 
-N > 1 (launched by torch.distributed.run, one rank per GPU): every rank extracts
-the displacement field of its own 4096^2 tile (weak scaling, no data-path collective
-inside the extraction), then the tiles' fields are stitched with one RCCL
-all_gather over xGMI inside the timed step.
+N = 1 (BASELINE.json configs[2]): 4096 x 4096 synthetic hex moire, 3 Bragg peaks x 16 reference
+k-vectors (explicit 4x4 lists), sigma = 10, weighted DCT-PCG unwrap with kmax = 10, fp32.  One step =
+one whole extract_displacement_field call through the C ABI of libgpa_hip.so on an image already
+resident in HBM (mean, 48 lock-ins, select, phases/weights, per-pixel least squares, two unwraps)
+PLUS the download of u to page-locked host memory ("D2H of u included"), which runs on
+the plan's copy stream while the kernels of the next step execute.  Extra keys: `resident_only` (the
+same loop with u left in HBM), `f64` (the reference's own precision), `kernels` (per-kernel HIP-event
+times with the roofline that bounds each), `cpu_baseline`.
 
-Rank 0 prints ONE JSON line with the contract fields plus `roofline` (dominant
-kernel, HIP-event timed on the plan's stream) and, at N = 1, `cpu_baseline` (the
-NumPy/SciPy oracle timed on this box's host cores on a bounded sample).
+N > 1 (one rank per GPU; `--gpus N` without a launcher starts N fresh child processes through
+torch.distributed.run before this process touches a GPU): the tile pipeline of BASELINE configs[3-4],
+pygpa_amd.distributed.TiledPipeline, on an image of N x 4096^2 pixels (N = 4: 8192^2 = configs[3]):
+halo windows dealt over the ranks -> all_gather of the gradient tiles -> global unwrap -> broadcast of u.
+Weak scaling: pixels per GPU are fixed.
+
+Rank 0 prints ONE JSON line.
 """
 import argparse
 import json
 import os
+import subprocess
 import sys
 import time
 
@@ -29,53 +32,12 @@ import numpy as np
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
-HBM_PEAK_GBS = 8000.0   # MI355X HBM3E spec peak (MI355X_MICROARCH.md: 8.0 TB/s spec, ~6.3 achievable)
+HBM_PEAK_GBS = 8000.0        # MI355X HBM3E spec peak (MI355X_MICROARCH.md: 8.0 TB/s spec, ~6.3 achievable)
+VALU_PEAK_TFLOPS = 157.3     # f32 vector peak: 1024 SIMD-32 x 2 flop x 2.4 GHz (same guide)
+VALU_ISSUE_PEAK = 1024 * 2.4e9 / 2   # wave64 VALU instructions / s: one per 2 cycles per SIMD
 
 
-def algorithmic_bytes(n0, n1, P, K, s, iters):
-    """Algorithmic HBM bytes of one step and of each sweep kernel launch.
-
-    pass A: read the real image once, write one complex intermediate per lock-in.
-    pass B: read those intermediates, write P complex lock-ins.
-    reconstruct: read P lock-ins, write dudx, dudy (2 comps each) and wnorm.
-    unwrap (per component): setup 7s, 19s per PCG iteration."""
-    px = n0 * n1
-    B = P * K
-    a = px * (s + 2 * s * B)
-    b = px * (2 * s * B + 2 * s * P)
-    rec = px * (2 * s * P + 5 * s)
-    unw = sum(px * (7 * s + 19 * s * it) for it in iters)
-    return {'passA': a, 'passB': b, 'reconstruct': rec, 'unwrap': unw, 'total': a + b + rec + unw}
-
-
-def cpu_baseline(kvecs, sigma, knx, kny, kmax):
-    """Time the CPU oracle (NumPy/SciPy port of the reference path) on bounded samples of the same
-    workload (same P x K, same kmax), about 15-25 s of host work in total."""
-    from oracle import gpa_oracle as orc
-    from pygpa_amd.synthetic import gaussian_bump_displacement, hex_moire, explicit_klists
-    cores = os.cpu_count() or 1
-    kw = np.linalg.norm(kvecs, axis=1).mean() / 2.5
-    klists = explicit_klists(kvecs, kw, knx, kny)
-    # (i) reference-faithful threading: pyGPA runs single-threaded pocketfft and a serial per-pixel
-    # solve (1024^2 sample); (ii) best effort: scipy.fft on every host core (2048^2 sample).
-    # The faster rate is the baseline.
-    runs = []
-    for w, sample in ((1, 1024), (cores, 2048)) if cores > 1 else ((1, 1024),):
-        shape = (sample, sample)
-        img = hex_moire(shape, kvecs, gaussian_bump_displacement(shape), noise=0.1, seed=7)
-        t = time.perf_counter()
-        orc.extract_displacement_field(img, kvecs, sigma=sigma, klists=klists, workers=w)
-        dt = time.perf_counter() - t
-        runs.append((sample * sample / dt / 1e6, w, sample, dt))
-    rate, w, sample, dt = max(runs)
-    return {'value': round(rate, 4), 'unit': 'Mpixels/s', 'cores': w, 'kind': 'port',
-            'sample': '%dx%d image, 3 peaks x %d k-vectors + weighted unwrap kmax=%d, oracle/gpa_oracle.py, scipy.fft '
-                      'workers=%d: %.1f s; all runs: ' % (sample, sample, knx * kny, kmax, w, dt) +
-                      ', '.join('%d^2 workers=%d %.1f s = %.3f Mpix/s' % (r[2], r[1], r[3], r[0]) for r in runs) +
-                      ' (host has %d cores)' % cores}
-
-
-def main():
+def parse_args():
     ap = argparse.ArgumentParser()
     ap.add_argument('--gpus', type=int, default=1)
     ap.add_argument('--steps', type=int, default=20)
@@ -86,161 +48,395 @@ def main():
     ap.add_argument('--dtype', default='f32', choices=['f32', 'f64'])
     ap.add_argument('--kmax', type=int, default=10)
     ap.add_argument('--no-cpu', action='store_true', help='skip the CPU baseline leg')
-    ap.add_argument('--force-torch', action='store_true', help='use the torch buffer path at N = 1 too (test aid)')
-    ap.add_argument('--inflight', type=int, default=1,
-                    help='images in flight per GPU (one plan each): 1 = strictly one after the other')
-    args = ap.parse_args()
+    ap.add_argument('--no-f64', action='store_true', help='skip the f64 leg')
+    ap.add_argument('--window', type=int, default=2048, help='N > 1: side of the (power-of-two) tile windows')
+    ap.add_argument('--backend', default='nccl', help='N > 1: torch.distributed backend (gloo stages through the host)')
+    ap.add_argument('--share-device', action='store_true', help='N > 1: every rank uses GPU 0 (test aid, with --backend gloo)')
+    return ap.parse_args()
 
-    world = int(os.environ.get('WORLD_SIZE', '1'))
-    rank = int(os.environ.get('RANK', '0'))
-    local_rank = int(os.environ.get('LOCAL_RANK', '0'))
-    torch = dist = None
-    use_torch = world > 1 or args.force_torch
-    if use_torch:
-        # torch is plumbing for the multi-GPU run only (process group + RCCL); it is imported
-        # BEFORE libgpa_hip.so so that both share the HIP runtime torch ships.  A single-GPU run
-        # does not need it (and its first import on a cold machine takes minutes).
-        import torch
-        import torch.distributed as dist
-        os.environ.setdefault('MASTER_ADDR', '127.0.0.1')
-        os.environ.setdefault('HSA_ENABLE_IPC_MODE_LEGACY', '0')
-        torch.cuda.set_device(local_rank)
-        if world > 1:
-            dist.init_process_group('nccl', rank=rank, world_size=world, device_id=torch.device('cuda', local_rank))
-    from pygpa_amd import _lib
-    from pygpa_amd.synthetic import hex_kvecs, gaussian_bump_displacement, hex_moire, explicit_klists
-    dev_index = local_rank if world > 1 else 0
 
+# -------------------------------------------------------------------------------------------------
+# byte / flop models
+# -------------------------------------------------------------------------------------------------
+def survey_bytes(n0, n1, P, K, s, iters):
+    """SURVEY.md 8(d)'s algorithmic bytes of one step (a 2-D FFT pair per lock-in, 19 arrays per PCG
+    iteration): the reference algorithm's traffic, kept as a yardstick."""
+    px = n0 * n1
+    sweep = px * P * (8 * s * K + 3 * s)
+    rec = px * (2 * s * P + 5 * s)
+    unw = sum(px * (7 * s + 19 * s * it) for it in iters)
+    return {'sweep': sweep, 'reconstruct': rec, 'unwrap': unw, 'total': sweep + rec + unw}
+
+
+def kernel_models(n0, n1, L0, L1, P, K, Bx, s, iters):
+    """Per-launch algorithmic HBM bytes (what THIS build's kernels must move: every operand once) and
+    nominal flops (5 L log2 L per complex FFT of length L) of each kernel of the step."""
+    px = n0 * n1
+    B = P * K
+    fft = lambda L: 5.0 * L * np.log2(L)
+    return {
+        # image once, one complex x-plane per distinct wx out
+        'passA_kernel': {'bytes': px * (s + 2 * s * Bx), 'flops': Bx * n1 * (2 * fft(L0) + 8 * L0)},
+        # every x-plane in once (the K/Bx-fold re-reads of a plane are served by L2), P winners out
+        'passB_kernel': {'bytes': px * (2 * s * Bx + 2 * s * P), 'flops': B * n0 * (2 * fft(L1) + 16 * L1)},
+        # P lock-ins in; wnorm, r0 of both components out
+        'reconstruct_setup_kernel': {'bytes': px * (2 * s * P + 3 * s), 'flops': None},
+        # per working launch and component: q, R in, R out / R in, Z out / Z, p in, p out / p, w in, q out
+        'rowdct_fused_kernel': {'bytes': px * 3 * s, 'flops': (n0 / 2) * (fft(L1) + 12 * L1)},
+        'colsolve_kernel': {'bytes': px * 2 * s, 'flops': (n1 / 2) * (2 * fft(L0) + 24 * L0)},
+        'rowidct_p_kernel': {'bytes': px * 3 * s, 'flops': (n0 / 2) * (fft(L1) + 12 * L1)},
+        'pq_kernel': {'bytes': px * 3 * s, 'flops': None},
+        # phi in/out once per flush plus the kept search directions
+        'phi_flush_kernel': {'bytes': None, 'flops': None},
+    }
+
+
+def cpu_baseline(kvecs, sigma, knx, kny, kmax, size):
+    """Time the CPU oracle (NumPy/SciPy port of the reference path) on the GPU box's host cores:
+    (i) reference-faithful threading (single-threaded pocketfft, serial per-pixel solve) on a 1024^2
+    sample; (ii) best effort on every core -- the candidates of a peak through a thread pool (the
+    analogue of the reference's dask wfr2_only_lockin_vec) and scipy.fft workers for the unwrap -- on
+    the benchmark's own image size when that fits the time budget, else 2048^2."""
+    from oracle import gpa_oracle as orc
+    from pygpa_amd.synthetic import gaussian_bump_displacement, hex_moire, explicit_klists
+    cores = os.cpu_count() or 1
+    kw = np.linalg.norm(kvecs, axis=1).mean() / 2.5
+    klists = explicit_klists(kvecs, kw, knx, kny)
+
+    def run(sample, workers, pool):
+        shape = (sample, sample)
+        img = hex_moire(shape, kvecs, gaussian_bump_displacement(shape), noise=0.1, seed=7)
+        t = time.perf_counter()
+        orc.extract_displacement_field(img, kvecs, sigma=sigma, klists=klists, workers=workers, pool=pool)
+        dt = time.perf_counter() - t
+        return {'rate': sample * sample / dt / 1e6, 'cores': max(workers, pool), 'sample': sample, 'seconds': dt,
+                'mode': 'pool=%d workers=%d' % (pool, workers)}
+
+    runs = [run(1024, 1, 1)]
+    if cores > 1:
+        pool = min(cores, knx * kny)
+        probe = run(1024, cores, pool)
+        runs.append(probe)
+        # the multi-core run scales ~ with pixels: take the benchmark size if it stays under ~45 s
+        full = size if probe['seconds'] * (size / 1024.0) ** 2 < 45.0 else 2048
+        if full > 1024:
+            runs.append(run(full, cores, pool))
+    best = max(runs, key=lambda r: r['rate'])      # the GPU/CPU ratio is quoted against the fastest CPU run
+    return {'value': round(best['rate'], 4), 'unit': 'Mpixels/s', 'cores': best['cores'], 'kind': 'port',
+            'sample': '%dx%d image, 3 peaks x %d k-vectors + weighted unwrap kmax=%d, oracle/gpa_oracle.py (%s): %.1f s; '
+                      'all runs: ' % (best['sample'], best['sample'], knx * kny, kmax, best['mode'], best['seconds']) +
+                      ', '.join('%d^2 %s %.1f s = %.3f Mpix/s' % (r['sample'], r['mode'], r['seconds'], r['rate']) for r in runs) +
+                      ' (host has %d cores)' % cores}
+
+
+# -------------------------------------------------------------------------------------------------
+# N = 1
+# -------------------------------------------------------------------------------------------------
+class SingleGPU:
+    def __init__(self, n, P, K, np_dt, kvecs, klists, sigma, kmax, seed=100):
+        from pygpa_amd import _lib
+        from pygpa_amd.synthetic import gaussian_bump_displacement, hex_moire
+        self._lib = _lib
+        self.n, self.kvecs, self.klists, self.sigma, self.kmax = n, kvecs, klists, sigma, kmax
+        img = hex_moire((n, n), kvecs, gaussian_bump_displacement((n, n)), noise=0.1, seed=seed, dtype=np_dt)
+        self.plan = _lib.Plan((n, n), P * K, np_dt, device=0)
+        self.d_img = _lib.DeviceBuffer(img.nbytes)
+        self.d_img.upload(img)
+        self.d_u = [_lib.DeviceBuffer(2 * img.nbytes) for _ in range(2)]
+        self.h_u = [_lib.pinned_empty((2, n, n), np_dt) for _ in range(2)]
+        # set-up, not a benchmark step: the first call per result buffer allocates lazily and runs eagerly, the
+        # second captures the call's ~110 launches into a hipGraph (libgpa_hip.so, extract_enqueue)
+        for j in (0, 1, 0, 1):
+            self.enqueue(j)
+        self.plan.sync()
+
+    def enqueue(self, j):
+        self.plan.extract_displacement_field_async(self.d_img.ptr, self.kvecs, self.klists, self.sigma, 2 * self.sigma,
+                                                   self.kmax, self.d_u[j].ptr)
+
+    def run(self, nsteps, download):
+        """nsteps steps back to back; with `download` the u of step i goes to pinned host memory on the copy
+        stream while step i + 1 computes into the other buffer"""
+        for i in range(nsteps):
+            j = i & 1
+            if download:
+                self.plan.download_wait(j)      # the copy that last read d_u[j] (step i - 2) has landed
+            self.enqueue(j)
+            if download:
+                self.plan.download_async(self.h_u[j], self.d_u[j].ptr, j)
+        self.plan.sync()
+
+    def timed(self, steps, warmup, download):
+        self.run(warmup, download)
+        t0 = time.perf_counter()
+        self.run(steps, download)
+        return time.perf_counter() - t0
+
+    def profile(self, reps=3):
+        self.plan.set_profiling(True)
+        stage = np.zeros(5)
+        kern = {}
+        for _ in range(reps):
+            self.plan.extract_displacement_field_dev(self.d_img.ptr, self.kvecs, self.klists, self.sigma, 2 * self.sigma,
+                                                     self.kmax, self.d_u[0].ptr)
+            stage += np.array(self.plan.last_stage_ms())
+            for name, (calls, ms) in self.plan.last_kernel_profile().items():
+                c, t = kern.get(name, (0, 0.0))
+                kern[name] = (calls, t + ms)
+        self.plan.set_profiling(False)
+        return stage / reps, {k: (c, t / reps) for k, (c, t) in kern.items()}
+
+    def close(self):
+        self.plan.close()
+        for b in [self.d_img] + self.d_u:
+            b.free()
+
+
+def load_counters():
+    """per-launch PMC figures of the committed rocprofv3 passes (profiles/counters.json): HBM bytes
+    (FETCH_SIZE doubled per the microarch guide + WRITE_SIZE) and VALU wave-instructions per kernel"""
+    path = os.path.join(ROOT, 'profiles', 'counters.json')
+    try:
+        return json.load(open(path))
+    except Exception:
+        return {}
+
+
+def single_gpu(args):
+    from pygpa_amd.synthetic import hex_kvecs, explicit_klists
     n = args.size
     knx, kny = (int(v) for v in args.kgrid.split('x')) if args.kgrid else (args.kside, args.kside)
     P, K = 3, knx * kny
-    np_dt = np.float32 if args.dtype == 'f32' else np.float64
-    s = 4 if args.dtype == 'f32' else 8
     kvecs = hex_kvecs(0.1, 7.0)
     sigma = int(np.ceil(1 / np.linalg.norm(kvecs, axis=1).min()))
     kw = np.linalg.norm(kvecs, axis=1).mean() / 2.5
     klists = np.stack(explicit_klists(kvecs, kw, knx, kny))
+    Bx = sum(len(np.unique(kl[:, 0])) for kl in klists)
+    np_dt = np.float32 if args.dtype == 'f32' else np.float64
+    s = 4 if args.dtype == 'f32' else 8
 
-    # every rank owns one tile of a (world * n) x n synthetic image
-    u_true = gaussian_bump_displacement((n, n))
-    img = hex_moire((n, n), kvecs, u_true, noise=0.1, seed=100 + rank, dtype=np_dt)
-    depth = max(1, args.inflight)
-    # one plan (workspace + streams) per image in flight
-    plans = [_lib.Plan((n, n), P * K, np_dt, device=dev_index) for _ in range(depth)]
-    # u buffers: with N > 1 at least two, so that the all_gather of step i (RCCL, torch's stream) overlaps
-    # the kernels of step i + 1 (plan streams), which write the other buffer
-    nb = depth if world == 1 else max(2, depth)
-    if use_torch:
-        dev = torch.device('cuda', dev_index)
-        t_dt = torch.float32 if args.dtype == 'f32' else torch.float64
-        t_img = torch.from_numpy(img).to(dev)
-        t_us = [torch.empty((2, n, n), dtype=t_dt, device=dev) for _ in range(nb)]
-        d_alls = [torch.empty((world, 2, n, n), dtype=t_dt, device=dev) for _ in range(nb)] if world > 1 else None
-        img_ptr, u_ptrs = t_img.data_ptr(), [t.data_ptr() for t in t_us]
+    g = SingleGPU(n, P, K, np_dt, kvecs, klists, sigma, args.kmax)
+    dt = g.timed(args.steps, args.warmup, download=True)
+    iters = g.plan.last_iters()
+    dt_res = g.timed(args.steps, 1, download=False)
+    stage, kern = g.profile()
+    L0, L1 = g.plan.fft_len(0), g.plan.fft_len(1)
+    g.close()
+
+    ms_per_step = dt / args.steps * 1e3
+    out = {
+        'metric': 'Mpixels/s displacement-field extraction (3 peaks, 4096^2 img) + achieved HBM GB/s',
+        'value': round(n * n * args.steps / dt / 1e6, 2),
+        'unit': 'Mpixels/s',
+        'n_gpus': 1, 'steps': args.steps, 'warmup': args.warmup,
+        'ms_per_step': round(ms_per_step, 4),
+        'higher_is_better': True, 'scaling': 'weak', 'vs_baseline': None,
+        'dtype': args.dtype, 'data': 'synthetic',
+        'config': {'workload': '%dx%d synthetic hex moire, 3 Bragg peaks x %d k-vectors, sigma=%d, weighted DCT-PCG '
+                               'unwrap kmax=%d, image resident in HBM, u downloaded to pinned host memory inside the '
+                               'step (BASELINE.json configs[2])' % (n, n, K, sigma, args.kmax),
+                   'image': [n, n], 'peaks': P, 'kvectors_per_peak': K, 'x_planes': int(Bx),
+                   'unwrap_iters': list(iters), 'd2h_of_u': 'included, overlapped with the next step (copy stream)'},
+        'resident_only': {'value': round(n * n * args.steps / dt_res / 1e6, 2), 'ms_per_step': round(dt_res / args.steps * 1e3, 4),
+                          'note': 'same loop with u left in HBM (round-1 definition)'},
+    }
+
+    # ---- per-kernel table: HIP-event time (serial run of the step), the bound the counters show, fractions of peak
+    models = kernel_models(n, n, L0, L1, P, K, Bx, s, iters)
+    counters = load_counters()
+    work = {'rowdct_fused_kernel': sum(iters), 'rowidct_p_kernel': sum(iters), 'pq_kernel': sum(iters),
+            'colsolve_kernel': sum(iters)}   # launches that do work (those after convergence return at once)
+    table = {}
+    for name, (calls, ms) in kern.items():
+        m = models.get(name, {})
+        c = counters.get(name, {})
+        working = work.get(name, calls)
+        row = {'launches': calls, 'working_launches': working, 'total_ms': round(ms, 4),
+               'avg_us_all_launches': round(ms / max(calls, 1) * 1e3, 2)}
+        per = ms * 1e-3 / max(working, 1)          # seconds per working launch (early-exit launches take ~2 us)
+        if m.get('bytes'):
+            row['algorithmic_GBps'] = round(m['bytes'] / per / 1e9, 1)
+            row['algorithmic_bytes_per_launch'] = int(m['bytes'])
+        if c.get('hbm_bytes'):
+            row['hbm_GBps'] = round(c['hbm_bytes'] / per / 1e9, 1)
+            row['hbm_frac'] = round(c['hbm_bytes'] / per / 1e9 / HBM_PEAK_GBS, 4)
+            row['hbm_bytes_per_launch'] = int(c['hbm_bytes'])
+        if m.get('flops'):
+            row['nominal_TFLOPs'] = round(m['flops'] / per / 1e12, 2)
+        if c.get('valu_insts'):
+            row['valu_issue_frac'] = round(c['valu_insts'] / per / VALU_ISSUE_PEAK, 4)
+        fr = {'hbm': row.get('hbm_frac', (m['bytes'] / per / 1e9 / HBM_PEAK_GBS) if m.get('bytes') else 0.0),
+              'valu': row.get('valu_issue_frac', 0.0)}
+        row['bound'] = max(fr, key=fr.get)
+        table[name] = row
+    out['kernels'] = table
+    out['stage_ms'] = {nm: round(float(v), 4) for nm, v in zip(
+        ['tables+mean', 'passA_kernel', 'passB_kernel', 'reconstruct_setup', 'unwrap(serial, both components)'], stage)}
+
+    # ---- roofline of the dominant kernel (largest single launch): pass B, VALU-issue bound
+    dom = max((k for k in table if table[k]['launches'] <= 2), key=lambda k: table[k]['total_ms'], default='passB_kernel')
+    drow, dm, dc = table[dom], models.get(dom, {}), counters.get(dom, {})
+    dsec = drow['total_ms'] * 1e-3 / max(drow['working_launches'], 1)
+    if drow['bound'] == 'valu' and dm.get('flops'):
+        out['roofline'] = {'bound': 'valu', 'kernel': dom, 'achieved': round(dm['flops'] / dsec / 1e12, 2),
+                           'peak': VALU_PEAK_TFLOPS, 'unit': 'TFLOP/s', 'frac': round(dm['flops'] / dsec / 1e12 / VALU_PEAK_TFLOPS, 4),
+                           'traffic': dc.get('hbm_bytes'), 'kernel_ms': round(dsec * 1e3, 4),
+                           'nominal_flops_per_launch': dm['flops'],
+                           'valu_issue_frac': drow.get('valu_issue_frac'),
+                           'note': 'f32 vector pipe, not MFMA: nominal 5 L log2 L flops per FFT over the HIP-event time; '
+                                   'valu_issue_frac = counted VALU wave-instructions / (1024 SIMDs x 1 per 2 cycles x 2.4 GHz)'}
     else:
-        bufs = [_lib.DeviceBuffer(img.nbytes)] + [_lib.DeviceBuffer(2 * img.nbytes) for _ in range(nb)]
-        bufs[0].upload(img)
-        img_ptr, u_ptrs = bufs[0].ptr, [b.ptr for b in bufs[1:]]
-        t_us = d_alls = None
-    gathered = [None] * nb
-    plan = plans[0]
+        ach = (dc.get('hbm_bytes') or dm.get('bytes') or 0) / dsec / 1e9
+        out['roofline'] = {'bound': 'hbm', 'kernel': dom, 'achieved': round(ach, 1), 'peak': HBM_PEAK_GBS, 'unit': 'GB/s',
+                           'frac': round(ach / HBM_PEAK_GBS, 4), 'traffic': dc.get('hbm_bytes'),
+                           'algorithmic_bytes_per_launch': dm.get('bytes'), 'kernel_ms': round(dsec * 1e3, 4)}
+    # whole step: the bytes this build's kernels must move / the bytes the counters saw / the survey's model
+    step_alg = sum((models[k]['bytes'] or 0) * table[k]['working_launches'] for k in table if k in models)
+    step_hbm = sum(counters[k]['hbm_bytes'] * table[k]['working_launches'] for k in table if counters.get(k, {}).get('hbm_bytes'))
+    res_s = dt_res / args.steps
+    out['whole_step'] = {'algorithmic_GBps': round(step_alg / res_s / 1e9, 1),
+                         'counter_GBps': round(step_hbm / res_s / 1e9, 1) if step_hbm else None,
+                         'counter_frac_of_hbm_peak': round(step_hbm / res_s / 1e9 / HBM_PEAK_GBS, 4) if step_hbm else None,
+                         'survey_model_GBps': round(survey_bytes(n, n, P, K, s, iters)['total'] / res_s / 1e9, 1),
+                         'note': 'over the resident-only step time; survey_model = SURVEY.md 8(d) bytes of the reference '
+                                 'algorithm (2-D FFT pairs, 19 arrays per PCG iteration), which this build does not move'}
 
-    def gather(pj, j):
-        # stitch the tiles' fields of the step that ran on plan pj into buffer j (RCCL all_gather over xGMI);
-        # asynchronous on torch's stream, the event guards the reuse of u buffer j
-        plans[pj].sync()
-        dist.all_gather_into_tensor(d_alls[j], t_us[j])
-        ev = torch.cuda.Event()
-        ev.record()
-        gathered[j] = ev
+    if not args.no_f64 and args.dtype == 'f32':
+        g64 = SingleGPU(n, P, K, np.float64, kvecs, klists, sigma, args.kmax)
+        k64 = max(3, args.steps // 4)
+        dt64 = g64.timed(k64, 1, download=True)
+        it64 = g64.plan.last_iters()
+        g64.close()
+        out['f64'] = {'value': round(n * n * k64 / dt64 / 1e6, 2), 'unit': 'Mpixels/s', 'ms_per_step': round(dt64 / k64 * 1e3, 4),
+                      'steps': k64, 'unwrap_iters': list(it64), 'note': 'the reference computes in complex128; same step, D2H of u included'}
+    if not args.no_cpu:
+        out['cpu_baseline'] = cpu_baseline(kvecs, sigma, knx, kny, args.kmax, n)
+    print(json.dumps(out), flush=True)
 
-    def run(nsteps):
-        pending = []
-        for i in range(nsteps):
-            j, pj = i % nb, i % depth
-            if gathered[j] is not None:        # the collective that reads t_us[j] must be done before it is rewritten
-                gathered[j].synchronize()
-                gathered[j] = None
-            plans[pj].extract_displacement_field_async(img_ptr, kvecs, klists, sigma, 2 * sigma, args.kmax, u_ptrs[j])
-            if world > 1:
-                pending.append((pj, j))
-                if len(pending) > depth - 1:
-                    gather(*pending.pop(0))
-        for pj, j in pending:
-            gather(pj, j)
+
+# -------------------------------------------------------------------------------------------------
+# N > 1: tile pipeline over the ranks
+# -------------------------------------------------------------------------------------------------
+def weak_shape(world, n):
+    """image of world * n^2 pixels, as square as powers of two allow (N = 4: 2n x 2n = configs[3])"""
+    a = 1
+    while a * a * 2 <= world:
+        a *= 2
+    b = world // a
+    if a * b != world:
+        a, b = world, 1
+    return (a * n, b * n) if a >= b else (b * n, a * n)
+
+
+def multi_gpu(args, world, rank, local_rank):
+    import torch
+    import torch.distributed as dist
+    os.environ.setdefault('MASTER_ADDR', '127.0.0.1')
+    os.environ.setdefault('HSA_ENABLE_IPC_MODE_LEGACY', '0')
+    dev_index = 0 if args.share_device else local_rank
+    torch.cuda.set_device(dev_index)
+    if args.backend == 'nccl':
+        dist.init_process_group('nccl', rank=rank, world_size=world, device_id=torch.device('cuda', dev_index))
+    else:
+        dist.init_process_group(args.backend, rank=rank, world_size=world)
+    from pygpa_amd import distributed as D
+    from pygpa_amd.synthetic import hex_kvecs, explicit_klists
+    n = args.size
+    knx, kny = (int(v) for v in args.kgrid.split('x')) if args.kgrid else (args.kside, args.kside)
+    P, K = 3, knx * kny
+    np_dt = np.float32 if args.dtype == 'f32' else np.float64
+    kvecs = hex_kvecs(0.1, 7.0)
+    sigma = int(np.ceil(1 / np.linalg.norm(kvecs, axis=1).min()))
+    kw = np.linalg.norm(kvecs, axis=1).mean() / 2.5
+    klists = np.stack(explicit_klists(kvecs, kw, knx, kny))
+    shape = weak_shape(world, n)
+    halo = 3 * sigma
+    W = min(args.window, min(shape))
+    pipe = D.TiledPipeline(shape, kvecs, klists, sigma, halo, kmax=args.kmax, dtype=np_dt, device=dev_index,
+                           window=(W, W))
+
+    # synthetic image: every rank generates only the pixels of its own windows (global coordinates)
+    def window_fn(w0, w1):
+        x = (np.arange(w0.start, w0.stop) - shape[0] // 2)[:, None].astype(np.float64)
+        y = (np.arange(w1.start, w1.stop) - shape[1] // 2)[None, :].astype(np.float64)
+        ux = 0.5 * x * np.exp(-0.5 * ((x / (shape[0] / 8.0)) ** 2 + 1.2 * (y / (shape[1] / 6.0)) ** 2))
+        img = np.zeros((w0.stop - w0.start, w1.stop - w1.start))
+        for kx, ky in kvecs:
+            img += np.cos(2 * np.pi * (kx * (x + ux) + ky * y))
+        rng = np.random.default_rng([100, w0.start, w1.start])
+        return (img + rng.normal(scale=0.05, size=img.shape)).astype(np_dt)
+
+    pipe.load(window_fn=window_fn)
+    dev = torch.device('cuda', dev_index)
 
     def fence():
-        for pl in plans:
-            pl.sync()
-        if use_torch:
-            torch.cuda.synchronize()
-        if world > 1:
-            dist.barrier()
-            torch.cuda.synchronize()
+        torch.cuda.synchronize(dev)
+        dist.barrier()
+        torch.cuda.synchronize(dev)
 
-    run(args.warmup)
+    for _ in range(args.warmup):
+        pipe.step()
     fence()
     t0 = time.perf_counter()
-    run(args.steps)
+    for _ in range(args.steps):
+        pipe.step()
     fence()
     dt = time.perf_counter() - t0
-    iters = plan.last_iters()
-    if world > 1:
-        t = torch.tensor([dt], dtype=torch.float64, device=torch.device('cuda', dev_index))
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        dt = float(t.item())
-
-    # per-kernel timing of the dominant kernels, HIP events on the plan's own stream
-    plan.set_profiling(True)
-    stage = np.zeros(5)
-    nprof = 5
-    for _ in range(nprof):
-        plan.extract_displacement_field_dev(img_ptr, kvecs, klists, sigma, 2 * sigma, args.kmax, u_ptrs[0])
-        stage += np.array(plan.last_stage_ms())
-    stage /= nprof
-    plan.set_profiling(False)
-
+    t = torch.tensor([dt], dtype=torch.float64)
+    if args.backend == 'nccl':
+        t = t.to(dev)
+    dist.all_reduce(t, op=dist.ReduceOp.MAX)
+    dt = float(t.item())
     if rank == 0:
-        ab = algorithmic_bytes(n, n, P, K, s, iters)
-        names = ['tables+mean', 'passA_kernel', 'passB_kernel', 'reconstruct_kernel', 'unwrap(all kernels)']
-        dom = 1 if stage[1] >= stage[2] else 2
-        dom_bytes = ab['passA'] if dom == 1 else ab['passB']
-        achieved = dom_bytes / (stage[dom] * 1e-3) / 1e9
-        traffic = None
-        tfile = os.path.join(ROOT, 'profiles', 'traffic.json')
-        if os.path.exists(tfile):
-            try:
-                traffic = json.load(open(tfile)).get(names[dom])
-            except Exception:
-                traffic = None
-        ms_per_step = dt / args.steps * 1e3
+        npx = shape[0] * shape[1]
+        cfg = {4: 'BASELINE.json configs[3]', 8: 'BASELINE.json configs[4] without the undistortion'}.get(world, 'configs[3] pipeline')
         out = {
             'metric': 'Mpixels/s displacement-field extraction (3 peaks, 4096^2 img) + achieved HBM GB/s',
-            'value': round(world * n * n * args.steps / dt / 1e6, 2),
-            'unit': 'Mpixels/s',
+            'value': round(npx * args.steps / dt / 1e6, 2), 'unit': 'Mpixels/s',
             'n_gpus': world, 'steps': args.steps, 'warmup': args.warmup,
-            'ms_per_step': round(ms_per_step, 4),
+            'ms_per_step': round(dt / args.steps * 1e3, 4),
             'higher_is_better': True, 'scaling': 'weak', 'vs_baseline': None,
             'dtype': args.dtype, 'data': 'synthetic',
-            'config': {'workload': '%dx%d synthetic hex moire per GPU, 3 Bragg peaks x %d k-vectors, sigma=%d, '
-                                   'weighted DCT-PCG unwrap kmax=%d (BASELINE.json configs[2])' % (n, n, K, sigma, args.kmax),
-                       'image': [n, n], 'peaks': P, 'kvectors_per_peak': K, 'unwrap_iters': list(iters),
-                       'sharding': 'one image tile per rank' + (', RCCL all_gather of u' if world > 1 else ''),
-                       'images_in_flight_per_gpu': depth},
-            'algorithmic_GBps_whole_step': round(ab['total'] / (ms_per_step * 1e-3) / 1e9, 1),
-            'stage_ms': {names[i]: round(float(stage[i]), 4) for i in range(5)},
-            'roofline': {'bound': 'hbm', 'kernel': names[dom], 'achieved': round(achieved, 1), 'peak': HBM_PEAK_GBS,
-                         'unit': 'GB/s', 'frac': round(achieved / HBM_PEAK_GBS, 4), 'traffic': traffic,
-                         'algorithmic_bytes_per_launch': dom_bytes, 'kernel_ms': round(float(stage[dom]), 4)},
+            'config': {'workload': '%dx%d synthetic hex moire (%d x %d^2 pixels) tiled into %d halo windows of %d^2 dealt over '
+                                   '%d ranks, 3 Bragg peaks x %d k-vectors, sigma=%d; all_gather of the gradient tiles, global '
+                                   'weighted unwrap kmax=%d on rank c %% N, broadcast of u (%s)'
+                                   % (shape[0], shape[1], world, n, len(pipe.tiles), W, world, K, sigma, args.kmax, cfg),
+                       'image': list(shape), 'tiles': len(pipe.tiles), 'window': [W, W], 'halo': halo,
+                       'tile_interior': list(pipe.tshape), 'peaks': P, 'kvectors_per_peak': K,
+                       'unwrap_iters': list(pipe.iters), 'backend': args.backend,
+                       'collectives': 'all_reduce(mean scalar), all_gather(gradient tiles), 2 x broadcast(u component)'},
         }
-        if world == 1 and not args.no_cpu:
-            out['cpu_baseline'] = cpu_baseline(kvecs, sigma, knx, kny, args.kmax)
         print(json.dumps(out), flush=True)
-    for pl in plans:
-        pl.close()
-    if world > 1:
-        dist.barrier()
-        dist.destroy_process_group()
+    pipe.close()
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def spawn(args):
+    """--gpus N without a launcher: start N fresh rank processes BEFORE this process touches the GPU,
+    relay rank 0's JSON line and exit with the children's return code"""
+    import socket
+    s = socket.socket()
+    s.bind(('127.0.0.1', 0))
+    port = s.getsockname()[1]
+    s.close()
+    cmd = [sys.executable, '-m', 'torch.distributed.run', '--nnodes=1', '--nproc-per-node', str(args.gpus),
+           '--master-addr', '127.0.0.1', '--master-port', str(port), os.path.abspath(__file__)] + sys.argv[1:]
+    env = dict(os.environ)
+    env.setdefault('HSA_ENABLE_IPC_MODE_LEGACY', '0')
+    r = subprocess.run(cmd, env=env)
+    sys.exit(r.returncode)
+
+
+def main():
+    args = parse_args()
+    if 'WORLD_SIZE' not in os.environ and args.gpus > 1:
+        spawn(args)
+    world = int(os.environ.get('WORLD_SIZE', '1'))
+    if world == 1:
+        single_gpu(args)
+    else:
+        multi_gpu(args, world, int(os.environ.get('RANK', '0')), int(os.environ.get('LOCAL_RANK', '0')))
 
 
 if __name__ == '__main__':

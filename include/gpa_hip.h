@@ -262,6 +262,20 @@ int gpa_timer_stop(gpa_plan* plan, float* ms_out);
  *   [3] reconstruct  [4] unwrap (both components)                             */
 int gpa_set_profiling(gpa_plan* plan, int on);
 int gpa_last_stage_ms(gpa_plan* plan, float* ms5);
+/* per-KERNEL device times of the last fused-driver call made with profiling on (every launch is
+ * bracketed by HIP events on the stream it runs on; the two unwraps then run one after the other):
+ * one text line "name launches total_ms" per kernel, NUL-terminated, into out[cap].              */
+int gpa_last_kernel_profile(gpa_plan* plan, char* out, size_t cap);
+
+/* Download of a result while the GPU goes on with the next call: copies `bytes` from device memory
+ * (e.g. the u of gpa_extract_displacement_field_async) to PAGE-LOCKED host memory on the plan's copy
+ * stream, ordered after everything enqueued on the plan so far.  `slot` (0..3) names the completion
+ * event: gpa_download_wait(plan, slot) blocks the host until that copy has landed.  The caller must not
+ * let a later call overwrite dev_src before the copy is done (alternate two result buffers and wait for
+ * slot i before reusing buffer i).  This is how bench.py keeps the D2H of u inside the timed step
+ *  without serialising it with the kernels.                                       */
+int gpa_download_async(gpa_plan* plan, void* host_dst, const void* dev_src, size_t bytes, int slot);
+int gpa_download_wait(gpa_plan* plan, int slot);
 
 #ifdef __cplusplus
 }

@@ -101,7 +101,7 @@ def sweep_grid(kx, ky, kw, kstep):
     return np.array([(wx, wy) for wx in wxs for wy in wys], dtype=np.float64).reshape(-1, 2)
 
 
-def sweep(image, sigma, klist, kref, want_grad=False, workers=1):
+def sweep(image, sigma, klist, kref, want_grad=False, workers=1, pool=1):
     """Adaptive lock-in over an explicit k-list.
 
     For every k in ``klist`` (in order) compute sf = lockin(image, k); a pixel
@@ -116,6 +116,11 @@ def sweep(image, sigma, klist, kref, want_grad=False, workers=1):
     Returns dict: 'lockin' (N,M) c128, 'kidx' (N,M) int32 index into klist of
     the winner (-1 where no candidate ever won), 'w' (2,N,M) f64 (gpa.py:685),
     and with want_grad 'grad' (N,M,2) f64.
+
+    ``pool`` > 1 computes the candidates' lock-ins `pool` at a time on a thread pool (the
+    analogue of the reference's dask-vectorised wfr2_only_lockin_vec, gpa.py:705-719; NumPy's
+    FFT and elementwise loops release the GIL); the selection below still runs in list
+    order, so the result is the same.  Only bench.py's multi-core CPU baseline uses it.
     """
     image = np.asarray(image)
     klist = np.asarray(klist, dtype=np.float64).reshape(-1, 2)
@@ -124,8 +129,19 @@ def sweep(image, sigma, klist, kref, want_grad=False, workers=1):
     best_amp = np.zeros((n0, n1))
     kidx = np.full((n0, n1), -1, dtype=np.int32)
     grad = np.zeros((n0, n1, 2)) if want_grad else None
+    ahead = {}
+    executor = None
+    if pool > 1:
+        from concurrent.futures import ThreadPoolExecutor
+        executor = ThreadPoolExecutor(max_workers=pool)
     for i, (wx, wy) in enumerate(klist):
-        sf = lockin(image, (wx, wy), sigma, workers=workers)
+        if executor is not None:
+            if i % pool == 0:
+                ahead = {j: executor.submit(lockin, image, tuple(klist[j]), sigma, workers)
+                         for j in range(i, min(i + pool, len(klist)))}
+            sf = ahead.pop(i).result()
+        else:
+            sf = lockin(image, (wx, wy), sigma, workers=workers)
         amp = np.abs(sf)
         take = amp > best_amp
         comp = carrier_1d(n0, -(wx - kref[0]))[:, None] * carrier_1d(n1, -(wy - kref[1]))[None, :]
@@ -137,6 +153,8 @@ def sweep(image, sigma, klist, kref, want_grad=False, workers=1):
             g = np.stack(np.gradient(ph), axis=-1)
             g = g + TWO_PI * np.array([wx - kref[0], wy - kref[1]])
             grad = np.where(take[..., None], g, grad)
+    if executor is not None:
+        executor.shutdown()
     w = np.zeros((2, n0, n1))
     won = kidx >= 0
     w[0][won] = klist[kidx[won], 0]
@@ -348,7 +366,7 @@ def reconstruct_u_inv_from_phases(kvecs, phases, weights, weighted_unwrap=True,
 
 
 def extract_displacement_field(image, kvecs, sigma=None, kwscale=2.5, ksteps=3,
-                               klists=None, workers=1, return_parts=False):
+                               klists=None, workers=1, return_parts=False, pool=1):
     """Top-level path, gpa.py:907-932 (deconvolve=False).
 
     ``klists``: optional list of P explicit (K,2) k-lists (wfr3-style,
@@ -362,7 +380,7 @@ def extract_displacement_field(image, kvecs, sigma=None, kwscale=2.5, ksteps=3,
     gs = []
     for p, pk in enumerate(kvecs):
         kl = sweep_grid(pk[0], pk[1], kw, kstep) if klists is None else klists[p]
-        gs.append(sweep(img0, sigma, kl, pk, workers=workers))
+        gs.append(sweep(img0, sigma, kl, pk, workers=1 if pool > 1 else workers, pool=pool))
     lockins = np.stack([g['lockin'] for g in gs])
     phases, weights, _ = phases_weights(lockins, sigma)
     u, iters = reconstruct_u_inv_from_phases(kvecs, phases, weights, workers=workers,

@@ -63,6 +63,9 @@ SIGNATURES = {
     'gpa_timer_stop': (_i, [_vp, _vp]),
     'gpa_set_profiling': (_i, [_vp, _i]),
     'gpa_last_stage_ms': (_i, [_vp, _vp]),
+    'gpa_last_kernel_profile': (_i, [_vp, C.c_char_p, _sz]),
+    'gpa_download_async': (_i, [_vp, _vp, _vp, _sz, _i]),
+    'gpa_download_wait': (_i, [_vp, _i]),
 }
 
 _lib = None
@@ -401,6 +404,24 @@ class Plan:
 
     def set_profiling(self, on):
         check(self.lib.gpa_set_profiling(self.handle, 1 if on else 0), 'gpa_set_profiling')
+
+    def last_kernel_profile(self):
+        """{kernel name: (launches, total ms)} of the last profiled fused-driver call"""
+        buf = C.create_string_buffer(1 << 16)
+        check(self.lib.gpa_last_kernel_profile(self.handle, buf, len(buf)), 'gpa_last_kernel_profile')
+        out = {}
+        for line in buf.value.decode().splitlines():
+            name, calls, ms = line.rsplit(' ', 2)
+            out[name] = (int(calls), float(ms))
+        return out
+
+    def download_async(self, host_array, dev_ptr, slot):
+        """enqueue the D2H copy of host_array.nbytes from dev_ptr into the (page-locked) host_array"""
+        check(self.lib.gpa_download_async(self.handle, _ptr(host_array), _ptr(int(dev_ptr)), host_array.nbytes, int(slot)),
+              'gpa_download_async')
+
+    def download_wait(self, slot):
+        check(self.lib.gpa_download_wait(self.handle, int(slot)), 'gpa_download_wait')
 
     def last_stage_ms(self):
         ms = (C.c_float * 5)()

@@ -102,6 +102,17 @@ static void build_filter_table(const Axis& ax, double sigma, std::vector<double>
 // ---------------------------------------------------------------------------
 // plan
 // ---------------------------------------------------------------------------
+struct GraphKey {
+  const void* image; void* u; void* lk; int32_t* kidx;
+  int P, K, Bx, mask_border, kmax, epoch;
+};
+struct GraphEntry {
+  GraphKey key;
+  hipGraph_t graph;
+  hipGraphExec_t exec;
+  bool failed;
+};
+
 struct gpa_plan {
   int device = 0, dtype = 0, n0 = 0, n1 = 0, max_batch = 0;
   Axis ax0{}, ax1{};
@@ -114,7 +125,8 @@ struct gpa_plan {
   void* Hx = nullptr;             // filter tables for the current sigma
   void* Hy = nullptr;
   double sigma_cached = -1.0;
-  void* Tbuf = nullptr;           // [max_batch][n0][n1] complex
+  void* Tbuf = nullptr;           // [tbuf_planes][n0][n1] complex: one plane per DISTINCT wx (x-plane), grown on demand
+  int tbuf_planes = 0;
   SweepTables tb{};
   double* d_kl = nullptr;         // [max_batch][2]
   double* d_kr = nullptr;
@@ -131,6 +143,8 @@ struct gpa_plan {
   size_t sf_bytes = 0;
   void* d_grad = nullptr;         // n0 x n1 x 2 staging for the host-pointer a4 call
   double* d_scratch = nullptr;    // 4096 doubles
+  void* d_aux0 = nullptr;         // n0 / n1 complex doubles: border-difference spectra (a9), Gaussian factors (f-4);
+  void* d_aux1 = nullptr;         // NOT the sweep's compensation tables, which stay valid across those calls
   void* d_lockin = nullptr;       // [P<=max_peaks][n0][n1] complex (staging / fused driver)
   int32_t* d_kidx = nullptr;
   int max_peaks = 0;
@@ -150,6 +164,14 @@ struct gpa_plan {
   bool profiling = false;
   hipEvent_t stage_ev[6] = {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};
   float stage_ms[5] = {0, 0, 0, 0, 0};
+  std::vector<GraphEntry> graphs;    // captured fused-driver calls (extract_enqueue)
+  bool use_graphs = true, serial_unwrap = false;
+  int tbuf_epoch = 0;                // bumped when a buffer baked into the graphs is reallocated
+  KernelProfiler* kprof = nullptr;   // per-kernel event pairs of the last profiled driver call
+  std::string kprof_table;           // "name calls total_ms" lines of that call
+  // downloads overlapped with the next call (gpa_download_async)
+  hipStream_t copy_stream = nullptr;
+  hipEvent_t ev_dl_ready = nullptr, ev_dl_done[4] = {nullptr, nullptr, nullptr, nullptr};
 };
 
 static Axis make_axis(int n) {
@@ -222,7 +244,10 @@ static int plan_build(gpa_plan* p) {
   }
   TRY(dmalloc(p, &p->Hx, (size_t)p->ax0.L * p->csz));
   TRY(dmalloc(p, &p->Hy, (size_t)p->ax1.L * p->csz));
-  TRY(dmalloc(p, &p->Tbuf, (size_t)B * npx * p->csz));
+  // pass A writes one plane per distinct wx, not per candidate (a 6x6 grid x 3 peaks needs 18 planes, not 108):
+  // start with what the non-sweep users need (<= 8 real planes) and grow in ensure_tbuf()
+  p->tbuf_planes = B < 4 ? B : 4;
+  TRY(dmalloc(p, &p->Tbuf, (size_t)p->tbuf_planes * npx * p->csz));
   TRY(dmalloc(p, &p->tb.cxb, (size_t)B * (p->ax0.L / 16) * p->csz));
   TRY(dmalloc(p, &p->tb.sx, (size_t)B * 16 * p->csz));
   TRY(dmalloc(p, &p->tb.wxw, (size_t)B * p->csz));
@@ -241,6 +266,8 @@ static int plan_build(gpa_plan* p) {
   TRY(dmalloc(p, &p->d_mean, 16));
   TRY(dmalloc(p, &p->d_tile_mean, 16));
   TRY(dmalloc(p, (void**)&p->d_scratch, 4096 * sizeof(double)));
+  TRY(dmalloc(p, &p->d_aux0, (size_t)p->n0 * 2 * sizeof(double)));
+  TRY(dmalloc(p, &p->d_aux1, (size_t)p->n1 * 2 * sizeof(double)));
   p->max_peaks = B < 8 ? B : 8;
   TRY(dmalloc(p, &p->d_lockin, (size_t)p->max_peaks * npx * p->csz));
   TRY(dmalloc(p, (void**)&p->d_kidx, (size_t)p->max_peaks * npx * sizeof(int32_t)));
@@ -311,6 +338,21 @@ static int stage_kvectors(gpa_plan* p, const double* kl, const double* kr_per_b,
   return GPA_OK;
 }
 
+// room for `planes` x-planes in Tbuf
+static int ensure_tbuf(gpa_plan* p, int planes) {
+  if (planes <= p->tbuf_planes) return GPA_OK;
+  const size_t npx = (size_t)p->n0 * p->n1;
+  HIP_TRY(hipStreamSynchronize(p->stream));
+  HIP_TRY(hipFree(p->Tbuf));
+  p->ws_bytes -= (size_t)p->tbuf_planes * npx * p->csz;
+  p->Tbuf = nullptr;
+  p->tbuf_planes = 0;
+  TRY(dmalloc(p, &p->Tbuf, (size_t)planes * npx * p->csz));
+  p->tbuf_planes = planes;
+  ++p->tbuf_epoch;   // captured graphs hold the old pointer
+  return GPA_OK;
+}
+
 // 2 pi kvecs for the per-pixel solves, re-staged only when the peaks change
 static int stage_kmat(gpa_plan* p, const double* kvecs, int P) {
   std::vector<double> km((size_t)2 * P);
@@ -359,6 +401,8 @@ gpa_plan* gpa_plan_create(int device, int n0, int n1, int max_batch, int dtype) 
   p->csz = 2 * p->rsz;
   p->ax0 = make_axis(n0);
   p->ax1 = make_axis(n1);
+  p->use_graphs = getenv("GPA_NO_GRAPH") == nullptr;
+  p->serial_unwrap = getenv("GPA_SERIAL_UNWRAP") != nullptr;
   const int maxlg = dtype == GPA_F32 ? 14 : 13;
   if (p->ax0.lg > maxlg || p->ax1.lg > maxlg) {
     fail(GPA_ERR_ARG, "gpa_plan_create: axis too long for an LDS-resident transform "
@@ -379,9 +423,14 @@ void gpa_plan_destroy(gpa_plan* p) {
   if (!p) return;
   hipSetDevice(p->device);
   if (p->stream) hipStreamSynchronize(p->stream);
+  for (auto& g : p->graphs) {
+    if (g.exec) hipGraphExecDestroy(g.exec);
+    if (g.graph) hipGraphDestroy(g.graph);
+  }
+  p->graphs.clear();
   void* bufs[] = {p->tw0, p->tw1, p->Hx, p->Hy, p->Tbuf, p->tb.cxb, p->tb.sx, p->tb.wxw, p->tb.cyb, p->tb.sy, p->tb.wyw, p->tb.planeof, p->d_pw,
                   p->tb.dx, p->tb.dy, p->d_kl, p->d_kr, p->d_image, p->d_mean, p->d_tile_mean, p->d_scratch,
-                  p->d_lockin, p->d_kidx, p->d_dudx, p->d_dudy, p->d_wnorm, p->d_u, p->d_kmat, p->d_sf, p->d_grad};
+                  p->d_lockin, p->d_kidx, p->d_dudx, p->d_dudy, p->d_wnorm, p->d_u, p->d_kmat, p->d_sf, p->d_grad, p->d_aux0, p->d_aux1};
   for (void* b : bufs)
     if (b) hipFree(b);
   unwrap_workspace_destroy(&p->uw);
@@ -393,6 +442,14 @@ void gpa_plan_destroy(gpa_plan* p) {
   blue_axis_destroy(&p->bx1);
   if (p->h_k) hipHostFree(p->h_k);
   if (p->h_iters) hipHostFree(p->h_iters);
+  if (p->kprof) {
+    for (int i = 0; i < p->kprof->npool; ++i) hipEventDestroy(p->kprof->pool[i]);
+    delete p->kprof;
+  }
+  if (p->copy_stream) { hipStreamSynchronize(p->copy_stream); hipStreamDestroy(p->copy_stream); }
+  if (p->ev_dl_ready) hipEventDestroy(p->ev_dl_ready);
+  for (auto e : p->ev_dl_done)
+    if (e) hipEventDestroy(e);
   if (p->ev0) hipEventDestroy(p->ev0);
   if (p->ev1) hipEventDestroy(p->ev1);
   for (auto e : p->stage_ev)
@@ -405,6 +462,7 @@ int gpa_plan_sync(gpa_plan* p) {
   if (!p) return fail(GPA_ERR_ARG, "null plan");
   HIP_TRY(hipStreamSynchronize(p->stream));
   if (p->stream2) HIP_TRY(hipStreamSynchronize(p->stream2));
+  if (p->copy_stream) HIP_TRY(hipStreamSynchronize(p->copy_stream));
   return GPA_OK;
 }
 size_t gpa_plan_workspace_bytes(const gpa_plan* p) { return p ? p->ws_bytes : 0; }
@@ -423,6 +481,7 @@ int gpa_lockin_batch_dev(gpa_plan* p, const void* image, const double* kvecs, in
   TRY(ensure_filters(p, sigma));
   int Bx = 0;
   TRY(stage_kvectors(p, kvecs, kvecs, B, &Bx));
+  TRY(ensure_tbuf(p, Bx));
   HIP_TRY(launch_passA(p->dtype, p->ax0, p->n1, image, nullptr, p->tb, p->Hx, p->tw0, p->Tbuf, Bx, p->stream));
   HIP_TRY(launch_passB(p->dtype, p->ax1, p->n0, p->Tbuf, p->Hy, p->tw1, p->tb, B, 1, false, out, nullptr,
                        p->stream));
@@ -462,6 +521,7 @@ static int sweep_peaks_dev(gpa_plan* p, const void* image, const void* mean, con
     }
   int Bx = 0;
   TRY(stage_kvectors(p, klists, kr.data(), B, &Bx));
+  TRY(ensure_tbuf(p, Bx));
   if (p->profiling) HIP_TRY(hipEventRecord(p->stage_ev[1], p->stream));
   HIP_TRY(launch_passA(p->dtype, p->ax0, p->n1, image, mean, p->tb, p->Hx, p->tw0, p->Tbuf, Bx, p->stream));
   if (p->profiling) HIP_TRY(hipEventRecord(p->stage_ev[2], p->stream));
@@ -490,6 +550,7 @@ int gpa_sweep_dev(gpa_plan* p, const void* image, const double* kref, const doub
   for (int k = 0; k < K; ++k) { kr[2 * k] = kref[0]; kr[2 * k + 1] = kref[1]; }
   int Bx = 0;
   TRY(stage_kvectors(p, klist, kr.data(), K, &Bx));
+  TRY(ensure_tbuf(p, Bx));
   HIP_TRY(launch_passA(p->dtype, p->ax0, p->n1, image, nullptr, p->tb, p->Hx, p->tw0, p->Tbuf, Bx, p->stream));
   HIP_TRY(launch_passB(p->dtype, p->ax1, p->n0, p->Tbuf, p->Hy, p->tw1, p->tb, K, 1, false, p->d_sf, nullptr, p->stream));
   HIP_TRY(launch_gradselect(p->dtype, p->d_sf, K, p->n0, p->n1, p->d_kl, p->d_kr, p->tb, lockin, kidx, grad, p->stream));
@@ -544,6 +605,7 @@ int gpa_weighted_lstsq(gpa_plan* p, const void* b, const void* weights, const do
   HIP_TRY(hipSetDevice(p->device));
   const size_t npx = (size_t)p->n0 * p->n1;
   // staging: b in d_lockin (P complex planes hold 2P real ones), weights in Tbuf
+  TRY(ensure_tbuf(p, (P + 1) / 2));
   HIP_TRY(hipMemcpyAsync(p->d_lockin, b, (size_t)P * npx * p->rsz, hipMemcpyHostToDevice, p->stream));
   HIP_TRY(hipMemcpyAsync(p->Tbuf, weights, (size_t)P * npx * p->rsz, hipMemcpyHostToDevice, p->stream));
   TRY(stage_kmat(p, kvecs, P));
@@ -601,19 +663,19 @@ int gpa_unwrap(gpa_plan* p, const void* psi, const void* weight, int kmax, doubl
 }
 
 // ---- fused driver --------------------------------------------------------------
-// enqueue the whole driver on the plan's streams without any host synchronisation
-static int extract_enqueue(gpa_plan* p, const void* image, const double* kvecs, int P, const double* klists, int K,
-                           double sigma, int mask_border, int kmax, void* u, void* lockins, int32_t* kidx) {
-  if (!p || !image || !kvecs || !klists || !u) return fail(GPA_ERR_ARG, "gpa_extract_displacement_field: null argument");
-  if (P < 2 || P > p->max_peaks) return fail(GPA_ERR_STATE, "gpa_extract_displacement_field: need 2 <= P <= 8");
-  if (K < 1 || P * K > p->max_batch) return fail(GPA_ERR_STATE, "gpa_extract_displacement_field: P*K exceeds max_batch");
-  if (kmax < 1) return fail(GPA_ERR_ARG, "kmax must be >= 1");
-  HIP_TRY(hipSetDevice(p->device));
-  const size_t npx = (size_t)p->n0 * p->n1;
-  if (p->profiling) HIP_TRY(hipEventRecord(p->stage_ev[0], p->stream));
-  HIP_TRY(launch_mean(p->dtype, image, npx, p->d_scratch, p->d_mean, p->stream));
-  void* lk = lockins ? lockins : p->d_lockin;
-  TRY(sweep_peaks_dev(p, image, p->d_mean, kvecs, P, klists, K, sigma, lk, kidx));
+// host-side preparation: filter / carrier / k-matrix tables (re-staged only when they change; these upload
+// synchronously), the x-plane buffer, and the second unwrap workspace + stream
+static int extract_stage(gpa_plan* p, const double* kvecs, int P, const double* klists, int K, double sigma, int* Bx) {
+  const int B = P * K;
+  TRY(ensure_filters(p, sigma));
+  std::vector<double> kr((size_t)B * 2);
+  for (int pp = 0; pp < P; ++pp)
+    for (int k = 0; k < K; ++k) {
+      kr[2 * ((size_t)pp * K + k)] = kvecs[2 * pp];
+      kr[2 * ((size_t)pp * K + k) + 1] = kvecs[2 * pp + 1];
+    }
+  TRY(stage_kvectors(p, klists, kr.data(), B, Bx));
+  TRY(ensure_tbuf(p, *Bx));
   TRY(stage_kmat(p, kvecs, P));
   if (!p->stream2) {
     // the two displacement components are independent solves: give the second one its own
@@ -626,6 +688,20 @@ static int extract_enqueue(gpa_plan* p, const void* image, const double* kvecs, 
     if (e2 != hipSuccess) return fail(GPA_ERR_HIP, std::string("second unwrap workspace: ") + hipGetErrorString(e2));
     p->ws_bytes += b2;
   }
+  return GPA_OK;
+}
+
+// every launch of the driver, nothing else: this is what a hipGraph of the call holds
+static int extract_launch(gpa_plan* p, const void* image, int P, int K, int Bx, int mask_border, int kmax, void* u,
+                          void* lk, int32_t* kidx) {
+  const size_t npx = (size_t)p->n0 * p->n1;
+  if (p->profiling) HIP_TRY(hipEventRecord(p->stage_ev[0], p->stream));
+  HIP_TRY(launch_mean(p->dtype, image, npx, p->d_scratch, p->d_mean, p->stream));
+  if (p->profiling) HIP_TRY(hipEventRecord(p->stage_ev[1], p->stream));
+  HIP_TRY(launch_passA(p->dtype, p->ax0, p->n1, image, p->d_mean, p->tb, p->Hx, p->tw0, p->Tbuf, Bx, p->stream));
+  if (p->profiling) HIP_TRY(hipEventRecord(p->stage_ev[2], p->stream));
+  HIP_TRY(launch_passB(p->dtype, p->ax1, p->n0, p->Tbuf, p->Hy, p->tw1, p->tb, P, K, true, lk, kidx, p->stream));
+  if (p->profiling) HIP_TRY(hipEventRecord(p->stage_ev[3], p->stream));
   // phases / weights / per-pixel least squares fused with the unwrap's set-up: the gradient fields never
   // go to HBM, the kernel leaves r0 of both components in the two unwrap workspaces
   int nparts = 0;
@@ -636,7 +712,7 @@ static int extract_enqueue(gpa_plan* p, const void* image, const double* kvecs, 
   HIP_TRY(hipEventRecord(p->ev_fork, p->stream));
   HIP_TRY(hipStreamWaitEvent(p->stream2, p->ev_fork, 0));
   hipError_t e = unwrap_enqueue_prepared(&p->uw, p->d_wnorm, nparts, kmax, 1e-9, true, u, p->stream);
-  if (getenv("GPA_SERIAL_UNWRAP")) {   // diagnostic: run the second component after the first (clean per-kernel timings)
+  if (p->profiling || p->serial_unwrap) {   // per-kernel timings: run the second component after the first
     HIP_TRY(hipEventRecord(p->ev_fork, p->stream));
     HIP_TRY(hipStreamWaitEvent(p->stream2, p->ev_fork, 0));
   }
@@ -648,6 +724,87 @@ static int extract_enqueue(gpa_plan* p, const void* image, const double* kvecs, 
   HIP_TRY(hipEventRecord(p->ev_join, p->stream2));
   HIP_TRY(hipStreamWaitEvent(p->stream, p->ev_join, 0));
   if (p->profiling) HIP_TRY(hipEventRecord(p->stage_ev[5], p->stream));
+  return GPA_OK;
+}
+
+static void drop_graphs(gpa_plan* p) {
+  if (p->graphs.empty()) return;
+  (void)hipStreamSynchronize(p->stream);   // an executable graph may still be running
+  for (auto& g : p->graphs) {
+    if (g.exec) hipGraphExecDestroy(g.exec);
+    if (g.graph) hipGraphDestroy(g.graph);
+  }
+  p->graphs.clear();
+}
+
+// enqueue the whole driver on the plan's streams without any host synchronisation.
+// A call is ~110 dependent kernel launches; small images are bound by the host's launch rate, not by the
+// kernels.  The launches of a call depend only on (pointers, P, K, x-planes, border, kmax) -- the tables the
+// kernels read are restaged in place by extract_stage -- so the second call with the same key captures them
+// into a hipGraph (both streams) and later calls replay it: one host call per image instead of ~110.
+static int extract_enqueue(gpa_plan* p, const void* image, const double* kvecs, int P, const double* klists, int K,
+                           double sigma, int mask_border, int kmax, void* u, void* lockins, int32_t* kidx) {
+  if (!p || !image || !kvecs || !klists || !u) return fail(GPA_ERR_ARG, "gpa_extract_displacement_field: null argument");
+  if (P < 2 || P > p->max_peaks) return fail(GPA_ERR_STATE, "gpa_extract_displacement_field: need 2 <= P <= 8");
+  if (K < 1 || P * K > p->max_batch) return fail(GPA_ERR_STATE, "gpa_extract_displacement_field: P*K exceeds max_batch");
+  if (kmax < 1) return fail(GPA_ERR_ARG, "kmax must be >= 1");
+  HIP_TRY(hipSetDevice(p->device));
+  int Bx = 0;
+  TRY(extract_stage(p, kvecs, P, klists, K, sigma, &Bx));
+  void* lk = lockins ? lockins : p->d_lockin;
+  // per-kernel event pairs while profiling (installed for this thread until the function returns)
+  struct ProfGuard { ~ProfGuard() { g_kprof = nullptr; } } prof_guard;
+  if (p->profiling) {
+    if (!p->kprof) p->kprof = new KernelProfiler();
+    p->kprof->n = 0;
+    g_kprof = p->kprof;
+  }
+  if (p->profiling || !p->use_graphs) return extract_launch(p, image, P, K, Bx, mask_border, kmax, u, lk, kidx);
+  const GraphKey key = {image, u, lk, kidx, P, K, Bx, mask_border, kmax, p->tbuf_epoch};
+  GraphEntry* ent = nullptr;
+  for (auto& g : p->graphs)
+    if (memcmp(&g.key, &key, sizeof(GraphKey)) == 0) ent = &g;
+  if (ent && ent->exec) {
+    HIP_TRY(hipGraphLaunch(ent->exec, p->stream));
+    return GPA_OK;
+  }
+  if (!ent) {
+    // first call with this key: run eagerly (lazy allocations and function attributes happen here)
+    if (p->graphs.size() >= 8) drop_graphs(p);
+    GraphEntry g{};
+    g.key = key;
+    p->graphs.push_back(g);
+    return extract_launch(p, image, P, K, Bx, mask_border, kmax, u, lk, kidx);
+  }
+  if (ent->failed) return extract_launch(p, image, P, K, Bx, mask_border, kmax, u, lk, kidx);
+  // second call: capture
+  hipError_t ce = hipStreamBeginCapture(p->stream, hipStreamCaptureModeRelaxed);
+  if (ce != hipSuccess) {
+    (void)hipGetLastError();
+    ent->failed = true;
+    return extract_launch(p, image, P, K, Bx, mask_border, kmax, u, lk, kidx);
+  }
+  const int rc = extract_launch(p, image, P, K, Bx, mask_border, kmax, u, lk, kidx);
+  hipGraph_t graph = nullptr;
+  ce = hipStreamEndCapture(p->stream, &graph);
+  if (rc != GPA_OK || ce != hipSuccess || !graph) {
+    (void)hipGetLastError();
+    if (graph) hipGraphDestroy(graph);
+    ent->failed = true;
+    if (rc != GPA_OK) return rc;
+    return extract_launch(p, image, P, K, Bx, mask_border, kmax, u, lk, kidx);
+  }
+  hipGraphExec_t exec = nullptr;
+  ce = hipGraphInstantiate(&exec, graph, nullptr, nullptr, 0);
+  if (ce != hipSuccess || !exec) {
+    (void)hipGetLastError();
+    hipGraphDestroy(graph);
+    ent->failed = true;
+    return extract_launch(p, image, P, K, Bx, mask_border, kmax, u, lk, kidx);
+  }
+  ent->graph = graph;
+  ent->exec = exec;
+  HIP_TRY(hipGraphLaunch(exec, p->stream));
   return GPA_OK;
 }
 
@@ -670,8 +827,29 @@ int gpa_extract_displacement_field_dev(gpa_plan* p, const void* image, const dou
                                        void* u, void* lockins, int32_t* kidx, int* iters_out) {
   TRY(extract_enqueue(p, image, kvecs, P, klists, K, sigma, mask_border, kmax, u, lockins, kidx));
   HIP_TRY(hipStreamSynchronize(p->stream));
-  if (p->profiling)
+  if (p->profiling) {
     for (int i = 0; i < 5; ++i) hipEventElapsedTime(&p->stage_ms[i], p->stage_ev[i], p->stage_ev[i + 1]);
+    // sum the per-kernel event pairs by name, in order of first appearance
+    std::vector<std::string> names;
+    std::vector<int> calls;
+    std::vector<double> total;
+    for (int i = 0; p->kprof && i < p->kprof->n; ++i) {
+      const KernelProfiler::Rec& r = p->kprof->rec[i];
+      float ms = 0.f;
+      if (hipEventElapsedTime(&ms, r.a, r.b) != hipSuccess) continue;
+      size_t j = 0;
+      while (j < names.size() && names[j] != r.name) ++j;
+      if (j == names.size()) { names.push_back(r.name); calls.push_back(0); total.push_back(0.0); }
+      ++calls[j];
+      total[j] += ms;
+    }
+    p->kprof_table.clear();
+    char line[160];
+    for (size_t j = 0; j < names.size(); ++j) {
+      snprintf(line, sizeof(line), "%s %d %.6f\n", names[j].c_str(), calls[j], total[j]);
+      p->kprof_table += line;
+    }
+  }
   if (iters_out) { iters_out[0] = p->h_iters[0]; iters_out[1] = p->h_iters[1]; }
   return GPA_OK;
 }
@@ -815,9 +993,9 @@ static int per_dft_staged(gpa_plan* p) {
     if (e != hipSuccess) return fail(GPA_ERR_HIP, std::string("gpa_per_dft tables: ") + hipGetErrorString(e));
     p->ws_bytes += b;
   }
-  // border-difference vectors live in the (otherwise idle) compensation tables: dy >= n1, dx >= n0 complex
-  void* d0 = p->tb.dy;
-  void* d1 = p->tb.dx;
+  // border-difference vectors: d0 holds n1, d1 holds n0 complex values
+  void* d0 = p->d_aux1;
+  void* d1 = p->d_aux0;
   HIP_TRY(per_pack(p->dtype, p->d_image, p->n0, p->n1, p->Tbuf, d0, d1, p->stream));
   HIP_TRY(dft2_inplace(p->dtype, p->bx0, p->bx1, p->Tbuf, p->stream));
   HIP_TRY(dft_rows_inplace(p->dtype, p->bx1, 1, d0, p->stream));
@@ -916,10 +1094,10 @@ int gpa_gaussian_deconvolve(gpa_plan* p, const void* data, int dr, double sigma,
     p->ws_bytes += b;
   }
   hipStream_t st = p->stream;
-  // k-space Gaussian factors (doubles) in the idle compensation tables: dx holds >= n0, dy >= n1 complex
+  // k-space Gaussian factors (doubles)
   std::vector<double> gx = gaussian_kspace(n0, sigma), gy = gaussian_kspace(n1, sigma);
-  double* d_gx = reinterpret_cast<double*>(p->tb.dx);
-  double* d_gy = reinterpret_cast<double*>(p->tb.dy);
+  double* d_gx = reinterpret_cast<double*>(p->d_aux0);
+  double* d_gy = reinterpret_cast<double*>(p->d_aux1);
   HIP_TRY(hipMemcpyAsync(d_gx, gx.data(), (size_t)n0 * sizeof(double), hipMemcpyHostToDevice, st));
   HIP_TRY(hipMemcpyAsync(d_gy, gy.data(), (size_t)n1 * sizeof(double), hipMemcpyHostToDevice, st));
   HIP_TRY(hipMemcpyAsync(p->d_image, data, (size_t)m0 * m1 * p->rsz, hipMemcpyHostToDevice, st));
@@ -953,6 +1131,7 @@ int gpa_phasegradient2J(gpa_plan* p, const double* kvecs, int P, const void* gra
   if (P < 2 || P > p->max_peaks) return fail(GPA_ERR_STATE, "gpa_phasegradient2J: need 2 <= P <= 8 (and P <= max_batch)");
   HIP_TRY(hipSetDevice(p->device));
   const size_t npx = (size_t)p->n0 * p->n1;
+  TRY(ensure_tbuf(p, (P + 1) / 2));
   void* d_J = nullptr;
   HIP_TRY(hipMalloc(&d_J, 4 * npx * p->rsz));
   int rc = GPA_OK;
@@ -1068,6 +1247,39 @@ int gpa_set_profiling(gpa_plan* p, int on) {
   p->profiling = on != 0;
   return GPA_OK;
 }
+int gpa_last_kernel_profile(gpa_plan* p, char* out, size_t cap) {
+  if (!p || !out || cap == 0) return fail(GPA_ERR_ARG, "null argument");
+  if (p->kprof_table.size() + 1 > cap) return fail(GPA_ERR_STATE, "gpa_last_kernel_profile: buffer too small");
+  memcpy(out, p->kprof_table.c_str(), p->kprof_table.size() + 1);
+  return GPA_OK;
+}
+
+// ---- downloads overlapped with later work --------------------------------------------------
+int gpa_download_async(gpa_plan* p, void* host_dst, const void* dev_src, size_t bytes, int slot) {
+  if (!p || !host_dst || !dev_src) return fail(GPA_ERR_ARG, "gpa_download_async: null argument");
+  if (slot < 0 || slot >= 4) return fail(GPA_ERR_ARG, "gpa_download_async: slot must be 0..3");
+  HIP_TRY(hipSetDevice(p->device));
+  if (!p->copy_stream) {
+    HIP_TRY(hipStreamCreateWithFlags(&p->copy_stream, hipStreamNonBlocking));
+    HIP_TRY(hipEventCreateWithFlags(&p->ev_dl_ready, hipEventDisableTiming));
+    for (auto& e : p->ev_dl_done) HIP_TRY(hipEventCreateWithFlags(&e, hipEventDisableTiming));
+  }
+  // after everything enqueued on the plan so far (the driver leaves its second stream joined into the first)
+  HIP_TRY(hipEventRecord(p->ev_dl_ready, p->stream));
+  HIP_TRY(hipStreamWaitEvent(p->copy_stream, p->ev_dl_ready, 0));
+  HIP_TRY(hipMemcpyAsync(host_dst, dev_src, bytes, hipMemcpyDeviceToHost, p->copy_stream));
+  HIP_TRY(hipEventRecord(p->ev_dl_done[slot], p->copy_stream));
+  return GPA_OK;
+}
+
+int gpa_download_wait(gpa_plan* p, int slot) {
+  if (!p) return fail(GPA_ERR_ARG, "null plan");
+  if (slot < 0 || slot >= 4) return fail(GPA_ERR_ARG, "gpa_download_wait: slot must be 0..3");
+  if (!p->copy_stream) return GPA_OK;   // nothing was ever enqueued
+  HIP_TRY(hipEventSynchronize(p->ev_dl_done[slot]));
+  return GPA_OK;
+}
+
 int gpa_last_stage_ms(gpa_plan* p, float* ms5) {
   if (!p || !ms5) return fail(GPA_ERR_ARG, "null argument");
   for (int i = 0; i < 5; ++i) ms5[i] = p->stage_ms[i];

@@ -7,6 +7,40 @@
 
 namespace gpa {
 
+// ---- per-kernel timing (bench.py's per-kernel rooflines) ----------------------------------------
+// While a KernelProfiler is installed on the calling thread (gpa_set_profiling), every launch site of
+// the fused driver brackets its kernel with a pair of HIP events on the stream it launches on; the
+// driver sums the pairs by kernel name after synchronising.  No profiler installed = two pointer tests.
+struct KernelProfiler {
+  struct Rec { const char* name; hipEvent_t a, b; };
+  static constexpr int MAXREC = 4096;
+  Rec rec[MAXREC];
+  int n = 0;
+  hipEvent_t pool[2 * MAXREC];
+  int npool = 0;
+};
+extern thread_local KernelProfiler* g_kprof;
+struct ProfScope {
+  hipStream_t s;
+  KernelProfiler::Rec* r = nullptr;
+  ProfScope(const char* name, hipStream_t stream) : s(stream) {
+    KernelProfiler* k = g_kprof;
+    if (!k || k->n >= KernelProfiler::MAXREC) return;
+    for (int j = 0; j < 2; ++j)
+      if (k->npool < 2 * (k->n + 1)) { if (hipEventCreate(&k->pool[k->npool]) != hipSuccess) return; ++k->npool; }
+    r = &k->rec[k->n];
+    r->name = name;
+    r->a = k->pool[2 * k->n];
+    r->b = k->pool[2 * k->n + 1];
+    ++k->n;
+    (void)hipEventRecord(r->a, s);
+  }
+  ~ProfScope() { if (r) (void)hipEventRecord(r->b, s); }
+};
+#define GPA_PROF_CAT2(a, b) a##b
+#define GPA_PROF_CAT(a, b) GPA_PROF_CAT2(a, b)
+#define GPA_PROF(name, stream) ::gpa::ProfScope GPA_PROF_CAT(_gpa_prof_, __LINE__)(name, stream)
+
 // One image axis: n samples, transformed with a power-of-two FFT of length L.
 // n == L  : periodic mode, the k-space Gaussian is applied bin by bin.
 // n <  L  : padded mode (L >= 2n-1): the circular convolution of length n is

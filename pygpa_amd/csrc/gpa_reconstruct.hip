@@ -294,6 +294,7 @@ static hipError_t launch_reconstruct_setup_t(const void* lockin, const double* k
                                              hipStream_t s) {
   dim3 grid((n1 + 4 * FUSED_COLS - 1) / (4 * FUSED_COLS), (n0 + FUSED_ROWS - 1) / FUSED_ROWS);
   *nparts = (int)(grid.x * grid.y);
+  GPA_PROF("reconstruct_setup_kernel", s);
 #define RS_CASE(PP)                                                                                                   \
   case PP:                                                                                                            \
     reconstruct_setup_kernel<T, PP><<<grid, 256, 0, s>>>((const cpx<T>*)lockin, kmat, n0, n1, border, (T*)wnorm,       \

@@ -16,6 +16,8 @@
 
 namespace gpa {
 
+thread_local KernelProfiler* g_kprof = nullptr;
+
 // ---------------------------------------------------------------------------
 // carrier / compensation tables, computed in double on the device
 // ---------------------------------------------------------------------------
@@ -107,6 +109,7 @@ __global__ void mean_final_kernel(const double* partial, int nparts, size_t coun
 hipError_t launch_mean(int dtype, const void* image, size_t count, double* scratch,
                        void* mean_out, hipStream_t s) {
   const int nparts = 1024;
+  GPA_PROF("mean_kernels", s);
   if (dtype == 0) {
     mean_partial_kernel<float><<<nparts, 256, 0, s>>>((const float*)image, count, scratch);
     mean_final_kernel<float><<<1, 256, 0, s>>>(scratch, nparts, count, (float*)mean_out);
@@ -435,6 +438,7 @@ static hipError_t run_passA(const Axis& a0, int n1, const void* image, const voi
     if (ysplit > B) ysplit = B;
     const int bchunk = (B + ysplit - 1) / ysplit;
     dim3 grid(tiles, (B + bchunk - 1) / bchunk);
+    GPA_PROF("passA_kernel", s);
     kern<<<grid, G::THREADS, G::LDS_BYTES, s>>>(
         (const T*)image, (const T*)mean, a0.n, n1, (const cpx<T>*)tb.cxb, (const cpx<T>*)tb.sx,
         (const cpx<T>*)tb.wxw,
@@ -456,6 +460,7 @@ static hipError_t run_passB(const Axis& a1, int n0, const void* Tbuf, const void
                                        hipFuncAttributeMaxDynamicSharedMemorySize, (int)G::LDS_BYTES);
     if (e != hipSuccess) return e;
     dim3 grid((n0 + G::NF - 1) / G::NF, P);
+    GPA_PROF("passB_kernel", s);
     kern<<<grid, G::THREADS, G::LDS_BYTES, s>>>(
         (const cpx<T>*)Tbuf, n0, a1.n, (const typename HType<PADDED, T>::type*)Hy,
         (const cpx<T>*)tw1, tb.planeof, (const cpx<T>*)tb.cyb, (const cpx<T>*)tb.sy, (const cpx<T>*)tb.wyw,

@@ -1208,6 +1208,7 @@ hipError_t run_colsolve(const Impl* w, int compat, hipStream_t s, const double* 
     if (e != hipSuccess) return e;
     const int npairs = w->n1 / 2, grid = (npairs + G::CC - 1) / G::CC;
     if (nrho) *nrho = grid;
+    GPA_PROF("colsolve_kernel", s);
     kern<<<grid, G::THREADS, G::LDS_BYTES, s>>>((T*)w->z, w->n1, (const cpx<T>*)w->tw0, (const cpx<T>*)w->wk0s,
                                                  (const T*)w->ha0[compat], (const T*)w->ham0[compat],
                                                  (const T*)w->hb1[compat], w->flags, part_norm, nnorm, it, eps, w->scal,
@@ -1227,6 +1228,7 @@ hipError_t run_rowdct_fused(const Impl* w, const void* q, int ring, const double
     if (e != hipSuccess) return e;
     const int npairs = w->n0 / 2, grid = (npairs + G::NF - 1) / G::NF;
     *nnorm = grid;
+    GPA_PROF("rowdct_fused_kernel", s);
     kern<<<grid, G::THREADS, G::LDS_BYTES, s>>>((T*)w->r, (const T*)q, w->n0, (const cpx<T>*)w->tw1,
                                                  (const cpx<T>*)w->wk1, w->flags, part_pq, npq, part_norm, w->scal, it,
                                                  ring);
@@ -1251,6 +1253,7 @@ hipError_t run_rowidct_p(const Impl* w, const void* pin, void* pout, const doubl
                                        (int)G::LDS_BYTES);
     if (e != hipSuccess) return e;
     const int npairs = w->n0 / 2, grid = (npairs + G::NF - 1) / G::NF;
+    GPA_PROF("rowidct_p_kernel", s);
     kern<<<grid, G::THREADS, G::LDS_BYTES, s>>>((const T*)w->z, (const T*)pin, (T*)pout, w->n0, (const cpx<T>*)w->tw1,
                                                  (const cpx<T>*)w->wk1, w->flags, part_rho, nrho, w->scal, it);
     return hipGetLastError();
@@ -1588,6 +1591,7 @@ static hipError_t run_pcg(Impl* w, const void* a, const void* b, const void* wei
     // other paths update phi in place and need it cleared
     const bool fused_path = !w->generic && (n1 % 4) == 0;
     if (!fused_path && (e = hipMemsetAsync(phi, 0, npx * w->rsz, s)) != hipSuccess) return e;
+    GPA_PROF("scalar_kernels", s);
     scal_init_kernel<<<1, 256, 0, s>>>(w->part, w->prepared_parts, w->scal, w->flags);
   }
   const bool vec4 = !w->generic && (n1 % 4) == 0;   // pq_kernel needs 16-byte aligned rows
@@ -1612,8 +1616,9 @@ static hipError_t run_pcg(Impl* w, const void* a, const void* b, const void* wei
     for (int j = 0; j < RING_MAX; ++j) rp.p[j] = (const T*)w->ring[j < ring ? j : 0];
     bool phi_unwritten = a == nullptr;   // prepared start: nobody has zeroed phi
     auto flush = [&]() {
-      phi_flush_kernel<T><<<gl, 256, 0, s>>>(rp, ring, (T*)phi, npx / 4, w->scal, w->flags, phi_unwritten ? 1 : 0);
-      phi_commit_kernel<<<1, 1, 0, s>>>(w->flags);
+      { GPA_PROF("phi_flush_kernel", s);
+        phi_flush_kernel<T><<<gl, 256, 0, s>>>(rp, ring, (T*)phi, npx / 4, w->scal, w->flags, phi_unwritten ? 1 : 0); }
+      { GPA_PROF("scalar_kernels", s); phi_commit_kernel<<<1, 1, 0, s>>>(w->flags); }
       phi_unwritten = false;
     };
     int nnorm = 0;
@@ -1625,11 +1630,13 @@ static hipError_t run_pcg(Impl* w, const void* a, const void* b, const void* wei
       const T* pin = (const T*)w->ring[(it + ring - 1) % ring];
       T* pout = (T*)w->ring[it % ring];
       if ((e = dispatch_rowidct_p(w, pin, pout, part_rho, nrow, it, s)) != hipSuccess) return e;
-      pq_kernel<T, true><<<gpq, 256, 0, s>>>(pout, nullptr, nullptr, (const T*)weight, n0, n1, (T*)w->q, part_pq,
-                                             w->scal, w->flags, nullptr, 0, it, band);
+      { GPA_PROF("pq_kernel", s);
+        pq_kernel<T, true><<<gpq, 256, 0, s>>>(pout, nullptr, nullptr, (const T*)weight, n0, n1, (T*)w->q, part_pq,
+                                               w->scal, w->flags, nullptr, 0, it, band); }
     }
-    final_alpha_kernel<<<1, 256, 0, s>>>(w->scal, part_pq, npq, kmax, ring, w->flags);
-    final_count_kernel<<<1, 1, 0, s>>>(w->flags, kmax);
+    { GPA_PROF("scalar_kernels", s);
+      final_alpha_kernel<<<1, 256, 0, s>>>(w->scal, part_pq, npq, kmax, ring, w->flags);
+      final_count_kernel<<<1, 1, 0, s>>>(w->flags, kmax); }
     flush();
     return hipGetLastError();
   }

@@ -169,57 +169,165 @@ def _tiled_device(image, kvecs, klists, sigma, halo, kmax, dtype, device, group,
             b.free()
         return u
 
-    torch, dist = _dist()
-    dev = torch.device('cuda', device)
-    t_dt = torch.float32 if dtype == np.float32 else torch.float64
-    multi = world > 1
-    per_rank = (len(tiles) + world - 1) // world
-    local = torch.zeros((per_rank, 5, t0, t1), dtype=t_dt, device=dev)
-    # a rank uploads only the windows of its own tiles (1/N of the image plus halos), one after the other;
-    # the mean of the WHOLE image that every tile is offset by (geometric_phase_analysis.py:919) is the host's
-    mean = float(img.mean(dtype=np.float64))
-    t_win = torch.empty(wshape, dtype=t_dt, device=dev)
-    torch.cuda.synchronize(dev)          # the plans run on their own streams
-    plane = t0 * t1
-    for slot, idx in enumerate(range(rank, len(tiles), world)):
-        _, (w0, w1), (o0, o1), (z0, z1) = tiles[idx]
-        plan_w.sync()                    # the previous tile has consumed the window buffer
-        t_win.copy_(torch.from_numpy(np.ascontiguousarray(img[w0, w1])))
-        torch.cuda.synchronize(dev)
-        base = local[slot].data_ptr()
-        plan_w.tile_gradients_dev(t_win.data_ptr(), wshape[1], 0, 0, mean, kvecs, klists, sigma, border,
-                                  (o0, o1, z0, z1), (base, t1, plane), (base + 2 * plane * rsz, t1, plane),
-                                  (base + 4 * plane * rsz, t1))
-    plan_w.sync()
-    # --- collective 1 (RCCL all_gather over xGMI): compact gradient tiles of every rank
-    if multi:
-        gathered = torch.empty((world,) + tuple(local.shape), dtype=t_dt, device=dev)
-        dist.all_gather_into_tensor(gathered, local, group=group)
-    else:
-        gathered = local[None]
-    full = torch.empty((5, n0, n1), dtype=t_dt, device=dev)
-    for idx, ((i, j), _, _, (z0, z1)) in enumerate(tiles):
-        full[:, i * t0:i * t0 + z0, j * t1:j * t1 + z1] = gathered[idx % world, idx // world, :, :z0, :z1]
-    del gathered, local, t_win
-    # --- global unwrap, one component per rank; collective 2 distributes the components
-    mine = torch.zeros((2, n0, n1), dtype=t_dt, device=dev)
-    todo = [c for c in range(2) if c % world == rank]
-    if todo:
-        w = full[4]
-        plan_g = _lib.get_plan(image.shape, 1, dtype, device)
-        for c in todo:
-            dx = full[c, :, :-1].contiguous()
-            dy = full[2 + c, :-1, :]
-            torch.cuda.synchronize(dev)
-            plan_g.unwrap_prediff_dev(dx.data_ptr(), dy.data_ptr(), w.data_ptr(), mine[c].data_ptr(), kmax=kmax)
-    torch.cuda.synchronize(dev)
-    if multi:
-        parts = torch.empty((world, 2, n0, n1), dtype=t_dt, device=dev)
-        dist.all_gather_into_tensor(parts, mine, group=group)
-        u = torch.stack([parts[c % world, c] for c in range(2)])
-    else:
-        u = mine
-    return u.cpu().numpy()
+    pipe = TiledPipeline(image.shape, kvecs, klists, sigma, halo, kmax, dtype, device, group, tiles=tiles,
+                         tshape=tshape, wshape=wshape)
+    pipe.load(img)
+    u = pipe.step().cpu().numpy()
+    pipe.close()
+    return u
+
+
+class TiledPipeline:
+    """Device-resident tile pipeline of one rank (module docstring), reusable over many images of one shape.
+
+    `load(image)` uploads this rank's windows (1/N of the image plus halos); `step()` runs
+      all_reduce of the tile-interior sums (the mean of the WHOLE image that every window is offset by,
+      geometric_phase_analysis.py:919; one scalar) -> tile stage (sweep + least squares per window, C ABI)
+      -> all_gather #1 of the gradient tiles -> stitch -> global unwrap of component c on rank c % N
+      -> broadcast of each component
+    and returns the stitched (2, N, M) field as a device tensor that every rank holds.  Buffers are torch
+    tensors (device memory + collectives are what torch is here for); with the "nccl" backend the
+    collectives run on them over RCCL/xGMI, with "gloo" (CPU tests, two ranks sharing a GPU) they are
+    staged through the host."""
+
+    def __init__(self, shape, kvecs, klists, sigma, halo, kmax=10, dtype=np.float32, device=0, group=None,
+                 grid=None, window=None, tiles=None, tshape=None, wshape=None):
+        from . import _lib
+        torch, dist = _dist()
+        self.torch, self.dist, self.group = torch, dist, group
+        self.world, self.rank = 1, 0
+        self.backend = None
+        if _initialized():
+            self.world, self.rank = dist.get_world_size(group), dist.get_rank(group)
+            self.backend = dist.get_backend(group)
+        self.shape = (int(shape[0]), int(shape[1]))
+        self.kvecs = np.asarray(kvecs, dtype=np.float64).reshape(-1, 2)
+        self.klists = np.asarray(klists, dtype=np.float64)
+        self.sigma, self.kmax = sigma, int(kmax)
+        self.border = 2 * int(sigma)
+        self.dtype = np.dtype(dtype)
+        self.device = int(device)
+        if tiles is None:
+            tiles, tshape, wshape = tile_plan(self.shape, grid, halo, window)
+        self.tiles, self.tshape, self.wshape = tiles, tuple(tshape), tuple(wshape)
+        self.mine = list(range(self.rank, len(tiles), self.world))
+        self.per_rank = (len(tiles) + self.world - 1) // self.world
+        P, K = self.klists.shape[:2]
+        self.plan_w = _lib.get_plan(self.wshape, P * K, self.dtype, self.device)
+        self.unwrappers = [c for c in range(2) if c % self.world == self.rank]
+        self.plan_g = _lib.get_plan(self.shape, 1, self.dtype, self.device) if self.unwrappers else None
+        dev = torch.device('cuda', self.device)
+        self.dev = dev
+        t_dt = torch.float32 if self.dtype == np.float32 else torch.float64
+        n0, n1 = self.shape
+        t0, t1 = self.tshape
+        self.wins = torch.zeros((max(len(self.mine), 1),) + self.wshape, dtype=t_dt, device=dev)
+        self.local = torch.zeros((self.per_rank, 5, t0, t1), dtype=t_dt, device=dev)
+        self.gathered = torch.zeros((self.world, self.per_rank, 5, t0, t1), dtype=t_dt, device=dev)
+        self.gdx = torch.zeros((2, n0, n1 - 1), dtype=t_dt, device=dev)
+        self.gdy = torch.zeros((2, n0 - 1, n1), dtype=t_dt, device=dev)
+        self.gw = torch.zeros((n0, n1), dtype=t_dt, device=dev)
+        self.u = torch.zeros((2, n0, n1), dtype=t_dt, device=dev)
+        self.sums = torch.zeros(1, dtype=torch.float64, device=dev)
+        self.mean = None
+        self.iters = [0, 0]
+
+    # ---- collectives (device tensors on RCCL, host-staged on gloo) -------------------------------
+    def _host_staged(self):
+        return self.backend is not None and self.backend != 'nccl'
+
+    def _all_reduce_sum(self, t):
+        if self.world == 1:
+            return t
+        if self._host_staged():
+            h = t.cpu()
+            self.dist.all_reduce(h, group=self.group)
+            t.copy_(h)
+        else:
+            self.dist.all_reduce(t, group=self.group)
+        return t
+
+    def _all_gather(self, out, t):
+        if self.world == 1:
+            out[0].copy_(t)
+        elif self._host_staged():
+            h = out.cpu()
+            self.dist.all_gather_into_tensor(h, t.cpu().contiguous(), group=self.group)
+            out.copy_(h)
+        else:
+            self.dist.all_gather_into_tensor(out, t, group=self.group)
+
+    def _broadcast(self, t, src):
+        if self.world == 1:
+            return
+        src_global = src if self.group is None else self.dist.get_global_rank(self.group, src)
+        if self._host_staged():
+            h = t.cpu()
+            self.dist.broadcast(h, src_global, group=self.group)
+            if self.rank != src:
+                t.copy_(h)
+        else:
+            self.dist.broadcast(t, src_global, group=self.group)
+
+    # ---- data ------------------------------------------------------------------------------------
+    def load(self, image=None, window_fn=None):
+        """upload this rank's windows: from the full `image` (every rank passes the same array) or from
+        `window_fn(slice0, slice1)` that produces the pixels of one window (so that no rank needs the
+        whole image in host memory)."""
+        torch = self.torch
+        for slot, idx in enumerate(self.mine):
+            _, (w0, w1), _, _ = self.tiles[idx]
+            win = window_fn(w0, w1) if window_fn is not None else image[w0, w1]
+            self.wins[slot].copy_(torch.from_numpy(np.ascontiguousarray(win, dtype=self.dtype)))
+        torch.cuda.synchronize(self.dev)
+
+    def image_mean(self):
+        """mean of the whole image: every pixel lies in exactly one tile interior, so the ranks add up the
+        sums over their interiors (device reductions, then one all_reduce of a scalar)"""
+        torch = self.torch
+        self.sums.zero_()
+        for slot, idx in enumerate(self.mine):
+            _, _, (o0, o1), (z0, z1) = self.tiles[idx]
+            self.sums += self.wins[slot, o0:o0 + z0, o1:o1 + z1].sum(dtype=torch.float64)
+        self._all_reduce_sum(self.sums)
+        return float(self.sums.item()) / (self.shape[0] * self.shape[1])
+
+    def step(self):
+        torch = self.torch
+        n0, n1 = self.shape
+        t0, t1 = self.tshape
+        rsz = self.dtype.itemsize
+        plane = t0 * t1
+        self.mean = self.image_mean()             # (.item() synchronises: the plans run on their own streams)
+        for slot, idx in enumerate(self.mine):
+            _, _, (o0, o1), (z0, z1) = self.tiles[idx]
+            base = self.local[slot].data_ptr()
+            self.plan_w.tile_gradients_dev(self.wins[slot].data_ptr(), self.wshape[1], 0, 0, self.mean, self.kvecs,
+                                           self.klists, self.sigma, self.border, (o0, o1, z0, z1),
+                                           (base, t1, plane), (base + 2 * plane * rsz, t1, plane),
+                                           (base + 4 * plane * rsz, t1))
+        self.plan_w.sync()
+        # --- collective 1 (RCCL all_gather over xGMI): compact gradient tiles of every rank
+        self._all_gather(self.gathered, self.local)
+        for idx, ((i, j), _, _, (z0, z1)) in enumerate(self.tiles):
+            src = self.gathered[idx % self.world, idx // self.world]
+            r0, c0 = i * t0, j * t1
+            zx, zy = min(z1, n1 - 1 - c0), min(z0, n0 - 1 - r0)
+            self.gdx[:, r0:r0 + z0, c0:c0 + zx] = src[0:2, :z0, :zx]
+            self.gdy[:, r0:r0 + zy, c0:c0 + z1] = src[2:4, :zy, :z1]
+            self.gw[r0:r0 + z0, c0:c0 + z1] = src[4, :z0, :z1]
+        torch.cuda.synchronize(self.dev)
+        # --- global unwrap, component c on rank c % world; collective 2 hands each component to everybody
+        for c in self.unwrappers:
+            self.iters[c] = self.plan_g.unwrap_prediff_dev(self.gdx[c].data_ptr(), self.gdy[c].data_ptr(),
+                                                           self.gw.data_ptr(), self.u[c].data_ptr(), kmax=self.kmax)
+        for c in range(2):
+            self._broadcast(self.u[c], c % self.world)
+        return self.u
+
+    def close(self):
+        for name in ('wins', 'local', 'gathered', 'gdx', 'gdy', 'gw', 'u'):
+            setattr(self, name, None)
 
 
 def extract_displacement_field_tiled(image, kvecs, grid=None, sigma=None, kwscale=2.5, ksteps=3, klists=None,

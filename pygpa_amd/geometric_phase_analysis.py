@@ -101,29 +101,71 @@ def fftbounds(n, d=1):
     return np.append(r, r[-1] + 1 / (n * d))
 
 
-def _decrease_threshold(t):
-    """geometric_phase_analysis.py:388-394"""
-    if t > 0.001:
-        t = t - 0.1 if t >= 0.2 else t / 2
-    return t
+_THRESHOLD_FLOOR = 0.001
+
+
+def _lower_threshold(t):
+    """Next value of the reference's threshold schedule (geometric_phase_analysis.py:388-394): steps of 0.1
+    down to 0.2, then halving, frozen once at or below 0.001.  Returns None when frozen."""
+    if t <= _THRESHOLD_FLOOR:
+        return None
+    return t - 0.1 if t >= 0.2 else t / 2
 
 
 def smallest_sum(ks):
-    """Smallest sum of three k-vectors with one sign flipped (geometric_phase_analysis.py:538-548)."""
-    ks = np.asarray(ks)
+    """Shortest of -a+b+c, a-b+c, a+b-c for three k-vectors a, b, c -- zero for a closed triangle
+    (geometric_phase_analysis.py:538-548); NaN for anything but three vectors."""
+    ks = np.asarray(ks, dtype=np.float64)
     if len(ks) != 3:
         return np.nan
-    sums = (np.ones((3, 3)) - 2 * np.eye(3)) @ ks
-    return sums[np.argmin(np.linalg.norm(sums, axis=1))]
+    a, b, c = ks
+    flipped = np.stack([-a + b + c, a - b + c, a + b - c])
+    return flipped[np.argmin(np.sqrt((flipped * flipped).sum(axis=1)))]
 
 
 def select_closest_to_triangle(ks):
-    """The 3 k-vectors that come closest to a triangle (geometric_phase_analysis.py:529-535)."""
+    """The three k-vectors closest to forming a triangle (geometric_phase_analysis.py:529-535): the
+    3-subset, first in itertools.combinations order, whose `smallest_sum` is shortest.  Closed
+    triangles of grid frequencies tie at rounding level, so the lengths are taken exactly like the
+    reference takes them (np.linalg.norm of the 2-vector)."""
     from itertools import combinations
-    print(f"closest triangle: {ks}")
-    combis = list(combinations(ks, 3))
-    sums = [np.linalg.norm(smallest_sum(combi)) for combi in combis]
-    return np.array(combis[np.argmin(sums)])
+    ks = np.asarray(ks, dtype=np.float64)
+    best, best_defect = None, np.inf
+    for triple in combinations(range(len(ks)), 3):
+        defect = np.linalg.norm(smallest_sum(ks[list(triple)]))
+        if defect < best_defect:
+            best, best_defect = triple, defect
+    return ks[list(best)]
+
+
+def _peak_candidates(plan, image, sigma, dog, threshold, pix_norm_range):
+    """One evaluation of the array work of extract_primary_ks (device: gpa_find_peaks) plus the ring
+    selection and the +k / -k merge: (all_ks, pixel radii of the selected peaks, their heights)."""
+    peaks, heights = plan.find_peaks(image, sigma, 50.0 if dog else 0.0, threshold)
+    offset = peaks - np.array(image.shape) // 2
+    radius = np.sqrt((offset * offset).sum(axis=1))
+    ring = (radius > pix_norm_range[0]) & (radius < pix_norm_range[1])
+    peaks, radius, heights = peaks[ring], radius[ring], heights[ring]
+    freq = [fftbounds(n) for n in image.shape]
+    ks = np.stack([freq[0][peaks[:, 0]], freq[1][peaks[:, 1]]], axis=1) if len(peaks) else np.zeros((0, 2))
+    return remove_negative_duplicates(ks), radius, heights
+
+
+def _relaxed_parameters(n_found, radius, heights, threshold, sigma):
+    """The reference's answer to "fewer than three k-vectors" (geometric_phase_analysis.py:447-467) as a
+    pure function: the (threshold, sigma) to try next, or None when nothing is left to relax.
+    With no peak at all only the threshold can drop; otherwise, in this order: a peak closer to the
+    centre than 5 sigma narrows the smoothing to a sixth of that distance, a threshold above a fifth
+    of the highest selected peak drops to it, else the threshold follows its schedule."""
+    if n_found > 0:
+        nearest = radius.min()
+        if nearest < 5 * sigma:
+            return threshold, nearest / 6
+        fifth = 0.2 * np.max(heights)
+        if threshold > fifth:
+            return fifth, sigma
+    lower = _lower_threshold(threshold)
+    return None if lower is None else (lower, sigma)
 
 
 def extract_primary_ks(image, plot=False, threshold=0.7, pix_norm_range=(2, 200), sigma=1, NMPERPIXEL=1., DoG=True,
@@ -132,64 +174,29 @@ def extract_primary_ks(image, plot=False, threshold=0.7, pix_norm_range=(2, 200)
     (geometric_phase_analysis.py:397-505); returns (primary_ks, all_ks).
 
     The array work -- smooth + periodic DFT, |fftshift|, Gaussian / difference-of-Gaussians smoothing,
-    peak_local_max -- runs on the device (gpa_find_peaks); the bookkeeping on the handful of peaks and
-    the parameter recursion are the reference's, including that recursive calls fall back to DoG=True.
-    ``plot`` only switches the reference's debug printing here (no figure is drawn)."""
+    peak_local_max -- runs on the device (gpa_find_peaks).  The reference adapts (threshold, sigma) by
+    calling itself; every such call hands its result through unchanged, so the recursion is a chain,
+    written here as a relaxation loop: evaluate, and while fewer than three k-vectors come out move
+    to the next parameters (`_relaxed_parameters`; like the reference, every retry uses DoG=True).
+    Then: three k-vectors are the answer, more than three are reduced to the triple closest to a
+    triangle, fewer are returned as found.  ``plot`` only enables progress messages (no figure)."""
     image = np.asarray(image)
     plan = _plan(image, 1, dtype)
-    cindices, vals = plan.find_peaks(image, sigma, 50.0 if DoG else 0.0, threshold)
-    kxs, kys = [fftbounds(n) for n in image.shape]
-    center = np.array(image.shape) // 2
-    coords = cindices - center
-    norms = np.linalg.norm(coords, axis=1)
-    selection = np.logical_and(norms < pix_norm_range[1], norms > pix_norm_range[0])
-    cindices, coords, vals = cindices[selection], coords[selection], vals[selection]
-    all_ks = np.array([kxs[cindices.T[0]], kys[cindices.T[1]]]).T
-    all_ks = remove_negative_duplicates(all_ks)
-    newparams = False
-    if len(all_ks) < 3:
-        newparams = True
-        if len(all_ks) == 0:
-            if threshold > _decrease_threshold(threshold):
-                threshold = _decrease_threshold(threshold)
-            else:
-                print("No ks found at minimum threshold!")
-                newparams = False
-        else:
-            coordsminlength = np.linalg.norm(coords, axis=1).min()
-            if coordsminlength < 5 * sigma:
-                sigma = coordsminlength / 6
-            elif threshold > 0.2 * np.max(vals):
-                threshold = 0.2 * np.max(vals)
-            elif threshold > _decrease_threshold(threshold):
-                threshold = _decrease_threshold(threshold)
-            else:
-                print("Can't find enough ks!")
-                newparams = False
-        if newparams:
-            primary_ks, all_ks = extract_primary_ks(image, plot=False, threshold=threshold, sigma=sigma,
-                                                    pix_norm_range=pix_norm_range, dtype=dtype)
-        else:
-            primary_ks = all_ks.copy()
-    if not newparams:
-        primary_ks = all_ks.copy()
-    if len(primary_ks) != 3:
-        if len(primary_ks) > 3:
-            primary_ks = select_closest_to_triangle(all_ks)
-        elif len(all_ks) > 6:
+    dog = bool(DoG)
+    while True:
+        all_ks, radius, heights = _peak_candidates(plan, image, sigma, dog, threshold, pix_norm_range)
+        if len(all_ks) >= 3:
+            break
+        step = _relaxed_parameters(len(all_ks), radius, heights, threshold, sigma)
+        if step is None:
             if plot:
-                print("all_ks > 3 but not enough primary_ks, selecting closest to triangle")
-            primary_ks = select_closest_to_triangle(all_ks)
-        elif threshold > _decrease_threshold(threshold) and not newparams:
-            if plot:
-                print(f"pks<3, all_ks < 6, decreasing threshold {threshold:.3f}")
-            threshold = _decrease_threshold(threshold)
-            primary_ks, all_ks = extract_primary_ks(image, plot=False, threshold=threshold, sigma=sigma,
-                                                    pix_norm_range=pix_norm_range, dtype=dtype)
-        else:
-            if plot:
-                print("pks < aks=3", len(all_ks), len(primary_ks))
-            primary_ks = all_ks.copy()
+                print('extract_primary_ks: only %d k-vector(s) at threshold %.4g, sigma %.3g; giving up'
+                      % (len(all_ks), threshold, sigma))
+            break
+        (threshold, sigma), dog = step, True
+    primary_ks = select_closest_to_triangle(all_ks) if len(all_ks) > 3 else all_ks.copy()
+    if plot and len(all_ks) > 3:
+        print('extract_primary_ks: %d candidates, kept the triple closest to a triangle' % len(all_ks))
     return primary_ks, all_ks
 
 

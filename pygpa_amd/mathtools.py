@@ -36,15 +36,21 @@ def periodic_difference(X, Y, period=2 * np.pi):
 
 
 def remove_negative_duplicates(ks):
-    """Drop the k-vectors that are negatives of earlier ones, x-coordinate made non-negative (if
-    zero, the y-coordinate) (mathtools.py:78-94)."""
+    """One representative per +k / -k pair (mathtools.py:78-94): every vector is oriented so that its
+    first non-zero coordinate is positive, then a vector is kept unless it coincides with an earlier
+    kept one within np.isclose's tolerance (rtol 1e-5 of the kept vector, atol = 1e-3 of the mean
+    smaller |coordinate|)."""
     ks = np.asarray(ks)
-    if ks.shape[0] == 0:
+    if len(ks) == 0:
         return ks
-    nonneg = np.where(np.sign(ks[:, [0]]) != 0, np.sign(ks[:, [0]]) * ks, np.sign(ks[:, [1]]) * ks)
-    npks = [nonneg[0]]
-    atol = 1e-3 * np.min(np.abs(nonneg), axis=1).mean()
-    for k in nonneg[1:]:
-        if not np.any(np.all(np.isclose(k, npks, atol=atol), axis=1)):
-            npks.append(k)
-    return np.array(npks)
+    lead = np.where(ks[:, 0] != 0, ks[:, 0], ks[:, 1])
+    oriented = ks * np.sign(lead)[:, None]
+    atol = 1e-3 * np.abs(oriented).min(axis=1).mean()
+    kept = np.empty_like(oriented)
+    n = 0
+    for k in oriented:
+        near = np.abs(k - kept[:n]) <= atol + 1e-5 * np.abs(kept[:n])
+        if not near.all(axis=1).any():
+            kept[n] = k
+            n += 1
+    return kept[:n].copy()

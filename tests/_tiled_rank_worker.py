@@ -1,0 +1,38 @@
+"""One rank of the 2-ranks-on-one-GPU test (tests/test_gpu_configs.py): torch.distributed over gloo,
+both ranks on cuda:0, the device-resident TiledPipeline with host-staged collectives.
+usage: RANK= WORLD_SIZE= MASTER_ADDR= MASTER_PORT= python _tiled_rank_worker.py OUT_PREFIX DTYPE"""
+import os
+import sys
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+sys.path.insert(0, os.path.join(ROOT, 'tests'))
+
+
+def main():
+    out_prefix, dtype = sys.argv[1], np.dtype(sys.argv[2])
+    rank, world = int(os.environ['RANK']), int(os.environ['WORLD_SIZE'])
+    import torch
+    import torch.distributed as dist
+    torch.cuda.set_device(0)
+    dist.init_process_group('gloo', rank=rank, world_size=world)
+    from pygpa_amd import distributed as D
+    from test_distributed import _case
+    img, kvecs, klists = _case()
+    # the public entry point (N > 1 -> TiledPipeline) ...
+    u = D.extract_displacement_field_tiled(img, kvecs, klists=klists, halo=20, window=(64, 128), dtype=dtype)
+    # ... and the reusable object, two steps on the same buffers
+    pipe = D.TiledPipeline(img.shape, kvecs, np.stack(klists), 6, 20, kmax=10, dtype=dtype, device=0, grid=(2, 2))
+    pipe.load(img)
+    pipe.step()
+    u2 = pipe.step().cpu().numpy()
+    np.savez(out_prefix + '_rank%d.npz' % rank, u=u, u2=u2, tiles=len(pipe.mine), iters=np.array(pipe.iters))
+    pipe.close()
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+if __name__ == '__main__':
+    main()

@@ -1,0 +1,391 @@
+"""BASELINE.json configs at their full sizes, the measured fp32 accuracy, the multi-rank device path and the
+hipGraph / table-staging machinery of the fused driver.  Run with `-m gpu` on an MI355X.
+
+Accuracy numbers are written to gpurun_out/r02_accuracy.json (copied to profiles/ when committed)."""
+import json
+import os
+import socket
+import subprocess
+import sys
+import time
+
+import numpy as np
+import pytest
+
+from conftest import kidx_mismatch_is_tie
+from oracle import gpa_oracle as orc
+from pygpa_amd import _lib
+from pygpa_amd.synthetic import hex_kvecs, gaussian_bump_displacement, hex_moire, explicit_klists
+
+pytestmark = pytest.mark.gpu
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+ACC_PATH = os.path.join(ROOT, 'gpurun_out', 'r02_accuracy.json')
+
+
+def _record(key, value):
+    os.makedirs(os.path.dirname(ACC_PATH), exist_ok=True)
+    data = {}
+    if os.path.exists(ACC_PATH):
+        try:
+            data = json.load(open(ACC_PATH))
+        except Exception:
+            data = {}
+    data[key] = value
+    json.dump(data, open(ACC_PATH, 'w'), indent=1, sort_keys=True)
+
+
+def _px_errors(u, ref, border):
+    """max / rms of |u - ref| in pixels, whole image and interior; the mean of each component is free
+    (phase_unwrap.py:110-114), so it is removed first"""
+    d = (u - u.mean(axis=(1, 2), keepdims=True)) - (ref - ref.mean(axis=(1, 2), keepdims=True))
+    di = d[:, border:-border, border:-border]
+    return {'max_px': float(np.abs(d).max()), 'rms_px': float(np.sqrt((d.astype(np.float64) ** 2).mean())),
+            'interior_max_px': float(np.abs(di).max()), 'interior_rms_px': float(np.sqrt((di.astype(np.float64) ** 2).mean()))}
+
+
+def _check_kidx_ties(kidx, ref_kidx, img0, klists, sigma, tie_tol):
+    """every winner that differs from the reference's must be an amplitude tie (per peak)"""
+    worst = 0.0
+    for p in range(len(klists)):
+        bad = kidx[p] != ref_kidx[p]
+        worst = max(worst, float(bad.mean()))
+        if bad.any():
+            amps = np.abs(orc.lockin_batch(img0, klists[p], sigma, workers=os.cpu_count() or 1))
+            assert np.all(kidx_mismatch_is_tie(amps, kidx[p], ref_kidx[p], tie_tol)[bad]), \
+                'peak %d: %d kidx mismatches that are not amplitude ties' % (p, int(bad.sum()))
+    return worst
+
+
+def _set_floor(v):
+    if v is None:
+        os.environ.pop('GPA_F32_EPS_FLOOR', None)
+    else:
+        os.environ['GPA_F32_EPS_FLOOR'] = v
+
+
+# ---- the sweep's compensation tables must survive per_dft / find_peaks / deconvolve -----
+def test_sweep_tables_survive_spectral_calls():
+    import pygpa_amd.geometric_phase_analysis as GPA
+    shape = (128, 160)
+    kvecs = hex_kvecs(0.1, 7.0)
+    img = hex_moire(shape, kvecs, gaussian_bump_displacement(shape), noise=0.1, seed=4)
+    img2 = hex_moire(shape, kvecs, gaussian_bump_displacement(shape), noise=0.2, seed=5)
+    for dtype in (np.float64, np.float32):
+        u1 = GPA.extract_displacement_field(img, kvecs, dtype=dtype)
+        GPA.extract_primary_ks(img2, dtype=dtype)          # per_dft + find_peaks on the SAME cached plan
+        GPA.per(img2, dtype=dtype)
+        u2 = GPA.extract_displacement_field(img, kvecs, dtype=dtype)   # same k-lists: tables are not re-staged
+        assert np.array_equal(u1, u2)
+        plan = _lib.get_plan(shape, 9, dtype)
+        klist = GPA._sweep_list(kvecs[0][0], kvecs[0][1], 0.04, 0.04 / 3)
+        a = plan.sweep(img, kvecs[0], klist, 10)
+        plan.per_dft(img2)
+        plan.find_peaks(img2, 1.0, 50.0, 0.5)
+        b = plan.sweep(img, kvecs[0], klist, 10)
+        assert np.array_equal(a[0], b[0]) and np.array_equal(a[1], b[1])
+    # deconvolve runs on a plan of the padded shape: share it with a sweep of that shape
+    pshape = (shape[0] + 80, shape[1] + 80)
+    imgp = hex_moire(pshape, kvecs, noise=0.1, seed=6)
+    plan = _lib.get_plan(pshape, 9, np.float64)
+    klist = GPA._sweep_list(kvecs[1][0], kvecs[1][1], 0.04, 0.04 / 3)
+    a = plan.sweep(imgp, kvecs[1], klist, 10)
+    GPA.gaussian_deconvolve(np.zeros((2,) + shape), 10, dr=20)
+    b = plan.sweep(imgp, kvecs[1], klist, 10)
+    assert np.array_equal(a[0], b[0])
+
+
+# ---- hipGraph replay of the fused driver -------------------------------------------------------------------
+@pytest.mark.parametrize('dtype', [np.float64, np.float32])
+def test_graph_replay_equals_eager(dtype):
+    """the 2nd call with one key captures the launches, later calls replay them: same bits as the eager
+    plan, also after the k-lists changed (tables restaged under an existing graph) and for a second buffer"""
+    from test_gpu_parity import DeviceArray
+    shape = (256, 512)
+    kvecs = hex_kvecs(0.1, 7.0)
+    img = hex_moire(shape, kvecs, gaussian_bump_displacement(shape), noise=0.1, seed=8)
+    img2 = hex_moire(shape, kvecs, gaussian_bump_displacement(shape), noise=0.3, seed=9)
+    kl_a = np.stack(explicit_klists(kvecs, 0.04, 2, 2))
+    kl_b = np.stack(explicit_klists(kvecs, 0.03, 2, 2))          # same K and x-plane count, other values
+    os.environ['GPA_NO_GRAPH'] = '1'
+    eager = _lib.Plan(shape, 12, dtype)
+    os.environ.pop('GPA_NO_GRAPH')
+    ref = {(i, k): eager.extract_displacement_field(im, kvecs, kl, 10, 20)[0]
+           for i, im in enumerate((img, img2)) for k, kl in (('a', kl_a), ('b', kl_b))}
+    eager.close()
+    plan = _lib.Plan(shape, 12, dtype)
+    d_img = [DeviceArray(img.astype(dtype)), DeviceArray(img2.astype(dtype))]
+    outs = [DeviceArray(np.zeros((2,) + shape, dtype=dtype)) for _ in range(2)]
+    seq = [(0, 'a', 0), (0, 'a', 0), (0, 'a', 0), (0, 'b', 0), (0, 'a', 0), (1, 'a', 1), (1, 'a', 1), (1, 'b', 1),
+           (1, 'a', 1), (0, 'a', 0), (0, 'b', 0)]
+    for i, k, j in seq:
+        plan.extract_displacement_field_async(d_img[i].ptr, kvecs, kl_a if k == 'a' else kl_b, 10, 20, 10, outs[j].ptr)
+        plan.sync()
+        assert np.array_equal(outs[j].get(), ref[(i, k)]), (i, k, j)
+    plan.close()
+
+
+def test_download_async_pipeline():
+    """gpa_download_async / gpa_download_wait: u of step i lands in pinned memory while step i + 1 runs"""
+    import pygpa_amd
+    from test_gpu_parity import DeviceArray
+    shape = (512, 512)
+    kvecs = hex_kvecs(0.1, 7.0)
+    klists = np.stack(explicit_klists(kvecs, 0.04, 2, 2))
+    imgs = [hex_moire(shape, kvecs, gaussian_bump_displacement(shape), noise=0.1, seed=s, dtype=np.float32) for s in range(4)]
+    plan = _lib.Plan(shape, 12, np.float32)
+    ref = [plan.extract_displacement_field(im, kvecs, klists, 10, 20)[0] for im in imgs]
+    d_imgs = [DeviceArray(im) for im in imgs]
+    d_u = [DeviceArray(np.zeros((2,) + shape, dtype=np.float32)) for _ in range(2)]
+    h_u = [pygpa_amd.pinned_empty((2,) + shape, np.float32) for _ in range(2)]
+    got = []
+    nsteps = 12
+    for st in range(nsteps):
+        j = st & 1
+        plan.download_wait(j)                       # the copy that last read d_u[j] / wrote h_u[j] has landed
+        if st >= 2:
+            got.append(((st - 2) % 4, h_u[j].copy()))
+        plan.extract_displacement_field_async(d_imgs[st % 4].ptr, kvecs, klists, 10, 20, 10, d_u[j].ptr)
+        plan.download_async(h_u[j], d_u[j].ptr, j)
+    for st in (nsteps - 2, nsteps - 1):
+        plan.download_wait(st & 1)
+        got.append((st % 4, h_u[st & 1].copy()))
+    plan.sync()
+    for i, u in got:
+        assert np.array_equal(u, ref[i]), i
+    plan.close()
+
+
+# ---- configs[1] and configs[2]: measured fp32 accuracy ------------------------------------------------------
+def test_config2_2048_accuracy():
+    """configs[1]: 2048^2, 3 x 8, fp32: device f64 and f32 against the oracle; achieved errors are recorded,
+    the asserted bounds are <= 2x what was measured on MI355X (round 2)"""
+    n = 2048
+    kvecs = hex_kvecs(0.1, 7.0)
+    img = hex_moire((n, n), kvecs, gaussian_bump_displacement((n, n)), noise=0.1, seed=5)
+    kw, sigma, _ = orc.derive_params(kvecs)
+    klists = np.stack(explicit_klists(kvecs, kw, 4, 2))
+    cores = os.cpu_count() or 1
+    u_ref, parts = orc.extract_displacement_field(img, kvecs, sigma=sigma, klists=klists, return_parts=True,
+                                                  workers=cores, pool=min(cores, 8))
+    ref_kidx = np.stack([g['kidx'] for g in parts['gs']])
+    img0 = img - img.mean()
+    rec = {'u_max_px': float(np.abs(u_ref).max())}
+    out = {}
+    for name, dtype, floor in (('f64', np.float64, None), ('f32', np.float32, None), ('f32_forced10', np.float32, '0')):
+        _set_floor(floor)
+        plan = _lib.Plan((n, n), 24, dtype)
+        u, _, kidx, iters = plan.extract_displacement_field(img, kvecs, klists, sigma, 2 * sigma, want_kidx=True)
+        plan.close()
+        _set_floor(None)
+        out[name] = u
+        rec[name] = dict(_px_errors(u, u_ref, 2 * sigma), iters=list(iters))
+        rec[name]['kidx_mismatch'] = _check_kidx_ties(kidx, ref_kidx, img0, klists, sigma, 1e-12 if dtype is np.float64 else 4e-6)
+    _record('config2_2048_3x8_vs_oracle', rec)
+    assert rec['f64']['kidx_mismatch'] == 0.0
+    assert rec['f64']['max_px'] < 1e-6
+    assert rec['f32']['interior_max_px'] < 0.02 and rec['f32']['max_px'] < 0.1
+
+
+def test_config3_4096_accuracy_f32_f64_oracle():
+    """configs[2]: 4096^2, 3 x 16 + weighted unwrap.  (1) device f64 against the ORACLE at full size;
+    (2) fp32 against fp64 with the default residual floor (9 + 8 iterations) and with 10 + 10 forced;
+    errors in pixels, recorded.  |u| reaches ~200 px; the reference's own bar for this field is 0.9 px."""
+    n = 4096
+    kvecs = hex_kvecs(0.1, 7.0)
+    img = hex_moire((n, n), kvecs, gaussian_bump_displacement((n, n)), noise=0.1, seed=100)
+    kw, sigma, _ = orc.derive_params(kvecs)
+    klists = np.stack(explicit_klists(kvecs, kw, 4, 4))
+    out, rec = {}, {}
+    for name, dtype, floor in (('f64', np.float64, None), ('f32', np.float32, None), ('f32_forced10', np.float32, '0')):
+        _set_floor(floor)
+        plan = _lib.Plan((n, n), 48, dtype)
+        out[name] = plan.extract_displacement_field(img, kvecs, klists, sigma, 2 * sigma, want_lockins=True, want_kidx=True)
+        plan.close()
+        _set_floor(None)
+    u64, l64, k64, it64 = out['f64']
+    assert it64 == (10, 10)
+    rec['u_max_px'] = float(np.abs(u64).max())
+    for name in ('f32', 'f32_forced10'):
+        u32, l32, k32, it32 = out[name]
+        rec[name + '_vs_f64'] = dict(_px_errors(u32, u64, 2 * sigma), iters=list(it32),
+                                     kidx_mismatch=float((k32 != k64).mean()))
+        same = k32 == k64
+        rec[name + '_vs_f64']['lockin_rel'] = float(np.abs(l32 - l64)[same].max() / np.abs(l64).max())
+    del l64
+    # (1) the oracle on every host core (candidates through a thread pool)
+    cores = os.cpu_count() or 1
+    t = time.time()
+    u_ref, parts = orc.extract_displacement_field(img, kvecs, sigma=sigma, klists=klists, return_parts=True,
+                                                  workers=cores, pool=min(cores, 16))
+    rec['oracle_seconds'] = time.time() - t
+    ref_kidx = np.stack([g['kidx'] for g in parts['gs']])
+    rec['f64_vs_oracle'] = dict(_px_errors(u64, u_ref, 2 * sigma))
+    img0 = img - img.mean()
+    rec['f64_vs_oracle']['kidx_mismatch'] = _check_kidx_ties(k64, ref_kidx, img0, klists, sigma, 1e-12)
+    rec['f32_vs_oracle'] = dict(_px_errors(out['f32'][0], u_ref, 2 * sigma))
+    rec['f32_vs_oracle']['kidx_mismatch'] = _check_kidx_ties(out['f32'][2], ref_kidx, img0, klists, sigma, 4e-6)
+    _record('config3_4096_3x16', rec)
+    assert rec['f64_vs_oracle']['kidx_mismatch'] == 0.0
+    assert rec['f64_vs_oracle']['max_px'] < 1e-5
+    assert rec['f32_vs_f64']['lockin_rel'] < 2e-5
+    assert rec['f32_vs_f64']['interior_max_px'] < 0.05 and rec['f32_vs_f64']['max_px'] < 0.2
+
+
+# ---- configs[3]: 8192^2 in halo tiles --------------------------------------------------------------------
+def test_config4_8192_tiled_vs_whole_image():
+    """configs[3] on one GPU (all tiles on rank 0): 8192^2, 3 x 16, fp32, 2048^2 power-of-two windows with a
+    3 sigma halo (25 tiles), global 8192^2 unwrap.  Tile interiors must agree with the whole-image run of
+    the same device kernels within 0.05 px (the free mean of each component removed)."""
+    from pygpa_amd import distributed as D
+    n = 8192
+    kvecs = hex_kvecs(0.1, 7.0)
+    img = hex_moire((n, n), kvecs, gaussian_bump_displacement((n, n)), noise=0.05, seed=41, dtype=np.float32)
+    klists = explicit_klists(kvecs, 0.04, 4, 4)
+    t = time.time()
+    u = D.extract_displacement_field_tiled(img, kvecs, sigma=10, klists=klists, halo=30, window=(2048, 2048), dtype=np.float32)
+    t_first = time.time() - t
+    t = time.time()
+    u = D.extract_displacement_field_tiled(img, kvecs, sigma=10, klists=klists, halo=30, window=(2048, 2048), dtype=np.float32)
+    t_tiled = time.time() - t
+    assert np.isfinite(u).all()
+    plan = _lib.Plan((n, n), 48, np.float32)
+    uw = plan.extract_displacement_field(img, kvecs, np.stack(klists), 10, 20, 10)[0]
+    t = time.time()
+    uw = plan.extract_displacement_field(img, kvecs, np.stack(klists), 10, 20, 10)[0]
+    t_whole = time.time() - t
+    plan.close()
+    err = _px_errors(u, uw, 64)
+    _record('config4_8192_tiled_vs_whole', dict(err, seconds_tiled_incl_pcie=t_tiled, seconds_first_call=t_first,
+                                                seconds_whole_incl_pcie=t_whole, tiles=25, window=2048, halo=30,
+                                                u_max_px=float(np.abs(uw).max())))
+    assert err['interior_max_px'] < 0.05
+
+
+def test_tiled_reduced_grid_vs_oracle_same_tiling():
+    """the config-4 tiling on a reduced grid (1024 x 1536, 512^2 windows, halo 30) against the oracle run on
+    the SAME tiling, f64 and f32"""
+    from pygpa_amd import distributed as D
+    import test_distributed as TD
+    shape = (1024, 1536)
+    kvecs = hex_kvecs(0.1, 7.0)
+    img = hex_moire(shape, kvecs, gaussian_bump_displacement(shape), noise=0.05, seed=17)
+    klists = explicit_klists(kvecs, 0.04, 2, 2)
+    u_ref = D.extract_displacement_field_tiled(img, kvecs, sigma=10, klists=klists, halo=30, window=(512, 512),
+                                               compute=TD._oracle_compute())
+    u = D.extract_displacement_field_tiled(img, kvecs, sigma=10, klists=klists, halo=30, window=(512, 512))
+    assert np.abs(u - u_ref).max() < 1e-7
+    u32 = D.extract_displacement_field_tiled(img, kvecs, sigma=10, klists=klists, halo=30, window=(512, 512), dtype=np.float32)
+    e = _px_errors(u32, u_ref, 20)
+    _record('tiled_1024x1536_f32_vs_oracle_same_tiling', e)
+    assert e['max_px'] < 0.05
+
+
+# ---- configs[4]: 16384^2 tile grid + Lawler-Fujita, end to end --------------------------------------------
+def test_config5_16384_tiled_undistort_end_to_end():
+    """configs[4] on one GPU: 16384^2, 3 x 16, fp32, 81 windows of 2048^2, global 16384^2 unwrap, then
+    undistort_image (Lawler-Fujita).  No oracle runs at this size; the checks are the reference's own
+    end-to-end properties (tests/test_geometric_phase_analysis.py:61-78): -u recovers the true displacement
+    within 0.9 px away from the border, and the undistorted image is the undeformed lattice within 2 %."""
+    from pygpa_amd import distributed as D
+    n = 16384
+    kvecs = hex_kvecs(0.1, 7.0)
+    # (built in row blocks: a 16384^2 float64 temporary is 2 GiB)
+    img = np.empty((n, n), dtype=np.float32)
+    orig = np.empty((n, n), dtype=np.float32)
+    ux = np.empty((n, n), dtype=np.float32)
+    y = (np.arange(n) - n // 2)[None, :].astype(np.float64)
+    for r0 in range(0, n, 1024):
+        x = (np.arange(r0, r0 + 1024) - n // 2)[:, None].astype(np.float64)
+        # a bump of at most ~25 px so that the 35 fixed-point rounds of the inversion converge everywhere
+        b = 0.05 * x * np.exp(-0.5 * ((x / (n / 8.0)) ** 2 + 1.2 * (y / (n / 6.0)) ** 2))
+        ux[r0:r0 + 1024] = b
+        acc, acc0 = np.zeros((1024, n)), np.zeros((1024, n))
+        for kx, ky in kvecs:
+            acc += np.cos(2 * np.pi * (kx * (x + b) + ky * y))
+            acc0 += np.cos(2 * np.pi * (kx * x + ky * y))
+        img[r0:r0 + 1024] = acc
+        orig[r0:r0 + 1024] = acc0
+    klists = explicit_klists(kvecs, 0.04, 4, 4)
+    t = time.time()
+    u = D.extract_displacement_field_tiled(img, kvecs, sigma=10, klists=klists, halo=30, window=(2048, 2048), dtype=np.float32)
+    t_first = time.time() - t
+    t = time.time()
+    u = D.extract_displacement_field_tiled(img, kvecs, sigma=10, klists=klists, halo=30, window=(2048, 2048), dtype=np.float32)
+    t_tiled = time.time() - t
+    assert np.isfinite(u).all()
+    b = 64
+    d0 = -u[0] - ux
+    d0 -= d0[b:-b, b:-b].mean()
+    d1 = -u[1]
+    d1 -= d1[b:-b, b:-b].mean()
+    e0, e1 = float(np.abs(d0[b:-b, b:-b]).max()), float(np.abs(d1[b:-b, b:-b]).max())
+    plan = _lib.Plan((n, n), 1, np.float32)
+    t = time.time()
+    rec_img = plan.undistort_image(img, u)
+    t_lf = time.time() - t
+    plan.close()
+    dev = np.abs(rec_img - orig)[256:-256, 256:-256] / np.abs(orig).max()
+    _record('config5_16384_tiled_undistort', {'seconds_tiled_incl_pcie': t_tiled, 'seconds_first_call': t_first,
+                                              'seconds_undistort_incl_pcie': t_lf, 'tiles': 81, 'window': 2048,
+                                              'u_err_max_px': [e0, e1], 'undistort_max_dev_frac': float(dev.max()),
+                                              'u_true_max_px': float(np.abs(ux).max())})
+    assert e0 < 0.9 and e1 < 0.9
+    assert dev.max() < 0.02
+
+
+# ---- N > 1 device path: two ranks sharing GPU 0 (gloo, host-staged collectives) ---------------------------
+def _free_port():
+    s = socket.socket()
+    s.bind(('127.0.0.1', 0))
+    port = s.getsockname()[1]
+    s.close()
+    return port
+
+
+def test_tiled_two_ranks_one_gpu(tmp_path):
+    """pygpa_amd.distributed.TiledPipeline with world size 2: windows dealt to two processes that share
+    cuda:0, all_reduce / all_gather / broadcast staged through the host on gloo.  Every rank must hold the
+    field of the single-process device run of the same tiling (the whole-image mean is reduced in another
+    order: 1e-10), for both tilings and both precisions."""
+    from pygpa_amd import distributed as D
+    import test_distributed as TD
+    img, kvecs, klists = TD._case()
+    for dtype in ('float64', 'float32'):
+        port = _free_port()
+        prefix = str(tmp_path / ('tiled_' + dtype))
+        procs = []
+        for r in range(2):
+            env = dict(os.environ, RANK=str(r), WORLD_SIZE='2', LOCAL_RANK=str(r), MASTER_ADDR='127.0.0.1',
+                       MASTER_PORT=str(port), HSA_ENABLE_IPC_MODE_LEGACY='0')
+            procs.append(subprocess.Popen([sys.executable, os.path.join(ROOT, 'tests', '_tiled_rank_worker.py'), prefix, dtype],
+                                          env=env, stdout=subprocess.PIPE, stderr=subprocess.STDOUT))
+        outs = [p.communicate(timeout=900)[0].decode() for p in procs]
+        assert all(p.returncode == 0 for p in procs), '\n'.join(outs)
+        u_w = D.extract_displacement_field_tiled(img, kvecs, klists=klists, halo=20, window=(64, 128), dtype=np.dtype(dtype))
+        u_g = D.extract_displacement_field_tiled(img, kvecs, (2, 2), klists=klists, halo=20, dtype=np.dtype(dtype))
+        tol = 1e-10 if dtype == 'float64' else 2e-4
+        ntiles = 0
+        for r in range(2):
+            g = np.load(prefix + '_rank%d.npz' % r)
+            assert np.abs(g['u'] - u_w).max() <= tol, (dtype, r)
+            assert np.abs(g['u2'] - u_g).max() <= tol, (dtype, r)
+            ntiles += int(g['tiles'])
+        assert ntiles == 4
+        g0, g1 = (np.load(prefix + '_rank%d.npz' % r) for r in range(2))
+        assert np.array_equal(g0['u'], g1['u']) and np.array_equal(g0['u2'], g1['u2'])
+
+
+def test_bench_gpus_flag_spawns_ranks():
+    """`python bench.py --gpus 2` (no launcher) must start 2 ranks itself and report n_gpus = 2 with the tile
+    pipeline as the workload; here both ranks share GPU 0 over gloo and the image is small"""
+    cmd = [sys.executable, os.path.join(ROOT, 'bench.py'), '--gpus', '2', '--steps', '2', '--warmup', '1', '--size', '256',
+           '--window', '128', '--kside', '2', '--backend', 'gloo', '--share-device']
+    env = {k: v for k, v in os.environ.items() if k not in ('RANK', 'WORLD_SIZE', 'LOCAL_RANK', 'MASTER_PORT')}
+    r = subprocess.run(cmd, env=env, stdout=subprocess.PIPE, stderr=subprocess.PIPE, timeout=900)
+    assert r.returncode == 0, r.stderr.decode()[-2000:]
+    lines = [ln for ln in r.stdout.decode().splitlines() if ln.startswith('{')]
+    assert len(lines) == 1
+    out = json.loads(lines[0])
+    assert out['n_gpus'] == 2 and out['steps'] == 2 and out['value'] > 0
+    assert out['config']['image'] == [512, 256] and out['config']['tiles'] >= 2
+    assert 'all_gather' in out['config']['collectives']

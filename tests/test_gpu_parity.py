@@ -598,46 +598,7 @@ def test_f4_gaussian_deconvolve_golden(golden, dtype):
     assert rel(dec_b, g['dec_b']) < tol
 
 
-# ---- BASELINE configs 2 and 3 at their full sizes -------------------------------------------------
-@pytest.mark.gpu
-def test_config2_2048_driver_vs_oracle():
-    """configs[1]: 2048^2, 3 peaks x 8 k-vectors, fp32 -- the whole driver against the oracle (f64)."""
-    n = 2048
-    kvecs = hex_kvecs(0.1, 7.0)
-    img = hex_moire((n, n), kvecs, gaussian_bump_displacement((n, n)), noise=0.1, seed=5)
-    kw, sigma, _ = orc.derive_params(kvecs)
-    klists = np.stack(explicit_klists(kvecs, kw, 4, 2))
-    plan = _lib.Plan((n, n), 24, np.float32)
-    u, _, kidx, iters = plan.extract_displacement_field(img, kvecs, klists, sigma, 2 * sigma, want_kidx=True)
-    plan.close()
-    u_ref, parts = orc.extract_displacement_field(img, kvecs, sigma=sigma, klists=klists, return_parts=True, workers=16)
-    ref_kidx = np.stack([g['kidx'] for g in parts['gs']])
-    assert (kidx != ref_kidx).mean() < 2e-3          # f32 amplitude ties between neighbouring candidates
-    assert rel(u, u_ref) < 2e-3                      # f32 PCG stopped at its residual floor, |u| ~ 100 px
-
-
-@pytest.mark.gpu
-def test_config3_4096_f32_vs_f64():
-    """configs[2]: 4096^2, 3 peaks x 16 k-vectors + weighted unwrap: the fp32 build against the fp64
-    build of the same kernels (the stated fp32-vs-fp64 tolerance check of BASELINE.json)."""
-    n = 4096
-    kvecs = hex_kvecs(0.1, 7.0)
-    img = hex_moire((n, n), kvecs, gaussian_bump_displacement((n, n)), noise=0.1, seed=100)
-    kw, sigma, _ = orc.derive_params(kvecs)
-    klists = np.stack(explicit_klists(kvecs, kw, 4, 4))
-    out = {}
-    for dtype in (np.float64, np.float32):
-        plan = _lib.Plan((n, n), 48, dtype)
-        out[dtype] = plan.extract_displacement_field(img, kvecs, klists, sigma, 2 * sigma, want_lockins=True, want_kidx=True)
-        plan.close()
-    u64, l64, k64, it64 = out[np.float64]
-    u32, l32, k32, it32 = out[np.float32]
-    assert it64 == (10, 10)
-    assert (k32 != k64).mean() < 2e-3
-    same = k32 == k64
-    assert np.abs(l32 - l64)[same].max() < 2e-5 * np.abs(l64).max()
-    # the fp32 PCG stops at its residual floor (8-9 of 10 iterations): tolerance relative to |u| ~ 200 px
-    assert rel(u32, u64) < 2e-3
+# (BASELINE configs at their full sizes: tests/test_gpu_configs.py)
 
 
 @pytest.mark.gpu
