@@ -90,6 +90,23 @@ int gpa_sweep(gpa_plan* plan, const void* image, const double* kref, const doubl
 int gpa_sweep_dev(gpa_plan* plan, const void* image, const double* kref, const double* klist,
                   int K, double sigma, void* lockin, int32_t* kidx, void* grad);
 
+/* a4 with the other gradient stencils of the reference, and a3's gated form:
+ * gpa_sweep_grad: gpa_sweep with grad != NULL and a selectable stencil.  grad_mode 0 = np.gradient (= gpa_sweep);
+ *   1 = forward differences along axis 0, axis 1 with NaN at the last index -- grad='diff' of cuGPA.wfr2_grad_opt /
+ *   wfr2_grad_single / wfr2_only_grad (cuGPA.py:58-62); 2 = the same with the two components exchanged -- grad='diff'
+ *   of wfr2_grad (geometric_phase_analysis.py:738-742).  wfr2_grad (:722-760) differentiates the compensated
+ *   lock-in and wraps per candidate, which is the same number up to rounding.
+ * gpa_sweep_gated: wfr4 (geometric_phase_analysis.py:839-862): candidate k replaces the kept candidate j (klist[0]
+ *   until something is accepted) only where |sf_k| is strictly larger AND gate[j * K + k] != 0; the caller builds
+ *   gate (K x K bytes, host) as || klist[j] - klist[k] || < 2 sqrt(2) dk in double.  kidx = -1 where nothing was
+ *   accepted (the reference reports klist[0] as 'w' there).                                                   */
+int gpa_sweep_grad(gpa_plan* plan, const void* image, const double* kref, const double* klist, int K,
+                   double sigma, int grad_mode, void* lockin, int32_t* kidx, void* grad);
+int gpa_sweep_grad_dev(gpa_plan* plan, const void* image, const double* kref, const double* klist, int K,
+                       double sigma, int grad_mode, void* lockin, int32_t* kidx, void* grad);
+int gpa_sweep_gated(gpa_plan* plan, const void* image, const double* kref, const double* klist, int K,
+                    double sigma, const uint8_t* gate, void* lockin, int32_t* kidx);
+
 /* a5+a6 -- phases/weights glue and per-pixel weighted least squares.
  *   phases = angle(lockin), weights = |lockin| * (mask + 1e-6), mask = 1 on
  *   [mask_border:-mask_border]^2 (extract_displacement_field,
@@ -102,6 +119,13 @@ int gpa_reconstruct_grad(gpa_plan* plan, const void* lockin, const double* kvecs
                          int mask_border, void* dudx, void* dudy, void* wnorm);
 int gpa_reconstruct_grad_dev(gpa_plan* plan, const void* lockin, const double* kvecs, int P,
                              int mask_border, void* dudx, void* dudy, void* wnorm);
+
+/* a6 with pre_diff=True (reconstruct_u_inv_from_phases, geometric_phase_analysis.py:228-237): grads
+ * (P x n0 x n1 x 2, host) already hold the phase gradients along axis 1 ([..., 0]) and axis 0 ([..., 1]) -- e.g.
+ * the `grad` outputs of gpa_sweep; they are wrapped, solved per pixel against 2 pi kvecs with `weights`
+ * (P x n0 x n1) and cropped to the difference grids: dudx 2 x n0 x (n1-1), dudy 2 x (n0-1) x n1, wnorm as above. */
+int gpa_reconstruct_prediff(gpa_plan* plan, const void* grads, const void* weights, const double* kvecs, int P,
+                            void* dudx, void* dudy, void* wnorm);
 
 /* a8 helper -- per-pixel weighted least squares on given right-hand sides:
  * minimise || w (2 pi kvecs x - b) || per pixel; the weighted branch of reconstruct_u_inv
@@ -191,6 +215,9 @@ int gpa_tile_gradients_dev(gpa_plan* plan, const void* image, size_t image_pitch
  *   scipy.ndimage.map_coordinates' defaults (order 3, mode='constant', cval=0); replaces
  *   undistort_image (:935-974).  deformed, out: n0 x n1.                          */
 int gpa_invert_u_overlap(gpa_plan* plan, const void* u, int iters, int edge, void* out);
+/* invert_u (geometric_phase_analysis.py:248-259), the variant without overlap: out is 2 x n0 x n1 and every
+ * round after the first samples at r + u_it(r) - edge.                                              */
+int gpa_invert_u(gpa_plan* plan, const void* u, int iters, int edge, void* out);
 int gpa_undistort_image(gpa_plan* plan, const void* deformed, const void* u, void* out);
 
 /* f-2 -- phase gradient -> Jacobian -> lattice properties.

@@ -176,6 +176,74 @@ def wfr2_grad_opt(image, sigma, kx, ky, kw, kstep, workers=1):
                  want_grad=True, workers=workers)
 
 
+def wfr4(image, sigma, klist, kref, dk):
+    """Gated sweep over an ordered k-list: a candidate replaces the kept one only where its amplitude is
+    strictly larger AND it lies within 2 sqrt(2) dk of the kept k-vector, which starts at klist[0] for
+    every pixel.  Follows wfr4 (gpa.py:839-862).  Returns 'lockin', 'w' (2,N,M) and 'kidx' (-1 where
+    nothing was ever accepted; 'w' is klist[0] there, as in the reference)."""
+    image = np.asarray(image)
+    klist = np.asarray(klist, dtype=np.float64).reshape(-1, 2)
+    n0, n1 = image.shape
+    best = np.zeros((n0, n1), dtype=np.complex128)
+    w = np.zeros((n0, n1, 2))
+    w[..., 0] = klist[0, 0]
+    w[..., 1] = klist[0, 1]
+    kidx = np.full((n0, n1), -1, dtype=np.int32)
+    for i, (wx, wy) in enumerate(klist):
+        sf = lockin(image, (wx, wy), sigma)
+        sf = sf * (carrier_1d(n0, -(wx - kref[0]))[:, None] * carrier_1d(n1, -(wy - kref[1]))[None, :])
+        t = np.abs(sf) > np.abs(best)
+        t = t & (np.linalg.norm(w - np.array([wx, wy]), axis=-1) < 2 * np.sqrt(2) * dk)
+        best[t] = sf[t]
+        w[t] = np.array([wx, wy])
+        kidx[t] = i
+    return {'lockin': best, 'w': np.moveaxis(w, -1, 0), 'kidx': kidx}
+
+
+def sweep_grad_variant(image, sigma, klist, kref, grad='diff', compensated=False):
+    """The gradient-returning sweeps that are NOT wfr2_grad_opt:
+      compensated=False: cuGPA.wfr2_grad_opt / wfr2_grad_single / wfr2_only_grad with grad='diff'
+        (cu.py:58-66): forward differences of -angle(sf) along axis 0, then axis 1, NaN appended at the end
+        of each axis, + 2 pi (w - kref), finally wrapToPi(2 g) / 2;
+      compensated=True: wfr2_grad (gpa.py:722-760): the gradient function acts on the phase of the
+        COMPENSATED lock-in and is wrapped per candidate; its 'diff' takes axis 1 first, then axis 0
+        (gpa.py:738-742); grad=None is np.gradient.
+    `grad` may also be a callable phase -> (N, M, 2) (compensated) or -> pair of (N, M) (cuGPA form)."""
+    image = np.asarray(image)
+    klist = np.asarray(klist, dtype=np.float64).reshape(-1, 2)
+    n0, n1 = image.shape
+    if grad == 'diff':
+        if compensated:
+            gf = lambda ph: np.stack([np.diff(ph, axis=1, append=np.nan), np.diff(ph, axis=0, append=np.nan)], axis=-1)
+        else:
+            gf = lambda ph: np.stack([np.diff(ph, axis=0, append=np.nan), np.diff(ph, axis=1, append=np.nan)], axis=-1)
+    elif grad is None:
+        gf = lambda ph: np.stack(np.gradient(ph), axis=-1)
+    else:
+        gf = grad if compensated else (lambda ph: np.stack(grad(ph), axis=-1))
+    best = np.zeros((n0, n1), dtype=np.complex128)
+    kidx = np.full((n0, n1), -1, dtype=np.int32)
+    out_grad = np.zeros((n0, n1, 2))
+    for i, (wx, wy) in enumerate(klist):
+        sf = lockin(image, (wx, wy), sigma)
+        comp = carrier_1d(n0, -(wx - kref[0]))[:, None] * carrier_1d(n1, -(wy - kref[1]))[None, :]
+        t = np.abs(sf) > np.abs(best)
+        if compensated:
+            g = wrap_to_pi(gf(-np.angle(sf * comp)) * 2) / 2
+        else:
+            g = gf(-np.angle(sf)) + TWO_PI * np.array([wx - kref[0], wy - kref[1]])
+        best = np.where(t, sf * comp, best)
+        kidx[t] = i
+        out_grad = np.where(t[..., None], g, out_grad)
+    if not compensated:
+        out_grad = wrap_to_pi(2 * out_grad) / 2
+    w = np.zeros((2, n0, n1))
+    won = kidx >= 0
+    w[0][won] = klist[kidx[won], 0]
+    w[1][won] = klist[kidx[won], 1]
+    return {'lockin': best, 'kidx': kidx, 'w': w, 'grad': out_grad}
+
+
 # --------------------------------------------------------------------------
 # a5: phases / weights glue
 # --------------------------------------------------------------------------
@@ -348,9 +416,17 @@ def unwrap(psi, weight=None, kmax=100, **kw):
 # a5+a6+a7 driver pieces and the top-level entry point
 # --------------------------------------------------------------------------
 def reconstruct_u_inv_from_phases(kvecs, phases, weights, weighted_unwrap=True,
-                                  kmax=10, workers=1, return_iters=False):
-    """gpa.py:196-245 (pre_diff=False branch)."""
-    dudx, dudy = reconstruct_gradients(kvecs, phases, weights)
+                                  kmax=10, workers=1, return_iters=False, pre_diff=False):
+    """gpa.py:196-245.  pre_diff=True (gpa.py:228-232): `phases` is (P, N, M, 2) and already holds the phase
+    gradients along axis 1 ([..., 0]) and axis 0 ([..., 1]); they are wrapped and cropped to the
+    difference grids instead of being differenced."""
+    if pre_diff:
+        kmat = TWO_PI * np.asarray(kvecs, dtype=np.float64)
+        phases = np.asarray(phases, dtype=np.float64)
+        dudx = weighted_lstsq(wrap_to_pi(phases[..., 0])[:, :, :-1], kmat, weights)
+        dudy = weighted_lstsq(wrap_to_pi(phases[..., 1])[:, :-1], kmat, weights)
+    else:
+        dudx, dudy = reconstruct_gradients(kvecs, phases, weights)
     wn = np.linalg.norm(weights, axis=0) if weighted_unwrap else None
     us, iters = [], []
     for i in range(2):
@@ -445,6 +521,18 @@ def invert_u_overlap(us, iters=35, edge=0, mode='nearest'):
     for _ in range(iters - 1):
         u_it = [ndi.map_coordinates(u, [xx + u_it[0], yy + u_it[1]], mode=mode) for u in us]
     u_it = [ndi.map_coordinates(u, [xx + u_it[0], yy + u_it[1]], mode=mode, cval=np.nan) for u in us]
+    return np.stack(u_it)
+
+
+def invert_u(us, iters=35, edge=0, mode='nearest'):
+    """The variant without overlap (gpa.py:248-259): the grid is the image's own, every one of the
+    `iters` rounds samples at r + u_it(r) - edge."""
+    import scipy.ndimage as ndi
+    us = np.asarray(us, dtype=np.float64)
+    xx, yy = np.mgrid[:us.shape[1], :us.shape[2]]
+    u_it = [ndi.map_coordinates(u, [xx, yy], mode=mode) for u in us]
+    for _ in range(iters):
+        u_it = [ndi.map_coordinates(u, [xx + u_it[0] - edge, yy + u_it[1] - edge], mode=mode) for u in us]
     return np.stack(u_it)
 
 

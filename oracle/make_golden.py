@@ -35,12 +35,21 @@ def _install_stubs():
     numba.prange = range
     sys.modules['numba'] = numba
 
+    class FakeDask(np.ndarray):
+        """ndarray with the two dask methods the *_vec spellings call (gpa.py:714-715, :827-828)"""
+        def rechunk(self, *a, **k):
+            return self
+
+        def compute(self):
+            return np.asarray(self)
+
     dask = types.ModuleType('dask')
     da = types.ModuleType('dask.array')
-    da.stack = np.stack
+    da.stack = lambda *a, **k: np.stack(*a, **k).view(FakeDask)
     da.asarray = np.asarray
     da.any = np.any
     da.as_gufunc = lambda **k: (lambda f: f)
+    da.FakeDask = FakeDask
     dask.array = da
     sys.modules['dask'] = dask
     sys.modules['dask.array'] = da
@@ -73,6 +82,50 @@ def _install_stubs():
     lg.transformations = lgt
     sys.modules['latticegen'] = lg
     sys.modules['latticegen.transformations'] = lgt
+
+
+def _import_cugpa():
+    """pyGPA.cuGPA (CuPy) over a NumPy-backed stand-in for cupy: every cp.* / cupyx.scipy.ndimage call is the
+    NumPy / SciPy function of the same name, results carry the .get() that cuGPA.py calls.  This runs the
+    reference's cuGPA code itself (np.complex, removed from NumPy 1.24, is restored for cu.py:145)."""
+    import scipy.ndimage as ndi
+
+    class CpArray(np.ndarray):
+        def get(self):
+            return np.asarray(self)
+
+    def view(x):
+        if isinstance(x, np.ndarray):
+            return x.view(CpArray)
+        if isinstance(x, (list, tuple)):
+            return type(x)(view(v) for v in x)
+        return x
+
+    def wrap(f):
+        return lambda *a, **k: view(f(*a, **k))
+
+    class Shim(types.ModuleType):
+        def __init__(self, name, src):
+            super().__init__(name)
+            self._src = src
+
+        def __getattr__(self, item):
+            v = getattr(self._src, item)
+            return wrap(v) if callable(v) and not isinstance(v, type) else v
+
+    cp = Shim('cupy', np)
+    cp.fft = Shim('cupy.fft', np.fft)
+    cp.ogrid = np.ogrid
+    cpx = types.ModuleType('cupyx')
+    cpxs = types.ModuleType('cupyx.scipy')
+    cpndi = Shim('cupyx.scipy.ndimage', ndi)
+    cpx.scipy = cpxs
+    cpxs.ndimage = cpndi
+    sys.modules.update({'cupy': cp, 'cupy.fft': cp.fft, 'cupyx': cpx, 'cupyx.scipy': cpxs, 'cupyx.scipy.ndimage': cpndi})
+    if not hasattr(np, 'complex'):
+        np.complex = complex
+    import pyGPA.cuGPA as cu
+    return cu
 
 
 def _import_reference():
@@ -319,6 +372,69 @@ def make_deconv_case(GPA):
     print('deconv         done, max |dec - data| = %.3f' % np.abs(out['dec'] - data).max())
 
 
+def make_variants_case(GPA):
+    """the remaining spellings of SURVEY 8(a) rows a3/a4/a6 and f-1: wfr4, wfr2_grad (grad=None / 'diff'),
+    the dask-vectorised *_vec forms, the cuGPA module (over the NumPy-backed cupy stand-in), invert_u,
+    reconstruct_u_inv_from_phases(pre_diff=True)"""
+    cu = _import_cugpa()
+    g = dict(np.load(os.path.join(OUT, 'hex_64.npz')))
+    img0 = g['image'] - g['image'].mean()
+    sigma, kw, kstep, kvecs = int(g['sigma']), float(g['kw']), float(g['kstep']), g['kvecs']
+    pk = kvecs[0]
+    out = dict(image=g['image'], kvecs=kvecs, sigma=np.int64(sigma), kw=kw, kstep=kstep)
+    ref = GPA.optwfr2(img0, sigma, pk[0], pk[1], kw=kw, kstep=kstep)
+    refg = GPA.wfr2_grad_opt(img0, sigma, pk[0], pk[1], kw=kw, kstep=kstep)
+    # wfr4: an ordered 5 x 5 list (nearest to the peak first), and a generate_klists ring
+    grid = np.array([(pk[0] + i * kstep, pk[1] + j * kstep) for i in range(-2, 3) for j in range(-2, 3)])
+    grid = grid[np.argsort(np.linalg.norm(grid - pk, axis=1), kind='stable')]
+    r4 = GPA.wfr4(img0, sigma, grid, pk, kstep)
+    out.update(wfr4_klist=grid, wfr4_dk=kstep, wfr4_lockin=r4['lockin'], wfr4_w=r4['w'])
+    ring = GPA.generate_klists(kvecs, kmax=1.12, kmin=0.9, sort_list=True)[1]
+    r4b = GPA.wfr4(img0, sigma, ring, kvecs[1], 0.005)
+    out.update(wfr4_ring=ring, wfr4_ring_lockin=r4b['lockin'], wfr4_ring_w=r4b['w'])
+    # wfr2_grad
+    import io, contextlib
+    with contextlib.redirect_stdout(io.StringIO()):
+        gn = GPA.wfr2_grad(img0, sigma, pk[0], pk[1], kw, kstep)
+        gd = GPA.wfr2_grad(img0, sigma, pk[0], pk[1], kw, kstep, grad='diff')
+    assert np.allclose(gn['lockin'], ref['lockin']) and np.array_equal(gn['w'], ref['w'])
+    out.update(wfr2_grad_none=gn['grad'], wfr2_grad_diff=gd['grad'])
+    # *_vec (vecGPA's result gets the .compute() a dask array would have, gpa.py:715)
+    real_vec = GPA.vecGPA
+    GPA.vecGPA = lambda *a, **k: real_vec(*a, **k).view(sys.modules['dask.array'].FakeDask)
+    lv = GPA.wfr2_only_lockin_vec(img0, sigma, pk[0], pk[1], kw, kstep)
+    gv = GPA.wfr2_grad_vec(img0, sigma, pk[0], pk[1], kw, kstep)
+    assert np.allclose(lv, ref['lockin']) and np.allclose(gv['lockin'], ref['lockin'])
+    assert np.allclose(gv['grad'], refg['grad']) and np.array_equal(gv['w'], ref['w'])
+    print('variants       *_vec forms == optwfr2 / wfr2_grad_opt: max |d lockin| %.2e, max |d grad| %.2e'
+          % (np.abs(lv - ref['lockin']).max(), np.abs(gv['grad'] - refg['grad']).max()))
+    GPA.vecGPA = real_vec
+    # cuGPA module
+    c0 = cu.wfr2_grad_opt(img0, sigma, pk[0], pk[1], kw, kstep)
+    cd = cu.wfr2_grad_opt(img0, sigma, pk[0], pk[1], kw, kstep, grad='diff')
+    cs = cu.wfr2_grad_single(img0, sigma, pk[0], pk[1], kw, kstep)
+    assert np.allclose(c0['lockin'], ref['lockin']) and np.allclose(c0['grad'], refg['grad'])
+    assert np.allclose(cu.wfr2_only_lockin(img0, sigma, pk, kw, kstep), ref['lockin'])
+    assert np.allclose(cu.cuGPA(img0, pk, sigma), GPA.optGPA(img0, pk, sigma))
+    assert np.array_equal(cu.wfr2_only_grad(img0, sigma, pk, kw, kstep, grad='diff'), cd['grad'], equal_nan=True)
+    out.update(cu_grad_none=c0['grad'], cu_grad_diff=cd['grad'], cu_single_lockin=cs['lockin'], cu_single_grad=cs['grad'])
+    # invert_u
+    w = dict(np.load(os.path.join(OUT, 'warp_96x80.npz')))
+    out.update(warp_u=w['u'], invert_u=GPA.invert_u(-w['u']), invert_u_edge2_it5=GPA.invert_u(-w['u'], iters=5, edge=2))
+    # pre_diff=True
+    gs = [GPA.wfr2_grad_opt(img0, sigma, k[0], k[1], kw=kw, kstep=kstep) for k in kvecs]
+    grads = np.stack([x['grad'] for x in gs])
+    mask = np.zeros(img0.shape)
+    mask[2 * sigma:-2 * sigma, 2 * sigma:-2 * sigma] = 1.
+    weights = np.stack([np.abs(x['lockin']) for x in gs]) * (mask + 1e-6)
+    out.update(prediff_grads=grads, prediff_weights=weights,
+               u_prediff=GPA.reconstruct_u_inv_from_phases(kvecs, grads, weights, pre_diff=True),
+               u_prediff_unweighted=GPA.reconstruct_u_inv_from_phases(kvecs, grads, weights, weighted_unwrap=False, pre_diff=True))
+    np.savez_compressed(os.path.join(OUT, 'variants_64.npz'), **out)
+    print('variants_64    done: wfr4 ring of %d candidates, %d pixels never accepted'
+          % (len(ring), int((np.abs(r4b['lockin']) == 0).sum())))
+
+
 def main():
     os.makedirs(OUT, exist_ok=True)
     GPA, pu = _import_reference()
@@ -333,6 +449,7 @@ def main():
     make_props_case(GPA)
     make_peaks_case(GPA)
     make_deconv_case(GPA)
+    make_variants_case(GPA)
 
 
 if __name__ == '__main__':

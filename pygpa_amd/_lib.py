@@ -34,6 +34,11 @@ SIGNATURES = {
     'gpa_lockin_batch_dev': (_i, [_vp, _vp, _vp, _i, _d, _vp]),
     'gpa_sweep': (_i, [_vp, _vp, _vp, _vp, _i, _d, _vp, _vp, _vp]),
     'gpa_sweep_dev': (_i, [_vp, _vp, _vp, _vp, _i, _d, _vp, _vp, _vp]),
+    'gpa_sweep_grad': (_i, [_vp, _vp, _vp, _vp, _i, _d, _i, _vp, _vp, _vp]),
+    'gpa_sweep_grad_dev': (_i, [_vp, _vp, _vp, _vp, _i, _d, _i, _vp, _vp, _vp]),
+    'gpa_sweep_gated': (_i, [_vp, _vp, _vp, _vp, _i, _d, _vp, _vp, _vp]),
+    'gpa_reconstruct_prediff': (_i, [_vp, _vp, _vp, _vp, _i, _vp, _vp, _vp]),
+    'gpa_invert_u': (_i, [_vp, _vp, _i, _i, _vp]),
     'gpa_reconstruct_grad': (_i, [_vp, _vp, _vp, _i, _i, _vp, _vp, _vp]),
     'gpa_reconstruct_grad_dev': (_i, [_vp, _vp, _vp, _i, _i, _vp, _vp, _vp]),
     'gpa_weighted_lstsq': (_i, [_vp, _vp, _vp, _vp, _i, _vp]),
@@ -173,16 +178,56 @@ class Plan:
               'gpa_lockin_batch')
         return out
 
-    def sweep(self, image, kref, klist, sigma, want_kidx=True, want_grad=False):
+    def sweep(self, image, kref, klist, sigma, want_kidx=True, want_grad=False, grad_mode=0):
         image = self._img(image)
         kref = _f64(kref).reshape(2)
         klist = _f64(klist).reshape(-1, 2)
         lockin = np.empty(self.shape, dtype=self.cdtype)
         kidx = np.empty(self.shape, dtype=np.int32) if want_kidx else None
         grad = np.empty(self.shape + (2,), dtype=self.rdtype) if want_grad else None
-        check(self.lib.gpa_sweep(self.handle, _ptr(image), _ptr(kref), _ptr(klist), len(klist), float(sigma),
-                                 _ptr(lockin), _ptr(kidx), _ptr(grad)), 'gpa_sweep')
+        if want_grad and grad_mode:
+            check(self.lib.gpa_sweep_grad(self.handle, _ptr(image), _ptr(kref), _ptr(klist), len(klist), float(sigma),
+                                          int(grad_mode), _ptr(lockin), _ptr(kidx), _ptr(grad)), 'gpa_sweep_grad')
+        else:
+            check(self.lib.gpa_sweep(self.handle, _ptr(image), _ptr(kref), _ptr(klist), len(klist), float(sigma),
+                                     _ptr(lockin), _ptr(kidx), _ptr(grad)), 'gpa_sweep')
         return lockin, kidx, grad
+
+    def sweep_gated(self, image, kref, klist, sigma, gate):
+        """wfr4's selection rule; gate: (K, K) bool, gate[j, k] = candidate k may replace the kept candidate j"""
+        image = self._img(image)
+        kref = _f64(kref).reshape(2)
+        klist = _f64(klist).reshape(-1, 2)
+        gate = np.ascontiguousarray(gate, dtype=np.uint8)
+        if gate.shape != (len(klist), len(klist)):
+            raise ValueError('gate must be (K, K)')
+        lockin = np.empty(self.shape, dtype=self.cdtype)
+        kidx = np.empty(self.shape, dtype=np.int32)
+        check(self.lib.gpa_sweep_gated(self.handle, _ptr(image), _ptr(kref), _ptr(klist), len(klist), float(sigma),
+                                       _ptr(gate), _ptr(lockin), _ptr(kidx)), 'gpa_sweep_gated')
+        return lockin, kidx
+
+    def reconstruct_prediff(self, grads, weights, kvecs):
+        kvecs = _f64(kvecs).reshape(-1, 2)
+        grads = np.ascontiguousarray(grads, dtype=self.rdtype)
+        weights = np.ascontiguousarray(weights, dtype=self.rdtype)
+        if grads.shape != (len(kvecs),) + self.shape + (2,) or weights.shape != grads.shape[:-1]:
+            raise ValueError('grads must be (P,) + plan shape + (2,), weights (P,) + plan shape')
+        n0, n1 = self.shape
+        dudx = np.empty((2, n0, n1 - 1), dtype=self.rdtype)
+        dudy = np.empty((2, n0 - 1, n1), dtype=self.rdtype)
+        wnorm = np.empty((n0, n1), dtype=self.rdtype)
+        check(self.lib.gpa_reconstruct_prediff(self.handle, _ptr(grads), _ptr(weights), _ptr(kvecs), len(kvecs),
+                                               _ptr(dudx), _ptr(dudy), _ptr(wnorm)), 'gpa_reconstruct_prediff')
+        return dudx, dudy, wnorm
+
+    def invert_u(self, us, iters=35, edge=0):
+        us = np.ascontiguousarray(us, dtype=self.rdtype)
+        if us.shape != (2,) + self.shape:
+            raise ValueError('us must have shape (2,) + plan shape')
+        out = np.empty((2,) + self.shape, dtype=self.rdtype)
+        check(self.lib.gpa_invert_u(self.handle, _ptr(us), int(iters), int(edge), _ptr(out)), 'gpa_invert_u')
+        return out
 
     def reconstruct_grad(self, lockins, kvecs, mask_border):
         lockins = np.ascontiguousarray(lockins, dtype=self.cdtype)

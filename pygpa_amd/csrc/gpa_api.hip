@@ -353,6 +353,21 @@ static int ensure_tbuf(gpa_plan* p, int planes) {
   return GPA_OK;
 }
 
+// scratch of at least `bytes` in p->d_sf (per-candidate phases of the a4 path, gate table of wfr4, batched lock-ins)
+static int ensure_sf(gpa_plan* p, size_t bytes) {
+  if (p->sf_bytes >= bytes) return GPA_OK;
+  if (p->d_sf) {
+    HIP_TRY(hipStreamSynchronize(p->stream));
+    HIP_TRY(hipFree(p->d_sf));
+    p->ws_bytes -= p->sf_bytes;
+    p->d_sf = nullptr;
+    p->sf_bytes = 0;
+  }
+  TRY(dmalloc(p, &p->d_sf, bytes));
+  p->sf_bytes = bytes;
+  return GPA_OK;
+}
+
 // 2 pi kvecs for the per-pixel solves, re-staged only when the peaks change
 static int stage_kmat(gpa_plan* p, const double* kvecs, int P) {
   std::vector<double> km((size_t)2 * P);
@@ -401,7 +416,7 @@ gpa_plan* gpa_plan_create(int device, int n0, int n1, int max_batch, int dtype) 
   p->csz = 2 * p->rsz;
   p->ax0 = make_axis(n0);
   p->ax1 = make_axis(n1);
-  p->use_graphs = getenv("GPA_NO_GRAPH") == nullptr;
+  p->use_graphs = getenv("GPA_USE_GRAPH") != nullptr;
   p->serial_unwrap = getenv("GPA_SERIAL_UNWRAP") != nullptr;
   const int maxlg = dtype == GPA_F32 ? 14 : 13;
   if (p->ax0.lg > maxlg || p->ax1.lg > maxlg) {
@@ -494,17 +509,12 @@ int gpa_lockin_batch(gpa_plan* p, const void* image, const double* kvecs, int B,
   HIP_TRY(hipSetDevice(p->device));
   const size_t npx = (size_t)p->n0 * p->n1;
   HIP_TRY(hipMemcpyAsync(p->d_image, image, npx * p->rsz, hipMemcpyHostToDevice, p->stream));
-  // results land in Tbuf's tail?  No: pass B reads Tbuf, so use a separate device buffer.
-  void* d_out = nullptr;
-  HIP_TRY(hipMalloc(&d_out, (size_t)B * npx * p->csz));
-  int r = gpa_lockin_batch_dev(p, p->d_image, kvecs, B, sigma, d_out);
-  if (r == GPA_OK) {
-    hipError_t e = hipMemcpyAsync(out, d_out, (size_t)B * npx * p->csz, hipMemcpyDeviceToHost, p->stream);
-    if (e == hipSuccess) e = hipStreamSynchronize(p->stream);
-    if (e != hipSuccess) r = fail(GPA_ERR_HIP, std::string("copy back: ") + hipGetErrorString(e));
-  }
-  hipFree(d_out);
-  return r;
+  // pass B reads Tbuf, so the B lock-ins land in the plan's grown-on-demand scratch
+  TRY(ensure_sf(p, (size_t)B * npx * p->csz));
+  TRY(gpa_lockin_batch_dev(p, p->d_image, kvecs, B, sigma, p->d_sf));
+  HIP_TRY(hipMemcpyAsync(out, p->d_sf, (size_t)B * npx * p->csz, hipMemcpyDeviceToHost, p->stream));
+  HIP_TRY(hipStreamSynchronize(p->stream));
+  return GPA_OK;
 }
 
 // ---- a3 ----------------------------------------------------------------------
@@ -531,20 +541,10 @@ static int sweep_peaks_dev(gpa_plan* p, const void* image, const void* mean, con
   return GPA_OK;
 }
 
-int gpa_sweep_dev(gpa_plan* p, const void* image, const double* kref, const double* klist, int K,
-                  double sigma, void* lockin, int32_t* kidx, void* grad) {
-  if (!p || !image || !kref || !klist || !lockin) return fail(GPA_ERR_ARG, "gpa_sweep: null argument");
-  if (K < 1) return fail(GPA_ERR_ARG, "gpa_sweep: K must be >= 1");
-  HIP_TRY(hipSetDevice(p->device));
-  if (!grad) return sweep_peaks_dev(p, image, nullptr, kref, 1, klist, K, sigma, lockin, kidx);
-  // a4: every candidate's lock-in is needed around the winner, so all K go to HBM once
+// one peak: stage tables, pass A, then pass B in the requested selection mode
+static int sweep_one_peak(gpa_plan* p, const void* image, const double* kref, const double* klist, int K, double sigma,
+                          int mode, void* lockin, int32_t* kidx, const uint8_t* d_gate, void* d_psi) {
   if (K > p->max_batch) return fail(GPA_ERR_STATE, "gpa_sweep: K exceeds the plan's max_batch");
-  const size_t npx = (size_t)p->n0 * p->n1, need = (size_t)K * npx * p->csz;
-  if (p->sf_bytes < need) {
-    if (p->d_sf) { HIP_TRY(hipStreamSynchronize(p->stream)); HIP_TRY(hipFree(p->d_sf)); p->ws_bytes -= p->sf_bytes; p->d_sf = nullptr; p->sf_bytes = 0; }
-    TRY(dmalloc(p, &p->d_sf, need));
-    p->sf_bytes = need;
-  }
   TRY(ensure_filters(p, sigma));
   std::vector<double> kr((size_t)K * 2);
   for (int k = 0; k < K; ++k) { kr[2 * k] = kref[0]; kr[2 * k + 1] = kref[1]; }
@@ -552,24 +552,77 @@ int gpa_sweep_dev(gpa_plan* p, const void* image, const double* kref, const doub
   TRY(stage_kvectors(p, klist, kr.data(), K, &Bx));
   TRY(ensure_tbuf(p, Bx));
   HIP_TRY(launch_passA(p->dtype, p->ax0, p->n1, image, nullptr, p->tb, p->Hx, p->tw0, p->Tbuf, Bx, p->stream));
-  HIP_TRY(launch_passB(p->dtype, p->ax1, p->n0, p->Tbuf, p->Hy, p->tw1, p->tb, K, 1, false, p->d_sf, nullptr, p->stream));
-  HIP_TRY(launch_gradselect(p->dtype, p->d_sf, K, p->n0, p->n1, p->d_kl, p->d_kr, p->tb, lockin, kidx, grad, p->stream));
+  HIP_TRY(launch_passB_ext(p->dtype, p->ax1, p->n0, p->Tbuf, p->Hy, p->tw1, p->tb, K, mode, lockin, kidx, d_gate, d_psi,
+                           p->stream));
   return GPA_OK;
 }
 
-int gpa_sweep(gpa_plan* p, const void* image, const double* kref, const double* klist, int K, double sigma,
-              void* lockin, int32_t* kidx, void* grad) {
+int gpa_sweep_grad_dev(gpa_plan* p, const void* image, const double* kref, const double* klist, int K, double sigma,
+                       int grad_mode, void* lockin, int32_t* kidx, void* grad) {
+  if (!p || !image || !kref || !klist || !lockin || !grad) return fail(GPA_ERR_ARG, "gpa_sweep_grad: null argument");
+  if (K < 1) return fail(GPA_ERR_ARG, "gpa_sweep_grad: K must be >= 1");
+  if (grad_mode < 0 || grad_mode > 2) return fail(GPA_ERR_ARG, "gpa_sweep_grad: grad_mode must be 0, 1 or 2");
+  HIP_TRY(hipSetDevice(p->device));
+  // a4: the winner is selected in registers by pass B as in the plain sweep; what the gradient stencil needs from
+  // the OTHER candidates is only the phase of the winner's candidate at the four neighbours, so pass B also writes
+  // one real per pixel and candidate (K reals instead of the K complex lock-ins of the first build)
+  const size_t npx = (size_t)p->n0 * p->n1;
+  TRY(ensure_sf(p, (size_t)K * npx * p->rsz));
+  int32_t* ki = kidx ? kidx : p->d_kidx;
+  TRY(sweep_one_peak(p, image, kref, klist, K, sigma, 3, lockin, ki, nullptr, p->d_sf));
+  HIP_TRY(launch_phasegrad(p->dtype, p->d_sf, K, ki, p->n0, p->n1, p->d_kl, p->d_kr, grad_mode, grad, p->stream));
+  return GPA_OK;
+}
+
+int gpa_sweep_dev(gpa_plan* p, const void* image, const double* kref, const double* klist, int K,
+                  double sigma, void* lockin, int32_t* kidx, void* grad) {
   if (!p || !image || !kref || !klist || !lockin) return fail(GPA_ERR_ARG, "gpa_sweep: null argument");
+  if (K < 1) return fail(GPA_ERR_ARG, "gpa_sweep: K must be >= 1");
+  HIP_TRY(hipSetDevice(p->device));
+  if (!grad) return sweep_peaks_dev(p, image, nullptr, kref, 1, klist, K, sigma, lockin, kidx);
+  return gpa_sweep_grad_dev(p, image, kref, klist, K, sigma, 0, lockin, kidx, grad);
+}
+
+static int sweep_host(gpa_plan* p, const void* image, const double* kref, const double* klist, int K, double sigma,
+                      int grad_mode, const uint8_t* gate, void* lockin, int32_t* kidx, void* grad) {
+  if (!p || !image || !kref || !klist || !lockin) return fail(GPA_ERR_ARG, "gpa_sweep: null argument");
+  if (K < 1) return fail(GPA_ERR_ARG, "gpa_sweep: K must be >= 1");
   HIP_TRY(hipSetDevice(p->device));
   const size_t npx = (size_t)p->n0 * p->n1;
   HIP_TRY(hipMemcpyAsync(p->d_image, image, npx * p->rsz, hipMemcpyHostToDevice, p->stream));
   if (grad && !p->d_grad) TRY(dmalloc(p, &p->d_grad, 2 * npx * p->rsz));
-  TRY(gpa_sweep_dev(p, p->d_image, kref, klist, K, sigma, p->d_lockin, p->d_kidx, grad ? p->d_grad : nullptr));
+  if (gate) {
+    TRY(ensure_sf(p, (size_t)K * K));
+    HIP_TRY(hipMemcpyAsync(p->d_sf, gate, (size_t)K * K, hipMemcpyHostToDevice, p->stream));
+    TRY(sweep_one_peak(p, p->d_image, kref, klist, K, sigma, 2, p->d_lockin, p->d_kidx, (const uint8_t*)p->d_sf, nullptr));
+  } else if (grad) {
+    TRY(gpa_sweep_grad_dev(p, p->d_image, kref, klist, K, sigma, grad_mode, p->d_lockin, p->d_kidx, p->d_grad));
+  } else {
+    TRY(sweep_peaks_dev(p, p->d_image, nullptr, kref, 1, klist, K, sigma, p->d_lockin, p->d_kidx));
+  }
   if (grad) HIP_TRY(hipMemcpyAsync(grad, p->d_grad, 2 * npx * p->rsz, hipMemcpyDeviceToHost, p->stream));
   HIP_TRY(hipMemcpyAsync(lockin, p->d_lockin, npx * p->csz, hipMemcpyDeviceToHost, p->stream));
   if (kidx) HIP_TRY(hipMemcpyAsync(kidx, p->d_kidx, npx * sizeof(int32_t), hipMemcpyDeviceToHost, p->stream));
   HIP_TRY(hipStreamSynchronize(p->stream));
   return GPA_OK;
+}
+
+int gpa_sweep(gpa_plan* p, const void* image, const double* kref, const double* klist, int K, double sigma,
+              void* lockin, int32_t* kidx, void* grad) {
+  return sweep_host(p, image, kref, klist, K, sigma, 0, nullptr, lockin, kidx, grad);
+}
+
+int gpa_sweep_grad(gpa_plan* p, const void* image, const double* kref, const double* klist, int K, double sigma,
+                   int grad_mode, void* lockin, int32_t* kidx, void* grad) {
+  if (!grad) return fail(GPA_ERR_ARG, "gpa_sweep_grad: null argument");
+  if (grad_mode < 0 || grad_mode > 2) return fail(GPA_ERR_ARG, "gpa_sweep_grad: grad_mode must be 0, 1 or 2");
+  return sweep_host(p, image, kref, klist, K, sigma, grad_mode, nullptr, lockin, kidx, grad);
+}
+
+int gpa_sweep_gated(gpa_plan* p, const void* image, const double* kref, const double* klist, int K, double sigma,
+                    const uint8_t* gate, void* lockin, int32_t* kidx) {
+  if (!gate) return fail(GPA_ERR_ARG, "gpa_sweep_gated: null argument");
+  return sweep_host(p, image, kref, klist, K, sigma, 0, gate, lockin, kidx, nullptr);
 }
 
 // ---- a5/a6 -------------------------------------------------------------------
@@ -592,6 +645,27 @@ int gpa_reconstruct_grad(gpa_plan* p, const void* lockin, const double* kvecs, i
   const size_t npx = (size_t)p->n0 * p->n1;
   HIP_TRY(hipMemcpyAsync(p->d_lockin, lockin, (size_t)P * npx * p->csz, hipMemcpyHostToDevice, p->stream));
   TRY(gpa_reconstruct_grad_dev(p, p->d_lockin, kvecs, P, mask_border, p->d_dudx, p->d_dudy, p->d_wnorm));
+  HIP_TRY(hipMemcpyAsync(dudx, p->d_dudx, (size_t)2 * p->n0 * (p->n1 - 1) * p->rsz, hipMemcpyDeviceToHost, p->stream));
+  HIP_TRY(hipMemcpyAsync(dudy, p->d_dudy, (size_t)2 * (p->n0 - 1) * p->n1 * p->rsz, hipMemcpyDeviceToHost, p->stream));
+  if (wnorm) HIP_TRY(hipMemcpyAsync(wnorm, p->d_wnorm, npx * p->rsz, hipMemcpyDeviceToHost, p->stream));
+  HIP_TRY(hipStreamSynchronize(p->stream));
+  return GPA_OK;
+}
+
+// reconstruct_u_inv_from_phases(pre_diff=True) (geometric_phase_analysis.py:228-237): the phase gradients are given
+int gpa_reconstruct_prediff(gpa_plan* p, const void* grads, const void* weights, const double* kvecs, int P, void* dudx,
+                            void* dudy, void* wnorm) {
+  if (!p || !grads || !weights || !kvecs || !dudx || !dudy) return fail(GPA_ERR_ARG, "gpa_reconstruct_prediff: null argument");
+  if (P < 2 || P > p->max_peaks) return fail(GPA_ERR_STATE, "gpa_reconstruct_prediff: need 2 <= P <= 8 (and P <= max_batch)");
+  HIP_TRY(hipSetDevice(p->device));
+  const size_t npx = (size_t)p->n0 * p->n1;
+  TRY(ensure_tbuf(p, (P + 1) / 2));
+  // staging: grads (P x npx x 2 reals = P complex planes) in d_lockin, weights in Tbuf
+  HIP_TRY(hipMemcpyAsync(p->d_lockin, grads, (size_t)P * npx * 2 * p->rsz, hipMemcpyHostToDevice, p->stream));
+  HIP_TRY(hipMemcpyAsync(p->Tbuf, weights, (size_t)P * npx * p->rsz, hipMemcpyHostToDevice, p->stream));
+  TRY(stage_kmat(p, kvecs, P));
+  HIP_TRY(launch_prediff(p->dtype, p->d_lockin, p->Tbuf, p->d_kmat, P, p->n0, p->n1, p->d_dudx, p->d_dudy, p->d_wnorm,
+                         p->stream));
   HIP_TRY(hipMemcpyAsync(dudx, p->d_dudx, (size_t)2 * p->n0 * (p->n1 - 1) * p->rsz, hipMemcpyDeviceToHost, p->stream));
   HIP_TRY(hipMemcpyAsync(dudy, p->d_dudy, (size_t)2 * (p->n0 - 1) * p->n1 * p->rsz, hipMemcpyDeviceToHost, p->stream));
   if (wnorm) HIP_TRY(hipMemcpyAsync(wnorm, p->d_wnorm, npx * p->rsz, hipMemcpyDeviceToHost, p->stream));
@@ -738,10 +812,12 @@ static void drop_graphs(gpa_plan* p) {
 }
 
 // enqueue the whole driver on the plan's streams without any host synchronisation.
-// A call is ~110 dependent kernel launches; small images are bound by the host's launch rate, not by the
-// kernels.  The launches of a call depend only on (pointers, P, K, x-planes, border, kmax) -- the tables the
-// kernels read are restaged in place by extract_stage -- so the second call with the same key captures them
-// into a hipGraph (both streams) and later calls replay it: one host call per image instead of ~110.
+// A call is ~110 kernel launches.  They depend only on (pointers, P, K, x-planes, border, kmax) -- the tables
+// the kernels read are restaged in place by extract_stage -- so with GPA_USE_GRAPH=1 the second call with one
+// key captures them into a hipGraph (both streams) and later calls replay it.  Measured on MI355X / ROCm 7.2
+// (profiles/r02_graph_vs_eager.txt) the replay is NOT faster than eager launches at any size (512^2: 0.65 vs
+// 0.60 ms; 4096^2: equal) and it serialises with the copy stream of gpa_download_async (9.4 vs 6.75 ms with
+// the D2H of u in the step), so eager launching is the default.
 static int extract_enqueue(gpa_plan* p, const void* image, const double* kvecs, int P, const double* klists, int K,
                            double sigma, int mask_border, int kmax, void* u, void* lockins, int32_t* kidx) {
   if (!p || !image || !kvecs || !klists || !u) return fail(GPA_ERR_ARG, "gpa_extract_displacement_field: null argument");
@@ -954,20 +1030,30 @@ int gpa_tile_gradients_dev(gpa_plan* p, const void* image, size_t image_pitch, i
   return GPA_OK;
 }
 
-int gpa_invert_u_overlap(gpa_plan* p, const void* u, int iters, int edge, void* out) {
-  if (!p || !u || !out) return fail(GPA_ERR_ARG, "gpa_invert_u_overlap: null argument");
-  if (iters < 1 || edge < 0) return fail(GPA_ERR_ARG, "gpa_invert_u_overlap: need iters >= 1, edge >= 0");
+static int invert_u_host(gpa_plan* p, const void* u, int iters, int edge, int shift, void* out) {
+  if (!p || !u || !out) return fail(GPA_ERR_ARG, "gpa_invert_u: null argument");
+  if (iters < 1 || edge < 0) return fail(GPA_ERR_ARG, "gpa_invert_u: need iters >= 1, edge >= 0");
   HIP_TRY(hipSetDevice(p->device));
   const size_t npx = (size_t)p->n0 * p->n1, nout = (size_t)(p->n0 + 2 * edge) * (p->n1 + 2 * edge);
   void* d_out = nullptr;
   HIP_TRY(hipMalloc(&d_out, 2 * nout * p->rsz));
   hipError_t e = hipMemcpyAsync(p->d_u, u, 2 * npx * p->rsz, hipMemcpyHostToDevice, p->stream);
-  if (e == hipSuccess) e = warp_invert_u(p->dtype, p->d_u, p->n0, p->n1, 1.0, iters, edge, d_out, p->stream);
+  if (e == hipSuccess) e = warp_invert_u(p->dtype, p->d_u, p->n0, p->n1, 1.0, iters, edge, shift, d_out, p->stream);
   if (e == hipSuccess) e = hipMemcpyAsync(out, d_out, 2 * nout * p->rsz, hipMemcpyDeviceToHost, p->stream);
   if (e == hipSuccess) e = hipStreamSynchronize(p->stream);
   hipFree(d_out);
-  if (e != hipSuccess) return fail(GPA_ERR_HIP, std::string("gpa_invert_u_overlap: ") + hipGetErrorString(e));
+  if (e != hipSuccess) return fail(GPA_ERR_HIP, std::string("gpa_invert_u: ") + hipGetErrorString(e));
   return GPA_OK;
+}
+
+int gpa_invert_u_overlap(gpa_plan* p, const void* u, int iters, int edge, void* out) {
+  return invert_u_host(p, u, iters, edge, 0, out);
+}
+
+// invert_u (geometric_phase_analysis.py:248-259): the image's own grid, one sampling at r and then `iters` rounds
+// at r + u_it(r) - edge
+int gpa_invert_u(gpa_plan* p, const void* u, int iters, int edge, void* out) {
+  return invert_u_host(p, u, iters, 0, edge, out);
 }
 
 int gpa_undistort_image(gpa_plan* p, const void* deformed, const void* u, void* out) {
@@ -977,7 +1063,7 @@ int gpa_undistort_image(gpa_plan* p, const void* deformed, const void* u, void* 
   HIP_TRY(hipMemcpyAsync(p->d_u, u, 2 * npx * p->rsz, hipMemcpyHostToDevice, p->stream));
   HIP_TRY(hipMemcpyAsync(p->d_image, deformed, npx * p->rsz, hipMemcpyHostToDevice, p->stream));
   // u_inv = invert_u_overlap(-u) (35 rounds, no overlap edge) lands in dudx (2 planes of n0*n1 fit)
-  HIP_TRY(warp_invert_u(p->dtype, p->d_u, p->n0, p->n1, -1.0, 35, 0, p->d_dudx, p->stream));
+  HIP_TRY(warp_invert_u(p->dtype, p->d_u, p->n0, p->n1, -1.0, 35, 0, 0, p->d_dudx, p->stream));
   HIP_TRY(warp_image(p->dtype, p->d_image, p->d_dudx, p->n0, p->n1, p->d_wnorm, p->stream));
   HIP_TRY(hipMemcpyAsync(out, p->d_wnorm, npx * p->rsz, hipMemcpyDeviceToHost, p->stream));
   HIP_TRY(hipStreamSynchronize(p->stream));

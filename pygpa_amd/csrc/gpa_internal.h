@@ -105,10 +105,16 @@ hipError_t launch_passA(int dtype, const Axis& a0, int n1, const void* image, co
 hipError_t launch_passB(int dtype, const Axis& a1, int n0, const void* Tbuf, const void* Hy,
                         const void* tw1, const SweepTables& tb, int P, int K, bool select,
                         void* out, int32_t* kidx, hipStream_t s);
-// a4: per-pixel best-of-K select over stored lock-ins sf[K][n0][n1] + phase gradient of the winner
-hipError_t launch_gradselect(int dtype, const void* sf, int K, int n0, int n1, const double* kl,
-                             const double* kr, const SweepTables& tb, void* lockin, int32_t* kidx,
-                             void* grad, hipStream_t s);
+// one peak, K candidates, the less travelled selection modes (gpa_sweep_ext.hip): mode 2 = gated selection of
+// wfr4 (gate: device K x K bytes, gate[j * K + k] != 0 where candidate k may replace the kept candidate j),
+// mode 3 = plain selection that also writes psi[k][x][y] = -angle(sf_k) of every candidate
+hipError_t launch_passB_ext(int dtype, const Axis& a1, int n0, const void* Tbuf, const void* Hy, const void* tw1,
+                            const SweepTables& tb, int K, int mode, void* out, int32_t* kidx, const uint8_t* gate,
+                            void* psi, hipStream_t s);
+// a4: phase gradient of the winner from the per-candidate phases (mode 0 np.gradient, 1 forward differences with
+// NaN at the end, 2 the same with swapped components)
+hipError_t launch_phasegrad(int dtype, const void* psi, int K, const int32_t* kidx, int n0, int n1, const double* kl,
+                            const double* kr, int mode, void* grad, hipStream_t s);
 int passA_cols(int dtype, int lg);
 // frequency bin held by (thread, register) after the forward transform of length 2^lg
 int spec_index_rt(int lg, int tid, int reg);
@@ -123,6 +129,11 @@ hipError_t launch_reconstruct(int dtype, const void* lockin, const double* kmat 
 hipError_t launch_reconstruct_setup(int dtype, const void* lockin, const double* kmat, int P, int n0, int n1,
                                     int border, void* wnorm, void* r0, void* r1, double* part0, double* part1,
                                     int* nparts, hipStream_t s);
+
+// pre_diff=True: grads (P x n0 x n1 x 2) are phase gradients along axis 1 ([..., 0]) and axis 0 ([..., 1]):
+// wrap, per-pixel weighted least squares for both, crop to the difference grids
+hipError_t launch_prediff(int dtype, const void* grads, const void* w, const double* kmat, int P, int n0, int n1,
+                          void* dudx, void* dudy, void* wnorm, hipStream_t s);
 
 hipError_t launch_wlstsq(int dtype, const void* b, const void* w, const double* kmat, int P, size_t npx,
                          void* out, hipStream_t s);
@@ -151,8 +162,8 @@ hipError_t launch_deconv_filter(int dtype, void* Z, int n0, int n1, const double
 hipError_t launch_deconv_unpack(int dtype, const void* Z, int m0, int m1, int pad, void* out, hipStream_t s);
 
 // ---- f-1 Lawler-Fujita (gpa_warp.hip); both synchronise the stream before returning -----------
-hipError_t warp_invert_u(int dtype, const void* d_u, int n0, int n1, double scale, int iters, int edge, void* d_out,
-                         hipStream_t s);
+hipError_t warp_invert_u(int dtype, const void* d_u, int n0, int n1, double scale, int iters, int edge, int shift,
+                         void* d_out, hipStream_t s);
 hipError_t warp_image(int dtype, const void* d_img, const void* d_uinv, int n0, int n1, void* d_out, hipStream_t s);
 
 }  // namespace gpa

@@ -1,0 +1,164 @@
+// Pass B of the lock-in sweep (y-axis filter on rows + per-pixel selection), shared by the translation
+// units that instantiate its modes: gpa_sweep.hip (all lock-ins / plain best-of-K, the headline path) and
+// gpa_sweep_ext.hip (gated selection of wfr4, selection + per-candidate phases for the a4 gradient).
+#pragma once
+#include "gpa_internal.h"
+
+namespace gpa {
+
+enum { PB_ALL = 0, PB_SELECT = 1, PB_GATED = 2, PB_PHASES = 3 };
+
+template <class T, int LG>
+struct PassBGeom {
+  using F = WgFFT<T, LG>;
+  static constexpr int NF = F::TPF >= 256 ? 1 : 256 / F::TPF;   // rows per workgroup
+  static constexpr int RS = F::LDS_ELEMS + (NF > 1 ? (F::TPF < 32 ? F::TPF : 0) : 0);
+  static constexpr int THREADS = NF * F::TPF;
+  static constexpr size_t LDS_BYTES = (size_t)NF * RS * sizeof(cpx<T>);
+};
+
+template <bool PADDED, class T>
+struct HType { using type = T; };
+template <class T>
+struct HType<true, T> { using type = cpx<T>; };
+
+template <class T> __device__ __forceinline__ cpx<T> hmul(cpx<T> a, T h) { return {a.x * h, a.y * h}; }
+template <class T> __device__ __forceinline__ cpx<T> hmul(cpx<T> a, cpx<T> h) { return cmul(a, h); }
+
+// ---------------------------------------------------------------------------
+// pass B: y-axis filter on rows, best-of-K select
+// ---------------------------------------------------------------------------
+template <class T, int LG, bool PADDED, int MODE>
+#ifndef GPA_F64_WAVES
+#define GPA_F64_WAVES 2   // f64: cap at 256 VGPRs (2 waves/SIMD) instead of 299 at 1 wave: pass B 7.5 -> 5.9 ms
+#endif
+__global__ __launch_bounds__((PassBGeom<T, LG>::THREADS), (sizeof(T) == 8 ? GPA_F64_WAVES : 1)) void passB_kernel(
+    const cpx<T>* __restrict__ Tin, int n0, int n1,
+    const typename HType<PADDED, T>::type* __restrict__ H, const cpx<T>* __restrict__ twtab,
+    const int* __restrict__ planeof, const cpx<T>* __restrict__ cyb, const cpx<T>* __restrict__ sy,
+    const cpx<T>* __restrict__ wyw, const cpx<T>* __restrict__ dx, const cpx<T>* __restrict__ dy, int K,
+    cpx<T>* __restrict__ out, int32_t* __restrict__ kidx, const uint8_t* __restrict__ gate, T* __restrict__ psi) {
+  constexpr bool SELECT = MODE != PB_ALL;
+  using F = WgFFT<T, LG>;
+  using G = PassBGeom<T, LG>;
+  constexpr int TPF = F::TPF, L = F::L;
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  const int tid = threadIdx.x % TPF, f = threadIdx.x / TPF;
+  cpx<T>* lds = reinterpret_cast<cpx<T>*>(smem) + f * G::RS;
+  const int row = blockIdx.x * G::NF + f;
+  const bool valid = row < n0;
+  const int p = blockIdx.y;
+
+  typename F::Twiddles tw;
+  F::load_twiddles(tw, twtab, tid);
+
+  cpx<T> best[16];
+  int bidx[16];
+#pragma unroll
+  for (int i = 0; i < 16; ++i) { best[i] = {T(0), T(0)}; bidx[i] = -1; }
+
+  const int nk = SELECT ? K : 1;
+  for (int k = 0; k < nk; ++k) {
+    const int b = SELECT ? p * K + k : p;
+    // the x-plane of this candidate (shared by every candidate with the same wx: re-reads hit L2)
+    const cpx<T>* src = Tin + ((size_t)planeof[b] * n0 + (valid ? row : 0)) * n1;
+    const cpx<T> cbase = cyb[(size_t)b * TPF + tid];
+    cpx<T> x[16];
+#pragma unroll
+    for (int i = 0; i < 16; ++i) {
+      cpx<T> ph = cmul(cbase, sy[b * 16 + i]);   // exp(2 pi i wy y) at y = tid + TPF*i
+      if constexpr (PADDED) {
+        const int slot = tid + TPF * i;
+        const int ys = axis_src(slot, n1, L, true);
+        if (slot >= n1) ph = cmul(ph, wyw[b]);
+        x[i] = ys >= 0 ? cmul(src[ys], ph) : cpx<T>{T(0), T(0)};
+      } else {
+        x[i] = cmul(src[tid + TPF * i], ph);   // rows past the image reuse row 0; their results are dropped
+      }
+    }
+    F::forward(x, lds, tid, tw);
+    {
+      const typename HType<PADDED, T>::type* Hb = H;
+      asm volatile("" : "+s"(Hb));   // re-read the filter table per candidate instead of pinning 16+ VGPRs
+#pragma unroll
+      for (int i = 0; i < 16; ++i) x[i] = hmul(x[i], Hb[i * TPF + tid]);
+    }
+    F::inverse(x, lds, tid, tw);
+    if constexpr (SELECT) {
+#pragma unroll
+      for (int i = 0; i < 16; ++i) {
+        // |sf|^2 of the kept candidate is recomputed rather than kept in a register
+        const T a = x[i].x * x[i].x + x[i].y * x[i].y;
+        const T ab = best[i].x * best[i].x + best[i].y * best[i].y;
+        if constexpr (MODE == PB_GATED) {
+          // wfr4 (geometric_phase_analysis.py:857-858): also within 2 sqrt(2) dk of the kept k-vector, which
+          // is klist[0] until something is accepted; gate[j * K + k] is that test, made by the host in double
+          const int j = bidx[i] < 0 ? 0 : bidx[i];
+          if (a > ab && gate[(size_t)j * K + k]) { best[i] = x[i]; bidx[i] = k; }
+        } else {
+          if (a > ab) { best[i] = x[i]; bidx[i] = k; }
+        }
+      }
+      if constexpr (MODE == PB_PHASES) {
+        // a4: -angle(sf) of EVERY candidate goes out (one real per pixel and candidate; the gradient
+        // kernel then reads the winner's phase at the pixel's four neighbours)
+        if (valid) {
+#pragma unroll
+          for (int i = 0; i < 16; ++i) {
+            const int yy = tid + TPF * i;
+            if (!PADDED || yy < n1) psi[((size_t)b * n0 + row) * n1 + yy] = -atan2(x[i].y, x[i].x);
+          }
+        }
+      }
+    } else {
+#pragma unroll
+      for (int i = 0; i < 16; ++i) best[i] = x[i];
+    }
+  }
+  if (!valid) return;
+#pragma unroll
+  for (int i = 0; i < 16; ++i) {
+    const int yy = tid + TPF * i;
+    if (!PADDED || yy < n1) {
+      const size_t o = ((size_t)p * n0 + row) * n1 + yy;
+      if constexpr (SELECT) {
+        cpx<T> v = {T(0), T(0)};
+        if (bidx[i] >= 0) {
+          const size_t bb = (size_t)p * K + bidx[i];
+          v = cmul(best[i], cmul(dx[bb * n0 + row], dy[bb * n1 + yy]));
+        }
+        out[o] = v;
+        if (kidx) kidx[o] = bidx[i];
+      } else {
+        out[o] = best[i];
+      }
+    }
+  }
+}
+
+
+template <class T, int LG, bool PADDED, int MODE>
+static hipError_t run_passB(const Axis& a1, int n0, const void* Tbuf, const void* Hy,
+                            const void* tw1, const SweepTables& tb, int P, int K, void* out,
+                            int32_t* kidx, const uint8_t* gate, void* psi, hipStream_t s) {
+  using G = PassBGeom<T, LG>;
+  if constexpr (G::LDS_BYTES > 160 * 1024) {
+    return hipErrorInvalidValue;
+  } else {
+    auto kern = passB_kernel<T, LG, PADDED, MODE>;
+    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern),
+                                       hipFuncAttributeMaxDynamicSharedMemorySize, (int)G::LDS_BYTES);
+    if (e != hipSuccess) return e;
+    dim3 grid((n0 + G::NF - 1) / G::NF, P);
+    GPA_PROF("passB_kernel", s);
+    kern<<<grid, G::THREADS, G::LDS_BYTES, s>>>(
+        (const cpx<T>*)Tbuf, n0, a1.n, (const typename HType<PADDED, T>::type*)Hy,
+        (const cpx<T>*)tw1, tb.planeof, (const cpx<T>*)tb.cyb, (const cpx<T>*)tb.sy, (const cpx<T>*)tb.wyw,
+        (const cpx<T>*)tb.dx, (const cpx<T>*)tb.dy, K, (cpx<T>*)out, kidx, gate, (T*)psi);
+    return hipGetLastError();
+  }
+}
+
+#define GPA_FOR_LG(X) X(6) X(7) X(8) X(9) X(10) X(11) X(12) X(13) X(14)
+
+}  // namespace gpa

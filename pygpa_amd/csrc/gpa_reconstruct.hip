@@ -339,6 +339,59 @@ __global__ __launch_bounds__(256) void wlstsq_kernel(const T* __restrict__ b, co
   out[npx + o] = s1;
 }
 
+// reconstruct_u_inv_from_phases(pre_diff=True), geometric_phase_analysis.py:228-237: g[p][x][y][0] / [1] are the
+// given phase gradients along axis 1 / axis 0; both are wrapped and solved against 2 pi kvecs with the weights of
+// their own pixel, dudx keeps columns [0, n1-1), dudy rows [0, n0-1); wnorm = || weights ||_2 over the peaks
+template <class T>
+__global__ __launch_bounds__(256) void prediff_kernel(const T* __restrict__ g, const T* __restrict__ w,
+                                                     const double* __restrict__ kmat, int P, int n0, int n1,
+                                                     T* __restrict__ dudx, T* __restrict__ dudy, T* __restrict__ wnorm) {
+  const int y = blockIdx.x * 256 + threadIdx.x, x = blockIdx.y;
+  if (y >= n1) return;
+  const size_t npx = (size_t)n0 * n1, o = (size_t)x * n1 + y;
+  T wv[MAXP], wmax = T(0), wsq = T(0);
+  for (int p = 0; p < P; ++p) {
+    wv[p] = w[p * npx + o];
+    const T a = wv[p] < T(0) ? -wv[p] : wv[p];
+    wmax = a > wmax ? a : wmax;
+  }
+  const T ws = wmax > T(0) ? T(1) / wmax : T(0);
+  T a00 = 0, a01 = 0, a11 = 0, rx0 = 0, rx1 = 0, ry0 = 0, ry1 = 0;
+  for (int p = 0; p < P; ++p) {
+    const T k0 = (T)kmat[2 * p], k1 = (T)kmat[2 * p + 1], wn = wv[p] * ws, ww = wn * wn;
+    const T bx = wrap_to_pi(g[2 * (p * npx + o)]), by = wrap_to_pi(g[2 * (p * npx + o) + 1]);
+    wsq += wn * wn;
+    a00 += ww * k0 * k0; a01 += ww * k0 * k1; a11 += ww * k1 * k1;
+    rx0 += ww * k0 * bx; rx1 += ww * k1 * bx;
+    ry0 += ww * k0 * by; ry1 += ww * k1 * by;
+  }
+  T s0, s1;
+  if (y + 1 < n1) {
+    solve2(a00, a01, a11, rx0, rx1, s0, s1);
+    dudx[(size_t)x * (n1 - 1) + y] = s0;
+    dudx[(size_t)n0 * (n1 - 1) + (size_t)x * (n1 - 1) + y] = s1;
+  }
+  if (x + 1 < n0) {
+    solve2(a00, a01, a11, ry0, ry1, s0, s1);
+    dudy[o] = s0;
+    dudy[(size_t)(n0 - 1) * n1 + o] = s1;
+  }
+  if (wnorm) wnorm[o] = sqrt(wsq) * wmax;
+}
+
+hipError_t launch_prediff(int dtype, const void* grads, const void* w, const double* kmat, int P, int n0, int n1,
+                          void* dudx, void* dudy, void* wnorm, hipStream_t s) {
+  if (P > MAXP) return hipErrorInvalidValue;
+  dim3 grid((n1 + 255) / 256, n0);
+  if (dtype == 0)
+    prediff_kernel<float><<<grid, 256, 0, s>>>((const float*)grads, (const float*)w, kmat, P, n0, n1, (float*)dudx,
+                                               (float*)dudy, (float*)wnorm);
+  else
+    prediff_kernel<double><<<grid, 256, 0, s>>>((const double*)grads, (const double*)w, kmat, P, n0, n1, (double*)dudx,
+                                                (double*)dudy, (double*)wnorm);
+  return hipGetLastError();
+}
+
 hipError_t launch_wlstsq(int dtype, const void* b, const void* w, const double* kmat, int P, size_t npx, void* out,
                          hipStream_t s) {
   if (P > MAXP) return hipErrorInvalidValue;

@@ -13,6 +13,7 @@
 // registers across its K candidates (strict '>' in list order == the reference's
 // first-maximum-wins rule, geometric_phase_analysis.py:679-684).
 #include "gpa_internal.h"
+#include "gpa_passb.h"
 
 namespace gpa {
 
@@ -145,23 +146,6 @@ struct PassAGeom {
   static constexpr bool FITS = (size_t)(F::LDS_ELEMS + 32) * sizeof(cpx<T>) <= 160 * 1024;
 };
 
-template <class T, int LG>
-struct PassBGeom {
-  using F = WgFFT<T, LG>;
-  static constexpr int NF = F::TPF >= 256 ? 1 : 256 / F::TPF;   // rows per workgroup
-  static constexpr int RS = F::LDS_ELEMS + (NF > 1 ? (F::TPF < 32 ? F::TPF : 0) : 0);
-  static constexpr int THREADS = NF * F::TPF;
-  static constexpr size_t LDS_BYTES = (size_t)NF * RS * sizeof(cpx<T>);
-};
-
-template <bool PADDED, class T>
-struct HType { using type = T; };
-template <class T>
-struct HType<true, T> { using type = cpx<T>; };
-
-template <class T> __device__ __forceinline__ cpx<T> hmul(cpx<T> a, T h) { return {a.x * h, a.y * h}; }
-template <class T> __device__ __forceinline__ cpx<T> hmul(cpx<T> a, cpx<T> h) { return cmul(a, h); }
-
 // ---------------------------------------------------------------------------
 // pass A: x-axis filter on column tiles
 // ---------------------------------------------------------------------------
@@ -264,159 +248,6 @@ __global__ __launch_bounds__((PassAGeom<T, LG>::THREADS)) void passA_kernel(
 }
 
 // ---------------------------------------------------------------------------
-// pass B: y-axis filter on rows, best-of-K select
-// ---------------------------------------------------------------------------
-template <class T, int LG, bool PADDED, bool SELECT>
-#ifndef GPA_F64_WAVES
-#define GPA_F64_WAVES 2   // f64: cap at 256 VGPRs (2 waves/SIMD) instead of 299 at 1 wave: pass B 7.5 -> 5.9 ms
-#endif
-__global__ __launch_bounds__((PassBGeom<T, LG>::THREADS), (sizeof(T) == 8 ? GPA_F64_WAVES : 1)) void passB_kernel(
-    const cpx<T>* __restrict__ Tin, int n0, int n1,
-    const typename HType<PADDED, T>::type* __restrict__ H, const cpx<T>* __restrict__ twtab,
-    const int* __restrict__ planeof, const cpx<T>* __restrict__ cyb, const cpx<T>* __restrict__ sy,
-    const cpx<T>* __restrict__ wyw, const cpx<T>* __restrict__ dx, const cpx<T>* __restrict__ dy, int K,
-    cpx<T>* __restrict__ out, int32_t* __restrict__ kidx) {
-  using F = WgFFT<T, LG>;
-  using G = PassBGeom<T, LG>;
-  constexpr int TPF = F::TPF, L = F::L;
-  extern __shared__ __attribute__((aligned(16))) char smem[];
-  const int tid = threadIdx.x % TPF, f = threadIdx.x / TPF;
-  cpx<T>* lds = reinterpret_cast<cpx<T>*>(smem) + f * G::RS;
-  const int row = blockIdx.x * G::NF + f;
-  const bool valid = row < n0;
-  const int p = blockIdx.y;
-
-  typename F::Twiddles tw;
-  F::load_twiddles(tw, twtab, tid);
-
-  cpx<T> best[16];
-  int bidx[16];
-#pragma unroll
-  for (int i = 0; i < 16; ++i) { best[i] = {T(0), T(0)}; bidx[i] = -1; }
-
-  const int nk = SELECT ? K : 1;
-  for (int k = 0; k < nk; ++k) {
-    const int b = SELECT ? p * K + k : p;
-    // the x-plane of this candidate (shared by every candidate with the same wx: re-reads hit L2)
-    const cpx<T>* src = Tin + ((size_t)planeof[b] * n0 + (valid ? row : 0)) * n1;
-    const cpx<T> cbase = cyb[(size_t)b * TPF + tid];
-    cpx<T> x[16];
-#pragma unroll
-    for (int i = 0; i < 16; ++i) {
-      cpx<T> ph = cmul(cbase, sy[b * 16 + i]);   // exp(2 pi i wy y) at y = tid + TPF*i
-      if constexpr (PADDED) {
-        const int slot = tid + TPF * i;
-        const int ys = axis_src(slot, n1, L, true);
-        if (slot >= n1) ph = cmul(ph, wyw[b]);
-        x[i] = ys >= 0 ? cmul(src[ys], ph) : cpx<T>{T(0), T(0)};
-      } else {
-        x[i] = cmul(src[tid + TPF * i], ph);   // rows past the image reuse row 0; their results are dropped
-      }
-    }
-    F::forward(x, lds, tid, tw);
-    {
-      const typename HType<PADDED, T>::type* Hb = H;
-      asm volatile("" : "+s"(Hb));   // re-read the filter table per candidate instead of pinning 16+ VGPRs
-#pragma unroll
-      for (int i = 0; i < 16; ++i) x[i] = hmul(x[i], Hb[i * TPF + tid]);
-    }
-    F::inverse(x, lds, tid, tw);
-    if constexpr (SELECT) {
-#pragma unroll
-      for (int i = 0; i < 16; ++i) {
-        // |sf|^2 of the kept candidate is recomputed rather than kept in a register
-        const T a = x[i].x * x[i].x + x[i].y * x[i].y;
-        const T ab = best[i].x * best[i].x + best[i].y * best[i].y;
-        if (a > ab) { best[i] = x[i]; bidx[i] = k; }
-      }
-    } else {
-#pragma unroll
-      for (int i = 0; i < 16; ++i) best[i] = x[i];
-    }
-  }
-  if (!valid) return;
-#pragma unroll
-  for (int i = 0; i < 16; ++i) {
-    const int yy = tid + TPF * i;
-    if (!PADDED || yy < n1) {
-      const size_t o = ((size_t)p * n0 + row) * n1 + yy;
-      if constexpr (SELECT) {
-        cpx<T> v = {T(0), T(0)};
-        if (bidx[i] >= 0) {
-          const size_t bb = (size_t)p * K + bidx[i];
-          v = cmul(best[i], cmul(dx[bb * n0 + row], dy[bb * n1 + yy]));
-        }
-        out[o] = v;
-        if (kidx) kidx[o] = bidx[i];
-      } else {
-        out[o] = best[i];
-      }
-    }
-  }
-}
-
-// ---------------------------------------------------------------------------
-// a4: select + phase-gradient of the winning candidate (wfr2_grad_opt,
-// geometric_phase_analysis.py:803-812).  Input: all K lock-ins of one peak, sf[k][x][y].
-// grad = np.gradient(-angle(sf_winner)) (central differences, one-sided at the borders)
-//        + 2 pi (w - kref), finally wrapToPi(2 g) / 2.
-// ---------------------------------------------------------------------------
-template <class T>
-__device__ __forceinline__ T neg_angle(cpx<T> v) { return -atan2(v.y, v.x); }
-
-template <class T>
-__global__ __launch_bounds__(256) void gradselect_kernel(const cpx<T>* __restrict__ sf, int K, int n0, int n1,
-                                                        const double* __restrict__ kl, const double* __restrict__ kr,
-                                                        const cpx<T>* __restrict__ dx, const cpx<T>* __restrict__ dy,
-                                                        cpx<T>* __restrict__ lockin, int32_t* __restrict__ kidx,
-                                                        T* __restrict__ grad) {
-  const int y = blockIdx.x * 256 + threadIdx.x, x = blockIdx.y;
-  if (y >= n1) return;
-  const size_t npx = (size_t)n0 * n1, o = (size_t)x * n1 + y;
-  T ba = T(0);
-  int bi = -1;
-  for (int k = 0; k < K; ++k) {
-    const cpx<T> v = sf[k * npx + o];
-    const T a = v.x * v.x + v.y * v.y;
-    if (a > ba) { ba = a; bi = k; }
-  }
-  cpx<T> out = {T(0), T(0)};
-  T g0 = T(0), g1 = T(0);
-  if (bi >= 0) {
-    const cpx<T>* pl = sf + bi * npx;
-    out = cmul(pl[o], cmul(dx[(size_t)bi * n0 + x], dy[(size_t)bi * n1 + y]));
-    const T c = neg_angle(pl[o]);
-    const T xm = x > 0 ? neg_angle(pl[o - n1]) : c, xp = x + 1 < n0 ? neg_angle(pl[o + n1]) : c;
-    const T ym = y > 0 ? neg_angle(pl[o - 1]) : c, yp = y + 1 < n1 ? neg_angle(pl[o + 1]) : c;
-    g0 = (x > 0 && x + 1 < n0) ? T(0.5) * (xp - xm) : (xp - xm);
-    g1 = (y > 0 && y + 1 < n1) ? T(0.5) * (yp - ym) : (yp - ym);
-    const T two_pi = T(6.28318530717958647692), pi = T(3.14159265358979323846);
-    g0 += (T)(6.28318530717958647692 * (kl[2 * bi] - kr[2 * bi]));
-    g1 += (T)(6.28318530717958647692 * (kl[2 * bi + 1] - kr[2 * bi + 1]));
-    // wrapToPi(2 g) / 2 with the floored modulo of mathtools.py:72-75
-    T t0 = T(2) * g0 + pi, t1 = T(2) * g1 + pi;
-    g0 = T(0.5) * (t0 - two_pi * floor(t0 / two_pi) - pi);
-    g1 = T(0.5) * (t1 - two_pi * floor(t1 / two_pi) - pi);
-  }
-  lockin[o] = out;
-  if (kidx) kidx[o] = bi;
-  grad[2 * o] = g0;
-  grad[2 * o + 1] = g1;
-}
-
-hipError_t launch_gradselect(int dtype, const void* sf, int K, int n0, int n1, const double* kl, const double* kr,
-                             const SweepTables& tb, void* lockin, int32_t* kidx, void* grad, hipStream_t s) {
-  dim3 grid((n1 + 255) / 256, n0);
-  if (dtype == 0)
-    gradselect_kernel<float><<<grid, 256, 0, s>>>((const cpx<float>*)sf, K, n0, n1, kl, kr, (const cpx<float>*)tb.dx,
-                                                  (const cpx<float>*)tb.dy, (cpx<float>*)lockin, kidx, (float*)grad);
-  else
-    gradselect_kernel<double><<<grid, 256, 0, s>>>((const cpx<double>*)sf, K, n0, n1, kl, kr, (const cpx<double>*)tb.dx,
-                                                   (const cpx<double>*)tb.dy, (cpx<double>*)lockin, kidx, (double*)grad);
-  return hipGetLastError();
-}
-
-// ---------------------------------------------------------------------------
 // launchers
 // ---------------------------------------------------------------------------
 template <class T, int LG, bool PADDED>
@@ -447,29 +278,6 @@ static hipError_t run_passA(const Axis& a0, int n1, const void* image, const voi
   }
 }
 
-template <class T, int LG, bool PADDED, bool SELECT>
-static hipError_t run_passB(const Axis& a1, int n0, const void* Tbuf, const void* Hy,
-                            const void* tw1, const SweepTables& tb, int P, int K, void* out,
-                            int32_t* kidx, hipStream_t s) {
-  using G = PassBGeom<T, LG>;
-  if constexpr (G::LDS_BYTES > 160 * 1024) {
-    return hipErrorInvalidValue;
-  } else {
-    auto kern = passB_kernel<T, LG, PADDED, SELECT>;
-    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern),
-                                       hipFuncAttributeMaxDynamicSharedMemorySize, (int)G::LDS_BYTES);
-    if (e != hipSuccess) return e;
-    dim3 grid((n0 + G::NF - 1) / G::NF, P);
-    GPA_PROF("passB_kernel", s);
-    kern<<<grid, G::THREADS, G::LDS_BYTES, s>>>(
-        (const cpx<T>*)Tbuf, n0, a1.n, (const typename HType<PADDED, T>::type*)Hy,
-        (const cpx<T>*)tw1, tb.planeof, (const cpx<T>*)tb.cyb, (const cpx<T>*)tb.sy, (const cpx<T>*)tb.wyw,
-        (const cpx<T>*)tb.dx, (const cpx<T>*)tb.dy, K, (cpx<T>*)out, kidx);
-    return hipGetLastError();
-  }
-}
-
-#define GPA_FOR_LG(X) X(6) X(7) X(8) X(9) X(10) X(11) X(12) X(13) X(14)
 
 hipError_t launch_passA(int dtype, const Axis& a0, int n1, const void* image, const void* mean,
                         const SweepTables& tb, const void* Hx, const void* tw0, void* Tbuf,
@@ -490,9 +298,9 @@ hipError_t launch_passA(int dtype, const Axis& a0, int n1, const void* image, co
 hipError_t launch_passB(int dtype, const Axis& a1, int n0, const void* Tbuf, const void* Hy,
                         const void* tw1, const SweepTables& tb, int P, int K, bool select,
                         void* out, int32_t* kidx, hipStream_t s) {
-#define CALL_B(T, LG, PD)                                                                   \
-  (select ? run_passB<T, LG, PD, true>(a1, n0, Tbuf, Hy, tw1, tb, P, K, out, kidx, s)       \
-          : run_passB<T, LG, PD, false>(a1, n0, Tbuf, Hy, tw1, tb, P, K, out, kidx, s))
+#define CALL_B(T, LG, PD)                                                                                        \
+  (select ? run_passB<T, LG, PD, PB_SELECT>(a1, n0, Tbuf, Hy, tw1, tb, P, K, out, kidx, nullptr, nullptr, s)      \
+          : run_passB<T, LG, PD, PB_ALL>(a1, n0, Tbuf, Hy, tw1, tb, P, K, out, kidx, nullptr, nullptr, s))
 #define CASE_B(LG)                                                           \
   case LG:                                                                   \
     if (dtype == 0) return a1.padded ? CALL_B(float, LG, true) : CALL_B(float, LG, false); \

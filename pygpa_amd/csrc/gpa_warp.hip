@@ -133,7 +133,7 @@ __device__ __forceinline__ void interp_nearest(const T* const (&coef)[NC], int m
 // u_it(r) <- u(r + u_it(r)), all rounds for one pixel (geometric_phase_analysis.py:291-299)
 template <class T>
 __global__ __launch_bounds__(256) void invert_kernel(const T* __restrict__ c0, const T* __restrict__ c1, int m0, int m1,
-                                                    int n0, int n1, int edge, int iters, T* __restrict__ out) {
+                                                    int n0, int n1, int edge, int shift, int iters, T* __restrict__ out) {
   const int o1 = n1 + 2 * edge, o0 = n0 + 2 * edge;
   const int j = blockIdx.x * 256 + threadIdx.x, i = blockIdx.y;
   if (j >= o1) return;
@@ -141,9 +141,11 @@ __global__ __launch_bounds__(256) void invert_kernel(const T* __restrict__ c0, c
   const T xb = T(i - edge + NPAD), yb = T(j - edge + NPAD);
   T v[2];
   interp_nearest<T, 2>(coef, m0, m1, xb, yb, v);
+  // (shift != 0: invert_u, which samples every later round at r + u_it - shift, geometric_phase_analysis.py:258)
+  const T xs = xb - T(shift), ys = yb - T(shift);
   for (int it = 0; it < iters; ++it) {
     T nv[2];
-    interp_nearest<T, 2>(coef, m0, m1, xb + v[0], yb + v[1], nv);
+    interp_nearest<T, 2>(coef, m0, m1, xs + v[0], ys + v[1], nv);
     v[0] = nv[0];
     v[1] = nv[1];
   }
@@ -201,7 +203,7 @@ hipError_t prefilter(const T* in, int m0, int m1, int ext, const T* d_h, T* tmp,
 }
 
 template <class T>
-hipError_t invert_t(const T* d_u, int n0, int n1, T scale, int iters, int edge, T* d_out, hipStream_t s) {
+hipError_t invert_t(const T* d_u, int n0, int n1, T scale, int iters, int edge, int shift, T* d_out, hipStream_t s) {
   const int m0 = n0 + 2 * NPAD, m1 = n1 + 2 * NPAD;
   const size_t mp = (size_t)m0 * m1;
   T *buf = nullptr, *d_h = nullptr;
@@ -215,7 +217,7 @@ hipError_t invert_t(const T* d_u, int n0, int n1, T scale, int iters, int edge, 
   }
   if (e == hipSuccess) {
     const int o1 = n1 + 2 * edge, o0 = n0 + 2 * edge;
-    invert_kernel<T><<<dim3((o1 + 255) / 256, o0), 256, 0, s>>>(c0, c1, m0, m1, n0, n1, edge, iters, d_out);
+    invert_kernel<T><<<dim3((o1 + 255) / 256, o0), 256, 0, s>>>(c0, c1, m0, m1, n0, n1, edge, shift, iters, d_out);
     e = hipGetLastError();
   }
   if (e == hipSuccess) e = hipStreamSynchronize(s);
@@ -245,10 +247,10 @@ hipError_t warp_t(const T* d_img, const T* d_uinv, int n0, int n1, T* d_out, hip
 }  // namespace
 
 // d_u: 2 x n0 x n1 (device); the field that is inverted is scale * u; d_out: 2 x (n0+2e) x (n1+2e)
-hipError_t warp_invert_u(int dtype, const void* d_u, int n0, int n1, double scale, int iters, int edge, void* d_out,
-                         hipStream_t s) {
-  return dtype == 0 ? invert_t<float>((const float*)d_u, n0, n1, (float)scale, iters, edge, (float*)d_out, s)
-                    : invert_t<double>((const double*)d_u, n0, n1, scale, iters, edge, (double*)d_out, s);
+hipError_t warp_invert_u(int dtype, const void* d_u, int n0, int n1, double scale, int iters, int edge, int shift,
+                         void* d_out, hipStream_t s) {
+  return dtype == 0 ? invert_t<float>((const float*)d_u, n0, n1, (float)scale, iters, edge, shift, (float*)d_out, s)
+                    : invert_t<double>((const double*)d_u, n0, n1, scale, iters, edge, shift, (double*)d_out, s);
 }
 // resample d_img (n0 x n1) at r + u_inv(r), order 3, mode='constant', cval=0
 hipError_t warp_image(int dtype, const void* d_img, const void* d_uinv, int n0, int n1, void* d_out, hipStream_t s) {

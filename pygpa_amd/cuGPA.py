@@ -14,18 +14,15 @@ def cuGPA(image, kvec, sigma=22):
 
 
 def wfr2_grad_opt(image, sigma, kx, ky, kw, kstep, grad=None):
-    """cuGPA.py:41-87.  Only the default np.gradient stencil (grad=None) is provided."""
-    if grad is not None:
-        raise NotImplementedError("only grad=None (np.gradient stencil) is provided")
-    g = _g.wfr2_grad_opt(image, sigma, kx, ky, kw, kstep)
+    """cuGPA.py:41-87.  grad: None (np.gradient), 'diff' (forward differences along axis 0, axis 1 with NaN
+    appended, cuGPA.py:58-62) or a callable phase -> (d/d axis 0, d/d axis 1)."""
+    g = _g._grad_sweep(image, sigma, _g._sweep_list(kx, ky, kw, kstep), (kx, ky), grad, False, None)
     return {'w': g['w'], 'lockin': g['lockin'], 'grad': g['grad']}
 
 
 def wfr2_grad_single(image, sigma, kx, ky, kw, kstep, grad=None):
     """Single-precision variant (cuGPA.py:90-133): no 'w' in the result."""
-    if grad is not None:
-        raise NotImplementedError("only grad=None (np.gradient stencil) is provided")
-    g = _g.wfr2_grad_opt(image, sigma, kx, ky, kw, kstep, dtype=np.float32)
+    g = _g._grad_sweep(image, sigma, _g._sweep_list(kx, ky, kw, kstep), (kx, ky), grad, False, np.float32)
     return {'lockin': g['lockin'], 'grad': g['grad']}
 
 

@@ -252,7 +252,7 @@ class TiledPipeline:
             out[0].copy_(t)
         elif self._host_staged():
             h = out.cpu()
-            self.dist.all_gather_into_tensor(h, t.cpu().contiguous(), group=self.group)
+            self.dist.all_gather_into_tensor(h, t.cpu().contiguous().unsqueeze(0), group=self.group)   # gloo wants world x input
             out.copy_(h)
         else:
             self.dist.all_gather_into_tensor(out, t, group=self.group)

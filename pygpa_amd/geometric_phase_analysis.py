@@ -81,15 +81,103 @@ def wfr2_only_lockin(image, sigma, kx, ky, kw, kstep, dtype=None):
     return _plan(image, len(klist), dtype).sweep(image, (kx, ky), klist, sigma, want_kidx=False)[0]
 
 
+def _grad_sweep(image, sigma, klist, kref, grad, compensated, dtype):
+    """Sweep + phase gradient of the winner for every gradient spelling of the reference.
+    grad None: np.gradient; 'diff': forward differences (NaN at the end of each axis), in the component order of
+    the module that is being mirrored; a callable: the lock-ins of all candidates come from the device
+    (gpa_lockin_batch) and the callable -- host Python by its nature -- is applied per candidate as the
+    reference does."""
+    klist = np.asarray(klist, dtype=np.float64).reshape(-1, 2)
+    plan = _plan(image, len(klist), dtype)
+    if grad is None or grad == 'diff':
+        mode = 0 if grad is None else (2 if compensated else 1)
+        lockin, kidx, g = plan.sweep(image, kref, klist, sigma, want_grad=True, grad_mode=mode)
+        return {'w': _w_from_kidx(kidx, klist), 'lockin': lockin, 'grad': g, 'kidx': kidx}
+    if not callable(grad):
+        raise ValueError("grad must be None, 'diff' or a callable")
+    image = np.asarray(image)
+    n0, n1 = image.shape
+    best = np.zeros((n0, n1), dtype=plan.cdtype)
+    kidx = np.full((n0, n1), -1, dtype=np.int32)
+    out = np.zeros((n0, n1, 2), dtype=plan.rdtype)
+    xx, yy = np.ogrid[0:n0, 0:n1]
+    for start in range(0, len(klist), 8):
+        sfs = plan.lockin_batch(image, klist[start:start + 8], sigma)
+        for i, sf in enumerate(sfs, start):
+            wx, wy = klist[i]
+            comp = np.exp(-2j * np.pi * ((wx - kref[0]) * xx + (wy - kref[1]) * yy))
+            t = np.abs(sf) > np.abs(best)
+            if compensated:      # wfr2_grad (geometric_phase_analysis.py:750-756)
+                g = wrapToPi(np.asarray(grad(-np.angle(sf * comp))) * 2) / 2
+            else:                # cuGPA (cuGPA.py:75-80)
+                g = np.stack(grad(-np.angle(sf)), axis=-1) + 2 * np.pi * np.array([wx - kref[0], wy - kref[1]])
+            best = np.where(t, sf * comp, best)
+            kidx[t] = i
+            out = np.where(t[..., None], g, out)
+    if not compensated:
+        out = wrapToPi(2 * out) / 2
+    return {'w': _w_from_kidx(kidx, klist), 'lockin': best, 'grad': out, 'kidx': kidx}
+
+
 def wfr2_grad_opt(image, sigma, kx, ky, kw, kstep, dtype=None):
     """Adaptive lock-in that also returns the winner's phase gradient
     (geometric_phase_analysis.py:763-813)."""
-    klist = _sweep_list(kx, ky, kw, kstep)
-    lockin, kidx, grad = _plan(image, len(klist), dtype).sweep(image, (kx, ky), klist, sigma, want_grad=True)
-    return {'w': _w_from_kidx(kidx, klist), 'lockin': lockin, 'grad': grad, 'kidx': kidx}
+    return _grad_sweep(image, sigma, _sweep_list(kx, ky, kw, kstep), (kx, ky), None, False, dtype)
 
 
-wfr2_grad = wfr2_grad_opt
+def wfr2_grad(image, sigma, kx, ky, kw, kstep, grad=None, dtype=None):
+    """geometric_phase_analysis.py:722-760: the gradient function acts on the phase of the compensated lock-in
+    (grad=None np.gradient -- the numbers of wfr2_grad_opt up to rounding --, 'diff' forward differences with
+    [..., 0] along axis 1 and [..., 1] along axis 0 (:738-742), or a callable phase -> (N, M, 2))."""
+    return _grad_sweep(image, sigma, _sweep_list(kx, ky, kw, kstep), (kx, ky), grad, True, dtype)
+
+
+def wfr2_grad_vec(image, sigma, kx, ky, kw, kstep, dtype=None):
+    """The dask-vectorised spelling of wfr2_grad_opt (geometric_phase_analysis.py:816-836): same numbers; here
+    the candidates are the batch dimension of the device kernels anyway."""
+    return wfr2_grad_opt(image, sigma, kx, ky, kw, kstep, dtype=dtype)
+
+
+def wfr2_only_lockin_vec(image, sigma, kx, ky, kw, kstep, dtype=None):
+    """The dask-vectorised spelling of wfr2_only_lockin (geometric_phase_analysis.py:705-719)."""
+    return wfr2_only_lockin(image, sigma, kx, ky, kw, kstep, dtype=dtype)
+
+
+def wfr4(image, sigma, klist, kref, dk, dtype=None):
+    """Sweep over an ORDERED k-list in which a candidate is accepted only where its amplitude is larger and it
+    lies within 2 sqrt(2) dk of the k-vector kept so far (geometric_phase_analysis.py:839-862).  The distance
+    test depends only on (kept candidate, new candidate): it is evaluated here in double for all K x K pairs and
+    the device kernel looks it up (gpa_sweep_gated)."""
+    klist = np.asarray(klist, dtype=np.float64).reshape(-1, 2)
+    gate = np.linalg.norm(klist[:, None, :] - klist[None, :, :], axis=-1) < 2 * np.sqrt(2) * dk
+    lockin, kidx = _plan(image, len(klist), dtype).sweep_gated(image, kref, klist, sigma, gate)
+    w = _w_from_kidx(kidx, klist)
+    never = kidx < 0
+    w[0][never], w[1][never] = klist[0]          # the reference starts every pixel at klist[0] (:850-851)
+    return {'w': w, 'lockin': lockin, 'kidx': kidx}
+
+
+def generate_klists(pks, dk=None, kmax=1.9, kmin=0.2, sort_list=False):
+    """Candidate lists for wfr3 / wfr4 (geometric_phase_analysis.py:865-889): for every peak the points of the
+    0.005-spaced k-grid inside the ring kmin..kmax (times the largest |k|) that are closer to this peak than to
+    any other peak or its negative; optionally sorted by distance from the peak.  Host bookkeeping."""
+    pks = np.asarray(pks, dtype=np.float64)
+    both = np.concatenate([pks, -pks])
+    longest = np.linalg.norm(pks, axis=1).max()
+    kmax, kmin = longest * kmax, longest * kmin
+    kk = np.mgrid[-kmax:kmax:0.005, -kmax:kmax:0.005]
+    dists = ((np.moveaxis(kk[..., None], 0, -1) - both) ** 2).sum(axis=-1)
+    r = (kk ** 2).sum(axis=0)
+    ring = (r < kmax ** 2) & (r > kmin ** 2)
+    nearest = dists.min(axis=-1)
+    klists = []
+    for i, pk in enumerate(pks):
+        klist = kk[:, ring & (nearest == dists[..., i])].T
+        if sort_list:
+            klist = klist[np.argsort(np.linalg.norm(klist - pk, axis=1))]
+        klists.append(klist)
+    return klists
+
 
 _NATIVE_SWEEPS = (optwfr2, wfr2_grad_opt)
 
@@ -293,12 +381,14 @@ def reconstruct_u_inv_from_phases(kvecs, phases, weights, weighted_unwrap=True, 
     weights * exp(i phases); with mask border 0 the per-pixel least squares and the
     unwrap weights are those of the reference up to a uniform factor (1 + 1e-6)
     that neither solution depends on."""
-    if pre_diff:
-        raise NotImplementedError('pre_diff=True is not part of the accelerated path')
     phases = np.asarray(phases, dtype=np.float64)
     weights = np.asarray(weights, dtype=np.float64)
-    plan = _lib.get_plan(phases.shape[1:], len(phases), DEFAULT_DTYPE if dtype is None else dtype)
-    dudx, dudy, wnorm = plan.reconstruct_grad(weights * np.exp(1j * phases), kvecs, 0)
+    plan = _lib.get_plan(weights.shape[1:], len(weights), DEFAULT_DTYPE if dtype is None else dtype)
+    if pre_diff:
+        # phases is (P, N, M, 2): given phase gradients, wrapped and solved per pixel on the device (:228-232)
+        dudx, dudy, wnorm = plan.reconstruct_prediff(phases, weights, kvecs)
+    else:
+        dudx, dudy, wnorm = plan.reconstruct_grad(weights * np.exp(1j * phases), kvecs, 0)
     us = []
     for i in range(2):
         if weighted_unwrap:
@@ -380,6 +470,15 @@ def invert_u_overlap(us, iters=35, edge=0, mode='nearest', dtype=None):
     us = np.asarray(us)
     plan = _lib.get_plan(us.shape[1:], 1, DEFAULT_DTYPE if dtype is None else dtype)
     return plan.invert_u_overlap(us, iters=iters, edge=edge)
+
+
+def invert_u(us, iters=35, edge=0, mode='nearest', dtype=None):
+    """The variant without overlap (geometric_phase_analysis.py:248-259): u_it on the image's own grid."""
+    if mode != 'nearest':
+        raise NotImplementedError("only mode='nearest' is provided")
+    us = np.asarray(us)
+    plan = _lib.get_plan(us.shape[1:], 1, DEFAULT_DTYPE if dtype is None else dtype)
+    return plan.invert_u(us, iters=iters, edge=edge)
 
 
 def undistort_image(deformed, u, dtype=None):

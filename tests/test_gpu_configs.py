@@ -76,7 +76,7 @@ def test_sweep_tables_survive_spectral_calls():
         GPA.per(img2, dtype=dtype)
         u2 = GPA.extract_displacement_field(img, kvecs, dtype=dtype)   # same k-lists: tables are not re-staged
         assert np.array_equal(u1, u2)
-        plan = _lib.get_plan(shape, 9, dtype)
+        plan = _lib.get_plan(shape, 64, dtype)
         klist = GPA._sweep_list(kvecs[0][0], kvecs[0][1], 0.04, 0.04 / 3)
         a = plan.sweep(img, kvecs[0], klist, 10)
         plan.per_dft(img2)
@@ -86,7 +86,7 @@ def test_sweep_tables_survive_spectral_calls():
     # deconvolve runs on a plan of the padded shape: share it with a sweep of that shape
     pshape = (shape[0] + 80, shape[1] + 80)
     imgp = hex_moire(pshape, kvecs, noise=0.1, seed=6)
-    plan = _lib.get_plan(pshape, 9, np.float64)
+    plan = _lib.get_plan(pshape, 64, np.float64)
     klist = GPA._sweep_list(kvecs[1][0], kvecs[1][1], 0.04, 0.04 / 3)
     a = plan.sweep(imgp, kvecs[1], klist, 10)
     GPA.gaussian_deconvolve(np.zeros((2,) + shape), 10, dr=20)
@@ -106,13 +106,13 @@ def test_graph_replay_equals_eager(dtype):
     img2 = hex_moire(shape, kvecs, gaussian_bump_displacement(shape), noise=0.3, seed=9)
     kl_a = np.stack(explicit_klists(kvecs, 0.04, 2, 2))
     kl_b = np.stack(explicit_klists(kvecs, 0.03, 2, 2))          # same K and x-plane count, other values
-    os.environ['GPA_NO_GRAPH'] = '1'
     eager = _lib.Plan(shape, 12, dtype)
-    os.environ.pop('GPA_NO_GRAPH')
     ref = {(i, k): eager.extract_displacement_field(im, kvecs, kl, 10, 20)[0]
            for i, im in enumerate((img, img2)) for k, kl in (('a', kl_a), ('b', kl_b))}
     eager.close()
+    os.environ['GPA_USE_GRAPH'] = '1'          # read when the plan is created (opt-in: not faster on ROCm 7.2)
     plan = _lib.Plan(shape, 12, dtype)
+    os.environ.pop('GPA_USE_GRAPH')
     d_img = [DeviceArray(img.astype(dtype)), DeviceArray(img2.astype(dtype))]
     outs = [DeviceArray(np.zeros((2,) + shape, dtype=dtype)) for _ in range(2)]
     seq = [(0, 'a', 0), (0, 'a', 0), (0, 'a', 0), (0, 'b', 0), (0, 'a', 0), (1, 'a', 1), (1, 'a', 1), (1, 'b', 1),
@@ -321,7 +321,7 @@ def test_config5_16384_tiled_undistort_end_to_end():
     e0, e1 = float(np.abs(d0[b:-b, b:-b]).max()), float(np.abs(d1[b:-b, b:-b]).max())
     plan = _lib.Plan((n, n), 1, np.float32)
     t = time.time()
-    rec_img = plan.undistort_image(img, u)
+    rec_img = plan.undistort_image(img, -u)      # the extracted field is -u_true (tests/test_geometric_phase_analysis.py:63)
     t_lf = time.time() - t
     plan.close()
     dev = np.abs(rec_img - orig)[256:-256, 256:-256] / np.abs(orig).max()

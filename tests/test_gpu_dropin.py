@@ -39,6 +39,37 @@ def test_displacement_field(testset):
     assert np.abs(u2 - u_true)[:, 20:-20, 20:-20].max() < np.abs(u1 - u_true)[:, 20:-20, 20:-20].max()
 
 
+@pytest.mark.parametrize('wfr_func', [cuGPA.wfr2_grad_opt, cuGPA.wfr2_grad_single])
+def test_cugpa_displacement_field(testset, wfr_func):
+    """reference tests/test_cuGPA.py:45-56, literally: the cuGPA module's sweeps plugged in as `wfr_func`
+    (the 'any other callable' branch of extract_displacement_field: positional (image, sigma, kx, ky) +
+    kw= / kstep= keywords, 'lockin' read from the returned mapping)"""
+    original, deformed, noise, ori_ks, gaussiandeform = testset
+    u = -GPA.extract_displacement_field(deformed + noise, ori_ks[:3], wfr_func=wfr_func)
+    assert u.shape == gaussiandeform.shape
+    assert np.all(np.abs(u - gaussiandeform)[:, 20:-20, 20:-20] < 0.9)
+    u2 = -GPA.extract_displacement_field(deformed, ori_ks[:3], deconvolve=True)
+    assert u2.shape == gaussiandeform.shape
+    assert np.all(np.abs(u2 - gaussiandeform)[:, 20:-20, 20:-20] < 0.05)
+    # the plug-in branch and the fused branch are the same numbers (f64 wrapper) / f32-close (single wrapper)
+    u_fused = -GPA.extract_displacement_field(deformed + noise, ori_ks[:3])
+    tol = 1e-9 if wfr_func is cuGPA.wfr2_grad_opt else 2e-3
+    assert np.abs(u - u_fused).max() < tol * np.abs(u_fused).max()
+
+
+@pytest.mark.parametrize('wfr_func1,wfr_func2', [(GPA.optwfr2, cuGPA.wfr2_grad_opt), (GPA.wfr2_grad_opt, cuGPA.wfr2_grad_opt)])
+def test_cugpa_wfr2_variants_lockin(wfr_func1, wfr_func2, testset):
+    """reference tests/test_cuGPA.py:66-82, literally"""
+    original, deformed, noise, ori_ks, _ = testset
+    kw = np.linalg.norm(ori_ks, axis=1).mean() / 2.5
+    sigma = int(np.ceil(1 / np.linalg.norm(ori_ks, axis=1).min()))
+    kstep = kw / 3
+    gs = [wfr_func1(deformed - deformed.mean(), sigma, pk[0], pk[1], kw=kw, kstep=kstep) for pk in ori_ks]
+    gs2 = [wfr_func2(deformed - deformed.mean(), sigma, pk[0], pk[1], kw=kw, kstep=kstep) for pk in ori_ks]
+    for g1, g2 in zip(gs, gs2):
+        assert np.allclose(g1['lockin'], g2['lockin'])
+
+
 def test_displacement_field_500():
     """the reference's own image size (500^2, not a power of two): padded-mode lock-ins + Bluestein unwrap"""
     shape = (500, 500)

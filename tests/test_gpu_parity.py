@@ -867,3 +867,86 @@ def test_random_shapes_lockin_sweep_grad_vs_oracle():
         amp = np.abs(ref['lockin'])
         ok = same & (amp > 1e-3 * amp.max())
         assert np.abs(d[ok]).max() < 1e-8, tag
+
+
+# ---- the remaining spellings of rows a3 / a4 / a6 / f-1 against the reference's outputs (variants_64) --------------
+@pytest.mark.gpu
+@pytest.mark.parametrize('dtype', DTYPES)
+def test_variants_wfr4(golden, dtype):
+    """wfr4's gated selection (ordered 5 x 5 list; a generate_klists ring of 210 candidates)"""
+    import pygpa_amd.geometric_phase_analysis as GPA
+    g = golden('variants_64')
+    img0 = g['image'] - g['image'].mean()
+    sigma = int(g['sigma'])
+    for klist, kref, dk, key in ((g['wfr4_klist'], g['kvecs'][0], float(g['wfr4_dk']), 'wfr4'),
+                                 (g['wfr4_ring'], g['kvecs'][1], 0.005, 'wfr4_ring')):
+        r = GPA.wfr4(img0, sigma, klist, kref, dk, dtype=dtype)
+        same = np.all(r['w'] == g[key + '_w'], axis=0)
+        if dtype is np.float64:
+            assert same.all()
+        else:
+            assert same.mean() > 0.97        # f32 amplitude near-ties flip a gated chain
+        assert rel(r['lockin'][same], g[key + '_lockin'][same]) < TOL[dtype]['lock']
+    # generate_klists is host bookkeeping: the list the golden ring was made from
+    ring = GPA.generate_klists(g['kvecs'], kmax=1.12, kmin=0.9, sort_list=True)[1]
+    assert np.array_equal(ring, g['wfr4_ring'])
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize('dtype', DTYPES)
+def test_variants_gradient_spellings(golden, dtype):
+    """wfr2_grad (None / 'diff' / callable), cuGPA 'diff' / callable, *_vec aliases, against the reference's outputs"""
+    import pygpa_amd.cuGPA as cuGPA
+    import pygpa_amd.geometric_phase_analysis as GPA
+    g = golden('variants_64')
+    h = golden('hex_64')
+    img0 = g['image'] - g['image'].mean()
+    sigma, pk, kw, kstep = int(g['sigma']), g['kvecs'][0], float(g['kw']), float(g['kstep'])
+    tol = TOL[dtype]['grad'] * np.pi
+
+    def close(a, ref, kidx):
+        ok = kidx == h['a3_kidx'][0]
+        assert ok.mean() > (0.999 if dtype is np.float64 else 0.99)
+        assert np.array_equal(np.isnan(a), np.isnan(ref))
+        d = np.abs(orc.wrap_to_pi(2 * (a - ref)) / 2)[ok]        # results live on a circle of circumference pi
+        assert np.nanmax(d) < tol
+
+    r = GPA.wfr2_grad(img0, sigma, pk[0], pk[1], kw, kstep, dtype=dtype)
+    close(r['grad'], g['wfr2_grad_none'], r['kidx'])
+    r = GPA.wfr2_grad(img0, sigma, pk[0], pk[1], kw, kstep, grad='diff', dtype=dtype)
+    close(r['grad'], g['wfr2_grad_diff'], r['kidx'])
+    rc = GPA.wfr2_grad(img0, sigma, pk[0], pk[1], kw, kstep, dtype=dtype,
+                       grad=lambda ph: np.stack([np.diff(ph, axis=1, append=np.nan), np.diff(ph, axis=0, append=np.nan)], axis=-1))
+    close(rc['grad'], g['wfr2_grad_diff'], rc['kidx'])
+    rv = GPA.wfr2_grad_vec(img0, sigma, pk[0], pk[1], kw, kstep, dtype=dtype)
+    ro = GPA.wfr2_grad_opt(img0, sigma, pk[0], pk[1], kw, kstep, dtype=dtype)
+    assert np.array_equal(rv['grad'], ro['grad']) and np.array_equal(rv['lockin'], ro['lockin'])
+    assert np.array_equal(GPA.wfr2_only_lockin_vec(img0, sigma, pk[0], pk[1], kw, kstep, dtype=dtype), ro['lockin'])
+    if dtype is np.float64:
+        c = cuGPA.wfr2_grad_opt(img0, sigma, pk[0], pk[1], kw, kstep, grad='diff')
+        kidx = GPA.optwfr2(img0, sigma, pk[0], pk[1], kw, kstep)['kidx']
+        close(c['grad'], g['cu_grad_diff'], kidx)
+        c2 = cuGPA.wfr2_grad_opt(img0, sigma, pk[0], pk[1], kw, kstep,
+                                 grad=lambda ph: (np.diff(ph, axis=0, append=np.nan), np.diff(ph, axis=1, append=np.nan)))
+        close(c2['grad'], g['cu_grad_diff'], kidx)
+        assert np.array_equal(cuGPA.wfr2_only_grad(img0, sigma, pk, kw, kstep, grad='diff'), c['grad'], equal_nan=True)
+    else:
+        cs = cuGPA.wfr2_grad_single(img0, sigma, pk[0], pk[1], kw, kstep)
+        assert 'w' not in cs
+        close(cs['grad'], g['cu_single_grad'], GPA.optwfr2(img0, sigma, pk[0], pk[1], kw, kstep, dtype=dtype)['kidx'])
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize('dtype', DTYPES)
+def test_variants_invert_u_and_prediff(golden, dtype):
+    import pygpa_amd.geometric_phase_analysis as GPA
+    g = golden('variants_64')
+    tol = 1e-10 if dtype is np.float64 else 2e-4
+    for key, kw in (('invert_u', dict()), ('invert_u_edge2_it5', dict(iters=5, edge=2))):
+        out = GPA.invert_u(-g['warp_u'], dtype=dtype, **kw)
+        assert out.shape == g[key].shape
+        assert np.abs(out - g[key]).max() < tol * max(1.0, np.abs(g[key]).max())
+    for key, wu in (('u_prediff', True), ('u_prediff_unweighted', False)):
+        u = GPA.reconstruct_u_inv_from_phases(g['kvecs'], g['prediff_grads'], g['prediff_weights'], weighted_unwrap=wu,
+                                              pre_diff=True, dtype=dtype)
+        assert rel(u, g[key]) < (1e-8 if dtype is np.float64 else 5e-4), key

@@ -57,3 +57,14 @@ def test_k_vector_helpers_match_oracle():
     for t in list(rng.random(200)) + [0.7, 0.2, 0.1999999, 0.001, 0.0005]:
         nxt = GPA._lower_threshold(t)
         assert (nxt is None and orc._decrease_threshold(t) == t) or nxt == orc._decrease_threshold(t)
+
+
+def test_generate_klists_matches_reference(golden):
+    """generate_klists (host bookkeeping for wfr3 / wfr4) against the list the reference produced"""
+    import pygpa_amd.geometric_phase_analysis as GPA
+    g = golden('variants_64')
+    lists = GPA.generate_klists(g['kvecs'], kmax=1.12, kmin=0.9, sort_list=True)
+    assert len(lists) == 3 and np.array_equal(lists[1], g['wfr4_ring'])
+    # unsorted: the same points in grid order
+    raw = GPA.generate_klists(g['kvecs'], kmax=1.12, kmin=0.9)[1]
+    assert sorted(map(tuple, raw)) == sorted(map(tuple, g['wfr4_ring']))

@@ -185,3 +185,46 @@ def test_f4_gaussian_deconvolve(golden):
     padded = np.pad(g['data'][0], 12, mode='reflect')
     direct = np.real(np.fft.ifft2(W * np.fft.fft2(padded)))[12:-12, 12:-12]
     assert np.allclose(direct, g['dec'][0], rtol=1e-10, atol=1e-11)
+
+
+# ---- the remaining spellings of rows a3 / a4 / a6 / f-1 (tests/golden/variants_64.npz) -----------------------
+def test_variants_wfr4_gated_sweep(golden):
+    g = golden('variants_64')
+    img0 = g['image'] - g['image'].mean()
+    r = orc.wfr4(img0, int(g['sigma']), g['wfr4_klist'], g['kvecs'][0], float(g['wfr4_dk']))
+    assert np.array_equal(r['w'], g['wfr4_w']) and np.allclose(r['lockin'], g['wfr4_lockin'], rtol=0, atol=1e-13)
+    r = orc.wfr4(img0, int(g['sigma']), g['wfr4_ring'], g['kvecs'][1], 0.005)
+    assert np.array_equal(r['w'], g['wfr4_ring_w']) and np.allclose(r['lockin'], g['wfr4_ring_lockin'], rtol=0, atol=1e-13)
+
+
+def test_variants_gradient_spellings(golden):
+    """wfr2_grad (compensated phase, grad None / 'diff' with its axis order) and the cuGPA module's 'diff'"""
+    g = golden('variants_64')
+    h = golden('hex_64')
+    img0 = g['image'] - g['image'].mean()
+    sigma, pk = int(g['sigma']), g['kvecs'][0]
+    klist = orc.sweep_grid(pk[0], pk[1], float(g['kw']), float(g['kstep']))
+    for key, kw in (('wfr2_grad_none', dict(grad=None, compensated=True)), ('wfr2_grad_diff', dict(grad='diff', compensated=True)),
+                    ('cu_grad_none', dict(grad=None, compensated=False)), ('cu_grad_diff', dict(grad='diff', compensated=False))):
+        r = orc.sweep_grad_variant(img0, sigma, klist, pk, **kw)
+        assert np.array_equal(np.isnan(r['grad']), np.isnan(g[key])), key
+        assert np.allclose(r['grad'], g[key], rtol=0, atol=1e-11, equal_nan=True), key
+        assert np.array_equal(r['kidx'], h['a3_kidx'][0])
+    # wfr2_grad(grad=None) and cuGPA.wfr2_grad_opt(grad=None) are wfr2_grad_opt up to rounding
+    assert np.allclose(g['wfr2_grad_none'], h['a4_grad0'], rtol=0, atol=1e-11)
+    assert np.allclose(g['cu_grad_none'], h['a4_grad0'], rtol=0, atol=1e-11)
+    # 'diff' of wfr2_grad is the cuGPA 'diff' with the two components swapped (gpa.py:738-742 vs cu.py:58-62)
+    a, b = g['wfr2_grad_diff'], g['cu_grad_diff']
+    ok = ~np.isnan(a[..., ::-1]) & ~np.isnan(b)
+    d = np.abs(orc.wrap_to_pi(2 * (a[..., ::-1] - b)) / 2)
+    assert d[ok].max() < 1e-11
+
+
+def test_variants_invert_u_and_prediff(golden):
+    g = golden('variants_64')
+    assert np.allclose(orc.invert_u(-g['warp_u']), g['invert_u'], rtol=0, atol=1e-12)
+    assert np.allclose(orc.invert_u(-g['warp_u'], iters=5, edge=2), g['invert_u_edge2_it5'], rtol=0, atol=1e-12)
+    for key, wu in (('u_prediff', True), ('u_prediff_unweighted', False)):
+        u = orc.reconstruct_u_inv_from_phases(g['kvecs'], g['prediff_grads'], g['prediff_weights'], weighted_unwrap=wu,
+                                              pre_diff=True, kmax=10 if wu else 100)
+        assert np.abs(u - g[key]).max() < 1e-9 * np.abs(g[key]).max(), key
