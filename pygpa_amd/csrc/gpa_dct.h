@@ -169,9 +169,10 @@ struct WgBluestein {
   // in : x[i] = sample at slot tid + TPF*i (must be 0 for slots >= n), natural layout
   // out: x[i] = X[k] at k = slot (< n); garbage for slots >= n
   // every thread of the workgroup must call (contains barriers)
+  template <class TW>
   __device__ __forceinline__ static void dft(cpx<T> (&x)[E], cpx<T>* lds, int tid, int n,
                                              const cpx<T>* __restrict__ chirp, const cpx<T>* __restrict__ bspec,
-                                             const typename F::Twiddles& tw) {
+                                             const TW& tw) {
     cpx<T> ch[E];
 #pragma unroll
     for (int i = 0; i < E; ++i) {

@@ -19,6 +19,7 @@
 // All per-thread steps are GPA_HD so that tests/host_fft_emulator.cpp can run the
 // very same index arithmetic on the CPU, thread by thread, phase by phase.
 #pragma once
+#include <type_traits>
 
 #if defined(__HIPCC__)
 #include <hip/hip_runtime.h>
@@ -234,6 +235,31 @@ struct WgFFT {
     if constexpr (P > 3) load_twiddles_pass<2>(tw, table, tid);
   }
 
+  // The same six base twiddles per pass, fetched from the table (L1 / L2 resident) where a butterfly needs them
+  // instead of living in registers for the whole kernel: 12 complex values per twiddled pass are 48 VGPRs in
+  // f64, which is what pushes f64 pass A over the 256-register limit (68 B of spills: 3.05 -> 2.2 ms without).
+  // Measured worse in f64 pass B (5.9 -> 6.9 ms: the loads sit in its K loop) and in the f64 row DCT kernels, which
+  // keep the register-resident form.  KTw = the per-precision choice of pass A.
+  struct TwiddlesMem {
+    const cpx<T>* table;
+    int tid;
+  };
+  GPA_HD static void load_twiddles(TwiddlesMem& tw, const cpx<T>* __restrict__ table, int tid) {
+    tw.table = table;
+    tw.tid = tid;
+  }
+  using KTw = typename std::conditional<sizeof(T) == 8, TwiddlesMem, Twiddles>::type;
+  // call once per iteration of a loop around transforms: keeps the compiler from hoisting the (loop invariant)
+  // table loads of TwiddlesMem out of the loop and back into registers
+  GPA_HD static void refresh(Twiddles&) {}
+  GPA_HD static void refresh(TwiddlesMem& tw) {
+#if defined(__HIP_DEVICE_COMPILE__)
+    asm volatile("" : "+s"(tw.table));
+#else
+    (void)tw;
+#endif
+  }
+
   // v[k] *= w^k (forward) or conj(w^k) (inverse), k = 1 .. r-1
   template <int p, int r, bool INV>
   GPA_HD static void twiddle(cpx<T>* v, const Twiddles& tw, int q) {
@@ -246,21 +272,42 @@ struct WgFFT {
       v[k] = t;
     }
   }
+  template <int p, int r, bool INV>
+  GPA_HD static void twiddle(cpx<T>* v, const TwiddlesMem& tw, int q) {
+    constexpr int lgLp = lg_len(p), lgS = lgLp - bits(p);
+    const int G = tw.tid + TPF * q;
+    const int m0 = G & ((1 << lgS) - 1);
+    const int u = m0 << (LOG2L - lgLp);   // exponent unit in the length-L table
+    cpx<T> lo[3], hi[3];
+#pragma unroll
+    for (int c = 0; c < 3; ++c) {
+      if ((c + 1) < r) lo[c] = tw.table[u * (c + 1)];
+      if (4 * (c + 1) < r) hi[c] = tw.table[u * 4 * (c + 1)];
+    }
+#pragma unroll
+    for (int k = 1; k < r; ++k) {
+      const int a = k >> 2, b = k & 3;
+      cpx<T> t = v[k];
+      if (a > 0) t = cmul_maybe_conj<INV>(t, hi[a - 1]);
+      if (b > 0) t = cmul_maybe_conj<INV>(t, lo[b - 1]);
+      v[k] = t;
+    }
+  }
 
   // one pass of butterflies on the thread's 16 registers (q and j loops are
   // fully unrolled, so every register index is static)
-  template <int p, bool INV>
-  GPA_HD static void butterflies(cpx<T> (&x)[E], const Twiddles& tw) {
+  template <int p, bool INV, class TW>
+  GPA_HD static void butterflies(cpx<T> (&x)[E], const TW& tw) {
     constexpr int r = 1 << bits(p), g = E / r;
-    constexpr bool TW = p < P - 1;
+    constexpr bool TWIDDLED = p < P - 1;
 #pragma unroll
     for (int q = 0; q < g; ++q) {
       cpx<T> v[r];
 #pragma unroll
       for (int j = 0; j < r; ++j) v[j] = x[q + g * j];
-      if constexpr (INV && TW) twiddle<p, r, true>(v, tw, q);
+      if constexpr (INV && TWIDDLED) twiddle<p, r, true>(v, tw, q);
       dft_regs<r, INV>(v);
-      if constexpr (!INV && TW) twiddle<p, r, false>(v, tw, q);
+      if constexpr (!INV && TWIDDLED) twiddle<p, r, false>(v, tw, q);
 #pragma unroll
       for (int j = 0; j < r; ++j) x[q + g * j] = v[j];
     }
@@ -293,15 +340,15 @@ struct WgFFT {
 
   // ---- phases (the code between two workgroup barriers) -------------------
   // forward: phase 0 .. P-1, barrier after every phase but the last
-  template <int ph, int LS = 1>
-  GPA_HD static void fwd_phase(cpx<T> (&x)[E], cpx<T>* lds, int tid, const Twiddles& tw) {
+  template <int ph, int LS = 1, class TW = Twiddles>
+  GPA_HD static void fwd_phase(cpx<T> (&x)[E], cpx<T>* lds, int tid, const TW& tw) {
     if constexpr (ph > 0) lds_read<ph, LS>(x, lds, tid);
     butterflies<ph, false>(x, tw);
     if constexpr (ph < P - 1) lds_write<ph, LS>(x, lds, tid);
   }
   // inverse: phase 0 handles pass P-1, phase P-1 handles pass 0
-  template <int ph, int LS = 1>
-  GPA_HD static void inv_phase(cpx<T> (&x)[E], cpx<T>* lds, int tid, const Twiddles& tw) {
+  template <int ph, int LS = 1, class TW = Twiddles>
+  GPA_HD static void inv_phase(cpx<T> (&x)[E], cpx<T>* lds, int tid, const TW& tw) {
     constexpr int p = P - 1 - ph;
     if constexpr (ph > 0) lds_read<p, LS>(x, lds, tid);
     butterflies<p, true>(x, tw);
@@ -311,9 +358,9 @@ struct WgFFT {
 #if defined(__HIPCC__)
   // whole transforms with workgroup barriers (every thread of the workgroup must call).
   // NT independent transforms per thread share each barrier: x[n] uses lds + n * lds_stride.
-  template <int NT, int LS = 1>
+  template <int NT, int LS = 1, class TW = Twiddles>
   __device__ __forceinline__ static void forward_multi(cpx<T> (&x)[NT][E], cpx<T>* lds, int lds_stride, int tid,
-                                                       const Twiddles& tw) {
+                                                       const TW& tw) {
 #pragma unroll
     for (int n = 0; n < NT; ++n) { fwd_phase<0, LS>(x[n], lds + n * lds_stride, tid, tw); if (NT > 1) __builtin_amdgcn_sched_barrier(0); }
     if constexpr (P > 1) {
@@ -332,9 +379,9 @@ struct WgFFT {
       for (int n = 0; n < NT; ++n) { fwd_phase<3, LS>(x[n], lds + n * lds_stride, tid, tw); if (NT > 1) __builtin_amdgcn_sched_barrier(0); }
     }
   }
-  template <int NT, int LS = 1>
+  template <int NT, int LS = 1, class TW = Twiddles>
   __device__ __forceinline__ static void inverse_multi(cpx<T> (&x)[NT][E], cpx<T>* lds, int lds_stride, int tid,
-                                                       const Twiddles& tw) {
+                                                       const TW& tw) {
 #pragma unroll
     for (int n = 0; n < NT; ++n) { inv_phase<0, LS>(x[n], lds + n * lds_stride, tid, tw); if (NT > 1) __builtin_amdgcn_sched_barrier(0); }
     if constexpr (P > 1) {
@@ -353,10 +400,12 @@ struct WgFFT {
       for (int n = 0; n < NT; ++n) { inv_phase<3, LS>(x[n], lds + n * lds_stride, tid, tw); if (NT > 1) __builtin_amdgcn_sched_barrier(0); }
     }
   }
-  __device__ __forceinline__ static void forward(cpx<T> (&x)[E], cpx<T>* lds, int tid, const Twiddles& tw) {
+  template <class TW>
+  __device__ __forceinline__ static void forward(cpx<T> (&x)[E], cpx<T>* lds, int tid, const TW& tw) {
     forward_multi<1>(*reinterpret_cast<cpx<T>(*)[1][E]>(&x), lds, 0, tid, tw);
   }
-  __device__ __forceinline__ static void inverse(cpx<T> (&x)[E], cpx<T>* lds, int tid, const Twiddles& tw) {
+  template <class TW>
+  __device__ __forceinline__ static void inverse(cpx<T> (&x)[E], cpx<T>* lds, int tid, const TW& tw) {
     inverse_multi<1>(*reinterpret_cast<cpx<T>(*)[1][E]>(&x), lds, 0, tid, tw);
   }
 #endif

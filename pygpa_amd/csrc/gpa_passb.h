@@ -60,6 +60,7 @@ __global__ __launch_bounds__((PassBGeom<T, LG>::THREADS), (sizeof(T) == 8 ? GPA_
   const int nk = SELECT ? K : 1;
   for (int k = 0; k < nk; ++k) {
     const int b = SELECT ? p * K + k : p;
+    F::refresh(tw);
     // the x-plane of this candidate (shared by every candidate with the same wx: re-reads hit L2)
     const cpx<T>* src = Tin + ((size_t)planeof[b] * n0 + (valid ? row : 0)) * n1;
     const cpx<T> cbase = cyb[(size_t)b * TPF + tid];

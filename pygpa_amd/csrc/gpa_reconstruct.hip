@@ -170,14 +170,14 @@ __global__ __launch_bounds__(256) void reconstruct_setup_kernel(const cpx<T>* __
                                                                const double* __restrict__ kmat, int n0, int n1,
                                                                int border, T* __restrict__ wnorm, T* __restrict__ r0,
                                                                T* __restrict__ r1, double* __restrict__ part0,
-                                                               double* __restrict__ part1) {
+                                                               double* __restrict__ part1, int band) {
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const int yw = (blockIdx.x * 4 + wave) * FUSED_COLS + lane - 1;
   const bool incol = yw >= 0 && yw < n1;
   const int yc = yw < 0 ? 0 : (yw >= n1 ? n1 - 1 : yw);
   const bool outcol = incol && lane >= 1 && lane <= FUSED_COLS;
-  const int x0 = blockIdx.y * FUSED_ROWS;
-  const int x1 = x0 + FUSED_ROWS < n0 ? x0 + FUSED_ROWS : n0;
+  const int x0 = blockIdx.y * band;
+  const int x1 = x0 + band < n0 ? x0 + band : n0;
   const int xs = x0 > 0 ? x0 - 1 : x0;
   const size_t npx = (size_t)n0 * n1;
   const bool has_r = incol && yw + 1 < n1;
@@ -292,13 +292,18 @@ template <class T>
 static hipError_t launch_reconstruct_setup_t(const void* lockin, const double* kmat, int P, int n0, int n1, int border,
                                              void* wnorm, void* r0, void* r1, double* part0, double* part1, int* nparts,
                                              hipStream_t s) {
-  dim3 grid((n1 + 4 * FUSED_COLS - 1) / (4 * FUSED_COLS), (n0 + FUSED_ROWS - 1) / FUSED_ROWS);
+  // rows per workgroup band: FUSED_ROWS for large images (one halo row per band is recomputed), fewer while the
+  // grid would leave most of the 256 CUs idle -- a band is a serial loop of ~1.5 us per row
+  int band = FUSED_ROWS;
+  const int gx = (n1 + 4 * FUSED_COLS - 1) / (4 * FUSED_COLS);
+  while (band > 2 && gx * ((n0 + band - 1) / band) < 1024) band /= 2;
+  dim3 grid(gx, (n0 + band - 1) / band);
   *nparts = (int)(grid.x * grid.y);
   GPA_PROF("reconstruct_setup_kernel", s);
 #define RS_CASE(PP)                                                                                                   \
   case PP:                                                                                                            \
     reconstruct_setup_kernel<T, PP><<<grid, 256, 0, s>>>((const cpx<T>*)lockin, kmat, n0, n1, border, (T*)wnorm,       \
-                                                         (T*)r0, (T*)r1, part0, part1);                              \
+                                                         (T*)r0, (T*)r1, part0, part1, band);                        \
     break;
   switch (P) {
     RS_CASE(2) RS_CASE(3) RS_CASE(4) RS_CASE(5) RS_CASE(6) RS_CASE(7) RS_CASE(8)

@@ -185,12 +185,13 @@ __global__ __launch_bounds__((PassAGeom<T, LG>::THREADS)) void passA_kernel(
       if (PADDED && slot >= n0) wrapmask |= 1u << i;
     }
   }
-  typename F::Twiddles tw;
+  typename F::KTw tw;
   F::load_twiddles(tw, twtab, t);
 
   const int b0 = blockIdx.y * bchunk;
   const int b1 = (b0 + bchunk < B) ? b0 + bchunk : B;
   for (int b = b0; b < b1; ++b) {
+    F::refresh(tw);
     const cpx<T> base = cxb[(size_t)b * TPF + t];
     cpx<T> x[NT][16];
 #pragma unroll

@@ -26,6 +26,7 @@
 #include <stdlib.h>
 #include <string.h>
 
+#include <type_traits>
 #include <vector>
 
 #include "gpa_dct.h"
@@ -53,6 +54,7 @@ struct Impl {
   void *wk0s;                // w_k along axis 0, spectral layout
   void *ha0[2], *ham0[2];    // 1 - cos term of axis-0 bins (spectral layout); [compat]
   void *hb1[2];              // 1 - cos term of axis-1 bins (natural); [compat]
+  void* tritab;              // TriCol per column (square power-of-two images): transform-free column solve
   double* scal;              // 8 doubles
   int* flags;                // [0] = iteration count, [1] = done
   double* part;              // 3 * MAXPART partial sums
@@ -569,9 +571,13 @@ __global__ __launch_bounds__((RowGeom<T, LG>::THREADS), (sizeof(T) == 8 ? GPA_F6
     }
     __syncthreads();   // in place: every sample of the two rows is in registers before any bin is written
   }
+#ifndef GPA_DCTF_LATE_RK
+#define GPA_DCTF_LATE_RK 0
+#endif
   // the kept spectrum is requested before the transform so that its latency hides behind it
+  // (GPA_DCTF_LATE_RK: after it instead -- 32 registers less across the transform, one more wave per SIMD)
   cpx<T> rk[16];
-  if (it > 0) {
+  if (it > 0 && !GPA_DCTF_LATE_RK) {
 #pragma unroll
     for (int i = 0; i < 16; ++i) rk[i] = {r[oa + tid + TPF * i], r[ob + tid + TPF * i]};
   }
@@ -580,6 +586,10 @@ __global__ __launch_bounds__((RowGeom<T, LG>::THREADS), (sizeof(T) == 8 ? GPA_F6
   D::fwd_scatter(x, lds, tid);
   __syncthreads();
   D::fwd_gather(x, lds, tid, wk);
+  if (it > 0 && GPA_DCTF_LATE_RK) {
+#pragma unroll
+    for (int i = 0; i < 16; ++i) rk[i] = {r[oa + tid + TPF * i], r[ob + tid + TPF * i]};
+  }
   double sq = 0;
 #pragma unroll
   for (int i = 0; i < 16; ++i) {
@@ -741,6 +751,229 @@ __global__ __launch_bounds__((ColGeom<T, LG>::THREADS)) void colsolve_kernel(T* 
       a = wave_sum(a);
       if (threadIdx.x == 0) part_rho[blockIdx.x] = a / (double)n1;
     }
+  }
+}
+
+// ---------------------------------------------------------------------------
+// columns without a transform (square images): for row frequency j the column solve
+//     z = C^-1 diag(1 / (lambda_k + mu_j)) C r ,  lambda_k = 2 cos(pi k / N) - 2,  mu_j = 2 cos(pi j / N) - 2
+// (C = DCT-II along the column) is the solution of the tridiagonal system (T + mu_j) z = r with T the second
+// difference matrix with reflecting ends -- the DCT-II basis diagonalises exactly that matrix.  Its Green's
+// function is the two-sided exponential -lam^(|n|+1) / (1 - lam^2), lam = (1 + h) - sqrt(h (2 + h)), h = 1 - cos(pi j / N),
+// on the half-sample symmetric extension of r, i.e. the cascade of a causal and an anticausal first-order recursion
+//     p_n = r_n + lam p_(n-1)        with p_(-1) = (A + lam^N B) / (1 - lam^(2N)),  A = sum lam^m r_m,  B = sum lam^m r_(N-1-m)
+//     z_n = -lam p_n + lam z_(n+1)   with z_N = -lam / (1 - lam) p_(N-1)
+// -- 5 multiply-adds per sample instead of two 4096-point FFTs, so the kernel is a pure stream.  A thread owns
+// ROWS consecutive rows of VEC adjacent columns (16-byte accesses; Q threads side by side cover Q * VEC columns
+// = 64 bytes of a row at 4096^2 f32); the recursions run in double (f32 data: error 1e-8, below an f32 FFT's),
+// chunk carries are combined by a scan through LDS.  Column j = 0 (mu = 0, the row means) is the singular one:
+// the reference divides its DC bin by 1 (phase_unwrap.py:110-114), i.e. z = T^+ (r - mean) + mean, which is the same
+// recursion with lam = 1 on r - mean followed by the removal of the mean of z.
+// rho = <r, z> follows from z alone: z'(T + mu) z = -sum (z_(n+1) - z_n)^2 + mu sum z_n^2, no cancellation.
+// ---------------------------------------------------------------------------
+struct TriCol {
+  double lam, lamR, lamN, inv, zn;   // lam^ROWS, lam^N, 1 / (1 - lam^(2N)), -lam / (1 - lam); column 0: 1, 1, 1, 0, 0
+};
+// rows per thread: the f32 tile of a thread (ROWS x 4 columns) has to leave room for the double-precision recursions
+// within the 128 VGPRs that 1024 threads per workgroup allow: 8 rows (32 registers); f64: 16 rows x 2 columns (64)
+template <class T> struct TriRows { static constexpr int value = sizeof(T) == 4 ? 8 : 16; };
+
+// scan x_s = v_s + m x_(s-1) over the S chunks of every column (REVERSE: from the last chunk down).  Threads are
+// laid out chunk-major with Q threads side by side, so a wavefront holds 64 / Q consecutive chunks of its Q column
+// groups: the scan runs inside the wavefront with lane shuffles (log2(64 / Q) steps), the wavefronts' totals are
+// chained through LDS (one barrier).  excl = x of the previous chunk in scan order (0 for the first), total = x of
+// the last one.  lds: >= 16 * Q * VEC doubles.
+template <int NV, int VEC, int Q, bool REVERSE>
+__device__ __forceinline__ void chunk_scan(const double (&v)[NV], const double (&m)[NV], double (&excl)[NV],
+                                           double (&total)[NV], double* lds, int col) {
+  constexpr int CPW = 64 / Q;                       // chunks per wavefront
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, nw = (blockDim.x + 63) >> 6;
+  const int active = blockDim.x < 64 ? blockDim.x / Q : CPW;   // chunks in this wavefront (tiny images: fewer)
+  const int sl = REVERSE ? active - 1 - lane / Q : lane / Q;   // position of this chunk in scan order inside the wavefront
+  const int wo = REVERSE ? nw - 1 - wave : wave;               // position of the wavefront in scan order
+  double cur[NV], mp[NV];
+#pragma unroll
+  for (int a = 0; a < NV; ++a) { cur[a] = v[a]; mp[a] = m[a]; }
+#pragma unroll
+  for (int off = 1; off < CPW; off <<= 1) {
+#pragma unroll
+    for (int a = 0; a < NV; ++a) {
+      const double t = REVERSE ? __shfl_down(cur[a], off * Q) : __shfl_up(cur[a], off * Q);
+      if (sl >= off) cur[a] += mp[a] * t;
+      mp[a] *= mp[a];
+    }
+  }
+  // mp = m^CPW: one wavefront's worth of chunks.  (active < CPW only when there is a single wavefront.)
+  __syncthreads();   // lds may still be read from an earlier scan
+  if (sl == active - 1) {
+#pragma unroll
+    for (int a = 0; a < NV; ++a) lds[(size_t)wo * (Q * VEC) + col + a] = cur[a];
+  }
+  __syncthreads();
+#pragma unroll
+  for (int a = 0; a < NV; ++a) {
+    double acc = 0.0;   // x at the end of the previous wavefront
+    for (int w = 0; w < wo; ++w) acc = acc * mp[a] + lds[(size_t)w * (Q * VEC) + col + a];
+    double tot = acc;
+    for (int w = wo; w < nw; ++w) tot = tot * mp[a] + lds[(size_t)w * (Q * VEC) + col + a];
+    total[a] = tot;
+    // m^(sl + 1) by squaring
+    double pw = 1.0, base = m[a];
+    for (int bit = sl + 1; bit; bit >>= 1) { if (bit & 1) pw *= base; base *= base; }
+    const double incl = cur[a] + pw * acc;
+    const double prev = REVERSE ? __shfl_down(incl, Q) : __shfl_up(incl, Q);
+    excl[a] = sl > 0 ? prev : acc;
+  }
+}
+
+template <class T, int VEC, int Q, int R>
+__global__ __launch_bounds__(1024) void colsolve_tri_kernel(const T* __restrict__ Zin, T* __restrict__ Z, int n0, int n1,
+                                                           const TriCol* __restrict__ tab, const T* __restrict__ hb,
+                                                           int* flags, const double* part_norm, int nnorm, int it,
+                                                           double eps, double* scal, double* part_rho) {
+  if (flags[1]) return;
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  double* lds = reinterpret_cast<double*>(smem);
+  __shared__ double shn[1024];
+  const int S = blockDim.x / Q;
+  const int q = threadIdx.x % Q, s = threadIdx.x / Q;
+  int tile = blockIdx.x;
+  if ((gridDim.x & 7) == 0) tile = (blockIdx.x & 7) * (gridDim.x >> 3) + (blockIdx.x >> 3);
+  const int y0 = (tile * Q + q) * VEC, row0 = s * R, col = q * VEC;
+  struct alignas(VEC * sizeof(T)) Vec { T v[VEC]; };
+  Vec x[R];
+#pragma unroll
+  for (int k = 0; k < R; ++k) x[k] = *reinterpret_cast<const Vec*>(Zin + (size_t)(row0 + k) * n1 + y0);
+  if (it > 0) {
+    // the reference's stopping test (phase_unwrap.py:348) on the update the row kernel has just applied
+    const double tot = reduce_partials(part_norm, nnorm, shn);
+    const double best = scal[10 + ((it - 1) & 1)];
+    const bool stop = sqrt(tot) < eps * sqrt(scal[5]) || tot == 0.0 || !(tot == tot) || tot > 1e4 * best;
+    if (blockIdx.x == 0 && threadIdx.x == 0) {
+      flags[0] = it;
+      scal[6] = tot;
+      scal[10 + (it & 1)] = tot < best ? tot : best;
+      if (stop) flags[1] = 1;
+    }
+    if (stop) return;
+  }
+  // (per-column constants are re-read from the table where they are needed instead of being kept in registers:
+  //  1024 threads leave 128 VGPRs per lane, 64 of which hold the tile)
+  const bool c0 = y0 == 0;   // this thread's first column is column 0, the singular one
+  // A sample is read by three recursions.  Each re-read goes through an opaque copy (reread()): hipcc otherwise
+  // shares the f32 -> f64 conversion between the passes and keeps all 64 converted samples of the thread alive
+  // from one pass to the next -- 128 registers more, i.e. spills at the 128 this launch geometry allows.
+  auto reread = [](T v) {
+    if constexpr (sizeof(T) == 4) asm volatile("" : "+v"(v));
+    return (double)v;
+  };
+  // ---- pass 1: chunk aggregates of the zero-initialised causal sum (b) and of A's weighted sum (aw)
+  double carry[VEC];         // becomes: the true p just above this chunk
+  double shift0 = 0.0;       // mean of column 0
+  // (two columns at a time: b, A's share, their scans' inputs and outputs for four columns at once do not fit)
+#pragma unroll
+  for (int h = 0; h < VEC; h += 2) {
+    double b[2], aw[2], lamR[2];
+#pragma unroll
+    for (int a2 = 0; a2 < 2; ++a2) {
+      const int a = h + a2;
+      const double lam = tab[y0 + a].lam;
+      lamR[a2] = tab[y0 + a].lamR;
+      double bb = 0.0;
+#pragma unroll
+      for (int k = 0; k < R; ++k) bb = (double)x[k].v[a] + lam * bb;
+      // A's share of this chunk in the data's own precision: it only enters through p_(-1) (f32: relative error
+      // 1e-7 in a boundary term)
+      const T lamT = (T)lam;
+      T ww = T(0);
+#pragma unroll
+      for (int k = R - 1; k >= 0; --k) ww = x[k].v[a] + lamT * ww;
+      b[a2] = bb;
+      aw[a2] = (double)ww;
+    }
+    double A[2], dummy[2], cP[2], B[2];
+    chunk_scan<2, VEC, Q, true>(aw, lamR, dummy, A, lds, col + h);
+    chunk_scan<2, VEC, Q, false>(b, lamR, cP, B, lds, col + h);
+#pragma unroll
+    for (int a2 = 0; a2 < 2; ++a2) {
+      const int a = h + a2;
+      // lamR^s by squaring (s < 1024)
+      double pw = 1.0, base = lamR[a2];
+      for (int bit = s; bit; bit >>= 1) { if (bit & 1) pw *= base; base *= base; }
+      carry[a] = cP[a2] + pw * (A[a2] + tab[y0 + a].lamN * B[a2]) * tab[y0 + a].inv;
+    }
+    if (h == 0 && c0) {
+      shift0 = B[0] / (double)n0;
+      carry[0] -= (double)row0 * shift0;
+    }
+  }
+  // ---- pass 2: causal recursion in place from the true carry; aggregate of the anticausal one
+  double e[VEC];
+#pragma unroll
+  for (int a = 0; a < VEC; ++a) {
+    const double lam = tab[y0 + a].lam, sh = (a == 0 && c0) ? shift0 : 0.0;
+    double p = carry[a];
+#pragma unroll
+    for (int k = 0; k < R; ++k) {
+      p = (reread(x[k].v[a]) - sh) + lam * p;
+      x[k].v[a] = (T)p;
+    }
+    // z_N = zn p_(N-1) enters the last chunk's aggregate (the stored, rounded p: the same value pass 3 starts from)
+    double ee = s == S - 1 ? tab[y0 + a].zn * (double)x[R - 1].v[a] : 0.0;
+#pragma unroll
+    for (int k = R - 1; k >= 0; --k) ee = lam * (ee - (double)x[k].v[a]);
+    e[a] = ee;
+  }
+  {
+    double lamR[VEC], Ztot[VEC];
+#pragma unroll
+    for (int a = 0; a < VEC; ++a) lamR[a] = tab[y0 + a].lamR;
+    chunk_scan<VEC, VEC, Q, true>(e, lamR, carry, Ztot, lds, col);   // carry: z just below this chunk
+  }
+  // ---- pass 3: anticausal recursion in place, rho from the quadratic form
+  double rho = 0.0, zsum0 = 0.0;
+#pragma unroll
+  for (int a = 0; a < VEC; ++a) {
+    const double lam = tab[y0 + a].lam;
+    double z = s == S - 1 ? tab[y0 + a].zn * (double)x[R - 1].v[a] : carry[a];
+    double dsq = 0.0, zsq = 0.0;
+#pragma unroll
+    for (int k = R - 1; k >= 0; --k) {
+      const double zn = lam * (z - reread(x[k].v[a]));
+      if (!(s == S - 1 && k == R - 1)) dsq += (z - zn) * (z - zn);   // no difference across the reflecting end
+      zsq += zn * zn;
+      z = zn;
+      x[k].v[a] = (T)zn;
+    }
+    double r = -dsq - 2.0 * (double)hb[y0 + a] * zsq;
+    if (a == 0 && c0) {
+#pragma unroll
+      for (int k = 0; k < R; ++k) zsum0 += (double)x[k].v[0];
+      if (s == 0) r += (double)n0 * shift0 * shift0;
+      r *= 0.5;                                   // c_0 = 1/2 of SciPy's DCT-II normalisation along the rows
+    }
+    rho += r;
+  }
+  if (tile == 0) {
+    // column 0: remove the mean of z, add the mean of r (its DC bin is divided by 1)
+    const double zs = block_sum(c0 ? zsum0 : 0.0, shn);
+    if (c0) {
+      const T fix = (T)(shift0 - zs / (double)n0);
+#pragma unroll
+      for (int k = 0; k < R; ++k) x[k].v[0] += fix;
+    }
+  }
+  {
+    // the store addresses equal the load addresses: recomputed from an opaque copy of the row so that the compiler
+    // does not keep 16 64-bit addresses alive across the three passes
+    int rs = row0;
+    asm volatile("" : "+v"(rs));
+#pragma unroll
+    for (int k = 0; k < R; ++k) *reinterpret_cast<Vec*>(Z + (size_t)(rs + k) * n1 + y0) = x[k];
+  }
+  if (part_rho) {
+    const double tot = block_sum(rho, shn);
+    if (threadIdx.x == 0) part_rho[blockIdx.x] = tot / (2.0 * (double)n1);
   }
 }
 
@@ -1273,9 +1506,50 @@ hipError_t dispatch_rowidct(const Impl* w, int* nparts, hipStream_t s) {
 #undef CASE
   return hipErrorInvalidValue;
 }
+template <class T, int VEC, int Q>
+hipError_t run_colsolve_tri(const Impl* w, int compat, hipStream_t s, const double* part_norm, int nnorm, int it, double eps,
+                            double* part_rho, int* nrho, const void* zin) {
+  constexpr int R = TriRows<T>::value;
+  auto kern = colsolve_tri_kernel<T, VEC, Q, R>;
+  const int S = w->n0 / R, threads = S * Q, grid = w->n1 / (Q * VEC);
+  const size_t lds = (size_t)16 * Q * VEC * sizeof(double);
+  hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+  if (e != hipSuccess) return e;
+  if (nrho) *nrho = grid;
+  GPA_PROF("colsolve_kernel", s);
+  kern<<<grid, threads, lds, s>>>((const T*)(zin ? zin : w->z), (T*)w->z, w->n0, w->n1, (const TriCol*)w->tritab,
+                                  (const T*)w->hb1[compat], w->flags, part_norm, nnorm, it, eps, w->scal, part_rho);
+  return hipGetLastError();
+}
+
+// square images: the transform-free column solve; Q (threads side by side along a row) as large as 1024 threads
+// per workgroup and >= 256 workgroups allow
+template <class T>
+hipError_t dispatch_colsolve_tri(const Impl* w, int compat, hipStream_t s, const double* part_norm, int nnorm, int it,
+                                 double eps, double* part_rho, int* nrho, const void* zin) {
+  constexpr int VEC = 16 / sizeof(T);
+  const int S = w->n0 / TriRows<T>::value;
+  int Q = 4;
+  while (Q > 1 && (S * Q > 1024 || w->n1 / (Q * VEC) < 256)) Q /= 2;
+  switch (Q) {
+    case 4: return run_colsolve_tri<T, VEC, 4>(w, compat, s, part_norm, nnorm, it, eps, part_rho, nrho, zin);
+    case 2: return run_colsolve_tri<T, VEC, 2>(w, compat, s, part_norm, nnorm, it, eps, part_rho, nrho, zin);
+    default: return run_colsolve_tri<T, VEC, 1>(w, compat, s, part_norm, nnorm, it, eps, part_rho, nrho, zin);
+  }
+}
+
 hipError_t dispatch_colsolve(const Impl* w, int compat, hipStream_t s, const double* part_norm = nullptr,
                              int nnorm = 0, int it = 0, double eps = 0.0, double* part_rho = nullptr,
                              int* nrho = nullptr, const void* zin = nullptr) {
+  // Square images can solve the columns without a transform (colsolve_tri_kernel).  Measured at 4096^2 on MI355X
+  // (profiles/r02_colsolve_tri.txt): f64 1.54 ms per step against 2.0 for the DCT kernel (whose f64 transforms
+  // spill), f32 82 us per launch against 68 -- the f32 DCT kernel is the faster one.  So: f64 by default,
+  // GPA_COLSOLVE=tri / fft forces one or the other (tests compare the two).
+  const char* mode = getenv("GPA_COLSOLVE");
+  const bool want_tri = mode ? mode[0] == 't' : w->dtype != 0;
+  if (w->tritab && part_rho && want_tri && w->n0 / (w->dtype == 0 ? TriRows<float>::value : TriRows<double>::value) <= 1024)
+    return w->dtype == 0 ? dispatch_colsolve_tri<float>(w, compat, s, part_norm, nnorm, it, eps, part_rho, nrho, zin)
+                         : dispatch_colsolve_tri<double>(w, compat, s, part_norm, nnorm, it, eps, part_rho, nrho, zin);
 #define CASE(LG) case LG: return w->dtype == 0 ? run_colsolve<float, LG>(w, compat, s, part_norm, nnorm, it, eps, part_rho, nrho, zin) \
                                                : run_colsolve<double, LG>(w, compat, s, part_norm, nnorm, it, eps, part_rho, nrho, zin);
   switch (w->lg0) { GPA_FOR_LG(CASE) }
@@ -1534,6 +1808,27 @@ hipError_t unwrap_workspace_create(int dtype, int n0, int n1, hipStream_t s, Unw
       if ((e = upload(dtype, &w->ham0[compat], am, &bytes, s)) != hipSuccess) return e;
       if ((e = upload(dtype, &w->hb1[compat], b, &bytes, s)) != hipSuccess) return e;
     }
+    if (n0 == n1) {
+      // transform-free column solve (colsolve_tri_kernel): per row frequency j the decay lam_j of the Green's
+      // function of (T + mu_j) and the constants of its boundary terms, in long double
+      std::vector<TriCol> tc((size_t)n1);
+      for (int j = 0; j < n1; ++j) {
+        if (j == 0) { tc[0] = {1.0, 1.0, 1.0, 0.0, 0.0}; continue; }
+        const long double sj = sinl((long double)M_PI * j / (2.0L * n1)), h = 2 * sj * sj;
+        const long double lam = (1 + h) - sqrtl(h * (2 + h));
+        tc[j].lam = (double)lam;
+        tc[j].lamR = (double)powl(lam, dtype == 0 ? TriRows<float>::value : TriRows<double>::value);
+        tc[j].lamN = (double)powl(lam, n0);
+        tc[j].inv = (double)(1.0L / (1.0L - powl(lam, 2.0L * n0)));
+        tc[j].zn = (double)(-lam / (1.0L - lam));
+      }
+      e = hipMalloc(&w->tritab, tc.size() * sizeof(TriCol));
+      if (e != hipSuccess) return e;
+      bytes += tc.size() * sizeof(TriCol);
+      e = hipMemcpyAsync(w->tritab, tc.data(), tc.size() * sizeof(TriCol), hipMemcpyHostToDevice, s);
+      if (e == hipSuccess) e = hipStreamSynchronize(s);
+      if (e != hipSuccess) return e;
+    }
   }
   if (bytes_out) *bytes_out = bytes;
   return hipSuccess;
@@ -1544,7 +1839,7 @@ void unwrap_workspace_destroy(UnwrapWorkspace* ws) {
   if (!w) return;
   void* bufs[] = {w->r, w->p, w->p2, w->q, w->z, w->tw0, w->tw1, w->wk1, w->wk0s, w->ha0[0], w->ha0[1], w->ham0[0],
                   w->ham0[1], w->hb1[0], w->hb1[1], w->scal, w->flags, w->part, w->btw0, w->btw1, w->chirp0, w->chirp1,
-                  w->bspec0, w->bspec1, w->gwk0, w->gwk1, w->gha0[0], w->gha0[1], w->gham0[0], w->gham0[1]};
+                  w->bspec0, w->bspec1, w->gwk0, w->gwk1, w->gha0[0], w->gha0[1], w->gham0[0], w->gham0[1], w->tritab};
   for (void* b : bufs)
     if (b) hipFree(b);
   for (int j = 2; j < w->nring; ++j)

@@ -950,3 +950,34 @@ def test_variants_invert_u_and_prediff(golden, dtype):
         u = GPA.reconstruct_u_inv_from_phases(g['kvecs'], g['prediff_grads'], g['prediff_weights'], weighted_unwrap=wu,
                                               pre_diff=True, dtype=dtype)
         assert rel(u, g[key]) < (1e-8 if dtype is np.float64 else 5e-4), key
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize('dtype', DTYPES)
+@pytest.mark.parametrize('n', [64, 256, 1024, 2048])
+def test_transform_free_column_solve_equals_dct_solve(n, dtype):
+    """square power-of-two images solve the columns of the preconditioner without a transform
+    (colsolve_tri_kernel: recursive filters + scans); GPA_COLSOLVE=tri / fft selects the column kernel (default: tri for f64, DCT for f32).  Same iterates up to rounding: iteration counts equal, phi within the PCG tolerance."""
+    rng = np.random.default_rng(n)
+    kvecs = hex_kvecs(0.1, 7.0)
+    img = hex_moire((n, n), kvecs, gaussian_bump_displacement((n, n)), noise=0.2, seed=n)
+    klists = np.stack(explicit_klists(kvecs, 0.04, 2, 2))
+    # a harder unwrap: rough weights, noisy phase, 40 iterations
+    w = rng.uniform(0.05, 1.0, size=(n, n))
+    psi = orc.wrap_to_pi(0.05 * np.add.outer(np.arange(n) ** 1.1, np.arange(n)) + rng.normal(scale=0.3, size=(n, n)))
+    plan = _lib.Plan((n, n), 12, dtype)
+    out = {}
+    for mode in ('tri', 'fft'):
+        os.environ['GPA_COLSOLVE'] = mode
+        try:
+            out[mode] = plan.extract_displacement_field(img, kvecs, klists, 10, 20, kmax=10)
+            out[mode + '_u'] = plan.unwrap(psi, w, kmax=40)
+        finally:
+            os.environ.pop('GPA_COLSOLVE', None)
+    plan.close()
+    tol = 1e-9 if dtype is np.float64 else 3e-5
+    assert out['tri'][3] == out['fft'][3]
+    assert rel(out['tri'][0], out['fft'][0]) < tol
+    assert rel(out['tri_u'][0], out['fft_u'][0]) < tol
+    if dtype is np.float64:
+        assert out['tri_u'][1] == out['fft_u'][1]
