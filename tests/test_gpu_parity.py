@@ -503,17 +503,7 @@ def test_tiled_device_resident_equals_host_staged():
         assert np.abs(u_dev - u_host).max() <= (5e-4 if dtype == np.float32 else 1e-9)
 
 
-@pytest.mark.gpu
-@pytest.mark.skipif(not os.environ.get('GPA_TEST_TORCH'), reason='imports torch (minutes on a cold box); set GPA_TEST_TORCH=1')
-def test_tiled_device_resident_torch_buffers():
-    """Same pipeline on torch device tensors (the N > 1 code path, collectives skipped at world 1)."""
-    from pygpa_amd import distributed as D
-    kvecs = hex_kvecs(0.1, 7.0)
-    img = hex_moire((192, 256), kvecs, gaussian_bump_displacement((192, 256)), noise=0.05, seed=3)
-    klists = explicit_klists(kvecs, 0.04, 3, 3)
-    u_dev = D.extract_displacement_field_tiled(img, kvecs, (2, 2), klists=klists, halo=24)
-    u_t = D.extract_displacement_field_tiled(img, kvecs, (2, 2), klists=klists, halo=24, _force_torch=True)
-    assert np.abs(u_dev - u_t).max() <= 1e-10   # (image mean taken on the device vs on the host)
+# (the torch-tensor pipeline of N > 1 ranks: tests/test_gpu_configs.py::test_tiled_two_ranks_one_gpu)
 
 
 # ---- f-4: Huber plane fit ------------------------------------------------------------------------
