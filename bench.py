@@ -47,6 +47,9 @@ def parse_args():
     ap.add_argument('--kgrid', default=None, help='NXxNY candidate grid per peak (e.g. 4x2 for BASELINE config 2)')
     ap.add_argument('--dtype', default='f32', choices=['f32', 'f64'])
     ap.add_argument('--kmax', type=int, default=10)
+    ap.add_argument('--inflight', type=int, default=1,
+                    help='N = 1: images in flight (one plan each; 1 = strictly one after the other). Small images leave most '
+                         'of the GPU idle between their ~45 dependent kernels; several in flight fill it')
     ap.add_argument('--no-cpu', action='store_true', help='skip the CPU baseline leg')
     ap.add_argument('--no-f64', action='store_true', help='skip the f64 leg')
     ap.add_argument('--window', type=int, default=2048, help='N > 1: side of the (power-of-two) tile windows')
@@ -133,38 +136,44 @@ def cpu_baseline(kvecs, sigma, knx, kny, kmax, size):
 # N = 1
 # -------------------------------------------------------------------------------------------------
 class SingleGPU:
-    def __init__(self, n, P, K, np_dt, kvecs, klists, sigma, kmax, seed=100):
+    def __init__(self, n, P, K, np_dt, kvecs, klists, sigma, kmax, seed=100, depth=1):
         from pygpa_amd import _lib
         from pygpa_amd.synthetic import gaussian_bump_displacement, hex_moire
         self._lib = _lib
         self.n, self.kvecs, self.klists, self.sigma, self.kmax = n, kvecs, klists, sigma, kmax
         img = hex_moire((n, n), kvecs, gaussian_bump_displacement((n, n)), noise=0.1, seed=seed, dtype=np_dt)
-        self.plan = _lib.Plan((n, n), P * K, np_dt, device=0)
+        self.depth = max(1, int(depth))
+        self.plans = [_lib.Plan((n, n), P * K, np_dt, device=0) for _ in range(self.depth)]
+        self.plan = self.plans[0]
         self.d_img = _lib.DeviceBuffer(img.nbytes)
         self.d_img.upload(img)
-        self.d_u = [_lib.DeviceBuffer(2 * img.nbytes) for _ in range(2)]
-        self.h_u = [_lib.pinned_empty((2, n, n), np_dt) for _ in range(2)]
-        # set-up, not a benchmark step: the first call per result buffer allocates lazily and runs eagerly, the
-        # second captures the call's ~110 launches into a hipGraph (libgpa_hip.so, extract_enqueue)
-        for j in (0, 1, 0, 1):
-            self.enqueue(j)
-        self.plan.sync()
+        # per plan: two result buffers on the device and two page-locked ones on the host
+        self.d_u = [[_lib.DeviceBuffer(2 * img.nbytes) for _ in range(2)] for _ in range(self.depth)]
+        self.h_u = [[_lib.pinned_empty((2, n, n), np_dt) for _ in range(2)] for _ in range(self.depth)]
+        for pl in range(self.depth):        # set-up, not benchmark steps: lazy allocations happen in the first calls
+            for j in (0, 1):
+                self.enqueue(pl, j)
+        self.sync()
 
-    def enqueue(self, j):
-        self.plan.extract_displacement_field_async(self.d_img.ptr, self.kvecs, self.klists, self.sigma, 2 * self.sigma,
-                                                   self.kmax, self.d_u[j].ptr)
+    def enqueue(self, pl, j):
+        self.plans[pl].extract_displacement_field_async(self.d_img.ptr, self.kvecs, self.klists, self.sigma, 2 * self.sigma,
+                                                        self.kmax, self.d_u[pl][j].ptr)
+
+    def sync(self):
+        for p in self.plans:
+            p.sync()
 
     def run(self, nsteps, download):
-        """nsteps steps back to back; with `download` the u of step i goes to pinned host memory on the copy
-        stream while step i + 1 computes into the other buffer"""
+        """nsteps steps; step i runs on plan i % depth.  With `download` the u of a step goes to pinned host memory on
+        its plan's copy stream while later steps compute (into the plan's other buffer / on the other plans)"""
         for i in range(nsteps):
-            j = i & 1
+            pl, j = i % self.depth, (i // self.depth) & 1
             if download:
-                self.plan.download_wait(j)      # the copy that last read d_u[j] (step i - 2) has landed
-            self.enqueue(j)
+                self.plans[pl].download_wait(j)      # the copy that last read d_u[pl][j] has landed
+            self.enqueue(pl, j)
             if download:
-                self.plan.download_async(self.h_u[j], self.d_u[j].ptr, j)
-        self.plan.sync()
+                self.plans[pl].download_async(self.h_u[pl][j], self.d_u[pl][j].ptr, j)
+        self.sync()
 
     def timed(self, steps, warmup, download):
         self.run(warmup, download)
@@ -178,7 +187,7 @@ class SingleGPU:
         kern = {}
         for _ in range(reps):
             self.plan.extract_displacement_field_dev(self.d_img.ptr, self.kvecs, self.klists, self.sigma, 2 * self.sigma,
-                                                     self.kmax, self.d_u[0].ptr)
+                                                     self.kmax, self.d_u[0][0].ptr)
             stage += np.array(self.plan.last_stage_ms())
             for name, (calls, ms) in self.plan.last_kernel_profile().items():
                 c, t = kern.get(name, (0, 0.0))
@@ -187,8 +196,9 @@ class SingleGPU:
         return stage / reps, {k: (c, t / reps) for k, (c, t) in kern.items()}
 
     def close(self):
-        self.plan.close()
-        for b in [self.d_img] + self.d_u:
+        for p in self.plans:
+            p.close()
+        for b in [self.d_img] + [x for pair in self.d_u for x in pair]:
             b.free()
 
 
@@ -215,7 +225,7 @@ def single_gpu(args):
     np_dt = np.float32 if args.dtype == 'f32' else np.float64
     s = 4 if args.dtype == 'f32' else 8
 
-    g = SingleGPU(n, P, K, np_dt, kvecs, klists, sigma, args.kmax)
+    g = SingleGPU(n, P, K, np_dt, kvecs, klists, sigma, args.kmax, depth=args.inflight)
     dt = g.timed(args.steps, args.warmup, download=True)
     iters = g.plan.last_iters()
     dt_res = g.timed(args.steps, 1, download=False)
@@ -236,7 +246,8 @@ def single_gpu(args):
                                'unwrap kmax=%d, image resident in HBM, u downloaded to pinned host memory inside the '
                                'step (BASELINE.json configs[2])' % (n, n, K, sigma, args.kmax),
                    'image': [n, n], 'peaks': P, 'kvectors_per_peak': K, 'x_planes': int(Bx),
-                   'unwrap_iters': list(iters), 'd2h_of_u': 'included, overlapped with the next step (copy stream)'},
+                   'unwrap_iters': list(iters), 'd2h_of_u': 'included, overlapped with the next step (copy stream)',
+                   'images_in_flight': g.depth},
         'resident_only': {'value': round(n * n * args.steps / dt_res / 1e6, 2), 'ms_per_step': round(dt_res / args.steps * 1e3, 4),
                           'note': 'same loop with u left in HBM (round-1 definition)'},
     }

@@ -7,6 +7,10 @@
 
 #include <algorithm>
 #include <complex>
+#include <condition_variable>
+#include <functional>
+#include <mutex>
+#include <thread>
 #include <string>
 #include <limits>
 #include <vector>
@@ -102,6 +106,53 @@ static void build_filter_table(const Axis& ax, double sigma, std::vector<double>
 // ---------------------------------------------------------------------------
 // plan
 // ---------------------------------------------------------------------------
+// One helper thread per plan: the fused driver enqueues the second displacement component's ~45 launches from it
+// while the calling thread enqueues the first component's.  A 4096^2 image does not care (the GPU is the limit), but
+// a call costs ~0.4 ms of host time for its ~110 launches, which IS the limit below ~1024^2 (tools/enqueue_cost.py).
+struct EnqueueWorker {
+  std::thread th;
+  std::mutex m;
+  std::condition_variable cv;
+  std::function<void()> job;
+  bool has_job = false, done = true, quit = false;
+  explicit EnqueueWorker(int device) {
+    th = std::thread([this, device] {
+      (void)hipSetDevice(device);
+      std::unique_lock<std::mutex> lk(m);
+      for (;;) {
+        cv.wait(lk, [this] { return has_job || quit; });
+        if (quit) return;
+        std::function<void()> j = std::move(job);
+        has_job = false;
+        lk.unlock();
+        j();
+        lk.lock();
+        done = true;
+        cv.notify_all();
+      }
+    });
+  }
+  void submit(std::function<void()> j) {
+    std::lock_guard<std::mutex> lk(m);
+    job = std::move(j);
+    has_job = true;
+    done = false;
+    cv.notify_all();
+  }
+  void wait() {
+    std::unique_lock<std::mutex> lk(m);
+    cv.wait(lk, [this] { return done; });
+  }
+  ~EnqueueWorker() {
+    {
+      std::lock_guard<std::mutex> lk(m);
+      quit = true;
+      cv.notify_all();
+    }
+    if (th.joinable()) th.join();
+  }
+};
+
 struct GraphKey {
   const void* image; void* u; void* lk; int32_t* kidx;
   int P, K, Bx, mask_border, kmax, epoch;
@@ -164,6 +215,8 @@ struct gpa_plan {
   bool profiling = false;
   hipEvent_t stage_ev[6] = {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};
   float stage_ms[5] = {0, 0, 0, 0, 0};
+  EnqueueWorker* worker = nullptr;   // second enqueueing thread of the fused driver
+  bool use_worker = true;
   std::vector<GraphEntry> graphs;    // captured fused-driver calls (extract_enqueue)
   bool use_graphs = true, serial_unwrap = false;
   int tbuf_epoch = 0;                // bumped when a buffer baked into the graphs is reallocated
@@ -418,6 +471,7 @@ gpa_plan* gpa_plan_create(int device, int n0, int n1, int max_batch, int dtype) 
   p->ax1 = make_axis(n1);
   p->use_graphs = getenv("GPA_USE_GRAPH") != nullptr;
   p->serial_unwrap = getenv("GPA_SERIAL_UNWRAP") != nullptr;
+  p->use_worker = getenv("GPA_NO_WORKER") == nullptr;
   const int maxlg = dtype == GPA_F32 ? 14 : 13;
   if (p->ax0.lg > maxlg || p->ax1.lg > maxlg) {
     fail(GPA_ERR_ARG, "gpa_plan_create: axis too long for an LDS-resident transform "
@@ -437,6 +491,8 @@ gpa_plan* gpa_plan_create(int device, int n0, int n1, int max_batch, int dtype) 
 void gpa_plan_destroy(gpa_plan* p) {
   if (!p) return;
   hipSetDevice(p->device);
+  delete p->worker;
+  p->worker = nullptr;
   if (p->stream) hipStreamSynchronize(p->stream);
   for (auto& g : p->graphs) {
     if (g.exec) hipGraphExecDestroy(g.exec);
@@ -785,15 +841,29 @@ static int extract_launch(gpa_plan* p, const void* image, int P, int K, int Bx, 
   if (p->profiling) HIP_TRY(hipEventRecord(p->stage_ev[4], p->stream));
   HIP_TRY(hipEventRecord(p->ev_fork, p->stream));
   HIP_TRY(hipStreamWaitEvent(p->stream2, p->ev_fork, 0));
+  // the second component's launches go out from the plan's helper thread while this thread enqueues the first
+  // (not while profiling -- the per-kernel event pairs belong to this thread -- or capturing a graph)
+  hipStreamCaptureStatus cap = hipStreamCaptureStatusNone;
+  (void)hipStreamIsCapturing(p->stream, &cap);
+  const bool threaded = p->use_worker && !p->profiling && !p->serial_unwrap && cap == hipStreamCaptureStatusNone;
+  hipError_t e2 = hipSuccess;
+  void* u1 = (char*)u + npx * p->rsz;
+  auto second = [&]() {
+    e2 = unwrap_enqueue_prepared(&p->uw2, p->d_wnorm, nparts, kmax, 1e-9, true, u1, p->stream2);
+    if (e2 == hipSuccess) e2 = unwrap_fetch_iters(&p->uw2, &p->h_iters[1], p->stream2);
+  };
+  if (threaded) {
+    if (!p->worker) p->worker = new EnqueueWorker(p->device);
+    p->worker->submit(second);
+  }
   hipError_t e = unwrap_enqueue_prepared(&p->uw, p->d_wnorm, nparts, kmax, 1e-9, true, u, p->stream);
   if (p->profiling || p->serial_unwrap) {   // per-kernel timings: run the second component after the first
     HIP_TRY(hipEventRecord(p->ev_fork, p->stream));
     HIP_TRY(hipStreamWaitEvent(p->stream2, p->ev_fork, 0));
   }
-  if (e == hipSuccess)
-    e = unwrap_enqueue_prepared(&p->uw2, p->d_wnorm, nparts, kmax, 1e-9, true, (char*)u + npx * p->rsz, p->stream2);
   if (e == hipSuccess) e = unwrap_fetch_iters(&p->uw, &p->h_iters[0], p->stream);
-  if (e == hipSuccess) e = unwrap_fetch_iters(&p->uw2, &p->h_iters[1], p->stream2);
+  if (threaded) p->worker->wait(); else second();
+  if (e == hipSuccess) e = e2;
   if (e != hipSuccess) return fail(GPA_ERR_HIP, std::string("unwrap: ") + hipGetErrorString(e));
   HIP_TRY(hipEventRecord(p->ev_join, p->stream2));
   HIP_TRY(hipStreamWaitEvent(p->stream, p->ev_join, 0));

@@ -37,6 +37,19 @@ struct ProfScope {
   }
   ~ProfScope() { if (r) (void)hipEventRecord(r->b, s); }
 };
+// hipFuncSetAttribute(MaxDynamicSharedMemorySize) once per kernel instantiation and device instead of once per
+// launch: the fused driver makes ~110 launches per image and a small image is bound by the host's launch rate.
+// `done` is a static of the calling template instantiation (one bit per device; a benign race repeats the call).
+inline hipError_t set_dynamic_lds_once(const void* kern, int bytes, unsigned& done) {
+  int dev = 0;
+  (void)hipGetDevice(&dev);
+  const unsigned bit = 1u << (dev & 31);
+  if (done & bit) return hipSuccess;
+  hipError_t e = hipFuncSetAttribute(kern, hipFuncAttributeMaxDynamicSharedMemorySize, bytes);
+  if (e == hipSuccess) done |= bit;
+  return e;
+}
+
 #define GPA_PROF_CAT2(a, b) a##b
 #define GPA_PROF_CAT(a, b) GPA_PROF_CAT2(a, b)
 #define GPA_PROF(name, stream) ::gpa::ProfScope GPA_PROF_CAT(_gpa_prof_, __LINE__)(name, stream)

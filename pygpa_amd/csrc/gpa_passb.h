@@ -147,8 +147,8 @@ static hipError_t run_passB(const Axis& a1, int n0, const void* Tbuf, const void
     return hipErrorInvalidValue;
   } else {
     auto kern = passB_kernel<T, LG, PADDED, MODE>;
-    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern),
-                                       hipFuncAttributeMaxDynamicSharedMemorySize, (int)G::LDS_BYTES);
+    static unsigned lds_set = 0;
+    hipError_t e = set_dynamic_lds_once(reinterpret_cast<const void*>(kern), (int)G::LDS_BYTES, lds_set);
     if (e != hipSuccess) return e;
     dim3 grid((n0 + G::NF - 1) / G::NF, P);
     GPA_PROF("passB_kernel", s);

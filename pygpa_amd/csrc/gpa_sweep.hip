@@ -260,8 +260,8 @@ static hipError_t run_passA(const Axis& a0, int n1, const void* image, const voi
     return hipErrorInvalidValue;
   } else {
     auto kern = passA_kernel<T, LG, PADDED>;
-    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern),
-                                       hipFuncAttributeMaxDynamicSharedMemorySize, (int)G::LDS_BYTES);
+    static unsigned lds_set = 0;
+    hipError_t e = set_dynamic_lds_once(reinterpret_cast<const void*>(kern), (int)G::LDS_BYTES, lds_set);
     if (e != hipSuccess) return e;
     const int tiles = (n1 + G::C - 1) / G::C;
     // split the lock-in loop over grid.y when there are too few column tiles to fill 256 CUs

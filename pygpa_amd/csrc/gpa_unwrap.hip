@@ -54,6 +54,7 @@ struct Impl {
   void *wk0s;                // w_k along axis 0, spectral layout
   void *ha0[2], *ham0[2];    // 1 - cos term of axis-0 bins (spectral layout); [compat]
   void *hb1[2];              // 1 - cos term of axis-1 bins (natural); [compat]
+  int col_mode;              // GPA_COLSOLVE of the current solve: 0 default, 1 tri, 2 fft (read once per solve)
   void* tritab;              // TriCol per column (square power-of-two images): transform-free column solve
   double* scal;              // 8 doubles
   int* flags;                // [0] = iteration count, [1] = done
@@ -1403,8 +1404,8 @@ hipError_t run_rowdct(const Impl* w, hipStream_t s) {
   if constexpr (!G::FITS) return hipErrorInvalidValue;
   else {
     auto kern = rowdct_kernel<T, LG>;
-    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize,
-                                       (int)G::LDS_BYTES);
+    static unsigned lds_set = 0;
+    hipError_t e = set_dynamic_lds_once(reinterpret_cast<const void*>(kern), (int)G::LDS_BYTES, lds_set);
     if (e != hipSuccess) return e;
     const int npairs = w->n0 / 2, grid = (npairs + G::NF - 1) / G::NF;
     kern<<<grid, G::THREADS, G::LDS_BYTES, s>>>((const T*)w->r, w->n0, (T*)w->z, (const cpx<T>*)w->tw1,
@@ -1418,8 +1419,8 @@ hipError_t run_rowidct(const Impl* w, int* nparts, hipStream_t s) {
   if constexpr (!G::FITS) return hipErrorInvalidValue;
   else {
     auto kern = rowidct_kernel<T, LG, RHO>;
-    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize,
-                                       (int)G::LDS_BYTES);
+    static unsigned lds_set = 0;
+    hipError_t e = set_dynamic_lds_once(reinterpret_cast<const void*>(kern), (int)G::LDS_BYTES, lds_set);
     if (e != hipSuccess) return e;
     const int npairs = w->n0 / 2, grid = (npairs + G::NF - 1) / G::NF;
     *nparts = grid;
@@ -1436,8 +1437,8 @@ hipError_t run_colsolve(const Impl* w, int compat, hipStream_t s, const double* 
   if constexpr (!G::FITS) return hipErrorInvalidValue;
   else {
     auto kern = part_rho ? colsolve_kernel<T, LG, true> : colsolve_kernel<T, LG, false>;
-    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize,
-                                       (int)G::LDS_BYTES);
+    static unsigned lds_set[2] = {0, 0};   // one flag word per instantiation
+    hipError_t e = set_dynamic_lds_once(reinterpret_cast<const void*>(kern), (int)G::LDS_BYTES, lds_set[part_rho ? 1 : 0]);
     if (e != hipSuccess) return e;
     const int npairs = w->n1 / 2, grid = (npairs + G::CC - 1) / G::CC;
     if (nrho) *nrho = grid;
@@ -1456,8 +1457,8 @@ hipError_t run_rowdct_fused(const Impl* w, const void* q, int ring, const double
   if constexpr (!G::FITS) return hipErrorInvalidValue;
   else {
     auto kern = rowdct_fused_kernel<T, LG>;
-    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize,
-                                       (int)G::LDS_BYTES);
+    static unsigned lds_set = 0;
+    hipError_t e = set_dynamic_lds_once(reinterpret_cast<const void*>(kern), (int)G::LDS_BYTES, lds_set);
     if (e != hipSuccess) return e;
     const int npairs = w->n0 / 2, grid = (npairs + G::NF - 1) / G::NF;
     *nnorm = grid;
@@ -1482,8 +1483,8 @@ hipError_t run_rowidct_p(const Impl* w, const void* pin, void* pout, const doubl
   if constexpr (!G::FITS) return hipErrorInvalidValue;
   else {
     auto kern = rowidct_p_kernel<T, LG>;
-    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize,
-                                       (int)G::LDS_BYTES);
+    static unsigned lds_set = 0;
+    hipError_t e = set_dynamic_lds_once(reinterpret_cast<const void*>(kern), (int)G::LDS_BYTES, lds_set);
     if (e != hipSuccess) return e;
     const int npairs = w->n0 / 2, grid = (npairs + G::NF - 1) / G::NF;
     GPA_PROF("rowidct_p_kernel", s);
@@ -1513,7 +1514,8 @@ hipError_t run_colsolve_tri(const Impl* w, int compat, hipStream_t s, const doub
   auto kern = colsolve_tri_kernel<T, VEC, Q, R>;
   const int S = w->n0 / R, threads = S * Q, grid = w->n1 / (Q * VEC);
   const size_t lds = (size_t)16 * Q * VEC * sizeof(double);
-  hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+  static unsigned lds_set = 0;
+    hipError_t e = set_dynamic_lds_once(reinterpret_cast<const void*>(kern), (int)lds, lds_set);
   if (e != hipSuccess) return e;
   if (nrho) *nrho = grid;
   GPA_PROF("colsolve_kernel", s);
@@ -1545,8 +1547,7 @@ hipError_t dispatch_colsolve(const Impl* w, int compat, hipStream_t s, const dou
   // (profiles/r02_colsolve_tri.txt): f64 1.54 ms per step against 2.0 for the DCT kernel (whose f64 transforms
   // spill), f32 82 us per launch against 68 -- the f32 DCT kernel is the faster one.  So: f64 by default,
   // GPA_COLSOLVE=tri / fft forces one or the other (tests compare the two).
-  const char* mode = getenv("GPA_COLSOLVE");
-  const bool want_tri = mode ? mode[0] == 't' : w->dtype != 0;
+  const bool want_tri = w->col_mode ? w->col_mode == 1 : w->dtype != 0;
   if (w->tritab && part_rho && want_tri && w->n0 / (w->dtype == 0 ? TriRows<float>::value : TriRows<double>::value) <= 1024)
     return w->dtype == 0 ? dispatch_colsolve_tri<float>(w, compat, s, part_norm, nnorm, it, eps, part_rho, nrho, zin)
                          : dispatch_colsolve_tri<double>(w, compat, s, part_norm, nnorm, it, eps, part_rho, nrho, zin);
@@ -1571,8 +1572,8 @@ hipError_t run_g_rowdct(const Impl* w, hipStream_t s) {
   if constexpr (!G::FITS) return hipErrorInvalidValue;
   else {
     auto kern = g_rowdct_kernel<T, LG>;
-    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize,
-                                       (int)G::LDS_BYTES);
+    static unsigned lds_set = 0;
+    hipError_t e = set_dynamic_lds_once(reinterpret_cast<const void*>(kern), (int)G::LDS_BYTES, lds_set);
     if (e != hipSuccess) return e;
     const int npairs = (w->n0 + 1) / 2, grid = (npairs + G::NF - 1) / G::NF;
     kern<<<grid, G::THREADS, G::LDS_BYTES, s>>>((const T*)w->r, w->n0, w->n1, (T*)w->z, (const cpx<T>*)w->btw1,
@@ -1587,8 +1588,8 @@ hipError_t run_g_rowidct(const Impl* w, int* nparts, hipStream_t s) {
   if constexpr (!G::FITS) return hipErrorInvalidValue;
   else {
     auto kern = g_rowidct_kernel<T, LG>;
-    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize,
-                                       (int)G::LDS_BYTES);
+    static unsigned lds_set = 0;
+    hipError_t e = set_dynamic_lds_once(reinterpret_cast<const void*>(kern), (int)G::LDS_BYTES, lds_set);
     if (e != hipSuccess) return e;
     const int npairs = (w->n0 + 1) / 2, grid = (npairs + G::NF - 1) / G::NF;
     *nparts = grid;
@@ -1604,8 +1605,8 @@ hipError_t run_g_colsolve(const Impl* w, int compat, hipStream_t s) {
   if constexpr (!G::FITS) return hipErrorInvalidValue;
   else {
     auto kern = g_colsolve_kernel<T, LG>;
-    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize,
-                                       (int)G::LDS_BYTES);
+    static unsigned lds_set = 0;
+    hipError_t e = set_dynamic_lds_once(reinterpret_cast<const void*>(kern), (int)G::LDS_BYTES, lds_set);
     if (e != hipSuccess) return e;
     const int npairs = (w->n1 + 1) / 2, grid = (npairs + G::NF - 1) / G::NF;
     kern<<<grid, G::THREADS, G::LDS_BYTES, s>>>((T*)w->z, w->n0, w->n1, (const cpx<T>*)w->btw0,
@@ -1858,6 +1859,10 @@ static hipError_t run_pcg(Impl* w, const void* a, const void* b, const void* wei
   // table has a zero away from the DC bin (I = 2M) and the reference itself returns NaN: there is nothing
   // to reproduce, and the true Laplacian eigenvalues are used instead.
   if (compat && (n0 >= 2 * n1 || n1 >= 2 * n0)) compat = 0;
+  {
+    const char* mode = getenv("GPA_COLSOLVE");   // once per solve, not per launch (environment lookups cost host time)
+    w->col_mode = !mode ? 0 : (mode[0] == 't' ? 1 : 2);
+  }
   const int g2 = n0, np2 = n0;   // stencil kernels: one workgroup per image row
   if (np2 > MAXPART) return hipErrorInvalidValue;
   // band height of the stencil kernel: 16 rows for large images, fewer when that would leave
@@ -2064,8 +2069,8 @@ hipError_t run_rowdft(const BlueAxis& a, int n0, void* Z, hipStream_t s) {
   if constexpr (!G::FITS) return hipErrorInvalidValue;
   else {
     auto kern = g_rowdft_kernel<T, LG>;
-    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize,
-                                       (int)G::LDS_BYTES);
+    static unsigned lds_set = 0;
+    hipError_t e = set_dynamic_lds_once(reinterpret_cast<const void*>(kern), (int)G::LDS_BYTES, lds_set);
     if (e != hipSuccess) return e;
     kern<<<(n0 + G::NF - 1) / G::NF, G::THREADS, G::LDS_BYTES, s>>>((cpx<T>*)Z, n0, a.n, (const cpx<T>*)a.tw,
                                                                      (const cpx<T>*)a.chirp, (const cpx<T>*)a.bspec);
@@ -2078,8 +2083,8 @@ hipError_t run_coldft(const BlueAxis& a, int n1, void* Z, hipStream_t s) {
   if constexpr (!G::FITS) return hipErrorInvalidValue;
   else {
     auto kern = g_coldft_kernel<T, LG>;
-    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize,
-                                       (int)G::LDS_BYTES);
+    static unsigned lds_set = 0;
+    hipError_t e = set_dynamic_lds_once(reinterpret_cast<const void*>(kern), (int)G::LDS_BYTES, lds_set);
     if (e != hipSuccess) return e;
     kern<<<(n1 + G::NF - 1) / G::NF, G::THREADS, G::LDS_BYTES, s>>>((cpx<T>*)Z, a.n, n1, (const cpx<T>*)a.tw,
                                                                      (const cpx<T>*)a.chirp, (const cpx<T>*)a.bspec);
