@@ -788,22 +788,27 @@ template <int NV, int VEC, int Q, bool REVERSE>
 __device__ __forceinline__ void chunk_scan(const double (&v)[NV], const double (&m)[NV], double (&excl)[NV],
                                            double (&total)[NV], double* lds, int col) {
   constexpr int CPW = 64 / Q;                       // chunks per wavefront
-  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, nw = (blockDim.x + 63) >> 6;
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, nw = (blockDim.x + 63) >> 6, q = lane % Q;
   const int active = blockDim.x < 64 ? blockDim.x / Q : CPW;   // chunks in this wavefront (tiny images: fewer)
   const int sl = REVERSE ? active - 1 - lane / Q : lane / Q;   // position of this chunk in scan order inside the wavefront
   const int wo = REVERSE ? nw - 1 - wave : wave;               // position of the wavefront in scan order
-  double cur[NV], mp[NV];
+  // ---- level 1: inside the wavefront, by lane shuffles; pw collects m^(sl + 1) from the squared multipliers
+  double cur[NV], mp[NV], pw[NV];
 #pragma unroll
-  for (int a = 0; a < NV; ++a) { cur[a] = v[a]; mp[a] = m[a]; }
+  for (int a = 0; a < NV; ++a) { cur[a] = v[a]; mp[a] = m[a]; pw[a] = 1.0; }
 #pragma unroll
   for (int off = 1; off < CPW; off <<= 1) {
 #pragma unroll
     for (int a = 0; a < NV; ++a) {
       const double t = REVERSE ? __shfl_down(cur[a], off * Q) : __shfl_up(cur[a], off * Q);
       if (sl >= off) cur[a] += mp[a] * t;
+      if ((sl + 1) & off) pw[a] *= mp[a];
       mp[a] *= mp[a];
     }
   }
+#pragma unroll
+  for (int a = 0; a < NV; ++a)
+    if (sl + 1 == CPW) pw[a] = mp[a];
   // mp = m^CPW: one wavefront's worth of chunks.  (active < CPW only when there is a single wavefront.)
   __syncthreads();   // lds may still be read from an earlier scan
   if (sl == active - 1) {
@@ -811,19 +816,27 @@ __device__ __forceinline__ void chunk_scan(const double (&v)[NV], const double (
     for (int a = 0; a < NV; ++a) lds[(size_t)wo * (Q * VEC) + col + a] = cur[a];
   }
   __syncthreads();
+  // ---- level 2: the (at most 16) wavefront totals, scanned by every wavefront for itself: the lane group that
+  // holds chunk g (mod 16) of the wavefront takes total g, four shuffle steps chain them, two shuffles fetch the
+  // value in front of this wavefront and the grand total
+  const int g = (lane / Q) & 15;
 #pragma unroll
   for (int a = 0; a < NV; ++a) {
-    double acc = 0.0;   // x at the end of the previous wavefront
-    for (int w = 0; w < wo; ++w) acc = acc * mp[a] + lds[(size_t)w * (Q * VEC) + col + a];
-    double tot = acc;
-    for (int w = wo; w < nw; ++w) tot = tot * mp[a] + lds[(size_t)w * (Q * VEC) + col + a];
-    total[a] = tot;
-    // m^(sl + 1) by squaring
-    double pw = 1.0, base = m[a];
-    for (int bit = sl + 1; bit; bit >>= 1) { if (bit & 1) pw *= base; base *= base; }
-    const double incl = cur[a] + pw * acc;
+    double t16 = g < nw ? lds[(size_t)g * (Q * VEC) + col + a] : 0.0;
+    double mq = mp[a];
+#pragma unroll
+    for (int off = 1; off < 16; off <<= 1) {
+      const double up = __shfl_up(t16, off * Q);
+      if (g >= off) t16 += mq * up;
+      mq *= mq;
+    }
+    const int gq = q;                                       // lane of group 0 that works on this thread's columns
+    const double acc = __shfl(t16, (wo > 0 ? wo - 1 : 0) * Q + gq);
+    total[a] = __shfl(t16, (nw - 1) * Q + gq);
+    const double before = wo > 0 ? acc : 0.0;               // x at the end of the previous wavefront
+    const double incl = cur[a] + pw[a] * before;
     const double prev = REVERSE ? __shfl_down(incl, Q) : __shfl_up(incl, Q);
-    excl[a] = sl > 0 ? prev : acc;
+    excl[a] = sl > 0 ? prev : before;
   }
 }
 
@@ -871,7 +884,7 @@ __global__ __launch_bounds__(1024) void colsolve_tri_kernel(const T* __restrict_
   // ---- pass 1: chunk aggregates of the zero-initialised causal sum (b) and of A's weighted sum (aw)
   double carry[VEC];         // becomes: the true p just above this chunk
   double shift0 = 0.0;       // mean of column 0
-  // (two columns at a time: b, A's share, their scans' inputs and outputs for four columns at once do not fit)
+  // (two columns at a time: four columns' scan inputs, outputs and multiplier powers at once do not fit)
 #pragma unroll
   for (int h = 0; h < VEC; h += 2) {
     double b[2], aw[2], lamR[2];
@@ -925,11 +938,14 @@ __global__ __launch_bounds__(1024) void colsolve_tri_kernel(const T* __restrict_
     for (int k = R - 1; k >= 0; --k) ee = lam * (ee - (double)x[k].v[a]);
     e[a] = ee;
   }
-  {
-    double lamR[VEC], Ztot[VEC];
 #pragma unroll
-    for (int a = 0; a < VEC; ++a) lamR[a] = tab[y0 + a].lamR;
-    chunk_scan<VEC, VEC, Q, true>(e, lamR, carry, Ztot, lds, col);   // carry: z just below this chunk
+  for (int h = 0; h < VEC; h += 2) {
+    double lamR[2], Ztot[2], e2[2] = {e[h], e[h + 1]}, cz[2];
+    lamR[0] = tab[y0 + h].lamR;
+    lamR[1] = tab[y0 + h + 1].lamR;
+    chunk_scan<2, VEC, Q, true>(e2, lamR, cz, Ztot, lds, col + h);   // z just below this chunk
+    carry[h] = cz[0];
+    carry[h + 1] = cz[1];
   }
   // ---- pass 3: anticausal recursion in place, rho from the quadratic form
   double rho = 0.0, zsum0 = 0.0;

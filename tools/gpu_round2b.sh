@@ -1,6 +1,6 @@
 #!/bin/bash
 # round 2, pass b: whole GPU suite, bench, kernel stats, PMC passes -> counters
-out=gpurun_out/r2b; mkdir -p $out
+out=gpurun_out/r2i; mkdir -p $out
 python -m pytest tests -q -m gpu -x --durations=12 > $out/pytest_gpu.log 2>&1
 tail -25 $out/pytest_gpu.log
 python bench.py > $out/bench.json 2> $out/bench.err; tail -3 $out/bench.err; cat $out/bench.json
