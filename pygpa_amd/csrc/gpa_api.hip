@@ -216,7 +216,7 @@ struct gpa_plan {
   hipEvent_t stage_ev[6] = {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};
   float stage_ms[5] = {0, 0, 0, 0, 0};
   EnqueueWorker* worker = nullptr;   // second enqueueing thread of the fused driver
-  bool use_worker = true;
+  bool use_worker = true, no_ksplit = false;
   std::vector<GraphEntry> graphs;    // captured fused-driver calls (extract_enqueue)
   bool use_graphs = true, serial_unwrap = false;
   int tbuf_epoch = 0;                // bumped when a buffer baked into the graphs is reallocated
@@ -472,6 +472,7 @@ gpa_plan* gpa_plan_create(int device, int n0, int n1, int max_batch, int dtype) 
   p->use_graphs = getenv("GPA_USE_GRAPH") != nullptr;
   p->serial_unwrap = getenv("GPA_SERIAL_UNWRAP") != nullptr;
   p->use_worker = getenv("GPA_NO_WORKER") == nullptr;
+  p->no_ksplit = getenv("GPA_NO_KSPLIT") != nullptr;
   const int maxlg = dtype == GPA_F32 ? 14 : 13;
   if (p->ax0.lg > maxlg || p->ax1.lg > maxlg) {
     fail(GPA_ERR_ARG, "gpa_plan_create: axis too long for an LDS-resident transform "
@@ -573,6 +574,29 @@ int gpa_lockin_batch(gpa_plan* p, const void* image, const double* kvecs, int B,
   return GPA_OK;
 }
 
+// pass B with selection.  A small image has few rows to spread over the 256 CUs and runs its K candidates one after
+// the other in each workgroup (512^2, K = 16: 82 us, a quarter of the image's time): there the candidates are split over
+// up to 4 workgroups per row and merged (launch_passB_split) -- same winners, same values.
+static int passB_select(gpa_plan* p, int P, int K, void* lockin, int32_t* kidx) {
+  const int rows_wg = (p->n0 + 7) / 8 * P;           // workgroups of the unsplit launch (at least: NF <= 8 rows each)
+  int ksplit = 1;
+  // (only while the unsplit launch has fewer workgroups than the chip has CUs: at 1024^2, 384 workgroups, the split
+  //  measured slower -- 153 -> 188 us -- because the merge pass and the partial slabs cost more than they save)
+  if (p->ax1.lg <= 10 && K >= 4 && !p->no_ksplit && rows_wg <= 256)
+    while (ksplit < 4 && ksplit * 2 <= K && rows_wg * ksplit < 1024) ksplit *= 2;
+  if (ksplit == 1) {
+    HIP_TRY(launch_passB(p->dtype, p->ax1, p->n0, p->Tbuf, p->Hy, p->tw1, p->tb, P, K, true, lockin, kidx, p->stream));
+    return GPA_OK;
+  }
+  const size_t npx = (size_t)p->n0 * p->n1, cnt = (size_t)ksplit * P * npx;
+  TRY(ensure_sf(p, cnt * (p->csz + sizeof(int32_t))));
+  void* part = p->d_sf;
+  int32_t* pidx = reinterpret_cast<int32_t*>((char*)p->d_sf + cnt * p->csz);
+  HIP_TRY(launch_passB_split(p->dtype, p->ax1, p->n0, p->Tbuf, p->Hy, p->tw1, p->tb, P, K, ksplit, part, pidx, lockin, kidx,
+                             p->stream));
+  return GPA_OK;
+}
+
 // ---- a3 ----------------------------------------------------------------------
 static int sweep_peaks_dev(gpa_plan* p, const void* image, const void* mean, const double* krefs, int P,
                            const double* klists, int K, double sigma, void* lockin, int32_t* kidx) {
@@ -591,8 +615,7 @@ static int sweep_peaks_dev(gpa_plan* p, const void* image, const void* mean, con
   if (p->profiling) HIP_TRY(hipEventRecord(p->stage_ev[1], p->stream));
   HIP_TRY(launch_passA(p->dtype, p->ax0, p->n1, image, mean, p->tb, p->Hx, p->tw0, p->Tbuf, Bx, p->stream));
   if (p->profiling) HIP_TRY(hipEventRecord(p->stage_ev[2], p->stream));
-  HIP_TRY(launch_passB(p->dtype, p->ax1, p->n0, p->Tbuf, p->Hy, p->tw1, p->tb, P, K, true, lockin, kidx,
-                       p->stream));
+  TRY(passB_select(p, P, K, lockin, kidx));
   if (p->profiling) HIP_TRY(hipEventRecord(p->stage_ev[3], p->stream));
   return GPA_OK;
 }
@@ -830,7 +853,7 @@ static int extract_launch(gpa_plan* p, const void* image, int P, int K, int Bx, 
   if (p->profiling) HIP_TRY(hipEventRecord(p->stage_ev[1], p->stream));
   HIP_TRY(launch_passA(p->dtype, p->ax0, p->n1, image, p->d_mean, p->tb, p->Hx, p->tw0, p->Tbuf, Bx, p->stream));
   if (p->profiling) HIP_TRY(hipEventRecord(p->stage_ev[2], p->stream));
-  HIP_TRY(launch_passB(p->dtype, p->ax1, p->n0, p->Tbuf, p->Hy, p->tw1, p->tb, P, K, true, lk, kidx, p->stream));
+  TRY(passB_select(p, P, K, lk, kidx));
   if (p->profiling) HIP_TRY(hipEventRecord(p->stage_ev[3], p->stream));
   // phases / weights / per-pixel least squares fused with the unwrap's set-up: the gradient fields never
   // go to HBM, the kernel leaves r0 of both components in the two unwrap workspaces

@@ -124,6 +124,11 @@ hipError_t launch_passB(int dtype, const Axis& a1, int n0, const void* Tbuf, con
 hipError_t launch_passB_ext(int dtype, const Axis& a1, int n0, const void* Tbuf, const void* Hy, const void* tw1,
                             const SweepTables& tb, int K, int mode, void* out, int32_t* kidx, const uint8_t* gate,
                             void* psi, hipStream_t s);
+// small images (transform length <= 1024): best-of-K with the K candidates of a row split over ksplit workgroups and a
+// merge pass; part / pidx: ksplit * P * n0 * n1 complex / int32 of scratch.  Same winners and values as launch_passB.
+hipError_t launch_passB_split(int dtype, const Axis& a1, int n0, const void* Tbuf, const void* Hy, const void* tw1,
+                              const SweepTables& tb, int P, int K, int ksplit, void* part, int32_t* pidx, void* out,
+                              int32_t* kidx, hipStream_t s);
 // a4: phase gradient of the winner from the per-candidate phases (mode 0 np.gradient, 1 forward differences with
 // NaN at the end, 2 the same with swapped components)
 hipError_t launch_phasegrad(int dtype, const void* psi, int K, const int32_t* kidx, int n0, int n1, const double* kl,

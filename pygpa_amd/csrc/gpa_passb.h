@@ -6,7 +6,7 @@
 
 namespace gpa {
 
-enum { PB_ALL = 0, PB_SELECT = 1, PB_GATED = 2, PB_PHASES = 3 };
+enum { PB_ALL = 0, PB_SELECT = 1, PB_GATED = 2, PB_PHASES = 3, PB_PART = 4 };
 
 template <class T, int LG>
 struct PassBGeom {
@@ -57,8 +57,17 @@ __global__ __launch_bounds__((PassBGeom<T, LG>::THREADS), (sizeof(T) == 8 ? GPA_
 #pragma unroll
   for (int i = 0; i < 16; ++i) { best[i] = {T(0), T(0)}; bidx[i] = -1; }
 
-  const int nk = SELECT ? K : 1;
-  for (int k = 0; k < nk; ++k) {
+  // PB_PART (small images): workgroup z of gridDim.z takes the candidates [z Kc, (z + 1) Kc) and leaves its RAW winner
+  // (uncompensated value + index) in slab z of out / kidx; merge_parts_kernel picks among the slabs in candidate
+  // order with the same strict '>' and applies the compensation -- the K candidates of a row then run on gridDim.z
+  // workgroups instead of one after the other in a single one
+  int k0 = 0, nk = SELECT ? K : 1;
+  if constexpr (MODE == PB_PART) {
+    const int kc = (K + (int)gridDim.z - 1) / (int)gridDim.z;
+    k0 = (int)blockIdx.z * kc;
+    nk = k0 + kc < K ? k0 + kc : K;
+  }
+  for (int k = k0; k < nk; ++k) {
     const int b = SELECT ? p * K + k : p;
     F::refresh(tw);
     // the x-plane of this candidate (shared by every candidate with the same wx: re-reads hit L2)
@@ -122,7 +131,11 @@ __global__ __launch_bounds__((PassBGeom<T, LG>::THREADS), (sizeof(T) == 8 ? GPA_
     const int yy = tid + TPF * i;
     if (!PADDED || yy < n1) {
       const size_t o = ((size_t)p * n0 + row) * n1 + yy;
-      if constexpr (SELECT) {
+      if constexpr (MODE == PB_PART) {
+        const size_t slab = (size_t)gridDim.y * n0 * n1;     // P * n0 * n1 values per slab
+        out[(size_t)blockIdx.z * slab + o] = best[i];
+        kidx[(size_t)blockIdx.z * slab + o] = bidx[i];
+      } else if constexpr (SELECT) {
         cpx<T> v = {T(0), T(0)};
         if (bidx[i] >= 0) {
           const size_t bb = (size_t)p * K + bidx[i];
@@ -141,7 +154,7 @@ __global__ __launch_bounds__((PassBGeom<T, LG>::THREADS), (sizeof(T) == 8 ? GPA_
 template <class T, int LG, bool PADDED, int MODE>
 static hipError_t run_passB(const Axis& a1, int n0, const void* Tbuf, const void* Hy,
                             const void* tw1, const SweepTables& tb, int P, int K, void* out,
-                            int32_t* kidx, const uint8_t* gate, void* psi, hipStream_t s) {
+                            int32_t* kidx, const uint8_t* gate, void* psi, hipStream_t s, int ksplit = 1) {
   using G = PassBGeom<T, LG>;
   if constexpr (G::LDS_BYTES > 160 * 1024) {
     return hipErrorInvalidValue;
@@ -150,7 +163,7 @@ static hipError_t run_passB(const Axis& a1, int n0, const void* Tbuf, const void
     static unsigned lds_set = 0;
     hipError_t e = set_dynamic_lds_once(reinterpret_cast<const void*>(kern), (int)G::LDS_BYTES, lds_set);
     if (e != hipSuccess) return e;
-    dim3 grid((n0 + G::NF - 1) / G::NF, P);
+    dim3 grid((n0 + G::NF - 1) / G::NF, P, ksplit);
     GPA_PROF("passB_kernel", s);
     kern<<<grid, G::THREADS, G::LDS_BYTES, s>>>(
         (const cpx<T>*)Tbuf, n0, a1.n, (const typename HType<PADDED, T>::type*)Hy,

@@ -62,6 +62,58 @@ hipError_t launch_phasegrad(int dtype, const void* psi, int K, const int32_t* ki
   return hipGetLastError();
 }
 
+// ---- small images: the K candidates of a peak split over ksplit workgroups per row (PB_PART) + merge ------------
+template <class T>
+__global__ __launch_bounds__(256) void merge_parts_kernel(const cpx<T>* __restrict__ part, const int32_t* __restrict__ pidx,
+                                                         int S, int P, int K, int n0, int n1, const cpx<T>* __restrict__ dx,
+                                                         const cpx<T>* __restrict__ dy, cpx<T>* __restrict__ out,
+                                                         int32_t* __restrict__ kidx) {
+  const int y = blockIdx.x * 256 + threadIdx.x, x = blockIdx.y, p = blockIdx.z;
+  if (y >= n1) return;
+  const size_t o = ((size_t)p * n0 + x) * n1 + y, slab = (size_t)P * n0 * n1;
+  cpx<T> best = {T(0), T(0)};
+  int bi = -1;
+  for (int z = 0; z < S; ++z) {
+    // slabs hold increasing candidate ranges: the sequential rule "strictly larger replaces" carries over
+    const cpx<T> v = part[(size_t)z * slab + o];
+    const T a = v.x * v.x + v.y * v.y, ab = best.x * best.x + best.y * best.y;
+    const int vi = pidx[(size_t)z * slab + o];
+    if (vi >= 0 && a > ab) { best = v; bi = vi; }
+  }
+  cpx<T> r = {T(0), T(0)};
+  if (bi >= 0) {
+    const size_t bb = (size_t)p * K + bi;
+    r = cmul(best, cmul(dx[bb * n0 + x], dy[bb * n1 + y]));
+  }
+  out[o] = r;
+  if (kidx) kidx[o] = bi;
+}
+
+// part: ksplit * P * n0 * n1 complex, pidx: the same count of int32 (scratch of the caller)
+hipError_t launch_passB_split(int dtype, const Axis& a1, int n0, const void* Tbuf, const void* Hy, const void* tw1,
+                              const SweepTables& tb, int P, int K, int ksplit, void* part, int32_t* pidx, void* out,
+                              int32_t* kidx, hipStream_t s) {
+  hipError_t e = hipErrorInvalidValue;
+#define CALL_P(T, LG, PD) run_passB<T, LG, PD, PB_PART>(a1, n0, Tbuf, Hy, tw1, tb, P, K, part, pidx, nullptr, nullptr, s, ksplit)
+#define CASE_P(LG)                                                                                  \
+  case LG:                                                                                          \
+    e = dtype == 0 ? (a1.padded ? CALL_P(float, LG, true) : CALL_P(float, LG, false))               \
+                   : (a1.padded ? CALL_P(double, LG, true) : CALL_P(double, LG, false));            \
+    break;
+  switch (a1.lg) { CASE_P(6) CASE_P(7) CASE_P(8) CASE_P(9) CASE_P(10) default: return hipErrorInvalidValue; }
+#undef CASE_P
+#undef CALL_P
+  if (e != hipSuccess) return e;
+  dim3 grid((a1.n + 255) / 256, n0, P);
+  if (dtype == 0)
+    merge_parts_kernel<float><<<grid, 256, 0, s>>>((const cpx<float>*)part, pidx, ksplit, P, K, n0, a1.n, (const cpx<float>*)tb.dx,
+                                                   (const cpx<float>*)tb.dy, (cpx<float>*)out, kidx);
+  else
+    merge_parts_kernel<double><<<grid, 256, 0, s>>>((const cpx<double>*)part, pidx, ksplit, P, K, n0, a1.n, (const cpx<double>*)tb.dx,
+                                                    (const cpx<double>*)tb.dy, (cpx<double>*)out, kidx);
+  return hipGetLastError();
+}
+
 // one peak (grid.y = 1), K candidates; mode PB_GATED (gate: device K x K bytes) or PB_PHASES (psi: K x n0 x n1)
 hipError_t launch_passB_ext(int dtype, const Axis& a1, int n0, const void* Tbuf, const void* Hy, const void* tw1,
                             const SweepTables& tb, int K, int mode, void* out, int32_t* kidx, const uint8_t* gate,

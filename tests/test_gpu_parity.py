@@ -241,6 +241,15 @@ def test_a8_iterate_gpa(golden):
     assert np.allclose(uw, g['u_weighted'], atol=1e-9)
     ug = GPA.reconstruct_u_inv(g['start_ks'] + g['corr'], g['prs'])
     assert np.allclose(ug, g['u_global'], atol=1e-9)
+    # the single-precision build of the same route: lock-ins, unwraps (kmax 25 / 200 hit the f32 residual floor
+    # first), Huber plane fits and the per-pixel solve in f32; the refined k-vectors land on the true ones as well
+    prs32, w32, corr32 = GPA.iterate_GPA(g['image'] - g['image'].mean(), g['start_ks'], int(g['sigma']), dtype=np.float32)
+    assert np.allclose(corr32, g['corr'], rtol=0, atol=2e-6)
+    assert np.allclose(w32, g['w'], rtol=2e-5, atol=1e-5)
+    assert np.abs(prs32 - g['prs']).max() < 2e-3 * np.abs(g['prs']).max()
+    assert np.abs(g['start_ks'] + corr32 - g['true_ks']).max() < 5e-4
+    uw32 = GPA.reconstruct_u_inv(g['start_ks'] + g['corr'], g['prs'], weights=g['w'], dtype=np.float32)
+    assert np.abs(uw32 - g['u_weighted']).max() < 2e-5 * max(1.0, np.abs(g['u_weighted']).max())
 
 
 @pytest.mark.parametrize('dtype', DTYPES)
@@ -971,3 +980,28 @@ def test_transform_free_column_solve_equals_dct_solve(n, dtype):
     assert rel(out['tri_u'][0], out['fft_u'][0]) < tol
     if dtype is np.float64:
         assert out['tri_u'][1] == out['fft_u'][1]
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize('dtype', DTYPES)
+@pytest.mark.parametrize('shape,knx', [((512, 512), 4), ((200, 300), 3), ((1024, 256), 2), ((96, 64), 5)])
+def test_candidate_split_pass_b_is_bit_identical(shape, knx, dtype):
+    """small images run the K candidates of a row on up to four workgroups and merge the partial winners
+    (launch_passB_split); GPA_NO_KSPLIT=1 (read at plan creation) keeps them in one workgroup: same bits"""
+    kvecs = hex_kvecs(0.1, 7.0)
+    img = hex_moire(shape, kvecs, gaussian_bump_displacement(shape), noise=0.3, seed=21)
+    klists = np.stack(explicit_klists(kvecs, 0.04, knx, knx))
+    K = knx * knx
+    os.environ['GPA_NO_KSPLIT'] = '1'
+    ref_plan = _lib.Plan(shape, 3 * K, dtype)
+    os.environ.pop('GPA_NO_KSPLIT')
+    plan = _lib.Plan(shape, 3 * K, dtype)
+    a = ref_plan.extract_displacement_field(img, kvecs, klists, 10, 20, want_lockins=True, want_kidx=True)
+    b = plan.extract_displacement_field(img, kvecs, klists, 10, 20, want_lockins=True, want_kidx=True)
+    assert np.array_equal(a[2], b[2]) and np.array_equal(a[1], b[1]) and np.array_equal(a[0], b[0])
+    img0 = img - img.mean()
+    s1 = ref_plan.sweep(img0, kvecs[1], klists[1], 10)
+    s2 = plan.sweep(img0, kvecs[1], klists[1], 10)
+    assert np.array_equal(s1[0], s2[0]) and np.array_equal(s1[1], s2[1])
+    ref_plan.close()
+    plan.close()
