@@ -71,27 +71,58 @@ static std::vector<double> gaussian_kspace(int n, double sigma) {
   return g;
 }
 
+// spatial kernel h[m] = (1/n) sum_k g[k] cos(2 pi k m / n), m = 0 .. n-1 (g is even): the taps of the circular filter
+static std::vector<double> spatial_kernel(int n, const std::vector<double>& g) {
+  // accumulated in long double (64-bit mantissa) so that the small taps are those of g as given, not summation noise
+  std::vector<double> h((size_t)n);
+  std::vector<long double> cs((size_t)n);
+  const long double w = 2.0L * 3.14159265358979323846264338327950288L / (long double)n;
+  for (int j = 0; j < n; ++j) cs[j] = cosl(w * (long double)j);
+  for (int m = 0; m < n; ++m) {
+    long double acc = 0;
+    for (int k = 0; k < n; ++k)
+      if (g[k] != 0.0) acc += (long double)g[k] * cs[(size_t)((long long)k * m % n)];
+    h[m] = (double)(acc / (long double)n);
+  }
+  return h;
+}
+
+// smallest E such that the taps at circular distance > E from lag 0 sum (in magnitude) to less than tol times the
+// sum of all taps: dropping them changes a filtered value by at most tol * max|input| * sum|h|, a guaranteed bound.
+// The taps of a Gaussian filter fall to the rounding floor of its k-space samples (~1e-17 of the central tap each,
+// the transform of the rounding errors of g) within ~9 sigma; beyond that they are noise the reference's own FFT
+// does not resolve either.
+static int kernel_support(const std::vector<double>& h, double tol) {
+  const int n = (int)h.size();
+  double total = 0;
+  for (double v : h) total += fabs(v);
+  double tail = 0;
+  for (int m = n / 2; m >= 1; --m) {
+    tail += fabs(h[m]) + (n - m != m ? fabs(h[n - m]) : 0.0);
+    if (tail > tol * total) return m;
+  }
+  return 0;
+}
+
 // Filter table of one axis in the spectral register layout [reg][thread]:
-// periodic mode -> real g[k]/L; padded mode -> complex DFT_L(h)/L with h = IDFT_n(g).
-static void build_filter_table(const Axis& ax, double sigma, std::vector<double>& out) {
+// periodic mode -> real g[k]/L; padded mode -> complex DFT_L(h~)/L with h~ the spatial kernel laid out at the lags
+// the axis' extension covers (full: lags 0 .. n-1; compact: lags -extL .. extR around slot 0).
+static void build_filter_table(const Axis& ax, const std::vector<double>& g, const std::vector<double>& hsp,
+                               std::vector<double>& out) {
   const int L = ax.L, tpf = L / 16;
-  std::vector<double> g = gaussian_kspace(ax.n, sigma);
   if (!ax.padded) {
     out.assign((size_t)L, 0.0);
     for (int i = 0; i < 16; ++i)
       for (int t = 0; t < tpf; ++t) out[(size_t)i * tpf + t] = g[spec_index_rt(ax.lg, t, i)] / (double)L;
     return;
   }
-  // spatial kernel h[m] = (1/n) sum_k g[k] cos(2 pi k m / n)  (g is even)
   const int n = ax.n;
   std::vector<std::complex<double>> h((size_t)L, 0.0);
-  std::vector<double> cs(n);
-  for (int j = 0; j < n; ++j) cs[j] = cos(2.0 * M_PI * (double)j / (double)n);
-  for (int m = 0; m < n; ++m) {
-    double acc = 0;
-    for (int k = 0; k < n; ++k)
-      if (g[k] != 0.0) acc += g[k] * cs[(size_t)((long long)k * m % n)];
-    h[m] = acc / (double)n;
+  if (ax.extR == 0) {
+    for (int m = 0; m < n; ++m) h[m] = hsp[m];
+  } else {
+    for (int m = 0; m <= ax.extL; ++m) h[m] = hsp[m];                    // lags 0 .. E: samples to the left
+    for (int m = 1; m <= ax.extR; ++m) h[(size_t)L - m] = hsp[n - m];     // lags -1 .. -E: samples to the right
   }
   host_fft_pow2(h, false);
   out.assign((size_t)2 * L, 0.0);
@@ -166,7 +197,8 @@ struct GraphEntry {
 
 struct gpa_plan {
   int device = 0, dtype = 0, n0 = 0, n1 = 0, max_batch = 0;
-  Axis ax0{}, ax1{};
+  Axis ax0{}, ax1{};              // the geometry in use (depends on sigma for non-power-of-two axes)
+  Axis ax0_full{}, ax1_full{};    // the plan's largest geometry (L >= 2n - 1): what the tables are sized for
   hipStream_t stream = nullptr;
   size_t rsz = 4, csz = 8;        // bytes per real / complex element
   size_t ws_bytes = 0;
@@ -216,7 +248,7 @@ struct gpa_plan {
   hipEvent_t stage_ev[6] = {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};
   float stage_ms[5] = {0, 0, 0, 0, 0};
   EnqueueWorker* worker = nullptr;   // second enqueueing thread of the fused driver
-  bool use_worker = true, no_ksplit = false;
+  bool use_worker = true, no_ksplit = false, no_compact = false;
   std::vector<GraphEntry> graphs;    // captured fused-driver calls (extract_enqueue)
   bool use_graphs = true, serial_unwrap = false;
   int tbuf_epoch = 0;                // bumped when a buffer baked into the graphs is reallocated
@@ -245,6 +277,22 @@ static Axis make_axis(int n) {
   }
   a.lg = lg;
   a.L = 1 << lg;
+  a.extL = a.padded ? n - 1 : 0;
+  a.extR = 0;
+  return a;
+}
+
+// the axis geometry for a kernel whose taps vanish beyond E samples: the compact extension if it allows a shorter
+// transform than the full one
+static Axis compact_axis(const Axis& full, int E) {
+  if (!full.padded || E >= (full.n - 1) / 2) return full;
+  int lg = 6;
+  while ((1 << lg) < full.n + 2 * E) ++lg;
+  if (lg >= full.lg) return full;
+  Axis a = full;
+  a.lg = lg;
+  a.L = 1 << lg;
+  a.extL = a.extR = E;
   return a;
 }
 
@@ -304,9 +352,11 @@ static int plan_build(gpa_plan* p) {
   TRY(dmalloc(p, &p->tb.cxb, (size_t)B * (p->ax0.L / 16) * p->csz));
   TRY(dmalloc(p, &p->tb.sx, (size_t)B * 16 * p->csz));
   TRY(dmalloc(p, &p->tb.wxw, (size_t)B * p->csz));
+  TRY(dmalloc(p, &p->tb.wxr, (size_t)B * p->csz));
   TRY(dmalloc(p, &p->tb.cyb, (size_t)B * (p->ax1.L / 16) * p->csz));
   TRY(dmalloc(p, &p->tb.sy, (size_t)B * 16 * p->csz));
   TRY(dmalloc(p, &p->tb.wyw, (size_t)B * p->csz));
+  TRY(dmalloc(p, &p->tb.wyr, (size_t)B * p->csz));
   TRY(dmalloc(p, (void**)&p->tb.planeof, (size_t)B * sizeof(int)));
   TRY(dmalloc(p, (void**)&p->d_pw, (size_t)B * sizeof(double)));
   TRY(dmalloc(p, &p->tb.dx, (size_t)B * p->n0 * p->csz));
@@ -338,14 +388,42 @@ static int plan_build(gpa_plan* p) {
   return GPA_OK;
 }
 
+static void drop_graphs(gpa_plan* p);
+
+static int upload_twiddles(gpa_plan* p, void* dst, int L) {
+  std::vector<double> t((size_t)2 * L);
+  for (int k = 0; k < L; ++k) {
+    t[2 * k] = cos(-2.0 * M_PI * k / L);
+    t[2 * k + 1] = sin(-2.0 * M_PI * k / L);
+  }
+  return upload_real_table(p, dst, t);
+}
+
 static int ensure_filters(gpa_plan* p, double sigma) {
   if (!(sigma > 0)) return fail(GPA_ERR_ARG, "sigma must be positive");
   if (sigma == p->sigma_cached) return GPA_OK;
-  std::vector<double> h;
-  build_filter_table(p->ax0, sigma, h);
-  TRY(upload_real_table(p, p->Hx, h));
-  build_filter_table(p->ax1, sigma, h);
-  TRY(upload_real_table(p, p->Hy, h));
+  HIP_TRY(hipStreamSynchronize(p->stream));   // the tables may still be read by an earlier asynchronous call
+  for (int axis = 0; axis < 2; ++axis) {
+    const Axis& full = axis == 0 ? p->ax0_full : p->ax1_full;
+    Axis& cur = axis == 0 ? p->ax0 : p->ax1;
+    std::vector<double> g = gaussian_kspace(full.n, sigma), hsp, table;
+    Axis want = full;
+    if (full.padded) {
+      hsp = spatial_kernel(full.n, g);
+      if (!p->no_compact) want = compact_axis(full, kernel_support(hsp, p->dtype == 0 ? 1e-9 : 1e-14));
+    }
+    if (want.lg != cur.lg || want.extR != cur.extR || want.extL != cur.extL) {
+      // another transform length for this sigma: twiddles of that length, and the carrier tables (laid out per
+      // L / 16 threads) have to be staged again
+      TRY(upload_twiddles(p, axis == 0 ? p->tw0 : p->tw1, want.L));
+      p->staged_kl.clear();
+      p->staged_kr.clear();
+      drop_graphs(p);
+      cur = want;
+    }
+    build_filter_table(cur, g, hsp, table);
+    TRY(upload_real_table(p, axis == 0 ? p->Hx : p->Hy, table));
+  }
   p->sigma_cached = sigma;
   return GPA_OK;
 }
@@ -467,12 +545,13 @@ gpa_plan* gpa_plan_create(int device, int n0, int n1, int max_batch, int dtype) 
   p->max_batch = max_batch;
   p->rsz = dtype == GPA_F32 ? 4 : 8;
   p->csz = 2 * p->rsz;
-  p->ax0 = make_axis(n0);
-  p->ax1 = make_axis(n1);
+  p->ax0 = p->ax0_full = make_axis(n0);
+  p->ax1 = p->ax1_full = make_axis(n1);
   p->use_graphs = getenv("GPA_USE_GRAPH") != nullptr;
   p->serial_unwrap = getenv("GPA_SERIAL_UNWRAP") != nullptr;
   p->use_worker = getenv("GPA_NO_WORKER") == nullptr;
   p->no_ksplit = getenv("GPA_NO_KSPLIT") != nullptr;
+  p->no_compact = getenv("GPA_NO_COMPACT") != nullptr;
   const int maxlg = dtype == GPA_F32 ? 14 : 13;
   if (p->ax0.lg > maxlg || p->ax1.lg > maxlg) {
     fail(GPA_ERR_ARG, "gpa_plan_create: axis too long for an LDS-resident transform "
@@ -500,7 +579,7 @@ void gpa_plan_destroy(gpa_plan* p) {
     if (g.graph) hipGraphDestroy(g.graph);
   }
   p->graphs.clear();
-  void* bufs[] = {p->tw0, p->tw1, p->Hx, p->Hy, p->Tbuf, p->tb.cxb, p->tb.sx, p->tb.wxw, p->tb.cyb, p->tb.sy, p->tb.wyw, p->tb.planeof, p->d_pw,
+  void* bufs[] = {p->tw0, p->tw1, p->Hx, p->Hy, p->Tbuf, p->tb.cxb, p->tb.sx, p->tb.wxw, p->tb.wxr, p->tb.cyb, p->tb.sy, p->tb.wyw, p->tb.wyr, p->tb.planeof, p->d_pw,
                   p->tb.dx, p->tb.dy, p->d_kl, p->d_kr, p->d_image, p->d_mean, p->d_tile_mean, p->d_scratch,
                   p->d_lockin, p->d_kidx, p->d_dudx, p->d_dudy, p->d_wnorm, p->d_u, p->d_kmat, p->d_sf, p->d_grad, p->d_aux0, p->d_aux1};
   for (void* b : bufs)

@@ -60,18 +60,26 @@ inline hipError_t set_dynamic_lds_once(const void* kern, int bytes, unsigned& do
 //           evaluated as a linear convolution of the periodically extended input
 //           with the full length-n spatial kernel -- the same numbers as
 //           IDFT_n(G * DFT_n(a)), without ever needing a length-n FFT.
+//           The extension covers extL samples to the left (FFT slots [L - extL, L)) and extR to the right
+//           (slots [n, n + extR)) of the n samples in slots [0, n).  Full form: extL = n - 1, extR = 0, the
+//           kernel's n taps at lags 0 .. n-1, L >= 2n - 1.  Compact form (chosen per sigma when it gives a shorter
+//           transform): the kernel of a Gaussian filter is negligible beyond E samples (the host measures E on
+//           the actual taps: everything dropped sums to < 1e-14 (f64) / 1e-9 (f32) of sum|h|), so lags -E .. E
+//           suffice, extL = extR = E and L >= n + 2E.
 struct Axis {
   int n;
   int lg;      // log2(L)
   int L;
   bool padded;
+  int extL, extR;
 };
 
 // source sample of FFT slot m (-1: zero padding)
-GPA_HD int axis_src(int m, int n, int L, bool padded) {
+GPA_HD int axis_src(int m, int n, int L, bool padded, int extL, int extR) {
   if (!padded) return m;
   if (m < n) return m;
-  if (m >= L - n + 1) return m - L + n;
+  if (m < n + extR) return m - n;
+  if (m >= L - extL) return m - L + n;
   return -1;
 }
 
@@ -89,10 +97,12 @@ GPA_HD int axis_src(int m, int n, int L, bool padded) {
 struct SweepTables {
   void* cxb;   // [Bx][L0/16] exp(2 pi i wx t): carrier along x at the thread's base row
   void* sx;    // [Bx][16]    exp(2 pi i wx (L0/16) i): per-register stride factor
-  void* wxw;   // [Bx]        exp(-2 pi i wx (L0 - n0)): wrap factor (padded mode)
-  void* cyb;   // [B][L1/16]  the same three for the y carrier of every candidate
+  void* wxw;   // [Bx]        exp(-2 pi i wx (L0 - n0)): wrap factor of the left extension (padded mode)
+  void* wxr;   // [Bx]        exp(-2 pi i wx n0): wrap factor of the right extension (compact padded mode)
+  void* cyb;   // [B][L1/16]  the same four for the y carrier of every candidate
   void* sy;    // [B][16]
   void* wyw;   // [B]
+  void* wyr;   // [B]
   void* dx;    // [B][n0]     exp(-2 pi i (wx - kx) x)   compensation to the peak centre
   void* dy;    // [B][n1]     exp(-2 pi i (wy - ky) y)
   int* planeof;   // [B] x-plane of each candidate

@@ -36,7 +36,8 @@ __global__ __launch_bounds__((PassBGeom<T, LG>::THREADS), (sizeof(T) == 8 ? GPA_
     const cpx<T>* __restrict__ Tin, int n0, int n1,
     const typename HType<PADDED, T>::type* __restrict__ H, const cpx<T>* __restrict__ twtab,
     const int* __restrict__ planeof, const cpx<T>* __restrict__ cyb, const cpx<T>* __restrict__ sy,
-    const cpx<T>* __restrict__ wyw, const cpx<T>* __restrict__ dx, const cpx<T>* __restrict__ dy, int K,
+    const cpx<T>* __restrict__ wyw, const cpx<T>* __restrict__ wyr, int extL, int extR,
+    const cpx<T>* __restrict__ dx, const cpx<T>* __restrict__ dy, int K,
     cpx<T>* __restrict__ out, int32_t* __restrict__ kidx, const uint8_t* __restrict__ gate, T* __restrict__ psi) {
   constexpr bool SELECT = MODE != PB_ALL;
   using F = WgFFT<T, LG>;
@@ -79,8 +80,8 @@ __global__ __launch_bounds__((PassBGeom<T, LG>::THREADS), (sizeof(T) == 8 ? GPA_
       cpx<T> ph = cmul(cbase, sy[b * 16 + i]);   // exp(2 pi i wy y) at y = tid + TPF*i
       if constexpr (PADDED) {
         const int slot = tid + TPF * i;
-        const int ys = axis_src(slot, n1, L, true);
-        if (slot >= n1) ph = cmul(ph, wyw[b]);
+        const int ys = axis_src(slot, n1, L, true, extL, extR);
+        if (slot >= n1) ph = cmul(ph, slot < n1 + extR ? wyr[b] : wyw[b]);
         x[i] = ys >= 0 ? cmul(src[ys], ph) : cpx<T>{T(0), T(0)};
       } else {
         x[i] = cmul(src[tid + TPF * i], ph);   // rows past the image reuse row 0; their results are dropped
@@ -168,6 +169,7 @@ static hipError_t run_passB(const Axis& a1, int n0, const void* Tbuf, const void
     kern<<<grid, G::THREADS, G::LDS_BYTES, s>>>(
         (const cpx<T>*)Tbuf, n0, a1.n, (const typename HType<PADDED, T>::type*)Hy,
         (const cpx<T>*)tw1, tb.planeof, (const cpx<T>*)tb.cyb, (const cpx<T>*)tb.sy, (const cpx<T>*)tb.wyw,
+        (const cpx<T>*)tb.wyr, a1.extL, a1.extR,
         (const cpx<T>*)tb.dx, (const cpx<T>*)tb.dy, K, (cpx<T>*)out, kidx, gate, (T*)psi);
     return hipGetLastError();
   }

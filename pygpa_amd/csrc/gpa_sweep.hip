@@ -33,7 +33,8 @@ __device__ __forceinline__ cpx<T> unit_phasor(double cycles) {
 template <class T>
 __global__ void tables_kernel(const double* __restrict__ kl, const double* __restrict__ kr,
                               const double* __restrict__ pw, int B, int Bx, int n0, int n1, int L0, int L1,
-                              cpx<T>* cxb, cpx<T>* sx, cpx<T>* wxw, cpx<T>* cyb, cpx<T>* sy, cpx<T>* wyw,
+                              cpx<T>* cxb, cpx<T>* sx, cpx<T>* wxw, cpx<T>* wxr, cpx<T>* cyb, cpx<T>* sy, cpx<T>* wyw,
+                              cpx<T>* wyr,
                               cpx<T>* dx, cpx<T>* dy) {
   const int b = blockIdx.y;
   const int j = blockIdx.x * blockDim.x + threadIdx.x;
@@ -43,6 +44,7 @@ __global__ void tables_kernel(const double* __restrict__ kl, const double* __res
     if (j < tpf) cxb[(size_t)b * tpf + j] = unit_phasor<T>(wx * j);
     if (j < 16) sx[b * 16 + j] = unit_phasor<T>(wx * (double)tpf * j);
     if (j == 0) wxw[b] = unit_phasor<T>(-wx * (double)(L0 - n0));
+    if (j == 1) wxr[b] = unit_phasor<T>(-wx * (double)n0);
   }
   if (b < B) {    // y carrier and compensation phasors of candidate b
     const double wx = kl[2 * b], wy = kl[2 * b + 1], kx = kr[2 * b], ky = kr[2 * b + 1];
@@ -50,6 +52,7 @@ __global__ void tables_kernel(const double* __restrict__ kl, const double* __res
     if (j < tpf) cyb[(size_t)b * tpf + j] = unit_phasor<T>(wy * j);
     if (j < 16) sy[b * 16 + j] = unit_phasor<T>(wy * (double)tpf * j);
     if (j == 0) wyw[b] = unit_phasor<T>(-wy * (double)(L1 - n1));
+    if (j == 1) wyr[b] = unit_phasor<T>(-wy * (double)n1);
     if (j < n1) dy[(size_t)b * n1 + j] = unit_phasor<T>(-(wy - ky) * j);
     if (j < n0) dx[(size_t)b * n0 + j] = unit_phasor<T>(-(wx - kx) * j);
   }
@@ -65,13 +68,13 @@ hipError_t launch_tables(int dtype, const Axis& a0, const Axis& a1, const double
   dim3 grid((len + 255) / 256, B > Bx ? B : Bx);
   if (dtype == 0)
     tables_kernel<float><<<grid, 256, 0, s>>>(kl, kr, pw, B, Bx, a0.n, a1.n, a0.L, a1.L, (cpx<float>*)tb.cxb,
-                                              (cpx<float>*)tb.sx, (cpx<float>*)tb.wxw, (cpx<float>*)tb.cyb,
-                                              (cpx<float>*)tb.sy, (cpx<float>*)tb.wyw, (cpx<float>*)tb.dx,
+                                              (cpx<float>*)tb.sx, (cpx<float>*)tb.wxw, (cpx<float>*)tb.wxr, (cpx<float>*)tb.cyb,
+                                              (cpx<float>*)tb.sy, (cpx<float>*)tb.wyw, (cpx<float>*)tb.wyr, (cpx<float>*)tb.dx,
                                               (cpx<float>*)tb.dy);
   else
     tables_kernel<double><<<grid, 256, 0, s>>>(kl, kr, pw, B, Bx, a0.n, a1.n, a0.L, a1.L, (cpx<double>*)tb.cxb,
-                                               (cpx<double>*)tb.sx, (cpx<double>*)tb.wxw, (cpx<double>*)tb.cyb,
-                                               (cpx<double>*)tb.sy, (cpx<double>*)tb.wyw, (cpx<double>*)tb.dx,
+                                               (cpx<double>*)tb.sx, (cpx<double>*)tb.wxw, (cpx<double>*)tb.wxr, (cpx<double>*)tb.cyb,
+                                               (cpx<double>*)tb.sy, (cpx<double>*)tb.wyw, (cpx<double>*)tb.wyr, (cpx<double>*)tb.dx,
                                                (cpx<double>*)tb.dy);
   return hipGetLastError();
 }
@@ -153,6 +156,7 @@ template <class T, int LG, bool PADDED>
 __global__ __launch_bounds__((PassAGeom<T, LG>::THREADS)) void passA_kernel(
     const T* __restrict__ image, const T* __restrict__ mean, int n0, int n1,
     const cpx<T>* __restrict__ cxb, const cpx<T>* __restrict__ sx, const cpx<T>* __restrict__ wxw,
+    const cpx<T>* __restrict__ wxr, int extL, int extR,
     const typename HType<PADDED, T>::type* __restrict__ H,
     const cpx<T>* __restrict__ twtab, cpx<T>* __restrict__ Tout, int B, int bchunk) {
   using F = WgFFT<T, LG>;
@@ -173,16 +177,16 @@ __global__ __launch_bounds__((PassAGeom<T, LG>::THREADS)) void passA_kernel(
   const T m = mean ? *mean : T(0);
 
   T val[NT][16];
-  unsigned wrapmask = 0;
+  unsigned wrapmask = 0, rightmask = 0;   // slots of the left / right periodic extension (padded mode)
 #pragma unroll
   for (int n = 0; n < NT; ++n) {
     const int y = y0 + n;
 #pragma unroll
     for (int i = 0; i < 16; ++i) {
       const int slot = t + TPF * i;
-      const int xs = axis_src(slot, n0, L, PADDED);
+      const int xs = axis_src(slot, n0, L, PADDED, extL, extR);
       val[n][i] = (y < n1 && xs >= 0) ? image[(size_t)xs * n1 + y] - m : T(0);
-      if (PADDED && slot >= n0) wrapmask |= 1u << i;
+      if (PADDED && slot >= n0) { if (slot < n0 + extR) rightmask |= 1u << i; else wrapmask |= 1u << i; }
     }
   }
   typename F::KTw tw;
@@ -198,6 +202,7 @@ __global__ __launch_bounds__((PassAGeom<T, LG>::THREADS)) void passA_kernel(
     for (int i = 0; i < 16; ++i) {
       cpx<T> ph = cmul(base, sx[b * 16 + i]);
       if (PADDED && ((wrapmask >> i) & 1)) ph = cmul(ph, wxw[b]);
+      if (PADDED && ((rightmask >> i) & 1)) ph = cmul(ph, wxr[b]);
 #pragma unroll
       for (int n = 0; n < NT; ++n) x[n][i] = {val[n][i] * ph.x, val[n][i] * ph.y};
     }
@@ -273,7 +278,7 @@ static hipError_t run_passA(const Axis& a0, int n1, const void* image, const voi
     GPA_PROF("passA_kernel", s);
     kern<<<grid, G::THREADS, G::LDS_BYTES, s>>>(
         (const T*)image, (const T*)mean, a0.n, n1, (const cpx<T>*)tb.cxb, (const cpx<T>*)tb.sx,
-        (const cpx<T>*)tb.wxw,
+        (const cpx<T>*)tb.wxw, (const cpx<T>*)tb.wxr, a0.extL, a0.extR,
         (const typename HType<PADDED, T>::type*)Hx, (const cpx<T>*)tw0, (cpx<T>*)Tbuf, B, bchunk);
     return hipGetLastError();
   }

@@ -1592,6 +1592,7 @@ hipError_t run_g_rowdct(const Impl* w, hipStream_t s) {
     hipError_t e = set_dynamic_lds_once(reinterpret_cast<const void*>(kern), (int)G::LDS_BYTES, lds_set);
     if (e != hipSuccess) return e;
     const int npairs = (w->n0 + 1) / 2, grid = (npairs + G::NF - 1) / G::NF;
+    GPA_PROF("g_rowdct_kernel", s);
     kern<<<grid, G::THREADS, G::LDS_BYTES, s>>>((const T*)w->r, w->n0, w->n1, (T*)w->z, (const cpx<T>*)w->btw1,
                                                  (const cpx<T>*)w->chirp1, (const cpx<T>*)w->bspec1,
                                                  (const cpx<T>*)w->gwk1, w->flags);
@@ -1609,6 +1610,7 @@ hipError_t run_g_rowidct(const Impl* w, int* nparts, hipStream_t s) {
     if (e != hipSuccess) return e;
     const int npairs = (w->n0 + 1) / 2, grid = (npairs + G::NF - 1) / G::NF;
     *nparts = grid;
+    GPA_PROF("g_rowidct_kernel", s);
     kern<<<grid, G::THREADS, G::LDS_BYTES, s>>>((T*)w->z, (const T*)w->r, w->n0, w->n1, (const cpx<T>*)w->btw1,
                                                  (const cpx<T>*)w->chirp1, (const cpx<T>*)w->bspec1,
                                                  (const cpx<T>*)w->gwk1, w->part, w->flags);
@@ -1625,6 +1627,7 @@ hipError_t run_g_colsolve(const Impl* w, int compat, hipStream_t s) {
     hipError_t e = set_dynamic_lds_once(reinterpret_cast<const void*>(kern), (int)G::LDS_BYTES, lds_set);
     if (e != hipSuccess) return e;
     const int npairs = (w->n1 + 1) / 2, grid = (npairs + G::NF - 1) / G::NF;
+    GPA_PROF("g_colsolve_kernel", s);
     kern<<<grid, G::THREADS, G::LDS_BYTES, s>>>((T*)w->z, w->n0, w->n1, (const cpx<T>*)w->btw0,
                                                  (const cpx<T>*)w->chirp0, (const cpx<T>*)w->bspec0,
                                                  (const cpx<T>*)w->gwk0, (const T*)w->gha0[compat],
@@ -1967,7 +1970,7 @@ static hipError_t run_pcg(Impl* w, const void* a, const void* b, const void* wei
       if ((e = dispatch_colsolve(w, compat, s)) != hipSuccess) return e;
       if ((e = dispatch_rowidct(w, &nrow, s)) != hipSuccess) return e;
     }
-    scal_rho_kernel<<<1, 256, 0, s>>>(w->part, nrow, w->scal, w->flags);
+    { GPA_PROF("scalar_kernels", s); scal_rho_kernel<<<1, 256, 0, s>>>(w->part, nrow, w->scal, w->flags); }
     T* pcur;
     if (vec4) {
       T* pin = (T*)((it & 1) ? w->p2 : w->p);
@@ -1977,13 +1980,16 @@ static hipError_t run_pcg(Impl* w, const void* a, const void* b, const void* wei
       scal_alpha_kernel<<<1, 256, 0, s>>>(w->part + MAXPART, npq, w->scal, w->flags);
     } else {
       pcur = (T*)w->p;
-      pupdate_kernel<T><<<gl, 256, 0, s>>>((const T*)w->z, pcur, npx, w->scal, w->flags);
-      applyq_kernel<T><<<g2, 256, 0, s>>>((const T*)pcur, (const T*)weight, n0, n1, (T*)w->q, w->part + MAXPART,
-                                          w->flags);
+      { GPA_PROF("pupdate_kernel", s);
+        pupdate_kernel<T><<<gl, 256, 0, s>>>((const T*)w->z, pcur, npx, w->scal, w->flags); }
+      { GPA_PROF("applyq_kernel", s);
+        applyq_kernel<T><<<g2, 256, 0, s>>>((const T*)pcur, (const T*)weight, n0, n1, (T*)w->q, w->part + MAXPART,
+                                            w->flags); }
       scal_alpha_kernel<<<1, 256, 0, s>>>(w->part + MAXPART, np2, w->scal, w->flags);
     }
-    update_kernel<T><<<gl, 256, 0, s>>>((const T*)pcur, (const T*)w->q, (T*)phi, (T*)w->r, npx, w->scal,
-                                        w->part + 2 * MAXPART, w->flags);
+    { GPA_PROF("update_kernel", s);
+      update_kernel<T><<<gl, 256, 0, s>>>((const T*)pcur, (const T*)w->q, (T*)phi, (T*)w->r, npx, w->scal,
+                                          w->part + 2 * MAXPART, w->flags); }
     scal_stop_kernel<<<1, 256, 0, s>>>(w->part + 2 * MAXPART, gl, w->scal, w->flags, kmax, eps);
   }
   return hipGetLastError();

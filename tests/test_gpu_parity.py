@@ -1005,3 +1005,42 @@ def test_candidate_split_pass_b_is_bit_identical(shape, knx, dtype):
     assert np.array_equal(s1[0], s2[0]) and np.array_equal(s1[1], s2[1])
     ref_plan.close()
     plan.close()
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize('dtype', DTYPES)
+@pytest.mark.parametrize('shape', [(300, 200), (1100, 600), (130, 1030)])
+def test_compact_padded_axes(shape, dtype, monkeypatch):
+    """non-power-of-two axes, narrow spatial kernel: the plan switches to the compact extension (lags -E .. E,
+    transform length pow2 >= n + 2E instead of >= 2n - 1) -- same numbers as the oracle and as the full
+    extension, and switching sigma on one plan (compact -> full -> compact) restages every table"""
+    kvecs = hex_kvecs(0.11, 4.0)
+    img = hex_moire(shape, kvecs, gaussian_bump_displacement(shape), noise=0.2, seed=5)
+    img0 = img - img.mean()
+    klist = explicit_klists(kvecs, 0.03, 3, 3)[0]
+    plan = _lib.Plan(shape, len(klist), dtype)
+    full_len = [plan.fft_len(0), plan.fft_len(1)]
+    monkeypatch.setenv('GPA_NO_COMPACT', '1')
+    plan_full = _lib.Plan(shape, len(klist), dtype)
+    monkeypatch.delenv('GPA_NO_COMPACT')
+    for sigma in (4, 60, 4, 9):
+        ref = orc.sweep(img0, sigma, klist, kvecs[0], workers=8)
+        lock, kidx, _ = plan.sweep(img0, kvecs[0], klist, sigma)
+        lens = [plan.fft_len(0), plan.fft_len(1)]
+        if sigma == 4:     # E ~ 31 (f64) | 24 (f32): 300 -> 512 (full 1024), 1100 -> 2048 (full 4096), 1030 -> 2048 (full 4096)
+            assert lens[0] < full_len[0] or lens[1] < full_len[1], (lens, full_len)
+        if sigma == 60 and shape == (300, 200):    # kernel as wide as the image: back to the full extension
+            assert lens == full_len
+        check_kidx(kidx, ref['kidx'], img0, klist, sigma, TOL[dtype]['tie'])
+        same = kidx == ref['kidx']
+        assert same.mean() > 0.999
+        assert rel(lock[same], ref['lockin'][same]) < TOL[dtype]['lock'], (sigma, lens)
+        lock_f, kidx_f, _ = plan_full.sweep(img0, kvecs[0], klist, sigma)
+        assert [plan_full.fft_len(0), plan_full.fft_len(1)] == full_len
+        same = kidx == kidx_f
+        assert same.mean() > 0.999 and rel(lock[same], lock_f[same]) < TOL[dtype]['lock']
+        # the unfused lock-in entry point shares the tables
+        lb = plan.lockin_batch(img0, klist[:2], sigma)
+        assert rel(lb, orc.lockin_batch(img0, klist[:2], sigma)) < TOL[dtype]['lock']
+    plan.close()
+    plan_full.close()
