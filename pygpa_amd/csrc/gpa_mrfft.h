@@ -1,0 +1,208 @@
+// Workgroup FFT of any length n = 2^a 3^b 5^c 7^d 11^e 13^f, the transform resident in LDS.
+//
+// The power-of-two engine (gpa_fft.h) keeps a transform in registers, 16 elements per thread, which ties the
+// length to 16 * threads and the radices to powers of two.  Image sizes that are not powers of two (500, 1000,
+// 1500, 3000 pixels; tile + 2 halo windows) used to be transformed through Bluestein's chirp-z on that engine:
+// two FFTs of length >= 2n - 1 per DFT of length n.  This engine transforms length n itself:
+//
+//   * Stockham autosort, decimation in frequency: pass p (radix R, s = product of the earlier radices) takes
+//     butterfly b = q + s pp (q < s, pp < n / (s R)) from elements b + j n/R (j < R: lane-consecutive, no bank
+//     conflicts), and writes X_k w_(n/s)^(pp k) to q + s (R pp + k).  Natural order in, natural order out,
+//     no digit reversal.
+//   * one LDS buffer: every thread loads its butterflies (<= 16 values) into registers, barrier, butterflies and
+//     twiddles in registers, stores, barrier.  T = threads per transform is chosen by the host so that
+//     ceil(n / (R T)) * R <= 16 for every radix (n = 3000: T = 256).
+//   * radices 16 / 8 / 4 / 2 come from gpa_fft.h's register DFTs, odd primes from one generic butterfly that
+//     pairs a_j with a_(R-j) (half the multiplications of the plain O(R^2) sum).
+//   * twiddles w_n^i from one table of n entries (L1-resident: 24 KB at n = 3000 f32); pp k s < n needs no modulo.
+//     b / s is a multiply-high by ceil(2^32 / s), exact for b s < 2^32 (n <= 2^14 here).
+//
+// The per-thread steps are GPA_HD: tests/host/mrfft_emulator.cpp runs them thread by thread on the CPU.
+#pragma once
+#include <stdint.h>
+
+#include "gpa_fft.h"
+
+namespace gpa {
+
+constexpr int MR_MAXPASS = 12;
+constexpr int MR_REGS = 16;
+
+struct MrPlan {
+  int n;                        // transform length
+  int np;                       // passes
+  int T;                        // threads per transform (multiple of 64)
+  int radix[MR_MAXPASS];
+  int stride[MR_MAXPASS];       // s_p = product of the radices of the passes before p
+  unsigned magic[MR_MAXPASS];   // ceil(2^32 / s_p)
+};
+
+// LDS image: one element of padding per 32 (stride-R stores of the first passes would otherwise pile onto a few banks)
+GPA_HD int mr_pad(int i) { return i + (i >> 5); }
+GPA_HD int mr_lds_elems(int n) { return mr_pad(n - 1) + 1; }
+
+GPA_HD unsigned mr_mulhi(unsigned a, unsigned b) {
+#if defined(__HIP_DEVICE_COMPILE__)
+  return __umulhi(a, b);
+#else
+  return (unsigned)(((uint64_t)a * (uint64_t)b) >> 32);
+#endif
+}
+
+// (cos, sin)(2 pi i / R) of the odd radices
+template <int R> struct MrTrig;
+template <> struct MrTrig<3> {
+  static GPA_HD double c(int i) { constexpr double t[3] = {1.0, -0.5, -0.5}; return t[i]; }
+  static GPA_HD double s(int i) { constexpr double t[3] = {0.0, 0.866025403784438646764, -0.866025403784438646764}; return t[i]; }
+};
+template <> struct MrTrig<5> {
+  static GPA_HD double c(int i) { constexpr double t[5] = {1.0, 0.309016994374947424102, -0.809016994374947424102, -0.809016994374947424102, 0.309016994374947424102}; return t[i]; }
+  static GPA_HD double s(int i) { constexpr double t[5] = {0.0, 0.951056516295153572116, 0.587785252292473129169, -0.587785252292473129169, -0.951056516295153572116}; return t[i]; }
+};
+template <> struct MrTrig<7> {
+  static GPA_HD double c(int i) { constexpr double t[7] = {1.0, 0.623489801858733530525, -0.222520933956314404289, -0.900968867902419126236, -0.900968867902419126236, -0.222520933956314404289, 0.623489801858733530525}; return t[i]; }
+  static GPA_HD double s(int i) { constexpr double t[7] = {0.0, 0.781831482468029808708, 0.974927912181823607018, 0.433883739117558120476, -0.433883739117558120476, -0.974927912181823607018, -0.781831482468029808708}; return t[i]; }
+};
+template <> struct MrTrig<11> {
+  static GPA_HD double c(int i) { constexpr double t[11] = {1.0, 0.841253532831181168862, 0.415415013001886425529, -0.142314838273285140444, -0.654860733945285064057, -0.95949297361449738989, -0.95949297361449738989, -0.654860733945285064057, -0.142314838273285140444, 0.415415013001886425529, 0.841253532831181168862}; return t[i]; }
+  static GPA_HD double s(int i) { constexpr double t[11] = {0.0, 0.540640817455597582108, 0.909631995354518371412, 0.989821441880932732376, 0.755749574354258283774, 0.281732556841429697711, -0.281732556841429697711, -0.755749574354258283774, -0.989821441880932732376, -0.909631995354518371412, -0.540640817455597582108}; return t[i]; }
+};
+template <> struct MrTrig<13> {
+  static GPA_HD double c(int i) { constexpr double t[13] = {1.0, 0.8854560256532098959, 0.568064746731155802512, 0.120536680255323053349, -0.35460488704253562597, -0.748510748171101098635, -0.970941817426052027157, -0.970941817426052027157, -0.748510748171101098635, -0.35460488704253562597, 0.120536680255323053349, 0.568064746731155802512, 0.8854560256532098959}; return t[i]; }
+  static GPA_HD double s(int i) { constexpr double t[13] = {0.0, 0.464723172043768545656, 0.82298386589365639458, 0.992708874098053992801, 0.93501624268541482344, 0.663122658240795202377, 0.239315664287557767149, -0.239315664287557767149, -0.663122658240795202377, -0.93501624268541482344, -0.992708874098053992801, -0.82298386589365639458, -0.464723172043768545656}; return t[i]; }
+};
+
+// forward DFT of R values in place, natural order.  Odd R: with P_j = a_j + a_(R-j), M_j = a_j - a_(R-j),
+//   X_k, X_(R-k) = a_0 + sum_j cos(2 pi j k / R) P_j  -/+  i sum_j sin(2 pi j k / R) M_j
+template <class T, int R>
+GPA_HD void mr_bfly(cpx<T>* a) {
+  if constexpr (R == 2 || R == 4 || R == 8 || R == 16) {
+    dft_regs<R, false>(a);
+  } else {
+    constexpr int H = (R - 1) / 2;
+    cpx<T> P[H], M[H];
+#pragma unroll
+    for (int j = 1; j <= H; ++j) {
+      P[j - 1] = a[j] + a[R - j];
+      M[j - 1] = a[j] - a[R - j];
+    }
+    const cpx<T> a0 = a[0];
+    cpx<T> x0 = a0;
+#pragma unroll
+    for (int j = 0; j < H; ++j) x0 = x0 + P[j];
+    a[0] = x0;
+#pragma unroll
+    for (int k = 1; k <= H; ++k) {
+      cpx<T> re = a0, im = {T(0), T(0)};
+#pragma unroll
+      for (int j = 1; j <= H; ++j) {
+        const T c = (T)MrTrig<R>::c((j * k) % R), s = (T)MrTrig<R>::s((j * k) % R);
+        re.x += c * P[j - 1].x;
+        re.y += c * P[j - 1].y;
+        im.x += s * M[j - 1].x;
+        im.y += s * M[j - 1].y;
+      }
+      a[k] = {re.x + im.y, re.y - im.x};
+      a[R - k] = {re.x - im.y, re.y + im.x};
+    }
+  }
+}
+
+// pass, first half: this thread's butterflies from LDS into registers
+template <class T, int R>
+GPA_HD void mr_load(cpx<T>* x, const cpx<T>* lds, int n, int tid, int Tn) {
+  constexpr int NB = MR_REGS / R;
+  const int nb = n / R;
+#pragma unroll
+  for (int u = 0; u < NB; ++u) {
+    const int b = tid + u * Tn;
+    if (b < nb) {
+#pragma unroll
+      for (int j = 0; j < R; ++j) x[u * R + j] = lds[mr_pad(b + j * nb)];
+    }
+  }
+}
+
+// pass, second half (after a barrier): butterflies, twiddles, autosort store.  W: w_n^i = exp(-2 pi i / n * i), i < n
+template <class T, int R>
+GPA_HD void mr_store(cpx<T>* x, cpx<T>* lds, int n, int s, unsigned magic, int tid, int Tn,
+                     const cpx<T>* __restrict__ W) {
+  constexpr int NB = MR_REGS / R;
+  const int nb = n / R;
+  const bool last = s * R == n;   // pp == 0 throughout: no twiddles
+#pragma unroll
+  for (int u = 0; u < NB; ++u) {
+    const int b = tid + u * Tn;
+    if (b < nb) {
+      mr_bfly<T, R>(x + u * R);
+      const int pp = s == 1 ? b : (int)mr_mulhi((unsigned)b, magic), q = b - pp * s;
+      const int base = q + s * R * pp, ws = pp * s;
+#pragma unroll
+      for (int k = 0; k < R; ++k) {
+        cpx<T> v = x[u * R + k];
+        if (k > 0 && !last) v = cmul(v, W[ws * k]);
+        lds[mr_pad(base + s * k)] = v;
+      }
+    }
+  }
+}
+
+#if defined(__HIPCC__)
+// the whole transform; the data must be in LDS and a barrier passed before the call, ends with a barrier.
+// Every thread of the workgroup must call (tid >= pl.T: idle lanes of a partially filled workgroup are not allowed --
+// the launch geometry is blockDim = transforms per workgroup * pl.T).
+template <class T>
+__device__ __forceinline__ void mr_run(cpx<T>* lds, const MrPlan& pl, const cpx<T>* __restrict__ W, int tid) {
+  cpx<T> x[MR_REGS];
+  for (int p = 0; p < pl.np; ++p) {
+    const int s = pl.stride[p];
+    const unsigned mg = pl.magic[p];
+#define GPA_MR_CASE(R)                                   \
+  case R:                                                \
+    mr_load<T, R>(x, lds, pl.n, tid, pl.T);              \
+    __syncthreads();                                     \
+    mr_store<T, R>(x, lds, pl.n, s, mg, tid, pl.T, W);   \
+    break;
+    switch (pl.radix[p]) {
+      GPA_MR_CASE(16) GPA_MR_CASE(8) GPA_MR_CASE(4) GPA_MR_CASE(2)
+      GPA_MR_CASE(3) GPA_MR_CASE(5) GPA_MR_CASE(7) GPA_MR_CASE(11) GPA_MR_CASE(13)
+    }
+#undef GPA_MR_CASE
+    __syncthreads();
+  }
+}
+#endif
+
+// host: factorise n and size the thread group; false if n has a prime factor > 13 (those lengths stay on Bluestein)
+inline bool mr_make_plan(int n, MrPlan* pl) {
+  if (n < 2) return false;
+  int m = n, np = 0, radix[64];
+  int twos = 0;
+  while (m % 2 == 0) { m /= 2; ++twos; }
+  const int odd[] = {13, 11, 7, 5, 3};
+  for (int r : odd)
+    while (m % r == 0) { m /= r; if (np < 64) radix[np++] = r; }
+  if (m != 1) return false;
+  while (twos >= 4) { if (np < 64) radix[np++] = 16; twos -= 4; }
+  if (twos == 3) radix[np++] = 8;
+  if (twos == 2) radix[np++] = 4;
+  if (twos == 1) radix[np++] = 2;
+  if (np > MR_MAXPASS) return false;
+  pl->n = n;
+  pl->np = np;
+  int T = 1, s = 1;
+  for (int p = 0; p < np; ++p) {
+    const int R = radix[p], nbmax = MR_REGS / R, nb = n / R;
+    const int need = (nb + nbmax - 1) / nbmax;
+    if (need > T) T = need;
+    pl->radix[p] = R;
+    pl->stride[p] = s;
+    pl->magic[p] = (unsigned)(((1ull << 32) + (uint64_t)s - 1) / (uint64_t)s);
+    if (s == 1) pl->magic[p] = 0;   // (2^32 does not fit in 32 bits; mr_store takes b / 1 = b directly)
+    s *= R;
+  }
+  pl->T = (T + 63) / 64 * 64;
+  return pl->T <= 1024 && (uint64_t)n * (uint64_t)n < (1ull << 32);
+}
+
+}  // namespace gpa

@@ -9,7 +9,7 @@ import pytest
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 
-@pytest.mark.parametrize('name', ['fft_emulator', 'dct_emulator'])
+@pytest.mark.parametrize('name', ['fft_emulator', 'dct_emulator', 'mrfft_emulator'])
 def test_emulator(name, tmp_path):
     gxx = shutil.which('g++')
     if gxx is None:
