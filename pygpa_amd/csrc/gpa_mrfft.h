@@ -148,21 +148,28 @@ GPA_HD void mr_store(cpx<T>* x, cpx<T>* lds, int n, int s, unsigned magic, int t
 }
 
 #if defined(__HIPCC__)
-// the whole transform; the data must be in LDS and a barrier passed before the call, ends with a barrier.
-// Every thread of the workgroup must call (tid >= pl.T: idle lanes of a partially filled workgroup are not allowed --
-// the launch geometry is blockDim = transforms per workgroup * pl.T).
-template <class T>
-__device__ __forceinline__ void mr_run(cpx<T>* lds, const MrPlan& pl, const cpx<T>* __restrict__ W, int tid) {
+// one pass as a real function call: inlined into a switch inside the pass loop, the nine radix bodies share one
+// register allocation problem and hipcc ends up with > 200 VGPRs (or the pass registers in scratch) where each body
+// alone needs 60-90; as callees they keep their own budgets and the kernel pays one s_swappc per pass
+// (CAP = the calling kernel's launch bound: one callee per bound, so that a kernel limited to 256 threads does not
+// inherit the 128-register budget of the 1024-thread variant)
+template <class T, int R, int CAP>
+__device__ __attribute__((noinline)) void mr_pass(cpx<T>* lds, int n, int s, unsigned mg, int tid, int Tn,
+                                                  const cpx<T>* __restrict__ W) {
   cpx<T> x[MR_REGS];
+  mr_load<T, R>(x, lds, n, tid, Tn);
+  __syncthreads();
+  mr_store<T, R>(x, lds, n, s, mg, tid, Tn, W);
+}
+
+// the whole transform; the data must be in LDS and a barrier passed before the call, ends with a barrier.
+// Every thread of the workgroup must call (the launch geometry is blockDim = transforms per workgroup * pl.T).
+template <int CAP, class T>
+__device__ __forceinline__ void mr_run(cpx<T>* lds, const MrPlan& pl, const cpx<T>* __restrict__ W, int tid) {
   for (int p = 0; p < pl.np; ++p) {
     const int s = pl.stride[p];
     const unsigned mg = pl.magic[p];
-#define GPA_MR_CASE(R)                                   \
-  case R:                                                \
-    mr_load<T, R>(x, lds, pl.n, tid, pl.T);              \
-    __syncthreads();                                     \
-    mr_store<T, R>(x, lds, pl.n, s, mg, tid, pl.T, W);   \
-    break;
+#define GPA_MR_CASE(R) case R: mr_pass<T, R, CAP>(lds, pl.n, s, mg, tid, pl.T, W); break;
     switch (pl.radix[p]) {
       GPA_MR_CASE(16) GPA_MR_CASE(8) GPA_MR_CASE(4) GPA_MR_CASE(2)
       GPA_MR_CASE(3) GPA_MR_CASE(5) GPA_MR_CASE(7) GPA_MR_CASE(11) GPA_MR_CASE(13)

@@ -30,6 +30,7 @@
 #include <vector>
 
 #include "gpa_dct.h"
+#include "gpa_mrfft.h"
 #include "gpa_internal.h"
 #include "gpa_unwrap.h"
 
@@ -67,6 +68,11 @@ struct Impl {
   void *bspec0, *bspec1;     // FFT_L(b)/L, spectral layout
   void *gwk0, *gwk1;         // w_k = exp(-i pi k / (2n)), natural order
   void *gha0[2], *gham0[2];  // 1 - cos term of axis-0 bins k and n0-k, natural order; [compat]
+  // generic sizes whose axis lengths factor into 2, 3, 5, 7, 11, 13 (and rows of a multiple of 4 pixels): the fused
+  // 4-kernel iteration on the mixed-radix FFT (gpa_unwrap_mr.h) instead of the Bluestein kernels
+  bool mr_ok;
+  MrPlan mr0, mr1;
+  void *mrW0, *mrW1;         // w_n^i = exp(-2 pi i / n * i) per axis
 };
 
 template <class T> struct C2 { static constexpr T pi = T(3.14159265358979323846), two_pi = T(6.28318530717958647692); };
@@ -1414,6 +1420,17 @@ __global__ __launch_bounds__(256) void per_combine_kernel(const cpx<T>* __restri
 
 #define GPA_FOR_LG(X) X(6) X(7) X(8) X(9) X(10) X(11) X(12) X(13) X(14)
 
+// mixed-radix fused kernels (gpa_unwrap_mr.h, included below)
+template <class T>
+hipError_t run_mr_rowdct_fused(const Impl* w, const void* q, int ring, const double* part_pq, int npq,
+                               double* part_norm, int it, int* nnorm, hipStream_t s);
+template <class T>
+hipError_t run_mr_rowidct_p(const Impl* w, const void* pin, void* pout, const double* part_rho, int nrho, int it,
+                            hipStream_t s);
+template <class T>
+hipError_t run_mr_colsolve(const Impl* w, int compat, hipStream_t s, const double* part_norm, int nnorm, int it,
+                           double eps, double* part_rho, int* nrho, const void* zin);
+
 template <class T, int LG>
 hipError_t run_rowdct(const Impl* w, hipStream_t s) {
   using G = RowGeom<T, LG>;
@@ -1511,6 +1528,9 @@ hipError_t run_rowidct_p(const Impl* w, const void* pin, void* pout, const doubl
 }
 hipError_t dispatch_rowidct_p(const Impl* w, const void* pin, void* pout, const double* part_rho, int nrho, int it,
                               hipStream_t s) {
+  if (w->generic)
+    return w->dtype == 0 ? run_mr_rowidct_p<float>(w, pin, pout, part_rho, nrho, it, s)
+                         : run_mr_rowidct_p<double>(w, pin, pout, part_rho, nrho, it, s);
 #define CASE(LG) case LG: return w->dtype == 0 ? run_rowidct_p<float, LG>(w, pin, pout, part_rho, nrho, it, s) \
                                                : run_rowidct_p<double, LG>(w, pin, pout, part_rho, nrho, it, s);
   switch (w->lg1) { GPA_FOR_LG(CASE) }
@@ -1559,6 +1579,9 @@ hipError_t dispatch_colsolve_tri(const Impl* w, int compat, hipStream_t s, const
 hipError_t dispatch_colsolve(const Impl* w, int compat, hipStream_t s, const double* part_norm = nullptr,
                              int nnorm = 0, int it = 0, double eps = 0.0, double* part_rho = nullptr,
                              int* nrho = nullptr, const void* zin = nullptr) {
+  if (w->generic && part_rho)
+    return w->dtype == 0 ? run_mr_colsolve<float>(w, compat, s, part_norm, nnorm, it, eps, part_rho, nrho, zin)
+                         : run_mr_colsolve<double>(w, compat, s, part_norm, nnorm, it, eps, part_rho, nrho, zin);
   // Square images can solve the columns without a transform (colsolve_tri_kernel).  Measured at 4096^2 on MI355X
   // (profiles/r02_colsolve_tri.txt): f64 1.54 ms per step against 2.0 for the DCT kernel (whose f64 transforms
   // spill), f32 82 us per launch against 68 -- the f32 DCT kernel is the faster one.  So: f64 by default,
@@ -1575,6 +1598,9 @@ hipError_t dispatch_colsolve(const Impl* w, int compat, hipStream_t s, const dou
 }
 hipError_t dispatch_rowdct_fused(const Impl* w, const void* q, int ring, const double* part_pq, int npq,
                                  double* part_norm, int it, int* nnorm, hipStream_t s) {
+  if (w->generic)
+    return w->dtype == 0 ? run_mr_rowdct_fused<float>(w, q, ring, part_pq, npq, part_norm, it, nnorm, s)
+                         : run_mr_rowdct_fused<double>(w, q, ring, part_pq, npq, part_norm, it, nnorm, s);
 #define CASE(LG) case LG: return w->dtype == 0 ? run_rowdct_fused<float, LG>(w, q, ring, part_pq, npq, part_norm, it, nnorm, s) \
                                                : run_rowdct_fused<double, LG>(w, q, ring, part_pq, npq, part_norm, it, nnorm, s);
   switch (w->lg1) { GPA_FOR_LG(CASE) }
@@ -1653,6 +1679,12 @@ hipError_t dispatch_g_colsolve(const Impl* w, int compat, hipStream_t s) {
 #undef CASE
   return hipErrorInvalidValue;
 }
+
+}  // namespace
+}  // namespace gpa
+#include "gpa_unwrap_mr.h"
+namespace gpa {
+namespace {
 
 // host-side radix-2 FFT in double, for the Bluestein kernel spectra
 void host_fft(std::vector<double>& re, std::vector<double>& im) {
@@ -1762,6 +1794,17 @@ hipError_t unwrap_workspace_create(int dtype, int n0, int n1, hipStream_t s, Unw
       if ((e = upload(dtype, ax == 0 ? &w->bspec0 : &w->bspec1, bs, &bytes, s)) != hipSuccess) return e;
       if ((e = upload(dtype, ax == 0 ? &w->gwk0 : &w->gwk1, wkv, &bytes, s)) != hipSuccess) return e;
     }
+    // fused mixed-radix path: both lengths smooth, rows of whole 4-pixel vectors (pq_kernel), one transform in LDS
+    w->mr_ok = !getenv("GPA_NO_MR") && (n1 % 4) == 0 && mr_make_plan(n0, &w->mr0) && mr_make_plan(n1, &w->mr1) &&
+               (size_t)mr_lds_elems(n0 > n1 ? n0 : n1) * 2 * w->rsz <= 159 * 1024;
+    if (w->mr_ok) {
+      for (int ax = 0; ax < 2; ++ax) {
+        const int n = ax == 0 ? n0 : n1;
+        std::vector<double> t((size_t)2 * n);
+        for (int k = 0; k < n; ++k) { t[2 * k] = cos(-2.0 * M_PI * k / n); t[2 * k + 1] = sin(-2.0 * M_PI * k / n); }
+        if ((e = upload(dtype, ax == 0 ? &w->mrW0 : &w->mrW1, t, &bytes, s)) != hipSuccess) return e;
+      }
+    }
     for (int compat = 0; compat < 2; ++compat) {
       const double A0 = compat ? n1 : n0, A1 = compat ? n0 : n1;
       std::vector<double> a((size_t)n0), am((size_t)n0), b((size_t)n1);
@@ -1859,7 +1902,8 @@ void unwrap_workspace_destroy(UnwrapWorkspace* ws) {
   if (!w) return;
   void* bufs[] = {w->r, w->p, w->p2, w->q, w->z, w->tw0, w->tw1, w->wk1, w->wk0s, w->ha0[0], w->ha0[1], w->ham0[0],
                   w->ham0[1], w->hb1[0], w->hb1[1], w->scal, w->flags, w->part, w->btw0, w->btw1, w->chirp0, w->chirp1,
-                  w->bspec0, w->bspec1, w->gwk0, w->gwk1, w->gha0[0], w->gha0[1], w->gham0[0], w->gham0[1], w->tritab};
+                  w->bspec0, w->bspec1, w->gwk0, w->gwk1, w->gha0[0], w->gha0[1], w->gham0[0], w->gham0[1], w->tritab,
+                  w->mrW0, w->mrW1};
   for (void* b : bufs)
     if (b) hipFree(b);
   for (int j = 2; j < w->nring; ++j)
@@ -1908,12 +1952,12 @@ static hipError_t run_pcg(Impl* w, const void* a, const void* b, const void* wei
     // prepared: r0 and its w->prepared_parts partial norms were written by the producer of the gradients
     // (reconstruct_setup_kernel).  phi = 0: the fused path's first phi_flush_kernel starts from 0, the
     // other paths update phi in place and need it cleared
-    const bool fused_path = !w->generic && (n1 % 4) == 0;
+    const bool fused_path = (!w->generic || w->mr_ok) && (n1 % 4) == 0;
     if (!fused_path && (e = hipMemsetAsync(phi, 0, npx * w->rsz, s)) != hipSuccess) return e;
     GPA_PROF("scalar_kernels", s);
     scal_init_kernel<<<1, 256, 0, s>>>(w->part, w->prepared_parts, w->scal, w->flags);
   }
-  const bool vec4 = !w->generic && (n1 % 4) == 0;   // pq_kernel needs 16-byte aligned rows
+  const bool vec4 = (!w->generic || w->mr_ok) && (n1 % 4) == 0;   // pq_kernel needs 16-byte aligned rows
   if (vec4) {
     // fused power-of-two path: 4 kernels per iteration, no scalar kernels.  The phi / r update
     // of iteration it-1 rides in the row-DCT kernel of iteration it; the stopping test is

@@ -1,0 +1,289 @@
+// Fused PCG kernels for image sizes that are not powers of two, on the mixed-radix LDS-resident FFT
+// (gpa_mrfft.h).  Included by gpa_unwrap.hip only (uses its Impl, reductions and scalar conventions).
+//
+// Same iteration as the power-of-two fused path (rowdct_fused -> colsolve -> rowidct_p -> pq, the residual kept
+// as its row spectrum, rho and ||r|| by Parseval), same scalars and flags, so run_pcg() drives both with one
+// loop.  What differs is where a transform lives: here the packed pair of rows / columns sits in LDS in the
+// Makhoul order (slot m holds sample makhoul_src(m)), the FFT passes run in place, and the DCT pre / post
+// processing reads bins k and n - k from LDS.  Global accesses are lane-consecutive along the rows; the column
+// kernel takes NF adjacent column pairs per workgroup (NF * 2 * sizeof(T) contiguous bytes per row).
+//
+// Replaces, per PCG iteration, the Bluestein kernels g_rowdct / g_colsolve / g_rowidct (4 FFTs of length
+// >= 2n - 1 per DCT pair instead of one of length n) and the separate pupdate / applyq / update / scal_* kernels:
+// 4 launches per iteration instead of 9.  (phase_unwrap.py:84-115 preconditioner, :326-349 iteration.)
+#pragma once
+#include "gpa_mrfft.h"
+
+namespace gpa {
+namespace {
+
+// LDS slot of sample c in the Makhoul order (inverse of makhoul_src)
+__device__ __forceinline__ int mr_slot_of(int c, int n) { return (c & 1) ? n - 1 - (c >> 1) : (c >> 1); }
+
+// rows: R = DCT-II_rows(r) (it == 0, in place) or R -= alpha DCT-II_rows(q) with the partial ||r||^2 (it > 0)
+template <class T, int MAXT>
+__global__ __launch_bounds__(MAXT) void mr_rowdct_fused_kernel(
+    T* __restrict__ r, const T* __restrict__ q, int n0, const MrPlan pl, int rs, const cpx<T>* __restrict__ W,
+    const cpx<T>* __restrict__ wk, const int* flags, const double* part_pq, int npq, double* part_norm, double* scal,
+    int it, int ring) {
+  if (flags[1]) return;
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  __shared__ double sh[32];
+  const int n = pl.n, Tn = pl.T;
+  const int tid = threadIdx.x % Tn, f = threadIdx.x / Tn, nf = blockDim.x / Tn;
+  cpx<T>* lds = reinterpret_cast<cpx<T>*>(smem) + (size_t)f * rs;
+  const int pr = blockIdx.x * nf + f;
+  const int xa = 2 * pr, xb = xa + 1;
+  const bool va = xa < n0, vb = xb < n0;
+  const size_t oa = (size_t)(va ? xa : 0) * n, ob = (size_t)(vb ? xb : 0) * n;
+  T alpha = T(0);
+  if (it > 0) {
+    const double pq = reduce_partials(part_pq, npq, sh);
+    const double alpha_d = scal[8 + ((it - 1) & 1)] / pq;   // phase_unwrap.py:343
+    alpha = (T)alpha_d;
+    if (blockIdx.x == 0 && threadIdx.x == 0) scal[SC_ALPHA + (it - 1) % ring] = alpha_d;
+  }
+  const T* src = it > 0 ? q : r;
+  for (int c = tid; c < n; c += Tn)
+    lds[mr_pad(mr_slot_of(c, n))] = {va ? src[oa + c] : T(0), vb ? src[ob + c] : T(0)};
+  __syncthreads();   // (it == 0, in place: both rows are in LDS before any bin is written)
+  mr_run<MAXT>(lds, pl, W, tid);
+  double sq = 0;
+  for (int k = tid; k < n; k += Tn) {
+    const cpx<T> zk = lds[mr_pad(k)], zm = lds[mr_pad(k == 0 ? 0 : n - k)];
+    const cpx<T> w = wk[k];
+    const cpx<T> X = cmul(w, zk) + cmulc(zm, w);
+    T ra = X.x, rb = X.y;
+    if (it > 0) {
+      ra = (va ? r[oa + k] : T(0)) - alpha * ra;
+      rb = (vb ? r[ob + k] : T(0)) - alpha * rb;
+      // sum_n r^2 = (1 / 2N) sum_k c_k R_k^2, c_0 = 1/2 (SciPy's unnormalised DCT-II)
+      const double t = (double)ra * (double)ra + (double)rb * (double)rb;
+      sq += k == 0 ? 0.5 * t : t;
+    }
+    if (va) r[oa + k] = ra;
+    if (vb) r[ob + k] = rb;
+  }
+  if (it > 0) {
+    const double tot = block_sum(sq, sh);
+    if (threadIdx.x == 0) part_norm[blockIdx.x] = tot / (2.0 * n);
+  }
+}
+
+// rows: z = DCT-III_rows(Z), p = z + beta p_prev -> the ring slot of this iteration
+template <class T, int MAXT>
+__global__ __launch_bounds__(MAXT) void mr_rowidct_p_kernel(
+    const T* __restrict__ Z, const T* __restrict__ pin, T* __restrict__ pout, int n0, const MrPlan pl, int rs,
+    const cpx<T>* __restrict__ W, const cpx<T>* __restrict__ wk, const int* flags, const double* part_rho, int nrho,
+    double* scal, int it) {
+  if (flags[1]) return;
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  __shared__ double sh[32];
+  const int n = pl.n, Tn = pl.T;
+  const int tid = threadIdx.x % Tn, f = threadIdx.x / Tn, nf = blockDim.x / Tn;
+  cpx<T>* lds = reinterpret_cast<cpx<T>*>(smem) + (size_t)f * rs;
+  const int pr = blockIdx.x * nf + f;
+  const int xa = 2 * pr, xb = xa + 1;
+  const bool va = xa < n0, vb = xb < n0;
+  const size_t oa = (size_t)(va ? xa : 0) * n, ob = (size_t)(vb ? xb : 0) * n;
+  for (int k = tid; k < n; k += Tn) {
+    const cpx<T> X = {va ? Z[oa + k] : T(0), vb ? Z[ob + k] : T(0)};
+    const cpx<T> Xm = k == 0 ? cpx<T>{T(0), T(0)} : cpx<T>{va ? Z[oa + n - k] : T(0), vb ? Z[ob + n - k] : T(0)};
+    const cpx<T> d = {X.x + Xm.y, X.y - Xm.x};     // X_k - i X_(n-k)
+    const cpx<T> v = cmulc(d, wk[k]);              // V_k = conj(w_k) (.) / 2
+    lds[mr_pad(k)] = {T(0.5) * v.x, T(-0.5) * v.y};   // conj(V_k): IDFT = conj(DFT(conj .))
+  }
+  const double rho = reduce_partials(part_rho, nrho, sh);   // (contains the barrier the transform needs)
+  const bool first = it == 0;                               // first iteration: p = z (pin is uninitialised)
+  const T beta = first ? T(0) : (T)(rho / scal[8 + ((it - 1) & 1)]);
+  if (blockIdx.x == 0 && threadIdx.x == 0) scal[8 + (it & 1)] = rho;
+  __syncthreads();
+  mr_run<MAXT>(lds, pl, W, tid);
+  const T inv_n = T(1) / T(n);
+  for (int c = tid; c < n; c += Tn) {
+    const cpx<T> v = lds[mr_pad(mr_slot_of(c, n))];
+    T pa = v.x * inv_n, pb = -v.y * inv_n;
+    if (!first) {
+      if (va) pa += beta * pin[oa + c];
+      if (vb) pb += beta * pin[ob + c];
+    }
+    if (va) pout[oa + c] = pa;
+    if (vb) pout[ob + c] = pb;
+  }
+}
+
+// columns: Z = DCT-III_cols( DCT-II_cols(R) / eigenvalues ), the stopping test on the update the row kernel has
+// just applied, partial rho = <r, z> from the packed spectra (see WgDCT::solve_combine for the Parseval argument)
+template <class T, int MAXT>
+__global__ __launch_bounds__(MAXT) void mr_colsolve_kernel(
+    const T* __restrict__ Zin, T* __restrict__ Z, int n1, const MrPlan pl, int rs, const cpx<T>* __restrict__ W,
+    const cpx<T>* __restrict__ wk, const T* __restrict__ ha, const T* __restrict__ ham, const T* __restrict__ hb,
+    int* flags, const double* part_norm, int nnorm, int it, double eps, double* scal, double* part_rho) {
+  if (flags[1]) return;
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  __shared__ double sh[32];
+  const int n = pl.n, Tn = pl.T, nf = blockDim.x / Tn;
+  // column pair fastest in the thread index: neighbouring lanes read neighbouring columns
+  const int f = threadIdx.x % nf, tid = threadIdx.x / nf;
+  cpx<T>* lds = reinterpret_cast<cpx<T>*>(smem) + (size_t)f * rs;
+  const int ya = (blockIdx.x * nf + f) * 2, yb = ya + 1;
+  const bool va = ya < n1, vb = yb < n1;
+  struct alignas(2 * sizeof(T)) Pair { T a, b; };
+  const bool vec = vb && (n1 & 1) == 0;   // the pair is one aligned 2-element access
+  for (int row = tid; row < n; row += Tn) {
+    const size_t o = (size_t)row * n1;
+    cpx<T> v = {T(0), T(0)};
+    if (vec) {
+      const Pair pz = *reinterpret_cast<const Pair*>(Zin + o + ya);
+      v = {pz.a, pz.b};
+    } else {
+      if (va) v.x = Zin[o + ya];
+      if (vb) v.y = Zin[o + yb];
+    }
+    lds[mr_pad(mr_slot_of(row, n))] = v;
+  }
+  if (it > 0) {
+    // the reference's stopping test (phase_unwrap.py:348), evaluated identically by every workgroup
+    const double tot = reduce_partials(part_norm, nnorm, sh);
+    const double best = scal[10 + ((it - 1) & 1)];
+    const bool stop = sqrt(tot) < eps * sqrt(scal[5]) || tot == 0.0 || !(tot == tot) || tot > 1e4 * best;
+    if (blockIdx.x == 0 && threadIdx.x == 0) {
+      flags[0] = it;
+      scal[6] = tot;
+      scal[10 + (it & 1)] = tot < best ? tot : best;
+      if (stop) flags[1] = 1;
+    }
+    if (stop) return;
+  }
+  __syncthreads();
+  mr_run<MAXT>(lds, pl, W, tid);
+  // bins k and n - k of the packed spectrum into registers, then (after a barrier) the solve in place
+  cpx<T> zk[MR_REGS], zm[MR_REGS];
+#pragma unroll
+  for (int i = 0; i < MR_REGS; ++i) {
+    const int k = tid + Tn * i;
+    if (k < n) {
+      zk[i] = lds[mr_pad(k)];
+      zm[i] = lds[mr_pad(k == 0 ? 0 : n - k)];
+    }
+  }
+  __syncthreads();
+  const T inv_n = T(1) / T(n), cn = T(-0.5) * inv_n;   // 1 / (2 (cos + cos - 2)) / n = cn / (ha + hb)
+  const T hba = va ? hb[ya] : T(1), hbb = vb ? hb[yb] : T(1);
+  const bool first_a = ya == 0;
+  double packed = 0.0, corr = 0.0;
+#pragma unroll
+  for (int i = 0; i < MR_REGS; ++i) {
+    const int k = tid + Tn * i;
+    if (k < n) {
+      const cpx<T> w = wk[k];
+      const T h = ha[k], hm = ham[k];
+      const cpx<T> qa = {T(0.5) * (zk[i].x + zm[i].x), T(0.5) * (zk[i].y - zm[i].y)};
+      const cpx<T> qb = {T(0.5) * (zk[i].y + zm[i].y), T(-0.5) * (zk[i].x - zm[i].x)};
+      const cpx<T> ua = cmul(w, qa), ub = cmul(w, qb);
+      T sa = cn * fast_recip(h + hba), sb = cn * fast_recip(h + hbb);
+      T sam = cn * fast_recip(hm + hba), sbm = cn * fast_recip(hm + hbb);
+      if (k == 0) {
+        sam = T(0);
+        sbm = T(0);
+        if (first_a) sa = inv_n;   // the DC bin is divided by 1 (phase_unwrap.py:110-114)
+      }
+      const cpx<T> pa = cmulc(cpx<T>{sa * ua.x, sam * ua.y}, w);
+      const cpx<T> pb = cmulc(cpx<T>{sb * ub.x, sbm * ub.y}, w);
+      const cpx<T> xn = {pa.x - pb.y, pa.y + pb.x};
+      lds[mr_pad(k)] = {xn.x, -xn.y};   // conjugated for the conj-DFT-conj inverse
+      packed += (double)zk[i].x * (double)xn.x + (double)zk[i].y * (double)xn.y;
+      if (first_a) corr += (k == 0 ? 0.5 : 1.0) * (double)ua.x * (double)ua.x * (double)sa;
+    }
+  }
+  __syncthreads();
+  mr_run<MAXT>(lds, pl, W, tid);
+  for (int row = tid; row < n; row += Tn) {
+    const size_t o = (size_t)row * n1;
+    const cpx<T> v = lds[mr_pad(mr_slot_of(row, n))];
+    if (vec) {
+      *reinterpret_cast<Pair*>(Z + o + ya) = Pair{v.x, -v.y};
+    } else {
+      if (va) Z[o + ya] = v.x;
+      if (vb) Z[o + yb] = -v.y;
+    }
+  }
+  const double tot = block_sum(va ? 0.5 * (packed - corr) : 0.0, sh);
+  if (threadIdx.x == 0) part_rho[blockIdx.x] = tot / (double)n1;
+}
+
+// dynamic LDS a kernel may ask for (the kernels also hold 256 bytes of static LDS for their reductions)
+constexpr int MR_LDS_MAX = 160 * 1024 - 1024;
+
+// transforms per workgroup: as many as `cap` threads allow, but not so many that the grid falls under 256 workgroups
+inline int mr_pick_nf(int pairs, int T, int cap, size_t lds_per_transform) {
+  int nf = cap / T;
+  if (nf > 4) nf = 4;
+  if (nf < 1) nf = 1;
+  while (nf > 1 && ((pairs + nf - 1) / nf < 256 || nf * lds_per_transform > (size_t)MR_LDS_MAX)) nf /= 2;
+  return nf;
+}
+
+#define GPA_MR_LAUNCH(KERNEL, threads, ...)                                                                    \
+  do {                                                                                                         \
+    if ((threads) <= 256) { GPA_MR_LAUNCH1(KERNEL, 256, __VA_ARGS__); }                                        \
+    else if ((threads) <= 512) { GPA_MR_LAUNCH1(KERNEL, 512, __VA_ARGS__); }                                   \
+    else { GPA_MR_LAUNCH1(KERNEL, 1024, __VA_ARGS__); }                                                        \
+  } while (0)
+#define GPA_MR_LAUNCH1(KERNEL, MAXT, ...)                                                                      \
+  do {                                                                                                         \
+    auto kern = KERNEL<T, MAXT>;                                                                               \
+    static unsigned lds_set = 0;                                                                               \
+    hipError_t e = set_dynamic_lds_once(reinterpret_cast<const void*>(kern), MR_LDS_MAX, lds_set);               \
+    if (e != hipSuccess) return e;                                                                             \
+    kern<<<grid, threads, lds, s>>>(__VA_ARGS__);                                                              \
+  } while (0)
+
+template <class T>
+hipError_t run_mr_rowdct_fused(const Impl* w, const void* q, int ring, const double* part_pq, int npq,
+                               double* part_norm, int it, int* nnorm, hipStream_t s) {
+  const MrPlan& pl = w->mr1;
+  const int rs = mr_lds_elems(pl.n), pairs = (w->n0 + 1) / 2;
+  const int nf = mr_pick_nf(pairs, pl.T, 256, (size_t)rs * sizeof(cpx<T>));
+  const int grid = (pairs + nf - 1) / nf, threads = nf * pl.T;
+  const size_t lds = (size_t)nf * rs * sizeof(cpx<T>);
+  *nnorm = grid;
+  GPA_PROF("rowdct_fused_kernel", s);
+  GPA_MR_LAUNCH(mr_rowdct_fused_kernel, threads, (T*)w->r, (const T*)q, w->n0, pl, rs, (const cpx<T>*)w->mrW1,
+                (const cpx<T>*)w->gwk1, w->flags, part_pq, npq, part_norm, w->scal, it, ring);
+  return hipGetLastError();
+}
+
+template <class T>
+hipError_t run_mr_rowidct_p(const Impl* w, const void* pin, void* pout, const double* part_rho, int nrho, int it,
+                            hipStream_t s) {
+  const MrPlan& pl = w->mr1;
+  const int rs = mr_lds_elems(pl.n), pairs = (w->n0 + 1) / 2;
+  const int nf = mr_pick_nf(pairs, pl.T, 256, (size_t)rs * sizeof(cpx<T>));
+  const int grid = (pairs + nf - 1) / nf, threads = nf * pl.T;
+  const size_t lds = (size_t)nf * rs * sizeof(cpx<T>);
+  GPA_PROF("rowidct_p_kernel", s);
+  GPA_MR_LAUNCH(mr_rowidct_p_kernel, threads, (const T*)w->z, (const T*)pin, (T*)pout, w->n0, pl, rs,
+                (const cpx<T>*)w->mrW1, (const cpx<T>*)w->gwk1, w->flags, part_rho, nrho, w->scal, it);
+  return hipGetLastError();
+}
+
+template <class T>
+hipError_t run_mr_colsolve(const Impl* w, int compat, hipStream_t s, const double* part_norm, int nnorm, int it,
+                           double eps, double* part_rho, int* nrho, const void* zin) {
+  const MrPlan& pl = w->mr0;
+  const int rs = mr_lds_elems(pl.n), pairs = (w->n1 + 1) / 2;
+  // f64: 512 threads at most, so that the 16 + 16 bins a thread holds in the solve fit 256 registers
+  const int nf = mr_pick_nf(pairs, pl.T, sizeof(T) == 4 ? 1024 : 512, (size_t)rs * sizeof(cpx<T>));
+  const int grid = (pairs + nf - 1) / nf, threads = nf * pl.T;
+  const size_t lds = (size_t)nf * rs * sizeof(cpx<T>);
+  if (nrho) *nrho = grid;
+  GPA_PROF("colsolve_kernel", s);
+  GPA_MR_LAUNCH(mr_colsolve_kernel, threads, (const T*)(zin ? zin : w->z), (T*)w->z, w->n1, pl, rs,
+                (const cpx<T>*)w->mrW0, (const cpx<T>*)w->gwk0, (const T*)w->gha0[compat], (const T*)w->gham0[compat],
+                (const T*)w->hb1[compat], w->flags, part_norm, nnorm, it, eps, w->scal, part_rho);
+  return hipGetLastError();
+}
+
+}  // namespace
+}  // namespace gpa

@@ -1044,3 +1044,39 @@ def test_compact_padded_axes(shape, dtype, monkeypatch):
         assert rel(lb, orc.lockin_batch(img0, klist[:2], sigma)) < TOL[dtype]['lock']
     plan.close()
     plan_full.close()
+
+
+def _unwrap_case(shape, seed, weighted=True):
+    rng = np.random.default_rng(seed)
+    n0, n1 = shape
+    x, y = np.meshgrid(np.arange(n0), np.arange(n1), indexing='ij')
+    phi = 0.23 * x - 0.17 * y + 2.5 * np.sin(x / (0.11 * n0 + 3.0)) * np.cos(y / (0.07 * n1 + 5.0))
+    psi = orc.wrap_to_pi(phi + 0.05 * rng.normal(size=shape))
+    weight = 0.3 + rng.random(shape) if weighted else None
+    return psi, weight
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize('shape', [(48, 80), (100, 60), (300, 200), (500, 500), (130, 104), (360, 364), (1000, 1500),
+                                   (66, 88), (512, 384)])
+def test_mixed_radix_fused_unwrap_vs_oracle(shape, monkeypatch):
+    """image sizes that factor into 2, 3, 5, 7, 11, 13 with rows of a multiple of 4 pixels run the fused
+    4-kernel PCG on the mixed-radix FFT: same numbers as the oracle (f64 1e-8, f32 within the PCG tolerance),
+    the same iteration count as the Bluestein path (GPA_NO_MR=1) and as the oracle's loop"""
+    psi, weight = _unwrap_case(shape, 31 + shape[0])
+    for kmax in (7, 40):
+        ref, ref_iters = orc.unwrap(psi, weight=weight, kmax=kmax, return_iters=True)
+        plan = _lib.Plan(shape, 1, np.float64)
+        got, iters = plan.unwrap(psi, weight, kmax=kmax)
+        assert rel(got, ref) < 1e-8, (shape, kmax)
+        assert iters == ref_iters, (shape, kmax, iters, ref_iters)
+        monkeypatch.setenv('GPA_NO_MR', '1')
+        plan_b = _lib.Plan(shape, 1, np.float64)
+        monkeypatch.delenv('GPA_NO_MR')
+        got_b, iters_b = plan_b.unwrap(psi, weight, kmax=kmax)
+        assert iters_b == iters and rel(got, got_b) < 1e-9
+        plan32 = _lib.Plan(shape, 1, np.float32)
+        got32, _ = plan32.unwrap(psi.astype(np.float32), None if weight is None else weight.astype(np.float32), kmax=kmax)
+        assert rel(got32 - got32.mean(), ref - ref.mean()) < 2e-4, (shape, kmax)
+        for p in (plan, plan_b, plan32):
+            p.close()
