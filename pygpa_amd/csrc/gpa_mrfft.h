@@ -13,8 +13,10 @@
 //     twiddles in registers, stores, barrier.  T = threads per transform is chosen by the host so that
 //     ceil(n / (R T)) * R <= 16 for every radix (n = 3000: T = 256).
 //   * radices 16 / 8 / 4 / 2 come from gpa_fft.h's register DFTs, odd primes from one generic butterfly that
-//     pairs a_j with a_(R-j) (half the multiplications of the plain O(R^2) sum).
-//   * twiddles w_n^i from one table of n entries (L1-resident: 24 KB at n = 3000 f32); pp k s < n needs no modulo.
+//     pairs a_j with a_(R-j) (half the multiplications of the plain O(R^2) sum), 6 / 10 / 12 / 14 / 15 from those by
+//     Good-Thomas index maps (no inner twiddles).  The host picks the factorisation with the fewest passes.
+//   * twiddles w_n^i from one table of n entries in global memory (L1 / L2 resident: 24 KB at n = 3000 f32; a copy
+//     in LDS measured no faster and costs occupancy -- tools/ubench/mrfft_bench.hip); pp k s < n needs no modulo.
 //     b / s is a multiply-high by ceil(2^32 / s), exact for b s < 2^32 (n <= 2^14 here).
 //
 // The per-thread steps are GPA_HD: tests/host/mrfft_emulator.cpp runs them thread by thread on the CPU.
@@ -72,12 +74,54 @@ template <> struct MrTrig<13> {
   static GPA_HD double s(int i) { constexpr double t[13] = {0.0, 0.464723172043768545656, 0.82298386589365639458, 0.992708874098053992801, 0.93501624268541482344, 0.663122658240795202377, 0.239315664287557767149, -0.239315664287557767149, -0.663122658240795202377, -0.93501624268541482344, -0.992708874098053992801, -0.82298386589365639458, -0.464723172043768545656}; return t[i]; }
 };
 
-// forward DFT of R values in place, natural order.  Odd R: with P_j = a_j + a_(R-j), M_j = a_j - a_(R-j),
+template <class T, int R> GPA_HD void mr_bfly(cpx<T>* a);
+
+constexpr int mr_inv_mod(int a, int m) {
+  for (int x = 1; x < m; ++x)
+    if ((a * x) % m == 1) return x;
+  return 0;
+}
+
+// R = R1 R2 with coprime factors: Good-Thomas index maps turn the DFT into an R1 x R2 two-dimensional one WITHOUT
+// twiddles between the two stages: input j = (R2 j1 + R1 j2) mod R, output k with k = k1 (mod R1), k = k2 (mod R2).
+// All indices are compile-time constants after unrolling: the maps cost no instructions.
+template <class T, int R1, int R2>
+GPA_HD void mr_bfly_pfa(cpx<T>* a) {
+  constexpr int R = R1 * R2, T1 = mr_inv_mod(R1 % R2, R2), T2 = mr_inv_mod(R2 % R1, R1);
+  cpx<T> y[R2][R1];
+#pragma unroll
+  for (int j2 = 0; j2 < R2; ++j2) {
+#pragma unroll
+    for (int j1 = 0; j1 < R1; ++j1) y[j2][j1] = a[(R2 * j1 + R1 * j2) % R];
+    mr_bfly<T, R1>(y[j2]);
+  }
+#pragma unroll
+  for (int k1 = 0; k1 < R1; ++k1) {
+    cpx<T> z[R2];
+#pragma unroll
+    for (int j2 = 0; j2 < R2; ++j2) z[j2] = y[j2][k1];
+    mr_bfly<T, R2>(z);
+#pragma unroll
+    for (int k2 = 0; k2 < R2; ++k2) a[(R2 * T2 * k1 + R1 * T1 * k2) % R] = z[k2];
+  }
+}
+
+// forward DFT of R values in place, natural order.  Odd prime R: with P_j = a_j + a_(R-j), M_j = a_j - a_(R-j),
 //   X_k, X_(R-k) = a_0 + sum_j cos(2 pi j k / R) P_j  -/+  i sum_j sin(2 pi j k / R) M_j
 template <class T, int R>
 GPA_HD void mr_bfly(cpx<T>* a) {
   if constexpr (R == 2 || R == 4 || R == 8 || R == 16) {
     dft_regs<R, false>(a);
+  } else if constexpr (R == 6) {
+    mr_bfly_pfa<T, 3, 2>(a);
+  } else if constexpr (R == 10) {
+    mr_bfly_pfa<T, 5, 2>(a);
+  } else if constexpr (R == 12) {
+    mr_bfly_pfa<T, 3, 4>(a);
+  } else if constexpr (R == 14) {
+    mr_bfly_pfa<T, 7, 2>(a);
+  } else if constexpr (R == 15) {
+    mr_bfly_pfa<T, 3, 5>(a);
   } else {
     constexpr int H = (R - 1) / 2;
     cpx<T> P[H], M[H];
@@ -123,10 +167,11 @@ GPA_HD void mr_load(cpx<T>* x, const cpx<T>* lds, int n, int tid, int Tn) {
   }
 }
 
-// pass, second half (after a barrier): butterflies, twiddles, autosort store.  W: w_n^i = exp(-2 pi i / n * i), i < n
+// pass, second half (after a barrier): butterflies, twiddles, autosort store.  W: w_n^i = exp(-2 pi i / n * i), i < n,
+// (entry i at mr_pad(i): the table may equally be a padded LDS copy)
 template <class T, int R>
 GPA_HD void mr_store(cpx<T>* x, cpx<T>* lds, int n, int s, unsigned magic, int tid, int Tn,
-                     const cpx<T>* __restrict__ W) {
+                     const cpx<T>* W) {
   constexpr int NB = MR_REGS / R;
   const int nb = n / R;
   const bool last = s * R == n;   // pp == 0 throughout: no twiddles
@@ -140,7 +185,7 @@ GPA_HD void mr_store(cpx<T>* x, cpx<T>* lds, int n, int s, unsigned magic, int t
 #pragma unroll
       for (int k = 0; k < R; ++k) {
         cpx<T> v = x[u * R + k];
-        if (k > 0 && !last) v = cmul(v, W[ws * k]);
+        if (k > 0 && !last) v = cmul(v, W[mr_pad(ws * k)]);
         lds[mr_pad(base + s * k)] = v;
       }
     }
@@ -155,7 +200,7 @@ GPA_HD void mr_store(cpx<T>* x, cpx<T>* lds, int n, int s, unsigned magic, int t
 // inherit the 128-register budget of the 1024-thread variant)
 template <class T, int R, int CAP>
 __device__ __attribute__((noinline)) void mr_pass(cpx<T>* lds, int n, int s, unsigned mg, int tid, int Tn,
-                                                  const cpx<T>* __restrict__ W) {
+                                                  const cpx<T>* W) {
   cpx<T> x[MR_REGS];
   mr_load<T, R>(x, lds, n, tid, Tn);
   __syncthreads();
@@ -165,14 +210,14 @@ __device__ __attribute__((noinline)) void mr_pass(cpx<T>* lds, int n, int s, uns
 // the whole transform; the data must be in LDS and a barrier passed before the call, ends with a barrier.
 // Every thread of the workgroup must call (the launch geometry is blockDim = transforms per workgroup * pl.T).
 template <int CAP, class T>
-__device__ __forceinline__ void mr_run(cpx<T>* lds, const MrPlan& pl, const cpx<T>* __restrict__ W, int tid) {
+__device__ __forceinline__ void mr_run(cpx<T>* lds, const MrPlan& pl, const cpx<T>* W, int tid) {
   for (int p = 0; p < pl.np; ++p) {
     const int s = pl.stride[p];
     const unsigned mg = pl.magic[p];
 #define GPA_MR_CASE(R) case R: mr_pass<T, R, CAP>(lds, pl.n, s, mg, tid, pl.T, W); break;
     switch (pl.radix[p]) {
-      GPA_MR_CASE(16) GPA_MR_CASE(8) GPA_MR_CASE(4) GPA_MR_CASE(2)
-      GPA_MR_CASE(3) GPA_MR_CASE(5) GPA_MR_CASE(7) GPA_MR_CASE(11) GPA_MR_CASE(13)
+      GPA_MR_CASE(16) GPA_MR_CASE(8) GPA_MR_CASE(4) GPA_MR_CASE(2) GPA_MR_CASE(3) GPA_MR_CASE(5) GPA_MR_CASE(7)
+      GPA_MR_CASE(11) GPA_MR_CASE(13) GPA_MR_CASE(6) GPA_MR_CASE(10) GPA_MR_CASE(12) GPA_MR_CASE(14) GPA_MR_CASE(15)
     }
 #undef GPA_MR_CASE
     __syncthreads();
@@ -180,35 +225,67 @@ __device__ __forceinline__ void mr_run(cpx<T>* lds, const MrPlan& pl, const cpx<
 }
 #endif
 
+// host: fewest passes with radices <= 16 (composite ones included: 3000 = 15 10 10 2 instead of 5 5 5 3 8; every pass
+// costs one trip of the whole transform through LDS whatever its radix)
+inline int mr_min_passes(int n, int* out) {
+  static const int allowed[] = {16, 15, 14, 13, 12, 11, 10, 8, 7, 6, 5, 4, 3, 2};
+  if (n == 1) return 0;
+  int best = 1 << 20, best_min = 0, pick[64], sub[64];
+  for (int r : allowed) {
+    if (n % r) continue;
+    const int c = mr_min_passes(n / r, sub);
+    if (c < 0 || c + 1 > 60) continue;
+    int mn = r;
+    for (int i = 0; i < c; ++i) mn = sub[i] < mn ? sub[i] : mn;
+    // among equally short factorisations the most balanced one (largest smallest radix): the pass of the smallest
+    // radix has the most butterflies and sets the thread count
+    if (c + 1 > best || (c + 1 == best && mn <= best_min)) continue;
+    best = c + 1;
+    best_min = mn;
+    pick[0] = r;
+    for (int i = 0; i < c; ++i) pick[i + 1] = sub[i];
+  }
+  if (best == 1 << 20) return -1;
+  for (int i = 0; i < best; ++i) out[i] = pick[i];
+  return best;
+}
+
 // host: factorise n and size the thread group; false if n has a prime factor > 13 (those lengths stay on Bluestein)
 inline bool mr_make_plan(int n, MrPlan* pl) {
   if (n < 2) return false;
-  int m = n, np = 0, radix[64];
-  int twos = 0;
-  while (m % 2 == 0) { m /= 2; ++twos; }
-  const int odd[] = {13, 11, 7, 5, 3};
-  for (int r : odd)
-    while (m % r == 0) { m /= r; if (np < 64) radix[np++] = r; }
-  if (m != 1) return false;
-  while (twos >= 4) { if (np < 64) radix[np++] = 16; twos -= 4; }
-  if (twos == 3) radix[np++] = 8;
-  if (twos == 2) radix[np++] = 4;
-  if (twos == 1) radix[np++] = 2;
-  if (np > MR_MAXPASS) return false;
+  {
+    int m = n;
+    for (int r : {2, 3, 5, 7, 11, 13})
+      while (m % r == 0) m /= r;
+    if (m != 1) return false;
+  }
+  int radix[64];
+  const int np = mr_min_passes(n, radix);
+  if (np < 1 || np > MR_MAXPASS) return false;
+  // odd radices first: the first passes store with a stride of R elements, which is free of bank conflicts for odd R
+  for (int i = 0; i < np; ++i)
+    for (int j = i + 1; j < np; ++j) {
+      const bool oi = radix[i] & 1, oj = radix[j] & 1;
+      if ((!oi && oj) || (oi == oj && radix[j] > radix[i])) { const int t = radix[i]; radix[i] = radix[j]; radix[j] = t; }
+    }
   pl->n = n;
   pl->np = np;
-  int T = 1, s = 1;
+  // threads per transform: one butterfly per thread and pass where 256 threads suffice (short transforms are
+  // latency-bound: fewer rounds per pass), otherwise as few as the 16 registers of a thread allow
+  int need = 1, want = 1, s = 1;
   for (int p = 0; p < np; ++p) {
     const int R = radix[p], nbmax = MR_REGS / R, nb = n / R;
-    const int need = (nb + nbmax - 1) / nbmax;
-    if (need > T) T = need;
+    if ((nb + nbmax - 1) / nbmax > need) need = (nb + nbmax - 1) / nbmax;
+    if (nb > want) want = nb;
     pl->radix[p] = R;
     pl->stride[p] = s;
-    pl->magic[p] = (unsigned)(((1ull << 32) + (uint64_t)s - 1) / (uint64_t)s);
-    if (s == 1) pl->magic[p] = 0;   // (2^32 does not fit in 32 bits; mr_store takes b / 1 = b directly)
+    pl->magic[p] = s == 1 ? 0u : (unsigned)(((1ull << 32) + (uint64_t)s - 1) / (uint64_t)s);   // (s == 1: b / 1 = b)
     s *= R;
   }
-  pl->T = (T + 63) / 64 * 64;
+  need = (need + 63) / 64 * 64;
+  want = (want + 63) / 64 * 64;
+  pl->T = want <= 256 ? want : need;
+  if (pl->T < need) pl->T = need;
   return pl->T <= 1024 && (uint64_t)n * (uint64_t)n < (1ull << 32);
 }
 

@@ -1800,8 +1800,11 @@ hipError_t unwrap_workspace_create(int dtype, int n0, int n1, hipStream_t s, Unw
     if (w->mr_ok) {
       for (int ax = 0; ax < 2; ++ax) {
         const int n = ax == 0 ? n0 : n1;
-        std::vector<double> t((size_t)2 * n);
-        for (int k = 0; k < n; ++k) { t[2 * k] = cos(-2.0 * M_PI * k / n); t[2 * k + 1] = sin(-2.0 * M_PI * k / n); }
+        std::vector<double> t((size_t)2 * mr_lds_elems(n), 0.0);   // entry k at mr_pad(k), see mr_store()
+        for (int k = 0; k < n; ++k) {
+          t[2 * (size_t)mr_pad(k)] = cos(-2.0 * M_PI * k / n);
+          t[2 * (size_t)mr_pad(k) + 1] = sin(-2.0 * M_PI * k / n);
+        }
         if ((e = upload(dtype, ax == 0 ? &w->mrW0 : &w->mrW1, t, &bytes, s)) != hipSuccess) return e;
       }
     }

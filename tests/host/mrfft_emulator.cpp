@@ -52,13 +52,13 @@ double test_one(int n, bool expect_plan) {
     for (int m = 0; m < n; ++m) s += in[m] * w[(long long)m * k % n];
     ref[k] = s;
   }
-  std::vector<cpx<T>> W(n), lds(mr_lds_elems(n)), regs((size_t)MR_REGS * pl.T);
-  for (int t = 0; t < n; ++t) W[t] = {(T)w[t].real(), (T)w[t].imag()};
+  std::vector<cpx<T>> W(mr_lds_elems(n)), lds(mr_lds_elems(n)), regs((size_t)MR_REGS * pl.T);
+  for (int t = 0; t < n; ++t) W[mr_pad(t)] = {(T)w[t].real(), (T)w[t].imag()};   // padded like the LDS copy
   for (int m = 0; m < n; ++m) lds[mr_pad(m)] = {(T)in[m].real(), (T)in[m].imag()};
   for (int p = 0; p < pl.np; ++p) {
     switch (pl.radix[p]) {
 #define CASE(R) case R: half_pass_load<T, R>(regs, lds, pl); half_pass_store<T, R>(regs, lds, pl, p, W); break;
-      CASE(2) CASE(3) CASE(4) CASE(5) CASE(7) CASE(8) CASE(11) CASE(13) CASE(16)
+      CASE(2) CASE(3) CASE(4) CASE(5) CASE(6) CASE(7) CASE(8) CASE(10) CASE(11) CASE(12) CASE(13) CASE(14) CASE(15) CASE(16)
 #undef CASE
       default: return 1.0;
     }
@@ -73,12 +73,16 @@ double test_one(int n, bool expect_plan) {
 }
 
 int main() {
-  const int sizes[] = {2, 3, 4, 5, 6, 8, 10, 12, 15, 16, 30, 32, 48, 60, 63, 64, 65, 80, 96, 100, 130, 200, 240, 256, 500,
+  const int sizes[] = {2, 3, 4, 5, 6, 7, 8, 10, 12, 14, 15, 16, 28, 30, 32, 48, 60, 63, 64, 65, 80, 84, 96, 100, 130, 200, 240, 256, 500,
                        512, 1000, 1040, 1500, 2000, 2112, 2160, 3000, 3003, 4096};
   int bad = 0;
   for (int n : sizes) {
     const double e32 = test_one<float>(n, true), e64 = test_one<double>(n, true);
-    printf("n = %5d  rel err f32 %.2e  f64 %.2e\n", n, e32, e64);
+    MrPlan pl;
+    mr_make_plan(n, &pl);
+    printf("n = %5d  T %4d  passes", n, pl.T);
+    for (int p = 0; p < pl.np; ++p) printf(" %d", pl.radix[p]);
+    printf("  rel err f32 %.2e  f64 %.2e\n", e32, e64);
     if (!(e32 < 3e-6) || !(e64 < 2e-14)) ++bad;   // (the naive reference sum itself carries ~sqrt(n) eps)
   }
   // lengths with a prime factor > 13 have no plan (they stay on Bluestein)
