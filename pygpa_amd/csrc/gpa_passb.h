@@ -29,10 +29,13 @@ template <class T> __device__ __forceinline__ cpx<T> hmul(cpx<T> a, cpx<T> h) { 
 // pass B: y-axis filter on rows, best-of-K select
 // ---------------------------------------------------------------------------
 template <class T, int LG, bool PADDED, int MODE>
+#ifndef GPA_PASSB_PADDED_WAVES
+#define GPA_PASSB_PADDED_WAVES 3   // f32, padded axis: the selects of the extension slots push hipcc to 200 VGPRs (2 waves); capped at 168
+#endif
 #ifndef GPA_F64_WAVES
 #define GPA_F64_WAVES 2   // f64: cap at 256 VGPRs (2 waves/SIMD) instead of 299 at 1 wave: pass B 7.5 -> 5.9 ms
 #endif
-__global__ __launch_bounds__((PassBGeom<T, LG>::THREADS), (sizeof(T) == 8 ? GPA_F64_WAVES : 1)) void passB_kernel(
+__global__ __launch_bounds__((PassBGeom<T, LG>::THREADS), (sizeof(T) == 8 ? GPA_F64_WAVES : (PADDED ? GPA_PASSB_PADDED_WAVES : 1))) void passB_kernel(
     const cpx<T>* __restrict__ Tin, int n0, int n1,
     const typename HType<PADDED, T>::type* __restrict__ H, const cpx<T>* __restrict__ twtab,
     const int* __restrict__ planeof, const cpx<T>* __restrict__ cyb, const cpx<T>* __restrict__ sy,
@@ -68,6 +71,22 @@ __global__ __launch_bounds__((PassBGeom<T, LG>::THREADS), (sizeof(T) == 8 ? GPA_
     k0 = (int)blockIdx.z * kc;
     nk = k0 + kc < K ? k0 + kc : K;
   }
+  // padded axes: which of this thread's slots lie in the right / left periodic extension or in the zero gap (the
+  // same for every candidate).  Registers whose 'TPF' slots all lie inside the image (a wave-uniform test) take the
+  // periodic code path; the others pick their source sample and wrap factor by selects, not branches -- per-element
+  // branches around the loads cost 83 exec-mask branches per candidate and serialised the 16 loads of a thread.
+  unsigned rmask = 0, wmask = 0, zmask = 0;
+  if constexpr (PADDED) {
+#pragma unroll
+    for (int i = 0; i < 16; ++i) {
+      const int slot = tid + TPF * i;
+      if (slot >= n1) {
+        if (slot < n1 + extR) rmask |= 1u << i;
+        else if (slot >= L - extL) wmask |= 1u << i;
+        else zmask |= 1u << i;
+      }
+    }
+  }
   for (int k = k0; k < nk; ++k) {
     const int b = SELECT ? p * K + k : p;
     F::refresh(tw);
@@ -75,14 +94,24 @@ __global__ __launch_bounds__((PassBGeom<T, LG>::THREADS), (sizeof(T) == 8 ? GPA_
     const cpx<T>* src = Tin + ((size_t)planeof[b] * n0 + (valid ? row : 0)) * n1;
     const cpx<T> cbase = cyb[(size_t)b * TPF + tid];
     cpx<T> x[16];
+    cpx<T> fr = {T(1), T(0)}, fw = {T(1), T(0)};
+    if constexpr (PADDED) { fr = wyr[b]; fw = wyw[b]; }
+    // (the source offsets of the extension slots do not depend on the candidate: computed from an opaque copy of
+    //  the thread index so that hipcc does not keep them -- 64-bit each -- in registers across the whole loop:
+    //  217 VGPRs / 2 waves per SIMD otherwise, against 165 / 3 of the periodic kernel)
+    int tl = tid;
+    if constexpr (PADDED) asm volatile("" : "+v"(tl));
 #pragma unroll
     for (int i = 0; i < 16; ++i) {
       cpx<T> ph = cmul(cbase, sy[b * 16 + i]);   // exp(2 pi i wy y) at y = tid + TPF*i
-      if constexpr (PADDED) {
-        const int slot = tid + TPF * i;
-        const int ys = axis_src(slot, n1, L, true, extL, extR);
-        if (slot >= n1) ph = cmul(ph, slot < n1 + extR ? wyr[b] : wyw[b]);
-        x[i] = ys >= 0 ? cmul(src[ys], ph) : cpx<T>{T(0), T(0)};
+      if (PADDED && TPF * (i + 1) > n1) {        // (uniform) some thread's slot of this register is beyond the image
+        const int slot = tl + TPF * i;
+        const bool r = (rmask >> i) & 1, w = (wmask >> i) & 1, z = (zmask >> i) & 1;
+        const int ys = z ? 0 : slot - (r ? n1 : (w ? L - n1 : 0));
+        const cpx<T> f = {r ? fr.x : (w ? fw.x : T(1)), r ? fr.y : (w ? fw.y : T(0))};
+        ph = cmul(ph, f);
+        if (z) ph = {T(0), T(0)};
+        x[i] = cmul(src[ys], ph);
       } else {
         x[i] = cmul(src[tid + TPF * i], ph);   // rows past the image reuse row 0; their results are dropped
       }

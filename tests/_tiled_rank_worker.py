@@ -1,6 +1,7 @@
-"""One rank of the 2-ranks-on-one-GPU test (tests/test_gpu_configs.py): torch.distributed over gloo,
-both ranks on cuda:0, the device-resident TiledPipeline with host-staged collectives.
-usage: RANK= WORLD_SIZE= MASTER_ADDR= MASTER_PORT= python _tiled_rank_worker.py OUT_PREFIX DTYPE"""
+"""One rank of the ranks-on-one-GPU tests (tests/test_gpu_configs.py): torch.distributed over gloo with the
+ranks sharing cuda:0 (device-resident TiledPipeline, host-staged collectives), or over nccl (= RCCL) with a
+single rank (the device-tensor collectives of the N > 1 path; RCCL does not take two ranks on one device).
+usage: RANK= WORLD_SIZE= MASTER_ADDR= MASTER_PORT= python _tiled_rank_worker.py OUT_PREFIX DTYPE [BACKEND]"""
 import os
 import sys
 
@@ -13,16 +14,21 @@ sys.path.insert(0, os.path.join(ROOT, 'tests'))
 
 def main():
     out_prefix, dtype = sys.argv[1], np.dtype(sys.argv[2])
+    backend = sys.argv[3] if len(sys.argv) > 3 else 'gloo'
     rank, world = int(os.environ['RANK']), int(os.environ['WORLD_SIZE'])
     import torch
     import torch.distributed as dist
     torch.cuda.set_device(0)
-    dist.init_process_group('gloo', rank=rank, world_size=world)
+    if backend == 'nccl':
+        dist.init_process_group('nccl', rank=rank, world_size=world, device_id=torch.device('cuda', 0))
+    else:
+        dist.init_process_group(backend, rank=rank, world_size=world)
     from pygpa_amd import distributed as D
     from test_distributed import _case
     img, kvecs, klists = _case()
     # the public entry point (N > 1 -> TiledPipeline) ...
-    u = D.extract_displacement_field_tiled(img, kvecs, klists=klists, halo=20, window=(64, 128), dtype=dtype)
+    u = D.extract_displacement_field_tiled(img, kvecs, klists=klists, halo=20, window=(64, 128), dtype=dtype,
+                                           _force_torch=True)
     # ... and the reusable object, two steps on the same buffers
     pipe = D.TiledPipeline(img.shape, kvecs, np.stack(klists), 6, 20, kmax=10, dtype=dtype, device=0, grid=(2, 2))
     pipe.load(img)

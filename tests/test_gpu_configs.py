@@ -375,6 +375,25 @@ def test_tiled_two_ranks_one_gpu(tmp_path):
         assert np.array_equal(g0['u'], g1['u']) and np.array_equal(g0['u2'], g1['u2'])
 
 
+def test_tiled_nccl_single_rank(tmp_path):
+    """the device-tensor collectives of the N > 1 path (all_reduce / all_gather_into_tensor / broadcast on RCCL)
+    with the one rank a single-GPU box allows: same field as the torch-free single-process run"""
+    from pygpa_amd import distributed as D
+    import test_distributed as TD
+    img, kvecs, klists = TD._case()
+    prefix = str(tmp_path / 'nccl1')
+    env = dict(os.environ, RANK='0', WORLD_SIZE='1', LOCAL_RANK='0', MASTER_ADDR='127.0.0.1',
+               MASTER_PORT=str(_free_port()), HSA_ENABLE_IPC_MODE_LEGACY='0')
+    r = subprocess.run([sys.executable, os.path.join(ROOT, 'tests', '_tiled_rank_worker.py'), prefix, 'float64', 'nccl'],
+                       env=env, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, timeout=900)
+    assert r.returncode == 0, r.stdout.decode()[-3000:]
+    g = np.load(prefix + '_rank0.npz')
+    u_w = D.extract_displacement_field_tiled(img, kvecs, klists=klists, halo=20, window=(64, 128), dtype=np.float64)
+    u_g = D.extract_displacement_field_tiled(img, kvecs, (2, 2), klists=klists, halo=20, dtype=np.float64)
+    assert np.abs(g['u'] - u_w).max() <= 1e-10 and np.abs(g['u2'] - u_g).max() <= 1e-10
+    assert int(g['tiles']) == 4
+
+
 def test_bench_gpus_flag_spawns_ranks():
     """`python bench.py --gpus 2` (no launcher) must start 2 ranks itself and report n_gpus = 2 with the tile
     pipeline as the workload; here both ranks share GPU 0 over gloo and the image is small"""
