@@ -846,7 +846,13 @@ __device__ __forceinline__ void chunk_scan(const double (&v)[NV], const double (
   }
 }
 
-template <class T, int VEC, int Q, int R>
+// RAGGED (image sizes that are not powers of two): n0 need not be a multiple of R nor the chunk count of 64 / Q --
+// the last real chunk sL holds nv < R rows, chunks behind it none, and the workgroup is padded with such empty
+// chunks to whole wavefronts.  The causal recursion simply runs on over the zero rows; its grand total then carries
+// lam^pad too much (pad = rows of padding), which the host folds into the table: tab.lamN = lam^(N - pad).  The
+// anticausal recursion starts at the last real row.  A column group beyond n1 (n1 not a multiple of Q * VEC) computes
+// on zeros and stores nothing.
+template <class T, int VEC, int Q, int R, bool RAGGED>
 __global__ __launch_bounds__(1024) void colsolve_tri_kernel(const T* __restrict__ Zin, T* __restrict__ Z, int n0, int n1,
                                                            const TriCol* __restrict__ tab, const T* __restrict__ hb,
                                                            int* flags, const double* part_norm, int nnorm, int it,
@@ -859,11 +865,23 @@ __global__ __launch_bounds__(1024) void colsolve_tri_kernel(const T* __restrict_
   const int q = threadIdx.x % Q, s = threadIdx.x / Q;
   int tile = blockIdx.x;
   if ((gridDim.x & 7) == 0) tile = (blockIdx.x & 7) * (gridDim.x >> 3) + (blockIdx.x >> 3);
-  const int y0 = (tile * Q + q) * VEC, row0 = s * R, col = q * VEC;
+  const int row0 = s * R, col = q * VEC;
+  const bool cv = !RAGGED || (tile * Q + q) * VEC < n1;   // this thread's columns exist
+  const int y0 = cv ? (tile * Q + q) * VEC : 0;
+  // last real chunk and the rows this thread's chunk holds
+  const int sL = RAGGED ? (n0 - 1) / R : S - 1;
+  const int nv = !RAGGED ? R : (s < sL ? R : (s == sL ? n0 - sL * R : 0));
   struct alignas(VEC * sizeof(T)) Vec { T v[VEC]; };
   Vec x[R];
 #pragma unroll
-  for (int k = 0; k < R; ++k) x[k] = *reinterpret_cast<const Vec*>(Zin + (size_t)(row0 + k) * n1 + y0);
+  for (int k = 0; k < R; ++k) {
+    if (!RAGGED || (k < nv && cv)) {
+      x[k] = *reinterpret_cast<const Vec*>(Zin + (size_t)(row0 + k) * n1 + y0);
+    } else {
+#pragma unroll
+      for (int a = 0; a < VEC; ++a) x[k].v[a] = T(0);
+    }
+  }
   if (it > 0) {
     // the reference's stopping test (phase_unwrap.py:348) on the update the row kernel has just applied
     const double tot = reduce_partials(part_norm, nnorm, shn);
@@ -879,7 +897,7 @@ __global__ __launch_bounds__(1024) void colsolve_tri_kernel(const T* __restrict_
   }
   // (per-column constants are re-read from the table where they are needed instead of being kept in registers:
   //  1024 threads leave 128 VGPRs per lane, 64 of which hold the tile)
-  const bool c0 = y0 == 0;   // this thread's first column is column 0, the singular one
+  const bool c0 = y0 == 0 && cv;   // this thread's first column is column 0, the singular one
   // A sample is read by three recursions.  Each re-read goes through an opaque copy (reread()): hipcc otherwise
   // shares the f32 -> f64 conversion between the passes and keeps all 64 converted samples of the thread alive
   // from one pass to the next -- 128 registers more, i.e. spills at the 128 this launch geometry allows.
@@ -929,6 +947,9 @@ __global__ __launch_bounds__(1024) void colsolve_tri_kernel(const T* __restrict_
   }
   // ---- pass 2: causal recursion in place from the true carry; aggregate of the anticausal one
   double e[VEC];
+  T plast[VEC];   // RAGGED: p of the last real row (chunk sL only)
+#pragma unroll
+  for (int a = 0; a < VEC; ++a) plast[a] = T(0);
 #pragma unroll
   for (int a = 0; a < VEC; ++a) {
     const double lam = tab[y0 + a].lam, sh = (a == 0 && c0) ? shift0 : 0.0;
@@ -939,9 +960,21 @@ __global__ __launch_bounds__(1024) void colsolve_tri_kernel(const T* __restrict_
       x[k].v[a] = (T)p;
     }
     // z_N = zn p_(N-1) enters the last chunk's aggregate (the stored, rounded p: the same value pass 3 starts from)
-    double ee = s == S - 1 ? tab[y0 + a].zn * (double)x[R - 1].v[a] : 0.0;
+    double ee;
+    if constexpr (!RAGGED) {
+      ee = s == S - 1 ? tab[y0 + a].zn * (double)x[R - 1].v[a] : 0.0;
 #pragma unroll
-    for (int k = R - 1; k >= 0; --k) ee = lam * (ee - (double)x[k].v[a]);
+      for (int k = R - 1; k >= 0; --k) ee = lam * (ee - (double)x[k].v[a]);
+    } else {
+      ee = 0.0;
+#pragma unroll
+      for (int k = R - 1; k >= 0; --k) {
+        if (k < nv) {
+          if (s == sL && k == nv - 1) { plast[a] = x[k].v[a]; ee = tab[y0 + a].zn * (double)x[k].v[a]; }
+          ee = lam * (ee - (double)x[k].v[a]);
+        }
+      }
+    }
     e[a] = ee;
   }
 #pragma unroll
@@ -958,24 +991,27 @@ __global__ __launch_bounds__(1024) void colsolve_tri_kernel(const T* __restrict_
 #pragma unroll
   for (int a = 0; a < VEC; ++a) {
     const double lam = tab[y0 + a].lam;
-    double z = s == S - 1 ? tab[y0 + a].zn * (double)x[R - 1].v[a] : carry[a];
+    double z = s == sL ? tab[y0 + a].zn * (double)(RAGGED ? plast[a] : x[R - 1].v[a]) : carry[a];
     double dsq = 0.0, zsq = 0.0;
 #pragma unroll
     for (int k = R - 1; k >= 0; --k) {
-      const double zn = lam * (z - reread(x[k].v[a]));
-      if (!(s == S - 1 && k == R - 1)) dsq += (z - zn) * (z - zn);   // no difference across the reflecting end
-      zsq += zn * zn;
-      z = zn;
-      x[k].v[a] = (T)zn;
+      if (!RAGGED || k < nv) {
+        const double zn = lam * (z - reread(x[k].v[a]));
+        if (!(s == sL && k == nv - 1)) dsq += (z - zn) * (z - zn);   // no difference across the reflecting end
+        zsq += zn * zn;
+        z = zn;
+        x[k].v[a] = (T)zn;
+      }
     }
     double r = -dsq - 2.0 * (double)hb[y0 + a] * zsq;
     if (a == 0 && c0) {
 #pragma unroll
-      for (int k = 0; k < R; ++k) zsum0 += (double)x[k].v[0];
+      for (int k = 0; k < R; ++k)
+        if (!RAGGED || k < nv) zsum0 += (double)x[k].v[0];
       if (s == 0) r += (double)n0 * shift0 * shift0;
       r *= 0.5;                                   // c_0 = 1/2 of SciPy's DCT-II normalisation along the rows
     }
-    rho += r;
+    rho += (!RAGGED || cv) ? r : 0.0;
   }
   if (tile == 0) {
     // column 0: remove the mean of z, add the mean of r (its DC bin is divided by 1)
@@ -992,7 +1028,8 @@ __global__ __launch_bounds__(1024) void colsolve_tri_kernel(const T* __restrict_
     int rs = row0;
     asm volatile("" : "+v"(rs));
 #pragma unroll
-    for (int k = 0; k < R; ++k) *reinterpret_cast<Vec*>(Z + (size_t)(rs + k) * n1 + y0) = x[k];
+    for (int k = 0; k < R; ++k)
+      if (!RAGGED || (k < nv && cv)) *reinterpret_cast<Vec*>(Z + (size_t)(rs + k) * n1 + y0) = x[k];
   }
   if (part_rho) {
     const double tot = block_sum(rho, shn);
@@ -1543,45 +1580,77 @@ hipError_t dispatch_rowidct(const Impl* w, int* nparts, hipStream_t s) {
 #undef CASE
   return hipErrorInvalidValue;
 }
+// threads side by side along a row (Q), chunks per workgroup (S, padded to whole wavefronts when there are several)
+// and the rows of padding that geometry implies -- shared by the launcher and by the table builder
+template <class T>
+void tri_geometry(int n0, int n1, int* Q_out, int* S_out, int* pad_out) {
+  constexpr int VEC = 16 / sizeof(T), R = TriRows<T>::value;
+  int S = (n0 + R - 1) / R;
+  int Q = 4;
+  while (Q > 1 && (S * Q > 1024 || n1 / (Q * VEC) < 256)) Q /= 2;
+  if (S * Q > 64) {
+    const int cpw = 64 / Q;
+    S = (S + cpw - 1) / cpw * cpw;
+    while (Q > 1 && S * Q > 1024) { Q /= 2; S = ((n0 + R - 1) / R + 64 / Q - 1) / (64 / Q) * (64 / Q); }
+  }
+  *Q_out = Q;
+  *S_out = S;
+  *pad_out = S * R - n0;
+}
+
 template <class T, int VEC, int Q>
-hipError_t run_colsolve_tri(const Impl* w, int compat, hipStream_t s, const double* part_norm, int nnorm, int it, double eps,
-                            double* part_rho, int* nrho, const void* zin) {
+hipError_t run_colsolve_tri(const Impl* w, int S, int compat, hipStream_t s, const double* part_norm, int nnorm, int it,
+                            double eps, double* part_rho, int* nrho, const void* zin) {
   constexpr int R = TriRows<T>::value;
-  auto kern = colsolve_tri_kernel<T, VEC, Q, R>;
-  const int S = w->n0 / R, threads = S * Q, grid = w->n1 / (Q * VEC);
+  const bool ragged = w->generic;
+  const int threads = S * Q, grid = (w->n1 + Q * VEC - 1) / (Q * VEC);
   const size_t lds = (size_t)16 * Q * VEC * sizeof(double);
-  static unsigned lds_set = 0;
-    hipError_t e = set_dynamic_lds_once(reinterpret_cast<const void*>(kern), (int)lds, lds_set);
-  if (e != hipSuccess) return e;
   if (nrho) *nrho = grid;
   GPA_PROF("colsolve_kernel", s);
-  kern<<<grid, threads, lds, s>>>((const T*)(zin ? zin : w->z), (T*)w->z, w->n0, w->n1, (const TriCol*)w->tritab,
-                                  (const T*)w->hb1[compat], w->flags, part_norm, nnorm, it, eps, w->scal, part_rho);
+  if (ragged) {
+    auto kern = colsolve_tri_kernel<T, VEC, Q, R, true>;
+    static unsigned lds_set = 0;
+    hipError_t e = set_dynamic_lds_once(reinterpret_cast<const void*>(kern), (int)lds, lds_set);
+    if (e != hipSuccess) return e;
+    kern<<<grid, threads, lds, s>>>((const T*)(zin ? zin : w->z), (T*)w->z, w->n0, w->n1, (const TriCol*)w->tritab,
+                                    (const T*)w->hb1[compat], w->flags, part_norm, nnorm, it, eps, w->scal, part_rho);
+  } else {
+    auto kern = colsolve_tri_kernel<T, VEC, Q, R, false>;
+    static unsigned lds_set = 0;
+    hipError_t e = set_dynamic_lds_once(reinterpret_cast<const void*>(kern), (int)lds, lds_set);
+    if (e != hipSuccess) return e;
+    kern<<<grid, threads, lds, s>>>((const T*)(zin ? zin : w->z), (T*)w->z, w->n0, w->n1, (const TriCol*)w->tritab,
+                                    (const T*)w->hb1[compat], w->flags, part_norm, nnorm, it, eps, w->scal, part_rho);
+  }
   return hipGetLastError();
 }
 
-// square images: the transform-free column solve; Q (threads side by side along a row) as large as 1024 threads
-// per workgroup and >= 256 workgroups allow
+// square images: the transform-free column solve
 template <class T>
 hipError_t dispatch_colsolve_tri(const Impl* w, int compat, hipStream_t s, const double* part_norm, int nnorm, int it,
                                  double eps, double* part_rho, int* nrho, const void* zin) {
   constexpr int VEC = 16 / sizeof(T);
-  const int S = w->n0 / TriRows<T>::value;
-  int Q = 4;
-  while (Q > 1 && (S * Q > 1024 || w->n1 / (Q * VEC) < 256)) Q /= 2;
+  int Q, S, pad;
+  tri_geometry<T>(w->n0, w->n1, &Q, &S, &pad);
   switch (Q) {
-    case 4: return run_colsolve_tri<T, VEC, 4>(w, compat, s, part_norm, nnorm, it, eps, part_rho, nrho, zin);
-    case 2: return run_colsolve_tri<T, VEC, 2>(w, compat, s, part_norm, nnorm, it, eps, part_rho, nrho, zin);
-    default: return run_colsolve_tri<T, VEC, 1>(w, compat, s, part_norm, nnorm, it, eps, part_rho, nrho, zin);
+    case 4: return run_colsolve_tri<T, VEC, 4>(w, S, compat, s, part_norm, nnorm, it, eps, part_rho, nrho, zin);
+    case 2: return run_colsolve_tri<T, VEC, 2>(w, S, compat, s, part_norm, nnorm, it, eps, part_rho, nrho, zin);
+    default: return run_colsolve_tri<T, VEC, 1>(w, S, compat, s, part_norm, nnorm, it, eps, part_rho, nrho, zin);
   }
 }
 
 hipError_t dispatch_colsolve(const Impl* w, int compat, hipStream_t s, const double* part_norm = nullptr,
                              int nnorm = 0, int it = 0, double eps = 0.0, double* part_rho = nullptr,
                              int* nrho = nullptr, const void* zin = nullptr) {
-  if (w->generic && part_rho)
+  if (w->generic && part_rho) {
+    // smooth sizes: the transform-free solve where it applies (square images; it is 2-3x faster than two mixed-radix
+    // transforms per column pair), GPA_COLSOLVE=fft keeps the transforms
+    if (w->tritab && w->col_mode != 2)
+      return w->dtype == 0 ? dispatch_colsolve_tri<float>(w, compat, s, part_norm, nnorm, it, eps, part_rho, nrho, zin)
+                           : dispatch_colsolve_tri<double>(w, compat, s, part_norm, nnorm, it, eps, part_rho, nrho, zin);
     return w->dtype == 0 ? run_mr_colsolve<float>(w, compat, s, part_norm, nnorm, it, eps, part_rho, nrho, zin)
                          : run_mr_colsolve<double>(w, compat, s, part_norm, nnorm, it, eps, part_rho, nrho, zin);
+  }
   // Square images can solve the columns without a transform (colsolve_tri_kernel).  Measured at 4096^2 on MI355X
   // (profiles/r02_colsolve_tri.txt): f64 1.54 ms per step against 2.0 for the DCT kernel (whose f64 transforms
   // spill), f32 82 us per launch against 68 -- the f32 DCT kernel is the faster one.  So: f64 by default,
@@ -1729,6 +1798,35 @@ int ilog2_exact(int n) {
 
 }  // namespace
 
+// transform-free column solve (colsolve_tri_kernel): per row frequency j the decay lam_j of the Green's function of
+// (T + mu_j) and the constants of its boundary terms, in long double.  lamN carries the launch geometry's padding
+// (lam^(N - pad), see the kernel); no table if the column does not fit one workgroup.
+hipError_t build_tritab(Impl* w, hipStream_t s, size_t* bytes) {
+  const int n0 = w->n0, n1 = w->n1;
+  int Q, S, pad;
+  if (w->dtype == 0) tri_geometry<float>(n0, n1, &Q, &S, &pad);
+  else tri_geometry<double>(n0, n1, &Q, &S, &pad);
+  if (S * Q > 1024) return hipSuccess;
+  const int R = w->dtype == 0 ? TriRows<float>::value : TriRows<double>::value;
+  std::vector<TriCol> tc((size_t)n1);
+  for (int j = 0; j < n1; ++j) {
+    if (j == 0) { tc[0] = {1.0, 1.0, 1.0, 0.0, 0.0}; continue; }
+    const long double sj = sinl((long double)M_PI * j / (2.0L * n1)), h = 2 * sj * sj;
+    const long double lam = (1 + h) - sqrtl(h * (2 + h));
+    tc[j].lam = (double)lam;
+    tc[j].lamR = (double)powl(lam, R);
+    tc[j].lamN = (double)powl(lam, (long double)(n0 - pad));
+    tc[j].inv = (double)(1.0L / (1.0L - powl(lam, 2.0L * n0)));
+    tc[j].zn = (double)(-lam / (1.0L - lam));
+  }
+  hipError_t e = hipMalloc(&w->tritab, tc.size() * sizeof(TriCol));
+  if (e != hipSuccess) return e;
+  *bytes += tc.size() * sizeof(TriCol);
+  e = hipMemcpyAsync(w->tritab, tc.data(), tc.size() * sizeof(TriCol), hipMemcpyHostToDevice, s);
+  if (e == hipSuccess) e = hipStreamSynchronize(s);
+  return e;
+}
+
 hipError_t unwrap_workspace_create(int dtype, int n0, int n1, hipStream_t s, UnwrapWorkspace* ws, size_t* bytes_out) {
   Impl* w = new Impl();
   memset(w, 0, sizeof(Impl));
@@ -1874,28 +1972,9 @@ hipError_t unwrap_workspace_create(int dtype, int n0, int n1, hipStream_t s, Unw
       if ((e = upload(dtype, &w->ham0[compat], am, &bytes, s)) != hipSuccess) return e;
       if ((e = upload(dtype, &w->hb1[compat], b, &bytes, s)) != hipSuccess) return e;
     }
-    if (n0 == n1) {
-      // transform-free column solve (colsolve_tri_kernel): per row frequency j the decay lam_j of the Green's
-      // function of (T + mu_j) and the constants of its boundary terms, in long double
-      std::vector<TriCol> tc((size_t)n1);
-      for (int j = 0; j < n1; ++j) {
-        if (j == 0) { tc[0] = {1.0, 1.0, 1.0, 0.0, 0.0}; continue; }
-        const long double sj = sinl((long double)M_PI * j / (2.0L * n1)), h = 2 * sj * sj;
-        const long double lam = (1 + h) - sqrtl(h * (2 + h));
-        tc[j].lam = (double)lam;
-        tc[j].lamR = (double)powl(lam, dtype == 0 ? TriRows<float>::value : TriRows<double>::value);
-        tc[j].lamN = (double)powl(lam, n0);
-        tc[j].inv = (double)(1.0L / (1.0L - powl(lam, 2.0L * n0)));
-        tc[j].zn = (double)(-lam / (1.0L - lam));
-      }
-      e = hipMalloc(&w->tritab, tc.size() * sizeof(TriCol));
-      if (e != hipSuccess) return e;
-      bytes += tc.size() * sizeof(TriCol);
-      e = hipMemcpyAsync(w->tritab, tc.data(), tc.size() * sizeof(TriCol), hipMemcpyHostToDevice, s);
-      if (e == hipSuccess) e = hipStreamSynchronize(s);
-      if (e != hipSuccess) return e;
-    }
+    if (n0 == n1 && (e = build_tritab(w, s, &bytes)) != hipSuccess) return e;
   }
+  if (w->supported && w->generic && w->mr_ok && n0 == n1 && (e = build_tritab(w, s, &bytes)) != hipSuccess) return e;
   if (bytes_out) *bytes_out = bytes;
   return hipSuccess;
 }

@@ -1058,11 +1058,12 @@ def _unwrap_case(shape, seed, weighted=True):
 
 @pytest.mark.gpu
 @pytest.mark.parametrize('shape', [(48, 80), (100, 60), (300, 200), (500, 500), (130, 104), (360, 364), (1000, 1500),
-                                   (66, 88), (512, 384)])
+                                   (66, 88), (512, 384), (36, 36), (100, 100), (1000, 1000), (1200, 1200)])
 def test_mixed_radix_fused_unwrap_vs_oracle(shape, monkeypatch):
     """image sizes that factor into 2, 3, 5, 7, 11, 13 with rows of a multiple of 4 pixels run the fused
-    4-kernel PCG on the mixed-radix FFT: same numbers as the oracle (f64 1e-8, f32 within the PCG tolerance),
-    the same iteration count as the Bluestein path (GPA_NO_MR=1) and as the oracle's loop"""
+    4-kernel PCG on the mixed-radix FFT (square ones with the transform-free column solve on ragged chunks):
+    same numbers as the oracle (f64 1e-8, f32 within the PCG tolerance), the same iteration count as the
+    Bluestein path (GPA_NO_MR=1) and as the oracle's loop"""
     psi, weight = _unwrap_case(shape, 31 + shape[0])
     for kmax in (7, 40):
         ref, ref_iters = orc.unwrap(psi, weight=weight, kmax=kmax, return_iters=True)
@@ -1075,6 +1076,12 @@ def test_mixed_radix_fused_unwrap_vs_oracle(shape, monkeypatch):
         monkeypatch.delenv('GPA_NO_MR')
         got_b, iters_b = plan_b.unwrap(psi, weight, kmax=kmax)
         assert iters_b == iters and rel(got, got_b) < 1e-9
+        if shape[0] == shape[1]:
+            # square: the columns are solved without a transform by default; the mixed-radix column kernel must agree
+            monkeypatch.setenv('GPA_COLSOLVE', 'fft')
+            got_f, iters_f = plan.unwrap(psi, weight, kmax=kmax)
+            monkeypatch.delenv('GPA_COLSOLVE')
+            assert iters_f == iters and rel(got, got_f) < 1e-9
         plan32 = _lib.Plan(shape, 1, np.float32)
         got32, _ = plan32.unwrap(psi.astype(np.float32), None if weight is None else weight.astype(np.float32), kmax=kmax)
         assert rel(got32 - got32.mean(), ref - ref.mean()) < 2e-4, (shape, kmax)
