@@ -186,6 +186,33 @@ def test_config2_2048_accuracy():
     assert rec['f32']['interior_max_px'] < 0.02 and rec['f32']['max_px'] < 0.1
 
 
+@pytest.mark.parametrize('shape', [(1080, 1920), (1000, 1000), (1280, 1024)])
+def test_non_power_of_two_frames_vs_oracle(shape):
+    """camera frame sizes that are not powers of two (HD 1080 x 1920, the reference's decade sizes, 1280 x 1024):
+    compact extension in the sweep, mixed-radix fused unwrap (transform-free columns when square) -- the whole
+    driver in f64 against the oracle (kidx exact up to ties, u to 1e-6 px), f32 within the config-2 bounds"""
+    kvecs = hex_kvecs(0.1, 7.0)
+    img = hex_moire(shape, kvecs, gaussian_bump_displacement(shape), noise=0.1, seed=9)
+    kw, sigma, _ = orc.derive_params(kvecs)
+    klists = np.stack(explicit_klists(kvecs, kw, 3, 2))
+    cores = os.cpu_count() or 1
+    u_ref, parts = orc.extract_displacement_field(img, kvecs, sigma=sigma, klists=klists, return_parts=True,
+                                                  workers=cores, pool=min(cores, 8))
+    ref_kidx = np.stack([g['kidx'] for g in parts['gs']])
+    img0 = img - img.mean()
+    rec = {'u_max_px': float(np.abs(u_ref).max())}
+    for name, dtype in (('f64', np.float64), ('f32', np.float32)):
+        plan = _lib.Plan(shape, 18, dtype)
+        u, _, kidx, iters = plan.extract_displacement_field(img, kvecs, klists, sigma, 2 * sigma, want_kidx=True)
+        rec[name] = dict(_px_errors(u, u_ref, 2 * sigma), iters=list(iters), fft_len=[plan.fft_len(0), plan.fft_len(1)])
+        rec[name]['kidx_mismatch'] = _check_kidx_ties(kidx, ref_kidx, img0, klists, sigma, 1e-12 if dtype is np.float64 else 4e-6)
+        plan.close()
+    _record('frame_%dx%d_3x6_vs_oracle' % shape, rec)
+    assert rec['f64']['kidx_mismatch'] == 0.0
+    assert rec['f64']['max_px'] < 1e-6
+    assert rec['f32']['interior_max_px'] < 0.02 and rec['f32']['max_px'] < 0.1
+
+
 def test_config3_4096_accuracy_f32_f64_oracle():
     """configs[2]: 4096^2, 3 x 16 + weighted unwrap.  (1) device f64 against the ORACLE at full size;
     (2) fp32 against fp64 with the default residual floor (9 + 8 iterations) and with 10 + 10 forced;
