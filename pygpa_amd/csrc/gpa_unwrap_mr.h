@@ -44,25 +44,67 @@ __global__ __launch_bounds__(MAXT) void mr_rowdct_fused_kernel(
     if (blockIdx.x == 0 && threadIdx.x == 0) scal[SC_ALPHA + (it - 1) % ring] = alpha_d;
   }
   const T* src = it > 0 ? q : r;
-  for (int c = tid; c < n; c += Tn)
-    lds[mr_pad(mr_slot_of(c, n))] = {va ? src[oa + c] : T(0), vb ? src[ob + c] : T(0)};
+  // all loads of a thread are issued before the first use (a loop of load -> LDS store pays one memory latency per
+  // trip); rows are whole 4-pixel vectors, n / (4 Tn) <= 4 vectors per thread and row
+  constexpr int NV = MR_REGS / 4;
+  const Vec4<T> zero4 = {{T(0), T(0), T(0), T(0)}};
+  {
+    Vec4<T> qa[NV], qb[NV];
+#pragma unroll
+    for (int i = 0; i < NV; ++i) {
+      const int c0 = 4 * (tid + Tn * i);
+      qa[i] = (c0 < n && va) ? *reinterpret_cast<const Vec4<T>*>(src + oa + c0) : zero4;
+      qb[i] = (c0 < n && vb) ? *reinterpret_cast<const Vec4<T>*>(src + ob + c0) : zero4;
+    }
+#pragma unroll
+    for (int i = 0; i < NV; ++i) {
+      const int c0 = 4 * (tid + Tn * i);
+      if (c0 < n) {
+#pragma unroll
+        for (int j = 0; j < 4; ++j) lds[mr_pad(mr_slot_of(c0 + j, n))] = {qa[i].v[j], qb[i].v[j]};
+      }
+    }
+  }
   __syncthreads();   // (it == 0, in place: both rows are in LDS before any bin is written)
   mr_run<MAXT>(lds, pl, W, tid);
   double sq = 0;
-  for (int k = tid; k < n; k += Tn) {
-    const cpx<T> zk = lds[mr_pad(k)], zm = lds[mr_pad(k == 0 ? 0 : n - k)];
-    const cpx<T> w = wk[k];
-    const cpx<T> X = cmul(w, zk) + cmulc(zm, w);
-    T ra = X.x, rb = X.y;
-    if (it > 0) {
-      ra = (va ? r[oa + k] : T(0)) - alpha * ra;
-      rb = (vb ? r[ob + k] : T(0)) - alpha * rb;
-      // sum_n r^2 = (1 / 2N) sum_k c_k R_k^2, c_0 = 1/2 (SciPy's unnormalised DCT-II)
-      const double t = (double)ra * (double)ra + (double)rb * (double)rb;
-      sq += k == 0 ? 0.5 * t : t;
+  {
+    Vec4<T> ra[NV], rb[NV];
+    struct alignas(4 * sizeof(cpx<T>)) W4 { cpx<T> v[4]; };
+    W4 w4[NV];
+#pragma unroll
+    for (int i = 0; i < NV; ++i) {
+      const int k0 = 4 * (tid + Tn * i);
+      ra[i] = (it > 0 && k0 < n && va) ? *reinterpret_cast<const Vec4<T>*>(r + oa + k0) : zero4;
+      rb[i] = (it > 0 && k0 < n && vb) ? *reinterpret_cast<const Vec4<T>*>(r + ob + k0) : zero4;
+      if (k0 < n) w4[i] = *reinterpret_cast<const W4*>(wk + k0);
     }
-    if (va) r[oa + k] = ra;
-    if (vb) r[ob + k] = rb;
+#pragma unroll
+    for (int i = 0; i < NV; ++i) {
+      const int k0 = 4 * (tid + Tn * i);
+      if (k0 < n) {
+        Vec4<T> oa4, ob4;
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+          const int k = k0 + j;
+          const cpx<T> zk = lds[mr_pad(k)], zm = lds[mr_pad(k == 0 ? 0 : n - k)];
+          const cpx<T> w = w4[i].v[j];
+          const cpx<T> X = cmul(w, zk) + cmulc(zm, w);
+          T xa = X.x, xb = X.y;
+          if (it > 0) {
+            xa = ra[i].v[j] - alpha * xa;
+            xb = rb[i].v[j] - alpha * xb;
+            // sum_n r^2 = (1 / 2N) sum_k c_k R_k^2, c_0 = 1/2 (SciPy's unnormalised DCT-II)
+            const double t = (double)xa * (double)xa + (double)xb * (double)xb;
+            sq += k == 0 ? 0.5 * t : t;
+          }
+          oa4.v[j] = xa;
+          ob4.v[j] = xb;
+        }
+        if (va) *reinterpret_cast<Vec4<T>*>(r + oa + k0) = oa4;
+        if (vb) *reinterpret_cast<Vec4<T>*>(r + ob + k0) = ob4;
+      }
+    }
   }
   if (it > 0) {
     const double tot = block_sum(sq, sh);
@@ -86,29 +128,77 @@ __global__ __launch_bounds__(MAXT) void mr_rowidct_p_kernel(
   const int xa = 2 * pr, xb = xa + 1;
   const bool va = xa < n0, vb = xb < n0;
   const size_t oa = (size_t)(va ? xa : 0) * n, ob = (size_t)(vb ? xb : 0) * n;
-  for (int k = tid; k < n; k += Tn) {
-    const cpx<T> X = {va ? Z[oa + k] : T(0), vb ? Z[ob + k] : T(0)};
-    const cpx<T> Xm = k == 0 ? cpx<T>{T(0), T(0)} : cpx<T>{va ? Z[oa + n - k] : T(0), vb ? Z[ob + n - k] : T(0)};
-    const cpx<T> d = {X.x + Xm.y, X.y - Xm.x};     // X_k - i X_(n-k)
-    const cpx<T> v = cmulc(d, wk[k]);              // V_k = conj(w_k) (.) / 2
-    lds[mr_pad(k)] = {T(0.5) * v.x, T(-0.5) * v.y};   // conj(V_k): IDFT = conj(DFT(conj .))
+  constexpr int NV = MR_REGS / 4;
+  const Vec4<T> zero4 = {{T(0), T(0), T(0), T(0)}};
+  // the two spectra come in with batched 16-byte loads and are parked in LDS in natural order: bin n - k, which the
+  // DCT-III needs next to bin k, would otherwise be a second, misaligned pass over the rows
+  {
+    Vec4<T> za[NV], zb[NV];
+#pragma unroll
+    for (int i = 0; i < NV; ++i) {
+      const int k0 = 4 * (tid + Tn * i);
+      za[i] = (k0 < n && va) ? *reinterpret_cast<const Vec4<T>*>(Z + oa + k0) : zero4;
+      zb[i] = (k0 < n && vb) ? *reinterpret_cast<const Vec4<T>*>(Z + ob + k0) : zero4;
+    }
+#pragma unroll
+    for (int i = 0; i < NV; ++i) {
+      const int k0 = 4 * (tid + Tn * i);
+      if (k0 < n) {
+#pragma unroll
+        for (int j = 0; j < 4; ++j) lds[mr_pad(k0 + j)] = {za[i].v[j], zb[i].v[j]};
+      }
+    }
   }
-  const double rho = reduce_partials(part_rho, nrho, sh);   // (contains the barrier the transform needs)
+  const double rho = reduce_partials(part_rho, nrho, sh);   // (contains the barrier the LDS image needs)
   const bool first = it == 0;                               // first iteration: p = z (pin is uninitialised)
   const T beta = first ? T(0) : (T)(rho / scal[8 + ((it - 1) & 1)]);
   if (blockIdx.x == 0 && threadIdx.x == 0) scal[8 + (it & 1)] = rho;
+  {
+    cpx<T> pv[MR_REGS];
+#pragma unroll
+    for (int i = 0; i < MR_REGS; ++i) {
+      const int k = tid + Tn * i;
+      if (k < n) {
+        const cpx<T> X = lds[mr_pad(k)];
+        const cpx<T> Xm = k == 0 ? cpx<T>{T(0), T(0)} : lds[mr_pad(n - k)];
+        const cpx<T> d = {X.x + Xm.y, X.y - Xm.x};     // X_k - i X_(n-k)
+        const cpx<T> v = cmulc(d, wk[k]);              // V_k = conj(w_k) (.) / 2
+        pv[i] = {T(0.5) * v.x, T(-0.5) * v.y};         // conj(V_k): IDFT = conj(DFT(conj .))
+      }
+    }
+    __syncthreads();
+#pragma unroll
+    for (int i = 0; i < MR_REGS; ++i) {
+      const int k = tid + Tn * i;
+      if (k < n) lds[mr_pad(k)] = pv[i];
+    }
+  }
   __syncthreads();
   mr_run<MAXT>(lds, pl, W, tid);
   const T inv_n = T(1) / T(n);
-  for (int c = tid; c < n; c += Tn) {
-    const cpx<T> v = lds[mr_pad(mr_slot_of(c, n))];
-    T pa = v.x * inv_n, pb = -v.y * inv_n;
-    if (!first) {
-      if (va) pa += beta * pin[oa + c];
-      if (vb) pb += beta * pin[ob + c];
+  {
+    Vec4<T> pa4[NV], pb4[NV];
+#pragma unroll
+    for (int i = 0; i < NV; ++i) {
+      const int c0 = 4 * (tid + Tn * i);
+      pa4[i] = (!first && c0 < n && va) ? *reinterpret_cast<const Vec4<T>*>(pin + oa + c0) : zero4;
+      pb4[i] = (!first && c0 < n && vb) ? *reinterpret_cast<const Vec4<T>*>(pin + ob + c0) : zero4;
     }
-    if (va) pout[oa + c] = pa;
-    if (vb) pout[ob + c] = pb;
+#pragma unroll
+    for (int i = 0; i < NV; ++i) {
+      const int c0 = 4 * (tid + Tn * i);
+      if (c0 < n) {
+        Vec4<T> oa4, ob4;
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+          const cpx<T> v = lds[mr_pad(mr_slot_of(c0 + j, n))];
+          oa4.v[j] = v.x * inv_n + beta * pa4[i].v[j];
+          ob4.v[j] = -v.y * inv_n + beta * pb4[i].v[j];
+        }
+        if (va) *reinterpret_cast<Vec4<T>*>(pout + oa + c0) = oa4;
+        if (vb) *reinterpret_cast<Vec4<T>*>(pout + ob + c0) = ob4;
+      }
+    }
   }
 }
 
@@ -130,17 +220,29 @@ __global__ __launch_bounds__(MAXT) void mr_colsolve_kernel(
   const bool va = ya < n1, vb = yb < n1;
   struct alignas(2 * sizeof(T)) Pair { T a, b; };
   const bool vec = vb && (n1 & 1) == 0;   // the pair is one aligned 2-element access
-  for (int row = tid; row < n; row += Tn) {
-    const size_t o = (size_t)row * n1;
-    cpx<T> v = {T(0), T(0)};
-    if (vec) {
-      const Pair pz = *reinterpret_cast<const Pair*>(Zin + o + ya);
-      v = {pz.a, pz.b};
-    } else {
-      if (va) v.x = Zin[o + ya];
-      if (vb) v.y = Zin[o + yb];
+  {
+    // (all of a thread's loads first, then the LDS stores: one memory latency instead of one per row)
+    cpx<T> v[MR_REGS];
+#pragma unroll
+    for (int i = 0; i < MR_REGS; ++i) {
+      const int row = tid + Tn * i;
+      v[i] = {T(0), T(0)};
+      if (row < n) {
+        const size_t o = (size_t)row * n1;
+        if (vec) {
+          const Pair pz = *reinterpret_cast<const Pair*>(Zin + o + ya);
+          v[i] = {pz.a, pz.b};
+        } else {
+          if (va) v[i].x = Zin[o + ya];
+          if (vb) v[i].y = Zin[o + yb];
+        }
+      }
     }
-    lds[mr_pad(mr_slot_of(row, n))] = v;
+#pragma unroll
+    for (int i = 0; i < MR_REGS; ++i) {
+      const int row = tid + Tn * i;
+      if (row < n) lds[mr_pad(mr_slot_of(row, n))] = v[i];
+    }
   }
   if (it > 0) {
     // the reference's stopping test (phase_unwrap.py:348), evaluated identically by every workgroup
