@@ -1087,3 +1087,41 @@ def test_mixed_radix_fused_unwrap_vs_oracle(shape, monkeypatch):
         assert rel(got32 - got32.mean(), ref - ref.mean()) < 2e-4, (shape, kmax)
         for p in (plan, plan_b, plan32):
             p.close()
+
+
+def _smooth_lengths(lo, hi):
+    out = []
+    for n in range(lo, hi + 1):
+        m = n
+        for r in (2, 3, 5, 7, 11, 13):
+            while m % r == 0:
+                m //= r
+        if m == 1:
+            out.append(n)
+    return out
+
+
+@pytest.mark.gpu
+def test_random_smooth_shapes_unwrap_vs_oracle():
+    """seeded random shapes whose sides factor into 2..13 (any mix of radices, square and rectangular, rows a
+    multiple of 4 or not): unwrap family in f64 against the oracle, iteration counts included.
+    GPA_TEST_RANDOM_CASES / GPA_TEST_RANDOM_SEED widen the sweep for soak runs."""
+    rng = np.random.default_rng(int(os.environ.get('GPA_TEST_RANDOM_SEED', '99')))
+    lengths = _smooth_lengths(8, 720)
+    done, want = 0, int(os.environ.get('GPA_TEST_RANDOM_CASES', '12'))
+    while done < want:
+        n0 = int(rng.choice(lengths))
+        n1 = n0 if rng.random() < 0.4 else int(rng.choice(lengths))
+        if max(n0, n1) >= 1.75 * min(n0, n1):
+            continue
+        done += 1
+        shape = (n0, n1)
+        psi, weight = _unwrap_case(shape, int(rng.integers(0, 2 ** 31)), weighted=bool(done % 3))
+        kmax = int(rng.integers(2, 30))
+        ref, ref_iters = orc.unwrap(psi, weight=weight, kmax=kmax, return_iters=True)
+        plan = _lib.get_plan(shape, 1, np.float64)
+        got, iters = plan.unwrap(psi, weight, kmax=kmax)
+        assert rel(got, ref) < 1e-8, (shape, kmax, rel(got, ref))
+        assert iters == ref_iters, (shape, kmax, iters, ref_iters)
+        got2, _ = plan.unwrap_prediff(np.diff(psi, axis=1), np.diff(psi, axis=0), weight, kmax=kmax)
+        assert rel(got2, ref) < 1e-8, (shape, kmax)
