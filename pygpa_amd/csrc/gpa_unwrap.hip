@@ -56,7 +56,8 @@ struct Impl {
   void *ha0[2], *ham0[2];    // 1 - cos term of axis-0 bins (spectral layout); [compat]
   void *hb1[2];              // 1 - cos term of axis-1 bins (natural); [compat]
   int col_mode;              // GPA_COLSOLVE of the current solve: 0 default, 1 tri, 2 fft (read once per solve)
-  void* tritab;              // TriCol per column (square power-of-two images): transform-free column solve
+  void* tritab;              // TriCol per column (square images): transform-free column solve
+  int triQ, triS;            // its launch geometry, fixed when the table is built (the table depends on it)
   double* scal;              // 8 doubles
   int* flags;                // [0] = iteration count, [1] = done
   double* part;              // 3 * MAXPART partial sums
@@ -1583,11 +1584,18 @@ hipError_t dispatch_rowidct(const Impl* w, int* nparts, hipStream_t s) {
 // threads side by side along a row (Q), chunks per workgroup (S, padded to whole wavefronts when there are several)
 // and the rows of padding that geometry implies -- shared by the launcher and by the table builder
 template <class T>
-void tri_geometry(int n0, int n1, int* Q_out, int* S_out, int* pad_out) {
+void tri_geometry(int n0, int n1, bool ragged, int* Q_out, int* S_out, int* pad_out) {
   constexpr int VEC = 16 / sizeof(T), R = TriRows<T>::value;
   int S = (n0 + R - 1) / R;
   int Q = 4;
-  while (Q > 1 && (S * Q > 1024 || n1 / (Q * VEC) < 256)) Q /= 2;
+  // (workgroups wanted at least: 256 on the power-of-two path as tuned in round 2; the ragged sizes measured faster
+  //  with wider workgroups down to ~100 of them -- 1000^2: Q = 2 18.6 us against 20.5 at Q = 1, 1500^2: 23.2 / 27.2)
+  const int min_wgs = ragged ? 100 : 256;
+  while (Q > 1 && (S * Q > 1024 || n1 / (Q * VEC) < min_wgs)) Q /= 2;
+  if (const char* fq = getenv("GPA_TRI_Q")) {   // diagnostic: force the number of column groups per workgroup
+    const int q = atoi(fq);
+    if ((q == 1 || q == 2 || q == 4) && S * q <= 1024) Q = q;
+  }
   if (S * Q > 64) {
     const int cpw = 64 / Q;
     S = (S + cpw - 1) / cpw * cpw;
@@ -1630,8 +1638,7 @@ template <class T>
 hipError_t dispatch_colsolve_tri(const Impl* w, int compat, hipStream_t s, const double* part_norm, int nnorm, int it,
                                  double eps, double* part_rho, int* nrho, const void* zin) {
   constexpr int VEC = 16 / sizeof(T);
-  int Q, S, pad;
-  tri_geometry<T>(w->n0, w->n1, &Q, &S, &pad);
+  const int Q = w->triQ, S = w->triS;
   switch (Q) {
     case 4: return run_colsolve_tri<T, VEC, 4>(w, S, compat, s, part_norm, nnorm, it, eps, part_rho, nrho, zin);
     case 2: return run_colsolve_tri<T, VEC, 2>(w, S, compat, s, part_norm, nnorm, it, eps, part_rho, nrho, zin);
@@ -1804,9 +1811,11 @@ int ilog2_exact(int n) {
 hipError_t build_tritab(Impl* w, hipStream_t s, size_t* bytes) {
   const int n0 = w->n0, n1 = w->n1;
   int Q, S, pad;
-  if (w->dtype == 0) tri_geometry<float>(n0, n1, &Q, &S, &pad);
-  else tri_geometry<double>(n0, n1, &Q, &S, &pad);
+  if (w->dtype == 0) tri_geometry<float>(n0, n1, w->generic, &Q, &S, &pad);
+  else tri_geometry<double>(n0, n1, w->generic, &Q, &S, &pad);
   if (S * Q > 1024) return hipSuccess;
+  w->triQ = Q;
+  w->triS = S;
   const int R = w->dtype == 0 ? TriRows<float>::value : TriRows<double>::value;
   std::vector<TriCol> tc((size_t)n1);
   for (int j = 0; j < n1; ++j) {
