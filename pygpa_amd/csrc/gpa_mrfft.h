@@ -225,6 +225,45 @@ __device__ __forceinline__ void mr_run(cpx<T>* lds, const MrPlan& pl, const cpx<
 }
 #endif
 
+// A DFT of length n as the kernels see it: the transform above when n is smooth, otherwise Bluestein's chirp-z on a
+// smooth length L >= 2n - 1 (NOT a power of two: n = 1392 runs L = 2800 = 2^4 5^2 7, not 4096):
+//   X[k] = conj(c_k) sum_m (x[m] conj(c_m)) c_(k-m),  c_m = exp(i pi m^2 / n)
+// = chirp multiply -> FFT_L -> multiply by bspec = FFT_L(b) / L (b[m] = b[L-m] = c_m) -> inverse FFT_L -> chirp multiply,
+// all on the LDS image.  Tables (double on the host): chirp[m], m < n; bspec[k], k < L, natural order.
+struct MrDft {
+  MrPlan pl;    // the FFT that is run: length n, or L for chirp-z
+  int n;        // length of the DFT
+  int blue;     // 1: chirp-z
+};
+
+#if defined(__HIPCC__)
+// in: x[m] at lds[mr_pad(m)], m < n (slots n .. L-1 may hold anything); out: X[k] at lds[mr_pad(k)], k < n.
+// A barrier must have been passed before the call; ends with a barrier.  Every thread of the workgroup calls.
+template <int CAP, class T>
+__device__ __forceinline__ void mr_dft(cpx<T>* lds, const MrDft& d, const cpx<T>* W, const cpx<T>* __restrict__ chirp,
+                                       const cpx<T>* __restrict__ bspec, int tid) {
+  if (!d.blue) {
+    mr_run<CAP>(lds, d.pl, W, tid);
+    return;
+  }
+  const int n = d.n, L = d.pl.n, Tn = d.pl.T;
+  for (int m = tid; m < L; m += Tn) lds[mr_pad(m)] = m < n ? cmulc(lds[mr_pad(m)], chirp[m]) : cpx<T>{T(0), T(0)};
+  __syncthreads();
+  mr_run<CAP>(lds, d.pl, W, tid);
+  for (int k = tid; k < L; k += Tn) {
+    const cpx<T> v = cmul(lds[mr_pad(k)], bspec[k]);
+    lds[mr_pad(k)] = {v.x, -v.y};   // conjugated: the inverse transform is conj(FFT(conj .)), 1/L is in bspec
+  }
+  __syncthreads();
+  mr_run<CAP>(lds, d.pl, W, tid);
+  for (int k = tid; k < n; k += Tn) {
+    const cpx<T> v = lds[mr_pad(k)];
+    lds[mr_pad(k)] = cmulc(cpx<T>{v.x, -v.y}, chirp[k]);
+  }
+  __syncthreads();
+}
+#endif
+
 // host: fewest passes with radices <= 16 (composite ones included: 3000 = 15 10 10 2 instead of 5 5 5 3 8; every pass
 // costs one trip of the whole transform through LDS whatever its radix)
 inline int mr_min_passes(int n, int* out) {
@@ -287,6 +326,18 @@ inline bool mr_make_plan(int n, MrPlan* pl) {
   pl->T = want <= 256 ? want : need;
   if (pl->T < need) pl->T = need;
   return pl->T <= 1024 && (uint64_t)n * (uint64_t)n < (1ull << 32);
+}
+
+// host: the DFT plan of an arbitrary length: direct when n is smooth, otherwise chirp-z on the smallest smooth
+// L >= 2n - 1 that has a plan; false if nothing fits max_lds_elems complex elements of LDS
+inline bool mr_make_dft(int n, int max_lds_elems, MrDft* d) {
+  d->n = n;
+  d->blue = 0;
+  if (mr_make_plan(n, &d->pl)) return mr_lds_elems(n) <= max_lds_elems;
+  d->blue = 1;
+  for (int L = 2 * n - 1; mr_lds_elems(L) <= max_lds_elems; ++L)
+    if (mr_make_plan(L, &d->pl)) return true;
+  return false;
 }
 
 }  // namespace gpa

@@ -72,8 +72,9 @@ struct Impl {
   // generic sizes whose axis lengths factor into 2, 3, 5, 7, 11, 13 (and rows of a multiple of 4 pixels): the fused
   // 4-kernel iteration on the mixed-radix FFT (gpa_unwrap_mr.h) instead of the Bluestein kernels
   bool mr_ok;
-  MrPlan mr0, mr1;
-  void *mrW0, *mrW1;         // w_n^i = exp(-2 pi i / n * i) per axis
+  MrDft mr0, mr1;            // per axis: direct transform of a smooth length, or chirp-z on a smooth L >= 2n - 1
+  void *mrW0, *mrW1;         // twiddles of the transform that is run, w_L^i at mr_pad(i)
+  void *mrB0, *mrB1;         // chirp-z only: FFT_L(b) / L in natural order (the chirp itself is chirp0 / chirp1)
 };
 
 template <class T> struct C2 { static constexpr T pi = T(3.14159265358979323846), two_pi = T(6.28318530717958647692); };
@@ -1901,18 +1902,63 @@ hipError_t unwrap_workspace_create(int dtype, int n0, int n1, hipStream_t s, Unw
       if ((e = upload(dtype, ax == 0 ? &w->bspec0 : &w->bspec1, bs, &bytes, s)) != hipSuccess) return e;
       if ((e = upload(dtype, ax == 0 ? &w->gwk0 : &w->gwk1, wkv, &bytes, s)) != hipSuccess) return e;
     }
-    // fused mixed-radix path: both lengths smooth, rows of whole 4-pixel vectors (pq_kernel), one transform in LDS
-    w->mr_ok = !getenv("GPA_NO_MR") && (n1 % 4) == 0 && mr_make_plan(n0, &w->mr0) && mr_make_plan(n1, &w->mr1) &&
-               (size_t)mr_lds_elems(n0 > n1 ? n0 : n1) * 2 * w->rsz <= 159 * 1024;
+    // fused path on the mixed-radix engine: rows of whole 4-pixel vectors (pq_kernel) and, per axis, a transform that
+    // fits LDS -- length n itself when it is smooth, chirp-z on the smallest smooth L >= 2n - 1 otherwise
+    {
+      const int max_elems = (int)((size_t)159 * 1024 / (2 * w->rsz));
+      w->mr_ok = !getenv("GPA_NO_MR") && (n1 % 4) == 0 && mr_make_dft(n0, max_elems, &w->mr0) &&
+                 mr_make_dft(n1, max_elems, &w->mr1);
+      if (getenv("GPA_MR_FORCE_BLUESTEIN") && w->mr_ok) {   // diagnostic / tests: chirp-z also for smooth lengths
+        for (MrDft* d : {&w->mr0, &w->mr1}) {
+          if (d->blue) continue;
+          MrDft t = *d;
+          t.blue = 1;
+          bool found = false;
+          for (int L = 2 * d->n - 1; mr_lds_elems(L) <= max_elems && !found; ++L) found = mr_make_plan(L, &t.pl);
+          if (found) *d = t; else w->mr_ok = false;
+        }
+      }
+    }
     if (w->mr_ok) {
       for (int ax = 0; ax < 2; ++ax) {
-        const int n = ax == 0 ? n0 : n1;
-        std::vector<double> t((size_t)2 * mr_lds_elems(n), 0.0);   // entry k at mr_pad(k), see mr_store()
-        for (int k = 0; k < n; ++k) {
-          t[2 * (size_t)mr_pad(k)] = cos(-2.0 * M_PI * k / n);
-          t[2 * (size_t)mr_pad(k) + 1] = sin(-2.0 * M_PI * k / n);
+        const MrDft& d = ax == 0 ? w->mr0 : w->mr1;
+        const int L = d.pl.n;
+        std::vector<double> t((size_t)2 * mr_lds_elems(L), 0.0);   // entry k at mr_pad(k), see mr_store()
+        for (int k = 0; k < L; ++k) {
+          t[2 * (size_t)mr_pad(k)] = cos(-2.0 * M_PI * k / L);
+          t[2 * (size_t)mr_pad(k) + 1] = sin(-2.0 * M_PI * k / L);
         }
         if ((e = upload(dtype, ax == 0 ? &w->mrW0 : &w->mrW1, t, &bytes, s)) != hipSuccess) return e;
+        if (d.blue) {
+          // FFT_L(b) / L, b[m] = b[L - m] = exp(i pi m^2 / n), by the engine's own passes in double on the host
+          std::vector<cpx<double>> W((size_t)mr_lds_elems(L)), img((size_t)mr_lds_elems(L), cpx<double>{0.0, 0.0});
+          std::vector<cpx<double>> regs((size_t)MR_REGS * d.pl.T);
+          for (int k = 0; k < L; ++k) W[mr_pad(k)] = {t[2 * (size_t)mr_pad(k)], t[2 * (size_t)mr_pad(k) + 1]};
+          for (int m = 0; m < d.n; ++m) {
+            const long long mm = ((long long)m * m) % (2LL * d.n);
+            const cpx<double> c = {cos(M_PI * (double)mm / d.n), sin(M_PI * (double)mm / d.n)};
+            img[mr_pad(m)] = c;
+            if (m > 0) img[mr_pad(L - m)] = c;
+          }
+          for (int p = 0; p < d.pl.np; ++p) {
+#define GPA_HOST_PASS(R)                                                                                              \
+  case R:                                                                                                             \
+    for (int tt = 0; tt < d.pl.T; ++tt) mr_load<double, R>(&regs[(size_t)MR_REGS * tt], img.data(), L, tt, d.pl.T);    \
+    for (int tt = 0; tt < d.pl.T; ++tt)                                                                               \
+      mr_store<double, R>(&regs[(size_t)MR_REGS * tt], img.data(), L, d.pl.stride[p], d.pl.magic[p], tt, d.pl.T,       \
+                          W.data());                                                                                  \
+    break;
+            switch (d.pl.radix[p]) {
+              GPA_HOST_PASS(2) GPA_HOST_PASS(3) GPA_HOST_PASS(4) GPA_HOST_PASS(5) GPA_HOST_PASS(6) GPA_HOST_PASS(7)
+              GPA_HOST_PASS(8) GPA_HOST_PASS(10) GPA_HOST_PASS(11) GPA_HOST_PASS(12) GPA_HOST_PASS(13) GPA_HOST_PASS(14)
+              GPA_HOST_PASS(15) GPA_HOST_PASS(16)
+            }
+#undef GPA_HOST_PASS
+          }
+          std::vector<double> bs((size_t)2 * L);
+          for (int k = 0; k < L; ++k) { bs[2 * k] = img[mr_pad(k)].x / L; bs[2 * k + 1] = img[mr_pad(k)].y / L; }
+          if ((e = upload(dtype, ax == 0 ? &w->mrB0 : &w->mrB1, bs, &bytes, s)) != hipSuccess) return e;
+        }
       }
     }
     for (int compat = 0; compat < 2; ++compat) {
@@ -1994,7 +2040,7 @@ void unwrap_workspace_destroy(UnwrapWorkspace* ws) {
   void* bufs[] = {w->r, w->p, w->p2, w->q, w->z, w->tw0, w->tw1, w->wk1, w->wk0s, w->ha0[0], w->ha0[1], w->ham0[0],
                   w->ham0[1], w->hb1[0], w->hb1[1], w->scal, w->flags, w->part, w->btw0, w->btw1, w->chirp0, w->chirp1,
                   w->bspec0, w->bspec1, w->gwk0, w->gwk1, w->gha0[0], w->gha0[1], w->gham0[0], w->gham0[1], w->tritab,
-                  w->mrW0, w->mrW1};
+                  w->mrW0, w->mrW1, w->mrB0, w->mrB1};
   for (void* b : bufs)
     if (b) hipFree(b);
   for (int j = 2; j < w->nring; ++j)

@@ -23,13 +23,14 @@ __device__ __forceinline__ int mr_slot_of(int c, int n) { return (c & 1) ? n - 1
 // rows: R = DCT-II_rows(r) (it == 0, in place) or R -= alpha DCT-II_rows(q) with the partial ||r||^2 (it > 0)
 template <class T, int MAXT>
 __global__ __launch_bounds__(MAXT) void mr_rowdct_fused_kernel(
-    T* __restrict__ r, const T* __restrict__ q, int n0, const MrPlan pl, int rs, const cpx<T>* __restrict__ W,
+    T* __restrict__ r, const T* __restrict__ q, int n0, const MrDft d, int rs, const cpx<T>* __restrict__ W,
+    const cpx<T>* __restrict__ chirp, const cpx<T>* __restrict__ bspec,
     const cpx<T>* __restrict__ wk, const int* flags, const double* part_pq, int npq, double* part_norm, double* scal,
     int it, int ring) {
   if (flags[1]) return;
   extern __shared__ __attribute__((aligned(16))) char smem[];
   __shared__ double sh[32];
-  const int n = pl.n, Tn = pl.T;
+  const int n = d.n, Tn = d.pl.T;
   const int tid = threadIdx.x % Tn, f = threadIdx.x / Tn, nf = blockDim.x / Tn;
   cpx<T>* lds = reinterpret_cast<cpx<T>*>(smem) + (size_t)f * rs;
   const int pr = blockIdx.x * nf + f;
@@ -66,7 +67,7 @@ __global__ __launch_bounds__(MAXT) void mr_rowdct_fused_kernel(
     }
   }
   __syncthreads();   // (it == 0, in place: both rows are in LDS before any bin is written)
-  mr_run<MAXT>(lds, pl, W, tid);
+  mr_dft<MAXT>(lds, d, W, chirp, bspec, tid);
   double sq = 0;
   {
     Vec4<T> ra[NV], rb[NV];
@@ -115,13 +116,14 @@ __global__ __launch_bounds__(MAXT) void mr_rowdct_fused_kernel(
 // rows: z = DCT-III_rows(Z), p = z + beta p_prev -> the ring slot of this iteration
 template <class T, int MAXT>
 __global__ __launch_bounds__(MAXT) void mr_rowidct_p_kernel(
-    const T* __restrict__ Z, const T* __restrict__ pin, T* __restrict__ pout, int n0, const MrPlan pl, int rs,
-    const cpx<T>* __restrict__ W, const cpx<T>* __restrict__ wk, const int* flags, const double* part_rho, int nrho,
+    const T* __restrict__ Z, const T* __restrict__ pin, T* __restrict__ pout, int n0, const MrDft d, int rs,
+    const cpx<T>* __restrict__ W, const cpx<T>* __restrict__ chirp, const cpx<T>* __restrict__ bspec,
+    const cpx<T>* __restrict__ wk, const int* flags, const double* part_rho, int nrho,
     double* scal, int it) {
   if (flags[1]) return;
   extern __shared__ __attribute__((aligned(16))) char smem[];
   __shared__ double sh[32];
-  const int n = pl.n, Tn = pl.T;
+  const int n = d.n, Tn = d.pl.T;
   const int tid = threadIdx.x % Tn, f = threadIdx.x / Tn, nf = blockDim.x / Tn;
   cpx<T>* lds = reinterpret_cast<cpx<T>*>(smem) + (size_t)f * rs;
   const int pr = blockIdx.x * nf + f;
@@ -174,7 +176,7 @@ __global__ __launch_bounds__(MAXT) void mr_rowidct_p_kernel(
     }
   }
   __syncthreads();
-  mr_run<MAXT>(lds, pl, W, tid);
+  mr_dft<MAXT>(lds, d, W, chirp, bspec, tid);
   const T inv_n = T(1) / T(n);
   {
     Vec4<T> pa4[NV], pb4[NV];
@@ -206,13 +208,14 @@ __global__ __launch_bounds__(MAXT) void mr_rowidct_p_kernel(
 // just applied, partial rho = <r, z> from the packed spectra (see WgDCT::solve_combine for the Parseval argument)
 template <class T, int MAXT>
 __global__ __launch_bounds__(MAXT) void mr_colsolve_kernel(
-    const T* __restrict__ Zin, T* __restrict__ Z, int n1, const MrPlan pl, int rs, const cpx<T>* __restrict__ W,
+    const T* __restrict__ Zin, T* __restrict__ Z, int n1, const MrDft d, int rs, const cpx<T>* __restrict__ W,
+    const cpx<T>* __restrict__ chirp, const cpx<T>* __restrict__ bspec,
     const cpx<T>* __restrict__ wk, const T* __restrict__ ha, const T* __restrict__ ham, const T* __restrict__ hb,
     int* flags, const double* part_norm, int nnorm, int it, double eps, double* scal, double* part_rho) {
   if (flags[1]) return;
   extern __shared__ __attribute__((aligned(16))) char smem[];
   __shared__ double sh[32];
-  const int n = pl.n, Tn = pl.T, nf = blockDim.x / Tn;
+  const int n = d.n, Tn = d.pl.T, nf = blockDim.x / Tn;
   // column pair fastest in the thread index: neighbouring lanes read neighbouring columns
   const int f = threadIdx.x % nf, tid = threadIdx.x / nf;
   cpx<T>* lds = reinterpret_cast<cpx<T>*>(smem) + (size_t)f * rs;
@@ -258,7 +261,7 @@ __global__ __launch_bounds__(MAXT) void mr_colsolve_kernel(
     if (stop) return;
   }
   __syncthreads();
-  mr_run<MAXT>(lds, pl, W, tid);
+  mr_dft<MAXT>(lds, d, W, chirp, bspec, tid);
   // bins k and n - k of the packed spectrum into registers, then (after a barrier) the solve in place
   cpx<T> zk[MR_REGS], zm[MR_REGS];
 #pragma unroll
@@ -299,7 +302,7 @@ __global__ __launch_bounds__(MAXT) void mr_colsolve_kernel(
     }
   }
   __syncthreads();
-  mr_run<MAXT>(lds, pl, W, tid);
+  mr_dft<MAXT>(lds, d, W, chirp, bspec, tid);
   for (int row = tid; row < n; row += Tn) {
     const size_t o = (size_t)row * n1;
     const cpx<T> v = lds[mr_pad(mr_slot_of(row, n))];
@@ -344,14 +347,15 @@ inline int mr_pick_nf(int pairs, int T, int cap, size_t lds_per_transform) {
 template <class T>
 hipError_t run_mr_rowdct_fused(const Impl* w, const void* q, int ring, const double* part_pq, int npq,
                                double* part_norm, int it, int* nnorm, hipStream_t s) {
-  const MrPlan& pl = w->mr1;
+  const MrDft& d = w->mr1;
+  const MrPlan& pl = d.pl;
   const int rs = mr_lds_elems(pl.n), pairs = (w->n0 + 1) / 2;
   const int nf = mr_pick_nf(pairs, pl.T, 256, (size_t)rs * sizeof(cpx<T>));
   const int grid = (pairs + nf - 1) / nf, threads = nf * pl.T;
   const size_t lds = (size_t)nf * rs * sizeof(cpx<T>);
   *nnorm = grid;
   GPA_PROF("rowdct_fused_kernel", s);
-  GPA_MR_LAUNCH(mr_rowdct_fused_kernel, threads, (T*)w->r, (const T*)q, w->n0, pl, rs, (const cpx<T>*)w->mrW1,
+  GPA_MR_LAUNCH(mr_rowdct_fused_kernel, threads, (T*)w->r, (const T*)q, w->n0, d, rs, (const cpx<T>*)w->mrW1, (const cpx<T>*)w->chirp1, (const cpx<T>*)w->mrB1,
                 (const cpx<T>*)w->gwk1, w->flags, part_pq, npq, part_norm, w->scal, it, ring);
   return hipGetLastError();
 }
@@ -359,21 +363,23 @@ hipError_t run_mr_rowdct_fused(const Impl* w, const void* q, int ring, const dou
 template <class T>
 hipError_t run_mr_rowidct_p(const Impl* w, const void* pin, void* pout, const double* part_rho, int nrho, int it,
                             hipStream_t s) {
-  const MrPlan& pl = w->mr1;
+  const MrDft& d = w->mr1;
+  const MrPlan& pl = d.pl;
   const int rs = mr_lds_elems(pl.n), pairs = (w->n0 + 1) / 2;
   const int nf = mr_pick_nf(pairs, pl.T, 256, (size_t)rs * sizeof(cpx<T>));
   const int grid = (pairs + nf - 1) / nf, threads = nf * pl.T;
   const size_t lds = (size_t)nf * rs * sizeof(cpx<T>);
   GPA_PROF("rowidct_p_kernel", s);
-  GPA_MR_LAUNCH(mr_rowidct_p_kernel, threads, (const T*)w->z, (const T*)pin, (T*)pout, w->n0, pl, rs,
-                (const cpx<T>*)w->mrW1, (const cpx<T>*)w->gwk1, w->flags, part_rho, nrho, w->scal, it);
+  GPA_MR_LAUNCH(mr_rowidct_p_kernel, threads, (const T*)w->z, (const T*)pin, (T*)pout, w->n0, d, rs,
+                (const cpx<T>*)w->mrW1, (const cpx<T>*)w->chirp1, (const cpx<T>*)w->mrB1, (const cpx<T>*)w->gwk1, w->flags, part_rho, nrho, w->scal, it);
   return hipGetLastError();
 }
 
 template <class T>
 hipError_t run_mr_colsolve(const Impl* w, int compat, hipStream_t s, const double* part_norm, int nnorm, int it,
                            double eps, double* part_rho, int* nrho, const void* zin) {
-  const MrPlan& pl = w->mr0;
+  const MrDft& d = w->mr0;
+  const MrPlan& pl = d.pl;
   const int rs = mr_lds_elems(pl.n), pairs = (w->n1 + 1) / 2;
   // f64: 512 threads at most, so that the 16 + 16 bins a thread holds in the solve fit 256 registers
   const int nf = mr_pick_nf(pairs, pl.T, sizeof(T) == 4 ? 1024 : 512, (size_t)rs * sizeof(cpx<T>));
@@ -381,8 +387,8 @@ hipError_t run_mr_colsolve(const Impl* w, int compat, hipStream_t s, const doubl
   const size_t lds = (size_t)nf * rs * sizeof(cpx<T>);
   if (nrho) *nrho = grid;
   GPA_PROF("colsolve_kernel", s);
-  GPA_MR_LAUNCH(mr_colsolve_kernel, threads, (const T*)(zin ? zin : w->z), (T*)w->z, w->n1, pl, rs,
-                (const cpx<T>*)w->mrW0, (const cpx<T>*)w->gwk0, (const T*)w->gha0[compat], (const T*)w->gham0[compat],
+  GPA_MR_LAUNCH(mr_colsolve_kernel, threads, (const T*)(zin ? zin : w->z), (T*)w->z, w->n1, d, rs,
+                (const cpx<T>*)w->mrW0, (const cpx<T>*)w->chirp0, (const cpx<T>*)w->mrB0, (const cpx<T>*)w->gwk0, (const T*)w->gha0[compat], (const T*)w->gham0[compat],
                 (const T*)w->hb1[compat], w->flags, part_norm, nnorm, it, eps, w->scal, part_rho);
   return hipGetLastError();
 }

@@ -1125,3 +1125,49 @@ def test_random_smooth_shapes_unwrap_vs_oracle():
         assert iters == ref_iters, (shape, kmax, iters, ref_iters)
         got2, _ = plan.unwrap_prediff(np.diff(psi, axis=1), np.diff(psi, axis=0), weight, kmax=kmax)
         assert rel(got2, ref) < 1e-8, (shape, kmax)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize('shape', [(68, 68), (136, 116), (204, 236), (332, 332), (1392, 1040), (1006, 1004)])
+def test_chirpz_fused_unwrap_vs_oracle(shape, monkeypatch):
+    """sides with a prime factor > 13 (17, 29, 59, 83, 251, 503): the fused iteration with chirp-z DFTs on a smooth
+    L >= 2n - 1 of the mixed-radix engine (transform-free columns when square) against the oracle and against
+    the power-of-two Bluestein path (GPA_NO_MR=1)"""
+    psi, weight = _unwrap_case(shape, 7 + shape[1])
+    for kmax in (6, 30):
+        ref, ref_iters = orc.unwrap(psi, weight=weight, kmax=kmax, return_iters=True)
+        plan = _lib.Plan(shape, 1, np.float64)
+        got, iters = plan.unwrap(psi, weight, kmax=kmax)
+        assert rel(got, ref) < 1e-8 and iters == ref_iters, (shape, kmax, rel(got, ref), iters, ref_iters)
+        monkeypatch.setenv('GPA_NO_MR', '1')
+        plan_b = _lib.Plan(shape, 1, np.float64)
+        monkeypatch.delenv('GPA_NO_MR')
+        got_b, iters_b = plan_b.unwrap(psi, weight, kmax=kmax)
+        assert iters_b == iters and rel(got, got_b) < 1e-9
+        if shape[0] == shape[1]:
+            monkeypatch.setenv('GPA_COLSOLVE', 'fft')   # the chirp-z column kernel instead of the recursions
+            got_f, iters_f = plan.unwrap(psi, weight, kmax=kmax)
+            monkeypatch.delenv('GPA_COLSOLVE')
+            assert iters_f == iters and rel(got, got_f) < 1e-9
+        plan32 = _lib.Plan(shape, 1, np.float32)
+        got32, _ = plan32.unwrap(psi.astype(np.float32), weight.astype(np.float32), kmax=kmax)
+        assert rel(got32 - got32.mean(), ref - ref.mean()) < 2e-4, (shape, kmax)
+        for p in (plan, plan_b, plan32):
+            p.close()
+
+
+@pytest.mark.gpu
+def test_chirpz_forced_on_smooth_lengths(monkeypatch):
+    """GPA_MR_FORCE_BLUESTEIN=1: the chirp-z route on lengths that have a direct plan must give the direct route's
+    iterates"""
+    shape = (300, 200)
+    psi, weight = _unwrap_case(shape, 3)
+    plan = _lib.Plan(shape, 1, np.float64)
+    monkeypatch.setenv('GPA_MR_FORCE_BLUESTEIN', '1')
+    plan_z = _lib.Plan(shape, 1, np.float64)
+    monkeypatch.delenv('GPA_MR_FORCE_BLUESTEIN')
+    a, ia = plan.unwrap(psi, weight, kmax=25)
+    b, ib = plan_z.unwrap(psi, weight, kmax=25)
+    assert ia == ib and rel(a, b) < 1e-9
+    plan.close()
+    plan_z.close()
