@@ -182,6 +182,18 @@ int gpa_extract_displacement_field_async(gpa_plan* plan, const void* image, cons
                                          int kmax, void* u, void* lockins, int32_t* kidx);
 int gpa_last_iters(gpa_plan* plan, int* iters2);
 
+/* A STACK of images of the plan's shape in one call (device pointers; no counterpart in the reference,
+ * whose extract_displacement_field (geometric_phase_analysis.py:907-932) takes one image): images
+ * B x n0 x n1, u B x 2 x n0 x n1.  The sweep and the least squares run image after image; the 2 B
+ * weighted unwraps (phase_unwrap.py:282-350) share one set of kernel launches, which is what bounds a
+ * small image.  Results equal B separate gpa_extract_displacement_field_dev calls bit for bit.
+ * iters_out: 2 B iteration counts, or NULL to return without synchronising (gpa_plan_sync).
+ * Rows must be a multiple of 4 pixels.                                                          */
+int gpa_extract_displacement_field_batch_dev(gpa_plan* plan, const void* images, int B,
+                                             const double* kvecs, int P, const double* klists, int K,
+                                             double sigma, int mask_border, int kmax, void* u,
+                                             int* iters_out);
+
 /* tile stage of the multi-GPU path: sweep + phases/weights + per-pixel least squares of
  * extract_displacement_field (:919-926, :234-237) WITHOUT the unwrap; the gradient tiles of all
  * ranks are stitched and unwrapped once globally.  The image is used

@@ -49,6 +49,7 @@ SIGNATURES = {
     'gpa_extract_displacement_field_dev': (_i, [_vp, _vp, _vp, _i, _vp, _i, _d, _i, _i, _vp, _vp, _vp, _vp]),
     'gpa_extract_displacement_field_async': (_i, [_vp, _vp, _vp, _i, _vp, _i, _d, _i, _i, _vp, _vp, _vp]),
     'gpa_last_iters': (_i, [_vp, _vp]),
+    'gpa_extract_displacement_field_batch_dev': (_i, [_vp, _vp, _i, _vp, _i, _vp, _i, _d, _i, _i, _vp, _vp]),
     'gpa_extract_gradients': (_i, [_vp, _vp, _vp, _i, _vp, _i, _d, _i, _vp, _vp, _vp]),
     'gpa_mean_dev': (_i, [_vp, _vp, _sz, _dp]),
     'gpa_tile_gradients_dev': (_i, [_vp, _vp, _sz, _i, _i, _d, _vp, _i, _vp, _i, _d, _i, _i, _i, _i, _i,
@@ -433,6 +434,39 @@ class Plan:
                                                             klists.shape[1], float(sigma), int(mask_border), int(kmax),
                                                             _ptr(u_ptr), _ptr(lockins_ptr), _ptr(kidx_ptr)),
               'gpa_extract_displacement_field_async')
+
+    def extract_displacement_field_batch_dev(self, images_ptr, nimages, kvecs, klists, sigma, mask_border, kmax, u_ptr,
+                                             want_iters=True):
+        """a stack of `nimages` images (device pointers: images nimages x n0 x n1, u nimages x 2 x n0 x n1): sweeps
+        image after image, the 2 * nimages unwraps in one set of launches.  Returns the (nimages, 2) iteration counts,
+        or None without synchronising when want_iters is False (pair with sync())"""
+        kvecs = _f64(kvecs).reshape(-1, 2)
+        P = len(kvecs)
+        klists = _f64(klists).reshape(P, -1, 2)
+        it = (C.c_int * (2 * int(nimages)))() if want_iters else None
+        check(self.lib.gpa_extract_displacement_field_batch_dev(self.handle, _ptr(images_ptr), int(nimages), _ptr(kvecs), P,
+                                                                _ptr(klists), klists.shape[1], float(sigma), int(mask_border),
+                                                                int(kmax), _ptr(u_ptr), it),
+              'gpa_extract_displacement_field_batch_dev')
+        return None if it is None else np.array(it[:], dtype=np.int64).reshape(int(nimages), 2)
+
+    def extract_displacement_field_stack(self, images, kvecs, klists, sigma, mask_border, kmax=10):
+        """host arrays: images (B, n0, n1) -> u (B, 2, n0, n1) and the (B, 2) iteration counts, through
+        extract_displacement_field_batch_dev"""
+        images = np.ascontiguousarray(images, dtype=self.rdtype)
+        if images.ndim != 3 or images.shape[1:] != tuple(self.shape):
+            raise ValueError('images must be (B, %d, %d)' % tuple(self.shape))
+        B = images.shape[0]
+        d_img = DeviceBuffer(images.nbytes)
+        d_u = DeviceBuffer(2 * images.nbytes)
+        try:
+            d_img.upload(images)
+            iters = self.extract_displacement_field_batch_dev(d_img.ptr, B, kvecs, klists, sigma, mask_border, kmax, d_u.ptr)
+            u = d_u.download((B, 2) + tuple(self.shape), self.rdtype)
+        finally:
+            d_img.free()
+            d_u.free()
+        return u, iters
 
     def last_iters(self):
         it = (C.c_int * 2)()

@@ -238,6 +238,11 @@ struct gpa_plan {
   void* d_u = nullptr;            // 2 x n0 x n1
   double* d_kmat = nullptr;       // [max_peaks][2]
   UnwrapWorkspace uw{};
+  // batched driver (gpa_extract_displacement_field_batch_dev): one workspace for the 2 x images solves of a call
+  UnwrapWorkspace uwb{};
+  int uwb_images = 0;
+  void* d_wnorm_b = nullptr;      // images x n0 x n1
+  int* h_iters_b = nullptr;       // pinned: 4 ints per problem
   UnwrapWorkspace uw2{};          // second workspace + stream: the two components of u unwrap concurrently
   hipStream_t stream2 = nullptr;
   hipEvent_t ev_fork = nullptr, ev_join = nullptr;
@@ -586,6 +591,9 @@ void gpa_plan_destroy(gpa_plan* p) {
     if (b) hipFree(b);
   unwrap_workspace_destroy(&p->uw);
   unwrap_workspace_destroy(&p->uw2);
+  if (p->uwb_images) unwrap_workspace_destroy(&p->uwb);
+  if (p->d_wnorm_b) (void)hipFree(p->d_wnorm_b);
+  if (p->h_iters_b) (void)hipHostFree(p->h_iters_b);
   if (p->stream2) { hipStreamSynchronize(p->stream2); hipStreamDestroy(p->stream2); }
   if (p->ev_fork) hipEventDestroy(p->ev_fork);
   if (p->ev_join) hipEventDestroy(p->ev_join);
@@ -1060,6 +1068,72 @@ int gpa_extract_displacement_field_async(gpa_plan* p, const void* image, const d
                                          const double* klists, int K, double sigma, int mask_border, int kmax,
                                          void* u, void* lockins, int32_t* kidx) {
   return extract_enqueue(p, image, kvecs, P, klists, K, sigma, mask_border, kmax, u, lockins, kidx);
+}
+
+// A stack of images of one shape in one call: the sweep and the least squares run image after image, the
+// 2 x images weighted unwraps then share ONE set of launches (blockIdx.z = problem) -- a small image is bound by
+// its ~90 dependent unwrap launches, not by their work, so the stack costs little more than one image.
+// images: B x n0 x n1, u: B x 2 x n0 x n1 (device pointers), iters_out: 2 B counts (host, may be NULL: no
+// synchronisation then).  The results are those of B separate gpa_extract_displacement_field_dev calls, bit for bit.
+int gpa_extract_displacement_field_batch_dev(gpa_plan* p, const void* images, int B, const double* kvecs, int P,
+                                             const double* klists, int K, double sigma, int mask_border, int kmax,
+                                             void* u, int* iters_out) {
+  if (!p || !images || !kvecs || !klists || !u) return fail(GPA_ERR_ARG, "gpa_extract_displacement_field_batch: null argument");
+  if (B < 1 || B > 4096) return fail(GPA_ERR_ARG, "gpa_extract_displacement_field_batch: need 1 <= images <= 4096");
+  if (P < 2 || P > p->max_peaks) return fail(GPA_ERR_STATE, "gpa_extract_displacement_field_batch: need 2 <= P <= 8");
+  if (K < 1 || P * K > p->max_batch) return fail(GPA_ERR_STATE, "gpa_extract_displacement_field_batch: P*K exceeds max_batch");
+  if (kmax < 1) return fail(GPA_ERR_ARG, "kmax must be >= 1");
+  if (p->n1 % 4) return fail(GPA_ERR_STATE, "gpa_extract_displacement_field_batch: rows must be a multiple of 4 pixels");
+  HIP_TRY(hipSetDevice(p->device));
+  int Bx = 0;
+  TRY(extract_stage(p, kvecs, P, klists, K, sigma, &Bx));
+  const size_t npx = (size_t)p->n0 * p->n1;
+  if (p->uwb_images != B) {
+    HIP_TRY(hipStreamSynchronize(p->stream));
+    if (p->uwb_images) {
+      unwrap_workspace_destroy(&p->uwb);
+      (void)hipFree(p->d_wnorm_b);
+      (void)hipHostFree(p->h_iters_b);
+      p->uwb_images = 0;
+      p->d_wnorm_b = nullptr;
+      p->h_iters_b = nullptr;
+    }
+    size_t bb = 0;
+    hipError_t e = unwrap_workspace_create(p->dtype, p->n0, p->n1, p->stream, &p->uwb, &bb, 2 * B);
+    if (e != hipSuccess) {
+      unwrap_workspace_destroy(&p->uwb);
+      return fail(GPA_ERR_HIP, std::string("batched unwrap workspace: ") + hipGetErrorString(e));
+    }
+    e = hipMalloc(&p->d_wnorm_b, (size_t)B * npx * p->rsz);
+    if (e == hipSuccess) e = hipHostMalloc((void**)&p->h_iters_b, (size_t)8 * B * sizeof(int));
+    if (e != hipSuccess) {
+      unwrap_workspace_destroy(&p->uwb);
+      if (p->d_wnorm_b) (void)hipFree(p->d_wnorm_b);
+      p->d_wnorm_b = nullptr;
+      return fail(GPA_ERR_HIP, std::string("batched driver buffers: ") + hipGetErrorString(e));
+    }
+    p->uwb_images = B;
+  }
+  int nparts = 0;
+  for (int i = 0; i < B; ++i) {
+    const void* image = (const char*)images + (size_t)i * npx * p->rsz;
+    HIP_TRY(launch_mean(p->dtype, image, npx, p->d_scratch, p->d_mean, p->stream));
+    HIP_TRY(launch_passA(p->dtype, p->ax0, p->n1, image, p->d_mean, p->tb, p->Hx, p->tw0, p->Tbuf, Bx, p->stream));
+    TRY(passB_select(p, P, K, p->d_lockin, nullptr));
+    HIP_TRY(launch_reconstruct_setup(p->dtype, p->d_lockin, p->d_kmat, P, p->n0, p->n1, mask_border,
+                                     (char*)p->d_wnorm_b + (size_t)i * npx * p->rsz,
+                                     unwrap_residual_buffer(&p->uwb, 2 * i), unwrap_residual_buffer(&p->uwb, 2 * i + 1),
+                                     unwrap_partials_buffer(&p->uwb, 2 * i), unwrap_partials_buffer(&p->uwb, 2 * i + 1),
+                                     &nparts, p->stream));
+  }
+  hipError_t e = unwrap_enqueue_prepared(&p->uwb, p->d_wnorm_b, nparts, kmax, 1e-9, true, u, p->stream);
+  if (e == hipSuccess) e = unwrap_fetch_iters(&p->uwb, p->h_iters_b, p->stream);
+  if (e != hipSuccess) return fail(GPA_ERR_HIP, std::string("batched unwrap: ") + hipGetErrorString(e));
+  if (iters_out) {
+    HIP_TRY(hipStreamSynchronize(p->stream));
+    for (int j = 0; j < 2 * B; ++j) iters_out[j] = p->h_iters_b[4 * j];
+  }
+  return GPA_OK;
 }
 
 int gpa_last_iters(gpa_plan* p, int* iters2) {

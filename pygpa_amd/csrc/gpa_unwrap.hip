@@ -41,9 +41,17 @@ namespace {
 constexpr int MAXPART = 65536;   // one partial sum per image row / per grid-stride block
 constexpr int RING_MAX = 10;     // search directions kept so that phi is updated once per RING_MAX iterations
 constexpr int SC_ALPHA = 16;     // scal[SC_ALPHA + j % ring] = alpha of iteration j
+// Batched solves: blockIdx.z = problem.  The image-sized arrays of problem pb sit pb * pimg elements behind those of
+// problem 0, its scalars / flags / partial sums SCAL_N / FLAGS_N / PART_N entries behind; problems 2i and 2i + 1 (the
+// two displacement components of image i) share the weight of image i.  A launch with gridDim.z = 1 is the single
+// solve it always was.
+constexpr int SCAL_N = SC_ALPHA + RING_MAX + 6;
+constexpr int FLAGS_N = 4;
+constexpr size_t PART_N = (size_t)3 * MAXPART;
 
 struct Impl {
   int dtype, n0, n1, lg0, lg1;
+  int nprob;                 // problems solved per launch (blockIdx.z): 1, or 2 x images of a batched driver call
   bool supported;
   size_t rsz;
   void *r, *p, *p2, *q, *z;   // p / p2: double-buffered search direction (= ring[0], ring[1])
@@ -211,6 +219,9 @@ __global__ __launch_bounds__(256) void setup_kernel(const T* __restrict__ a, con
 
 // scalar kernels (one block each) -------------------------------------------
 __global__ void scal_init_kernel(const double* part, int nparts, double* scal, int* flags) {
+  part += blockIdx.z * PART_N;
+  scal += blockIdx.z * SCAL_N;
+  flags += blockIdx.z * FLAGS_N;
   __shared__ double sh[256];
   double acc = 0;
   for (int i = threadIdx.x; i < nparts; i += 256) acc += part[i];
@@ -321,7 +332,19 @@ __global__ __launch_bounds__(256) void pq_kernel(const T* __restrict__ z, const 
                                                 T* __restrict__ pout, const T* __restrict__ w, int n0, int n1,
                                                 T* __restrict__ q, double* part, double* scal,
                                                 const int* flags, const double* part_rho, int nrho, int it,
-                                                int band) {
+                                                int band, size_t pimg = 0) {
+  {
+    const size_t pb = blockIdx.z;
+    z += pb * pimg;
+    if (pin) pin += pb * pimg;
+    if (pout) pout += pb * pimg;
+    if (w) w += (pb >> 1) * pimg;   // the two components of an image share its weight
+    q += pb * pimg;
+    part += pb * PART_N;
+    scal += pb * SCAL_N;
+    flags += pb * FLAGS_N;
+    if (part_rho) part_rho += pb * PART_N;
+  }
   if (flags[1]) return;
   __shared__ double sh[256];
   bool first;
@@ -532,7 +555,16 @@ template <class T, int LG>
 __global__ __launch_bounds__((RowGeom<T, LG>::THREADS), (sizeof(T) == 8 ? GPA_F64_WAVES : GPA_DCTF_WAVES)) void rowdct_fused_kernel(
     T* __restrict__ r, const T* __restrict__ q, int n0, const cpx<T>* __restrict__ twtab,
     const cpx<T>* __restrict__ wk, const int* flags, const double* part_pq, int npq, double* part_norm,
-    double* scal, int it, int ring) {
+    double* scal, int it, int ring, size_t pimg) {
+  {
+    const size_t pb = blockIdx.z;
+    r += pb * pimg;
+    q += pb * pimg;
+    flags += pb * FLAGS_N;
+    scal += pb * SCAL_N;
+    part_pq += pb * PART_N;
+    part_norm += pb * PART_N;
+  }
   // The fused iteration keeps the residual as its row spectrum R = DCT-II_rows(r) (the only consumers of r
   // are this transform, ||r|| and <r,z>, and the last two follow from the spectra by Parseval):
   //   it == 0: r (spatial, from the set-up) -> R, in place;
@@ -627,6 +659,9 @@ __global__ __launch_bounds__((RowGeom<T, LG>::THREADS), (sizeof(T) == 8 ? GPA_F6
 // kernel will compute it; the residual of the last iteration is not formed, nothing reads it)
 __global__ __launch_bounds__(256) void final_alpha_kernel(double* scal, const double* part_pq, int npq, int it, int ring,
                                                          const int* flags) {
+  scal += blockIdx.z * SCAL_N;
+  part_pq += blockIdx.z * PART_N;
+  flags += blockIdx.z * FLAGS_N;
   if (flags[1]) return;
   __shared__ double sh[256];
   const double pq = reduce_partials(part_pq, npq, sh);
@@ -641,7 +676,11 @@ template <class T> struct RingPtrs { const T* p[RING_MAX]; };
 template <class T>
 __global__ __launch_bounds__(256) void phi_flush_kernel(RingPtrs<T> ringp, int ring, T* __restrict__ phi, size_t count4,
                                                        const double* __restrict__ scal, const int* __restrict__ flags,
-                                                       int init) {
+                                                       int init, size_t pimg) {
+  const size_t pb = blockIdx.z;
+  phi += pb * pimg;
+  scal += pb * SCAL_N;
+  flags += pb * FLAGS_N;
   // init: phi has not been written yet (prepared start) -- this flush starts from 0 instead of reading it
   const int a = flags[2], b = flags[0];
   if (a >= b && !init) return;
@@ -650,15 +689,19 @@ __global__ __launch_bounds__(256) void phi_flush_kernel(RingPtrs<T> ringp, int r
     if (!init) f = reinterpret_cast<const Vec4<T>*>(phi)[i];
     for (int j = a; j < b; ++j) {
       const T alpha = (T)scal[SC_ALPHA + j % ring];
-      const Vec4<T> pv = reinterpret_cast<const Vec4<T>*>(ringp.p[j % ring])[i];
+      const Vec4<T> pv = reinterpret_cast<const Vec4<T>*>(ringp.p[j % ring] + pb * pimg)[i];
 #pragma unroll
       for (int c = 0; c < 4; ++c) f.v[c] += alpha * pv.v[c];
     }
     reinterpret_cast<Vec4<T>*>(phi)[i] = f;
   }
 }
-__global__ void phi_commit_kernel(int* flags) { flags[2] = flags[0]; }
+__global__ void phi_commit_kernel(int* flags) {
+  flags += blockIdx.z * FLAGS_N;
+  flags[2] = flags[0];
+}
 __global__ void final_count_kernel(int* flags, int kmax) {
+  flags += blockIdx.z * FLAGS_N;
   if (flags[1]) return;
   flags[0] = kmax;
   flags[1] = 1;
@@ -675,7 +718,16 @@ __global__ __launch_bounds__((ColGeom<T, LG>::THREADS)) void colsolve_kernel(T* 
                                                                           int* flags, const double* part_norm,
                                                                           int nnorm, int it, double eps,
                                                                           double* scal, double* part_rho,
-                                                                          const T* __restrict__ Zin) {
+                                                                          const T* __restrict__ Zin, size_t pimg) {
+  {
+    const size_t pb = blockIdx.z;
+    Z += pb * pimg;
+    if (Zin) Zin += pb * pimg;
+    flags += pb * FLAGS_N;
+    scal += pb * SCAL_N;
+    part_norm += pb * PART_N;
+    part_rho += pb * PART_N;
+  }
   if (flags[1]) return;
   using F = WgFFT<T, LG>;
   using D = WgDCT<T, LG>;
@@ -858,7 +910,16 @@ template <class T, int VEC, int Q, int R, bool RAGGED>
 __global__ __launch_bounds__(1024) void colsolve_tri_kernel(const T* __restrict__ Zin, T* __restrict__ Z, int n0, int n1,
                                                            const TriCol* __restrict__ tab, const T* __restrict__ hb,
                                                            int* flags, const double* part_norm, int nnorm, int it,
-                                                           double eps, double* scal, double* part_rho) {
+                                                           double eps, double* scal, double* part_rho, size_t pimg) {
+  {
+    const size_t pb = blockIdx.z;
+    Zin += pb * pimg;
+    Z += pb * pimg;
+    flags += pb * FLAGS_N;
+    scal += pb * SCAL_N;
+    part_norm += pb * PART_N;
+    part_rho += pb * PART_N;
+  }
   if (flags[1]) return;
   extern __shared__ __attribute__((aligned(16))) char smem[];
   double* lds = reinterpret_cast<double*>(smem);
@@ -1106,7 +1167,16 @@ template <class T, int LG>
 __global__ __launch_bounds__((RowGeom<T, LG>::THREADS), (GPA_IDCTP_COND ? 4 : (sizeof(T) == 8 ? GPA_F64_WAVES : 1))) void rowidct_p_kernel(
     const T* __restrict__ Z, const T* __restrict__ pin, T* __restrict__ pout, int n0,
     const cpx<T>* __restrict__ twtab, const cpx<T>* __restrict__ wk, const int* flags, const double* part_rho,
-    int nrho, double* scal, int it) {
+    int nrho, double* scal, int it, size_t pimg) {
+  {
+    const size_t pb = blockIdx.z;
+    Z += pb * pimg;
+    pin += pb * pimg;
+    pout += pb * pimg;
+    flags += pb * FLAGS_N;
+    scal += pb * SCAL_N;
+    part_rho += pb * PART_N;
+  }
   if (flags[1]) return;
   using F = WgFFT<T, LG>;
   using D = WgDCT<T, LG>;
@@ -1515,10 +1585,10 @@ hipError_t run_colsolve(const Impl* w, int compat, hipStream_t s, const double* 
     const int npairs = w->n1 / 2, grid = (npairs + G::CC - 1) / G::CC;
     if (nrho) *nrho = grid;
     GPA_PROF("colsolve_kernel", s);
-    kern<<<grid, G::THREADS, G::LDS_BYTES, s>>>((T*)w->z, w->n1, (const cpx<T>*)w->tw0, (const cpx<T>*)w->wk0s,
+    kern<<<dim3(grid, 1, w->nprob), G::THREADS, G::LDS_BYTES, s>>>((T*)w->z, w->n1, (const cpx<T>*)w->tw0, (const cpx<T>*)w->wk0s,
                                                  (const T*)w->ha0[compat], (const T*)w->ham0[compat],
                                                  (const T*)w->hb1[compat], w->flags, part_norm, nnorm, it, eps, w->scal,
-                                                 part_rho, (const T*)zin);
+                                                 part_rho, (const T*)zin, (size_t)w->n0 * w->n1);
     return hipGetLastError();
   }
 }
@@ -1535,9 +1605,9 @@ hipError_t run_rowdct_fused(const Impl* w, const void* q, int ring, const double
     const int npairs = w->n0 / 2, grid = (npairs + G::NF - 1) / G::NF;
     *nnorm = grid;
     GPA_PROF("rowdct_fused_kernel", s);
-    kern<<<grid, G::THREADS, G::LDS_BYTES, s>>>((T*)w->r, (const T*)q, w->n0, (const cpx<T>*)w->tw1,
+    kern<<<dim3(grid, 1, w->nprob), G::THREADS, G::LDS_BYTES, s>>>((T*)w->r, (const T*)q, w->n0, (const cpx<T>*)w->tw1,
                                                  (const cpx<T>*)w->wk1, w->flags, part_pq, npq, part_norm, w->scal, it,
-                                                 ring);
+                                                 ring, (size_t)w->n0 * w->n1);
     return hipGetLastError();
   }
 }
@@ -1560,8 +1630,8 @@ hipError_t run_rowidct_p(const Impl* w, const void* pin, void* pout, const doubl
     if (e != hipSuccess) return e;
     const int npairs = w->n0 / 2, grid = (npairs + G::NF - 1) / G::NF;
     GPA_PROF("rowidct_p_kernel", s);
-    kern<<<grid, G::THREADS, G::LDS_BYTES, s>>>((const T*)w->z, (const T*)pin, (T*)pout, w->n0, (const cpx<T>*)w->tw1,
-                                                 (const cpx<T>*)w->wk1, w->flags, part_rho, nrho, w->scal, it);
+    kern<<<dim3(grid, 1, w->nprob), G::THREADS, G::LDS_BYTES, s>>>((const T*)w->z, (const T*)pin, (T*)pout, w->n0, (const cpx<T>*)w->tw1,
+                                                 (const cpx<T>*)w->wk1, w->flags, part_rho, nrho, w->scal, it, (size_t)w->n0 * w->n1);
     return hipGetLastError();
   }
 }
@@ -1621,15 +1691,17 @@ hipError_t run_colsolve_tri(const Impl* w, int S, int compat, hipStream_t s, con
     static unsigned lds_set = 0;
     hipError_t e = set_dynamic_lds_once(reinterpret_cast<const void*>(kern), (int)lds, lds_set);
     if (e != hipSuccess) return e;
-    kern<<<grid, threads, lds, s>>>((const T*)(zin ? zin : w->z), (T*)w->z, w->n0, w->n1, (const TriCol*)w->tritab,
-                                    (const T*)w->hb1[compat], w->flags, part_norm, nnorm, it, eps, w->scal, part_rho);
+    kern<<<dim3(grid, 1, w->nprob), threads, lds, s>>>((const T*)(zin ? zin : w->z), (T*)w->z, w->n0, w->n1,
+                                    (const TriCol*)w->tritab, (const T*)w->hb1[compat], w->flags, part_norm, nnorm, it, eps,
+                                    w->scal, part_rho, (size_t)w->n0 * w->n1);
   } else {
     auto kern = colsolve_tri_kernel<T, VEC, Q, R, false>;
     static unsigned lds_set = 0;
     hipError_t e = set_dynamic_lds_once(reinterpret_cast<const void*>(kern), (int)lds, lds_set);
     if (e != hipSuccess) return e;
-    kern<<<grid, threads, lds, s>>>((const T*)(zin ? zin : w->z), (T*)w->z, w->n0, w->n1, (const TriCol*)w->tritab,
-                                    (const T*)w->hb1[compat], w->flags, part_norm, nnorm, it, eps, w->scal, part_rho);
+    kern<<<dim3(grid, 1, w->nprob), threads, lds, s>>>((const T*)(zin ? zin : w->z), (T*)w->z, w->n0, w->n1,
+                                    (const TriCol*)w->tritab, (const T*)w->hb1[compat], w->flags, part_norm, nnorm, it, eps,
+                                    w->scal, part_rho, (size_t)w->n0 * w->n1);
   }
   return hipGetLastError();
 }
@@ -1837,7 +1909,8 @@ hipError_t build_tritab(Impl* w, hipStream_t s, size_t* bytes) {
   return e;
 }
 
-hipError_t unwrap_workspace_create(int dtype, int n0, int n1, hipStream_t s, UnwrapWorkspace* ws, size_t* bytes_out) {
+hipError_t unwrap_workspace_create(int dtype, int n0, int n1, hipStream_t s, UnwrapWorkspace* ws, size_t* bytes_out,
+                                   int nprob) {
   Impl* w = new Impl();
   memset(w, 0, sizeof(Impl));
   ws->impl = w;
@@ -1847,6 +1920,7 @@ hipError_t unwrap_workspace_create(int dtype, int n0, int n1, hipStream_t s, Unw
   w->dtype = dtype;
   w->n0 = n0;
   w->n1 = n1;
+  w->nprob = nprob < 1 ? 1 : nprob;
   w->rsz = dtype == 0 ? 4 : 8;
   w->lg0 = ilog2_exact(n0);
   w->lg1 = ilog2_exact(n1);
@@ -1862,18 +1936,18 @@ hipError_t unwrap_workspace_create(int dtype, int n0, int n1, hipStream_t s, Unw
   hipError_t e;
   void** arrs[] = {&w->r, &w->p, &w->p2, &w->q, &w->z};
   for (void** a : arrs) {
-    e = hipMalloc(a, npx * w->rsz);
+    e = hipMalloc(a, npx * w->rsz * w->nprob);
     if (e != hipSuccess) return e;
-    bytes += npx * w->rsz;
+    bytes += npx * w->rsz * w->nprob;
   }
   w->ring[0] = w->p;
   w->ring[1] = w->p2;
   w->nring = 2;
-  e = hipMalloc((void**)&w->scal, (SC_ALPHA + RING_MAX + 6) * sizeof(double));
+  e = hipMalloc((void**)&w->scal, (size_t)SCAL_N * w->nprob * sizeof(double));
   if (e != hipSuccess) return e;
-  e = hipMalloc((void**)&w->flags, 4 * sizeof(int));
+  e = hipMalloc((void**)&w->flags, (size_t)FLAGS_N * w->nprob * sizeof(int));
   if (e != hipSuccess) return e;
-  e = hipMalloc((void**)&w->part, (size_t)3 * MAXPART * sizeof(double));
+  e = hipMalloc((void**)&w->part, PART_N * w->nprob * sizeof(double));
   if (e != hipSuccess) return e;
   if (w->supported && w->generic) {
     for (int ax = 0; ax < 2; ++ax) {
@@ -2092,9 +2166,10 @@ static hipError_t run_pcg(Impl* w, const void* a, const void* b, const void* wei
     const bool fused_path = (!w->generic || w->mr_ok) && (n1 % 4) == 0;
     if (!fused_path && (e = hipMemsetAsync(phi, 0, npx * w->rsz, s)) != hipSuccess) return e;
     GPA_PROF("scalar_kernels", s);
-    scal_init_kernel<<<1, 256, 0, s>>>(w->part, w->prepared_parts, w->scal, w->flags);
+    scal_init_kernel<<<dim3(1, 1, w->nprob), 256, 0, s>>>(w->part, w->prepared_parts, w->scal, w->flags);
   }
   const bool vec4 = (!w->generic || w->mr_ok) && (n1 % 4) == 0;   // pq_kernel needs 16-byte aligned rows
+  if (w->nprob > 1 && (a || !vec4)) return hipErrorNotSupported;   // batched: prepared start on the fused path only
   if (vec4) {
     // fused power-of-two path: 4 kernels per iteration, no scalar kernels.  The phi / r update
     // of iteration it-1 rides in the row-DCT kernel of iteration it; the stopping test is
@@ -2108,7 +2183,7 @@ static hipError_t run_pcg(Impl* w, const void* a, const void* b, const void* wei
     if (ring < 2) ring = 2;
     while (w->nring < ring) {
       void* buf = nullptr;
-      if (hipMalloc(&buf, npx * w->rsz) != hipSuccess) { (void)hipGetLastError(); break; }
+      if (hipMalloc(&buf, npx * w->rsz * w->nprob) != hipSuccess) { (void)hipGetLastError(); break; }
       w->ring[w->nring++] = buf;
     }
     if (w->nring < ring) ring = w->nring;   // out of memory: flush more often
@@ -2117,8 +2192,9 @@ static hipError_t run_pcg(Impl* w, const void* a, const void* b, const void* wei
     bool phi_unwritten = a == nullptr;   // prepared start: nobody has zeroed phi
     auto flush = [&]() {
       { GPA_PROF("phi_flush_kernel", s);
-        phi_flush_kernel<T><<<gl, 256, 0, s>>>(rp, ring, (T*)phi, npx / 4, w->scal, w->flags, phi_unwritten ? 1 : 0); }
-      { GPA_PROF("scalar_kernels", s); phi_commit_kernel<<<1, 1, 0, s>>>(w->flags); }
+        phi_flush_kernel<T><<<dim3(gl, 1, w->nprob), 256, 0, s>>>(rp, ring, (T*)phi, npx / 4, w->scal, w->flags,
+                                                                 phi_unwritten ? 1 : 0, npx); }
+      { GPA_PROF("scalar_kernels", s); phi_commit_kernel<<<dim3(1, 1, w->nprob), 1, 0, s>>>(w->flags); }
       phi_unwritten = false;
     };
     int nnorm = 0;
@@ -2131,12 +2207,13 @@ static hipError_t run_pcg(Impl* w, const void* a, const void* b, const void* wei
       T* pout = (T*)w->ring[it % ring];
       if ((e = dispatch_rowidct_p(w, pin, pout, part_rho, nrow, it, s)) != hipSuccess) return e;
       { GPA_PROF("pq_kernel", s);
-        pq_kernel<T, true><<<gpq, 256, 0, s>>>(pout, nullptr, nullptr, (const T*)weight, n0, n1, (T*)w->q, part_pq,
-                                               w->scal, w->flags, nullptr, 0, it, band); }
+        pq_kernel<T, true><<<dim3(gpq.x, gpq.y, w->nprob), 256, 0, s>>>(pout, nullptr, nullptr, (const T*)weight, n0, n1,
+                                                                        (T*)w->q, part_pq, w->scal, w->flags, nullptr, 0, it,
+                                                                        band, npx); }
     }
     { GPA_PROF("scalar_kernels", s);
-      final_alpha_kernel<<<1, 256, 0, s>>>(w->scal, part_pq, npq, kmax, ring, w->flags);
-      final_count_kernel<<<1, 1, 0, s>>>(w->flags, kmax); }
+      final_alpha_kernel<<<dim3(1, 1, w->nprob), 256, 0, s>>>(w->scal, part_pq, npq, kmax, ring, w->flags);
+      final_count_kernel<<<dim3(1, 1, w->nprob), 1, 0, s>>>(w->flags, kmax); }
     flush();
     return hipGetLastError();
   }
@@ -2184,8 +2261,14 @@ hipError_t unwrap_enqueue(UnwrapWorkspace* ws, const void* a, const void* b, con
                        : run_pcg<double>(w, a, b, weight, from_psi, kmax, eps, axes_compat ? 1 : 0, phi, s);
 }
 
-void* unwrap_residual_buffer(UnwrapWorkspace* ws) { return ws->impl ? ((Impl*)ws->impl)->r : nullptr; }
-double* unwrap_partials_buffer(UnwrapWorkspace* ws) { return ws->impl ? ((Impl*)ws->impl)->part : nullptr; }
+void* unwrap_residual_buffer(UnwrapWorkspace* ws, int problem) {
+  Impl* w = (Impl*)ws->impl;
+  return w ? (char*)w->r + (size_t)problem * w->n0 * w->n1 * w->rsz : nullptr;
+}
+double* unwrap_partials_buffer(UnwrapWorkspace* ws, int problem) {
+  Impl* w = (Impl*)ws->impl;
+  return w ? w->part + (size_t)problem * PART_N : nullptr;
+}
 
 hipError_t unwrap_enqueue_prepared(UnwrapWorkspace* ws, const void* weight, int nparts, int kmax, double eps,
                                    bool axes_compat, void* phi, hipStream_t s) {
@@ -2212,7 +2295,8 @@ hipError_t unwrap_finish(UnwrapWorkspace* ws, int* iters_out, hipStream_t s) {
 hipError_t unwrap_fetch_iters(UnwrapWorkspace* ws, int* host_pinned, hipStream_t s) {
   Impl* w = (Impl*)ws->impl;
   if (!w || !w->supported) return hipErrorNotSupported;
-  return hipMemcpyAsync(host_pinned, w->flags, sizeof(int), hipMemcpyDeviceToHost, s);
+  return hipMemcpyAsync(host_pinned, w->flags, w->nprob == 1 ? sizeof(int) : (size_t)FLAGS_N * w->nprob * sizeof(int),
+                        hipMemcpyDeviceToHost, s);
 }
 
 hipError_t unwrap_run(UnwrapWorkspace* ws, const void* a, const void* b, const void* weight, bool from_psi, int kmax,

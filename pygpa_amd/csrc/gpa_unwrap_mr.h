@@ -26,7 +26,16 @@ __global__ __launch_bounds__(MAXT) void mr_rowdct_fused_kernel(
     T* __restrict__ r, const T* __restrict__ q, int n0, const MrDft d, int rs, const cpx<T>* __restrict__ W,
     const cpx<T>* __restrict__ chirp, const cpx<T>* __restrict__ bspec,
     const cpx<T>* __restrict__ wk, const int* flags, const double* part_pq, int npq, double* part_norm, double* scal,
-    int it, int ring) {
+    int it, int ring, size_t pimg) {
+  {
+    const size_t pb = blockIdx.z;
+    r += pb * pimg;
+    q += pb * pimg;
+    flags += pb * FLAGS_N;
+    scal += pb * SCAL_N;
+    part_pq += pb * PART_N;
+    part_norm += pb * PART_N;
+  }
   if (flags[1]) return;
   extern __shared__ __attribute__((aligned(16))) char smem[];
   __shared__ double sh[32];
@@ -119,7 +128,16 @@ __global__ __launch_bounds__(MAXT) void mr_rowidct_p_kernel(
     const T* __restrict__ Z, const T* __restrict__ pin, T* __restrict__ pout, int n0, const MrDft d, int rs,
     const cpx<T>* __restrict__ W, const cpx<T>* __restrict__ chirp, const cpx<T>* __restrict__ bspec,
     const cpx<T>* __restrict__ wk, const int* flags, const double* part_rho, int nrho,
-    double* scal, int it) {
+    double* scal, int it, size_t pimg) {
+  {
+    const size_t pb = blockIdx.z;
+    Z += pb * pimg;
+    pin += pb * pimg;
+    pout += pb * pimg;
+    flags += pb * FLAGS_N;
+    scal += pb * SCAL_N;
+    part_rho += pb * PART_N;
+  }
   if (flags[1]) return;
   extern __shared__ __attribute__((aligned(16))) char smem[];
   __shared__ double sh[32];
@@ -211,7 +229,16 @@ __global__ __launch_bounds__(MAXT) void mr_colsolve_kernel(
     const T* __restrict__ Zin, T* __restrict__ Z, int n1, const MrDft d, int rs, const cpx<T>* __restrict__ W,
     const cpx<T>* __restrict__ chirp, const cpx<T>* __restrict__ bspec,
     const cpx<T>* __restrict__ wk, const T* __restrict__ ha, const T* __restrict__ ham, const T* __restrict__ hb,
-    int* flags, const double* part_norm, int nnorm, int it, double eps, double* scal, double* part_rho) {
+    int* flags, const double* part_norm, int nnorm, int it, double eps, double* scal, double* part_rho, size_t pimg) {
+  {
+    const size_t pb = blockIdx.z;
+    Zin += pb * pimg;
+    Z += pb * pimg;
+    flags += pb * FLAGS_N;
+    scal += pb * SCAL_N;
+    part_norm += pb * PART_N;
+    part_rho += pb * PART_N;
+  }
   if (flags[1]) return;
   extern __shared__ __attribute__((aligned(16))) char smem[];
   __shared__ double sh[32];
@@ -341,7 +368,7 @@ inline int mr_pick_nf(int pairs, int T, int cap, size_t lds_per_transform) {
     static unsigned lds_set = 0;                                                                               \
     hipError_t e = set_dynamic_lds_once(reinterpret_cast<const void*>(kern), MR_LDS_MAX, lds_set);               \
     if (e != hipSuccess) return e;                                                                             \
-    kern<<<grid, threads, lds, s>>>(__VA_ARGS__);                                                              \
+    kern<<<dim3(grid, 1, w->nprob), threads, lds, s>>>(__VA_ARGS__);                                                              \
   } while (0)
 
 template <class T>
@@ -356,7 +383,7 @@ hipError_t run_mr_rowdct_fused(const Impl* w, const void* q, int ring, const dou
   *nnorm = grid;
   GPA_PROF("rowdct_fused_kernel", s);
   GPA_MR_LAUNCH(mr_rowdct_fused_kernel, threads, (T*)w->r, (const T*)q, w->n0, d, rs, (const cpx<T>*)w->mrW1, (const cpx<T>*)w->chirp1, (const cpx<T>*)w->mrB1,
-                (const cpx<T>*)w->gwk1, w->flags, part_pq, npq, part_norm, w->scal, it, ring);
+                (const cpx<T>*)w->gwk1, w->flags, part_pq, npq, part_norm, w->scal, it, ring, (size_t)w->n0 * w->n1);
   return hipGetLastError();
 }
 
@@ -371,7 +398,7 @@ hipError_t run_mr_rowidct_p(const Impl* w, const void* pin, void* pout, const do
   const size_t lds = (size_t)nf * rs * sizeof(cpx<T>);
   GPA_PROF("rowidct_p_kernel", s);
   GPA_MR_LAUNCH(mr_rowidct_p_kernel, threads, (const T*)w->z, (const T*)pin, (T*)pout, w->n0, d, rs,
-                (const cpx<T>*)w->mrW1, (const cpx<T>*)w->chirp1, (const cpx<T>*)w->mrB1, (const cpx<T>*)w->gwk1, w->flags, part_rho, nrho, w->scal, it);
+                (const cpx<T>*)w->mrW1, (const cpx<T>*)w->chirp1, (const cpx<T>*)w->mrB1, (const cpx<T>*)w->gwk1, w->flags, part_rho, nrho, w->scal, it, (size_t)w->n0 * w->n1);
   return hipGetLastError();
 }
 
@@ -389,7 +416,7 @@ hipError_t run_mr_colsolve(const Impl* w, int compat, hipStream_t s, const doubl
   GPA_PROF("colsolve_kernel", s);
   GPA_MR_LAUNCH(mr_colsolve_kernel, threads, (const T*)(zin ? zin : w->z), (T*)w->z, w->n1, d, rs,
                 (const cpx<T>*)w->mrW0, (const cpx<T>*)w->chirp0, (const cpx<T>*)w->mrB0, (const cpx<T>*)w->gwk0, (const T*)w->gha0[compat], (const T*)w->gham0[compat],
-                (const T*)w->hb1[compat], w->flags, part_norm, nnorm, it, eps, w->scal, part_rho);
+                (const T*)w->hb1[compat], w->flags, part_norm, nnorm, it, eps, w->scal, part_rho, (size_t)w->n0 * w->n1);
   return hipGetLastError();
 }
 

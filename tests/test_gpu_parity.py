@@ -1171,3 +1171,29 @@ def test_chirpz_forced_on_smooth_lengths(monkeypatch):
     assert ia == ib and rel(a, b) < 1e-9
     plan.close()
     plan_z.close()
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize('dtype', DTYPES)
+@pytest.mark.parametrize('shape', [(128, 128), (256, 512), (100, 60), (300, 300), (136, 116)])
+def test_image_stack_equals_single_images(shape, dtype):
+    """gpa_extract_displacement_field_batch_dev: a stack of images through one set of unwrap launches
+    (blockIdx.z = problem) -- every image's u and iteration counts equal the single-image driver's bit for bit
+    (power-of-two, smooth, square smooth with transform-free columns, chirp-z sizes)"""
+    kvecs = hex_kvecs(0.12, 5.0)
+    sigma = 5
+    klists = np.stack(explicit_klists(kvecs, 0.04, 2, 2))
+    B = 5
+    imgs = np.stack([hex_moire(shape, kvecs, (0.3 + 0.2 * i) * gaussian_bump_displacement(shape), noise=0.05 * (i + 1), seed=i)
+                     for i in range(B)])
+    imgs[3] = imgs[3, ::-1, ::-1]   # (different images converge after different iteration counts)
+    plan = _lib.Plan(shape, 12, dtype)
+    u_b, it_b = plan.extract_displacement_field_stack(imgs, kvecs, klists, sigma, 2 * sigma, kmax=10)
+    for i in range(B):
+        u, _, _, iters = plan.extract_displacement_field(imgs[i], kvecs, klists, sigma, 2 * sigma, kmax=10)
+        assert np.array_equal(u_b[i], u), (shape, i, float(np.abs(u_b[i] - u).max()))
+        assert tuple(it_b[i]) == tuple(iters), (shape, i)
+    # a second call with another stack size reallocates the batch workspace
+    u_b2, _ = plan.extract_displacement_field_stack(imgs[:2], kvecs, klists, sigma, 2 * sigma, kmax=10)
+    assert np.array_equal(u_b2, u_b[:2])
+    plan.close()
