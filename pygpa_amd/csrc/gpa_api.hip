@@ -243,6 +243,11 @@ struct gpa_plan {
   int uwb_images = 0;
   void* d_wnorm_b = nullptr;      // images x n0 x n1
   int* h_iters_b = nullptr;       // pinned: 4 ints per problem
+  // sweep of a chunk of images in one set of launches: x-planes, lock-ins, means, mean scratch per image
+  void *bT = nullptr, *bL = nullptr, *bMean = nullptr;
+  double* bScratch = nullptr;
+  size_t bT_bytes = 0, bL_bytes = 0;
+  int b_chunk = 0;
   UnwrapWorkspace uw2{};          // second workspace + stream: the two components of u unwrap concurrently
   hipStream_t stream2 = nullptr;
   hipEvent_t ev_fork = nullptr, ev_join = nullptr;
@@ -594,6 +599,8 @@ void gpa_plan_destroy(gpa_plan* p) {
   if (p->uwb_images) unwrap_workspace_destroy(&p->uwb);
   if (p->d_wnorm_b) (void)hipFree(p->d_wnorm_b);
   if (p->h_iters_b) (void)hipHostFree(p->h_iters_b);
+  for (void* b : {p->bT, p->bL, p->bMean, (void*)p->bScratch})
+    if (b) (void)hipFree(b);
   if (p->stream2) { hipStreamSynchronize(p->stream2); hipStreamDestroy(p->stream2); }
   if (p->ev_fork) hipEventDestroy(p->ev_fork);
   if (p->ev_join) hipEventDestroy(p->ev_join);
@@ -1070,9 +1077,9 @@ int gpa_extract_displacement_field_async(gpa_plan* p, const void* image, const d
   return extract_enqueue(p, image, kvecs, P, klists, K, sigma, mask_border, kmax, u, lockins, kidx);
 }
 
-// A stack of images of one shape in one call: the sweep and the least squares run image after image, the
-// 2 x images weighted unwraps then share ONE set of launches (blockIdx.z = problem) -- a small image is bound by
-// its ~90 dependent unwrap launches, not by their work, so the stack costs little more than one image.
+// A stack of images of one shape in one call: every kernel of the driver takes an image / problem index from its
+// grid, so the stack is ONE set of ~50 launches instead of ~110 per image -- a small image is bound by its chain of
+// dependent launches, not by their work.
 // images: B x n0 x n1, u: B x 2 x n0 x n1 (device pointers), iters_out: 2 B counts (host, may be NULL: no
 // synchronisation then).  The results are those of B separate gpa_extract_displacement_field_dev calls, bit for bit.
 int gpa_extract_displacement_field_batch_dev(gpa_plan* p, const void* images, int B, const double* kvecs, int P,
@@ -1114,17 +1121,42 @@ int gpa_extract_displacement_field_batch_dev(gpa_plan* p, const void* images, in
     }
     p->uwb_images = B;
   }
+  // the sweep and the least squares of a chunk of images are ONE set of launches too (blockIdx.z / .y = image);
+  // the chunk is what fits ~3 GB of x-planes (512^2: the whole stack, 4096^2: one image at a time)
+  const size_t t_img = (size_t)Bx * npx * p->csz, l_img = (size_t)P * npx * p->csz;
+  int chunk = (int)std::min<size_t>((size_t)B, std::max<size_t>(1, ((size_t)3 << 30) / t_img));
+  if ((size_t)chunk * t_img > p->bT_bytes || (size_t)chunk * l_img > p->bL_bytes || chunk > p->b_chunk) {
+    HIP_TRY(hipStreamSynchronize(p->stream));
+    for (void* b : {p->bT, p->bL, p->bMean, (void*)p->bScratch})
+      if (b) (void)hipFree(b);
+    p->bT = p->bL = p->bMean = nullptr;
+    p->bScratch = nullptr;
+    p->bT_bytes = p->bL_bytes = 0;
+    p->b_chunk = 0;
+    hipError_t ea = hipMalloc(&p->bT, (size_t)chunk * t_img);
+    if (ea == hipSuccess) ea = hipMalloc(&p->bL, (size_t)chunk * l_img);
+    if (ea == hipSuccess) ea = hipMalloc(&p->bMean, (size_t)chunk * 8);
+    if (ea == hipSuccess) ea = hipMalloc((void**)&p->bScratch, (size_t)chunk * 1024 * sizeof(double));
+    if (ea != hipSuccess) return fail(GPA_ERR_HIP, std::string("batched sweep buffers: ") + hipGetErrorString(ea));
+    p->bT_bytes = (size_t)chunk * t_img;
+    p->bL_bytes = (size_t)chunk * l_img;
+    p->b_chunk = chunk;
+  }
   int nparts = 0;
-  for (int i = 0; i < B; ++i) {
-    const void* image = (const char*)images + (size_t)i * npx * p->rsz;
-    HIP_TRY(launch_mean(p->dtype, image, npx, p->d_scratch, p->d_mean, p->stream));
-    HIP_TRY(launch_passA(p->dtype, p->ax0, p->n1, image, p->d_mean, p->tb, p->Hx, p->tw0, p->Tbuf, Bx, p->stream));
-    TRY(passB_select(p, P, K, p->d_lockin, nullptr));
-    HIP_TRY(launch_reconstruct_setup(p->dtype, p->d_lockin, p->d_kmat, P, p->n0, p->n1, mask_border,
-                                     (char*)p->d_wnorm_b + (size_t)i * npx * p->rsz,
-                                     unwrap_residual_buffer(&p->uwb, 2 * i), unwrap_residual_buffer(&p->uwb, 2 * i + 1),
-                                     unwrap_partials_buffer(&p->uwb, 2 * i), unwrap_partials_buffer(&p->uwb, 2 * i + 1),
-                                     &nparts, p->stream));
+  const size_t rstride = 2 * npx;                                                     // residual slices per image
+  const size_t pstride = (size_t)(unwrap_partials_buffer(&p->uwb, 2) - unwrap_partials_buffer(&p->uwb, 0));
+  for (int c0 = 0; c0 < B; c0 += chunk) {
+    const int nimg = std::min(chunk, B - c0);
+    const void* image = (const char*)images + (size_t)c0 * npx * p->rsz;
+    HIP_TRY(launch_mean(p->dtype, image, npx, p->bScratch, p->bMean, p->stream, nimg));
+    HIP_TRY(launch_passA(p->dtype, p->ax0, p->n1, image, p->bMean, p->tb, p->Hx, p->tw0, p->bT, Bx, p->stream, nimg));
+    HIP_TRY(launch_passB(p->dtype, p->ax1, p->n0, p->bT, p->Hy, p->tw1, p->tb, P, K, true, p->bL, nullptr, p->stream, nimg,
+                         Bx));
+    HIP_TRY(launch_reconstruct_setup(p->dtype, p->bL, p->d_kmat, P, p->n0, p->n1, mask_border,
+                                     (char*)p->d_wnorm_b + (size_t)c0 * npx * p->rsz,
+                                     unwrap_residual_buffer(&p->uwb, 2 * c0), unwrap_residual_buffer(&p->uwb, 2 * c0 + 1),
+                                     unwrap_partials_buffer(&p->uwb, 2 * c0), unwrap_partials_buffer(&p->uwb, 2 * c0 + 1),
+                                     &nparts, p->stream, nimg, rstride, pstride));
   }
   hipError_t e = unwrap_enqueue_prepared(&p->uwb, p->d_wnorm_b, nparts, kmax, 1e-9, true, u, p->stream);
   if (e == hipSuccess) e = unwrap_fetch_iters(&p->uwb, p->h_iters_b, p->stream);

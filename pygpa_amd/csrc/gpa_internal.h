@@ -117,17 +117,17 @@ hipError_t launch_tables(int dtype, const Axis& a0, const Axis& a1, const double
                          hipStream_t s);
 // mean_out: device scalar of the plan dtype; scratch: >= 1024 doubles
 hipError_t launch_mean(int dtype, const void* image, size_t count, double* scratch,
-                       void* mean_out, hipStream_t s);
+                       void* mean_out, hipStream_t s, int nimg = 1);
 // x-axis pass over the Bx x-planes: Tbuf[plane][x][y] = Cx( (image - mean) * cx_plane )[x][y]
 hipError_t launch_passA(int dtype, const Axis& a0, int n1, const void* image, const void* mean,
                         const SweepTables& tb, const void* Hx, const void* tw0, void* Tbuf,
-                        int Bx, hipStream_t s);
+                        int Bx, hipStream_t s, int nimg = 1);
 // y-axis pass.  select = true: per peak p (grid.y = P) loop over its K candidates
 // keeping the strictly-largest |sf|, write compensated lock-in (+ kidx).
 // select = false: write all B lock-ins (P = B, K = 1).
 hipError_t launch_passB(int dtype, const Axis& a1, int n0, const void* Tbuf, const void* Hy,
                         const void* tw1, const SweepTables& tb, int P, int K, bool select,
-                        void* out, int32_t* kidx, hipStream_t s);
+                        void* out, int32_t* kidx, hipStream_t s, int nimg = 1, int Bx = 0);
 // one peak, K candidates, the less travelled selection modes (gpa_sweep_ext.hip): mode 2 = gated selection of
 // wfr4 (gate: device K x K bytes, gate[j * K + k] != 0 where candidate k may replace the kept candidate j),
 // mode 3 = plain selection that also writes psi[k][x][y] = -angle(sf_k) of every candidate
@@ -156,7 +156,7 @@ hipError_t launch_reconstruct(int dtype, const void* lockin, const double* kmat 
 // *nparts partial sums of ||r0||^2 each
 hipError_t launch_reconstruct_setup(int dtype, const void* lockin, const double* kmat, int P, int n0, int n1,
                                     int border, void* wnorm, void* r0, void* r1, double* part0, double* part1,
-                                    int* nparts, hipStream_t s);
+                                    int* nparts, hipStream_t s, int nimg = 1, size_t rstride = 0, size_t pstride = 0);
 
 // pre_diff=True: grads (P x n0 x n1 x 2) are phase gradients along axis 1 ([..., 0]) and axis 0 ([..., 1]):
 // wrap, per-pixel weighted least squares for both, crop to the difference grids

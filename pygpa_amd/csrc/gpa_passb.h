@@ -41,7 +41,8 @@ __global__ __launch_bounds__((PassBGeom<T, LG>::THREADS), (sizeof(T) == 8 ? GPA_
     const int* __restrict__ planeof, const cpx<T>* __restrict__ cyb, const cpx<T>* __restrict__ sy,
     const cpx<T>* __restrict__ wyw, const cpx<T>* __restrict__ wyr, int extL, int extR,
     const cpx<T>* __restrict__ dx, const cpx<T>* __restrict__ dy, int K,
-    cpx<T>* __restrict__ out, int32_t* __restrict__ kidx, const uint8_t* __restrict__ gate, T* __restrict__ psi) {
+    cpx<T>* __restrict__ out, int32_t* __restrict__ kidx, const uint8_t* __restrict__ gate, T* __restrict__ psi,
+    int P, int Bx) {
   constexpr bool SELECT = MODE != PB_ALL;
   using F = WgFFT<T, LG>;
   using G = PassBGeom<T, LG>;
@@ -51,7 +52,9 @@ __global__ __launch_bounds__((PassBGeom<T, LG>::THREADS), (sizeof(T) == 8 ? GPA_
   cpx<T>* lds = reinterpret_cast<cpx<T>*>(smem) + f * G::RS;
   const int row = blockIdx.x * G::NF + f;
   const bool valid = row < n0;
-  const int p = blockIdx.y;
+  // image stacks: blockIdx.y = image * P + peak.  `p` indexes the outputs (one plane per image and peak), `pt` the
+  // candidate tables (the same for every image); image img reads its own Bx x-planes
+  const int p = blockIdx.y, pt = p % P, img = p / P;
 
   typename F::Twiddles tw;
   F::load_twiddles(tw, twtab, tid);
@@ -88,10 +91,10 @@ __global__ __launch_bounds__((PassBGeom<T, LG>::THREADS), (sizeof(T) == 8 ? GPA_
     }
   }
   for (int k = k0; k < nk; ++k) {
-    const int b = SELECT ? p * K + k : p;
+    const int b = SELECT ? pt * K + k : pt;
     F::refresh(tw);
     // the x-plane of this candidate (shared by every candidate with the same wx: re-reads hit L2)
-    const cpx<T>* src = Tin + ((size_t)planeof[b] * n0 + (valid ? row : 0)) * n1;
+    const cpx<T>* src = Tin + (((size_t)img * Bx + planeof[b]) * n0 + (valid ? row : 0)) * n1;
     const cpx<T> cbase = cyb[(size_t)b * TPF + tid];
     cpx<T> x[16];
     cpx<T> fr = {T(1), T(0)}, fw = {T(1), T(0)};
@@ -146,7 +149,7 @@ __global__ __launch_bounds__((PassBGeom<T, LG>::THREADS), (sizeof(T) == 8 ? GPA_
 #pragma unroll
           for (int i = 0; i < 16; ++i) {
             const int yy = tid + TPF * i;
-            if (!PADDED || yy < n1) psi[((size_t)b * n0 + row) * n1 + yy] = -atan2(x[i].y, x[i].x);
+            if (!PADDED || yy < n1) psi[((size_t)(p * K + k) * n0 + row) * n1 + yy] = -atan2(x[i].y, x[i].x);
           }
         }
       }
@@ -168,7 +171,7 @@ __global__ __launch_bounds__((PassBGeom<T, LG>::THREADS), (sizeof(T) == 8 ? GPA_
       } else if constexpr (SELECT) {
         cpx<T> v = {T(0), T(0)};
         if (bidx[i] >= 0) {
-          const size_t bb = (size_t)p * K + bidx[i];
+          const size_t bb = (size_t)pt * K + bidx[i];
           v = cmul(best[i], cmul(dx[bb * n0 + row], dy[bb * n1 + yy]));
         }
         out[o] = v;
@@ -184,7 +187,8 @@ __global__ __launch_bounds__((PassBGeom<T, LG>::THREADS), (sizeof(T) == 8 ? GPA_
 template <class T, int LG, bool PADDED, int MODE>
 static hipError_t run_passB(const Axis& a1, int n0, const void* Tbuf, const void* Hy,
                             const void* tw1, const SweepTables& tb, int P, int K, void* out,
-                            int32_t* kidx, const uint8_t* gate, void* psi, hipStream_t s, int ksplit = 1) {
+                            int32_t* kidx, const uint8_t* gate, void* psi, hipStream_t s, int ksplit = 1, int nimg = 1,
+                            int Bx = 0) {
   using G = PassBGeom<T, LG>;
   if constexpr (G::LDS_BYTES > 160 * 1024) {
     return hipErrorInvalidValue;
@@ -193,13 +197,13 @@ static hipError_t run_passB(const Axis& a1, int n0, const void* Tbuf, const void
     static unsigned lds_set = 0;
     hipError_t e = set_dynamic_lds_once(reinterpret_cast<const void*>(kern), (int)G::LDS_BYTES, lds_set);
     if (e != hipSuccess) return e;
-    dim3 grid((n0 + G::NF - 1) / G::NF, P, ksplit);
+    dim3 grid((n0 + G::NF - 1) / G::NF, P * nimg, ksplit);
     GPA_PROF("passB_kernel", s);
     kern<<<grid, G::THREADS, G::LDS_BYTES, s>>>(
         (const cpx<T>*)Tbuf, n0, a1.n, (const typename HType<PADDED, T>::type*)Hy,
         (const cpx<T>*)tw1, tb.planeof, (const cpx<T>*)tb.cyb, (const cpx<T>*)tb.sy, (const cpx<T>*)tb.wyw,
         (const cpx<T>*)tb.wyr, a1.extL, a1.extR,
-        (const cpx<T>*)tb.dx, (const cpx<T>*)tb.dy, K, (cpx<T>*)out, kidx, gate, (T*)psi);
+        (const cpx<T>*)tb.dx, (const cpx<T>*)tb.dy, K, (cpx<T>*)out, kidx, gate, (T*)psi, P, Bx);
     return hipGetLastError();
   }
 }

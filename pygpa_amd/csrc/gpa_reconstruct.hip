@@ -170,7 +170,19 @@ __global__ __launch_bounds__(256) void reconstruct_setup_kernel(const cpx<T>* __
                                                                const double* __restrict__ kmat, int n0, int n1,
                                                                int border, T* __restrict__ wnorm, T* __restrict__ r0,
                                                                T* __restrict__ r1, double* __restrict__ part0,
-                                                               double* __restrict__ part1, int band) {
+                                                               double* __restrict__ part1, int band, size_t rstride,
+                                                               size_t pstride) {
+  {
+    // image stacks: blockIdx.z = image; its lock-ins / weight follow those of the image before, its two residuals and
+    // partial-sum blocks lie rstride elements / pstride doubles behind the previous image's (the batched workspace)
+    const size_t img = blockIdx.z, npx_ = (size_t)n0 * n1;
+    lockin += img * P * npx_;
+    wnorm += img * npx_;
+    r0 += img * rstride;
+    r1 += img * rstride;
+    part0 += img * pstride;
+    part1 += img * pstride;
+  }
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const int yw = (blockIdx.x * 4 + wave) * FUSED_COLS + lane - 1;
   const bool incol = yw >= 0 && yw < n1;
@@ -291,19 +303,19 @@ __global__ __launch_bounds__(256) void reconstruct_setup_kernel(const cpx<T>* __
 template <class T>
 static hipError_t launch_reconstruct_setup_t(const void* lockin, const double* kmat, int P, int n0, int n1, int border,
                                              void* wnorm, void* r0, void* r1, double* part0, double* part1, int* nparts,
-                                             hipStream_t s) {
+                                             hipStream_t s, int nimg, size_t rstride, size_t pstride) {
   // rows per workgroup band: FUSED_ROWS for large images (one halo row per band is recomputed), fewer while the
   // grid would leave most of the 256 CUs idle -- a band is a serial loop of ~1.5 us per row
   int band = FUSED_ROWS;
   const int gx = (n1 + 4 * FUSED_COLS - 1) / (4 * FUSED_COLS);
   while (band > 2 && gx * ((n0 + band - 1) / band) < 1024) band /= 2;
-  dim3 grid(gx, (n0 + band - 1) / band);
+  dim3 grid(gx, (n0 + band - 1) / band, nimg);
   *nparts = (int)(grid.x * grid.y);
   GPA_PROF("reconstruct_setup_kernel", s);
 #define RS_CASE(PP)                                                                                                   \
   case PP:                                                                                                            \
     reconstruct_setup_kernel<T, PP><<<grid, 256, 0, s>>>((const cpx<T>*)lockin, kmat, n0, n1, border, (T*)wnorm,       \
-                                                         (T*)r0, (T*)r1, part0, part1, band);                        \
+                                                         (T*)r0, (T*)r1, part0, part1, band, rstride, pstride);      \
     break;
   switch (P) {
     RS_CASE(2) RS_CASE(3) RS_CASE(4) RS_CASE(5) RS_CASE(6) RS_CASE(7) RS_CASE(8)
@@ -315,10 +327,12 @@ static hipError_t launch_reconstruct_setup_t(const void* lockin, const double* k
 
 hipError_t launch_reconstruct_setup(int dtype, const void* lockin, const double* kmat, int P, int n0, int n1,
                                     int border, void* wnorm, void* r0, void* r1, double* part0, double* part1,
-                                    int* nparts, hipStream_t s) {
+                                    int* nparts, hipStream_t s, int nimg, size_t rstride, size_t pstride) {
   if (P > MAXP || P < 2) return hipErrorInvalidValue;
-  return dtype == 0 ? launch_reconstruct_setup_t<float>(lockin, kmat, P, n0, n1, border, wnorm, r0, r1, part0, part1, nparts, s)
-                    : launch_reconstruct_setup_t<double>(lockin, kmat, P, n0, n1, border, wnorm, r0, r1, part0, part1, nparts, s);
+  return dtype == 0 ? launch_reconstruct_setup_t<float>(lockin, kmat, P, n0, n1, border, wnorm, r0, r1, part0, part1, nparts, s,
+                                                        nimg, rstride, pstride)
+                    : launch_reconstruct_setup_t<double>(lockin, kmat, P, n0, n1, border, wnorm, r0, r1, part0, part1, nparts, s,
+                                                         nimg, rstride, pstride);
 }
 
 // per-pixel weighted least squares on given right-hand sides b (P x n0 x n1), the weighted

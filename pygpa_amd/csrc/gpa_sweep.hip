@@ -84,6 +84,8 @@ hipError_t launch_tables(int dtype, const Axis& a0, const Axis& a1, const double
 // ---------------------------------------------------------------------------
 template <class T>
 __global__ void mean_partial_kernel(const T* __restrict__ img, size_t count, double* partial) {
+  img += (size_t)blockIdx.y * count;        // (image stacks: blockIdx.y = image)
+  partial += (size_t)blockIdx.y * gridDim.x;
   __shared__ double sh[256];
   double acc = 0;
   for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < count; i += (size_t)gridDim.x * 256)
@@ -98,6 +100,8 @@ __global__ void mean_partial_kernel(const T* __restrict__ img, size_t count, dou
 }
 template <class T>
 __global__ void mean_final_kernel(const double* partial, int nparts, size_t count, T* mean_out) {
+  partial += (size_t)blockIdx.y * nparts;
+  mean_out += blockIdx.y;
   __shared__ double sh[256];
   double acc = 0;
   for (int i = threadIdx.x; i < nparts; i += 256) acc += partial[i];
@@ -110,16 +114,18 @@ __global__ void mean_final_kernel(const double* partial, int nparts, size_t coun
   if (threadIdx.x == 0) *mean_out = (T)(sh[0] / (double)count);
 }
 
+// nimg > 1: the means of nimg images of `count` pixels, one after the other in memory (scratch: 1024 doubles per
+// image, mean_out: nimg values); every image's sum is formed exactly as by a single-image call
 hipError_t launch_mean(int dtype, const void* image, size_t count, double* scratch,
-                       void* mean_out, hipStream_t s) {
+                       void* mean_out, hipStream_t s, int nimg) {
   const int nparts = 1024;
   GPA_PROF("mean_kernels", s);
   if (dtype == 0) {
-    mean_partial_kernel<float><<<nparts, 256, 0, s>>>((const float*)image, count, scratch);
-    mean_final_kernel<float><<<1, 256, 0, s>>>(scratch, nparts, count, (float*)mean_out);
+    mean_partial_kernel<float><<<dim3(nparts, nimg), 256, 0, s>>>((const float*)image, count, scratch);
+    mean_final_kernel<float><<<dim3(1, nimg), 256, 0, s>>>(scratch, nparts, count, (float*)mean_out);
   } else {
-    mean_partial_kernel<double><<<nparts, 256, 0, s>>>((const double*)image, count, scratch);
-    mean_final_kernel<double><<<1, 256, 0, s>>>(scratch, nparts, count, (double*)mean_out);
+    mean_partial_kernel<double><<<dim3(nparts, nimg), 256, 0, s>>>((const double*)image, count, scratch);
+    mean_final_kernel<double><<<dim3(1, nimg), 256, 0, s>>>(scratch, nparts, count, (double*)mean_out);
   }
   return hipGetLastError();
 }
@@ -174,7 +180,10 @@ __global__ __launch_bounds__((PassAGeom<T, LG>::THREADS)) void passA_kernel(
   int tile = blockIdx.x;
   if ((gridDim.x & 7) == 0) tile = (blockIdx.x & 7) * (gridDim.x >> 3) + (blockIdx.x >> 3);
   const int y0 = tile * G::C + c * NT;
-  const T m = mean ? *mean : T(0);
+  // image stacks: blockIdx.z = image, its B planes behind those of the image before
+  image += (size_t)blockIdx.z * n0 * n1;
+  Tout += (size_t)blockIdx.z * B * n0 * n1;
+  const T m = mean ? mean[blockIdx.z] : T(0);
 
   T val[NT][16];
   unsigned wrapmask = 0, rightmask = 0;   // slots of the left / right periodic extension (padded mode)
@@ -259,7 +268,7 @@ __global__ __launch_bounds__((PassAGeom<T, LG>::THREADS)) void passA_kernel(
 template <class T, int LG, bool PADDED>
 static hipError_t run_passA(const Axis& a0, int n1, const void* image, const void* mean,
                             const SweepTables& tb, const void* Hx, const void* tw0, void* Tbuf,
-                            int B, hipStream_t s) {
+                            int B, hipStream_t s, int nimg) {
   using G = PassAGeom<T, LG>;
   if constexpr (!G::FITS) {
     return hipErrorInvalidValue;
@@ -274,7 +283,7 @@ static hipError_t run_passA(const Axis& a0, int n1, const void* image, const voi
     while (tiles * ysplit < 512 && ysplit < B) ysplit *= 2;
     if (ysplit > B) ysplit = B;
     const int bchunk = (B + ysplit - 1) / ysplit;
-    dim3 grid(tiles, (B + bchunk - 1) / bchunk);
+    dim3 grid(tiles, (B + bchunk - 1) / bchunk, nimg);
     GPA_PROF("passA_kernel", s);
     kern<<<grid, G::THREADS, G::LDS_BYTES, s>>>(
         (const T*)image, (const T*)mean, a0.n, n1, (const cpx<T>*)tb.cxb, (const cpx<T>*)tb.sx,
@@ -287,15 +296,15 @@ static hipError_t run_passA(const Axis& a0, int n1, const void* image, const voi
 
 hipError_t launch_passA(int dtype, const Axis& a0, int n1, const void* image, const void* mean,
                         const SweepTables& tb, const void* Hx, const void* tw0, void* Tbuf,
-                        int B, hipStream_t s) {
+                        int B, hipStream_t s, int nimg) {
 #define CASE_A(LG)                                                                                \
   case LG:                                                                                        \
     if (dtype == 0)                                                                               \
-      return a0.padded ? run_passA<float, LG, true>(a0, n1, image, mean, tb, Hx, tw0, Tbuf, B, s) \
-                       : run_passA<float, LG, false>(a0, n1, image, mean, tb, Hx, tw0, Tbuf, B, s); \
+      return a0.padded ? run_passA<float, LG, true>(a0, n1, image, mean, tb, Hx, tw0, Tbuf, B, s, nimg) \
+                       : run_passA<float, LG, false>(a0, n1, image, mean, tb, Hx, tw0, Tbuf, B, s, nimg); \
     else                                                                                          \
-      return a0.padded ? run_passA<double, LG, true>(a0, n1, image, mean, tb, Hx, tw0, Tbuf, B, s) \
-                       : run_passA<double, LG, false>(a0, n1, image, mean, tb, Hx, tw0, Tbuf, B, s);
+      return a0.padded ? run_passA<double, LG, true>(a0, n1, image, mean, tb, Hx, tw0, Tbuf, B, s, nimg) \
+                       : run_passA<double, LG, false>(a0, n1, image, mean, tb, Hx, tw0, Tbuf, B, s, nimg);
   switch (a0.lg) { GPA_FOR_LG(CASE_A) }
 #undef CASE_A
   return hipErrorInvalidValue;
@@ -303,10 +312,10 @@ hipError_t launch_passA(int dtype, const Axis& a0, int n1, const void* image, co
 
 hipError_t launch_passB(int dtype, const Axis& a1, int n0, const void* Tbuf, const void* Hy,
                         const void* tw1, const SweepTables& tb, int P, int K, bool select,
-                        void* out, int32_t* kidx, hipStream_t s) {
-#define CALL_B(T, LG, PD)                                                                                        \
-  (select ? run_passB<T, LG, PD, PB_SELECT>(a1, n0, Tbuf, Hy, tw1, tb, P, K, out, kidx, nullptr, nullptr, s)      \
-          : run_passB<T, LG, PD, PB_ALL>(a1, n0, Tbuf, Hy, tw1, tb, P, K, out, kidx, nullptr, nullptr, s))
+                        void* out, int32_t* kidx, hipStream_t s, int nimg, int Bx) {
+#define CALL_B(T, LG, PD)                                                                                                   \
+  (select ? run_passB<T, LG, PD, PB_SELECT>(a1, n0, Tbuf, Hy, tw1, tb, P, K, out, kidx, nullptr, nullptr, s, 1, nimg, Bx)    \
+          : run_passB<T, LG, PD, PB_ALL>(a1, n0, Tbuf, Hy, tw1, tb, P, K, out, kidx, nullptr, nullptr, s, 1, nimg, Bx))
 #define CASE_B(LG)                                                           \
   case LG:                                                                   \
     if (dtype == 0) return a1.padded ? CALL_B(float, LG, true) : CALL_B(float, LG, false); \
