@@ -320,9 +320,46 @@ def single_gpu(args):
         g64.close()
         out['f64'] = {'value': round(n * n * k64 / dt64 / 1e6, 2), 'unit': 'Mpixels/s', 'ms_per_step': round(dt64 / k64 * 1e3, 4),
                       'steps': k64, 'unwrap_iters': list(it64), 'note': 'the reference computes in complex128; same step, D2H of u included'}
+    if not args.no_f64 and args.dtype == 'f32' and n == 4096:
+        out['small_image_stacks'] = small_image_stacks(kvecs, klists, sigma, args.kmax)
     if not args.no_cpu:
         out['cpu_baseline'] = cpu_baseline(kvecs, sigma, knx, kny, args.kmax, n)
     print(json.dumps(out), flush=True)
+
+
+def small_image_stacks(kvecs, klists, sigma, kmax, sizes=(512, 1024), stack=16, reps=6):
+    """extra key of the default run (a fraction of a second): the sizes the reference's users run most, one image
+    per call against a stack of `stack` frames in ONE call (gpa_extract_displacement_field_batch_dev: every kernel
+    takes an image index from its grid), images and u resident in HBM, f32, same 3 x 16 workload"""
+    from pygpa_amd import _lib
+    from pygpa_amd.synthetic import gaussian_bump_displacement, hex_moire
+    res = {'stack': stack, 'note': 'Mpixels/s, u left in HBM; single = one image per driver call, stacked = %d frames per call' % stack}
+    for n in sizes:
+        img = hex_moire((n, n), kvecs, gaussian_bump_displacement((n, n)), noise=0.1, seed=1, dtype=np.float32)
+        plan = _lib.Plan((n, n), klists.shape[0] * klists.shape[1], np.float32, device=0)
+        frames = np.stack([img] * stack)
+        d, u = _lib.DeviceBuffer(frames.nbytes), _lib.DeviceBuffer(2 * frames.nbytes)
+        d.upload(frames)
+        t = {}
+        for mode in ('single', 'stacked'):
+            def run(k):
+                for _ in range(k):
+                    if mode == 'single':
+                        plan.extract_displacement_field_async(d.ptr, kvecs, klists, sigma, 2 * sigma, kmax, u.ptr)
+                    else:
+                        plan.extract_displacement_field_batch_dev(d.ptr, stack, kvecs, klists, sigma, 2 * sigma, kmax, u.ptr,
+                                                                  want_iters=False)
+                plan.sync()
+            run(2)
+            k = reps * (stack if mode == 'single' else 1)
+            t0 = time.perf_counter()
+            run(k)
+            t[mode] = (time.perf_counter() - t0) / (k if mode == 'single' else k * stack)
+        res['%dx%d' % (n, n)] = {'single': round(n * n / t['single'] / 1e6, 1), 'stacked': round(n * n / t['stacked'] / 1e6, 1)}
+        d.free()
+        u.free()
+        plan.close()
+    return res
 
 
 # -------------------------------------------------------------------------------------------------

@@ -446,6 +446,30 @@ def extract_displacement_field(image, kvecs, sigma=None, kwscale=2.5, ksteps=3, 
     return u
 
 
+def extract_displacement_field_stack(images, kvecs, sigma=None, kwscale=2.5, ksteps=3, klists=None, dtype=None):
+    """`extract_displacement_field` of every image of a stack (B, N, M) with one set of k-vectors -- frames of a
+    movie, a tilt or temperature series -- in ONE device call: every kernel of the driver takes an image index from
+    its grid, so the ~110 dependent launches that bound a small image are paid once per stack (512^2 frames: x4
+    the single-image rate).  No counterpart in the reference (a Python loop over `extract_displacement_field`,
+    geometric_phase_analysis.py:907-932, gives the same numbers); rows must be a multiple of 4 pixels.
+    Returns u of shape (B, 2, N, M)."""
+    images = np.asarray(images)
+    if images.ndim != 3:
+        raise ValueError('images must be a stack (B, N, M)')
+    kvecs = np.asarray(kvecs, dtype=np.float64).reshape(-1, 2)
+    norms = np.linalg.norm(kvecs, axis=1)
+    kw = norms.mean() / kwscale
+    if sigma is None:
+        sigma = int(np.ceil(1 / norms.min()))
+    if klists is None:
+        klists = [_sweep_list(pk[0], pk[1], kw, kw / ksteps) for pk in kvecs]
+    klists = [np.asarray(kl, dtype=np.float64).reshape(-1, 2) for kl in klists]
+    K = max(len(kl) for kl in klists)
+    padded = np.stack([np.concatenate([kl, np.repeat(kl[-1:], K - len(kl), axis=0)]) for kl in klists])
+    plan = _lib.get_plan(images.shape[1:], len(kvecs) * K, DEFAULT_DTYPE if dtype is None else dtype)
+    return plan.extract_displacement_field_stack(images, kvecs, padded, sigma, int(2 * sigma), kmax=10)[0]
+
+
 def gaussian_deconvolve(data, sigma, dr=20, balance=5000, dtype=None):
     """Deconvolve a stack of fields by the Gaussian of width sigma (geometric_phase_analysis.py:892-904):
     reflect padding by 2*dr, skimage.restoration.wiener with `balance`, cropping -- on the device

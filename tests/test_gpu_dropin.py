@@ -39,6 +39,19 @@ def test_displacement_field(testset):
     assert np.abs(u2 - u_true)[:, 20:-20, 20:-20].max() < np.abs(u1 - u_true)[:, 20:-20, 20:-20].max()
 
 
+def test_displacement_field_stack(testset):
+    """the stack form (one device call for all frames) returns what a loop over the reference-shaped
+    extract_displacement_field returns, frame by frame, to the last bit -- and passes the reference's own bar"""
+    original, deformed, noise, ks, u_true = testset
+    frames = np.stack([deformed + noise, deformed, deformed[::-1, ::-1] + 0.5 * noise])
+    for dtype in (np.float64, np.float32):
+        us = GPA.extract_displacement_field_stack(frames, ks, dtype=dtype)
+        assert us.shape == (3,) + u_true.shape
+        for i in range(3):
+            assert np.array_equal(us[i], GPA.extract_displacement_field(frames[i], ks, dtype=dtype))
+        assert np.all(np.abs(-us[0] - u_true)[:, 20:-20, 20:-20] < 0.9)
+
+
 @pytest.mark.parametrize('wfr_func', [cuGPA.wfr2_grad_opt, cuGPA.wfr2_grad_single])
 def test_cugpa_displacement_field(testset, wfr_func):
     """reference tests/test_cuGPA.py:45-56, literally: the cuGPA module's sweeps plugged in as `wfr_func`
