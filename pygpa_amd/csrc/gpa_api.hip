@@ -217,6 +217,12 @@ struct gpa_plan {
   int last_planes = 0;
   std::vector<double> staged_kl, staged_kr, staged_kmat;   // what the device tables currently hold
   int* h_iters = nullptr;         // pinned: iteration counts of the last (possibly asynchronous) driver call
+  int iters_stride = 1;           // 1: two-stream driver (h_iters[0], [1]); 4: paired workspace (h_iters[0], [4])
+  // images of up to 1024^2: both components of u in ONE set of launches (blockIdx.z) on one stream -- measured 8 %
+  // (512^2) to 14 % (256^2) faster than two streams, whose kernels are too small to overlap; from 2048^2 on the two
+  // streams win by 4 % (profiles/r02_image_stacks.txt, 'stack of 1')
+  UnwrapWorkspace uwp{};
+  bool have_uwp = false, use_pair = false;
   double* h_k = nullptr;          // pinned staging, 4 * max_batch doubles
   void* d_image = nullptr;        // staging for host-pointer entry points
   void* d_mean = nullptr;
@@ -374,7 +380,7 @@ static int plan_build(gpa_plan* p) {
   TRY(dmalloc(p, (void**)&p->d_kl, (size_t)B * 2 * sizeof(double)));
   TRY(dmalloc(p, (void**)&p->d_kr, (size_t)B * 2 * sizeof(double)));
   HIP_TRY(hipHostMalloc((void**)&p->h_k, ((size_t)B * 6 + 32) * sizeof(double)));
-  HIP_TRY(hipHostMalloc((void**)&p->h_iters, 4 * sizeof(int)));
+  HIP_TRY(hipHostMalloc((void**)&p->h_iters, 8 * sizeof(int)));
   TRY(dmalloc(p, &p->d_image, npx * p->rsz));
   TRY(dmalloc(p, &p->d_mean, 16));
   TRY(dmalloc(p, &p->d_tile_mean, 16));
@@ -597,6 +603,7 @@ void gpa_plan_destroy(gpa_plan* p) {
   unwrap_workspace_destroy(&p->uw);
   unwrap_workspace_destroy(&p->uw2);
   if (p->uwb_images) unwrap_workspace_destroy(&p->uwb);
+  if (p->have_uwp) unwrap_workspace_destroy(&p->uwp);
   if (p->d_wnorm_b) (void)hipFree(p->d_wnorm_b);
   if (p->h_iters_b) (void)hipHostFree(p->h_iters_b);
   for (void* b : {p->bT, p->bL, p->bMean, (void*)p->bScratch})
@@ -924,6 +931,18 @@ static int extract_stage(gpa_plan* p, const double* kvecs, int P, const double* 
   TRY(stage_kvectors(p, klists, kr.data(), B, Bx));
   TRY(ensure_tbuf(p, *Bx));
   TRY(stage_kmat(p, kvecs, P));
+  p->use_pair = (size_t)p->n0 * p->n1 <= (size_t)1024 * 1024 && (p->n1 % 4) == 0 && !getenv("GPA_NO_PAIR");
+  if (p->use_pair && !p->have_uwp) {
+    size_t bp = 0;
+    hipError_t ep = unwrap_workspace_create(p->dtype, p->n0, p->n1, p->stream, &p->uwp, &bp, 2);
+    if (ep != hipSuccess) {
+      unwrap_workspace_destroy(&p->uwp);
+      return fail(GPA_ERR_HIP, std::string("paired unwrap workspace: ") + hipGetErrorString(ep));
+    }
+    p->ws_bytes += bp;
+    p->have_uwp = true;
+  }
+  if (p->use_pair && !unwrap_supports_batch(&p->uwp)) p->use_pair = false;
   if (!p->stream2) {
     // the two displacement components are independent solves: give the second one its own
     // workspace and stream so the latency-bound kernels of one fill the gaps of the other
@@ -952,6 +971,18 @@ static int extract_launch(gpa_plan* p, const void* image, int P, int K, int Bx, 
   // phases / weights / per-pixel least squares fused with the unwrap's set-up: the gradient fields never
   // go to HBM, the kernel leaves r0 of both components in the two unwrap workspaces
   int nparts = 0;
+  if (p->use_pair && p->have_uwp && !p->profiling && !p->serial_unwrap) {
+    HIP_TRY(launch_reconstruct_setup(p->dtype, lk, p->d_kmat, P, p->n0, p->n1, mask_border, p->d_wnorm,
+                                     unwrap_residual_buffer(&p->uwp, 0), unwrap_residual_buffer(&p->uwp, 1),
+                                     unwrap_partials_buffer(&p->uwp, 0), unwrap_partials_buffer(&p->uwp, 1), &nparts,
+                                     p->stream));
+    hipError_t ep = unwrap_enqueue_prepared(&p->uwp, p->d_wnorm, nparts, kmax, 1e-9, true, u, p->stream);
+    if (ep == hipSuccess) ep = unwrap_fetch_iters(&p->uwp, p->h_iters, p->stream);
+    if (ep != hipSuccess) return fail(GPA_ERR_HIP, std::string("unwrap: ") + hipGetErrorString(ep));
+    p->iters_stride = 4;
+    return GPA_OK;
+  }
+  p->iters_stride = 1;
   HIP_TRY(launch_reconstruct_setup(p->dtype, lk, p->d_kmat, P, p->n0, p->n1, mask_border, p->d_wnorm,
                                    unwrap_residual_buffer(&p->uw), unwrap_residual_buffer(&p->uw2),
                                    unwrap_partials_buffer(&p->uw), unwrap_partials_buffer(&p->uw2), &nparts, p->stream));
@@ -1111,6 +1142,10 @@ int gpa_extract_displacement_field_batch_dev(gpa_plan* p, const void* images, in
       unwrap_workspace_destroy(&p->uwb);
       return fail(GPA_ERR_HIP, std::string("batched unwrap workspace: ") + hipGetErrorString(e));
     }
+    if (!unwrap_supports_batch(&p->uwb)) {
+      unwrap_workspace_destroy(&p->uwb);
+      return fail(GPA_ERR_STATE, "gpa_extract_displacement_field_batch: this image shape has no batched unwrap");
+    }
     e = hipMalloc(&p->d_wnorm_b, (size_t)B * npx * p->rsz);
     if (e == hipSuccess) e = hipHostMalloc((void**)&p->h_iters_b, (size_t)8 * B * sizeof(int));
     if (e != hipSuccess) {
@@ -1172,7 +1207,7 @@ int gpa_last_iters(gpa_plan* p, int* iters2) {
   if (!p || !iters2) return fail(GPA_ERR_ARG, "null argument");
   HIP_TRY(hipStreamSynchronize(p->stream));
   iters2[0] = p->h_iters[0];
-  iters2[1] = p->h_iters[1];
+  iters2[1] = p->h_iters[p->iters_stride];
   return GPA_OK;
 }
 
@@ -1204,7 +1239,7 @@ int gpa_extract_displacement_field_dev(gpa_plan* p, const void* image, const dou
       p->kprof_table += line;
     }
   }
-  if (iters_out) { iters_out[0] = p->h_iters[0]; iters_out[1] = p->h_iters[1]; }
+  if (iters_out) { iters_out[0] = p->h_iters[0]; iters_out[1] = p->h_iters[p->iters_stride]; }
   return GPA_OK;
 }
 

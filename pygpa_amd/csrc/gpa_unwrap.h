@@ -16,6 +16,8 @@ struct UnwrapWorkspace {
 hipError_t unwrap_workspace_create(int dtype, int n0, int n1, hipStream_t s, UnwrapWorkspace* ws,
                                    size_t* bytes_out, int nprob = 1);
 void unwrap_workspace_destroy(UnwrapWorkspace* ws);
+// whether the workspace's image shape runs the fused iteration, the only one that takes several problems per launch
+bool unwrap_supports_batch(const UnwrapWorkspace* ws);
 
 // prediff == false: a = dx (n0 x (n1-1)), b = dy ((n0-1) x n1)
 // prediff == true : a = psi (n0 x n1), b ignored (differences taken on the device)

@@ -2108,6 +2108,11 @@ hipError_t unwrap_workspace_create(int dtype, int n0, int n1, hipStream_t s, Unw
   return hipSuccess;
 }
 
+bool unwrap_supports_batch(const UnwrapWorkspace* ws) {
+  const Impl* w = (const Impl*)ws->impl;
+  return w && w->supported && (!w->generic || w->mr_ok) && (w->n1 % 4) == 0;
+}
+
 void unwrap_workspace_destroy(UnwrapWorkspace* ws) {
   Impl* w = (Impl*)ws->impl;
   if (!w) return;
