@@ -187,8 +187,7 @@ int gpa_last_iters(gpa_plan* plan, int* iters2);
  * B x n0 x n1, u B x 2 x n0 x n1.  The sweep and the least squares run image after image; the 2 B
  * weighted unwraps (phase_unwrap.py:282-350) share one set of kernel launches, which is what bounds a
  * small image.  Results equal B separate gpa_extract_displacement_field_dev calls bit for bit.
- * iters_out: 2 B iteration counts, or NULL to return without synchronising (gpa_plan_sync).
- * Rows must be a multiple of 4 pixels.                                                          */
+ * iters_out: 2 B iteration counts, or NULL to return without synchronising (gpa_plan_sync).         */
 int gpa_extract_displacement_field_batch_dev(gpa_plan* plan, const void* images, int B,
                                              const double* kvecs, int P, const double* klists, int K,
                                              double sigma, int mask_border, int kmax, void* u,

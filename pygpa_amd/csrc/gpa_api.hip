@@ -931,7 +931,7 @@ static int extract_stage(gpa_plan* p, const double* kvecs, int P, const double* 
   TRY(stage_kvectors(p, klists, kr.data(), B, Bx));
   TRY(ensure_tbuf(p, *Bx));
   TRY(stage_kmat(p, kvecs, P));
-  p->use_pair = (size_t)p->n0 * p->n1 <= (size_t)1024 * 1024 && (p->n1 % 4) == 0 && !getenv("GPA_NO_PAIR");
+  p->use_pair = (size_t)p->n0 * p->n1 <= (size_t)1024 * 1024 && !getenv("GPA_NO_PAIR");
   if (p->use_pair && !p->have_uwp) {
     size_t bp = 0;
     hipError_t ep = unwrap_workspace_create(p->dtype, p->n0, p->n1, p->stream, &p->uwp, &bp, 2);
@@ -1121,7 +1121,6 @@ int gpa_extract_displacement_field_batch_dev(gpa_plan* p, const void* images, in
   if (P < 2 || P > p->max_peaks) return fail(GPA_ERR_STATE, "gpa_extract_displacement_field_batch: need 2 <= P <= 8");
   if (K < 1 || P * K > p->max_batch) return fail(GPA_ERR_STATE, "gpa_extract_displacement_field_batch: P*K exceeds max_batch");
   if (kmax < 1) return fail(GPA_ERR_ARG, "kmax must be >= 1");
-  if (p->n1 % 4) return fail(GPA_ERR_STATE, "gpa_extract_displacement_field_batch: rows must be a multiple of 4 pixels");
   HIP_TRY(hipSetDevice(p->device));
   int Bx = 0;
   TRY(extract_stage(p, kvecs, P, klists, K, sigma, &Bx));

@@ -322,12 +322,15 @@ __global__ __launch_bounds__(256) void applyq_kernel(const T* __restrict__ p, co
 // image row, 4 pixels per thread (16-byte accesses); partial <p, q> per row.
 template <class T>
 struct alignas(4 * sizeof(T)) Vec4 { T v[4]; };
+// V consecutive pixels of a row: V = 4 where rows are whole 16-byte (f32) vectors, V = 1 for any other row length
+template <class T, int V>
+struct alignas(V * sizeof(T)) VecN { T v[V]; };
 
 constexpr int PQ_ROWS = 16;   // rows per workgroup band of pq_kernel (large images; fewer for small ones)
 
 // PGIVEN: `z` already holds the search direction p (written by rowidct_p_kernel): no combination with
 // pin, no copy to pout, no beta
-template <class T, bool PGIVEN = false>
+template <class T, bool PGIVEN = false, int V = 4>
 __global__ __launch_bounds__(256) void pq_kernel(const T* __restrict__ z, const T* __restrict__ pin,
                                                 T* __restrict__ pout, const T* __restrict__ w, int n0, int n1,
                                                 T* __restrict__ q, double* part, double* scal,
@@ -366,33 +369,33 @@ __global__ __launch_bounds__(256) void pq_kernel(const T* __restrict__ z, const 
   // a workgroup owns a band of PQ_ROWS rows x 1024 columns and slides down it with the
   // previous / current / next row in registers: every row of z, p, w is read once
   // (plus a 2-row halo per band) instead of three times by three different workgroups.
-  const int y0 = (blockIdx.x * 256 + threadIdx.x) * 4;
+  const int y0 = (blockIdx.x * 256 + threadIdx.x) * V;
   const int x0 = blockIdx.y * band;
   const int x1 = x0 + band < n0 ? x0 + band : n0;
   double pq = 0;
   if (y0 < n1) {
-    auto load_p = [&](int x, Vec4<T>& out) {
+    auto load_p = [&](int x, VecN<T, V>& out) {
       const size_t o = (size_t)x * n1 + y0;
-      const Vec4<T> a = *reinterpret_cast<const Vec4<T>*>(z + o);
+      const VecN<T, V> a = *reinterpret_cast<const VecN<T, V>*>(z + o);
       if (first) { out = a; return; }
-      const Vec4<T> b = *reinterpret_cast<const Vec4<T>*>(pin + o);
+      const VecN<T, V> b = *reinterpret_cast<const VecN<T, V>*>(pin + o);
 #pragma unroll
-      for (int j = 0; j < 4; ++j) out.v[j] = a.v[j] + beta * b.v[j];
+      for (int j = 0; j < V; ++j) out.v[j] = a.v[j] + beta * b.v[j];
     };
-    auto load_w = [&](int x, Vec4<T>& out) {
+    auto load_w = [&](int x, VecN<T, V>& out) {
       if (!w) {
 #pragma unroll
-        for (int j = 0; j < 4; ++j) out.v[j] = T(1);
+        for (int j = 0; j < V; ++j) out.v[j] = T(1);
         return;
       }
-      out = *reinterpret_cast<const Vec4<T>*>(w + (size_t)x * n1 + y0);
+      out = *reinterpret_cast<const VecN<T, V>*>(w + (size_t)x * n1 + y0);
 #pragma unroll
-      for (int j = 0; j < 4; ++j) out.v[j] *= out.v[j];
+      for (int j = 0; j < V; ++j) out.v[j] *= out.v[j];
     };
-    const bool hasl = y0 > 0, hasr = y0 + 4 < n1;
-    Vec4<T> pu, pc, pd, wu, wc, wd;
+    const bool hasl = y0 > 0, hasr = y0 + V < n1;
+    VecN<T, V> pu, pc, pd, wu, wc, wd;
 #pragma unroll
-    for (int j = 0; j < 4; ++j) pu.v[j] = wu.v[j] = T(0);
+    for (int j = 0; j < V; ++j) pu.v[j] = wu.v[j] = T(0);
     if (x0 > 0) { load_p(x0 - 1, pu); load_w(x0 - 1, wu); }
     load_p(x0, pc);
     load_w(x0, wc);
@@ -403,25 +406,25 @@ __global__ __launch_bounds__(256) void pq_kernel(const T* __restrict__ z, const 
       // left / right neighbours come from the adjacent lanes' registers; only the two
       // lanes at the ends of a wavefront have to go to memory
       const int lane = threadIdx.x & 63;
-      T pl = __shfl_up(pc.v[3], 1), pr = __shfl_down(pc.v[0], 1);
-      T wl = __shfl_up(wc.v[3], 1), wr = __shfl_down(wc.v[0], 1);
+      T pl = __shfl_up(pc.v[V - 1], 1), pr = __shfl_down(pc.v[0], 1);
+      T wl = __shfl_up(wc.v[V - 1], 1), wr = __shfl_down(wc.v[0], 1);
       if (lane == 0 && hasl) {
         if constexpr (PGIVEN) pl = z[o - 1]; else pl = comb(z[o - 1], pin[o - 1]);
         wl = T(1);
         if (w) { wl = w[o - 1]; wl *= wl; }
       }
       if (lane == 63 && hasr) {
-        if constexpr (PGIVEN) pr = z[o + 4]; else pr = comb(z[o + 4], pin[o + 4]);
+        if constexpr (PGIVEN) pr = z[o + V]; else pr = comb(z[o + V], pin[o + V]);
         wr = T(1);
-        if (w) { wr = w[o + 4]; wr *= wr; }
+        if (w) { wr = w[o + V]; wr *= wr; }
       }
-      Vec4<T> qv;
+      VecN<T, V> qv;
 #pragma unroll
-      for (int j = 0; j < 4; ++j) {
+      for (int j = 0; j < V; ++j) {
         const T c = pc.v[j], wj = wc.v[j];
         T acc = T(0);
         // q = sum over the 4 edges of min(w^2, w_nb^2) * (p_nb - p)   (phase_unwrap.py:118-132)
-        if (j < 3) { const T wn = wc.v[j + 1]; acc += (wn < wj ? wn : wj) * (pc.v[j + 1] - c); }
+        if (j < V - 1) { const T wn = wc.v[j + 1]; acc += (wn < wj ? wn : wj) * (pc.v[j + 1] - c); }
         else if (hasr) acc += (wr < wj ? wr : wj) * (pr - c);
         if (j > 0) { const T wn = wc.v[j - 1]; acc += (wn < wj ? wn : wj) * (pc.v[j - 1] - c); }
         else if (hasl) acc += (wl < wj ? wl : wj) * (pl - c);
@@ -430,8 +433,8 @@ __global__ __launch_bounds__(256) void pq_kernel(const T* __restrict__ z, const 
         qv.v[j] = acc;
         pq += (double)c * (double)acc;
       }
-      if constexpr (!PGIVEN) *reinterpret_cast<Vec4<T>*>(pout + o) = pc;
-      *reinterpret_cast<Vec4<T>*>(q + o) = qv;
+      if constexpr (!PGIVEN) *reinterpret_cast<VecN<T, V>*>(pout + o) = pc;
+      *reinterpret_cast<VecN<T, V>*>(q + o) = qv;
       pu = pc; wu = wc;
       pc = pd; wc = wd;
     }
@@ -673,7 +676,7 @@ __global__ __launch_bounds__(256) void final_alpha_kernel(double* scal, const do
 // iteration, phase_unwrap.py:344, without writing phi back in between).  Runs whether or not the
 // iteration has stopped; phi_commit_kernel then records what was applied.
 template <class T> struct RingPtrs { const T* p[RING_MAX]; };
-template <class T>
+template <class T, int V = 4>
 __global__ __launch_bounds__(256) void phi_flush_kernel(RingPtrs<T> ringp, int ring, T* __restrict__ phi, size_t count4,
                                                        const double* __restrict__ scal, const int* __restrict__ flags,
                                                        int init, size_t pimg) {
@@ -685,15 +688,17 @@ __global__ __launch_bounds__(256) void phi_flush_kernel(RingPtrs<T> ringp, int r
   const int a = flags[2], b = flags[0];
   if (a >= b && !init) return;
   for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < count4; i += (size_t)gridDim.x * 256) {
-    Vec4<T> f = {T(0), T(0), T(0), T(0)};
-    if (!init) f = reinterpret_cast<const Vec4<T>*>(phi)[i];
+    VecN<T, V> f;
+#pragma unroll
+    for (int c = 0; c < V; ++c) f.v[c] = T(0);
+    if (!init) f = reinterpret_cast<const VecN<T, V>*>(phi)[i];
     for (int j = a; j < b; ++j) {
       const T alpha = (T)scal[SC_ALPHA + j % ring];
-      const Vec4<T> pv = reinterpret_cast<const Vec4<T>*>(ringp.p[j % ring] + pb * pimg)[i];
+      const VecN<T, V> pv = reinterpret_cast<const VecN<T, V>*>(ringp.p[j % ring] + pb * pimg)[i];
 #pragma unroll
-      for (int c = 0; c < 4; ++c) f.v[c] += alpha * pv.v[c];
+      for (int c = 0; c < V; ++c) f.v[c] += alpha * pv.v[c];
     }
-    reinterpret_cast<Vec4<T>*>(phi)[i] = f;
+    reinterpret_cast<VecN<T, V>*>(phi)[i] = f;
   }
 }
 __global__ void phi_commit_kernel(int* flags) {
@@ -1886,7 +1891,7 @@ hipError_t build_tritab(Impl* w, hipStream_t s, size_t* bytes) {
   int Q, S, pad;
   if (w->dtype == 0) tri_geometry<float>(n0, n1, w->generic, &Q, &S, &pad);
   else tri_geometry<double>(n0, n1, w->generic, &Q, &S, &pad);
-  if (S * Q > 1024) return hipSuccess;
+  if (S * Q > 1024 || n1 % (w->dtype == 0 ? 4 : 2)) return hipSuccess;   // (16-byte column vectors)
   w->triQ = Q;
   w->triS = S;
   const int R = w->dtype == 0 ? TriRows<float>::value : TriRows<double>::value;
@@ -1980,7 +1985,7 @@ hipError_t unwrap_workspace_create(int dtype, int n0, int n1, hipStream_t s, Unw
     // fits LDS -- length n itself when it is smooth, chirp-z on the smallest smooth L >= 2n - 1 otherwise
     {
       const int max_elems = (int)((size_t)159 * 1024 / (2 * w->rsz));
-      w->mr_ok = !getenv("GPA_NO_MR") && (n1 % 4) == 0 && mr_make_dft(n0, max_elems, &w->mr0) &&
+      w->mr_ok = !getenv("GPA_NO_MR") && mr_make_dft(n0, max_elems, &w->mr0) &&
                  mr_make_dft(n1, max_elems, &w->mr1);
       if (getenv("GPA_MR_FORCE_BLUESTEIN") && w->mr_ok) {   // diagnostic / tests: chirp-z also for smooth lengths
         for (MrDft* d : {&w->mr0, &w->mr1}) {
@@ -2110,7 +2115,7 @@ hipError_t unwrap_workspace_create(int dtype, int n0, int n1, hipStream_t s, Unw
 
 bool unwrap_supports_batch(const UnwrapWorkspace* ws) {
   const Impl* w = (const Impl*)ws->impl;
-  return w && w->supported && (!w->generic || w->mr_ok) && (w->n1 % 4) == 0;
+  return w && w->supported && (!w->generic || w->mr_ok);
 }
 
 void unwrap_workspace_destroy(UnwrapWorkspace* ws) {
@@ -2146,9 +2151,13 @@ static hipError_t run_pcg(Impl* w, const void* a, const void* b, const void* wei
   if (np2 > MAXPART) return hipErrorInvalidValue;
   // band height of the stencil kernel: 16 rows for large images, fewer when that would leave
   // less than ~2048 workgroups (small images are latency-, not bandwidth-bound)
+  // rows of whole 4-pixel vectors take 16-byte accesses in the stencil / flush / mixed-radix row kernels, any other
+  // row length (generic sizes only: power-of-two rows are always whole vectors) their one-pixel instantiations
+  const int V = (n1 % 4) == 0 ? 4 : 1;
+  const int pqcols = 256 * V;
   int band = PQ_ROWS;
-  while (band > 4 && (size_t)((n1 + 1023) / 1024) * ((n0 + band - 1) / band) < 2048) band /= 2;
-  const dim3 gpq((n1 + 1023) / 1024, (n0 + band - 1) / band);
+  while (band > 4 && (size_t)((n1 + pqcols - 1) / pqcols) * ((n0 + band - 1) / band) < 2048) band /= 2;
+  const dim3 gpq((n1 + pqcols - 1) / pqcols, (n0 + band - 1) / band);
   const int npq = gpq.x * gpq.y;
   if (npq > MAXPART) return hipErrorInvalidValue;
   const int gl = 2048;   // grid-stride elementwise kernels
@@ -2168,12 +2177,12 @@ static hipError_t run_pcg(Impl* w, const void* a, const void* b, const void* wei
     // prepared: r0 and its w->prepared_parts partial norms were written by the producer of the gradients
     // (reconstruct_setup_kernel).  phi = 0: the fused path's first phi_flush_kernel starts from 0, the
     // other paths update phi in place and need it cleared
-    const bool fused_path = (!w->generic || w->mr_ok) && (n1 % 4) == 0;
+    const bool fused_path = !w->generic || w->mr_ok;
     if (!fused_path && (e = hipMemsetAsync(phi, 0, npx * w->rsz, s)) != hipSuccess) return e;
     GPA_PROF("scalar_kernels", s);
     scal_init_kernel<<<dim3(1, 1, w->nprob), 256, 0, s>>>(w->part, w->prepared_parts, w->scal, w->flags);
   }
-  const bool vec4 = (!w->generic || w->mr_ok) && (n1 % 4) == 0;   // pq_kernel needs 16-byte aligned rows
+  const bool vec4 = !w->generic || w->mr_ok;   // the fused 4-kernel iteration
   if (w->nprob > 1 && (a || !vec4)) return hipErrorNotSupported;   // batched: prepared start on the fused path only
   if (vec4) {
     // fused power-of-two path: 4 kernels per iteration, no scalar kernels.  The phi / r update
@@ -2197,8 +2206,12 @@ static hipError_t run_pcg(Impl* w, const void* a, const void* b, const void* wei
     bool phi_unwritten = a == nullptr;   // prepared start: nobody has zeroed phi
     auto flush = [&]() {
       { GPA_PROF("phi_flush_kernel", s);
-        phi_flush_kernel<T><<<dim3(gl, 1, w->nprob), 256, 0, s>>>(rp, ring, (T*)phi, npx / 4, w->scal, w->flags,
-                                                                 phi_unwritten ? 1 : 0, npx); }
+        if (V == 4)
+          phi_flush_kernel<T, 4><<<dim3(gl, 1, w->nprob), 256, 0, s>>>(rp, ring, (T*)phi, npx / 4, w->scal, w->flags,
+                                                                      phi_unwritten ? 1 : 0, npx);
+        else
+          phi_flush_kernel<T, 1><<<dim3(gl, 1, w->nprob), 256, 0, s>>>(rp, ring, (T*)phi, npx, w->scal, w->flags,
+                                                                      phi_unwritten ? 1 : 0, npx); }
       { GPA_PROF("scalar_kernels", s); phi_commit_kernel<<<dim3(1, 1, w->nprob), 1, 0, s>>>(w->flags); }
       phi_unwritten = false;
     };
@@ -2212,9 +2225,14 @@ static hipError_t run_pcg(Impl* w, const void* a, const void* b, const void* wei
       T* pout = (T*)w->ring[it % ring];
       if ((e = dispatch_rowidct_p(w, pin, pout, part_rho, nrow, it, s)) != hipSuccess) return e;
       { GPA_PROF("pq_kernel", s);
-        pq_kernel<T, true><<<dim3(gpq.x, gpq.y, w->nprob), 256, 0, s>>>(pout, nullptr, nullptr, (const T*)weight, n0, n1,
-                                                                        (T*)w->q, part_pq, w->scal, w->flags, nullptr, 0, it,
-                                                                        band, npx); }
+        if (V == 4)
+          pq_kernel<T, true, 4><<<dim3(gpq.x, gpq.y, w->nprob), 256, 0, s>>>(pout, nullptr, nullptr, (const T*)weight, n0,
+                                                                             n1, (T*)w->q, part_pq, w->scal, w->flags,
+                                                                             nullptr, 0, it, band, npx);
+        else
+          pq_kernel<T, true, 1><<<dim3(gpq.x, gpq.y, w->nprob), 256, 0, s>>>(pout, nullptr, nullptr, (const T*)weight, n0,
+                                                                             n1, (T*)w->q, part_pq, w->scal, w->flags,
+                                                                             nullptr, 0, it, band, npx); }
     }
     { GPA_PROF("scalar_kernels", s);
       final_alpha_kernel<<<dim3(1, 1, w->nprob), 256, 0, s>>>(w->scal, part_pq, npq, kmax, ring, w->flags);

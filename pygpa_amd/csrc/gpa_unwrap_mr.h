@@ -21,7 +21,7 @@ namespace {
 __device__ __forceinline__ int mr_slot_of(int c, int n) { return (c & 1) ? n - 1 - (c >> 1) : (c >> 1); }
 
 // rows: R = DCT-II_rows(r) (it == 0, in place) or R -= alpha DCT-II_rows(q) with the partial ||r||^2 (it > 0)
-template <class T, int MAXT>
+template <class T, int MAXT, int V>
 __global__ __launch_bounds__(MAXT) void mr_rowdct_fused_kernel(
     T* __restrict__ r, const T* __restrict__ q, int n0, const MrDft d, int rs, const cpx<T>* __restrict__ W,
     const cpx<T>* __restrict__ chirp, const cpx<T>* __restrict__ bspec,
@@ -56,22 +56,24 @@ __global__ __launch_bounds__(MAXT) void mr_rowdct_fused_kernel(
   const T* src = it > 0 ? q : r;
   // all loads of a thread are issued before the first use (a loop of load -> LDS store pays one memory latency per
   // trip); rows are whole 4-pixel vectors, n / (4 Tn) <= 4 vectors per thread and row
-  constexpr int NV = MR_REGS / 4;
-  const Vec4<T> zero4 = {{T(0), T(0), T(0), T(0)}};
+  constexpr int NV = MR_REGS / V;
+  VecN<T, V> zero4;
+#pragma unroll
+  for (int j = 0; j < V; ++j) zero4.v[j] = T(0);
   {
-    Vec4<T> qa[NV], qb[NV];
+    VecN<T, V> qa[NV], qb[NV];
 #pragma unroll
     for (int i = 0; i < NV; ++i) {
-      const int c0 = 4 * (tid + Tn * i);
-      qa[i] = (c0 < n && va) ? *reinterpret_cast<const Vec4<T>*>(src + oa + c0) : zero4;
-      qb[i] = (c0 < n && vb) ? *reinterpret_cast<const Vec4<T>*>(src + ob + c0) : zero4;
+      const int c0 = V * (tid + Tn * i);
+      qa[i] = (c0 < n && va) ? *reinterpret_cast<const VecN<T, V>*>(src + oa + c0) : zero4;
+      qb[i] = (c0 < n && vb) ? *reinterpret_cast<const VecN<T, V>*>(src + ob + c0) : zero4;
     }
 #pragma unroll
     for (int i = 0; i < NV; ++i) {
-      const int c0 = 4 * (tid + Tn * i);
+      const int c0 = V * (tid + Tn * i);
       if (c0 < n) {
 #pragma unroll
-        for (int j = 0; j < 4; ++j) lds[mr_pad(mr_slot_of(c0 + j, n))] = {qa[i].v[j], qb[i].v[j]};
+        for (int j = 0; j < V; ++j) lds[mr_pad(mr_slot_of(c0 + j, n))] = {qa[i].v[j], qb[i].v[j]};
       }
     }
   }
@@ -79,23 +81,23 @@ __global__ __launch_bounds__(MAXT) void mr_rowdct_fused_kernel(
   mr_dft<MAXT>(lds, d, W, chirp, bspec, tid);
   double sq = 0;
   {
-    Vec4<T> ra[NV], rb[NV];
-    struct alignas(4 * sizeof(cpx<T>)) W4 { cpx<T> v[4]; };
+    VecN<T, V> ra[NV], rb[NV];
+    struct alignas(V * sizeof(cpx<T>)) W4 { cpx<T> v[V]; };
     W4 w4[NV];
 #pragma unroll
     for (int i = 0; i < NV; ++i) {
-      const int k0 = 4 * (tid + Tn * i);
-      ra[i] = (it > 0 && k0 < n && va) ? *reinterpret_cast<const Vec4<T>*>(r + oa + k0) : zero4;
-      rb[i] = (it > 0 && k0 < n && vb) ? *reinterpret_cast<const Vec4<T>*>(r + ob + k0) : zero4;
+      const int k0 = V * (tid + Tn * i);
+      ra[i] = (it > 0 && k0 < n && va) ? *reinterpret_cast<const VecN<T, V>*>(r + oa + k0) : zero4;
+      rb[i] = (it > 0 && k0 < n && vb) ? *reinterpret_cast<const VecN<T, V>*>(r + ob + k0) : zero4;
       if (k0 < n) w4[i] = *reinterpret_cast<const W4*>(wk + k0);
     }
 #pragma unroll
     for (int i = 0; i < NV; ++i) {
-      const int k0 = 4 * (tid + Tn * i);
+      const int k0 = V * (tid + Tn * i);
       if (k0 < n) {
-        Vec4<T> oa4, ob4;
+        VecN<T, V> oa4, ob4;
 #pragma unroll
-        for (int j = 0; j < 4; ++j) {
+        for (int j = 0; j < V; ++j) {
           const int k = k0 + j;
           const cpx<T> zk = lds[mr_pad(k)], zm = lds[mr_pad(k == 0 ? 0 : n - k)];
           const cpx<T> w = w4[i].v[j];
@@ -111,8 +113,8 @@ __global__ __launch_bounds__(MAXT) void mr_rowdct_fused_kernel(
           oa4.v[j] = xa;
           ob4.v[j] = xb;
         }
-        if (va) *reinterpret_cast<Vec4<T>*>(r + oa + k0) = oa4;
-        if (vb) *reinterpret_cast<Vec4<T>*>(r + ob + k0) = ob4;
+        if (va) *reinterpret_cast<VecN<T, V>*>(r + oa + k0) = oa4;
+        if (vb) *reinterpret_cast<VecN<T, V>*>(r + ob + k0) = ob4;
       }
     }
   }
@@ -123,7 +125,7 @@ __global__ __launch_bounds__(MAXT) void mr_rowdct_fused_kernel(
 }
 
 // rows: z = DCT-III_rows(Z), p = z + beta p_prev -> the ring slot of this iteration
-template <class T, int MAXT>
+template <class T, int MAXT, int V>
 __global__ __launch_bounds__(MAXT) void mr_rowidct_p_kernel(
     const T* __restrict__ Z, const T* __restrict__ pin, T* __restrict__ pout, int n0, const MrDft d, int rs,
     const cpx<T>* __restrict__ W, const cpx<T>* __restrict__ chirp, const cpx<T>* __restrict__ bspec,
@@ -148,24 +150,26 @@ __global__ __launch_bounds__(MAXT) void mr_rowidct_p_kernel(
   const int xa = 2 * pr, xb = xa + 1;
   const bool va = xa < n0, vb = xb < n0;
   const size_t oa = (size_t)(va ? xa : 0) * n, ob = (size_t)(vb ? xb : 0) * n;
-  constexpr int NV = MR_REGS / 4;
-  const Vec4<T> zero4 = {{T(0), T(0), T(0), T(0)}};
+  constexpr int NV = MR_REGS / V;
+  VecN<T, V> zero4;
+#pragma unroll
+  for (int j = 0; j < V; ++j) zero4.v[j] = T(0);
   // the two spectra come in with batched 16-byte loads and are parked in LDS in natural order: bin n - k, which the
   // DCT-III needs next to bin k, would otherwise be a second, misaligned pass over the rows
   {
-    Vec4<T> za[NV], zb[NV];
+    VecN<T, V> za[NV], zb[NV];
 #pragma unroll
     for (int i = 0; i < NV; ++i) {
-      const int k0 = 4 * (tid + Tn * i);
-      za[i] = (k0 < n && va) ? *reinterpret_cast<const Vec4<T>*>(Z + oa + k0) : zero4;
-      zb[i] = (k0 < n && vb) ? *reinterpret_cast<const Vec4<T>*>(Z + ob + k0) : zero4;
+      const int k0 = V * (tid + Tn * i);
+      za[i] = (k0 < n && va) ? *reinterpret_cast<const VecN<T, V>*>(Z + oa + k0) : zero4;
+      zb[i] = (k0 < n && vb) ? *reinterpret_cast<const VecN<T, V>*>(Z + ob + k0) : zero4;
     }
 #pragma unroll
     for (int i = 0; i < NV; ++i) {
-      const int k0 = 4 * (tid + Tn * i);
+      const int k0 = V * (tid + Tn * i);
       if (k0 < n) {
 #pragma unroll
-        for (int j = 0; j < 4; ++j) lds[mr_pad(k0 + j)] = {za[i].v[j], zb[i].v[j]};
+        for (int j = 0; j < V; ++j) lds[mr_pad(k0 + j)] = {za[i].v[j], zb[i].v[j]};
       }
     }
   }
@@ -197,26 +201,26 @@ __global__ __launch_bounds__(MAXT) void mr_rowidct_p_kernel(
   mr_dft<MAXT>(lds, d, W, chirp, bspec, tid);
   const T inv_n = T(1) / T(n);
   {
-    Vec4<T> pa4[NV], pb4[NV];
+    VecN<T, V> pa4[NV], pb4[NV];
 #pragma unroll
     for (int i = 0; i < NV; ++i) {
-      const int c0 = 4 * (tid + Tn * i);
-      pa4[i] = (!first && c0 < n && va) ? *reinterpret_cast<const Vec4<T>*>(pin + oa + c0) : zero4;
-      pb4[i] = (!first && c0 < n && vb) ? *reinterpret_cast<const Vec4<T>*>(pin + ob + c0) : zero4;
+      const int c0 = V * (tid + Tn * i);
+      pa4[i] = (!first && c0 < n && va) ? *reinterpret_cast<const VecN<T, V>*>(pin + oa + c0) : zero4;
+      pb4[i] = (!first && c0 < n && vb) ? *reinterpret_cast<const VecN<T, V>*>(pin + ob + c0) : zero4;
     }
 #pragma unroll
     for (int i = 0; i < NV; ++i) {
-      const int c0 = 4 * (tid + Tn * i);
+      const int c0 = V * (tid + Tn * i);
       if (c0 < n) {
-        Vec4<T> oa4, ob4;
+        VecN<T, V> oa4, ob4;
 #pragma unroll
-        for (int j = 0; j < 4; ++j) {
+        for (int j = 0; j < V; ++j) {
           const cpx<T> v = lds[mr_pad(mr_slot_of(c0 + j, n))];
           oa4.v[j] = v.x * inv_n + beta * pa4[i].v[j];
           ob4.v[j] = -v.y * inv_n + beta * pb4[i].v[j];
         }
-        if (va) *reinterpret_cast<Vec4<T>*>(pout + oa + c0) = oa4;
-        if (vb) *reinterpret_cast<Vec4<T>*>(pout + ob + c0) = ob4;
+        if (va) *reinterpret_cast<VecN<T, V>*>(pout + oa + c0) = oa4;
+        if (vb) *reinterpret_cast<VecN<T, V>*>(pout + ob + c0) = ob4;
       }
     }
   }
@@ -224,7 +228,7 @@ __global__ __launch_bounds__(MAXT) void mr_rowidct_p_kernel(
 
 // columns: Z = DCT-III_cols( DCT-II_cols(R) / eigenvalues ), the stopping test on the update the row kernel has
 // just applied, partial rho = <r, z> from the packed spectra (see WgDCT::solve_combine for the Parseval argument)
-template <class T, int MAXT>
+template <class T, int MAXT, int V>   // (V unused: the columns are read pair by pair)
 __global__ __launch_bounds__(MAXT) void mr_colsolve_kernel(
     const T* __restrict__ Zin, T* __restrict__ Z, int n1, const MrDft d, int rs, const cpx<T>* __restrict__ W,
     const cpx<T>* __restrict__ chirp, const cpx<T>* __restrict__ bspec,
@@ -356,15 +360,15 @@ inline int mr_pick_nf(int pairs, int T, int cap, size_t lds_per_transform) {
   return nf;
 }
 
-#define GPA_MR_LAUNCH(KERNEL, threads, ...)                                                                    \
+#define GPA_MR_LAUNCH(KERNEL, VV, threads, ...)                                                                    \
   do {                                                                                                         \
-    if ((threads) <= 256) { GPA_MR_LAUNCH1(KERNEL, 256, __VA_ARGS__); }                                        \
-    else if ((threads) <= 512) { GPA_MR_LAUNCH1(KERNEL, 512, __VA_ARGS__); }                                   \
-    else { GPA_MR_LAUNCH1(KERNEL, 1024, __VA_ARGS__); }                                                        \
+    if ((threads) <= 256) { GPA_MR_LAUNCH1(KERNEL, VV, 256, __VA_ARGS__); }                                    \
+    else if ((threads) <= 512) { GPA_MR_LAUNCH1(KERNEL, VV, 512, __VA_ARGS__); }                               \
+    else { GPA_MR_LAUNCH1(KERNEL, VV, 1024, __VA_ARGS__); }                                                     \
   } while (0)
-#define GPA_MR_LAUNCH1(KERNEL, MAXT, ...)                                                                      \
+#define GPA_MR_LAUNCH1(KERNEL, VV, MAXT, ...)                                                                    \
   do {                                                                                                         \
-    auto kern = KERNEL<T, MAXT>;                                                                               \
+    auto kern = KERNEL<T, MAXT, VV>;                                                                           \
     static unsigned lds_set = 0;                                                                               \
     hipError_t e = set_dynamic_lds_once(reinterpret_cast<const void*>(kern), MR_LDS_MAX, lds_set);               \
     if (e != hipSuccess) return e;                                                                             \
@@ -382,8 +386,12 @@ hipError_t run_mr_rowdct_fused(const Impl* w, const void* q, int ring, const dou
   const size_t lds = (size_t)nf * rs * sizeof(cpx<T>);
   *nnorm = grid;
   GPA_PROF("rowdct_fused_kernel", s);
-  GPA_MR_LAUNCH(mr_rowdct_fused_kernel, threads, (T*)w->r, (const T*)q, w->n0, d, rs, (const cpx<T>*)w->mrW1, (const cpx<T>*)w->chirp1, (const cpx<T>*)w->mrB1,
-                (const cpx<T>*)w->gwk1, w->flags, part_pq, npq, part_norm, w->scal, it, ring, (size_t)w->n0 * w->n1);
+#define GPA_MR_ARGS                                                                                                    \
+  (T*)w->r, (const T*)q, w->n0, d, rs, (const cpx<T>*)w->mrW1, (const cpx<T>*)w->chirp1, (const cpx<T>*)w->mrB1,       \
+      (const cpx<T>*)w->gwk1, w->flags, part_pq, npq, part_norm, w->scal, it, ring, (size_t)w->n0 * w->n1
+  if ((w->n1 % 4) == 0) GPA_MR_LAUNCH(mr_rowdct_fused_kernel, 4, threads, GPA_MR_ARGS);
+  else GPA_MR_LAUNCH(mr_rowdct_fused_kernel, 1, threads, GPA_MR_ARGS);
+#undef GPA_MR_ARGS
   return hipGetLastError();
 }
 
@@ -397,8 +405,12 @@ hipError_t run_mr_rowidct_p(const Impl* w, const void* pin, void* pout, const do
   const int grid = (pairs + nf - 1) / nf, threads = nf * pl.T;
   const size_t lds = (size_t)nf * rs * sizeof(cpx<T>);
   GPA_PROF("rowidct_p_kernel", s);
-  GPA_MR_LAUNCH(mr_rowidct_p_kernel, threads, (const T*)w->z, (const T*)pin, (T*)pout, w->n0, d, rs,
-                (const cpx<T>*)w->mrW1, (const cpx<T>*)w->chirp1, (const cpx<T>*)w->mrB1, (const cpx<T>*)w->gwk1, w->flags, part_rho, nrho, w->scal, it, (size_t)w->n0 * w->n1);
+#define GPA_MR_ARGS                                                                                                   \
+  (const T*)w->z, (const T*)pin, (T*)pout, w->n0, d, rs, (const cpx<T>*)w->mrW1, (const cpx<T>*)w->chirp1,            \
+      (const cpx<T>*)w->mrB1, (const cpx<T>*)w->gwk1, w->flags, part_rho, nrho, w->scal, it, (size_t)w->n0 * w->n1
+  if ((w->n1 % 4) == 0) GPA_MR_LAUNCH(mr_rowidct_p_kernel, 4, threads, GPA_MR_ARGS);
+  else GPA_MR_LAUNCH(mr_rowidct_p_kernel, 1, threads, GPA_MR_ARGS);
+#undef GPA_MR_ARGS
   return hipGetLastError();
 }
 
@@ -414,7 +426,7 @@ hipError_t run_mr_colsolve(const Impl* w, int compat, hipStream_t s, const doubl
   const size_t lds = (size_t)nf * rs * sizeof(cpx<T>);
   if (nrho) *nrho = grid;
   GPA_PROF("colsolve_kernel", s);
-  GPA_MR_LAUNCH(mr_colsolve_kernel, threads, (const T*)(zin ? zin : w->z), (T*)w->z, w->n1, d, rs,
+  GPA_MR_LAUNCH(mr_colsolve_kernel, 4, threads, (const T*)(zin ? zin : w->z), (T*)w->z, w->n1, d, rs,
                 (const cpx<T>*)w->mrW0, (const cpx<T>*)w->chirp0, (const cpx<T>*)w->mrB0, (const cpx<T>*)w->gwk0, (const T*)w->gha0[compat], (const T*)w->gham0[compat],
                 (const T*)w->hb1[compat], w->flags, part_norm, nnorm, it, eps, w->scal, part_rho, (size_t)w->n0 * w->n1);
   return hipGetLastError();

@@ -451,7 +451,7 @@ def extract_displacement_field_stack(images, kvecs, sigma=None, kwscale=2.5, kst
     movie, a tilt or temperature series -- in ONE device call: every kernel of the driver takes an image index from
     its grid, so the ~110 dependent launches that bound a small image are paid once per stack (512^2 frames: x4
     the single-image rate).  No counterpart in the reference (a Python loop over `extract_displacement_field`,
-    geometric_phase_analysis.py:907-932, gives the same numbers); rows must be a multiple of 4 pixels.
+    geometric_phase_analysis.py:907-932, gives the same numbers).
     Returns u of shape (B, 2, N, M)."""
     images = np.asarray(images)
     if images.ndim != 3:

@@ -1058,10 +1058,12 @@ def _unwrap_case(shape, seed, weighted=True):
 
 @pytest.mark.gpu
 @pytest.mark.parametrize('shape', [(48, 80), (100, 60), (300, 200), (500, 500), (130, 104), (360, 364), (1000, 1500),
-                                   (66, 88), (512, 384), (36, 36), (100, 100), (1000, 1000), (1200, 1200)])
+                                   (66, 88), (512, 384), (36, 36), (100, 100), (1000, 1000), (1200, 1200),
+                                   (63, 65), (250, 250), (126, 90), (1001, 1001), (75, 77)])
 def test_mixed_radix_fused_unwrap_vs_oracle(shape, monkeypatch):
-    """image sizes that factor into 2, 3, 5, 7, 11, 13 with rows of a multiple of 4 pixels run the fused
-    4-kernel PCG on the mixed-radix FFT (square ones with the transform-free column solve on ragged chunks):
+    """image sizes that factor into 2, 3, 5, 7, 11, 13 run the fused 4-kernel PCG on the mixed-radix FFT (square ones
+    with the transform-free column solve on ragged chunks; rows that are not whole 4-pixel vectors -- 63 x 65, 250^2,
+    1001^2 -- through the one-pixel instantiations of the stencil, flush and row kernels):
     same numbers as the oracle (f64 1e-8, f32 within the PCG tolerance), the same iteration count as the
     Bluestein path (GPA_NO_MR=1) and as the oracle's loop"""
     psi, weight = _unwrap_case(shape, 31 + shape[0])
@@ -1128,7 +1130,7 @@ def test_random_smooth_shapes_unwrap_vs_oracle():
 
 
 @pytest.mark.gpu
-@pytest.mark.parametrize('shape', [(68, 68), (136, 116), (204, 236), (332, 332), (1392, 1040), (1006, 1004)])
+@pytest.mark.parametrize('shape', [(68, 68), (136, 116), (204, 236), (332, 332), (1392, 1040), (1006, 1004), (97, 101), (202, 202)])
 def test_chirpz_fused_unwrap_vs_oracle(shape, monkeypatch):
     """sides with a prime factor > 13 (17, 29, 59, 83, 251, 503): the fused iteration with chirp-z DFTs on a smooth
     L >= 2n - 1 of the mixed-radix engine (transform-free columns when square) against the oracle and against
@@ -1175,7 +1177,7 @@ def test_chirpz_forced_on_smooth_lengths(monkeypatch):
 
 @pytest.mark.gpu
 @pytest.mark.parametrize('dtype', DTYPES)
-@pytest.mark.parametrize('shape', [(128, 128), (256, 512), (100, 60), (300, 300), (136, 116)])
+@pytest.mark.parametrize('shape', [(128, 128), (256, 512), (100, 60), (300, 300), (136, 116), (63, 65), (250, 250)])
 def test_image_stack_equals_single_images(shape, dtype):
     """gpa_extract_displacement_field_batch_dev: a stack of images through one set of unwrap launches
     (blockIdx.z = problem) -- every image's u and iteration counts equal the single-image driver's bit for bit
