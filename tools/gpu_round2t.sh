@@ -3,6 +3,7 @@
 out=gpurun_out/r2t; mkdir -p $out
 python -m pytest tests -q -m gpu -x --durations=12 > $out/pytest_gpu.log 2>&1
 tail -22 $out/pytest_gpu.log
+python __graft_entry__.py smoke 2>&1 | tail -1
 python bench.py > $out/bench.json 2> $out/bench.err; tail -3 $out/bench.err; cat $out/bench.json
 ROOT=$PWD
 cd /tmp && export TMPDIR=/tmp
