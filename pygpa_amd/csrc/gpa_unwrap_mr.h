@@ -5,8 +5,11 @@
 // as its row spectrum, rho and ||r|| by Parseval), same scalars and flags, so run_pcg() drives both with one
 // loop.  What differs is where a transform lives: here the packed pair of rows / columns sits in LDS in the
 // Makhoul order (slot m holds sample makhoul_src(m)), the FFT passes run in place, and the DCT pre / post
-// processing reads bins k and n - k from LDS.  Global accesses are lane-consecutive along the rows; the column
-// kernel takes NF adjacent column pairs per workgroup (NF * 2 * sizeof(T) contiguous bytes per row).
+// processing reads bins k and n - k from LDS.  Global accesses are lane-consecutive along the rows and batched
+// (every load of a thread is issued before the first use), V pixels per access: V = 4 where rows are whole 16-byte
+// vectors, V = 1 otherwise; the column kernel takes NF adjacent column pairs per workgroup (NF * 2 * sizeof(T)
+// contiguous bytes per row).  A DFT is mr_dft(): the mixed-radix transform of length n, or chirp-z on a smooth
+// L >= 2n - 1 when n has a prime factor > 13.  blockIdx.z selects the problem of a batched solve (see gpa_unwrap.hip).
 //
 // Replaces, per PCG iteration, the Bluestein kernels g_rowdct / g_colsolve / g_rowidct (4 FFTs of length
 // >= 2n - 1 per DCT pair instead of one of length n) and the separate pupdate / applyq / update / scal_* kernels:
