@@ -192,6 +192,8 @@ int gpa_extract_displacement_field_batch_dev(gpa_plan* plan, const void* images,
                                              const double* kvecs, int P, const double* klists, int K,
                                              double sigma, int mask_border, int kmax, void* u,
                                              int* iters_out);
+/* waits for the plan's stream and returns the 2 B iteration counts of the last batch call (B <= its stack size) */
+int gpa_last_batch_iters(gpa_plan* plan, int B, int* iters_out);
 
 /* tile stage of the multi-GPU path: sweep + phases/weights + per-pixel least squares of
  * extract_displacement_field (:919-926, :234-237) WITHOUT the unwrap; the gradient tiles of all

@@ -50,6 +50,7 @@ SIGNATURES = {
     'gpa_extract_displacement_field_async': (_i, [_vp, _vp, _vp, _i, _vp, _i, _d, _i, _i, _vp, _vp, _vp]),
     'gpa_last_iters': (_i, [_vp, _vp]),
     'gpa_extract_displacement_field_batch_dev': (_i, [_vp, _vp, _i, _vp, _i, _vp, _i, _d, _i, _i, _vp, _vp]),
+    'gpa_last_batch_iters': (_i, [_vp, _i, _vp]),
     'gpa_extract_gradients': (_i, [_vp, _vp, _vp, _i, _vp, _i, _d, _i, _vp, _vp, _vp]),
     'gpa_mean_dev': (_i, [_vp, _vp, _sz, _dp]),
     'gpa_tile_gradients_dev': (_i, [_vp, _vp, _sz, _i, _i, _d, _vp, _i, _vp, _i, _d, _i, _i, _i, _i, _i,
@@ -450,23 +451,67 @@ class Plan:
               'gpa_extract_displacement_field_batch_dev')
         return None if it is None else np.array(it[:], dtype=np.int64).reshape(int(nimages), 2)
 
-    def extract_displacement_field_stack(self, images, kvecs, klists, sigma, mask_border, kmax=10):
-        """host arrays: images (B, n0, n1) -> u (B, 2, n0, n1) and the (B, 2) iteration counts, through
-        extract_displacement_field_batch_dev"""
-        images = np.ascontiguousarray(images, dtype=self.rdtype)
+    def extract_displacement_field_stack(self, images, kvecs, klists, sigma, mask_border, kmax=10, chunk=None, out=None):
+        """host arrays: images (B, n0, n1) -> u (B, 2, n0, n1) (written into `out` if given) and the (B, 2)
+        iteration counts, through extract_displacement_field_batch_dev.  The stack goes through the GPU in chunks of
+        `chunk` frames (default: ~16 Mpixel per chunk) on two sets of device buffers: while the GPU works on chunk i a
+        host thread uploads chunk i + 1 and another downloads chunk i - 1 (PCIe is full duplex, plain hipMemcpy on the
+        default stream does not wait for the plan's non-blocking streams, ctypes releases the GIL)."""
+        from concurrent.futures import ThreadPoolExecutor
+        images = np.asarray(images)
         if images.ndim != 3 or images.shape[1:] != tuple(self.shape):
             raise ValueError('images must be (B, %d, %d)' % tuple(self.shape))
         B = images.shape[0]
-        d_img = DeviceBuffer(images.nbytes)
-        d_u = DeviceBuffer(2 * images.nbytes)
+        npx = int(self.shape[0]) * int(self.shape[1])
+        if chunk is None:
+            chunk = max(1, min(B, (16 << 20) // npx))
+        chunk = int(max(1, min(chunk, B)))
+        nchunks = -(-B // chunk)
+        item = np.dtype(self.rdtype).itemsize
+        # (a plain array: page-locking hundreds of MB costs more than it saves -- 104 ms for 256 MB on the MI355X box,
+        #  where hipMemcpy into pageable memory runs at ~50 GB/s anyway; pass out= to reuse a buffer)
+        u = out if out is not None else np.empty((B, 2) + tuple(self.shape), self.rdtype)
+        if u.shape != (B, 2) + tuple(self.shape) or u.dtype != self.rdtype or not u.flags.c_contiguous:
+            raise ValueError('out must be a C-contiguous (B, 2, n0, n1) array of the plan dtype')
+        iters = np.zeros((B, 2), dtype=np.int64)
+        d_img = [DeviceBuffer(chunk * npx * item) for _ in range(min(2, nchunks))]
+        d_u = [DeviceBuffer(2 * chunk * npx * item) for _ in range(min(2, nchunks))]
+        bounds = [(c * chunk, min(B, (c + 1) * chunk)) for c in range(nchunks)]
+
+        def upload(c):
+            a, b = bounds[c]
+            d_img[c % 2].upload(np.ascontiguousarray(images[a:b], dtype=self.rdtype))
+
+        def download(c):
+            a, b = bounds[c]
+            d_u[c % 2].download_into(u[a:b])
+
         try:
-            d_img.upload(images)
-            iters = self.extract_displacement_field_batch_dev(d_img.ptr, B, kvecs, klists, sigma, mask_border, kmax, d_u.ptr)
-            u = d_u.download((B, 2) + tuple(self.shape), self.rdtype)
+            with ThreadPoolExecutor(1) as up_pool, ThreadPoolExecutor(1) as dn_pool:
+                ups = {0: up_pool.submit(upload, 0)}
+                dns = {}
+                for c in range(nchunks):
+                    ups[c].result()                       # chunk c is on the device
+                    if c - 2 in dns:
+                        dns.pop(c - 2).result()           # its u buffer has been read out
+                    a, b = bounds[c]
+                    it = self.extract_displacement_field_batch_dev(d_img[c % 2].ptr, b - a, kvecs, klists, sigma, mask_border,
+                                                                   kmax, d_u[c % 2].ptr, want_iters=False)
+                    if c + 1 < nchunks:                    # (its image buffer was last read by chunk c - 1: done, see sync below)
+                        ups[c + 1] = up_pool.submit(upload, c + 1)
+                    iters[a:b] = self._batch_iters(b - a)   # synchronises: chunk c is finished
+                    dns[c] = dn_pool.submit(download, c)
+                for f in dns.values():
+                    f.result()
         finally:
-            d_img.free()
-            d_u.free()
+            for buf in d_img + d_u:
+                buf.free()
         return u, iters
+
+    def _batch_iters(self, nimages):
+        it = (C.c_int * (2 * int(nimages)))()
+        check(self.lib.gpa_last_batch_iters(self.handle, int(nimages), it), 'gpa_last_batch_iters')
+        return np.array(it[:], dtype=np.int64).reshape(int(nimages), 2)
 
     def last_iters(self):
         it = (C.c_int * 2)()
@@ -533,6 +578,13 @@ class DeviceBuffer:
         if self._hip.hipMemcpy(out.ctypes.data_as(C.c_void_p), C.c_void_p(self.ptr), C.c_size_t(out.nbytes), 2) != 0:
             raise GPAError('hipMemcpy D2H failed')
         return out
+
+    def download_into(self, out):
+        """copy the first out.nbytes bytes into the (C-contiguous) array `out`"""
+        if not out.flags.c_contiguous:
+            raise ValueError('destination must be C-contiguous')
+        if self._hip.hipMemcpy(out.ctypes.data_as(C.c_void_p), C.c_void_p(self.ptr), C.c_size_t(out.nbytes), 2) != 0:
+            raise GPAError('hipMemcpy D2H failed')
 
     def free(self):
         if getattr(self, 'ptr', None):

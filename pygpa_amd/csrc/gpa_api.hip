@@ -1202,6 +1202,13 @@ int gpa_extract_displacement_field_batch_dev(gpa_plan* p, const void* images, in
   return GPA_OK;
 }
 
+int gpa_last_batch_iters(gpa_plan* p, int B, int* iters_out) {
+  if (!p || !iters_out || B < 1 || B > p->uwb_images) return fail(GPA_ERR_ARG, "gpa_last_batch_iters: bad argument");
+  HIP_TRY(hipStreamSynchronize(p->stream));
+  for (int j = 0; j < 2 * B; ++j) iters_out[j] = p->h_iters_b[4 * j];
+  return GPA_OK;
+}
+
 int gpa_last_iters(gpa_plan* p, int* iters2) {
   if (!p || !iters2) return fail(GPA_ERR_ARG, "null argument");
   HIP_TRY(hipStreamSynchronize(p->stream));

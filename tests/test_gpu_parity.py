@@ -1198,4 +1198,7 @@ def test_image_stack_equals_single_images(shape, dtype):
     # a second call with another stack size reallocates the batch workspace
     u_b2, _ = plan.extract_displacement_field_stack(imgs[:2], kvecs, klists, sigma, 2 * sigma, kmax=10)
     assert np.array_equal(u_b2, u_b[:2])
+    # chunks of 2 frames (2 + 2 + 1) through the double-buffered upload / compute / download pipeline
+    u_c, it_c = plan.extract_displacement_field_stack(imgs, kvecs, klists, sigma, 2 * sigma, kmax=10, chunk=2)
+    assert np.array_equal(u_c, u_b) and np.array_equal(it_c, it_b)
     plan.close()
