@@ -488,3 +488,61 @@ def extract_displacement_field_ksharded(image, kvecs, sigma=None, kwscale=2.5, k
     parts = _all_gather_np(mine_u, group)
     u = np.stack([parts[c % world][c] for c in range(2)])
     return u, best, bidx
+
+
+# ---- stacks of frames: the units shard, nothing is exchanged on the data path ----------------------------------------
+def stack_shares(nframes, world):
+    """contiguous blocks of frames per rank, sizes differing by at most one: [(start, stop)] * world"""
+    base, extra = divmod(int(nframes), int(world))
+    out, a = [], 0
+    for r in range(world):
+        b = a + base + (1 if r < extra else 0)
+        out.append((a, b))
+        a = b
+    return out
+
+
+def extract_displacement_field_stack_sharded(frames, kvecs, sigma=None, kwscale=2.5, ksteps=3, klists=None, kmax=10,
+                                             dtype=np.float32, device=0, group=None, gather=True, compute=None):
+    """A stack of frames (B, N, M) over the ranks of the process group: rank r runs
+    `Plan.extract_displacement_field_stack` (one device call per chunk of frames, pygpa_amd/_lib.py) on its
+    contiguous block -- the frames are independent, so there is NO data-path collective and the rate scales with
+    the number of GPUs (weak scaling).  gather=True: every rank receives u of all frames (one all_gather of the
+    results, padded to equal block sizes); gather=False: (u of the own block, (start, stop)).
+    `compute(frames_block, kvecs, klists, sigma, border, kmax) -> u_block` replaces the device call (CPU tests)."""
+    world, rank = 1, 0
+    if _initialized():
+        _, dist = _dist()
+        world, rank = dist.get_world_size(group), dist.get_rank(group)
+    frames = np.asarray(frames)
+    if frames.ndim != 3:
+        raise ValueError('frames must be a stack (B, N, M)')
+    kvecs = np.asarray(kvecs, dtype=np.float64).reshape(-1, 2)
+    norms = np.linalg.norm(kvecs, axis=1)
+    kw = norms.mean() / kwscale
+    if sigma is None:
+        sigma = int(np.ceil(1 / norms.min()))
+    if klists is None:
+        from .geometric_phase_analysis import _sweep_list
+        klists = [_sweep_list(pk[0], pk[1], kw, kw / ksteps) for pk in kvecs]
+    K = max(len(k) for k in klists)
+    klists = np.stack([np.concatenate([np.asarray(k), np.repeat(np.asarray(k)[-1:], K - len(k), axis=0)]) for k in klists])
+    shares = stack_shares(frames.shape[0], world)
+    a, b = shares[rank]
+    if compute is None:
+        from . import _lib
+        plan = _lib.get_plan(frames.shape[1:], len(kvecs) * K, dtype, device)
+
+        def compute(block, kvecs, klists, sigma, border, kmax):
+            return plan.extract_displacement_field_stack(block, kvecs, klists, sigma, border, kmax=kmax)[0]
+    mine = compute(frames[a:b], kvecs, klists, sigma, int(2 * sigma), kmax) if b > a else \
+        np.empty((0, 2) + frames.shape[1:], dtype=dtype)
+    if not gather:
+        return mine, (a, b)
+    if world == 1:
+        return mine
+    width = max(s[1] - s[0] for s in shares)
+    padded = np.zeros((width, 2) + frames.shape[1:], dtype=mine.dtype)
+    padded[:b - a] = mine
+    parts = _all_gather_np(padded, group)
+    return np.concatenate([parts[r][:shares[r][1] - shares[r][0]] for r in range(world)], axis=0)

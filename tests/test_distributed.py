@@ -169,3 +169,56 @@ def test_ksharded_matches_whole_sweep(tmp_path, world):
         assert np.array_equal(g['kidx'], np.stack([x['kidx'] for x in parts['gs']]))
         assert np.array_equal(g['lock'], np.stack([x['lockin'] for x in parts['gs']]))
         assert np.array_equal(g['u'], u_ref)
+
+
+# ---- stacks of frames over the ranks ----------------------------------------------------------------------------------
+def _oracle_stack_compute():
+    from oracle import gpa_oracle as orc
+
+    def compute(block, kvecs, klists, sigma, border, kmax):
+        return np.stack([orc.extract_displacement_field(f, kvecs, sigma=sigma, klists=klists) for f in block]) \
+            if len(block) else np.empty((0, 2) + block.shape[1:])
+    return compute
+
+
+def _stack_case():
+    img, kvecs, klists = _case()
+    frames = np.stack([np.roll(img, 3 * i, axis=1)[:64, :96] * (1.0 + 0.1 * i) for i in range(5)])
+    return frames, kvecs, klists
+
+
+def _sworker(rank, world, port, out_path):
+    sys.path.insert(0, ROOT)
+    import torch.distributed as dist
+    from pygpa_amd import distributed as D
+    dist.init_process_group('gloo', init_method='tcp://127.0.0.1:%d' % port, rank=rank, world_size=world)
+    frames, kvecs, klists = _stack_case()
+    u = D.extract_displacement_field_stack_sharded(frames, kvecs, klists=klists, dtype=np.float64, compute=_oracle_stack_compute())
+    own, span = D.extract_displacement_field_stack_sharded(frames, kvecs, klists=klists, dtype=np.float64, gather=False,
+                                                           compute=_oracle_stack_compute())
+    np.savez(out_path % rank, u=u, own=own, span=np.array(span))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+@pytest.mark.parametrize('world', [2, 3])
+def test_stack_sharded_over_ranks(tmp_path, world):
+    """5 frames dealt in contiguous blocks over 2 / 3 ranks (gloo): no collective on the data path, the gathered
+    result is the single-process result frame for frame, blocks differ in size by at most one"""
+    import torch.multiprocessing as mp
+    from pygpa_amd import distributed as D
+    frames, kvecs, klists = _stack_case()
+    assert D.stack_shares(5, 3) == [(0, 2), (2, 4), (4, 5)] and D.stack_shares(2, 4) == [(0, 1), (1, 2), (2, 2), (2, 2)]
+    u1 = D.extract_displacement_field_stack_sharded(frames, kvecs, klists=klists, dtype=np.float64, compute=_oracle_stack_compute())
+    assert u1.shape == (5, 2, 64, 96)
+    port = _free_port()
+    out = str(tmp_path / 'stack_rank%d.npz')
+    mp.spawn(_sworker, args=(world, port, out), nprocs=world, join=True)
+    spans = []
+    for r in range(world):
+        g = np.load(out % r)
+        assert np.array_equal(g['u'], u1), 'rank %d' % r
+        a, b = (int(v) for v in g['span'])
+        assert np.array_equal(g['own'], u1[a:b])
+        spans.append((a, b))
+    assert spans == D.stack_shares(5, world)

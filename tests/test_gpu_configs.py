@@ -421,6 +421,30 @@ def test_tiled_nccl_single_rank(tmp_path):
     assert int(g['tiles']) == 4
 
 
+def test_stack_frames_over_two_ranks_one_gpu(tmp_path):
+    """pygpa_amd.distributed.extract_displacement_field_stack_sharded with world size 2 (both ranks on cuda:0,
+    gloo): blocks of frames per rank, no data-path collective, the gathered field equals the single-process
+    stack call frame for frame, bit for bit"""
+    from pygpa_amd import distributed as D
+    import test_distributed as TD
+    frames, kvecs, klists = TD._stack_case()
+    for dtype in ('float64', 'float32'):
+        port = _free_port()
+        prefix = str(tmp_path / ('stack_' + dtype))
+        procs = []
+        for r in range(2):
+            env = dict(os.environ, RANK=str(r), WORLD_SIZE='2', LOCAL_RANK=str(r), MASTER_ADDR='127.0.0.1',
+                       MASTER_PORT=str(port), HSA_ENABLE_IPC_MODE_LEGACY='0')
+            procs.append(subprocess.Popen([sys.executable, os.path.join(ROOT, 'tests', '_stack_rank_worker.py'), prefix, dtype],
+                                          env=env, stdout=subprocess.PIPE, stderr=subprocess.STDOUT))
+        outs = [p.communicate(timeout=900)[0].decode() for p in procs]
+        assert all(p.returncode == 0 for p in procs), '\n'.join(outs)
+        u1 = D.extract_displacement_field_stack_sharded(frames, kvecs, klists=klists, dtype=np.dtype(dtype))
+        assert u1.shape == (5, 2) + frames.shape[1:]
+        for r in range(2):
+            assert np.array_equal(np.load(prefix + '_rank%d.npy' % r), u1), (dtype, r)
+
+
 def test_bench_gpus_flag_spawns_ranks():
     """`python bench.py --gpus 2` (no launcher) must start 2 ranks itself and report n_gpus = 2 with the tile
     pipeline as the workload; here both ranks share GPU 0 over gloo and the image is small"""
