@@ -37,6 +37,19 @@ struct ProfScope {
   }
   ~ProfScope() { if (r) (void)hipEventRecord(r->b, s); }
 };
+// XCD-aware tile order of the column kernels.  Workgroups are dealt to the 8 XCDs round robin (block b -> XCD b % 8),
+// and every XCD has its own L2: neighbouring column tiles share 128-byte lines of the rows they touch, so they must
+// meet in ONE L2 -- otherwise every XCD fetches (and partially writes) the line for itself.  XCD x therefore gets a
+// contiguous run of tiles: start(x) = x * (grid / 8) + min(x, grid % 8).  (Counters at 3000^2, where the grid of 375
+// tiles is not a multiple of 8 and the old power-of-two-only remap did nothing: the transform-free column kernel
+// moved 181 MB per launch for 72 MB of algorithmic traffic.)
+#if defined(__HIPCC__)
+__device__ __forceinline__ int xcd_tile(int b, int grid) {
+  const int base = grid >> 3, rem = grid & 7, x = b & 7, idx = b >> 3;
+  return x * base + (x < rem ? x : rem) + idx;
+}
+#endif
+
 // hipFuncSetAttribute(MaxDynamicSharedMemorySize) once per kernel instantiation and device instead of once per
 // launch: the fused driver makes ~110 launches per image and a small image is bound by the host's launch rate.
 // `done` is a static of the calling template instantiation (one bit per device; a benign race repeats the call).

@@ -177,8 +177,7 @@ __global__ __launch_bounds__((PassAGeom<T, LG>::THREADS)) void passA_kernel(
   // XCD-aware tile order: workgroups b, b+8, b+16, ... share an XCD (round-robin
   // dispatch), so give each XCD a contiguous run of column tiles -- the tiles that
   // share a 128-byte line of the output then meet in one L2 and leave it as whole lines.
-  int tile = blockIdx.x;
-  if ((gridDim.x & 7) == 0) tile = (blockIdx.x & 7) * (gridDim.x >> 3) + (blockIdx.x >> 3);
+  const int tile = xcd_tile(blockIdx.x, gridDim.x);
   const int y0 = tile * G::C + c * NT;
   // image stacks: blockIdx.z = image, its B planes behind those of the image before
   image += (size_t)blockIdx.z * n0 * n1;

@@ -743,8 +743,7 @@ __global__ __launch_bounds__((ColGeom<T, LG>::THREADS)) void colsolve_kernel(T* 
   const int c = threadIdx.x % CT, t = threadIdx.x / CT;
   cpx<T>* lds = reinterpret_cast<cpx<T>*>(smem) + c;
   // XCD-aware tile order (see passA_kernel): neighbouring column tiles meet in one L2
-  int tile = blockIdx.x;
-  if ((gridDim.x & 7) == 0) tile = (blockIdx.x & 7) * (gridDim.x >> 3) + (blockIdx.x >> 3);
+  const int tile = xcd_tile(blockIdx.x, gridDim.x);
   const int y0 = (tile * G::CC + c * NT) * 2;       // first real column of this thread
   const bool valid = y0 + 2 * NT - 1 < n1;          // n1 is a power of two >= 64: tiles are never ragged
   const int yy = valid ? y0 : 0;
@@ -931,8 +930,7 @@ __global__ __launch_bounds__(1024) void colsolve_tri_kernel(const T* __restrict_
   __shared__ double shn[1024];
   const int S = blockDim.x / Q;
   const int q = threadIdx.x % Q, s = threadIdx.x / Q;
-  int tile = blockIdx.x;
-  if ((gridDim.x & 7) == 0) tile = (blockIdx.x & 7) * (gridDim.x >> 3) + (blockIdx.x >> 3);
+  const int tile = xcd_tile(blockIdx.x, gridDim.x);
   const int row0 = s * R, col = q * VEC;
   const bool cv = !RAGGED || (tile * Q + q) * VEC < n1;   // this thread's columns exist
   const int y0 = cv ? (tile * Q + q) * VEC : 0;

@@ -253,7 +253,8 @@ __global__ __launch_bounds__(MAXT) void mr_colsolve_kernel(
   // column pair fastest in the thread index: neighbouring lanes read neighbouring columns
   const int f = threadIdx.x % nf, tid = threadIdx.x / nf;
   cpx<T>* lds = reinterpret_cast<cpx<T>*>(smem) + (size_t)f * rs;
-  const int ya = (blockIdx.x * nf + f) * 2, yb = ya + 1;
+  // (neighbouring column groups on one XCD: they share the 128-byte lines of every row, see xcd_tile())
+  const int ya = (xcd_tile(blockIdx.x, gridDim.x) * nf + f) * 2, yb = ya + 1;
   const bool va = ya < n1, vb = yb < n1;
   struct alignas(2 * sizeof(T)) Pair { T a, b; };
   const bool vec = vb && (n1 & 1) == 0;   // the pair is one aligned 2-element access
