@@ -152,9 +152,16 @@ GPA_HD void mr_bfly(cpx<T>* a) {
   }
 }
 
+// The LDS image and the twiddle table are addressed through pointers to their SCALARS (element i = scalars 2i, 2i + 1)
+// so that mr_pass can hand over address-space-qualified pointers: behind a real function call hipcc no longer knows
+// that `lds` is LDS and `W` global memory and emitted FLAT loads / stores for both (flat_load_dwordx2 where the
+// inlined code has ds_read_b64).
+template <class T, class P> GPA_HD cpx<T> mr_get(P p, int i) { return {p[2 * i], p[2 * i + 1]}; }
+template <class T, class P> GPA_HD void mr_put(P p, int i, cpx<T> v) { p[2 * i] = v.x; p[2 * i + 1] = v.y; }
+
 // pass, first half: this thread's butterflies from LDS into registers
-template <class T, int R>
-GPA_HD void mr_load(cpx<T>* x, const cpx<T>* lds, int n, int tid, int Tn) {
+template <class T, int R, class LP>
+GPA_HD void mr_load(cpx<T>* x, LP lds, int n, int tid, int Tn) {
   constexpr int NB = MR_REGS / R;
   const int nb = n / R;
 #pragma unroll
@@ -162,16 +169,15 @@ GPA_HD void mr_load(cpx<T>* x, const cpx<T>* lds, int n, int tid, int Tn) {
     const int b = tid + u * Tn;
     if (b < nb) {
 #pragma unroll
-      for (int j = 0; j < R; ++j) x[u * R + j] = lds[mr_pad(b + j * nb)];
+      for (int j = 0; j < R; ++j) x[u * R + j] = mr_get<T>(lds, mr_pad(b + j * nb));
     }
   }
 }
 
 // pass, second half (after a barrier): butterflies, twiddles, autosort store.  W: w_n^i = exp(-2 pi i / n * i), i < n,
 // (entry i at mr_pad(i): the table may equally be a padded LDS copy)
-template <class T, int R>
-GPA_HD void mr_store(cpx<T>* x, cpx<T>* lds, int n, int s, unsigned magic, int tid, int Tn,
-                     const cpx<T>* W) {
+template <class T, int R, class LP, class WP>
+GPA_HD void mr_store(cpx<T>* x, LP lds, int n, int s, unsigned magic, int tid, int Tn, WP W) {
   constexpr int NB = MR_REGS / R;
   const int nb = n / R;
   const bool last = s * R == n;   // pp == 0 throughout: no twiddles
@@ -185,8 +191,8 @@ GPA_HD void mr_store(cpx<T>* x, cpx<T>* lds, int n, int s, unsigned magic, int t
 #pragma unroll
       for (int k = 0; k < R; ++k) {
         cpx<T> v = x[u * R + k];
-        if (k > 0 && !last) v = cmul(v, W[mr_pad(ws * k)]);
-        lds[mr_pad(base + s * k)] = v;
+        if (k > 0 && !last) v = cmul(v, mr_get<T>(W, mr_pad(ws * k)));
+        mr_put<T>(lds, mr_pad(base + s * k), v);
       }
     }
   }
@@ -201,10 +207,14 @@ GPA_HD void mr_store(cpx<T>* x, cpx<T>* lds, int n, int s, unsigned magic, int t
 template <class T, int R, int CAP>
 __device__ __attribute__((noinline)) void mr_pass(cpx<T>* lds, int n, int s, unsigned mg, int tid, int Tn,
                                                   const cpx<T>* W) {
+  using lds_scalar = __attribute__((address_space(3))) T;
+  using glb_scalar = const __attribute__((address_space(1))) T;
+  lds_scalar* l = (lds_scalar*)reinterpret_cast<T*>(lds);        // (the caller's LDS image)
+  glb_scalar* w = (glb_scalar*)reinterpret_cast<const T*>(W);    // (the twiddle table in global memory)
   cpx<T> x[MR_REGS];
-  mr_load<T, R>(x, lds, n, tid, Tn);
+  mr_load<T, R>(x, l, n, tid, Tn);
   __syncthreads();
-  mr_store<T, R>(x, lds, n, s, mg, tid, Tn, W);
+  mr_store<T, R>(x, l, n, s, mg, tid, Tn, w);
 }
 
 // the whole transform; the data must be in LDS and a barrier passed before the call, ends with a barrier.

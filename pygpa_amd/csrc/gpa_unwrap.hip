@@ -2020,10 +2020,11 @@ hipError_t unwrap_workspace_create(int dtype, int n0, int n1, hipStream_t s, Unw
           for (int p = 0; p < d.pl.np; ++p) {
 #define GPA_HOST_PASS(R)                                                                                              \
   case R:                                                                                                             \
-    for (int tt = 0; tt < d.pl.T; ++tt) mr_load<double, R>(&regs[(size_t)MR_REGS * tt], img.data(), L, tt, d.pl.T);    \
     for (int tt = 0; tt < d.pl.T; ++tt)                                                                               \
-      mr_store<double, R>(&regs[(size_t)MR_REGS * tt], img.data(), L, d.pl.stride[p], d.pl.magic[p], tt, d.pl.T,       \
-                          W.data());                                                                                  \
+      mr_load<double, R>(&regs[(size_t)MR_REGS * tt], reinterpret_cast<const double*>(img.data()), L, tt, d.pl.T);    \
+    for (int tt = 0; tt < d.pl.T; ++tt)                                                                               \
+      mr_store<double, R>(&regs[(size_t)MR_REGS * tt], reinterpret_cast<double*>(img.data()), L, d.pl.stride[p],      \
+                          d.pl.magic[p], tt, d.pl.T, reinterpret_cast<const double*>(W.data()));                      \
     break;
             switch (d.pl.radix[p]) {
               GPA_HOST_PASS(2) GPA_HOST_PASS(3) GPA_HOST_PASS(4) GPA_HOST_PASS(5) GPA_HOST_PASS(6) GPA_HOST_PASS(7)

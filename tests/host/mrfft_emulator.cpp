@@ -14,13 +14,14 @@ using namespace gpa;
 
 template <class T, int R>
 void half_pass_load(std::vector<cpx<T>>& regs, const std::vector<cpx<T>>& lds, const MrPlan& pl) {
-  for (int t = 0; t < pl.T; ++t) mr_load<T, R>(&regs[(size_t)MR_REGS * t], lds.data(), pl.n, t, pl.T);
+  for (int t = 0; t < pl.T; ++t) mr_load<T, R>(&regs[(size_t)MR_REGS * t], reinterpret_cast<const T*>(lds.data()), pl.n, t, pl.T);
 }
 template <class T, int R>
 void half_pass_store(std::vector<cpx<T>>& regs, std::vector<cpx<T>>& lds, const MrPlan& pl, int p,
                      const std::vector<cpx<T>>& W) {
   for (int t = 0; t < pl.T; ++t)
-    mr_store<T, R>(&regs[(size_t)MR_REGS * t], lds.data(), pl.n, pl.stride[p], pl.magic[p], t, pl.T, W.data());
+    mr_store<T, R>(&regs[(size_t)MR_REGS * t], reinterpret_cast<T*>(lds.data()), pl.n, pl.stride[p], pl.magic[p], t, pl.T,
+                   reinterpret_cast<const T*>(W.data()));
 }
 
 template <class T>

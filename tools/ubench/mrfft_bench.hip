@@ -12,7 +12,7 @@ using namespace gpa;
 template <class T, int R, int MODE>
 __device__ __attribute__((noinline)) void pass(cpx<T>* lds, int n, int s, unsigned mg, int tid, int Tn, const cpx<T>* W) {
   cpx<T> x[MR_REGS];
-  mr_load<T, R>(x, lds, n, tid, Tn);
+  mr_load<T, R>(x, reinterpret_cast<const T*>(lds), n, tid, Tn);
   __syncthreads();
   constexpr int NB = MR_REGS / R;
   const int nb = n / R;
