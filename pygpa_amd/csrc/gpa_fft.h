@@ -279,11 +279,20 @@ struct WgFFT {
     const int m0 = G & ((1 << lgS) - 1);
     const int u = m0 << (LOG2L - lgLp);   // exponent unit in the length-L table
     cpx<T> lo[3], hi[3];
+#if defined(__HIP_DEVICE_COMPILE__)
+    // (the table pointer went through refresh()'s opaque asm and lost its address space: read it as global memory,
+    //  not through FLAT instructions)
+    const __attribute__((address_space(1))) T* g = (const __attribute__((address_space(1))) T*)reinterpret_cast<const T*>(tw.table);
+#define GPA_TW_AT(j) cpx<T>{g[2 * (j)], g[2 * (j) + 1]}
+#else
+#define GPA_TW_AT(j) tw.table[(j)]
+#endif
 #pragma unroll
     for (int c = 0; c < 3; ++c) {
-      if ((c + 1) < r) lo[c] = tw.table[u * (c + 1)];
-      if (4 * (c + 1) < r) hi[c] = tw.table[u * 4 * (c + 1)];
+      if ((c + 1) < r) lo[c] = GPA_TW_AT(u * (c + 1));
+      if (4 * (c + 1) < r) hi[c] = GPA_TW_AT(u * 4 * (c + 1));
     }
+#undef GPA_TW_AT
 #pragma unroll
     for (int k = 1; k < r; ++k) {
       const int a = k >> 2, b = k & 3;

@@ -25,6 +25,17 @@ struct HType<true, T> { using type = cpx<T>; };
 template <class T> __device__ __forceinline__ cpx<T> hmul(cpx<T> a, T h) { return {a.x * h, a.y * h}; }
 template <class T> __device__ __forceinline__ cpx<T> hmul(cpx<T> a, cpx<T> h) { return cmul(a, h); }
 
+// entry j of the filter table behind an opaque pointer (asm volatile hides it from LICM so that the table is re-read
+// per candidate instead of being pinned in 16+ registers).  The opaque pointer also loses its address space -- hipcc
+// emitted FLAT loads for the table -- so it is read through a global-address-space scalar pointer.
+template <bool PADDED, class T>
+__device__ __forceinline__ typename HType<PADDED, T>::type hload(const typename HType<PADDED, T>::type* Hb, int j) {
+  using gscalar = const __attribute__((address_space(1))) T;
+  gscalar* g = (gscalar*)reinterpret_cast<const T*>(Hb);
+  if constexpr (PADDED) return cpx<T>{g[2 * j], g[2 * j + 1]};
+  else return g[j];
+}
+
 // ---------------------------------------------------------------------------
 // pass B: y-axis filter on rows, best-of-K select
 // ---------------------------------------------------------------------------
@@ -135,7 +146,7 @@ __global__ __launch_bounds__((PassBGeom<T, LG>::THREADS), (sizeof(T) == 8 ? GPA_
       const typename HType<PADDED, T>::type* Hb = H;
       asm volatile("" : "+s"(Hb));   // re-read the filter table per candidate instead of pinning 16+ VGPRs
 #pragma unroll
-      for (int i = 0; i < 16; ++i) x[i] = hmul(x[i], Hb[i * TPF + tid]);
+      for (int i = 0; i < 16; ++i) x[i] = hmul(x[i], hload<PADDED, T>(Hb, i * TPF + tid));
     }
     F::inverse(x, lds, tid, tw);
     if constexpr (SELECT) {

@@ -222,7 +222,7 @@ __global__ __launch_bounds__((PassAGeom<T, LG>::THREADS)) void passA_kernel(
       asm volatile("" : "+s"(Hb));
 #pragma unroll
       for (int i = 0; i < 16; ++i) {
-        const auto h = Hb[i * TPF + t];
+        const auto h = hload<PADDED, T>(Hb, i * TPF + t);
 #pragma unroll
         for (int n = 0; n < NT; ++n) x[n][i] = hmul(x[n][i], h);
       }
