@@ -442,6 +442,7 @@ def main():
     make_case(GPA, pu, 'hex_64', (64, 64), 0.15, 7.0, noise=0.0, seed=0, store_w=True)
     make_case(GPA, pu, 'hex_48x80', (48, 80), 0.17, 11.0, noise=0.0, seed=1)
     make_case(GPA, pu, 'hex_63x65', (63, 65), 0.15, 3.0, noise=0.05, seed=2)
+    make_case(GPA, pu, 'hex_60', (60, 60), 0.16, 5.0, noise=0.02, seed=4)   # square, 2^2 3 5: mixed-radix rows, ragged recursions
     make_case(GPA, pu, 'hex_128_noise', (128, 128), 0.1, 7.0, noise=0.5, seed=3, full=False, grad=False)
     make_iterate_case(GPA, pu)
     make_unwrap_ramp(pu)

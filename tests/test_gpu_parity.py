@@ -23,7 +23,7 @@ TOL = {
     np.float32: dict(lock=2e-6, grad=2e-5, pcg=2e-5, tie=2e-6),
 }
 DTYPES = [np.float64, np.float32]
-FULL_CASES = ['hex_64', 'hex_48x80', 'hex_63x65']
+FULL_CASES = ['hex_64', 'hex_48x80', 'hex_63x65', 'hex_60']
 
 
 def rel(a, b):
@@ -124,7 +124,7 @@ def test_reference_unwrap_ramp(golden, dtype):
 
 
 @pytest.mark.parametrize('dtype', DTYPES)
-@pytest.mark.parametrize('name', ['hex_64', 'hex_48x80', 'hex_63x65', 'hex_128_noise'])
+@pytest.mark.parametrize('name', ['hex_64', 'hex_48x80', 'hex_63x65', 'hex_128_noise', 'hex_60'])
 def test_fused_driver_golden(golden, name, dtype):
     g = golden(name)
     sigma = int(g['sigma'])

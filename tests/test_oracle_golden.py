@@ -6,7 +6,7 @@ import scipy.ndimage as ndi
 
 from oracle import gpa_oracle as orc
 
-CASES = ['hex_64', 'hex_48x80', 'hex_63x65']
+CASES = ['hex_64', 'hex_48x80', 'hex_63x65', 'hex_60']
 
 
 def test_gaussian_matches_scipy_fourier_gaussian():
