@@ -67,9 +67,13 @@ __global__ __launch_bounds__(MAXT) void mr_rowdct_fused_kernel(
     VecN<T, V> qa[NV], qb[NV];
 #pragma unroll
     for (int i = 0; i < NV; ++i) {
-      const int c0 = V * (tid + Tn * i);
-      qa[i] = (c0 < n && va) ? *reinterpret_cast<const VecN<T, V>*>(src + oa + c0) : zero4;
-      qb[i] = (c0 < n && vb) ? *reinterpret_cast<const VecN<T, V>*>(src + ob + c0) : zero4;
+      // (loads are unconditional from a clamped address and zeroed by a select afterwards: a load inside a branch
+      //  sits in its own basic block and is waited for on its own, see pass B of the sweep)
+      const int c0 = V * (tid + Tn * i), cc = c0 < n ? c0 : 0;
+      qa[i] = *reinterpret_cast<const VecN<T, V>*>(src + oa + cc);
+      qb[i] = *reinterpret_cast<const VecN<T, V>*>(src + ob + cc);
+      if (!(c0 < n && va)) qa[i] = zero4;
+      if (!(c0 < n && vb)) qb[i] = zero4;
     }
 #pragma unroll
     for (int i = 0; i < NV; ++i) {
@@ -89,10 +93,12 @@ __global__ __launch_bounds__(MAXT) void mr_rowdct_fused_kernel(
     W4 w4[NV];
 #pragma unroll
     for (int i = 0; i < NV; ++i) {
-      const int k0 = V * (tid + Tn * i);
-      ra[i] = (it > 0 && k0 < n && va) ? *reinterpret_cast<const VecN<T, V>*>(r + oa + k0) : zero4;
-      rb[i] = (it > 0 && k0 < n && vb) ? *reinterpret_cast<const VecN<T, V>*>(r + ob + k0) : zero4;
-      if (k0 < n) w4[i] = *reinterpret_cast<const W4*>(wk + k0);
+      const int k0 = V * (tid + Tn * i), kc = k0 < n ? k0 : 0;
+      ra[i] = *reinterpret_cast<const VecN<T, V>*>(r + oa + kc);
+      rb[i] = *reinterpret_cast<const VecN<T, V>*>(r + ob + kc);
+      if (!(it > 0 && k0 < n && va)) ra[i] = zero4;
+      if (!(it > 0 && k0 < n && vb)) rb[i] = zero4;
+      w4[i] = *reinterpret_cast<const W4*>(wk + kc);
     }
 #pragma unroll
     for (int i = 0; i < NV; ++i) {
@@ -163,9 +169,11 @@ __global__ __launch_bounds__(MAXT) void mr_rowidct_p_kernel(
     VecN<T, V> za[NV], zb[NV];
 #pragma unroll
     for (int i = 0; i < NV; ++i) {
-      const int k0 = V * (tid + Tn * i);
-      za[i] = (k0 < n && va) ? *reinterpret_cast<const VecN<T, V>*>(Z + oa + k0) : zero4;
-      zb[i] = (k0 < n && vb) ? *reinterpret_cast<const VecN<T, V>*>(Z + ob + k0) : zero4;
+      const int k0 = V * (tid + Tn * i), kc = k0 < n ? k0 : 0;
+      za[i] = *reinterpret_cast<const VecN<T, V>*>(Z + oa + kc);
+      zb[i] = *reinterpret_cast<const VecN<T, V>*>(Z + ob + kc);
+      if (!(k0 < n && va)) za[i] = zero4;
+      if (!(k0 < n && vb)) zb[i] = zero4;
     }
 #pragma unroll
     for (int i = 0; i < NV; ++i) {
@@ -207,9 +215,11 @@ __global__ __launch_bounds__(MAXT) void mr_rowidct_p_kernel(
     VecN<T, V> pa4[NV], pb4[NV];
 #pragma unroll
     for (int i = 0; i < NV; ++i) {
-      const int c0 = V * (tid + Tn * i);
-      pa4[i] = (!first && c0 < n && va) ? *reinterpret_cast<const VecN<T, V>*>(pin + oa + c0) : zero4;
-      pb4[i] = (!first && c0 < n && vb) ? *reinterpret_cast<const VecN<T, V>*>(pin + ob + c0) : zero4;
+      const int c0 = V * (tid + Tn * i), cc = c0 < n ? c0 : 0;
+      pa4[i] = *reinterpret_cast<const VecN<T, V>*>(pin + oa + cc);   // (a ring slot: allocated even before it holds a p)
+      pb4[i] = *reinterpret_cast<const VecN<T, V>*>(pin + ob + cc);
+      if (!(!first && c0 < n && va)) pa4[i] = zero4;
+      if (!(!first && c0 < n && vb)) pb4[i] = zero4;
     }
 #pragma unroll
     for (int i = 0; i < NV; ++i) {
@@ -264,17 +274,16 @@ __global__ __launch_bounds__(MAXT) void mr_colsolve_kernel(
 #pragma unroll
     for (int i = 0; i < MR_REGS; ++i) {
       const int row = tid + Tn * i;
-      v[i] = {T(0), T(0)};
-      if (row < n) {
-        const size_t o = (size_t)row * n1;
-        if (vec) {
-          const Pair pz = *reinterpret_cast<const Pair*>(Zin + o + ya);
-          v[i] = {pz.a, pz.b};
-        } else {
-          if (va) v[i].x = Zin[o + ya];
-          if (vb) v[i].y = Zin[o + yb];
-        }
+      const size_t o = (size_t)(row < n ? row : 0) * n1;   // (clamped: the load is unconditional, see the row kernels)
+      if (vec) {
+        const Pair pz = *reinterpret_cast<const Pair*>(Zin + o + ya);
+        v[i] = {pz.a, pz.b};
+      } else {
+        v[i] = {Zin[o + (va ? ya : 0)], Zin[o + (vb ? yb : 0)]};
+        if (!va) v[i].x = T(0);
+        if (!vb) v[i].y = T(0);
       }
+      if (row >= n) v[i] = {T(0), T(0)};
     }
 #pragma unroll
     for (int i = 0; i < MR_REGS; ++i) {
