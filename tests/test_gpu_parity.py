@@ -1202,3 +1202,33 @@ def test_image_stack_equals_single_images(shape, dtype):
     u_c, it_c = plan.extract_displacement_field_stack(imgs, kvecs, klists, sigma, 2 * sigma, kmax=10, chunk=2)
     assert np.array_equal(u_c, u_b) and np.array_equal(it_c, it_b)
     plan.close()
+
+
+@pytest.mark.gpu
+def test_random_stacks_equal_single_images():
+    """seeded random (shape, stack size, precision) draws -- any parity of the sides, power-of-two, smooth and chirp-z
+    lengths mixed -- the stack call equals the single-image driver frame for frame, bit for bit.
+    GPA_TEST_RANDOM_CASES / GPA_TEST_RANDOM_SEED widen the sweep."""
+    rng = np.random.default_rng(int(os.environ.get('GPA_TEST_RANDOM_SEED', '5')))
+    want = max(4, int(os.environ.get('GPA_TEST_RANDOM_CASES', '10')) // 2)
+    sizes = [32, 48, 60, 63, 64, 65, 68, 75, 96, 100, 116, 128, 130, 160, 250, 256]
+    done = 0
+    while done < want:
+        n0, n1 = (int(v) for v in rng.choice(sizes, 2))
+        if max(n0, n1) >= 1.75 * min(n0, n1):
+            continue
+        done += 1
+        shape = (n0, n1)
+        dtype = np.float64 if rng.random() < 0.5 else np.float32
+        B = int(rng.integers(1, 7))
+        kvecs = hex_kvecs(float(rng.uniform(0.1, 0.2)), float(rng.uniform(0, 60)))
+        sigma = int(rng.integers(3, 7))
+        klists = np.stack(explicit_klists(kvecs, 0.03, int(rng.integers(1, 3)), int(rng.integers(1, 3))))
+        imgs = np.stack([hex_moire(shape, kvecs, 0.3 * gaussian_bump_displacement(shape), noise=0.05 + 0.1 * i, seed=int(rng.integers(0, 1000)))
+                         for i in range(B)])
+        plan = _lib.get_plan(shape, klists.shape[0] * klists.shape[1], dtype)
+        u_b, it_b = plan.extract_displacement_field_stack(imgs, kvecs, klists, sigma, 2 * sigma, kmax=10, chunk=int(rng.integers(1, B + 1)))
+        for i in range(B):
+            u, _, _, iters = plan.extract_displacement_field(imgs[i], kvecs, klists, sigma, 2 * sigma, kmax=10, want_kidx=True)
+            assert np.array_equal(u_b[i], u), (shape, np.dtype(dtype).name, B, i)
+            assert tuple(it_b[i]) == tuple(iters), (shape, B, i)
