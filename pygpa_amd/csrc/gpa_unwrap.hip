@@ -661,14 +661,18 @@ __global__ __launch_bounds__((RowGeom<T, LG>::THREADS), (sizeof(T) == 8 ? GPA_F6
 // fused path, after the last iteration: alpha of that iteration for phi_flush_kernel (no further row
 // kernel will compute it; the residual of the last iteration is not formed, nothing reads it)
 __global__ __launch_bounds__(256) void final_alpha_kernel(double* scal, const double* part_pq, int npq, int it, int ring,
-                                                         const int* flags) {
+                                                         int* flags) {
   scal += blockIdx.z * SCAL_N;
   part_pq += blockIdx.z * PART_N;
   flags += blockIdx.z * FLAGS_N;
   if (flags[1]) return;
   __shared__ double sh[256];
   const double pq = reduce_partials(part_pq, npq, sh);
-  if (threadIdx.x == 0) scal[SC_ALPHA + (it - 1) % ring] = scal[8 + ((it - 1) & 1)] / pq;
+  if (threadIdx.x == 0) {
+    scal[SC_ALPHA + (it - 1) % ring] = scal[8 + ((it - 1) & 1)] / pq;
+    flags[0] = it;   // all kmax updates done (a separate one-thread kernel used to record this)
+    flags[1] = 1;
+  }
 }
 
 // phi += sum_j alpha_j p_j over the updates j in [flags[2], flags[0]) that the iteration has completed
@@ -704,12 +708,6 @@ __global__ __launch_bounds__(256) void phi_flush_kernel(RingPtrs<T> ringp, int r
 __global__ void phi_commit_kernel(int* flags) {
   flags += blockIdx.z * FLAGS_N;
   flags[2] = flags[0];
-}
-__global__ void final_count_kernel(int* flags, int kmax) {
-  flags += blockIdx.z * FLAGS_N;
-  if (flags[1]) return;
-  flags[0] = kmax;
-  flags[1] = 1;
 }
 
 // columns: Z -> DCT-II along axis 0, divide by eigenvalues, DCT-III along axis 0 (in place)
@@ -2234,8 +2232,7 @@ static hipError_t run_pcg(Impl* w, const void* a, const void* b, const void* wei
                                                                              nullptr, 0, it, band, npx); }
     }
     { GPA_PROF("scalar_kernels", s);
-      final_alpha_kernel<<<dim3(1, 1, w->nprob), 256, 0, s>>>(w->scal, part_pq, npq, kmax, ring, w->flags);
-      final_count_kernel<<<dim3(1, 1, w->nprob), 1, 0, s>>>(w->flags, kmax); }
+      final_alpha_kernel<<<dim3(1, 1, w->nprob), 256, 0, s>>>(w->scal, part_pq, npq, kmax, ring, w->flags); }
     flush();
     return hipGetLastError();
   }
