@@ -30,10 +30,10 @@ template <class T> GPA_HD T fast_recip(T x) {
 // (valid for odd N too: the first ceil(N/2) slots take the even samples)
 GPA_HD int makhoul_src(int m, int N) { return m < (N + 1) / 2 ? 2 * m : 2 * (N - 1 - m) + 1; }
 
-template <class T, int LG>
+template <class T, int LG, int EE = 16>
 struct WgDCT {
-  using F = WgFFT<T, LG>;
-  static constexpr int N = F::L, TPF = F::TPF, E = 16;
+  using F = WgFFT<T, LG, EE>;
+  static constexpr int N = F::L, TPF = F::TPF, E = EE;
 
   // ---- forward DCT-II of a packed pair -------------------------------------
   // in : x = permuted input in the natural layout (slot m = tid + TPF*i)

@@ -1,7 +1,7 @@
 // Workgroup-level power-of-two FFT for gfx950: radix-2^b butterflies in registers,
 // padded in-place exchanges through LDS.  Written for 64-wide wavefronts: every
-// thread owns E = 16 complex elements, a transform of length L uses L/16 threads,
-// and a pass of radix r makes each thread do 16/r butterflies.
+// thread owns E = 16 (or 8) complex elements, a transform of length L uses L/E threads,
+// and a pass of radix r makes each thread do E/r butterflies.
 //
 // Layouts
 //   natural  : thread t, register i  <->  element  t + (L/16) * i          (coalesced in t)
@@ -149,13 +149,19 @@ GPA_HD void dft_regs(cpx<T>* v) {
 // ---------------------------------------------------------------------------
 // Workgroup FFT of length L = 2^LOG2L, 64 <= L <= 16384.
 // ---------------------------------------------------------------------------
-template <class T, int LOG2L>
+// EE = elements per thread: 16 (the sweep kernels and long transforms: fewest LDS exchanges), or 8 -- half the
+// instructions per wavefront on twice the threads, which is what a SHORT transform wants: a 512-point kernel
+// runs one wavefront per SIMD and is bound by that wavefront's instruction issue, not by the chip.
+template <class T, int LOG2L, int EE = 16>
 struct WgFFT {
   static_assert(LOG2L >= 6 && LOG2L <= 14, "supported lengths: 64 .. 16384");
+  static_assert(EE == 16 || EE == 8, "elements per thread: 16 or 8");
   static constexpr int L = 1 << LOG2L;
-  static constexpr int E = 16;
+  static constexpr int E = EE;
+  static constexpr int LGE = EE == 16 ? 4 : 3;
   static constexpr int TPF = L / E;           // threads per transform
-  static constexpr int P = (LOG2L + 3) / 4;   // passes
+  static constexpr int P = (LOG2L + LGE - 1) / LGE;   // passes (radix <= E)
+  static_assert(P <= 4, "at most four passes");
   static constexpr int LDS_ELEMS = L + L / 16;
 
   // bits of pass p (balanced split of LOG2L into P digits, larger digits first)
@@ -207,7 +213,7 @@ struct WgFFT {
   // Base twiddles kept in registers for the whole kernel (loop invariant across
   // the k-vector sweep): for twiddled pass p and butterfly group q,
   // lo = w^1, w^2, w^3 and hi = w^4, w^8, w^12 with w = exp(-2 pi i m0 / L_p).
-  static constexpr int GMAX = 2;   // radix >= 8 in every twiddled pass
+  static constexpr int GMAX = 2;   // radix >= E / 2 in every twiddled pass
   struct Twiddles {
     cpx<T> lo[P > 1 ? P - 1 : 1][GMAX][3];
     cpx<T> hi[P > 1 ? P - 1 : 1][GMAX][3];
@@ -216,7 +222,7 @@ struct WgFFT {
   template <int p>
   GPA_HD static void load_twiddles_pass(Twiddles& tw, const cpx<T>* __restrict__ table, int tid) {
     constexpr int b = bits(p), r = 1 << b, g = E / r, lgLp = lg_len(p), lgS = lgLp - b;
-    static_assert(g <= GMAX, "twiddled passes must have radix >= 8");
+    static_assert(g <= GMAX, "twiddled passes must have radix >= E / 2");
 #pragma unroll
     for (int q = 0; q < g; ++q) {
       const int G = tid + TPF * q;

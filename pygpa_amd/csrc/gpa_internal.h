@@ -158,7 +158,7 @@ hipError_t launch_phasegrad(int dtype, const void* psi, int K, const int32_t* ki
                             const double* kr, int mode, void* grad, hipStream_t s);
 int passA_cols(int dtype, int lg);
 // frequency bin held by (thread, register) after the forward transform of length 2^lg
-int spec_index_rt(int lg, int tid, int reg);
+int spec_index_rt(int lg, int tid, int reg, int elems = 16);   // elems: elements per thread of the transform (16 or 8)
 
 // ---- reconstruct (gpa_reconstruct.hip) -------------------------------------
 hipError_t launch_reconstruct(int dtype, const void* lockin, const double* kmat /*dev P*2, 2 pi k*/,

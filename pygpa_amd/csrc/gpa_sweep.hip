@@ -333,7 +333,14 @@ int passA_cols(int dtype, int lg) {
   return 0;
 }
 
-int spec_index_rt(int lg, int tid, int reg) {
+int spec_index_rt(int lg, int tid, int reg, int elems) {
+  if (elems == 8) {
+#define CASE_S8(LG) \
+  case LG: return WgFFT<float, LG, 8>::spec_index(tid, reg);
+    switch (lg) { CASE_S8(6) CASE_S8(7) CASE_S8(8) CASE_S8(9) CASE_S8(10) CASE_S8(11) CASE_S8(12) }
+#undef CASE_S8
+    return -1;
+  }
 #define CASE_S(LG) \
   case LG: return WgFFT<float, LG>::spec_index(tid, reg);
   switch (lg) { GPA_FOR_LG(CASE_S) }

@@ -464,9 +464,26 @@ __global__ __launch_bounds__(256) void update_kernel(const T* __restrict__ p, co
 // ---------------------------------------------------------------------------
 // DCT kernels
 // ---------------------------------------------------------------------------
+// Elements per thread of the fused kernels' transforms: 8 for axes up to 2048, 16 for longer ones.  A 512-point
+// kernel puts ONE wavefront on a SIMD and is bound by that wavefront's instruction stream (2000-3200 instructions at
+// 16 elements per thread; profiles/r02_gridbarrier_microbench.txt): half the elements per thread on twice the
+// threads cut it to 1000-1900 (512^2: 635 -> 755 Mpix/s, 256^2: 189 -> 221, 2048^2: +2 %, f64 2048^2: +3 % and no
+// spills).  At 4096 points the fourth pass and its LDS exchange cost more than the shorter stream saves
+// (f32 2567 -> 2322 Mpix/s, f64 1045 -> 997): long axes keep 16.
+#ifndef GPA_UNWRAP_E8_MAXLG
+#define GPA_UNWRAP_E8_MAXLG 11
+#endif
+#ifndef GPA_UNWRAP_E8_MAXLG_F64
+#define GPA_UNWRAP_E8_MAXLG_F64 11
+#endif
+constexpr int unwrap_elems(int lg, size_t real_size) {
+  return lg <= (real_size == 8 ? GPA_UNWRAP_E8_MAXLG_F64 : GPA_UNWRAP_E8_MAXLG) ? 8 : 16;
+}
+
 template <class T, int LG>
 struct RowGeom {
-  using F = WgFFT<T, LG>;
+  using F = WgFFT<T, LG, unwrap_elems(LG, sizeof(T))>;
+  using D = WgDCT<T, LG, unwrap_elems(LG, sizeof(T))>;
   static constexpr int NF = F::TPF >= 256 ? 1 : 256 / F::TPF;   // row PAIRS per workgroup
   static constexpr int RS = F::LDS_ELEMS + (NF > 1 ? (F::TPF < 32 ? F::TPF : 0) : 0);
   static constexpr int THREADS = NF * F::TPF;
@@ -475,7 +492,8 @@ struct RowGeom {
 };
 template <class T, int LG>
 struct ColGeom {
-  using F = WgFFT<T, LG>;
+  using F = WgFFT<T, LG, unwrap_elems(LG, sizeof(T))>;
+  using D = WgDCT<T, LG, unwrap_elems(LG, sizeof(T))>;
   static constexpr int cols() {
     // as many column pairs as LDS and 1024 threads allow (wide tiles = long row segments) ...
     int c = 16;
@@ -502,48 +520,6 @@ struct ColGeom {
   static constexpr size_t LDS_BYTES = (size_t)NT * REGION * sizeof(cpx<T>);
   static constexpr bool FITS = (size_t)(F::LDS_ELEMS + 32) * sizeof(cpx<T>) <= 160 * 1024;
 };
-
-// rows: r (n0 x n1) -> Z = DCT-II along axis 1
-template <class T, int LG>
-__global__ __launch_bounds__((RowGeom<T, LG>::THREADS)) void rowdct_kernel(const T* __restrict__ r, int n0,
-                                                                        T* __restrict__ Z,
-                                                                        const cpx<T>* __restrict__ twtab,
-                                                                        const cpx<T>* __restrict__ wk,
-                                                                        const int* flags) {
-  if (flags[1]) return;
-  using F = WgFFT<T, LG>;
-  using D = WgDCT<T, LG>;
-  using G = RowGeom<T, LG>;
-  constexpr int TPF = F::TPF, N = F::L;
-  extern __shared__ __attribute__((aligned(16))) char smem[];
-  const int tid = threadIdx.x % TPF, f = threadIdx.x / TPF;
-  cpx<T>* lds = reinterpret_cast<cpx<T>*>(smem) + f * G::RS;
-  const int pr = blockIdx.x * G::NF + f;
-  const bool valid = 2 * pr + 1 < n0;
-  const T* ra = r + (size_t)(valid ? 2 * pr : 0) * N;
-  const T* rb = ra + N;
-  typename F::Twiddles tw;
-  F::load_twiddles(tw, twtab, tid);
-  cpx<T> x[16];
-#pragma unroll
-  for (int i = 0; i < 16; ++i) {
-    const int src = makhoul_src(tid + TPF * i, N);
-    x[i] = {ra[src], rb[src]};
-  }
-  F::forward(x, lds, tid, tw);
-  __syncthreads();
-  D::fwd_scatter(x, lds, tid);
-  __syncthreads();
-  D::fwd_gather(x, lds, tid, wk);
-  if (!valid) return;
-  T* za = Z + (size_t)(2 * pr) * N;
-  T* zb = za + N;
-#pragma unroll
-  for (int i = 0; i < 16; ++i) {
-    za[tid + TPF * i] = x[i].x;
-    zb[tid + TPF * i] = x[i].y;
-  }
-}
 
 // fused path: apply the pending update of the previous iteration (alpha from the pq
 // kernel's partial sums), then DCT-II along axis 1 of the new residual
@@ -574,10 +550,10 @@ __global__ __launch_bounds__((RowGeom<T, LG>::THREADS), (sizeof(T) == 8 ? GPA_F6
   //   it  > 0: R -= alpha DCT-II_rows(q)    (linearity; phase_unwrap.py:345), partial ||r||^2 from R.
   // So the update reads q and R and writes R: three arrays instead of r, q in and r, Z out.
   if (flags[1]) return;
-  using F = WgFFT<T, LG>;
-  using D = WgDCT<T, LG>;
   using G = RowGeom<T, LG>;
-  constexpr int TPF = F::TPF, N = F::L;
+  using F = typename G::F;
+  using D = typename G::D;
+  constexpr int TPF = F::TPF, N = F::L, E = F::E;
   extern __shared__ __attribute__((aligned(16))) char smem[];
   __shared__ double sh[RowGeom<T, LG>::THREADS];
   const int tid = threadIdx.x % TPF, f = threadIdx.x / TPF;
@@ -587,7 +563,7 @@ __global__ __launch_bounds__((RowGeom<T, LG>::THREADS), (sizeof(T) == 8 ? GPA_F6
   const size_t oa = (size_t)(valid ? 2 * pr : 0) * N, ob = oa + N;
   typename F::Twiddles tw;
   F::load_twiddles(tw, twtab, tid);
-  cpx<T> x[16];
+  cpx<T> x[E];
   T alpha = T(0);
   if (it > 0) {
     const double pq = reduce_partials(part_pq, npq, sh);
@@ -605,11 +581,11 @@ __global__ __launch_bounds__((RowGeom<T, LG>::THREADS), (sizeof(T) == 8 ? GPA_F6
     }
     __syncthreads();
 #pragma unroll
-    for (int i = 0; i < 16; ++i) x[i] = lds[F::pad(makhoul_src(tid + TPF * i, N))];
+    for (int i = 0; i < E; ++i) x[i] = lds[F::pad(makhoul_src(tid + TPF * i, N))];
     __syncthreads();
   } else {
 #pragma unroll
-    for (int i = 0; i < 16; ++i) {
+    for (int i = 0; i < E; ++i) {
       const int src = makhoul_src(tid + TPF * i, N);
       x[i] = {r[oa + src], r[ob + src]};
     }
@@ -620,10 +596,10 @@ __global__ __launch_bounds__((RowGeom<T, LG>::THREADS), (sizeof(T) == 8 ? GPA_F6
 #endif
   // the kept spectrum is requested before the transform so that its latency hides behind it
   // (GPA_DCTF_LATE_RK: after it instead -- 32 registers less across the transform, one more wave per SIMD)
-  cpx<T> rk[16];
+  cpx<T> rk[E];
   if (it > 0 && !GPA_DCTF_LATE_RK) {
 #pragma unroll
-    for (int i = 0; i < 16; ++i) rk[i] = {r[oa + tid + TPF * i], r[ob + tid + TPF * i]};
+    for (int i = 0; i < E; ++i) rk[i] = {r[oa + tid + TPF * i], r[ob + tid + TPF * i]};
   }
   F::forward(x, lds, tid, tw);
   __syncthreads();
@@ -632,11 +608,11 @@ __global__ __launch_bounds__((RowGeom<T, LG>::THREADS), (sizeof(T) == 8 ? GPA_F6
   D::fwd_gather(x, lds, tid, wk);
   if (it > 0 && GPA_DCTF_LATE_RK) {
 #pragma unroll
-    for (int i = 0; i < 16; ++i) rk[i] = {r[oa + tid + TPF * i], r[ob + tid + TPF * i]};
+    for (int i = 0; i < E; ++i) rk[i] = {r[oa + tid + TPF * i], r[ob + tid + TPF * i]};
   }
   double sq = 0;
 #pragma unroll
-  for (int i = 0; i < 16; ++i) {
+  for (int i = 0; i < E; ++i) {
     const int k = tid + TPF * i;
     T ra = x[i].x, rb = x[i].y;
     if (it > 0) {
@@ -732,9 +708,10 @@ __global__ __launch_bounds__((ColGeom<T, LG>::THREADS)) void colsolve_kernel(T* 
     part_rho += pb * PART_N;
   }
   if (flags[1]) return;
-  using F = WgFFT<T, LG>;
-  using D = WgDCT<T, LG>;
   using G = ColGeom<T, LG>;
+  using F = typename G::F;
+  using D = typename G::D;
+  constexpr int E = F::E;
   const T* Zsrc = Zin ? Zin : Z;   // fused path: reads the kept row spectrum of r, writes the solve to Z
   constexpr int TPF = F::TPF, N = F::L, CT = G::CT, NT = G::NT;
   extern __shared__ __attribute__((aligned(16))) char smem[];
@@ -747,10 +724,10 @@ __global__ __launch_bounds__((ColGeom<T, LG>::THREADS)) void colsolve_kernel(T* 
   const int yy = valid ? y0 : 0;
   typename F::Twiddles tw;
   F::load_twiddles(tw, twtab, t);
-  cpx<T> x[NT][16];
+  cpx<T> x[NT][E];
   struct alignas(NT * sizeof(cpx<T>)) Vec { cpx<T> v[NT]; };
 #pragma unroll
-  for (int i = 0; i < 16; ++i) {
+  for (int i = 0; i < E; ++i) {
     const int row = makhoul_src(t + TPF * i, N);
     const Vec q = *reinterpret_cast<const Vec*>(Zsrc + (size_t)row * n1 + yy);
 #pragma unroll
@@ -798,7 +775,7 @@ __global__ __launch_bounds__((ColGeom<T, LG>::THREADS)) void colsolve_kernel(T* 
     int ts = t;
     asm volatile("" : "+v"(ts));
 #pragma unroll
-    for (int i = 0; i < 16; ++i) {
+    for (int i = 0; i < E; ++i) {
       const int row = makhoul_src(ts + TPF * i, N);
       Vec q;
 #pragma unroll
@@ -1101,58 +1078,6 @@ __global__ __launch_bounds__(1024) void colsolve_tri_kernel(const T* __restrict_
   }
 }
 
-// rows: Z -> z = DCT-III along axis 1 (in place), partial rho = <r, z>
-template <class T, int LG, bool RHO>
-__global__ __launch_bounds__((RowGeom<T, LG>::THREADS)) void rowidct_kernel(T* __restrict__ Z, const T* __restrict__ r,
-                                                                         int n0, const cpx<T>* __restrict__ twtab,
-                                                                         const cpx<T>* __restrict__ wk, double* part,
-                                                                         const int* flags) {
-  if (flags[1]) return;
-  using F = WgFFT<T, LG>;
-  using D = WgDCT<T, LG>;
-  using G = RowGeom<T, LG>;
-  constexpr int TPF = F::TPF, N = F::L;
-  extern __shared__ __attribute__((aligned(16))) char smem[];
-  __shared__ double sh[1024];
-  const int tid = threadIdx.x % TPF, f = threadIdx.x / TPF;
-  cpx<T>* lds = reinterpret_cast<cpx<T>*>(smem) + f * G::RS;
-  const int pr = blockIdx.x * G::NF + f;
-  const bool valid = 2 * pr + 1 < n0;
-  T* za = Z + (size_t)(valid ? 2 * pr : 0) * N;
-  T* zb = za + N;
-  typename F::Twiddles tw;
-  F::load_twiddles(tw, twtab, tid);
-  cpx<T> x[16], xm[16];
-#pragma unroll
-  for (int i = 0; i < 16; ++i) {
-    const int k = tid + TPF * i;
-    x[i] = {za[k], zb[k]};
-    xm[i] = k == 0 ? cpx<T>{T(0), T(0)} : cpx<T>{za[N - k], zb[N - k]};
-  }
-  D::inv_prepare(x, xm, tid, wk);
-  F::forward(x, lds, tid, tw);
-  __syncthreads();
-  D::inv_scatter(x, lds, tid, T(1) / T(N));
-  __syncthreads();
-  D::inv_gather(x, lds, tid);
-  double dot = 0;
-  if (valid) {
-    const T* ra = r + (size_t)(2 * pr) * N;
-    const T* rb = ra + N;
-#pragma unroll
-    for (int i = 0; i < 16; ++i) {
-      const int c = tid + TPF * i;
-      za[c] = x[i].x;
-      zb[c] = x[i].y;
-      if constexpr (RHO) dot += (double)ra[c] * (double)x[i].x + (double)rb[c] * (double)x[i].y;
-    }
-  }
-  if constexpr (RHO) {   // (the fused path takes rho from the column kernel's spectra instead)
-    const double tot = block_sum(dot, sh);
-    if (threadIdx.x == 0) part[blockIdx.x] = tot;
-  }
-}
-
 // fused path: rows Z -> z = DCT-III along axis 1, and straight on to the new search direction
 // p = z + beta p_prev (phase_unwrap.py:336-340) -- z itself never goes to HBM.  beta = rho / rho_prev with
 // rho from the column kernel's Parseval partial sums.
@@ -1179,10 +1104,10 @@ __global__ __launch_bounds__((RowGeom<T, LG>::THREADS), (GPA_IDCTP_COND ? 4 : (s
     part_rho += pb * PART_N;
   }
   if (flags[1]) return;
-  using F = WgFFT<T, LG>;
-  using D = WgDCT<T, LG>;
   using G = RowGeom<T, LG>;
-  constexpr int TPF = F::TPF, N = F::L;
+  using F = typename G::F;
+  using D = typename G::D;
+  constexpr int TPF = F::TPF, N = F::L, E = F::E;
   extern __shared__ __attribute__((aligned(16))) char smem[];
   __shared__ double sh[RowGeom<T, LG>::THREADS];
   const int tid = threadIdx.x % TPF, f = threadIdx.x / TPF;
@@ -1192,9 +1117,9 @@ __global__ __launch_bounds__((RowGeom<T, LG>::THREADS), (GPA_IDCTP_COND ? 4 : (s
   const size_t oa = (size_t)(valid ? 2 * pr : 0) * N, ob = oa + N;
   typename F::Twiddles tw;
   F::load_twiddles(tw, twtab, tid);
-  cpx<T> x[16], xm[16];
+  cpx<T> x[E], xm[E];
 #pragma unroll
-  for (int i = 0; i < 16; ++i) {
+  for (int i = 0; i < E; ++i) {
     const int k = tid + TPF * i;
     x[i] = {Z[oa + k], Z[ob + k]};
     xm[i] = k == 0 ? cpx<T>{T(0), T(0)} : cpx<T>{Z[oa + N - k], Z[ob + N - k]};
@@ -1212,7 +1137,7 @@ __global__ __launch_bounds__((RowGeom<T, LG>::THREADS), (GPA_IDCTP_COND ? 4 : (s
   D::inv_gather(x, lds, tid);
   if (!valid) return;
 #pragma unroll
-  for (int i = 0; i < 16; ++i) {
+  for (int i = 0; i < E; ++i) {
     const int c = tid + TPF * i;
     T pa = x[i].x, pb = x[i].y;
     if (!first) {
@@ -1542,46 +1467,16 @@ hipError_t run_mr_colsolve(const Impl* w, int compat, hipStream_t s, const doubl
                            double eps, double* part_rho, int* nrho, const void* zin);
 
 template <class T, int LG>
-hipError_t run_rowdct(const Impl* w, hipStream_t s) {
-  using G = RowGeom<T, LG>;
-  if constexpr (!G::FITS) return hipErrorInvalidValue;
-  else {
-    auto kern = rowdct_kernel<T, LG>;
-    static unsigned lds_set = 0;
-    hipError_t e = set_dynamic_lds_once(reinterpret_cast<const void*>(kern), (int)G::LDS_BYTES, lds_set);
-    if (e != hipSuccess) return e;
-    const int npairs = w->n0 / 2, grid = (npairs + G::NF - 1) / G::NF;
-    kern<<<grid, G::THREADS, G::LDS_BYTES, s>>>((const T*)w->r, w->n0, (T*)w->z, (const cpx<T>*)w->tw1,
-                                                 (const cpx<T>*)w->wk1, w->flags);
-    return hipGetLastError();
-  }
-}
-template <class T, int LG, bool RHO = true>
-hipError_t run_rowidct(const Impl* w, int* nparts, hipStream_t s) {
-  using G = RowGeom<T, LG>;
-  if constexpr (!G::FITS) return hipErrorInvalidValue;
-  else {
-    auto kern = rowidct_kernel<T, LG, RHO>;
-    static unsigned lds_set = 0;
-    hipError_t e = set_dynamic_lds_once(reinterpret_cast<const void*>(kern), (int)G::LDS_BYTES, lds_set);
-    if (e != hipSuccess) return e;
-    const int npairs = w->n0 / 2, grid = (npairs + G::NF - 1) / G::NF;
-    *nparts = grid;
-    kern<<<grid, G::THREADS, G::LDS_BYTES, s>>>((T*)w->z, (const T*)w->r, w->n0, (const cpx<T>*)w->tw1,
-                                                 (const cpx<T>*)w->wk1, w->part, w->flags);
-    return hipGetLastError();
-  }
-}
-template <class T, int LG>
 hipError_t run_colsolve(const Impl* w, int compat, hipStream_t s, const double* part_norm = nullptr, int nnorm = 0,
                         int it = 0, double eps = 0.0, double* part_rho = nullptr, int* nrho = nullptr,
                         const void* zin = nullptr) {
   using G = ColGeom<T, LG>;
   if constexpr (!G::FITS) return hipErrorInvalidValue;
   else {
-    auto kern = part_rho ? colsolve_kernel<T, LG, true> : colsolve_kernel<T, LG, false>;
-    static unsigned lds_set[2] = {0, 0};   // one flag word per instantiation
-    hipError_t e = set_dynamic_lds_once(reinterpret_cast<const void*>(kern), (int)G::LDS_BYTES, lds_set[part_rho ? 1 : 0]);
+    if (!part_rho) return hipErrorInvalidValue;   // (the only caller is the fused iteration)
+    auto kern = colsolve_kernel<T, LG, true>;
+    static unsigned lds_set = 0;
+    hipError_t e = set_dynamic_lds_once(reinterpret_cast<const void*>(kern), (int)G::LDS_BYTES, lds_set);
     if (e != hipSuccess) return e;
     const int npairs = w->n1 / 2, grid = (npairs + G::CC - 1) / G::CC;
     if (nrho) *nrho = grid;
@@ -1613,12 +1508,6 @@ hipError_t run_rowdct_fused(const Impl* w, const void* q, int ring, const double
   }
 }
 
-hipError_t dispatch_rowdct(const Impl* w, hipStream_t s) {
-#define CASE(LG) case LG: return w->dtype == 0 ? run_rowdct<float, LG>(w, s) : run_rowdct<double, LG>(w, s);
-  switch (w->lg1) { GPA_FOR_LG(CASE) }
-#undef CASE
-  return hipErrorInvalidValue;
-}
 template <class T, int LG>
 hipError_t run_rowidct_p(const Impl* w, const void* pin, void* pout, const double* part_rho, int nrho, int it,
                          hipStream_t s) {
@@ -1643,12 +1532,6 @@ hipError_t dispatch_rowidct_p(const Impl* w, const void* pin, void* pout, const 
                          : run_mr_rowidct_p<double>(w, pin, pout, part_rho, nrho, it, s);
 #define CASE(LG) case LG: return w->dtype == 0 ? run_rowidct_p<float, LG>(w, pin, pout, part_rho, nrho, it, s) \
                                                : run_rowidct_p<double, LG>(w, pin, pout, part_rho, nrho, it, s);
-  switch (w->lg1) { GPA_FOR_LG(CASE) }
-#undef CASE
-  return hipErrorInvalidValue;
-}
-hipError_t dispatch_rowidct(const Impl* w, int* nparts, hipStream_t s) {
-#define CASE(LG) case LG: return w->dtype == 0 ? run_rowidct<float, LG>(w, nparts, s) : run_rowidct<double, LG>(w, nparts, s);
   switch (w->lg1) { GPA_FOR_LG(CASE) }
 #undef CASE
   return hipErrorInvalidValue;
@@ -2071,12 +1954,13 @@ hipError_t unwrap_workspace_create(int dtype, int n0, int n1, hipStream_t s, Unw
       e = upload(dtype, &w->wk1, t, &bytes, s);
       if (e != hipSuccess) return e;
     }
-    const int tpf0 = n0 / 16;
+    // tables of the column kernel in the spectral layout [register][thread] of ITS transform (unwrap_elems)
+    const int E0 = unwrap_elems(w->lg0, (size_t)w->rsz), tpf0 = n0 / E0;
     {
       std::vector<double> t((size_t)2 * n0);
-      for (int i = 0; i < 16; ++i)
+      for (int i = 0; i < E0; ++i)
         for (int tt = 0; tt < tpf0; ++tt) {
-          const int k = spec_index_rt(w->lg0, tt, i);
+          const int k = spec_index_rt(w->lg0, tt, i, E0);
           t[2 * ((size_t)i * tpf0 + tt)] = cos(-M_PI * k / (2.0 * n0));
           t[2 * ((size_t)i * tpf0 + tt) + 1] = sin(-M_PI * k / (2.0 * n0));
         }
@@ -2088,9 +1972,9 @@ hipError_t unwrap_workspace_create(int dtype, int n0, int n1, hipStream_t s, Unw
     for (int compat = 0; compat < 2; ++compat) {
       const double A0 = compat ? n1 : n0, A1 = compat ? n0 : n1;
       std::vector<double> a((size_t)n0), am((size_t)n0), b((size_t)n1);
-      for (int i = 0; i < 16; ++i)
+      for (int i = 0; i < E0; ++i)
         for (int tt = 0; tt < tpf0; ++tt) {
-          const int k = spec_index_rt(w->lg0, tt, i);
+          const int k = spec_index_rt(w->lg0, tt, i, E0);
           const double sk = sin(M_PI * k / (2.0 * A0)), sm = sin(M_PI * (n0 - k) / (2.0 * A0));
           a[(size_t)i * tpf0 + tt] = 2 * sk * sk;
           am[(size_t)i * tpf0 + tt] = 2 * sm * sm;
@@ -2236,34 +2120,20 @@ static hipError_t run_pcg(Impl* w, const void* a, const void* b, const void* wei
     flush();
     return hipGetLastError();
   }
+  // sizes without a fused path (no mixed-radix plan fits LDS): the Bluestein kernels, one vector update per kernel
   for (int it = 0; it < kmax; ++it) {
     int nrow = 0;
-    if (w->generic) {
-      if ((e = dispatch_g_rowdct(w, s)) != hipSuccess) return e;
-      if ((e = dispatch_g_colsolve(w, compat, s)) != hipSuccess) return e;
-      if ((e = dispatch_g_rowidct(w, &nrow, s)) != hipSuccess) return e;
-    } else {
-      if ((e = dispatch_rowdct(w, s)) != hipSuccess) return e;
-      if ((e = dispatch_colsolve(w, compat, s)) != hipSuccess) return e;
-      if ((e = dispatch_rowidct(w, &nrow, s)) != hipSuccess) return e;
-    }
+    if ((e = dispatch_g_rowdct(w, s)) != hipSuccess) return e;
+    if ((e = dispatch_g_colsolve(w, compat, s)) != hipSuccess) return e;
+    if ((e = dispatch_g_rowidct(w, &nrow, s)) != hipSuccess) return e;
     { GPA_PROF("scalar_kernels", s); scal_rho_kernel<<<1, 256, 0, s>>>(w->part, nrow, w->scal, w->flags); }
-    T* pcur;
-    if (vec4) {
-      T* pin = (T*)((it & 1) ? w->p2 : w->p);
-      pcur = (T*)((it & 1) ? w->p : w->p2);
-      pq_kernel<T><<<gpq, 256, 0, s>>>((const T*)w->z, pin, pcur, (const T*)weight, n0, n1, (T*)w->q,
-                                       w->part + MAXPART, w->scal, w->flags, nullptr, 0, -1, band);
-      scal_alpha_kernel<<<1, 256, 0, s>>>(w->part + MAXPART, npq, w->scal, w->flags);
-    } else {
-      pcur = (T*)w->p;
-      { GPA_PROF("pupdate_kernel", s);
-        pupdate_kernel<T><<<gl, 256, 0, s>>>((const T*)w->z, pcur, npx, w->scal, w->flags); }
-      { GPA_PROF("applyq_kernel", s);
-        applyq_kernel<T><<<g2, 256, 0, s>>>((const T*)pcur, (const T*)weight, n0, n1, (T*)w->q, w->part + MAXPART,
-                                            w->flags); }
-      scal_alpha_kernel<<<1, 256, 0, s>>>(w->part + MAXPART, np2, w->scal, w->flags);
-    }
+    T* pcur = (T*)w->p;
+    { GPA_PROF("pupdate_kernel", s);
+      pupdate_kernel<T><<<gl, 256, 0, s>>>((const T*)w->z, pcur, npx, w->scal, w->flags); }
+    { GPA_PROF("applyq_kernel", s);
+      applyq_kernel<T><<<g2, 256, 0, s>>>((const T*)pcur, (const T*)weight, n0, n1, (T*)w->q, w->part + MAXPART,
+                                          w->flags); }
+    scal_alpha_kernel<<<1, 256, 0, s>>>(w->part + MAXPART, np2, w->scal, w->flags);
     { GPA_PROF("update_kernel", s);
       update_kernel<T><<<gl, 256, 0, s>>>((const T*)pcur, (const T*)w->q, (T*)phi, (T*)w->r, npx, w->scal,
                                           w->part + 2 * MAXPART, w->flags); }

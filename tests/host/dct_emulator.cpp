@@ -9,21 +9,21 @@
 
 using namespace gpa;
 
-template <class T, int LG>
+template <class T, int LG, int EE>
 struct Emu {
-  using F = WgFFT<T, LG>;
-  using D = WgDCT<T, LG>;
-  static constexpr int N = F::L, TPF = F::TPF;
+  using F = WgFFT<T, LG, EE>;
+  using D = WgDCT<T, LG, EE>;
+  static constexpr int N = F::L, TPF = F::TPF, E = EE;
   std::vector<cpx<T>> regs, lds, table, wk;
   std::vector<typename F::Twiddles> tw;
-  Emu() : regs(16 * TPF), lds(F::LDS_ELEMS), table(N), wk(N), tw(TPF) {
+  Emu() : regs(E * TPF), lds(F::LDS_ELEMS), table(N), wk(N), tw(TPF) {
     for (int t = 0; t < N; ++t) {
       table[t] = {(T)std::cos(-2 * M_PI * t / N), (T)std::sin(-2 * M_PI * t / N)};
       wk[t] = {(T)std::cos(-M_PI * t / (2.0 * N)), (T)std::sin(-M_PI * t / (2.0 * N))};
     }
     for (int t = 0; t < TPF; ++t) F::load_twiddles(tw[t], table.data(), t);
   }
-  cpx<T> (&R(int t))[16] { return *reinterpret_cast<cpx<T>(*)[16]>(&regs[16 * t]); }
+  cpx<T> (&R(int t))[E] { return *reinterpret_cast<cpx<T>(*)[E]>(&regs[E * t]); }
   void forward() {
     for (int t = 0; t < TPF; ++t) F::template fwd_phase<0>(R(t), lds.data(), t, tw[t]);
     if constexpr (F::P > 1) for (int t = 0; t < TPF; ++t) F::template fwd_phase<1>(R(t), lds.data(), t, tw[t]);
@@ -57,12 +57,12 @@ static void naive_idct2(const std::vector<double>& X, std::vector<double>& x) {
   }
 }
 
-template <class T, int LG>
+template <class T, int LG, int EE = 16>
 void test_one() {
-  using F = WgFFT<T, LG>;
-  using D = WgDCT<T, LG>;
-  constexpr int N = F::L, TPF = F::TPF;
-  Emu<T, LG> e;
+  using F = WgFFT<T, LG, EE>;
+  using D = WgDCT<T, LG, EE>;
+  constexpr int N = F::L, TPF = F::TPF, E = EE;
+  Emu<T, LG, EE> e;
   std::vector<double> a(N), b(N), Xa, Xb;
   srand(LG);
   for (int i = 0; i < N; ++i) { a[i] = rand() / (double)RAND_MAX - 0.5; b[i] = rand() / (double)RAND_MAX - 0.3; }
@@ -70,7 +70,7 @@ void test_one() {
   naive_dct2(b, Xb);
   // ---- forward
   for (int t = 0; t < TPF; ++t)
-    for (int i = 0; i < 16; ++i) {
+    for (int i = 0; i < E; ++i) {
       int src = makhoul_src(t + TPF * i, N);
       e.R(t)[i] = {(T)a[src], (T)b[src]};
     }
@@ -79,7 +79,7 @@ void test_one() {
   for (int t = 0; t < TPF; ++t) D::fwd_gather(e.R(t), e.lds.data(), t, e.wk.data());
   double err = 0, nrm = 0;
   for (int t = 0; t < TPF; ++t)
-    for (int i = 0; i < 16; ++i) {
+    for (int i = 0; i < E; ++i) {
       int k = t + TPF * i;
       err = std::max(err, std::abs(e.R(t)[i].x - Xa[k]));
       err = std::max(err, std::abs(e.R(t)[i].y - Xb[k]));
@@ -87,21 +87,21 @@ void test_one() {
     }
   double e_fwd = err / nrm;
   // ---- inverse (registers now hold X natural; build the mirror)
-  std::vector<cpx<T>> xm(16 * TPF);
+  std::vector<cpx<T>> xm(E * TPF);
   for (int t = 0; t < TPF; ++t)
-    for (int i = 0; i < 16; ++i) {
+    for (int i = 0; i < E; ++i) {
       int k = t + TPF * i;
-      xm[16 * t + i] = k == 0 ? cpx<T>{0, 0} : cpx<T>{(T)Xa[N - k], (T)Xb[N - k]};
+      xm[E * t + i] = k == 0 ? cpx<T>{0, 0} : cpx<T>{(T)Xa[N - k], (T)Xb[N - k]};
       e.R(t)[i] = {(T)Xa[k], (T)Xb[k]};
     }
   for (int t = 0; t < TPF; ++t)
-    D::inv_prepare(e.R(t), *reinterpret_cast<cpx<T>(*)[16]>(&xm[16 * t]), t, e.wk.data());
+    D::inv_prepare(e.R(t), *reinterpret_cast<cpx<T>(*)[E]>(&xm[E * t]), t, e.wk.data());
   e.forward();
   for (int t = 0; t < TPF; ++t) D::inv_scatter(e.R(t), e.lds.data(), t, (T)(1.0 / N));
   for (int t = 0; t < TPF; ++t) D::inv_gather(e.R(t), e.lds.data(), t);
   double e_inv = 0;
   for (int t = 0; t < TPF; ++t)
-    for (int i = 0; i < 16; ++i) {
+    for (int i = 0; i < E; ++i) {
       int c = t + TPF * i;
       e_inv = std::max(e_inv, std::abs(e.R(t)[i].x - a[c]));
       e_inv = std::max(e_inv, std::abs(e.R(t)[i].y - b[c]));
@@ -111,7 +111,7 @@ void test_one() {
   std::vector<T> ca(N), cam(N);
   std::vector<cpx<T>> wspec(N);
   for (int t = 0; t < TPF; ++t)
-    for (int i = 0; i < 16; ++i) {
+    for (int i = 0; i < E; ++i) {
       int k = F::spec_index(t, i);
       ca[i * TPF + t] = (T)(2 * std::pow(std::sin(M_PI * k / (2 * A)), 2));
       cam[i * TPF + t] = (T)(2 * std::pow(std::sin(M_PI * (N - k) / (2 * A)), 2));
@@ -129,7 +129,7 @@ void test_one() {
   naive_idct2(Ya, ya);
   naive_idct2(Yb, yb);
   for (int t = 0; t < TPF; ++t)
-    for (int i = 0; i < 16; ++i) {
+    for (int i = 0; i < E; ++i) {
       int src = makhoul_src(t + TPF * i, N);
       e.R(t)[i] = {(T)a[src], (T)b[src]};
     }
@@ -141,14 +141,14 @@ void test_one() {
   e.inverse();
   double e_sol = 0, n_sol = 0;
   for (int t = 0; t < TPF; ++t)
-    for (int i = 0; i < 16; ++i) {
+    for (int i = 0; i < E; ++i) {
       int dst = makhoul_src(t + TPF * i, N);
       e_sol = std::max(e_sol, std::abs(e.R(t)[i].x - ya[dst]));
       e_sol = std::max(e_sol, std::abs(e.R(t)[i].y - yb[dst]));
       n_sol = std::max(n_sol, std::abs(ya[dst]));
     }
   e_sol /= n_sol;
-  printf("N=%5d %s dct_fwd=%.2e idct=%.2e fused_solve=%.2e\n", N, sizeof(T) == 4 ? "f32" : "f64", e_fwd, e_inv, e_sol);
+  printf("N=%5d E=%2d %s dct_fwd=%.2e idct=%.2e fused_solve=%.2e\n", N, E, sizeof(T) == 4 ? "f32" : "f64", e_fwd, e_inv, e_sol);
   double tol = sizeof(T) == 4 ? 5e-6 : 1e-11;  // the naive O(N^2) reference itself loses digits
   if (e_fwd > tol || e_inv > tol || e_sol > 20 * tol) { printf("FAIL\n"); exit(1); }
 }
@@ -156,5 +156,8 @@ void test_one() {
 int main() {
   test_one<double, 6>(); test_one<double, 7>(); test_one<double, 9>(); test_one<double, 10>(); test_one<double, 12>();
   test_one<float, 6>(); test_one<float, 8>(); test_one<float, 11>(); test_one<float, 13>();
+  // eight elements per thread
+  test_one<double, 6, 8>(); test_one<double, 8, 8>(); test_one<double, 9, 8>(); test_one<double, 10, 8>(); test_one<double, 11, 8>();
+  test_one<float, 7, 8>(); test_one<float, 9, 8>(); test_one<float, 10, 8>(); test_one<float, 12, 8>();
   printf("OK\n");
 }

@@ -12,28 +12,29 @@
 
 using namespace gpa;
 
-template <class T, int LG, int ph>
+template <class T, int LG, int ph, int EE>
 void run_fwd_phase(std::vector<cpx<T>>& regs, std::vector<cpx<T>>& lds,
-                   std::vector<typename WgFFT<T, LG>::Twiddles>& tw) {
-  using F = WgFFT<T, LG>;
+                   std::vector<typename WgFFT<T, LG, EE>::Twiddles>& tw) {
+  using F = WgFFT<T, LG, EE>;
   for (int t = 0; t < F::TPF; ++t) {
-    cpx<T>(&x)[16] = *reinterpret_cast<cpx<T>(*)[16]>(&regs[16 * t]);
+    cpx<T>(&x)[EE] = *reinterpret_cast<cpx<T>(*)[EE]>(&regs[EE * t]);
     F::template fwd_phase<ph>(x, lds.data(), t, tw[t]);
   }
 }
-template <class T, int LG, int ph>
+template <class T, int LG, int ph, int EE>
 void run_inv_phase(std::vector<cpx<T>>& regs, std::vector<cpx<T>>& lds,
-                   std::vector<typename WgFFT<T, LG>::Twiddles>& tw) {
-  using F = WgFFT<T, LG>;
+                   std::vector<typename WgFFT<T, LG, EE>::Twiddles>& tw) {
+  using F = WgFFT<T, LG, EE>;
   for (int t = 0; t < F::TPF; ++t) {
-    cpx<T>(&x)[16] = *reinterpret_cast<cpx<T>(*)[16]>(&regs[16 * t]);
+    cpx<T>(&x)[EE] = *reinterpret_cast<cpx<T>(*)[EE]>(&regs[EE * t]);
     F::template inv_phase<ph>(x, lds.data(), t, tw[t]);
   }
 }
 
-template <class T, int LG>
+template <class T, int LG, int EE = 16>
 double test_one() {
-  using F = WgFFT<T, LG>;
+  using F = WgFFT<T, LG, EE>;
+  constexpr int E = EE;
   const int L = F::L;
   std::vector<std::complex<double>> in(L), ref(L);
   srand(LG * 7 + sizeof(T));
@@ -70,39 +71,39 @@ double test_one() {
   for (int t = 0; t < L; ++t) table[t] = {(T)std::cos(-2 * M_PI * t / L), (T)std::sin(-2 * M_PI * t / L)};
   std::vector<typename F::Twiddles> tw(F::TPF);
   for (int t = 0; t < F::TPF; ++t) F::load_twiddles(tw[t], table.data(), t);
-  std::vector<cpx<T>> regs(16 * F::TPF), lds(F::LDS_ELEMS, cpx<T>{(T)1e30, (T)1e30});
+  std::vector<cpx<T>> regs(E * F::TPF), lds(F::LDS_ELEMS, cpx<T>{(T)1e30, (T)1e30});
   for (int t = 0; t < F::TPF; ++t)
-    for (int i = 0; i < 16; ++i) {
+    for (int i = 0; i < E; ++i) {
       auto v = in[t + F::TPF * i];
-      regs[16 * t + i] = {(T)v.real(), (T)v.imag()};
+      regs[E * t + i] = {(T)v.real(), (T)v.imag()};
     }
-  run_fwd_phase<T, LG, 0>(regs, lds, tw);
-  if constexpr (F::P > 1) run_fwd_phase<T, LG, 1>(regs, lds, tw);
-  if constexpr (F::P > 2) run_fwd_phase<T, LG, 2>(regs, lds, tw);
-  if constexpr (F::P > 3) run_fwd_phase<T, LG, 3>(regs, lds, tw);
+  run_fwd_phase<T, LG, 0, EE>(regs, lds, tw);
+  if constexpr (F::P > 1) run_fwd_phase<T, LG, 1, EE>(regs, lds, tw);
+  if constexpr (F::P > 2) run_fwd_phase<T, LG, 2, EE>(regs, lds, tw);
+  if constexpr (F::P > 3) run_fwd_phase<T, LG, 3, EE>(regs, lds, tw);
   double err = 0, nrm = 0;
   std::vector<char> seen(L, 0);
   for (int t = 0; t < F::TPF; ++t)
-    for (int i = 0; i < 16; ++i) {
+    for (int i = 0; i < E; ++i) {
       int k = F::spec_index(t, i);
       if (k < 0 || k >= L || seen[k]) { printf("bad spec_index L=%d t=%d i=%d k=%d\n", L, t, i, k); exit(1); }
       seen[k] = 1;
-      auto v = regs[16 * t + i];
+      auto v = regs[E * t + i];
       err = std::max(err, std::abs(std::complex<double>(v.x, v.y) - ref[k]));
       nrm = std::max(nrm, std::abs(ref[k]));
     }
   double e1 = err / nrm;
-  run_inv_phase<T, LG, 0>(regs, lds, tw);
-  if constexpr (F::P > 1) run_inv_phase<T, LG, 1>(regs, lds, tw);
-  if constexpr (F::P > 2) run_inv_phase<T, LG, 2>(regs, lds, tw);
-  if constexpr (F::P > 3) run_inv_phase<T, LG, 3>(regs, lds, tw);
+  run_inv_phase<T, LG, 0, EE>(regs, lds, tw);
+  if constexpr (F::P > 1) run_inv_phase<T, LG, 1, EE>(regs, lds, tw);
+  if constexpr (F::P > 2) run_inv_phase<T, LG, 2, EE>(regs, lds, tw);
+  if constexpr (F::P > 3) run_inv_phase<T, LG, 3, EE>(regs, lds, tw);
   double e2 = 0;
   for (int t = 0; t < F::TPF; ++t)
-    for (int i = 0; i < 16; ++i) {
-      auto v = regs[16 * t + i];
+    for (int i = 0; i < E; ++i) {
+      auto v = regs[E * t + i];
       e2 = std::max(e2, std::abs(std::complex<double>(v.x, v.y) / (double)L - in[t + F::TPF * i]));
     }
-  printf("L=%5d %s P=%d fwd_rel_err=%.2e roundtrip_err=%.2e\n", L, sizeof(T) == 4 ? "f32" : "f64", F::P, e1, e2);
+  printf("L=%5d E=%2d %s P=%d fwd_rel_err=%.2e roundtrip_err=%.2e\n", L, E, sizeof(T) == 4 ? "f32" : "f64", F::P, e1, e2);
   double tol = sizeof(T) == 4 ? 2e-6 : 4e-15;
   if (e1 > tol || e2 > tol) { printf("FAIL\n"); exit(1); }
   return e1;
@@ -112,6 +113,9 @@ template <class T>
 void all() {
   test_one<T, 6>(); test_one<T, 7>(); test_one<T, 8>(); test_one<T, 9>(); test_one<T, 10>();
   test_one<T, 11>(); test_one<T, 12>(); test_one<T, 13>(); test_one<T, 14>();
+  // eight elements per thread (the short transforms of the unwrap kernels)
+  test_one<T, 6, 8>(); test_one<T, 7, 8>(); test_one<T, 8, 8>(); test_one<T, 9, 8>(); test_one<T, 10, 8>();
+  test_one<T, 11, 8>(); test_one<T, 12, 8>();
 }
 
 int main() {

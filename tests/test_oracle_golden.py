@@ -137,6 +137,22 @@ def test_a9_per_known_answers():
     assert shat[0, 0] == 0
 
 
+def test_f3_peak_local_max_known_answers():
+    """The stand-in for skimage.feature.peak_local_max (absent from this image) against what scikit-image's
+    own documentation states for min_distance = 1: both isolated maxima, highest first; a plateau-free border
+    pixel is never a peak (exclude_border); a constant image has none."""
+    img = np.zeros((7, 7))
+    img[3, 4] = 1
+    img[3, 2] = 1.5
+    assert orc.peak_local_max(img, 0.0).tolist() == [[3, 2], [3, 4]]
+    assert orc.peak_local_max(img, 0.8).tolist() == [[3, 2]]          # 1 < 0.8 * 1.5
+    edge = np.zeros((7, 7))
+    edge[0, 3] = 2.0
+    edge[4, 4] = 1.0
+    assert orc.peak_local_max(edge, 0.0).tolist() == [[4, 4]]
+    assert len(orc.peak_local_max(np.ones((5, 5)), 0.5)) == 0
+
+
 def test_f1_lawler_fujita(golden):
     g = golden('warp_96x80')
     assert np.allclose(orc.invert_u_overlap(-g['u']), g['u_inv'], rtol=0, atol=1e-12, equal_nan=True)
