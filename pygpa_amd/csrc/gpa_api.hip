@@ -217,7 +217,8 @@ struct gpa_plan {
   int last_planes = 0;
   std::vector<double> staged_kl, staged_kr, staged_kmat;   // what the device tables currently hold
   int* h_iters = nullptr;         // pinned: iteration counts of the last (possibly asynchronous) driver call
-  int iters_stride = 1;           // 1: two-stream driver (h_iters[0], [1]); 4: paired workspace (h_iters[0], [4])
+  int iters_stride = 1;           // 1: two-stream driver (h_iters[0], [1]); 4: paired workspace (flag words of 2 problems)
+  int iters_off = 0;              // paired / batched: the word of a problem's flags that holds its count
   // images of up to 1024^2: both components of u in ONE set of launches (blockIdx.z) on one stream -- measured 8 %
   // (512^2) to 14 % (256^2) faster than two streams, whose kernels are too small to overlap; from 2048^2 on the two
   // streams win by 4 % (profiles/r02_image_stacks.txt, 'stack of 1')
@@ -980,9 +981,11 @@ static int extract_launch(gpa_plan* p, const void* image, int P, int K, int Bx, 
     if (ep == hipSuccess) ep = unwrap_fetch_iters(&p->uwp, p->h_iters, p->stream);
     if (ep != hipSuccess) return fail(GPA_ERR_HIP, std::string("unwrap: ") + hipGetErrorString(ep));
     p->iters_stride = 4;
+    p->iters_off = unwrap_iters_slot(&p->uwp);
     return GPA_OK;
   }
   p->iters_stride = 1;
+  p->iters_off = 0;
   HIP_TRY(launch_reconstruct_setup(p->dtype, lk, p->d_kmat, P, p->n0, p->n1, mask_border, p->d_wnorm,
                                    unwrap_residual_buffer(&p->uw), unwrap_residual_buffer(&p->uw2),
                                    unwrap_partials_buffer(&p->uw), unwrap_partials_buffer(&p->uw2), &nparts, p->stream));
@@ -1197,7 +1200,7 @@ int gpa_extract_displacement_field_batch_dev(gpa_plan* p, const void* images, in
   if (e != hipSuccess) return fail(GPA_ERR_HIP, std::string("batched unwrap: ") + hipGetErrorString(e));
   if (iters_out) {
     HIP_TRY(hipStreamSynchronize(p->stream));
-    for (int j = 0; j < 2 * B; ++j) iters_out[j] = p->h_iters_b[4 * j];
+    for (int j = 0; j < 2 * B; ++j) iters_out[j] = p->h_iters_b[4 * j + unwrap_iters_slot(&p->uwb)];
   }
   return GPA_OK;
 }
@@ -1205,15 +1208,15 @@ int gpa_extract_displacement_field_batch_dev(gpa_plan* p, const void* images, in
 int gpa_last_batch_iters(gpa_plan* p, int B, int* iters_out) {
   if (!p || !iters_out || B < 1 || B > p->uwb_images) return fail(GPA_ERR_ARG, "gpa_last_batch_iters: bad argument");
   HIP_TRY(hipStreamSynchronize(p->stream));
-  for (int j = 0; j < 2 * B; ++j) iters_out[j] = p->h_iters_b[4 * j];
+  for (int j = 0; j < 2 * B; ++j) iters_out[j] = p->h_iters_b[4 * j + unwrap_iters_slot(&p->uwb)];
   return GPA_OK;
 }
 
 int gpa_last_iters(gpa_plan* p, int* iters2) {
   if (!p || !iters2) return fail(GPA_ERR_ARG, "null argument");
   HIP_TRY(hipStreamSynchronize(p->stream));
-  iters2[0] = p->h_iters[0];
-  iters2[1] = p->h_iters[p->iters_stride];
+  iters2[0] = p->h_iters[p->iters_off];
+  iters2[1] = p->h_iters[p->iters_stride + p->iters_off];
   return GPA_OK;
 }
 
@@ -1245,7 +1248,7 @@ int gpa_extract_displacement_field_dev(gpa_plan* p, const void* image, const dou
       p->kprof_table += line;
     }
   }
-  if (iters_out) { iters_out[0] = p->h_iters[0]; iters_out[1] = p->h_iters[p->iters_stride]; }
+  if (iters_out) { iters_out[0] = p->h_iters[p->iters_off]; iters_out[1] = p->h_iters[p->iters_stride + p->iters_off]; }
   return GPA_OK;
 }
 

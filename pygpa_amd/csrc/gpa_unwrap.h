@@ -59,5 +59,7 @@ hipError_t unwrap_finish(UnwrapWorkspace* ws, int* iters_out, hipStream_t s);
 // asynchronous copy of the iteration count into (pinned) host memory, no synchronisation
 // (a batched workspace: nprob counts, 4 ints apart -- host_pinned[4 * pb])
 hipError_t unwrap_fetch_iters(UnwrapWorkspace* ws, int* host_pinned, hipStream_t s);
+// several problems per workspace: unwrap_fetch_iters() copies 4 flag words per problem, the count is word unwrap_iters_slot()
+int unwrap_iters_slot(const UnwrapWorkspace* ws);
 
 }  // namespace gpa

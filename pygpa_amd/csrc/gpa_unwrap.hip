@@ -52,6 +52,7 @@ constexpr size_t PART_N = (size_t)3 * MAXPART;
 struct Impl {
   int dtype, n0, n1, lg0, lg1;
   int nprob;                 // problems solved per launch (blockIdx.z): 1, or 2 x images of a batched driver call
+  int iters_slot;            // flags[iters_slot] = iterations performed (3: fused iteration, 0: plain scheme)
   bool supported;
   size_t rsz;
   void *r, *p, *p2, *q, *z;   // p / p2: double-buffered search direction (= ring[0], ring[1])
@@ -123,14 +124,37 @@ __device__ __forceinline__ double reduce_partials(const double* __restrict__ par
   return block_sum(acc, sh);
 }
 
+// Start of a solve on prepared residuals, folded into the first row kernel of the fused iteration (it used to be
+// a one-block kernel of its own): ||r0||^2 from the producer's partial sums, evaluated by every workgroup in the
+// same order; block 0 files it and resets the flags, which no other workgroup of that launch reads.
+// Returns false when r0 == 0 everywhere: nothing to do (phase_unwrap.py:326).
+__device__ __forceinline__ bool solve_init(const double* __restrict__ part0, int nparts, double* scal, int* flags,
+                                           double* sh) {
+  const double tot = reduce_partials(part0, nparts, sh);
+  if (blockIdx.x == 0 && threadIdx.x == 0) {
+    scal[5] = tot;   // ||r0||^2
+    scal[6] = tot;
+    scal[7] = tot;   // smallest ||r||^2 seen
+    scal[10] = tot;
+    scal[11] = tot;
+    scal[1] = 0.0;
+    flags[0] = 0;
+    flags[2] = 0;
+    flags[3] = 0;
+    flags[1] = tot == 0.0 ? 1 : 0;
+  }
+  return tot != 0.0;
+}
+
 // Scalars of the fused power-of-two path (single writer = block 0 of the named kernel;
 // values a kernel both reads and replaces are double-buffered by iteration parity):
 //   scal[5] = ||r0||^2                    (scal_init_kernel)
 //   scal[8 + (it & 1)]  = rho of iteration it            (rowidct_p_kernel)
 //   scal[10 + (it & 1)] = smallest ||r||^2 up to it      (colsolve_kernel)
-//   scal[16 + (j % ring)] = alpha of iteration j         (rowdct_fused_kernel / final_alpha_kernel)
+//   scal[16 + (j % ring)] = alpha of iteration j         (rowdct_fused_kernel; the last one: final phi_flush_kernel)
 //   flags[0] = completed updates k, flags[1] = done      (colsolve_kernel / final kernel)
 //   flags[2] = updates already applied to phi            (phi_commit_kernel)
+//   flags[3] = iterations performed, for the host        (the final phi_flush_kernel)
 
 // ---------------------------------------------------------------------------
 // setup: r0 = div( WW * wrap(grad) ), phi = 0, partial ||r0||^2
@@ -235,6 +259,7 @@ __global__ void scal_init_kernel(const double* part, int nparts, double* scal, i
     scal[1] = 0.0;
     flags[0] = 0;
     flags[2] = 0;
+    flags[3] = 0;
     flags[1] = tot == 0.0 ? 1 : 0;   // r == 0 everywhere: nothing to do (phase_unwrap.py:326)
   }
 }
@@ -533,8 +558,8 @@ struct ColGeom {
 template <class T, int LG>
 __global__ __launch_bounds__((RowGeom<T, LG>::THREADS), (sizeof(T) == 8 ? GPA_F64_WAVES : GPA_DCTF_WAVES)) void rowdct_fused_kernel(
     T* __restrict__ r, const T* __restrict__ q, int n0, const cpx<T>* __restrict__ twtab,
-    const cpx<T>* __restrict__ wk, const int* flags, const double* part_pq, int npq, double* part_norm,
-    double* scal, int it, int ring, size_t pimg) {
+    const cpx<T>* __restrict__ wk, int* flags, const double* part_pq, int npq, double* part_norm,
+    double* scal, int it, int ring, int init, size_t pimg) {
   {
     const size_t pb = blockIdx.z;
     r += pb * pimg;
@@ -549,13 +574,15 @@ __global__ __launch_bounds__((RowGeom<T, LG>::THREADS), (sizeof(T) == 8 ? GPA_F6
   //   it == 0: r (spatial, from the set-up) -> R, in place;
   //   it  > 0: R -= alpha DCT-II_rows(q)    (linearity; phase_unwrap.py:345), partial ||r||^2 from R.
   // So the update reads q and R and writes R: three arrays instead of r, q in and r, Z out.
-  if (flags[1]) return;
   using G = RowGeom<T, LG>;
   using F = typename G::F;
   using D = typename G::D;
   constexpr int TPF = F::TPF, N = F::L, E = F::E;
   extern __shared__ __attribute__((aligned(16))) char smem[];
   __shared__ double sh[RowGeom<T, LG>::THREADS];
+  // init (first iteration of a solve on prepared residuals): part_pq / npq are the producer's partial norms of r0
+  if (init) { if (!solve_init(part_pq, npq, scal, flags, sh)) return; }
+  else if (flags[1]) return;
   const int tid = threadIdx.x % TPF, f = threadIdx.x / TPF;
   cpx<T>* lds = reinterpret_cast<cpx<T>*>(smem) + f * G::RS;
   const int pr = blockIdx.x * G::NF + f;
@@ -634,23 +661,6 @@ __global__ __launch_bounds__((RowGeom<T, LG>::THREADS), (sizeof(T) == 8 ? GPA_F6
   }
 }
 
-// fused path, after the last iteration: alpha of that iteration for phi_flush_kernel (no further row
-// kernel will compute it; the residual of the last iteration is not formed, nothing reads it)
-__global__ __launch_bounds__(256) void final_alpha_kernel(double* scal, const double* part_pq, int npq, int it, int ring,
-                                                         int* flags) {
-  scal += blockIdx.z * SCAL_N;
-  part_pq += blockIdx.z * PART_N;
-  flags += blockIdx.z * FLAGS_N;
-  if (flags[1]) return;
-  __shared__ double sh[256];
-  const double pq = reduce_partials(part_pq, npq, sh);
-  if (threadIdx.x == 0) {
-    scal[SC_ALPHA + (it - 1) % ring] = scal[8 + ((it - 1) & 1)] / pq;
-    flags[0] = it;   // all kmax updates done (a separate one-thread kernel used to record this)
-    flags[1] = 1;
-  }
-}
-
 // phi += sum_j alpha_j p_j over the updates j in [flags[2], flags[0]) that the iteration has completed
 // but phi has not seen yet, in iteration order (the same additions the reference makes one per
 // iteration, phase_unwrap.py:344, without writing phi back in between).  Runs whether or not the
@@ -658,14 +668,32 @@ __global__ __launch_bounds__(256) void final_alpha_kernel(double* scal, const do
 template <class T> struct RingPtrs { const T* p[RING_MAX]; };
 template <class T, int V = 4>
 __global__ __launch_bounds__(256) void phi_flush_kernel(RingPtrs<T> ringp, int ring, T* __restrict__ phi, size_t count4,
-                                                       const double* __restrict__ scal, const int* __restrict__ flags,
-                                                       int init, size_t pimg) {
+                                                       const double* __restrict__ scal, int* __restrict__ flags,
+                                                       int init, size_t pimg, int final_it, const double* part_pq,
+                                                       int npq) {
   const size_t pb = blockIdx.z;
   phi += pb * pimg;
   scal += pb * SCAL_N;
   flags += pb * FLAGS_N;
   // init: phi has not been written yet (prepared start) -- this flush starts from 0 instead of reading it
-  const int a = flags[2], b = flags[0];
+  const int a = flags[2];
+  int b = flags[0];
+  // final_it = kmax: the flush that ends the solve.  If the iteration has not stopped by itself, the step length
+  // of its last update (no further row kernel computes it) is evaluated here, by every workgroup, from the stencil
+  // kernel's partial sums -- and nothing the other workgroups read is written: the iteration count goes to
+  // flags[3].  (This used to take two more one-block kernels and a commit.)
+  int jlast = -1;
+  double alpha_last = 0.0;
+  if (final_it > 0) {
+    __shared__ double sh[256];
+    if (!flags[1]) {
+      const double pq = reduce_partials(part_pq + pb * PART_N, npq, sh);
+      alpha_last = scal[8 + ((final_it - 1) & 1)] / pq;   // phase_unwrap.py:343
+      jlast = final_it - 1;
+      b = final_it;
+    }
+    if (blockIdx.x == 0 && threadIdx.x == 0) flags[3] = b;
+  }
   if (a >= b && !init) return;
   for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < count4; i += (size_t)gridDim.x * 256) {
     VecN<T, V> f;
@@ -673,7 +701,7 @@ __global__ __launch_bounds__(256) void phi_flush_kernel(RingPtrs<T> ringp, int r
     for (int c = 0; c < V; ++c) f.v[c] = T(0);
     if (!init) f = reinterpret_cast<const VecN<T, V>*>(phi)[i];
     for (int j = a; j < b; ++j) {
-      const T alpha = (T)scal[SC_ALPHA + j % ring];
+      const T alpha = j == jlast ? (T)alpha_last : (T)scal[SC_ALPHA + j % ring];
       const VecN<T, V> pv = reinterpret_cast<const VecN<T, V>*>(ringp.p[j % ring] + pb * pimg)[i];
 #pragma unroll
       for (int c = 0; c < V; ++c) f.v[c] += alpha * pv.v[c];
@@ -1458,7 +1486,7 @@ __global__ __launch_bounds__(256) void per_combine_kernel(const cpx<T>* __restri
 // mixed-radix fused kernels (gpa_unwrap_mr.h, included below)
 template <class T>
 hipError_t run_mr_rowdct_fused(const Impl* w, const void* q, int ring, const double* part_pq, int npq,
-                               double* part_norm, int it, int* nnorm, hipStream_t s);
+                               double* part_norm, int it, int* nnorm, int init, hipStream_t s);
 template <class T>
 hipError_t run_mr_rowidct_p(const Impl* w, const void* pin, void* pout, const double* part_rho, int nrho, int it,
                             hipStream_t s);
@@ -1490,7 +1518,7 @@ hipError_t run_colsolve(const Impl* w, int compat, hipStream_t s, const double* 
 }
 template <class T, int LG>
 hipError_t run_rowdct_fused(const Impl* w, const void* q, int ring, const double* part_pq, int npq,
-                            double* part_norm, int it, int* nnorm, hipStream_t s) {
+                            double* part_norm, int it, int* nnorm, int init, hipStream_t s) {
   using G = RowGeom<T, LG>;
   if constexpr (!G::FITS) return hipErrorInvalidValue;
   else {
@@ -1503,7 +1531,7 @@ hipError_t run_rowdct_fused(const Impl* w, const void* q, int ring, const double
     GPA_PROF("rowdct_fused_kernel", s);
     kern<<<dim3(grid, 1, w->nprob), G::THREADS, G::LDS_BYTES, s>>>((T*)w->r, (const T*)q, w->n0, (const cpx<T>*)w->tw1,
                                                  (const cpx<T>*)w->wk1, w->flags, part_pq, npq, part_norm, w->scal, it,
-                                                 ring, (size_t)w->n0 * w->n1);
+                                                 ring, init, (size_t)w->n0 * w->n1);
     return hipGetLastError();
   }
 }
@@ -1629,13 +1657,14 @@ hipError_t dispatch_colsolve(const Impl* w, int compat, hipStream_t s, const dou
 #undef CASE
   return hipErrorInvalidValue;
 }
+// init: first iteration of a solve on prepared residuals -- part_pq / npq are then the producer's partial norms
 hipError_t dispatch_rowdct_fused(const Impl* w, const void* q, int ring, const double* part_pq, int npq,
-                                 double* part_norm, int it, int* nnorm, hipStream_t s) {
+                                 double* part_norm, int it, int* nnorm, int init, hipStream_t s) {
   if (w->generic)
-    return w->dtype == 0 ? run_mr_rowdct_fused<float>(w, q, ring, part_pq, npq, part_norm, it, nnorm, s)
-                         : run_mr_rowdct_fused<double>(w, q, ring, part_pq, npq, part_norm, it, nnorm, s);
-#define CASE(LG) case LG: return w->dtype == 0 ? run_rowdct_fused<float, LG>(w, q, ring, part_pq, npq, part_norm, it, nnorm, s) \
-                                               : run_rowdct_fused<double, LG>(w, q, ring, part_pq, npq, part_norm, it, nnorm, s);
+    return w->dtype == 0 ? run_mr_rowdct_fused<float>(w, q, ring, part_pq, npq, part_norm, it, nnorm, init, s)
+                         : run_mr_rowdct_fused<double>(w, q, ring, part_pq, npq, part_norm, it, nnorm, init, s);
+#define CASE(LG) case LG: return w->dtype == 0 ? run_rowdct_fused<float, LG>(w, q, ring, part_pq, npq, part_norm, it, nnorm, init, s) \
+                                               : run_rowdct_fused<double, LG>(w, q, ring, part_pq, npq, part_norm, it, nnorm, init, s);
   switch (w->lg1) { GPA_FOR_LG(CASE) }
 #undef CASE
   return hipErrorInvalidValue;
@@ -2060,10 +2089,14 @@ static hipError_t run_pcg(Impl* w, const void* a, const void* b, const void* wei
     // other paths update phi in place and need it cleared
     const bool fused_path = !w->generic || w->mr_ok;
     if (!fused_path && (e = hipMemsetAsync(phi, 0, npx * w->rsz, s)) != hipSuccess) return e;
-    GPA_PROF("scalar_kernels", s);
-    scal_init_kernel<<<dim3(1, 1, w->nprob), 256, 0, s>>>(w->part, w->prepared_parts, w->scal, w->flags);
+    // (fused path: the first row kernel starts the solve from the producer's partial norms, solve_init())
+    if (!fused_path) {
+      GPA_PROF("scalar_kernels", s);
+      scal_init_kernel<<<dim3(1, 1, w->nprob), 256, 0, s>>>(w->part, w->prepared_parts, w->scal, w->flags);
+    }
   }
   const bool vec4 = !w->generic || w->mr_ok;   // the fused 4-kernel iteration
+  w->iters_slot = vec4 ? 3 : 0;
   if (w->nprob > 1 && (a || !vec4)) return hipErrorNotSupported;   // batched: prepared start on the fused path only
   if (vec4) {
     // fused power-of-two path: 4 kernels per iteration, no scalar kernels.  The phi / r update
@@ -2085,23 +2118,28 @@ static hipError_t run_pcg(Impl* w, const void* a, const void* b, const void* wei
     RingPtrs<T> rp;
     for (int j = 0; j < RING_MAX; ++j) rp.p[j] = (const T*)w->ring[j < ring ? j : 0];
     bool phi_unwritten = a == nullptr;   // prepared start: nobody has zeroed phi
-    auto flush = [&]() {
+    // final_it = kmax: the flush that ends the solve (takes the last step length from the stencil kernel's partial
+    // sums and files the iteration count); otherwise a flush in mid-solve, committed by a one-thread kernel
+    auto flush = [&](int final_it) {
       { GPA_PROF("phi_flush_kernel", s);
         if (V == 4)
           phi_flush_kernel<T, 4><<<dim3(gl, 1, w->nprob), 256, 0, s>>>(rp, ring, (T*)phi, npx / 4, w->scal, w->flags,
-                                                                      phi_unwritten ? 1 : 0, npx);
+                                                                      phi_unwritten ? 1 : 0, npx, final_it, part_pq, npq);
         else
           phi_flush_kernel<T, 1><<<dim3(gl, 1, w->nprob), 256, 0, s>>>(rp, ring, (T*)phi, npx, w->scal, w->flags,
-                                                                      phi_unwritten ? 1 : 0, npx); }
-      { GPA_PROF("scalar_kernels", s); phi_commit_kernel<<<dim3(1, 1, w->nprob), 1, 0, s>>>(w->flags); }
+                                                                      phi_unwritten ? 1 : 0, npx, final_it, part_pq, npq); }
+      if (!final_it) { GPA_PROF("scalar_kernels", s); phi_commit_kernel<<<dim3(1, 1, w->nprob), 1, 0, s>>>(w->flags); }
       phi_unwritten = false;
     };
     int nnorm = 0;
     for (int it = 0; it < kmax; ++it) {
-      if ((e = dispatch_rowdct_fused(w, w->q, ring, part_pq, npq, part_norm, it, &nnorm, s)) != hipSuccess) return e;
+      // (first iteration of a prepared start: the partial norms of r0 ride in the part_pq / npq arguments)
+      const bool init = it == 0 && a == nullptr;
+      if ((e = dispatch_rowdct_fused(w, w->q, ring, init ? w->part : part_pq, init ? w->prepared_parts : npq, part_norm, it,
+                                     &nnorm, init ? 1 : 0, s)) != hipSuccess) return e;
       int nrow = 0;   // partial sums of rho = <r, z>: one per column workgroup (Parseval, solve_combine)
       if ((e = dispatch_colsolve(w, compat, s, part_norm, nnorm, it, eps, part_rho, &nrow, w->r)) != hipSuccess) return e;
-      if (it > 0 && it % ring == 0) flush();   // slot it % ring still holds p of iteration it - ring
+      if (it > 0 && it % ring == 0) flush(0);   // slot it % ring still holds p of iteration it - ring
       const T* pin = (const T*)w->ring[(it + ring - 1) % ring];
       T* pout = (T*)w->ring[it % ring];
       if ((e = dispatch_rowidct_p(w, pin, pout, part_rho, nrow, it, s)) != hipSuccess) return e;
@@ -2115,9 +2153,7 @@ static hipError_t run_pcg(Impl* w, const void* a, const void* b, const void* wei
                                                                              n1, (T*)w->q, part_pq, w->scal, w->flags,
                                                                              nullptr, 0, it, band, npx); }
     }
-    { GPA_PROF("scalar_kernels", s);
-      final_alpha_kernel<<<dim3(1, 1, w->nprob), 256, 0, s>>>(w->scal, part_pq, npq, kmax, ring, w->flags); }
-    flush();
+    flush(kmax);
     return hipGetLastError();
   }
   // sizes without a fused path (no mixed-radix plan fits LDS): the Bluestein kernels, one vector update per kernel
@@ -2173,7 +2209,7 @@ hipError_t unwrap_finish(UnwrapWorkspace* ws, int* iters_out, hipStream_t s) {
   Impl* w = (Impl*)ws->impl;
   if (!w || !w->supported) return hipErrorNotSupported;
   int it = 0;
-  hipError_t e = hipMemcpyAsync(&it, w->flags, sizeof(int), hipMemcpyDeviceToHost, s);
+  hipError_t e = hipMemcpyAsync(&it, w->flags + w->iters_slot, sizeof(int), hipMemcpyDeviceToHost, s);
   if (e != hipSuccess) return e;
   e = hipStreamSynchronize(s);
   if (e != hipSuccess) return e;
@@ -2184,8 +2220,14 @@ hipError_t unwrap_finish(UnwrapWorkspace* ws, int* iters_out, hipStream_t s) {
 hipError_t unwrap_fetch_iters(UnwrapWorkspace* ws, int* host_pinned, hipStream_t s) {
   Impl* w = (Impl*)ws->impl;
   if (!w || !w->supported) return hipErrorNotSupported;
-  return hipMemcpyAsync(host_pinned, w->flags, w->nprob == 1 ? sizeof(int) : (size_t)FLAGS_N * w->nprob * sizeof(int),
-                        hipMemcpyDeviceToHost, s);
+  // one problem: its count alone; several: the flag words of all of them, the count of problem j at
+  // host_pinned[FLAGS_N * j + unwrap_iters_slot()]
+  if (w->nprob == 1) return hipMemcpyAsync(host_pinned, w->flags + w->iters_slot, sizeof(int), hipMemcpyDeviceToHost, s);
+  return hipMemcpyAsync(host_pinned, w->flags, (size_t)FLAGS_N * w->nprob * sizeof(int), hipMemcpyDeviceToHost, s);
+}
+int unwrap_iters_slot(const UnwrapWorkspace* ws) {
+  const Impl* w = (const Impl*)ws->impl;
+  return w ? w->iters_slot : 0;
 }
 
 hipError_t unwrap_run(UnwrapWorkspace* ws, const void* a, const void* b, const void* weight, bool from_psi, int kmax,

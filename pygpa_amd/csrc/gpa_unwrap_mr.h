@@ -28,8 +28,8 @@ template <class T, int MAXT, int V>
 __global__ __launch_bounds__(MAXT) void mr_rowdct_fused_kernel(
     T* __restrict__ r, const T* __restrict__ q, int n0, const MrDft d, int rs, const cpx<T>* __restrict__ W,
     const cpx<T>* __restrict__ chirp, const cpx<T>* __restrict__ bspec,
-    const cpx<T>* __restrict__ wk, const int* flags, const double* part_pq, int npq, double* part_norm, double* scal,
-    int it, int ring, size_t pimg) {
+    const cpx<T>* __restrict__ wk, int* flags, const double* part_pq, int npq, double* part_norm, double* scal,
+    int it, int ring, int init, size_t pimg) {
   {
     const size_t pb = blockIdx.z;
     r += pb * pimg;
@@ -39,9 +39,11 @@ __global__ __launch_bounds__(MAXT) void mr_rowdct_fused_kernel(
     part_pq += pb * PART_N;
     part_norm += pb * PART_N;
   }
-  if (flags[1]) return;
   extern __shared__ __attribute__((aligned(16))) char smem[];
   __shared__ double sh[32];
+  // init (first iteration of a solve on prepared residuals): part_pq / npq are the producer's partial norms of r0
+  if (init) { if (!solve_init(part_pq, npq, scal, flags, sh)) return; }
+  else if (flags[1]) return;
   const int n = d.n, Tn = d.pl.T;
   const int tid = threadIdx.x % Tn, f = threadIdx.x / Tn, nf = blockDim.x / Tn;
   cpx<T>* lds = reinterpret_cast<cpx<T>*>(smem) + (size_t)f * rs;
@@ -390,7 +392,7 @@ inline int mr_pick_nf(int pairs, int T, int cap, size_t lds_per_transform) {
 
 template <class T>
 hipError_t run_mr_rowdct_fused(const Impl* w, const void* q, int ring, const double* part_pq, int npq,
-                               double* part_norm, int it, int* nnorm, hipStream_t s) {
+                               double* part_norm, int it, int* nnorm, int init, hipStream_t s) {
   const MrDft& d = w->mr1;
   const MrPlan& pl = d.pl;
   const int rs = mr_lds_elems(pl.n), pairs = (w->n0 + 1) / 2;
@@ -401,7 +403,7 @@ hipError_t run_mr_rowdct_fused(const Impl* w, const void* q, int ring, const dou
   GPA_PROF("rowdct_fused_kernel", s);
 #define GPA_MR_ARGS                                                                                                    \
   (T*)w->r, (const T*)q, w->n0, d, rs, (const cpx<T>*)w->mrW1, (const cpx<T>*)w->chirp1, (const cpx<T>*)w->mrB1,       \
-      (const cpx<T>*)w->gwk1, w->flags, part_pq, npq, part_norm, w->scal, it, ring, (size_t)w->n0 * w->n1
+      (const cpx<T>*)w->gwk1, w->flags, part_pq, npq, part_norm, w->scal, it, ring, init, (size_t)w->n0 * w->n1
   if ((w->n1 % 4) == 0) GPA_MR_LAUNCH(mr_rowdct_fused_kernel, 4, threads, GPA_MR_ARGS);
   else GPA_MR_LAUNCH(mr_rowdct_fused_kernel, 1, threads, GPA_MR_ARGS);
 #undef GPA_MR_ARGS
