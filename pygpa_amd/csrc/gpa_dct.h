@@ -56,6 +56,16 @@ struct WgDCT {
     }
   }
 
+  // the same with w_k of the thread's bins already in registers (requested before the transform)
+  GPA_HD static void fwd_gather(cpx<T> (&x)[E], const cpx<T>* lds, int tid, const cpx<T> (&wkv)[E]) {
+#pragma unroll
+    for (int i = 0; i < E; ++i) {
+      const int k = tid + TPF * i;
+      const cpx<T> zk = lds[F::pad(k)], zm = lds[F::pad((N - k) & (N - 1))];
+      x[i] = cmul(wkv[i], zk) + cmulc(zm, wkv[i]);
+    }
+  }
+
   // ---- fused DCT-II -> per-bin scale -> DCT-III of a packed pair -------------
   // After F::forward the thread holds Z[k], k = spec_index(tid, i).
   // sequence: F::forward; barrier; solve_scatter; barrier; solve_combine; F::inverse
@@ -68,11 +78,35 @@ struct WgDCT {
   // cos + cos - 2 cancels catastrophically in f32 near the DC corner.
   template <int LS = 1>
   GPA_HD static void solve_scatter(const cpx<T> (&x)[E], cpx<T>* lds, int tid) { fwd_scatter<LS>(x, lds, tid); }
+  // the thread's table entries in registers: requested before the forward transform by kernels that are bound by
+  // their chain of memory round trips (short transforms), see solve_combine below
+  struct SolveTables { cpx<T> w[E]; T h[E], hm[E]; };
+  GPA_HD static void load_solve_tables(SolveTables& t, int tid, const cpx<T>* __restrict__ wspec,
+                                       const T* __restrict__ ha, const T* __restrict__ ham) {
+#pragma unroll
+    for (int i = 0; i < E; ++i) {
+      t.w[i] = wspec[i * TPF + tid];
+      t.h[i] = ha[i * TPF + tid];
+      t.hm[i] = ham[i * TPF + tid];
+    }
+  }
+  template <int LS = 1>
+  GPA_HD static void solve_combine(cpx<T> (&x)[E], const cpx<T>* lds, int tid, const SolveTables& tb, T hb_a, T hb_b,
+                                   bool first_a, bool first_b, T inv_n, double* rho = nullptr) {
+    solve_combine_impl<LS, true>(x, lds, tid, &tb, nullptr, nullptr, nullptr, hb_a, hb_b, first_a, first_b, inv_n, rho);
+  }
   template <int LS = 1>
   GPA_HD static void solve_combine(cpx<T> (&x)[E], const cpx<T>* lds, int tid,
                                    const cpx<T>* __restrict__ wspec, const T* __restrict__ ha,
                                    const T* __restrict__ ham, T hb_a, T hb_b, bool first_a,
                                    bool first_b, T inv_n, double* rho = nullptr) {
+    solve_combine_impl<LS, false>(x, lds, tid, nullptr, wspec, ha, ham, hb_a, hb_b, first_a, first_b, inv_n, rho);
+  }
+  template <int LS, bool REGS>
+  GPA_HD static void solve_combine_impl(cpx<T> (&x)[E], const cpx<T>* lds, int tid, const SolveTables* tb,
+                                        const cpx<T>* __restrict__ wspec, const T* __restrict__ ha,
+                                        const T* __restrict__ ham, T hb_a, T hb_b, bool first_a,
+                                        bool first_b, T inv_n, double* rho) {
     // rho (optional): this thread's share of <input, output> of the solve, summed over both packed sequences.
     // The forward / inverse transforms are unnormalised with 1/N folded into the scale, so by the DFT's
     // Parseval relation  sum_n (a za + b zb) = Re sum_k Z_in[k] conj(Z_out[k])  on the PACKED spectra -- two
@@ -87,10 +121,13 @@ struct WgDCT {
       for (int i = 0; i < E; ++i) {
         const int k = F::spec_index(tid, i);
         const cpx<T> zk = x[i], zm = lds[LS * F::pad((N - k) & (N - 1))];
-        const cpx<T> w = wspec[i * TPF + tid];
+        cpx<T> w;
+        if constexpr (REGS) w = tb->w[i]; else w = wspec[i * TPF + tid];
         const cpx<T> va = {T(0.5) * (zk.x + zm.x), T(0.5) * (zk.y - zm.y)};
         const T uax = w.x * va.x - w.y * va.y;
-        T sa = T(-0.5) * inv_n * fast_recip(ha[i * TPF + tid] + hb_a);
+        T h0;
+        if constexpr (REGS) h0 = tb->h[i]; else h0 = ha[i * TPF + tid];
+        T sa = T(-0.5) * inv_n * fast_recip(h0 + hb_a);
         if (k == 0) sa = inv_n;
         corr += (k == 0 ? T(0.5) : T(1)) * uax * uax * sa;
       }
@@ -99,8 +136,10 @@ struct WgDCT {
     for (int i = 0; i < E; ++i) {
       const int k = F::spec_index(tid, i);
       const cpx<T> zk = x[i], zm = lds[LS * F::pad((N - k) & (N - 1))];
-      const cpx<T> w = wspec[i * TPF + tid];
-      const T h = ha[i * TPF + tid], hm = ham[i * TPF + tid];
+      cpx<T> w;
+      T h, hm;
+      if constexpr (REGS) { w = tb->w[i]; h = tb->h[i]; hm = tb->hm[i]; }
+      else { w = wspec[i * TPF + tid]; h = ha[i * TPF + tid]; hm = ham[i * TPF + tid]; }
       // split the packed transform: Va = (Zk + conj Zm)/2, Vb = (Zk - conj Zm)/(2i)
       const cpx<T> va = {T(0.5) * (zk.x + zm.x), T(0.5) * (zk.y - zm.y)};
       const cpx<T> vb = {T(0.5) * (zk.y + zm.y), T(-0.5) * (zk.x - zm.x)};
@@ -135,6 +174,14 @@ struct WgDCT {
       const cpx<T> d = {x[i].x + xm[i].y, x[i].y - xm[i].x};   // X_k - i X_{N-k}
       const cpx<T> v = cmulc(d, wk[k]);                        // * conj(w_k)
       x[i] = {T(0.5) * v.x, T(-0.5) * v.y};                    // conj(V_k): IFFT = conj(FFT(conj .))
+    }
+  }
+  GPA_HD static void inv_prepare(cpx<T> (&x)[E], const cpx<T> (&xm)[E], const cpx<T> (&wkv)[E]) {
+#pragma unroll
+    for (int i = 0; i < E; ++i) {
+      const cpx<T> d = {x[i].x + xm[i].y, x[i].y - xm[i].x};   // X_k - i X_{N-k}
+      const cpx<T> v = cmulc(d, wkv[i]);                       // * conj(w_k)
+      x[i] = {T(0.5) * v.x, T(-0.5) * v.y};
     }
   }
   GPA_HD static void inv_scatter(const cpx<T> (&x)[E], cpx<T>* lds, int tid, T inv_n) {

@@ -53,6 +53,7 @@ struct Impl {
   int dtype, n0, n1, lg0, lg1;
   int nprob;                 // problems solved per launch (blockIdx.z): 1, or 2 x images of a batched driver call
   int iters_slot;            // flags[iters_slot] = iterations performed (3: fused iteration, 0: plain scheme)
+  bool lat_ok;               // latency-tuned kernel variants allowed (GPA_NO_LAT unset), read once per solve
   bool supported;
   size_t rsz;
   void *r, *p, *p2, *q, *z;   // p / p2: double-buffered search direction (= ring[0], ring[1])
@@ -116,6 +117,13 @@ __device__ __forceinline__ double block_sum(double v, double* sh) {
   return sh[16];
 }
 
+// the loads of reduce_partials() alone: a kernel requests them with all its other inputs and reduces
+// (block_sum) after its single wait
+__device__ __forceinline__ double load_partials(const double* __restrict__ part, int n) {
+  double acc = 0;
+  for (int i = threadIdx.x; i < n; i += blockDim.x) acc += part[i];
+  return acc;
+}
 // sum of n partial sums written by an EARLIER kernel, computed identically (same order) by
 // every workgroup that needs it: a consumer-side reduction that costs no launch
 __device__ __forceinline__ double reduce_partials(const double* __restrict__ part, int n, double* sh) {
@@ -468,6 +476,101 @@ __global__ __launch_bounds__(256) void pq_kernel(const T* __restrict__ z, const 
   if (threadIdx.x == 0) part[blockIdx.y * gridDim.x + blockIdx.x] = tot;
 }
 
+// The same stencil for bands of a few rows (images up to 2048^2, where pq_kernel's band is 4 rows): every row the
+// band touches -- its BAND rows, one above, one below, and the left / right neighbour pixels of the thread's
+// vector -- is requested before anything waits, so the kernel pays ONE memory round trip instead of one per row
+// of the sliding window (at 512^2 the kernel is nothing but its latency chain: 5.2 us).  Same arithmetic in the
+// same order as pq_kernel<T, true, V>: results and partial sums are bit-identical.
+template <class T, int V, int BAND>
+__global__ __launch_bounds__(256) void pq_small_kernel(const T* __restrict__ p, const T* __restrict__ w, int n0, int n1,
+                                                      T* __restrict__ q, double* part, const int* flags, size_t pimg) {
+  {
+    const size_t pb = blockIdx.z;
+    p += pb * pimg;
+    if (w) w += (pb >> 1) * pimg;   // the two components of an image share its weight
+    q += pb * pimg;
+    part += pb * PART_N;
+    flags += pb * FLAGS_N;
+  }
+  __shared__ double sh[256];
+  const int stop = flags[1];
+  const int y0 = (blockIdx.x * 256 + threadIdx.x) * V;
+  const int x0 = blockIdx.y * BAND;
+  const bool act = y0 < n1;
+  const int yc = act ? y0 : 0;
+  const bool hasl = act && y0 > 0, hasr = act && y0 + V < n1;   // (idle threads read their clamped addresses only)
+  VecN<T, V> pr[BAND + 2], wr[BAND + 2];
+  T pl[BAND], prr[BAND], wl[BAND], wrr[BAND];
+#pragma unroll
+  for (int r = 0; r < BAND + 2; ++r) {
+    int x = x0 - 1 + r;
+    x = x < 0 ? 0 : (x > n0 - 1 ? n0 - 1 : x);   // rows outside the image are loaded from a clamped address and not used
+    pr[r] = *reinterpret_cast<const VecN<T, V>*>(p + (size_t)x * n1 + yc);
+  }
+#pragma unroll
+  for (int r = 0; r < BAND; ++r) {
+    int x = x0 + r;
+    x = x > n0 - 1 ? n0 - 1 : x;
+    pl[r] = p[(size_t)x * n1 + (hasl ? yc - 1 : yc)];
+    prr[r] = p[(size_t)x * n1 + (hasr ? yc + V : yc)];
+  }
+  if (w) {
+#pragma unroll
+    for (int r = 0; r < BAND + 2; ++r) {
+      int x = x0 - 1 + r;
+      x = x < 0 ? 0 : (x > n0 - 1 ? n0 - 1 : x);
+      wr[r] = *reinterpret_cast<const VecN<T, V>*>(w + (size_t)x * n1 + yc);
+    }
+#pragma unroll
+    for (int r = 0; r < BAND; ++r) {
+      int x = x0 + r;
+      x = x > n0 - 1 ? n0 - 1 : x;
+      wl[r] = w[(size_t)x * n1 + (hasl ? yc - 1 : yc)];
+      wrr[r] = w[(size_t)x * n1 + (hasr ? yc + V : yc)];
+    }
+  } else {
+#pragma unroll
+    for (int r = 0; r < BAND + 2; ++r)
+#pragma unroll
+      for (int j = 0; j < V; ++j) wr[r].v[j] = T(1);
+#pragma unroll
+    for (int r = 0; r < BAND; ++r) wl[r] = wrr[r] = T(1);
+  }
+  if (stop) return;
+#pragma unroll
+  for (int r = 0; r < BAND + 2; ++r)
+#pragma unroll
+    for (int j = 0; j < V; ++j) wr[r].v[j] *= wr[r].v[j];
+#pragma unroll
+  for (int r = 0; r < BAND; ++r) { wl[r] *= wl[r]; wrr[r] *= wrr[r]; }
+  double pq = 0;
+#pragma unroll
+  for (int r = 0; r < BAND; ++r) {
+    const int x = x0 + r;
+    if (!act || x >= n0) continue;
+    const bool up = x > 0, dn = x + 1 < n0;
+    const VecN<T, V>&pc = pr[r + 1], &wc = wr[r + 1];
+    VecN<T, V> qv;
+#pragma unroll
+    for (int j = 0; j < V; ++j) {
+      const T c = pc.v[j], wj = wc.v[j];
+      T acc = T(0);
+      // q = sum over the 4 edges of min(w^2, w_nb^2) * (p_nb - p)   (phase_unwrap.py:118-132)
+      if (j < V - 1) { const T wn = wc.v[j + 1]; acc += (wn < wj ? wn : wj) * (pc.v[j + 1] - c); }
+      else if (hasr) acc += (wrr[r] < wj ? wrr[r] : wj) * (prr[r] - c);
+      if (j > 0) { const T wn = wc.v[j - 1]; acc += (wn < wj ? wn : wj) * (pc.v[j - 1] - c); }
+      else if (hasl) acc += (wl[r] < wj ? wl[r] : wj) * (pl[r] - c);
+      if (dn) { const T wn = wr[r + 2].v[j]; acc += (wn < wj ? wn : wj) * (pr[r + 2].v[j] - c); }
+      if (up) { const T wn = wr[r].v[j]; acc += (wn < wj ? wn : wj) * (pr[r].v[j] - c); }
+      qv.v[j] = acc;
+      pq += (double)c * (double)acc;
+    }
+    *reinterpret_cast<VecN<T, V>*>(q + (size_t)x * n1 + y0) = qv;
+  }
+  const double tot = block_sum(pq, sh);
+  if (threadIdx.x == 0) part[blockIdx.y * gridDim.x + blockIdx.x] = tot;
+}
+
 template <class T>
 __global__ __launch_bounds__(256) void update_kernel(const T* __restrict__ p, const T* __restrict__ q,
                                                     T* __restrict__ phi, T* __restrict__ r, size_t count,
@@ -555,7 +658,8 @@ struct ColGeom {
 #ifndef GPA_F64_WAVES
 #define GPA_F64_WAVES 2   // f64 row kernels: 2 waves/SIMD (256 VGPRs) beat 1 wave with AGPR spill-over
 #endif
-template <class T, int LG>
+// LAT: the latency-tuned variant (one image per call, axes up to 1024) -- same arithmetic, same results
+template <class T, int LG, bool LAT = false>
 __global__ __launch_bounds__((RowGeom<T, LG>::THREADS), (sizeof(T) == 8 ? GPA_F64_WAVES : GPA_DCTF_WAVES)) void rowdct_fused_kernel(
     T* __restrict__ r, const T* __restrict__ q, int n0, const cpx<T>* __restrict__ twtab,
     const cpx<T>* __restrict__ wk, int* flags, const double* part_pq, int npq, double* part_norm,
@@ -581,7 +685,13 @@ __global__ __launch_bounds__((RowGeom<T, LG>::THREADS), (sizeof(T) == 8 ? GPA_F6
   extern __shared__ __attribute__((aligned(16))) char smem[];
   __shared__ double sh[RowGeom<T, LG>::THREADS];
   // init (first iteration of a solve on prepared residuals): part_pq / npq are the producer's partial norms of r0
+  // EARLY (short transforms): every input of an update -- flags, q, the kept spectrum, w_k, partial sums, rho -- is
+  // requested before anything waits, so the kernel pays one memory round trip instead of five in a row
+  constexpr bool EARLY = LAT && E == 8;
+  const bool early = EARLY && it > 0;
+  int stop = 0;
   if (init) { if (!solve_init(part_pq, npq, scal, flags, sh)) return; }
+  else if (early) stop = flags[1];
   else if (flags[1]) return;
   const int tid = threadIdx.x % TPF, f = threadIdx.x / TPF;
   cpx<T>* lds = reinterpret_cast<cpx<T>*>(smem) + f * G::RS;
@@ -591,8 +701,54 @@ __global__ __launch_bounds__((RowGeom<T, LG>::THREADS), (sizeof(T) == 8 ? GPA_F6
   typename F::Twiddles tw;
   F::load_twiddles(tw, twtab, tid);
   cpx<T> x[E];
+  cpx<T> rk[E];
+  cpx<T> wkv[EARLY ? E : 1];
   T alpha = T(0);
-  if (it > 0) {
+  if (early) {
+    // up to 1024 points the even/odd-permuted DCT input is fetched directly (stride-2 accesses: these sizes are
+    // latency-, not bandwidth-bound, and the detour through LDS costs two barriers); 2048 points: 16-byte loads
+    constexpr bool DIRECTQ = LG <= 10;
+    constexpr int NQ = N / (4 * TPF);   // 16-byte vectors of q per thread and row
+    Vec4<T> qa[NQ], qb[NQ];
+    if constexpr (DIRECTQ) {
+#pragma unroll
+      for (int i = 0; i < E; ++i) {
+        const int src = makhoul_src(tid + TPF * i, N);
+        x[i] = {q[oa + src], q[ob + src]};
+      }
+    } else {
+#pragma unroll
+      for (int v = 0; v < NQ; ++v) {
+        const int c0 = 4 * (tid + TPF * v);
+        qa[v] = *reinterpret_cast<const Vec4<T>*>(q + oa + c0);
+        qb[v] = *reinterpret_cast<const Vec4<T>*>(q + ob + c0);
+      }
+    }
+#pragma unroll
+    for (int i = 0; i < E; ++i) {
+      rk[i] = {r[oa + tid + TPF * i], r[ob + tid + TPF * i]};
+      wkv[EARLY ? i : 0] = wk[tid + TPF * i];
+    }
+    const double pq_part = load_partials(part_pq, npq);
+    const double rho = scal[8 + ((it - 1) & 1)];
+    if (stop) return;
+    const double pq = block_sum(pq_part, sh);
+    const double alpha_d = rho / pq;   // phase_unwrap.py:343
+    alpha = (T)alpha_d;
+    if (blockIdx.x == 0 && threadIdx.x == 0) scal[SC_ALPHA + (it - 1) % ring] = alpha_d;
+    if constexpr (!DIRECTQ) {
+#pragma unroll
+      for (int v = 0; v < NQ; ++v) {
+        const int c0 = 4 * (tid + TPF * v);
+#pragma unroll
+        for (int j = 0; j < 4; ++j) lds[F::pad(c0 + j)] = {qa[v].v[j], qb[v].v[j]};
+      }
+      __syncthreads();
+#pragma unroll
+      for (int i = 0; i < E; ++i) x[i] = lds[F::pad(makhoul_src(tid + TPF * i, N))];
+      __syncthreads();
+    }
+  } else if (it > 0) {
     const double pq = reduce_partials(part_pq, npq, sh);
     const double alpha_d = scal[8 + ((it - 1) & 1)] / pq;   // phase_unwrap.py:343
     alpha = (T)alpha_d;
@@ -623,8 +779,7 @@ __global__ __launch_bounds__((RowGeom<T, LG>::THREADS), (sizeof(T) == 8 ? GPA_F6
 #endif
   // the kept spectrum is requested before the transform so that its latency hides behind it
   // (GPA_DCTF_LATE_RK: after it instead -- 32 registers less across the transform, one more wave per SIMD)
-  cpx<T> rk[E];
-  if (it > 0 && !GPA_DCTF_LATE_RK) {
+  if (it > 0 && !early && !GPA_DCTF_LATE_RK) {
 #pragma unroll
     for (int i = 0; i < E; ++i) rk[i] = {r[oa + tid + TPF * i], r[ob + tid + TPF * i]};
   }
@@ -632,7 +787,8 @@ __global__ __launch_bounds__((RowGeom<T, LG>::THREADS), (sizeof(T) == 8 ? GPA_F6
   __syncthreads();
   D::fwd_scatter(x, lds, tid);
   __syncthreads();
-  D::fwd_gather(x, lds, tid, wk);
+  if constexpr (EARLY) { if (early) D::fwd_gather(x, lds, tid, wkv); else D::fwd_gather(x, lds, tid, wk); }
+  else D::fwd_gather(x, lds, tid, wk);
   if (it > 0 && GPA_DCTF_LATE_RK) {
 #pragma unroll
     for (int i = 0; i < E; ++i) rk[i] = {r[oa + tid + TPF * i], r[ob + tid + TPF * i]};
@@ -715,7 +871,7 @@ __global__ void phi_commit_kernel(int* flags) {
 }
 
 // columns: Z -> DCT-II along axis 0, divide by eigenvalues, DCT-III along axis 0 (in place)
-template <class T, int LG, bool RHO>
+template <class T, int LG, bool RHO, bool LAT = false>
 __global__ __launch_bounds__((ColGeom<T, LG>::THREADS)) void colsolve_kernel(T* __restrict__ Z, int n1,
                                                                           const cpx<T>* __restrict__ twtab,
                                                                           const cpx<T>* __restrict__ wspec,
@@ -735,11 +891,15 @@ __global__ __launch_bounds__((ColGeom<T, LG>::THREADS)) void colsolve_kernel(T* 
     part_norm += pb * PART_N;
     part_rho += pb * PART_N;
   }
-  if (flags[1]) return;
   using G = ColGeom<T, LG>;
   using F = typename G::F;
   using D = typename G::D;
   constexpr int E = F::E;
+  // EARLY (short transforms): flags, tile, partial sums and scalars are requested together, the early exit and the
+  // stopping test come after that single round trip (see rowdct_fused_kernel)
+  constexpr bool EARLY = LAT && E == 8;
+  const int stopped = flags[1];
+  if (!EARLY && stopped) return;
   const T* Zsrc = Zin ? Zin : Z;   // fused path: reads the kept row spectrum of r, writes the solve to Z
   constexpr int TPF = F::TPF, N = F::L, CT = G::CT, NT = G::NT;
   extern __shared__ __attribute__((aligned(16))) char smem[];
@@ -762,13 +922,27 @@ __global__ __launch_bounds__((ColGeom<T, LG>::THREADS)) void colsolve_kernel(T* 
     for (int n = 0; n < NT; ++n) x[n][i] = q.v[n];
   }
   __shared__ double shn[ColGeom<T, LG>::THREADS];
+  // (short transforms: the solve's tables too)
+  typename D::SolveTables stb;
+  T hbv[NT][2];
+  if constexpr (EARLY) {
+    D::load_solve_tables(stb, t, wspec, ha, ham);
+#pragma unroll
+    for (int n = 0; n < NT; ++n) { hbv[n][0] = hb[yy + 2 * n]; hbv[n][1] = hb[yy + 2 * n + 1]; }
+  }
+  double norm_part = 0, best = 0, norm0 = 0;
+  if (it > 0) {
+    norm_part = load_partials(part_norm, nnorm);
+    best = scal[10 + ((it - 1) & 1)];
+    norm0 = scal[5];
+  }
+  if (EARLY && stopped) return;
   if (it > 0) {
     // (placed after the tile loads have been issued so its latency hides behind them)
     // fused path: the update of iteration it-1 was applied by this iteration's row kernel;
     // every workgroup evaluates the reference's stopping test (phase_unwrap.py:348) on it
-    const double tot = reduce_partials(part_norm, nnorm, shn);
-    const double best = scal[10 + ((it - 1) & 1)];
-    const bool stop = sqrt(tot) < eps * sqrt(scal[5]) || tot == 0.0 || !(tot == tot) || tot > 1e4 * best;
+    const double tot = block_sum(norm_part, shn);
+    const bool stop = sqrt(tot) < eps * sqrt(norm0) || tot == 0.0 || !(tot == tot) || tot > 1e4 * best;
     if (blockIdx.x == 0 && threadIdx.x == 0) {
       flags[0] = it;                                   // updates completed
       scal[6] = tot;
@@ -786,9 +960,14 @@ __global__ __launch_bounds__((ColGeom<T, LG>::THREADS)) void colsolve_kernel(T* 
   // row kernel that follows need not read r again
   double rho = 0.0;
 #pragma unroll
-  for (int n = 0; n < NT; ++n)
-    D::template solve_combine<CT>(x[n], lds + n * G::REGION, t, wspec, ha, ham, hb[yy + 2 * n], hb[yy + 2 * n + 1],
-                                  yy + 2 * n == 0, false, T(1) / T(N), RHO ? &rho : nullptr);
+  for (int n = 0; n < NT; ++n) {
+    if constexpr (EARLY)
+      D::template solve_combine<CT>(x[n], lds + n * G::REGION, t, stb, hbv[n][0], hbv[n][1], yy + 2 * n == 0, false,
+                                    T(1) / T(N), RHO ? &rho : nullptr);
+    else
+      D::template solve_combine<CT>(x[n], lds + n * G::REGION, t, wspec, ha, ham, hb[yy + 2 * n], hb[yy + 2 * n + 1],
+                                    yy + 2 * n == 0, false, T(1) / T(N), RHO ? &rho : nullptr);
+  }
   __syncthreads();
   // parked in (static) LDS; reduced after the stores, where no transform data is live any more
   if constexpr (RHO) shn[threadIdx.x] = valid ? rho : 0.0;
@@ -1111,7 +1290,7 @@ __global__ __launch_bounds__(1024) void colsolve_tri_kernel(const T* __restrict_
 // rho from the column kernel's Parseval partial sums.
 // f32, 4096-point rows: 4 waves per SIMD (<= 128 VGPRs; the unconstrained allocation takes 130 and runs at 3):
 // 49 -> 43 us.  Other lengths would spill under that cap (2048: 13 -> 16 us) and keep the default.
-template <class T, int LG>
+template <class T, int LG, bool LAT = false>
 #ifndef GPA_IDCTP_COND
 #define GPA_IDCTP_COND (sizeof(T) == 4 && LG == 12)
 #endif
@@ -1131,11 +1310,18 @@ __global__ __launch_bounds__((RowGeom<T, LG>::THREADS), (GPA_IDCTP_COND ? 4 : (s
     scal += pb * SCAL_N;
     part_rho += pb * PART_N;
   }
-  if (flags[1]) return;
+  // Every input of the kernel is requested before anything waits (one memory round trip for the flags, the
+  // spectrum, the previous search direction, the tables and the partial sums together -- a 512-point kernel is
+  // little more than its chain of dependent round trips), then the early exit, then the arithmetic.
+  const int stop = flags[1];
   using G = RowGeom<T, LG>;
   using F = typename G::F;
   using D = typename G::D;
   constexpr int TPF = F::TPF, N = F::L, E = F::E;
+  // (short transforms only: the long ones are bandwidth-bound, hide latency behind other workgroups and have no
+  //  registers to spare for 2 E more values)
+  constexpr bool EARLY = LAT && E == 8;
+  if (!EARLY && stop) return;
   extern __shared__ __attribute__((aligned(16))) char smem[];
   __shared__ double sh[RowGeom<T, LG>::THREADS];
   const int tid = threadIdx.x % TPF, f = threadIdx.x / TPF;
@@ -1145,19 +1331,25 @@ __global__ __launch_bounds__((RowGeom<T, LG>::THREADS), (GPA_IDCTP_COND ? 4 : (s
   const size_t oa = (size_t)(valid ? 2 * pr : 0) * N, ob = oa + N;
   typename F::Twiddles tw;
   F::load_twiddles(tw, twtab, tid);
-  cpx<T> x[E], xm[E];
+  cpx<T> x[E], xm[E], wkv[EARLY ? E : 1], pv[EARLY ? E : 1];
+  const bool first = it == 0;                        // first iteration: p = z (pin is uninitialised)
 #pragma unroll
   for (int i = 0; i < E; ++i) {
     const int k = tid + TPF * i;
     x[i] = {Z[oa + k], Z[ob + k]};
     xm[i] = k == 0 ? cpx<T>{T(0), T(0)} : cpx<T>{Z[oa + N - k], Z[ob + N - k]};
+    if constexpr (EARLY) {
+      wkv[i] = wk[k];
+      pv[i] = first ? cpx<T>{T(0), T(0)} : cpx<T>{pin[oa + k], pin[ob + k]};
+    }
   }
-  // (after the loads have been issued so its latency hides behind them)
-  const double rho = reduce_partials(part_rho, nrho, sh);
-  const bool first = it == 0;                        // first iteration: p = z (pin is uninitialised)
-  const T beta = first ? T(0) : (T)(rho / scal[8 + ((it - 1) & 1)]);
+  const double rho_part = load_partials(part_rho, nrho);
+  const double rho_prev = scal[8 + ((it - 1) & 1)];
+  if (stop) return;
+  const double rho = block_sum(rho_part, sh);
+  const T beta = first ? T(0) : (T)(rho / rho_prev);
   if (blockIdx.x == 0 && threadIdx.x == 0) scal[8 + (it & 1)] = rho;
-  D::inv_prepare(x, xm, tid, wk);
+  if constexpr (EARLY) D::inv_prepare(x, xm, wkv); else D::inv_prepare(x, xm, tid, wk);
   F::forward(x, lds, tid, tw);
   __syncthreads();
   D::inv_scatter(x, lds, tid, T(1) / T(N));
@@ -1169,8 +1361,13 @@ __global__ __launch_bounds__((RowGeom<T, LG>::THREADS), (GPA_IDCTP_COND ? 4 : (s
     const int c = tid + TPF * i;
     T pa = x[i].x, pb = x[i].y;
     if (!first) {
-      pa += beta * pin[oa + c];
-      pb += beta * pin[ob + c];
+      if constexpr (EARLY) {
+        pa += beta * pv[i].x;
+        pb += beta * pv[i].y;
+      } else {
+        pa += beta * pin[oa + c];
+        pb += beta * pin[ob + c];
+      }
     }
     pout[oa + c] = pa;
     pout[ob + c] = pb;
@@ -1483,6 +1680,20 @@ __global__ __launch_bounds__(256) void per_combine_kernel(const cpx<T>* __restri
 
 #define GPA_FOR_LG(X) X(6) X(7) X(8) X(9) X(10) X(11) X(12) X(13) X(14)
 
+// One image per call and axes up to 1024: the fused kernels are bound by their chains of dependent memory round
+// trips, not by bandwidth or occupancy, and run as latency-tuned instantiations (every input requested before the
+// first wait: ~30 more registers).  Stacks of frames and larger images fill the GPU and keep the lean ones
+// (measured: 64 frames of 512^2 2596 -> 2475 Mpix/s and 2048^2 2565 -> 2493 with the latency-tuned kernels).
+// The two kinds evaluate the same formulas; the compiler contracts multiply-adds differently in places, so results
+// agree to rounding, not to the bit (GPA_NO_LAT=1 runs the lean kernels everywhere: tests use it to compare a stack
+// with single calls exactly).
+#ifndef GPA_UNWRAP_LAT_MAXLG
+#define GPA_UNWRAP_LAT_MAXLG 10
+#endif
+static bool unwrap_latency_tuned(const Impl* w, int lg) {
+  return w->lat_ok && w->nprob <= 2 && lg <= GPA_UNWRAP_LAT_MAXLG;
+}
+
 // mixed-radix fused kernels (gpa_unwrap_mr.h, included below)
 template <class T>
 hipError_t run_mr_rowdct_fused(const Impl* w, const void* q, int ring, const double* part_pq, int npq,
@@ -1502,9 +1713,11 @@ hipError_t run_colsolve(const Impl* w, int compat, hipStream_t s, const double* 
   if constexpr (!G::FITS) return hipErrorInvalidValue;
   else {
     if (!part_rho) return hipErrorInvalidValue;   // (the only caller is the fused iteration)
-    auto kern = colsolve_kernel<T, LG, true>;
-    static unsigned lds_set = 0;
-    hipError_t e = set_dynamic_lds_once(reinterpret_cast<const void*>(kern), (int)G::LDS_BYTES, lds_set);
+    const bool lat = unwrap_latency_tuned(w, LG);
+    auto kern = colsolve_kernel<T, LG, true, false>;
+    if constexpr (LG <= GPA_UNWRAP_LAT_MAXLG) { if (lat) kern = colsolve_kernel<T, LG, true, true>; }
+    static unsigned lds_set[2] = {0, 0};   // one flag word per instantiation
+    hipError_t e = set_dynamic_lds_once(reinterpret_cast<const void*>(kern), (int)G::LDS_BYTES, lds_set[lat ? 1 : 0]);
     if (e != hipSuccess) return e;
     const int npairs = w->n1 / 2, grid = (npairs + G::CC - 1) / G::CC;
     if (nrho) *nrho = grid;
@@ -1522,9 +1735,11 @@ hipError_t run_rowdct_fused(const Impl* w, const void* q, int ring, const double
   using G = RowGeom<T, LG>;
   if constexpr (!G::FITS) return hipErrorInvalidValue;
   else {
-    auto kern = rowdct_fused_kernel<T, LG>;
-    static unsigned lds_set = 0;
-    hipError_t e = set_dynamic_lds_once(reinterpret_cast<const void*>(kern), (int)G::LDS_BYTES, lds_set);
+    const bool lat = unwrap_latency_tuned(w, LG);
+    auto kern = rowdct_fused_kernel<T, LG, false>;
+    if constexpr (LG <= GPA_UNWRAP_LAT_MAXLG) { if (lat) kern = rowdct_fused_kernel<T, LG, true>; }
+    static unsigned lds_set[2] = {0, 0};   // one flag word per instantiation
+    hipError_t e = set_dynamic_lds_once(reinterpret_cast<const void*>(kern), (int)G::LDS_BYTES, lds_set[lat ? 1 : 0]);
     if (e != hipSuccess) return e;
     const int npairs = w->n0 / 2, grid = (npairs + G::NF - 1) / G::NF;
     *nnorm = grid;
@@ -1542,9 +1757,11 @@ hipError_t run_rowidct_p(const Impl* w, const void* pin, void* pout, const doubl
   using G = RowGeom<T, LG>;
   if constexpr (!G::FITS) return hipErrorInvalidValue;
   else {
-    auto kern = rowidct_p_kernel<T, LG>;
-    static unsigned lds_set = 0;
-    hipError_t e = set_dynamic_lds_once(reinterpret_cast<const void*>(kern), (int)G::LDS_BYTES, lds_set);
+    const bool lat = unwrap_latency_tuned(w, LG);
+    auto kern = rowidct_p_kernel<T, LG, false>;
+    if constexpr (LG <= GPA_UNWRAP_LAT_MAXLG) { if (lat) kern = rowidct_p_kernel<T, LG, true>; }
+    static unsigned lds_set[2] = {0, 0};   // one flag word per instantiation
+    hipError_t e = set_dynamic_lds_once(reinterpret_cast<const void*>(kern), (int)G::LDS_BYTES, lds_set[lat ? 1 : 0]);
     if (e != hipSuccess) return e;
     const int npairs = w->n0 / 2, grid = (npairs + G::NF - 1) / G::NF;
     GPA_PROF("rowidct_p_kernel", s);
@@ -2056,6 +2273,7 @@ static hipError_t run_pcg(Impl* w, const void* a, const void* b, const void* wei
   {
     const char* mode = getenv("GPA_COLSOLVE");   // once per solve, not per launch (environment lookups cost host time)
     w->col_mode = !mode ? 0 : (mode[0] == 't' ? 1 : 2);
+    w->lat_ok = getenv("GPA_NO_LAT") == nullptr;
   }
   const int g2 = n0, np2 = n0;   // stencil kernels: one workgroup per image row
   if (np2 > MAXPART) return hipErrorInvalidValue;
@@ -2144,7 +2362,14 @@ static hipError_t run_pcg(Impl* w, const void* a, const void* b, const void* wei
       T* pout = (T*)w->ring[it % ring];
       if ((e = dispatch_rowidct_p(w, pin, pout, part_rho, nrow, it, s)) != hipSuccess) return e;
       { GPA_PROF("pq_kernel", s);
-        if (V == 4)
+        if (band == 4 && w->lat_ok && w->nprob <= 2 && npx <= ((size_t)1 << 20)) {
+          if (V == 4)
+            pq_small_kernel<T, 4, 4><<<dim3(gpq.x, gpq.y, w->nprob), 256, 0, s>>>(pout, (const T*)weight, n0, n1, (T*)w->q,
+                                                                                 part_pq, w->flags, npx);
+          else
+            pq_small_kernel<T, 1, 4><<<dim3(gpq.x, gpq.y, w->nprob), 256, 0, s>>>(pout, (const T*)weight, n0, n1, (T*)w->q,
+                                                                                 part_pq, w->flags, npx);
+        } else if (V == 4)
           pq_kernel<T, true, 4><<<dim3(gpq.x, gpq.y, w->nprob), 256, 0, s>>>(pout, nullptr, nullptr, (const T*)weight, n0,
                                                                              n1, (T*)w->q, part_pq, w->scal, w->flags,
                                                                              nullptr, 0, it, band, npx);

@@ -1178,10 +1178,14 @@ def test_chirpz_forced_on_smooth_lengths(monkeypatch):
 @pytest.mark.gpu
 @pytest.mark.parametrize('dtype', DTYPES)
 @pytest.mark.parametrize('shape', [(128, 128), (256, 512), (100, 60), (300, 300), (136, 116), (63, 65), (250, 250)])
-def test_image_stack_equals_single_images(shape, dtype):
+def test_image_stack_equals_single_images(shape, dtype, monkeypatch):
     """gpa_extract_displacement_field_batch_dev: a stack of images through one set of unwrap launches
     (blockIdx.z = problem) -- every image's u and iteration counts equal the single-image driver's bit for bit
-    (power-of-two, smooth, square smooth with transform-free columns, chirp-z sizes)"""
+    (power-of-two, smooth, square smooth with transform-free columns, chirp-z sizes).  Bit for bit with the same
+    kernels on both sides (GPA_NO_LAT=1: a single small power-of-two image otherwise runs latency-tuned
+    instantiations of the row / column kernels, whose multiply-adds the compiler contracts differently); with the
+    default kernels: to rounding, 1e-5 (f32) / 1e-12 (f64) of max |u|, and the same iteration counts."""
+    monkeypatch.setenv('GPA_NO_LAT', '1')
     kvecs = hex_kvecs(0.12, 5.0)
     sigma = 5
     klists = np.stack(explicit_klists(kvecs, 0.04, 2, 2))
@@ -1201,14 +1205,23 @@ def test_image_stack_equals_single_images(shape, dtype):
     # chunks of 2 frames (2 + 2 + 1) through the double-buffered upload / compute / download pipeline
     u_c, it_c = plan.extract_displacement_field_stack(imgs, kvecs, klists, sigma, 2 * sigma, kmax=10, chunk=2)
     assert np.array_equal(u_c, u_b) and np.array_equal(it_c, it_b)
+    # default kernels for the single image
+    monkeypatch.delenv('GPA_NO_LAT')
+    tol = (1e-5 if dtype == np.float32 else 1e-12) * float(np.abs(u_b).max())
+    for i in range(B):
+        u, _, _, iters = plan.extract_displacement_field(imgs[i], kvecs, klists, sigma, 2 * sigma, kmax=10)
+        assert float(np.abs(u_b[i] - u).max()) <= tol, (shape, i, float(np.abs(u_b[i] - u).max()), tol)
+        assert tuple(it_b[i]) == tuple(iters), (shape, i)
     plan.close()
 
 
 @pytest.mark.gpu
-def test_random_stacks_equal_single_images():
-    """seeded random (shape, stack size, precision) draws -- any parity of the sides, power-of-two, smooth and chirp-z
+def test_random_stacks_equal_single_images(monkeypatch):
+    """(GPA_NO_LAT=1: the same kernels for a stack and for a single image, see test_image_stack_equals_single_images)
+    seeded random (shape, stack size, precision) draws -- any parity of the sides, power-of-two, smooth and chirp-z
     lengths mixed -- the stack call equals the single-image driver frame for frame, bit for bit.
     GPA_TEST_RANDOM_CASES / GPA_TEST_RANDOM_SEED widen the sweep."""
+    monkeypatch.setenv('GPA_NO_LAT', '1')
     rng = np.random.default_rng(int(os.environ.get('GPA_TEST_RANDOM_SEED', '5')))
     want = max(4, int(os.environ.get('GPA_TEST_RANDOM_CASES', '10')) // 2)
     sizes = [32, 48, 60, 63, 64, 65, 68, 75, 96, 100, 116, 128, 130, 160, 250, 256]
