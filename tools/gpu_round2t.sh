@@ -1,7 +1,8 @@
 #!/bin/bash
 # round 2, closing pass: whole GPU suite, bench line, kernel stats, PMC passes -> counters; kernel stats of a 3000^2 run
+ulimit -c 0
 out=gpurun_out/r2t; mkdir -p $out
-python -m pytest tests -q -m gpu -x --durations=12 > $out/pytest_gpu.log 2>&1
+timeout 1200 python -m pytest tests -q -m gpu -x --durations=12 > $out/pytest_gpu.log 2>&1
 tail -22 $out/pytest_gpu.log
 python __graft_entry__.py smoke 2>&1 | tail -1
 python bench.py > $out/bench.json 2> $out/bench.err; tail -3 $out/bench.err; cat $out/bench.json
