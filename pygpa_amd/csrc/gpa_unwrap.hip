@@ -67,7 +67,7 @@ struct Impl {
   void *hb1[2];              // 1 - cos term of axis-1 bins (natural); [compat]
   int col_mode;              // GPA_COLSOLVE of the current solve: 0 default, 1 tri, 2 fft (read once per solve)
   void* tritab;              // TriCol per column (square images): transform-free column solve
-  int triQ, triS;            // its launch geometry, fixed when the table is built (the table depends on it)
+  int triQ, triS, triR;      // its launch geometry, fixed when the table is built (the table depends on it)
   double* scal;              // 8 doubles
   int* flags;                // [0] = iteration count, [1] = done
   double* part;              // 3 * MAXPART partial sums
@@ -1024,6 +1024,14 @@ struct TriCol {
 // rows per thread: the f32 tile of a thread (ROWS x 4 columns) has to leave room for the double-precision recursions
 // within the 128 VGPRs that 1024 threads per workgroup allow: 8 rows (32 registers); f64: 16 rows x 2 columns (64)
 template <class T> struct TriRows { static constexpr int value = sizeof(T) == 4 ? 8 : 16; };
+// Short columns take half as many rows per thread on twice the threads: with ~125 one-wavefront workgroups on 256
+// CUs the kernel is bound by the instruction stream of a wavefront (4089 instructions at 8 rows x 4 columns, a
+// quarter of them f64), not by anything the chip shares.  GPA_TRI_SMALL = largest n0 that does (diagnostic).
+inline int tri_rows(size_t real_size, int n0) {
+  const int base = real_size == 4 ? 8 : 16;
+  static const int small = getenv("GPA_TRI_SMALL") ? atoi(getenv("GPA_TRI_SMALL")) : 640;
+  return n0 <= small ? base / 2 : base;
+}
 
 // scan x_s = v_s + m x_(s-1) over the S chunks of every column (REVERSE: from the last chunk down).  Threads are
 // laid out chunk-major with Q threads side by side, so a wavefront holds 64 / Q consecutive chunks of its Q column
@@ -1784,8 +1792,8 @@ hipError_t dispatch_rowidct_p(const Impl* w, const void* pin, void* pout, const 
 // threads side by side along a row (Q), chunks per workgroup (S, padded to whole wavefronts when there are several)
 // and the rows of padding that geometry implies -- shared by the launcher and by the table builder
 template <class T>
-void tri_geometry(int n0, int n1, bool ragged, int* Q_out, int* S_out, int* pad_out) {
-  constexpr int VEC = 16 / sizeof(T), R = TriRows<T>::value;
+void tri_geometry(int n0, int n1, bool ragged, int R, int* Q_out, int* S_out, int* pad_out) {
+  constexpr int VEC = 16 / sizeof(T);
   int S = (n0 + R - 1) / R;
   int Q = 4;
   // (workgroups wanted at least: 256 on the power-of-two path as tuned in round 2; the ragged sizes measured faster
@@ -1806,10 +1814,9 @@ void tri_geometry(int n0, int n1, bool ragged, int* Q_out, int* S_out, int* pad_
   *pad_out = S * R - n0;
 }
 
-template <class T, int VEC, int Q>
+template <class T, int VEC, int Q, int R>
 hipError_t run_colsolve_tri(const Impl* w, int S, int compat, hipStream_t s, const double* part_norm, int nnorm, int it,
                             double eps, double* part_rho, int* nrho, const void* zin) {
-  constexpr int R = TriRows<T>::value;
   const bool ragged = w->generic;
   const int threads = S * Q, grid = (w->n1 + Q * VEC - 1) / (Q * VEC);
   const size_t lds = (size_t)16 * Q * VEC * sizeof(double);
@@ -1839,13 +1846,22 @@ hipError_t run_colsolve_tri(const Impl* w, int S, int compat, hipStream_t s, con
 template <class T>
 hipError_t dispatch_colsolve_tri(const Impl* w, int compat, hipStream_t s, const double* part_norm, int nnorm, int it,
                                  double eps, double* part_rho, int* nrho, const void* zin) {
-  constexpr int VEC = 16 / sizeof(T);
+  constexpr int VEC = 16 / sizeof(T), RB = TriRows<T>::value;
   const int Q = w->triQ, S = w->triS;
-  switch (Q) {
-    case 4: return run_colsolve_tri<T, VEC, 4>(w, S, compat, s, part_norm, nnorm, it, eps, part_rho, nrho, zin);
-    case 2: return run_colsolve_tri<T, VEC, 2>(w, S, compat, s, part_norm, nnorm, it, eps, part_rho, nrho, zin);
-    default: return run_colsolve_tri<T, VEC, 1>(w, S, compat, s, part_norm, nnorm, it, eps, part_rho, nrho, zin);
+#define GPA_TRI_CALL(QQ, RR) run_colsolve_tri<T, VEC, QQ, RR>(w, S, compat, s, part_norm, nnorm, it, eps, part_rho, nrho, zin)
+  if (w->triR == RB) {
+    switch (Q) {
+      case 4: return GPA_TRI_CALL(4, RB);
+      case 2: return GPA_TRI_CALL(2, RB);
+      default: return GPA_TRI_CALL(1, RB);
+    }
   }
+  switch (Q) {
+    case 4: return GPA_TRI_CALL(4, RB / 2);
+    case 2: return GPA_TRI_CALL(2, RB / 2);
+    default: return GPA_TRI_CALL(1, RB / 2);
+  }
+#undef GPA_TRI_CALL
 }
 
 hipError_t dispatch_colsolve(const Impl* w, int compat, hipStream_t s, const double* part_norm = nullptr,
@@ -1865,7 +1881,7 @@ hipError_t dispatch_colsolve(const Impl* w, int compat, hipStream_t s, const dou
   // spill), f32 82 us per launch against 68 -- the f32 DCT kernel is the faster one.  So: f64 by default,
   // GPA_COLSOLVE=tri / fft forces one or the other (tests compare the two).
   const bool want_tri = w->col_mode ? w->col_mode == 1 : w->dtype != 0;
-  if (w->tritab && part_rho && want_tri && w->n0 / (w->dtype == 0 ? TriRows<float>::value : TriRows<double>::value) <= 1024)
+  if (w->tritab && part_rho && want_tri && w->n0 / w->triR <= 1024)
     return w->dtype == 0 ? dispatch_colsolve_tri<float>(w, compat, s, part_norm, nnorm, it, eps, part_rho, nrho, zin)
                          : dispatch_colsolve_tri<double>(w, compat, s, part_norm, nnorm, it, eps, part_rho, nrho, zin);
 #define CASE(LG) case LG: return w->dtype == 0 ? run_colsolve<float, LG>(w, compat, s, part_norm, nnorm, it, eps, part_rho, nrho, zin) \
@@ -2014,12 +2030,13 @@ int ilog2_exact(int n) {
 hipError_t build_tritab(Impl* w, hipStream_t s, size_t* bytes) {
   const int n0 = w->n0, n1 = w->n1;
   int Q, S, pad;
-  if (w->dtype == 0) tri_geometry<float>(n0, n1, w->generic, &Q, &S, &pad);
-  else tri_geometry<double>(n0, n1, w->generic, &Q, &S, &pad);
+  const int R = tri_rows(w->rsz, n0);
+  if (w->dtype == 0) tri_geometry<float>(n0, n1, w->generic, R, &Q, &S, &pad);
+  else tri_geometry<double>(n0, n1, w->generic, R, &Q, &S, &pad);
   if (S * Q > 1024 || n1 % (w->dtype == 0 ? 4 : 2)) return hipSuccess;   // (16-byte column vectors)
   w->triQ = Q;
   w->triS = S;
-  const int R = w->dtype == 0 ? TriRows<float>::value : TriRows<double>::value;
+  w->triR = R;
   std::vector<TriCol> tc((size_t)n1);
   for (int j = 0; j < n1; ++j) {
     if (j == 0) { tc[0] = {1.0, 1.0, 1.0, 0.0, 0.0}; continue; }
