@@ -73,8 +73,23 @@ __global__ __launch_bounds__(256) void merge_parts_kernel(const cpx<T>* __restri
   const size_t o = ((size_t)p * n0 + x) * n1 + y, slab = (size_t)P * n0 * n1;
   cpx<T> best = {T(0), T(0)};
   int bi = -1;
-  for (int z = 0; z < S; ++z) {
+  // the first four slabs (all there are today) are requested together: a loop of load -> compare pays one memory
+  // round trip per slab, and this kernel runs where nothing hides them (small images)
+  cpx<T> v4[4];
+  int i4[4];
+#pragma unroll
+  for (int z = 0; z < 4; ++z) {
+    const size_t zo = (size_t)(z < S ? z : 0) * slab + o;
+    v4[z] = part[zo];
+    i4[z] = pidx[zo];
+  }
+#pragma unroll
+  for (int z = 0; z < 4; ++z) {
     // slabs hold increasing candidate ranges: the sequential rule "strictly larger replaces" carries over
+    const T a = v4[z].x * v4[z].x + v4[z].y * v4[z].y, ab = best.x * best.x + best.y * best.y;
+    if (z < S && i4[z] >= 0 && a > ab) { best = v4[z]; bi = i4[z]; }
+  }
+  for (int z = 4; z < S; ++z) {
     const cpx<T> v = part[(size_t)z * slab + o];
     const T a = v.x * v.x + v.y * v.y, ab = best.x * best.x + best.y * best.y;
     const int vi = pidx[(size_t)z * slab + o];
