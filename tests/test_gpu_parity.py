@@ -1245,3 +1245,27 @@ def test_random_stacks_equal_single_images(monkeypatch):
             u, _, _, iters = plan.extract_displacement_field(imgs[i], kvecs, klists, sigma, 2 * sigma, kmax=10, want_kidx=True)
             assert np.array_equal(u_b[i], u), (shape, np.dtype(dtype).name, B, i)
             assert tuple(it_b[i]) == tuple(iters), (shape, B, i)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize('dtype', DTYPES)
+@pytest.mark.parametrize('n', [256, 512, 1024])
+def test_latency_tuned_kernels_equal_lean_kernels(n, dtype, monkeypatch):
+    """One image up to 1024^2 runs latency-tuned instantiations of the fused PCG kernels (every input requested before
+    the first wait; pq_small_kernel instead of the sliding-window stencil); stacks and larger images run the lean ones.
+    Same formulas: the driver's u agrees to rounding (1e-5 / 1e-12 of max |u|) with the same iteration counts, and both
+    hold the oracle's bar of test_driver_vs_oracle_512 indirectly through it."""
+    shape = (n, n)
+    kvecs = hex_kvecs(0.1, 7.0)
+    sigma = 6
+    klists = np.stack(explicit_klists(kvecs, 0.03, 2, 2))
+    img = hex_moire(shape, kvecs, 0.5 * gaussian_bump_displacement(shape), noise=0.1, seed=3)
+    plan = _lib.Plan(shape, 12, dtype)
+    u_lat, _, _, it_lat = plan.extract_displacement_field(img, kvecs, klists, sigma, 2 * sigma, kmax=10)
+    monkeypatch.setenv('GPA_NO_LAT', '1')
+    u_lean, _, _, it_lean = plan.extract_displacement_field(img, kvecs, klists, sigma, 2 * sigma, kmax=10)
+    monkeypatch.delenv('GPA_NO_LAT')
+    assert tuple(it_lat) == tuple(it_lean)
+    tol = (1e-5 if dtype == np.float32 else 1e-12) * float(np.abs(u_lean).max())
+    assert float(np.abs(u_lat - u_lean).max()) <= tol
+    plan.close()
