@@ -256,7 +256,7 @@ def single_gpu(args):
     models = kernel_models(n, n, L0, L1, P, K, Bx, s, iters)
     counters = load_counters()
     work = {'rowdct_fused_kernel': sum(iters), 'rowidct_p_kernel': sum(iters), 'pq_kernel': sum(iters),
-            'colsolve_kernel': sum(iters)}   # launches that do work (those after convergence return at once)
+            'rowidct_pq_kernel': sum(iters), 'colsolve_kernel': sum(iters)}   # launches that do work (those after convergence return at once)
     table = {}
     for name, (calls, ms) in kern.items():
         m = models.get(name, {})

@@ -1382,6 +1382,145 @@ __global__ __launch_bounds__((RowGeom<T, LG>::THREADS), (GPA_IDCTP_COND ? 4 : (s
   }
 }
 
+// One image, rows of at most 512 pixels: rowidct_p_kernel and the stencil kernel in ONE launch.  At these sizes a
+// launch costs more than the work of either (an empty kernel: 3.6 us; the stencil kernel: 4.0), so the row kernel
+// also transforms the row pair above and the one below its own NF pairs, keeps all 2 NF + 4 rows of the new search
+// direction in LDS and applies q = A^T W^2 A p to its own rows there.  (NF + 2) / NF of the transforms instead of one
+// more launch per iteration; the GPU is far from full at these sizes.  Same formulas as the two kernels.
+#define GPA_ROWPQ_MAXLG 9
+template <class T, int LG>
+struct RowPqGeom {
+  using G = RowGeom<T, LG>;
+  static constexpr int NFH = G::NF + 2;                       // transform groups: own pairs + one halo pair each side
+  static constexpr int THREADS = NFH * G::F::TPF;
+  static constexpr size_t FFT_BYTES = (size_t)NFH * G::RS * sizeof(cpx<T>);
+  static constexpr int PROWS = 2 * NFH;                       // rows of p kept for the stencil
+  static constexpr int PPITCH = G::F::L + 4;                  // (a pad of 4 keeps 16-byte row alignment)
+  static constexpr size_t LDS_BYTES = FFT_BYTES + (size_t)PROWS * PPITCH * sizeof(T);
+};
+template <class T, int LG>
+__global__ __launch_bounds__((RowPqGeom<T, LG>::THREADS)) void rowidct_pq_kernel(
+    const T* __restrict__ Z, const T* __restrict__ pin, T* __restrict__ pout, const T* __restrict__ wgt,
+    T* __restrict__ q, int n0, const cpx<T>* __restrict__ twtab, const cpx<T>* __restrict__ wk, const int* flags,
+    const double* part_rho, int nrho, double* part_pq, double* scal, int it, size_t pimg) {
+  {
+    const size_t pb = blockIdx.z;
+    Z += pb * pimg;
+    pin += pb * pimg;
+    pout += pb * pimg;
+    q += pb * pimg;
+    if (wgt) wgt += (pb >> 1) * pimg;   // the two components of an image share its weight
+    flags += pb * FLAGS_N;
+    scal += pb * SCAL_N;
+    part_rho += pb * PART_N;
+    part_pq += pb * PART_N;
+  }
+  using G = RowGeom<T, LG>;
+  using H = RowPqGeom<T, LG>;
+  using F = typename G::F;
+  using D = typename G::D;
+  constexpr int TPF = F::TPF, N = F::L, E = F::E, NF = G::NF;
+  static_assert(E == 8, "latency-tuned kernels use the 8-element transforms");
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  __shared__ double sh[H::THREADS];
+  const int stop = flags[1];
+  const int tid = threadIdx.x % TPF, f = threadIdx.x / TPF;
+  cpx<T>* lds = reinterpret_cast<cpx<T>*>(smem) + f * G::RS;
+  T* prow = reinterpret_cast<T*>(smem + H::FFT_BYTES);
+  const int npairs = n0 / 2;
+  const int pr = (int)blockIdx.x * NF + f - 1;        // group 0 / NF + 1: the halo pairs
+  const bool valid = pr >= 0 && pr < npairs;
+  const bool own = valid && f >= 1 && f <= NF;
+  const size_t oa = (size_t)(valid ? 2 * pr : 0) * N, ob = oa + N;
+  typename F::Twiddles tw;
+  F::load_twiddles(tw, twtab, tid);
+  cpx<T> x[E], xm[E], wkv[E], pv[E];
+  const bool first = it == 0;
+#pragma unroll
+  for (int i = 0; i < E; ++i) {
+    const int k = tid + TPF * i;
+    x[i] = {Z[oa + k], Z[ob + k]};
+    xm[i] = k == 0 ? cpx<T>{T(0), T(0)} : cpx<T>{Z[oa + N - k], Z[ob + N - k]};
+    wkv[i] = wk[k];
+    pv[i] = first ? cpx<T>{T(0), T(0)} : cpx<T>{pin[oa + k], pin[ob + k]};
+  }
+  const double rho_part = load_partials(part_rho, nrho);
+  const double rho_prev = scal[8 + ((it - 1) & 1)];
+  if (stop) return;
+  const double rho = block_sum(rho_part, sh);
+  const T beta = first ? T(0) : (T)(rho / rho_prev);
+  if (blockIdx.x == 0 && threadIdx.x == 0) scal[8 + (it & 1)] = rho;
+  D::inv_prepare(x, xm, wkv);
+  F::forward(x, lds, tid, tw);
+  __syncthreads();
+  D::inv_scatter(x, lds, tid, T(1) / T(N));
+  __syncthreads();
+  D::inv_gather(x, lds, tid);
+#pragma unroll
+  for (int i = 0; i < E; ++i) {
+    const int c = tid + TPF * i;
+    T pa = x[i].x, pb = x[i].y;
+    if (!first) {
+      pa += beta * pv[i].x;
+      pb += beta * pv[i].y;
+    }
+    if (own) {
+      pout[oa + c] = pa;
+      pout[ob + c] = pb;
+    }
+    prow[(2 * f) * H::PPITCH + c] = pa;
+    prow[(2 * f + 1) * H::PPITCH + c] = pb;
+  }
+  __syncthreads();
+  // ---- q = A^T W^2 A p on the 2 NF own rows, 4 pixels per item (as pq_kernel: min of the squared weights per edge)
+  const int xbase = 2 * (int)blockIdx.x * NF;                // first own image row; LDS row of image row x: x - xbase + 2
+  constexpr int VPR = N / 4;                                  // 4-pixel items per row
+  double pq = 0;
+  for (int item = threadIdx.x; item < 2 * NF * VPR; item += H::THREADS) {
+    const int rl = item / VPR, c0 = (item % VPR) * 4;
+    const int xg = xbase + rl;
+    if (xg >= n0) continue;
+    const bool up = xg > 0, dn = xg + 1 < n0, hasl = c0 > 0, hasr = c0 + 4 < N;
+    const T* pc = prow + (rl + 2) * H::PPITCH + c0;
+    const Vec4<T> vc = *reinterpret_cast<const Vec4<T>*>(pc);
+    const Vec4<T> vu = *reinterpret_cast<const Vec4<T>*>(pc - H::PPITCH), vd = *reinterpret_cast<const Vec4<T>*>(pc + H::PPITCH);
+    const T pl = hasl ? pc[-1] : T(0), prr = hasr ? pc[4] : T(0);
+    Vec4<T> wc, wu, wd;
+    T wl = T(1), wr = T(1);
+#pragma unroll
+    for (int j = 0; j < 4; ++j) wc.v[j] = wu.v[j] = wd.v[j] = T(1);
+    if (wgt) {
+      const T* wp = wgt + (size_t)xg * N + c0;
+      wc = *reinterpret_cast<const Vec4<T>*>(wp);
+      wu = *reinterpret_cast<const Vec4<T>*>(up ? wp - N : wp);
+      wd = *reinterpret_cast<const Vec4<T>*>(dn ? wp + N : wp);
+      wl = hasl ? wp[-1] : T(1);
+      wr = hasr ? wp[4] : T(1);
+#pragma unroll
+      for (int j = 0; j < 4; ++j) { wc.v[j] *= wc.v[j]; wu.v[j] *= wu.v[j]; wd.v[j] *= wd.v[j]; }
+      wl *= wl;
+      wr *= wr;
+    }
+    Vec4<T> qv;
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      const T c = vc.v[j], wj = wc.v[j];
+      T acc = T(0);
+      if (j < 3) { const T wn = wc.v[j + 1]; acc += (wn < wj ? wn : wj) * (vc.v[j + 1] - c); }
+      else if (hasr) acc += (wr < wj ? wr : wj) * (prr - c);
+      if (j > 0) { const T wn = wc.v[j - 1]; acc += (wn < wj ? wn : wj) * (vc.v[j - 1] - c); }
+      else if (hasl) acc += (wl < wj ? wl : wj) * (pl - c);
+      if (dn) { const T wn = wd.v[j]; acc += (wn < wj ? wn : wj) * (vd.v[j] - c); }
+      if (up) { const T wn = wu.v[j]; acc += (wn < wj ? wn : wj) * (vu.v[j] - c); }
+      qv.v[j] = acc;
+      pq += (double)c * (double)acc;
+    }
+    *reinterpret_cast<Vec4<T>*>(q + (size_t)xg * N + c0) = qv;
+  }
+  const double tot = block_sum(pq, sh);
+  if (threadIdx.x == 0) part_pq[blockIdx.x] = tot;
+}
+
 // ---------------------------------------------------------------------------
 // generic-size DCT kernels (Bluestein).  Same data flow as the power-of-two kernels,
 // everything in the natural layout; 4 FFTs of length L >= 2n-1 per column instead of 2 of
@@ -1777,6 +1916,36 @@ hipError_t run_rowidct_p(const Impl* w, const void* pin, void* pout, const doubl
                                                  (const cpx<T>*)w->wk1, w->flags, part_rho, nrho, w->scal, it, (size_t)w->n0 * w->n1);
     return hipGetLastError();
   }
+}
+// the row kernel and the stencil in one launch (one image, rows up to 512 pixels); *npq_out = partial sums of <p, q>
+template <class T, int LG>
+hipError_t run_rowidct_pq(const Impl* w, const void* pin, void* pout, const void* weight, const double* part_rho,
+                          int nrho, double* part_pq, int* npq_out, int it, hipStream_t s) {
+  if constexpr (LG > GPA_ROWPQ_MAXLG || unwrap_elems(LG, sizeof(T)) != 8) return hipErrorInvalidValue;
+  else {
+    using G = RowGeom<T, LG>;
+    using H = RowPqGeom<T, LG>;
+    auto kern = rowidct_pq_kernel<T, LG>;
+    static unsigned lds_set = 0;
+    hipError_t e = set_dynamic_lds_once(reinterpret_cast<const void*>(kern), (int)H::LDS_BYTES, lds_set);
+    if (e != hipSuccess) return e;
+    const int npairs = w->n0 / 2, grid = (npairs + G::NF - 1) / G::NF;
+    if (grid > MAXPART) return hipErrorInvalidValue;
+    *npq_out = grid;
+    GPA_PROF("rowidct_pq_kernel", s);
+    kern<<<dim3(grid, 1, w->nprob), H::THREADS, H::LDS_BYTES, s>>>((const T*)w->z, (const T*)pin, (T*)pout, (const T*)weight,
+                                                 (T*)w->q, w->n0, (const cpx<T>*)w->tw1, (const cpx<T>*)w->wk1, w->flags,
+                                                 part_rho, nrho, part_pq, w->scal, it, (size_t)w->n0 * w->n1);
+    return hipGetLastError();
+  }
+}
+hipError_t dispatch_rowidct_pq(const Impl* w, const void* pin, void* pout, const void* weight, const double* part_rho,
+                               int nrho, double* part_pq, int* npq_out, int it, hipStream_t s) {
+#define CASE(LG) case LG: return w->dtype == 0 ? run_rowidct_pq<float, LG>(w, pin, pout, weight, part_rho, nrho, part_pq, npq_out, it, s) \
+                                               : run_rowidct_pq<double, LG>(w, pin, pout, weight, part_rho, nrho, part_pq, npq_out, it, s);
+  switch (w->lg1) { CASE(6) CASE(7) CASE(8) CASE(9) }
+#undef CASE
+  return hipErrorInvalidValue;
 }
 hipError_t dispatch_rowidct_p(const Impl* w, const void* pin, void* pout, const double* part_rho, int nrho, int it,
                               hipStream_t s) {
@@ -2277,6 +2446,12 @@ void unwrap_workspace_destroy(UnwrapWorkspace* ws) {
   ws->impl = nullptr;
 }
 
+// GPA_NO_ROWPQ=1 (diagnostic): keep the stencil a launch of its own for small single images
+static bool getenv_rowpq_off() {
+  static const bool v = getenv("GPA_NO_ROWPQ") != nullptr;
+  return v;
+}
+
 template <class T>
 static hipError_t run_pcg(Impl* w, const void* a, const void* b, const void* weight, bool from_psi, int kmax,
                           double eps, int compat, void* phi, hipStream_t s) {
@@ -2303,7 +2478,7 @@ static hipError_t run_pcg(Impl* w, const void* a, const void* b, const void* wei
   int band = PQ_ROWS;
   while (band > 4 && (size_t)((n1 + pqcols - 1) / pqcols) * ((n0 + band - 1) / band) < 2048) band /= 2;
   const dim3 gpq((n1 + pqcols - 1) / pqcols, (n0 + band - 1) / band);
-  const int npq = gpq.x * gpq.y;
+  int npq = gpq.x * gpq.y;   // (the fused row + stencil kernel of small images reports its own count)
   if (npq > MAXPART) return hipErrorInvalidValue;
   const int gl = 2048;   // grid-stride elementwise kernels
   // the residual of an f32 iteration cannot fall below a few ulps of ||r0||
@@ -2367,6 +2542,9 @@ static hipError_t run_pcg(Impl* w, const void* a, const void* b, const void* wei
       phi_unwritten = false;
     };
     int nnorm = 0;
+    // one image with rows of at most 512 pixels: row kernel and stencil in one launch (rowidct_pq_kernel)
+    const bool rowpq = !w->generic && w->lat_ok && w->nprob <= 2 && w->lg1 <= GPA_ROWPQ_MAXLG && w->n0 >= 4 &&
+                       !getenv_rowpq_off();
     for (int it = 0; it < kmax; ++it) {
       // (first iteration of a prepared start: the partial norms of r0 ride in the part_pq / npq arguments)
       const bool init = it == 0 && a == nullptr;
@@ -2377,6 +2555,10 @@ static hipError_t run_pcg(Impl* w, const void* a, const void* b, const void* wei
       if (it > 0 && it % ring == 0) flush(0);   // slot it % ring still holds p of iteration it - ring
       const T* pin = (const T*)w->ring[(it + ring - 1) % ring];
       T* pout = (T*)w->ring[it % ring];
+      if (rowpq) {
+        if ((e = dispatch_rowidct_pq(w, pin, pout, weight, part_rho, nrow, part_pq, &npq, it, s)) != hipSuccess) return e;
+        continue;
+      }
       if ((e = dispatch_rowidct_p(w, pin, pout, part_rho, nrow, it, s)) != hipSuccess) return e;
       { GPA_PROF("pq_kernel", s);
         if (band == 4 && w->lat_ok && w->nprob <= 2 && npx <= ((size_t)1 << 20)) {
