@@ -1387,6 +1387,7 @@ __global__ __launch_bounds__((RowGeom<T, LG>::THREADS), (GPA_IDCTP_COND ? 4 : (s
 // also transforms the row pair above and the one below its own NF pairs, keeps all 2 NF + 4 rows of the new search
 // direction in LDS and applies q = A^T W^2 A p to its own rows there.  (NF + 2) / NF of the transforms instead of one
 // more launch per iteration; the GPU is far from full at these sizes.  Same formulas as the two kernels.
+// (1024-pixel rows: two own pairs per workgroup, i.e. twice the transforms -- measured slower, 1612 -> 1530 Mpix/s.)
 #define GPA_ROWPQ_MAXLG 9
 template <class T, int LG>
 struct RowPqGeom {
