@@ -1445,6 +1445,36 @@ __global__ __launch_bounds__((RowPqGeom<T, LG>::THREADS)) void rowidct_pq_kernel
     wkv[i] = wk[k];
     pv[i] = first ? cpx<T>{T(0), T(0)} : cpx<T>{pin[oa + k], pin[ob + k]};
   }
+  // f32: the stencil's weights are requested here too, with everything else (f64 has no registers to spare for them)
+  const int xbase = 2 * (int)blockIdx.x * NF;                // first own image row; LDS row of image row x: x - xbase + 2
+  constexpr int VPR = N / 4;                                  // 4-pixel items per row
+  constexpr int NITEM = (2 * NF * VPR + H::THREADS - 1) / H::THREADS;
+  constexpr bool WPRE = sizeof(T) == 4;
+  Vec4<T> wcv[WPRE ? NITEM : 1], wuv[WPRE ? NITEM : 1], wdv[WPRE ? NITEM : 1];
+  T wlv[WPRE ? NITEM : 1], wrv[WPRE ? NITEM : 1];
+  if constexpr (WPRE) {
+#pragma unroll
+    for (int t = 0; t < NITEM; ++t) {
+      const int item = threadIdx.x + t * H::THREADS;
+      const int rl = item / VPR, c0 = (item % VPR) * 4;
+      int xg = xbase + rl;
+      const bool act = item < 2 * NF * VPR && xg < n0;
+      xg = act ? xg : 0;
+      const bool up = xg > 0, dn = xg + 1 < n0, hasl = c0 > 0, hasr = c0 + 4 < N;
+      if (wgt) {
+        const T* wp = wgt + (size_t)xg * N + c0;
+        wcv[t] = *reinterpret_cast<const Vec4<T>*>(wp);
+        wuv[t] = *reinterpret_cast<const Vec4<T>*>(up ? wp - N : wp);
+        wdv[t] = *reinterpret_cast<const Vec4<T>*>(dn ? wp + N : wp);
+        wlv[t] = wp[hasl ? -1 : 0];
+        wrv[t] = wp[hasr ? 4 : 0];
+      } else {
+#pragma unroll
+        for (int j = 0; j < 4; ++j) wcv[t].v[j] = wuv[t].v[j] = wdv[t].v[j] = T(1);
+        wlv[t] = wrv[t] = T(1);
+      }
+    }
+  }
   const double rho_part = load_partials(part_rho, nrho);
   const double rho_prev = scal[8 + ((it - 1) & 1)];
   if (stop) return;
@@ -1474,10 +1504,11 @@ __global__ __launch_bounds__((RowPqGeom<T, LG>::THREADS)) void rowidct_pq_kernel
   }
   __syncthreads();
   // ---- q = A^T W^2 A p on the 2 NF own rows, 4 pixels per item (as pq_kernel: min of the squared weights per edge)
-  const int xbase = 2 * (int)blockIdx.x * NF;                // first own image row; LDS row of image row x: x - xbase + 2
-  constexpr int VPR = N / 4;                                  // 4-pixel items per row
   double pq = 0;
-  for (int item = threadIdx.x; item < 2 * NF * VPR; item += H::THREADS) {
+#pragma unroll
+  for (int t = 0; t < NITEM; ++t) {
+    const int item = threadIdx.x + t * H::THREADS;
+    if (item >= 2 * NF * VPR) continue;
     const int rl = item / VPR, c0 = (item % VPR) * 4;
     const int xg = xbase + rl;
     if (xg >= n0) continue;
@@ -1488,20 +1519,24 @@ __global__ __launch_bounds__((RowPqGeom<T, LG>::THREADS)) void rowidct_pq_kernel
     const T pl = hasl ? pc[-1] : T(0), prr = hasr ? pc[4] : T(0);
     Vec4<T> wc, wu, wd;
     T wl = T(1), wr = T(1);
+    if constexpr (WPRE) {
+      wc = wcv[t]; wu = wuv[t]; wd = wdv[t]; wl = wlv[t]; wr = wrv[t];
+    } else {
 #pragma unroll
-    for (int j = 0; j < 4; ++j) wc.v[j] = wu.v[j] = wd.v[j] = T(1);
-    if (wgt) {
-      const T* wp = wgt + (size_t)xg * N + c0;
-      wc = *reinterpret_cast<const Vec4<T>*>(wp);
-      wu = *reinterpret_cast<const Vec4<T>*>(up ? wp - N : wp);
-      wd = *reinterpret_cast<const Vec4<T>*>(dn ? wp + N : wp);
-      wl = hasl ? wp[-1] : T(1);
-      wr = hasr ? wp[4] : T(1);
-#pragma unroll
-      for (int j = 0; j < 4; ++j) { wc.v[j] *= wc.v[j]; wu.v[j] *= wu.v[j]; wd.v[j] *= wd.v[j]; }
-      wl *= wl;
-      wr *= wr;
+      for (int j = 0; j < 4; ++j) wc.v[j] = wu.v[j] = wd.v[j] = T(1);
+      if (wgt) {
+        const T* wp = wgt + (size_t)xg * N + c0;
+        wc = *reinterpret_cast<const Vec4<T>*>(wp);
+        wu = *reinterpret_cast<const Vec4<T>*>(up ? wp - N : wp);
+        wd = *reinterpret_cast<const Vec4<T>*>(dn ? wp + N : wp);
+        wl = hasl ? wp[-1] : T(1);
+        wr = hasr ? wp[4] : T(1);
+      }
     }
+#pragma unroll
+    for (int j = 0; j < 4; ++j) { wc.v[j] *= wc.v[j]; wu.v[j] *= wu.v[j]; wd.v[j] *= wd.v[j]; }
+    wl *= wl;
+    wr *= wr;
     Vec4<T> qv;
 #pragma unroll
     for (int j = 0; j < 4; ++j) {
