@@ -42,8 +42,18 @@ __global__ __launch_bounds__(MAXT) void mr_rowdct_fused_kernel(
   extern __shared__ __attribute__((aligned(16))) char smem[];
   __shared__ double sh[32];
   // init (first iteration of a solve on prepared residuals): part_pq / npq are the producer's partial norms of r0
+  int stop = 0;
+  double pq_part = 0, rho_it = 0;
   if (init) { if (!solve_init(part_pq, npq, scal, flags, sh)) return; }
-  else if (flags[1]) return;
+  else {
+    // flags, partial sums and rho in one round trip; the early exit after it
+    stop = flags[1];
+    if (it > 0) {
+      pq_part = load_partials(part_pq, npq);
+      rho_it = scal[8 + ((it - 1) & 1)];
+    }
+    if (stop) return;
+  }
   const int n = d.n, Tn = d.pl.T;
   const int tid = threadIdx.x % Tn, f = threadIdx.x / Tn, nf = blockDim.x / Tn;
   cpx<T>* lds = reinterpret_cast<cpx<T>*>(smem) + (size_t)f * rs;
@@ -53,8 +63,8 @@ __global__ __launch_bounds__(MAXT) void mr_rowdct_fused_kernel(
   const size_t oa = (size_t)(va ? xa : 0) * n, ob = (size_t)(vb ? xb : 0) * n;
   T alpha = T(0);
   if (it > 0) {
-    const double pq = reduce_partials(part_pq, npq, sh);
-    const double alpha_d = scal[8 + ((it - 1) & 1)] / pq;   // phase_unwrap.py:343
+    const double pq = block_sum(pq_part, sh);
+    const double alpha_d = rho_it / pq;   // phase_unwrap.py:343
     alpha = (T)alpha_d;
     if (blockIdx.x == 0 && threadIdx.x == 0) scal[SC_ALPHA + (it - 1) % ring] = alpha_d;
   }
@@ -151,7 +161,10 @@ __global__ __launch_bounds__(MAXT) void mr_rowidct_p_kernel(
     scal += pb * SCAL_N;
     part_rho += pb * PART_N;
   }
-  if (flags[1]) return;
+  // the flags, the partial sums and rho are requested with the spectra; the early exit follows that one round trip
+  const int stop = flags[1];
+  const double rho_part = load_partials(part_rho, nrho);
+  const double rho_prev = scal[8 + ((it - 1) & 1)];
   extern __shared__ __attribute__((aligned(16))) char smem[];
   __shared__ double sh[32];
   const int n = d.n, Tn = d.pl.T;
@@ -186,9 +199,10 @@ __global__ __launch_bounds__(MAXT) void mr_rowidct_p_kernel(
       }
     }
   }
-  const double rho = reduce_partials(part_rho, nrho, sh);   // (contains the barrier the LDS image needs)
+  if (stop) return;
+  const double rho = block_sum(rho_part, sh);               // (contains the barrier the LDS image needs)
   const bool first = it == 0;                               // first iteration: p = z (pin is uninitialised)
-  const T beta = first ? T(0) : (T)(rho / scal[8 + ((it - 1) & 1)]);
+  const T beta = first ? T(0) : (T)(rho / rho_prev);
   if (blockIdx.x == 0 && threadIdx.x == 0) scal[8 + (it & 1)] = rho;
   {
     cpx<T> pv[MR_REGS];
