@@ -391,7 +391,7 @@ class Plan:
         npx = self.shape[0] * self.shape[1]
         item = np.dtype(self.rdtype).itemsize
         if getattr(self, '_d_img', None) is None:
-            self._d_img, self._d_u = DeviceBuffer(npx * item), DeviceBuffer(2 * npx * item)
+            self._d_img, self._d_u = DeviceBuffer(npx * item, self.device), DeviceBuffer(2 * npx * item, self.device)
         if image.dtype == self.rdtype and image.flags.c_contiguous:
             src = image
         else:
@@ -501,7 +501,7 @@ class Plan:
         npx = int(self.shape[0]) * int(self.shape[1])
         if chunk is None:
             chunk = max(1, min(B, (16 << 20) // npx))
-        chunk = int(max(1, min(chunk, B)))
+        chunk = int(max(1, min(chunk, B, 4096)))     # the batched driver takes at most 4096 frames per call
         nchunks = -(-B // chunk)
         item = np.dtype(self.rdtype).itemsize
         # (a plain array: page-locking hundreds of MB costs more than it saves -- 104 ms for 256 MB on the MI355X box,
@@ -510,8 +510,8 @@ class Plan:
         if u.shape != (B, 2) + tuple(self.shape) or u.dtype != self.rdtype or not u.flags.c_contiguous:
             raise ValueError('out must be a C-contiguous (B, 2, n0, n1) array of the plan dtype')
         iters = np.zeros((B, 2), dtype=np.int64)
-        d_img = [DeviceBuffer(chunk * npx * item) for _ in range(min(2, nchunks))]
-        d_u = [DeviceBuffer(2 * chunk * npx * item) for _ in range(min(2, nchunks))]
+        d_img = [DeviceBuffer(chunk * npx * item, self.device) for _ in range(min(2, nchunks))]
+        d_u = [DeviceBuffer(2 * chunk * npx * item, self.device) for _ in range(min(2, nchunks))]
         bounds = [(c * chunk, min(B, (c + 1) * chunk)) for c in range(nchunks)]
 
         def upload(c):
@@ -594,23 +594,36 @@ class DeviceBuffer:
     callers of the `_dev` / `_async` entry points that do not want torch for it."""
     _hip = None
 
-    def __init__(self, nbytes):
+    def __init__(self, nbytes, device=0):
+        """`device`: the GPU the memory lives on.  hipMalloc / hipMemcpy act on the calling THREAD's current device, so
+        every method selects it first (a plan on GPU 1 used from a thread whose current device is 0 -- the default of
+        every new thread, e.g. the upload / download workers of the stack call -- would otherwise allocate on GPU 0
+        and hand the plan's kernels a pointer they cannot reach)."""
         load()
         if DeviceBuffer._hip is None:
             DeviceBuffer._hip = C.CDLL('libamdhip64.so')   # already mapped as a dependency of libgpa_hip.so
+        self.device = int(device)
+        self._select()
         p = C.c_void_p()
         rc = self._hip.hipMalloc(C.byref(p), C.c_size_t(int(nbytes)))
         if rc != 0 or not p.value:
-            raise GPAError('hipMalloc(%d) failed (%d)' % (nbytes, rc))
+            raise GPAError('hipMalloc(%d) on device %d failed (%d)' % (nbytes, self.device, rc))
         self.ptr, self.nbytes = p.value, int(nbytes)
+
+    def _select(self):
+        rc = self._hip.hipSetDevice(C.c_int(self.device))
+        if rc != 0:
+            raise GPAError('hipSetDevice(%d) failed (%d)' % (self.device, rc))
 
     def upload(self, host):
         host = np.ascontiguousarray(host)
+        self._select()
         if self._hip.hipMemcpy(C.c_void_p(self.ptr), host.ctypes.data_as(C.c_void_p), C.c_size_t(host.nbytes), 1) != 0:
             raise GPAError('hipMemcpy H2D failed')
 
     def download(self, shape, dtype):
         out = np.empty(shape, dtype=dtype)
+        self._select()
         if self._hip.hipMemcpy(out.ctypes.data_as(C.c_void_p), C.c_void_p(self.ptr), C.c_size_t(out.nbytes), 2) != 0:
             raise GPAError('hipMemcpy D2H failed')
         return out
@@ -619,11 +632,13 @@ class DeviceBuffer:
         """copy the first out.nbytes bytes into the (C-contiguous) array `out`"""
         if not out.flags.c_contiguous:
             raise ValueError('destination must be C-contiguous')
+        self._select()
         if self._hip.hipMemcpy(out.ctypes.data_as(C.c_void_p), C.c_void_p(self.ptr), C.c_size_t(out.nbytes), 2) != 0:
             raise GPAError('hipMemcpy D2H failed')
 
     def free(self):
         if getattr(self, 'ptr', None):
+            self._hip.hipSetDevice(C.c_int(self.device))
             self._hip.hipFree(C.c_void_p(self.ptr))
             self.ptr = None
 

@@ -17,6 +17,7 @@
 
 #include "../../include/gpa_hip.h"
 #include "gpa_internal.h"
+#include "gpa_passb_shared.h"
 #include "gpa_unwrap.h"
 
 using namespace gpa;
@@ -102,6 +103,22 @@ static int kernel_support(const std::vector<double>& h, double tol) {
     if (tail > tol * total) return m;
   }
   return 0;
+}
+
+// taps h[0 .. mmax] only (the shared-forward pass B needs the first few sigma of them, not all n): same sums as
+// spatial_kernel
+static std::vector<double> spatial_taps(int n, const std::vector<double>& g, int mmax) {
+  std::vector<double> h((size_t)mmax + 1);
+  std::vector<long double> cs((size_t)n);
+  const long double w = 2.0L * 3.14159265358979323846264338327950288L / (long double)n;
+  for (int j = 0; j < n; ++j) cs[j] = cosl(w * (long double)j);
+  for (int m = 0; m <= mmax; ++m) {
+    long double acc = 0;
+    for (int k = 0; k < n; ++k)
+      if (g[k] != 0.0) acc += (long double)g[k] * cs[(size_t)((long long)k * m % n)];
+    h[m] = (double)(acc / (long double)n);
+  }
+  return h;
 }
 
 // Filter table of one axis in the spectral register layout [reg][thread]:
@@ -208,6 +225,16 @@ struct gpa_plan {
   void* Hx = nullptr;             // filter tables for the current sigma
   void* Hy = nullptr;
   double sigma_cached = -1.0;
+  // shared-forward pass B (gpa_passb_shared.h): per-sigma taps, per-(sigma, k-list) candidate tables
+  PassBSharedTables sh{};
+  double* d_taps = nullptr;       // g(0 .. sh_etab) of the y axis' circular filter, doubles
+  int sh_etab = 0, sh_E = 0, sh_Epad = 0;
+  bool sh_ok = false;             // this sigma / axis can run it
+  bool use_shared = true;         // GPA_NO_SHARED=1 keeps the per-candidate forward transforms
+  int sh_epoch = 0, sh_built_epoch = -1, sh_built_K = 0, sh_built_B = 0;   // tables follow sigma and the staged k-list
+  bool sh_use = false;            // ... and the staged candidates form runs of >= 2 on an x-plane
+  size_t sh_gb_bytes = 0, sh_psi_bytes = 0;
+  std::vector<int> staged_planeof;
   void* Tbuf = nullptr;           // [tbuf_planes][n0][n1] complex: one plane per DISTINCT wx (x-plane), grown on demand
   int tbuf_planes = 0;
   SweepTables tb{};
@@ -420,6 +447,7 @@ static int ensure_filters(gpa_plan* p, double sigma) {
   if (!(sigma > 0)) return fail(GPA_ERR_ARG, "sigma must be positive");
   if (sigma == p->sigma_cached) return GPA_OK;
   HIP_TRY(hipStreamSynchronize(p->stream));   // the tables may still be read by an earlier asynchronous call
+  p->sigma_cached = -1.0;   // a failure below must not leave half-switched tables behind a matching sigma
   for (int axis = 0; axis < 2; ++axis) {
     const Axis& full = axis == 0 ? p->ax0_full : p->ax1_full;
     Axis& cur = axis == 0 ? p->ax0 : p->ax1;
@@ -440,8 +468,101 @@ static int ensure_filters(gpa_plan* p, double sigma) {
     }
     build_filter_table(cur, g, hsp, table);
     TRY(upload_real_table(p, axis == 0 ? p->Hx : p->Hy, table));
+    if (axis == 1) {
+      // shared-forward pass B: the taps of this axis' filter out to where they are rounding noise, the support E
+      // beyond which they are dropped from the end fix (the same criterion as the compact extension above)
+      p->sh_ok = false;
+      ++p->sh_epoch;
+      const int n = cur.n;
+      int mmax = (int)ceil(10.0 * sigma) + 16;
+      if (p->use_shared && !cur.padded && mmax < n / 2 && mmax <= 1024) {
+        std::vector<double> taps = spatial_taps(n, g, mmax);
+        double total = fabs(taps[0]), tail = 0;
+        for (int m = 1; m <= mmax; ++m) total += 2 * fabs(taps[m]);
+        int E = 1;
+        const double tol = p->dtype == 0 ? 1e-9 : 1e-14;
+        for (int m = mmax; m >= 1; --m) {
+          tail += 2 * fabs(taps[m]);
+          if (tail > tol * total) { E = m; break; }
+        }
+        if (passB_shared_supports(p->dtype, cur, E)) {
+          const int Epad = (E + 15) & ~15;
+          if (!p->d_taps) TRY(dmalloc(p, (void**)&p->d_taps, 1025 * sizeof(double)));
+          if (!p->sh.gtab) TRY(dmalloc(p, &p->sh.gtab, (2 * 256 + 16) * p->rsz));
+          HIP_TRY(hipMemcpyAsync(p->d_taps, taps.data(), ((size_t)mmax + 1) * sizeof(double), hipMemcpyHostToDevice, p->stream));
+          HIP_TRY(hipStreamSynchronize(p->stream));
+          std::vector<double> gt((size_t)2 * Epad + 16, 0.0);
+          for (int m = 1; m <= E; ++m) gt[m] = taps[m];
+          TRY(upload_real_table(p, p->sh.gtab, gt));
+          p->sh_etab = mmax;
+          p->sh_E = E;
+          p->sh_Epad = Epad;
+          p->sh_ok = true;
+        }
+      }
+    }
   }
   p->sigma_cached = sigma;
+  return GPA_OK;
+}
+
+// candidate tables of the shared-forward pass B for the staged k-list (P peaks of K candidates): rebuilt when sigma
+// or the list changed.  Leaves p->sh_use = whether pass B should take that kernel for this (P, K).
+static int shared_prepare(gpa_plan* p, int P, int K) {
+  p->sh_use = false;
+  const int B = P * K;
+  if (!p->sh_ok || !p->use_shared || K < 2 || (int)p->staged_planeof.size() < B) return GPA_OK;
+  if (p->sh_built_epoch == p->sh_epoch && p->sh_built_K == K && p->sh_built_B == B) {
+    p->sh_use = p->sh.desc != nullptr;
+    return GPA_OK;
+  }
+  // runs of candidates on one x-plane, in list order; chunks of <= NC candidates per matrix pass
+  const int NC = p->dtype == 0 ? 4 : 2;
+  std::vector<int> desc((size_t)B, 0);
+  int runs = 0;
+  for (int pp = 0; pp < P; ++pp) {
+    int k = 0, chunk = 0;
+    while (k < K) {
+      int e = k + 1;
+      while (e < K && p->staged_planeof[pp * K + e] == p->staged_planeof[pp * K + k]) ++e;
+      ++runs;
+      for (int j = k; j < e; ++j) {
+        const int r = j - k, slot = r % NC;
+        int d = slot << 2;
+        if (r == 0) d |= 1;
+        if (slot == 0) { d |= 2 | (std::min(NC, e - j) << 4); ++chunk; }
+        d |= (chunk & 1) << 7;   // parity of the chunk (double-buffered staging of its phasors)
+        desc[(size_t)pp * K + j] = d;
+      }
+      k = e;
+    }
+  }
+  p->sh_built_epoch = p->sh_epoch;
+  p->sh_built_K = K;
+  p->sh_built_B = B;
+  if (2 * runs > B) {   // fewer than two candidates per forward transform on average: nothing to share
+    if (p->sh.desc) { HIP_TRY(hipStreamSynchronize(p->stream)); (void)hipFree(p->sh.desc); p->sh.desc = nullptr; }
+    return GPA_OK;
+  }
+  HIP_TRY(hipStreamSynchronize(p->stream));
+  const size_t gb = (size_t)B * p->ax1.L * p->rsz, ps = (size_t)B * p->sh_Epad * p->csz;
+  if (gb > p->sh_gb_bytes) {
+    if (p->sh.Gb) { (void)hipFree(p->sh.Gb); p->ws_bytes -= p->sh_gb_bytes; p->sh.Gb = nullptr; p->sh_gb_bytes = 0; }
+    TRY(dmalloc(p, &p->sh.Gb, gb));
+    p->sh_gb_bytes = gb;
+  }
+  if (ps > p->sh_psi_bytes) {
+    if (p->sh.psi) { (void)hipFree(p->sh.psi); p->ws_bytes -= p->sh_psi_bytes; p->sh.psi = nullptr; p->sh_psi_bytes = 0; }
+    TRY(dmalloc(p, &p->sh.psi, ps));
+    p->sh_psi_bytes = ps;
+  }
+  if (!p->sh.dyc) TRY(dmalloc(p, &p->sh.dyc, (size_t)p->max_peaks * p->n1 * p->csz));
+  if (!p->sh.desc) TRY(dmalloc(p, (void**)&p->sh.desc, (size_t)p->max_batch * sizeof(int)));
+  HIP_TRY(hipMemcpyAsync(p->sh.desc, desc.data(), (size_t)B * sizeof(int), hipMemcpyHostToDevice, p->stream));
+  HIP_TRY(launch_shared_tables(p->dtype, p->ax1, p->d_kl, p->d_kr, p->d_taps, p->sh_etab, p->sh_E, p->sh_Epad, B, K, p->sh,
+                               p->stream));
+  HIP_TRY(hipStreamSynchronize(p->stream));   // `desc` is a local
+  p->sh_use = true;
   return GPA_OK;
 }
 
@@ -474,6 +595,8 @@ static int stage_kvectors(gpa_plan* p, const double* kl, const double* kr_per_b,
     if (found < 0) { h_pw[Bx] = kl[2 * b]; found = Bx++; }
     h_po[b] = found;
   }
+  p->staged_planeof.assign(h_po, h_po + B);
+  ++p->sh_epoch;
   HIP_TRY(hipMemcpyAsync(p->d_kl, h_kl, (size_t)B * 2 * sizeof(double), hipMemcpyHostToDevice, p->stream));
   HIP_TRY(hipMemcpyAsync(p->d_kr, h_kr, (size_t)B * 2 * sizeof(double), hipMemcpyHostToDevice, p->stream));
   HIP_TRY(hipMemcpyAsync(p->d_pw, h_pw, (size_t)Bx * sizeof(double), hipMemcpyHostToDevice, p->stream));
@@ -569,6 +692,7 @@ gpa_plan* gpa_plan_create(int device, int n0, int n1, int max_batch, int dtype) 
   p->use_worker = getenv("GPA_NO_WORKER") == nullptr;
   p->no_ksplit = getenv("GPA_NO_KSPLIT") != nullptr;
   p->no_compact = getenv("GPA_NO_COMPACT") != nullptr;
+  p->use_shared = getenv("GPA_NO_SHARED") == nullptr;
   const int maxlg = dtype == GPA_F32 ? 14 : 13;
   if (p->ax0.lg > maxlg || p->ax1.lg > maxlg) {
     fail(GPA_ERR_ARG, "gpa_plan_create: axis too long for an LDS-resident transform "
@@ -598,7 +722,8 @@ void gpa_plan_destroy(gpa_plan* p) {
   p->graphs.clear();
   void* bufs[] = {p->tw0, p->tw1, p->Hx, p->Hy, p->Tbuf, p->tb.cxb, p->tb.sx, p->tb.wxw, p->tb.wxr, p->tb.cyb, p->tb.sy, p->tb.wyw, p->tb.wyr, p->tb.planeof, p->d_pw,
                   p->tb.dx, p->tb.dy, p->d_kl, p->d_kr, p->d_image, p->d_mean, p->d_tile_mean, p->d_scratch,
-                  p->d_lockin, p->d_kidx, p->d_dudx, p->d_dudy, p->d_wnorm, p->d_u, p->d_kmat, p->d_sf, p->d_grad, p->d_aux0, p->d_aux1};
+                  p->d_lockin, p->d_kidx, p->d_dudx, p->d_dudy, p->d_wnorm, p->d_u, p->d_kmat, p->d_sf, p->d_grad, p->d_aux0, p->d_aux1,
+                  p->sh.Gb, p->sh.psi, p->sh.dyc, p->sh.gtab, p->sh.desc, p->d_taps};
   for (void* b : bufs)
     if (b) hipFree(b);
   unwrap_workspace_destroy(&p->uw);
@@ -687,7 +812,12 @@ static int passB_select(gpa_plan* p, int P, int K, void* lockin, int32_t* kidx) 
   if (p->ax1.lg <= 10 && K >= 4 && !p->no_ksplit && rows_wg <= 256)
     while (ksplit < 4 && ksplit * 2 <= K && rows_wg * ksplit < 1024) ksplit *= 2;
   if (ksplit == 1) {
-    HIP_TRY(launch_passB(p->dtype, p->ax1, p->n0, p->Tbuf, p->Hy, p->tw1, p->tb, P, K, true, lockin, kidx, p->stream));
+    TRY(shared_prepare(p, P, K));
+    if (p->sh_use)
+      HIP_TRY(launch_passB_shared(p->dtype, p->ax1, p->n0, p->Tbuf, p->tw1, p->tb, p->sh, p->sh_E, p->sh_Epad, P, K, lockin,
+                                  kidx, p->stream));
+    else
+      HIP_TRY(launch_passB(p->dtype, p->ax1, p->n0, p->Tbuf, p->Hy, p->tw1, p->tb, P, K, true, lockin, kidx, p->stream));
     return GPA_OK;
   }
   const size_t npx = (size_t)p->n0 * p->n1, cnt = (size_t)ksplit * P * npx;
@@ -1179,6 +1309,7 @@ int gpa_extract_displacement_field_batch_dev(gpa_plan* p, const void* images, in
     p->bL_bytes = (size_t)chunk * l_img;
     p->b_chunk = chunk;
   }
+  TRY(shared_prepare(p, P, K));
   int nparts = 0;
   const size_t rstride = 2 * npx;                                                     // residual slices per image
   const size_t pstride = (size_t)(unwrap_partials_buffer(&p->uwb, 2) - unwrap_partials_buffer(&p->uwb, 0));
@@ -1187,8 +1318,12 @@ int gpa_extract_displacement_field_batch_dev(gpa_plan* p, const void* images, in
     const void* image = (const char*)images + (size_t)c0 * npx * p->rsz;
     HIP_TRY(launch_mean(p->dtype, image, npx, p->bScratch, p->bMean, p->stream, nimg));
     HIP_TRY(launch_passA(p->dtype, p->ax0, p->n1, image, p->bMean, p->tb, p->Hx, p->tw0, p->bT, Bx, p->stream, nimg));
-    HIP_TRY(launch_passB(p->dtype, p->ax1, p->n0, p->bT, p->Hy, p->tw1, p->tb, P, K, true, p->bL, nullptr, p->stream, nimg,
-                         Bx));
+    if (p->sh_use)
+      HIP_TRY(launch_passB_shared(p->dtype, p->ax1, p->n0, p->bT, p->tw1, p->tb, p->sh, p->sh_E, p->sh_Epad, P, K, p->bL,
+                                  nullptr, p->stream, nimg, Bx));
+    else
+      HIP_TRY(launch_passB(p->dtype, p->ax1, p->n0, p->bT, p->Hy, p->tw1, p->tb, P, K, true, p->bL, nullptr, p->stream, nimg,
+                           Bx));
     HIP_TRY(launch_reconstruct_setup(p->dtype, p->bL, p->d_kmat, P, p->n0, p->n1, mask_border,
                                      (char*)p->d_wnorm_b + (size_t)c0 * npx * p->rsz,
                                      unwrap_residual_buffer(&p->uwb, 2 * c0), unwrap_residual_buffer(&p->uwb, 2 * c0 + 1),

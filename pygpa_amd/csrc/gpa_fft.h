@@ -309,6 +309,69 @@ struct WgFFT {
     }
   }
 
+  // Three-pass transforms with the base twiddles of pass 0 in registers and those of pass 1 in LDS: pass 1's
+  // exponents depend on the thread only through m0 = G mod S_1 (16 distinct sets at 4096 points, 8 below), so ONE
+  // small table serves the workgroup and the thread keeps 12 registers (f32; 24 in f64) fewer across the k-loop.
+  // t1: [S_1][6] complex in LDS, filled by fill_pass1_table (every thread of the workgroup calls it, then a barrier
+  // before the first transform).
+  struct TwiddlesP1Lds {
+    cpx<T> lo[GMAX][3], hi[GMAX][3];
+    const cpx<T>* t1;
+    int tid;
+  };
+  static constexpr int P1_SETS = P == 3 ? (1 << (lg_len(1) - bits(1))) : 1;
+  GPA_HD static void fill_pass1_table(cpx<T>* t1, const cpx<T>* __restrict__ table, int thread, int nthreads) {
+    static_assert(P == 3, "TwiddlesP1Lds: three-pass transforms only");
+    constexpr int lgLp = lg_len(1);
+    for (int e = thread; e < P1_SETS * 6; e += nthreads) {
+      const int m0 = e / 6, c = e % 6;
+      const int u = m0 << (LOG2L - lgLp);
+      t1[e] = table[c < 3 ? u * (c + 1) : u * 4 * (c - 2)];
+    }
+  }
+  GPA_HD static void load_twiddles(TwiddlesP1Lds& tw, const cpx<T>* __restrict__ table, int tid, const cpx<T>* t1) {
+    static_assert(P == 3, "TwiddlesP1Lds: three-pass transforms only");
+    constexpr int b = bits(0), r = 1 << b, g = E / r, lgS = LOG2L - b;
+#pragma unroll
+    for (int q = 0; q < g; ++q) {
+      const int G = tid + TPF * q;
+      const int u = G & ((1 << lgS) - 1);
+#pragma unroll
+      for (int c = 0; c < 3; ++c) {
+        if ((c + 1) < r) tw.lo[q][c] = table[u * (c + 1)];
+        if (4 * (c + 1) < r) tw.hi[q][c] = table[u * 4 * (c + 1)];
+      }
+    }
+    tw.t1 = t1;
+    tw.tid = tid;
+  }
+  template <int p, int r, bool INV>
+  GPA_HD static void twiddle(cpx<T>* v, const TwiddlesP1Lds& tw, int q) {
+    cpx<T> lo[3], hi[3];
+    if constexpr (p == 0) {
+#pragma unroll
+      for (int c = 0; c < 3; ++c) { lo[c] = tw.lo[q][c]; hi[c] = tw.hi[q][c]; }
+    } else {
+      constexpr int lgS = lg_len(p) - bits(p);
+      const int m0 = (tw.tid + TPF * q) & ((1 << lgS) - 1);
+      const cpx<T>* t = tw.t1 + m0 * 6;
+#pragma unroll
+      for (int c = 0; c < 3; ++c) {
+        if ((c + 1) < r) lo[c] = t[c];
+        if (4 * (c + 1) < r) hi[c] = t[3 + c];
+      }
+    }
+#pragma unroll
+    for (int k = 1; k < r; ++k) {
+      const int a = k >> 2, b = k & 3;
+      cpx<T> t = v[k];
+      if (a > 0) t = cmul_maybe_conj<INV>(t, hi[a - 1]);
+      if (b > 0) t = cmul_maybe_conj<INV>(t, lo[b - 1]);
+      v[k] = t;
+    }
+  }
+  GPA_HD static void refresh(TwiddlesP1Lds&) {}
+
   // one pass of butterflies on the thread's 16 registers (q and j loops are
   // fully unrolled, so every register index is static)
   template <int p, bool INV, class TW>

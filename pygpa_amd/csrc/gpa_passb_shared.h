@@ -1,0 +1,36 @@
+// Interface of the shared-forward pass B (gpa_passb_shared.hip): best-of-K selection with ONE forward transform per
+// x-plane row, a per-candidate shifted real Gaussian, and the exact end fix-up as a small Hankel contraction on the
+// matrix cores.  Replaces, for the sweep, the per-candidate forward transforms of gpa_passb.h; same selection rule
+// (geometric_phase_analysis.py:679-684), same outputs.
+#pragma once
+#include "gpa_internal.h"
+
+namespace gpa {
+
+// candidates whose end fix-up is contracted in one matrix pass (16 columns = 2 ends x NC x (re, im); f64 uses half of
+// the columns so that two workgroups still share a CU's LDS at 4096 points)
+template <class T> struct PassBSharedNC { static constexpr int value = sizeof(T) == 4 ? 4 : 2; };
+
+// Device tables, element types of the plan dtype (T real, cpx<T> complex):
+struct PassBSharedTables {
+  void* Gb;     // [B][L] T      shifted Gaussian of candidate b in the spectral register layout, / L
+  void* psi;    // [B][Epad] cpx (phi_b - [periodic]) exp(2 pi i wy_b (a0 + 1)): post-factor of the end fix
+  void* dyc;    // [P][n1] cpx   exp(2 pi i ky y): compensation of the winner, candidate-independent
+  void* gtab;   // [2 Epad + 16] T   Hankel taps: gtab[s] = g(s) for 1 <= s <= E, 0 elsewhere
+  int* desc;    // [B] per candidate: bit 0 = first of a run of candidates on one x-plane (read the row, forward
+                //   transform), bit 1 = first of a chunk of <= NC candidates (matrix pass), bits 2-3 = slot in the
+                //   chunk, bits 4-6 = candidates in the chunk, bit 7 = parity of the chunk
+};
+
+// can the shared pass B run this axis (3-pass transforms, taps that vanish beyond E <= L / 16 samples, LDS)?
+bool passB_shared_supports(int dtype, const Axis& a1, int E);
+
+// kl / kr: device [B][2] candidates and their peaks; taps: device doubles g(0 .. Etab) of the length-n circular filter
+hipError_t launch_shared_tables(int dtype, const Axis& a1, const double* kl, const double* kr, const double* taps, int Etab,
+                                int E, int Epad, int B, int K, const PassBSharedTables& st, hipStream_t s);
+
+hipError_t launch_passB_shared(int dtype, const Axis& a1, int n0, const void* Tbuf, const void* tw1, const SweepTables& tb,
+                               const PassBSharedTables& st, int E, int Epad, int P, int K, void* out, int32_t* kidx,
+                               hipStream_t s, int nimg = 1, int Bx = 0);
+
+}  // namespace gpa

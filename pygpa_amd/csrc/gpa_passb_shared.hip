@@ -1,0 +1,504 @@
+// Pass B of the best-of-K sweep with the forward transform SHARED by the candidates of an x-plane.
+//
+// The reference computes, for every candidate b of a peak (geometric_phase_analysis.py:72-75, :679-684),
+//     sf_b(y) = sum_y' g((y - y') mod n) T(y') c_b(y'),   c_b(y) = exp(2 pi i wy_b y),
+// T = the x-plane of the candidate (pass A), g = the taps of the circular Gaussian filter.  Pulling the carrier
+// through the sum,
+//     sf_b(y) = c_b(y) [ (g_b (*) T)(y) + fix_b(y) ],      g_b(m) = g(m) exp(-2 pi i wy_b m)   (signed lag m),
+// the transform of g_b is REAL (the Gaussian shifted by wy_b, tabulated in double per candidate) and T no longer
+// carries anything of the candidate: the candidates that share an x-plane share ONE forward transform of its row
+// (4 forward + 16 inverse transforms per row and peak for a 4 x 4 grid instead of 16 + 16, and one read of the row
+// instead of four).  c_b(y) is a unit phasor: it does not change |sf| and merges with the compensation
+// exp(-2 pi i (wy_b - ky) y) of :683 into the candidate-independent exp(2 pi i ky y), applied once to the winner.
+//
+// fix_b is where the identity fails: the carrier is not n-periodic, so the pairs (y, y') that the circular filter
+// joins AROUND the row end carry exp(-/+ 2 pi i wy_b n) relative to what g_b (*) T gives them.  With taps that vanish
+// beyond E samples only the outputs within E of either end are touched,
+//     fix_b(n - a)  = (phi_b - 1)       sum_{j=0}^{E-a} g(a + j) exp(+2 pi i wy_b (a + j)) T(j)           a = 1 .. E
+//     fix_b(a - 1)  = (conj phi_b - 1)  sum_{j=0}^{E-a} g(a + j) exp(-2 pi i wy_b (a + j)) T(n - 1 - j),  phi_b = exp(-2 pi i wy_b n),
+// i.e. one small dense REAL Hankel matrix G[a][j] = g(a + j) (the same for every candidate) times the end strips of
+// the row pre-multiplied by the candidate's phasor -- a dense contraction, which is what the matrix cores are for:
+// it runs as v_mfma_f32_16x16x4_f32 / v_mfma_f64_16x16x4_f64 (exact f32 / f64 FMA chains) on the otherwise idle
+// matrix pipe beside the VALU-bound transforms, 16 columns = 2 ends x NC candidates x (re, im) at a time.
+// On a zero-padded (non-power-of-two) row the same formulas hold with (phi_b - 0): g_b (*) T then contains no
+// wrapped pair at all and the transform length only has to be >= n + E.
+//
+// Selection ("strictly larger |sf| replaces", in list order) keeps only |best|^2 in registers: a winner is stored
+// to `out` the moment it wins and the row is revisited once at the end for the compensation phasor, which frees the
+// registers that the shared spectrum needs.
+#include "gpa_internal.h"
+#include "gpa_passb_shared.h"
+
+namespace gpa {
+
+template <class T> struct MfmaVec;
+template <> struct MfmaVec<float> { typedef float type __attribute__((ext_vector_type(4))); };
+template <> struct MfmaVec<double> { typedef double type __attribute__((ext_vector_type(4))); };
+
+__device__ __forceinline__ MfmaVec<float>::type mfma16(float a, float b, MfmaVec<float>::type c) {
+  return __builtin_amdgcn_mfma_f32_16x16x4f32(a, b, c, 0, 0, 0);
+}
+__device__ __forceinline__ MfmaVec<double>::type mfma16(double a, double b, MfmaVec<double>::type c) {
+  return __builtin_amdgcn_mfma_f64_16x16x4f64(a, b, c, 0, 0, 0);
+}
+// row of the 16 x 16 result held in element r of lane-quarter kq (f64 uses a different map than every other dtype)
+template <class T> __device__ __forceinline__ int mfma_row(int kq, int r) {
+  if constexpr (sizeof(T) == 8) return kq + 4 * r;
+  else return 4 * kq + r;
+}
+
+template <class T> struct upair { T u, v; };
+
+#ifndef GPA_PBS_PREFETCH
+#define GPA_PBS_PREFETCH 0
+#endif
+#ifndef GPA_PBS_NOFIX
+#define GPA_PBS_NOFIX 0     // diagnosis only: skip the end fix (wrong results at the row ends)
+#endif
+#ifndef GPA_PBS_NOSTORE
+#define GPA_PBS_NOSTORE 0   // diagnosis only: skip the winner stores
+#endif
+
+// the shifted Gaussian of one candidate: sixteen reals per thread in the spectral register layout
+template <class T, int TPF>
+__device__ __forceinline__ void load_gb(T (&h)[16], const T* gbrow, int tid) {
+  using gscalar = const __attribute__((address_space(1))) T;
+  gscalar* gb = (gscalar*)gbrow;
+#pragma unroll
+  for (int i = 0; i < 16; ++i) h[i] = gb[i * TPF + tid];
+}
+template <class T> __device__ __forceinline__ cpx<T> load_cpx(__amdgpu_buffer_rsrc_t r, int voff, int soff);
+
+typedef int v2i_t __attribute__((ext_vector_type(2)));
+typedef int v4i_t __attribute__((ext_vector_type(4)));
+__device__ __forceinline__ void store_cpx(cpx<float> v, __amdgpu_buffer_rsrc_t r, int voff, int soff) {
+  v2i_t d = {__float_as_int(v.x), __float_as_int(v.y)};
+  __builtin_amdgcn_raw_buffer_store_b64(d, r, voff, soff, 0);
+}
+template <> __device__ __forceinline__ cpx<float> load_cpx<float>(__amdgpu_buffer_rsrc_t r, int voff, int soff) {
+  v2i_t d = __builtin_amdgcn_raw_buffer_load_b64(r, voff, soff, 16 /* sc1: served by L2 */);
+  return {__int_as_float(d.x), __int_as_float(d.y)};
+}
+template <> __device__ __forceinline__ cpx<double> load_cpx<double>(__amdgpu_buffer_rsrc_t r, int voff, int soff) {
+  v4i_t d = __builtin_amdgcn_raw_buffer_load_b128(r, voff, soff, 16);
+  const long long a = ((long long)(unsigned)d.x) | ((long long)d.y << 32), b = ((long long)(unsigned)d.z) | ((long long)d.w << 32);
+  return {__longlong_as_double(a), __longlong_as_double(b)};
+}
+__device__ __forceinline__ void store_cpx(cpx<double> v, __amdgpu_buffer_rsrc_t r, int voff, int soff) {
+  const long long a = __double_as_longlong(v.x), b = __double_as_longlong(v.y);
+  v4i_t d = {(int)a, (int)(a >> 32), (int)b, (int)(b >> 32)};
+  __builtin_amdgcn_raw_buffer_store_b128(d, r, voff, soff, 0);
+}
+
+template <class T, int LG>
+struct PassBSGeom {
+  using F = WgFFT<T, LG>;
+  static_assert(F::P == 3, "three-pass transforms only (1024 .. 4096 points)");
+  static constexpr int TPF = F::TPF;
+  static_assert(TPF >= 64, "a row needs whole wavefronts");
+  static constexpr int NF = TPF >= 256 ? 1 : 256 / TPF;   // rows per workgroup
+  static constexpr int THREADS = NF * TPF;
+  static constexpr int NW = TPF / 64;                      // wavefronts per row
+  static constexpr int NC = PassBSharedNC<T>::value;       // candidates per matrix pass
+  static constexpr int LOGNC = NC == 4 ? 2 : 1;
+  // f32: the candidate phasors the end fix needs (pre-factors of the strips, post-factors of the results) are staged
+  // in LDS once per chunk of NC candidates, so that neither the matrix pass nor the fix-up waits on global loads
+  // (which queue behind the winner stores in vmcnt).  f64 has no LDS left for that at 4096 points.
+  static constexpr bool STAGE = sizeof(T) == 4;
+  static constexpr int T1 = F::P1_SETS * 6;                // pass-1 twiddle table (complex), one per workgroup
+  // end strips: f32 keeps the four (end, re/im) forms the matrix pass multiplies directly, f64 (no LDS to spare at
+  // 4096 points) the two complex strips and forms them per lane with selects
+  static constexpr int SV = sizeof(T) == 4 ? 4 : 2;
+  // per-row LDS in complex elements: transform image | end strips [end][re/im variant][Epad] | results [NC][end][Epad]
+  // | staged pre-factors [NC][Epad] | staged post-factors [2][NC][Epad] (double-buffered by chunk parity)
+  __host__ __device__ static size_t row_elems(int Epad) {
+    return (size_t)F::LDS_ELEMS + SV * (size_t)Epad + 2 * NC * (size_t)Epad + (STAGE ? 3 * NC * (size_t)Epad : 0);
+  }
+  __host__ __device__ static size_t lds_bytes(int Epad) {
+    return (NF * row_elems(Epad) + T1) * sizeof(cpx<T>) + (2 * (size_t)Epad + 16) * sizeof(T);
+  }
+};
+
+#ifndef GPA_PBS_F32_WAVES
+#define GPA_PBS_F32_WAVES 3
+#endif
+#ifndef GPA_PBS_F64_WAVES
+#define GPA_PBS_F64_WAVES 2
+#endif
+
+template <class T, int LG, bool PADDED>
+__global__ __launch_bounds__((PassBSGeom<T, LG>::THREADS), (sizeof(T) == 8 ? GPA_PBS_F64_WAVES : GPA_PBS_F32_WAVES)) void passB_shared_kernel(
+    const cpx<T>* __restrict__ Tin, int n0, int n1, const T* __restrict__ Gb, const cpx<T>* __restrict__ twtab,
+    const int* __restrict__ planeof, const int* __restrict__ desc, const cpx<T>* __restrict__ cyb,
+    const cpx<T>* __restrict__ psi, const T* __restrict__ gtab, const cpx<T>* __restrict__ dx,
+    const cpx<T>* __restrict__ dyc, int K, int E, int Epad, cpx<T>* out, int32_t* kidx, int P, int Bx) {
+  using F = WgFFT<T, LG>;
+  using G = PassBSGeom<T, LG>;
+  using V4 = typename MfmaVec<T>::type;
+  constexpr int TPF = F::TPF, L = F::L, NC = G::NC;
+  constexpr bool STAGE = G::STAGE;
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  // (a row owns whole wavefronts: its index is wave-uniform, which keeps every row base address in SGPRs)
+  const int tid = threadIdx.x % TPF, f = __builtin_amdgcn_readfirstlane(threadIdx.x / TPF);
+  cpx<T>* lds = reinterpret_cast<cpx<T>*>(smem) + (size_t)f * G::row_elems(Epad);
+  upair<T>* strip = reinterpret_cast<upair<T>*>(lds + F::LDS_ELEMS);
+  cpx<T>* fixb = lds + F::LDS_ELEMS + G::SV * Epad;
+  cpx<T>* pre_l = fixb + 2 * NC * Epad;          // [NC][Epad]       (STAGE)
+  cpx<T>* psi_l = pre_l + NC * Epad;             // [2][NC][Epad]    (STAGE)
+  cpx<T>* t1 = reinterpret_cast<cpx<T>*>(smem) + (size_t)G::NF * G::row_elems(Epad);
+  T* glds = reinterpret_cast<T*>(t1 + G::T1);
+  const int row = blockIdx.x * G::NF + f;
+  const bool valid = row < n0;
+  const int rr = valid ? row : 0;
+  const int p = blockIdx.y, pt = p % P, img = p / P;
+  const int lane = threadIdx.x & 63, wrow = tid >> 6;
+
+  // Hankel taps g(1 .. E) (zero beyond) and the pass-1 twiddles: first read after the barriers of the first transform
+  for (int i = threadIdx.x; i < 2 * Epad + 16; i += G::THREADS) glds[i] = gtab[i];
+  F::fill_pass1_table(t1, twtab, threadIdx.x, G::THREADS);
+  __syncthreads();
+
+  typename F::TwiddlesP1Lds tw;
+  F::load_twiddles(tw, twtab, tid, t1);
+
+  T ab[16];
+#pragma unroll
+  for (int i = 0; i < 16; ++i) ab[i] = T(0);
+  const size_t obase = ((size_t)p * n0 + rr) * n1;
+  // the winner's row as a buffer: a lane that does not win (or lies beyond the image) stores to an out-of-range
+  // offset, which the hardware drops -- sixteen predicated stores per candidate without a branch
+  const __amdgpu_buffer_rsrc_t orow = __builtin_amdgcn_make_buffer_rsrc((void*)(out + obase), 0, n1 * (int)sizeof(cpx<T>), 0x00020000);
+  const __amdgpu_buffer_rsrc_t krow = __builtin_amdgcn_make_buffer_rsrc((void*)(kidx ? kidx + obase : nullptr), 0, kidx ? n1 * 4 : 0, 0x00020000);
+  constexpr int OOB = (int)0x80000000;
+  // registers that hold the last E samples of the row (zero-padded rows: wherever n1 puts them)
+  const int iA = PADDED ? (n1 - E) / TPF : 15, iB = PADDED ? (n1 - 1) / TPF : 15;
+
+  cpx<T> X[16];
+  T h[16];
+  for (int k = 0; k < K; ++k) {
+    const int b = pt * K + k;
+    const int d = desc[b];
+    if (d & 1) {
+      // ---- a new x-plane: read its row once, take the end strips, forward transform -------------------------
+      const cpx<T>* src = Tin + (((size_t)img * Bx + planeof[b]) * n0 + rr) * n1;
+      const cpx<T> cs = dx[(size_t)b * n0 + rr];   // exp(-2 pi i (wx - kx) x): the same for every candidate of the plane
+      cpx<T> tail = {T(0), T(0)};
+      if (tid < E) tail = src[n1 - 1 - tid];
+#pragma unroll
+      for (int i = 0; i < 16; ++i) {
+        const int yy = tid + TPF * i;
+        cpx<T> v = {T(0), T(0)};
+        if (!PADDED || yy < n1) v = src[yy];
+        X[i] = cmul(v, cs);
+      }
+      if (tid < Epad) {
+        // strips in the two forms the matrix pass reads (it forms ONE real of t * p or t * conj(p) per lane as
+        // u p.x + v p.y): end 0 = T(j), j < E (feeds the outputs at the row's end), end 1 = T(n - 1 - j)
+        const bool in = tid < E;
+        const cpx<T> s0 = in ? X[0] : cpx<T>{T(0), T(0)};
+        const cpx<T> s1 = in ? cmul(tail, cs) : cpx<T>{T(0), T(0)};
+        if constexpr (G::SV == 4) {
+          strip[0 * Epad + tid] = {s0.x, -s0.y};   // end 0, real part of t p
+          strip[1 * Epad + tid] = {s0.y, s0.x};    // end 0, imaginary part
+          strip[2 * Epad + tid] = {s1.x, s1.y};    // end 1, real part of t conj(p)
+          strip[3 * Epad + tid] = {s1.y, -s1.x};   // end 1, imaginary part
+        } else {
+          strip[0 * Epad + tid] = {s0.x, s0.y};
+          strip[1 * Epad + tid] = {s1.x, s1.y};
+        }
+      }
+      F::forward(X, lds, tid, tw);
+    }
+    // ---- candidate b: shifted Gaussian, inverse transform (the matrix pass of a new chunk rides between its barriers)
+    const int par = (d >> 7) & 1;   // parity of the chunk: which copy of the staged post-factors this candidate reads
+    cpx<T> y[16];
+    {
+#if GPA_PBS_PREFETCH
+      if (k == 0) load_gb<T, TPF>(h, Gb + (size_t)b * L, tid);
+#else
+      load_gb<T, TPF>(h, Gb + (size_t)b * L, tid);
+#endif
+      if constexpr (STAGE) {
+        if (d & 2) {
+          // phasors of this chunk's candidates into LDS: exp(2 pi i wy j) (strip pre-factors) and the post-factors
+          const int nc = (d >> 4) & 7;
+          for (int e = tid; e < NC * Epad; e += TPF) {
+            const int c = e / Epad, j = e - c * Epad, cc = c < nc ? c : nc - 1;
+            pre_l[e] = cyb[(size_t)(b + cc) * TPF + j];
+            psi_l[(size_t)par * NC * Epad + e] = psi[(size_t)(b + cc) * Epad + j];
+          }
+        }
+      }
+#pragma unroll
+      for (int i = 0; i < 16; ++i) y[i] = {X[i].x * h[i], X[i].y * h[i]};
+    }
+    cpx<T> psL = {T(0), T(0)}, psR = {T(0), T(0)};
+    const int a0R = PADDED ? 0 : TPF - 1 - tid;
+    if constexpr (!STAGE) {
+      // post-factors of the end fix, requested now, used after the transform
+      psL = psi[(size_t)b * Epad + (tid < E ? tid : 0)];
+      psR = psi[(size_t)b * Epad + (a0R < E ? a0R : 0)];
+    }
+    F::template inv_phase<0>(y, lds, tid, tw);
+    __syncthreads();
+    if ((d & 2) && !GPA_PBS_NOFIX) {
+      // end-fix contraction for the candidates b .. b + nc - 1: D[a][n] = sum_j g(a + 1 + j) B[j][n], column
+      // n = (end, candidate, re/im).  Lane l supplies A[l & 15][l >> 4] and B[l >> 4][l & 15] of each k-step.
+      const int nc = (d >> 4) & 7;
+      const int n = lane & 15, kq = lane >> 4;
+      const int c = (n >> 1) & (NC - 1), end = (n >> (1 + G::LOGNC)) & 1, reim = n & 1;
+      const cpx<T>* pre = STAGE ? pre_l + c * Epad : cyb + (size_t)(b + (c < nc ? c : nc - 1)) * TPF;
+      const upair<T>* sp = strip + (G::SV == 4 ? end * 2 + reim : end) * Epad;
+      // (two-strip form: u, v and the sign of v picked per lane)
+      const bool swp = reim != 0;
+      const T sgn = (end == 0) == swp ? T(1) : T(-1);
+      const int Mt = (E + 15) >> 4;
+      for (int mt = wrow; mt < Mt; mt += G::NW) {
+        V4 acc0 = {T(0), T(0), T(0), T(0)}, acc1 = {T(0), T(0), T(0), T(0)};
+        // k-steps whose taps g(16 mt + 1 + 4 s + ...) are not all beyond E
+        int ns = ((E - 16 * mt - 1) >> 2) + 1;
+        if (ns > (Epad >> 2)) ns = Epad >> 2;
+        const T* ga = glds + 16 * mt + (lane & 15) + kq + 1;
+        // four k-steps at a time, their twelve operand loads requested together: the contraction sits between two
+        // barriers of the transform, on the critical path of the whole workgroup
+        for (int s = 0; s < ns; s += 4) {
+          upair<T> q[4];
+          cpx<T> pp[4];
+          T av[4];
+#pragma unroll
+          for (int u = 0; u < 4; ++u) {
+            int j = 4 * (s + u) + kq;
+            j = j < Epad ? j : Epad - 1;
+            q[u] = sp[j];
+            if constexpr (G::SV == 2) q[u] = {swp ? q[u].v : q[u].u, sgn * (swp ? q[u].u : q[u].v)};
+            pp[u] = pre[j];
+            av[u] = ga[4 * (s + u)];
+          }
+#pragma unroll
+          for (int u = 0; u < 4; ++u) {
+            // (k-steps past ns multiply taps that are zero by zero-padded strips: harmless, and only whole batches run)
+            const T bv = q[u].u * pp[u].x + q[u].v * pp[u].y;
+            if (u & 1) acc1 = mfma16(av[u], bv, acc1);
+            else acc0 = mfma16(av[u], bv, acc0);
+          }
+        }
+        if (n < 4 * NC) {
+#pragma unroll
+          for (int r = 0; r < 4; ++r) {
+            const int a0 = 16 * mt + mfma_row<T>(kq, r);
+            reinterpret_cast<T*>(fixb + (size_t)(c * 2 + end) * Epad + a0)[reim] = acc0[r] + acc1[r];
+          }
+        }
+      }
+    }
+    F::template inv_phase<1>(y, lds, tid, tw);
+    __syncthreads();
+    F::template inv_phase<2>(y, lds, tid, tw);
+    // ---- the outputs within E of either end get their wrapped pairs ------------------------------------------
+#if !GPA_PBS_NOFIX
+    {
+      const int c = (d >> 2) & 3;
+      const cpx<T>* pl = psi_l + (size_t)(par * NC + c) * Epad;
+      if (tid < E) {
+        const cpx<T> fx = fixb[(size_t)(c * 2 + 1) * Epad + tid];
+        if constexpr (STAGE) psL = pl[tid];
+        const cpx<T> t = cmulc(fx, psL);
+        y[0].x += t.x;
+        y[0].y += t.y;
+      }
+      if constexpr (!PADDED) {
+        if (a0R < E) {
+          const cpx<T> fx = fixb[(size_t)(c * 2 + 0) * Epad + a0R];
+          if constexpr (STAGE) psR = pl[a0R];
+          const cpx<T> t = cmul(fx, psR);
+          y[15].x += t.x;
+          y[15].y += t.y;
+        }
+      } else {
+#pragma unroll
+        for (int i = 0; i < 16; ++i) {
+          if (i == iA || i == iB) {
+            const int a0 = n1 - 1 - (tid + TPF * i);
+            if (a0 >= 0 && a0 < E) {
+              const cpx<T> fx = fixb[(size_t)(c * 2 + 0) * Epad + a0];
+              const cpx<T> ps = STAGE ? pl[a0] : psi[(size_t)b * Epad + a0];
+              const cpx<T> t = cmul(fx, ps);
+              y[i].x += t.x;
+              y[i].y += t.y;
+            }
+          }
+        }
+      }
+    }
+#endif
+#if GPA_PBS_PREFETCH
+    // the next candidate's Gaussian is requested BEFORE this candidate's stores: vmcnt counts loads and stores in
+    // order, so loads issued behind the stores would wait for the stores' acknowledgements as well
+    if (k + 1 < K) load_gb<T, TPF>(h, Gb + (size_t)(b + 1) * L, tid);
+    __builtin_amdgcn_sched_barrier(0);
+#endif
+    // ---- strict '>' in list order; the winner goes to memory at once ----------------------------------------
+#pragma unroll
+    for (int i = 0; i < 16; ++i) {
+      const int yy = tid + TPF * i;
+      const T a = y[i].x * y[i].x + y[i].y * y[i].y;
+      const bool win = a > ab[i];
+      ab[i] = win ? a : ab[i];
+      // (byte offset; OOB = 0x80000000 stays out of range after the arithmetic shift below, never multiply it)
+      const int woff = (win && valid && (!PADDED || yy < n1)) ? tid * (int)sizeof(cpx<T>) : OOB;
+#if !GPA_PBS_NOSTORE
+      store_cpx(y[i], orow, woff, i * TPF * (int)sizeof(cpx<T>));
+      constexpr int SH = sizeof(cpx<T>) == 8 ? 1 : 2;   // complex byte offset -> int32 byte offset
+      if (kidx) __builtin_amdgcn_raw_buffer_store_b32(k, krow, woff >> SH, i * TPF * 4, 0);
+#endif
+    }
+  }
+  if (!valid) return;
+  // ---- compensation to the peak centre: exp(2 pi i ky y), the same for every candidate ---------------------------
+  // The winners were stored through the buffer descriptor by this very lane; the stores must have reached L2 before
+  // the row is read back (the compiler sees no alias between the descriptor and a plain pointer, and a load may
+  // overtake a store in flight), and the read goes to L2 (sc1), not to whatever L1 holds.
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  const cpx<T>* dyp = dyc + (size_t)pt * n1;
+  cpx<T> w[16];
+#pragma unroll
+  for (int i = 0; i < 16; ++i) {
+    const int yy = tid + TPF * i;
+    w[i] = load_cpx<T>(orow, (!PADDED || yy < n1) ? tid * (int)sizeof(cpx<T>) : OOB, i * TPF * (int)sizeof(cpx<T>));
+  }
+#pragma unroll
+  for (int i = 0; i < 16; ++i) {
+    const int yy = tid + TPF * i;
+    if (!PADDED || yy < n1) {
+      cpx<T> v = {T(0), T(0)};
+      if (ab[i] > T(0)) v = cmul(w[i], dyp[yy]);
+      else if (kidx) kidx[obase + yy] = -1;
+      out[obase + yy] = v;
+    }
+  }
+}
+
+// ---------------------------------------------------------------------------------------------------------------
+// tables: the shifted Gaussian of every candidate in the spectral register layout, the post-factors of the end fix
+// and the compensation phasor of every peak, all evaluated in double
+// ---------------------------------------------------------------------------------------------------------------
+template <class T>
+__device__ __forceinline__ cpx<T> unit_phasor_s(double cycles) {
+  double fr = cycles - rint(cycles);
+  double s, c;
+  sincospi(2.0 * fr, &s, &c);
+  return {(T)c, (T)s};
+}
+
+template <class T, int LG>
+__global__ __launch_bounds__(256) void shared_tables_kernel(const double* __restrict__ kl, const double* __restrict__ kr,
+                                                           const double* __restrict__ taps, int Etab, int n1, int E,
+                                                           int Epad, int wrapped, int K, T* __restrict__ Gb,
+                                                           cpx<T>* __restrict__ psi, cpx<T>* __restrict__ dyc) {
+  using F = WgFFT<T, LG>;
+  constexpr int L = F::L, TPF = F::TPF;
+  const int b = blockIdx.y;
+  const int idx = blockIdx.x * 256 + threadIdx.x;
+  const double wy = kl[2 * b + 1];
+  if (idx < L) {
+    // G_b[k] = sum_m g(m) exp(-2 pi i (wy + k / L) m) over the signed lags: real, g even
+    const int i = idx / TPF, t = idx % TPF;
+    const int kbin = F::spec_index(t, i);
+    const double fq = wy + (double)kbin / (double)L;
+    double acc = 0;
+    for (int m = Etab; m >= 1; --m) {
+      const double ph = fq * (double)m;
+      acc += taps[m] * cospi(2.0 * (ph - rint(ph)));
+    }
+    Gb[(size_t)b * L + idx] = (T)((taps[0] + 2.0 * acc) / (double)L);
+  }
+  if (idx < Epad) {
+    // (phi_b - [row is periodic]) exp(2 pi i wy (a0 + 1)),  phi_b = exp(-2 pi i wy n)
+    double ps, pc, qs, qc;
+    const double c0 = -wy * (double)n1, c1 = wy * (double)(idx + 1);
+    sincospi(2.0 * (c0 - rint(c0)), &ps, &pc);
+    sincospi(2.0 * (c1 - rint(c1)), &qs, &qc);
+    pc -= wrapped ? 1.0 : 0.0;
+    cpx<T> v = {(T)(pc * qc - ps * qs), (T)(pc * qs + ps * qc)};
+    if (idx >= E) v = {T(0), T(0)};
+    psi[(size_t)b * Epad + idx] = v;
+  }
+  if (b % K == 0 && idx < n1) dyc[(size_t)(b / K) * n1 + idx] = unit_phasor_s<T>(kr[2 * b + 1] * (double)idx);
+}
+
+template <class T, int LG>
+static hipError_t run_shared_tables(const Axis& a1, const double* kl, const double* kr, const double* taps, int Etab, int E,
+                                    int Epad, int B, int K, const PassBSharedTables& st, hipStream_t s) {
+  int len = a1.L > a1.n ? a1.L : a1.n;
+  if (len < Epad) len = Epad;
+  dim3 grid((len + 255) / 256, B);
+  shared_tables_kernel<T, LG><<<grid, 256, 0, s>>>(kl, kr, taps, Etab, a1.n, E, Epad, a1.padded ? 0 : 1, K, (T*)st.Gb,
+                                                   (cpx<T>*)st.psi, (cpx<T>*)st.dyc);
+  return hipGetLastError();
+}
+
+hipError_t launch_shared_tables(int dtype, const Axis& a1, const double* kl, const double* kr, const double* taps, int Etab,
+                                int E, int Epad, int B, int K, const PassBSharedTables& st, hipStream_t s) {
+#define CASE_T(LG)                                                                                              \
+  case LG:                                                                                                      \
+    return dtype == 0 ? run_shared_tables<float, LG>(a1, kl, kr, taps, Etab, E, Epad, B, K, st, s)             \
+                      : run_shared_tables<double, LG>(a1, kl, kr, taps, Etab, E, Epad, B, K, st, s);
+  switch (a1.lg) { CASE_T(10) CASE_T(11) CASE_T(12) }
+#undef CASE_T
+  return hipErrorInvalidValue;
+}
+
+template <class T, int LG, bool PADDED>
+static hipError_t run_passB_shared(const Axis& a1, int n0, const void* Tbuf, const void* tw1, const SweepTables& tb,
+                                   const PassBSharedTables& st, int E, int Epad, int P, int K, void* out, int32_t* kidx,
+                                   hipStream_t s, int nimg, int Bx) {
+  using G = PassBSGeom<T, LG>;
+  const size_t lds = G::lds_bytes(Epad);
+  if (lds > 160 * 1024 || E > G::TPF || Epad > G::TPF) return hipErrorInvalidValue;
+  auto kern = passB_shared_kernel<T, LG, PADDED>;
+  // (the dynamic LDS size depends on Epad: raise the limit whenever a larger one comes along)
+  static int lds_set[32] = {0};
+  int dev = 0;
+  (void)hipGetDevice(&dev);
+  if (lds_set[dev & 31] < (int)lds) {
+    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    if (e != hipSuccess) return e;
+    lds_set[dev & 31] = (int)lds;
+  }
+  dim3 grid((n0 + G::NF - 1) / G::NF, P * nimg);
+  GPA_PROF("passB_shared_kernel", s);
+  kern<<<grid, G::THREADS, lds, s>>>((const cpx<T>*)Tbuf, n0, a1.n, (const T*)st.Gb, (const cpx<T>*)tw1, tb.planeof, st.desc,
+                                     (const cpx<T>*)tb.cyb, (const cpx<T>*)st.psi, (const T*)st.gtab, (const cpx<T>*)tb.dx,
+                                     (const cpx<T>*)st.dyc, K, E, Epad, (cpx<T>*)out, kidx, P, Bx);
+  return hipGetLastError();
+}
+
+bool passB_shared_supports(int dtype, const Axis& a1, int E) {
+  if (a1.lg < 10 || a1.lg > 12) return false;
+  const int tpf = a1.L / 16;
+  const int Epad = (E + 15) & ~15;
+  if (E < 1 || Epad > tpf || 2 * E > a1.n) return false;
+  if (a1.padded && a1.n + E > a1.L) return false;
+  const size_t csz = dtype == 0 ? 8 : 16;
+  const int nf = tpf >= 256 ? 1 : 256 / tpf, nc = dtype == 0 ? 4 : 2;
+  const size_t stage = dtype == 0 ? 3 * nc * (size_t)Epad : 0;
+  const size_t lds = (nf * ((size_t)(a1.L + a1.L / 16) + (dtype == 0 ? 4 : 2) * (size_t)Epad + 2 * nc * (size_t)Epad + stage) + 16 * 6) * csz +
+                     (2 * (size_t)Epad + 16) * (csz / 2);
+  return lds <= 160 * 1024;
+}
+
+hipError_t launch_passB_shared(int dtype, const Axis& a1, int n0, const void* Tbuf, const void* tw1, const SweepTables& tb,
+                               const PassBSharedTables& st, int E, int Epad, int P, int K, void* out, int32_t* kidx,
+                               hipStream_t s, int nimg, int Bx) {
+#define CALL_S(T, LG) \
+  (a1.padded ? run_passB_shared<T, LG, true>(a1, n0, Tbuf, tw1, tb, st, E, Epad, P, K, out, kidx, s, nimg, Bx) \
+             : run_passB_shared<T, LG, false>(a1, n0, Tbuf, tw1, tb, st, E, Epad, P, K, out, kidx, s, nimg, Bx))
+#define CASE_S(LG) \
+  case LG: return dtype == 0 ? CALL_S(float, LG) : CALL_S(double, LG);
+  switch (a1.lg) { CASE_S(10) CASE_S(11) CASE_S(12) }
+#undef CASE_S
+#undef CALL_S
+  return hipErrorInvalidValue;
+}
+
+}  // namespace gpa

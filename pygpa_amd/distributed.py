@@ -144,12 +144,12 @@ def _tiled_device(image, kvecs, klists, sigma, halo, kmax, dtype, device, group,
     plan_w = _lib.get_plan(wshape, P * K, dtype, device)
     img = np.ascontiguousarray(image, dtype=dtype)
     if not use_torch:
-        d_img = _lib.DeviceBuffer(img.nbytes)
+        d_img = _lib.DeviceBuffer(img.nbytes, device)
         d_img.upload(img)
         mean = plan_w.mean_dev(d_img.ptr, npx)
-        gdx = _lib.DeviceBuffer(2 * n0 * (n1 - 1) * rsz)
-        gdy = _lib.DeviceBuffer(2 * (n0 - 1) * n1 * rsz)
-        gw = _lib.DeviceBuffer(npx * rsz)
+        gdx = _lib.DeviceBuffer(2 * n0 * (n1 - 1) * rsz, device)
+        gdy = _lib.DeviceBuffer(2 * (n0 - 1) * n1 * rsz, device)
+        gw = _lib.DeviceBuffer(npx * rsz, device)
         for (i, j), (w0, w1), (o0, o1), (z0, z1) in tiles:
             gi, gj = i * t0, j * t1
             plan_w.tile_gradients_dev(d_img.ptr, n1, w0.start, w1.start, mean, kvecs, klists, sigma, border,
@@ -160,7 +160,7 @@ def _tiled_device(image, kvecs, klists, sigma, halo, kmax, dtype, device, group,
         plan_w.sync()
         d_img.free()
         plan_g = _lib.get_plan(image.shape, 1, dtype, device)
-        d_u = _lib.DeviceBuffer(2 * npx * rsz)
+        d_u = _lib.DeviceBuffer(2 * npx * rsz, device)
         for c in range(2):
             plan_g.unwrap_prediff_dev(gdx.ptr + c * n0 * (n1 - 1) * rsz, gdy.ptr + c * (n0 - 1) * n1 * rsz, gw.ptr,
                                       d_u.ptr + c * npx * rsz, kmax=kmax)
