@@ -82,6 +82,8 @@ def kernel_models(n0, n1, L0, L1, P, K, Bx, s, iters):
         'passA_kernel': {'bytes': px * (s + 2 * s * Bx), 'flops': Bx * n1 * (2 * fft(L0) + 8 * L0)},
         # every x-plane in once (the K/Bx-fold re-reads of a plane are served by L2), P winners out
         'passB_kernel': {'bytes': px * (2 * s * Bx + 2 * s * P), 'flops': B * n0 * (2 * fft(L1) + 16 * L1)},
+        # the same traffic with ONE forward transform per x-plane row (Bx) and one inverse per candidate (B)
+        'passB_shared_kernel': {'bytes': px * (2 * s * Bx + 2 * s * P), 'flops': n0 * ((Bx + B) * fft(L1) + B * 10 * L1)},
         # P lock-ins in; wnorm, r0 of both components out
         'reconstruct_setup_kernel': {'bytes': px * (2 * s * P + 3 * s), 'flops': None},
         # per working launch and component: q, R in, R out / R in, Z out / Z, p in, p out / p, w in, q out
@@ -212,49 +214,55 @@ def load_counters():
         return {}
 
 
-def single_gpu(args):
+def measure(n, knx, kny, np_dt, kmax, steps, warmup, depth=1, profile=True):
+    """One configuration on GPU 0: timed loop with the D2H of u, the same loop with u left in HBM, and (profile) the
+    per-kernel HIP-event table with the roofline of the dominant kernel."""
     from pygpa_amd.synthetic import hex_kvecs, explicit_klists
-    n = args.size
-    knx, kny = (int(v) for v in args.kgrid.split('x')) if args.kgrid else (args.kside, args.kside)
     P, K = 3, knx * kny
     kvecs = hex_kvecs(0.1, 7.0)
     sigma = int(np.ceil(1 / np.linalg.norm(kvecs, axis=1).min()))
     kw = np.linalg.norm(kvecs, axis=1).mean() / 2.5
     klists = np.stack(explicit_klists(kvecs, kw, knx, kny))
     Bx = sum(len(np.unique(kl[:, 0])) for kl in klists)
-    np_dt = np.float32 if args.dtype == 'f32' else np.float64
-    s = 4 if args.dtype == 'f32' else 8
-
-    g = SingleGPU(n, P, K, np_dt, kvecs, klists, sigma, args.kmax, depth=args.inflight)
-    dt = g.timed(args.steps, args.warmup, download=True)
+    s = np.dtype(np_dt).itemsize
+    g = SingleGPU(n, P, K, np_dt, kvecs, klists, sigma, kmax, depth=depth)
+    dt = g.timed(steps, warmup, download=True)
     iters = g.plan.last_iters()
-    dt_res = g.timed(args.steps, 1, download=False)
-    stage, kern = g.profile()
-    L0, L1 = g.plan.fft_len(0), g.plan.fft_len(1)
+    dt_res = g.timed(steps, 1, download=False)
+    res = {'n': n, 'P': P, 'K': K, 'Bx': int(Bx), 'sigma': sigma, 'kvecs': kvecs, 'klists': klists, 'iters': list(iters),
+           'value': round(n * n * steps / dt / 1e6, 2), 'ms_per_step': round(dt / steps * 1e3, 4),
+           'resident_value': round(n * n * steps / dt_res / 1e6, 2), 'resident_ms': round(dt_res / steps * 1e3, 4),
+           'depth': g.depth}
+    if np_dt is np.float32:
+        # the reference's iteration count: the f32 residual floor (a stopping test of THIS build, DESIGN 2.6) switched
+        # off, i.e. kmax iterations per component as the reference runs -- read per solve, so the same plans serve
+        os.environ['GPA_F32_EPS_FLOOR'] = '0'
+        try:
+            dtf = g.timed(steps, 1, download=True)
+            res['forced_iters'] = {'value': round(n * n * steps / dtf / 1e6, 2), 'ms_per_step': round(dtf / steps * 1e3, 4),
+                                   'unwrap_iters': list(g.plan.last_iters()),
+                                   'note': 'GPA_F32_EPS_FLOOR=0: the PCG runs the reference\'s iteration count (no f32 '
+                                           'residual floor); same step, D2H of u included'}
+        finally:
+            del os.environ['GPA_F32_EPS_FLOOR']
+    if profile:
+        stage, kern = g.profile()
+        L0, L1 = g.plan.fft_len(0), g.plan.fft_len(1)
+        res.update(kernel_table(n, L0, L1, P, K, Bx, s, iters, kern, stage, dt_res / steps))
     g.close()
+    return res
 
-    ms_per_step = dt / args.steps * 1e3
-    out = {
-        'metric': 'Mpixels/s displacement-field extraction (3 peaks, 4096^2 img) + achieved HBM GB/s',
-        'value': round(n * n * args.steps / dt / 1e6, 2),
-        'unit': 'Mpixels/s',
-        'n_gpus': 1, 'steps': args.steps, 'warmup': args.warmup,
-        'ms_per_step': round(ms_per_step, 4),
-        'higher_is_better': True, 'scaling': 'weak', 'vs_baseline': None,
-        'dtype': args.dtype, 'data': 'synthetic',
-        'config': {'workload': '%dx%d synthetic hex moire, 3 Bragg peaks x %d k-vectors, sigma=%d, weighted DCT-PCG '
-                               'unwrap kmax=%d, image resident in HBM, u downloaded to pinned host memory inside the '
-                               'step (BASELINE.json configs[2])' % (n, n, K, sigma, args.kmax),
-                   'image': [n, n], 'peaks': P, 'kvectors_per_peak': K, 'x_planes': int(Bx),
-                   'unwrap_iters': list(iters), 'd2h_of_u': 'included, overlapped with the next step (copy stream)',
-                   'images_in_flight': g.depth},
-        'resident_only': {'value': round(n * n * args.steps / dt_res / 1e6, 2), 'ms_per_step': round(dt_res / args.steps * 1e3, 4),
-                          'note': 'same loop with u left in HBM (round-1 definition)'},
-    }
 
-    # ---- per-kernel table: HIP-event time (serial run of the step), the bound the counters show, fractions of peak
+def kernel_table(n, L0, L1, P, K, Bx, s, iters, kern, stage, res_s):
+    """per-kernel table: HIP-event time (serial run of the step), the bound the counters show, fractions of peak; the
+    roofline object of the dominant kernel; whole-step traffic figures"""
+    out = {}
     models = kernel_models(n, n, L0, L1, P, K, Bx, s, iters)
     counters = load_counters()
+    meta = counters.get('_meta', {})
+    same_cfg = meta.get('config', {'n': 4096, 'K': 16, 'dtype': 'f32'}) == {'n': n, 'K': K, 'dtype': 'f32' if s == 4 else 'f64'}
+    if not same_cfg:
+        counters = {}      # the committed counters belong to ONE configuration (their _meta says which)
     work = {'rowdct_fused_kernel': sum(iters), 'rowidct_p_kernel': sum(iters), 'pq_kernel': sum(iters),
             'rowidct_pq_kernel': sum(iters), 'colsolve_kernel': sum(iters)}   # launches that do work (those after convergence return at once)
     table = {}
@@ -277,7 +285,7 @@ def single_gpu(args):
         if c.get('valu_insts'):
             row['valu_issue_frac'] = round(c['valu_insts'] / per / VALU_ISSUE_PEAK, 4)
         fr = {'hbm': row.get('hbm_frac', (m['bytes'] / per / 1e9 / HBM_PEAK_GBS) if m.get('bytes') else 0.0),
-              'valu': row.get('valu_issue_frac', 0.0)}
+              'valu': row.get('valu_issue_frac', (m['flops'] / per / 1e12 / VALU_PEAK_TFLOPS) if m.get('flops') else 0.0)}
         row['bound'] = max(fr, key=fr.get)
         table[name] = row
     out['kernels'] = table
@@ -285,42 +293,81 @@ def single_gpu(args):
         ['tables+mean', 'passA_kernel', 'passB_kernel', 'reconstruct_setup', 'unwrap(serial, both components)'], stage)}
 
     # ---- roofline of the dominant kernel (largest single launch): pass B, VALU-issue bound
-    dom = max((k for k in table if table[k]['launches'] <= 2), key=lambda k: table[k]['total_ms'], default='passB_kernel')
+    dom = max((k for k in table if table[k]['launches'] <= 2), key=lambda k: table[k]['total_ms'], default='passB_shared_kernel')
     drow, dm, dc = table[dom], models.get(dom, {}), counters.get(dom, {})
     dsec = drow['total_ms'] * 1e-3 / max(drow['working_launches'], 1)
+    src = {'clock': 'HIP events on the launch stream around every launch of the kernel, averaged over 3 profiled steps of '
+                    'this run (adds ~3 us per launch to what rocprofv3 --kernel-trace reports: profiles/)',
+           'counters': ('profiles/counters.json measured on commit %s, %s (%s)' % (meta.get('commit', '?'), meta.get('date', '?'),
+                                                                                meta.get('how', 'rocprofv3 --pmc passes')))
+                       if counters else 'none for this configuration (traffic: null)'}
     if drow['bound'] == 'valu' and dm.get('flops'):
         out['roofline'] = {'bound': 'valu', 'kernel': dom, 'achieved': round(dm['flops'] / dsec / 1e12, 2),
                            'peak': VALU_PEAK_TFLOPS, 'unit': 'TFLOP/s', 'frac': round(dm['flops'] / dsec / 1e12 / VALU_PEAK_TFLOPS, 4),
                            'traffic': dc.get('hbm_bytes'), 'kernel_ms': round(dsec * 1e3, 4),
                            'nominal_flops_per_launch': dm['flops'],
-                           'valu_issue_frac': drow.get('valu_issue_frac'),
-                           'note': 'f32 vector pipe, not MFMA: nominal 5 L log2 L flops per FFT over the HIP-event time; '
+                           'valu_issue_frac': drow.get('valu_issue_frac'), 'source': src,
+                           'note': 'f32 vector pipe (the transforms) beside a small f32 MFMA contraction (the end fix): nominal '
+                                   '5 L log2 L flops per transform THIS kernel executes over the HIP-event time; '
                                    'valu_issue_frac = counted VALU wave-instructions / (1024 SIMDs x 1 per 2 cycles x 2.4 GHz)'}
     else:
         ach = (dc.get('hbm_bytes') or dm.get('bytes') or 0) / dsec / 1e9
         out['roofline'] = {'bound': 'hbm', 'kernel': dom, 'achieved': round(ach, 1), 'peak': HBM_PEAK_GBS, 'unit': 'GB/s',
                            'frac': round(ach / HBM_PEAK_GBS, 4), 'traffic': dc.get('hbm_bytes'),
-                           'algorithmic_bytes_per_launch': dm.get('bytes'), 'kernel_ms': round(dsec * 1e3, 4)}
+                           'algorithmic_bytes_per_launch': dm.get('bytes'), 'kernel_ms': round(dsec * 1e3, 4), 'source': src}
     # whole step: the bytes this build's kernels must move / the bytes the counters saw / the survey's model
     step_alg = sum((models[k]['bytes'] or 0) * table[k]['working_launches'] for k in table if k in models)
     step_hbm = sum(counters[k]['hbm_bytes'] * table[k]['working_launches'] for k in table if counters.get(k, {}).get('hbm_bytes'))
-    res_s = dt_res / args.steps
     out['whole_step'] = {'algorithmic_GBps': round(step_alg / res_s / 1e9, 1),
                          'counter_GBps': round(step_hbm / res_s / 1e9, 1) if step_hbm else None,
                          'counter_frac_of_hbm_peak': round(step_hbm / res_s / 1e9 / HBM_PEAK_GBS, 4) if step_hbm else None,
                          'survey_model_GBps': round(survey_bytes(n, n, P, K, s, iters)['total'] / res_s / 1e9, 1),
                          'note': 'over the resident-only step time; survey_model = SURVEY.md 8(d) bytes of the reference '
                                  'algorithm (2-D FFT pairs, 19 arrays per PCG iteration), which this build does not move'}
+    return out
+
+
+def single_gpu(args):
+    n = args.size
+    knx, kny = (int(v) for v in args.kgrid.split('x')) if args.kgrid else (args.kside, args.kside)
+    np_dt = np.float32 if args.dtype == 'f32' else np.float64
+    m = measure(n, knx, kny, np_dt, args.kmax, args.steps, args.warmup, depth=args.inflight)
+    P, K, sigma, kvecs, klists = m['P'], m['K'], m['sigma'], m['kvecs'], m['klists']
+    out = {
+        'metric': 'Mpixels/s displacement-field extraction (3 peaks, 4096^2 img) + achieved HBM GB/s',
+        'value': m['value'],
+        'unit': 'Mpixels/s',
+        'n_gpus': 1, 'steps': args.steps, 'warmup': args.warmup,
+        'ms_per_step': m['ms_per_step'],
+        'higher_is_better': True, 'scaling': 'weak', 'vs_baseline': None,
+        'dtype': args.dtype, 'data': 'synthetic',
+        'config': {'workload': '%dx%d synthetic hex moire, 3 Bragg peaks x %d k-vectors, sigma=%d, weighted DCT-PCG '
+                               'unwrap kmax=%d, image resident in HBM, u downloaded to pinned host memory inside the '
+                               'step (BASELINE.json configs[2])' % (n, n, K, sigma, args.kmax),
+                   'image': [n, n], 'peaks': P, 'kvectors_per_peak': K, 'x_planes': m['Bx'],
+                   'unwrap_iters': m['iters'], 'd2h_of_u': 'included, overlapped with the next step (copy stream)',
+                   'images_in_flight': m['depth']},
+        'resident_only': {'value': m['resident_value'], 'ms_per_step': m['resident_ms'],
+                          'note': 'same loop with u left in HBM (round-1 definition)'},
+    }
+    for key in ('forced_iters', 'kernels', 'stage_ms', 'roofline', 'whole_step'):
+        if key in m:
+            out[key] = m[key]
 
     if not args.no_f64 and args.dtype == 'f32':
-        g64 = SingleGPU(n, P, K, np.float64, kvecs, klists, sigma, args.kmax)
         k64 = max(3, args.steps // 4)
-        dt64 = g64.timed(k64, 1, download=True)
-        it64 = g64.plan.last_iters()
-        g64.close()
-        out['f64'] = {'value': round(n * n * k64 / dt64 / 1e6, 2), 'unit': 'Mpixels/s', 'ms_per_step': round(dt64 / k64 * 1e3, 4),
-                      'steps': k64, 'unwrap_iters': list(it64), 'note': 'the reference computes in complex128; same step, D2H of u included'}
-    if not args.no_f64 and args.dtype == 'f32' and n == 4096:
+        m64 = measure(n, knx, kny, np.float64, args.kmax, k64, 1, profile=False)
+        out['f64'] = {'value': m64['value'], 'unit': 'Mpixels/s', 'ms_per_step': m64['ms_per_step'],
+                      'steps': k64, 'unwrap_iters': m64['iters'], 'note': 'the reference computes in complex128; same step, D2H of u included'}
+    if not args.no_f64 and args.dtype == 'f32' and n == 4096 and not args.kgrid:
+        # BASELINE.json configs[1] (2048^2, 3 peaks x 8 k-vectors as the survey's 4 x 2 list, f32) in the same run
+        c2 = measure(2048, 4, 2, np.float32, args.kmax, max(10, args.steps), 3)
+        out['config2'] = {'workload': '2048x2048 synthetic hex moire, 3 Bragg peaks x 8 k-vectors (4 x 2 list), f32, kmax=%d, '
+                                      'D2H of u included (BASELINE.json configs[1])' % args.kmax,
+                          'value': c2['value'], 'unit': 'Mpixels/s', 'ms_per_step': c2['ms_per_step'],
+                          'resident_only': c2['resident_value'], 'unwrap_iters': c2['iters'],
+                          'forced_iters': c2.get('forced_iters'), 'roofline': c2['roofline'], 'whole_step': c2['whole_step'],
+                          'kernels_ms': {k: v['total_ms'] for k, v in c2['kernels'].items()}}
         out['small_image_stacks'] = small_image_stacks(kvecs, klists, sigma, args.kmax)
     if not args.no_cpu:
         out['cpu_baseline'] = cpu_baseline(kvecs, sigma, knx, kny, args.kmax, n)

@@ -55,6 +55,12 @@ template <class T> struct upair { T u, v; };
 #ifndef GPA_PBS_NOFIX
 #define GPA_PBS_NOFIX 0     // diagnosis only: skip the end fix (wrong results at the row ends)
 #endif
+#ifndef GPA_PBS_NOB2
+#define GPA_PBS_NOB2 0      // experiment: no barrier before the last (intra-wavefront) exchange of the inverse
+#endif
+#ifndef GPA_PBS_EXECSTORE
+#define GPA_PBS_EXECSTORE 0  // experiment: winners stored under the EXEC mask instead of through dropped offsets
+#endif
 #ifndef GPA_PBS_NOSTORE
 #define GPA_PBS_NOSTORE 0   // diagnosis only: skip the winner stores
 #endif
@@ -111,8 +117,11 @@ struct PassBSGeom {
   static constexpr int SV = sizeof(T) == 4 ? 4 : 2;
   // per-row LDS in complex elements: transform image | end strips [end][re/im variant][Epad] | results [NC][end][Epad]
   // | staged pre-factors [NC][Epad] | staged post-factors [2][NC][Epad] (double-buffered by chunk parity)
+  // (rows of these small tables are ES = Epad + 4 elements apart: with a stride of Epad * 8 bytes, a multiple of the
+  //  256-byte bank period, the 4 - 8 rows a matrix-pass instruction touches would all sit on the same banks)
   __host__ __device__ static size_t row_elems(int Epad) {
-    return (size_t)F::LDS_ELEMS + SV * (size_t)Epad + 2 * NC * (size_t)Epad + (STAGE ? 3 * NC * (size_t)Epad : 0);
+    const size_t ES = (size_t)Epad + 4;
+    return (size_t)F::LDS_ELEMS + SV * ES + 2 * NC * ES + (STAGE ? 3 * NC * ES : 0);
   }
   __host__ __device__ static size_t lds_bytes(int Epad) {
     return (NF * row_elems(Epad) + T1) * sizeof(cpx<T>) + (2 * (size_t)Epad + 16) * sizeof(T);
@@ -142,9 +151,10 @@ __global__ __launch_bounds__((PassBSGeom<T, LG>::THREADS), (sizeof(T) == 8 ? GPA
   const int tid = threadIdx.x % TPF, f = __builtin_amdgcn_readfirstlane(threadIdx.x / TPF);
   cpx<T>* lds = reinterpret_cast<cpx<T>*>(smem) + (size_t)f * G::row_elems(Epad);
   upair<T>* strip = reinterpret_cast<upair<T>*>(lds + F::LDS_ELEMS);
-  cpx<T>* fixb = lds + F::LDS_ELEMS + G::SV * Epad;
-  cpx<T>* pre_l = fixb + 2 * NC * Epad;          // [NC][Epad]       (STAGE)
-  cpx<T>* psi_l = pre_l + NC * Epad;             // [2][NC][Epad]    (STAGE)
+  const int ES = Epad + 4;                       // row stride of the small tables
+  cpx<T>* fixb = lds + F::LDS_ELEMS + G::SV * ES;
+  cpx<T>* pre_l = fixb + 2 * NC * ES;            // [NC][ES]       (STAGE)
+  cpx<T>* psi_l = pre_l + NC * ES;               // [2][NC][ES]    (STAGE)
   cpx<T>* t1 = reinterpret_cast<cpx<T>*>(smem) + (size_t)G::NF * G::row_elems(Epad);
   T* glds = reinterpret_cast<T*>(t1 + G::T1);
   const int row = blockIdx.x * G::NF + f;
@@ -198,13 +208,13 @@ __global__ __launch_bounds__((PassBSGeom<T, LG>::THREADS), (sizeof(T) == 8 ? GPA
         const cpx<T> s0 = in ? X[0] : cpx<T>{T(0), T(0)};
         const cpx<T> s1 = in ? cmul(tail, cs) : cpx<T>{T(0), T(0)};
         if constexpr (G::SV == 4) {
-          strip[0 * Epad + tid] = {s0.x, -s0.y};   // end 0, real part of t p
-          strip[1 * Epad + tid] = {s0.y, s0.x};    // end 0, imaginary part
-          strip[2 * Epad + tid] = {s1.x, s1.y};    // end 1, real part of t conj(p)
-          strip[3 * Epad + tid] = {s1.y, -s1.x};   // end 1, imaginary part
+          strip[0 * ES + tid] = {s0.x, -s0.y};   // end 0, real part of t p
+          strip[1 * ES + tid] = {s0.y, s0.x};    // end 0, imaginary part
+          strip[2 * ES + tid] = {s1.x, s1.y};    // end 1, real part of t conj(p)
+          strip[3 * ES + tid] = {s1.y, -s1.x};   // end 1, imaginary part
         } else {
-          strip[0 * Epad + tid] = {s0.x, s0.y};
-          strip[1 * Epad + tid] = {s1.x, s1.y};
+          strip[0 * ES + tid] = {s0.x, s0.y};
+          strip[1 * ES + tid] = {s1.x, s1.y};
         }
       }
       F::forward(X, lds, tid, tw);
@@ -224,8 +234,8 @@ __global__ __launch_bounds__((PassBSGeom<T, LG>::THREADS), (sizeof(T) == 8 ? GPA
           const int nc = (d >> 4) & 7;
           for (int e = tid; e < NC * Epad; e += TPF) {
             const int c = e / Epad, j = e - c * Epad, cc = c < nc ? c : nc - 1;
-            pre_l[e] = cyb[(size_t)(b + cc) * TPF + j];
-            psi_l[(size_t)par * NC * Epad + e] = psi[(size_t)(b + cc) * Epad + j];
+            pre_l[c * ES + j] = cyb[(size_t)(b + cc) * TPF + j];
+            psi_l[(par * NC + c) * ES + j] = psi[(size_t)(b + cc) * Epad + j];
           }
         }
       }
@@ -247,8 +257,8 @@ __global__ __launch_bounds__((PassBSGeom<T, LG>::THREADS), (sizeof(T) == 8 ? GPA
       const int nc = (d >> 4) & 7;
       const int n = lane & 15, kq = lane >> 4;
       const int c = (n >> 1) & (NC - 1), end = (n >> (1 + G::LOGNC)) & 1, reim = n & 1;
-      const cpx<T>* pre = STAGE ? pre_l + c * Epad : cyb + (size_t)(b + (c < nc ? c : nc - 1)) * TPF;
-      const upair<T>* sp = strip + (G::SV == 4 ? end * 2 + reim : end) * Epad;
+      const cpx<T>* pre = STAGE ? pre_l + c * ES : cyb + (size_t)(b + (c < nc ? c : nc - 1)) * TPF;
+      const upair<T>* sp = strip + (G::SV == 4 ? end * 2 + reim : end) * ES;
       // (two-strip form: u, v and the sign of v picked per lane)
       const bool swp = reim != 0;
       const T sgn = (end == 0) == swp ? T(1) : T(-1);
@@ -286,21 +296,23 @@ __global__ __launch_bounds__((PassBSGeom<T, LG>::THREADS), (sizeof(T) == 8 ? GPA
 #pragma unroll
           for (int r = 0; r < 4; ++r) {
             const int a0 = 16 * mt + mfma_row<T>(kq, r);
-            reinterpret_cast<T*>(fixb + (size_t)(c * 2 + end) * Epad + a0)[reim] = acc0[r] + acc1[r];
+            reinterpret_cast<T*>(fixb + (c * 2 + end) * ES + a0)[reim] = acc0[r] + acc1[r];
           }
         }
       }
     }
     F::template inv_phase<1>(y, lds, tid, tw);
+#if !GPA_PBS_NOB2
     __syncthreads();
+#endif
     F::template inv_phase<2>(y, lds, tid, tw);
     // ---- the outputs within E of either end get their wrapped pairs ------------------------------------------
 #if !GPA_PBS_NOFIX
     {
       const int c = (d >> 2) & 3;
-      const cpx<T>* pl = psi_l + (size_t)(par * NC + c) * Epad;
+      const cpx<T>* pl = psi_l + (par * NC + c) * ES;
       if (tid < E) {
-        const cpx<T> fx = fixb[(size_t)(c * 2 + 1) * Epad + tid];
+        const cpx<T> fx = fixb[(c * 2 + 1) * ES + tid];
         if constexpr (STAGE) psL = pl[tid];
         const cpx<T> t = cmulc(fx, psL);
         y[0].x += t.x;
@@ -308,7 +320,7 @@ __global__ __launch_bounds__((PassBSGeom<T, LG>::THREADS), (sizeof(T) == 8 ? GPA
       }
       if constexpr (!PADDED) {
         if (a0R < E) {
-          const cpx<T> fx = fixb[(size_t)(c * 2 + 0) * Epad + a0R];
+          const cpx<T> fx = fixb[(c * 2 + 0) * ES + a0R];
           if constexpr (STAGE) psR = pl[a0R];
           const cpx<T> t = cmul(fx, psR);
           y[15].x += t.x;
@@ -320,7 +332,7 @@ __global__ __launch_bounds__((PassBSGeom<T, LG>::THREADS), (sizeof(T) == 8 ? GPA
           if (i == iA || i == iB) {
             const int a0 = n1 - 1 - (tid + TPF * i);
             if (a0 >= 0 && a0 < E) {
-              const cpx<T> fx = fixb[(size_t)(c * 2 + 0) * Epad + a0];
+              const cpx<T> fx = fixb[(c * 2 + 0) * ES + a0];
               const cpx<T> ps = STAGE ? pl[a0] : psi[(size_t)b * Epad + a0];
               const cpx<T> t = cmul(fx, ps);
               y[i].x += t.x;
@@ -346,7 +358,10 @@ __global__ __launch_bounds__((PassBSGeom<T, LG>::THREADS), (sizeof(T) == 8 ? GPA
       ab[i] = win ? a : ab[i];
       // (byte offset; OOB = 0x80000000 stays out of range after the arithmetic shift below, never multiply it)
       const int woff = (win && valid && (!PADDED || yy < n1)) ? tid * (int)sizeof(cpx<T>) : OOB;
-#if !GPA_PBS_NOSTORE
+#if GPA_PBS_EXECSTORE
+      if (woff != OOB) store_cpx(y[i], orow, woff, i * TPF * (int)sizeof(cpx<T>));
+      if (kidx && woff != OOB) __builtin_amdgcn_raw_buffer_store_b32(k, krow, woff >> (sizeof(cpx<T>) == 8 ? 1 : 2), i * TPF * 4, 0);
+#elif !GPA_PBS_NOSTORE
       store_cpx(y[i], orow, woff, i * TPF * (int)sizeof(cpx<T>));
       constexpr int SH = sizeof(cpx<T>) == 8 ? 1 : 2;   // complex byte offset -> int32 byte offset
       if (kidx) __builtin_amdgcn_raw_buffer_store_b32(k, krow, woff >> SH, i * TPF * 4, 0);
@@ -481,8 +496,9 @@ bool passB_shared_supports(int dtype, const Axis& a1, int E) {
   if (a1.padded && a1.n + E > a1.L) return false;
   const size_t csz = dtype == 0 ? 8 : 16;
   const int nf = tpf >= 256 ? 1 : 256 / tpf, nc = dtype == 0 ? 4 : 2;
-  const size_t stage = dtype == 0 ? 3 * nc * (size_t)Epad : 0;
-  const size_t lds = (nf * ((size_t)(a1.L + a1.L / 16) + (dtype == 0 ? 4 : 2) * (size_t)Epad + 2 * nc * (size_t)Epad + stage) + 16 * 6) * csz +
+  const size_t ES = (size_t)Epad + 4;
+  const size_t stage = dtype == 0 ? 3 * nc * ES : 0;
+  const size_t lds = (nf * ((size_t)(a1.L + a1.L / 16) + (dtype == 0 ? 4 : 2) * ES + 2 * nc * ES + stage) + 16 * 6) * csz +
                      (2 * (size_t)Epad + 16) * (csz / 2);
   return lds <= 160 * 1024;
 }

@@ -12,7 +12,7 @@ import json
 import os
 import sys
 
-SHORT = ['passA_kernel', 'passB_kernel', 'reconstruct_setup_kernel', 'rowdct_fused_kernel', 'colsolve_kernel',
+SHORT = ['passA_kernel', 'passB_shared_kernel', 'passB_kernel', 'reconstruct_setup_kernel', 'rowdct_fused_kernel', 'colsolve_kernel',
          'rowidct_p_kernel', 'pq_kernel', 'phi_flush_kernel', 'mean_partial_kernel']
 acc = collections.defaultdict(lambda: collections.defaultdict(list))
 for d in sys.argv[2:]:
@@ -20,9 +20,10 @@ for d in sys.argv[2:]:
         for r in csv.DictReader(open(f)):
             for s in SHORT:
                 if s in r['Kernel_Name']:
-                    if s == 'passB_kernel' and 'float' not in r['Kernel_Name']:
+                    if s in ('passB_kernel', 'passB_shared_kernel') and 'float' not in r['Kernel_Name']:
                         continue
                     acc[s][r['Counter_Name']].append(float(r['Counter_Value']))
+                    break
 out = {}
 for k, cs in acc.items():
     row = {}
@@ -41,11 +42,16 @@ for k, cs in acc.items():
     if 'TCC_HIT_sum' in m and 'TCC_MISS_sum' in m:
         row['l2_requests'] = int(m['TCC_HIT_sum'] + m['TCC_MISS_sum'])
         row['l2_hit_rate'] = round(m['TCC_HIT_sum'] / max(m['TCC_HIT_sum'] + m['TCC_MISS_sum'], 1), 4)
-    for c in ('SQ_WAVES', 'SQ_INSTS_LDS', 'SQ_LDS_BANK_CONFLICT', 'SQ_LDS_IDX_ACTIVE', 'SQ_WAVE_CYCLES', 'SQ_WAIT_INST_ANY', 'SQ_BUSY_CYCLES', 'SQ_ACTIVE_INST_VALU', 'GRBM_GUI_ACTIVE'):
+    for c in ('SQ_WAIT_ANY', 'SQ_ACTIVE_INST_ANY', 'SQ_INSTS_VALU_MFMA_F32', 'SQ_INSTS_VMEM_WR', 'SQ_INSTS_VMEM_RD', 'SQ_WAVES', 'SQ_INSTS_LDS', 'SQ_LDS_BANK_CONFLICT', 'SQ_LDS_IDX_ACTIVE', 'SQ_WAVE_CYCLES', 'SQ_WAIT_INST_ANY', 'SQ_BUSY_CYCLES', 'SQ_ACTIVE_INST_VALU', 'GRBM_GUI_ACTIVE'):
         if c in m:
             row[c] = int(m[c])
     out[k] = row
 out['_note'] = ('per WORKING launch, rocprofv3 --pmc separate passes of `python bench.py --no-cpu --no-f64` (4096^2, 3x16, f32); '
                 'hbm_bytes = (2 x FETCH_SIZE + WRITE_SIZE) KB x 1024 (FETCH_SIZE doubled per MI355X_MICROARCH.md for gfx950)')
+import datetime
+out['_meta'] = {'commit': os.environ.get('COMMIT', 'unknown'), 'date': datetime.date.today().isoformat(),
+                'config': {'n': int(os.environ.get('PMC_SIZE', '4096')), 'K': int(os.environ.get('PMC_K', '16')),
+                           'dtype': os.environ.get('PMC_DTYPE', 'f32')},
+                'how': 'rocprofv3 --pmc, one pass per counter set, bench.py --steps 2 --warmup 1 --no-cpu --no-f64'}
 json.dump(out, open(sys.argv[1], 'w'), indent=1, sort_keys=True)
 print(json.dumps(out, indent=1, sort_keys=True))
