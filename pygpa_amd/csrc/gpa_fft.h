@@ -326,7 +326,10 @@ struct WgFFT {
     for (int e = thread; e < P1_SETS * 6; e += nthreads) {
       const int m0 = e / 6, c = e % 6;
       const int u = m0 << (LOG2L - lgLp);
-      t1[e] = table[c < 3 ? u * (c + 1) : u * 4 * (c - 2)];
+      // (a radix-8 pass uses w^1..w^4 only: the other exponents would reach past the table)
+      constexpr int r1 = 1 << bits(1);
+      const int ex = c < 3 ? c + 1 : 4 * (c - 2);
+      t1[e] = ex < r1 ? table[u * ex] : cpx<T>{T(1), T(0)};
     }
   }
   GPA_HD static void load_twiddles(TwiddlesP1Lds& tw, const cpx<T>* __restrict__ table, int tid, const cpx<T>* t1) {

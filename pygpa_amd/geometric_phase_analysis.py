@@ -158,25 +158,40 @@ def wfr4(image, sigma, klist, kref, dk, dtype=None):
 
 
 def generate_klists(pks, dk=None, kmax=1.9, kmin=0.2, sort_list=False):
-    """Candidate lists for wfr3 / wfr4 (geometric_phase_analysis.py:865-889): for every peak the points of the
-    0.005-spaced k-grid inside the ring kmin..kmax (times the largest |k|) that are closer to this peak than to
-    any other peak or its negative; optionally sorted by distance from the peak.  Host bookkeeping."""
-    pks = np.asarray(pks, dtype=np.float64)
-    both = np.concatenate([pks, -pks])
-    longest = np.linalg.norm(pks, axis=1).max()
-    kmax, kmin = longest * kmax, longest * kmin
-    kk = np.mgrid[-kmax:kmax:0.005, -kmax:kmax:0.005]
-    dists = ((np.moveaxis(kk[..., None], 0, -1) - both) ** 2).sum(axis=-1)
-    r = (kk ** 2).sum(axis=0)
-    ring = (r < kmax ** 2) & (r > kmin ** 2)
-    nearest = dists.min(axis=-1)
-    klists = []
-    for i, pk in enumerate(pks):
-        klist = kk[:, ring & (nearest == dists[..., i])].T
+    """Candidate lists for wfr3 / wfr4 (geometric_phase_analysis.py:865-889).  A fixed 0.005-spaced k-grid covers the
+    square of half-width kmax * max|k|; a grid point goes to peak i when it lies in the ring kmin .. kmax (times
+    max|k|) and no peak or negated peak is strictly closer to it than peak i (so a point equidistant from two peaks
+    is in both lists).  Points come out in row-major grid order, or sorted by distance from the peak.
+
+    Built as a running nearest-site search over the 2 P sites on one (n x n) plane at a time -- the Voronoi cell of
+    each peak among {+k, -k} -- rather than a (n, n, 2 P) distance cube; `dk` is accepted and unused like in the
+    reference.  Host bookkeeping, pinned by tests/golden/variants_64.npz ('wfr4_ring') and tests/test_host_logic.py."""
+    sites = np.asarray(pks, dtype=np.float64).reshape(-1, 2)
+    npk = len(sites)
+    sites = np.vstack([sites, -sites])
+    scale = np.sqrt((sites[:npk] ** 2).sum(axis=1)).max()
+    outer, inner = scale * kmax, scale * kmin
+    step = 0.005
+    # the axis of np.mgrid[-outer:outer:step]: start + i * step
+    axis = np.arange(int(np.ceil((outer - (-outer)) / step))) * step + (-outer)
+    gx, gy = axis[:, None], axis[None, :]
+    rr = gx ** 2 + gy ** 2
+    keep = (rr < outer ** 2) & (rr > inner ** 2)
+
+    def dist2(site):
+        return (gx - site[0]) ** 2 + (gy - site[1]) ** 2
+
+    nearest = dist2(sites[0])
+    for site in sites[1:]:
+        np.minimum(nearest, dist2(site), out=nearest)
+    lists = []
+    for i in range(npk):
+        ix, iy = np.nonzero(keep & (dist2(sites[i]) == nearest))
+        pts = np.column_stack([axis[ix], axis[iy]])
         if sort_list:
-            klist = klist[np.argsort(np.linalg.norm(klist - pk, axis=1))]
-        klists.append(klist)
-    return klists
+            pts = pts[np.argsort(np.linalg.norm(pts - sites[i], axis=1))]
+        lists.append(pts)
+    return lists
 
 
 _NATIVE_SWEEPS = (optwfr2, wfr2_grad_opt)

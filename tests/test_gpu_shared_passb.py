@@ -1,0 +1,127 @@
+"""GPU parity of the shared-forward pass B (gpa_passb_shared.hip): one forward transform per x-plane row, a shifted
+real Gaussian per candidate and the exact end fix as a Hankel contraction on the matrix cores, against the oracle
+(`kidx` identical in f64) and against the per-candidate pass B it replaces (GPA_NO_SHARED=1).  The end fix acts on
+the first / last E ~ 6-8 sigma columns of every row: those are checked on their own.
+Semantics: geometric_phase_analysis.py:72-75 (lock-in), :679-684 (strict '>' in list order, compensation)."""
+import numpy as np
+import pytest
+
+from oracle import gpa_oracle as orc
+from pygpa_amd import _lib
+from pygpa_amd.synthetic import hex_kvecs, gaussian_bump_displacement, hex_moire, explicit_klists
+from test_gpu_parity import TOL, check_kidx, rel
+
+pytestmark = pytest.mark.gpu
+DTYPES = [np.float64, np.float32]
+
+
+def _case(shape, knx, kny, seed=5, noise=0.2, peak=1):
+    kvecs = hex_kvecs(0.1, 7.0)
+    img = hex_moire(shape, kvecs, gaussian_bump_displacement(shape), noise=noise, seed=seed)
+    img0 = img - img.mean()
+    kw, sigma, _ = orc.derive_params(kvecs)
+    klist = explicit_klists(kvecs, kw, knx, kny)[peak]
+    return img0, kvecs[peak], klist, sigma
+
+
+def _sweep(shape, dtype, img0, kref, klist, sigma):
+    plan = _lib.Plan(shape, len(klist), dtype)
+    lock, kidx, _ = plan.sweep(img0, kref, klist, sigma)
+    plan.close()
+    return lock, kidx
+
+
+@pytest.mark.parametrize('dtype', DTYPES)
+@pytest.mark.parametrize('shape,grid', [((96, 4096), (4, 4)), ((80, 2048), (4, 2)), ((72, 4096), (3, 7)), ((2304, 1024), (4, 4))])
+def test_shared_passb_vs_oracle_and_end_columns(shape, grid, dtype, monkeypatch):
+    """4096-, 2048- and (tall) 1024-wide sweeps: winner index identical to the oracle in f64 (up to exact amplitude
+    ties in f32), values within the lock-in tolerance everywhere AND in the first / last 3 sigma columns on their own;
+    grids of 4, 2 and 7 candidates per x-plane exercise whole and ragged chunks of the matrix pass."""
+    img0, kref, klist, sigma = _case(shape, *grid)
+    ref = orc.sweep(img0, sigma, klist, kref, workers=8)
+    lock, kidx = _sweep(shape, dtype, img0, kref, klist, sigma)
+    check_kidx(kidx, ref['kidx'], img0, klist, sigma, TOL[dtype]['tie'])
+    same = kidx == ref['kidx']
+    if dtype is np.float64:
+        assert same.all(), 'f64 winner index differs from the oracle at %d pixels' % int((~same).sum())
+    assert same.mean() > 0.9999
+    sc = np.abs(ref['lockin']).max()
+    d = np.where(same, np.abs(lock - ref['lockin']), 0) / sc
+    e3 = int(3 * sigma)
+    assert d.max() < TOL[dtype]['lock']
+    assert max(d[:, :e3].max(), d[:, -e3:].max()) < TOL[dtype]['lock']
+    # and the kernel it replaces gives the same numbers to rounding
+    monkeypatch.setenv('GPA_NO_SHARED', '1')
+    lock_old, kidx_old = _sweep(shape, dtype, img0, kref, klist, sigma)
+    both = kidx == kidx_old
+    assert both.mean() > 0.9999
+    assert (np.where(both, np.abs(lock - lock_old), 0) / sc).max() < 2 * TOL[dtype]['lock']
+
+
+@pytest.mark.parametrize('dtype', DTYPES)
+def test_shared_passb_wide_and_narrow_kernels(dtype):
+    """sigma changes the support E of the taps (and with it the matrix pass' shape); a sigma whose taps do not vanish
+    within a row's reach falls back to the per-candidate kernel -- either way the oracle's numbers"""
+    shape = (64, 2048)
+    kvecs = hex_kvecs(0.1, 7.0)
+    img = hex_moire(shape, kvecs, gaussian_bump_displacement(shape), noise=0.1, seed=2)
+    img0 = img - img.mean()
+    kw, _, _ = orc.derive_params(kvecs)
+    klist = explicit_klists(kvecs, kw, 4, 4)[0]
+    plan = _lib.Plan(shape, len(klist), dtype)
+    for sigma in (4.0, 10.0, 17.5, 40.0):
+        ref = orc.sweep(img0, sigma, klist, kvecs[0], workers=8)
+        lock, kidx, _ = plan.sweep(img0, kvecs[0], klist, sigma)
+        check_kidx(kidx, ref['kidx'], img0, klist, sigma, TOL[dtype]['tie'])
+        same = kidx == ref['kidx']
+        assert same.mean() > 0.999, sigma
+        assert rel(lock[same], ref['lockin'][same]) < TOL[dtype]['lock'], sigma
+    plan.close()
+
+
+@pytest.mark.parametrize('dtype', DTYPES)
+def test_shared_passb_list_orders(dtype):
+    """lists that are not wx-outer grids: a wy-outer list (runs of one candidate per x-plane: nothing to share, the
+    per-candidate kernel runs) and a list with a repeated x-plane run; the first maximum in LIST order wins"""
+    shape = (64, 2048)
+    img0, kref, klist, sigma = _case(shape, 4, 4, seed=9)
+    wy_outer = klist.reshape(4, 4, 2).transpose(1, 0, 2).reshape(-1, 2).copy()
+    split_runs = np.concatenate([klist[:2], klist[8:12], klist[2:4], klist[4:8], klist[12:]])
+    dup = np.concatenate([klist, klist[5:7]])          # exact amplitude ties: the earlier index must keep winning
+    for kl in (wy_outer, split_runs, dup):
+        ref = orc.sweep(img0, sigma, kl, kref, workers=8)
+        lock, kidx = _sweep(shape, dtype, img0, kref, kl, sigma)
+        if dtype is np.float64:
+            assert np.array_equal(kidx, ref['kidx'])
+        else:
+            check_kidx(kidx, ref['kidx'], img0, kl, sigma, TOL[dtype]['tie'])
+        same = kidx == ref['kidx']
+        assert rel(lock[same], ref['lockin'][same]) < TOL[dtype]['lock']
+
+
+@pytest.mark.parametrize('dtype', DTYPES)
+def test_shared_passb_zero_rows_and_driver(dtype):
+    """rows of zeros keep lock-in 0 and winner -1 (the accumulator starts at 0, :677); the fused driver at 1024^2
+    (three peaks: the shared kernel's 1024-point instantiation, several rows per workgroup) against the oracle"""
+    shape = (64, 2048)
+    img0, kref, klist, sigma = _case(shape, 4, 4, seed=3)
+    img0[:, :] = 0.0
+    lock, kidx = _sweep(shape, dtype, img0, kref, klist, sigma)
+    assert np.all(lock == 0) and np.all(kidx == -1)
+    shape = (1024, 1024)
+    kvecs = hex_kvecs(0.1, 7.0)
+    img = hex_moire(shape, kvecs, gaussian_bump_displacement(shape), noise=0.2, seed=4)
+    kw, sigma, _ = orc.derive_params(kvecs)
+    klists = explicit_klists(kvecs, kw, 4, 4)
+    u_ref, parts = orc.extract_displacement_field(img, kvecs, klists=klists, return_parts=True, workers=8)
+    plan = _lib.Plan(shape, 48, dtype)
+    u, lock, kidx, _ = plan.extract_displacement_field(img, kvecs, np.stack(klists), sigma, 2 * sigma, kmax=10,
+                                                       want_lockins=True, want_kidx=True)
+    plan.close()
+    for p in range(3):
+        if dtype is np.float64:
+            assert np.array_equal(kidx[p], parts['gs'][p]['kidx'])
+        same = kidx[p] == parts['gs'][p]['kidx']
+        assert same.mean() > 0.999
+        assert rel(lock[p][same], parts['gs'][p]['lockin'][same]) < TOL[dtype]['lock']
+    assert rel(u, u_ref) < (1e-8 if dtype is np.float64 else 5e-4)
