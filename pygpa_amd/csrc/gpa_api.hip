@@ -229,6 +229,9 @@ struct gpa_plan {
   PassBSharedTables sh{};
   double* d_taps = nullptr;       // g(0 .. sh_etab) of the y axis' circular filter, doubles
   int sh_etab = 0, sh_E = 0, sh_Epad = 0;
+  Axis ax1s{};                    // its geometry of the y axis: periodic as ax1, or zero-padded to L >= n1 + E
+  void* tw1s = nullptr;           // twiddles of ax1s.L when that differs from ax1.L
+  int tw1s_L = 0;
   bool sh_ok = false;             // this sigma / axis can run it
   bool use_shared = true;         // GPA_NO_SHARED=1 keeps the per-candidate forward transforms
   int sh_epoch = 0, sh_built_epoch = -1, sh_built_K = 0, sh_built_B = 0;   // tables follow sigma and the staged k-list
@@ -475,7 +478,7 @@ static int ensure_filters(gpa_plan* p, double sigma) {
       ++p->sh_epoch;
       const int n = cur.n;
       int mmax = (int)ceil(10.0 * sigma) + 16;
-      if (p->use_shared && !cur.padded && mmax < n / 2 && mmax <= 1024) {
+      if (p->use_shared && mmax < n / 2 && mmax <= 1024) {
         std::vector<double> taps = spatial_taps(n, g, mmax);
         double total = fabs(taps[0]), tail = 0;
         for (int m = 1; m <= mmax; ++m) total += 2 * fabs(taps[m]);
@@ -485,8 +488,23 @@ static int ensure_filters(gpa_plan* p, double sigma) {
           tail += 2 * fabs(taps[m]);
           if (tail > tol * total) { E = m; break; }
         }
-        if (passB_shared_supports(p->dtype, cur, E)) {
+        // a row that is not a power of two long is zero-padded to the next power of two >= n + E: the shared kernel
+        // needs no periodic extension (its end fix supplies every wrapped pair), only room for the filter's reach
+        Axis sa = cur;
+        if (cur.padded) {
+          sa.lg = 6;
+          while ((1 << sa.lg) < n + E) ++sa.lg;
+          sa.L = 1 << sa.lg;
+          sa.extL = sa.extR = 0;
+        }
+        if (passB_shared_supports(p->dtype, sa, E)) {
           const int Epad = (E + 15) & ~15;
+          if (sa.L != cur.L && p->tw1s_L != sa.L) {
+            if (!p->tw1s) TRY(dmalloc(p, &p->tw1s, (size_t)4096 * p->csz));
+            TRY(upload_twiddles(p, p->tw1s, sa.L));
+            p->tw1s_L = sa.L;
+          }
+          p->ax1s = sa;
           if (!p->d_taps) TRY(dmalloc(p, (void**)&p->d_taps, 1025 * sizeof(double)));
           if (!p->sh.gtab) TRY(dmalloc(p, &p->sh.gtab, (2 * 256 + 16) * p->rsz));
           HIP_TRY(hipMemcpyAsync(p->d_taps, taps.data(), ((size_t)mmax + 1) * sizeof(double), hipMemcpyHostToDevice, p->stream));
@@ -545,7 +563,7 @@ static int shared_prepare(gpa_plan* p, int P, int K) {
     return GPA_OK;
   }
   HIP_TRY(hipStreamSynchronize(p->stream));
-  const size_t gb = (size_t)B * p->ax1.L * p->rsz, ps = (size_t)B * p->sh_Epad * p->csz;
+  const size_t gb = (size_t)B * p->ax1s.L * p->rsz, ps = (size_t)B * p->sh_Epad * p->csz;
   if (gb > p->sh_gb_bytes) {
     if (p->sh.Gb) { (void)hipFree(p->sh.Gb); p->ws_bytes -= p->sh_gb_bytes; p->sh.Gb = nullptr; p->sh_gb_bytes = 0; }
     TRY(dmalloc(p, &p->sh.Gb, gb));
@@ -559,7 +577,7 @@ static int shared_prepare(gpa_plan* p, int P, int K) {
   if (!p->sh.dyc) TRY(dmalloc(p, &p->sh.dyc, (size_t)p->max_peaks * p->n1 * p->csz));
   if (!p->sh.desc) TRY(dmalloc(p, (void**)&p->sh.desc, (size_t)p->max_batch * sizeof(int)));
   HIP_TRY(hipMemcpyAsync(p->sh.desc, desc.data(), (size_t)B * sizeof(int), hipMemcpyHostToDevice, p->stream));
-  HIP_TRY(launch_shared_tables(p->dtype, p->ax1, p->d_kl, p->d_kr, p->d_taps, p->sh_etab, p->sh_E, p->sh_Epad, B, K, p->sh,
+  HIP_TRY(launch_shared_tables(p->dtype, p->ax1s, p->d_kl, p->d_kr, p->d_taps, p->sh_etab, p->sh_E, p->sh_Epad, B, K, p->sh,
                                p->stream));
   HIP_TRY(hipStreamSynchronize(p->stream));   // `desc` is a local
   p->sh_use = true;
@@ -723,7 +741,7 @@ void gpa_plan_destroy(gpa_plan* p) {
   void* bufs[] = {p->tw0, p->tw1, p->Hx, p->Hy, p->Tbuf, p->tb.cxb, p->tb.sx, p->tb.wxw, p->tb.wxr, p->tb.cyb, p->tb.sy, p->tb.wyw, p->tb.wyr, p->tb.planeof, p->d_pw,
                   p->tb.dx, p->tb.dy, p->d_kl, p->d_kr, p->d_image, p->d_mean, p->d_tile_mean, p->d_scratch,
                   p->d_lockin, p->d_kidx, p->d_dudx, p->d_dudy, p->d_wnorm, p->d_u, p->d_kmat, p->d_sf, p->d_grad, p->d_aux0, p->d_aux1,
-                  p->sh.Gb, p->sh.psi, p->sh.dyc, p->sh.gtab, p->sh.desc, p->d_taps};
+                  p->sh.Gb, p->sh.psi, p->sh.dyc, p->sh.gtab, p->sh.desc, p->d_taps, p->tw1s};
   for (void* b : bufs)
     if (b) hipFree(b);
   unwrap_workspace_destroy(&p->uw);
@@ -814,8 +832,8 @@ static int passB_select(gpa_plan* p, int P, int K, void* lockin, int32_t* kidx) 
   if (ksplit == 1) {
     TRY(shared_prepare(p, P, K));
     if (p->sh_use)
-      HIP_TRY(launch_passB_shared(p->dtype, p->ax1, p->n0, p->Tbuf, p->tw1, p->tb, p->sh, p->sh_E, p->sh_Epad, P, K, lockin,
-                                  kidx, p->stream));
+      HIP_TRY(launch_passB_shared(p->dtype, p->ax1s, p->n0, p->Tbuf, p->ax1s.L == p->ax1.L ? p->tw1 : p->tw1s, p->tb,
+                                  p->ax1.L / 16, p->sh, p->sh_E, p->sh_Epad, P, K, lockin, kidx, p->stream));
     else
       HIP_TRY(launch_passB(p->dtype, p->ax1, p->n0, p->Tbuf, p->Hy, p->tw1, p->tb, P, K, true, lockin, kidx, p->stream));
     return GPA_OK;
@@ -1319,8 +1337,8 @@ int gpa_extract_displacement_field_batch_dev(gpa_plan* p, const void* images, in
     HIP_TRY(launch_mean(p->dtype, image, npx, p->bScratch, p->bMean, p->stream, nimg));
     HIP_TRY(launch_passA(p->dtype, p->ax0, p->n1, image, p->bMean, p->tb, p->Hx, p->tw0, p->bT, Bx, p->stream, nimg));
     if (p->sh_use)
-      HIP_TRY(launch_passB_shared(p->dtype, p->ax1, p->n0, p->bT, p->tw1, p->tb, p->sh, p->sh_E, p->sh_Epad, P, K, p->bL,
-                                  nullptr, p->stream, nimg, Bx));
+      HIP_TRY(launch_passB_shared(p->dtype, p->ax1s, p->n0, p->bT, p->ax1s.L == p->ax1.L ? p->tw1 : p->tw1s, p->tb,
+                                  p->ax1.L / 16, p->sh, p->sh_E, p->sh_Epad, P, K, p->bL, nullptr, p->stream, nimg, Bx));
     else
       HIP_TRY(launch_passB(p->dtype, p->ax1, p->n0, p->bT, p->Hy, p->tw1, p->tb, P, K, true, p->bL, nullptr, p->stream, nimg,
                            Bx));

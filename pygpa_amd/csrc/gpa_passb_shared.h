@@ -29,8 +29,10 @@ bool passB_shared_supports(int dtype, const Axis& a1, int E);
 hipError_t launch_shared_tables(int dtype, const Axis& a1, const double* kl, const double* kr, const double* taps, int Etab,
                                 int E, int Epad, int B, int K, const PassBSharedTables& st, hipStream_t s);
 
+// a1: the shared kernel's own geometry of the y axis (periodic, or zero-padded to L >= n + E); tw1: twiddles of a1.L;
+// cyb_stride: entries per candidate of tb.cyb (the plan's L1 / 16, which a1.L / 16 may be smaller than)
 hipError_t launch_passB_shared(int dtype, const Axis& a1, int n0, const void* Tbuf, const void* tw1, const SweepTables& tb,
-                               const PassBSharedTables& st, int E, int Epad, int P, int K, void* out, int32_t* kidx,
-                               hipStream_t s, int nimg = 1, int Bx = 0);
+                               int cyb_stride, const PassBSharedTables& st, int E, int Epad, int P, int K, void* out,
+                               int32_t* kidx, hipStream_t s, int nimg = 1, int Bx = 0);
 
 }  // namespace gpa

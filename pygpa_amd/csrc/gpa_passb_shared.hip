@@ -73,7 +73,7 @@ __device__ __forceinline__ void load_gb(T (&h)[16], const T* gbrow, int tid) {
 #pragma unroll
   for (int i = 0; i < 16; ++i) h[i] = gb[i * TPF + tid];
 }
-template <class T> __device__ __forceinline__ cpx<T> load_cpx(__amdgpu_buffer_rsrc_t r, int voff, int soff);
+template <class T> __device__ __forceinline__ cpx<T> load_cpx(__amdgpu_buffer_rsrc_t r, int voff, int soff, int aux = 16);
 
 typedef int v2i_t __attribute__((ext_vector_type(2)));
 typedef int v4i_t __attribute__((ext_vector_type(4)));
@@ -81,12 +81,13 @@ __device__ __forceinline__ void store_cpx(cpx<float> v, __amdgpu_buffer_rsrc_t r
   v2i_t d = {__float_as_int(v.x), __float_as_int(v.y)};
   __builtin_amdgcn_raw_buffer_store_b64(d, r, voff, soff, 0);
 }
-template <> __device__ __forceinline__ cpx<float> load_cpx<float>(__amdgpu_buffer_rsrc_t r, int voff, int soff) {
-  v2i_t d = __builtin_amdgcn_raw_buffer_load_b64(r, voff, soff, 16 /* sc1: served by L2 */);
+// aux 16 = sc1: served by L2, not by whatever L1 holds (the read-back of the winners); 0 = an ordinary load
+template <> __device__ __forceinline__ cpx<float> load_cpx<float>(__amdgpu_buffer_rsrc_t r, int voff, int soff, int aux) {
+  v2i_t d = aux ? __builtin_amdgcn_raw_buffer_load_b64(r, voff, soff, 16) : __builtin_amdgcn_raw_buffer_load_b64(r, voff, soff, 0);
   return {__int_as_float(d.x), __int_as_float(d.y)};
 }
-template <> __device__ __forceinline__ cpx<double> load_cpx<double>(__amdgpu_buffer_rsrc_t r, int voff, int soff) {
-  v4i_t d = __builtin_amdgcn_raw_buffer_load_b128(r, voff, soff, 16);
+template <> __device__ __forceinline__ cpx<double> load_cpx<double>(__amdgpu_buffer_rsrc_t r, int voff, int soff, int aux) {
+  v4i_t d = aux ? __builtin_amdgcn_raw_buffer_load_b128(r, voff, soff, 16) : __builtin_amdgcn_raw_buffer_load_b128(r, voff, soff, 0);
   const long long a = ((long long)(unsigned)d.x) | ((long long)d.y << 32), b = ((long long)(unsigned)d.z) | ((long long)d.w << 32);
   return {__longlong_as_double(a), __longlong_as_double(b)};
 }
@@ -102,7 +103,12 @@ struct PassBSGeom {
   static_assert(F::P == 3, "three-pass transforms only (1024 .. 4096 points)");
   static constexpr int TPF = F::TPF;
   static_assert(TPF >= 64, "a row needs whole wavefronts");
-  static constexpr int NF = TPF >= 256 ? 1 : 256 / TPF;   // rows per workgroup
+  // (2048-point rows, 128 threads each: ONE row per workgroup -- two rows per workgroup cost a third of the occupancy
+  //  to LDS: 514 -> 428 us at 2048^2, 3 x 8)
+#ifndef GPA_PBS_MINTHREADS
+#define GPA_PBS_MINTHREADS 128
+#endif
+  static constexpr int NF = TPF >= GPA_PBS_MINTHREADS ? 1 : GPA_PBS_MINTHREADS / TPF;   // rows per workgroup
   static constexpr int THREADS = NF * TPF;
   static constexpr int NW = TPF / 64;                      // wavefronts per row
   static constexpr int NC = PassBSharedNC<T>::value;       // candidates per matrix pass
@@ -131,16 +137,19 @@ struct PassBSGeom {
 #ifndef GPA_PBS_F32_WAVES
 #define GPA_PBS_F32_WAVES 3
 #endif
+#ifndef GPA_PBS_PAD_WAVES
+#define GPA_PBS_PAD_WAVES 3   // f32, zero-padded rows
+#endif
 #ifndef GPA_PBS_F64_WAVES
 #define GPA_PBS_F64_WAVES 2
 #endif
 
 template <class T, int LG, bool PADDED>
-__global__ __launch_bounds__((PassBSGeom<T, LG>::THREADS), (sizeof(T) == 8 ? GPA_PBS_F64_WAVES : GPA_PBS_F32_WAVES)) void passB_shared_kernel(
+__global__ __launch_bounds__((PassBSGeom<T, LG>::THREADS), (sizeof(T) == 8 ? GPA_PBS_F64_WAVES : (PADDED ? GPA_PBS_PAD_WAVES : GPA_PBS_F32_WAVES))) void passB_shared_kernel(
     const cpx<T>* __restrict__ Tin, int n0, int n1, const T* __restrict__ Gb, const cpx<T>* __restrict__ twtab,
     const int* __restrict__ planeof, const int* __restrict__ desc, const cpx<T>* __restrict__ cyb,
     const cpx<T>* __restrict__ psi, const T* __restrict__ gtab, const cpx<T>* __restrict__ dx,
-    const cpx<T>* __restrict__ dyc, int K, int E, int Epad, cpx<T>* out, int32_t* kidx, int P, int Bx) {
+    const cpx<T>* __restrict__ dyc, int K, int E, int Epad, cpx<T>* out, int32_t* kidx, int P, int Bx, int cyb_stride) {
   using F = WgFFT<T, LG>;
   using G = PassBSGeom<T, LG>;
   using V4 = typename MfmaVec<T>::type;
@@ -194,12 +203,15 @@ __global__ __launch_bounds__((PassBSGeom<T, LG>::THREADS), (sizeof(T) == 8 ? GPA
       const cpx<T> cs = dx[(size_t)b * n0 + rr];   // exp(-2 pi i (wx - kx) x): the same for every candidate of the plane
       cpx<T> tail = {T(0), T(0)};
       if (tid < E) tail = src[n1 - 1 - tid];
+      if constexpr (PADDED) {
+        // (zero-padded rows: the slots beyond the row read as zero through the range check of a buffer descriptor)
+        const __amdgpu_buffer_rsrc_t srow = __builtin_amdgcn_make_buffer_rsrc((void*)src, 0, n1 * (int)sizeof(cpx<T>), 0x00020000);
 #pragma unroll
-      for (int i = 0; i < 16; ++i) {
-        const int yy = tid + TPF * i;
-        cpx<T> v = {T(0), T(0)};
-        if (!PADDED || yy < n1) v = src[yy];
-        X[i] = cmul(v, cs);
+        for (int i = 0; i < 16; ++i)
+          X[i] = cmul(load_cpx<T>(srow, (tid + TPF * i) * (int)sizeof(cpx<T>), 0, 0), cs);
+      } else {
+#pragma unroll
+        for (int i = 0; i < 16; ++i) X[i] = cmul(src[tid + TPF * i], cs);
       }
       if (tid < Epad) {
         // strips in the two forms the matrix pass reads (it forms ONE real of t * p or t * conj(p) per lane as
@@ -234,7 +246,7 @@ __global__ __launch_bounds__((PassBSGeom<T, LG>::THREADS), (sizeof(T) == 8 ? GPA
           const int nc = (d >> 4) & 7;
           for (int e = tid; e < NC * Epad; e += TPF) {
             const int c = e / Epad, j = e - c * Epad, cc = c < nc ? c : nc - 1;
-            pre_l[c * ES + j] = cyb[(size_t)(b + cc) * TPF + j];
+            pre_l[c * ES + j] = cyb[(size_t)(b + cc) * cyb_stride + j];
             psi_l[(par * NC + c) * ES + j] = psi[(size_t)(b + cc) * Epad + j];
           }
         }
@@ -257,7 +269,7 @@ __global__ __launch_bounds__((PassBSGeom<T, LG>::THREADS), (sizeof(T) == 8 ? GPA
       const int nc = (d >> 4) & 7;
       const int n = lane & 15, kq = lane >> 4;
       const int c = (n >> 1) & (NC - 1), end = (n >> (1 + G::LOGNC)) & 1, reim = n & 1;
-      const cpx<T>* pre = STAGE ? pre_l + c * ES : cyb + (size_t)(b + (c < nc ? c : nc - 1)) * TPF;
+      const cpx<T>* pre = STAGE ? pre_l + c * ES : cyb + (size_t)(b + (c < nc ? c : nc - 1)) * cyb_stride;
       const upair<T>* sp = strip + (G::SV == 4 ? end * 2 + reim : end) * ES;
       // (two-strip form: u, v and the sign of v picked per lane)
       const bool swp = reim != 0;
@@ -327,18 +339,24 @@ __global__ __launch_bounds__((PassBSGeom<T, LG>::THREADS), (sizeof(T) == 8 ? GPA
           y[15].y += t.y;
         }
       } else {
+        // zero-padded rows: the last E samples sit in register iA and, where they straddle a register, iB = iA + 1
+        // (wave-uniform): the two possible corrections are formed without touching y, then added to whichever
+        // register holds them under scalar branches
+        cpx<T> fA = {T(0), T(0)}, fB = {T(0), T(0)};
+        {
+          const int aA = n1 - 1 - (tid + TPF * iA), aB = aA - TPF;
+          const bool inA = aA >= 0 && aA < E, inB = aB >= 0 && aB < E && iB != iA;
+          const int qa = inA ? aA : 0, qb = inB ? aB : 0;
+          const cpx<T> xa = fixb[(c * 2 + 0) * ES + qa], xb = fixb[(c * 2 + 0) * ES + qb];
+          const cpx<T> pa = STAGE ? pl[qa] : psi[(size_t)b * Epad + qa], pb = STAGE ? pl[qb] : psi[(size_t)b * Epad + qb];
+          const cpx<T> ta = cmul(xa, pa), tb2 = cmul(xb, pb);
+          fA = {inA ? ta.x : T(0), inA ? ta.y : T(0)};
+          fB = {inB ? tb2.x : T(0), inB ? tb2.y : T(0)};
+        }
 #pragma unroll
         for (int i = 0; i < 16; ++i) {
-          if (i == iA || i == iB) {
-            const int a0 = n1 - 1 - (tid + TPF * i);
-            if (a0 >= 0 && a0 < E) {
-              const cpx<T> fx = fixb[(c * 2 + 0) * ES + a0];
-              const cpx<T> ps = STAGE ? pl[a0] : psi[(size_t)b * Epad + a0];
-              const cpx<T> t = cmul(fx, ps);
-              y[i].x += t.x;
-              y[i].y += t.y;
-            }
-          }
+          if (i == iA) { y[i].x += fA.x; y[i].y += fA.y; }
+          if (i == iB && iB != iA) { y[i].x += fB.x; y[i].y += fB.y; }
         }
       }
     }
@@ -357,14 +375,17 @@ __global__ __launch_bounds__((PassBSGeom<T, LG>::THREADS), (sizeof(T) == 8 ? GPA
       const bool win = a > ab[i];
       ab[i] = win ? a : ab[i];
       // (byte offset; OOB = 0x80000000 stays out of range after the arithmetic shift below, never multiply it)
-      const int woff = (win && valid && (!PADDED || yy < n1)) ? tid * (int)sizeof(cpx<T>) : OOB;
+      // (zero-padded rows: the whole column offset goes into the range-checked voffset, so that the slots beyond
+      //  the row are dropped by the descriptor's num_records; soffset is not range checked)
+      const int woff = (win && valid) ? (PADDED ? yy : tid) * (int)sizeof(cpx<T>) : OOB;
+      constexpr int SOFF = PADDED ? 0 : 1;
 #if GPA_PBS_EXECSTORE
-      if (woff != OOB) store_cpx(y[i], orow, woff, i * TPF * (int)sizeof(cpx<T>));
-      if (kidx && woff != OOB) __builtin_amdgcn_raw_buffer_store_b32(k, krow, woff >> (sizeof(cpx<T>) == 8 ? 1 : 2), i * TPF * 4, 0);
+      if (woff != OOB) store_cpx(y[i], orow, woff, SOFF * i * TPF * (int)sizeof(cpx<T>));
+      if (kidx && woff != OOB) __builtin_amdgcn_raw_buffer_store_b32(k, krow, woff >> (sizeof(cpx<T>) == 8 ? 1 : 2), SOFF * i * TPF * 4, 0);
 #elif !GPA_PBS_NOSTORE
-      store_cpx(y[i], orow, woff, i * TPF * (int)sizeof(cpx<T>));
+      store_cpx(y[i], orow, woff, SOFF * i * TPF * (int)sizeof(cpx<T>));
       constexpr int SH = sizeof(cpx<T>) == 8 ? 1 : 2;   // complex byte offset -> int32 byte offset
-      if (kidx) __builtin_amdgcn_raw_buffer_store_b32(k, krow, woff >> SH, i * TPF * 4, 0);
+      if (kidx) __builtin_amdgcn_raw_buffer_store_b32(k, krow, woff >> SH, SOFF * i * TPF * 4, 0);
 #endif
     }
   }
@@ -379,7 +400,7 @@ __global__ __launch_bounds__((PassBSGeom<T, LG>::THREADS), (sizeof(T) == 8 ? GPA
 #pragma unroll
   for (int i = 0; i < 16; ++i) {
     const int yy = tid + TPF * i;
-    w[i] = load_cpx<T>(orow, (!PADDED || yy < n1) ? tid * (int)sizeof(cpx<T>) : OOB, i * TPF * (int)sizeof(cpx<T>));
+    w[i] = PADDED ? load_cpx<T>(orow, yy * (int)sizeof(cpx<T>), 0) : load_cpx<T>(orow, tid * (int)sizeof(cpx<T>), i * TPF * (int)sizeof(cpx<T>));
   }
 #pragma unroll
   for (int i = 0; i < 16; ++i) {
@@ -465,7 +486,7 @@ hipError_t launch_shared_tables(int dtype, const Axis& a1, const double* kl, con
 
 template <class T, int LG, bool PADDED>
 static hipError_t run_passB_shared(const Axis& a1, int n0, const void* Tbuf, const void* tw1, const SweepTables& tb,
-                                   const PassBSharedTables& st, int E, int Epad, int P, int K, void* out, int32_t* kidx,
+                                   int cyb_stride, const PassBSharedTables& st, int E, int Epad, int P, int K, void* out, int32_t* kidx,
                                    hipStream_t s, int nimg, int Bx) {
   using G = PassBSGeom<T, LG>;
   const size_t lds = G::lds_bytes(Epad);
@@ -484,18 +505,20 @@ static hipError_t run_passB_shared(const Axis& a1, int n0, const void* Tbuf, con
   GPA_PROF("passB_shared_kernel", s);
   kern<<<grid, G::THREADS, lds, s>>>((const cpx<T>*)Tbuf, n0, a1.n, (const T*)st.Gb, (const cpx<T>*)tw1, tb.planeof, st.desc,
                                      (const cpx<T>*)tb.cyb, (const cpx<T>*)st.psi, (const T*)st.gtab, (const cpx<T>*)tb.dx,
-                                     (const cpx<T>*)st.dyc, K, E, Epad, (cpx<T>*)out, kidx, P, Bx);
+                                     (const cpx<T>*)st.dyc, K, E, Epad, (cpx<T>*)out, kidx, P, Bx, cyb_stride);
   return hipGetLastError();
 }
 
 bool passB_shared_supports(int dtype, const Axis& a1, int E) {
-  if (a1.lg < 10 || a1.lg > 12) return false;
+  // 1024-point rows (one wavefront per row: the whole matrix pass and both end fixes on it) measured slower than
+  // the per-candidate kernel (1024^2, 3 x 16: 189 against 131 us): from 2048 points on
+  if (a1.lg < 11 || a1.lg > 12) return false;
   const int tpf = a1.L / 16;
   const int Epad = (E + 15) & ~15;
   if (E < 1 || Epad > tpf || 2 * E > a1.n) return false;
   if (a1.padded && a1.n + E > a1.L) return false;
   const size_t csz = dtype == 0 ? 8 : 16;
-  const int nf = tpf >= 256 ? 1 : 256 / tpf, nc = dtype == 0 ? 4 : 2;
+  const int nf = tpf >= GPA_PBS_MINTHREADS ? 1 : GPA_PBS_MINTHREADS / tpf, nc = dtype == 0 ? 4 : 2;
   const size_t ES = (size_t)Epad + 4;
   const size_t stage = dtype == 0 ? 3 * nc * ES : 0;
   const size_t lds = (nf * ((size_t)(a1.L + a1.L / 16) + (dtype == 0 ? 4 : 2) * ES + 2 * nc * ES + stage) + 16 * 6) * csz +
@@ -504,11 +527,11 @@ bool passB_shared_supports(int dtype, const Axis& a1, int E) {
 }
 
 hipError_t launch_passB_shared(int dtype, const Axis& a1, int n0, const void* Tbuf, const void* tw1, const SweepTables& tb,
-                               const PassBSharedTables& st, int E, int Epad, int P, int K, void* out, int32_t* kidx,
+                               int cyb_stride, const PassBSharedTables& st, int E, int Epad, int P, int K, void* out, int32_t* kidx,
                                hipStream_t s, int nimg, int Bx) {
 #define CALL_S(T, LG) \
-  (a1.padded ? run_passB_shared<T, LG, true>(a1, n0, Tbuf, tw1, tb, st, E, Epad, P, K, out, kidx, s, nimg, Bx) \
-             : run_passB_shared<T, LG, false>(a1, n0, Tbuf, tw1, tb, st, E, Epad, P, K, out, kidx, s, nimg, Bx))
+  (a1.padded ? run_passB_shared<T, LG, true>(a1, n0, Tbuf, tw1, tb, cyb_stride, st, E, Epad, P, K, out, kidx, s, nimg, Bx) \
+             : run_passB_shared<T, LG, false>(a1, n0, Tbuf, tw1, tb, cyb_stride, st, E, Epad, P, K, out, kidx, s, nimg, Bx))
 #define CASE_S(LG) \
   case LG: return dtype == 0 ? CALL_S(float, LG) : CALL_S(double, LG);
   switch (a1.lg) { CASE_S(10) CASE_S(11) CASE_S(12) }

@@ -655,6 +655,9 @@ struct ColGeom {
 #ifndef GPA_DCTF_WAVES
 #define GPA_DCTF_WAVES 1
 #endif
+#ifndef GPA_EARLY16
+#define GPA_EARLY16 0   // experiment: the every-input-first kernel variants also for 16-element transforms
+#endif
 #ifndef GPA_F64_WAVES
 #define GPA_F64_WAVES 2   // f64 row kernels: 2 waves/SIMD (256 VGPRs) beat 1 wave with AGPR spill-over
 #endif
@@ -687,7 +690,7 @@ __global__ __launch_bounds__((RowGeom<T, LG>::THREADS), (sizeof(T) == 8 ? GPA_F6
   // init (first iteration of a solve on prepared residuals): part_pq / npq are the producer's partial norms of r0
   // EARLY (short transforms): every input of an update -- flags, q, the kept spectrum, w_k, partial sums, rho -- is
   // requested before anything waits, so the kernel pays one memory round trip instead of five in a row
-  constexpr bool EARLY = LAT && E == 8;
+  constexpr bool EARLY = LAT && (E == 8 || GPA_EARLY16);
   const bool early = EARLY && it > 0;
   int stop = 0;
   if (init) { if (!solve_init(part_pq, npq, scal, flags, sh)) return; }
@@ -1305,7 +1308,7 @@ template <class T, int LG, bool LAT = false>
 #ifndef GPA_F64_WAVES
 #define GPA_F64_WAVES 2   // f64 row kernels: 2 waves/SIMD (256 VGPRs) beat 1 wave with AGPR spill-over
 #endif
-__global__ __launch_bounds__((RowGeom<T, LG>::THREADS), (GPA_IDCTP_COND ? 4 : (sizeof(T) == 8 ? GPA_F64_WAVES : 1))) void rowidct_p_kernel(
+__global__ __launch_bounds__((RowGeom<T, LG>::THREADS), ((GPA_IDCTP_COND && !LAT) ? 4 : (sizeof(T) == 8 ? GPA_F64_WAVES : 1))) void rowidct_p_kernel(
     const T* __restrict__ Z, const T* __restrict__ pin, T* __restrict__ pout, int n0,
     const cpx<T>* __restrict__ twtab, const cpx<T>* __restrict__ wk, const int* flags, const double* part_rho,
     int nrho, double* scal, int it, size_t pimg) {
@@ -1328,7 +1331,7 @@ __global__ __launch_bounds__((RowGeom<T, LG>::THREADS), (GPA_IDCTP_COND ? 4 : (s
   constexpr int TPF = F::TPF, N = F::L, E = F::E;
   // (short transforms only: the long ones are bandwidth-bound, hide latency behind other workgroups and have no
   //  registers to spare for 2 E more values)
-  constexpr bool EARLY = LAT && E == 8;
+  constexpr bool EARLY = LAT && (E == 8 || GPA_EARLY16);
   if (!EARLY && stop) return;
   extern __shared__ __attribute__((aligned(16))) char smem[];
   __shared__ double sh[RowGeom<T, LG>::THREADS];

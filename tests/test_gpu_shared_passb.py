@@ -32,9 +32,11 @@ def _sweep(shape, dtype, img0, kref, klist, sigma):
 
 
 @pytest.mark.parametrize('dtype', DTYPES)
-@pytest.mark.parametrize('shape,grid', [((96, 4096), (4, 4)), ((80, 2048), (4, 2)), ((72, 4096), (3, 7)), ((2304, 1024), (4, 4))])
+@pytest.mark.parametrize('shape,grid', [((96, 4096), (4, 4)), ((80, 2048), (4, 2)), ((72, 4096), (3, 7)), ((2304, 1024), (4, 4)),
+                                        ((96, 3000), (4, 4)), ((80, 1500), (4, 2)), ((60, 1000), (3, 3)), ((2100, 700), (4, 4))])
 def test_shared_passb_vs_oracle_and_end_columns(shape, grid, dtype, monkeypatch):
-    """4096-, 2048- and (tall) 1024-wide sweeps: winner index identical to the oracle in f64 (up to exact amplitude
+    """4096-, 2048- and (tall) 1024-wide sweeps (the last on the per-candidate kernel), and rows that are not powers of two (zero-padded to >= n + E: the end
+    fix then supplies EVERY wrapped pair): winner index identical to the oracle in f64 (up to exact amplitude
     ties in f32), values within the lock-in tolerance everywhere AND in the first / last 3 sigma columns on their own;
     grids of 4, 2 and 7 candidates per x-plane exercise whole and ragged chunks of the matrix pass."""
     img0, kref, klist, sigma = _case(shape, *grid)
@@ -101,14 +103,14 @@ def test_shared_passb_list_orders(dtype):
 
 @pytest.mark.parametrize('dtype', DTYPES)
 def test_shared_passb_zero_rows_and_driver(dtype):
-    """rows of zeros keep lock-in 0 and winner -1 (the accumulator starts at 0, :677); the fused driver at 1024^2
-    (three peaks: the shared kernel's 1024-point instantiation, several rows per workgroup) against the oracle"""
+    """rows of zeros keep lock-in 0 and winner -1 (the accumulator starts at 0, :677); the fused driver (three peaks
+    in one launch) against the oracle"""
     shape = (64, 2048)
     img0, kref, klist, sigma = _case(shape, 4, 4, seed=3)
     img0[:, :] = 0.0
     lock, kidx = _sweep(shape, dtype, img0, kref, klist, sigma)
     assert np.all(lock == 0) and np.all(kidx == -1)
-    shape = (1024, 1024)
+    shape = (512, 2048)
     kvecs = hex_kvecs(0.1, 7.0)
     img = hex_moire(shape, kvecs, gaussian_bump_displacement(shape), noise=0.2, seed=4)
     kw, sigma, _ = orc.derive_params(kvecs)

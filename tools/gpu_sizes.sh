@@ -1,13 +1,13 @@
 #!/bin/bash
-out=gpurun_out/r2j; mkdir -p $out
-for s in 500 512 1000 1024 1500 2000 2048 3000; do
-  python bench.py --size $s --no-cpu --no-f64 --steps 20 > $out/bench_$s.json 2>> $out/bench.err
+# usage (GPU box): [SIZES="500 1000 1500 2000 3000"] [ENVV="GPA_NO_SHARED=1"] tools/gpu_sizes.sh -- bench.py per image size (one image per call,
+# D2H included / resident), with the per-kernel times of the sweep
+ulimit -c 0
+cd "$GRAFT_REPO_ROOT" || exit 1
+[ -n "$ENVV" ] && export $ENVV
+for n in ${SIZES:-500 512 1000 1024 1500 2000 2048 3000 4096}; do
+  timeout 300 python3 bench.py --size $n --steps 10 --warmup 3 --no-cpu --no-f64 2>/dev/null | N=$n python3 -c "
+import json,sys,os
+d=json.loads(sys.stdin.read().strip().splitlines()[-1])
+k=d['kernels']
+print('%5s^2  %8.1f Mpix/s  resident %8.1f  ' % (os.environ['N'], d['value'], d['resident_only']['value']), {n[:14]: round(v['total_ms']*1e3) for n,v in k.items() if 'pass' in n or 'recon' in n}, d['config']['unwrap_iters'])"
 done
-python - <<'PY'
-import json
-for s in (500,512,1000,1024,1500,2000,2048,3000):
-    try:
-        d=json.load(open('gpurun_out/r2j/bench_%d.json'%s)); print(s, d['value'], d['ms_per_step'], d['resident_only']['value'], d['config']['unwrap_iters'], d['stage_ms'])
-    except Exception as e: print(s,'ERR',e)
-PY
-tail -5 $out/bench.err
