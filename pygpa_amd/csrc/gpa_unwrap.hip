@@ -608,9 +608,15 @@ constexpr int unwrap_elems(int lg, size_t real_size) {
   return lg <= (real_size == 8 ? GPA_UNWRAP_E8_MAXLG_F64 : GPA_UNWRAP_E8_MAXLG) ? 8 : 16;
 }
 
+#ifndef GPA_ROW_TWLDS
+#define GPA_ROW_TWLDS 1   // 16-element three-pass row transforms: pass-1 base twiddles from a small LDS table (12 VGPRs less in f32)
+#endif
 template <class T, int LG>
 struct RowGeom {
   using F = WgFFT<T, LG, unwrap_elems(LG, sizeof(T))>;
+  static constexpr bool TWLDS = GPA_ROW_TWLDS && F::E == 16 && F::P == 3;
+  using TW = typename std::conditional<TWLDS, typename F::TwiddlesP1Lds, typename F::Twiddles>::type;
+  static constexpr int T1N = TWLDS ? F::P1_SETS * 6 : 1;
   using D = WgDCT<T, LG, unwrap_elems(LG, sizeof(T))>;
   static constexpr int NF = F::TPF >= 256 ? 1 : 256 / F::TPF;   // row PAIRS per workgroup
   static constexpr int RS = F::LDS_ELEMS + (NF > 1 ? (F::TPF < 32 ? F::TPF : 0) : 0);
@@ -701,6 +707,7 @@ __global__ __launch_bounds__((RowGeom<T, LG>::THREADS), (sizeof(T) == 8 ? GPA_F6
   const int pr = blockIdx.x * G::NF + f;
   const bool valid = 2 * pr + 1 < n0;
   const size_t oa = (size_t)(valid ? 2 * pr : 0) * N, ob = oa + N;
+  // (register twiddles here: the LDS table of rowidct_p_kernel made this kernel's allocation worse, 156 -> 160 VGPRs)
   typename F::Twiddles tw;
   F::load_twiddles(tw, twtab, tid);
   cpx<T> x[E];
@@ -1340,8 +1347,15 @@ __global__ __launch_bounds__((RowGeom<T, LG>::THREADS), ((GPA_IDCTP_COND && !LAT
   const int pr = blockIdx.x * G::NF + f;
   const bool valid = 2 * pr + 1 < n0;
   const size_t oa = (size_t)(valid ? 2 * pr : 0) * N, ob = oa + N;
-  typename F::Twiddles tw;
-  F::load_twiddles(tw, twtab, tid);
+  typename G::TW tw;
+  __shared__ cpx<T> t1s[G::T1N];
+  if constexpr (G::TWLDS) {
+    F::fill_pass1_table(t1s, twtab, threadIdx.x, G::THREADS);
+    __syncthreads();
+    F::load_twiddles(tw, twtab, tid, t1s);
+  } else {
+    F::load_twiddles(tw, twtab, tid);
+  }
   cpx<T> x[E], xm[E], wkv[EARLY ? E : 1], pv[EARLY ? E : 1];
   const bool first = it == 0;                        // first iteration: p = z (pin is uninitialised)
 #pragma unroll
