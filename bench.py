@@ -55,6 +55,8 @@ def parse_args():
     ap.add_argument('--window', type=int, default=2048, help='N > 1: side of the (power-of-two) tile windows')
     ap.add_argument('--backend', default='nccl', help='N > 1: torch.distributed backend (gloo stages through the host)')
     ap.add_argument('--share-device', action='store_true', help='N > 1: every rank uses GPU 0 (test aid, with --backend gloo)')
+    ap.add_argument('--schedule', default='stream', choices=['stream', 'step'],
+                    help='N > 1: image-pipelined schedule (TiledPipeline.run_stream) or the unpipelined step()')
     return ap.parse_args()
 
 
@@ -413,7 +415,10 @@ def small_image_stacks(kvecs, klists, sigma, kmax, sizes=(512, 1024), stack=16, 
 # N > 1: tile pipeline over the ranks
 # -------------------------------------------------------------------------------------------------
 def weak_shape(world, n):
-    """image of world * n^2 pixels, as square as powers of two allow (N = 4: 2n x 2n = configs[3])"""
+    """image of world * n^2 pixels, as square as powers of two allow (N = 4: 2n x 2n = BASELINE configs[3]); N = 8 runs
+    BASELINE configs[4]'s 4n x 4n = 16384^2 image (2 n^2 pixels per GPU: the throughput in Mpixels/s stays comparable)"""
+    if world == 8:
+        return (4 * n, 4 * n)
     a = 1
     while a * a * 2 <= world:
         a *= 2
@@ -469,12 +474,22 @@ def multi_gpu(args, world, rank, local_rank):
         dist.barrier()
         torch.cuda.synchronize(dev)
 
-    for _ in range(args.warmup):
-        pipe.step()
+    # one step = one image through the tile pipeline.  Default: the image-pipelined schedule (run_stream: the global
+    # unwrap of image i on the rotating owners (2 i + c) % N beside the sweeps of image i + 1); --schedule step = the
+    # unpipelined step() (unwrap on ranks 0 / 1 while the others wait, u broadcast to every rank)
+    stream = args.schedule == 'stream'
+    if stream:
+        pipe.run_stream([None] * max(args.warmup, 1))
+    else:
+        for _ in range(args.warmup):
+            pipe.step()
     fence()
     t0 = time.perf_counter()
-    for _ in range(args.steps):
-        pipe.step()
+    if stream:
+        its = pipe.run_stream([None] * args.steps)
+    else:
+        for _ in range(args.steps):
+            pipe.step()
     fence()
     dt = time.perf_counter() - t0
     t = torch.tensor([dt], dtype=torch.float64)
@@ -484,7 +499,20 @@ def multi_gpu(args, world, rank, local_rank):
     dt = float(t.item())
     if rank == 0:
         npx = shape[0] * shape[1]
-        cfg = {4: 'BASELINE.json configs[3]', 8: 'BASELINE.json configs[4] without the undistortion'}.get(world, 'configs[3] pipeline')
+        cfg = {4: 'BASELINE.json configs[3]', 8: 'BASELINE.json configs[4]: the 16384^2 image, WITHOUT the Lawler-Fujita '
+                  'undistortion (a per-image host call on the rank that ends up with u, not part of this step)'}.get(world, 'configs[3] pipeline')
+        if stream:
+            unw = [it for it in its if it[0] is not None or it[1] is not None]
+            sched = ('image-pipelined: gather of 3 of 5 gradient fields to each of the two unwrap owners (2 i + c) %% N of image i, '
+                     'global weighted unwrap kmax=%d there beside the sweeps of image i + 1, component 1 handed to the owner of '
+                     'component 0' % args.kmax)
+            coll = 'all_reduce(mean scalar), 2 x gather(3 gradient fields of every tile -> one owner), send/recv(u component)'
+            stages = {k: round(v / args.steps * 1e3, 3) for k, v in pipe.stage_s.items()}
+            iters_rep = [list(it) for it in unw[:2]]
+        else:
+            sched = 'all_gather of the gradient tiles, global weighted unwrap kmax=%d on rank c %% N, broadcast of u' % args.kmax
+            coll = 'all_reduce(mean scalar), all_gather(gradient tiles), 2 x broadcast(u component)'
+            stages, iters_rep = None, list(pipe.iters)
         out = {
             'metric': 'Mpixels/s displacement-field extraction (3 peaks, 4096^2 img) + achieved HBM GB/s',
             'value': round(npx * args.steps / dt / 1e6, 2), 'unit': 'Mpixels/s',
@@ -492,14 +520,15 @@ def multi_gpu(args, world, rank, local_rank):
             'ms_per_step': round(dt / args.steps * 1e3, 4),
             'higher_is_better': True, 'scaling': 'weak', 'vs_baseline': None,
             'dtype': args.dtype, 'data': 'synthetic',
-            'config': {'workload': '%dx%d synthetic hex moire (%d x %d^2 pixels) tiled into %d halo windows of %d^2 dealt over '
-                                   '%d ranks, 3 Bragg peaks x %d k-vectors, sigma=%d; all_gather of the gradient tiles, global '
-                                   'weighted unwrap kmax=%d on rank c %% N, broadcast of u (%s)'
-                                   % (shape[0], shape[1], world, n, len(pipe.tiles), W, world, K, sigma, args.kmax, cfg),
+            'config': {'workload': '%dx%d synthetic hex moire (%.3g x %d^2 pixels per GPU) tiled into %d halo windows of %d^2 dealt '
+                                   'over %d ranks, 3 Bragg peaks x %d k-vectors, sigma=%d; %s (%s); windows resident in HBM'
+                                   % (shape[0], shape[1], shape[0] * shape[1] / float(world * n * n), n, len(pipe.tiles), W, world, K,
+                                      sigma, sched, cfg),
                        'image': list(shape), 'tiles': len(pipe.tiles), 'window': [W, W], 'halo': halo,
                        'tile_interior': list(pipe.tshape), 'peaks': P, 'kvectors_per_peak': K,
-                       'unwrap_iters': list(pipe.iters), 'backend': args.backend,
-                       'collectives': 'all_reduce(mean scalar), all_gather(gradient tiles), 2 x broadcast(u component)'},
+                       'pixels_per_gpu': shape[0] * shape[1] // world, 'schedule': args.schedule,
+                       'unwrap_iters': iters_rep, 'backend': args.backend, 'collectives': coll,
+                       'stage_ms_per_image_rank0': stages},
         }
         print(json.dumps(out), flush=True)
     pipe.close()

@@ -150,6 +150,13 @@ int gpa_unwrap_prediff(gpa_plan* plan, const void* dx, const void* dy, const voi
 int gpa_unwrap_prediff_dev(gpa_plan* plan, const void* dx, const void* dy, const void* weight,
                            int kmax, double eps, int poisson_axes_compat, void* phi,
                            int* iters_out);
+/* the two halves of gpa_unwrap_prediff_dev for callers that overlap a global unwrap with other work on the same GPU
+ * (the image-pipelined multi-GPU schedule, pygpa_amd/distributed.py): `_enqueue_dev` puts the whole solve on the
+ * plan's stream and returns at once; gpa_unwrap_finish waits for it and hands back the iteration count.  One solve
+ * in flight per plan.                                                                                        */
+int gpa_unwrap_prediff_enqueue_dev(gpa_plan* plan, const void* dx, const void* dy, const void* weight,
+                                   int kmax, double eps, int poisson_axes_compat, void* phi);
+int gpa_unwrap_finish(gpa_plan* plan, int* iters_out);
 /* same from a wrapped phase image psi (phase_unwrap.py:141-208) */
 int gpa_unwrap(gpa_plan* plan, const void* psi, const void* weight, int kmax, double eps,
                int poisson_axes_compat, void* phi, int* iters_out);

@@ -44,6 +44,8 @@ SIGNATURES = {
     'gpa_weighted_lstsq': (_i, [_vp, _vp, _vp, _vp, _i, _vp]),
     'gpa_unwrap_prediff': (_i, [_vp, _vp, _vp, _vp, _i, _d, _i, _vp, _vp]),
     'gpa_unwrap_prediff_dev': (_i, [_vp, _vp, _vp, _vp, _i, _d, _i, _vp, _vp]),
+    'gpa_unwrap_prediff_enqueue_dev': (_i, [_vp, _vp, _vp, _vp, _i, _d, _i, _vp]),
+    'gpa_unwrap_finish': (_i, [_vp, _vp]),
     'gpa_unwrap': (_i, [_vp, _vp, _vp, _i, _d, _i, _vp, _vp]),
     'gpa_extract_displacement_field': (_i, [_vp, _vp, _vp, _i, _vp, _i, _d, _i, _i, _vp, _vp, _vp, _vp]),
     'gpa_extract_displacement_field_dev': (_i, [_vp, _vp, _vp, _i, _vp, _i, _d, _i, _i, _vp, _vp, _vp, _vp]),
@@ -447,6 +449,18 @@ class Plan:
                                               _ptr(None if weight_ptr is None else int(weight_ptr)), int(kmax), float(eps),
                                               int(bool(axes_compat)), _ptr(int(phi_ptr)), C.byref(iters)),
               'gpa_unwrap_prediff_dev')
+        return iters.value
+
+    def unwrap_prediff_enqueue_dev(self, dx_ptr, dy_ptr, weight_ptr, phi_ptr, kmax=100, eps=1e-9, axes_compat=True):
+        """the solve of unwrap_prediff_dev put on the plan's stream without waiting for it (unwrap_finish does)"""
+        check(self.lib.gpa_unwrap_prediff_enqueue_dev(self.handle, _ptr(int(dx_ptr)), _ptr(int(dy_ptr)),
+                                                      _ptr(None if weight_ptr is None else int(weight_ptr)), int(kmax),
+                                                      float(eps), int(bool(axes_compat)), _ptr(int(phi_ptr))),
+              'gpa_unwrap_prediff_enqueue_dev')
+
+    def unwrap_finish(self):
+        iters = C.c_int(0)
+        check(self.lib.gpa_unwrap_finish(self.handle, C.byref(iters)), 'gpa_unwrap_finish')
         return iters.value
 
     def extract_displacement_field_dev(self, image_ptr, kvecs, klists, sigma, mask_border, kmax, u_ptr,

@@ -1031,6 +1031,26 @@ int gpa_unwrap_prediff_dev(gpa_plan* p, const void* dx, const void* dy, const vo
   return GPA_OK;
 }
 
+int gpa_unwrap_prediff_enqueue_dev(gpa_plan* p, const void* dx, const void* dy, const void* weight, int kmax, double eps,
+                                   int compat, void* phi) {
+  if (!p || !dx || !dy || !phi) return fail(GPA_ERR_ARG, "gpa_unwrap_prediff_enqueue: null argument");
+  if (kmax < 1) return fail(GPA_ERR_ARG, "gpa_unwrap_prediff_enqueue: kmax must be >= 1");
+  HIP_TRY(hipSetDevice(p->device));
+  hipError_t e = unwrap_enqueue(&p->uw, dx, dy, weight, false, kmax, eps, compat != 0, phi, p->stream);
+  if (e != hipSuccess) return fail(GPA_ERR_HIP, std::string("unwrap: ") + hipGetErrorString(e));
+  return GPA_OK;
+}
+
+int gpa_unwrap_finish(gpa_plan* p, int* iters_out) {
+  if (!p) return fail(GPA_ERR_ARG, "gpa_unwrap_finish: null plan");
+  HIP_TRY(hipSetDevice(p->device));
+  int iters = 0;
+  hipError_t e = unwrap_finish(&p->uw, &iters, p->stream);
+  if (e != hipSuccess) return fail(GPA_ERR_HIP, std::string("unwrap: ") + hipGetErrorString(e));
+  if (iters_out) *iters_out = iters;
+  return GPA_OK;
+}
+
 int gpa_unwrap_prediff(gpa_plan* p, const void* dx, const void* dy, const void* weight, int kmax, double eps,
                        int compat, void* phi, int* iters_out) {
   if (!p || !dx || !dy || !phi) return fail(GPA_ERR_ARG, "gpa_unwrap_prediff: null argument");

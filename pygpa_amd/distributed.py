@@ -177,6 +177,58 @@ def _tiled_device(image, kvecs, klists, sigma, halo, kmax, dtype, device, group,
     return u
 
 
+class HipTileBackend:
+    """What TiledPipeline asks of the GPU, through the C ABI of libgpa_hip.so: the tile stage of one window (sweep +
+    per-pixel least squares, interiors written into the rank's compact tile buffer), the global weighted unwrap of
+    one component (started on the global plan's own stream, waited for later), synchronisation.  A test double with
+    the same five methods (tests/test_distributed.py: CPU tensors + the oracle) lets the schedule, the collectives
+    and the stitching run under gloo without a GPU."""
+
+    def __init__(self, torch, wshape, shape, nbatch, dtype, device, two_solves):
+        from . import _lib
+        self.torch = torch
+        self.device = torch.device('cuda', int(device))
+        self.rsz = np.dtype(dtype).itemsize
+        self.plan_w = _lib.get_plan(wshape, nbatch, dtype, device)
+        self._mk = lambda: _lib.Plan(shape, 1, dtype, device)
+        self._get = lambda: _lib.get_plan(shape, 1, dtype, device)
+        self.plan_c = [None, None]
+        self.two_solves = two_solves    # a rank that owns both components of an image solves them on two plans at once
+        self.own = []
+
+    def _plan(self, c):
+        if self.plan_c[c] is None:
+            if c == 1 and self.two_solves:
+                self.plan_c[1] = self._mk()
+                self.own.append(self.plan_c[1])
+            else:
+                self.plan_c[c] = self._get()
+        return self.plan_c[c]
+
+    def tile_gradients(self, win, wpitch, mean, kvecs, klists, sigma, border, rect, local_slot, t1, plane):
+        base = local_slot.data_ptr()
+        self.plan_w.tile_gradients_dev(win.data_ptr(), wpitch, 0, 0, mean, kvecs, klists, sigma, border, rect,
+                                       (base, t1, plane), (base + 2 * plane * self.rsz, t1, plane),
+                                       (base + 4 * plane * self.rsz, t1))
+
+    def sync_tiles(self):
+        self.plan_w.sync()
+
+    def unwrap_start(self, c, gdx, gdy, gw, out, kmax):
+        self._plan(c).unwrap_prediff_enqueue_dev(gdx.data_ptr(), gdy.data_ptr(), gw.data_ptr(), out.data_ptr(), kmax=kmax)
+
+    def unwrap_wait(self, c):
+        return self._plan(c).unwrap_finish()
+
+    def sync_device(self):
+        self.torch.cuda.synchronize(self.device)
+
+    def close(self):
+        for pl in self.own:
+            pl.close()
+        self.own = []
+
+
 class TiledPipeline:
     """Device-resident tile pipeline of one rank (module docstring), reusable over many images of one shape.
 
@@ -191,8 +243,7 @@ class TiledPipeline:
     staged through the host."""
 
     def __init__(self, shape, kvecs, klists, sigma, halo, kmax=10, dtype=np.float32, device=0, group=None,
-                 grid=None, window=None, tiles=None, tshape=None, wshape=None):
-        from . import _lib
+                 grid=None, window=None, tiles=None, tshape=None, wshape=None, backend=None):
         torch, dist = _dist()
         self.torch, self.dist, self.group = torch, dist, group
         self.world, self.rank = 1, 0
@@ -213,10 +264,10 @@ class TiledPipeline:
         self.mine = list(range(self.rank, len(tiles), self.world))
         self.per_rank = (len(tiles) + self.world - 1) // self.world
         P, K = self.klists.shape[:2]
-        self.plan_w = _lib.get_plan(self.wshape, P * K, self.dtype, self.device)
         self.unwrappers = [c for c in range(2) if c % self.world == self.rank]
-        self.plan_g = _lib.get_plan(self.shape, 1, self.dtype, self.device) if self.unwrappers else None
-        dev = torch.device('cuda', self.device)
+        self.be = backend if backend is not None else HipTileBackend(torch, self.wshape, self.shape, P * K, self.dtype,
+                                                                     self.device, two_solves=self.world == 1)
+        dev = self.be.device
         self.dev = dev
         t_dt = torch.float32 if self.dtype == np.float32 else torch.float64
         n0, n1 = self.shape
@@ -279,7 +330,7 @@ class TiledPipeline:
             _, (w0, w1), _, _ = self.tiles[idx]
             win = window_fn(w0, w1) if window_fn is not None else image[w0, w1]
             self.wins[slot].copy_(torch.from_numpy(np.ascontiguousarray(win, dtype=self.dtype)))
-        torch.cuda.synchronize(self.dev)
+        self.be.sync_device()
 
     def image_mean(self):
         """mean of the whole image: every pixel lies in exactly one tile interior, so the ranks add up the
@@ -301,12 +352,9 @@ class TiledPipeline:
         self.mean = self.image_mean()             # (.item() synchronises: the plans run on their own streams)
         for slot, idx in enumerate(self.mine):
             _, _, (o0, o1), (z0, z1) = self.tiles[idx]
-            base = self.local[slot].data_ptr()
-            self.plan_w.tile_gradients_dev(self.wins[slot].data_ptr(), self.wshape[1], 0, 0, self.mean, self.kvecs,
-                                           self.klists, self.sigma, self.border, (o0, o1, z0, z1),
-                                           (base, t1, plane), (base + 2 * plane * rsz, t1, plane),
-                                           (base + 4 * plane * rsz, t1))
-        self.plan_w.sync()
+            self.be.tile_gradients(self.wins[slot], self.wshape[1], self.mean, self.kvecs, self.klists, self.sigma,
+                                   self.border, (o0, o1, z0, z1), self.local[slot], t1, plane)
+        self.be.sync_tiles()
         # --- collective 1 (RCCL all_gather over xGMI): compact gradient tiles of every rank
         self._all_gather(self.gathered, self.local)
         for idx, ((i, j), _, _, (z0, z1)) in enumerate(self.tiles):
@@ -316,17 +364,163 @@ class TiledPipeline:
             self.gdx[:, r0:r0 + z0, c0:c0 + zx] = src[0:2, :z0, :zx]
             self.gdy[:, r0:r0 + zy, c0:c0 + z1] = src[2:4, :zy, :z1]
             self.gw[r0:r0 + z0, c0:c0 + z1] = src[4, :z0, :z1]
-        torch.cuda.synchronize(self.dev)
+        self.be.sync_device()
         # --- global unwrap, component c on rank c % world; collective 2 hands each component to everybody
         for c in self.unwrappers:
-            self.iters[c] = self.plan_g.unwrap_prediff_dev(self.gdx[c].data_ptr(), self.gdy[c].data_ptr(),
-                                                           self.gw.data_ptr(), self.u[c].data_ptr(), kmax=self.kmax)
+            self.be.unwrap_start(c, self.gdx[c], self.gdy[c], self.gw, self.u[c], self.kmax)
+            self.iters[c] = self.be.unwrap_wait(c)
         for c in range(2):
             self._broadcast(self.u[c], c % self.world)
         return self.u
 
+    # ---- image-pipelined schedule ---------------------------------------------------------------------------
+    # step() leaves N - 2 of N GPUs idle during the global unwrap (54 % of single-GPU time).  For a STREAM of images
+    # the unwrap of image i therefore runs on a rotating pair of ranks -- component c of image i on rank
+    # (2 i + c) % N, on the global plan's own stream -- while ALL ranks sweep the windows of image i + 1; only the
+    # two owners receive the gradient tiles they need (a gather each, 3 of the 5 fields), and the second owner hands
+    # its component to the first, which then holds the whole field of image i.  No collective involves every rank's
+    # full-size data any more: per image and rank 1/N of the image goes out once.
+    def owners(self, i):
+        """ranks that unwrap component 0 / component 1 of image i; the first one ends up with the whole field"""
+        return (2 * i) % self.world, (2 * i + 1) % self.world
+
+    def _gather_to(self, fields, dst):
+        """gather local[:, fields] of every rank on rank dst -> (world, per_rank, len(fields), t0, t1) there, None elsewhere"""
+        torch, dist = self.torch, self.dist
+        part = self.local[:, fields].contiguous()
+        if self.world == 1:
+            return part.unsqueeze(0)
+        dst_global = dst if self.group is None else dist.get_global_rank(self.group, dst)
+        if self._host_staged():
+            part = part.cpu()
+        outs = [torch.empty_like(part) for _ in range(self.world)] if self.rank == dst else None
+        dist.gather(part, outs, dst=dst_global, group=self.group)
+        if self.rank != dst:
+            return None
+        got = torch.stack(outs)
+        return got.to(self.dev) if self._host_staged() else got
+
+    def _stitch_component(self, got, c, buf):
+        """tiles of (dudx_c, dudy_c, weight) gathered on this rank -> the full-size fields of buffer set `buf`"""
+        n0, n1 = self.shape
+        t0, t1 = self.tshape
+        gdx, gdy, gw = self._pbuf[buf]
+        for idx, ((i, j), _, _, (z0, z1)) in enumerate(self.tiles):
+            src = got[idx % self.world, idx // self.world]
+            r0, c0 = i * t0, j * t1
+            zx, zy = min(z1, n1 - 1 - c0), min(z0, n0 - 1 - r0)
+            gdx[c, r0:r0 + z0, c0:c0 + zx] = src[0, :z0, :zx]
+            gdy[c, r0:r0 + zy, c0:c0 + z1] = src[1, :zy, :z1]
+            gw[c, r0:r0 + z0, c0:c0 + z1] = src[2, :z0, :z1]
+
+    def _send_component(self, t, src, dst):
+        """component 1 of an image from its owner to the owner of component 0 (point to point)"""
+        if src == dst:
+            return
+        dist = self.dist
+        g = (lambda r: r) if self.group is None else (lambda r: dist.get_global_rank(self.group, r))
+        if self.rank == src:
+            dist.send(t.cpu() if self._host_staged() else t, g(dst), group=self.group)
+        elif self.rank == dst:
+            if self._host_staged():
+                h = t.cpu()
+                dist.recv(h, g(src), group=self.group)
+                t.copy_(h)
+            else:
+                dist.recv(t, g(src), group=self.group)
+
+    def run_stream(self, sources, on_result=None):
+        """A stream of images of the pipeline's shape through the image-pipelined schedule.
+
+        sources: iterable of images -- full arrays (every rank passes the same), callables window_fn(slice0,
+        slice1), or None for "the windows that are loaded already".  For image i the field ends up on rank owners(i)[0]; `on_result(i, u)` is called there with the
+        (2, N, M) device tensor (valid until the image after next finishes).  Returns on every rank the list of
+        iteration counts [(it0, it1) or None per image] and leaves per-stage wall times of this rank in
+        `self.stage_s` (load, mean, tile stage, gather + stitch, waiting for unwraps, hand-over).
+        Per image the arithmetic is that of step(): the same windows, the same tile kernels, the same global solves --
+        the fields are equal bit for bit (tests/test_distributed.py, tests/test_gpu_configs.py)."""
+        import time
+        torch = self.torch
+        n0, n1 = self.shape
+        t0, t1 = self.tshape
+        plane = t0 * t1
+        t_dt = torch.float32 if self.dtype == np.float32 else torch.float64
+        if getattr(self, '_pbuf', None) is None:
+            # two sets of stitched fields (the unwrap of image i reads one while image i + 1 is stitched into the other);
+            # the weight is kept per component because the two owners of an image are different ranks
+            self._pbuf = [(torch.zeros((2, n0, n1 - 1), dtype=t_dt, device=self.dev),
+                           torch.zeros((2, n0 - 1, n1), dtype=t_dt, device=self.dev),
+                           torch.zeros((2, n0, n1), dtype=t_dt, device=self.dev)) for _ in range(2)]
+            self._pu = [torch.zeros((2, n0, n1), dtype=t_dt, device=self.dev) for _ in range(2)]
+        st = {k: 0.0 for k in ('load', 'mean', 'tiles', 'gather', 'unwrap_wait', 'handover')}
+        iters_all = []
+        pending = None      # (index, buffer set) of the image whose unwraps are in flight
+
+        def finish(pi, pb):
+            a, b = self.owners(pi)
+            t = time.perf_counter()
+            its = [None, None]
+            for c, owner in ((0, a), (1, b)):
+                if self.rank == owner:
+                    its[c] = self.be.unwrap_wait(c)
+            st['unwrap_wait'] += time.perf_counter() - t
+            t = time.perf_counter()
+            self._send_component(self._pu[pb][1], b, a)
+            st['handover'] += time.perf_counter() - t
+            if self.rank == a and on_result is not None:
+                self.be.sync_device()
+                on_result(pi, self._pu[pb])
+            iters_all.append(tuple(its))
+
+        for i, src in enumerate(sources):
+            buf = i & 1
+            t = time.perf_counter()
+            if src is None:
+                pass                      # the windows loaded last stay (benchmarks: input resident in HBM)
+            elif callable(src):
+                self.load(window_fn=src)
+            else:
+                self.load(src)
+            st['load'] += time.perf_counter() - t
+            t = time.perf_counter()
+            self.mean = self.image_mean()
+            st['mean'] += time.perf_counter() - t
+            t = time.perf_counter()
+            for slot, idx in enumerate(self.mine):
+                _, _, (o0, o1), (z0, z1) = self.tiles[idx]
+                self.be.tile_gradients(self.wins[slot], self.wshape[1], self.mean, self.kvecs, self.klists, self.sigma,
+                                       self.border, (o0, o1, z0, z1), self.local[slot], t1, plane)
+            # the previous image's unwraps have been running beside these launches; their owners wait for them now
+            if pending is not None:
+                st['tiles'] += time.perf_counter() - t
+                finish(*pending)
+                pending = None
+                t = time.perf_counter()
+            self.be.sync_tiles()
+            st['tiles'] += time.perf_counter() - t
+            t = time.perf_counter()
+            a, b = self.owners(i)
+            # tiles hold (dudx0, dudx1, dudy0, dudy1, w): component c needs fields (c, 2 + c, 4)
+            for c, owner in ((0, a), (1, b)):
+                got = self._gather_to([c, 2 + c, 4], owner)
+                if self.rank == owner:
+                    self._stitch_component(got, c, buf)
+            self.be.sync_device()
+            st['gather'] += time.perf_counter() - t
+            for c, owner in ((0, a), (1, b)):
+                if self.rank == owner:
+                    gdx, gdy, gw = self._pbuf[buf]
+                    self.be.unwrap_start(c, gdx[c], gdy[c], gw[c], self._pu[buf][c], self.kmax)
+            pending = (i, buf)
+        if pending is not None:
+            finish(*pending)
+        self.stage_s = st
+        return iters_all
+
     def close(self):
-        for name in ('wins', 'local', 'gathered', 'gdx', 'gdy', 'gw', 'u'):
+        if getattr(self, 'be', None) is not None:
+            self.be.close()
+        for name in ('wins', 'local', 'gathered', 'gdx', 'gdy', 'gw', 'u', '_pbuf', '_pu'):
             setattr(self, name, None)
 
 

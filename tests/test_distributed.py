@@ -222,3 +222,100 @@ def test_stack_sharded_over_ranks(tmp_path, world):
         assert np.array_equal(g['own'], u1[a:b])
         spans.append((a, b))
     assert spans == D.stack_shares(5, world)
+
+
+# ---- the image-pipelined schedule (TiledPipeline.run_stream) on CPU tensors ------------------------------------------
+class OracleTileBackend:
+    """test double of pygpa_amd.distributed.HipTileBackend: the five things TiledPipeline asks of the GPU, done by the
+    oracle on CPU tensors -- so the schedule (rotating unwrap owners), the gathers, the point-to-point hand-over and the
+    stitching of run_stream run under gloo without a GPU"""
+
+    def __init__(self):
+        import torch
+        self.torch = torch
+        self.device = torch.device('cpu')
+        self.gradients, self.unwrap = _oracle_compute()
+        self.iters = {}
+
+    def tile_gradients(self, win, wpitch, mean, kvecs, klists, sigma, border, rect, local_slot, t1, plane):
+        o0, o1, z0, z1 = rect
+        w = win.numpy() - mean
+        dudx, dudy, wn = self.gradients(np.ascontiguousarray(w), kvecs, klists, sigma, border)
+        dx = np.zeros((2,) + w.shape)
+        dy = np.zeros((2,) + w.shape)
+        dx[:, :, :-1] = dudx
+        dy[:, :-1, :] = dudy
+        t = self.torch.from_numpy
+        local_slot.zero_()
+        local_slot[0:2, :z0, :z1] = t(dx[:, o0:o0 + z0, o1:o1 + z1])
+        local_slot[2:4, :z0, :z1] = t(dy[:, o0:o0 + z0, o1:o1 + z1])
+        local_slot[4, :z0, :z1] = t(wn[o0:o0 + z0, o1:o1 + z1])
+
+    def sync_tiles(self):
+        pass
+
+    def unwrap_start(self, c, gdx, gdy, gw, out, kmax):
+        out.copy_(self.torch.from_numpy(self.unwrap(gdx.numpy(), gdy.numpy(), gw.numpy(), kmax)))
+        self.iters[c] = kmax
+
+    def unwrap_wait(self, c):
+        return self.iters[c]
+
+    def sync_device(self):
+        pass
+
+    def close(self):
+        pass
+
+
+def _stream_images(n):
+    from pygpa_amd.synthetic import hex_kvecs, gaussian_bump_displacement, hex_moire
+    shape = (128, 192)
+    kvecs = hex_kvecs(0.17, 7.0)
+    return [hex_moire(shape, kvecs, (0.2 + 0.1 * i) * gaussian_bump_displacement(shape), noise=0.05, seed=20 + i) for i in range(n)]
+
+
+def _stream_worker(rank, world, port, out_path):
+    sys.path.insert(0, ROOT)
+    if world > 1:
+        import torch.distributed as dist
+        dist.init_process_group('gloo', init_method='tcp://127.0.0.1:%d' % port, rank=rank, world_size=world)
+    from pygpa_amd import distributed as D
+    _, kvecs, klists = _case()
+    images = _stream_images(4)
+    pipe = D.TiledPipeline(images[0].shape, kvecs, np.stack(klists), 6, 20, kmax=10, dtype=np.float64, grid=(2, 2),
+                           backend=OracleTileBackend())
+    ref = []
+    for img in images:                      # the unpipelined step, image by image
+        pipe.load(img)
+        ref.append(pipe.step().clone().numpy())
+    got = {}
+    iters = pipe.run_stream(images, on_result=lambda i, u: got.__setitem__(i, u.clone().numpy()))
+    assert len(iters) == len(images)
+    for i in range(len(images)):
+        a, b = pipe.owners(i)
+        assert (a, b) == ((2 * i) % world, (2 * i + 1) % world)
+        assert (i in got) == (rank == a), 'the field of image %d must arrive on rank %d only' % (i, a)
+        if rank == a:
+            assert np.array_equal(got[i], ref[i]), 'image %d: pipelined field differs from step()' % i
+    assert set(pipe.stage_s) == {'load', 'mean', 'tiles', 'gather', 'unwrap_wait', 'handover'}
+    np.save(out_path % rank, np.array(sorted(got)))
+    pipe.close()
+    if world > 1:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+@pytest.mark.parametrize('world', [1, 2, 3])
+def test_pipelined_stream_equals_step(tmp_path, world):
+    """TiledPipeline.run_stream (unwrap of image i on the rotating owners (2 i + c) % N while every rank sweeps image
+    i + 1; gather of 3 of 5 fields to each owner; component 1 handed to the owner of component 0) gives, per image, the
+    field of step() bit for bit, on 1, 2 and 3 ranks"""
+    import torch.multiprocessing as mp
+    out = str(tmp_path / 'got_rank%d.npy')
+    if world == 1:
+        _stream_worker(0, 1, 0, out)
+    else:
+        mp.spawn(_stream_worker, args=(world, _free_port(), out), nprocs=world, join=True)
+    seen = np.concatenate([np.load(out % r) for r in range(world)])
+    assert sorted(seen.tolist()) == [0, 1, 2, 3]      # every image's field arrived exactly once

@@ -369,6 +369,29 @@ def _free_port():
     return port
 
 
+@pytest.mark.parametrize('world', [1, 2, 3])
+def test_pipelined_stream_ranks_one_gpu(tmp_path, world):
+    """TiledPipeline.run_stream on the device with 1, 2 and 3 ranks sharing cuda:0 (gloo, host-staged gathers and
+    hand-over): five images, the unwrap of image i on ranks (2 i + c) % N beside the sweeps of image i + 1; on its
+    owner every field equals step() of the same image bit for bit, and each arrives exactly once"""
+    for dtype in ('float64', 'float32'):
+        port = _free_port()
+        prefix = str(tmp_path / ('stream_%d_%s' % (world, dtype)))
+        procs = []
+        for r in range(world):
+            env = dict(os.environ, RANK=str(r), WORLD_SIZE=str(world), LOCAL_RANK=str(r), MASTER_ADDR='127.0.0.1',
+                       MASTER_PORT=str(port), HSA_ENABLE_IPC_MODE_LEGACY='0')
+            procs.append(subprocess.Popen([sys.executable, os.path.join(ROOT, 'tests', '_stream_rank_worker.py'), prefix, dtype],
+                                          env=env, stdout=subprocess.PIPE, stderr=subprocess.STDOUT))
+        outs = [p.communicate(timeout=900)[0].decode() for p in procs]
+        assert all(p.returncode == 0 for p in procs), '\n'.join(outs)
+        res = [np.load(prefix + '_rank%d.npz' % r) for r in range(world)]
+        assert all(bool(g['ok']) for g in res), (world, dtype)
+        assert sorted(np.concatenate([g['seen'] for g in res]).tolist()) == [0, 1, 2, 3, 4]
+        for g in res[1:]:
+            assert np.array_equal(g['ref0'], res[0]['ref0'])      # step() itself: every rank holds the same field
+
+
 def test_tiled_two_ranks_one_gpu(tmp_path):
     """pygpa_amd.distributed.TiledPipeline with world size 2: windows dealt to two processes that share
     cuda:0, all_reduce / all_gather / broadcast staged through the host on gloo.  Every rank must hold the
@@ -458,4 +481,10 @@ def test_bench_gpus_flag_spawns_ranks():
     out = json.loads(lines[0])
     assert out['n_gpus'] == 2 and out['steps'] == 2 and out['value'] > 0
     assert out['config']['image'] == [512, 256] and out['config']['tiles'] >= 2
-    assert 'all_gather' in out['config']['collectives']
+    assert out['config']['schedule'] == 'stream' and 'gather' in out['config']['collectives']
+    assert set(out['config']['stage_ms_per_image_rank0']) == {'load', 'mean', 'tiles', 'gather', 'unwrap_wait', 'handover'}
+    # the unpipelined schedule stays available
+    r = subprocess.run(cmd + ['--schedule', 'step'], env=env, stdout=subprocess.PIPE, stderr=subprocess.PIPE, timeout=900)
+    assert r.returncode == 0, r.stderr.decode()[-2000:]
+    out = json.loads([ln for ln in r.stdout.decode().splitlines() if ln.startswith('{')][0])
+    assert out['config']['schedule'] == 'step' and 'all_gather' in out['config']['collectives']
