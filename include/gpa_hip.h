@@ -238,6 +238,10 @@ int gpa_invert_u_overlap(gpa_plan* plan, const void* u, int iters, int edge, voi
 /* invert_u (geometric_phase_analysis.py:248-259), the variant without overlap: out is 2 x n0 x n1 and every
  * round after the first samples at r + u_it(r) - edge.                                              */
 int gpa_invert_u(gpa_plan* plan, const void* u, int iters, int edge, void* out);
+/* both with scipy.ndimage's boundary mode as an argument (the `mode=` keyword of the two reference functions):
+ * mode 0 = 'nearest' (their default, what the two entry points above run), 1 = 'constant' (cval 0; the last round of
+ * invert_u_overlap passes cval = nan, geometric_phase_analysis.py:297-299).  overlap != 0: invert_u_overlap.      */
+int gpa_invert_u_mode(gpa_plan* plan, const void* u, int iters, int edge, int overlap, int mode, void* out);
 int gpa_undistort_image(gpa_plan* plan, const void* deformed, const void* u, void* out);
 
 /* f-2 -- phase gradient -> Jacobian -> lattice properties.

@@ -39,6 +39,7 @@ SIGNATURES = {
     'gpa_sweep_gated': (_i, [_vp, _vp, _vp, _vp, _i, _d, _vp, _vp, _vp]),
     'gpa_reconstruct_prediff': (_i, [_vp, _vp, _vp, _vp, _i, _vp, _vp, _vp]),
     'gpa_invert_u': (_i, [_vp, _vp, _i, _i, _vp]),
+    'gpa_invert_u_mode': (_i, [_vp, _vp, _i, _i, _i, _i, _vp]),
     'gpa_reconstruct_grad': (_i, [_vp, _vp, _vp, _i, _i, _vp, _vp, _vp]),
     'gpa_reconstruct_grad_dev': (_i, [_vp, _vp, _vp, _i, _i, _vp, _vp, _vp]),
     'gpa_weighted_lstsq': (_i, [_vp, _vp, _vp, _vp, _i, _vp]),
@@ -231,12 +232,17 @@ class Plan:
                                                _ptr(dudx), _ptr(dudy), _ptr(wnorm)), 'gpa_reconstruct_prediff')
         return dudx, dudy, wnorm
 
-    def invert_u(self, us, iters=35, edge=0):
+    _WARP_MODES = {'nearest': 0, 'constant': 1}
+
+    def invert_u(self, us, iters=35, edge=0, mode='nearest'):
         us = np.ascontiguousarray(us, dtype=self.rdtype)
         if us.shape != (2,) + self.shape:
             raise ValueError('us must have shape (2,) + plan shape')
+        if mode not in self._WARP_MODES:
+            raise NotImplementedError("mode must be 'nearest' or 'constant'")
         out = np.empty((2,) + self.shape, dtype=self.rdtype)
-        check(self.lib.gpa_invert_u(self.handle, _ptr(us), int(iters), int(edge), _ptr(out)), 'gpa_invert_u')
+        check(self.lib.gpa_invert_u_mode(self.handle, _ptr(us), int(iters), int(edge), 0, self._WARP_MODES[mode], _ptr(out)),
+              'gpa_invert_u_mode')
         return out
 
     def reconstruct_grad(self, lockins, kvecs, mask_border):
@@ -261,12 +267,15 @@ class Plan:
               'gpa_weighted_lstsq')
         return out
 
-    def invert_u_overlap(self, us, iters=35, edge=0):
+    def invert_u_overlap(self, us, iters=35, edge=0, mode='nearest'):
         us = np.ascontiguousarray(us, dtype=self.rdtype)
         if us.shape != (2,) + self.shape:
             raise ValueError('us must have shape (2,) + plan shape')
+        if mode not in self._WARP_MODES:
+            raise NotImplementedError("mode must be 'nearest' or 'constant'")
         out = np.empty((2, self.shape[0] + 2 * edge, self.shape[1] + 2 * edge), dtype=self.rdtype)
-        check(self.lib.gpa_invert_u_overlap(self.handle, _ptr(us), int(iters), int(edge), _ptr(out)), 'gpa_invert_u_overlap')
+        check(self.lib.gpa_invert_u_mode(self.handle, _ptr(us), int(iters), int(edge), 1, self._WARP_MODES[mode], _ptr(out)),
+              'gpa_invert_u_mode')
         return out
 
     def undistort_image(self, deformed, u):

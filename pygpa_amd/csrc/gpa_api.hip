@@ -1525,7 +1525,7 @@ int gpa_tile_gradients_dev(gpa_plan* p, const void* image, size_t image_pitch, i
   return GPA_OK;
 }
 
-static int invert_u_host(gpa_plan* p, const void* u, int iters, int edge, int shift, void* out) {
+static int invert_u_host(gpa_plan* p, const void* u, int iters, int edge, int shift, void* out, int mode = 0) {
   if (!p || !u || !out) return fail(GPA_ERR_ARG, "gpa_invert_u: null argument");
   if (iters < 1 || edge < 0) return fail(GPA_ERR_ARG, "gpa_invert_u: need iters >= 1, edge >= 0");
   HIP_TRY(hipSetDevice(p->device));
@@ -1533,7 +1533,7 @@ static int invert_u_host(gpa_plan* p, const void* u, int iters, int edge, int sh
   void* d_out = nullptr;
   HIP_TRY(hipMalloc(&d_out, 2 * nout * p->rsz));
   hipError_t e = hipMemcpyAsync(p->d_u, u, 2 * npx * p->rsz, hipMemcpyHostToDevice, p->stream);
-  if (e == hipSuccess) e = warp_invert_u(p->dtype, p->d_u, p->n0, p->n1, 1.0, iters, edge, shift, d_out, p->stream);
+  if (e == hipSuccess) e = warp_invert_u(p->dtype, p->d_u, p->n0, p->n1, 1.0, iters, edge, shift, d_out, p->stream, mode);
   if (e == hipSuccess) e = hipMemcpyAsync(out, d_out, 2 * nout * p->rsz, hipMemcpyDeviceToHost, p->stream);
   if (e == hipSuccess) e = hipStreamSynchronize(p->stream);
   hipFree(d_out);
@@ -1549,6 +1549,13 @@ int gpa_invert_u_overlap(gpa_plan* p, const void* u, int iters, int edge, void* 
 // at r + u_it(r) - edge
 int gpa_invert_u(gpa_plan* p, const void* u, int iters, int edge, void* out) {
   return invert_u_host(p, u, iters, 0, edge, out);
+}
+
+// the two with scipy's boundary mode as an argument: 0 = 'nearest', 1 = 'constant' (the `mode=` keyword of
+// geometric_phase_analysis.py:248, :262); overlap != 0 = invert_u_overlap
+int gpa_invert_u_mode(gpa_plan* p, const void* u, int iters, int edge, int overlap, int mode, void* out) {
+  if (mode != 0 && mode != 1) return fail(GPA_ERR_ARG, "gpa_invert_u_mode: mode must be 0 (nearest) or 1 (constant)");
+  return overlap ? invert_u_host(p, u, iters, edge, 0, out, mode) : invert_u_host(p, u, iters, 0, edge, out, mode);
 }
 
 int gpa_undistort_image(gpa_plan* p, const void* deformed, const void* u, void* out) {

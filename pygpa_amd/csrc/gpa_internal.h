@@ -203,8 +203,9 @@ hipError_t launch_deconv_filter(int dtype, void* Z, int n0, int n1, const double
 hipError_t launch_deconv_unpack(int dtype, const void* Z, int m0, int m1, int pad, void* out, hipStream_t s);
 
 // ---- f-1 Lawler-Fujita (gpa_warp.hip); both synchronise the stream before returning -----------
+// mode: 0 = scipy 'nearest' (the reference's default), 1 = 'constant'
 hipError_t warp_invert_u(int dtype, const void* d_u, int n0, int n1, double scale, int iters, int edge, int shift,
-                         void* d_out, hipStream_t s);
+                         void* d_out, hipStream_t s, int mode = 0);
 hipError_t warp_image(int dtype, const void* d_img, const void* d_uinv, int n0, int n1, void* d_out, hipStream_t s);
 
 }  // namespace gpa

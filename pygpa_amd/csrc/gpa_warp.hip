@@ -130,6 +130,60 @@ __device__ __forceinline__ void interp_nearest(const T* const (&coef)[NC], int m
   }
 }
 
+// mode='constant': whole-sample mirrored taps, `cval` where the coordinate leaves [0, n-1] (NaN coordinates too)
+template <class T, int NC>
+__device__ __forceinline__ void interp_constant(const T* const (&coef)[NC], int n0, int n1, T x, T y, T cval, T (&out)[NC]) {
+  if (!(x >= T(0) && x <= T(n0 - 1) && y >= T(0) && y <= T(n1 - 1))) {
+#pragma unroll
+    for (int n = 0; n < NC; ++n) out[n] = cval;
+    return;
+  }
+  const T fx = floor(x), fy = floor(y);
+  T wx[4], wy[4];
+  bspline_weights(x - fx, wx);
+  bspline_weights(y - fy, wy);
+  const int ix = (int)fx - 1, iy = (int)fy - 1;
+  int cy[4];
+#pragma unroll
+  for (int b = 0; b < 4; ++b) cy[b] = ext_index(iy + b, n1, EXT_MIRROR);
+#pragma unroll
+  for (int n = 0; n < NC; ++n) out[n] = T(0);
+#pragma unroll
+  for (int a = 0; a < 4; ++a) {
+    const size_t row = (size_t)ext_index(ix + a, n0, EXT_MIRROR) * n1;
+#pragma unroll
+    for (int n = 0; n < NC; ++n) {
+      const T* cr = coef[n] + row;
+      out[n] += wx[a] * (wy[0] * cr[cy[0]] + wy[1] * cr[cy[1]] + wy[2] * cr[cy[2]] + wy[3] * cr[cy[3]]);
+    }
+  }
+}
+
+// the same fixed point with scipy's mode='constant' (geometric_phase_analysis.py:248, :262 `mode=`): coefficients of the
+// unpadded field, 0 outside it in every round but the last of the overlap variant, which passes cval=nan (:297-299)
+template <class T>
+__global__ __launch_bounds__(256) void invert_constant_kernel(const T* __restrict__ c0, const T* __restrict__ c1, int n0, int n1,
+                                                             int edge, int shift, int iters, int nan_last,
+                                                             T* __restrict__ out) {
+  const int o1 = n1 + 2 * edge, o0 = n0 + 2 * edge;
+  const int j = blockIdx.x * 256 + threadIdx.x, i = blockIdx.y;
+  if (j >= o1) return;
+  const T* const coef[2] = {c0, c1};
+  const T xb = T(i - edge), yb = T(j - edge);
+  T v[2];
+  interp_constant<T, 2>(coef, n0, n1, xb, yb, T(0), v);
+  const T xs = xb - T(shift), ys = yb - T(shift);
+  for (int it = 0; it < iters; ++it) {
+    T nv[2];
+    const T cval = (nan_last && it == iters - 1) ? (T)__builtin_nan("") : T(0);
+    interp_constant<T, 2>(coef, n0, n1, xs + v[0], ys + v[1], cval, nv);
+    v[0] = nv[0];
+    v[1] = nv[1];
+  }
+  out[(size_t)i * o1 + j] = v[0];
+  out[(size_t)o0 * o1 + (size_t)i * o1 + j] = v[1];
+}
+
 // u_it(r) <- u(r + u_it(r)), all rounds for one pixel (geometric_phase_analysis.py:291-299)
 template <class T>
 __global__ __launch_bounds__(256) void invert_kernel(const T* __restrict__ c0, const T* __restrict__ c1, int m0, int m1,
@@ -203,6 +257,30 @@ hipError_t prefilter(const T* in, int m0, int m1, int ext, const T* d_h, T* tmp,
 }
 
 template <class T>
+hipError_t invert_constant_t(const T* d_u, int n0, int n1, T scale, int iters, int edge, int shift, T* d_out, hipStream_t s) {
+  const size_t npx = (size_t)n0 * n1;
+  T *buf = nullptr, *d_h = nullptr;
+  hipError_t e = hipMalloc((void**)&buf, 4 * npx * sizeof(T));   // scaled copy, tmp, coef0, coef1
+  if (e != hipSuccess) return e;
+  e = build_taps<T>(&d_h, s);
+  T *cp = buf, *tmp = buf + npx, *c0 = buf + 2 * npx, *c1 = buf + 3 * npx;
+  for (int c = 0; c < 2 && e == hipSuccess; ++c) {
+    pad_edge_kernel<T><<<dim3((n1 + 255) / 256, n0), 256, 0, s>>>(d_u + (size_t)c * npx, n0, n1, 0, scale, cp);
+    e = prefilter<T>(cp, n0, n1, EXT_MIRROR, d_h, tmp, c == 0 ? c0 : c1, s);
+  }
+  if (e == hipSuccess) {
+    const int o1 = n1 + 2 * edge, o0 = n0 + 2 * edge;
+    // invert_u_overlap (shift == 0) ends on a cval=nan round; invert_u (shift = edge) does not
+    invert_constant_kernel<T><<<dim3((o1 + 255) / 256, o0), 256, 0, s>>>(c0, c1, n0, n1, edge, shift, iters, shift == 0 ? 1 : 0, d_out);
+    e = hipGetLastError();
+  }
+  if (e == hipSuccess) e = hipStreamSynchronize(s);
+  hipFree(buf);
+  if (d_h) hipFree(d_h);
+  return e;
+}
+
+template <class T>
 hipError_t invert_t(const T* d_u, int n0, int n1, T scale, int iters, int edge, int shift, T* d_out, hipStream_t s) {
   const int m0 = n0 + 2 * NPAD, m1 = n1 + 2 * NPAD;
   const size_t mp = (size_t)m0 * m1;
@@ -248,7 +326,10 @@ hipError_t warp_t(const T* d_img, const T* d_uinv, int n0, int n1, T* d_out, hip
 
 // d_u: 2 x n0 x n1 (device); the field that is inverted is scale * u; d_out: 2 x (n0+2e) x (n1+2e)
 hipError_t warp_invert_u(int dtype, const void* d_u, int n0, int n1, double scale, int iters, int edge, int shift,
-                         void* d_out, hipStream_t s) {
+                         void* d_out, hipStream_t s, int mode) {
+  if (mode == 1)
+    return dtype == 0 ? invert_constant_t<float>((const float*)d_u, n0, n1, (float)scale, iters, edge, shift, (float*)d_out, s)
+                      : invert_constant_t<double>((const double*)d_u, n0, n1, scale, iters, edge, shift, (double*)d_out, s);
   return dtype == 0 ? invert_t<float>((const float*)d_u, n0, n1, (float)scale, iters, edge, shift, (float*)d_out, s)
                     : invert_t<double>((const double*)d_u, n0, n1, scale, iters, edge, shift, (double*)d_out, s);
 }

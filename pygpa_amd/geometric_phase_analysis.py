@@ -503,21 +503,19 @@ def gaussian_deconvolve(data, sigma, dr=20, balance=5000, dtype=None):
 def invert_u_overlap(us, iters=35, edge=0, mode='nearest', dtype=None):
     """Numerical inverse of the displacement `us` (geometric_phase_analysis.py:262-300):
     u_it(r + us(r)) = r, by `iters` rounds of cubic-spline resampling on the grid extended by
-    `edge` pixels.  Only mode='nearest' (the reference's default) is provided."""
-    if mode != 'nearest':
-        raise NotImplementedError("only mode='nearest' is provided")
+    `edge` pixels.  mode: scipy.ndimage's 'nearest' (the reference's default) or 'constant' (cval 0, the last round
+    cval = nan as in the reference); the other scipy modes are not provided."""
     us = np.asarray(us)
     plan = _lib.get_plan(us.shape[1:], 1, DEFAULT_DTYPE if dtype is None else dtype)
-    return plan.invert_u_overlap(us, iters=iters, edge=edge)
+    return plan.invert_u_overlap(us, iters=iters, edge=edge, mode=mode)
 
 
 def invert_u(us, iters=35, edge=0, mode='nearest', dtype=None):
-    """The variant without overlap (geometric_phase_analysis.py:248-259): u_it on the image's own grid."""
-    if mode != 'nearest':
-        raise NotImplementedError("only mode='nearest' is provided")
+    """The variant without overlap (geometric_phase_analysis.py:248-259): u_it on the image's own grid; mode 'nearest'
+    or 'constant' as above."""
     us = np.asarray(us)
     plan = _lib.get_plan(us.shape[1:], 1, DEFAULT_DTYPE if dtype is None else dtype)
-    return plan.invert_u(us, iters=iters, edge=edge)
+    return plan.invert_u(us, iters=iters, edge=edge, mode=mode)
 
 
 def undistort_image(deformed, u, dtype=None):
