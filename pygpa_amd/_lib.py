@@ -554,11 +554,23 @@ class Plan:
                     if c - 2 in dns:
                         dns.pop(c - 2).result()           # its u buffer has been read out
                     a, b = bounds[c]
-                    it = self.extract_displacement_field_batch_dev(d_img[c % 2].ptr, b - a, kvecs, klists, sigma, mask_border,
-                                                                   kmax, d_u[c % 2].ptr, want_iters=False)
+                    batched = True
+                    try:
+                        self.extract_displacement_field_batch_dev(d_img[c % 2].ptr, b - a, kvecs, klists, sigma, mask_border,
+                                                                  kmax, d_u[c % 2].ptr, want_iters=False)
+                    except GPAError as err:
+                        # shapes without a batched unwrap (sides no fused path covers): the same frames one call each --
+                        # the numbers the docstring promises, just without the shared launch chain
+                        if 'no batched unwrap' not in str(err):
+                            raise
+                        batched = False
+                        for f in range(b - a):
+                            iters[a + f] = self.extract_displacement_field_dev(d_img[c % 2].ptr + f * npx * item, kvecs, klists, sigma,
+                                                                               mask_border, kmax, d_u[c % 2].ptr + 2 * f * npx * item)
                     if c + 1 < nchunks:                    # (its image buffer was last read by chunk c - 1: done, see sync below)
                         ups[c + 1] = up_pool.submit(upload, c + 1)
-                    iters[a:b] = self._batch_iters(b - a)   # synchronises: chunk c is finished
+                    if batched:
+                        iters[a:b] = self._batch_iters(b - a)   # synchronises: chunk c is finished
                     dns[c] = dn_pool.submit(download, c)
                 for f in dns.values():
                     f.result()

@@ -1296,7 +1296,10 @@ int gpa_extract_displacement_field_batch_dev(gpa_plan* p, const void* images, in
   int Bx = 0;
   TRY(extract_stage(p, kvecs, P, klists, K, sigma, &Bx));
   const size_t npx = (size_t)p->n0 * p->n1;
-  if (p->uwb_images != B) {
+  // the batched workspace is a capacity: fewer frames (a ragged last chunk, a shorter stack) reuse it
+  if (B <= p->uwb_images) {
+    if (!unwrap_set_active(&p->uwb, 2 * B)) return fail(GPA_ERR_STATE, "batched unwrap workspace: bad active count");
+  } else {
     HIP_TRY(hipStreamSynchronize(p->stream));
     if (p->uwb_images) {
       unwrap_workspace_destroy(&p->uwb);

@@ -56,6 +56,8 @@ double* unwrap_partials_buffer(UnwrapWorkspace* ws, int problem = 0);
 hipError_t unwrap_enqueue_prepared(UnwrapWorkspace* ws, const void* weight, int nparts, int kmax, double eps,
                                    bool axes_compat, void* phi, hipStream_t s);
 hipError_t unwrap_finish(UnwrapWorkspace* ws, int* iters_out, hipStream_t s);
+// solve the first n problems of a workspace created for more (false: n exceeds its capacity)
+bool unwrap_set_active(UnwrapWorkspace* ws, int n);
 // asynchronous copy of the iteration count into (pinned) host memory, no synchronisation
 // (a batched workspace: nprob counts, 4 ints apart -- host_pinned[4 * pb])
 hipError_t unwrap_fetch_iters(UnwrapWorkspace* ws, int* host_pinned, hipStream_t s);

@@ -52,6 +52,7 @@ constexpr size_t PART_N = (size_t)3 * MAXPART;
 struct Impl {
   int dtype, n0, n1, lg0, lg1;
   int nprob;                 // problems solved per launch (blockIdx.z): 1, or 2 x images of a batched driver call
+  int cap;                   // problems the buffers hold (nprob <= cap: unwrap_set_active)
   int iters_slot;            // flags[iters_slot] = iterations performed (3: fused iteration, 0: plain scheme)
   bool lat_ok;               // latency-tuned kernel variants allowed (GPA_NO_LAT unset), read once per solve
   bool supported;
@@ -2290,6 +2291,7 @@ hipError_t unwrap_workspace_create(int dtype, int n0, int n1, hipStream_t s, Unw
   w->n0 = n0;
   w->n1 = n1;
   w->nprob = nprob < 1 ? 1 : nprob;
+  w->cap = w->nprob;
   w->rsz = dtype == 0 ? 4 : 8;
   w->lg0 = ilog2_exact(n0);
   w->lg1 = ilog2_exact(n1);
@@ -2305,18 +2307,18 @@ hipError_t unwrap_workspace_create(int dtype, int n0, int n1, hipStream_t s, Unw
   hipError_t e;
   void** arrs[] = {&w->r, &w->p, &w->p2, &w->q, &w->z};
   for (void** a : arrs) {
-    e = hipMalloc(a, npx * w->rsz * w->nprob);
+    e = hipMalloc(a, npx * w->rsz * w->cap);
     if (e != hipSuccess) return e;
-    bytes += npx * w->rsz * w->nprob;
+    bytes += npx * w->rsz * w->cap;
   }
   w->ring[0] = w->p;
   w->ring[1] = w->p2;
   w->nring = 2;
-  e = hipMalloc((void**)&w->scal, (size_t)SCAL_N * w->nprob * sizeof(double));
+  e = hipMalloc((void**)&w->scal, (size_t)SCAL_N * w->cap * sizeof(double));
   if (e != hipSuccess) return e;
-  e = hipMalloc((void**)&w->flags, (size_t)FLAGS_N * w->nprob * sizeof(int));
+  e = hipMalloc((void**)&w->flags, (size_t)FLAGS_N * w->cap * sizeof(int));
   if (e != hipSuccess) return e;
-  e = hipMalloc((void**)&w->part, PART_N * w->nprob * sizeof(double));
+  e = hipMalloc((void**)&w->part, PART_N * w->cap * sizeof(double));
   if (e != hipSuccess) return e;
   if (w->supported && w->generic) {
     for (int ax = 0; ax < 2; ++ax) {
@@ -2574,7 +2576,7 @@ static hipError_t run_pcg(Impl* w, const void* a, const void* b, const void* wei
     if (ring < 2) ring = 2;
     while (w->nring < ring) {
       void* buf = nullptr;
-      if (hipMalloc(&buf, npx * w->rsz * w->nprob) != hipSuccess) { (void)hipGetLastError(); break; }
+      if (hipMalloc(&buf, npx * w->rsz * w->cap) != hipSuccess) { (void)hipGetLastError(); break; }
       w->ring[w->nring++] = buf;
     }
     if (w->nring < ring) ring = w->nring;   // out of memory: flush more often
@@ -2701,6 +2703,14 @@ hipError_t unwrap_fetch_iters(UnwrapWorkspace* ws, int* host_pinned, hipStream_t
   // host_pinned[FLAGS_N * j + unwrap_iters_slot()]
   if (w->nprob == 1) return hipMemcpyAsync(host_pinned, w->flags + w->iters_slot, sizeof(int), hipMemcpyDeviceToHost, s);
   return hipMemcpyAsync(host_pinned, w->flags, (size_t)FLAGS_N * w->nprob * sizeof(int), hipMemcpyDeviceToHost, s);
+}
+// a workspace created for `cap` problems solves the first n of them (n <= cap): a stack whose last chunk is ragged,
+// or a shorter stack, reuses the buffers instead of paying a destroy / create (hipMalloc, table upload) per change
+bool unwrap_set_active(UnwrapWorkspace* ws, int n) {
+  Impl* w = (Impl*)ws->impl;
+  if (!w || n < 1 || n > w->cap) return false;
+  w->nprob = n;
+  return true;
 }
 int unwrap_iters_slot(const UnwrapWorkspace* ws) {
   const Impl* w = (const Impl*)ws->impl;

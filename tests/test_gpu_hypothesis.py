@@ -111,3 +111,32 @@ def test_invert_u_modes_vs_scipy(dtype, tol):
                 assert np.abs(out[ok] - ref[ok]).max() < tol * max(1.0, np.abs(ref[ok]).max()), (mode, kw, fn.__name__)
     with pytest.raises(NotImplementedError):
         GPA.invert_u(us, mode='wrap', dtype=dtype)
+
+
+def test_stack_ragged_chunks_and_fallback(monkeypatch):
+    """ADVICE r02: the batched unwrap workspace is a capacity (a ragged last chunk and a shorter second stack reuse it);
+    a shape without a batched unwrap (here: the mixed-radix engine switched off on a 100 x 60 frame) falls back to
+    per-frame calls instead of raising -- both give the per-frame loop's numbers"""
+    monkeypatch.setenv('GPA_NO_LAT', '1')
+    kvecs = hex_kvecs(0.12, 11.0)
+    shape = (128, 96)
+    frames = np.stack([hex_moire(shape, kvecs, None, noise=0.1, seed=s) for s in range(5)])
+    kw = np.linalg.norm(kvecs, axis=1).mean() / 2.5
+    from pygpa_amd.synthetic import explicit_klists
+    klists = np.stack(explicit_klists(kvecs, kw, 2, 2))
+    plan = _lib.Plan(shape, 12, np.float64)
+    ref = np.stack([plan.extract_displacement_field(f, kvecs, klists, 8, 16)[0] for f in frames])
+    u, it = plan.extract_displacement_field_stack(frames, kvecs, klists, 8, 16, chunk=2)      # chunks of 2, 2, 1
+    assert np.array_equal(u, ref) and it.shape == (5, 2)
+    u3, _ = plan.extract_displacement_field_stack(frames[:3], kvecs, klists, 8, 16, chunk=3)  # grows the capacity
+    u1, _ = plan.extract_displacement_field_stack(frames[3:4], kvecs, klists, 8, 16)           # and a shorter stack reuses it
+    assert np.array_equal(u3, ref[:3]) and np.array_equal(u1, ref[3:4])
+    plan.close()
+    monkeypatch.setenv('GPA_NO_MR', '1')
+    shape = (100, 60)
+    frames = np.stack([hex_moire(shape, kvecs, None, noise=0.1, seed=s) for s in range(3)])
+    plan = _lib.Plan(shape, 12, np.float64)
+    ref = np.stack([plan.extract_displacement_field(f, kvecs, klists, 8, 16)[0] for f in frames])
+    u, it = plan.extract_displacement_field_stack(frames, kvecs, klists, 8, 16)
+    assert np.array_equal(u, ref) and np.all(it > 0)
+    plan.close()

@@ -1,0 +1,45 @@
+#!/bin/bash
+# usage (GPU box): COMMIT=<sha> [ROUND=r03] [SKIP_TESTS=1] tools/gpu_close.sh
+# Closing pass of a round: the whole GPU suite, smoke, the bench line, rocprofv3 kernel stats (4096^2 f32 / f64, 3000^2, 512^2)
+# and the PMC passes behind profiles/counters.json (one pass per counter set: the guide's rule).  Everything lands under
+# gpurun_out/close/; copy what is to be kept into profiles/ with the round's prefix.
+ulimit -c 0
+ROOT=$GRAFT_REPO_ROOT
+cd "$ROOT" || exit 1
+out=$ROOT/gpurun_out/close; mkdir -p $out
+if [ -z "$SKIP_TESTS" ]; then
+  timeout 2400 python -m pytest tests -q -m gpu -x --durations=12 > $out/pytest_gpu.log 2>&1
+  echo "pytest rc=$?"; tail -4 $out/pytest_gpu.log
+fi
+timeout 300 python __graft_entry__.py smoke 2>&1 | tail -1
+timeout 900 python bench.py > $out/bench.json 2> $out/bench.err; echo "bench rc=$?"; tail -2 $out/bench.err; head -c 700 $out/bench.json; echo
+cd /tmp && export TMPDIR=/tmp
+kstats() {   # tag, bench args...
+  tag=$1; shift
+  timeout 600 rocprofv3 --kernel-trace --stats --output-format csv -d $out/ks_$tag -- python3 $ROOT/bench.py --steps 5 --warmup 1 --no-cpu --no-f64 "$@" > $out/ks_$tag.log 2>&1
+  f=$(ls $out/ks_$tag/*/*kernel_stats.csv 2>/dev/null | head -1)
+  [ -n "$f" ] && cp $f $out/kernel_stats_$tag.csv && head -12 $out/kernel_stats_$tag.csv | cut -c1-150
+  rm -rf $out/ks_$tag
+}
+kstats 4096_f32
+kstats 4096_f64 --dtype f64
+kstats 3000_f32 --size 3000
+kstats 2048_c2 --size 2048 --kgrid 4x2
+kstats 512_f32 --size 512
+i=0
+for set in "FETCH_SIZE" "WRITE_SIZE" "SQ_INSTS_VALU SQ_WAVES SQ_INSTS_LDS SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE SQ_WAVE_CYCLES SQ_WAIT_INST_ANY SQ_BUSY_CYCLES" \
+           "SQ_WAIT_ANY SQ_ACTIVE_INST_ANY SQ_ACTIVE_INST_VALU SQ_INSTS_VALU_MFMA_F32 SQ_INSTS_VMEM_WR SQ_INSTS_VMEM_RD" "TCC_HIT_sum TCC_MISS_sum GRBM_GUI_ACTIVE"; do
+  timeout 300 rocprofv3 --pmc $set --output-format csv -d $out/pmc_$i -- python3 $ROOT/bench.py --steps 2 --warmup 1 --no-cpu --no-f64 > $out/pmc_$i.log 2>&1
+  echo "pmc pass $i ($set): rc=$?"
+  i=$((i+1))
+done
+cd $ROOT
+COMMIT=${COMMIT:-unknown} python3 tools/make_counters.py $out/counters.json $out/pmc_[0-9] > /dev/null; head -c 900 $out/counters.json; echo
+# f64 traffic of the sweep (18.2 GB moved for 4 GB needed)
+j=0
+for set in "FETCH_SIZE" "WRITE_SIZE"; do
+  timeout 300 rocprofv3 --pmc $set --output-format csv -d $out/pmc64_$j -- python3 $ROOT/bench.py --dtype f64 --steps 2 --warmup 1 --no-cpu --no-f64 > $out/pmc64_$j.log 2>&1
+  j=$((j+1))
+done
+COMMIT=${COMMIT:-unknown} PMC_DTYPE=f64 python3 tools/make_counters.py $out/counters_f64.json $out/pmc64_[0-9] > /dev/null
+rm -rf $out/pmc_[0-9] $out/pmc64_[0-9]
