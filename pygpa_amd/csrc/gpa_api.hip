@@ -238,6 +238,16 @@ struct gpa_plan {
   bool sh_use = false;            // ... and the staged candidates form runs of >= 2 on an x-plane
   size_t sh_gb_bytes = 0, sh_psi_bytes = 0;
   std::vector<int> staged_planeof;
+  // shared-forward pass A: the same for the x axis (tables per x-plane)
+  bool shA_ok = false;
+  int shA_etab = 0, shA_E = 0, shA_Epad = 0;
+  Axis ax0s{};
+  void* tw0s = nullptr;
+  int tw0s_L = 0;
+  double* d_taps0 = nullptr;
+  void *shA_gtab = nullptr, *shA_Gx = nullptr, *shA_psi = nullptr, *shA_sx = nullptr;
+  size_t shA_gx_bytes = 0, shA_psi_bytes = 0;
+  int shA_built_epoch = -1, shA_built_Bx = 0;
   void* Tbuf = nullptr;           // [tbuf_planes][n0][n1] complex: one plane per DISTINCT wx (x-plane), grown on demand
   int tbuf_planes = 0;
   SweepTables tb{};
@@ -471,6 +481,51 @@ static int ensure_filters(gpa_plan* p, double sigma) {
     }
     build_filter_table(cur, g, hsp, table);
     TRY(upload_real_table(p, axis == 0 ? p->Hx : p->Hy, table));
+    if (axis == 0) {
+      // shared-forward pass A: taps, support and (for lengths that are not powers of two) the zero-padded geometry
+      // of the x axis, exactly as for the y axis below
+      p->shA_ok = false;
+      const int n = cur.n;
+      int mmax = (int)ceil(10.0 * sigma) + 16;
+      if (p->use_shared && mmax < n / 2 && mmax <= 1024) {
+        std::vector<double> taps = spatial_taps(n, g, mmax);
+        double total = fabs(taps[0]), tail = 0;
+        for (int m = 1; m <= mmax; ++m) total += 2 * fabs(taps[m]);
+        int E = 1;
+        const double tol = p->dtype == 0 ? 1e-9 : 1e-14;
+        for (int m = mmax; m >= 1; --m) {
+          tail += 2 * fabs(taps[m]);
+          if (tail > tol * total) { E = m; break; }
+        }
+        Axis sa = cur;
+        if (cur.padded) {
+          sa.lg = 6;
+          while ((1 << sa.lg) < n + E) ++sa.lg;
+          sa.L = 1 << sa.lg;
+          sa.extL = sa.extR = 0;
+        }
+        if (passA_shared_supports(p->dtype, sa, E)) {
+          const int Epad = (E + 15) & ~15;
+          if (sa.L != cur.L && p->tw0s_L != sa.L) {
+            if (!p->tw0s) TRY(dmalloc(p, &p->tw0s, (size_t)4096 * p->csz));
+            TRY(upload_twiddles(p, p->tw0s, sa.L));
+            p->tw0s_L = sa.L;
+          }
+          p->ax0s = sa;
+          if (!p->d_taps0) TRY(dmalloc(p, (void**)&p->d_taps0, 1025 * sizeof(double)));
+          if (!p->shA_gtab) TRY(dmalloc(p, &p->shA_gtab, (2 * 256 + 16) * p->rsz));
+          HIP_TRY(hipMemcpyAsync(p->d_taps0, taps.data(), ((size_t)mmax + 1) * sizeof(double), hipMemcpyHostToDevice, p->stream));
+          HIP_TRY(hipStreamSynchronize(p->stream));
+          std::vector<double> gt((size_t)2 * Epad + 16, 0.0);
+          for (int m = 1; m <= E; ++m) gt[m] = taps[m];
+          TRY(upload_real_table(p, p->shA_gtab, gt));
+          p->shA_etab = mmax;
+          p->shA_E = E;
+          p->shA_Epad = Epad;
+          p->shA_ok = true;
+        }
+      }
+    }
     if (axis == 1) {
       // shared-forward pass B: the taps of this axis' filter out to where they are rounding noise, the support E
       // beyond which they are dropped from the end fix (the same criterion as the compact extension above)
@@ -670,6 +725,8 @@ static int stage_kmat(gpa_plan* p, const double* kvecs, int P) {
   return GPA_OK;
 }
 
+static int run_passA(gpa_plan* p, const void* image, const void* mean, void* Tbuf, int Bx, int nimg = 1);
+
 // ---------------------------------------------------------------------------
 // exported functions
 // ---------------------------------------------------------------------------
@@ -741,7 +798,8 @@ void gpa_plan_destroy(gpa_plan* p) {
   void* bufs[] = {p->tw0, p->tw1, p->Hx, p->Hy, p->Tbuf, p->tb.cxb, p->tb.sx, p->tb.wxw, p->tb.wxr, p->tb.cyb, p->tb.sy, p->tb.wyw, p->tb.wyr, p->tb.planeof, p->d_pw,
                   p->tb.dx, p->tb.dy, p->d_kl, p->d_kr, p->d_image, p->d_mean, p->d_tile_mean, p->d_scratch,
                   p->d_lockin, p->d_kidx, p->d_dudx, p->d_dudy, p->d_wnorm, p->d_u, p->d_kmat, p->d_sf, p->d_grad, p->d_aux0, p->d_aux1,
-                  p->sh.Gb, p->sh.psi, p->sh.dyc, p->sh.gtab, p->sh.desc, p->d_taps, p->tw1s};
+                  p->sh.Gb, p->sh.psi, p->sh.dyc, p->sh.gtab, p->sh.desc, p->d_taps, p->tw1s,
+                  p->tw0s, p->d_taps0, p->shA_gtab, p->shA_Gx, p->shA_psi, p->shA_sx};
   for (void* b : bufs)
     if (b) hipFree(b);
   unwrap_workspace_destroy(&p->uw);
@@ -799,7 +857,7 @@ int gpa_lockin_batch_dev(gpa_plan* p, const void* image, const double* kvecs, in
   int Bx = 0;
   TRY(stage_kvectors(p, kvecs, kvecs, B, &Bx));
   TRY(ensure_tbuf(p, Bx));
-  HIP_TRY(launch_passA(p->dtype, p->ax0, p->n1, image, nullptr, p->tb, p->Hx, p->tw0, p->Tbuf, Bx, p->stream));
+  TRY(run_passA(p, image, nullptr, p->Tbuf, Bx));
   HIP_TRY(launch_passB(p->dtype, p->ax1, p->n0, p->Tbuf, p->Hy, p->tw1, p->tb, B, 1, false, out, nullptr,
                        p->stream));
   return GPA_OK;
@@ -816,6 +874,53 @@ int gpa_lockin_batch(gpa_plan* p, const void* image, const double* kvecs, int B,
   TRY(gpa_lockin_batch_dev(p, p->d_image, kvecs, B, sigma, p->d_sf));
   HIP_TRY(hipMemcpyAsync(out, p->d_sf, (size_t)B * npx * p->csz, hipMemcpyDeviceToHost, p->stream));
   HIP_TRY(hipStreamSynchronize(p->stream));
+  return GPA_OK;
+}
+
+// per-plane tables of the shared-forward pass A for the staged x-planes: rebuilt when sigma or the k-list changed
+static int sharedA_prepare(gpa_plan* p, int Bx, bool* use) {
+  *use = false;
+  // Opt-in (GPA_SHARED_A=1).  Measured at 4096^2, 3 x 4 planes, f32 (profiles/r03_passA_shared.txt): 1.0 - 1.2 ms against
+  // the per-plane kernel's 0.815 ms although its transforms alone take 0.43 ms against 0.51 ms: pass A is bound by
+  // the drain of its 32-byte-segment stores (~0.6 - 0.75 ms for 1.6 GB), which the per-plane kernel hides behind the
+  // forward transform of the NEXT plane (it needs nothing from memory), while the shared kernel's next plane starts
+  // with table loads that queue behind those stores.  Kept for the record and for the tests that pin its parity.
+  if (!p->shA_ok || !p->use_shared || Bx < 2 || !getenv("GPA_SHARED_A")) return GPA_OK;
+  if (p->shA_built_epoch == p->sh_epoch && p->shA_built_Bx == Bx) { *use = true; return GPA_OK; }
+  HIP_TRY(hipStreamSynchronize(p->stream));
+  const size_t gx = (size_t)Bx * p->ax0s.L * p->rsz, ps = (size_t)Bx * p->shA_Epad * p->csz;
+  if (gx > p->shA_gx_bytes) {
+    if (p->shA_Gx) { (void)hipFree(p->shA_Gx); p->ws_bytes -= p->shA_gx_bytes; p->shA_Gx = nullptr; p->shA_gx_bytes = 0; }
+    TRY(dmalloc(p, &p->shA_Gx, gx));
+    p->shA_gx_bytes = gx;
+  }
+  if (ps > p->shA_psi_bytes) {
+    if (p->shA_psi) { (void)hipFree(p->shA_psi); p->ws_bytes -= p->shA_psi_bytes; p->shA_psi = nullptr; p->shA_psi_bytes = 0; }
+    TRY(dmalloc(p, &p->shA_psi, ps));
+    p->shA_psi_bytes = ps;
+  }
+  if (!p->shA_sx) TRY(dmalloc(p, &p->shA_sx, (size_t)p->max_batch * 16 * p->csz));
+  HIP_TRY(launch_sharedA_tables(p->dtype, p->ax0s, p->d_pw, p->d_taps0, p->shA_etab, p->shA_E, p->shA_Epad, Bx, p->shA_Gx,
+                                p->shA_psi, p->shA_sx, p->stream));
+  p->shA_built_epoch = p->sh_epoch;
+  p->shA_built_Bx = Bx;
+  *use = true;
+  return GPA_OK;
+}
+
+// pass A over the staged x-planes: one forward transform per column for all planes where the axis allows it
+// (gpa_passb_shared.h), the per-plane forward transforms otherwise
+static int run_passA(gpa_plan* p, const void* image, const void* mean, void* Tbuf, int Bx, int nimg) {
+  bool shared = false;
+  TRY(sharedA_prepare(p, Bx, &shared));
+  if (shared) {
+    SweepTables tb = p->tb;
+    tb.sx = p->shA_sx;     // stride factors of the kernel's own transform length
+    HIP_TRY(launch_passA_shared(p->dtype, p->ax0s, p->n1, image, mean, tb, p->ax0.L / 16, p->shA_Gx, p->shA_psi, p->shA_gtab,
+                                p->ax0s.L == p->ax0.L ? p->tw0 : p->tw0s, p->shA_E, p->shA_Epad, Tbuf, Bx, p->stream, nimg));
+  } else {
+    HIP_TRY(launch_passA(p->dtype, p->ax0, p->n1, image, mean, p->tb, p->Hx, p->tw0, Tbuf, Bx, p->stream, nimg));
+  }
   return GPA_OK;
 }
 
@@ -863,7 +968,7 @@ static int sweep_peaks_dev(gpa_plan* p, const void* image, const void* mean, con
   TRY(stage_kvectors(p, klists, kr.data(), B, &Bx));
   TRY(ensure_tbuf(p, Bx));
   if (p->profiling) HIP_TRY(hipEventRecord(p->stage_ev[1], p->stream));
-  HIP_TRY(launch_passA(p->dtype, p->ax0, p->n1, image, mean, p->tb, p->Hx, p->tw0, p->Tbuf, Bx, p->stream));
+  TRY(run_passA(p, image, mean, p->Tbuf, Bx));
   if (p->profiling) HIP_TRY(hipEventRecord(p->stage_ev[2], p->stream));
   TRY(passB_select(p, P, K, lockin, kidx));
   if (p->profiling) HIP_TRY(hipEventRecord(p->stage_ev[3], p->stream));
@@ -880,7 +985,7 @@ static int sweep_one_peak(gpa_plan* p, const void* image, const double* kref, co
   int Bx = 0;
   TRY(stage_kvectors(p, klist, kr.data(), K, &Bx));
   TRY(ensure_tbuf(p, Bx));
-  HIP_TRY(launch_passA(p->dtype, p->ax0, p->n1, image, nullptr, p->tb, p->Hx, p->tw0, p->Tbuf, Bx, p->stream));
+  TRY(run_passA(p, image, nullptr, p->Tbuf, Bx));
   HIP_TRY(launch_passB_ext(p->dtype, p->ax1, p->n0, p->Tbuf, p->Hy, p->tw1, p->tb, K, mode, lockin, kidx, d_gate, d_psi,
                            p->stream));
   return GPA_OK;
@@ -1133,7 +1238,7 @@ static int extract_launch(gpa_plan* p, const void* image, int P, int K, int Bx, 
   if (p->profiling) HIP_TRY(hipEventRecord(p->stage_ev[0], p->stream));
   HIP_TRY(launch_mean(p->dtype, image, npx, p->d_scratch, p->d_mean, p->stream));
   if (p->profiling) HIP_TRY(hipEventRecord(p->stage_ev[1], p->stream));
-  HIP_TRY(launch_passA(p->dtype, p->ax0, p->n1, image, p->d_mean, p->tb, p->Hx, p->tw0, p->Tbuf, Bx, p->stream));
+  TRY(run_passA(p, image, p->d_mean, p->Tbuf, Bx));
   if (p->profiling) HIP_TRY(hipEventRecord(p->stage_ev[2], p->stream));
   TRY(passB_select(p, P, K, lk, kidx));
   if (p->profiling) HIP_TRY(hipEventRecord(p->stage_ev[3], p->stream));
@@ -1358,7 +1463,7 @@ int gpa_extract_displacement_field_batch_dev(gpa_plan* p, const void* images, in
     const int nimg = std::min(chunk, B - c0);
     const void* image = (const char*)images + (size_t)c0 * npx * p->rsz;
     HIP_TRY(launch_mean(p->dtype, image, npx, p->bScratch, p->bMean, p->stream, nimg));
-    HIP_TRY(launch_passA(p->dtype, p->ax0, p->n1, image, p->bMean, p->tb, p->Hx, p->tw0, p->bT, Bx, p->stream, nimg));
+    TRY(run_passA(p, image, p->bMean, p->bT, Bx, nimg));
     if (p->sh_use)
       HIP_TRY(launch_passB_shared(p->dtype, p->ax1s, p->n0, p->bT, p->ax1s.L == p->ax1.L ? p->tw1 : p->tw1s, p->tb,
                                   p->ax1.L / 16, p->sh, p->sh_E, p->sh_Epad, P, K, p->bL, nullptr, p->stream, nimg, Bx));

@@ -35,4 +35,15 @@ hipError_t launch_passB_shared(int dtype, const Axis& a1, int n0, const void* Tb
                                int cyb_stride, const PassBSharedTables& st, int E, int Epad, int P, int K, void* out,
                                int32_t* kidx, hipStream_t s, int nimg = 1, int Bx = 0);
 
+// ---- pass A with the forward transform shared by all x-planes of a column (same file) -------------------------------
+// a0: the kernel's own geometry of the x axis (periodic, or zero-padded to L >= n0 + E); tw0: twiddles of a0.L;
+// Gx [Bx][L] / psix [Bx][Epad] from launch_sharedA_tables (pw: device doubles, the distinct wx); gtab: Hankel taps of
+// the x axis; cxb_stride: entries per plane of tb.cxb.  tb.sx must hold exp(2 pi i wx (a0.L / 16) i): the sxs table of launch_sharedA_tables.
+bool passA_shared_supports(int dtype, const Axis& a0, int E);
+hipError_t launch_sharedA_tables(int dtype, const Axis& a0, const double* pw, const double* taps, int Etab, int E, int Epad,
+                                 int Bx, void* Gx, void* psix, void* sxs /*[Bx][16] stride factors for a0.L*/, hipStream_t s);
+hipError_t launch_passA_shared(int dtype, const Axis& a0, int n1, const void* image, const void* mean, const SweepTables& tb,
+                               int cxb_stride, const void* Gx, const void* psix, const void* gtab, const void* tw0, int E,
+                               int Epad, void* Tbuf, int B, hipStream_t s, int nimg = 1);
+
 }  // namespace gpa

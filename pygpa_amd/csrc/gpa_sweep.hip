@@ -237,6 +237,9 @@ __global__ __launch_bounds__((PassAGeom<T, LG>::THREADS)) void passA_kernel(
 #pragma unroll
         for (int i = 0; i < 16; ++i) {
           const int slot = t + TPF * i;
+#ifdef GPA_PA_NOSTORE
+          if (i > 0) continue;   // diagnosis only
+#endif
           if (!PADDED || slot < n0) {
             struct alignas(2 * sizeof(cpx<T>)) Pair { cpx<T> a, b; };
             Pair pr = {x[0][i], x[1][i]};

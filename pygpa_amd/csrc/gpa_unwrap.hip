@@ -360,7 +360,10 @@ struct alignas(4 * sizeof(T)) Vec4 { T v[4]; };
 template <class T, int V>
 struct alignas(V * sizeof(T)) VecN { T v[V]; };
 
-constexpr int PQ_ROWS = 16;   // rows per workgroup band of pq_kernel (large images; fewer for small ones)
+#ifndef GPA_PQ_ROWS
+#define GPA_PQ_ROWS 16
+#endif
+constexpr int PQ_ROWS = GPA_PQ_ROWS;   // rows per workgroup band of pq_kernel (large images; fewer for small ones)
 
 // PGIVEN: `z` already holds the search direction p (written by rowidct_p_kernel): no combination with
 // pin, no copy to pout, no beta
@@ -708,9 +711,20 @@ __global__ __launch_bounds__((RowGeom<T, LG>::THREADS), (sizeof(T) == 8 ? GPA_F6
   const int pr = blockIdx.x * G::NF + f;
   const bool valid = 2 * pr + 1 < n0;
   const size_t oa = (size_t)(valid ? 2 * pr : 0) * N, ob = oa + N;
-  // (register twiddles here: the LDS table of rowidct_p_kernel made this kernel's allocation worse, 156 -> 160 VGPRs)
-  typename F::Twiddles tw;
-  F::load_twiddles(tw, twtab, tid);
+  // (register twiddles by default: the LDS table of rowidct_p_kernel made this kernel's allocation worse, 156 -> 160 VGPRs)
+#ifndef GPA_DCTF_TWLDS
+#define GPA_DCTF_TWLDS 0
+#endif
+  constexpr bool TWL = GPA_DCTF_TWLDS && G::TWLDS;
+  typename std::conditional<TWL, typename F::TwiddlesP1Lds, typename F::Twiddles>::type tw;
+  __shared__ cpx<T> t1s[TWL ? G::T1N : 1];
+  if constexpr (TWL) {
+    F::fill_pass1_table(t1s, twtab, threadIdx.x, G::THREADS);
+    __syncthreads();
+    F::load_twiddles(tw, twtab, tid, t1s);
+  } else {
+    F::load_twiddles(tw, twtab, tid);
+  }
   cpx<T> x[E];
   cpx<T> rk[E];
   cpx<T> wkv[EARLY ? E : 1];

@@ -110,7 +110,7 @@ def test_shared_passb_zero_rows_and_driver(dtype):
     img0[:, :] = 0.0
     lock, kidx = _sweep(shape, dtype, img0, kref, klist, sigma)
     assert np.all(lock == 0) and np.all(kidx == -1)
-    shape = (512, 2048)
+    shape = (1200, 2048)
     kvecs = hex_kvecs(0.1, 7.0)
     img = hex_moire(shape, kvecs, gaussian_bump_displacement(shape), noise=0.2, seed=4)
     kw, sigma, _ = orc.derive_params(kvecs)
@@ -127,3 +127,32 @@ def test_shared_passb_zero_rows_and_driver(dtype):
         assert same.mean() > 0.999
         assert rel(lock[p][same], parts['gs'][p]['lockin'][same]) < TOL[dtype]['lock']
     assert rel(u, u_ref) < (1e-8 if dtype is np.float64 else 5e-4)
+
+
+@pytest.mark.parametrize('dtype', DTYPES)
+@pytest.mark.parametrize('shape', [(2048, 96), (4096, 64), (3000, 80), (1500, 72)])
+def test_shared_pass_a_opt_in(shape, dtype, monkeypatch):
+    """the shared-forward pass A (GPA_SHARED_A=1: one forward transform per column for all x-planes, end fix of the
+    first / last rows on the matrix cores) -- measured slower than the per-plane kernel and therefore off by default,
+    its numbers pinned all the same: oracle's lock-ins (all of them, gpa_lockin_batch, and the sweep's winners), the
+    first / last 3 sigma ROWS on their own, periodic and zero-padded columns"""
+    monkeypatch.setenv('GPA_SHARED_A', '1')
+    kvecs = hex_kvecs(0.1, 7.0)
+    img = hex_moire(shape, kvecs, gaussian_bump_displacement(shape), noise=0.2, seed=6)
+    img0 = img - img.mean()
+    kw, sigma, _ = orc.derive_params(kvecs)
+    klist = explicit_klists(kvecs, kw, 4, 2)[2]
+    plan = _lib.Plan(shape, len(klist), dtype)
+    out = plan.lockin_batch(img0, klist, sigma)
+    ref = orc.lockin_batch(img0, klist, sigma)
+    sc = np.abs(ref).max()
+    e3 = int(3 * sigma)
+    d = np.abs(out - ref) / sc
+    assert d.max() < TOL[dtype]['lock']
+    assert max(d[:, :e3, :].max(), d[:, -e3:, :].max()) < TOL[dtype]['lock']
+    refs = orc.sweep(img0, sigma, klist, kvecs[2], workers=8)
+    lock, kidx, _ = plan.sweep(img0, kvecs[2], klist, sigma)
+    plan.close()
+    check_kidx(kidx, refs['kidx'], img0, klist, sigma, TOL[dtype]['tie'])
+    same = kidx == refs['kidx']
+    assert same.mean() > 0.999 and rel(lock[same], refs['lockin'][same]) < TOL[dtype]['lock']
