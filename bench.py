@@ -84,8 +84,11 @@ def kernel_models(n0, n1, L0, L1, P, K, Bx, s, iters):
         'passA_kernel': {'bytes': px * (s + 2 * s * Bx), 'flops': Bx * n1 * (2 * fft(L0) + 8 * L0)},
         # every x-plane in once (the K/Bx-fold re-reads of a plane are served by L2), P winners out
         'passB_kernel': {'bytes': px * (2 * s * Bx + 2 * s * P), 'flops': B * n0 * (2 * fft(L1) + 16 * L1)},
-        # the same traffic with ONE forward transform per x-plane row (Bx) and one inverse per candidate (B)
-        'passB_shared_kernel': {'bytes': px * (2 * s * Bx + 2 * s * P), 'flops': n0 * ((Bx + B) * fft(L1) + B * 10 * L1)},
+        # the same traffic and the same ALGORITHMIC flops (the reference's lock-in of every candidate: a forward and an
+        # inverse transform per candidate and row); the kernel EXECUTES one forward transform per x-plane
+        # row (Bx) and one inverse per candidate (B) -- 'executed_flops'
+        'passB_shared_kernel': {'bytes': px * (2 * s * Bx + 2 * s * P), 'flops': B * n0 * (2 * fft(L1) + 16 * L1),
+                                'executed_flops': n0 * ((Bx + B) * fft(L1) + B * 10 * L1)},
         # P lock-ins in; wnorm, r0 of both components out
         'reconstruct_setup_kernel': {'bytes': px * (2 * s * P + 3 * s), 'flops': None},
         # per working launch and component: q, R in, R out / R in, Z out / Z, p in, p out / p, w in, q out
@@ -284,6 +287,8 @@ def kernel_table(n, L0, L1, P, K, Bx, s, iters, kern, stage, res_s):
             row['hbm_bytes_per_launch'] = int(c['hbm_bytes'])
         if m.get('flops'):
             row['nominal_TFLOPs'] = round(m['flops'] / per / 1e12, 2)
+        if m.get('executed_flops'):
+            row['executed_TFLOPs'] = round(m['executed_flops'] / per / 1e12, 2)
         if c.get('valu_insts'):
             row['valu_issue_frac'] = round(c['valu_insts'] / per / VALU_ISSUE_PEAK, 4)
         fr = {'hbm': row.get('hbm_frac', (m['bytes'] / per / 1e9 / HBM_PEAK_GBS) if m.get('bytes') else 0.0),
@@ -308,10 +313,13 @@ def kernel_table(n, L0, L1, P, K, Bx, s, iters, kern, stage, res_s):
                            'peak': VALU_PEAK_TFLOPS, 'unit': 'TFLOP/s', 'frac': round(dm['flops'] / dsec / 1e12 / VALU_PEAK_TFLOPS, 4),
                            'traffic': dc.get('hbm_bytes'), 'kernel_ms': round(dsec * 1e3, 4),
                            'nominal_flops_per_launch': dm['flops'],
+                           'executed_flops_per_launch': dm.get('executed_flops', dm['flops']),
+                           'executed_TFLOPs': round(dm.get('executed_flops', dm['flops']) / dsec / 1e12, 2),
                            'valu_issue_frac': drow.get('valu_issue_frac'), 'source': src,
-                           'note': 'f32 vector pipe (the transforms) beside a small f32 MFMA contraction (the end fix): nominal '
-                                   '5 L log2 L flops per transform THIS kernel executes over the HIP-event time; '
-                                   'valu_issue_frac = counted VALU wave-instructions / (1024 SIMDs x 1 per 2 cycles x 2.4 GHz)'}
+                           'note': 'vector pipe (the transforms) beside a small MFMA contraction (the end fix). achieved = ALGORITHMIC flops '
+                                   '(the reference algorithm: a forward and an inverse transform per candidate and row, nominal 5 L log2 L each) '
+                                   'over the HIP-event time; the shared-forward kernel executes fewer (executed_*: one forward transform per '
+                                   'x-plane row); valu_issue_frac = counted VALU wave-instructions / (1024 SIMDs x 1 per 2 cycles x 2.4 GHz)'}
     else:
         ach = (dc.get('hbm_bytes') or dm.get('bytes') or 0) / dsec / 1e9
         out['roofline'] = {'bound': 'hbm', 'kernel': dom, 'achieved': round(ach, 1), 'peak': HBM_PEAK_GBS, 'unit': 'GB/s',
