@@ -229,6 +229,7 @@ struct gpa_plan {
   PassBSharedTables sh{};
   double* d_taps = nullptr;       // g(0 .. sh_etab) of the y axis' circular filter, doubles
   int sh_etab = 0, sh_E = 0, sh_Epad = 0;
+  int sh_elems = 16;              // elements per thread of its row transform (8 for 4096-point rows, see passB_shared_elems)
   Axis ax1s{};                    // its geometry of the y axis: periodic as ax1, or zero-padded to L >= n1 + E
   void* tw1s = nullptr;           // twiddles of ax1s.L when that differs from ax1.L
   int tw1s_L = 0;
@@ -570,6 +571,7 @@ static int ensure_filters(gpa_plan* p, double sigma) {
           p->sh_etab = mmax;
           p->sh_E = E;
           p->sh_Epad = Epad;
+          p->sh_elems = passB_shared_elems(p->dtype, sa);
           p->sh_ok = true;
         }
       }
@@ -633,7 +635,7 @@ static int shared_prepare(gpa_plan* p, int P, int K) {
   if (!p->sh.desc) TRY(dmalloc(p, (void**)&p->sh.desc, (size_t)p->max_batch * sizeof(int)));
   HIP_TRY(hipMemcpyAsync(p->sh.desc, desc.data(), (size_t)B * sizeof(int), hipMemcpyHostToDevice, p->stream));
   HIP_TRY(launch_shared_tables(p->dtype, p->ax1s, p->d_kl, p->d_kr, p->d_taps, p->sh_etab, p->sh_E, p->sh_Epad, B, K, p->sh,
-                               p->stream));
+                               p->stream, p->sh_elems));
   HIP_TRY(hipStreamSynchronize(p->stream));   // `desc` is a local
   p->sh_use = true;
   return GPA_OK;
@@ -938,7 +940,7 @@ static int passB_select(gpa_plan* p, int P, int K, void* lockin, int32_t* kidx) 
     TRY(shared_prepare(p, P, K));
     if (p->sh_use)
       HIP_TRY(launch_passB_shared(p->dtype, p->ax1s, p->n0, p->Tbuf, p->ax1s.L == p->ax1.L ? p->tw1 : p->tw1s, p->tb,
-                                  p->ax1.L / 16, p->sh, p->sh_E, p->sh_Epad, P, K, lockin, kidx, p->stream));
+                                  p->ax1.L / 16, p->sh, p->sh_E, p->sh_Epad, P, K, lockin, kidx, p->stream, 1, 0, p->sh_elems));
     else
       HIP_TRY(launch_passB(p->dtype, p->ax1, p->n0, p->Tbuf, p->Hy, p->tw1, p->tb, P, K, true, lockin, kidx, p->stream));
     return GPA_OK;
@@ -1466,7 +1468,7 @@ int gpa_extract_displacement_field_batch_dev(gpa_plan* p, const void* images, in
     TRY(run_passA(p, image, p->bMean, p->bT, Bx, nimg));
     if (p->sh_use)
       HIP_TRY(launch_passB_shared(p->dtype, p->ax1s, p->n0, p->bT, p->ax1s.L == p->ax1.L ? p->tw1 : p->tw1s, p->tb,
-                                  p->ax1.L / 16, p->sh, p->sh_E, p->sh_Epad, P, K, p->bL, nullptr, p->stream, nimg, Bx));
+                                  p->ax1.L / 16, p->sh, p->sh_E, p->sh_Epad, P, K, p->bL, nullptr, p->stream, nimg, Bx, p->sh_elems));
     else
       HIP_TRY(launch_passB(p->dtype, p->ax1, p->n0, p->bT, p->Hy, p->tw1, p->tb, P, K, true, p->bL, nullptr, p->stream, nimg,
                            Bx));

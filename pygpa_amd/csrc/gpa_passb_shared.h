@@ -24,16 +24,19 @@ struct PassBSharedTables {
 
 // can the shared pass B run this axis (3-pass transforms, taps that vanish beyond E <= L / 16 samples, LDS)?
 bool passB_shared_supports(int dtype, const Axis& a1, int E);
+int passB_shared_elems(int dtype, const Axis& a1);
 
 // kl / kr: device [B][2] candidates and their peaks; taps: device doubles g(0 .. Etab) of the length-n circular filter
 hipError_t launch_shared_tables(int dtype, const Axis& a1, const double* kl, const double* kr, const double* taps, int Etab,
-                                int E, int Epad, int B, int K, const PassBSharedTables& st, hipStream_t s);
+                                int E, int Epad, int B, int K, const PassBSharedTables& st, hipStream_t s, int elems = 16);
 
+// elems: elements per thread of the row transform (16; 8 exists for 4096-point rows), the same value in
+// launch_shared_tables (the candidate tables are laid out for it).
 // a1: the shared kernel's own geometry of the y axis (periodic, or zero-padded to L >= n + E); tw1: twiddles of a1.L;
 // cyb_stride: entries per candidate of tb.cyb (the plan's L1 / 16, which a1.L / 16 may be smaller than)
 hipError_t launch_passB_shared(int dtype, const Axis& a1, int n0, const void* Tbuf, const void* tw1, const SweepTables& tb,
                                int cyb_stride, const PassBSharedTables& st, int E, int Epad, int P, int K, void* out,
-                               int32_t* kidx, hipStream_t s, int nimg = 1, int Bx = 0);
+                               int32_t* kidx, hipStream_t s, int nimg = 1, int Bx = 0, int elems = 16);
 
 // ---- pass A with the forward transform shared by all x-planes of a column (same file) -------------------------------
 // a0: the kernel's own geometry of the x axis (periodic, or zero-padded to L >= n0 + E); tw0: twiddles of a0.L;

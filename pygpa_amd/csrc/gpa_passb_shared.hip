@@ -26,6 +26,8 @@
 // Selection ("strictly larger |sf| replaces", in list order) keeps only |best|^2 in registers: a winner is stored
 // to `out` the moment it wins and the row is revisited once at the end for the compensation phasor, which frees the
 // registers that the shared spectrum needs.
+#include <stdlib.h>
+
 #include "gpa_internal.h"
 #include "gpa_passb_shared.h"
 
@@ -55,9 +57,6 @@ template <class T> struct upair { T u, v; };
 #ifndef GPA_PBS_NOFIX
 #define GPA_PBS_NOFIX 0     // diagnosis only: skip the end fix (wrong results at the row ends)
 #endif
-#ifndef GPA_PBS_NOB2
-#define GPA_PBS_NOB2 0      // experiment: no barrier before the last (intra-wavefront) exchange of the inverse
-#endif
 #ifndef GPA_PBS_EXECSTORE
 #define GPA_PBS_EXECSTORE 0  // experiment: winners stored under the EXEC mask instead of through dropped offsets
 #endif
@@ -66,12 +65,12 @@ template <class T> struct upair { T u, v; };
 #endif
 
 // the shifted Gaussian of one candidate: sixteen reals per thread in the spectral register layout
-template <class T, int TPF>
-__device__ __forceinline__ void load_gb(T (&h)[16], const T* gbrow, int tid) {
+template <class T, int TPF, int EE>
+__device__ __forceinline__ void load_gb(T (&h)[EE], const T* gbrow, int tid) {
   using gscalar = const __attribute__((address_space(1))) T;
   gscalar* gb = (gscalar*)gbrow;
 #pragma unroll
-  for (int i = 0; i < 16; ++i) h[i] = gb[i * TPF + tid];
+  for (int i = 0; i < EE; ++i) h[i] = gb[i * TPF + tid];
 }
 template <class T> __device__ __forceinline__ cpx<T> load_cpx(__amdgpu_buffer_rsrc_t r, int voff, int soff, int aux = 16);
 
@@ -106,10 +105,13 @@ __device__ __forceinline__ void store_cpx(cpx<double> v, __amdgpu_buffer_rsrc_t 
   __builtin_amdgcn_raw_buffer_store_b128(d, r, voff, soff, 0);
 }
 
-template <class T, int LG>
+// EE = elements per thread of the row transform: 16 (256 threads per 4096-point row, three passes) or 8 (512 threads,
+// four passes: half the registers per thread -- the shared spectrum, the working copy and |best|^2 are per-element
+// arrays -- for one more exchange per transform)
+template <class T, int LG, int EE = 16>
 struct PassBSGeom {
-  using F = WgFFT<T, LG>;
-  static_assert(F::P == 3, "three-pass transforms only (1024 .. 4096 points)");
+  using F = WgFFT<T, LG, EE>;
+  static_assert(F::P == 3 || F::P == 4, "three- or four-pass transforms");
   static constexpr int TPF = F::TPF;
   static_assert(TPF >= 64, "a row needs whole wavefronts");
   // (2048-point rows, 128 threads each: ONE row per workgroup -- two rows per workgroup cost a third of the occupancy
@@ -126,7 +128,8 @@ struct PassBSGeom {
   // in LDS once per chunk of NC candidates, so that neither the matrix pass nor the fix-up waits on global loads
   // (which queue behind the winner stores in vmcnt).  f64 has no LDS left for that at 4096 points.
   static constexpr bool STAGE = sizeof(T) == 4;
-  static constexpr int T1 = F::P1_SETS * 6;                // pass-1 twiddle table (complex), one per workgroup
+  static constexpr bool TWL = F::P == 3;                   // pass-1 twiddles from an LDS table (three-pass transforms)
+  static constexpr int T1 = TWL ? F::P1_SETS * 6 : 0;      // that table (complex), one per workgroup
   // end strips: f32 keeps the four (end, re/im) forms the matrix pass multiplies directly, f64 (no LDS to spare at
   // 4096 points) the two complex strips and forms them per lane with selects
   static constexpr int SV = sizeof(T) == 4 ? 4 : 2;
@@ -153,14 +156,22 @@ struct PassBSGeom {
 #define GPA_PBS_F64_WAVES 2
 #endif
 
-template <class T, int LG, bool PADDED>
-__global__ __launch_bounds__((PassBSGeom<T, LG>::THREADS), (sizeof(T) == 8 ? GPA_PBS_F64_WAVES : (PADDED ? GPA_PBS_PAD_WAVES : GPA_PBS_F32_WAVES))) void passB_shared_kernel(
+#ifndef GPA_PBS_E8_WAVES
+#define GPA_PBS_E8_WAVES 4    // eight elements per thread, f32: 128 VGPRs
+#endif
+#ifndef GPA_PBS_E8_F64_WAVES
+#define GPA_PBS_E8_F64_WAVES 2
+#endif
+template <class T, int LG, bool PADDED, int EE>
+__global__ __launch_bounds__((PassBSGeom<T, LG, EE>::THREADS),
+                             (EE == 8 ? (sizeof(T) == 8 ? GPA_PBS_E8_F64_WAVES : GPA_PBS_E8_WAVES)
+                                      : (sizeof(T) == 8 ? GPA_PBS_F64_WAVES : (PADDED ? GPA_PBS_PAD_WAVES : GPA_PBS_F32_WAVES)))) void passB_shared_kernel(
     const cpx<T>* __restrict__ Tin, int n0, int n1, const T* __restrict__ Gb, const cpx<T>* __restrict__ twtab,
     const int* __restrict__ planeof, const int* __restrict__ desc, const cpx<T>* __restrict__ cyb,
     const cpx<T>* __restrict__ psi, const T* __restrict__ gtab, const cpx<T>* __restrict__ dx,
     const cpx<T>* __restrict__ dyc, int K, int E, int Epad, cpx<T>* out, int32_t* kidx, int P, int Bx, int cyb_stride) {
-  using F = WgFFT<T, LG>;
-  using G = PassBSGeom<T, LG>;
+  using F = WgFFT<T, LG, EE>;
+  using G = PassBSGeom<T, LG, EE>;
   using V4 = typename MfmaVec<T>::type;
   constexpr int TPF = F::TPF, L = F::L, NC = G::NC;
   constexpr bool STAGE = G::STAGE;
@@ -183,15 +194,18 @@ __global__ __launch_bounds__((PassBSGeom<T, LG>::THREADS), (sizeof(T) == 8 ? GPA
 
   // Hankel taps g(1 .. E) (zero beyond) and the pass-1 twiddles: first read after the barriers of the first transform
   for (int i = threadIdx.x; i < 2 * Epad + 16; i += G::THREADS) glds[i] = gtab[i];
-  F::fill_pass1_table(t1, twtab, threadIdx.x, G::THREADS);
-  __syncthreads();
+  typename std::conditional<G::TWL, typename F::TwiddlesP1Lds, typename F::Twiddles>::type tw;
+  if constexpr (G::TWL) {
+    F::fill_pass1_table(t1, twtab, threadIdx.x, G::THREADS);
+    __syncthreads();
+    F::load_twiddles(tw, twtab, tid, t1);
+  } else {
+    F::load_twiddles(tw, twtab, tid);
+  }
 
-  typename F::TwiddlesP1Lds tw;
-  F::load_twiddles(tw, twtab, tid, t1);
-
-  T ab[16];
+  T ab[EE];
 #pragma unroll
-  for (int i = 0; i < 16; ++i) ab[i] = T(0);
+  for (int i = 0; i < EE; ++i) ab[i] = T(0);
   const size_t obase = ((size_t)p * n0 + rr) * n1;
   // the winner's row as a buffer: a lane that does not win (or lies beyond the image) stores to an out-of-range
   // offset, which the hardware drops -- sixteen predicated stores per candidate without a branch
@@ -199,10 +213,10 @@ __global__ __launch_bounds__((PassBSGeom<T, LG>::THREADS), (sizeof(T) == 8 ? GPA
   const __amdgpu_buffer_rsrc_t krow = __builtin_amdgcn_make_buffer_rsrc((void*)(kidx ? kidx + obase : nullptr), 0, kidx ? n1 * 4 : 0, 0x00020000);
   constexpr int OOB = (int)0x80000000;
   // registers that hold the last E samples of the row (zero-padded rows: wherever n1 puts them)
-  const int iA = PADDED ? (n1 - E) / TPF : 15, iB = PADDED ? (n1 - 1) / TPF : 15;
+  const int iA = PADDED ? (n1 - E) / TPF : EE - 1, iB = PADDED ? (n1 - 1) / TPF : EE - 1;
 
-  cpx<T> X[16];
-  T h[16];
+  cpx<T> X[EE];
+  T h[EE];
   for (int k = 0; k < K; ++k) {
     const int b = pt * K + k;
     const int d = desc[b];
@@ -216,11 +230,11 @@ __global__ __launch_bounds__((PassBSGeom<T, LG>::THREADS), (sizeof(T) == 8 ? GPA
         // (zero-padded rows: the slots beyond the row read as zero through the range check of a buffer descriptor)
         const __amdgpu_buffer_rsrc_t srow = __builtin_amdgcn_make_buffer_rsrc((void*)src, 0, n1 * (int)sizeof(cpx<T>), 0x00020000);
 #pragma unroll
-        for (int i = 0; i < 16; ++i)
+        for (int i = 0; i < EE; ++i)
           X[i] = cmul(load_cpx<T>(srow, (tid + TPF * i) * (int)sizeof(cpx<T>), 0, 0), cs);
       } else {
 #pragma unroll
-        for (int i = 0; i < 16; ++i) X[i] = cmul(src[tid + TPF * i], cs);
+        for (int i = 0; i < EE; ++i) X[i] = cmul(src[tid + TPF * i], cs);
       }
       if (tid < Epad) {
         // strips in the two forms the matrix pass reads (it forms ONE real of t * p or t * conj(p) per lane as
@@ -242,12 +256,12 @@ __global__ __launch_bounds__((PassBSGeom<T, LG>::THREADS), (sizeof(T) == 8 ? GPA
     }
     // ---- candidate b: shifted Gaussian, inverse transform (the matrix pass of a new chunk rides between its barriers)
     const int par = (d >> 7) & 1;   // parity of the chunk: which copy of the staged post-factors this candidate reads
-    cpx<T> y[16];
+    cpx<T> y[EE];
     {
 #if GPA_PBS_PREFETCH
-      if (k == 0) load_gb<T, TPF>(h, Gb + (size_t)b * L, tid);
+      if (k == 0) load_gb<T, TPF, EE>(h, Gb + (size_t)b * L, tid);
 #else
-      load_gb<T, TPF>(h, Gb + (size_t)b * L, tid);
+      load_gb<T, TPF, EE>(h, Gb + (size_t)b * L, tid);
 #endif
       if constexpr (STAGE) {
         if (d & 2) {
@@ -261,7 +275,7 @@ __global__ __launch_bounds__((PassBSGeom<T, LG>::THREADS), (sizeof(T) == 8 ? GPA
         }
       }
 #pragma unroll
-      for (int i = 0; i < 16; ++i) y[i] = {X[i].x * h[i], X[i].y * h[i]};
+      for (int i = 0; i < EE; ++i) y[i] = {X[i].x * h[i], X[i].y * h[i]};
     }
     cpx<T> psL = {T(0), T(0)}, psR = {T(0), T(0)};
     const int a0R = PADDED ? 0 : TPF - 1 - tid;
@@ -323,10 +337,12 @@ __global__ __launch_bounds__((PassBSGeom<T, LG>::THREADS), (sizeof(T) == 8 ? GPA
       }
     }
     F::template inv_phase<1>(y, lds, tid, tw);
-#if !GPA_PBS_NOB2
     __syncthreads();
-#endif
     F::template inv_phase<2>(y, lds, tid, tw);
+    if constexpr (F::P == 4) {
+      __syncthreads();
+      F::template inv_phase<3>(y, lds, tid, tw);
+    }
     // ---- the outputs within E of either end get their wrapped pairs ------------------------------------------
 #if !GPA_PBS_NOFIX
     {
@@ -344,8 +360,8 @@ __global__ __launch_bounds__((PassBSGeom<T, LG>::THREADS), (sizeof(T) == 8 ? GPA
           const cpx<T> fx = fixb[(c * 2 + 0) * ES + a0R];
           if constexpr (STAGE) psR = pl[a0R];
           const cpx<T> t = cmul(fx, psR);
-          y[15].x += t.x;
-          y[15].y += t.y;
+          y[EE - 1].x += t.x;
+          y[EE - 1].y += t.y;
         }
       } else {
         // zero-padded rows: the last E samples sit in register iA and, where they straddle a register, iB = iA + 1
@@ -363,7 +379,7 @@ __global__ __launch_bounds__((PassBSGeom<T, LG>::THREADS), (sizeof(T) == 8 ? GPA
           fB = {inB ? tb2.x : T(0), inB ? tb2.y : T(0)};
         }
 #pragma unroll
-        for (int i = 0; i < 16; ++i) {
+        for (int i = 0; i < EE; ++i) {
           if (i == iA) { y[i].x += fA.x; y[i].y += fA.y; }
           if (i == iB && iB != iA) { y[i].x += fB.x; y[i].y += fB.y; }
         }
@@ -373,12 +389,12 @@ __global__ __launch_bounds__((PassBSGeom<T, LG>::THREADS), (sizeof(T) == 8 ? GPA
 #if GPA_PBS_PREFETCH
     // the next candidate's Gaussian is requested BEFORE this candidate's stores: vmcnt counts loads and stores in
     // order, so loads issued behind the stores would wait for the stores' acknowledgements as well
-    if (k + 1 < K) load_gb<T, TPF>(h, Gb + (size_t)(b + 1) * L, tid);
+    if (k + 1 < K) load_gb<T, TPF, EE>(h, Gb + (size_t)(b + 1) * L, tid);
     __builtin_amdgcn_sched_barrier(0);
 #endif
     // ---- strict '>' in list order; the winner goes to memory at once ----------------------------------------
 #pragma unroll
-    for (int i = 0; i < 16; ++i) {
+    for (int i = 0; i < EE; ++i) {
       const int yy = tid + TPF * i;
       const T a = y[i].x * y[i].x + y[i].y * y[i].y;
       const bool win = a > ab[i];
@@ -405,14 +421,14 @@ __global__ __launch_bounds__((PassBSGeom<T, LG>::THREADS), (sizeof(T) == 8 ? GPA
   // overtake a store in flight), and the read goes to L2 (sc1), not to whatever L1 holds.
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
   const cpx<T>* dyp = dyc + (size_t)pt * n1;
-  cpx<T> w[16];
+  cpx<T> w[EE];
 #pragma unroll
-  for (int i = 0; i < 16; ++i) {
+  for (int i = 0; i < EE; ++i) {
     const int yy = tid + TPF * i;
     w[i] = PADDED ? load_cpx<T>(orow, yy * (int)sizeof(cpx<T>), 0) : load_cpx<T>(orow, tid * (int)sizeof(cpx<T>), i * TPF * (int)sizeof(cpx<T>));
   }
 #pragma unroll
-  for (int i = 0; i < 16; ++i) {
+  for (int i = 0; i < EE; ++i) {
     const int yy = tid + TPF * i;
     if (!PADDED || yy < n1) {
       cpx<T> v = {T(0), T(0)};
@@ -828,12 +844,12 @@ hipError_t launch_passA_shared(int dtype, const Axis& a0, int n1, const void* im
 // and the compensation phasor of every peak, all evaluated in double
 // ---------------------------------------------------------------------------------------------------------------
 
-template <class T, int LG>
+template <class T, int LG, int EE>
 __global__ __launch_bounds__(256) void shared_tables_kernel(const double* __restrict__ kl, const double* __restrict__ kr,
                                                            const double* __restrict__ taps, int Etab, int n1, int E,
                                                            int Epad, int wrapped, int K, T* __restrict__ Gb,
                                                            cpx<T>* __restrict__ psi, cpx<T>* __restrict__ dyc) {
-  using F = WgFFT<T, LG>;
+  using F = WgFFT<T, LG, EE>;
   constexpr int L = F::L, TPF = F::TPF;
   const int b = blockIdx.y;
   const int idx = blockIdx.x * 256 + threadIdx.x;
@@ -864,36 +880,41 @@ __global__ __launch_bounds__(256) void shared_tables_kernel(const double* __rest
   if (b % K == 0 && idx < n1) dyc[(size_t)(b / K) * n1 + idx] = unit_phasor_s<T>(kr[2 * b + 1] * (double)idx);
 }
 
-template <class T, int LG>
+template <class T, int LG, int EE>
 static hipError_t run_shared_tables(const Axis& a1, const double* kl, const double* kr, const double* taps, int Etab, int E,
                                     int Epad, int B, int K, const PassBSharedTables& st, hipStream_t s) {
   int len = a1.L > a1.n ? a1.L : a1.n;
   if (len < Epad) len = Epad;
   dim3 grid((len + 255) / 256, B);
-  shared_tables_kernel<T, LG><<<grid, 256, 0, s>>>(kl, kr, taps, Etab, a1.n, E, Epad, a1.padded ? 0 : 1, K, (T*)st.Gb,
+  shared_tables_kernel<T, LG, EE><<<grid, 256, 0, s>>>(kl, kr, taps, Etab, a1.n, E, Epad, a1.padded ? 0 : 1, K, (T*)st.Gb,
                                                    (cpx<T>*)st.psi, (cpx<T>*)st.dyc);
   return hipGetLastError();
 }
 
 hipError_t launch_shared_tables(int dtype, const Axis& a1, const double* kl, const double* kr, const double* taps, int Etab,
-                                int E, int Epad, int B, int K, const PassBSharedTables& st, hipStream_t s) {
-#define CASE_T(LG)                                                                                              \
-  case LG:                                                                                                      \
-    return dtype == 0 ? run_shared_tables<float, LG>(a1, kl, kr, taps, Etab, E, Epad, B, K, st, s)             \
-                      : run_shared_tables<double, LG>(a1, kl, kr, taps, Etab, E, Epad, B, K, st, s);
-  switch (a1.lg) { CASE_T(10) CASE_T(11) CASE_T(12) }
+                                int E, int Epad, int B, int K, const PassBSharedTables& st, hipStream_t s, int elems) {
+#ifdef GPA_PBS_BUILD_E8      // the eight-element instantiations: measured slower (profiles/r03_passB_variants.txt), not built by default
+#define CASE_T8(LG) CASE_T(LG, 8)
+#else
+#define CASE_T8(LG)
+#endif
+#define CASE_T(LG, EE)                                                                                              \
+  if (a1.lg == LG && elems == EE)                                                                                   \
+    return dtype == 0 ? run_shared_tables<float, LG, EE>(a1, kl, kr, taps, Etab, E, Epad, B, K, st, s)             \
+                      : run_shared_tables<double, LG, EE>(a1, kl, kr, taps, Etab, E, Epad, B, K, st, s);
+  CASE_T(11, 16) CASE_T(12, 16) CASE_T8(12)
 #undef CASE_T
   return hipErrorInvalidValue;
 }
 
-template <class T, int LG, bool PADDED>
+template <class T, int LG, bool PADDED, int EE>
 static hipError_t run_passB_shared(const Axis& a1, int n0, const void* Tbuf, const void* tw1, const SweepTables& tb,
                                    int cyb_stride, const PassBSharedTables& st, int E, int Epad, int P, int K, void* out, int32_t* kidx,
                                    hipStream_t s, int nimg, int Bx) {
-  using G = PassBSGeom<T, LG>;
+  using G = PassBSGeom<T, LG, EE>;
   const size_t lds = G::lds_bytes(Epad);
   if (lds > 160 * 1024 || E > G::TPF || Epad > G::TPF) return hipErrorInvalidValue;
-  auto kern = passB_shared_kernel<T, LG, PADDED>;
+  auto kern = passB_shared_kernel<T, LG, PADDED, EE>;
   // (the dynamic LDS size depends on Epad: raise the limit whenever a larger one comes along)
   static int lds_set[32] = {0};
   int dev = 0;
@@ -909,6 +930,18 @@ static hipError_t run_passB_shared(const Axis& a1, int n0, const void* Tbuf, con
                                      (const cpx<T>*)tb.cyb, (const cpx<T>*)st.psi, (const T*)st.gtab, (const cpx<T>*)tb.dx,
                                      (const cpx<T>*)st.dyc, K, E, Epad, (cpx<T>*)out, kidx, P, Bx, cyb_stride);
   return hipGetLastError();
+}
+
+// elements per thread the kernel runs this axis with
+int passB_shared_elems(int dtype, const Axis& a1) {
+  (void)dtype;
+#ifdef GPA_PBS_BUILD_E8
+  static const bool e8 = getenv("GPA_PBS_E8") != nullptr;   // experiment switch
+  return (a1.lg == 12 && e8) ? 8 : 16;
+#else
+  (void)a1;
+  return 16;
+#endif
 }
 
 bool passB_shared_supports(int dtype, const Axis& a1, int E) {
@@ -930,13 +963,18 @@ bool passB_shared_supports(int dtype, const Axis& a1, int E) {
 
 hipError_t launch_passB_shared(int dtype, const Axis& a1, int n0, const void* Tbuf, const void* tw1, const SweepTables& tb,
                                int cyb_stride, const PassBSharedTables& st, int E, int Epad, int P, int K, void* out, int32_t* kidx,
-                               hipStream_t s, int nimg, int Bx) {
-#define CALL_S(T, LG) \
-  (a1.padded ? run_passB_shared<T, LG, true>(a1, n0, Tbuf, tw1, tb, cyb_stride, st, E, Epad, P, K, out, kidx, s, nimg, Bx) \
-             : run_passB_shared<T, LG, false>(a1, n0, Tbuf, tw1, tb, cyb_stride, st, E, Epad, P, K, out, kidx, s, nimg, Bx))
-#define CASE_S(LG) \
-  case LG: return dtype == 0 ? CALL_S(float, LG) : CALL_S(double, LG);
-  switch (a1.lg) { CASE_S(10) CASE_S(11) CASE_S(12) }
+                               hipStream_t s, int nimg, int Bx, int elems) {
+#define CALL_S(T, LG, EE) \
+  (a1.padded ? run_passB_shared<T, LG, true, EE>(a1, n0, Tbuf, tw1, tb, cyb_stride, st, E, Epad, P, K, out, kidx, s, nimg, Bx) \
+             : run_passB_shared<T, LG, false, EE>(a1, n0, Tbuf, tw1, tb, cyb_stride, st, E, Epad, P, K, out, kidx, s, nimg, Bx))
+#ifdef GPA_PBS_BUILD_E8
+#define CASE_S8(LG) CASE_S(LG, 8)
+#else
+#define CASE_S8(LG)
+#endif
+#define CASE_S(LG, EE) \
+  if (a1.lg == LG && elems == EE) return dtype == 0 ? CALL_S(float, LG, EE) : CALL_S(double, LG, EE);
+  CASE_S(11, 16) CASE_S(12, 16) CASE_S8(12)
 #undef CASE_S
 #undef CALL_S
   return hipErrorInvalidValue;
