@@ -230,6 +230,10 @@ struct gpa_plan {
   double* d_taps = nullptr;       // g(0 .. sh_etab) of the y axis' circular filter, doubles
   int sh_etab = 0, sh_E = 0, sh_Epad = 0;
   int sh_elems = 16;              // elements per thread of its row transform (8 for 4096-point rows, see passB_shared_elems)
+  int sh_nbl = 16;                // live spectral registers of the staged candidates (band rotation, passB_shared_nbl)
+  double sh_sigma = 0.0;          // the sigma the taps belong to (band cut-off)
+  double* d_wys = nullptr;        // [max_batch] candidate frequencies wy + rotation
+  int* d_shifts = nullptr;        // [max_peaks] band rotation of every peak, in blocks of L / 16 bins
   Axis ax1s{};                    // its geometry of the y axis: periodic as ax1, or zero-padded to L >= n1 + E
   void* tw1s = nullptr;           // twiddles of ax1s.L when that differs from ax1.L
   int tw1s_L = 0;
@@ -572,6 +576,7 @@ static int ensure_filters(gpa_plan* p, double sigma) {
           p->sh_E = E;
           p->sh_Epad = Epad;
           p->sh_elems = passB_shared_elems(p->dtype, sa);
+          p->sh_sigma = sigma;
           p->sh_ok = true;
         }
       }
@@ -620,6 +625,37 @@ static int shared_prepare(gpa_plan* p, int P, int K) {
     return GPA_OK;
   }
   HIP_TRY(hipStreamSynchronize(p->stream));
+  // Band rotation.  The shifted Gaussian of a candidate is negligible (below 1e-9 of its peak in f32, 1e-17 in f64)
+  // outside |f + wy| < fc; over the candidates of a peak the live band is (-wy_max - fc, -wy_min + fc).  Rotating the
+  // row by exp(-2 pi i s y / 16) and the candidates to wy + s / 16 moves that band down by s blocks of L / 16 bins:
+  // s = the block the band starts in, so that it occupies blocks 0 .. need-1 -- the spectral registers the kernel keeps.
+  const int EEs = p->sh_elems;
+  const double fc = sqrt(log(p->dtype == 0 ? 1e9 : 1e17) / (2.0 * M_PI * M_PI * p->sh_sigma * p->sh_sigma));
+  std::vector<int> shifts((size_t)P, 0);
+  std::vector<double> wys((size_t)B);
+  int need = 1;
+  for (int pp = 0; pp < P; ++pp) {
+    double wmin = p->staged_kl[2 * ((size_t)pp * K) + 1], wmax = wmin;
+    for (int k = 1; k < K; ++k) {
+      const double w = p->staged_kl[2 * ((size_t)pp * K + k) + 1];
+      wmin = std::min(wmin, w);
+      wmax = std::max(wmax, w);
+    }
+    const double lo = -wmax - fc, width = (wmax - wmin) + 2 * fc;
+    const double flo = (lo - floor(lo)) * EEs;             // start of the band in blocks, in [0, 16)
+    const int sft = (int)floor(flo) % EEs;
+    const int blocks = width >= 1.0 ? EEs : (int)ceil((flo - floor(flo)) + width * EEs + 1e-9);
+    shifts[pp] = blocks >= EEs ? 0 : sft;
+    need = std::max(need, std::min(blocks, EEs));
+    for (int k = 0; k < K; ++k)
+      wys[(size_t)pp * K + k] = p->staged_kl[2 * ((size_t)pp * K + k) + 1] + (double)shifts[pp] / EEs;
+  }
+  p->sh_nbl = getenv("GPA_PBS_FULLBAND") ? EEs : passB_shared_nbl(p->dtype, need);
+  if (p->sh_nbl >= EEs) {   // nothing to gain: no rotation
+    for (int pp = 0; pp < P; ++pp) shifts[pp] = 0;
+    for (int bq = 0; bq < B; ++bq) wys[bq] = p->staged_kl[2 * (size_t)bq + 1];
+    p->sh_nbl = EEs;
+  }
   const size_t gb = (size_t)B * p->ax1s.L * p->rsz, ps = (size_t)B * p->sh_Epad * p->csz;
   if (gb > p->sh_gb_bytes) {
     if (p->sh.Gb) { (void)hipFree(p->sh.Gb); p->ws_bytes -= p->sh_gb_bytes; p->sh.Gb = nullptr; p->sh_gb_bytes = 0; }
@@ -627,15 +663,21 @@ static int shared_prepare(gpa_plan* p, int P, int K) {
     p->sh_gb_bytes = gb;
   }
   if (ps > p->sh_psi_bytes) {
-    if (p->sh.psi) { (void)hipFree(p->sh.psi); p->ws_bytes -= p->sh_psi_bytes; p->sh.psi = nullptr; p->sh_psi_bytes = 0; }
+    if (p->sh.psi) { (void)hipFree(p->sh.psi); (void)hipFree(p->sh.pre); p->ws_bytes -= 2 * p->sh_psi_bytes; p->sh.psi = p->sh.pre = nullptr; p->sh_psi_bytes = 0; }
     TRY(dmalloc(p, &p->sh.psi, ps));
+    TRY(dmalloc(p, &p->sh.pre, ps));
     p->sh_psi_bytes = ps;
   }
+  if (!p->sh.rot16) TRY(dmalloc(p, &p->sh.rot16, (size_t)p->max_peaks * 16 * p->csz));
+  if (!p->d_wys) TRY(dmalloc(p, (void**)&p->d_wys, (size_t)p->max_batch * sizeof(double)));
+  if (!p->d_shifts) TRY(dmalloc(p, (void**)&p->d_shifts, (size_t)p->max_peaks * sizeof(int)));
+  HIP_TRY(hipMemcpyAsync(p->d_wys, wys.data(), (size_t)B * sizeof(double), hipMemcpyHostToDevice, p->stream));
+  HIP_TRY(hipMemcpyAsync(p->d_shifts, shifts.data(), (size_t)P * sizeof(int), hipMemcpyHostToDevice, p->stream));
   if (!p->sh.dyc) TRY(dmalloc(p, &p->sh.dyc, (size_t)p->max_peaks * p->n1 * p->csz));
   if (!p->sh.desc) TRY(dmalloc(p, (void**)&p->sh.desc, (size_t)p->max_batch * sizeof(int)));
   HIP_TRY(hipMemcpyAsync(p->sh.desc, desc.data(), (size_t)B * sizeof(int), hipMemcpyHostToDevice, p->stream));
-  HIP_TRY(launch_shared_tables(p->dtype, p->ax1s, p->d_kl, p->d_kr, p->d_taps, p->sh_etab, p->sh_E, p->sh_Epad, B, K, p->sh,
-                               p->stream, p->sh_elems));
+  HIP_TRY(launch_shared_tables(p->dtype, p->ax1s, p->d_wys, p->d_kr, p->d_shifts, p->d_taps, p->sh_etab, p->sh_E, p->sh_Epad, B, K,
+                               p->sh_nbl, p->sh, p->stream, p->sh_elems));
   HIP_TRY(hipStreamSynchronize(p->stream));   // `desc` is a local
   p->sh_use = true;
   return GPA_OK;
@@ -801,7 +843,7 @@ void gpa_plan_destroy(gpa_plan* p) {
                   p->tb.dx, p->tb.dy, p->d_kl, p->d_kr, p->d_image, p->d_mean, p->d_tile_mean, p->d_scratch,
                   p->d_lockin, p->d_kidx, p->d_dudx, p->d_dudy, p->d_wnorm, p->d_u, p->d_kmat, p->d_sf, p->d_grad, p->d_aux0, p->d_aux1,
                   p->sh.Gb, p->sh.psi, p->sh.dyc, p->sh.gtab, p->sh.desc, p->d_taps, p->tw1s,
-                  p->tw0s, p->d_taps0, p->shA_gtab, p->shA_Gx, p->shA_psi, p->shA_sx};
+                  p->tw0s, p->d_taps0, p->shA_gtab, p->shA_Gx, p->shA_psi, p->shA_sx, p->sh.pre, p->sh.rot16, p->d_wys, p->d_shifts};
   for (void* b : bufs)
     if (b) hipFree(b);
   unwrap_workspace_destroy(&p->uw);
@@ -940,7 +982,7 @@ static int passB_select(gpa_plan* p, int P, int K, void* lockin, int32_t* kidx) 
     TRY(shared_prepare(p, P, K));
     if (p->sh_use)
       HIP_TRY(launch_passB_shared(p->dtype, p->ax1s, p->n0, p->Tbuf, p->ax1s.L == p->ax1.L ? p->tw1 : p->tw1s, p->tb,
-                                  p->ax1.L / 16, p->sh, p->sh_E, p->sh_Epad, P, K, lockin, kidx, p->stream, 1, 0, p->sh_elems));
+                                  p->sh, p->sh_E, p->sh_Epad, P, K, lockin, kidx, p->stream, 1, 0, p->sh_elems, p->sh_nbl));
     else
       HIP_TRY(launch_passB(p->dtype, p->ax1, p->n0, p->Tbuf, p->Hy, p->tw1, p->tb, P, K, true, lockin, kidx, p->stream));
     return GPA_OK;
@@ -1468,7 +1510,7 @@ int gpa_extract_displacement_field_batch_dev(gpa_plan* p, const void* images, in
     TRY(run_passA(p, image, p->bMean, p->bT, Bx, nimg));
     if (p->sh_use)
       HIP_TRY(launch_passB_shared(p->dtype, p->ax1s, p->n0, p->bT, p->ax1s.L == p->ax1.L ? p->tw1 : p->tw1s, p->tb,
-                                  p->ax1.L / 16, p->sh, p->sh_E, p->sh_Epad, P, K, p->bL, nullptr, p->stream, nimg, Bx, p->sh_elems));
+                                  p->sh, p->sh_E, p->sh_Epad, P, K, p->bL, nullptr, p->stream, nimg, Bx, p->sh_elems, p->sh_nbl));
     else
       HIP_TRY(launch_passB(p->dtype, p->ax1, p->n0, p->bT, p->Hy, p->tw1, p->tb, P, K, true, p->bL, nullptr, p->stream, nimg,
                            Bx));

@@ -13,10 +13,12 @@ template <class T> struct PassBSharedNC { static constexpr int value = sizeof(T)
 
 // Device tables, element types of the plan dtype (T real, cpx<T> complex):
 struct PassBSharedTables {
-  void* Gb;     // [B][L] T      shifted Gaussian of candidate b in the spectral register layout, / L
+  void* Gb;     // [B][NBL * L / 16] T  shifted Gaussian of candidate b, its live registers in the spectral layout, / L
   void* psi;    // [B][Epad] cpx (phi_b - [periodic]) exp(2 pi i wy_b (a0 + 1)): post-factor of the end fix
   void* dyc;    // [P][n1] cpx   exp(2 pi i ky y): compensation of the winner, candidate-independent
   void* gtab;   // [2 Epad + 16] T   Hankel taps: gtab[s] = g(s) for 1 <= s <= E, 0 elsewhere
+  void* pre;    // [B][Epad] cpx  exp(2 pi i wy'_b j): pre-factor of the end strips (wy' = wy + band rotation)
+  void* rot16;  // [P][16] cpx    exp(-2 pi i s_p r / 16): the band rotation of peak p at column r mod 16
   int* desc;    // [B] per candidate: bit 0 = first of a run of candidates on one x-plane (read the row, forward
                 //   transform), bit 1 = first of a chunk of <= NC candidates (matrix pass), bits 2-3 = slot in the
                 //   chunk, bits 4-6 = candidates in the chunk, bit 7 = parity of the chunk
@@ -26,17 +28,20 @@ struct PassBSharedTables {
 bool passB_shared_supports(int dtype, const Axis& a1, int E);
 int passB_shared_elems(int dtype, const Axis& a1);
 
-// kl / kr: device [B][2] candidates and their peaks; taps: device doubles g(0 .. Etab) of the length-n circular filter
-hipError_t launch_shared_tables(int dtype, const Axis& a1, const double* kl, const double* kr, const double* taps, int Etab,
-                                int E, int Epad, int B, int K, const PassBSharedTables& st, hipStream_t s, int elems = 16);
+// wys: device [B] doubles wy_b + shift(peak) / 16; kr: device [B][2] peaks of the candidates; shifts: device [P] ints, the
+// band rotation of every peak in blocks of L / 16 bins; taps: device doubles g(0 .. Etab) of the length-n circular filter;
+// nbl: live spectral registers (passB_shared_nbl)
+hipError_t launch_shared_tables(int dtype, const Axis& a1, const double* wys, const double* kr, const int* shifts,
+                                const double* taps, int Etab, int E, int Epad, int B, int K, int nbl, const PassBSharedTables& st,
+                                hipStream_t s, int elems = 16);
+int passB_shared_nbl(int dtype, int need);
 
 // elems: elements per thread of the row transform (16; 8 exists for 4096-point rows), the same value in
 // launch_shared_tables (the candidate tables are laid out for it).
-// a1: the shared kernel's own geometry of the y axis (periodic, or zero-padded to L >= n + E); tw1: twiddles of a1.L;
-// cyb_stride: entries per candidate of tb.cyb (the plan's L1 / 16, which a1.L / 16 may be smaller than)
+// a1: the shared kernel's own geometry of the y axis (periodic, or zero-padded to L >= n + E); tw1: twiddles of a1.L
 hipError_t launch_passB_shared(int dtype, const Axis& a1, int n0, const void* Tbuf, const void* tw1, const SweepTables& tb,
-                               int cyb_stride, const PassBSharedTables& st, int E, int Epad, int P, int K, void* out,
-                               int32_t* kidx, hipStream_t s, int nimg = 1, int Bx = 0, int elems = 16);
+                               const PassBSharedTables& st, int E, int Epad, int P, int K, void* out, int32_t* kidx,
+                               hipStream_t s, int nimg = 1, int Bx = 0, int elems = 16, int nbl = 16);
 
 // ---- pass A with the forward transform shared by all x-planes of a column (same file) -------------------------------
 // a0: the kernel's own geometry of the x axis (periodic, or zero-padded to L >= n0 + E); tw0: twiddles of a0.L;

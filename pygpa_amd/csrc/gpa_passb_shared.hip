@@ -51,9 +51,6 @@ template <class T> __device__ __forceinline__ int mfma_row(int kq, int r) {
 
 template <class T> struct upair { T u, v; };
 
-#ifndef GPA_PBS_PREFETCH
-#define GPA_PBS_PREFETCH 0
-#endif
 #ifndef GPA_PBS_NOFIX
 #define GPA_PBS_NOFIX 0     // diagnosis only: skip the end fix (wrong results at the row ends)
 #endif
@@ -162,14 +159,21 @@ struct PassBSGeom {
 #ifndef GPA_PBS_E8_F64_WAVES
 #define GPA_PBS_E8_F64_WAVES 2
 #endif
-template <class T, int LG, bool PADDED, int EE>
+// NBL = live spectral registers.  The Gaussian keeps a band of bins; in the spectral register layout register i of
+// every thread holds bin kappa(thread) + (L / EE) i, i.e. block i of L / EE consecutive bins.  The host rotates each
+// peak's band to block 0 (an input phasor exp(-2 pi i s y / EE) of period EE and candidate frequencies wy + s / EE: the
+// same products, the spectrum shifted by s blocks), so only registers 0 .. NBL-1 of the shared spectrum and of the
+// candidate's Gaussian are live: fewer registers (the next candidate's Gaussian is requested before this
+// candidate's stores), and the zeros of the other registers prune the first inverse pass at compile time.
+template <class T, int LG, bool PADDED, int EE, int NBL>
 __global__ __launch_bounds__((PassBSGeom<T, LG, EE>::THREADS),
                              (EE == 8 ? (sizeof(T) == 8 ? GPA_PBS_E8_F64_WAVES : GPA_PBS_E8_WAVES)
                                       : (sizeof(T) == 8 ? GPA_PBS_F64_WAVES : (PADDED ? GPA_PBS_PAD_WAVES : GPA_PBS_F32_WAVES)))) void passB_shared_kernel(
     const cpx<T>* __restrict__ Tin, int n0, int n1, const T* __restrict__ Gb, const cpx<T>* __restrict__ twtab,
-    const int* __restrict__ planeof, const int* __restrict__ desc, const cpx<T>* __restrict__ cyb,
+    const int* __restrict__ planeof, const int* __restrict__ desc, const cpx<T>* __restrict__ pre_g,
     const cpx<T>* __restrict__ psi, const T* __restrict__ gtab, const cpx<T>* __restrict__ dx,
-    const cpx<T>* __restrict__ dyc, int K, int E, int Epad, cpx<T>* out, int32_t* kidx, int P, int Bx, int cyb_stride) {
+    const cpx<T>* __restrict__ dyc, const cpx<T>* __restrict__ rot16, int K, int E, int Epad, cpx<T>* out,
+    int32_t* kidx, int P, int Bx) {
   using F = WgFFT<T, LG, EE>;
   using G = PassBSGeom<T, LG, EE>;
   using V4 = typename MfmaVec<T>::type;
@@ -215,33 +219,40 @@ __global__ __launch_bounds__((PassBSGeom<T, LG, EE>::THREADS),
   // registers that hold the last E samples of the row (zero-padded rows: wherever n1 puts them)
   const int iA = PADDED ? (n1 - E) / TPF : EE - 1, iB = PADDED ? (n1 - 1) / TPF : EE - 1;
 
-  cpx<T> X[EE];
-  T h[EE];
+  cpx<T> X[NBL];
+  T h[NBL];
+  // the rotation phasor of this peak at the thread's columns (period EE in y: one value per thread) and at the
+  // column of its tail sample
+  const cpx<T> rot = rot16[pt * EE + (tid & (EE - 1))];
+  const cpx<T> rot_tail = rot16[pt * EE + ((n1 - 1 - (tid < E ? tid : 0)) & (EE - 1))];
+  constexpr bool PREFETCH = NBL < EE;
   for (int k = 0; k < K; ++k) {
     const int b = pt * K + k;
     const int d = desc[b];
     if (d & 1) {
       // ---- a new x-plane: read its row once, take the end strips, forward transform -------------------------
       const cpx<T>* src = Tin + (((size_t)img * Bx + planeof[b]) * n0 + rr) * n1;
-      const cpx<T> cs = dx[(size_t)b * n0 + rr];   // exp(-2 pi i (wx - kx) x): the same for every candidate of the plane
+      const cpx<T> cs0 = dx[(size_t)b * n0 + rr];   // exp(-2 pi i (wx - kx) x): the same for every candidate of the plane
+      const cpx<T> cs = cmul(cs0, rot);              // ... times the band rotation at this thread's columns
       cpx<T> tail = {T(0), T(0)};
       if (tid < E) tail = src[n1 - 1 - tid];
+      cpx<T> XX[EE];
       if constexpr (PADDED) {
         // (zero-padded rows: the slots beyond the row read as zero through the range check of a buffer descriptor)
         const __amdgpu_buffer_rsrc_t srow = __builtin_amdgcn_make_buffer_rsrc((void*)src, 0, n1 * (int)sizeof(cpx<T>), 0x00020000);
 #pragma unroll
         for (int i = 0; i < EE; ++i)
-          X[i] = cmul(load_cpx<T>(srow, (tid + TPF * i) * (int)sizeof(cpx<T>), 0, 0), cs);
+          XX[i] = cmul(load_cpx<T>(srow, (tid + TPF * i) * (int)sizeof(cpx<T>), 0, 0), cs);
       } else {
 #pragma unroll
-        for (int i = 0; i < EE; ++i) X[i] = cmul(src[tid + TPF * i], cs);
+        for (int i = 0; i < EE; ++i) XX[i] = cmul(src[tid + TPF * i], cs);
       }
       if (tid < Epad) {
         // strips in the two forms the matrix pass reads (it forms ONE real of t * p or t * conj(p) per lane as
         // u p.x + v p.y): end 0 = T(j), j < E (feeds the outputs at the row's end), end 1 = T(n - 1 - j)
         const bool in = tid < E;
-        const cpx<T> s0 = in ? X[0] : cpx<T>{T(0), T(0)};
-        const cpx<T> s1 = in ? cmul(tail, cs) : cpx<T>{T(0), T(0)};
+        const cpx<T> s0 = in ? XX[0] : cpx<T>{T(0), T(0)};
+        const cpx<T> s1 = in ? cmul(tail, cmul(cs0, rot_tail)) : cpx<T>{T(0), T(0)};
         if constexpr (G::SV == 4) {
           strip[0 * ES + tid] = {s0.x, -s0.y};   // end 0, real part of t p
           strip[1 * ES + tid] = {s0.y, s0.x};    // end 0, imaginary part
@@ -252,30 +263,32 @@ __global__ __launch_bounds__((PassBSGeom<T, LG, EE>::THREADS),
           strip[1 * ES + tid] = {s1.x, s1.y};
         }
       }
-      F::forward(X, lds, tid, tw);
+      F::forward(XX, lds, tid, tw);
+      // only the band's blocks are kept (the transform's other outputs are dead code)
+#pragma unroll
+      for (int i = 0; i < NBL; ++i) X[i] = XX[i];
     }
     // ---- candidate b: shifted Gaussian, inverse transform (the matrix pass of a new chunk rides between its barriers)
     const int par = (d >> 7) & 1;   // parity of the chunk: which copy of the staged post-factors this candidate reads
     cpx<T> y[EE];
     {
-#if GPA_PBS_PREFETCH
-      if (k == 0) load_gb<T, TPF, EE>(h, Gb + (size_t)b * L, tid);
-#else
-      load_gb<T, TPF, EE>(h, Gb + (size_t)b * L, tid);
-#endif
+      if (!PREFETCH || k == 0) load_gb<T, TPF, NBL>(h, Gb + (size_t)b * (NBL * TPF), tid);
       if constexpr (STAGE) {
         if (d & 2) {
           // phasors of this chunk's candidates into LDS: exp(2 pi i wy j) (strip pre-factors) and the post-factors
           const int nc = (d >> 4) & 7;
           for (int e = tid; e < NC * Epad; e += TPF) {
             const int c = e / Epad, j = e - c * Epad, cc = c < nc ? c : nc - 1;
-            pre_l[c * ES + j] = cyb[(size_t)(b + cc) * cyb_stride + j];
+            pre_l[c * ES + j] = pre_g[(size_t)(b + cc) * Epad + j];
             psi_l[(par * NC + c) * ES + j] = psi[(size_t)(b + cc) * Epad + j];
           }
         }
       }
 #pragma unroll
-      for (int i = 0; i < EE; ++i) y[i] = {X[i].x * h[i], X[i].y * h[i]};
+      for (int i = 0; i < EE; ++i) {
+        if (i < NBL) y[i] = {X[i < NBL ? i : 0].x * h[i < NBL ? i : 0], X[i < NBL ? i : 0].y * h[i < NBL ? i : 0]};
+        else y[i] = {T(0), T(0)};
+      }
     }
     cpx<T> psL = {T(0), T(0)}, psR = {T(0), T(0)};
     const int a0R = PADDED ? 0 : TPF - 1 - tid;
@@ -292,7 +305,7 @@ __global__ __launch_bounds__((PassBSGeom<T, LG, EE>::THREADS),
       const int nc = (d >> 4) & 7;
       const int n = lane & 15, kq = lane >> 4;
       const int c = (n >> 1) & (NC - 1), end = (n >> (1 + G::LOGNC)) & 1, reim = n & 1;
-      const cpx<T>* pre = STAGE ? pre_l + c * ES : cyb + (size_t)(b + (c < nc ? c : nc - 1)) * cyb_stride;
+      const cpx<T>* pre = STAGE ? pre_l + c * ES : pre_g + (size_t)(b + (c < nc ? c : nc - 1)) * Epad;
       const upair<T>* sp = strip + (G::SV == 4 ? end * 2 + reim : end) * ES;
       // (two-strip form: u, v and the sign of v picked per lane)
       const bool swp = reim != 0;
@@ -386,12 +399,11 @@ __global__ __launch_bounds__((PassBSGeom<T, LG, EE>::THREADS),
       }
     }
 #endif
-#if GPA_PBS_PREFETCH
-    // the next candidate's Gaussian is requested BEFORE this candidate's stores: vmcnt counts loads and stores in
-    // order, so loads issued behind the stores would wait for the stores' acknowledgements as well
-    if (k + 1 < K) load_gb<T, TPF, EE>(h, Gb + (size_t)(b + 1) * L, tid);
-    __builtin_amdgcn_sched_barrier(0);
-#endif
+    // the next candidate's Gaussian (NBL values) is requested BEFORE this candidate's stores: vmcnt counts loads and
+    // stores in order, so loads issued behind the stores would wait for the stores' acknowledgements as well
+    if constexpr (PREFETCH) {
+      if (k + 1 < K) load_gb<T, TPF, NBL>(h, Gb + (size_t)(b + 1) * (NBL * TPF), tid);
+    }
     // ---- strict '>' in list order; the winner goes to memory at once ----------------------------------------
 #pragma unroll
     for (int i = 0; i < EE; ++i) {
@@ -845,17 +857,19 @@ hipError_t launch_passA_shared(int dtype, const Axis& a0, int n1, const void* im
 // ---------------------------------------------------------------------------------------------------------------
 
 template <class T, int LG, int EE>
-__global__ __launch_bounds__(256) void shared_tables_kernel(const double* __restrict__ kl, const double* __restrict__ kr,
-                                                           const double* __restrict__ taps, int Etab, int n1, int E,
-                                                           int Epad, int wrapped, int K, T* __restrict__ Gb,
-                                                           cpx<T>* __restrict__ psi, cpx<T>* __restrict__ dyc) {
+__global__ __launch_bounds__(256) void shared_tables_kernel(const double* __restrict__ wys, const double* __restrict__ kr,
+                                                           const int* __restrict__ shifts, const double* __restrict__ taps,
+                                                           int Etab, int n1, int E, int Epad, int wrapped, int K, int nbl,
+                                                           T* __restrict__ Gb, cpx<T>* __restrict__ psi,
+                                                           cpx<T>* __restrict__ dyc, cpx<T>* __restrict__ pre,
+                                                           cpx<T>* __restrict__ rot16) {
   using F = WgFFT<T, LG, EE>;
   constexpr int L = F::L, TPF = F::TPF;
   const int b = blockIdx.y;
   const int idx = blockIdx.x * 256 + threadIdx.x;
-  const double wy = kl[2 * b + 1];
-  if (idx < L) {
-    // G_b[k] = sum_m g(m) exp(-2 pi i (wy + k / L) m) over the signed lags: real, g even
+  const double wy = wys[b];     // the candidate's frequency plus its peak's band rotation s / EE
+  if (idx < nbl * TPF) {
+    // G_b[k] = sum_m g(m) exp(-2 pi i (wy + k / L) m) over the signed lags: real, g even; live registers only
     const int i = idx / TPF, t = idx % TPF;
     const int kbin = F::spec_index(t, i);
     const double fq = wy + (double)kbin / (double)L;
@@ -864,10 +878,10 @@ __global__ __launch_bounds__(256) void shared_tables_kernel(const double* __rest
       const double ph = fq * (double)m;
       acc += taps[m] * cospi(2.0 * (ph - rint(ph)));
     }
-    Gb[(size_t)b * L + idx] = (T)((taps[0] + 2.0 * acc) / (double)L);
+    Gb[(size_t)b * (nbl * TPF) + idx] = (T)((taps[0] + 2.0 * acc) / (double)L);
   }
   if (idx < Epad) {
-    // (phi_b - [row is periodic]) exp(2 pi i wy (a0 + 1)),  phi_b = exp(-2 pi i wy n)
+    // (phi_b - [row is periodic]) exp(2 pi i wy (a0 + 1)),  phi_b = exp(-2 pi i wy n);  pre-factor exp(2 pi i wy j)
     double ps, pc, qs, qc;
     const double c0 = -wy * (double)n1, c1 = wy * (double)(idx + 1);
     sincospi(2.0 * (c0 - rint(c0)), &ps, &pc);
@@ -876,45 +890,53 @@ __global__ __launch_bounds__(256) void shared_tables_kernel(const double* __rest
     cpx<T> v = {(T)(pc * qc - ps * qs), (T)(pc * qs + ps * qc)};
     if (idx >= E) v = {T(0), T(0)};
     psi[(size_t)b * Epad + idx] = v;
+    pre[(size_t)b * Epad + idx] = unit_phasor_s<T>(wy * (double)idx);
   }
-  if (b % K == 0 && idx < n1) dyc[(size_t)(b / K) * n1 + idx] = unit_phasor_s<T>(kr[2 * b + 1] * (double)idx);
+  if (b % K == 0) {
+    const int p = b / K;
+    const double sh = (double)shifts[p] / (double)EE;
+    if (idx < n1) dyc[(size_t)p * n1 + idx] = unit_phasor_s<T>((kr[2 * b + 1] + sh) * (double)idx);
+    if (idx < EE) rot16[p * EE + idx] = unit_phasor_s<T>(-sh * (double)idx);
+  }
 }
 
 template <class T, int LG, int EE>
-static hipError_t run_shared_tables(const Axis& a1, const double* kl, const double* kr, const double* taps, int Etab, int E,
-                                    int Epad, int B, int K, const PassBSharedTables& st, hipStream_t s) {
+static hipError_t run_shared_tables(const Axis& a1, const double* wys, const double* kr, const int* shifts, const double* taps,
+                                    int Etab, int E, int Epad, int B, int K, int nbl, const PassBSharedTables& st, hipStream_t s) {
   int len = a1.L > a1.n ? a1.L : a1.n;
   if (len < Epad) len = Epad;
   dim3 grid((len + 255) / 256, B);
-  shared_tables_kernel<T, LG, EE><<<grid, 256, 0, s>>>(kl, kr, taps, Etab, a1.n, E, Epad, a1.padded ? 0 : 1, K, (T*)st.Gb,
-                                                   (cpx<T>*)st.psi, (cpx<T>*)st.dyc);
+  shared_tables_kernel<T, LG, EE><<<grid, 256, 0, s>>>(wys, kr, shifts, taps, Etab, a1.n, E, Epad, a1.padded ? 0 : 1, K, nbl,
+                                                       (T*)st.Gb, (cpx<T>*)st.psi, (cpx<T>*)st.dyc, (cpx<T>*)st.pre,
+                                                       (cpx<T>*)st.rot16);
   return hipGetLastError();
 }
 
-hipError_t launch_shared_tables(int dtype, const Axis& a1, const double* kl, const double* kr, const double* taps, int Etab,
-                                int E, int Epad, int B, int K, const PassBSharedTables& st, hipStream_t s, int elems) {
+hipError_t launch_shared_tables(int dtype, const Axis& a1, const double* wys, const double* kr, const int* shifts,
+                                const double* taps, int Etab, int E, int Epad, int B, int K, int nbl, const PassBSharedTables& st,
+                                hipStream_t s, int elems) {
 #ifdef GPA_PBS_BUILD_E8      // the eight-element instantiations: measured slower (profiles/r03_passB_variants.txt), not built by default
 #define CASE_T8(LG) CASE_T(LG, 8)
 #else
 #define CASE_T8(LG)
 #endif
-#define CASE_T(LG, EE)                                                                                              \
-  if (a1.lg == LG && elems == EE)                                                                                   \
-    return dtype == 0 ? run_shared_tables<float, LG, EE>(a1, kl, kr, taps, Etab, E, Epad, B, K, st, s)             \
-                      : run_shared_tables<double, LG, EE>(a1, kl, kr, taps, Etab, E, Epad, B, K, st, s);
+#define CASE_T(LG, EE)                                                                                                  \
+  if (a1.lg == LG && elems == EE)                                                                                       \
+    return dtype == 0 ? run_shared_tables<float, LG, EE>(a1, wys, kr, shifts, taps, Etab, E, Epad, B, K, nbl, st, s)    \
+                      : run_shared_tables<double, LG, EE>(a1, wys, kr, shifts, taps, Etab, E, Epad, B, K, nbl, st, s);
   CASE_T(11, 16) CASE_T(12, 16) CASE_T8(12)
 #undef CASE_T
   return hipErrorInvalidValue;
 }
 
-template <class T, int LG, bool PADDED, int EE>
+template <class T, int LG, bool PADDED, int EE, int NBL>
 static hipError_t run_passB_shared(const Axis& a1, int n0, const void* Tbuf, const void* tw1, const SweepTables& tb,
-                                   int cyb_stride, const PassBSharedTables& st, int E, int Epad, int P, int K, void* out, int32_t* kidx,
+                                   const PassBSharedTables& st, int E, int Epad, int P, int K, void* out, int32_t* kidx,
                                    hipStream_t s, int nimg, int Bx) {
   using G = PassBSGeom<T, LG, EE>;
   const size_t lds = G::lds_bytes(Epad);
   if (lds > 160 * 1024 || E > G::TPF || Epad > G::TPF) return hipErrorInvalidValue;
-  auto kern = passB_shared_kernel<T, LG, PADDED, EE>;
+  auto kern = passB_shared_kernel<T, LG, PADDED, EE, NBL>;
   // (the dynamic LDS size depends on Epad: raise the limit whenever a larger one comes along)
   static int lds_set[32] = {0};
   int dev = 0;
@@ -927,8 +949,8 @@ static hipError_t run_passB_shared(const Axis& a1, int n0, const void* Tbuf, con
   dim3 grid((n0 + G::NF - 1) / G::NF, P * nimg);
   GPA_PROF("passB_shared_kernel", s);
   kern<<<grid, G::THREADS, lds, s>>>((const cpx<T>*)Tbuf, n0, a1.n, (const T*)st.Gb, (const cpx<T>*)tw1, tb.planeof, st.desc,
-                                     (const cpx<T>*)tb.cyb, (const cpx<T>*)st.psi, (const T*)st.gtab, (const cpx<T>*)tb.dx,
-                                     (const cpx<T>*)st.dyc, K, E, Epad, (cpx<T>*)out, kidx, P, Bx, cyb_stride);
+                                     (const cpx<T>*)st.pre, (const cpx<T>*)st.psi, (const T*)st.gtab, (const cpx<T>*)tb.dx,
+                                     (const cpx<T>*)st.dyc, (const cpx<T>*)st.rot16, K, E, Epad, (cpx<T>*)out, kidx, P, Bx);
   return hipGetLastError();
 }
 
@@ -961,20 +983,29 @@ bool passB_shared_supports(int dtype, const Axis& a1, int E) {
   return lds <= 160 * 1024;
 }
 
+// the live-register counts that are built: the smallest one that holds `need` blocks
+int passB_shared_nbl(int dtype, int need) {
+  if (dtype == 0 && need <= 6) return 6;
+  if (need <= 8) return 8;
+  return 16;
+}
+
 hipError_t launch_passB_shared(int dtype, const Axis& a1, int n0, const void* Tbuf, const void* tw1, const SweepTables& tb,
-                               int cyb_stride, const PassBSharedTables& st, int E, int Epad, int P, int K, void* out, int32_t* kidx,
-                               hipStream_t s, int nimg, int Bx, int elems) {
-#define CALL_S(T, LG, EE) \
-  (a1.padded ? run_passB_shared<T, LG, true, EE>(a1, n0, Tbuf, tw1, tb, cyb_stride, st, E, Epad, P, K, out, kidx, s, nimg, Bx) \
-             : run_passB_shared<T, LG, false, EE>(a1, n0, Tbuf, tw1, tb, cyb_stride, st, E, Epad, P, K, out, kidx, s, nimg, Bx))
+                               const PassBSharedTables& st, int E, int Epad, int P, int K, void* out, int32_t* kidx,
+                               hipStream_t s, int nimg, int Bx, int elems, int nbl) {
+#define CALL_S(T, LG, EE, NBL) \
+  (a1.padded ? run_passB_shared<T, LG, true, EE, NBL>(a1, n0, Tbuf, tw1, tb, st, E, Epad, P, K, out, kidx, s, nimg, Bx) \
+             : run_passB_shared<T, LG, false, EE, NBL>(a1, n0, Tbuf, tw1, tb, st, E, Epad, P, K, out, kidx, s, nimg, Bx))
+#define CASE_S(LG, EE, NBL) \
+  if (a1.lg == LG && elems == EE && nbl == NBL) return dtype == 0 ? CALL_S(float, LG, EE, NBL) : CALL_S(double, LG, EE, NBL);
+#define CASE_F32(LG, EE, NBL) \
+  if (a1.lg == LG && elems == EE && nbl == NBL && dtype == 0) return CALL_S(float, LG, EE, NBL);
+  CASE_F32(11, 16, 6) CASE_F32(12, 16, 6)
+  CASE_S(11, 16, 8) CASE_S(12, 16, 8) CASE_S(11, 16, 16) CASE_S(12, 16, 16)
 #ifdef GPA_PBS_BUILD_E8
-#define CASE_S8(LG) CASE_S(LG, 8)
-#else
-#define CASE_S8(LG)
+  CASE_S(12, 8, 8)
 #endif
-#define CASE_S(LG, EE) \
-  if (a1.lg == LG && elems == EE) return dtype == 0 ? CALL_S(float, LG, EE) : CALL_S(double, LG, EE);
-  CASE_S(11, 16) CASE_S(12, 16) CASE_S8(12)
+#undef CASE_F32
 #undef CASE_S
 #undef CALL_S
   return hipErrorInvalidValue;
