@@ -15,8 +15,8 @@ def test_weak_shapes_keep_pixels_per_gpu():
     assert bench.weak_shape(1, 4096) == (4096, 4096)
     assert bench.weak_shape(2, 4096) == (8192, 4096)
     assert bench.weak_shape(4, 4096) == (8192, 8192)            # BASELINE configs[3]
-    assert bench.weak_shape(8, 4096) == (16384, 8192)
-    for w in range(1, 9):
+    assert bench.weak_shape(8, 4096) == (16384, 16384)          # BASELINE configs[4]'s image (2 x 4096^2 per GPU)
+    for w in range(1, 8):
         a, b = bench.weak_shape(w, 512)
         assert a * b == w * 512 * 512 and a >= b
 
@@ -27,6 +27,10 @@ def test_kernel_models_add_up():
     px = 4096 * 4096
     assert m['passA_kernel']['bytes'] == px * (4 + 2 * 4 * 12)
     assert m['passB_kernel']['bytes'] == px * (2 * 4 * 12 + 2 * 4 * 3)
+    # the shared-forward pass B: same algorithmic bytes and flops, fewer executed (12 forward + 48 inverse transforms per row)
+    sh = m['passB_shared_kernel']
+    assert sh['bytes'] == m['passB_kernel']['bytes'] and sh['flops'] == m['passB_kernel']['flops']
+    assert 0.6 < sh['executed_flops'] / sh['flops'] < 0.7
     assert m['colsolve_kernel']['bytes'] == 2 * 4 * px and m['pq_kernel']['bytes'] == 3 * 4 * px
     # nominal flops of pass B: 48 lock-ins x 4096 rows x two 4096-point FFTs
     assert 1.0 <= m["passB_kernel"]["flops"] / (48 * 4096 * 2 * 5 * 4096 * 12) < 1.2   # + carrier / filter multiplies
