@@ -12,8 +12,11 @@ if [ -z "$SKIP_TESTS" ]; then
   echo "pytest rc=$?"; tail -4 $out/pytest_gpu.log
 fi
 timeout 300 python __graft_entry__.py smoke 2>&1 | tail -1
-timeout 900 python bench.py > $out/bench.json 2> $out/bench.err; echo "bench rc=$?"; tail -2 $out/bench.err; head -c 700 $out/bench.json; echo
+[ -n "$PMC_FIRST" ] && echo "(bench line after the counters)" || timeout 900 python bench.py > $out/bench.json 2> $out/bench.err; echo "bench rc=$?"; tail -2 $out/bench.err; head -c 700 $out/bench.json; echo
 cd /tmp && export TMPDIR=/tmp
+# (the two unwrap components run one after the other while the kernels are timed: concurrent kernels of the two streams
+#  stretch each other's durations)
+export GPA_SERIAL_UNWRAP=1
 kstats() {   # tag, bench args...
   tag=$1; shift
   timeout 600 rocprofv3 --kernel-trace --stats --output-format csv -d $out/ks_$tag -- python3 $ROOT/bench.py --steps 5 --warmup 1 --no-cpu --no-f64 "$@" > $out/ks_$tag.log 2>&1
@@ -26,6 +29,8 @@ kstats 4096_f64 --dtype f64
 kstats 3000_f32 --size 3000
 kstats 2048_c2 --size 2048 --kgrid 4x2
 kstats 512_f32 --size 512
+unset GPA_SERIAL_UNWRAP
+[ -n "$SKIP_PMC" ] && exit 0
 i=0
 for set in "FETCH_SIZE" "WRITE_SIZE" "SQ_INSTS_VALU SQ_WAVES SQ_INSTS_LDS SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE SQ_WAVE_CYCLES SQ_WAIT_INST_ANY SQ_BUSY_CYCLES" \
            "SQ_WAIT_ANY SQ_ACTIVE_INST_ANY SQ_ACTIVE_INST_VALU SQ_INSTS_VALU_MFMA_F32 SQ_INSTS_VMEM_WR SQ_INSTS_VMEM_RD" "TCC_HIT_sum TCC_MISS_sum GRBM_GUI_ACTIVE"; do
