@@ -60,6 +60,9 @@ template <class T> struct upair { T u, v; };
 #ifndef GPA_PBS_NOSTORE
 #define GPA_PBS_NOSTORE 0   // diagnosis only: skip the winner stores
 #endif
+#ifndef GPA_PBS_NTLOAD
+#define GPA_PBS_NTLOAD 0    // experiment: the x-plane row (read once) as a non-temporal load, so that it does not evict the winners' rows from L2
+#endif
 
 // the shifted Gaussian of one candidate: sixteen reals per thread in the spectral register layout
 template <class T, int TPF, int EE>
@@ -70,6 +73,17 @@ __device__ __forceinline__ void load_gb(T (&h)[EE], const T* gbrow, int tid) {
   for (int i = 0; i < EE; ++i) h[i] = gb[i * TPF + tid];
 }
 template <class T> __device__ __forceinline__ cpx<T> load_cpx(__amdgpu_buffer_rsrc_t r, int voff, int soff, int aux = 16);
+// a value that is read once: non-temporal (streams through L2)
+__device__ __forceinline__ cpx<float> load_once(const cpx<float>* p) {
+  typedef float v2f_t __attribute__((ext_vector_type(2)));
+  const v2f_t d = __builtin_nontemporal_load(reinterpret_cast<const v2f_t*>(p));
+  return {d.x, d.y};
+}
+__device__ __forceinline__ cpx<double> load_once(const cpx<double>* p) {
+  typedef double v2d_t __attribute__((ext_vector_type(2)));
+  const v2d_t d = __builtin_nontemporal_load(reinterpret_cast<const v2d_t*>(p));
+  return {d.x, d.y};
+}
 
 typedef int v2i_t __attribute__((ext_vector_type(2)));
 typedef int v4i_t __attribute__((ext_vector_type(4)));
@@ -245,7 +259,7 @@ __global__ __launch_bounds__((PassBSGeom<T, LG, EE>::THREADS),
           XX[i] = cmul(load_cpx<T>(srow, (tid + TPF * i) * (int)sizeof(cpx<T>), 0, 0), cs);
       } else {
 #pragma unroll
-        for (int i = 0; i < EE; ++i) XX[i] = cmul(src[tid + TPF * i], cs);
+        for (int i = 0; i < EE; ++i) XX[i] = cmul(GPA_PBS_NTLOAD ? load_once(src + tid + TPF * i) : src[tid + TPF * i], cs);
       }
       if (tid < Epad) {
         // strips in the two forms the matrix pass reads (it forms ONE real of t * p or t * conj(p) per lane as
