@@ -487,7 +487,8 @@ def multi_gpu(args, world, rank, local_rank):
     # unpipelined step() (unwrap on ranks 0 / 1 while the others wait, u broadcast to every rank)
     stream = args.schedule == 'stream'
     if stream:
-        pipe.run_stream([None] * max(args.warmup, 1))
+        # (untimed) at least one image per pair of unwrap owners, so that every point-to-point route has been used once
+        pipe.run_stream([None] * max(args.warmup, (world + 1) // 2, 1))
     else:
         for _ in range(args.warmup):
             pipe.step()

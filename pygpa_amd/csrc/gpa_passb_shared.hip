@@ -61,7 +61,7 @@ template <class T> struct upair { T u, v; };
 #define GPA_PBS_NOSTORE 0   // diagnosis only: skip the winner stores
 #endif
 #ifndef GPA_PBS_NTLOAD
-#define GPA_PBS_NTLOAD 0    // experiment: the x-plane row (read once) as a non-temporal load, so that it does not evict the winners' rows from L2
+#define GPA_PBS_NTLOAD 1    // the x-plane row (read once) as a non-temporal load, so that it does not evict the winners' rows from L2 (-2.5 %, L2 hit rate 0.69 -> 0.80)
 #endif
 
 // the shifted Gaussian of one candidate: sixteen reals per thread in the spectral register layout
@@ -92,13 +92,13 @@ __device__ __forceinline__ void store_cpx(cpx<float> v, __amdgpu_buffer_rsrc_t r
   v2i_t d = {__float_as_int(v.x), __float_as_int(v.y)};
   __builtin_amdgcn_raw_buffer_store_b64(d, r, voff, soff, 0);
 }
-// aux 16 = sc1: served by L2, not by whatever L1 holds (the read-back of the winners); 0 = an ordinary load
+// aux 16 = sc1: served by L2, not by whatever L1 holds (the read-back of the winners); 2 = nt (read once); 0 = an ordinary load
 template <> __device__ __forceinline__ cpx<float> load_cpx<float>(__amdgpu_buffer_rsrc_t r, int voff, int soff, int aux) {
-  v2i_t d = aux ? __builtin_amdgcn_raw_buffer_load_b64(r, voff, soff, 16) : __builtin_amdgcn_raw_buffer_load_b64(r, voff, soff, 0);
+  v2i_t d = aux == 16 ? __builtin_amdgcn_raw_buffer_load_b64(r, voff, soff, 16) : aux == 2 ? __builtin_amdgcn_raw_buffer_load_b64(r, voff, soff, 2) : __builtin_amdgcn_raw_buffer_load_b64(r, voff, soff, 0);
   return {__int_as_float(d.x), __int_as_float(d.y)};
 }
 template <> __device__ __forceinline__ cpx<double> load_cpx<double>(__amdgpu_buffer_rsrc_t r, int voff, int soff, int aux) {
-  v4i_t d = aux ? __builtin_amdgcn_raw_buffer_load_b128(r, voff, soff, 16) : __builtin_amdgcn_raw_buffer_load_b128(r, voff, soff, 0);
+  v4i_t d = aux == 16 ? __builtin_amdgcn_raw_buffer_load_b128(r, voff, soff, 16) : aux == 2 ? __builtin_amdgcn_raw_buffer_load_b128(r, voff, soff, 2) : __builtin_amdgcn_raw_buffer_load_b128(r, voff, soff, 0);
   const long long a = ((long long)(unsigned)d.x) | ((long long)d.y << 32), b = ((long long)(unsigned)d.z) | ((long long)d.w << 32);
   return {__longlong_as_double(a), __longlong_as_double(b)};
 }
@@ -256,7 +256,7 @@ __global__ __launch_bounds__((PassBSGeom<T, LG, EE>::THREADS),
         const __amdgpu_buffer_rsrc_t srow = __builtin_amdgcn_make_buffer_rsrc((void*)src, 0, n1 * (int)sizeof(cpx<T>), 0x00020000);
 #pragma unroll
         for (int i = 0; i < EE; ++i)
-          XX[i] = cmul(load_cpx<T>(srow, (tid + TPF * i) * (int)sizeof(cpx<T>), 0, 0), cs);
+          XX[i] = cmul(load_cpx<T>(srow, (tid + TPF * i) * (int)sizeof(cpx<T>), 0, GPA_PBS_NTLOAD ? 2 : 0), cs);
       } else {
 #pragma unroll
         for (int i = 0; i < EE; ++i) XX[i] = cmul(GPA_PBS_NTLOAD ? load_once(src + tid + TPF * i) : src[tid + TPF * i], cs);

@@ -419,15 +419,24 @@ class TiledPipeline:
             return
         dist = self.dist
         g = (lambda r: r) if self.group is None else (lambda r: dist.get_global_rank(self.group, r))
-        if self.rank == src:
-            dist.send(t.cpu() if self._host_staged() else t, g(dst), group=self.group)
-        elif self.rank == dst:
-            if self._host_staged():
+        if self._host_staged():
+            if self.rank == src:
+                dist.send(t.cpu(), g(dst), group=self.group)
+            elif self.rank == dst:
                 h = t.cpu()
                 dist.recv(h, g(src), group=self.group)
                 t.copy_(h)
-            else:
-                dist.recv(t, g(src), group=self.group)
+            return
+        # RCCL: a grouped isend / irecv runs on the communicator of the whole group (a bare send / recv would build a
+        # two-rank communicator per pair on first use, inside somebody's timed region)
+        ops = []
+        if self.rank == src:
+            ops.append(dist.P2POp(dist.isend, t, g(dst), group=self.group))
+        elif self.rank == dst:
+            ops.append(dist.P2POp(dist.irecv, t, g(src), group=self.group))
+        if ops:
+            for w in dist.batch_isend_irecv(ops):
+                w.wait()
 
     def run_stream(self, sources, on_result=None):
         """A stream of images of the pipeline's shape through the image-pipelined schedule.
