@@ -82,14 +82,36 @@ hipError_t launch_tables(int dtype, const Axis& a0, const Axis& a1, const double
 // ---------------------------------------------------------------------------
 // image mean (deterministic two-stage reduction in double)
 // ---------------------------------------------------------------------------
+template <class T> struct alignas(16) MeanVec4 { T v[4]; };
 template <class T>
 __global__ void mean_partial_kernel(const T* __restrict__ img, size_t count, double* partial) {
   img += (size_t)blockIdx.y * count;        // (image stacks: blockIdx.y = image)
   partial += (size_t)blockIdx.y * gridDim.x;
   __shared__ double sh[256];
   double acc = 0;
-  for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < count; i += (size_t)gridDim.x * 256)
-    acc += (double)img[i];
+  if ((count & 3) == 0 && (reinterpret_cast<size_t>(img) & 15) == 0) {
+    // 16-byte loads, four independent chains per thread (the scalar loop was one dependent chain of 4-byte loads:
+    // 33 us for a 4096^2 image, a third of HBM rate); fixed order, so the sum is reproducible
+    const MeanVec4<T>* v = reinterpret_cast<const MeanVec4<T>*>(img);
+    const size_t c4 = count >> 2, step = (size_t)gridDim.x * 256;
+    double a0 = 0, a1 = 0, a2 = 0, a3 = 0;
+    size_t i = (size_t)blockIdx.x * 256 + threadIdx.x;
+    for (; i + step < c4; i += 2 * step) {
+      const MeanVec4<T> u = v[i], w = v[i + step];
+      a0 += (double)u.v[0] + (double)w.v[0];
+      a1 += (double)u.v[1] + (double)w.v[1];
+      a2 += (double)u.v[2] + (double)w.v[2];
+      a3 += (double)u.v[3] + (double)w.v[3];
+    }
+    if (i < c4) {
+      const MeanVec4<T> u = v[i];
+      a0 += (double)u.v[0]; a1 += (double)u.v[1]; a2 += (double)u.v[2]; a3 += (double)u.v[3];
+    }
+    acc = (a0 + a1) + (a2 + a3);
+  } else {
+    for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < count; i += (size_t)gridDim.x * 256)
+      acc += (double)img[i];
+  }
   sh[threadIdx.x] = acc;
   __syncthreads();
   for (int s = 128; s > 0; s >>= 1) {
