@@ -628,7 +628,7 @@ struct RowGeom {
   static constexpr size_t LDS_BYTES = (size_t)NF * RS * sizeof(cpx<T>);
   static constexpr bool FITS = LDS_BYTES <= 160 * 1024;
 };
-template <class T, int LG>
+template <class T, int LG, bool LAT = false>
 struct ColGeom {
   using F = WgFFT<T, LG, unwrap_elems(LG, sizeof(T))>;
   using D = WgDCT<T, LG, unwrap_elems(LG, sizeof(T))>;
@@ -641,7 +641,16 @@ struct ColGeom {
 #ifndef GPA_COL_WANT
 #define GPA_COL_WANT 16
 #endif
-    const int want = LG >= 12 ? GPA_COL_WANT : (LG == 11 ? 2 : 1);
+#ifndef GPA_COL_WANT11
+#define GPA_COL_WANT11 2
+#endif
+#ifndef GPA_COL_WANT10
+#define GPA_COL_WANT10 4   // 1024-point columns: 4 pairs (32-byte row segments): single image 1600 -> 1700 Mpix/s; 2 -> 1660, 8 -> 1630
+#endif
+#ifndef GPA_COL_WANT9
+#define GPA_COL_WANT9 4   // 512-point columns in stacks (lean kernels): 64 frames 2580 -> 2830 Mpix/s; a single image (LAT) keeps 1 (879 against 862)
+#endif
+    const int want = LG >= 12 ? GPA_COL_WANT : (LG == 11 ? GPA_COL_WANT11 : (LG == 10 ? GPA_COL_WANT10 : (LG == 9 && !LAT ? GPA_COL_WANT9 : 1)));
     return c < want ? c : want;
   }
   static constexpr int CC = cols();   // packed column PAIRS (complex transforms) per workgroup
@@ -897,7 +906,7 @@ __global__ void phi_commit_kernel(int* flags) {
 
 // columns: Z -> DCT-II along axis 0, divide by eigenvalues, DCT-III along axis 0 (in place)
 template <class T, int LG, bool RHO, bool LAT = false>
-__global__ __launch_bounds__((ColGeom<T, LG>::THREADS)) void colsolve_kernel(T* __restrict__ Z, int n1,
+__global__ __launch_bounds__((ColGeom<T, LG, LAT>::THREADS)) void colsolve_kernel(T* __restrict__ Z, int n1,
                                                                           const cpx<T>* __restrict__ twtab,
                                                                           const cpx<T>* __restrict__ wspec,
                                                                           const T* __restrict__ ha,
@@ -916,7 +925,7 @@ __global__ __launch_bounds__((ColGeom<T, LG>::THREADS)) void colsolve_kernel(T* 
     part_norm += pb * PART_N;
     part_rho += pb * PART_N;
   }
-  using G = ColGeom<T, LG>;
+  using G = ColGeom<T, LG, LAT>;
   using F = typename G::F;
   using D = typename G::D;
   constexpr int E = F::E;
@@ -946,7 +955,7 @@ __global__ __launch_bounds__((ColGeom<T, LG>::THREADS)) void colsolve_kernel(T* 
 #pragma unroll
     for (int n = 0; n < NT; ++n) x[n][i] = q.v[n];
   }
-  __shared__ double shn[ColGeom<T, LG>::THREADS];
+  __shared__ double shn[ColGeom<T, LG, LAT>::THREADS];
   // (short transforms: the solve's tables too)
   typename D::SolveTables stb;
   T hbv[NT][2];
@@ -1924,24 +1933,29 @@ template <class T, int LG>
 hipError_t run_colsolve(const Impl* w, int compat, hipStream_t s, const double* part_norm = nullptr, int nnorm = 0,
                         int it = 0, double eps = 0.0, double* part_rho = nullptr, int* nrho = nullptr,
                         const void* zin = nullptr) {
-  using G = ColGeom<T, LG>;
-  if constexpr (!G::FITS) return hipErrorInvalidValue;
+  if constexpr (!ColGeom<T, LG>::FITS) return hipErrorInvalidValue;
   else {
     if (!part_rho) return hipErrorInvalidValue;   // (the only caller is the fused iteration)
     const bool lat = unwrap_latency_tuned(w, LG);
-    auto kern = colsolve_kernel<T, LG, true, false>;
-    if constexpr (LG <= GPA_UNWRAP_LAT_MAXLG) { if (lat) kern = colsolve_kernel<T, LG, true, true>; }
-    static unsigned lds_set[2] = {0, 0};   // one flag word per instantiation
-    hipError_t e = set_dynamic_lds_once(reinterpret_cast<const void*>(kern), (int)G::LDS_BYTES, lds_set[lat ? 1 : 0]);
-    if (e != hipSuccess) return e;
-    const int npairs = w->n1 / 2, grid = (npairs + G::CC - 1) / G::CC;
-    if (nrho) *nrho = grid;
-    GPA_PROF("colsolve_kernel", s);
-    kern<<<dim3(grid, 1, w->nprob), G::THREADS, G::LDS_BYTES, s>>>((T*)w->z, w->n1, (const cpx<T>*)w->tw0, (const cpx<T>*)w->wk0s,
-                                                 (const T*)w->ha0[compat], (const T*)w->ham0[compat],
-                                                 (const T*)w->hb1[compat], w->flags, part_norm, nnorm, it, eps, w->scal,
-                                                 part_rho, (const T*)zin, (size_t)w->n0 * w->n1);
-    return hipGetLastError();
+    // (the latency-tuned instantiation has its own tile geometry: narrower column tiles for one 512^2 image)
+    auto launch = [&](auto latc) -> hipError_t {
+      constexpr bool LATC = decltype(latc)::value;
+      using G = ColGeom<T, LG, LATC>;
+      auto kern = colsolve_kernel<T, LG, true, LATC>;
+      static unsigned lds_set = 0;   // one flag word per instantiation of this lambda
+      hipError_t e = set_dynamic_lds_once(reinterpret_cast<const void*>(kern), (int)G::LDS_BYTES, lds_set);
+      if (e != hipSuccess) return e;
+      const int npairs = w->n1 / 2, grid = (npairs + G::CC - 1) / G::CC;
+      if (nrho) *nrho = grid;
+      GPA_PROF("colsolve_kernel", s);
+      kern<<<dim3(grid, 1, w->nprob), G::THREADS, G::LDS_BYTES, s>>>((T*)w->z, w->n1, (const cpx<T>*)w->tw0, (const cpx<T>*)w->wk0s,
+                                                   (const T*)w->ha0[compat], (const T*)w->ham0[compat],
+                                                   (const T*)w->hb1[compat], w->flags, part_norm, nnorm, it, eps, w->scal,
+                                                   part_rho, (const T*)zin, (size_t)w->n0 * w->n1);
+      return hipGetLastError();
+    };
+    if constexpr (LG <= GPA_UNWRAP_LAT_MAXLG) { if (lat) return launch(std::true_type{}); }
+    return launch(std::false_type{});
   }
 }
 template <class T, int LG>
