@@ -61,3 +61,51 @@ def test_product_never_imports_oracle():
                 src = open(os.path.join(dirpath, f)).read()
                 assert not re.search(r'^\s*(from|import)\s+oracle\b', src, flags=re.M), f
                 assert 'gpa_oracle' not in src, f
+
+
+def test_device_buffer_selects_its_device_first(monkeypatch):
+    """hipMalloc / hipMemcpy act on the calling thread's current device, so a DeviceBuffer of a plan on
+    GPU n must select GPU n before every runtime call -- also from a fresh thread (the upload / download workers of
+    the stack call), whose current device is 0.  Checked against a recording stand-in for the HIP runtime (the test
+    boxes have one GPU)."""
+    import ctypes as C
+    import threading
+    _ensure_built()
+    _lib.load()
+    calls = []
+
+    class FakeHip:
+        def hipSetDevice(self, d):
+            calls.append(('set', threading.get_ident(), d.value))
+            return 0
+
+        def hipMalloc(self, pp, n):
+            calls.append(('malloc', threading.get_ident(), n.value))
+            C.cast(pp, C.POINTER(C.c_void_p))[0] = 0x1000
+            return 0
+
+        def hipMemcpy(self, dst, src, n, kind):
+            calls.append(('memcpy', threading.get_ident(), kind))
+            return 0
+
+        def hipFree(self, p):
+            calls.append(('free', threading.get_ident(), p.value))
+            return 0
+
+    monkeypatch.setattr(_lib.DeviceBuffer, '_hip', FakeHip())
+    buf = _lib.DeviceBuffer(64, device=3)
+    assert [c[0] for c in calls] == ['set', 'malloc'] and calls[0][2] == 3
+
+    def worker():
+        buf.upload(np.zeros(8))
+        buf.download((8,), np.float64)
+        buf.download_into(np.zeros(8))
+    t = threading.Thread(target=worker)
+    t.start()
+    t.join()
+    buf.free()
+    ops = [c[0] for c in calls[2:]]
+    assert ops == ['set', 'memcpy', 'set', 'memcpy', 'set', 'memcpy', 'set', 'free']
+    assert all(c[2] == 3 for c in calls if c[0] == 'set')
+    # the worker thread made its own selections
+    assert {c[1] for c in calls[2:8]} != {calls[0][1]}
