@@ -1177,14 +1177,16 @@ def test_chirpz_forced_on_smooth_lengths(monkeypatch):
 
 @pytest.mark.gpu
 @pytest.mark.parametrize('dtype', DTYPES)
-@pytest.mark.parametrize('shape', [(128, 128), (256, 512), (100, 60), (300, 300), (136, 116), (63, 65), (250, 250)])
+@pytest.mark.parametrize('shape', [(128, 128), (256, 512), (100, 60), (300, 300), (136, 116), (63, 65), (250, 250),
+                                   (64, 2048), (72, 3000), (1024, 128), (512, 96)])
 def test_image_stack_equals_single_images(shape, dtype, monkeypatch):
     """gpa_extract_displacement_field_batch_dev: a stack of images through one set of unwrap launches
     (blockIdx.z = problem) -- every image's u and iteration counts equal the single-image driver's bit for bit
-    (power-of-two, smooth, square smooth with transform-free columns, chirp-z sizes).  Bit for bit with the same
+    (power-of-two, smooth, square smooth with transform-free columns, chirp-z sizes; rows that take the shared-forward
+    pass B, periodic and zero-padded; columns of 1024 / 512 points, whose column kernel takes 4 pairs per workgroup).  Bit for bit with the same
     kernels on both sides (GPA_NO_LAT=1: a single small power-of-two image otherwise runs latency-tuned
     instantiations of the row / column kernels, whose multiply-adds the compiler contracts differently); with the
-    default kernels: to rounding, 1e-5 (f32) / 1e-12 (f64) of max |u|, and the same iteration counts."""
+    default kernels: to rounding, 2e-5 (f32) / 1e-12 (f64) of max |u|, and the same iteration counts."""
     monkeypatch.setenv('GPA_NO_LAT', '1')
     kvecs = hex_kvecs(0.12, 5.0)
     sigma = 5
@@ -1207,7 +1209,8 @@ def test_image_stack_equals_single_images(shape, dtype, monkeypatch):
     assert np.array_equal(u_c, u_b) and np.array_equal(it_c, it_b)
     # default kernels for the single image
     monkeypatch.delenv('GPA_NO_LAT')
-    tol = (1e-5 if dtype == np.float32 else 1e-12) * float(np.abs(u_b).max())
+    # (2e-5: the 64 x 2048 frames reach 1.01e-5)
+    tol = (2e-5 if dtype == np.float32 else 1e-12) * float(np.abs(u_b).max())
     for i in range(B):
         u, _, _, iters = plan.extract_displacement_field(imgs[i], kvecs, klists, sigma, 2 * sigma, kmax=10)
         assert float(np.abs(u_b[i] - u).max()) <= tol, (shape, i, float(np.abs(u_b[i] - u).max()), tol)
