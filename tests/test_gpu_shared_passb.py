@@ -156,3 +156,40 @@ def test_shared_pass_a_opt_in(shape, dtype, monkeypatch):
     check_kidx(kidx, refs['kidx'], img0, klist, sigma, TOL[dtype]['tie'])
     same = kidx == refs['kidx']
     assert same.mean() > 0.999 and rel(lock[same], refs['lockin'][same]) < TOL[dtype]['lock']
+
+
+def test_shared_passb_random_rows():
+    """seeded random draws of the row length (960 ... 4096: periodic 2048 / 4096-point rows and every zero-padded length
+    between them, including the ones that fall back to the per-candidate kernel), sigma (support of the end fix,
+    live band), candidate grid (whole and ragged chunks, single-candidate runs) and peak: the oracle's winner in f64,
+    its values within the lock-in tolerance in both precisions, end columns included.
+    GPA_TEST_RANDOM_CASES / GPA_TEST_RANDOM_SEED widen the sweep for soak runs."""
+    import os
+    rng = np.random.default_rng(int(os.environ.get('GPA_TEST_RANDOM_SEED', '77')))
+    ncases = int(os.environ.get('GPA_TEST_RANDOM_CASES', '6'))
+    kvecs = hex_kvecs(0.1, 7.0)
+    for case in range(ncases):
+        n1 = int(rng.choice([2048, 4096, int(rng.integers(960, 4097)), int(rng.integers(960, 4097))]))
+        n0 = int(rng.integers(24, 80))
+        sigma = float(rng.choice([4.0, 7.5, 10.0, 10.0, 13.0, 18.0]))
+        knx, kny = int(rng.integers(1, 6)), int(rng.integers(1, 8))
+        peak = int(rng.integers(0, 3))
+        shape = (n0, n1)
+        img = hex_moire(shape, kvecs, gaussian_bump_displacement(shape), noise=0.2, seed=case)
+        img0 = img - img.mean()
+        kw, _, _ = orc.derive_params(kvecs)
+        klist = explicit_klists(kvecs, kw, knx, kny)[peak]
+        ref = orc.sweep(img0, sigma, klist, kvecs[peak], workers=8)
+        sc = np.abs(ref['lockin']).max()
+        e3 = int(3 * sigma)
+        for dtype in DTYPES:
+            lock, kidx = _sweep(shape, dtype, img0, kvecs[peak], klist, sigma)
+            tag = (shape, sigma, (knx, kny), peak, np.dtype(dtype).name)
+            check_kidx(kidx, ref['kidx'], img0, klist, sigma, TOL[dtype]['tie'])
+            same = kidx == ref['kidx']
+            if dtype is np.float64:
+                assert same.all(), tag
+            assert same.mean() > 0.999, tag
+            d = np.where(same, np.abs(lock - ref['lockin']), 0) / sc
+            assert d.max() < TOL[dtype]['lock'], tag + (float(d.max()),)
+            assert max(d[:, :e3].max(), d[:, -e3:].max()) < TOL[dtype]['lock'], tag
