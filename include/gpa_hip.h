@@ -289,6 +289,12 @@ int gpa_gaussian_deconvolve(gpa_plan* plan, const void* data, int dr, double sig
  * geometric_phase_analysis.py:429).  out: n0 x n1 complex.                    */
 int gpa_per_dft(gpa_plan* plan, const void* image, void* out);
 
+/* a9, the whole of moisan2011.per(image, inverse_dft) (the reference imports it at
+ * geometric_phase_analysis.py:9 and calls it at :429 with inverse_dft=False):
+ * inverse_dft == 0: p_out, s_out = DFTs of the periodic and the smooth component (n0 x n1 complex; s_out may be NULL);
+ * inverse_dft != 0: p_out, s_out = the two components themselves (n0 x n1 real), p + s = image.      */
+int gpa_per(gpa_plan* plan, const void* image, int inverse_dft, void* p_out, void* s_out);
+
 /* f-3 -- Bragg-peak candidates, the array work of extract_primary_ks
  * (geometric_phase_analysis.py:427-437): smooth = gaussian_filter(|fftshift(per_dft(image - mean))|,
  * sigma) minus, when dog_sigma > 0, the same with dog_sigma (scipy.ndimage.gaussian_filter

@@ -67,6 +67,7 @@ SIGNATURES = {
     'gpa_fit_plane': (_i, [_vp, _vp, _i, _d, _dp, _ip]),
     'gpa_fit_plane_dev': (_i, [_vp, _vp, _i, _d, _dp, _ip]),
     'gpa_per_dft': (_i, [_vp, _vp, _vp]),
+    'gpa_per': (_i, [_vp, _vp, _i, _vp, _vp]),
     'gpa_gaussian_deconvolve': (_i, [_vp, _vp, _i, _d, _d, _vp]),
     'gpa_find_peaks': (_i, [_vp, _vp, _d, _d, _d, _i, _vp, _vp, _ip, _vp]),
     'gpa_timer_start': (_i, [_vp]),
@@ -344,6 +345,14 @@ class Plan:
         out = np.empty(self.shape, dtype=self.cdtype)
         check(self.lib.gpa_per_dft(self.handle, _ptr(image), _ptr(out)), 'gpa_per_dft')
         return out
+
+    def per(self, image, inverse_dft=True):
+        """moisan2011.per: (p, s) real for inverse_dft=True, their DFTs (p_hat, s_hat) otherwise"""
+        image = self._img(image)
+        dt = self.rdtype if inverse_dft else self.cdtype
+        pc, sc = np.empty(self.shape, dtype=dt), np.empty(self.shape, dtype=dt)
+        check(self.lib.gpa_per(self.handle, _ptr(image), 1 if inverse_dft else 0, _ptr(pc), _ptr(sc)), 'gpa_per')
+        return pc, sc
 
     def unwrap_prediff(self, dx, dy, weight=None, kmax=100, eps=1e-9, axes_compat=True):
         n0, n1 = self.shape

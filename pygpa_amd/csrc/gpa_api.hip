@@ -1755,6 +1755,28 @@ int gpa_per_dft(gpa_plan* p, const void* image, void* out) {
   return GPA_OK;
 }
 
+// moisan2011.per in full: inverse_dft == 0 -> (p_hat, s_hat) complex (s_out may be null), != 0 -> (p, s) real
+int gpa_per(gpa_plan* p, const void* image, int inverse_dft, void* p_out, void* s_out) {
+  if (!p || !image || !p_out || (inverse_dft && !s_out)) return fail(GPA_ERR_ARG, "gpa_per: null argument");
+  HIP_TRY(hipSetDevice(p->device));
+  const size_t npx = (size_t)p->n0 * p->n1;
+  HIP_TRY(hipMemcpyAsync(p->d_image, image, npx * p->rsz, hipMemcpyHostToDevice, p->stream));
+  TRY(per_dft_staged(p));   // p_hat in d_lockin, u_hat still in Tbuf
+  if (!inverse_dft) {
+    HIP_TRY(hipMemcpyAsync(p_out, p->d_lockin, npx * p->csz, hipMemcpyDeviceToHost, p->stream));
+    if (s_out) {
+      HIP_TRY(per_smooth_hat(p->dtype, p->Tbuf, p->d_lockin, npx, p->stream));
+      HIP_TRY(hipMemcpyAsync(s_out, p->Tbuf, npx * p->csz, hipMemcpyDeviceToHost, p->stream));
+    }
+  } else {
+    HIP_TRY(per_components(p->dtype, p->bx0, p->bx1, p->d_lockin, p->d_image, p->d_wnorm, p->d_dudx, p->stream));
+    HIP_TRY(hipMemcpyAsync(p_out, p->d_wnorm, npx * p->rsz, hipMemcpyDeviceToHost, p->stream));
+    HIP_TRY(hipMemcpyAsync(s_out, p->d_dudx, npx * p->rsz, hipMemcpyDeviceToHost, p->stream));
+  }
+  HIP_TRY(hipStreamSynchronize(p->stream));
+  return GPA_OK;
+}
+
 // ---- f-3 -------------------------------------------------------------------------
 // scipy.ndimage._filters._gaussian_kernel1d (order 0): exp(-x^2 / 2 sigma^2) / sum, radius int(4 sigma + 0.5)
 static int gaussian_weights(double sigma, std::vector<double>& w) {

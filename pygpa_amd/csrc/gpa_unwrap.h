@@ -41,6 +41,9 @@ hipError_t dft_rows_inplace(int dtype, const BlueAxis& a, int rows, void* Z, hip
 // border-difference vectors d0 (length n1), d1 (length n0); per_combine forms
 // P^ = U^ - V^ / (2 cos(2 pi q / n0) + 2 cos(2 pi r / n1) - 4) with V^ from D0 = DFT(d0), D1 = DFT(d1)
 hipError_t per_pack(int dtype, const void* image, int n0, int n1, void* Z, void* d0, void* d1, hipStream_t s);
+hipError_t per_smooth_hat(int dtype, void* Uhat_inout, const void* Phat, size_t n, hipStream_t s);
+hipError_t per_components(int dtype, const BlueAxis& a0, const BlueAxis& a1, void* Phat_destroyed, const void* image,
+                          void* p_out, void* s_out, hipStream_t s);
 hipError_t per_combine(int dtype, const void* Uhat, const void* D0, const void* D1, int n0, int n1, void* out,
                        hipStream_t s);
 

@@ -2856,6 +2856,53 @@ hipError_t per_pack(int dtype, const void* image, int n0, int n1, void* Z, void*
     per_pack_kernel<double><<<grid, 256, 0, s>>>((const double*)image, n0, n1, (cpx<double>*)Z, (cpx<double>*)d0, (cpx<double>*)d1);
   return hipGetLastError();
 }
+// the rest of moisan2011.per: s_hat = u_hat - p_hat, and the two components in real space through ONE more DFT:
+// p = Re(ifft2(p_hat)) = Re(fft2(conj(p_hat))) / (n0 n1), s = u - p
+namespace {
+template <class T>
+__global__ __launch_bounds__(256) void per_diff_kernel(cpx<T>* __restrict__ Uh, const cpx<T>* __restrict__ Ph, size_t n) {
+  const size_t i = (size_t)blockIdx.x * 256 + threadIdx.x;
+  if (i < n) Uh[i] = {Uh[i].x - Ph[i].x, Uh[i].y - Ph[i].y};
+}
+template <class T>
+__global__ __launch_bounds__(256) void per_conj_kernel(cpx<T>* __restrict__ Z, size_t n) {
+  const size_t i = (size_t)blockIdx.x * 256 + threadIdx.x;
+  if (i < n) Z[i].y = -Z[i].y;
+}
+template <class T>
+__global__ __launch_bounds__(256) void per_real_kernel(const cpx<T>* __restrict__ Z, const T* __restrict__ u, double scale,
+                                                       T* __restrict__ pout, T* __restrict__ sout, size_t n) {
+  const size_t i = (size_t)blockIdx.x * 256 + threadIdx.x;
+  if (i < n) {
+    const T pv = (T)((double)Z[i].x * scale);
+    pout[i] = pv;
+    sout[i] = u[i] - pv;
+  }
+}
+}  // namespace
+hipError_t per_smooth_hat(int dtype, void* Uhat_inout, const void* Phat, size_t n, hipStream_t s) {
+  const unsigned grid = (unsigned)((n + 255) / 256);
+  if (dtype == 0) per_diff_kernel<float><<<grid, 256, 0, s>>>((cpx<float>*)Uhat_inout, (const cpx<float>*)Phat, n);
+  else per_diff_kernel<double><<<grid, 256, 0, s>>>((cpx<double>*)Uhat_inout, (const cpx<double>*)Phat, n);
+  return hipGetLastError();
+}
+hipError_t per_components(int dtype, const BlueAxis& a0, const BlueAxis& a1, void* Phat_destroyed, const void* image,
+                          void* p_out, void* s_out, hipStream_t s) {
+  const size_t n = (size_t)a0.n * a1.n;
+  const unsigned grid = (unsigned)((n + 255) / 256);
+  if (dtype == 0) per_conj_kernel<float><<<grid, 256, 0, s>>>((cpx<float>*)Phat_destroyed, n);
+  else per_conj_kernel<double><<<grid, 256, 0, s>>>((cpx<double>*)Phat_destroyed, n);
+  hipError_t e = hipGetLastError();
+  if (e != hipSuccess) return e;
+  e = dft2_inplace(dtype, a0, a1, Phat_destroyed, s);
+  if (e != hipSuccess) return e;
+  const double scale = 1.0 / (double)n;
+  if (dtype == 0)
+    per_real_kernel<float><<<grid, 256, 0, s>>>((const cpx<float>*)Phat_destroyed, (const float*)image, scale, (float*)p_out, (float*)s_out, n);
+  else
+    per_real_kernel<double><<<grid, 256, 0, s>>>((const cpx<double>*)Phat_destroyed, (const double*)image, scale, (double*)p_out, (double*)s_out, n);
+  return hipGetLastError();
+}
 hipError_t per_combine(int dtype, const void* Uhat, const void* D0, const void* D1, int n0, int n1, void* out,
                        hipStream_t s) {
   dim3 grid((n1 + 255) / 256, n0);

@@ -323,15 +323,14 @@ def calc_diff_from_isotropic(ani_ks, symmetry=6):
 
 
 # --------------------------------------------------------------------------- a9
-def per(image, inverse_dft=False, dtype=None):
-    """DFT of the periodic component of Moisan's periodic + smooth decomposition -- the
-    only thing the reference takes from the third-party moisan2011.per, at
-    geometric_phase_analysis.py:429 (`pd, _ = per(image, inverse_dft=False)`).
-    Returns (p_hat, None); the smooth part is not computed.  Parity of this function is
-    unpinned (moisan2011 is not part of the reference checkout): restated from Moisan (2011)."""
-    if inverse_dft:
-        raise NotImplementedError('only inverse_dft=False (the reference call site) is provided')
-    return _plan(image, 1, dtype).per_dft(image), None
+def per(image, inverse_dft=True, dtype=None):
+    """Moisan's periodic + smooth decomposition, the third-party `moisan2011.per` the reference imports
+    (geometric_phase_analysis.py:9; its one call is `pd, _ = per(image, inverse_dft=False)` at :429).
+    inverse_dft=True (moisan2011's default): (p, s), the periodic and the smooth component, p + s = image;
+    inverse_dft=False: their DFTs (p_hat, s_hat).  Computed on the device (`gpa_per`).  Parity of this function is
+    unpinned (moisan2011 is not part of the reference checkout): restated from Moisan (2011) and held to the
+    decomposition's defining properties (tests/per_properties.py)."""
+    return _plan(image, 1, dtype).per(image, inverse_dft=bool(inverse_dft))
 
 
 # --------------------------------------------------------------------------- a8

@@ -86,8 +86,13 @@ def test_per_dft_defining_properties(shape, dtype, tol):
     u = (rng.standard_normal(shape) + ramp).astype(dtype)
     plan = _lib.Plan(shape, 1, dtype)
     phat = plan.per_dft(u)
+    # the components themselves from the device (gpa_per, inverse_dft=True) through the same checks: their DFT is taken
+    # here, on the host, only to feed the checker
+    pc, sc = plan.per(u, inverse_dft=True)
     plan.close()
     check_decomposition(u.astype(np.float64), phat, tol, rng)
+    assert np.abs(pc.astype(np.float64) + sc - u).max() < 4 * tol * np.abs(u).max()
+    check_decomposition(u.astype(np.float64), np.fft.fft2(pc.astype(np.float64)), 4 * tol, rng)
 
 
 @pytest.mark.parametrize('dtype,tol', [(np.float64, 1e-10), (np.float32, 3e-4)])

@@ -261,7 +261,7 @@ def test_a9_per_dft(shape, dtype):
     rng = np.random.default_rng(5)
     img = rng.normal(size=shape) + np.linspace(0, 3, shape[1])[None, :] + np.linspace(-1, 0, shape[0])[:, None] ** 2
     img = img - img.mean()          # as the call site does (geometric_phase_analysis.py:428)
-    phat, _ = GPA.per(img, inverse_dft=False, dtype=dtype)
+    phat, shat = GPA.per(img, inverse_dft=False, dtype=dtype)
     ref, sref = orc.per(img, inverse_dft=False)
     # f32: a chirp-z DFT carries ~1e-5 of the largest bin as error (f64: 1e-11)
     tol = 1e-10 if dtype is np.float64 else 5e-5   # the oracle's own 2cos+2cos-4 cancels to ~1e-11 near DC
@@ -269,6 +269,14 @@ def test_a9_per_dft(shape, dtype):
     # known answers: mean(p) = mean(image) (= 0 here); p + s = image
     assert abs(phat[0, 0]) < tol * np.abs(ref).max()
     assert rel(phat + sref, np.fft.fft2(img)) < tol
+    # the other three outputs of moisan2011.per: s_hat, and (inverse_dft=True, its default) the components themselves
+    assert np.abs(shat - sref).max() < tol * np.abs(ref).max()
+    pc, sc = GPA.per(img, dtype=dtype)
+    pref, sref_c = orc.per(img, inverse_dft=True)
+    assert pc.dtype == np.dtype(dtype) and sc.dtype == np.dtype(dtype)
+    sc_tol = (1e-10 if dtype is np.float64 else 2e-5) * np.abs(img).max()
+    assert np.abs(pc - pref).max() < sc_tol and np.abs(sc - sref_c).max() < sc_tol
+    assert np.abs(pc + sc - img).max() < (1e-12 if dtype is np.float64 else 1e-6) * np.abs(img).max()
 
 
 def test_tiled_path_device_vs_oracle():
