@@ -300,7 +300,8 @@ def kernel_table(n, L0, L1, P, K, Bx, s, iters, kern, stage, res_s):
         ['tables+mean', 'passA_kernel', 'passB_kernel', 'reconstruct_setup', 'unwrap(serial, both components)'], stage)}
 
     # ---- roofline of the dominant kernel (largest single launch): pass B, VALU-issue bound
-    dom = max((k for k in table if table[k]['launches'] <= 2), key=lambda k: table[k]['total_ms'], default='passB_shared_kernel')
+    dom = max((k for k in table if table[k]['launches'] <= 2 and (models.get(k, {}).get('bytes') or models.get(k, {}).get('flops'))),
+              key=lambda k: table[k]['total_ms'], default='passB_shared_kernel')
     drow, dm, dc = table[dom], models.get(dom, {}), counters.get(dom, {})
     dsec = drow['total_ms'] * 1e-3 / max(drow['working_launches'], 1)
     src = {'clock': 'HIP events on the launch stream around every launch of the kernel, averaged over 3 profiled steps of '
@@ -539,6 +540,18 @@ def multi_gpu(args, world, rank, local_rank):
                        'unwrap_iters': iters_rep, 'backend': args.backend, 'collectives': coll,
                        'stage_ms_per_image_rank0': stages},
         }
+        # roofline of the tile stage's dominant kernel (pass B on one window), measured on this rank AFTER the timed
+        # region on a whole-image call of the window's shape: the same kernel instantiation on the same rows
+        try:
+            torch.cuda.synchronize(dev)
+            m = measure(W, knx, kny, np_dt, args.kmax, 5, 1, profile=True)
+            rf = dict(m['roofline'])
+            rf['note'] = ('dominant kernel of the tile stage, from a %d^2 whole-image call on rank 0 after the timed region '
+                          '(same kernel, same window shape); ' % W) + str(rf.get('note', ''))
+            out['roofline'] = rf
+        except Exception as e:   # the scaling line must not die of its diagnostics
+            out['roofline'] = None
+            out['roofline_error'] = '%s: %s' % (type(e).__name__, e)
         print(json.dumps(out), flush=True)
     pipe.close()
     dist.barrier()

@@ -483,6 +483,7 @@ def test_bench_gpus_flag_spawns_ranks():
     assert out['config']['image'] == [512, 256] and out['config']['tiles'] >= 2
     assert out['config']['schedule'] == 'stream' and 'gather' in out['config']['collectives']
     assert set(out['config']['stage_ms_per_image_rank0']) == {'load', 'mean', 'tiles', 'gather', 'unwrap_wait', 'handover'}
+    assert out['roofline'] is not None and out['roofline']['achieved'] > 0 and 'tile stage' in out['roofline']['note'], out.get('roofline_error')
     # the unpipelined schedule stays available
     r = subprocess.run(cmd + ['--schedule', 'step'], env=env, stdout=subprocess.PIPE, stderr=subprocess.PIPE, timeout=900)
     assert r.returncode == 0, r.stderr.decode()[-2000:]
