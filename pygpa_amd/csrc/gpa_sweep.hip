@@ -160,7 +160,19 @@ struct PassAGeom {
   using F = WgFFT<T, LG>;
   // columns per workgroup: as many as fit 1024 threads and the 160 KiB LDS
   static constexpr int cols() {
-    int c = 16;
+#ifndef GPA_PA_C10
+#define GPA_PA_C10 8
+#endif
+#ifndef GPA_PA_C9
+#define GPA_PA_C9 16
+#endif
+#ifndef GPA_PA_C11
+#define GPA_PA_C11 4
+#endif
+#ifndef GPA_PA_C12
+#define GPA_PA_C12 16
+#endif
+    int c = LG == 10 ? GPA_PA_C10 : (LG == 9 ? GPA_PA_C9 : (LG == 11 ? GPA_PA_C11 : (LG == 12 ? GPA_PA_C12 : 16)));
     while (c > 1 && (c * F::TPF > 1024 || (size_t)c * (F::LDS_ELEMS + 32) * sizeof(cpx<T>) > 160 * 1024)) c /= 2;
     return c;
   }
