@@ -11,7 +11,14 @@ enum { PB_ALL = 0, PB_SELECT = 1, PB_GATED = 2, PB_PHASES = 3, PB_PART = 4 };
 template <class T, int LG>
 struct PassBGeom {
   using F = WgFFT<T, LG>;
-  static constexpr int NF = F::TPF >= 256 ? 1 : 256 / F::TPF;   // rows per workgroup
+  // rows per workgroup: up to 1024-point rows ONE wavefront per workgroup (a row of 64 threads, or two of 32: every
+  // exchange stays inside the wavefront and small images get more, smaller workgroups: 1024^2 131 -> 117 us);
+  // longer rows fill 256 threads
+#ifndef GPA_PB_THREADS_SMALL
+#define GPA_PB_THREADS_SMALL 64
+#endif
+  static constexpr int WGT = LG <= 10 ? GPA_PB_THREADS_SMALL : 256;
+  static constexpr int NF = F::TPF >= WGT ? 1 : WGT / F::TPF;   // rows per workgroup
   static constexpr int RS = F::LDS_ELEMS + (NF > 1 ? (F::TPF < 32 ? F::TPF : 0) : 0);
   static constexpr int THREADS = NF * F::TPF;
   static constexpr size_t LDS_BYTES = (size_t)NF * RS * sizeof(cpx<T>);
