@@ -615,14 +615,20 @@ constexpr int unwrap_elems(int lg, size_t real_size) {
 #ifndef GPA_ROW_TWLDS
 #define GPA_ROW_TWLDS 1   // 16-element three-pass row transforms: pass-1 base twiddles from a small LDS table (12 VGPRs less in f32)
 #endif
-template <class T, int LG>
+template <class T, int LG, bool LAT = false>
 struct RowGeom {
   using F = WgFFT<T, LG, unwrap_elems(LG, sizeof(T))>;
   static constexpr bool TWLDS = GPA_ROW_TWLDS && F::E == 16 && F::P == 3;
   using TW = typename std::conditional<TWLDS, typename F::TwiddlesP1Lds, typename F::Twiddles>::type;
   static constexpr int T1N = TWLDS ? F::P1_SETS * 6 : 1;
   using D = WgDCT<T, LG, unwrap_elems(LG, sizeof(T))>;
-  static constexpr int NF = F::TPF >= 256 ? 1 : 256 / F::TPF;   // row PAIRS per workgroup
+  // threads per workgroup: 256; the latency-tuned kernels of ONE image with rows up to 512 pixels take 128 (twice the
+  // workgroups on a GPU that such an image leaves mostly empty: 512^2 893 -> 935 Mpix/s; stacks prefer 256)
+#ifndef GPA_ROW_THREADS_LAT
+#define GPA_ROW_THREADS_LAT 128
+#endif
+  static constexpr int WGT = (LAT && LG <= 9) ? GPA_ROW_THREADS_LAT : 256;
+  static constexpr int NF = F::TPF >= WGT ? 1 : WGT / F::TPF;   // row PAIRS per workgroup
   static constexpr int RS = F::LDS_ELEMS + (NF > 1 ? (F::TPF < 32 ? F::TPF : 0) : 0);
   static constexpr int THREADS = NF * F::TPF;
   static constexpr size_t LDS_BYTES = (size_t)NF * RS * sizeof(cpx<T>);
@@ -682,7 +688,7 @@ struct ColGeom {
 #endif
 // LAT: the latency-tuned variant (one image per call, axes up to 1024) -- same arithmetic, same results
 template <class T, int LG, bool LAT = false>
-__global__ __launch_bounds__((RowGeom<T, LG>::THREADS), (sizeof(T) == 8 ? GPA_F64_WAVES : GPA_DCTF_WAVES)) void rowdct_fused_kernel(
+__global__ __launch_bounds__((RowGeom<T, LG, LAT>::THREADS), (sizeof(T) == 8 ? GPA_F64_WAVES : GPA_DCTF_WAVES)) void rowdct_fused_kernel(
     T* __restrict__ r, const T* __restrict__ q, int n0, const cpx<T>* __restrict__ twtab,
     const cpx<T>* __restrict__ wk, int* flags, const double* part_pq, int npq, double* part_norm,
     double* scal, int it, int ring, int init, size_t pimg) {
@@ -700,12 +706,12 @@ __global__ __launch_bounds__((RowGeom<T, LG>::THREADS), (sizeof(T) == 8 ? GPA_F6
   //   it == 0: r (spatial, from the set-up) -> R, in place;
   //   it  > 0: R -= alpha DCT-II_rows(q)    (linearity; phase_unwrap.py:345), partial ||r||^2 from R.
   // So the update reads q and R and writes R: three arrays instead of r, q in and r, Z out.
-  using G = RowGeom<T, LG>;
+  using G = RowGeom<T, LG, LAT>;
   using F = typename G::F;
   using D = typename G::D;
   constexpr int TPF = F::TPF, N = F::L, E = F::E;
   extern __shared__ __attribute__((aligned(16))) char smem[];
-  __shared__ double sh[RowGeom<T, LG>::THREADS];
+  __shared__ double sh[RowGeom<T, LG, LAT>::THREADS];
   // init (first iteration of a solve on prepared residuals): part_pq / npq are the producer's partial norms of r0
   // EARLY (short transforms): every input of an update -- flags, q, the kept spectrum, w_k, partial sums, rho -- is
   // requested before anything waits, so the kernel pays one memory round trip instead of five in a row
@@ -1339,7 +1345,7 @@ template <class T, int LG, bool LAT = false>
 #ifndef GPA_F64_WAVES
 #define GPA_F64_WAVES 2   // f64 row kernels: 2 waves/SIMD (256 VGPRs) beat 1 wave with AGPR spill-over
 #endif
-__global__ __launch_bounds__((RowGeom<T, LG>::THREADS), ((GPA_IDCTP_COND && !LAT) ? 4 : (sizeof(T) == 8 ? GPA_F64_WAVES : 1))) void rowidct_p_kernel(
+__global__ __launch_bounds__((RowGeom<T, LG, LAT>::THREADS), ((GPA_IDCTP_COND && !LAT) ? 4 : (sizeof(T) == 8 ? GPA_F64_WAVES : 1))) void rowidct_p_kernel(
     const T* __restrict__ Z, const T* __restrict__ pin, T* __restrict__ pout, int n0,
     const cpx<T>* __restrict__ twtab, const cpx<T>* __restrict__ wk, const int* flags, const double* part_rho,
     int nrho, double* scal, int it, size_t pimg) {
@@ -1356,7 +1362,7 @@ __global__ __launch_bounds__((RowGeom<T, LG>::THREADS), ((GPA_IDCTP_COND && !LAT
   // spectrum, the previous search direction, the tables and the partial sums together -- a 512-point kernel is
   // little more than its chain of dependent round trips), then the early exit, then the arithmetic.
   const int stop = flags[1];
-  using G = RowGeom<T, LG>;
+  using G = RowGeom<T, LG, LAT>;
   using F = typename G::F;
   using D = typename G::D;
   constexpr int TPF = F::TPF, N = F::L, E = F::E;
@@ -1365,7 +1371,7 @@ __global__ __launch_bounds__((RowGeom<T, LG>::THREADS), ((GPA_IDCTP_COND && !LAT
   constexpr bool EARLY = LAT && (E == 8 || GPA_EARLY16);
   if (!EARLY && stop) return;
   extern __shared__ __attribute__((aligned(16))) char smem[];
-  __shared__ double sh[RowGeom<T, LG>::THREADS];
+  __shared__ double sh[RowGeom<T, LG, LAT>::THREADS];
   const int tid = threadIdx.x % TPF, f = threadIdx.x / TPF;
   cpx<T>* lds = reinterpret_cast<cpx<T>*>(smem) + f * G::RS;
   const int pr = blockIdx.x * G::NF + f;
@@ -1432,7 +1438,7 @@ __global__ __launch_bounds__((RowGeom<T, LG>::THREADS), ((GPA_IDCTP_COND && !LAT
 #define GPA_ROWPQ_MAXLG 9
 template <class T, int LG>
 struct RowPqGeom {
-  using G = RowGeom<T, LG>;
+  using G = RowGeom<T, LG, true>;   // (this kernel only serves one small image: the latency-tuned geometry)
   static constexpr int NFH = G::NF + 2;                       // transform groups: own pairs + one halo pair each side
   static constexpr int THREADS = NFH * G::F::TPF;
   static constexpr size_t FFT_BYTES = (size_t)NFH * G::RS * sizeof(cpx<T>);
@@ -1457,7 +1463,7 @@ __global__ __launch_bounds__((RowPqGeom<T, LG>::THREADS)) void rowidct_pq_kernel
     part_rho += pb * PART_N;
     part_pq += pb * PART_N;
   }
-  using G = RowGeom<T, LG>;
+  using G = RowGeom<T, LG, true>;
   using H = RowPqGeom<T, LG>;
   using F = typename G::F;
   using D = typename G::D;
@@ -1961,42 +1967,50 @@ hipError_t run_colsolve(const Impl* w, int compat, hipStream_t s, const double* 
 template <class T, int LG>
 hipError_t run_rowdct_fused(const Impl* w, const void* q, int ring, const double* part_pq, int npq,
                             double* part_norm, int it, int* nnorm, int init, hipStream_t s) {
-  using G = RowGeom<T, LG>;
-  if constexpr (!G::FITS) return hipErrorInvalidValue;
+  if constexpr (!RowGeom<T, LG>::FITS) return hipErrorInvalidValue;
   else {
     const bool lat = unwrap_latency_tuned(w, LG);
-    auto kern = rowdct_fused_kernel<T, LG, false>;
-    if constexpr (LG <= GPA_UNWRAP_LAT_MAXLG) { if (lat) kern = rowdct_fused_kernel<T, LG, true>; }
-    static unsigned lds_set[2] = {0, 0};   // one flag word per instantiation
-    hipError_t e = set_dynamic_lds_once(reinterpret_cast<const void*>(kern), (int)G::LDS_BYTES, lds_set[lat ? 1 : 0]);
-    if (e != hipSuccess) return e;
-    const int npairs = w->n0 / 2, grid = (npairs + G::NF - 1) / G::NF;
-    *nnorm = grid;
-    GPA_PROF("rowdct_fused_kernel", s);
-    kern<<<dim3(grid, 1, w->nprob), G::THREADS, G::LDS_BYTES, s>>>((T*)w->r, (const T*)q, w->n0, (const cpx<T>*)w->tw1,
-                                                 (const cpx<T>*)w->wk1, w->flags, part_pq, npq, part_norm, w->scal, it,
-                                                 ring, init, (size_t)w->n0 * w->n1);
-    return hipGetLastError();
+    auto launch = [&](auto latc) -> hipError_t {
+      constexpr bool LATC = decltype(latc)::value;
+      using G = RowGeom<T, LG, LATC>;
+      auto kern = rowdct_fused_kernel<T, LG, LATC>;
+      static unsigned lds_set = 0;   // one flag word per instantiation of this lambda
+      hipError_t e = set_dynamic_lds_once(reinterpret_cast<const void*>(kern), (int)G::LDS_BYTES, lds_set);
+      if (e != hipSuccess) return e;
+      const int npairs = w->n0 / 2, grid = (npairs + G::NF - 1) / G::NF;
+      *nnorm = grid;
+      GPA_PROF("rowdct_fused_kernel", s);
+      kern<<<dim3(grid, 1, w->nprob), G::THREADS, G::LDS_BYTES, s>>>((T*)w->r, (const T*)q, w->n0, (const cpx<T>*)w->tw1,
+                                                   (const cpx<T>*)w->wk1, w->flags, part_pq, npq, part_norm, w->scal, it,
+                                                   ring, init, (size_t)w->n0 * w->n1);
+      return hipGetLastError();
+    };
+    if constexpr (LG <= GPA_UNWRAP_LAT_MAXLG) { if (lat) return launch(std::true_type{}); }
+    return launch(std::false_type{});
   }
 }
 
 template <class T, int LG>
 hipError_t run_rowidct_p(const Impl* w, const void* pin, void* pout, const double* part_rho, int nrho, int it,
                          hipStream_t s) {
-  using G = RowGeom<T, LG>;
-  if constexpr (!G::FITS) return hipErrorInvalidValue;
+  if constexpr (!RowGeom<T, LG>::FITS) return hipErrorInvalidValue;
   else {
     const bool lat = unwrap_latency_tuned(w, LG);
-    auto kern = rowidct_p_kernel<T, LG, false>;
-    if constexpr (LG <= GPA_UNWRAP_LAT_MAXLG) { if (lat) kern = rowidct_p_kernel<T, LG, true>; }
-    static unsigned lds_set[2] = {0, 0};   // one flag word per instantiation
-    hipError_t e = set_dynamic_lds_once(reinterpret_cast<const void*>(kern), (int)G::LDS_BYTES, lds_set[lat ? 1 : 0]);
-    if (e != hipSuccess) return e;
-    const int npairs = w->n0 / 2, grid = (npairs + G::NF - 1) / G::NF;
-    GPA_PROF("rowidct_p_kernel", s);
-    kern<<<dim3(grid, 1, w->nprob), G::THREADS, G::LDS_BYTES, s>>>((const T*)w->z, (const T*)pin, (T*)pout, w->n0, (const cpx<T>*)w->tw1,
-                                                 (const cpx<T>*)w->wk1, w->flags, part_rho, nrho, w->scal, it, (size_t)w->n0 * w->n1);
-    return hipGetLastError();
+    auto launch = [&](auto latc) -> hipError_t {
+      constexpr bool LATC = decltype(latc)::value;
+      using G = RowGeom<T, LG, LATC>;
+      auto kern = rowidct_p_kernel<T, LG, LATC>;
+      static unsigned lds_set = 0;
+      hipError_t e = set_dynamic_lds_once(reinterpret_cast<const void*>(kern), (int)G::LDS_BYTES, lds_set);
+      if (e != hipSuccess) return e;
+      const int npairs = w->n0 / 2, grid = (npairs + G::NF - 1) / G::NF;
+      GPA_PROF("rowidct_p_kernel", s);
+      kern<<<dim3(grid, 1, w->nprob), G::THREADS, G::LDS_BYTES, s>>>((const T*)w->z, (const T*)pin, (T*)pout, w->n0, (const cpx<T>*)w->tw1,
+                                                   (const cpx<T>*)w->wk1, w->flags, part_rho, nrho, w->scal, it, (size_t)w->n0 * w->n1);
+      return hipGetLastError();
+    };
+    if constexpr (LG <= GPA_UNWRAP_LAT_MAXLG) { if (lat) return launch(std::true_type{}); }
+    return launch(std::false_type{});
   }
 }
 // the row kernel and the stencil in one launch (one image, rows up to 512 pixels); *npq_out = partial sums of <p, q>
@@ -2005,7 +2019,7 @@ hipError_t run_rowidct_pq(const Impl* w, const void* pin, void* pout, const void
                           int nrho, double* part_pq, int* npq_out, int it, hipStream_t s) {
   if constexpr (LG > GPA_ROWPQ_MAXLG || unwrap_elems(LG, sizeof(T)) != 8) return hipErrorInvalidValue;
   else {
-    using G = RowGeom<T, LG>;
+    using G = RowGeom<T, LG, true>;
     using H = RowPqGeom<T, LG>;
     auto kern = rowidct_pq_kernel<T, LG>;
     static unsigned lds_set = 0;
