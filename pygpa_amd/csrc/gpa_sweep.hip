@@ -140,7 +140,9 @@ __global__ void mean_final_kernel(const double* partial, int nparts, size_t coun
 // image, mean_out: nimg values); every image's sum is formed exactly as by a single-image call
 hipError_t launch_mean(int dtype, const void* image, size_t count, double* scratch,
                        void* mean_out, hipStream_t s, int nimg) {
-  const int nparts = 1024;
+  // one workgroup per 4096 pixels, 32 ... 1024 of them (a 512^2 image was reduced by 1024 workgroups, most of them idle)
+  const size_t want = count / 4096;
+  const int nparts = want > 1024 ? 1024 : (want < 32 ? 32 : (int)want);
   GPA_PROF("mean_kernels", s);
   if (dtype == 0) {
     mean_partial_kernel<float><<<dim3(nparts, nimg), 256, 0, s>>>((const float*)image, count, scratch);
