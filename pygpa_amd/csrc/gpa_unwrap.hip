@@ -627,7 +627,10 @@ struct RowGeom {
 #ifndef GPA_ROW_THREADS_LAT
 #define GPA_ROW_THREADS_LAT 128
 #endif
-  static constexpr int WGT = (LAT && LG <= 9) ? GPA_ROW_THREADS_LAT : 256;
+#ifndef GPA_ROW_THREADS
+#define GPA_ROW_THREADS 256
+#endif
+  static constexpr int WGT = (LAT && LG <= 9) ? GPA_ROW_THREADS_LAT : GPA_ROW_THREADS;
   static constexpr int NF = F::TPF >= WGT ? 1 : WGT / F::TPF;   // row PAIRS per workgroup
   static constexpr int RS = F::LDS_ELEMS + (NF > 1 ? (F::TPF < 32 ? F::TPF : 0) : 0);
   static constexpr int THREADS = NF * F::TPF;
