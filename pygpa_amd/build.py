@@ -17,7 +17,7 @@ HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(HERE, 'csrc')
 BUILD = os.path.join(CSRC, '_build')
 LIB = os.path.join(HERE, 'libgpa_hip.so')
-SOURCES = ['gpa_sweep.hip', 'gpa_passb_shared.hip', 'gpa_sweep_ext.hip', 'gpa_reconstruct.hip', 'gpa_unwrap.hip', 'gpa_warp.hip', 'gpa_peaks.hip', 'gpa_api.hip']
+SOURCES = ['gpa_sweep.hip', 'gpa_passb_shared.hip', 'gpa_sweep_ext.hip', 'gpa_reconstruct.hip', 'gpa_unwrap.hip', 'gpa_dft2.hip', 'gpa_warp.hip', 'gpa_peaks.hip', 'gpa_api.hip']
 ARCH = 'gfx950'
 FLAGS = ['-O3', '-std=c++17', '-fPIC', '--offload-arch=' + ARCH, '-fno-gpu-rdc',
          '-Wno-unused-result', '-Wno-unused-value', '-ffp-contract=fast', '-fno-slp-vectorize']

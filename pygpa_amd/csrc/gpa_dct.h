@@ -237,4 +237,19 @@ struct WgBluestein {
 #endif
 };
 
+// workgroup geometry of the natural-layout (Bluestein) kernels: the generic-size DCT kernels of gpa_unwrap.hip and the
+// plain DFTs of gpa_dft2.hip
+template <class T, int LG>
+struct GenGeom {
+  using F = WgFFT<T, LG>;
+  static constexpr int NF = F::TPF >= 256 ? 1 : 256 / F::TPF;   // transforms per workgroup
+  static constexpr int RS = F::LDS_ELEMS + (NF > 1 ? (F::TPF < 32 ? F::TPF : 0) : 0);
+  static constexpr int THREADS = NF * F::TPF;
+  static constexpr size_t LDS_BYTES = (size_t)NF * RS * sizeof(cpx<T>);
+  static constexpr bool FITS = LDS_BYTES <= 160 * 1024;
+};
+
+// every transform length of the 16-element engine: 64 ... 16384
+#define GPA_FOR_LG(X) X(6) X(7) X(8) X(9) X(10) X(11) X(12) X(13) X(14)
+
 }  // namespace gpa

@@ -9,7 +9,7 @@ mkdir -p pygpa_amd/variants pygpa_amd/csrc/_build
 F="-O3 -std=c++17 -fPIC --offload-arch=gfx950 -fno-gpu-rdc -Wno-unused-result -Wno-unused-value -ffp-contract=fast -fno-slp-vectorize"
 hipcc $F "$@" -c pygpa_amd/csrc/$tu.hip -o pygpa_amd/csrc/_build/${tu}_$name.o
 objs=""
-for t in gpa_sweep gpa_passb_shared gpa_sweep_ext gpa_reconstruct gpa_unwrap gpa_warp gpa_peaks gpa_api; do
+for t in gpa_sweep gpa_passb_shared gpa_sweep_ext gpa_reconstruct gpa_unwrap gpa_dft2 gpa_warp gpa_peaks gpa_api; do
   if [ $t = $tu ]; then objs="$objs pygpa_amd/csrc/_build/${tu}_$name.o"; else objs="$objs pygpa_amd/csrc/_build/$t.o"; fi
 done
 hipcc -shared -fPIC --offload-arch=gfx950 -fno-gpu-rdc -o pygpa_amd/variants/libgpa_$name.so $objs
