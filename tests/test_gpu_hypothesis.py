@@ -7,7 +7,7 @@ direction psi; what the reference asserts -- every extracted k within 1.5 / size
 on latticegen's conventions."""
 import numpy as np
 import pytest
-from hypothesis import given, settings, HealthCheck
+from hypothesis import example, given, settings, HealthCheck
 import hypothesis.strategies as st
 
 import pygpa_amd.geometric_phase_analysis as GPA
@@ -17,7 +17,8 @@ from pygpa_amd.synthetic import hex_kvecs, hex_moire
 from per_properties import check_decomposition
 
 pytestmark = pytest.mark.gpu
-COMMON = dict(deadline=None, suppress_health_check=[HealthCheck.too_slow, HealthCheck.data_too_large])
+# derandomize: the same draws on every run (a GPU suite that fails one run in ten teaches nothing)
+COMMON = dict(deadline=None, derandomize=True, suppress_health_check=[HealthCheck.too_slow, HealthCheck.data_too_large])
 
 
 @settings(max_examples=20, **COMMON)
@@ -65,14 +66,27 @@ def strained_ks(r_k, theta, psi, kappa):
 @settings(max_examples=40, **COMMON)
 @given(theta=st.floats(0., 60.), psi=st.floats(-90., 90.), kappa=st.floats(1. + 1e-7, 2, exclude_min=True),
        r_k=st.floats(0.03, 0.24))
+@example(r_k=0.03, theta=1.625, psi=1.75, kappa=1.65625)   # found by hypothesis: the reference's algorithm itself misses here
 def test_extract_primary_ks(r_k, theta, psi, kappa):
-    """reference tests/test_geometric_phase_analysis.py:44-58"""
+    """reference tests/test_geometric_phase_analysis.py:44-58, as a PARITY property: on every drawn lattice the device
+    finds exactly the k-vectors the oracle's restatement of the reference driver finds (grid frequencies: equal), and
+    wherever those satisfy the reference's accuracy bar -- every extracted k within 1.5 / size of a generating k -- so
+    do the device's.  (The bar itself is a property of the reference's peak finder, not of this build: with this
+    build's lattice generator it fails at the corner of the parameter box, r_k = 0.03 strained by kappa = 1.66, where
+    the smallest k is 2.3 bins from DC -- for the oracle exactly as for the device.)"""
+    from oracle import gpa_oracle as orc
     size = 128
     ori_ks = strained_ks(r_k, theta, psi, kappa)
     original = hex_moire((size, size), ori_ks[:3])
     ext_ks, _ = GPA.extract_primary_ks(original, DoG=False)
+    ref_ks, _ = orc.extract_primary_ks(original, DoG=False)
+    assert ext_ks.shape == ref_ks.shape and np.abs(ext_ks - ref_ks).max() < 1e-12
     abs_diffs = np.linalg.norm((ext_ks[None] - ori_ks[:, None]), axis=-1).min(axis=0)
-    assert np.all(abs_diffs < 1.5 / size)
+    ref_diffs = np.linalg.norm((ref_ks[None] - ori_ks[:, None]), axis=-1).min(axis=0)
+    if np.all(ref_diffs < 1.5 / size):
+        assert np.all(abs_diffs < 1.5 / size)
+    if r_k >= 0.06:      # away from that corner the bar holds outright
+        assert np.all(abs_diffs < 1.5 / size)
 
 
 @pytest.mark.parametrize('dtype,tol', [(np.float64, 1e-11), (np.float32, 3e-6)])
