@@ -560,7 +560,7 @@ static int ensure_filters(gpa_plan* p, double sigma) {
         if (passB_shared_supports(p->dtype, sa, E)) {
           const int Epad = (E + 15) & ~15;
           if (sa.L != cur.L && p->tw1s_L != sa.L) {
-            if (!p->tw1s) TRY(dmalloc(p, &p->tw1s, (size_t)4096 * p->csz));
+            if (!p->tw1s) TRY(dmalloc(p, &p->tw1s, (size_t)8192 * p->csz));   // (the longest row transform of the shared kernel)
             TRY(upload_twiddles(p, p->tw1s, sa.L));
             p->tw1s_L = sa.L;
           }

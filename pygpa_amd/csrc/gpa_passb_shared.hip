@@ -179,10 +179,13 @@ struct PassBSGeom {
 // same products, the spectrum shifted by s blocks), so only registers 0 .. NBL-1 of the shared spectrum and of the
 // candidate's Gaussian are live: fewer registers (the next candidate's Gaussian is requested before this
 // candidate's stores), and the zeros of the other registers prune the first inverse pass at compile time.
+#ifndef GPA_PBS_L13_WAVES
+#define GPA_PBS_L13_WAVES 3   // 8192-point rows: one workgroup of 8 wavefronts per CU whatever the register budget
+#endif
 template <class T, int LG, bool PADDED, int EE, int NBL>
 __global__ __launch_bounds__((PassBSGeom<T, LG, EE>::THREADS),
                              (EE == 8 ? (sizeof(T) == 8 ? GPA_PBS_E8_F64_WAVES : GPA_PBS_E8_WAVES)
-                                      : (sizeof(T) == 8 ? GPA_PBS_F64_WAVES : (PADDED ? GPA_PBS_PAD_WAVES : GPA_PBS_F32_WAVES)))) void passB_shared_kernel(
+                                      : (sizeof(T) == 8 ? GPA_PBS_F64_WAVES : (LG >= 13 ? GPA_PBS_L13_WAVES : (PADDED ? GPA_PBS_PAD_WAVES : GPA_PBS_F32_WAVES))))) void passB_shared_kernel(
     const cpx<T>* __restrict__ Tin, int n0, int n1, const T* __restrict__ Gb, const cpx<T>* __restrict__ twtab,
     const int* __restrict__ planeof, const int* __restrict__ desc, const cpx<T>* __restrict__ pre_g,
     const cpx<T>* __restrict__ psi, const T* __restrict__ gtab, const cpx<T>* __restrict__ dx,
@@ -938,7 +941,7 @@ hipError_t launch_shared_tables(int dtype, const Axis& a1, const double* wys, co
   if (a1.lg == LG && elems == EE)                                                                                       \
     return dtype == 0 ? run_shared_tables<float, LG, EE>(a1, wys, kr, shifts, taps, Etab, E, Epad, B, K, nbl, st, s)    \
                       : run_shared_tables<double, LG, EE>(a1, wys, kr, shifts, taps, Etab, E, Epad, B, K, nbl, st, s);
-  CASE_T(11, 16) CASE_T(12, 16) CASE_T8(12)
+  CASE_T(11, 16) CASE_T(12, 16) CASE_T(13, 16) CASE_T8(12)
 #undef CASE_T
   return hipErrorInvalidValue;
 }
@@ -983,7 +986,8 @@ int passB_shared_elems(int dtype, const Axis& a1) {
 bool passB_shared_supports(int dtype, const Axis& a1, int E) {
   // 1024-point rows (one wavefront per row: the whole matrix pass and both end fixes on it) measured slower than
   // the per-candidate kernel (1024^2, 3 x 16: 189 against 131 us): from 2048 points on
-  if (a1.lg < 11 || a1.lg > 12) return false;
+  // (8192-point rows: f32 only -- four passes, one workgroup of 512 threads per CU)
+  if (a1.lg < 11 || a1.lg > (dtype == 0 ? 13 : 12)) return false;
   const int tpf = a1.L / 16;
   const int Epad = (E + 15) & ~15;
   if (E < 1 || Epad > tpf || 2 * E > a1.n) return false;
@@ -1014,7 +1018,7 @@ hipError_t launch_passB_shared(int dtype, const Axis& a1, int n0, const void* Tb
   if (a1.lg == LG && elems == EE && nbl == NBL) return dtype == 0 ? CALL_S(float, LG, EE, NBL) : CALL_S(double, LG, EE, NBL);
 #define CASE_F32(LG, EE, NBL) \
   if (a1.lg == LG && elems == EE && nbl == NBL && dtype == 0) return CALL_S(float, LG, EE, NBL);
-  CASE_F32(11, 16, 6) CASE_F32(12, 16, 6)
+  CASE_F32(11, 16, 6) CASE_F32(12, 16, 6) CASE_F32(13, 16, 6) CASE_F32(13, 16, 8) CASE_F32(13, 16, 16)
   CASE_S(11, 16, 8) CASE_S(12, 16, 8) CASE_S(11, 16, 16) CASE_S(12, 16, 16)
 #ifdef GPA_PBS_BUILD_E8
   CASE_S(12, 8, 8)

@@ -33,12 +33,15 @@ def _sweep(shape, dtype, img0, kref, klist, sigma):
 
 @pytest.mark.parametrize('dtype', DTYPES)
 @pytest.mark.parametrize('shape,grid', [((96, 4096), (4, 4)), ((80, 2048), (4, 2)), ((72, 4096), (3, 7)), ((2304, 1024), (4, 4)),
-                                        ((96, 3000), (4, 4)), ((80, 1500), (4, 2)), ((60, 1000), (3, 3)), ((2100, 700), (4, 4))])
+                                        ((96, 3000), (4, 4)), ((80, 1500), (4, 2)), ((60, 1000), (3, 3)), ((2100, 700), (4, 4)),
+                                        ((40, 8192), (4, 4)), ((36, 6000), (4, 2)), ((32, 8100), (3, 3))])
 def test_shared_passb_vs_oracle_and_end_columns(shape, grid, dtype, monkeypatch):
-    """4096-, 2048- and (tall) 1024-wide sweeps (the last on the per-candidate kernel), and rows that are not powers of two (zero-padded to >= n + E: the end
+    """8192- (f32: four-pass transforms; f64 stays on the per-candidate kernel), 4096-, 2048- and (tall) 1024-wide sweeps (the last on the per-candidate kernel), and rows that are not powers of two (zero-padded to >= n + E: the end
     fix then supplies EVERY wrapped pair): winner index identical to the oracle in f64 (up to exact amplitude
     ties in f32), values within the lock-in tolerance everywhere AND in the first / last 3 sigma columns on their own;
     grids of 4, 2 and 7 candidates per x-plane exercise whole and ragged chunks of the matrix pass."""
+    if dtype is np.float64 and shape[1] > 4096 and shape[1] & (shape[1] - 1):
+        pytest.skip('f64 plans take axes that are not powers of two up to 4096 points')
     img0, kref, klist, sigma = _case(shape, *grid)
     ref = orc.sweep(img0, sigma, klist, kref, workers=8)
     lock, kidx = _sweep(shape, dtype, img0, kref, klist, sigma)
