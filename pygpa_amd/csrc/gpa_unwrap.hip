@@ -1344,7 +1344,7 @@ __global__ __launch_bounds__(1024) void colsolve_tri_kernel(const T* __restrict_
 // 49 -> 43 us.  Other lengths would spill under that cap (2048: 13 -> 16 us) and keep the default.
 template <class T, int LG, bool LAT = false>
 #ifndef GPA_IDCTP_COND
-#define GPA_IDCTP_COND (sizeof(T) == 4 && LG == 12)
+#define GPA_IDCTP_COND (sizeof(T) == 4 && (LG == 12 || LG == 13))   // (8192 points: 28 B of scratch buy a second workgroup per CU, -12 %)
 #endif
 #ifndef GPA_F64_WAVES
 #define GPA_F64_WAVES 2   // f64 row kernels: 2 waves/SIMD (256 VGPRs) beat 1 wave with AGPR spill-over
