@@ -2039,7 +2039,9 @@ hipError_t dispatch_colsolve(const Impl* w, int compat, hipStream_t s, const dou
   // (profiles/r02_colsolve_tri.txt): f64 1.54 ms per step against 2.0 for the DCT kernel (whose f64 transforms
   // spill), f32 82 us per launch against 68 -- the f32 DCT kernel is the faster one.  So: f64 by default,
   // GPA_COLSOLVE=tri / fft forces one or the other (tests compare the two).
-  const bool want_tri = w->col_mode ? w->col_mode == 1 : w->dtype != 0;
+  // (f32 columns of 8192 points: the transform kernel is down to two column pairs -- 16-byte row segments -- per
+  //  workgroup there and loses to the recursion: 453 against ~330 us per launch)
+  const bool want_tri = w->col_mode ? w->col_mode == 1 : (w->dtype != 0 || w->lg0 >= 13);
   if (w->tritab && part_rho && want_tri && w->n0 / w->triR <= 1024)
     return w->dtype == 0 ? dispatch_colsolve_tri<float>(w, compat, s, part_norm, nnorm, it, eps, part_rho, nrho, zin)
                          : dispatch_colsolve_tri<double>(w, compat, s, part_norm, nnorm, it, eps, part_rho, nrho, zin);
