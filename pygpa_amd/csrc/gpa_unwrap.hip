@@ -1073,6 +1073,7 @@ template <class T> struct TriRows { static constexpr int value = sizeof(T) == 4 
 // quarter of them f64), not by anything the chip shares.  GPA_TRI_SMALL = largest n0 that does (diagnostic).
 inline int tri_rows(size_t real_size, int n0) {
   const int base = real_size == 4 ? 8 : 16;
+  if (real_size == 4 && n0 > 8192) return 2 * base;   // (1024 threads hold at most 1024 chunks)
   static const int small = getenv("GPA_TRI_SMALL") ? atoi(getenv("GPA_TRI_SMALL")) : 640;
   return n0 <= small ? base / 2 : base;
 }
@@ -2008,6 +2009,11 @@ hipError_t dispatch_colsolve_tri(const Impl* w, int compat, hipStream_t s, const
   constexpr int VEC = 16 / sizeof(T), RB = TriRows<T>::value;
   const int Q = w->triQ, S = w->triS;
 #define GPA_TRI_CALL(QQ, RR) run_colsolve_tri<T, VEC, QQ, RR>(w, S, compat, s, part_norm, nnorm, it, eps, part_rho, nrho, zin)
+  if constexpr (sizeof(T) == 4) {
+    // f32 columns of 16384 points: 16 rows per thread (1024 chunks), Q = 1 -- spills, and still ahead of a transform
+    // kernel that is down to ONE column pair (8-byte row segments) per workgroup there
+    if (w->triR == 2 * RB) return GPA_TRI_CALL(1, 2 * RB);
+  }
   if (w->triR == RB) {
     switch (Q) {
       case 4: return GPA_TRI_CALL(4, RB);
