@@ -8,9 +8,11 @@ k-vectors (explicit 4x4 lists), sigma = 10, weighted DCT-PCG unwrap with kmax = 
 one whole extract_displacement_field call through the C ABI of libgpa_hip.so on an image already
 resident in HBM (mean, 48 lock-ins, select, phases/weights, per-pixel least squares, two unwraps)
 PLUS the download of u to page-locked host memory ("D2H of u included"), which runs on
-the plan's copy stream while the kernels of the next step execute.  Extra keys: `resident_only` (the
-same loop with u left in HBM), `f64` (the reference's own precision), `kernels` (per-kernel HIP-event
-times with the roofline that bounds each), `cpu_baseline`.
+the plan's copy stream while the kernels of the next step execute.  The PCG of the timed step stops by the
+reference's test alone (kmax or ||r|| < 1e-9 ||r0||: 10 + 10 iterations on this image); the library's f32 default,
+which also stops at a residual floor of its own, is the extra key `early_stop`.  Other extra keys: `resident_only`
+(the same loop with u left in HBM), `f64` (the reference's own precision), `host_call` (host arrays in and out: H2D
+and D2H inside the call), `kernels` (per-kernel HIP-event times with the roofline that bounds each), `cpu_baseline`.
 
 N > 1 (one rank per GPU; `--gpus N` without a launcher starts N fresh child processes through
 torch.distributed.run before this process touches a GPU): the tile pipeline of BASELINE configs[3-4],
@@ -209,14 +211,31 @@ class SingleGPU:
             b.free()
 
 
+def csrc_sha256():
+    """hash of the kernel sources the counters were measured on (the GPU box has no .git: the tree itself is the
+    witness).  tools/make_counters.py stamps it into profiles/counters.json."""
+    import glob
+    import hashlib
+    h = hashlib.sha256()
+    for f in sorted(glob.glob(os.path.join(ROOT, 'pygpa_amd', 'csrc', '*.h*'))):
+        h.update(os.path.basename(f).encode())
+        h.update(open(f, 'rb').read())
+    return h.hexdigest()[:16]
+
+
 def load_counters():
     """per-launch PMC figures of the committed rocprofv3 passes (profiles/counters.json): HBM bytes
-    (FETCH_SIZE doubled per the microarch guide + WRITE_SIZE) and VALU wave-instructions per kernel"""
+    (FETCH_SIZE doubled per the microarch guide + WRITE_SIZE) and VALU wave-instructions per kernel.
+    REFUSED (empty: traffic null) when the file was measured on other kernel sources than this tree's."""
     path = os.path.join(ROOT, 'profiles', 'counters.json')
     try:
-        return json.load(open(path))
+        c = json.load(open(path))
     except Exception:
         return {}
+    if c.get('_meta', {}).get('csrc_sha256') != csrc_sha256():
+        return {'_stale': 'profiles/counters.json (commit %s) was measured on other kernel sources than this tree (csrc hash %s '
+                          'vs %s): not used' % (c.get('_meta', {}).get('commit', '?'), c.get('_meta', {}).get('csrc_sha256', 'none'),
+                                                csrc_sha256())}
 
 
 def measure(n, knx, kny, np_dt, kmax, steps, warmup, depth=1, profile=True):
@@ -230,30 +249,35 @@ def measure(n, knx, kny, np_dt, kmax, steps, warmup, depth=1, profile=True):
     klists = np.stack(explicit_klists(kvecs, kw, knx, kny))
     Bx = sum(len(np.unique(kl[:, 0])) for kl in klists)
     s = np.dtype(np_dt).itemsize
+    from pygpa_amd import _lib
     g = SingleGPU(n, P, K, np_dt, kvecs, klists, sigma, kmax, depth=depth)
-    dt = g.timed(steps, warmup, download=True)
-    iters = g.plan.last_iters()
-    dt_res = g.timed(steps, 1, download=False)
-    res = {'n': n, 'P': P, 'K': K, 'Bx': int(Bx), 'sigma': sigma, 'kvecs': kvecs, 'klists': klists, 'iters': list(iters),
-           'value': round(n * n * steps / dt / 1e6, 2), 'ms_per_step': round(dt / steps * 1e3, 4),
-           'resident_value': round(n * n * steps / dt_res / 1e6, 2), 'resident_ms': round(dt_res / steps * 1e3, 4),
-           'depth': g.depth}
+    # The timed step runs the REFERENCE's stopping test alone (phase_unwrap.py:348: k >= kmax or ||r|| < 1e-9 ||r0||): the
+    # library's f32 default adds a residual floor of its own (4e-6 ||r0||) that ends the benchmark image's
+    # solves after 9 + 8 iterations where the reference runs 10 + 10 -- switched off here (F32_EPS_FLOOR=0, read per
+    # solve), and reported beside the headline as `early_stop`.
     if np_dt is np.float32:
-        # the reference's iteration count: the f32 residual floor (a stopping test of THIS build) switched
-        # off, i.e. kmax iterations per component as the reference runs -- read per solve, so the same plans serve
-        os.environ['GPA_F32_EPS_FLOOR'] = '0'
-        try:
-            dtf = g.timed(steps, 1, download=True)
-            res['forced_iters'] = {'value': round(n * n * steps / dtf / 1e6, 2), 'ms_per_step': round(dtf / steps * 1e3, 4),
-                                   'unwrap_iters': list(g.plan.last_iters()),
-                                   'note': 'GPA_F32_EPS_FLOOR=0: the PCG runs the reference\'s iteration count (no f32 '
-                                           'residual floor); same step, D2H of u included'}
-        finally:
-            del os.environ['GPA_F32_EPS_FLOOR']
-    if profile:
-        stage, kern = g.profile()
-        L0, L1 = g.plan.fft_len(0), g.plan.fft_len(1)
-        res.update(kernel_table(n, L0, L1, P, K, Bx, s, iters, kern, stage, dt_res / steps))
+        _lib.set_option('F32_EPS_FLOOR', '0')
+    try:
+        dt = g.timed(steps, warmup, download=True)
+        iters = g.plan.last_iters()
+        dt_res = g.timed(steps, 1, download=False)
+        res = {'n': n, 'P': P, 'K': K, 'Bx': int(Bx), 'sigma': sigma, 'kvecs': kvecs, 'klists': klists, 'iters': list(iters),
+               'value': round(n * n * steps / dt / 1e6, 2), 'ms_per_step': round(dt / steps * 1e3, 4),
+               'resident_value': round(n * n * steps / dt_res / 1e6, 2), 'resident_ms': round(dt_res / steps * 1e3, 4),
+               'depth': g.depth}
+        if profile:
+            stage, kern = g.profile()
+            L0, L1 = g.plan.fft_len(0), g.plan.fft_len(1)
+            res.update(kernel_table(n, L0, L1, P, K, Bx, s, iters, kern, stage, dt_res / steps))
+    finally:
+        if np_dt is np.float32:
+            _lib.set_option('F32_EPS_FLOOR', None)
+    if np_dt is np.float32:
+        dte = g.timed(steps, 1, download=True)
+        res['early_stop'] = {'value': round(n * n * steps / dte / 1e6, 2), 'ms_per_step': round(dte / steps * 1e3, 4),
+                             'unwrap_iters': list(g.plan.last_iters()),
+                             'note': 'the library default in f32: solves also stop at the f32 residual floor 4e-6 ||r0|| (not in the '
+                                     'reference); same step, D2H of u included.  NOT the headline.'}
     g.close()
     return res
 
@@ -264,6 +288,7 @@ def kernel_table(n, L0, L1, P, K, Bx, s, iters, kern, stage, res_s):
     out = {}
     models = kernel_models(n, n, L0, L1, P, K, Bx, s, iters)
     counters = load_counters()
+    stale = counters.pop('_stale', None)
     meta = counters.get('_meta', {})
     same_cfg = meta.get('config', {'n': 4096, 'K': 16, 'dtype': 'f32'}) == {'n': n, 'K': K, 'dtype': 'f32' if s == 4 else 'f64'}
     if not same_cfg:
@@ -292,7 +317,7 @@ def kernel_table(n, L0, L1, P, K, Bx, s, iters, kern, stage, res_s):
         if c.get('valu_insts'):
             row['valu_issue_frac'] = round(c['valu_insts'] / per / VALU_ISSUE_PEAK, 4)
         fr = {'hbm': row.get('hbm_frac', (m['bytes'] / per / 1e9 / HBM_PEAK_GBS) if m.get('bytes') else 0.0),
-              'valu': row.get('valu_issue_frac', (m['flops'] / per / 1e12 / VALU_PEAK_TFLOPS) if m.get('flops') else 0.0)}
+              'valu': row.get('valu_issue_frac', ((m.get('executed_flops') or m['flops']) / per / 1e12 / VALU_PEAK_TFLOPS) if m.get('flops') else 0.0)}
         row['bound'] = max(fr, key=fr.get)
         table[name] = row
     out['kernels'] = table
@@ -308,19 +333,24 @@ def kernel_table(n, L0, L1, P, K, Bx, s, iters, kern, stage, res_s):
                     'this run (adds ~3 us per launch to what rocprofv3 --kernel-trace reports: profiles/)',
            'counters': ('profiles/counters.json measured on commit %s, %s (%s)' % (meta.get('commit', '?'), meta.get('date', '?'),
                                                                                 meta.get('how', 'rocprofv3 --pmc passes')))
-                       if counters else 'none for this configuration (traffic: null)'}
+                       if counters else (stale or 'none for this configuration (traffic: null)')}
     if drow['bound'] == 'valu' and dm.get('flops'):
-        out['roofline'] = {'bound': 'valu', 'kernel': dom, 'achieved': round(dm['flops'] / dsec / 1e12, 2),
-                           'peak': VALU_PEAK_TFLOPS, 'unit': 'TFLOP/s', 'frac': round(dm['flops'] / dsec / 1e12 / VALU_PEAK_TFLOPS, 4),
+        ex = dm.get('executed_flops', dm['flops'])
+        out['roofline'] = {'bound': 'valu', 'kernel': dom, 'achieved': round(ex / dsec / 1e12, 2),
+                           'peak': VALU_PEAK_TFLOPS, 'unit': 'TFLOP/s', 'frac': round(ex / dsec / 1e12 / VALU_PEAK_TFLOPS, 4),
                            'traffic': dc.get('hbm_bytes'), 'kernel_ms': round(dsec * 1e3, 4),
-                           'nominal_flops_per_launch': dm['flops'],
-                           'executed_flops_per_launch': dm.get('executed_flops', dm['flops']),
-                           'executed_TFLOPs': round(dm.get('executed_flops', dm['flops']) / dsec / 1e12, 2),
+                           'executed_flops_per_launch': ex,
+                           'algorithmic_flops_per_launch': dm['flops'],
+                           'algorithmic_TFLOPs': round(dm['flops'] / dsec / 1e12, 2),
+                           'algorithmic_frac': round(dm['flops'] / dsec / 1e12 / VALU_PEAK_TFLOPS, 4),
+                           'algorithmic_bytes_per_launch': dm.get('bytes'),
                            'valu_issue_frac': drow.get('valu_issue_frac'), 'source': src,
-                           'note': 'vector pipe (the transforms) beside a small MFMA contraction (the end fix). achieved = ALGORITHMIC flops '
-                                   '(the reference algorithm: a forward and an inverse transform per candidate and row, nominal 5 L log2 L each) '
-                                   'over the HIP-event time; the shared-forward kernel executes fewer (executed_*: one forward transform per '
-                                   'x-plane row); valu_issue_frac = counted VALU wave-instructions / (1024 SIMDs x 1 per 2 cycles x 2.4 GHz)'}
+                           'note': 'frac = EXECUTED flops over peak: the transforms the kernel performs (one forward per x-plane row, one '
+                                   'inverse per candidate, nominal 5 L log2 L each) over the HIP-event time, against the f32 vector peak; '
+                                   'algorithmic_* credits the reference algorithm\'s work instead (a forward AND an inverse transform per '
+                                   'candidate and row), which the shared-forward kernel does not perform; valu_issue_frac = counted VALU '
+                                   'wave-instructions / (1024 SIMDs x 1 per 2 cycles x 2.4 GHz); a small MFMA contraction (the row-end fix) '
+                                   'runs beside the vector pipe'}
     else:
         ach = (dc.get('hbm_bytes') or dm.get('bytes') or 0) / dsec / 1e9
         out['roofline'] = {'bound': 'hbm', 'kernel': dom, 'achieved': round(ach, 1), 'peak': HBM_PEAK_GBS, 'unit': 'GB/s',
@@ -356,12 +386,13 @@ def single_gpu(args):
                                'unwrap kmax=%d, image resident in HBM, u downloaded to pinned host memory inside the '
                                'step (BASELINE.json configs[2])' % (n, n, K, sigma, args.kmax),
                    'image': [n, n], 'peaks': P, 'kvectors_per_peak': K, 'x_planes': m['Bx'],
-                   'unwrap_iters': m['iters'], 'd2h_of_u': 'included, overlapped with the next step (copy stream)',
+                   'unwrap_iters': m['iters'], 'stopping_test': "the reference's alone (kmax or ||r|| < 1e-9 ||r0||); the library's f32 residual floor is off",
+                   'd2h_of_u': 'included, overlapped with the next step (copy stream)',
                    'images_in_flight': m['depth']},
         'resident_only': {'value': m['resident_value'], 'ms_per_step': m['resident_ms'],
                           'note': 'same loop with u left in HBM (round-1 definition)'},
     }
-    for key in ('forced_iters', 'kernels', 'stage_ms', 'roofline', 'whole_step'):
+    for key in ('early_stop', 'kernels', 'stage_ms', 'roofline', 'whole_step'):
         if key in m:
             out[key] = m[key]
 
@@ -377,12 +408,52 @@ def single_gpu(args):
                                       'D2H of u included (BASELINE.json configs[1])' % args.kmax,
                           'value': c2['value'], 'unit': 'Mpixels/s', 'ms_per_step': c2['ms_per_step'],
                           'resident_only': c2['resident_value'], 'unwrap_iters': c2['iters'],
-                          'forced_iters': c2.get('forced_iters'), 'roofline': c2['roofline'], 'whole_step': c2['whole_step'],
+                          'early_stop': c2.get('early_stop'), 'roofline': c2['roofline'], 'whole_step': c2['whole_step'],
                           'kernels_ms': {k: v['total_ms'] for k, v in c2['kernels'].items()}}
         out['small_image_stacks'] = small_image_stacks(kvecs, klists, sigma, args.kmax)
+    if not args.no_f64:
+        out['host_call'] = host_call(n, knx, kny, np_dt, args.kmax)
     if not args.no_cpu:
         out['cpu_baseline'] = cpu_baseline(kvecs, sigma, knx, kny, args.kmax, n)
     print(json.dumps(out), flush=True)
+
+
+def host_call(n, knx, kny, np_dt, kmax, reps=5):
+    """SURVEY.md 8(d) "H2D reported separately": the call a user of the reference's NumPy-in / NumPy-out signature makes
+    (geometric_phase_analysis.py:907-932) -- Plan.extract_displacement_field on HOST arrays, H2D of the image and D2H of u
+    inside the timed call -- with pageable arrays and with page-locked ones.  Never `value`."""
+    from pygpa_amd import _lib
+    from pygpa_amd.synthetic import hex_kvecs, explicit_klists, gaussian_bump_displacement, hex_moire
+    kvecs = hex_kvecs(0.1, 7.0)
+    sigma = int(np.ceil(1 / np.linalg.norm(kvecs, axis=1).min()))
+    kw = np.linalg.norm(kvecs, axis=1).mean() / 2.5
+    klists = np.stack(explicit_klists(kvecs, kw, knx, kny))
+    img = hex_moire((n, n), kvecs, gaussian_bump_displacement((n, n)), noise=0.1, seed=100, dtype=np_dt)
+    plan = _lib.Plan((n, n), 3 * knx * kny, np_dt, device=0)
+    out = {}
+    if np_dt is np.float32:
+        _lib.set_option('F32_EPS_FLOOR', '0')
+    try:
+        for kind in ('pageable', 'pinned'):
+            if kind == 'pinned':
+                src, dst = _lib.pinned_empty((n, n), np_dt), _lib.pinned_empty((2, n, n), np_dt)
+                src[...] = img
+            else:
+                src, dst = img, np.empty((2, n, n), np_dt)
+            plan.extract_displacement_field(src, kvecs, klists, sigma, 2 * sigma, kmax=kmax, out=dst)
+            t0 = time.perf_counter()
+            for _ in range(reps):
+                plan.extract_displacement_field(src, kvecs, klists, sigma, 2 * sigma, kmax=kmax, out=dst)
+            dt = (time.perf_counter() - t0) / reps
+            out[kind] = {'value': round(n * n / dt / 1e6, 1), 'ms_per_call': round(dt * 1e3, 3)}
+    finally:
+        if np_dt is np.float32:
+            _lib.set_option('F32_EPS_FLOOR', None)
+    plan.close()
+    out['unit'] = 'Mpixels/s'
+    out['note'] = ('one synchronous host-array call per image: H2D of the image + the step + D2H of u inside the timed call, nothing '
+                   'overlapped between calls (PCIe-inclusive rate; `value` has the image resident in HBM)')
+    return out
 
 
 def small_image_stacks(kvecs, klists, sigma, kmax, sizes=(512, 1024), stack=16, reps=6):
@@ -449,7 +520,10 @@ def multi_gpu(args, world, rank, local_rank):
     else:
         dist.init_process_group(args.backend, rank=rank, world_size=world)
     from pygpa_amd import distributed as D
+    from pygpa_amd import _lib
     from pygpa_amd.synthetic import hex_kvecs, explicit_klists
+    if args.dtype == 'f32':
+        _lib.set_option('F32_EPS_FLOOR', '0')   # the reference's stopping test alone, as in the N = 1 headline
     n = args.size
     knx, kny = (int(v) for v in args.kgrid.split('x')) if args.kgrid else (args.kside, args.kside)
     P, K = 3, knx * kny
@@ -530,6 +604,10 @@ def multi_gpu(args, world, rank, local_rank):
             'ms_per_step': round(dt / args.steps * 1e3, 4),
             'higher_is_better': True, 'scaling': 'weak', 'vs_baseline': None,
             'dtype': args.dtype, 'data': 'synthetic',
+            #  N = 8 runs BASELINE configs[4]'s 16384^2 image: 2 x the pixels per GPU of N = 1, 2, 4
+            'weak_scaling_pixels_per_gpu': shape[0] * shape[1] // world,
+            'weak_scaling_note': None if world != 8 else 'N = 8 is configs[4] (16384^2): 2 x 4096^2 pixels per GPU, twice the per-GPU '
+                                 'work of the N = 1 / 2 / 4 points -- compare Mpixels/s, not a strict weak-scaling efficiency',
             'config': {'workload': '%dx%d synthetic hex moire (%.3g x %d^2 pixels per GPU) tiled into %d halo windows of %d^2 dealt '
                                    'over %d ranks, 3 Bragg peaks x %d k-vectors, sigma=%d; %s (%s); windows resident in HBM'
                                    % (shape[0], shape[1], shape[0] * shape[1] / float(world * n * n), n, len(pipe.tiles), W, world, K,

@@ -47,6 +47,14 @@ typedef struct gpa_plan gpa_plan;
 int gpa_version(void);
 const char* gpa_last_error(void);
 int gpa_device_count(void);
+/* Diagnostic / test switches of the library (no counterpart in the reference).  `name` is one of
+ * the switches documented in INTEGRATION.md ("NO_LAT", "COLSOLVE", "F32_EPS_FLOOR", ..., with or
+ * without the GPA_ prefix), `value` its text value or NULL to clear it.  The switches start from
+ * the environment variables GPA_<NAME> as they were when the library was first used; after that
+ * only this call changes them (the library never reads the environment on a call path).
+ * Switches read at plan creation (NO_SHARED, NO_COMPACT, NO_KSPLIT, NO_MR, MR_FORCE_BLUESTEIN,
+ * USE_GRAPH, SERIAL_UNWRAP, NO_WORKER) apply to plans created afterwards.  Process-wide.        */
+int gpa_set_option(const char* name, const char* value);
 
 /* One plan = one device + one stream + workspace for images of shape (n0, n1)
  * and up to max_batch simultaneous lock-ins (peaks x k-vectors).              */
@@ -201,6 +209,9 @@ int gpa_extract_displacement_field_batch_dev(gpa_plan* plan, const void* images,
                                              int* iters_out);
 /* waits for the plan's stream and returns the 2 B iteration counts of the last batch call (B <= its stack size) */
 int gpa_last_batch_iters(gpa_plan* plan, int B, int* iters_out);
+/* 1 if the batch call above covers the plan's image shape (every shape whose unwrap runs the fused
+ * iteration), 0 if the caller has to loop over gpa_extract_displacement_field_dev instead            */
+int gpa_supports_batch(gpa_plan* plan);
 
 /* tile stage of the multi-GPU path: sweep + phases/weights + per-pixel least squares of
  * extract_displacement_field (:919-926, :234-237) WITHOUT the unwrap; the gradient tiles of all

@@ -24,6 +24,7 @@ SIGNATURES = {
     'gpa_version': (_i, []),
     'gpa_last_error': (C.c_char_p, []),
     'gpa_device_count': (_i, []),
+    'gpa_set_option': (_i, [C.c_char_p, C.c_char_p]),
     'gpa_plan_create': (_vp, [_i, _i, _i, _i, _i]),
     'gpa_plan_destroy': (None, [_vp]),
     'gpa_plan_sync': (_i, [_vp]),
@@ -54,6 +55,7 @@ SIGNATURES = {
     'gpa_last_iters': (_i, [_vp, _vp]),
     'gpa_extract_displacement_field_batch_dev': (_i, [_vp, _vp, _i, _vp, _i, _vp, _i, _d, _i, _i, _vp, _vp]),
     'gpa_last_batch_iters': (_i, [_vp, _i, _vp]),
+    'gpa_supports_batch': (_i, [_vp]),
     'gpa_extract_gradients': (_i, [_vp, _vp, _vp, _i, _vp, _i, _d, _i, _vp, _vp, _vp]),
     'gpa_mean_dev': (_i, [_vp, _vp, _sz, _dp]),
     'gpa_tile_gradients_dev': (_i, [_vp, _vp, _sz, _i, _i, _d, _vp, _i, _vp, _i, _d, _i, _i, _i, _i, _i,
@@ -117,6 +119,30 @@ def last_error():
 def check(code, what):
     if code != 0:
         raise GPAError('%s failed (%d): %s' % (what, code, last_error()))
+
+
+def set_option(name, value):
+    """gpa_set_option: a diagnostic / test switch of the library ('NO_LAT', 'COLSOLVE', 'F32_EPS_FLOOR', ...; the
+    names of INTEGRATION.md).  value None clears it.  The library reads the GPA_<NAME> environment variables once, when
+    it is first used; afterwards only this call changes a switch."""
+    check(load().gpa_set_option(str(name).encode(), None if value is None else str(value).encode()), 'gpa_set_option')
+
+
+class options:
+    """with options(NO_LAT=1, COLSOLVE='tri'): ...  -- switches set for the block and cleared after it"""
+
+    def __init__(self, **kw):
+        self.kw = kw
+
+    def __enter__(self):
+        for k, v in self.kw.items():
+            set_option(k, v)
+        return self
+
+    def __exit__(self, *exc):
+        for k in self.kw:
+            set_option(k, None)
+        return False
 
 
 def _ptr(a):
@@ -545,6 +571,7 @@ class Plan:
         d_img = [DeviceBuffer(chunk * npx * item, self.device) for _ in range(min(2, nchunks))]
         d_u = [DeviceBuffer(2 * chunk * npx * item, self.device) for _ in range(min(2, nchunks))]
         bounds = [(c * chunk, min(B, (c + 1) * chunk)) for c in range(nchunks)]
+        batched = bool(self.lib.gpa_supports_batch(self.handle))   # asked once, not discovered per chunk from an error text
 
         def upload(c):
             a, b = bounds[c]
@@ -563,16 +590,12 @@ class Plan:
                     if c - 2 in dns:
                         dns.pop(c - 2).result()           # its u buffer has been read out
                     a, b = bounds[c]
-                    batched = True
-                    try:
+                    if batched:
                         self.extract_displacement_field_batch_dev(d_img[c % 2].ptr, b - a, kvecs, klists, sigma, mask_border,
                                                                   kmax, d_u[c % 2].ptr, want_iters=False)
-                    except GPAError as err:
+                    else:
                         # shapes without a batched unwrap (sides no fused path covers): the same frames one call each --
                         # the numbers the docstring promises, just without the shared launch chain
-                        if 'no batched unwrap' not in str(err):
-                            raise
-                        batched = False
                         for f in range(b - a):
                             iters[a + f] = self.extract_displacement_field_dev(d_img[c % 2].ptr + f * npx * item, kvecs, klists, sigma,
                                                                                mask_border, kmax, d_u[c % 2].ptr + 2 * f * npx * item)

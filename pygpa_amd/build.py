@@ -17,7 +17,8 @@ HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(HERE, 'csrc')
 BUILD = os.path.join(CSRC, '_build')
 LIB = os.path.join(HERE, 'libgpa_hip.so')
-SOURCES = ['gpa_sweep.hip', 'gpa_passb_shared.hip', 'gpa_sweep_ext.hip', 'gpa_reconstruct.hip', 'gpa_unwrap.hip', 'gpa_dft2.hip', 'gpa_warp.hip', 'gpa_peaks.hip', 'gpa_api.hip']
+SOURCES = ['gpa_sweep.hip', 'gpa_passb_shared.hip', 'gpa_sweep_ext.hip', 'gpa_reconstruct.hip', 'gpa_unwrap.hip', 'gpa_unwrap_rows.hip', 'gpa_unwrap_cols.hip', 'gpa_unwrap_colstream.hip', 'gpa_unwrap_stencil.hip', 'gpa_unwrap_generic.hip',
+           'gpa_unwrap_tables.hip', 'gpa_dft2.hip', 'gpa_warp.hip', 'gpa_peaks.hip', 'gpa_api.hip']
 ARCH = 'gfx950'
 FLAGS = ['-O3', '-std=c++17', '-fPIC', '--offload-arch=' + ARCH, '-fno-gpu-rdc',
          '-Wno-unused-result', '-Wno-unused-value', '-ffp-contract=fast', '-fno-slp-vectorize']
@@ -65,6 +66,10 @@ def build(force=False, jobs=None, verbose=True):
             raise RuntimeError('hipcc failed for %s:\n%s\n%s' % (src, r.stdout, r.stderr))
         return r.stderr
 
+    # objects of translation units that no longer exist (or of one-off variant builds) do not belong to this tree
+    for f in os.listdir(BUILD):
+        if f.endswith('.o') and os.path.join(BUILD, f) not in objs:
+            os.remove(os.path.join(BUILD, f))
     with ThreadPoolExecutor(max_workers=jobs) as ex:
         for warn in ex.map(compile_one, todo):
             if warn and verbose:

@@ -27,6 +27,29 @@ static int fail(int code, const std::string& msg) {
   g_err = msg;
   return code;
 }
+// ---- run-time options -------------------------------------------------------------------------
+namespace gpa {
+static const char* const kOptNames[OPT_COUNT] = {
+    "PBS_FULLBAND", "USE_GRAPH", "SERIAL_UNWRAP", "NO_WORKER", "NO_KSPLIT", "NO_COMPACT", "NO_SHARED", "SHARED_A",
+    "NO_PAIR", "PBS_E8", "TRI_SMALL", "TRI_Q", "NO_MR", "MR_FORCE_BLUESTEIN", "NO_ROWPQ", "COLSOLVE", "NO_LAT",
+    "F32_EPS_FLOOR", "COLSTREAM_CHUNK", "NO_ROWHALF"};
+static OptVal g_opts[OPT_COUNT];
+static std::once_flag g_opts_once;
+static void opt_assign(OptVal& o, const char* value) {
+  o.set = value != nullptr;
+  o.num = value ? atof(value) : 0.0;
+  memset(o.str, 0, sizeof(o.str));
+  if (value) strncpy(o.str, value, sizeof(o.str) - 1);
+}
+static void opts_from_env() {
+  for (int k = 0; k < OPT_COUNT; ++k) opt_assign(g_opts[k], getenv((std::string("GPA_") + kOptNames[k]).c_str()));
+}
+const OptVal& opt(OptKey k) {
+  std::call_once(g_opts_once, opts_from_env);
+  return g_opts[k];
+}
+}  // namespace gpa
+
 #define HIP_TRY(expr)                                                                         \
   do {                                                                                        \
     hipError_t _e = (expr);                                                                   \
@@ -240,6 +263,7 @@ struct gpa_plan {
   bool sh_ok = false;             // this sigma / axis can run it
   bool use_shared = true;         // GPA_NO_SHARED=1 keeps the per-candidate forward transforms
   int sh_epoch = 0, sh_built_epoch = -1, sh_built_K = 0, sh_built_B = 0;   // tables follow sigma and the staged k-list
+  bool sh_built_ok = false;       // the tables of that key are complete and worth using
   bool sh_use = false;            // ... and the staged candidates form runs of >= 2 on an x-plane
   size_t sh_gb_bytes = 0, sh_psi_bytes = 0;
   std::vector<int> staged_planeof;
@@ -593,9 +617,13 @@ static int shared_prepare(gpa_plan* p, int P, int K) {
   const int B = P * K;
   if (!p->sh_ok || !p->use_shared || K < 2 || (int)p->staged_planeof.size() < B) return GPA_OK;
   if (p->sh_built_epoch == p->sh_epoch && p->sh_built_K == K && p->sh_built_B == B) {
-    p->sh_use = p->sh.desc != nullptr;
+    p->sh_use = p->sh_built_ok;
     return GPA_OK;
   }
+  // (the cache key is committed only when the tables are complete: a failed allocation below must not leave a key
+  //  that sends the next call to the kernel with freed tables -- ADVICE r03)
+  p->sh_built_epoch = -1;
+  p->sh_built_ok = false;
   // runs of candidates on one x-plane, in list order; chunks of <= NC candidates per matrix pass
   const int NC = p->dtype == 0 ? 4 : 2;
   std::vector<int> desc((size_t)B, 0);
@@ -617,11 +645,10 @@ static int shared_prepare(gpa_plan* p, int P, int K) {
       k = e;
     }
   }
-  p->sh_built_epoch = p->sh_epoch;
-  p->sh_built_K = K;
-  p->sh_built_B = B;
   if (2 * runs > B) {   // fewer than two candidates per forward transform on average: nothing to share
-    if (p->sh.desc) { HIP_TRY(hipStreamSynchronize(p->stream)); (void)hipFree(p->sh.desc); p->sh.desc = nullptr; }
+    p->sh_built_epoch = p->sh_epoch;
+    p->sh_built_K = K;
+    p->sh_built_B = B;
     return GPA_OK;
   }
   HIP_TRY(hipStreamSynchronize(p->stream));
@@ -650,7 +677,7 @@ static int shared_prepare(gpa_plan* p, int P, int K) {
     for (int k = 0; k < K; ++k)
       wys[(size_t)pp * K + k] = p->staged_kl[2 * ((size_t)pp * K + k) + 1] + (double)shifts[pp] / EEs;
   }
-  p->sh_nbl = getenv("GPA_PBS_FULLBAND") ? EEs : passB_shared_nbl(p->dtype, need);
+  p->sh_nbl = opt_set(OPT_PBS_FULLBAND) ? EEs : passB_shared_nbl(p->dtype, need);
   if (p->sh_nbl >= EEs) {   // nothing to gain: no rotation
     for (int pp = 0; pp < P; ++pp) shifts[pp] = 0;
     for (int bq = 0; bq < B; ++bq) wys[bq] = p->staged_kl[2 * (size_t)bq + 1];
@@ -679,6 +706,10 @@ static int shared_prepare(gpa_plan* p, int P, int K) {
   HIP_TRY(launch_shared_tables(p->dtype, p->ax1s, p->d_wys, p->d_kr, p->d_shifts, p->d_taps, p->sh_etab, p->sh_E, p->sh_Epad, B, K,
                                p->sh_nbl, p->sh, p->stream, p->sh_elems));
   HIP_TRY(hipStreamSynchronize(p->stream));   // `desc` is a local
+  p->sh_built_epoch = p->sh_epoch;
+  p->sh_built_K = K;
+  p->sh_built_B = B;
+  p->sh_built_ok = true;
   p->sh_use = true;
   return GPA_OK;
 }
@@ -777,6 +808,18 @@ static int run_passA(gpa_plan* p, const void* image, const void* mean, void* Tbu
 extern "C" {
 
 int gpa_version(void) { return 100; }
+
+int gpa_set_option(const char* name, const char* value) {
+  if (!name) return fail(GPA_ERR_ARG, "gpa_set_option: null name");
+  if (strncmp(name, "GPA_", 4) == 0) name += 4;
+  (void)opt(OPT_NO_LAT);   // make sure the environment has been read first
+  for (int k = 0; k < OPT_COUNT; ++k)
+    if (strcmp(name, kOptNames[k]) == 0) {
+      opt_assign(g_opts[k], value);
+      return GPA_OK;
+    }
+  return fail(GPA_ERR_ARG, std::string("gpa_set_option: unknown option ") + name);
+}
 const char* gpa_last_error(void) { return g_err.c_str(); }
 
 int gpa_device_count(void) {
@@ -806,12 +849,12 @@ gpa_plan* gpa_plan_create(int device, int n0, int n1, int max_batch, int dtype) 
   p->csz = 2 * p->rsz;
   p->ax0 = p->ax0_full = make_axis(n0);
   p->ax1 = p->ax1_full = make_axis(n1);
-  p->use_graphs = getenv("GPA_USE_GRAPH") != nullptr;
-  p->serial_unwrap = getenv("GPA_SERIAL_UNWRAP") != nullptr;
-  p->use_worker = getenv("GPA_NO_WORKER") == nullptr;
-  p->no_ksplit = getenv("GPA_NO_KSPLIT") != nullptr;
-  p->no_compact = getenv("GPA_NO_COMPACT") != nullptr;
-  p->use_shared = getenv("GPA_NO_SHARED") == nullptr;
+  p->use_graphs = opt_set(OPT_USE_GRAPH);
+  p->serial_unwrap = opt_set(OPT_SERIAL_UNWRAP);
+  p->use_worker = !opt_set(OPT_NO_WORKER);
+  p->no_ksplit = opt_set(OPT_NO_KSPLIT);
+  p->no_compact = opt_set(OPT_NO_COMPACT);
+  p->use_shared = !opt_set(OPT_NO_SHARED);
   const int maxlg = dtype == GPA_F32 ? 14 : 13;
   if (p->ax0.lg > maxlg || p->ax1.lg > maxlg) {
     fail(GPA_ERR_ARG, "gpa_plan_create: axis too long for an LDS-resident transform "
@@ -929,8 +972,9 @@ static int sharedA_prepare(gpa_plan* p, int Bx, bool* use) {
   // the drain of its 32-byte-segment stores (~0.6 - 0.75 ms for 1.6 GB), which the per-plane kernel hides behind the
   // forward transform of the NEXT plane (it needs nothing from memory), while the shared kernel's next plane starts
   // with table loads that queue behind those stores.  Kept for the record and for the tests that pin its parity.
-  if (!p->shA_ok || !p->use_shared || Bx < 2 || !getenv("GPA_SHARED_A")) return GPA_OK;
+  if (!p->shA_ok || !p->use_shared || Bx < 2 || !opt_set(OPT_SHARED_A)) return GPA_OK;
   if (p->shA_built_epoch == p->sh_epoch && p->shA_built_Bx == Bx) { *use = true; return GPA_OK; }
+  p->shA_built_epoch = -1;   // committed again only when the tables are complete
   HIP_TRY(hipStreamSynchronize(p->stream));
   const size_t gx = (size_t)Bx * p->ax0s.L * p->rsz, ps = (size_t)Bx * p->shA_Epad * p->csz;
   if (gx > p->shA_gx_bytes) {
@@ -1167,6 +1211,39 @@ int gpa_weighted_lstsq(gpa_plan* p, const void* b, const void* weights, const do
   return GPA_OK;
 }
 
+// per-kernel event pairs of a profiled call, summed by name in order of first appearance -> p->kprof_table
+static void collect_kernel_profile(gpa_plan* p) {
+  std::vector<std::string> names;
+  std::vector<int> calls;
+  std::vector<double> total;
+  for (int i = 0; p->kprof && i < p->kprof->n; ++i) {
+    const KernelProfiler::Rec& r = p->kprof->rec[i];
+    float ms = 0.f;
+    if (hipEventElapsedTime(&ms, r.a, r.b) != hipSuccess) continue;
+    size_t j = 0;
+    while (j < names.size() && names[j] != r.name) ++j;
+    if (j == names.size()) { names.push_back(r.name); calls.push_back(0); total.push_back(0.0); }
+    ++calls[j];
+    total[j] += ms;
+  }
+  p->kprof_table.clear();
+  char line[160];
+  for (size_t j = 0; j < names.size(); ++j) {
+    snprintf(line, sizeof(line), "%s %d %.6f\n", names[j].c_str(), calls[j], total[j]);
+    p->kprof_table += line;
+  }
+}
+// installs the plan's profiler on the calling thread for the lifetime of the object (while gpa_set_profiling is on)
+struct ProfInstall {
+  explicit ProfInstall(gpa_plan* p) {
+    if (!p->profiling) return;
+    if (!p->kprof) p->kprof = new KernelProfiler();
+    p->kprof->n = 0;
+    g_kprof = p->kprof;
+  }
+  ~ProfInstall() { g_kprof = nullptr; }
+};
+
 // ---- a7 ----------------------------------------------------------------------
 int gpa_unwrap_prediff_dev(gpa_plan* p, const void* dx, const void* dy, const void* weight, int kmax,
                            double eps, int compat, void* phi, int* iters_out) {
@@ -1174,8 +1251,10 @@ int gpa_unwrap_prediff_dev(gpa_plan* p, const void* dx, const void* dy, const vo
   if (kmax < 1) return fail(GPA_ERR_ARG, "gpa_unwrap_prediff: kmax must be >= 1");
   HIP_TRY(hipSetDevice(p->device));
   int iters = 0;
+  ProfInstall prof(p);   // (gpa_set_profiling: per-kernel times of this solve through gpa_last_kernel_profile)
   hipError_t e = unwrap_run(&p->uw, dx, dy, weight, false, kmax, eps, compat != 0, phi, &iters, p->stream);
   if (e != hipSuccess) return fail(GPA_ERR_HIP, std::string("unwrap: ") + hipGetErrorString(e));
+  if (p->profiling) collect_kernel_profile(p);
   if (iters_out) *iters_out = iters;
   return GPA_OK;
 }
@@ -1249,7 +1328,7 @@ static int extract_stage(gpa_plan* p, const double* kvecs, int P, const double* 
   TRY(stage_kvectors(p, klists, kr.data(), B, Bx));
   TRY(ensure_tbuf(p, *Bx));
   TRY(stage_kmat(p, kvecs, P));
-  p->use_pair = (size_t)p->n0 * p->n1 <= (size_t)1024 * 1024 && !getenv("GPA_NO_PAIR");
+  p->use_pair = (size_t)p->n0 * p->n1 <= (size_t)1024 * 1024 && !opt_set(OPT_NO_PAIR);
   if (p->use_pair && !p->have_uwp) {
     size_t bp = 0;
     hipError_t ep = unwrap_workspace_create(p->dtype, p->n0, p->n1, p->stream, &p->uwp, &bp, 2);
@@ -1367,12 +1446,7 @@ static int extract_enqueue(gpa_plan* p, const void* image, const double* kvecs, 
   TRY(extract_stage(p, kvecs, P, klists, K, sigma, &Bx));
   void* lk = lockins ? lockins : p->d_lockin;
   // per-kernel event pairs while profiling (installed for this thread until the function returns)
-  struct ProfGuard { ~ProfGuard() { g_kprof = nullptr; } } prof_guard;
-  if (p->profiling) {
-    if (!p->kprof) p->kprof = new KernelProfiler();
-    p->kprof->n = 0;
-    g_kprof = p->kprof;
-  }
+  ProfInstall prof(p);
   if (p->profiling || !p->use_graphs) return extract_launch(p, image, P, K, Bx, mask_border, kmax, u, lk, kidx);
   const GraphKey key = {image, u, lk, kidx, P, K, Bx, mask_border, kmax, p->tbuf_epoch};
   GraphEntry* ent = nullptr;
@@ -1530,6 +1604,13 @@ int gpa_extract_displacement_field_batch_dev(gpa_plan* p, const void* images, in
   return GPA_OK;
 }
 
+// whether gpa_extract_displacement_field_batch_dev can take this plan's image shape (the fused iteration covers it);
+// callers with other shapes loop over gpa_extract_displacement_field_dev instead
+int gpa_supports_batch(gpa_plan* p) {
+  if (!p) return 0;
+  return unwrap_supports_batch(&p->uw) ? 1 : 0;
+}
+
 int gpa_last_batch_iters(gpa_plan* p, int B, int* iters_out) {
   if (!p || !iters_out || B < 1 || B > p->uwb_images) return fail(GPA_ERR_ARG, "gpa_last_batch_iters: bad argument");
   HIP_TRY(hipStreamSynchronize(p->stream));
@@ -1552,26 +1633,7 @@ int gpa_extract_displacement_field_dev(gpa_plan* p, const void* image, const dou
   HIP_TRY(hipStreamSynchronize(p->stream));
   if (p->profiling) {
     for (int i = 0; i < 5; ++i) hipEventElapsedTime(&p->stage_ms[i], p->stage_ev[i], p->stage_ev[i + 1]);
-    // sum the per-kernel event pairs by name, in order of first appearance
-    std::vector<std::string> names;
-    std::vector<int> calls;
-    std::vector<double> total;
-    for (int i = 0; p->kprof && i < p->kprof->n; ++i) {
-      const KernelProfiler::Rec& r = p->kprof->rec[i];
-      float ms = 0.f;
-      if (hipEventElapsedTime(&ms, r.a, r.b) != hipSuccess) continue;
-      size_t j = 0;
-      while (j < names.size() && names[j] != r.name) ++j;
-      if (j == names.size()) { names.push_back(r.name); calls.push_back(0); total.push_back(0.0); }
-      ++calls[j];
-      total[j] += ms;
-    }
-    p->kprof_table.clear();
-    char line[160];
-    for (size_t j = 0; j < names.size(); ++j) {
-      snprintf(line, sizeof(line), "%s %d %.6f\n", names[j].c_str(), calls[j], total[j]);
-      p->kprof_table += line;
-    }
+    collect_kernel_profile(p);
   }
   if (iters_out) { iters_out[0] = p->h_iters[p->iters_off]; iters_out[1] = p->h_iters[p->iters_stride + p->iters_off]; }
   return GPA_OK;
@@ -1677,7 +1739,7 @@ int gpa_tile_gradients_dev(gpa_plan* p, const void* image, size_t image_pitch, i
   return GPA_OK;
 }
 
-static int invert_u_host(gpa_plan* p, const void* u, int iters, int edge, int shift, void* out, int mode = 0) {
+static int invert_u_host(gpa_plan* p, const void* u, int iters, int edge, int shift, void* out, int mode, bool overlap) {
   if (!p || !u || !out) return fail(GPA_ERR_ARG, "gpa_invert_u: null argument");
   if (iters < 1 || edge < 0) return fail(GPA_ERR_ARG, "gpa_invert_u: need iters >= 1, edge >= 0");
   HIP_TRY(hipSetDevice(p->device));
@@ -1685,7 +1747,7 @@ static int invert_u_host(gpa_plan* p, const void* u, int iters, int edge, int sh
   void* d_out = nullptr;
   HIP_TRY(hipMalloc(&d_out, 2 * nout * p->rsz));
   hipError_t e = hipMemcpyAsync(p->d_u, u, 2 * npx * p->rsz, hipMemcpyHostToDevice, p->stream);
-  if (e == hipSuccess) e = warp_invert_u(p->dtype, p->d_u, p->n0, p->n1, 1.0, iters, edge, shift, d_out, p->stream, mode);
+  if (e == hipSuccess) e = warp_invert_u(p->dtype, p->d_u, p->n0, p->n1, 1.0, iters, edge, shift, d_out, p->stream, mode, overlap ? 1 : 0);
   if (e == hipSuccess) e = hipMemcpyAsync(out, d_out, 2 * nout * p->rsz, hipMemcpyDeviceToHost, p->stream);
   if (e == hipSuccess) e = hipStreamSynchronize(p->stream);
   hipFree(d_out);
@@ -1694,20 +1756,20 @@ static int invert_u_host(gpa_plan* p, const void* u, int iters, int edge, int sh
 }
 
 int gpa_invert_u_overlap(gpa_plan* p, const void* u, int iters, int edge, void* out) {
-  return invert_u_host(p, u, iters, edge, 0, out);
+  return invert_u_host(p, u, iters, edge, 0, out, 0, true);
 }
 
 // invert_u (geometric_phase_analysis.py:248-259): the image's own grid, one sampling at r and then `iters` rounds
 // at r + u_it(r) - edge
 int gpa_invert_u(gpa_plan* p, const void* u, int iters, int edge, void* out) {
-  return invert_u_host(p, u, iters, 0, edge, out);
+  return invert_u_host(p, u, iters, 0, edge, out, 0, false);
 }
 
 // the two with scipy's boundary mode as an argument: 0 = 'nearest', 1 = 'constant' (the `mode=` keyword of
 // geometric_phase_analysis.py:248, :262); overlap != 0 = invert_u_overlap
 int gpa_invert_u_mode(gpa_plan* p, const void* u, int iters, int edge, int overlap, int mode, void* out) {
   if (mode != 0 && mode != 1) return fail(GPA_ERR_ARG, "gpa_invert_u_mode: mode must be 0 (nearest) or 1 (constant)");
-  return overlap ? invert_u_host(p, u, iters, edge, 0, out, mode) : invert_u_host(p, u, iters, 0, edge, out, mode);
+  return overlap ? invert_u_host(p, u, iters, edge, 0, out, mode, true) : invert_u_host(p, u, iters, 0, edge, out, mode, false);
 }
 
 int gpa_undistort_image(gpa_plan* p, const void* deformed, const void* u, void* out) {

@@ -63,6 +63,23 @@ inline hipError_t set_dynamic_lds_once(const void* kern, int bytes, unsigned& do
   return e;
 }
 
+// ---- run-time options (gpa_set_option, include/gpa_hip.h) ---------------------------------------
+// Diagnostic / test switches of the library.  The table is filled ONCE from the environment (GPA_<NAME>) when the
+// library first looks at it and changed afterwards only through gpa_set_option(): no getenv() on any call path.
+// A switch is "set" when it has a value at all (GPA_NO_LAT=0 is set, as it always was); num = atof(value).
+enum OptKey {
+  OPT_PBS_FULLBAND, OPT_USE_GRAPH, OPT_SERIAL_UNWRAP, OPT_NO_WORKER, OPT_NO_KSPLIT, OPT_NO_COMPACT, OPT_NO_SHARED,
+  OPT_SHARED_A, OPT_NO_PAIR, OPT_PBS_E8, OPT_TRI_SMALL, OPT_TRI_Q, OPT_NO_MR, OPT_MR_FORCE_BLUESTEIN, OPT_NO_ROWPQ,
+  OPT_COLSOLVE, OPT_NO_LAT, OPT_F32_EPS_FLOOR, OPT_COLSTREAM_CHUNK, OPT_NO_ROWHALF, OPT_COUNT
+};
+struct OptVal {
+  bool set;
+  double num;
+  char str[24];
+};
+const OptVal& opt(OptKey k);
+inline bool opt_set(OptKey k) { return opt(k).set; }
+
 #define GPA_PROF_CAT2(a, b) a##b
 #define GPA_PROF_CAT(a, b) GPA_PROF_CAT2(a, b)
 #define GPA_PROF(name, stream) ::gpa::ProfScope GPA_PROF_CAT(_gpa_prof_, __LINE__)(name, stream)
@@ -203,9 +220,10 @@ hipError_t launch_deconv_filter(int dtype, void* Z, int n0, int n1, const double
 hipError_t launch_deconv_unpack(int dtype, const void* Z, int m0, int m1, int pad, void* out, hipStream_t s);
 
 // ---- f-1 Lawler-Fujita (gpa_warp.hip); both synchronise the stream before returning -----------
-// mode: 0 = scipy 'nearest' (the reference's default), 1 = 'constant'
+// mode: 0 = scipy 'nearest' (the reference's default), 1 = 'constant'; nan_last (mode 1 only): the last round samples
+// with cval = NaN as invert_u_overlap does (geometric_phase_analysis.py:296-299), invert_u never does (:255-258)
 hipError_t warp_invert_u(int dtype, const void* d_u, int n0, int n1, double scale, int iters, int edge, int shift,
-                         void* d_out, hipStream_t s, int mode = 0);
+                         void* d_out, hipStream_t s, int mode = 0, int nan_last = 0);
 hipError_t warp_image(int dtype, const void* d_img, const void* d_uinv, int n0, int n1, void* d_out, hipStream_t s);
 
 }  // namespace gpa

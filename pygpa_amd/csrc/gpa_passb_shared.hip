@@ -975,7 +975,7 @@ static hipError_t run_passB_shared(const Axis& a1, int n0, const void* Tbuf, con
 int passB_shared_elems(int dtype, const Axis& a1) {
   (void)dtype;
 #ifdef GPA_PBS_BUILD_E8
-  static const bool e8 = getenv("GPA_PBS_E8") != nullptr;   // experiment switch
+  const bool e8 = opt_set(OPT_PBS_E8);   // experiment switch
   return (a1.lg == 12 && e8) ? 8 : 16;
 #else
   (void)a1;

@@ -1,0 +1,456 @@
+// a7, column half of the preconditioner z = idctn(dctn(r) / eig) (phase_unwrap.py:95-115) as a STREAM: the
+// transform-free recursion of colsolve_tri_kernel (gpa_unwrap_cols.hip) without its need to hold a whole column in one
+// workgroup.
+//
+// For row frequency j the column solve is (T + mu_j) z = r with T the second-difference matrix with reflecting ends; with
+// lam = (1 + h) - sqrt(h (2 + h)), h = 1 - cos(pi j / N), it is the cascade
+//     p_n = r_n + lam p_(n-1)            p_(-1) = (A + lam^N B) / (1 - lam^(2N)),  A = sum lam^m r_m,  B = sum lam^m r_(N-1-m)
+//     z_n = lam (z_(n+1) - p_n)          z_N    = -lam / (1 - lam) p_(N-1)
+// A column of 4096 .. 16384 points does not fit the registers of a workgroup together with enough neighbours to make
+// its row segments long (the resident kernels are down to 32 / 16 / 8-byte segments at 4096 / 8192 / 16384 points and
+// run at 0.25 / 0.12 / 0.07 of the HBM rate).  Both recursions are linear, so a column is cut into chunks of C rows and
+// the solve becomes three launches that never hold more than C rows of a column:
+//   colstream_agg_kernel    per chunk and column the two zero-start sums  a = sum lam^k r_k,  b = sum lam^(len-1-k) r_k
+//                           (reads R once, writes 16 bytes per C samples)
+//   colstream_scan_kernel   per column, over its S chunks: A, B, p_(-1); the p that enters every chunk; z_N; the z that
+//                           enters every chunk from below (the zero-start z-sum of a chunk follows from a, b in closed
+//                           form, see the kernel).  Also the stopping test of the iteration (phase_unwrap.py:348) and
+//                           the singular column j = 0 (lam = 1: the reference divides its DC bin by 1, :110-114).
+//   colstream_apply_kernel  per chunk and column: both recursions from the true carries, rho = <r, z> from z alone as the
+//                           quadratic form -sum (z_(n+1) - z_n)^2 + mu sum z_n^2 (reads R again, writes Z)
+// Every access is a 256-thread workgroup reading C rows of 256 adjacent columns: 1 KiB (f32) contiguous per row, any
+// number of workgroups in flight.  12 bytes per sample instead of 8, at the streaming rate.
+#include "gpa_unwrap_impl.h"
+
+namespace gpa {
+namespace {
+
+constexpr int CS_COLS = 256;   // columns per workgroup = threads per workgroup
+
+// per-column constants of the scan (doubles; built on the host in long double)
+struct StreamCol {
+  double lam, lamC, lamL, lamN, inv, zn, g, q2;   // lam^C, lam^len(last chunk), lam^N, 1 / (1 - lam^(2N)), -lam / (1 - lam),
+                                                  // g = lam / (1 - lam^2), q2 = lam^2 / (1 - lam^2); column 0: lam = 1, rest 0
+};
+
+// exclusive prefix sum over the threads of a workgroup in thread order (fixed shuffle tree per wavefront, fixed order over
+// the wavefronts: deterministic); *total = the sum over all threads.  sh: >= 17 doubles.
+__device__ __forceinline__ double block_excl_scan(double v, double* sh, double* total) {
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, nw = (blockDim.x + 63) >> 6;
+  double inc = v;
+#pragma unroll
+  for (int off = 1; off < 64; off <<= 1) {
+    const double t = __shfl_up(inc, off);
+    if (lane >= off) inc += t;
+  }
+  __syncthreads();   // sh may still be read from an earlier call
+  if (lane == 63) sh[wave] = inc;
+  __syncthreads();
+  double front = 0.0, tot = 0.0;
+  for (int i = 0; i < nw; ++i) {
+    const double w = sh[i];
+    if (i < wave) front += w;
+    tot += w;
+  }
+  *total = tot;
+  return front + inc - v;
+}
+
+// A sample is read by two recursions.  The second read goes through an opaque copy: hipcc otherwise shares the
+// f32 -> f64 conversion between the passes and keeps all C converted samples of the thread alive (2 C registers more).
+template <class T>
+__device__ __forceinline__ double reread(T v) {
+  if constexpr (sizeof(T) == 4) asm volatile("" : "+v"(v));
+  return (double)v;
+}
+
+// ---- launch 1: chunk sums -----------------------------------------------------------------------
+template <class T, int C, bool RAGGED>
+__global__ __launch_bounds__(CS_COLS) void colstream_agg_kernel(const T* __restrict__ R, int n0, int n1,
+                                                               const double* __restrict__ lamtab, double2* __restrict__ agg,
+                                                               const int* flags, size_t pimg, size_t pagg) {
+  {
+    const size_t pb = blockIdx.z;
+    R += pb * pimg;
+    agg += pb * pagg;
+    flags += pb * FLAGS_N;
+  }
+  if (flags[1]) return;   // (stopped in an EARLIER iteration; this iteration's test is the scan kernel's)
+  const int y = blockIdx.x * CS_COLS + threadIdx.x, s = blockIdx.y;
+  const bool cv = !RAGGED || y < n1;
+  const int yc = cv ? y : 0;
+  const int row0 = s * C;
+  const int len = !RAGGED ? C : (n0 - row0 < C ? n0 - row0 : C);
+  // (a wave-uniform row pointer plus the lane's 32-bit column: the scalar-base form of the load, no 64-bit address
+  //  per row in vector registers)
+  const T* rp = R + (size_t)row0 * n1;
+  const unsigned yo = (unsigned)yc * (unsigned)sizeof(T);   // byte offset, 32 bits: base (scalar) + zext(offset)
+  T x[C];
+#pragma unroll
+  for (int k = 0; k < C; ++k) {
+    x[k] = (!RAGGED || k < len) ? *reinterpret_cast<const T*>(reinterpret_cast<const char*>(rp) + yo) : T(0);
+    rp += n1;
+  }
+  const double lam = lamtab[yc];
+  double b = 0.0, a = 0.0;
+#pragma unroll
+  for (int k = 0; k < C; ++k) {
+    if (!RAGGED || k < len) b = (double)x[k] + lam * b;
+    if ((k & 7) == 7) __builtin_amdgcn_sched_barrier(0);   // (see colstream_apply_kernel)
+  }
+#pragma unroll
+  for (int k = C - 1; k >= 0; --k) {
+    if (!RAGGED || k < len) a = reread(x[k]) + lam * a;
+    if ((k & 7) == 0) __builtin_amdgcn_sched_barrier(0);
+  }
+  if (cv) agg[(size_t)s * n1 + y] = make_double2(a, b);
+}
+
+// ---- launch 2: the scan over the chunks of every column ------------------------------------------
+// Threads are laid out (column, segment): G segments of M consecutive chunks per column, G side by side in the thread
+// index's high part so that a wavefront reads 64 adjacent columns.  Three linear recurrences over the chunks --
+//   A (from the last chunk up), B and the chunk-end p (from the first chunk down), the chunk-start z (from the last up)
+// -- each as: compose the segment's chunks (registers), exchange the G segment results through LDS, apply.
+template <class T, int G, int M>
+__global__ __launch_bounds__(64 * G) void colstream_scan_kernel(const T* __restrict__ R, T* __restrict__ Z, int n0, int n1, int C, int S,
+                                                               const StreamCol* __restrict__ tab,
+                                                               const double2* __restrict__ agg, double* __restrict__ carP, double* __restrict__ carZ,
+                                                               int* flags, const double* part_norm, int nnorm, int it, double eps,
+                                                               double* scal, double* part_rho, int rho_slot, size_t pimg,
+                                                               size_t pagg) {
+  {
+    const size_t pb = blockIdx.z;
+    R += pb * pimg;
+    Z += pb * pimg;
+    agg += pb * pagg;
+    carP += pb * pagg;
+    carZ += pb * pagg;
+    flags += pb * FLAGS_N;
+    scal += pb * SCAL_N;
+    part_norm += pb * PART_N;
+    part_rho += pb * PART_N;
+  }
+  if (flags[1]) return;
+  __shared__ double shn[64 * G];
+  __shared__ double xa[G][64], xb[G][64], xm[G][64];
+  if (it > 0) {
+    // the reference's stopping test (phase_unwrap.py:348) on the update the row kernel has just applied, evaluated by
+    // every workgroup of this launch; the other two launches of the solve read the flag
+    const double tot = reduce_partials(part_norm, nnorm, shn);
+    const double best = scal[10 + ((it - 1) & 1)];
+    const bool stop = sqrt(tot) < eps * sqrt(scal[5]) || tot == 0.0 || !(tot == tot) || tot > 1e4 * best;
+    if (blockIdx.x == 0 && threadIdx.x == 0) {
+      flags[0] = it;
+      scal[6] = tot;
+      scal[10 + (it & 1)] = tot < best ? tot : best;
+      if (stop) flags[1] = 1;
+    }
+    if (stop) return;
+  }
+  const int lane = threadIdx.x & 63, g = threadIdx.x >> 6;
+  const int ncb = (n1 + 63) / 64;   // column blocks; the block after them solves column 0
+  if ((int)blockIdx.x == ncb) {
+    // ---- column 0 (lam = 1, the row means): z = T^+ (r - mean) + mean, i.e. p = cumsum(r - mean), z_n = -sum_(m >= n) p_m,
+    // then the mean of z removed and the mean of r added (its DC bin is divided by 1).  One workgroup, thread t owns
+    // rows [t m, (t + 1) m).
+    const int nt = 64 * G, m = (n0 + nt - 1) / nt, t = threadIdx.x;
+    const int ra = t * m < n0 ? t * m : n0, rb = (t + 1) * m < n0 ? (t + 1) * m : n0;
+    const T* col = R;
+    double sum = 0.0;
+    for (int n = ra; n < rb; ++n) sum += (double)col[(size_t)n * n1];
+    const double shift0 = block_sum(sum, shn) / (double)n0;
+    // p at the end of the rows of the threads in front of this one
+    double total;
+    const double before = block_excl_scan(sum - (double)(rb - ra) * shift0, shn, &total);
+    // local p: its sum (for the z of the rows above), sum_n (n + 1) p_n (= -sum_n z_n) and sum p^2 over rows 0 .. N-2
+    double p = before, psum = 0.0, wsum = 0.0, dsq = 0.0;
+    for (int n = ra; n < rb; ++n) {
+      p += (double)col[(size_t)n * n1] - shift0;
+      psum += p;
+      wsum += (double)(n + 1) * p;
+      if (n < n0 - 1) dsq += p * p;
+    }
+    const double pfront = block_excl_scan(psum, shn, &total);
+    const double after = total - pfront - psum;         // sum of p over the rows of the threads behind this one
+    const double zs = -block_sum(wsum, shn);             // sum_n z_n,  z_n = -sum_(m >= n) p_m
+    const double fix = shift0 - zs / (double)n0;
+    {
+      double pp = before, run = psum;                    // run = sum of the local p from row n on
+      for (int n = ra; n < rb; ++n) {
+        Z[(size_t)n * n1] = (T)(-(after + run) + fix);
+        pp += (double)col[(size_t)n * n1] - shift0;
+        run -= pp;
+      }
+    }
+    // rho of column 0 (colsolve_tri_kernel: r = -dsq + N shift0^2, times c_0 = 1/2)
+    const double d = block_sum(dsq, shn);
+    if (threadIdx.x == 0) part_rho[rho_slot] = 0.5 * (-d + (double)n0 * shift0 * shift0) / (2.0 * (double)n1);
+    return;
+  }
+  const int y = blockIdx.x * 64 + lane;
+  const bool cv = y < n1 && y > 0;     // (column 0 is the last workgroup's)
+  const int yc = y < n1 ? y : 0;
+  const StreamCol tc = tab[yc];
+  const int s0 = g * M;                // first chunk of this thread's segment
+  auto mult = [&](int s) { return s == S - 1 ? tc.lamL : tc.lamC; };   // lam^len(s)
+  double av[M], bv[M];
+#pragma unroll
+  for (int i = 0; i < M; ++i) {
+    const int s = s0 + i;
+    const double2 v = s < S ? agg[(size_t)s * n1 + yc] : make_double2(0.0, 0.0);
+    av[i] = v.x;
+    bv[i] = v.y;
+  }
+  // segment results: A-part (from the segment's last chunk up), B-part (down), total multiplier
+  double Aseg = 0.0, Bseg = 0.0, Mseg = 1.0;
+#pragma unroll
+  for (int i = M - 1; i >= 0; --i)
+    if (s0 + i < S) Aseg = av[i] + mult(s0 + i) * Aseg;
+#pragma unroll
+  for (int i = 0; i < M; ++i)
+    if (s0 + i < S) { Bseg = bv[i] + mult(s0 + i) * Bseg; Mseg *= mult(s0 + i); }
+  xa[g][lane] = Aseg;
+  xb[g][lane] = Bseg;
+  xm[g][lane] = Mseg;
+  __syncthreads();
+  double A = 0.0, B = 0.0;
+#pragma unroll
+  for (int j = G - 1; j >= 0; --j) A = xa[j][lane] + xm[j][lane] * A;
+#pragma unroll
+  for (int j = 0; j < G; ++j) B = xb[j][lane] + xm[j][lane] * B;
+  const double pm1 = (A + tc.lamN * B) * tc.inv;       // p_(-1)
+  // p at the end of the segments before this one, and at the end of the column
+  double P = pm1, Plast = pm1;
+#pragma unroll
+  for (int j = 0; j < G; ++j) {
+    Plast = xb[j][lane] + xm[j][lane] * Plast;
+    if (j < g) P = Plast;
+  }
+  // forward over the segment's chunks: the p that enters each; and its zero-start z-sum
+  //   e_s = -sum_k lam^(k+1) p_k,  p_k = p0_k + lam^(k+1) Pin  =>  e_s = -g (a_s - lam^(len+1) b_s) - q2 (1 - lam^(2 len)) Pin
+  // (p0 the zero-start recursion of the chunk; the first term is that recursion's z-sum in closed form)
+  // (the entering p goes to memory at once and e_s replaces a_s in its register: two arrays of M doubles live, not four)
+#pragma unroll
+  for (int i = 0; i < M; ++i) {
+    const int s = s0 + i;
+    if (s < S) {
+      if (cv) carP[(size_t)s * n1 + y] = P;
+      const double ml = mult(s);
+      av[i] = -tc.g * (av[i] - tc.lam * ml * bv[i]) - tc.q2 * (1.0 - ml * ml) * P;
+      P = bv[i] + ml * P;
+    } else {
+      av[i] = 0.0;
+    }
+  }
+  double Eseg = 0.0;
+#pragma unroll
+  for (int i = M - 1; i >= 0; --i)
+    if (s0 + i < S) Eseg = av[i] + mult(s0 + i) * Eseg;
+  __syncthreads();   // xa is read above by every thread
+  xa[g][lane] = Eseg;
+  __syncthreads();
+  double Zc = tc.zn * Plast;                           // z_N
+#pragma unroll
+  for (int j = G - 1; j >= 0; --j)
+    if (j > g) Zc = xa[j][lane] + xm[j][lane] * Zc;
+#pragma unroll
+  for (int i = M - 1; i >= 0; --i) {
+    const int s = s0 + i;
+    if (s < S) {
+      if (cv) carZ[(size_t)s * n1 + y] = Zc;
+      Zc = av[i] + mult(s) * Zc;
+    }
+  }
+}
+
+// ---- launch 3: the recursions, chunk by chunk ---------------------------------------------------
+template <class T, int C, bool RAGGED>
+__global__ __launch_bounds__(CS_COLS) void colstream_apply_kernel(const T* __restrict__ R, T* __restrict__ Z, int n0, int n1, int S,
+                                                                 const double* __restrict__ lamtab, const T* __restrict__ hb,
+                                                                 const double* __restrict__ carP,
+                                                                 const double* __restrict__ carZ, const int* flags,
+                                                                 double* part_rho, size_t pimg, size_t pagg) {
+  {
+    const size_t pb = blockIdx.z;
+    R += pb * pimg;
+    Z += pb * pimg;
+    carP += pb * pagg;
+    carZ += pb * pagg;
+    flags += pb * FLAGS_N;
+    part_rho += pb * PART_N;
+  }
+  if (flags[1]) return;
+  __shared__ double shn[CS_COLS];
+  const int y = blockIdx.x * CS_COLS + threadIdx.x, s = blockIdx.y;
+  const bool cv = (!RAGGED || y < n1) && y > 0;   // column 0 is solved by the scan kernel
+  const int yc = (!RAGGED || y < n1) ? y : 0;
+  const int row0 = s * C;
+  const int len = !RAGGED ? C : (n0 - row0 < C ? n0 - row0 : C);
+  const T* rp = R + (size_t)row0 * n1;
+  const unsigned yo = (unsigned)yc * (unsigned)sizeof(T);   // byte offset, 32 bits: base (scalar) + zext(offset)
+  T x[C];
+#pragma unroll
+  for (int k = 0; k < C; ++k) {
+    x[k] = (!RAGGED || k < len) ? *reinterpret_cast<const T*>(reinterpret_cast<const char*>(rp) + yo) : T(0);
+    rp += n1;
+  }
+  const double lam = lamtab[yc];
+  const double cp = carP[(size_t)s * n1 + yc], cz = carZ[(size_t)s * n1 + yc];
+  const double mu2 = 2.0 * (double)hb[yc];
+  // causal recursion from the true carry, in place (stored in the data's precision, as colsolve_tri_kernel does)
+  // (scheduling fences every 8 rows: left alone, hipcc hoists the f32 -> f64 conversions of all C samples to the top of
+  //  the chain and keeps 2 C more registers alive)
+  double p = cp;
+#pragma unroll
+  for (int k = 0; k < C; ++k) {
+    if (!RAGGED || k < len) {
+      p = (double)x[k] + lam * p;
+      x[k] = (T)p;
+    }
+    if ((k & 7) == 7) __builtin_amdgcn_sched_barrier(0);
+  }
+  // anticausal recursion in place; rho from the quadratic form (no difference across the reflecting end)
+  double z = cz, dsq = 0.0, zsq = 0.0;
+  const bool last = s == S - 1;
+#pragma unroll
+  for (int k = C - 1; k >= 0; --k) {
+    if (!RAGGED || k < len) {
+      const double zn = lam * (z - reread(x[k]));
+      if (!(last && k == len - 1)) dsq += (z - zn) * (z - zn);
+      zsq += zn * zn;
+      z = zn;
+      x[k] = (T)zn;
+    }
+    if ((k & 7) == 0) {
+      // (the two sums are pinned here: hipcc otherwise sinks their whole accumulation behind the stores and keeps every
+      //  z of the chunk alive as a double until then)
+      asm volatile("" : "+v"(dsq), "+v"(zsq));
+      __builtin_amdgcn_sched_barrier(0);
+    }
+  }
+  if (cv) {
+    T* zp = Z + (size_t)row0 * n1;
+#pragma unroll
+    for (int k = 0; k < C; ++k) {
+      if (!RAGGED || k < len) *reinterpret_cast<T*>(reinterpret_cast<char*>(zp) + yo) = x[k];
+      zp += n1;
+    }
+  }
+  const double tot = block_sum(cv ? -dsq - mu2 * zsq : 0.0, shn);
+  if (threadIdx.x == 0) part_rho[(size_t)blockIdx.y * gridDim.x + blockIdx.x] = tot / (2.0 * (double)n1);
+}
+
+template <class T, int C>
+hipError_t run_stream(const Impl* w, int compat, hipStream_t s, const double* part_norm, int nnorm, int it, double eps,
+                      double* part_rho, int* nrho, const void* zin) {
+  const int n0 = w->n0, n1 = w->n1, S = w->strS;
+  const size_t pimg = (size_t)n0 * n1, pagg = (size_t)S * n1;
+  const bool ragged = (n0 % C) != 0 || (n1 % CS_COLS) != 0;
+  const dim3 grid((n1 + CS_COLS - 1) / CS_COLS, S, w->nprob);
+  const int nparts = grid.x * grid.y;
+  if (nparts + 1 > MAXPART) return hipErrorInvalidValue;
+  const T* R = (const T*)(zin ? zin : w->z);
+  {
+    GPA_PROF("colstream_agg_kernel", s);
+    if (ragged) colstream_agg_kernel<T, C, true><<<grid, CS_COLS, 0, s>>>(R, n0, n1, w->strlam, (double2*)w->stragg, w->flags, pimg, pagg);
+    else colstream_agg_kernel<T, C, false><<<grid, CS_COLS, 0, s>>>(R, n0, n1, w->strlam, (double2*)w->stragg, w->flags, pimg, pagg);
+  }
+  {
+    GPA_PROF("colstream_scan_kernel", s);
+    const dim3 gs((n1 + 63) / 64 + 1, 1, w->nprob);
+    // segments per column x chunks per segment: G * M >= S
+#define GPA_SCAN(GG, MM)                                                                                                   \
+  colstream_scan_kernel<T, GG, MM><<<gs, 64 * GG, 0, s>>>(R, (T*)w->z, n0, n1, C, S, (const StreamCol*)w->strtab,           \
+                                                          (const double2*)w->stragg, (double*)w->strcar, (double*)w->strcar + w->cap * pagg, w->flags, part_norm, \
+                                                          nnorm, it, eps, w->scal, part_rho, nparts, pimg, pagg)
+    if (S <= 16) GPA_SCAN(4, 4);
+    else if (S <= 32) GPA_SCAN(8, 4);
+    else if (S <= 64) GPA_SCAN(8, 8);
+    else if (S <= 128) GPA_SCAN(16, 8);
+    else if (S <= 256) GPA_SCAN(16, 16);
+    else return hipErrorInvalidValue;
+#undef GPA_SCAN
+  }
+  {
+    GPA_PROF("colstream_apply_kernel", s);
+    if (ragged)
+      colstream_apply_kernel<T, C, true><<<grid, CS_COLS, 0, s>>>(R, (T*)w->z, n0, n1, S, w->strlam, (const T*)w->hb1[compat],
+                                                                 (const double*)w->strcar, (const double*)w->strcar + w->cap * pagg,
+                                                                 w->flags, part_rho, pimg, pagg);
+    else
+      colstream_apply_kernel<T, C, false><<<grid, CS_COLS, 0, s>>>(R, (T*)w->z, n0, n1, S, w->strlam, (const T*)w->hb1[compat],
+                                                                  (const double*)w->strcar, (const double*)w->strcar + w->cap * pagg,
+                                                                 w->flags, part_rho, pimg, pagg);
+  }
+  if (nrho) *nrho = nparts + 1;
+  return hipGetLastError();
+}
+
+}  // namespace
+
+// rows per chunk of the streamed column solve for a column of n0 points (0: not offered)
+int colstream_chunk(int n0, int n1) {
+  if (n0 != n1 || n0 < 64) return 0;
+  int C = n0 >= 8192 ? 128 : (n0 >= 1024 ? 64 : 32);
+  if (opt_set(OPT_COLSTREAM_CHUNK)) {
+    const int c = (int)opt(OPT_COLSTREAM_CHUNK).num;
+    if (c == 32 || c == 64 || c == 128) C = c;
+  }
+  while (C > 32 && (n0 + C - 1) / C < 4) C /= 2;
+  if ((n0 + C - 1) / C > 256) return 0;
+  return C;
+}
+
+// per-column constants (long double on the host) and the chunk-sum / carry buffers
+hipError_t build_streamtab(Impl* w, hipStream_t s, size_t* bytes) {
+  const int n0 = w->n0, n1 = w->n1;
+  const int C = colstream_chunk(n0, n1);
+  if (!C) return hipSuccess;
+  const int S = (n0 + C - 1) / C, L = n0 - (S - 1) * C;
+  std::vector<StreamCol> tc((size_t)n1);
+  std::vector<double> lam((size_t)n1);
+  for (int j = 0; j < n1; ++j) {
+    if (j == 0) { tc[0] = {1.0, 1.0, 1.0, 1.0, 0.0, 0.0, 0.0, 0.0}; lam[0] = 1.0; continue; }
+    const long double sj = sinl((long double)M_PI * j / (2.0L * n1)), h = 2 * sj * sj;
+    const long double l = (1 + h) - sqrtl(h * (2 + h));
+    tc[j].lam = (double)l;
+    tc[j].lamC = (double)powl(l, C);
+    tc[j].lamL = (double)powl(l, L);
+    tc[j].lamN = (double)powl(l, (long double)n0);
+    tc[j].inv = (double)(1.0L / (1.0L - powl(l, 2.0L * n0)));
+    tc[j].zn = (double)(-l / (1.0L - l));
+    tc[j].g = (double)(l / (1.0L - l * l));
+    tc[j].q2 = (double)(l * l / (1.0L - l * l));
+    lam[j] = (double)l;
+  }
+  hipError_t e = hipMalloc(&w->strtab, tc.size() * sizeof(StreamCol));
+  if (e == hipSuccess) e = hipMalloc((void**)&w->strlam, lam.size() * sizeof(double));
+  const size_t ab = (size_t)S * n1 * 2 * sizeof(double) * w->cap;
+  if (e == hipSuccess) e = hipMalloc(&w->stragg, ab);
+  if (e == hipSuccess) e = hipMalloc(&w->strcar, ab);
+  if (e != hipSuccess) return e;
+  *bytes += tc.size() * sizeof(StreamCol) + lam.size() * sizeof(double) + 2 * ab;
+  e = hipMemcpyAsync(w->strtab, tc.data(), tc.size() * sizeof(StreamCol), hipMemcpyHostToDevice, s);
+  if (e == hipSuccess) e = hipMemcpyAsync(w->strlam, lam.data(), lam.size() * sizeof(double), hipMemcpyHostToDevice, s);
+  if (e == hipSuccess) e = hipStreamSynchronize(s);
+  w->strC = C;
+  w->strS = S;
+  return e;
+}
+
+hipError_t dispatch_colstream(const Impl* w, int compat, hipStream_t s, const double* part_norm, int nnorm, int it, double eps,
+                              double* part_rho, int* nrho, const void* zin) {
+  if (!w->strtab) return hipErrorInvalidValue;
+#define GPA_STREAM(CC)                                                                                                 \
+  return w->dtype == 0 ? run_stream<float, CC>(w, compat, s, part_norm, nnorm, it, eps, part_rho, nrho, zin)           \
+                       : run_stream<double, CC>(w, compat, s, part_norm, nnorm, it, eps, part_rho, nrho, zin)
+  switch (w->strC) {
+    case 32: GPA_STREAM(32);
+    case 64: GPA_STREAM(64);
+    case 128: GPA_STREAM(128);
+  }
+#undef GPA_STREAM
+  return hipErrorInvalidValue;
+}
+
+}  // namespace gpa

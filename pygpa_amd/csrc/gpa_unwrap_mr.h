@@ -1,5 +1,5 @@
 // Fused PCG kernels for image sizes that are not powers of two, on the mixed-radix LDS-resident FFT
-// (gpa_mrfft.h).  Included by gpa_unwrap.hip only (uses its Impl, reductions and scalar conventions).
+// (gpa_mrfft.h).  Included by gpa_unwrap_generic.hip only (Impl, reductions and scalar conventions: gpa_unwrap_impl.h).
 //
 // Same iteration as the power-of-two fused path (rowdct_fused -> colsolve -> rowidct_p -> pq, the residual kept
 // as its row spectrum, rho and ||r|| by Parseval), same scalars and flags, so run_pcg() drives both with one
@@ -15,7 +15,7 @@
 // >= 2n - 1 per DCT pair instead of one of length n) and the separate pupdate / applyq / update / scal_* kernels:
 // 4 launches per iteration instead of 9.  (phase_unwrap.py:84-115 preconditioner, :326-349 iteration.)
 #pragma once
-#include "gpa_mrfft.h"
+#include "gpa_unwrap_impl.h"
 
 namespace gpa {
 namespace {

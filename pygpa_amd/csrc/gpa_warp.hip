@@ -257,7 +257,8 @@ hipError_t prefilter(const T* in, int m0, int m1, int ext, const T* d_h, T* tmp,
 }
 
 template <class T>
-hipError_t invert_constant_t(const T* d_u, int n0, int n1, T scale, int iters, int edge, int shift, T* d_out, hipStream_t s) {
+hipError_t invert_constant_t(const T* d_u, int n0, int n1, T scale, int iters, int edge, int shift, int nan_last, T* d_out,
+                             hipStream_t s) {
   const size_t npx = (size_t)n0 * n1;
   T *buf = nullptr, *d_h = nullptr;
   hipError_t e = hipMalloc((void**)&buf, 4 * npx * sizeof(T));   // scaled copy, tmp, coef0, coef1
@@ -270,8 +271,10 @@ hipError_t invert_constant_t(const T* d_u, int n0, int n1, T scale, int iters, i
   }
   if (e == hipSuccess) {
     const int o1 = n1 + 2 * edge, o0 = n0 + 2 * edge;
-    // invert_u_overlap (shift == 0) ends on a cval=nan round; invert_u (shift = edge) does not
-    invert_constant_kernel<T><<<dim3((o1 + 255) / 256, o0), 256, 0, s>>>(c0, c1, n0, n1, edge, shift, iters, shift == 0 ? 1 : 0, d_out);
+    // nan_last: invert_u_overlap ends on a cval=nan round (geometric_phase_analysis.py:296-299); invert_u never passes
+    // cval (:255-258) and keeps 0 outside -- said by the caller, not guessed from the geometry (invert_u with its
+    // default edge = 0 has shift == 0 too)
+    invert_constant_kernel<T><<<dim3((o1 + 255) / 256, o0), 256, 0, s>>>(c0, c1, n0, n1, edge, shift, iters, nan_last ? 1 : 0, d_out);
     e = hipGetLastError();
   }
   if (e == hipSuccess) e = hipStreamSynchronize(s);
@@ -326,10 +329,10 @@ hipError_t warp_t(const T* d_img, const T* d_uinv, int n0, int n1, T* d_out, hip
 
 // d_u: 2 x n0 x n1 (device); the field that is inverted is scale * u; d_out: 2 x (n0+2e) x (n1+2e)
 hipError_t warp_invert_u(int dtype, const void* d_u, int n0, int n1, double scale, int iters, int edge, int shift,
-                         void* d_out, hipStream_t s, int mode) {
+                         void* d_out, hipStream_t s, int mode, int nan_last) {
   if (mode == 1)
-    return dtype == 0 ? invert_constant_t<float>((const float*)d_u, n0, n1, (float)scale, iters, edge, shift, (float*)d_out, s)
-                      : invert_constant_t<double>((const double*)d_u, n0, n1, scale, iters, edge, shift, (double*)d_out, s);
+    return dtype == 0 ? invert_constant_t<float>((const float*)d_u, n0, n1, (float)scale, iters, edge, shift, nan_last, (float*)d_out, s)
+                      : invert_constant_t<double>((const double*)d_u, n0, n1, scale, iters, edge, shift, nan_last, (double*)d_out, s);
   return dtype == 0 ? invert_t<float>((const float*)d_u, n0, n1, (float)scale, iters, edge, shift, (float*)d_out, s)
                     : invert_t<double>((const double*)d_u, n0, n1, scale, iters, edge, shift, (double*)d_out, s);
 }

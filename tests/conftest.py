@@ -41,3 +41,18 @@ def kidx_mismatch_is_tie(amp_stack, kidx_a, kidx_b, rtol):
     aa = np.take_along_axis(amp_stack, ia[None], 0)[0]
     ab = np.take_along_axis(amp_stack, ib[None], 0)[0]
     return np.abs(aa - ab) <= rtol * amp_stack.max()
+
+
+@pytest.fixture
+def gpa_option():
+    """set diagnostic switches of the library (gpa_set_option) for one test; whatever was set is cleared afterwards"""
+    from pygpa_amd import _lib
+    touched = set()
+
+    def setter(name, value):
+        touched.add(name)
+        _lib.set_option(name, value)
+
+    yield setter
+    for name in touched:
+        _lib.set_option(name, None)

@@ -58,9 +58,9 @@ def _check_kidx_ties(kidx, ref_kidx, img0, klists, sigma, tie_tol):
 
 def _set_floor(v):
     if v is None:
-        os.environ.pop('GPA_F32_EPS_FLOOR', None)
+        _lib.set_option('F32_EPS_FLOOR', None)
     else:
-        os.environ['GPA_F32_EPS_FLOOR'] = v
+        _lib.set_option('F32_EPS_FLOOR', v)
 
 
 # ---- the sweep's compensation tables must survive per_dft / find_peaks / deconvolve -----
@@ -110,9 +110,9 @@ def test_graph_replay_equals_eager(dtype):
     ref = {(i, k): eager.extract_displacement_field(im, kvecs, kl, 10, 20)[0]
            for i, im in enumerate((img, img2)) for k, kl in (('a', kl_a), ('b', kl_b))}
     eager.close()
-    os.environ['GPA_USE_GRAPH'] = '1'          # read when the plan is created (opt-in: not faster on ROCm 7.2)
+    _lib.set_option('USE_GRAPH', '1')          # read when the plan is created (opt-in: not faster on ROCm 7.2)
     plan = _lib.Plan(shape, 12, dtype)
-    os.environ.pop('GPA_USE_GRAPH')
+    _lib.set_option('USE_GRAPH', None)
     d_img = [DeviceArray(img.astype(dtype)), DeviceArray(img2.astype(dtype))]
     outs = [DeviceArray(np.zeros((2,) + shape, dtype=dtype)) for _ in range(2)]
     seq = [(0, 'a', 0), (0, 'a', 0), (0, 'a', 0), (0, 'b', 0), (0, 'a', 0), (1, 'a', 1), (1, 'a', 1), (1, 'b', 1),

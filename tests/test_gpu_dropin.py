@@ -39,11 +39,11 @@ def test_displacement_field(testset):
     assert np.abs(u2 - u_true)[:, 20:-20, 20:-20].max() < np.abs(u1 - u_true)[:, 20:-20, 20:-20].max()
 
 
-def test_displacement_field_stack(testset, monkeypatch):
+def test_displacement_field_stack(testset, monkeypatch, gpa_option):
     """the stack form (one device call for all frames) returns what a loop over the reference-shaped
     extract_displacement_field returns, frame by frame, to the last bit (same kernels on both sides: GPA_NO_LAT,
     see test_image_stack_equals_single_images) -- and passes the reference's own bar"""
-    monkeypatch.setenv('GPA_NO_LAT', '1')
+    gpa_option('NO_LAT', '1')
     original, deformed, noise, ks, u_true = testset
     frames = np.stack([deformed + noise, deformed, deformed[::-1, ::-1] + 0.5 * noise])
     for dtype in (np.float64, np.float32):

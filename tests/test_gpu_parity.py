@@ -975,12 +975,12 @@ def test_transform_free_column_solve_equals_dct_solve(n, dtype):
     plan = _lib.Plan((n, n), 12, dtype)
     out = {}
     for mode in ('tri', 'fft'):
-        os.environ['GPA_COLSOLVE'] = mode
+        _lib.set_option('COLSOLVE', mode)
         try:
             out[mode] = plan.extract_displacement_field(img, kvecs, klists, 10, 20, kmax=10)
             out[mode + '_u'] = plan.unwrap(psi, w, kmax=40)
         finally:
-            os.environ.pop('GPA_COLSOLVE', None)
+            _lib.set_option('COLSOLVE', None)
     plan.close()
     tol = 1e-9 if dtype is np.float64 else 3e-5
     assert out['tri'][3] == out['fft'][3]
@@ -1000,9 +1000,9 @@ def test_candidate_split_pass_b_is_bit_identical(shape, knx, dtype):
     img = hex_moire(shape, kvecs, gaussian_bump_displacement(shape), noise=0.3, seed=21)
     klists = np.stack(explicit_klists(kvecs, 0.04, knx, knx))
     K = knx * knx
-    os.environ['GPA_NO_KSPLIT'] = '1'
+    _lib.set_option('NO_KSPLIT', '1')
     ref_plan = _lib.Plan(shape, 3 * K, dtype)
-    os.environ.pop('GPA_NO_KSPLIT')
+    _lib.set_option('NO_KSPLIT', None)
     plan = _lib.Plan(shape, 3 * K, dtype)
     a = ref_plan.extract_displacement_field(img, kvecs, klists, 10, 20, want_lockins=True, want_kidx=True)
     b = plan.extract_displacement_field(img, kvecs, klists, 10, 20, want_lockins=True, want_kidx=True)
@@ -1018,7 +1018,7 @@ def test_candidate_split_pass_b_is_bit_identical(shape, knx, dtype):
 @pytest.mark.gpu
 @pytest.mark.parametrize('dtype', DTYPES)
 @pytest.mark.parametrize('shape', [(300, 200), (1100, 600), (130, 1030)])
-def test_compact_padded_axes(shape, dtype, monkeypatch):
+def test_compact_padded_axes(shape, dtype, monkeypatch, gpa_option):
     """non-power-of-two axes, narrow spatial kernel: the plan switches to the compact extension (lags -E .. E,
     transform length pow2 >= n + 2E instead of >= 2n - 1) -- same numbers as the oracle and as the full
     extension, and switching sigma on one plan (compact -> full -> compact) restages every table"""
@@ -1028,9 +1028,9 @@ def test_compact_padded_axes(shape, dtype, monkeypatch):
     klist = explicit_klists(kvecs, 0.03, 3, 3)[0]
     plan = _lib.Plan(shape, len(klist), dtype)
     full_len = [plan.fft_len(0), plan.fft_len(1)]
-    monkeypatch.setenv('GPA_NO_COMPACT', '1')
+    gpa_option('NO_COMPACT', '1')
     plan_full = _lib.Plan(shape, len(klist), dtype)
-    monkeypatch.delenv('GPA_NO_COMPACT')
+    gpa_option('NO_COMPACT', None)
     for sigma in (4, 60, 4, 9):
         ref = orc.sweep(img0, sigma, klist, kvecs[0], workers=8)
         lock, kidx, _ = plan.sweep(img0, kvecs[0], klist, sigma)
@@ -1068,7 +1068,7 @@ def _unwrap_case(shape, seed, weighted=True):
 @pytest.mark.parametrize('shape', [(48, 80), (100, 60), (300, 200), (500, 500), (130, 104), (360, 364), (1000, 1500),
                                    (66, 88), (512, 384), (36, 36), (100, 100), (1000, 1000), (1200, 1200),
                                    (63, 65), (250, 250), (126, 90), (1001, 1001), (75, 77)])
-def test_mixed_radix_fused_unwrap_vs_oracle(shape, monkeypatch):
+def test_mixed_radix_fused_unwrap_vs_oracle(shape, monkeypatch, gpa_option):
     """image sizes that factor into 2, 3, 5, 7, 11, 13 run the fused 4-kernel PCG on the mixed-radix FFT (square ones
     with the transform-free column solve on ragged chunks; rows that are not whole 4-pixel vectors -- 63 x 65, 250^2,
     1001^2 -- through the one-pixel instantiations of the stencil, flush and row kernels):
@@ -1081,16 +1081,16 @@ def test_mixed_radix_fused_unwrap_vs_oracle(shape, monkeypatch):
         got, iters = plan.unwrap(psi, weight, kmax=kmax)
         assert rel(got, ref) < 1e-8, (shape, kmax)
         assert iters == ref_iters, (shape, kmax, iters, ref_iters)
-        monkeypatch.setenv('GPA_NO_MR', '1')
+        gpa_option('NO_MR', '1')
         plan_b = _lib.Plan(shape, 1, np.float64)
-        monkeypatch.delenv('GPA_NO_MR')
+        gpa_option('NO_MR', None)
         got_b, iters_b = plan_b.unwrap(psi, weight, kmax=kmax)
         assert iters_b == iters and rel(got, got_b) < 1e-9
         if shape[0] == shape[1]:
             # square: the columns are solved without a transform by default; the mixed-radix column kernel must agree
-            monkeypatch.setenv('GPA_COLSOLVE', 'fft')
+            gpa_option('COLSOLVE', 'fft')
             got_f, iters_f = plan.unwrap(psi, weight, kmax=kmax)
-            monkeypatch.delenv('GPA_COLSOLVE')
+            gpa_option('COLSOLVE', None)
             assert iters_f == iters and rel(got, got_f) < 1e-9
         plan32 = _lib.Plan(shape, 1, np.float32)
         got32, _ = plan32.unwrap(psi.astype(np.float32), None if weight is None else weight.astype(np.float32), kmax=kmax)
@@ -1139,7 +1139,7 @@ def test_random_smooth_shapes_unwrap_vs_oracle():
 
 @pytest.mark.gpu
 @pytest.mark.parametrize('shape', [(68, 68), (136, 116), (204, 236), (332, 332), (1392, 1040), (1006, 1004), (97, 101), (202, 202)])
-def test_chirpz_fused_unwrap_vs_oracle(shape, monkeypatch):
+def test_chirpz_fused_unwrap_vs_oracle(shape, monkeypatch, gpa_option):
     """sides with a prime factor > 13 (17, 29, 59, 83, 251, 503): the fused iteration with chirp-z DFTs on a smooth
     L >= 2n - 1 of the mixed-radix engine (transform-free columns when square) against the oracle and against
     the power-of-two Bluestein path (GPA_NO_MR=1)"""
@@ -1149,15 +1149,15 @@ def test_chirpz_fused_unwrap_vs_oracle(shape, monkeypatch):
         plan = _lib.Plan(shape, 1, np.float64)
         got, iters = plan.unwrap(psi, weight, kmax=kmax)
         assert rel(got, ref) < 1e-8 and iters == ref_iters, (shape, kmax, rel(got, ref), iters, ref_iters)
-        monkeypatch.setenv('GPA_NO_MR', '1')
+        gpa_option('NO_MR', '1')
         plan_b = _lib.Plan(shape, 1, np.float64)
-        monkeypatch.delenv('GPA_NO_MR')
+        gpa_option('NO_MR', None)
         got_b, iters_b = plan_b.unwrap(psi, weight, kmax=kmax)
         assert iters_b == iters and rel(got, got_b) < 1e-9
         if shape[0] == shape[1]:
-            monkeypatch.setenv('GPA_COLSOLVE', 'fft')   # the chirp-z column kernel instead of the recursions
+            gpa_option('COLSOLVE', 'fft')   # the chirp-z column kernel instead of the recursions
             got_f, iters_f = plan.unwrap(psi, weight, kmax=kmax)
-            monkeypatch.delenv('GPA_COLSOLVE')
+            gpa_option('COLSOLVE', None)
             assert iters_f == iters and rel(got, got_f) < 1e-9
         plan32 = _lib.Plan(shape, 1, np.float32)
         got32, _ = plan32.unwrap(psi.astype(np.float32), weight.astype(np.float32), kmax=kmax)
@@ -1167,15 +1167,15 @@ def test_chirpz_fused_unwrap_vs_oracle(shape, monkeypatch):
 
 
 @pytest.mark.gpu
-def test_chirpz_forced_on_smooth_lengths(monkeypatch):
+def test_chirpz_forced_on_smooth_lengths(monkeypatch, gpa_option):
     """GPA_MR_FORCE_BLUESTEIN=1: the chirp-z route on lengths that have a direct plan must give the direct route's
     iterates"""
     shape = (300, 200)
     psi, weight = _unwrap_case(shape, 3)
     plan = _lib.Plan(shape, 1, np.float64)
-    monkeypatch.setenv('GPA_MR_FORCE_BLUESTEIN', '1')
+    gpa_option('MR_FORCE_BLUESTEIN', '1')
     plan_z = _lib.Plan(shape, 1, np.float64)
-    monkeypatch.delenv('GPA_MR_FORCE_BLUESTEIN')
+    gpa_option('MR_FORCE_BLUESTEIN', None)
     a, ia = plan.unwrap(psi, weight, kmax=25)
     b, ib = plan_z.unwrap(psi, weight, kmax=25)
     assert ia == ib and rel(a, b) < 1e-9
@@ -1187,7 +1187,7 @@ def test_chirpz_forced_on_smooth_lengths(monkeypatch):
 @pytest.mark.parametrize('dtype', DTYPES)
 @pytest.mark.parametrize('shape', [(128, 128), (256, 512), (100, 60), (300, 300), (136, 116), (63, 65), (250, 250),
                                    (64, 2048), (72, 3000), (1024, 128), (512, 96)])
-def test_image_stack_equals_single_images(shape, dtype, monkeypatch):
+def test_image_stack_equals_single_images(shape, dtype, monkeypatch, gpa_option):
     """gpa_extract_displacement_field_batch_dev: a stack of images through one set of unwrap launches
     (blockIdx.z = problem) -- every image's u and iteration counts equal the single-image driver's bit for bit
     (power-of-two, smooth, square smooth with transform-free columns, chirp-z sizes; rows that take the shared-forward
@@ -1195,7 +1195,7 @@ def test_image_stack_equals_single_images(shape, dtype, monkeypatch):
     kernels on both sides (GPA_NO_LAT=1: a single small power-of-two image otherwise runs latency-tuned
     instantiations of the row / column kernels, whose multiply-adds the compiler contracts differently); with the
     default kernels: to rounding, 2e-5 (f32) / 1e-12 (f64) of max |u|, and the same iteration counts."""
-    monkeypatch.setenv('GPA_NO_LAT', '1')
+    gpa_option('NO_LAT', '1')
     kvecs = hex_kvecs(0.12, 5.0)
     sigma = 5
     klists = np.stack(explicit_klists(kvecs, 0.04, 2, 2))
@@ -1216,7 +1216,7 @@ def test_image_stack_equals_single_images(shape, dtype, monkeypatch):
     u_c, it_c = plan.extract_displacement_field_stack(imgs, kvecs, klists, sigma, 2 * sigma, kmax=10, chunk=2)
     assert np.array_equal(u_c, u_b) and np.array_equal(it_c, it_b)
     # default kernels for the single image
-    monkeypatch.delenv('GPA_NO_LAT')
+    gpa_option('NO_LAT', None)
     # (2e-5: the 64 x 2048 frames reach 1.01e-5)
     tol = (2e-5 if dtype == np.float32 else 1e-12) * float(np.abs(u_b).max())
     for i in range(B):
@@ -1227,12 +1227,12 @@ def test_image_stack_equals_single_images(shape, dtype, monkeypatch):
 
 
 @pytest.mark.gpu
-def test_random_stacks_equal_single_images(monkeypatch):
+def test_random_stacks_equal_single_images(monkeypatch, gpa_option):
     """(GPA_NO_LAT=1: the same kernels for a stack and for a single image, see test_image_stack_equals_single_images)
     seeded random (shape, stack size, precision) draws -- any parity of the sides, power-of-two, smooth and chirp-z
     lengths mixed -- the stack call equals the single-image driver frame for frame, bit for bit.
     GPA_TEST_RANDOM_CASES / GPA_TEST_RANDOM_SEED widen the sweep."""
-    monkeypatch.setenv('GPA_NO_LAT', '1')
+    gpa_option('NO_LAT', '1')
     rng = np.random.default_rng(int(os.environ.get('GPA_TEST_RANDOM_SEED', '5')))
     want = max(4, int(os.environ.get('GPA_TEST_RANDOM_CASES', '10')) // 2)
     sizes = [32, 48, 60, 63, 64, 65, 68, 75, 96, 100, 116, 128, 130, 160, 250, 256]
@@ -1261,7 +1261,7 @@ def test_random_stacks_equal_single_images(monkeypatch):
 @pytest.mark.gpu
 @pytest.mark.parametrize('dtype', DTYPES)
 @pytest.mark.parametrize('n', [256, 512, 1024])
-def test_latency_tuned_kernels_equal_lean_kernels(n, dtype, monkeypatch):
+def test_latency_tuned_kernels_equal_lean_kernels(n, dtype, monkeypatch, gpa_option):
     """One image up to 1024^2 runs latency-tuned instantiations of the fused PCG kernels (every input requested before
     the first wait; pq_small_kernel instead of the sliding-window stencil); stacks and larger images run the lean ones.
     Same formulas: the driver's u agrees to rounding (1e-5 / 1e-12 of max |u|) with the same iteration counts, and both
@@ -1273,9 +1273,9 @@ def test_latency_tuned_kernels_equal_lean_kernels(n, dtype, monkeypatch):
     img = hex_moire(shape, kvecs, 0.5 * gaussian_bump_displacement(shape), noise=0.1, seed=3)
     plan = _lib.Plan(shape, 12, dtype)
     u_lat, _, _, it_lat = plan.extract_displacement_field(img, kvecs, klists, sigma, 2 * sigma, kmax=10)
-    monkeypatch.setenv('GPA_NO_LAT', '1')
+    gpa_option('NO_LAT', '1')
     u_lean, _, _, it_lean = plan.extract_displacement_field(img, kvecs, klists, sigma, 2 * sigma, kmax=10)
-    monkeypatch.delenv('GPA_NO_LAT')
+    gpa_option('NO_LAT', None)
     assert tuple(it_lat) == tuple(it_lean)
     tol = (1e-5 if dtype == np.float32 else 1e-12) * float(np.abs(u_lean).max())
     assert float(np.abs(u_lat - u_lean).max()) <= tol

@@ -35,7 +35,7 @@ def _sweep(shape, dtype, img0, kref, klist, sigma):
 @pytest.mark.parametrize('shape,grid', [((96, 4096), (4, 4)), ((80, 2048), (4, 2)), ((72, 4096), (3, 7)), ((2304, 1024), (4, 4)),
                                         ((96, 3000), (4, 4)), ((80, 1500), (4, 2)), ((60, 1000), (3, 3)), ((2100, 700), (4, 4)),
                                         ((40, 8192), (4, 4)), ((36, 6000), (4, 2)), ((32, 8100), (3, 3))])
-def test_shared_passb_vs_oracle_and_end_columns(shape, grid, dtype, monkeypatch):
+def test_shared_passb_vs_oracle_and_end_columns(shape, grid, dtype, monkeypatch, gpa_option):
     """8192- (f32: four-pass transforms; f64 stays on the per-candidate kernel), 4096-, 2048- and (tall) 1024-wide sweeps (the last on the per-candidate kernel), and rows that are not powers of two (zero-padded to >= n + E: the end
     fix then supplies EVERY wrapped pair): winner index identical to the oracle in f64 (up to exact amplitude
     ties in f32), values within the lock-in tolerance everywhere AND in the first / last 3 sigma columns on their own;
@@ -56,7 +56,7 @@ def test_shared_passb_vs_oracle_and_end_columns(shape, grid, dtype, monkeypatch)
     assert d.max() < TOL[dtype]['lock']
     assert max(d[:, :e3].max(), d[:, -e3:].max()) < TOL[dtype]['lock']
     # and the kernel it replaces gives the same numbers to rounding
-    monkeypatch.setenv('GPA_NO_SHARED', '1')
+    gpa_option('NO_SHARED', '1')
     lock_old, kidx_old = _sweep(shape, dtype, img0, kref, klist, sigma)
     both = kidx == kidx_old
     assert both.mean() > 0.9999
@@ -134,12 +134,12 @@ def test_shared_passb_zero_rows_and_driver(dtype):
 
 @pytest.mark.parametrize('dtype', DTYPES)
 @pytest.mark.parametrize('shape', [(2048, 96), (4096, 64), (3000, 80), (1500, 72)])
-def test_shared_pass_a_opt_in(shape, dtype, monkeypatch):
+def test_shared_pass_a_opt_in(shape, dtype, monkeypatch, gpa_option):
     """the shared-forward pass A (GPA_SHARED_A=1: one forward transform per column for all x-planes, end fix of the
     first / last rows on the matrix cores) -- measured slower than the per-plane kernel and therefore off by default,
     its numbers pinned all the same: oracle's lock-ins (all of them, gpa_lockin_batch, and the sweep's winners), the
     first / last 3 sigma ROWS on their own, periodic and zero-padded columns"""
-    monkeypatch.setenv('GPA_SHARED_A', '1')
+    gpa_option('SHARED_A', '1')
     kvecs = hex_kvecs(0.1, 7.0)
     img = hex_moire(shape, kvecs, gaussian_bump_displacement(shape), noise=0.2, seed=6)
     img0 = img - img.mean()

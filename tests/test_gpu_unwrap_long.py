@@ -1,0 +1,152 @@
+"""GPU parity tests of the weighted unwrap (a7, phase_unwrap.py:282-350) on LONG axes and of the streamed column
+solve -- the kernel instantiations the 8192^2 and 16384^2 global solves of BASELINE configs[3] / [4] select.
+
+The reference is one code path for every size; this build runs different kernels from 8192 points on (four-pass row
+transforms, 4-wave rowidct_p, the streamed recursion down the columns).  Every one of them is held to the ORACLE here:
+  * elongated images (64 x 16384, 16384 x 64, 96 x 8192, 8192 x 96, 128 x 8192 ...): the long-row kernels and the
+    long-column DCT kernel against the oracle, which costs < 1 s at these shapes.  (Aspect ratios >= 2: the reference's
+    swapped-axis eigenvalue table is singular there and its result NaN; device and oracle use the true eigenvalues,
+    as in test_unwrap_elongated_images.)
+  * square images: the streamed column solve (gpa_unwrap_colstream.hip) against the oracle at 256^2 ... 2048^2 in both
+    precisions, ragged sizes included, and at 8192^2 (f32, 3 iterations: the oracle needs ~1 minute there);
+    against the resident column kernels (DCT / transform-free) at 4096^2.
+Which kernels ran is asserted through gpa_last_kernel_profile.
+
+Tolerances (relative to max |phi|): f64 1e-8, f32 5e-5 (a 16384-point f32 transform carries ~1e-6 per pass)."""
+import numpy as np
+import pytest
+
+from oracle import gpa_oracle as orc
+from pygpa_amd import _lib
+
+pytestmark = pytest.mark.gpu
+
+
+def rel(a, b):
+    return float(np.abs(a - b).max() / max(np.abs(b).max(), 1e-300))
+
+
+def make_problem(shape, seed, rough=False):
+    """wrapped noisy phase of a smooth field + a weight with structure; returns dx, dy (pre-differenced) and weight"""
+    rng = np.random.default_rng(seed)
+    n0, n1 = shape
+    x = np.arange(n0)[:, None] / float(n0)
+    y = np.arange(n1)[None, :] / float(n1)
+    phi = 40.0 * x + 25.0 * y + 6.0 * np.sin(2 * np.pi * (1.5 * x + 0.5 * y)) * np.cos(2 * np.pi * 2.0 * y)
+    psi = orc.wrap_to_pi(phi + (0.3 if rough else 0.05) * rng.normal(size=shape))
+    weight = (0.05 + rng.random(shape)) if rough else (0.5 + 0.5 * np.cos(2 * np.pi * 3 * x) * np.cos(2 * np.pi * 2 * y) + 0.2 * rng.random(shape))
+    weight = np.abs(weight) + 0.02
+    return np.diff(psi, axis=1), np.diff(psi, axis=0), weight
+
+
+def solve_profiled(shape, dtype, dx, dy, w, kmax):
+    plan = _lib.Plan(shape, 1, dtype)
+    plan.set_profiling(True)
+    phi, it = plan.unwrap_prediff(dx, dy, w, kmax=kmax)
+    prof = plan.last_kernel_profile()
+    plan.close()
+    return phi, it, prof
+
+
+# (both sides powers of two: the power-of-two kernels; 96 x 8192 / 8192 x 96 run the same long axes on the mixed-radix
+#  engine, whose kernels share the profile names)
+LONG_SHAPES = [((64, 16384), [np.float32]), ((16384, 64), [np.float32]),
+               ((128, 8192), [np.float32, np.float64]), ((8192, 128), [np.float32, np.float64]),
+               ((96, 8192), [np.float32]), ((8192, 96), [np.float32]), ((2048, 8192), [np.float32])]
+
+
+@pytest.mark.parametrize('shape,dtypes', LONG_SHAPES)
+def test_long_axis_unwrap_vs_oracle(shape, dtypes):
+    """8192- and 16384-point rows / columns against the oracle, weighted, kmax 10: the four-pass rowdct_fused / rowidct_p
+    instantiations (rows) and the long-column DCT kernel (columns)"""
+    dx, dy, w = make_problem(shape, seed=shape[0] + shape[1])
+    ref, ref_it = orc.unwrap_prediff(dx, dy, w, kmax=10, compat=False, return_iters=True)
+    for dtype in dtypes:
+        phi, it, prof = solve_profiled(shape, dtype, dx, dy, w, 10)
+        tol = 1e-8 if dtype is np.float64 else 5e-5
+        assert np.isfinite(phi).all()
+        assert rel(phi, ref) < tol, (shape, np.dtype(dtype).name, rel(phi, ref))
+        if dtype is np.float64:
+            assert it == ref_it
+        # the fused iteration ran (rows up to 512 pixels: row kernel and stencil in one launch)
+        want = ['rowdct_fused_kernel', 'colsolve_kernel', 'phi_flush_kernel']
+        want += ['rowidct_pq_kernel'] if (shape[1] <= 512 and shape[0] & (shape[0] - 1) == 0) else ['rowidct_p_kernel', 'pq_kernel']
+        for k in want:
+            assert k in prof and prof[k][0] >= 1, (k, sorted(prof))
+
+
+@pytest.mark.parametrize('dtype', [np.float64, np.float32])
+@pytest.mark.parametrize('n', [256, 500, 1000, 1024, 2048])
+def test_streamed_column_solve_vs_oracle(n, dtype, gpa_option):
+    """square images with the streamed column solve forced (COLSOLVE=stream): chunk sums -> scan -> recursions, against the
+    oracle's dctn / idctn preconditioner; 500 and 1000 are ragged (last chunk short, columns not a multiple of 256)"""
+    shape = (n, n)
+    dx, dy, w = make_problem(shape, seed=n, rough=True)
+    ref, ref_it = orc.unwrap_prediff(dx, dy, w, kmax=12, return_iters=True)
+    gpa_option('COLSOLVE', 'stream')
+    phi, it, prof = solve_profiled(shape, dtype, dx, dy, w, 12)
+    for k in ('colstream_agg_kernel', 'colstream_scan_kernel', 'colstream_apply_kernel'):
+        assert k in prof, sorted(prof)
+    assert 'colsolve_kernel' not in prof and 'colsolve_tri_kernel' not in prof
+    assert rel(phi, ref) < (1e-8 if dtype is np.float64 else 5e-5), rel(phi, ref)
+    if dtype is np.float64:
+        assert it == ref_it
+    # unweighted, a different chunk height
+    gpa_option('COLSTREAM_CHUNK', '32' if n >= 1024 else '64')
+    ref_u = orc.unwrap_prediff(dx, dy, None, kmax=5)
+    plan = _lib.Plan(shape, 1, dtype)
+    phi_u, _ = plan.unwrap_prediff(dx, dy, None, kmax=5)
+    plan.close()
+    assert rel(phi_u, ref_u) < (1e-8 if dtype is np.float64 else 5e-5)
+
+
+@pytest.mark.parametrize('dtype', [np.float64, np.float32])
+def test_streamed_column_solve_equals_resident_kernels_4096(dtype, gpa_option):
+    """4096^2 (the headline size; the streamed solve is its default): same iterates as the resident column kernels --
+    the DCT kernel and the transform-free recursion -- iteration counts equal in f64, phi within the PCG tolerance"""
+    n = 4096
+    dx, dy, w = make_problem((n, n), seed=7, rough=True)
+    out = {}
+    for mode in ('stream', 'tri', 'fft'):
+        gpa_option('COLSOLVE', mode)
+        phi, it, prof = solve_profiled((n, n), dtype, dx, dy, w, 10)
+        out[mode] = (phi, it)
+        want = {'stream': 'colstream_apply_kernel', 'tri': 'colsolve_tri_kernel', 'fft': 'colsolve_kernel'}[mode]
+        assert want in prof, (mode, sorted(prof))
+    gpa_option('COLSOLVE', None)
+    phi, it, prof = solve_profiled((n, n), dtype, dx, dy, w, 10)
+    assert 'colstream_apply_kernel' in prof            # the default at this size
+    tol = 1e-9 if dtype is np.float64 else 5e-5
+    for mode in ('tri', 'fft'):
+        assert rel(out['stream'][0], out[mode][0]) < tol, (mode, rel(out['stream'][0], out[mode][0]))
+        if dtype is np.float64:
+            assert out['stream'][1] == out[mode][1]
+    assert np.array_equal(phi, out['stream'][0])
+
+
+def test_unwrap_8192_square_vs_oracle():
+    """the 8192^2 global solve of BASELINE configs[3] against the ORACLE at full size (f32, weighted, 3 iterations: the
+    oracle's 8192^2 DCTs take about a minute on the host): four-pass row kernels + the streamed column solve"""
+    n = 8192
+    dx, dy, w = make_problem((n, n), seed=11)
+    ref = orc.unwrap_prediff(dx, dy, w, kmax=3, workers=-1)
+    phi, it, prof = solve_profiled((n, n), np.float32, dx, dy, w, 3)
+    assert it == 3
+    for k in ('rowdct_fused_kernel', 'rowidct_p_kernel', 'colstream_agg_kernel', 'colstream_scan_kernel', 'colstream_apply_kernel'):
+        assert k in prof, sorted(prof)
+    assert rel(phi, ref) < 5e-5, rel(phi, ref)
+
+
+@pytest.mark.parametrize('n', [8192, 16384])
+def test_long_square_streamed_vs_resident_columns(n, gpa_option):
+    """8192^2 and 16384^2 (f32): the streamed column solve against the resident transform-free kernel it replaces
+    (16 rows per thread at 16384 points), 4 iterations; and the fused driver's iteration counts agree"""
+    dx, dy, w = make_problem((n, n), seed=n)
+    out = {}
+    for mode in ('stream', 'tri'):
+        gpa_option('COLSOLVE', mode)
+        phi, it, prof = solve_profiled((n, n), np.float32, dx, dy, w, 4)
+        out[mode] = phi
+        assert ('colstream_apply_kernel' if mode == 'stream' else 'colsolve_tri_kernel') in prof, sorted(prof)
+        assert it == 4
+    assert rel(out['stream'], out['tri']) < 5e-5, rel(out['stream'], out['tri'])
