@@ -68,11 +68,13 @@ __device__ __forceinline__ double reread(T v) {
 template <class T, int C, bool RAGGED>
 __global__ __launch_bounds__(CS_COLS) void colstream_agg_kernel(const T* __restrict__ R, int n0, int n1,
                                                                const double* __restrict__ lamtab, double2* __restrict__ agg,
-                                                               const int* flags, size_t pimg, size_t pagg) {
+                                                               double2* __restrict__ agg0, int S, const int* flags, size_t pimg,
+                                                               size_t pagg) {
   {
     const size_t pb = blockIdx.z;
     R += pb * pimg;
     agg += pb * pagg;
+    agg0 += pb * S;
     flags += pb * FLAGS_N;
   }
   if (flags[1]) return;   // (stopped in an EARLIER iteration; this iteration's test is the scan kernel's)
@@ -104,6 +106,19 @@ __global__ __launch_bounds__(CS_COLS) void colstream_agg_kernel(const T* __restr
     if ((k & 7) == 0) __builtin_amdgcn_sched_barrier(0);
   }
   if (cv) agg[(size_t)s * n1 + y] = make_double2(a, b);
+  if (y == 0) {
+    // column 0 (lam = 1, the row means) is solved on r - mean with the mean of z removed afterwards (scan kernel): that
+    // needs, of the zero-start running sum p0_k of the chunk, c = sum_k p0_k and d = sum_k (k + 1) p0_k as well
+    double p0 = 0.0, c = 0.0, d = 0.0;
+#pragma unroll
+    for (int k = 0; k < C; ++k)
+      if (!RAGGED || k < len) {
+        p0 += reread(x[k]);
+        c += p0;
+        d += (double)(k + 1) * p0;
+      }
+    agg0[s] = make_double2(c, d);
+  }
 }
 
 // ---- launch 2: the scan over the chunks of every column ------------------------------------------
@@ -111,20 +126,20 @@ __global__ __launch_bounds__(CS_COLS) void colstream_agg_kernel(const T* __restr
 // index's high part so that a wavefront reads 64 adjacent columns.  Three linear recurrences over the chunks --
 //   A (from the last chunk up), B and the chunk-end p (from the first chunk down), the chunk-start z (from the last up)
 // -- each as: compose the segment's chunks (registers), exchange the G segment results through LDS, apply.
-template <class T, int G, int M>
-__global__ __launch_bounds__(64 * G) void colstream_scan_kernel(const T* __restrict__ R, T* __restrict__ Z, int n0, int n1, int C, int S,
-                                                               const StreamCol* __restrict__ tab,
-                                                               const double2* __restrict__ agg, double* __restrict__ carP, double* __restrict__ carZ,
+template <int G, int M>
+__global__ __launch_bounds__(64 * G) void colstream_scan_kernel(int n0, int n1, int C, int S, const StreamCol* __restrict__ tab,
+                                                               const double2* __restrict__ agg, const double2* __restrict__ agg0,
+                                                               double* __restrict__ carP, double* __restrict__ carZ, double* __restrict__ col0,
                                                                int* flags, const double* part_norm, int nnorm, int it, double eps,
                                                                double* scal, double* part_rho, int rho_slot, size_t pimg,
                                                                size_t pagg) {
   {
     const size_t pb = blockIdx.z;
-    R += pb * pimg;
-    Z += pb * pimg;
     agg += pb * pagg;
+    agg0 += pb * S;
     carP += pb * pagg;
     carZ += pb * pagg;
+    col0 += pb * 2;
     flags += pb * FLAGS_N;
     scal += pb * SCAL_N;
     part_norm += pb * PART_N;
@@ -151,44 +166,71 @@ __global__ __launch_bounds__(64 * G) void colstream_scan_kernel(const T* __restr
   const int ncb = (n1 + 63) / 64;   // column blocks; the block after them solves column 0
   if ((int)blockIdx.x == ncb) {
     // ---- column 0 (lam = 1, the row means): z = T^+ (r - mean) + mean, i.e. p = cumsum(r - mean), z_n = -sum_(m >= n) p_m,
-    // then the mean of z removed and the mean of r added (its DC bin is divided by 1).  One workgroup, thread t owns
-    // rows [t m, (t + 1) m).
-    const int nt = 64 * G, m = (n0 + nt - 1) / nt, t = threadIdx.x;
-    const int ra = t * m < n0 ? t * m : n0, rb = (t + 1) * m < n0 ? (t + 1) * m : n0;
-    const T* col = R;
-    double sum = 0.0;
-    for (int n = ra; n < rb; ++n) sum += (double)col[(size_t)n * n1];
-    const double shift0 = block_sum(sum, shn) / (double)n0;
-    // p at the end of the rows of the threads in front of this one
-    double total;
-    const double before = block_excl_scan(sum - (double)(rb - ra) * shift0, shn, &total);
-    // local p: its sum (for the z of the rows above), sum_n (n + 1) p_n (= -sum_n z_n) and sum p^2 over rows 0 .. N-2
-    double p = before, psum = 0.0, wsum = 0.0, dsq = 0.0;
-    for (int n = ra; n < rb; ++n) {
-      p += (double)col[(size_t)n * n1] - shift0;
-      psum += p;
-      wsum += (double)(n + 1) * p;
-      if (n < n0 - 1) dsq += p * p;
-    }
-    const double pfront = block_excl_scan(psum, shn, &total);
-    const double after = total - pfront - psum;         // sum of p over the rows of the threads behind this one
-    const double zs = -block_sum(wsum, shn);             // sum_n z_n,  z_n = -sum_(m >= n) p_m
-    const double fix = shift0 - zs / (double)n0;
-    {
-      double pp = before, run = psum;                    // run = sum of the local p from row n on
-      for (int n = ra; n < rb; ++n) {
-        Z[(size_t)n * n1] = (T)(-(after + run) + fix);
-        pp += (double)col[(size_t)n * n1] - shift0;
-        run -= pp;
+    // then the mean of z removed and the mean of r added (the reference divides its DC bin by 1, phase_unwrap.py:110-114).
+    // From the chunk sums b = sum r, c, d of colstream_agg_kernel; one wavefront, lane i owns chunks [i NJ, (i + 1) NJ).
+    if (threadIdx.x >= 64) return;
+    constexpr int NJ = (G * M + 63) / 64;
+    auto wave_incl = [&](double v) {
+#pragma unroll
+      for (int off = 1; off < 64; off <<= 1) {
+        const double t = __shfl_up(v, off);
+        if (lane >= off) v += t;
       }
+      return v;
+    };
+    double bj[NJ], cj[NJ], dj[NJ], lj[NJ];
+    double bsum = 0.0;
+#pragma unroll
+    for (int j = 0; j < NJ; ++j) {
+      const int sc = lane * NJ + j;
+      const bool v = sc < S;
+      const double2 cd = v ? agg0[sc] : make_double2(0.0, 0.0);
+      bj[j] = v ? agg[(size_t)sc * n1].y : 0.0;
+      cj[j] = cd.x;
+      dj[j] = cd.y;
+      lj[j] = !v ? 0.0 : (double)(sc == S - 1 ? n0 - (S - 1) * C : C);
+      bsum += bj[j];
     }
-    // rho of column 0 (colsolve_tri_kernel: r = -dsq + N shift0^2, times c_0 = 1/2)
-    const double d = block_sum(dsq, shn);
-    if (threadIdx.x == 0) part_rho[rho_slot] = 0.5 * (-d + (double)n0 * shift0 * shift0) / (2.0 * (double)n1);
+    const double shift0 = __shfl(wave_incl(bsum), 63) / (double)n0;
+    // p entering every chunk
+    double lp = 0.0;
+#pragma unroll
+    for (int j = 0; j < NJ; ++j) lp += bj[j] - lj[j] * shift0;
+    double Pin = wave_incl(lp) - lp;
+    double pin[NJ], ps[NJ], ws = 0.0, lps = 0.0;
+#pragma unroll
+    for (int j = 0; j < NJ; ++j) {
+      const int sc = lane * NJ + j;
+      const double len = lj[j], tri = 0.5 * len * (len + 1.0);
+      pin[j] = Pin;
+      ps[j] = len * Pin + cj[j] - shift0 * tri;                                   // sum of p over the chunk
+      ws += (double)sc * (double)C * ps[j] + dj[j] - shift0 * tri * (2.0 * len + 1.0) / 3.0 + Pin * tri;   // sum (n + 1) p_n
+      lps += ps[j];
+      Pin += bj[j] - len * shift0;
+    }
+    const double incl = wave_incl(lps), total = __shfl(incl, 63);
+    double after = total - incl;                         // sum of p over the chunks of the lanes behind this one
+    const double zs = -__shfl(wave_incl(ws), 63);        // sum_n z_n
+    const double fix = shift0 - zs / (double)n0;
+#pragma unroll
+    for (int j = NJ - 1; j >= 0; --j) {
+      const int sc = lane * NJ + j;
+      if (sc < S) {
+        carP[(size_t)sc * n1] = pin[j];
+        carZ[(size_t)sc * n1] = -after;                  // z entering the chunk from below
+      }
+      after += ps[j];
+    }
+    if (lane == 0) {
+      col0[0] = shift0;
+      col0[1] = fix;
+      // (colsolve_tri_kernel: rho of column 0 = (-sum p^2 + N shift0^2) c_0, c_0 = 1/2; the sum is the apply kernel's)
+      part_rho[rho_slot] = 0.5 * (double)n0 * shift0 * shift0 / (2.0 * (double)n1);
+    }
     return;
   }
   const int y = blockIdx.x * 64 + lane;
-  const bool cv = y < n1 && y > 0;     // (column 0 is the last workgroup's)
+  const bool cv = y < n1 && y > 0;     // (column 0 is the extra workgroup's)
   const int yc = y < n1 ? y : 0;
   const StreamCol tc = tab[yc];
   const int s0 = g * M;                // first chunk of this thread's segment
@@ -268,21 +310,22 @@ template <class T, int C, bool RAGGED>
 __global__ __launch_bounds__(CS_COLS) void colstream_apply_kernel(const T* __restrict__ R, T* __restrict__ Z, int n0, int n1, int S,
                                                                  const double* __restrict__ lamtab, const T* __restrict__ hb,
                                                                  const double* __restrict__ carP,
-                                                                 const double* __restrict__ carZ, const int* flags,
-                                                                 double* part_rho, size_t pimg, size_t pagg) {
+                                                                 const double* __restrict__ carZ, const double* __restrict__ col0,
+                                                                 const int* flags, double* part_rho, size_t pimg, size_t pagg) {
   {
     const size_t pb = blockIdx.z;
     R += pb * pimg;
     Z += pb * pimg;
     carP += pb * pagg;
     carZ += pb * pagg;
+    col0 += pb * 2;
     flags += pb * FLAGS_N;
     part_rho += pb * PART_N;
   }
   if (flags[1]) return;
   __shared__ double shn[CS_COLS];
   const int y = blockIdx.x * CS_COLS + threadIdx.x, s = blockIdx.y;
-  const bool cv = (!RAGGED || y < n1) && y > 0;   // column 0 is solved by the scan kernel
+  const bool cv = !RAGGED || y < n1;
   const int yc = (!RAGGED || y < n1) ? y : 0;
   const int row0 = s * C;
   const int len = !RAGGED ? C : (n0 - row0 < C ? n0 - row0 : C);
@@ -297,6 +340,8 @@ __global__ __launch_bounds__(CS_COLS) void colstream_apply_kernel(const T* __res
   const double lam = lamtab[yc];
   const double cp = carP[(size_t)s * n1 + yc], cz = carZ[(size_t)s * n1 + yc];
   const double mu2 = 2.0 * (double)hb[yc];
+  // column 0: r - mean goes in, z + (mean of r - mean of z) comes out (both from the scan kernel); any other column: 0, 0
+  const double sh0 = y == 0 ? col0[0] : 0.0, fx0 = y == 0 ? col0[1] : 0.0;
   // causal recursion from the true carry, in place (stored in the data's precision, as colsolve_tri_kernel does)
   // (scheduling fences every 8 rows: left alone, hipcc hoists the f32 -> f64 conversions of all C samples to the top of
   //  the chain and keeps 2 C more registers alive)
@@ -304,7 +349,7 @@ __global__ __launch_bounds__(CS_COLS) void colstream_apply_kernel(const T* __res
 #pragma unroll
   for (int k = 0; k < C; ++k) {
     if (!RAGGED || k < len) {
-      p = (double)x[k] + lam * p;
+      p = ((double)x[k] - sh0) + lam * p;
       x[k] = (T)p;
     }
     if ((k & 7) == 7) __builtin_amdgcn_sched_barrier(0);
@@ -319,7 +364,7 @@ __global__ __launch_bounds__(CS_COLS) void colstream_apply_kernel(const T* __res
       if (!(last && k == len - 1)) dsq += (z - zn) * (z - zn);
       zsq += zn * zn;
       z = zn;
-      x[k] = (T)zn;
+      x[k] = (T)(zn + fx0);
     }
     if ((k & 7) == 0) {
       // (the two sums are pinned here: hipcc otherwise sinks their whole accumulation behind the stores and keeps every
@@ -336,7 +381,8 @@ __global__ __launch_bounds__(CS_COLS) void colstream_apply_kernel(const T* __res
       zp += n1;
     }
   }
-  const double tot = block_sum(cv ? -dsq - mu2 * zsq : 0.0, shn);
+  const double rr = (-dsq - mu2 * zsq) * (y == 0 ? 0.5 : 1.0);   // (c_0 = 1/2 of SciPy's DCT-II normalisation along the rows)
+  const double tot = block_sum(cv ? rr : 0.0, shn);
   if (threadIdx.x == 0) part_rho[(size_t)blockIdx.y * gridDim.x + blockIdx.x] = tot / (2.0 * (double)n1);
 }
 
@@ -350,19 +396,24 @@ hipError_t run_stream(const Impl* w, int compat, hipStream_t s, const double* pa
   const int nparts = grid.x * grid.y;
   if (nparts + 1 > MAXPART) return hipErrorInvalidValue;
   const T* R = (const T*)(zin ? zin : w->z);
+  // column 0's own chunk sums and its two scalars live behind the carries: [cap][S] double2, [cap][2] doubles
+  double* carP = (double*)w->strcar;
+  double* carZ = carP + w->cap * pagg;
+  double2* agg0 = (double2*)(carZ + w->cap * pagg);
+  double* col0 = (double*)(agg0 + (size_t)w->cap * S);
   {
     GPA_PROF("colstream_agg_kernel", s);
-    if (ragged) colstream_agg_kernel<T, C, true><<<grid, CS_COLS, 0, s>>>(R, n0, n1, w->strlam, (double2*)w->stragg, w->flags, pimg, pagg);
-    else colstream_agg_kernel<T, C, false><<<grid, CS_COLS, 0, s>>>(R, n0, n1, w->strlam, (double2*)w->stragg, w->flags, pimg, pagg);
+    if (ragged) colstream_agg_kernel<T, C, true><<<grid, CS_COLS, 0, s>>>(R, n0, n1, w->strlam, (double2*)w->stragg, agg0, S, w->flags, pimg, pagg);
+    else colstream_agg_kernel<T, C, false><<<grid, CS_COLS, 0, s>>>(R, n0, n1, w->strlam, (double2*)w->stragg, agg0, S, w->flags, pimg, pagg);
   }
   {
     GPA_PROF("colstream_scan_kernel", s);
     const dim3 gs((n1 + 63) / 64 + 1, 1, w->nprob);
     // segments per column x chunks per segment: G * M >= S
 #define GPA_SCAN(GG, MM)                                                                                                   \
-  colstream_scan_kernel<T, GG, MM><<<gs, 64 * GG, 0, s>>>(R, (T*)w->z, n0, n1, C, S, (const StreamCol*)w->strtab,           \
-                                                          (const double2*)w->stragg, (double*)w->strcar, (double*)w->strcar + w->cap * pagg, w->flags, part_norm, \
-                                                          nnorm, it, eps, w->scal, part_rho, nparts, pimg, pagg)
+  colstream_scan_kernel<GG, MM><<<gs, 64 * GG, 0, s>>>(n0, n1, C, S, (const StreamCol*)w->strtab, (const double2*)w->stragg, \
+                                                          agg0, carP, carZ, col0, w->flags, part_norm, nnorm, it, eps, w->scal, \
+                                                          part_rho, nparts, pimg, pagg)
     if (S <= 16) GPA_SCAN(4, 4);
     else if (S <= 32) GPA_SCAN(8, 4);
     else if (S <= 64) GPA_SCAN(8, 8);
@@ -375,12 +426,10 @@ hipError_t run_stream(const Impl* w, int compat, hipStream_t s, const double* pa
     GPA_PROF("colstream_apply_kernel", s);
     if (ragged)
       colstream_apply_kernel<T, C, true><<<grid, CS_COLS, 0, s>>>(R, (T*)w->z, n0, n1, S, w->strlam, (const T*)w->hb1[compat],
-                                                                 (const double*)w->strcar, (const double*)w->strcar + w->cap * pagg,
-                                                                 w->flags, part_rho, pimg, pagg);
+                                                                 carP, carZ, col0, w->flags, part_rho, pimg, pagg);
     else
       colstream_apply_kernel<T, C, false><<<grid, CS_COLS, 0, s>>>(R, (T*)w->z, n0, n1, S, w->strlam, (const T*)w->hb1[compat],
-                                                                  (const double*)w->strcar, (const double*)w->strcar + w->cap * pagg,
-                                                                 w->flags, part_rho, pimg, pagg);
+                                                                  carP, carZ, col0, w->flags, part_rho, pimg, pagg);
   }
   if (nrho) *nrho = nparts + 1;
   return hipGetLastError();
@@ -427,7 +476,7 @@ hipError_t build_streamtab(Impl* w, hipStream_t s, size_t* bytes) {
   if (e == hipSuccess) e = hipMalloc((void**)&w->strlam, lam.size() * sizeof(double));
   const size_t ab = (size_t)S * n1 * 2 * sizeof(double) * w->cap;
   if (e == hipSuccess) e = hipMalloc(&w->stragg, ab);
-  if (e == hipSuccess) e = hipMalloc(&w->strcar, ab);
+  if (e == hipSuccess) e = hipMalloc(&w->strcar, ab + (size_t)w->cap * (S * 2 + 2) * sizeof(double));
   if (e != hipSuccess) return e;
   *bytes += tc.size() * sizeof(StreamCol) + lam.size() * sizeof(double) + 2 * ab;
   e = hipMemcpyAsync(w->strtab, tc.data(), tc.size() * sizeof(StreamCol), hipMemcpyHostToDevice, s);
