@@ -237,6 +237,40 @@ int gpa_tile_gradients_dev(gpa_plan* plan, const void* image, size_t image_pitch
                            size_t dx_pitch, size_t dx_plane, void* dy, size_t dy_pitch,
                            size_t dy_plane, void* wn, size_t wn_pitch);
 
+/* The tile pipeline's own data path (SURVEY.md 8(b) "gpa_extract_sharded", 8(e) option 2; no counterpart in the
+ * reference, whose only batching is the dask k-batch, geometric_phase_analysis.py:705-719).  Everything below is
+ * asynchronous on the plan's stream and leaves its result on the device: an image goes through
+ * pygpa_amd.distributed.TiledPipeline without a host synchronisation between its stages.
+ *
+ * gpa_tile_sums_dev: sum over the interior rectangles of `ntiles` windows that lie win_stride elements apart (row
+ *   pitch win_pitch): rects_dev = ntiles x (o0, o1, z0, z1) ints ON THE DEVICE, max_rows >= every z0, the sum as ONE
+ *   double at sum_dev (fixed summation order: reruns are bit-identical).  The ranks all-reduce these sums.
+ * gpa_tile_set_mean_dev: the plan's tile mean = sum_dev[0] * scale (scale = 1 / pixels of the whole image): what
+ *   gpa_tile_gradients_meandev_dev subtracts (geometric_phase_analysis.py:919) instead of a host-side value.
+ * gpa_tile_gradients_meandev_dev: gpa_tile_gradients_dev with that mean; a window whose pitch equals the plan's n1 is
+ *   read in place; wn_plane != 0 writes a second copy of the weight wn_plane elements behind the first (each unwrap
+ *   owner receives its component's two gradients AND the weight as one contiguous block).
+ * gpa_stitch_tiles_dev: tiles[slot][f] (t0 x t1 elements, pitch tile_pitch; slots slot_stride and fields field_stride
+ *   elements apart) -> dst[f] (host array of nf <= 6 device pointers) at (r0, c0) of table_dev = ntiles x (slot, r0, c0,
+ *   z0, z1) ints on the device, clipped to dst_rows[f] x dst_cols[f] (the difference fields are one column / row
+ *   short of the image).  One launch for all tiles and fields.
+ * gpa_plan_wait_stream / gpa_stream_wait_plan: the plan's stream waits for the work enqueued so far on `stream` (a
+ *   hipStream_t as an opaque pointer, NULL = the default stream; e.g. torch.cuda.current_stream().cuda_stream, on
+ *   which the RCCL collectives are ordered) and the other way round -- events, no host synchronisation.          */
+int gpa_tile_sums_dev(gpa_plan* plan, const void* wins, size_t win_stride, size_t win_pitch, const int* rects_dev,
+                      int ntiles, int max_rows, double* sum_dev);
+int gpa_tile_set_mean_dev(gpa_plan* plan, const double* sum_dev, double scale);
+int gpa_tile_gradients_meandev_dev(gpa_plan* plan, const void* image, size_t image_pitch, int r0, int c0,
+                                   const double* kvecs, int P, const double* klists, int K, double sigma,
+                                   int mask_border, int i0, int j0, int t0, int t1, void* dx, size_t dx_pitch,
+                                   size_t dx_plane, void* dy, size_t dy_pitch, size_t dy_plane, void* wn,
+                                   size_t wn_pitch, size_t wn_plane);
+int gpa_stitch_tiles_dev(gpa_plan* plan, const void* tiles, size_t slot_stride, size_t field_stride,
+                         size_t tile_pitch, const int* table_dev, int ntiles, int t0, int t1, int nf,
+                         void* const* dst, const size_t* dst_pitch, const int* dst_rows, const int* dst_cols);
+int gpa_plan_wait_stream(gpa_plan* plan, void* stream);
+int gpa_stream_wait_plan(gpa_plan* plan, void* stream);
+
 /* f-1 -- Lawler-Fujita undistortion.
  * gpa_invert_u_overlap: fixed-point inverse of a displacement field, `iters` rounds of cubic-
  *   spline resampling with mode='nearest' on the grid extended by `edge` pixels; replaces

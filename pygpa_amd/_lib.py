@@ -60,6 +60,13 @@ SIGNATURES = {
     'gpa_mean_dev': (_i, [_vp, _vp, _sz, _dp]),
     'gpa_tile_gradients_dev': (_i, [_vp, _vp, _sz, _i, _i, _d, _vp, _i, _vp, _i, _d, _i, _i, _i, _i, _i,
                                     _vp, _sz, _sz, _vp, _sz, _sz, _vp, _sz]),
+    'gpa_tile_sums_dev': (_i, [_vp, _vp, _sz, _sz, _vp, _i, _i, _vp]),
+    'gpa_tile_set_mean_dev': (_i, [_vp, _vp, _d]),
+    'gpa_tile_gradients_meandev_dev': (_i, [_vp, _vp, _sz, _i, _i, _vp, _i, _vp, _i, _d, _i, _i, _i, _i, _i,
+                                            _vp, _sz, _sz, _vp, _sz, _sz, _vp, _sz, _sz]),
+    'gpa_stitch_tiles_dev': (_i, [_vp, _vp, _sz, _sz, _sz, _vp, _i, _i, _i, _i, _vp, _vp, _vp, _vp]),
+    'gpa_plan_wait_stream': (_i, [_vp, _vp]),
+    'gpa_stream_wait_plan': (_i, [_vp, _vp]),
     'gpa_invert_u_overlap': (_i, [_vp, _vp, _i, _i, _vp]),
     'gpa_undistort_image': (_i, [_vp, _vp, _vp, _vp]),
     'gpa_phasegradient2J': (_i, [_vp, _vp, _i, _vp, _vp, _d, _vp, _vp]),
@@ -486,6 +493,48 @@ class Plan:
                                               int(mask_border), i0, j0, t0, t1, _ptr(int(dx[0])), int(dx[1]), int(dx[2]),
                                               _ptr(int(dy[0])), int(dy[1]), int(dy[2]), _ptr(int(wn[0])), int(wn[1])),
               'gpa_tile_gradients_dev')
+
+    def tile_sums_dev(self, wins_ptr, win_stride, win_pitch, rects_dev_ptr, ntiles, max_rows, sum_dev_ptr):
+        """sum over the interior rectangles (device table of (o0, o1, z0, z1)) of ntiles windows -> one double on the device"""
+        check(self.lib.gpa_tile_sums_dev(self.handle, _ptr(int(wins_ptr)), int(win_stride), int(win_pitch),
+                                         _ptr(int(rects_dev_ptr)), int(ntiles), int(max_rows), _ptr(int(sum_dev_ptr))),
+              'gpa_tile_sums_dev')
+
+    def tile_set_mean_dev(self, sum_dev_ptr, scale):
+        check(self.lib.gpa_tile_set_mean_dev(self.handle, _ptr(int(sum_dev_ptr)), float(scale)), 'gpa_tile_set_mean_dev')
+
+    def tile_gradients_meandev_dev(self, image_ptr, image_pitch, r0, c0, kvecs, klists, sigma, mask_border, interior, dx, dy, wn):
+        """tile_gradients_dev with the mean of gpa_tile_set_mean_dev; wn = (ptr, pitch, plane): plane != 0 writes the
+        weight twice (plane elements apart)"""
+        kvecs = _f64(kvecs).reshape(-1, 2)
+        P = len(kvecs)
+        klists = _f64(klists).reshape(P, -1, 2)
+        i0, j0, t0, t1 = (int(v) for v in interior)
+        check(self.lib.gpa_tile_gradients_meandev_dev(self.handle, _ptr(int(image_ptr)), int(image_pitch), int(r0), int(c0),
+                                                      _ptr(kvecs), P, _ptr(klists), klists.shape[1], float(sigma),
+                                                      int(mask_border), i0, j0, t0, t1, _ptr(int(dx[0])), int(dx[1]), int(dx[2]),
+                                                      _ptr(int(dy[0])), int(dy[1]), int(dy[2]), _ptr(int(wn[0])), int(wn[1]),
+                                                      int(wn[2])),
+              'gpa_tile_gradients_meandev_dev')
+
+    def stitch_tiles_dev(self, tiles_ptr, slot_stride, field_stride, tile_pitch, table_dev_ptr, ntiles, t0, t1, dst):
+        """dst: list of (device pointer, pitch, rows, cols) per field (<= 6); one launch on the plan's stream"""
+        nf = len(dst)
+        ptrs = (C.c_void_p * nf)(*[int(d[0]) for d in dst])
+        pitch = (C.c_size_t * nf)(*[int(d[1]) for d in dst])
+        rows = (C.c_int * nf)(*[int(d[2]) for d in dst])
+        cols = (C.c_int * nf)(*[int(d[3]) for d in dst])
+        check(self.lib.gpa_stitch_tiles_dev(self.handle, _ptr(int(tiles_ptr)), int(slot_stride), int(field_stride),
+                                            int(tile_pitch), _ptr(int(table_dev_ptr)), int(ntiles), int(t0), int(t1), nf,
+                                            ptrs, pitch, rows, cols), 'gpa_stitch_tiles_dev')
+
+    def wait_stream(self, stream):
+        """the plan's stream waits for what has been enqueued on `stream` (raw hipStream_t as an int, 0 = default)"""
+        check(self.lib.gpa_plan_wait_stream(self.handle, C.c_void_p(int(stream))), 'gpa_plan_wait_stream')
+
+    def stream_wait(self, stream):
+        """`stream` waits for what has been enqueued on the plan's stream"""
+        check(self.lib.gpa_stream_wait_plan(self.handle, C.c_void_p(int(stream))), 'gpa_stream_wait_plan')
 
     def unwrap_prediff_dev(self, dx_ptr, dy_ptr, weight_ptr, phi_ptr, kmax=100, eps=1e-9, axes_compat=True):
         iters = C.c_int(0)

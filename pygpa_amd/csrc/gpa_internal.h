@@ -219,6 +219,21 @@ hipError_t launch_deconv_filter(int dtype, void* Z, int n0, int n1, const double
                                 hipStream_t s);
 hipError_t launch_deconv_unpack(int dtype, const void* Z, int m0, int m1, int pad, void* out, hipStream_t s);
 
+// ---- tile pipeline (gpa_tiles.hip): all on stream s, nothing synchronises ------------------------------
+// sum over the interior rectangles rects_dev[t] = (o0, o1, z0, z1) of ntiles windows (win_stride / pitch in elements);
+// part: >= ntiles * tile_sums_bands(max_rows) doubles, ticket: one zeroed unsigned, out: one double
+hipError_t launch_tile_sums(int dtype, const void* wins, size_t win_stride, size_t pitch, const int* rects_dev, int ntiles,
+                            int max_rows, double* part, unsigned* ticket, double* out, hipStream_t s);
+int tile_sums_bands(int max_rows);
+hipError_t launch_set_mean(int dtype, const double* sum, double scale, void* mean_out, hipStream_t s);
+// nf <= 6 rectangular copies (rows x cols elements, pitches in elements) in one launch
+hipError_t launch_copy_fields(int dtype, const void* const* src, void* const* dst, const size_t* src_pitch,
+                              const size_t* dst_pitch, const int* rows, const int* cols, int nf, hipStream_t s);
+// table_dev[t] = (slot, r0, c0, z0, z1); tiles[slot][f] (t0 x t1, pitch tile_pitch) -> dst[f] at (r0, c0), clipped to dst_rows / dst_cols
+hipError_t launch_stitch(int dtype, const void* tiles, size_t slot_stride, size_t field_stride, size_t tile_pitch,
+                         const int* table_dev, int ntiles, int t0, int t1, int nf, void* const* dst, const size_t* dst_pitch,
+                         const int* dst_rows, const int* dst_cols, hipStream_t s);
+
 // ---- f-1 Lawler-Fujita (gpa_warp.hip); both synchronise the stream before returning -----------
 // mode: 0 = scipy 'nearest' (the reference's default), 1 = 'constant'; nan_last (mode 1 only): the last round samples
 // with cval = NaN as invert_u_overlap does (geometric_phase_analysis.py:296-299), invert_u never does (:255-258)

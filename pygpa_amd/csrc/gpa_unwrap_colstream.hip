@@ -77,7 +77,9 @@ __global__ __launch_bounds__(CS_COLS) void colstream_agg_kernel(const T* __restr
     agg0 += pb * S;
     flags += pb * FLAGS_N;
   }
-  if (flags[1]) return;   // (stopped in an EARLIER iteration; this iteration's test is the scan kernel's)
+  // (stopped in an EARLIER iteration?  this iteration's test is the scan kernel's.  The flag is requested with the data and
+  //  looked at after the loads have been issued: one memory round trip, not two)
+  const int stopped = flags[1];
   const int y = blockIdx.x * CS_COLS + threadIdx.x, s = blockIdx.y;
   const bool cv = !RAGGED || y < n1;
   const int yc = cv ? y : 0;
@@ -94,6 +96,7 @@ __global__ __launch_bounds__(CS_COLS) void colstream_agg_kernel(const T* __restr
     rp += n1;
   }
   const double lam = lamtab[yc];
+  if (stopped) return;
   double b = 0.0, a = 0.0;
 #pragma unroll
   for (int k = 0; k < C; ++k) {
@@ -145,15 +148,39 @@ __global__ __launch_bounds__(64 * G) void colstream_scan_kernel(int n0, int n1, 
     part_norm += pb * PART_N;
     part_rho += pb * PART_N;
   }
-  if (flags[1]) return;
+  // every input -- flag, partial norms, scalars, the column's constants and chunk sums -- is requested before the first
+  // wait: the kernel is a chain of dependent round trips otherwise (65 workgroups at 4096^2: nothing to overlap them with)
+  const int stopped = flags[1];
   __shared__ double shn[64 * G];
   __shared__ double xa[G][64], xb[G][64], xm[G][64];
+  double norm_part = 0.0, best = 0.0, norm0 = 0.0;
+  if (it > 0) {
+    norm_part = load_partials(part_norm, nnorm);
+    best = scal[10 + ((it - 1) & 1)];
+    norm0 = scal[5];
+  }
+  const int lane = threadIdx.x & 63, g = threadIdx.x >> 6;
+  const int ncb = (n1 + 63) / 64;   // column blocks; the block after them solves column 0
+  const bool colblock = (int)blockIdx.x < ncb;
+  const int y = blockIdx.x * 64 + lane;
+  const bool cv = colblock && y < n1 && y > 0;     // (column 0 is the extra workgroup's)
+  const int yc = (colblock && y < n1) ? y : 0;
+  const StreamCol tc = tab[yc];
+  const int s0 = g * M;                // first chunk of this thread's segment
+  double av[M], bv[M];
+#pragma unroll
+  for (int i = 0; i < M; ++i) {
+    const int s = s0 + i;
+    const double2 v = (s < S && colblock) ? agg[(size_t)s * n1 + yc] : make_double2(0.0, 0.0);
+    av[i] = v.x;
+    bv[i] = v.y;
+  }
+  if (stopped) return;
   if (it > 0) {
     // the reference's stopping test (phase_unwrap.py:348) on the update the row kernel has just applied, evaluated by
     // every workgroup of this launch; the other two launches of the solve read the flag
-    const double tot = reduce_partials(part_norm, nnorm, shn);
-    const double best = scal[10 + ((it - 1) & 1)];
-    const bool stop = sqrt(tot) < eps * sqrt(scal[5]) || tot == 0.0 || !(tot == tot) || tot > 1e4 * best;
+    const double tot = block_sum(norm_part, shn);
+    const bool stop = sqrt(tot) < eps * sqrt(norm0) || tot == 0.0 || !(tot == tot) || tot > 1e4 * best;
     if (blockIdx.x == 0 && threadIdx.x == 0) {
       flags[0] = it;
       scal[6] = tot;
@@ -162,9 +189,7 @@ __global__ __launch_bounds__(64 * G) void colstream_scan_kernel(int n0, int n1, 
     }
     if (stop) return;
   }
-  const int lane = threadIdx.x & 63, g = threadIdx.x >> 6;
-  const int ncb = (n1 + 63) / 64;   // column blocks; the block after them solves column 0
-  if ((int)blockIdx.x == ncb) {
+  if (!colblock) {
     // ---- column 0 (lam = 1, the row means): z = T^+ (r - mean) + mean, i.e. p = cumsum(r - mean), z_n = -sum_(m >= n) p_m,
     // then the mean of z removed and the mean of r added (the reference divides its DC bin by 1, phase_unwrap.py:110-114).
     // From the chunk sums b = sum r, c, d of colstream_agg_kernel; one wavefront, lane i owns chunks [i NJ, (i + 1) NJ).
@@ -229,20 +254,7 @@ __global__ __launch_bounds__(64 * G) void colstream_scan_kernel(int n0, int n1, 
     }
     return;
   }
-  const int y = blockIdx.x * 64 + lane;
-  const bool cv = y < n1 && y > 0;     // (column 0 is the extra workgroup's)
-  const int yc = y < n1 ? y : 0;
-  const StreamCol tc = tab[yc];
-  const int s0 = g * M;                // first chunk of this thread's segment
   auto mult = [&](int s) { return s == S - 1 ? tc.lamL : tc.lamC; };   // lam^len(s)
-  double av[M], bv[M];
-#pragma unroll
-  for (int i = 0; i < M; ++i) {
-    const int s = s0 + i;
-    const double2 v = s < S ? agg[(size_t)s * n1 + yc] : make_double2(0.0, 0.0);
-    av[i] = v.x;
-    bv[i] = v.y;
-  }
   // segment results: A-part (from the segment's last chunk up), B-part (down), total multiplier
   double Aseg = 0.0, Bseg = 0.0, Mseg = 1.0;
 #pragma unroll
@@ -322,7 +334,7 @@ __global__ __launch_bounds__(CS_COLS) void colstream_apply_kernel(const T* __res
     flags += pb * FLAGS_N;
     part_rho += pb * PART_N;
   }
-  if (flags[1]) return;
+  const int stopped = flags[1];   // (requested with the data, see colstream_agg_kernel)
   __shared__ double shn[CS_COLS];
   const int y = blockIdx.x * CS_COLS + threadIdx.x, s = blockIdx.y;
   const bool cv = !RAGGED || y < n1;
@@ -342,6 +354,7 @@ __global__ __launch_bounds__(CS_COLS) void colstream_apply_kernel(const T* __res
   const double mu2 = 2.0 * (double)hb[yc];
   // column 0: r - mean goes in, z + (mean of r - mean of z) comes out (both from the scan kernel); any other column: 0, 0
   const double sh0 = y == 0 ? col0[0] : 0.0, fx0 = y == 0 ? col0[1] : 0.0;
+  if (stopped) return;
   // causal recursion from the true carry, in place (stored in the data's precision, as colsolve_tri_kernel does)
   // (scheduling fences every 8 rows: left alone, hipcc hoists the f32 -> f64 conversions of all C samples to the top of
   //  the chain and keeps 2 C more registers alive)

@@ -178,69 +178,114 @@ def _tiled_device(image, kvecs, klists, sigma, halo, kmax, dtype, device, group,
 
 
 class HipTileBackend:
-    """What TiledPipeline asks of the GPU, through the C ABI of libgpa_hip.so: the tile stage of one window (sweep +
-    per-pixel least squares, interiors written into the rank's compact tile buffer), the global weighted unwrap of
-    one component (started on the global plan's own stream, waited for later), synchronisation.  A test double with
-    the same five methods (tests/test_distributed.py: CPU tensors + the oracle) lets the schedule, the collectives
+    """What TiledPipeline asks of the GPU, through the C ABI of libgpa_hip.so: the sum over the tile interiors (one
+    launch, result on the device), the tile stage of one window (sweep + per-pixel least squares, interiors written into
+    the rank's tile buffer by one copy launch), the stitching of gathered tiles (one launch per component), the global
+    weighted unwrap of one component (on the global plan's own stream, waited for later), and the ORDER between the
+    plans' streams and torch's current stream (events: no host synchronisation on the nccl / single-rank path).  A test
+    double with the same methods (tests/test_distributed.py: CPU tensors + the oracle) lets the schedule, the collectives
     and the stitching run under gloo without a GPU."""
 
-    def __init__(self, torch, wshape, shape, nbatch, dtype, device, two_solves):
+    def __init__(self, torch, wshape, shape, nbatch, dtype, device):
         from . import _lib
         self.torch = torch
         self.device = torch.device('cuda', int(device))
         self.rsz = np.dtype(dtype).itemsize
+        self.wshape = wshape
         self.plan_w = _lib.get_plan(wshape, nbatch, dtype, device)
         self._mk = lambda: _lib.Plan(shape, 1, dtype, device)
         self._get = lambda: _lib.get_plan(shape, 1, dtype, device)
-        self.plan_c = [None, None]
-        self.two_solves = two_solves    # a rank that owns both components of an image solves them on two plans at once
-        self.own = []
+        self.plan_shared = None         # the cached global plan: every solve that does not overlap another one here
+        self.plan_second = None         # a second global plan (stream + workspace), created only when a rank solves both
+        self.plan_c = [None, None]      # components of one image at once; plan_c[c] = the plan of c's solve in flight
 
-    def _plan(self, c):
-        if self.plan_c[c] is None:
-            if c == 1 and self.two_solves:
-                self.plan_c[1] = self._mk()
-                self.own.append(self.plan_c[1])
-            else:
-                self.plan_c[c] = self._get()
+    def _plan(self, c, concurrent=False):
+        """global plan of component c.  concurrent: this rank solves BOTH components of one image at once (run_stream on
+        one rank) and component 1 gets a plan -- stream and workspace -- of its own; otherwise the two share the cached
+        global plan (step() solves them one after the other and gains nothing from a second one: ADVICE r03)"""
+        if c == 1 and concurrent:
+            if self.plan_second is None:
+                self.plan_second = self._mk()
+            self.plan_c[1] = self.plan_second
+        else:
+            if self.plan_shared is None:
+                self.plan_shared = self._get()
+            self.plan_c[c] = self.plan_shared
         return self.plan_c[c]
 
-    def tile_gradients(self, win, wpitch, mean, kvecs, klists, sigma, border, rect, local_slot, t1, plane):
-        base = local_slot.data_ptr()
-        self.plan_w.tile_gradients_dev(win.data_ptr(), wpitch, 0, 0, mean, kvecs, klists, sigma, border, rect,
-                                       (base, t1, plane), (base + 2 * plane * self.rsz, t1, plane),
-                                       (base + 4 * plane * self.rsz, t1))
+    def _torch_stream(self):
+        return self.torch.cuda.current_stream(self.device).cuda_stream
 
-    def sync_tiles(self):
-        self.plan_w.sync()
+    def tile_sums(self, wins, rects, ntiles, max_rows, out):
+        self.plan_w.tile_sums_dev(wins.data_ptr(), wins.stride(0), wins.stride(1), rects.data_ptr(), ntiles, max_rows,
+                                  out.data_ptr())
 
-    def unwrap_start(self, c, gdx, gdy, gw, out, kmax):
-        self._plan(c).unwrap_prediff_enqueue_dev(gdx.data_ptr(), gdy.data_ptr(), gw.data_ptr(), out.data_ptr(), kmax=kmax)
+    def set_mean(self, sum_t, scale):
+        self.plan_w.tile_set_mean_dev(sum_t.data_ptr(), scale)
+
+    def tile_gradients(self, win, wpitch, kvecs, klists, sigma, border, rect, local, slot):
+        """local: (2, per_rank, 3, t0, t1); component c's block of this tile = (dudx_c, dudy_c, weight)"""
+        t0, t1 = local.shape[3], local.shape[4]
+        plane, comp = t0 * t1, local.stride(0)
+        base = local[0, slot].data_ptr()
+        self.plan_w.tile_gradients_meandev_dev(win.data_ptr(), wpitch, 0, 0, kvecs, klists, sigma, border, rect,
+                                               (base, t1, comp), (base + plane * self.rsz, t1, comp),
+                                               (base + 2 * plane * self.rsz, t1, comp))
+
+    def tiles_to_torch(self, host):
+        """what the tile plan has enqueued becomes visible to torch: its current stream waits (collectives on device
+        tensors are ordered on that stream), or -- host: data about to be staged through the host -- the plan is drained"""
+        if host:
+            self.plan_w.sync()
+        else:
+            self.plan_w.stream_wait(self._torch_stream())
+
+    def torch_to_tiles(self):
+        """the tile plan's stream waits for torch's current stream (the all-reduced sum)"""
+        self.plan_w.wait_stream(self._torch_stream())
+
+    def stitch(self, c, tiles, slot_stride, table, ntiles, t0, t1, gdx, gdy, gw, concurrent=False):
+        """tiles[slot] = (dudx_c, dudy_c, w) -> the full-size fields of component c, on that component's plan, whose
+        stream first waits for torch's (the gather that filled `tiles`)"""
+        pl = self._plan(c, concurrent)
+        pl.wait_stream(self._torch_stream())
+        n0, n1 = gw.shape
+        pl.stitch_tiles_dev(tiles.data_ptr(), slot_stride, t0 * t1, t1, table.data_ptr(), ntiles, t0, t1,
+                            [(gdx.data_ptr(), n1 - 1, n0, n1 - 1), (gdy.data_ptr(), n1, n0 - 1, n1), (gw.data_ptr(), n1, n0, n1)])
+
+    def unwrap_start(self, c, gdx, gdy, gw, out, kmax, concurrent=False):
+        self._plan(c, concurrent).unwrap_prediff_enqueue_dev(gdx.data_ptr(), gdy.data_ptr(), gw.data_ptr(), out.data_ptr(), kmax=kmax)
 
     def unwrap_wait(self, c):
-        return self._plan(c).unwrap_finish()
+        return self.plan_c[c].unwrap_finish()
+
+    def unwrap_to_torch(self, c):
+        """torch's current stream waits for component c's plan (its field is about to be sent / handed out)"""
+        self.plan_c[c].stream_wait(self._torch_stream())
 
     def sync_device(self):
         self.torch.cuda.synchronize(self.device)
 
     def close(self):
-        for pl in self.own:
-            pl.close()
-        self.own = []
+        if self.plan_second is not None:
+            self.plan_second.close()
+        self.plan_second = self.plan_shared = None
+        self.plan_c = [None, None]
 
 
 class TiledPipeline:
     """Device-resident tile pipeline of one rank (module docstring), reusable over many images of one shape.
 
     `load(image)` uploads this rank's windows (1/N of the image plus halos); `step()` runs
-      all_reduce of the tile-interior sums (the mean of the WHOLE image that every window is offset by,
-      geometric_phase_analysis.py:919; one scalar) -> tile stage (sweep + least squares per window, C ABI)
-      -> all_gather #1 of the gradient tiles -> stitch -> global unwrap of component c on rank c % N
-      -> broadcast of each component
+      sum over the tile interiors (one launch) -> all_reduce (the mean of the WHOLE image that every window is offset
+      by, geometric_phase_analysis.py:919; one scalar that never leaves the device) -> tile stage (sweep + least squares
+      per window, C ABI) -> all_gather #1 of the gradient tiles -> stitch (one launch per component) -> global unwrap of
+      component c on rank c % N -> broadcast of each component
     and returns the stitched (2, N, M) field as a device tensor that every rank holds.  Buffers are torch
     tensors (device memory + collectives are what torch is here for); with the "nccl" backend the
     collectives run on them over RCCL/xGMI, with "gloo" (CPU tests, two ranks sharing a GPU) they are
-    staged through the host."""
+    staged through the host.  The tile buffer keeps, per component c, the block (dudx_c, dudy_c, weight) of every tile
+    contiguous: what the owner of component c is sent is one slice, and the stitch reads it as it arrives."""
 
     def __init__(self, shape, kvecs, klists, sigma, halo, kmax=10, dtype=np.float32, device=0, group=None,
                  grid=None, window=None, tiles=None, tshape=None, wshape=None, backend=None):
@@ -266,21 +311,31 @@ class TiledPipeline:
         P, K = self.klists.shape[:2]
         self.unwrappers = [c for c in range(2) if c % self.world == self.rank]
         self.be = backend if backend is not None else HipTileBackend(torch, self.wshape, self.shape, P * K, self.dtype,
-                                                                     self.device, two_solves=self.world == 1)
+                                                                     self.device)
         dev = self.be.device
         self.dev = dev
         t_dt = torch.float32 if self.dtype == np.float32 else torch.float64
         n0, n1 = self.shape
         t0, t1 = self.tshape
+        pr = self.per_rank
         self.wins = torch.zeros((max(len(self.mine), 1),) + self.wshape, dtype=t_dt, device=dev)
-        self.local = torch.zeros((self.per_rank, 5, t0, t1), dtype=t_dt, device=dev)
-        self.gathered = torch.zeros((self.world, self.per_rank, 5, t0, t1), dtype=t_dt, device=dev)
+        self.local = torch.zeros((2, pr, 3, t0, t1), dtype=t_dt, device=dev)
+        self.gathered = torch.zeros((self.world, 2, pr, 3, t0, t1), dtype=t_dt, device=dev) if self.world > 1 else None
         self.gdx = torch.zeros((2, n0, n1 - 1), dtype=t_dt, device=dev)
         self.gdy = torch.zeros((2, n0 - 1, n1), dtype=t_dt, device=dev)
         self.gw = torch.zeros((n0, n1), dtype=t_dt, device=dev)
         self.u = torch.zeros((2, n0, n1), dtype=t_dt, device=dev)
         self.sums = torch.zeros(1, dtype=torch.float64, device=dev)
-        self.mean = None
+        # device tables: interior rectangles of this rank's windows; (slot, r0, c0, z0, z1) of every tile for the stitch of
+        # a buffer gathered as (world, 2, per_rank, ...) [step] and as (world, per_rank, ...) [run_stream]
+        rects = [[self.tiles[idx][2][0], self.tiles[idx][2][1], self.tiles[idx][3][0], self.tiles[idx][3][1]] for idx in self.mine]
+        self.rects = torch.tensor(rects if rects else [[0, 0, 1, 1]], dtype=torch.int32, device=dev)
+        self.max_rows = max([r[2] for r in rects] + [1])
+        tab = lambda slot_of: torch.tensor([[slot_of(idx), ij[0] * t0, ij[1] * t1, z[0], z[1]]
+                                            for idx, (ij, _, _, z) in enumerate(self.tiles)], dtype=torch.int32, device=dev)
+        self.table_step = tab(lambda idx: (idx % self.world) * 2 * pr + idx // self.world)
+        self.table_stream = tab(lambda idx: (idx % self.world) * pr + idx // self.world)
+        self.mean = None      # (kept for callers that read it: the scalar itself stays on the device)
         self.iters = [0, 0]
 
     # ---- collectives (device tensors on RCCL, host-staged on gloo) -------------------------------
@@ -299,9 +354,7 @@ class TiledPipeline:
         return t
 
     def _all_gather(self, out, t):
-        if self.world == 1:
-            out[0].copy_(t)
-        elif self._host_staged():
+        if self._host_staged():
             h = out.cpu()
             self.dist.all_gather_into_tensor(h, t.cpu().contiguous().unsqueeze(0), group=self.group)   # gloo wants world x input
             out.copy_(h)
@@ -333,40 +386,43 @@ class TiledPipeline:
         self.be.sync_device()
 
     def image_mean(self):
-        """mean of the whole image: every pixel lies in exactly one tile interior, so the ranks add up the
-        sums over their interiors (device reductions, then one all_reduce of a scalar)"""
-        torch = self.torch
-        self.sums.zero_()
+        """mean of the whole image, left ON THE DEVICE as the tile plan's mean: every pixel lies in exactly one tile
+        interior, so each rank sums its interiors in one launch (deterministic order), the ranks all-reduce the one
+        double, and the tile stage reads sum / pixels from device memory -- no host synchronisation"""
+        if self.mine:
+            self.be.tile_sums(self.wins, self.rects, len(self.mine), self.max_rows, self.sums)
+        else:
+            self.sums.zero_()
+        if self.world > 1:
+            self.be.tiles_to_torch(self._host_staged())
+            self._all_reduce_sum(self.sums)
+            self.be.torch_to_tiles()
+        self.be.set_mean(self.sums, 1.0 / (self.shape[0] * self.shape[1]))
+
+    def _tile_stage(self):
         for slot, idx in enumerate(self.mine):
             _, _, (o0, o1), (z0, z1) = self.tiles[idx]
-            self.sums += self.wins[slot, o0:o0 + z0, o1:o1 + z1].sum(dtype=torch.float64)
-        self._all_reduce_sum(self.sums)
-        return float(self.sums.item()) / (self.shape[0] * self.shape[1])
+            self.be.tile_gradients(self.wins[slot], self.wshape[1], self.kvecs, self.klists, self.sigma, self.border,
+                                   (o0, o1, z0, z1), self.local, slot)
 
     def step(self):
-        torch = self.torch
         n0, n1 = self.shape
         t0, t1 = self.tshape
-        rsz = self.dtype.itemsize
         plane = t0 * t1
-        self.mean = self.image_mean()             # (.item() synchronises: the plans run on their own streams)
-        for slot, idx in enumerate(self.mine):
-            _, _, (o0, o1), (z0, z1) = self.tiles[idx]
-            self.be.tile_gradients(self.wins[slot], self.wshape[1], self.mean, self.kvecs, self.klists, self.sigma,
-                                   self.border, (o0, o1, z0, z1), self.local[slot], t1, plane)
-        self.be.sync_tiles()
-        # --- collective 1 (RCCL all_gather over xGMI): compact gradient tiles of every rank
-        self._all_gather(self.gathered, self.local)
-        for idx, ((i, j), _, _, (z0, z1)) in enumerate(self.tiles):
-            src = self.gathered[idx % self.world, idx // self.world]
-            r0, c0 = i * t0, j * t1
-            zx, zy = min(z1, n1 - 1 - c0), min(z0, n0 - 1 - r0)
-            self.gdx[:, r0:r0 + z0, c0:c0 + zx] = src[0:2, :z0, :zx]
-            self.gdy[:, r0:r0 + zy, c0:c0 + z1] = src[2:4, :zy, :z1]
-            self.gw[r0:r0 + z0, c0:c0 + z1] = src[4, :z0, :z1]
-        self.be.sync_device()
-        # --- global unwrap, component c on rank c % world; collective 2 hands each component to everybody
+        self.image_mean()
+        self._tile_stage()
+        # --- collective 1 (RCCL all_gather over xGMI): the tile blocks of every rank (one rank: read in place)
+        self.be.tiles_to_torch(self._host_staged())
+        if self.world > 1:
+            self._all_gather(self.gathered, self.local)
+            src = self.gathered
+        else:
+            src = self.local
+        # --- stitch + global unwrap, component c on rank c % world; collective 2 hands each component to everybody
         for c in self.unwrappers:
+            comp = src[0, c] if self.world > 1 else src[c]
+            self.be.stitch(c, comp, 3 * plane, self.table_step if self.world > 1 else self.table_stream, len(self.tiles), t0, t1,
+                           self.gdx[c], self.gdy[c], self.gw)
             self.be.unwrap_start(c, self.gdx[c], self.gdy[c], self.gw, self.u[c], self.kmax)
             self.iters[c] = self.be.unwrap_wait(c)
         for c in range(2):
@@ -384,34 +440,26 @@ class TiledPipeline:
         """ranks that unwrap component 0 / component 1 of image i; the first one ends up with the whole field"""
         return (2 * i) % self.world, (2 * i + 1) % self.world
 
-    def _gather_to(self, fields, dst):
-        """gather local[:, fields] of every rank on rank dst -> (world, per_rank, len(fields), t0, t1) there, None elsewhere"""
-        torch, dist = self.torch, self.dist
-        part = self.local[:, fields].contiguous()
+    def _gather_to(self, c, dst):
+        """component c's tile blocks of every rank on rank dst, in its preallocated receive buffer (world, per_rank, 3,
+        t0, t1) -- the ranks' slices are received in place, nothing is stacked or copied afterwards; None elsewhere.
+        One rank: the tile buffer itself."""
+        dist = self.dist
+        part = self.local[c]                      # contiguous: one slice per owner
         if self.world == 1:
-            return part.unsqueeze(0)
+            return part
         dst_global = dst if self.group is None else dist.get_global_rank(self.group, dst)
+        rx = self._rx[c] if self.rank == dst else None
         if self._host_staged():
-            part = part.cpu()
-        outs = [torch.empty_like(part) for _ in range(self.world)] if self.rank == dst else None
-        dist.gather(part, outs, dst=dst_global, group=self.group)
-        if self.rank != dst:
-            return None
-        got = torch.stack(outs)
-        return got.to(self.dev) if self._host_staged() else got
-
-    def _stitch_component(self, got, c, buf):
-        """tiles of (dudx_c, dudy_c, weight) gathered on this rank -> the full-size fields of buffer set `buf`"""
-        n0, n1 = self.shape
-        t0, t1 = self.tshape
-        gdx, gdy, gw = self._pbuf[buf]
-        for idx, ((i, j), _, _, (z0, z1)) in enumerate(self.tiles):
-            src = got[idx % self.world, idx // self.world]
-            r0, c0 = i * t0, j * t1
-            zx, zy = min(z1, n1 - 1 - c0), min(z0, n0 - 1 - r0)
-            gdx[c, r0:r0 + z0, c0:c0 + zx] = src[0, :z0, :zx]
-            gdy[c, r0:r0 + zy, c0:c0 + z1] = src[1, :zy, :z1]
-            gw[c, r0:r0 + z0, c0:c0 + z1] = src[2, :z0, :z1]
+            hp = part.cpu()
+            outs = [self.torch.empty_like(hp) for _ in range(self.world)] if rx is not None else None
+            dist.gather(hp, outs, dst=dst_global, group=self.group)
+            if rx is not None:
+                for r, o in enumerate(outs):
+                    rx[r].copy_(o)
+            return rx
+        dist.gather(part, list(rx.unbind(0)) if rx is not None else None, dst=dst_global, group=self.group)
+        return rx
 
     def _send_component(self, t, src, dst):
         """component 1 of an image from its owner to the owner of component 0 (point to point)"""
@@ -445,7 +493,9 @@ class TiledPipeline:
         slice1), or None for "the windows that are loaded already".  For image i the field ends up on rank owners(i)[0]; `on_result(i, u)` is called there with the
         (2, N, M) device tensor (valid until the image after next finishes).  Returns on every rank the list of
         iteration counts [(it0, it1) or None per image] and leaves per-stage wall times of this rank in
-        `self.stage_s` (load, mean, tile stage, gather + stitch, waiting for unwraps, hand-over).
+        `self.stage_s` (load, mean, tile stage, gather + stitch, waiting for unwraps, hand-over: host time spent
+        ENQUEUEING on the nccl / single-rank path, where nothing between the load and the wait for the unwraps
+        synchronises with the device).
         Per image the arithmetic is that of step(): the same windows, the same tile kernels, the same global solves --
         the fields are equal bit for bit (tests/test_distributed.py, tests/test_gpu_configs.py)."""
         import time
@@ -461,9 +511,14 @@ class TiledPipeline:
                            torch.zeros((2, n0 - 1, n1), dtype=t_dt, device=self.dev),
                            torch.zeros((2, n0, n1), dtype=t_dt, device=self.dev)) for _ in range(2)]
             self._pu = [torch.zeros((2, n0, n1), dtype=t_dt, device=self.dev) for _ in range(2)]
+            # receive buffers of the gathers (allocated once; a component's buffer is free again when its unwrap,
+            # which follows the stitch on the same stream, has been waited for -- before the next image's gather)
+            self._rx = [torch.zeros((self.world, self.per_rank, 3, t0, t1), dtype=t_dt, device=self.dev)
+                        for _ in range(2)] if self.world > 1 else None
         st = {k: 0.0 for k in ('load', 'mean', 'tiles', 'gather', 'unwrap_wait', 'handover')}
         iters_all = []
         pending = None      # (index, buffer set) of the image whose unwraps are in flight
+        both = self.world == 1     # this rank solves both components of an image at once: two plans
 
         def finish(pi, pb):
             a, b = self.owners(pi)
@@ -492,34 +547,28 @@ class TiledPipeline:
                 self.load(src)
             st['load'] += time.perf_counter() - t
             t = time.perf_counter()
-            self.mean = self.image_mean()
+            self.image_mean()
             st['mean'] += time.perf_counter() - t
             t = time.perf_counter()
-            for slot, idx in enumerate(self.mine):
-                _, _, (o0, o1), (z0, z1) = self.tiles[idx]
-                self.be.tile_gradients(self.wins[slot], self.wshape[1], self.mean, self.kvecs, self.klists, self.sigma,
-                                       self.border, (o0, o1, z0, z1), self.local[slot], t1, plane)
+            self._tile_stage()
             # the previous image's unwraps have been running beside these launches; their owners wait for them now
             if pending is not None:
                 st['tiles'] += time.perf_counter() - t
                 finish(*pending)
                 pending = None
                 t = time.perf_counter()
-            self.be.sync_tiles()
+            self.be.tiles_to_torch(self._host_staged())
             st['tiles'] += time.perf_counter() - t
             t = time.perf_counter()
             a, b = self.owners(i)
-            # tiles hold (dudx0, dudx1, dudy0, dudy1, w): component c needs fields (c, 2 + c, 4)
             for c, owner in ((0, a), (1, b)):
-                got = self._gather_to([c, 2 + c, 4], owner)
-                if self.rank == owner:
-                    self._stitch_component(got, c, buf)
-            self.be.sync_device()
-            st['gather'] += time.perf_counter() - t
-            for c, owner in ((0, a), (1, b)):
+                got = self._gather_to(c, owner)
                 if self.rank == owner:
                     gdx, gdy, gw = self._pbuf[buf]
-                    self.be.unwrap_start(c, gdx[c], gdy[c], gw[c], self._pu[buf][c], self.kmax)
+                    self.be.stitch(c, got, 3 * plane, self.table_stream, len(self.tiles), t0, t1, gdx[c], gdy[c], gw[c],
+                                   concurrent=both)
+                    self.be.unwrap_start(c, gdx[c], gdy[c], gw[c], self._pu[buf][c], self.kmax, concurrent=both)
+            st['gather'] += time.perf_counter() - t
             pending = (i, buf)
         if pending is not None:
             finish(*pending)
@@ -529,7 +578,8 @@ class TiledPipeline:
     def close(self):
         if getattr(self, 'be', None) is not None:
             self.be.close()
-        for name in ('wins', 'local', 'gathered', 'gdx', 'gdy', 'gw', 'u', '_pbuf', '_pu'):
+        for name in ('wins', 'local', 'gathered', 'gdx', 'gdy', 'gw', 'u', '_pbuf', '_pu', '_rx', 'rects', 'table_step',
+                     'table_stream'):
             setattr(self, name, None)
 
 

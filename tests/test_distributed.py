@@ -226,9 +226,9 @@ def test_stack_sharded_over_ranks(tmp_path, world):
 
 # ---- the image-pipelined schedule (TiledPipeline.run_stream) on CPU tensors ------------------------------------------
 class OracleTileBackend:
-    """test double of pygpa_amd.distributed.HipTileBackend: the five things TiledPipeline asks of the GPU, done by the
-    oracle on CPU tensors -- so the schedule (rotating unwrap owners), the gathers, the point-to-point hand-over and the
-    stitching of run_stream run under gloo without a GPU"""
+    """test double of pygpa_amd.distributed.HipTileBackend: what TiledPipeline asks of the GPU, done by the oracle on CPU
+    tensors -- so the schedule (rotating unwrap owners), the device-resident mean, the gathers into preallocated receive
+    buffers, the table-driven stitch, the point-to-point hand-over run under gloo without a GPU"""
 
     def __init__(self):
         import torch
@@ -236,30 +236,67 @@ class OracleTileBackend:
         self.device = torch.device('cpu')
         self.gradients, self.unwrap = _oracle_compute()
         self.iters = {}
+        self.mean = None
 
-    def tile_gradients(self, win, wpitch, mean, kvecs, klists, sigma, border, rect, local_slot, t1, plane):
+    def tile_sums(self, wins, rects, ntiles, max_rows, out):
+        tot = 0.0
+        for t in range(ntiles):
+            o0, o1, z0, z1 = (int(v) for v in rects[t])
+            assert z0 <= max_rows
+            tot += float(wins[t, o0:o0 + z0, o1:o1 + z1].to(self.torch.float64).sum())
+        out[0] = tot
+
+    def set_mean(self, sum_t, scale):
+        self.mean = float(sum_t[0]) * scale
+
+    def tile_gradients(self, win, wpitch, kvecs, klists, sigma, border, rect, local, slot):
         o0, o1, z0, z1 = rect
-        w = win.numpy() - mean
+        w = win.numpy() - self.mean
         dudx, dudy, wn = self.gradients(np.ascontiguousarray(w), kvecs, klists, sigma, border)
         dx = np.zeros((2,) + w.shape)
         dy = np.zeros((2,) + w.shape)
         dx[:, :, :-1] = dudx
         dy[:, :-1, :] = dudy
         t = self.torch.from_numpy
-        local_slot.zero_()
-        local_slot[0:2, :z0, :z1] = t(dx[:, o0:o0 + z0, o1:o1 + z1])
-        local_slot[2:4, :z0, :z1] = t(dy[:, o0:o0 + z0, o1:o1 + z1])
-        local_slot[4, :z0, :z1] = t(wn[o0:o0 + z0, o1:o1 + z1])
+        for c in range(2):
+            blk = local[c, slot]
+            blk.zero_()
+            blk[0, :z0, :z1] = t(dx[c, o0:o0 + z0, o1:o1 + z1])
+            blk[1, :z0, :z1] = t(dy[c, o0:o0 + z0, o1:o1 + z1])
+            blk[2, :z0, :z1] = t(wn[o0:o0 + z0, o1:o1 + z1])
 
-    def sync_tiles(self):
+    def tiles_to_torch(self, host):
         pass
 
-    def unwrap_start(self, c, gdx, gdy, gw, out, kmax):
+    def torch_to_tiles(self):
+        pass
+
+    def stitch(self, c, tiles, slot_stride, table, ntiles, t0, t1, gdx, gdy, gw, concurrent=False):
+        """the table-driven stitch of gpa_stitch_tiles_dev on a flat view of the gathered buffer"""
+        flat = tiles.contiguous().view(-1) if tiles.is_contiguous() else None
+        assert flat is not None or tiles.dim() == 4
+        base = tiles.storage_offset()
+        store = tiles.untyped_storage()
+        whole = self.torch.empty(0, dtype=tiles.dtype).set_(store)      # the buffer the slots are strided in
+        n0, n1 = gw.shape
+        plane = t0 * t1
+        for t in range(ntiles):
+            slot, r0, c0, z0, z1 = (int(v) for v in table[t])
+            blk = whole[base + slot * slot_stride: base + slot * slot_stride + 3 * plane].view(3, t0, t1)
+            zx, zy = min(z1, n1 - 1 - c0), min(z0, n0 - 1 - r0)
+            gdx[r0:r0 + z0, c0:c0 + zx] = blk[0, :z0, :zx]
+            gdy[r0:r0 + zy, c0:c0 + z1] = blk[1, :zy, :z1]
+            gw[r0:r0 + z0, c0:c0 + z1] = blk[2, :z0, :z1]
+
+    def unwrap_start(self, c, gdx, gdy, gw, out, kmax, concurrent=False):
         out.copy_(self.torch.from_numpy(self.unwrap(gdx.numpy(), gdy.numpy(), gw.numpy(), kmax)))
         self.iters[c] = kmax
 
     def unwrap_wait(self, c):
         return self.iters[c]
+
+    def unwrap_to_torch(self, c):
+        pass
 
     def sync_device(self):
         pass

@@ -77,7 +77,7 @@ def test_long_axis_unwrap_vs_oracle(shape, dtypes):
             assert it == ref_it
         # the fused iteration ran (rows up to 512 pixels: row kernel and stencil in one launch)
         want = ['rowdct_fused_kernel', 'colsolve_kernel', 'phi_flush_kernel']
-        want += ['rowidct_pq_kernel'] if (shape[1] <= 512 and shape[0] & (shape[0] - 1) == 0) else ['rowidct_p_kernel', 'pq_kernel']
+        want += ['rowidct_pq_kernel'] if (shape[1] <= 512 and shape[0] & (shape[0] - 1) == 0 and shape[1] & (shape[1] - 1) == 0) else ['rowidct_p_kernel', 'pq_kernel']
         for k in want:
             assert k in prof and prof[k][0] >= 1, (k, sorted(prof))
 

@@ -58,14 +58,9 @@ def main():
         torch.cuda.synchronize()
         t_step = time.perf_counter() - t0
         # the stages on their own (nothing else on the GPU): what the scaling model of DESIGN.md 5 is built from
-        t0_, t1_ = pipe.tshape
-        plane = t0_ * t1_
         def tile_stage():
-            for slot, idx in enumerate(pipe.mine):
-                _, _, (o0, o1), (z0, z1) = pipe.tiles[idx]
-                pipe.be.tile_gradients(pipe.wins[slot], pipe.wshape[1], pipe.mean, pipe.kvecs, pipe.klists, pipe.sigma,
-                                       pipe.border, (o0, o1, z0, z1), pipe.local[slot], t1_, plane)
-            pipe.be.sync_tiles()
+            pipe._tile_stage()
+            pipe.be.tiles_to_torch(True)
         tile_stage()
         t0 = time.perf_counter(); tile_stage(); t_tiles = time.perf_counter() - t0
         def unwrap(c):
