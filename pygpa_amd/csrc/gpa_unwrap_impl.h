@@ -45,6 +45,7 @@ struct Impl {
   void* ring[10];            // search directions of the last RING iterations (fused path), grown on demand
   int nring;
   void *tw0, *tw1;           // FFT twiddles per axis
+  void* tw1h;                // twiddles of length n1 / 2: rows of 8192 points and more run half-length transforms
   void *wk1;                 // w_k along axis 1, natural order
   void *wk0s;                // w_k along axis 0, spectral layout
   void *ha0[2], *ham0[2];    // 1 - cos term of axis-0 bins (spectral layout); [compat]
@@ -233,6 +234,9 @@ constexpr int unwrap_elems(int lg, size_t real_size) {
 // with single calls exactly).
 #ifndef GPA_UNWRAP_LAT_MAXLG
 #define GPA_UNWRAP_LAT_MAXLG 10
+#endif
+#ifndef GPA_ROWHALF_MINLG
+#define GPA_ROWHALF_MINLG 13   // rows from 2^13 points on: one row per half-length transform (gpa_unwrap_rows.hip)
 #endif
 #ifndef GPA_COLSTREAM_MIN
 #define GPA_COLSTREAM_MIN 4096   // square images from this side on take the streamed column solve by default

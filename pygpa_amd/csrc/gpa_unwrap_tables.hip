@@ -234,6 +234,16 @@ hipError_t unwrap_workspace_create(int dtype, int n0, int n1, hipStream_t s, Unw
       e = upload(dtype, ax == 0 ? &w->tw0 : &w->tw1, t, &bytes, s);
       if (e != hipSuccess) return e;
     }
+    if (w->lg1 >= GPA_ROWHALF_MINLG) {
+      const int h = n1 / 2;
+      std::vector<double> t((size_t)2 * h);
+      for (int k = 0; k < h; ++k) {
+        t[2 * k] = cos(-2.0 * M_PI * k / h);
+        t[2 * k + 1] = sin(-2.0 * M_PI * k / h);
+      }
+      e = upload(dtype, &w->tw1h, t, &bytes, s);
+      if (e != hipSuccess) return e;
+    }
     {
       std::vector<double> t((size_t)2 * n1);
       for (int k = 0; k < n1; ++k) {
@@ -296,7 +306,7 @@ void unwrap_workspace_destroy(UnwrapWorkspace* ws) {
   void* bufs[] = {w->r, w->p, w->p2, w->q, w->z, w->tw0, w->tw1, w->wk1, w->wk0s, w->ha0[0], w->ha0[1], w->ham0[0],
                   w->ham0[1], w->hb1[0], w->hb1[1], w->scal, w->flags, w->part, w->btw0, w->btw1, w->chirp0, w->chirp1,
                   w->bspec0, w->bspec1, w->gwk0, w->gwk1, w->gha0[0], w->gha0[1], w->gham0[0], w->gham0[1], w->tritab,
-                  w->mrW0, w->mrW1, w->mrB0, w->mrB1, w->strtab, w->strlam, w->stragg, w->strcar};
+                  w->mrW0, w->mrW1, w->mrB0, w->mrB1, w->strtab, w->strlam, w->stragg, w->strcar, w->tw1h};
   for (void* b : bufs)
     if (b) hipFree(b);
   for (int j = 2; j < w->nring; ++j)
