@@ -31,7 +31,7 @@ __device__ __forceinline__ double block_sum0(double v, double* sh) {
 // ---- sum over the interior rectangles of a rank's windows ----------------------------------------
 // rects[t] = (o0, o1, z0, z1) of window t; one workgroup per (band of TS_ROWS rows, tile); partial sums to part[tile][band],
 // then the last workgroup to finish (a ticket) adds them in index order -- the result does not depend on who that is.
-constexpr int TS_ROWS = 8;
+constexpr int TS_ROWS = 16;
 template <class T>
 __global__ __launch_bounds__(256) void tile_sums_kernel(const T* __restrict__ wins, size_t win_stride, size_t pitch,
                                                        const int* __restrict__ rects, int nbands, double* part,
@@ -42,10 +42,14 @@ __global__ __launch_bounds__(256) void tile_sums_kernel(const T* __restrict__ wi
   const int o0 = rects[4 * t], o1 = rects[4 * t + 1], z0 = rects[4 * t + 2], z1 = rects[4 * t + 3];
   const T* w = wins + (size_t)t * win_stride;
   double acc = 0.0;
-  const int ra = band * TS_ROWS, rb = ra + TS_ROWS < z0 ? ra + TS_ROWS : z0;
-  for (int r = ra; r < rb; ++r) {
-    const T* row = w + (size_t)(o0 + r) * pitch + o1;
-    for (int c = threadIdx.x; c < z1; c += 256) acc += (double)row[c];
+  const int ra = band * TS_ROWS;
+  // (the TS_ROWS loads of a column are independent: all requested before the first is added)
+  for (int c = threadIdx.x; c < z1; c += 256) {
+    T v[TS_ROWS];
+#pragma unroll
+    for (int j = 0; j < TS_ROWS; ++j) v[j] = ra + j < z0 ? w[(size_t)(o0 + ra + j) * pitch + o1 + c] : T(0);
+#pragma unroll
+    for (int j = 0; j < TS_ROWS; ++j) acc += (double)v[j];
   }
   const double tot = block_sum0(acc, sh);
   const int nblocks = gridDim.x * gridDim.y;
@@ -81,16 +85,24 @@ struct FieldCopy {
   int rows, cols;
 };
 struct FieldCopies { FieldCopy f[6]; };
-constexpr int CP_ROWS = 8;   // rows per workgroup of the two copy kernels
+constexpr int CP_ROWS = 32;  // rows per workgroup of the two copy kernels (8 at a time in flight per thread)
 template <class T>
 __global__ __launch_bounds__(256) void copy_fields_kernel(FieldCopies fc) {
   const FieldCopy f = fc.f[blockIdx.z];
   const int c = blockIdx.x * 256 + threadIdx.x;
   if (c >= f.cols) return;
+  for (int j0 = 0; j0 < CP_ROWS; j0 += 8) {
+    T v[8];
 #pragma unroll
-  for (int j = 0; j < CP_ROWS; ++j) {
-    const int r = blockIdx.y * CP_ROWS + j;
-    if (r < f.rows) ((T*)f.dst)[(size_t)r * f.dst_pitch + c] = ((const T*)f.src)[(size_t)r * f.src_pitch + c];
+    for (int j = 0; j < 8; ++j) {
+      const int r = blockIdx.y * CP_ROWS + j0 + j;
+      v[j] = r < f.rows ? ((const T*)f.src)[(size_t)r * f.src_pitch + c] : T(0);
+    }
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+      const int r = blockIdx.y * CP_ROWS + j0 + j;
+      if (r < f.rows) ((T*)f.dst)[(size_t)r * f.dst_pitch + c] = v[j];
+    }
   }
 }
 
@@ -111,10 +123,18 @@ __global__ __launch_bounds__(256) void stitch_kernel(const T* __restrict__ tiles
   const int c = blockIdx.x * 256 + threadIdx.x;
   if (c >= z1 || c0 + c >= d.cols[f]) return;
   const T* src = tiles + (size_t)slot * slot_stride + (size_t)f * field_stride;
+  for (int j0 = 0; j0 < CP_ROWS; j0 += 8) {
+    T v[8];
 #pragma unroll
-  for (int j = 0; j < CP_ROWS; ++j) {
-    const int r = blockIdx.y * CP_ROWS + j;
-    if (r < z0 && r0 + r < d.rows[f]) ((T*)d.dst[f])[(size_t)(r0 + r) * d.pitch[f] + c0 + c] = src[(size_t)r * tile_pitch + c];
+    for (int j = 0; j < 8; ++j) {
+      const int r = blockIdx.y * CP_ROWS + j0 + j;
+      v[j] = (r < z0 && r0 + r < d.rows[f]) ? src[(size_t)r * tile_pitch + c] : T(0);
+    }
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+      const int r = blockIdx.y * CP_ROWS + j0 + j;
+      if (r < z0 && r0 + r < d.rows[f]) ((T*)d.dst[f])[(size_t)(r0 + r) * d.pitch[f] + c0 + c] = v[j];
+    }
   }
 }
 
