@@ -32,7 +32,7 @@ namespace gpa {
 static const char* const kOptNames[OPT_COUNT] = {
     "PBS_FULLBAND", "USE_GRAPH", "SERIAL_UNWRAP", "NO_WORKER", "NO_KSPLIT", "NO_COMPACT", "NO_SHARED", "SHARED_A",
     "NO_PAIR", "PBS_E8", "TRI_SMALL", "TRI_Q", "NO_MR", "MR_FORCE_BLUESTEIN", "NO_ROWPQ", "COLSOLVE", "NO_LAT",
-    "F32_EPS_FLOOR", "COLSTREAM_CHUNK", "NO_ROWHALF"};
+    "F32_EPS_FLOOR", "COLSTREAM_CHUNK", "NO_ROWHALF", "PAIR_MAXSIDE"};
 static OptVal g_opts[OPT_COUNT];
 static std::once_flag g_opts_once;
 static void opt_assign(OptVal& o, const char* value) {
@@ -1335,7 +1335,11 @@ static int extract_stage(gpa_plan* p, const double* kvecs, int P, const double* 
   TRY(stage_kvectors(p, klists, kr.data(), B, Bx));
   TRY(ensure_tbuf(p, *Bx));
   TRY(stage_kmat(p, kvecs, P));
-  p->use_pair = (size_t)p->n0 * p->n1 <= (size_t)1024 * 1024 && !opt_set(OPT_NO_PAIR);
+  {
+    // (PAIR_MAXSIDE: measurement switch for the size up to which both components share one set of launches)
+    const size_t side = opt_set(OPT_PAIR_MAXSIDE) ? (size_t)opt(OPT_PAIR_MAXSIDE).num : 1024;
+    p->use_pair = (size_t)p->n0 * p->n1 <= side * side && !opt_set(OPT_NO_PAIR);
+  }
   if (p->use_pair && !p->have_uwp) {
     size_t bp = 0;
     hipError_t ep = unwrap_workspace_create(p->dtype, p->n0, p->n1, p->stream, &p->uwp, &bp, 2);

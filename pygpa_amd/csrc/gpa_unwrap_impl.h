@@ -239,7 +239,7 @@ constexpr int unwrap_elems(int lg, size_t real_size) {
 #define GPA_ROWHALF_MINLG 13   // rows from 2^13 points on: one row per half-length transform (gpa_unwrap_rows.hip)
 #endif
 #ifndef GPA_COLSTREAM_MIN
-#define GPA_COLSTREAM_MIN 4096   // square images from this side on take the streamed column solve by default
+#define GPA_COLSTREAM_MIN 2048   // square images from this side on take the streamed column solve by default (2048^2: 26 -> 19 us per iteration, 3000^2: 58 -> 43; 1024^2: slower)
 #endif
 #define GPA_ROWPQ_MAXLG 9   // rows up to 512 pixels: row kernel and stencil in one launch (rowidct_pq_kernel)
 inline bool unwrap_latency_tuned(const Impl* w, int lg) {
