@@ -96,6 +96,11 @@ def kernel_models(n0, n1, L0, L1, P, K, Bx, s, iters):
         # per working launch and component: q, R in, R out / R in, Z out / Z, p in, p out / p, w in, q out
         'rowdct_fused_kernel': {'bytes': px * 3 * s, 'flops': (n0 / 2) * (fft(L1) + 12 * L1)},
         'colsolve_kernel': {'bytes': px * 2 * s, 'flops': (n1 / 2) * (2 * fft(L0) + 24 * L0)},
+        'colsolve_tri_kernel': {'bytes': px * 2 * s, 'flops': None},
+        # the streamed column solve: R in (chunk sums out: 16 B per 64 samples) / sums in, carries out / R + carries in, Z out
+        'colstream_agg_kernel': {'bytes': px * s, 'flops': None},
+        'colstream_scan_kernel': {'bytes': None, 'flops': None},
+        'colstream_apply_kernel': {'bytes': px * 2 * s, 'flops': None},
         'rowidct_p_kernel': {'bytes': px * 3 * s, 'flops': (n0 / 2) * (fft(L1) + 12 * L1)},
         'pq_kernel': {'bytes': px * 3 * s, 'flops': None},
         # phi in/out once per flush plus the kept search directions
@@ -236,6 +241,7 @@ def load_counters():
         return {'_stale': 'profiles/counters.json (commit %s) was measured on other kernel sources than this tree (csrc hash %s '
                           'vs %s): not used' % (c.get('_meta', {}).get('commit', '?'), c.get('_meta', {}).get('csrc_sha256', 'none'),
                                                 csrc_sha256())}
+    return c
 
 
 def measure(n, knx, kny, np_dt, kmax, steps, warmup, depth=1, profile=True):
@@ -293,8 +299,8 @@ def kernel_table(n, L0, L1, P, K, Bx, s, iters, kern, stage, res_s):
     same_cfg = meta.get('config', {'n': 4096, 'K': 16, 'dtype': 'f32'}) == {'n': n, 'K': K, 'dtype': 'f32' if s == 4 else 'f64'}
     if not same_cfg:
         counters = {}      # the committed counters belong to ONE configuration (their _meta says which)
-    work = {'rowdct_fused_kernel': sum(iters), 'rowidct_p_kernel': sum(iters), 'pq_kernel': sum(iters),
-            'rowidct_pq_kernel': sum(iters), 'colsolve_kernel': sum(iters)}   # launches that do work (those after convergence return at once)
+    work = {k: sum(iters) for k in ('rowdct_fused_kernel', 'rowidct_p_kernel', 'pq_kernel', 'rowidct_pq_kernel', 'colsolve_kernel',
+                                     'colsolve_tri_kernel', 'colstream_agg_kernel', 'colstream_scan_kernel', 'colstream_apply_kernel')}   # launches that do work (those after convergence return at once)
     table = {}
     for name, (calls, ms) in kern.items():
         m = models.get(name, {})

@@ -51,3 +51,21 @@ def test_gpus_flag_spawns_and_fails_loudly_without_gpu():
     assert not [ln for ln in r.stdout.decode().splitlines() if ln.startswith('{')]     # no JSON line from a run that did not happen
     err = r.stderr.decode()
     assert 'torch.distributed' in err or 'ChildFailedError' in err or 'cuda' in err.lower()
+
+
+def test_counters_are_refused_on_other_kernel_sources(tmp_path, monkeypatch):
+    """profiles/counters.json carries the hash of the kernel sources it was measured on; bench.py uses it only on a tree
+    with the same hash (the bench must not trust counters of another build)"""
+    import json
+    import bench
+    h = bench.csrc_sha256()
+    assert len(h) == 16 and h == bench.csrc_sha256()
+    (tmp_path / 'profiles').mkdir()
+    f = tmp_path / 'profiles' / 'counters.json'
+    monkeypatch.setattr(bench, 'ROOT', str(tmp_path))
+    monkeypatch.setattr(bench, 'csrc_sha256', lambda: h)
+    f.write_text(json.dumps({'_meta': {'commit': 'abc', 'csrc_sha256': h}, 'passB_shared_kernel': {'hbm_bytes': 1}}))
+    assert bench.load_counters()['passB_shared_kernel']['hbm_bytes'] == 1
+    f.write_text(json.dumps({'_meta': {'commit': 'abc', 'csrc_sha256': 'somethingelse'}, 'passB_shared_kernel': {'hbm_bytes': 1}}))
+    c = bench.load_counters()
+    assert list(c) == ['_stale'] and 'not used' in c['_stale']

@@ -24,6 +24,8 @@ def main():
     args = ap.parse_args()
     import torch
     from pygpa_amd import distributed as D
+    from pygpa_amd import _lib
+    _lib.set_option('F32_EPS_FLOOR', '0')   # the reference's stopping test alone (kmax iterations here), as in bench.py
     from pygpa_amd.synthetic import hex_kvecs, explicit_klists
     kvecs = hex_kvecs(0.1, 7.0)
     sigma = 10
@@ -68,7 +70,21 @@ def main():
             return pipe.be.unwrap_wait(c)
         unwrap(0)
         t0 = time.perf_counter(); it0 = unwrap(0); t_unw = time.perf_counter() - t0
-        iso = {'tile_stage_s_all_windows': round(t_tiles, 5), 'tile_stage_s_per_window_alone': round(t_tiles / len(pipe.tiles), 6),
+        # the pipeline's own data-path kernels on an otherwise idle GPU: interior sums + mean, stitch of one component
+        def timed(fn, reps=3):
+            fn(); torch.cuda.synchronize()
+            t0 = time.perf_counter()
+            for _ in range(reps):
+                fn()
+            pipe.be.sync_tiles_all()
+            return (time.perf_counter() - t0) / reps
+        pipe.be.sync_tiles_all = lambda: (pipe.be.plan_w.sync(), [pl.sync() for pl in pipe.be.plan_c if pl is not None], torch.cuda.synchronize())
+        t_mean = timed(pipe.image_mean)
+        plane = pipe.tshape[0] * pipe.tshape[1]
+        t_stitch = timed(lambda: pipe.be.stitch(0, pipe.local[0], 3 * plane, pipe.table_stream, len(pipe.tiles), pipe.tshape[0], pipe.tshape[1],
+                                                pipe.gdx[0], pipe.gdy[0], pipe.gw))
+        iso = {'mean_s_alone': round(t_mean, 6), 'stitch_s_one_component_alone': round(t_stitch, 6),
+               'tile_stage_s_all_windows': round(t_tiles, 5), 'tile_stage_s_per_window_alone': round(t_tiles / len(pipe.tiles), 6),
                'unwrap_s_one_component_alone': round(t_unw, 5), 'unwrap_iters': it0}
         print(n, 'alone:', json.dumps(iso), flush=True)
         out['%d' % n] = {'alone': iso,'windows': len(pipe.tiles), 'window': W, 'stream_s_per_image': round(dt, 5), 'step_s_per_image': round(t_step, 5),
