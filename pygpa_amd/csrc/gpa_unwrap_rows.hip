@@ -622,16 +622,23 @@ __global__ __launch_bounds__((RowHalfGeom<T, LG>::THREADS), (sizeof(T) == 4 && L
   Vec4<T> stage[NV];
 #pragma unroll
   for (int v = 0; v < NV; ++v) stage[v] = *reinterpret_cast<const Vec4<T>*>(src + 4 * (tid + TPF * v));
-  // the kept spectrum is requested before the transform so that its latency hides behind it
+  // the kept spectrum is requested before the transform so that its latency hides behind it -- except for f32 rows of
+  // 16384 points, whose 128-register budget (two workgroups per CU) it would overrun: there it is requested after
+  // the transform, and the other workgroup of the CU covers the wait
+#ifndef GPA_ROWHALF_LATE_R
+#define GPA_ROWHALF_LATE_R (sizeof(T) == 4 && LG == 14)
+#endif
+  constexpr bool LATE_R = GPA_ROWHALF_LATE_R;
   T rlo[E], rhi[E];
-  if (it > 0) {
+  auto load_kept = [&]() {
 #pragma unroll
     for (int i = 0; i < E; ++i) {
       const int k = tid + TPF * i;
       rlo[i] = r[o + k];
       rhi[i] = r[o + (k == 0 ? HN : N - k)];
     }
-  }
+  };
+  if (it > 0 && !LATE_R) load_kept();
 #pragma unroll
   for (int v = 0; v < NV; ++v) {
     const int j = tid + TPF * v;
@@ -644,6 +651,7 @@ __global__ __launch_bounds__((RowHalfGeom<T, LG>::THREADS), (sizeof(T) == 4 && L
   for (int i = 0; i < E; ++i) x[i] = lds[F::pad(tid + TPF * i)];
   __syncthreads();
   F::forward(x, lds, tid, tw);
+  if (it > 0 && LATE_R) load_kept();
   __syncthreads();
 #pragma unroll
   for (int i = 0; i < E; ++i) lds[F::pad(F::spec_index(tid, i))] = x[i];
@@ -803,7 +811,10 @@ hipError_t run_rowidct_p_half(const Impl* w, const void* pin, void* pout, const 
   return hipGetLastError();
 }
 // rows of 8192 points and more take the half-length kernels (NO_ROWHALF: the packed ones, for tests and measurements)
-inline bool use_row_half(const Impl* w) { return w->lg1 >= GPA_ROWHALF_MINLG && w->tw1h && !opt_set(OPT_NO_ROWHALF); }
+inline bool use_row_half(const Impl* w) {
+  const int minlg = opt_set(OPT_ROWHALF_MINLG) ? (int)opt(OPT_ROWHALF_MINLG).num : GPA_ROWHALF_MINLG;
+  return w->lg1 >= minlg && w->lg1 >= 12 && w->tw1h && !opt_set(OPT_NO_ROWHALF);
+}
 }  // namespace
 
 hipError_t pow2_rowidct_pq(const Impl* w, const void* pin, void* pout, const void* weight, const double* part_rho,
@@ -817,6 +828,8 @@ hipError_t pow2_rowidct_pq(const Impl* w, const void* pin, void* pout, const voi
 hipError_t pow2_rowidct_p(const Impl* w, const void* pin, void* pout, const double* part_rho, int nrho, int it,
                           hipStream_t s) {
   if (use_row_half(w)) {
+    if (w->lg1 == 12) return w->dtype == 0 ? run_rowidct_p_half<float, 12>(w, pin, pout, part_rho, nrho, it, s)
+                                            : run_rowidct_p_half<double, 12>(w, pin, pout, part_rho, nrho, it, s);
     if (w->lg1 == 13) return w->dtype == 0 ? run_rowidct_p_half<float, 13>(w, pin, pout, part_rho, nrho, it, s)
                                             : run_rowidct_p_half<double, 13>(w, pin, pout, part_rho, nrho, it, s);
     if (w->lg1 == 14 && w->dtype == 0) return run_rowidct_p_half<float, 14>(w, pin, pout, part_rho, nrho, it, s);
@@ -831,6 +844,8 @@ hipError_t pow2_rowidct_p(const Impl* w, const void* pin, void* pout, const doub
 hipError_t pow2_rowdct_fused(const Impl* w, const void* q, int ring, const double* part_pq, int npq, double* part_norm,
                              int it, int* nnorm, int init, hipStream_t s) {
   if (use_row_half(w)) {
+    if (w->lg1 == 12) return w->dtype == 0 ? run_rowdct_half<float, 12>(w, q, ring, part_pq, npq, part_norm, it, nnorm, init, s)
+                                            : run_rowdct_half<double, 12>(w, q, ring, part_pq, npq, part_norm, it, nnorm, init, s);
     if (w->lg1 == 13) return w->dtype == 0 ? run_rowdct_half<float, 13>(w, q, ring, part_pq, npq, part_norm, it, nnorm, init, s)
                                             : run_rowdct_half<double, 13>(w, q, ring, part_pq, npq, part_norm, it, nnorm, init, s);
     if (w->lg1 == 14 && w->dtype == 0) return run_rowdct_half<float, 14>(w, q, ring, part_pq, npq, part_norm, it, nnorm, init, s);

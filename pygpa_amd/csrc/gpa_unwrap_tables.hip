@@ -234,7 +234,7 @@ hipError_t unwrap_workspace_create(int dtype, int n0, int n1, hipStream_t s, Unw
       e = upload(dtype, ax == 0 ? &w->tw0 : &w->tw1, t, &bytes, s);
       if (e != hipSuccess) return e;
     }
-    if (w->lg1 >= GPA_ROWHALF_MINLG) {
+    if (w->lg1 >= 12) {   // (rows of 4096 points can be switched to the half-length kernels for measurements: ROWHALF_MINLG)
       const int h = n1 / 2;
       std::vector<double> t((size_t)2 * h);
       for (int k = 0; k < h; ++k) {
