@@ -29,15 +29,15 @@ __device__ __forceinline__ double block_sum0(double v, double* sh) {
 }
 
 // ---- sum over the interior rectangles of a rank's windows ----------------------------------------
-// rects[t] = (o0, o1, z0, z1) of window t; one workgroup per (band of TS_ROWS rows, tile); partial sums to part[tile][band],
-// then the last workgroup to finish (a ticket) adds them in index order -- the result does not depend on who that is.
+// rects[t] = (o0, o1, z0, z1) of window t; one workgroup per (band of TS_ROWS rows, tile) writes its partial sum to
+// part[tile][band]; a second one-workgroup launch adds the partials in index order.  (Two launches, not a
+// last-workgroup-done ticket: an agent-scope fence per workgroup -- L2 write-back and invalidate across the 8 XCDs -- made
+// the ticket version take 1.0 ms for 320 MB at 16384^2; profiles/r04_tile_kernels.txt.)
 constexpr int TS_ROWS = 16;
 template <class T>
 __global__ __launch_bounds__(256) void tile_sums_kernel(const T* __restrict__ wins, size_t win_stride, size_t pitch,
-                                                       const int* __restrict__ rects, int nbands, double* part,
-                                                       unsigned* ticket, double* out) {
+                                                       const int* __restrict__ rects, int nbands, double* part) {
   __shared__ double sh[8];
-  __shared__ bool last;
   const int t = blockIdx.y, band = blockIdx.x;
   const int o0 = rects[4 * t], o1 = rects[4 * t + 1], z0 = rects[4 * t + 2], z1 = rects[4 * t + 3];
   const T* w = wins + (size_t)t * win_stride;
@@ -52,23 +52,14 @@ __global__ __launch_bounds__(256) void tile_sums_kernel(const T* __restrict__ wi
     for (int j = 0; j < TS_ROWS; ++j) acc += (double)v[j];
   }
   const double tot = block_sum0(acc, sh);
-  const int nblocks = gridDim.x * gridDim.y;
-  if (threadIdx.x == 0) {
-    part[(size_t)t * nbands + band] = tot;
-    __threadfence();
-    last = atomicAdd(ticket, 1u) == (unsigned)(nblocks - 1);
-  }
-  __syncthreads();
-  if (!last) return;
-  __threadfence();
+  if (threadIdx.x == 0) part[(size_t)t * nbands + band] = tot;
+}
+__global__ __launch_bounds__(256) void tile_sums_final_kernel(const double* __restrict__ part, int n, double* out) {
+  __shared__ double sh[8];
   double a = 0.0;
-  for (int i = threadIdx.x; i < nblocks; i += 256) a += part[i];   // (fixed assignment of partials to threads)
-  __syncthreads();
+  for (int i = threadIdx.x; i < n; i += 256) a += part[i];   // (fixed assignment of partials to threads)
   const double s = block_sum0(a, sh);
-  if (threadIdx.x == 0) {
-    out[0] = s;
-    *ticket = 0;   // ready for the next launch
-  }
+  if (threadIdx.x == 0) out[0] = s;
 }
 
 // mean of the whole image in the plan's element type from the (all-reduced) sum
@@ -145,9 +136,11 @@ hipError_t launch_tile_sums(int dtype, const void* wins, size_t win_stride, size
   const int nbands = (max_rows + TS_ROWS - 1) / TS_ROWS;
   GPA_PROF("tile_sums_kernel", s);
   if (dtype == 0)
-    tile_sums_kernel<float><<<dim3(nbands, ntiles), 256, 0, s>>>((const float*)wins, win_stride, pitch, rects_dev, nbands, part, ticket, out);
+    tile_sums_kernel<float><<<dim3(nbands, ntiles), 256, 0, s>>>((const float*)wins, win_stride, pitch, rects_dev, nbands, part);
   else
-    tile_sums_kernel<double><<<dim3(nbands, ntiles), 256, 0, s>>>((const double*)wins, win_stride, pitch, rects_dev, nbands, part, ticket, out);
+    tile_sums_kernel<double><<<dim3(nbands, ntiles), 256, 0, s>>>((const double*)wins, win_stride, pitch, rects_dev, nbands, part);
+  tile_sums_final_kernel<<<1, 256, 0, s>>>(part, nbands * ntiles, out);
+  (void)ticket;
   return hipGetLastError();
 }
 int tile_sums_bands(int max_rows) { return (max_rows + TS_ROWS - 1) / TS_ROWS; }
