@@ -1,5 +1,5 @@
 #!/bin/bash
-# usage (GPU box): COMMIT=<sha> [ROUND=r03] [SKIP_TESTS=1] tools/gpu_close.sh
+# usage (GPU box): COMMIT=<sha> [SKIP_TESTS=1] [SKIP_PMC=1] tools/gpu_close.sh
 # Closing pass of a round: the whole GPU suite, smoke, the bench line, rocprofv3 kernel stats (4096^2 f32 / f64, 3000^2, 512^2)
 # and the PMC passes behind profiles/counters.json (one pass per counter set: the guide's rule).  Everything lands under
 # gpurun_out/close/; copy what is to be kept into profiles/ with the round's prefix.
@@ -30,6 +30,13 @@ kstats 3000_f32 --size 3000
 kstats 2048_c2 --size 2048 --kgrid 4x2
 kstats 512_f32 --size 512
 unset GPA_SERIAL_UNWRAP
+# one unwrap component at 8192^2 / 16384^2 and the tile pipeline's image stream at 16384^2 (-> gpurun_out/kstats/)
+WHAT="unwrap8192 unwrap16384 tiles16384" bash $ROOT/tools/gpu_kstats.sh > $out/kstats_long.log 2>&1; tail -3 $out/kstats_long.log | cut -c1-150
+cp $ROOT/gpurun_out/kstats/kernel_stats_unwrap_8192.csv $ROOT/gpurun_out/kstats/kernel_stats_unwrap_16384.csv $ROOT/gpurun_out/kstats/kernel_stats_tiles_16384.csv $out/ 2>/dev/null
+cp $ROOT/gpurun_out/stage_times.json $out/ 2>/dev/null
+cd $ROOT && timeout 600 bash tools/gpu_unwrap_sizes.sh > /dev/null 2>&1; cp gpurun_out/unwrap_sizes.txt $out/ 2>/dev/null
+SIZES="256 500 512 1000 1024 1500 2000 2048 3000 4096 8192 16384" timeout 900 bash tools/gpu_sizes.sh > /dev/null 2>&1; cp gpurun_out/sizes.txt $out/ 2>/dev/null
+cd /tmp
 [ -n "$SKIP_PMC" ] && exit 0
 i=0
 for set in "FETCH_SIZE" "WRITE_SIZE" "SQ_INSTS_VALU SQ_WAVES SQ_INSTS_LDS SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE SQ_WAVE_CYCLES SQ_WAIT_INST_ANY SQ_BUSY_CYCLES" \
