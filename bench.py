@@ -98,7 +98,9 @@ def kernel_models(n0, n1, L0, L1, P, K, Bx, s, iters):
         'colsolve_kernel': {'bytes': px * 2 * s, 'flops': (n1 / 2) * (2 * fft(L0) + 24 * L0)},
         'colsolve_tri_kernel': {'bytes': px * 2 * s, 'flops': None},
         # the streamed column solve: R in (chunk sums out: 16 B per 64 samples) / sums in, carries out / R + carries in, Z out
-        'colstream_agg_kernel': {'bytes': px * s, 'flops': None},
+        'colstream_agg_kernel': {'bytes': px * s, 'flops': None},   # (R in; with the stencil-fused iteration R, D in, R out: kernel_table)
+        # stencil + row transform in one launch: p, w in, D = DCT_rows(q) out
+        'pqdct_kernel': {'bytes': px * 3 * s, 'flops': (n0 / 2) * (fft(L1) + 12 * L1)},
         'colstream_scan_kernel': {'bytes': None, 'flops': None},
         'colstream_apply_kernel': {'bytes': px * 2 * s, 'flops': None},
         'rowidct_p_kernel': {'bytes': px * 3 * s, 'flops': (n0 / 2) * (fft(L1) + 12 * L1)},
@@ -300,7 +302,12 @@ def kernel_table(n, L0, L1, P, K, Bx, s, iters, kern, stage, res_s):
     if not same_cfg:
         counters = {}      # the committed counters belong to ONE configuration (their _meta says which)
     work = {k: sum(iters) for k in ('rowdct_fused_kernel', 'rowidct_p_kernel', 'pq_kernel', 'rowidct_pq_kernel', 'colsolve_kernel',
-                                     'colsolve_tri_kernel', 'colstream_agg_kernel', 'colstream_scan_kernel', 'colstream_apply_kernel')}   # launches that do work (those after convergence return at once)
+                                     'colsolve_tri_kernel', 'colstream_agg_kernel', 'colstream_scan_kernel', 'colstream_apply_kernel', 'pqdct_kernel')}   # launches that do work (those after convergence return at once)
+    if 'pqdct_kernel' in kern and 'colstream_agg_kernel' in kern:
+        # the stencil-fused iteration: the first launch of each component only sums (R in), the others apply R -= alpha D
+        # as well (R, D in, R out): bytes per launch averaged over the launches of the step
+        calls = kern['colstream_agg_kernel'][0]
+        models['colstream_agg_kernel'] = {'bytes': n * n * s * (2 * 1 + 3 * max(calls - 2, 0)) / max(calls, 1), 'flops': None}
     table = {}
     for name, (calls, ms) in kern.items():
         m = models.get(name, {})

@@ -80,16 +80,25 @@ static hipError_t run_pcg(Impl* w, const void* a, const void* b, const void* wei
     int nnorm = 0;
     // one image with rows of at most 512 pixels: row kernel and stencil in one launch (rowidct_pq_kernel)
     const bool rowpq = !w->generic && w->lat_ok && w->nprob <= 2 && w->lg1 <= GPA_ROWPQ_MAXLG && w->n0 >= 4 && !opt_set(OPT_NO_ROWPQ);
+    // rows of 2048 / 4096 points with the streamed column solve: stencil and row transform in one launch (pqdct_kernel),
+    // the residual update applied by the column solve's first launch -- five launches and 44 bytes per pixel per
+    // iteration instead of six and 48 (NO_PQDCT keeps the separate kernels)
+    const bool fuse_pq = !rowpq && pow2_pqdct_offered(w) && colstream_is_default(w) && !opt_set(OPT_NO_PQDCT);
     for (int it = 0; it < kmax; ++it) {
       // (first iteration of a prepared start: the partial norms of r0 ride in the part_pq / npq arguments)
       const bool init = it == 0 && a == nullptr;
       const double* pin_part = init ? w->part : part_pq;
       const int pin_n = init ? w->prepared_parts : npq;
-      e = w->generic ? mr_rowdct_fused(w, w->q, ring, pin_part, pin_n, part_norm, it, &nnorm, init ? 1 : 0, s)
-                     : pow2_rowdct_fused(w, w->q, ring, pin_part, pin_n, part_norm, it, &nnorm, init ? 1 : 0, s);
-      if (e != hipSuccess) return e;
       int nrow = 0;   // partial sums of rho = <r, z>: one per column workgroup (Parseval, solve_combine)
-      if ((e = dispatch_colsolve(w, compat, s, part_norm, nnorm, it, eps, part_rho, &nrow, w->r)) != hipSuccess) return e;
+      if (fuse_pq && it > 0) {
+        // w->q holds D = DCT_rows(q) of the previous iteration: R -= alpha D inside the column solve
+        if ((e = dispatch_colstream_update(w, compat, s, it, eps, ring, w->q, part_pq, npq, part_norm, &nnorm, part_rho, &nrow)) != hipSuccess) return e;
+      } else {
+        e = w->generic ? mr_rowdct_fused(w, w->q, ring, pin_part, pin_n, part_norm, it, &nnorm, init ? 1 : 0, s)
+                       : pow2_rowdct_fused(w, w->q, ring, pin_part, pin_n, part_norm, it, &nnorm, init ? 1 : 0, s);
+        if (e != hipSuccess) return e;
+        if ((e = dispatch_colsolve(w, compat, s, part_norm, nnorm, it, eps, part_rho, &nrow, w->r)) != hipSuccess) return e;
+      }
       if (it > 0 && it % ring == 0) {   // slot it % ring still holds p of iteration it - ring: a flush in mid-solve
         if ((e = launch_phi_flush(w, ring, phi, phi_unwritten, 0, part_pq, npq, s)) != hipSuccess) return e;
         phi_unwritten = false;
@@ -102,7 +111,13 @@ static hipError_t run_pcg(Impl* w, const void* a, const void* b, const void* wei
       }
       e = w->generic ? mr_rowidct_p(w, pin, pout, part_rho, nrow, it, s) : pow2_rowidct_p(w, pin, pout, part_rho, nrow, it, s);
       if (e != hipSuccess) return e;
-      if ((e = launch_pq(w, pout, weight, it, part_pq, s)) != hipSuccess) return e;
+      if (fuse_pq && it + 1 < kmax) {
+        if ((e = pow2_pqdct(w, pout, weight, part_pq, &npq, s)) != hipSuccess) return e;
+      } else {
+        // (the last iteration's q is only needed for its <p, q>: the plain stencil)
+        npq = pq_partials(w);
+        if ((e = launch_pq(w, pout, weight, it, part_pq, s)) != hipSuccess) return e;
+      }
     }
     // the flush that ends the solve takes the last step length from the stencil kernel's partial sums and files the
     // iteration count

@@ -537,12 +537,15 @@ hipError_t dispatch_colsolve_tri(const Impl* w, int compat, hipStream_t s, const
 }
 }  // namespace
 
+bool colstream_is_default(const Impl* w) {
+  return w->strtab && (w->col_mode == 3 || (w->col_mode == 0 && w->n0 >= GPA_COLSTREAM_MIN));
+}
 hipError_t dispatch_colsolve(const Impl* w, int compat, hipStream_t s, const double* part_norm, int nnorm, int it,
                              double eps, double* part_rho, int* nrho, const void* zin) {
   // Square images from 4096 points a side: the streamed recursion (gpa_unwrap_colstream.hip) -- three launches that
   // read 1 KiB row pieces at the streaming rate instead of one that holds whole columns and is down to 32 / 16 / 8-byte
   // pieces at 4096 / 8192 / 16384 points.  COLSOLVE=stream forces it wherever it is offered, =tri / =fft the resident kernels.
-  if (w->strtab && part_rho && (w->col_mode == 3 || (w->col_mode == 0 && w->n0 >= GPA_COLSTREAM_MIN)))
+  if (part_rho && colstream_is_default(w))
     return dispatch_colstream(w, compat, s, part_norm, nnorm, it, eps, part_rho, nrho, zin);
   if (w->generic && part_rho) {
     // smooth sizes: the transform-free solve where it applies (square images; it is 2-3x faster than two mixed-radix

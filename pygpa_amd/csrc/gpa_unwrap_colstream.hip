@@ -65,17 +65,28 @@ __device__ __forceinline__ double reread(T v) {
 }
 
 // ---- launch 1: chunk sums -----------------------------------------------------------------------
-template <class T, int C, bool RAGGED>
-__global__ __launch_bounds__(CS_COLS) void colstream_agg_kernel(const T* __restrict__ R, int n0, int n1,
+// UPDATE (iterations >= 1 of the stencil-fused iteration, gpa_unwrap.hip): the kernel first applies the pending update of the
+// row spectrum, R <- R - alpha D with D = DCT-II_rows(q) from pqdct_kernel and alpha = rho / <p, q> from that kernel's
+// partial sums (phase_unwrap.py:343-345; by linearity the update of r is the update of its row spectrum), writes R back,
+// and adds the partial ||r||^2 = (1 / 2N) sum_k c_k R_k^2 (Parseval, c_0 = 1/2) that the scan kernel's stopping test reads.
+template <class T, int C, bool RAGGED, bool UPDATE>
+__global__ __launch_bounds__(CS_COLS) void colstream_agg_kernel(T* __restrict__ R, const T* __restrict__ Dq, int n0, int n1,
                                                                const double* __restrict__ lamtab, double2* __restrict__ agg,
-                                                               double2* __restrict__ agg0, int S, const int* flags, size_t pimg,
-                                                               size_t pagg) {
+                                                               double2* __restrict__ agg0, int S, const int* flags,
+                                                               const double* part_pq, int npq, double* scal, int it, int ring,
+                                                               double* part_norm, size_t pimg, size_t pagg) {
   {
     const size_t pb = blockIdx.z;
     R += pb * pimg;
+    if (UPDATE) Dq += pb * pimg;
     agg += pb * pagg;
     agg0 += pb * S;
     flags += pb * FLAGS_N;
+    if (UPDATE) {
+      part_pq += pb * PART_N;
+      part_norm += pb * PART_N;
+      scal += pb * SCAL_N;
+    }
   }
   // (stopped in an EARLIER iteration?  this iteration's test is the scan kernel's.  The flag is requested with the data and
   //  looked at after the loads have been issued: one memory round trip, not two)
@@ -87,16 +98,50 @@ __global__ __launch_bounds__(CS_COLS) void colstream_agg_kernel(const T* __restr
   const int len = !RAGGED ? C : (n0 - row0 < C ? n0 - row0 : C);
   // (a wave-uniform row pointer plus the lane's 32-bit column: the scalar-base form of the load, no 64-bit address
   //  per row in vector registers)
-  const T* rp = R + (size_t)row0 * n1;
   const unsigned yo = (unsigned)yc * (unsigned)sizeof(T);   // byte offset, 32 bits: base (scalar) + zext(offset)
   T x[C];
+  {
+    const T* rp = R + (size_t)row0 * n1;
 #pragma unroll
-  for (int k = 0; k < C; ++k) {
-    x[k] = (!RAGGED || k < len) ? *reinterpret_cast<const T*>(reinterpret_cast<const char*>(rp) + yo) : T(0);
-    rp += n1;
+    for (int k = 0; k < C; ++k) {
+      x[k] = (!RAGGED || k < len) ? *reinterpret_cast<const T*>(reinterpret_cast<const char*>(rp) + yo) : T(0);
+      rp += n1;
+    }
   }
   const double lam = lamtab[yc];
-  if (stopped) return;
+  [[maybe_unused]] __shared__ double sh[32];
+  if constexpr (UPDATE) {
+    double pq_part = load_partials(part_pq, npq);
+    const double rho = scal[8 + ((it - 1) & 1)];
+    if (stopped) return;
+    const double pq = block_sum(pq_part, sh);
+    const double alpha_d = rho / pq;   // phase_unwrap.py:343
+    const T alpha = (T)alpha_d;
+    // (phi += alpha p is not applied here: alpha is filed for phi_flush_kernel)
+    if (blockIdx.x == 0 && blockIdx.y == 0 && threadIdx.x == 0) scal[SC_ALPHA + (it - 1) % ring] = alpha_d;
+    const T* dp = Dq + (size_t)row0 * n1;
+    T* wp = R + (size_t)row0 * n1;
+    double sq = 0.0;
+#pragma unroll
+    for (int k0 = 0; k0 < C; k0 += 16) {
+      T d[16];
+#pragma unroll
+      for (int j = 0; j < 16; ++j)
+        d[j] = (!RAGGED || k0 + j < len) ? *reinterpret_cast<const T*>(reinterpret_cast<const char*>(dp + (size_t)(k0 + j) * n1) + yo) : T(0);
+#pragma unroll
+      for (int j = 0; j < 16; ++j) {
+        const int k = k0 + j;
+        x[k] = x[k] - alpha * d[j];
+        if ((!RAGGED || k < len) && cv) *reinterpret_cast<T*>(reinterpret_cast<char*>(wp + (size_t)k * n1) + yo) = x[k];
+        sq += (double)x[k] * (double)x[k];
+      }
+    }
+    if (y == 0) sq *= 0.5;
+    const double tot = block_sum(cv ? sq : 0.0, sh);
+    if (threadIdx.x == 0) part_norm[(size_t)blockIdx.y * gridDim.x + blockIdx.x] = tot / (2.0 * (double)n1);
+  } else {
+    if (stopped) return;
+  }
   double b = 0.0, a = 0.0;
 #pragma unroll
   for (int k = 0; k < C; ++k) {
@@ -399,16 +444,24 @@ __global__ __launch_bounds__(CS_COLS) void colstream_apply_kernel(const T* __res
   if (threadIdx.x == 0) part_rho[(size_t)blockIdx.y * gridDim.x + blockIdx.x] = tot / (2.0 * (double)n1);
 }
 
+// upd != nullptr: the stencil-fused iteration -- the first launch applies R -= alpha D before it sums (see the kernel)
+struct StreamUpdate {
+  const void* dq;
+  const double* part_pq;
+  int npq, ring;
+  double* part_norm_out;
+  int* nnorm_out;
+};
 template <class T, int C>
 hipError_t run_stream(const Impl* w, int compat, hipStream_t s, const double* part_norm, int nnorm, int it, double eps,
-                      double* part_rho, int* nrho, const void* zin) {
+                      double* part_rho, int* nrho, const void* zin, const StreamUpdate* upd = nullptr) {
   const int n0 = w->n0, n1 = w->n1, S = w->strS;
   const size_t pimg = (size_t)n0 * n1, pagg = (size_t)S * n1;
   const bool ragged = (n0 % C) != 0 || (n1 % CS_COLS) != 0;
   const dim3 grid((n1 + CS_COLS - 1) / CS_COLS, S, w->nprob);
   const int nparts = grid.x * grid.y;
   if (nparts + 1 > MAXPART) return hipErrorInvalidValue;
-  const T* R = (const T*)(zin ? zin : w->z);
+  T* R = (T*)(zin ? const_cast<void*>(zin) : w->z);
   // column 0's own chunk sums and its two scalars live behind the carries: [cap][S] double2, [cap][2] doubles
   double* carP = (double*)w->strcar;
   double* carZ = carP + w->cap * pagg;
@@ -416,8 +469,17 @@ hipError_t run_stream(const Impl* w, int compat, hipStream_t s, const double* pa
   double* col0 = (double*)(agg0 + (size_t)w->cap * S);
   {
     GPA_PROF("colstream_agg_kernel", s);
-    if (ragged) colstream_agg_kernel<T, C, true><<<grid, CS_COLS, 0, s>>>(R, n0, n1, w->strlam, (double2*)w->stragg, agg0, S, w->flags, pimg, pagg);
-    else colstream_agg_kernel<T, C, false><<<grid, CS_COLS, 0, s>>>(R, n0, n1, w->strlam, (double2*)w->stragg, agg0, S, w->flags, pimg, pagg);
+    if (upd) {
+      if (nparts > MAXPART) return hipErrorInvalidValue;
+      *upd->nnorm_out = nparts;
+      part_norm = upd->part_norm_out;
+      nnorm = nparts;
+      if (ragged) colstream_agg_kernel<T, C, true, true><<<grid, CS_COLS, 0, s>>>(R, (const T*)upd->dq, n0, n1, w->strlam, (double2*)w->stragg, agg0, S, w->flags, upd->part_pq, upd->npq, w->scal, it, upd->ring, upd->part_norm_out, pimg, pagg);
+      else colstream_agg_kernel<T, C, false, true><<<grid, CS_COLS, 0, s>>>(R, (const T*)upd->dq, n0, n1, w->strlam, (double2*)w->stragg, agg0, S, w->flags, upd->part_pq, upd->npq, w->scal, it, upd->ring, upd->part_norm_out, pimg, pagg);
+    } else {
+      if (ragged) colstream_agg_kernel<T, C, true, false><<<grid, CS_COLS, 0, s>>>(R, nullptr, n0, n1, w->strlam, (double2*)w->stragg, agg0, S, w->flags, nullptr, 0, nullptr, it, 0, nullptr, pimg, pagg);
+      else colstream_agg_kernel<T, C, false, false><<<grid, CS_COLS, 0, s>>>(R, nullptr, n0, n1, w->strlam, (double2*)w->stragg, agg0, S, w->flags, nullptr, 0, nullptr, it, 0, nullptr, pimg, pagg);
+    }
   }
   {
     GPA_PROF("colstream_scan_kernel", s);
@@ -498,6 +560,25 @@ hipError_t build_streamtab(Impl* w, hipStream_t s, size_t* bytes) {
   w->strC = C;
   w->strS = S;
   return e;
+}
+
+// the stencil-fused iteration's column solve: R (w->r) -= alpha DCT_rows(q) (dq, from pqdct_kernel) first, then the solve;
+// part_norm_out / nnorm_out: the partial ||r||^2 of the updated residual (read by this call's own scan kernel)
+hipError_t dispatch_colstream_update(const Impl* w, int compat, hipStream_t s, int it, double eps, int ring, const void* dq,
+                                     const double* part_pq, int npq, double* part_norm_out, int* nnorm_out, double* part_rho,
+                                     int* nrho) {
+  if (!w->strtab) return hipErrorInvalidValue;
+  const StreamUpdate upd = {dq, part_pq, npq, ring, part_norm_out, nnorm_out};
+#define GPA_STREAMU(CC)                                                                                                \
+  return w->dtype == 0 ? run_stream<float, CC>(w, compat, s, nullptr, 0, it, eps, part_rho, nrho, w->r, &upd)          \
+                       : run_stream<double, CC>(w, compat, s, nullptr, 0, it, eps, part_rho, nrho, w->r, &upd)
+  switch (w->strC) {
+    case 32: GPA_STREAMU(32);
+    case 64: GPA_STREAMU(64);
+    case 128: GPA_STREAMU(128);
+  }
+#undef GPA_STREAMU
+  return hipErrorInvalidValue;
 }
 
 hipError_t dispatch_colstream(const Impl* w, int compat, hipStream_t s, const double* part_norm, int nnorm, int it, double eps,

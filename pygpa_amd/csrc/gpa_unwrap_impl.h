@@ -89,6 +89,9 @@ hipError_t pow2_rowidct_p(const Impl* w, const void* pin, void* pout, const doub
                           hipStream_t s);
 hipError_t pow2_rowidct_pq(const Impl* w, const void* pin, void* pout, const void* weight, const double* part_rho,
                            int nrho, double* part_pq, int* npq_out, int it, hipStream_t s);
+// stencil + row transform in one launch (rows of 2048 / 4096 points): D = DCT_rows(A^T W^2 A p) into w->q, partial <p, q>
+bool pow2_pqdct_offered(const Impl* w);
+hipError_t pow2_pqdct(const Impl* w, const void* p, const void* weight, double* part_pq, int* npq, hipStream_t s);
 // columns (gpa_unwrap_cols.hip): every size
 hipError_t dispatch_colsolve(const Impl* w, int compat, hipStream_t s, const double* part_norm, int nnorm, int it,
                              double eps, double* part_rho, int* nrho, const void* zin);
@@ -97,6 +100,11 @@ int colstream_chunk(int n0, int n1);   // rows per chunk it would use for this s
 hipError_t build_streamtab(Impl* w, hipStream_t s, size_t* bytes);
 hipError_t dispatch_colstream(const Impl* w, int compat, hipStream_t s, const double* part_norm, int nnorm, int it,
                               double eps, double* part_rho, int* nrho, const void* zin);
+// the same after R (w->r) -= alpha dq, alpha from part_pq (the stencil-fused iteration); writes the partial ||r||^2
+hipError_t dispatch_colstream_update(const Impl* w, int compat, hipStream_t s, int it, double eps, int ring, const void* dq,
+                                     const double* part_pq, int npq, double* part_norm_out, int* nnorm_out, double* part_rho,
+                                     int* nrho);
+bool colstream_is_default(const Impl* w);   // the streamed solve is what dispatch_colsolve would run for this workspace / mode
 // sizes that are not powers of two (gpa_unwrap_generic.hip)
 hipError_t mr_rowdct_fused(const Impl* w, const void* q, int ring, const double* part_pq, int npq, double* part_norm,
                            int it, int* nnorm, int init, hipStream_t s);

@@ -810,6 +810,169 @@ hipError_t run_rowidct_p_half(const Impl* w, const void* pin, void* pout, const 
                                                                 w->scal, it, (size_t)w->n0 * w->n1);
   return hipGetLastError();
 }
+
+// ---------------------------------------------------------------------------
+// Stencil and row transform in ONE launch (rows of 2048 / 4096 points, streamed column solve): D = DCT-II_rows(A^T W^2 A p).
+//
+// q = A^T W^2 A p (phase_unwrap.py:118-132) has a single consumer, the row transform of the next iteration's residual
+// update r -= alpha q, and by linearity that update is R -= alpha DCT_rows(q) on the kept row spectrum.  alpha = rho / <p, q>
+// needs the whole image's <p, q>, so the transform cannot finish the update -- but it need not: it writes D = DCT_rows(q)
+// where q used to go, and the chunk-sum kernel of the streamed column solve, which reads R anyway, applies R -= alpha D
+// on the fly (colstream_agg_kernel<..., UPDATE>).  q never reaches HBM; the iteration is
+//     pqdct (p, w in, D out) -> colstream agg (R, D in, R out) -> scan -> apply (R in, Z out) -> rowidct_p (Z, p in, p out)
+// five launches and 44 bytes per pixel instead of six and 48.  A workgroup owns a row pair (2 pr, 2 pr + 1): it reads
+// the four rows pr*2 - 1 .. pr*2 + 2 of p and w with 16-byte accesses (the halo rows are its neighbours' own rows: L2),
+// forms q of its two rows in registers exactly as pq_kernel does (same edge order: right, left, down, up), parks them
+// in LDS as the packed pair's transform input, and runs rowdct_fused_kernel's transform.
+// ---------------------------------------------------------------------------
+#ifndef GPA_PQDCT_WAVES
+#define GPA_PQDCT_WAVES 4
+#endif
+template <class T, int LG>
+__global__ __launch_bounds__((RowGeom<T, LG>::THREADS), (sizeof(T) == 8 ? GPA_F64_WAVES : GPA_PQDCT_WAVES)) void pqdct_kernel(
+    const T* __restrict__ p, const T* __restrict__ wgt, T* __restrict__ Dout, int n0, const cpx<T>* __restrict__ twtab,
+    const cpx<T>* __restrict__ wk, const int* flags, double* part_pq, size_t pimg) {
+  {
+    const size_t pb = blockIdx.z;
+    p += pb * pimg;
+    Dout += pb * pimg;
+    if (wgt) wgt += (pb >> 1) * pimg;   // the two components of an image share its weight
+    flags += pb * FLAGS_N;
+    part_pq += pb * PART_N;
+  }
+  using G = RowGeom<T, LG>;
+  using F = typename G::F;
+  using D = typename G::D;
+  static_assert(G::NF == 1, "one row pair per workgroup");
+  constexpr int TPF = F::TPF, N = F::L, E = F::E;
+  const int stop = flags[1];
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  __shared__ double sh[RowGeom<T, LG>::THREADS];
+  const int tid = threadIdx.x, lane = tid & 63;
+  cpx<T>* lds = reinterpret_cast<cpx<T>*>(smem);
+  const int xa = 2 * (int)blockIdx.x, xb = xa + 1;
+  const bool up = xa > 0, dn = xb + 1 < n0;
+  const size_t oa = (size_t)xa * N, ob = oa + N;
+  typename G::TW tw;
+  __shared__ cpx<T> t1s[G::T1N];
+  if constexpr (G::TWLDS) {
+    F::fill_pass1_table(t1s, twtab, threadIdx.x, G::THREADS);
+    __syncthreads();
+    F::load_twiddles(tw, twtab, tid, t1s);
+  } else {
+    F::load_twiddles(tw, twtab, tid);
+  }
+  constexpr int NQ = N / (4 * TPF);   // 16-byte vectors per thread and row
+  // the four rows of p (halo rows outside the image are never used: their address is clamped to a row of the pair)
+  Vec4<T> pu[NQ], pa[NQ], pb_[NQ], pd[NQ];
+#pragma unroll
+  for (int v = 0; v < NQ; ++v) {
+    const int c0 = 4 * (tid + TPF * v);
+    pu[v] = *reinterpret_cast<const Vec4<T>*>(p + (up ? oa - N : oa) + c0);
+    pa[v] = *reinterpret_cast<const Vec4<T>*>(p + oa + c0);
+    pb_[v] = *reinterpret_cast<const Vec4<T>*>(p + ob + c0);
+    pd[v] = *reinterpret_cast<const Vec4<T>*>(p + (dn ? ob + N : ob) + c0);
+  }
+  if (stop) return;
+  double pq = 0;
+#pragma unroll
+  for (int v = 0; v < NQ; ++v) {
+    const int c0 = 4 * (tid + TPF * v);
+    const bool hasl = c0 > 0, hasr = c0 + 4 < N;
+    Vec4<T> wu, wa, wb, wd;
+    if (wgt) {
+      wu = *reinterpret_cast<const Vec4<T>*>(wgt + (up ? oa - N : oa) + c0);
+      wa = *reinterpret_cast<const Vec4<T>*>(wgt + oa + c0);
+      wb = *reinterpret_cast<const Vec4<T>*>(wgt + ob + c0);
+      wd = *reinterpret_cast<const Vec4<T>*>(wgt + (dn ? ob + N : ob) + c0);
+#pragma unroll
+      for (int j = 0; j < 4; ++j) { wu.v[j] *= wu.v[j]; wa.v[j] *= wa.v[j]; wb.v[j] *= wb.v[j]; wd.v[j] *= wd.v[j]; }
+    } else {
+#pragma unroll
+      for (int j = 0; j < 4; ++j) wu.v[j] = wa.v[j] = wb.v[j] = wd.v[j] = T(1);
+    }
+    // left / right neighbours of the thread's four pixels come from the adjacent lanes; the two lanes at the ends of a
+    // wavefront go to memory
+    T pla = __shfl_up(pa[v].v[3], 1), pra = __shfl_down(pa[v].v[0], 1), plb = __shfl_up(pb_[v].v[3], 1), prb = __shfl_down(pb_[v].v[0], 1);
+    T wla = __shfl_up(wa.v[3], 1), wra = __shfl_down(wa.v[0], 1), wlb = __shfl_up(wb.v[3], 1), wrb = __shfl_down(wb.v[0], 1);
+    if (lane == 0 && hasl) {
+      pla = p[oa + c0 - 1];
+      plb = p[ob + c0 - 1];
+      wla = wlb = T(1);
+      if (wgt) { wla = wgt[oa + c0 - 1]; wla *= wla; wlb = wgt[ob + c0 - 1]; wlb *= wlb; }
+    }
+    if (lane == 63 && hasr) {
+      pra = p[oa + c0 + 4];
+      prb = p[ob + c0 + 4];
+      wra = wrb = T(1);
+      if (wgt) { wra = wgt[oa + c0 + 4]; wra *= wra; wrb = wgt[ob + c0 + 4]; wrb *= wrb; }
+    }
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      // q = sum over the 4 edges of min(w^2, w_nb^2) * (p_nb - p)   (phase_unwrap.py:118-132), row a then row b
+      T qa, qb;
+      {
+        const T c = pa[v].v[j], wj = wa.v[j];
+        T acc = T(0);
+        if (j < 3) { const T wn = wa.v[j + 1]; acc += (wn < wj ? wn : wj) * (pa[v].v[j + 1] - c); }
+        else if (hasr) acc += (wra < wj ? wra : wj) * (pra - c);
+        if (j > 0) { const T wn = wa.v[j - 1]; acc += (wn < wj ? wn : wj) * (pa[v].v[j - 1] - c); }
+        else if (hasl) acc += (wla < wj ? wla : wj) * (pla - c);
+        { const T wn = wb.v[j]; acc += (wn < wj ? wn : wj) * (pb_[v].v[j] - c); }
+        if (up) { const T wn = wu.v[j]; acc += (wn < wj ? wn : wj) * (pu[v].v[j] - c); }
+        qa = acc;
+        pq += (double)c * (double)acc;
+      }
+      {
+        const T c = pb_[v].v[j], wj = wb.v[j];
+        T acc = T(0);
+        if (j < 3) { const T wn = wb.v[j + 1]; acc += (wn < wj ? wn : wj) * (pb_[v].v[j + 1] - c); }
+        else if (hasr) acc += (wrb < wj ? wrb : wj) * (prb - c);
+        if (j > 0) { const T wn = wb.v[j - 1]; acc += (wn < wj ? wn : wj) * (pb_[v].v[j - 1] - c); }
+        else if (hasl) acc += (wlb < wj ? wlb : wj) * (plb - c);
+        if (dn) { const T wn = wd.v[j]; acc += (wn < wj ? wn : wj) * (pd[v].v[j] - c); }
+        { const T wn = wa.v[j]; acc += (wn < wj ? wn : wj) * (pa[v].v[j] - c); }
+        qb = acc;
+        pq += (double)c * (double)acc;
+      }
+      lds[F::pad(c0 + j)] = {qa, qb};
+    }
+  }
+  __syncthreads();
+  cpx<T> x[E];
+#pragma unroll
+  for (int i = 0; i < E; ++i) x[i] = lds[F::pad(makhoul_src(tid + TPF * i, N))];
+  __syncthreads();
+  F::forward(x, lds, tid, tw);
+  __syncthreads();
+  D::fwd_scatter(x, lds, tid);
+  __syncthreads();
+  D::fwd_gather(x, lds, tid, wk);
+#pragma unroll
+  for (int i = 0; i < E; ++i) {
+    const int k = tid + TPF * i;
+    Dout[oa + k] = x[i].x;
+    Dout[ob + k] = x[i].y;
+  }
+  const double tot = block_sum(pq, sh);
+  if (threadIdx.x == 0) part_pq[blockIdx.x] = tot;
+}
+
+template <class T, int LG>
+hipError_t run_pqdct(const Impl* w, const void* p, const void* weight, double* part_pq, int* npq, hipStream_t s) {
+  using G = RowGeom<T, LG>;
+  auto kern = pqdct_kernel<T, LG>;
+  static unsigned lds_set = 0;
+  hipError_t e = set_dynamic_lds_once(reinterpret_cast<const void*>(kern), (int)G::LDS_BYTES, lds_set);
+  if (e != hipSuccess) return e;
+  const int grid = w->n0 / 2;
+  if (grid > MAXPART) return hipErrorInvalidValue;
+  *npq = grid;
+  GPA_PROF("pqdct_kernel", s);
+  kern<<<dim3(grid, 1, w->nprob), G::THREADS, G::LDS_BYTES, s>>>((const T*)p, (const T*)weight, (T*)w->q, w->n0, (const cpx<T>*)w->tw1,
+                                                               (const cpx<T>*)w->wk1, w->flags, part_pq, (size_t)w->n0 * w->n1);
+  return hipGetLastError();
+}
 // rows of 8192 points and more take the half-length kernels (NO_ROWHALF: the packed ones, for tests and measurements)
 inline bool use_row_half(const Impl* w) {
   const int minlg = opt_set(OPT_ROWHALF_MINLG) ? (int)opt(OPT_ROWHALF_MINLG).num : GPA_ROWHALF_MINLG;
@@ -817,6 +980,12 @@ inline bool use_row_half(const Impl* w) {
 }
 }  // namespace
 
+bool pow2_pqdct_offered(const Impl* w) { return !w->generic && (w->lg1 == 11 || w->lg1 == 12) && (w->n0 % 2) == 0; }
+hipError_t pow2_pqdct(const Impl* w, const void* p, const void* weight, double* part_pq, int* npq, hipStream_t s) {
+  if (w->lg1 == 11) return w->dtype == 0 ? run_pqdct<float, 11>(w, p, weight, part_pq, npq, s) : run_pqdct<double, 11>(w, p, weight, part_pq, npq, s);
+  if (w->lg1 == 12) return w->dtype == 0 ? run_pqdct<float, 12>(w, p, weight, part_pq, npq, s) : run_pqdct<double, 12>(w, p, weight, part_pq, npq, s);
+  return hipErrorInvalidValue;
+}
 hipError_t pow2_rowidct_pq(const Impl* w, const void* pin, void* pout, const void* weight, const double* part_rho,
                            int nrho, double* part_pq, int* npq_out, int it, hipStream_t s) {
 #define CASE(LG) case LG: return w->dtype == 0 ? run_rowidct_pq<float, LG>(w, pin, pout, weight, part_rho, nrho, part_pq, npq_out, it, s) \

@@ -157,3 +157,32 @@ def test_long_square_streamed_vs_resident_columns(n, gpa_option):
         assert ('colstream_apply_kernel' if mode == 'stream' else 'colsolve_tri_kernel') in prof, sorted(prof)
         assert it == 4
     assert rel(out['stream'], out['tri']) < 5e-5, rel(out['stream'], out['tri'])
+
+
+@pytest.mark.parametrize('dtype', [np.float64, np.float32])
+@pytest.mark.parametrize('n', [2048, 4096])
+def test_stencil_fused_iteration_equals_separate_kernels(n, dtype, gpa_option):
+    """rows of 2048 / 4096 points: the iteration with the stencil inside the row-transform launch (pqdct_kernel: q never
+    reaches HBM, the residual update R -= alpha DCT_rows(q) rides in the column solve's first launch) against the same
+    solve with separate stencil / row-transform / update kernels (NO_PQDCT): same iterates to rounding -- iteration counts
+    equal, phi within the PCG tolerance -- and, at 2048^2, the oracle's phi"""
+    dx, dy, w = make_problem((n, n), seed=n + 1, rough=True)
+    phi_f, it_f, prof_f = solve_profiled((n, n), dtype, dx, dy, w, 12)
+    assert 'pqdct_kernel' in prof_f and prof_f['pqdct_kernel'][0] == 11 and prof_f['pq_kernel'][0] == 1, sorted(prof_f.items())
+    assert 'rowdct_fused_kernel' in prof_f and prof_f['rowdct_fused_kernel'][0] == 1      # iteration 0 only
+    gpa_option('NO_PQDCT', '1')
+    phi_s, it_s, prof_s = solve_profiled((n, n), dtype, dx, dy, w, 12)
+    assert 'pqdct_kernel' not in prof_s and prof_s['pq_kernel'][0] == 12
+    assert it_f == it_s
+    assert rel(phi_f, phi_s) < (1e-10 if dtype is np.float64 else 3e-5), rel(phi_f, phi_s)
+    # unweighted, few iterations (kmax 2: the fused kernel runs once)
+    gpa_option('NO_PQDCT', None)
+    pu_f, _, _ = solve_profiled((n, n), dtype, dx, dy, None, 2)
+    gpa_option('NO_PQDCT', '1')
+    pu_s, _, _ = solve_profiled((n, n), dtype, dx, dy, None, 2)
+    assert rel(pu_f, pu_s) < (1e-10 if dtype is np.float64 else 3e-5)
+    if n == 2048:
+        ref, ref_it = orc.unwrap_prediff(dx, dy, w, kmax=12, return_iters=True)
+        assert rel(phi_f, ref) < (1e-8 if dtype is np.float64 else 5e-5)
+        if dtype is np.float64:
+            assert it_f == ref_it

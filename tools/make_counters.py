@@ -13,7 +13,7 @@ import os
 import sys
 
 SHORT = ['passA_kernel', 'passB_shared_kernel', 'passB_kernel', 'reconstruct_setup_kernel', 'rowdct_fused_kernel', 'rowdct_half_kernel',
-         'rowidct_p_half_kernel', 'colstream_agg_kernel', 'colstream_scan_kernel', 'colstream_apply_kernel', 'colsolve_tri_kernel', 'colsolve_kernel',
+         'rowidct_p_half_kernel', 'pqdct_kernel', 'colstream_agg_kernel', 'colstream_scan_kernel', 'colstream_apply_kernel', 'colsolve_tri_kernel', 'colsolve_kernel',
          'rowidct_p_kernel', 'pq_kernel', 'phi_flush_kernel', 'mean_partial_kernel']
 acc = collections.defaultdict(lambda: collections.defaultdict(list))
 for d in sys.argv[2:]:

@@ -23,7 +23,7 @@ dt = np.float32 if a.dtype == 'f32' else np.float64
 s = np.dtype(dt).itemsize
 # algorithmic bytes per pixel and working launch
 BPP = {'rowdct_fused_kernel': 3, 'colsolve_kernel': 2, 'colsolve_tri_kernel': 2, 'colstream_agg_kernel': 1, 'colstream_scan_kernel': 0,
-       'colstream_apply_kernel': 2, 'rowidct_p_kernel': 3, 'pq_kernel': 3, 'rowidct_pq_kernel': 5}
+       'colstream_apply_kernel': 2, 'rowidct_p_kernel': 3, 'pq_kernel': 3, 'rowidct_pq_kernel': 5, 'pqdct_kernel': 3}
 _lib.set_option('F32_EPS_FLOOR', '0')
 if a.chunk:
     _lib.set_option('COLSTREAM_CHUNK', a.chunk)
