@@ -186,3 +186,21 @@ def test_stencil_fused_iteration_equals_separate_kernels(n, dtype, gpa_option):
         assert rel(phi_f, ref) < (1e-8 if dtype is np.float64 else 5e-5)
         if dtype is np.float64:
             assert it_f == ref_it
+
+
+def test_stack_of_2048_frames_equals_single_images():
+    """a stack of 2048^2 frames (blockIdx.z = problem) through the stencil-fused iteration and the streamed column solve:
+    every frame's u and iteration counts equal the single-image driver's bit for bit (same kernels, same partial-sum order)"""
+    from pygpa_amd.synthetic import hex_kvecs, gaussian_bump_displacement, hex_moire, explicit_klists
+    n = 2048
+    kvecs = hex_kvecs(0.1, 7.0)
+    klists = np.stack(explicit_klists(kvecs, 0.04, 2, 2))
+    imgs = np.stack([hex_moire((n, n), kvecs, (0.4 + 0.3 * i) * gaussian_bump_displacement((n, n)), noise=0.05, seed=i, dtype=np.float32)
+                     for i in range(3)])
+    plan = _lib.Plan((n, n), 12, np.float32)
+    u_b, it_b = plan.extract_displacement_field_stack(imgs, kvecs, klists, 10, 20, kmax=10, chunk=3)
+    for i in range(3):
+        u, _, _, iters = plan.extract_displacement_field(imgs[i], kvecs, klists, 10, 20, kmax=10)
+        assert np.array_equal(u_b[i], u), (i, float(np.abs(u_b[i] - u).max()))
+        assert tuple(it_b[i]) == tuple(iters)
+    plan.close()
