@@ -856,6 +856,109 @@ __global__ __launch_bounds__((RowGeom<T, LG>::THREADS), (sizeof(T) == 8 ? GPA_F6
   const int xa = 2 * xcd_tile((int)blockIdx.x, (int)gridDim.x), xb = xa + 1;
   const bool up = xa > 0, dn = xb + 1 < n0;
   const size_t oa = (size_t)xa * N, ob = oa + N;
+  constexpr int NQ = N / (4 * TPF);   // 16-byte vectors per thread and row
+  // The row pair's columns are worked through in NPH phases of VP vectors.  Every load of a phase -- four rows of p, four
+  // rows of w, the neighbour pixels of the two lanes at the ends of a wavefront -- is requested before anything of the
+  // phase is used, and the second phase's rows of p are requested before the first phase computes: two memory round
+  // trips per workgroup (the first cut of this kernel waited once per vector and row of w: five).
+  constexpr int NPH = NQ >= 2 ? 2 : 1, VP = NQ / NPH;
+  struct Rows { Vec4<T> u[VP], a[VP], b[VP], d[VP]; };
+  struct Edge { T la[VP], ra[VP], lb[VP], rb[VP]; };
+  auto load_rows = [&](const T* base, int ph, Rows& r) {
+#pragma unroll
+    for (int v = 0; v < VP; ++v) {
+      const int c0 = 4 * (tid + TPF * (ph * VP + v));
+      // (halo rows outside the image are never used: their address is clamped to a row of the pair)
+      r.u[v] = *reinterpret_cast<const Vec4<T>*>(base + (up ? oa - N : oa) + c0);
+      r.a[v] = *reinterpret_cast<const Vec4<T>*>(base + oa + c0);
+      r.b[v] = *reinterpret_cast<const Vec4<T>*>(base + ob + c0);
+      r.d[v] = *reinterpret_cast<const Vec4<T>*>(base + (dn ? ob + N : ob) + c0);
+    }
+  };
+  // left / right neighbours of a thread's four pixels come from the adjacent lanes; the two lanes at the ends of a
+  // wavefront go to memory (requested here, used in compute())
+  auto load_edges = [&](const T* base, int ph, Edge& e) {
+#pragma unroll
+    for (int v = 0; v < VP; ++v) {
+      const int c0 = 4 * (tid + TPF * (ph * VP + v));
+      e.la[v] = e.lb[v] = e.ra[v] = e.rb[v] = T(1);
+      if (lane == 0 && c0 > 0) { e.la[v] = base[oa + c0 - 1]; e.lb[v] = base[ob + c0 - 1]; }
+      if (lane == 63 && c0 + 4 < N) { e.ra[v] = base[oa + c0 + 4]; e.rb[v] = base[ob + c0 + 4]; }
+    }
+  };
+  auto ones = [&](Rows& r, Edge& e) {
+#pragma unroll
+    for (int v = 0; v < VP; ++v) {
+#pragma unroll
+      for (int j = 0; j < 4; ++j) r.u[v].v[j] = r.a[v].v[j] = r.b[v].v[j] = r.d[v].v[j] = T(1);
+      e.la[v] = e.lb[v] = e.ra[v] = e.rb[v] = T(1);
+    }
+  };
+  double pq = 0;
+  auto compute = [&](int ph, const Rows& P, Rows& W, const Edge& EP, Edge& EW) {
+#pragma unroll
+    for (int v = 0; v < VP; ++v) {
+      const int c0 = 4 * (tid + TPF * (ph * VP + v));
+      const bool hasl = c0 > 0, hasr = c0 + 4 < N;
+      if (wgt) {
+#pragma unroll
+        for (int j = 0; j < 4; ++j) { W.u[v].v[j] *= W.u[v].v[j]; W.a[v].v[j] *= W.a[v].v[j]; W.b[v].v[j] *= W.b[v].v[j]; W.d[v].v[j] *= W.d[v].v[j]; }
+        EW.la[v] *= EW.la[v]; EW.lb[v] *= EW.lb[v]; EW.ra[v] *= EW.ra[v]; EW.rb[v] *= EW.rb[v];
+      }
+      T pla = __shfl_up(P.a[v].v[3], 1), pra = __shfl_down(P.a[v].v[0], 1), plb = __shfl_up(P.b[v].v[3], 1), prb = __shfl_down(P.b[v].v[0], 1);
+      T wla = __shfl_up(W.a[v].v[3], 1), wra = __shfl_down(W.a[v].v[0], 1), wlb = __shfl_up(W.b[v].v[3], 1), wrb = __shfl_down(W.b[v].v[0], 1);
+      if (lane == 0) { pla = EP.la[v]; plb = EP.lb[v]; wla = EW.la[v]; wlb = EW.lb[v]; }
+      if (lane == 63) { pra = EP.ra[v]; prb = EP.rb[v]; wra = EW.ra[v]; wrb = EW.rb[v]; }
+#pragma unroll
+      for (int j = 0; j < 4; ++j) {
+        // q = sum over the 4 edges of min(w^2, w_nb^2) * (p_nb - p)   (phase_unwrap.py:118-132), row a then row b
+        T qa, qb;
+        {
+          const T c = P.a[v].v[j], wj = W.a[v].v[j];
+          T acc = T(0);
+          if (j < 3) { const T wn = W.a[v].v[j + 1]; acc += (wn < wj ? wn : wj) * (P.a[v].v[j + 1] - c); }
+          else if (hasr) acc += (wra < wj ? wra : wj) * (pra - c);
+          if (j > 0) { const T wn = W.a[v].v[j - 1]; acc += (wn < wj ? wn : wj) * (P.a[v].v[j - 1] - c); }
+          else if (hasl) acc += (wla < wj ? wla : wj) * (pla - c);
+          { const T wn = W.b[v].v[j]; acc += (wn < wj ? wn : wj) * (P.b[v].v[j] - c); }
+          if (up) { const T wn = W.u[v].v[j]; acc += (wn < wj ? wn : wj) * (P.u[v].v[j] - c); }
+          qa = acc;
+          pq += (double)c * (double)acc;
+        }
+        {
+          const T c = P.b[v].v[j], wj = W.b[v].v[j];
+          T acc = T(0);
+          if (j < 3) { const T wn = W.b[v].v[j + 1]; acc += (wn < wj ? wn : wj) * (P.b[v].v[j + 1] - c); }
+          else if (hasr) acc += (wrb < wj ? wrb : wj) * (prb - c);
+          if (j > 0) { const T wn = W.b[v].v[j - 1]; acc += (wn < wj ? wn : wj) * (P.b[v].v[j - 1] - c); }
+          else if (hasl) acc += (wlb < wj ? wlb : wj) * (plb - c);
+          if (dn) { const T wn = W.d[v].v[j]; acc += (wn < wj ? wn : wj) * (P.d[v].v[j] - c); }
+          { const T wn = W.a[v].v[j]; acc += (wn < wj ? wn : wj) * (P.a[v].v[j] - c); }
+          qb = acc;
+          pq += (double)c * (double)acc;
+        }
+        lds[F::pad(c0 + j)] = {qa, qb};
+      }
+    }
+  };
+  Rows pA, wA;
+  Edge epA, ewA;
+  load_rows(p, 0, pA);
+  load_edges(p, 0, epA);
+  if (wgt) { load_rows(wgt, 0, wA); load_edges(wgt, 0, ewA); } else ones(wA, ewA);
+  if (stop) return;
+  compute(0, pA, wA, epA, ewA);
+  if constexpr (NPH == 2) {
+    // (the second phase reuses the first one's registers: requesting its rows of p ahead of the first phase's arithmetic
+    //  overruns the 128 registers of four waves per SIMD by 100 bytes of scratch)
+    asm volatile("" ::: "memory");   // (the compiler must not hoist these loads into the first phase either)
+    __builtin_amdgcn_sched_barrier(0);
+    load_rows(p, 1, pA);
+    load_edges(p, 1, epA);
+    if (wgt) { load_rows(wgt, 1, wA); load_edges(wgt, 1, ewA); } else ones(wA, ewA);
+    compute(1, pA, wA, epA, ewA);
+  }
+  // (the transform's twiddles only now: requested before the stencil they would hold 12-24 registers through it)
   typename G::TW tw;
   __shared__ cpx<T> t1s[G::T1N];
   if constexpr (G::TWLDS) {
@@ -864,82 +967,6 @@ __global__ __launch_bounds__((RowGeom<T, LG>::THREADS), (sizeof(T) == 8 ? GPA_F6
     F::load_twiddles(tw, twtab, tid, t1s);
   } else {
     F::load_twiddles(tw, twtab, tid);
-  }
-  constexpr int NQ = N / (4 * TPF);   // 16-byte vectors per thread and row
-  // the four rows of p (halo rows outside the image are never used: their address is clamped to a row of the pair)
-  Vec4<T> pu[NQ], pa[NQ], pb_[NQ], pd[NQ];
-#pragma unroll
-  for (int v = 0; v < NQ; ++v) {
-    const int c0 = 4 * (tid + TPF * v);
-    pu[v] = *reinterpret_cast<const Vec4<T>*>(p + (up ? oa - N : oa) + c0);
-    pa[v] = *reinterpret_cast<const Vec4<T>*>(p + oa + c0);
-    pb_[v] = *reinterpret_cast<const Vec4<T>*>(p + ob + c0);
-    pd[v] = *reinterpret_cast<const Vec4<T>*>(p + (dn ? ob + N : ob) + c0);
-  }
-  if (stop) return;
-  double pq = 0;
-#pragma unroll
-  for (int v = 0; v < NQ; ++v) {
-    const int c0 = 4 * (tid + TPF * v);
-    const bool hasl = c0 > 0, hasr = c0 + 4 < N;
-    Vec4<T> wu, wa, wb, wd;
-    if (wgt) {
-      wu = *reinterpret_cast<const Vec4<T>*>(wgt + (up ? oa - N : oa) + c0);
-      wa = *reinterpret_cast<const Vec4<T>*>(wgt + oa + c0);
-      wb = *reinterpret_cast<const Vec4<T>*>(wgt + ob + c0);
-      wd = *reinterpret_cast<const Vec4<T>*>(wgt + (dn ? ob + N : ob) + c0);
-#pragma unroll
-      for (int j = 0; j < 4; ++j) { wu.v[j] *= wu.v[j]; wa.v[j] *= wa.v[j]; wb.v[j] *= wb.v[j]; wd.v[j] *= wd.v[j]; }
-    } else {
-#pragma unroll
-      for (int j = 0; j < 4; ++j) wu.v[j] = wa.v[j] = wb.v[j] = wd.v[j] = T(1);
-    }
-    // left / right neighbours of the thread's four pixels come from the adjacent lanes; the two lanes at the ends of a
-    // wavefront go to memory
-    T pla = __shfl_up(pa[v].v[3], 1), pra = __shfl_down(pa[v].v[0], 1), plb = __shfl_up(pb_[v].v[3], 1), prb = __shfl_down(pb_[v].v[0], 1);
-    T wla = __shfl_up(wa.v[3], 1), wra = __shfl_down(wa.v[0], 1), wlb = __shfl_up(wb.v[3], 1), wrb = __shfl_down(wb.v[0], 1);
-    if (lane == 0 && hasl) {
-      pla = p[oa + c0 - 1];
-      plb = p[ob + c0 - 1];
-      wla = wlb = T(1);
-      if (wgt) { wla = wgt[oa + c0 - 1]; wla *= wla; wlb = wgt[ob + c0 - 1]; wlb *= wlb; }
-    }
-    if (lane == 63 && hasr) {
-      pra = p[oa + c0 + 4];
-      prb = p[ob + c0 + 4];
-      wra = wrb = T(1);
-      if (wgt) { wra = wgt[oa + c0 + 4]; wra *= wra; wrb = wgt[ob + c0 + 4]; wrb *= wrb; }
-    }
-#pragma unroll
-    for (int j = 0; j < 4; ++j) {
-      // q = sum over the 4 edges of min(w^2, w_nb^2) * (p_nb - p)   (phase_unwrap.py:118-132), row a then row b
-      T qa, qb;
-      {
-        const T c = pa[v].v[j], wj = wa.v[j];
-        T acc = T(0);
-        if (j < 3) { const T wn = wa.v[j + 1]; acc += (wn < wj ? wn : wj) * (pa[v].v[j + 1] - c); }
-        else if (hasr) acc += (wra < wj ? wra : wj) * (pra - c);
-        if (j > 0) { const T wn = wa.v[j - 1]; acc += (wn < wj ? wn : wj) * (pa[v].v[j - 1] - c); }
-        else if (hasl) acc += (wla < wj ? wla : wj) * (pla - c);
-        { const T wn = wb.v[j]; acc += (wn < wj ? wn : wj) * (pb_[v].v[j] - c); }
-        if (up) { const T wn = wu.v[j]; acc += (wn < wj ? wn : wj) * (pu[v].v[j] - c); }
-        qa = acc;
-        pq += (double)c * (double)acc;
-      }
-      {
-        const T c = pb_[v].v[j], wj = wb.v[j];
-        T acc = T(0);
-        if (j < 3) { const T wn = wb.v[j + 1]; acc += (wn < wj ? wn : wj) * (pb_[v].v[j + 1] - c); }
-        else if (hasr) acc += (wrb < wj ? wrb : wj) * (prb - c);
-        if (j > 0) { const T wn = wb.v[j - 1]; acc += (wn < wj ? wn : wj) * (pb_[v].v[j - 1] - c); }
-        else if (hasl) acc += (wlb < wj ? wlb : wj) * (plb - c);
-        if (dn) { const T wn = wd.v[j]; acc += (wn < wj ? wn : wj) * (pd[v].v[j] - c); }
-        { const T wn = wa.v[j]; acc += (wn < wj ? wn : wj) * (pa[v].v[j] - c); }
-        qb = acc;
-        pq += (double)c * (double)acc;
-      }
-      lds[F::pad(c0 + j)] = {qa, qb};
-    }
   }
   __syncthreads();
   cpx<T> x[E];
