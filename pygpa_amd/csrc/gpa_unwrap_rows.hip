@@ -1003,161 +1003,6 @@ hipError_t run_pqdct(const Impl* w, const void* p, const void* weight, double* p
                                                                (const cpx<T>*)w->wk1, w->flags, part_pq, (size_t)w->n0 * w->n1);
   return hipGetLastError();
 }
-
-// pqdct_kernel for the half-length row form (rows of 8192 / 16384 points): one row per workgroup, its stencil from the
-// rows above and below (the neighbours' own rows: L2, XCD-aware order), staged as the half-length transform's input
-// t[j] = (q[4j], q[4j+2]), t[N/2-1-j] = (q[4j+3], q[4j+1]); writes D = DCT-II_row(q) and the partial <p, q>.
-template <class T, int LG>
-__global__ __launch_bounds__((RowHalfGeom<T, LG>::THREADS), (sizeof(T) == 4 && LG == 14 ? GPA_ROWHALF14_WAVES : 1)) void pqdct_half_kernel(
-    const T* __restrict__ p, const T* __restrict__ wgt, T* __restrict__ Dout, int n0, const cpx<T>* __restrict__ twh,
-    const cpx<T>* __restrict__ twn, const cpx<T>* __restrict__ wk, const int* flags, double* part_pq, size_t pimg) {
-  {
-    const size_t pb = blockIdx.z;
-    p += pb * pimg;
-    Dout += pb * pimg;
-    if (wgt) wgt += (pb >> 1) * pimg;
-    flags += pb * FLAGS_N;
-    part_pq += pb * PART_N;
-  }
-  using G = RowHalfGeom<T, LG>;
-  using F = typename G::F;
-  constexpr int N = G::N, HN = G::HN, TPF = G::TPF, E = 16;
-  const int stop = flags[1];
-  extern __shared__ __attribute__((aligned(16))) char smem[];
-  __shared__ double sh[RowHalfGeom<T, LG>::THREADS];
-  const int tid = threadIdx.x, lane = tid & 63;
-  cpx<T>* lds = reinterpret_cast<cpx<T>*>(smem);
-  const int x = xcd_tile((int)blockIdx.x, (int)gridDim.x);
-  const bool up = x > 0, dn = x + 1 < n0;
-  const size_t o = (size_t)x * N;
-  constexpr int NV = N / (4 * TPF);   // 16-byte vectors per thread: 8
-  constexpr int NPH = 2, VP = NV / NPH;
-  struct Rows { Vec4<T> u[VP], c[VP], d[VP]; };
-  struct Edge { T l[VP], r[VP]; };
-  auto load_rows = [&](const T* base, int ph, Rows& r) {
-#pragma unroll
-    for (int v = 0; v < VP; ++v) {
-      const int c0 = 4 * (tid + TPF * (ph * VP + v));
-      r.u[v] = *reinterpret_cast<const Vec4<T>*>(base + (up ? o - N : o) + c0);
-      r.c[v] = *reinterpret_cast<const Vec4<T>*>(base + o + c0);
-      r.d[v] = *reinterpret_cast<const Vec4<T>*>(base + (dn ? o + N : o) + c0);
-    }
-  };
-  auto load_edges = [&](const T* base, int ph, Edge& e) {
-#pragma unroll
-    for (int v = 0; v < VP; ++v) {
-      const int c0 = 4 * (tid + TPF * (ph * VP + v));
-      e.l[v] = e.r[v] = T(1);
-      if (lane == 0 && c0 > 0) e.l[v] = base[o + c0 - 1];
-      if (lane == 63 && c0 + 4 < N) e.r[v] = base[o + c0 + 4];
-    }
-  };
-  auto ones = [&](Rows& r, Edge& e) {
-#pragma unroll
-    for (int v = 0; v < VP; ++v) {
-#pragma unroll
-      for (int j = 0; j < 4; ++j) r.u[v].v[j] = r.c[v].v[j] = r.d[v].v[j] = T(1);
-      e.l[v] = e.r[v] = T(1);
-    }
-  };
-  double pq = 0;
-  auto compute = [&](int ph, const Rows& P, Rows& W, const Edge& EP, Edge& EW) {
-#pragma unroll
-    for (int v = 0; v < VP; ++v) {
-      const int jv = tid + TPF * (ph * VP + v), c0 = 4 * jv;
-      const bool hasl = c0 > 0, hasr = c0 + 4 < N;
-      if (wgt) {
-#pragma unroll
-        for (int j = 0; j < 4; ++j) { W.u[v].v[j] *= W.u[v].v[j]; W.c[v].v[j] *= W.c[v].v[j]; W.d[v].v[j] *= W.d[v].v[j]; }
-        EW.l[v] *= EW.l[v];
-        EW.r[v] *= EW.r[v];
-      }
-      T pl = __shfl_up(P.c[v].v[3], 1), pr = __shfl_down(P.c[v].v[0], 1);
-      T wl = __shfl_up(W.c[v].v[3], 1), wr = __shfl_down(W.c[v].v[0], 1);
-      if (lane == 0) { pl = EP.l[v]; wl = EW.l[v]; }
-      if (lane == 63) { pr = EP.r[v]; wr = EW.r[v]; }
-      T q[4];
-#pragma unroll
-      for (int j = 0; j < 4; ++j) {
-        // q = sum over the 4 edges of min(w^2, w_nb^2) * (p_nb - p)   (phase_unwrap.py:118-132; edge order of pq_kernel)
-        const T c = P.c[v].v[j], wj = W.c[v].v[j];
-        T acc = T(0);
-        if (j < 3) { const T wn = W.c[v].v[j + 1]; acc += (wn < wj ? wn : wj) * (P.c[v].v[j + 1] - c); }
-        else if (hasr) acc += (wr < wj ? wr : wj) * (pr - c);
-        if (j > 0) { const T wn = W.c[v].v[j - 1]; acc += (wn < wj ? wn : wj) * (P.c[v].v[j - 1] - c); }
-        else if (hasl) acc += (wl < wj ? wl : wj) * (pl - c);
-        if (dn) { const T wn = W.d[v].v[j]; acc += (wn < wj ? wn : wj) * (P.d[v].v[j] - c); }
-        if (up) { const T wn = W.u[v].v[j]; acc += (wn < wj ? wn : wj) * (P.u[v].v[j] - c); }
-        q[j] = acc;
-        pq += (double)c * (double)acc;
-      }
-      lds[F::pad(jv)] = {q[0], q[2]};
-      lds[F::pad(HN - 1 - jv)] = {q[3], q[1]};
-    }
-  };
-  Rows pA, wA;
-  Edge epA, ewA;
-  load_rows(p, 0, pA);
-  load_edges(p, 0, epA);
-  if (wgt) { load_rows(wgt, 0, wA); load_edges(wgt, 0, ewA); } else ones(wA, ewA);
-  if (stop) return;
-  compute(0, pA, wA, epA, ewA);
-  asm volatile("" ::: "memory");
-  __builtin_amdgcn_sched_barrier(0);
-  load_rows(p, 1, pA);
-  load_edges(p, 1, epA);
-  if (wgt) { load_rows(wgt, 1, wA); load_edges(wgt, 1, ewA); } else ones(wA, ewA);
-  compute(1, pA, wA, epA, ewA);
-  typename F::Twiddles tw;
-  F::load_twiddles(tw, twh, tid);
-  __syncthreads();
-  cpx<T> xr[E];
-#pragma unroll
-  for (int i = 0; i < E; ++i) xr[i] = lds[F::pad(tid + TPF * i)];
-  __syncthreads();
-  F::forward(xr, lds, tid, tw);
-  __syncthreads();
-#pragma unroll
-  for (int i = 0; i < E; ++i) lds[F::pad(F::spec_index(tid, i))] = xr[i];
-  __syncthreads();
-#pragma unroll
-  for (int i = 0; i < E; ++i) {
-    const int k = tid + TPF * i;
-    const cpx<T> zk = lds[F::pad(k)], zm = lds[F::pad((HN - k) & (HN - 1))];
-    T xlo, xhi;
-    if (k == 0) {
-      xlo = T(2) * (zk.x + zk.y);
-      xhi = T(1.41421356237309504880) * (zk.x - zk.y);
-    } else {
-      const cpx<T> ve = {T(0.5) * (zk.x + zm.x), T(0.5) * (zk.y - zm.y)};
-      const cpx<T> vo = {T(0.5) * (zk.y + zm.y), T(-0.5) * (zk.x - zm.x)};
-      const cpx<T> V = ve + cmul(twn[k], vo);
-      const cpx<T> U = cmul(wk[k], V);
-      xlo = T(2) * U.x;
-      xhi = T(-2) * U.y;
-    }
-    Dout[o + k] = xlo;
-    Dout[o + (k == 0 ? HN : N - k)] = xhi;
-  }
-  const double tot = block_sum(pq, sh);
-  if (threadIdx.x == 0) part_pq[blockIdx.x] = tot;
-}
-
-template <class T, int LG>
-hipError_t run_pqdct_half(const Impl* w, const void* p, const void* weight, double* part_pq, int* npq, hipStream_t s) {
-  using G = RowHalfGeom<T, LG>;
-  auto kern = pqdct_half_kernel<T, LG>;
-  static unsigned lds_set = 0;
-  hipError_t e = set_dynamic_lds_once(reinterpret_cast<const void*>(kern), (int)G::LDS_BYTES, lds_set);
-  if (e != hipSuccess) return e;
-  if (w->n0 > MAXPART) return hipErrorInvalidValue;
-  *npq = w->n0;
-  GPA_PROF("pqdct_kernel", s);
-  kern<<<dim3(w->n0, 1, w->nprob), G::THREADS, G::LDS_BYTES, s>>>((const T*)p, (const T*)weight, (T*)w->q, w->n0, (const cpx<T>*)w->tw1h,
-                                                                (const cpx<T>*)w->tw1, (const cpx<T>*)w->wk1, w->flags, part_pq,
-                                                                (size_t)w->n0 * w->n1);
-  return hipGetLastError();
-}
 // rows of 8192 points and more take the half-length kernels (NO_ROWHALF: the packed ones, for tests and measurements)
 inline bool use_row_half(const Impl* w) {
   const int minlg = opt_set(OPT_ROWHALF_MINLG) ? (int)opt(OPT_ROWHALF_MINLG).num : GPA_ROWHALF_MINLG;
@@ -1165,14 +1010,8 @@ inline bool use_row_half(const Impl* w) {
 }
 }  // namespace
 
-bool pow2_pqdct_offered(const Impl* w) {
-  if (w->generic || (w->n0 % 2)) return false;
-  if (w->lg1 == 11 || w->lg1 == 12) return true;
-  return use_row_half(w) && (w->lg1 == 13 || (w->lg1 == 14 && w->dtype == 0));
-}
+bool pow2_pqdct_offered(const Impl* w) { return !w->generic && (w->lg1 == 11 || w->lg1 == 12) && (w->n0 % 2) == 0; }
 hipError_t pow2_pqdct(const Impl* w, const void* p, const void* weight, double* part_pq, int* npq, hipStream_t s) {
-  if (w->lg1 == 13) return w->dtype == 0 ? run_pqdct_half<float, 13>(w, p, weight, part_pq, npq, s) : run_pqdct_half<double, 13>(w, p, weight, part_pq, npq, s);
-  if (w->lg1 == 14) return run_pqdct_half<float, 14>(w, p, weight, part_pq, npq, s);
   if (w->lg1 == 11) return w->dtype == 0 ? run_pqdct<float, 11>(w, p, weight, part_pq, npq, s) : run_pqdct<double, 11>(w, p, weight, part_pq, npq, s);
   if (w->lg1 == 12) return w->dtype == 0 ? run_pqdct<float, 12>(w, p, weight, part_pq, npq, s) : run_pqdct<double, 12>(w, p, weight, part_pq, npq, s);
   return hipErrorInvalidValue;
