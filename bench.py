@@ -308,6 +308,10 @@ def kernel_table(n, L0, L1, P, K, Bx, s, iters, kern, stage, res_s):
         # as well (R, D in, R out): bytes per launch averaged over the launches of the step
         calls = kern['colstream_agg_kernel'][0]
         models['colstream_agg_kernel'] = {'bytes': n * n * s * (2 * 1 + 3 * max(calls - 2, 0)) / max(calls, 1), 'flops': None}
+        # ... and the row transform of r0 / the plain stencil run once per component (first / last iteration), the fused
+        # stencil + transform in every iteration between
+        ncomp = len(iters)
+        work.update({'rowdct_fused_kernel': ncomp, 'pq_kernel': ncomp, 'pqdct_kernel': max(sum(iters) - ncomp, 1)})
     table = {}
     for name, (calls, ms) in kern.items():
         m = models.get(name, {})

@@ -1,7 +1,8 @@
 #!/bin/bash
 # usage (GPU box): COMMIT=<sha> [SKIP_TESTS=1] [SKIP_PMC=1] tools/gpu_close.sh
-# Closing pass of a round: the whole GPU suite, smoke, the bench line, rocprofv3 kernel stats (4096^2 f32 / f64, 3000^2, 512^2)
-# and the PMC passes behind profiles/counters.json (one pass per counter set: the guide's rule).  Everything lands under
+# Closing pass of a round: the whole GPU suite, smoke, rocprofv3 kernel stats (4096^2 f32 / f64, 3000^2, 512^2)
+# the PMC passes behind profiles/counters.json (one pass per counter set: the guide's rule), then the bench line (which
+# reads those counters).  Everything lands under
 # gpurun_out/close/; copy what is to be kept into profiles/ with the round's prefix.
 ulimit -c 0
 ROOT=$GRAFT_REPO_ROOT
@@ -12,7 +13,6 @@ if [ -z "$SKIP_TESTS" ]; then
   echo "pytest rc=$?"; tail -4 $out/pytest_gpu.log
 fi
 timeout 300 python __graft_entry__.py smoke 2>&1 | tail -1
-[ -n "$PMC_FIRST" ] && echo "(bench line after the counters)" || timeout 900 python bench.py > $out/bench.json 2> $out/bench.err; echo "bench rc=$?"; tail -2 $out/bench.err; head -c 700 $out/bench.json; echo
 cd /tmp && export TMPDIR=/tmp
 # (the two unwrap components run one after the other while the kernels are timed: concurrent kernels of the two streams
 #  stretch each other's durations)
@@ -37,7 +37,10 @@ cp $ROOT/gpurun_out/stage_times.json $out/ 2>/dev/null
 cd $ROOT && timeout 600 bash tools/gpu_unwrap_sizes.sh > /dev/null 2>&1; cp gpurun_out/unwrap_sizes.txt $out/ 2>/dev/null
 SIZES="256 500 512 1000 1024 1500 2000 2048 3000 4096 8192 16384" timeout 900 bash tools/gpu_sizes.sh > /dev/null 2>&1; cp gpurun_out/sizes.txt $out/ 2>/dev/null
 cd /tmp
-[ -n "$SKIP_PMC" ] && exit 0
+bench_line() {   # the bench line LAST: its roofline reads the counters of this very tree (profiles/counters.json, checked by hash)
+  cd $ROOT; timeout 900 python bench.py > $out/bench.json 2> $out/bench.err; echo "bench rc=$?"; tail -2 $out/bench.err; head -c 700 $out/bench.json; echo
+}
+if [ -n "$SKIP_PMC" ]; then bench_line; exit 0; fi
 i=0
 for set in "FETCH_SIZE" "WRITE_SIZE" "SQ_INSTS_VALU SQ_WAVES SQ_INSTS_LDS SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE SQ_WAVE_CYCLES SQ_WAIT_INST_ANY SQ_BUSY_CYCLES" \
            "SQ_WAIT_ANY SQ_ACTIVE_INST_ANY SQ_ACTIVE_INST_VALU SQ_INSTS_VALU_MFMA_F32 SQ_INSTS_VMEM_WR SQ_INSTS_VMEM_RD" "TCC_HIT_sum TCC_MISS_sum GRBM_GUI_ACTIVE"; do
@@ -47,6 +50,7 @@ for set in "FETCH_SIZE" "WRITE_SIZE" "SQ_INSTS_VALU SQ_WAVES SQ_INSTS_LDS SQ_LDS
 done
 cd $ROOT
 COMMIT=${COMMIT:-unknown} python3 tools/make_counters.py $out/counters.json $out/pmc_[0-9] > /dev/null; head -c 900 $out/counters.json; echo
+cp $out/counters.json $ROOT/profiles/counters.json
 # f64 traffic of the sweep (18.2 GB moved for 4 GB needed)
 j=0
 for set in "FETCH_SIZE" "WRITE_SIZE"; do
@@ -55,3 +59,4 @@ for set in "FETCH_SIZE" "WRITE_SIZE"; do
 done
 COMMIT=${COMMIT:-unknown} PMC_DTYPE=f64 python3 tools/make_counters.py $out/counters_f64.json $out/pmc64_[0-9] > /dev/null
 rm -rf $out/pmc_[0-9] $out/pmc64_[0-9]
+bench_line
