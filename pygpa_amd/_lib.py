@@ -31,6 +31,7 @@ SIGNATURES = {
     'gpa_plan_workspace_bytes': (_sz, [_vp]),
     'gpa_plan_stream': (_vp, [_vp]),
     'gpa_plan_fft_len': (_i, [_vp, _i]),
+    'gpa_plan_axis_native': (_i, [_vp, _i]),
     'gpa_lockin_batch': (_i, [_vp, _vp, _vp, _i, _d, _vp]),
     'gpa_lockin_batch_dev': (_i, [_vp, _vp, _vp, _i, _d, _vp]),
     'gpa_sweep': (_i, [_vp, _vp, _vp, _vp, _i, _d, _vp, _vp, _vp]),
@@ -210,6 +211,10 @@ class Plan:
 
     def fft_len(self, axis):
         return self.lib.gpa_plan_fft_len(self.handle, axis)
+
+    def axis_native(self, axis):
+        """True when the sweep runs this axis at its own length on the mixed-radix engine (after a call that took sigma)"""
+        return bool(self.lib.gpa_plan_axis_native(self.handle, axis))
 
     def sync(self):
         check(self.lib.gpa_plan_sync(self.handle), 'gpa_plan_sync')

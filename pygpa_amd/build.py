@@ -17,7 +17,7 @@ HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(HERE, 'csrc')
 BUILD = os.path.join(CSRC, '_build')
 LIB = os.path.join(HERE, 'libgpa_hip.so')
-SOURCES = ['gpa_sweep.hip', 'gpa_passb_shared.hip', 'gpa_sweep_ext.hip', 'gpa_reconstruct.hip', 'gpa_unwrap.hip', 'gpa_unwrap_rows.hip', 'gpa_unwrap_cols.hip', 'gpa_unwrap_colstream.hip', 'gpa_unwrap_stencil.hip', 'gpa_unwrap_generic.hip',
+SOURCES = ['gpa_sweep.hip', 'gpa_sweep_mr.hip', 'gpa_passb_shared.hip', 'gpa_sweep_ext.hip', 'gpa_reconstruct.hip', 'gpa_unwrap.hip', 'gpa_unwrap_rows.hip', 'gpa_unwrap_cols.hip', 'gpa_unwrap_colstream.hip', 'gpa_unwrap_stencil.hip', 'gpa_unwrap_generic.hip',
            'gpa_unwrap_tables.hip', 'gpa_dft2.hip', 'gpa_warp.hip', 'gpa_tiles.hip', 'gpa_peaks.hip', 'gpa_api.hip']
 ARCH = 'gfx950'
 FLAGS = ['-O3', '-std=c++17', '-fPIC', '--offload-arch=' + ARCH, '-fno-gpu-rdc',

@@ -32,7 +32,8 @@ namespace gpa {
 static const char* const kOptNames[OPT_COUNT] = {
     "PBS_FULLBAND", "USE_GRAPH", "SERIAL_UNWRAP", "NO_WORKER", "NO_KSPLIT", "NO_COMPACT", "NO_SHARED", "SHARED_A",
     "NO_PAIR", "PBS_E8", "TRI_SMALL", "TRI_Q", "NO_MR", "MR_FORCE_BLUESTEIN", "NO_ROWPQ", "COLSOLVE", "NO_LAT",
-    "F32_EPS_FLOOR", "COLSTREAM_CHUNK", "NO_ROWHALF", "PAIR_MAXSIDE", "ROWHALF_MINLG", "NO_PQDCT"};
+    "F32_EPS_FLOOR", "COLSTREAM_CHUNK", "NO_ROWHALF", "PAIR_MAXSIDE", "ROWHALF_MINLG", "NO_PQDCT", "NO_NATIVE",
+    "NATIVE_RATIO", "NATIVE_SHARED"};
 static OptVal g_opts[OPT_COUNT];
 static std::once_flag g_opts_once;
 static void opt_assign(OptVal& o, const char* value) {
@@ -239,6 +240,9 @@ struct gpa_plan {
   int device = 0, dtype = 0, n0 = 0, n1 = 0, max_batch = 0;
   Axis ax0{}, ax1{};              // the geometry in use (depends on sigma for non-power-of-two axes)
   Axis ax0_full{}, ax1_full{};    // the plan's largest geometry (L >= 2n - 1): what the tables are sized for
+  // native mode of an axis (gpa_sweep_mr.hip): the length-n twiddles (uploaded once) and the filter table of the cached sigma
+  void *natW0 = nullptr, *natW1 = nullptr, *natH0 = nullptr, *natH1 = nullptr;
+  double natkey_cached = -2.0;    // the NO_NATIVE / NATIVE_RATIO options the cached geometry was chosen under
   hipStream_t stream = nullptr;
   size_t rsz = 4, csz = 8;        // bytes per real / complex element
   size_t ws_bytes = 0;
@@ -369,6 +373,9 @@ static Axis make_axis(int n) {
   a.L = 1 << lg;
   a.extL = a.padded ? n - 1 : 0;
   a.extR = 0;
+  a.native = false;
+  a.pl = MrPlan{};
+  a.natW = a.natH = nullptr;
   return a;
 }
 
@@ -439,11 +446,12 @@ static int plan_build(gpa_plan* p) {
   // start with what the non-sweep users need (<= 8 real planes) and grow in ensure_tbuf()
   p->tbuf_planes = B < 4 ? B : 4;
   TRY(dmalloc(p, &p->Tbuf, (size_t)p->tbuf_planes * npx * p->csz));
-  TRY(dmalloc(p, &p->tb.cxb, (size_t)B * (p->ax0.L / 16) * p->csz));
+  // (carrier base tables: one entry per thread of a transform -- L / 16, or up to 256 for an axis in native mode)
+  TRY(dmalloc(p, &p->tb.cxb, (size_t)B * std::max(p->ax0.L / 16, 256) * p->csz));
   TRY(dmalloc(p, &p->tb.sx, (size_t)B * 16 * p->csz));
   TRY(dmalloc(p, &p->tb.wxw, (size_t)B * p->csz));
   TRY(dmalloc(p, &p->tb.wxr, (size_t)B * p->csz));
-  TRY(dmalloc(p, &p->tb.cyb, (size_t)B * (p->ax1.L / 16) * p->csz));
+  TRY(dmalloc(p, &p->tb.cyb, (size_t)B * std::max(p->ax1.L / 16, 256) * p->csz));
   TRY(dmalloc(p, &p->tb.sy, (size_t)B * 16 * p->csz));
   TRY(dmalloc(p, &p->tb.wyw, (size_t)B * p->csz));
   TRY(dmalloc(p, &p->tb.wyr, (size_t)B * p->csz));
@@ -491,7 +499,10 @@ static int upload_twiddles(gpa_plan* p, void* dst, int L) {
 
 static int ensure_filters(gpa_plan* p, double sigma) {
   if (!(sigma > 0)) return fail(GPA_ERR_ARG, "sigma must be positive");
-  if (sigma == p->sigma_cached) return GPA_OK;
+  // an axis that is not a power of two long runs at its own length on the mixed-radix engine when the padded
+  // transform would be at least NATIVE_RATIO (default 1.5) times as long (Axis::native)
+  const double natkey = opt_set(OPT_NO_NATIVE) ? -1.0 : (opt_set(OPT_NATIVE_RATIO) ? opt(OPT_NATIVE_RATIO).num : 1.5);
+  if (sigma == p->sigma_cached && natkey == p->natkey_cached) return GPA_OK;
   HIP_TRY(hipStreamSynchronize(p->stream));   // the tables may still be read by an earlier asynchronous call
   p->sigma_cached = -1.0;   // a failure below must not leave half-switched tables behind a matching sigma
   for (int axis = 0; axis < 2; ++axis) {
@@ -503,7 +514,32 @@ static int ensure_filters(gpa_plan* p, double sigma) {
       hsp = spatial_kernel(full.n, g);
       if (!p->no_compact) want = compact_axis(full, kernel_support(hsp, p->dtype == 0 ? 1e-9 : 1e-14));
     }
-    if (want.lg != cur.lg || want.extR != cur.extR || want.extL != cur.extL) {
+    {
+      MrPlan pl{};
+      want.native = natkey > 0 && full.padded && full.n >= 48 && mr_make_plan(full.n, &pl) && pl.T <= 256 &&
+                    (double)want.L >= natkey * (double)full.n;
+      if (want.native) {
+        want.pl = pl;
+        void** Wd = axis == 0 ? &p->natW0 : &p->natW1;
+        void** Hd = axis == 0 ? &p->natH0 : &p->natH1;
+        if (!*Wd) {
+          TRY(dmalloc(p, Wd, (size_t)mr_lds_elems(full.n) * p->csz));
+          TRY(dmalloc(p, Hd, (size_t)full.n * p->rsz));
+          std::vector<double> t((size_t)2 * mr_lds_elems(full.n), 0.0);   // entry k at mr_pad(k), see mr_store()
+          for (int k = 0; k < full.n; ++k) {
+            t[2 * (size_t)mr_pad(k)] = cos(-2.0 * M_PI * k / full.n);
+            t[2 * (size_t)mr_pad(k) + 1] = sin(-2.0 * M_PI * k / full.n);
+          }
+          TRY(upload_real_table(p, *Wd, t));
+        }
+        std::vector<double> hn((size_t)full.n);
+        for (int k = 0; k < full.n; ++k) hn[k] = g[k] / (double)full.n;
+        TRY(upload_real_table(p, *Hd, hn));
+        want.natW = *Wd;
+        want.natH = *Hd;
+      }
+    }
+    if (want.lg != cur.lg || want.extR != cur.extR || want.extL != cur.extL || want.native != cur.native) {
       // another transform length for this sigma: twiddles of that length, and the carrier tables (laid out per
       // L / 16 threads) have to be staged again
       TRY(upload_twiddles(p, axis == 0 ? p->tw0 : p->tw1, want.L));
@@ -611,6 +647,7 @@ static int ensure_filters(gpa_plan* p, double sigma) {
     }
   }
   p->sigma_cached = sigma;
+  p->natkey_cached = natkey;
   return GPA_OK;
 }
 
@@ -940,6 +977,10 @@ int gpa_plan_fft_len(const gpa_plan* p, int axis) {
   if (!p) return 0;
   return axis == 0 ? p->ax0.L : p->ax1.L;
 }
+int gpa_plan_axis_native(const gpa_plan* p, int axis) {
+  if (!p) return 0;
+  return (axis == 0 ? p->ax0.native : p->ax1.native) ? 1 : 0;
+}
 
 // ---- a1/a2 -------------------------------------------------------------------
 int gpa_lockin_batch_dev(gpa_plan* p, const void* image, const double* kvecs, int B, double sigma,
@@ -1031,6 +1072,9 @@ static int passB_select(gpa_plan* p, int P, int K, void* lockin, int32_t* kidx) 
     while (ksplit < 4 && ksplit * 2 <= K && rows_wg * ksplit < 1024) ksplit *= 2;
   if (ksplit == 1) {
     TRY(shared_prepare(p, P, K));
+    // (a row in native mode: the per-candidate kernel at length n rather than the shared-forward kernel on the
+    //  zero-padded power of two, unless NATIVE_SHARED asks for the latter)
+    if (p->sh_use && p->ax1.native && !opt_set(OPT_NATIVE_SHARED)) p->sh_use = false;
     if (p->sh_use)
       HIP_TRY(launch_passB_shared(p->dtype, p->ax1s, p->n0, p->Tbuf, p->ax1s.L == p->ax1.L ? p->tw1 : p->tw1s, p->tb,
                                   p->sh, p->sh_E, p->sh_Epad, P, K, lockin, kidx, p->stream, 1, 0, p->sh_elems, p->sh_nbl));
@@ -1585,6 +1629,7 @@ int gpa_extract_displacement_field_batch_dev(gpa_plan* p, const void* images, in
     p->b_chunk = chunk;
   }
   TRY(shared_prepare(p, P, K));
+  if (p->sh_use && p->ax1.native && !opt_set(OPT_NATIVE_SHARED)) p->sh_use = false;   // (as in passB_select)
   int nparts = 0;
   const size_t rstride = 2 * npx;                                                     // residual slices per image
   const size_t pstride = (size_t)(unwrap_partials_buffer(&p->uwb, 2) - unwrap_partials_buffer(&p->uwb, 0));

@@ -32,7 +32,7 @@ __device__ __forceinline__ cpx<T> unit_phasor(double cycles) {
 
 template <class T>
 __global__ void tables_kernel(const double* __restrict__ kl, const double* __restrict__ kr,
-                              const double* __restrict__ pw, int B, int Bx, int n0, int n1, int L0, int L1,
+                              const double* __restrict__ pw, int B, int Bx, int n0, int n1, int L0, int L1, int tpf0, int tpf1,
                               cpx<T>* cxb, cpx<T>* sx, cpx<T>* wxw, cpx<T>* wxr, cpx<T>* cyb, cpx<T>* sy, cpx<T>* wyw,
                               cpx<T>* wyr,
                               cpx<T>* dx, cpx<T>* dy) {
@@ -40,7 +40,7 @@ __global__ void tables_kernel(const double* __restrict__ kl, const double* __res
   const int j = blockIdx.x * blockDim.x + threadIdx.x;
   if (b < Bx) {   // x carrier of x-plane b
     const double wx = pw[b];
-    const int tpf = L0 / 16;
+    const int tpf = tpf0;
     if (j < tpf) cxb[(size_t)b * tpf + j] = unit_phasor<T>(wx * j);
     if (j < 16) sx[b * 16 + j] = unit_phasor<T>(wx * (double)tpf * j);
     if (j == 0) wxw[b] = unit_phasor<T>(-wx * (double)(L0 - n0));
@@ -48,7 +48,7 @@ __global__ void tables_kernel(const double* __restrict__ kl, const double* __res
   }
   if (b < B) {    // y carrier and compensation phasors of candidate b
     const double wx = kl[2 * b], wy = kl[2 * b + 1], kx = kr[2 * b], ky = kr[2 * b + 1];
-    const int tpf = L1 / 16;
+    const int tpf = tpf1;
     if (j < tpf) cyb[(size_t)b * tpf + j] = unit_phasor<T>(wy * j);
     if (j < 16) sy[b * 16 + j] = unit_phasor<T>(wy * (double)tpf * j);
     if (j == 0) wyw[b] = unit_phasor<T>(-wy * (double)(L1 - n1));
@@ -61,18 +61,20 @@ __global__ void tables_kernel(const double* __restrict__ kl, const double* __res
 hipError_t launch_tables(int dtype, const Axis& a0, const Axis& a1, const double* kl,
                          const double* kr, int B, const double* pw, int Bx, const SweepTables& tb,
                          hipStream_t s) {
+  // (a native axis: one base entry per thread of its mixed-radix transform, stride factors in steps of that count)
+  const int tpf0 = axis_tpf(a0), tpf1 = axis_tpf(a1);
   int len = a0.n > a1.n ? a0.n : a1.n;
-  if (len < a0.L / 16) len = a0.L / 16;
-  if (len < a1.L / 16) len = a1.L / 16;
+  if (len < tpf0) len = tpf0;
+  if (len < tpf1) len = tpf1;
   if (len < 16) len = 16;
   dim3 grid((len + 255) / 256, B > Bx ? B : Bx);
   if (dtype == 0)
-    tables_kernel<float><<<grid, 256, 0, s>>>(kl, kr, pw, B, Bx, a0.n, a1.n, a0.L, a1.L, (cpx<float>*)tb.cxb,
+    tables_kernel<float><<<grid, 256, 0, s>>>(kl, kr, pw, B, Bx, a0.n, a1.n, a0.L, a1.L, tpf0, tpf1, (cpx<float>*)tb.cxb,
                                               (cpx<float>*)tb.sx, (cpx<float>*)tb.wxw, (cpx<float>*)tb.wxr, (cpx<float>*)tb.cyb,
                                               (cpx<float>*)tb.sy, (cpx<float>*)tb.wyw, (cpx<float>*)tb.wyr, (cpx<float>*)tb.dx,
                                               (cpx<float>*)tb.dy);
   else
-    tables_kernel<double><<<grid, 256, 0, s>>>(kl, kr, pw, B, Bx, a0.n, a1.n, a0.L, a1.L, (cpx<double>*)tb.cxb,
+    tables_kernel<double><<<grid, 256, 0, s>>>(kl, kr, pw, B, Bx, a0.n, a1.n, a0.L, a1.L, tpf0, tpf1, (cpx<double>*)tb.cxb,
                                                (cpx<double>*)tb.sx, (cpx<double>*)tb.wxw, (cpx<double>*)tb.wxr, (cpx<double>*)tb.cyb,
                                                (cpx<double>*)tb.sy, (cpx<double>*)tb.wyw, (cpx<double>*)tb.wyr, (cpx<double>*)tb.dx,
                                                (cpx<double>*)tb.dy);
@@ -335,6 +337,7 @@ static hipError_t run_passA(const Axis& a0, int n1, const void* image, const voi
 hipError_t launch_passA(int dtype, const Axis& a0, int n1, const void* image, const void* mean,
                         const SweepTables& tb, const void* Hx, const void* tw0, void* Tbuf,
                         int B, hipStream_t s, int nimg) {
+  if (a0.native) return launch_passA_mr(dtype, a0, n1, image, mean, tb, Tbuf, B, s, nimg);
 #define CASE_A(LG)                                                                                \
   case LG:                                                                                        \
     if (dtype == 0)                                                                               \
@@ -351,6 +354,8 @@ hipError_t launch_passA(int dtype, const Axis& a0, int n1, const void* image, co
 hipError_t launch_passB(int dtype, const Axis& a1, int n0, const void* Tbuf, const void* Hy,
                         const void* tw1, const SweepTables& tb, int P, int K, bool select,
                         void* out, int32_t* kidx, hipStream_t s, int nimg, int Bx) {
+  if (a1.native)
+    return launch_passB_mr(dtype, a1, n0, Tbuf, tb, P, K, select ? PB_SELECT : PB_ALL, out, kidx, nullptr, nullptr, s, 1, nimg, Bx);
 #define CALL_B(T, LG, PD)                                                                                                   \
   (select ? run_passB<T, LG, PD, PB_SELECT>(a1, n0, Tbuf, Hy, tw1, tb, P, K, out, kidx, nullptr, nullptr, s, 1, nimg, Bx)    \
           : run_passB<T, LG, PD, PB_ALL>(a1, n0, Tbuf, Hy, tw1, tb, P, K, out, kidx, nullptr, nullptr, s, 1, nimg, Bx))
