@@ -32,7 +32,7 @@ namespace gpa {
 static const char* const kOptNames[OPT_COUNT] = {
     "PBS_FULLBAND", "USE_GRAPH", "SERIAL_UNWRAP", "NO_WORKER", "NO_KSPLIT", "NO_COMPACT", "NO_SHARED", "SHARED_A",
     "NO_PAIR", "PBS_E8", "TRI_SMALL", "TRI_Q", "NO_MR", "MR_FORCE_BLUESTEIN", "NO_ROWPQ", "COLSOLVE", "NO_LAT",
-    "F32_EPS_FLOOR", "COLSTREAM_CHUNK", "NO_ROWHALF", "PAIR_MAXSIDE", "ROWHALF_MINLG", "NO_PQDCT", "NO_NATIVE",
+    "F32_EPS_FLOOR", "COLSTREAM_CHUNK", "NO_ROWHALF", "PAIR_MAXSIDE", "ROWHALF_MINLG", "NO_PQDCT", "NATIVE",
     "NATIVE_RATIO", "NATIVE_SHARED"};
 static OptVal g_opts[OPT_COUNT];
 static std::once_flag g_opts_once;
@@ -499,9 +499,9 @@ static int upload_twiddles(gpa_plan* p, void* dst, int L) {
 
 static int ensure_filters(gpa_plan* p, double sigma) {
   if (!(sigma > 0)) return fail(GPA_ERR_ARG, "sigma must be positive");
-  // an axis that is not a power of two long runs at its own length on the mixed-radix engine when the padded
-  // transform would be at least NATIVE_RATIO (default 1.5) times as long (Axis::native)
-  const double natkey = opt_set(OPT_NO_NATIVE) ? -1.0 : (opt_set(OPT_NATIVE_RATIO) ? opt(OPT_NATIVE_RATIO).num : 1.5);
+  // NATIVE=1 (opt-in, measured slower: Axis::native): an axis that is not a power of two long runs at its own length on
+  // the mixed-radix engine when the padded transform would be at least NATIVE_RATIO (default 1.5) times as long
+  const double natkey = !opt_set(OPT_NATIVE) ? -1.0 : (opt_set(OPT_NATIVE_RATIO) ? opt(OPT_NATIVE_RATIO).num : 1.5);
   if (sigma == p->sigma_cached && natkey == p->natkey_cached) return GPA_OK;
   HIP_TRY(hipStreamSynchronize(p->stream));   // the tables may still be read by an earlier asynchronous call
   p->sigma_cached = -1.0;   // a failure below must not leave half-switched tables behind a matching sigma

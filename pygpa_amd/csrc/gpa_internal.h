@@ -72,7 +72,7 @@ enum OptKey {
   OPT_PBS_FULLBAND, OPT_USE_GRAPH, OPT_SERIAL_UNWRAP, OPT_NO_WORKER, OPT_NO_KSPLIT, OPT_NO_COMPACT, OPT_NO_SHARED,
   OPT_SHARED_A, OPT_NO_PAIR, OPT_PBS_E8, OPT_TRI_SMALL, OPT_TRI_Q, OPT_NO_MR, OPT_MR_FORCE_BLUESTEIN, OPT_NO_ROWPQ,
   OPT_COLSOLVE, OPT_NO_LAT, OPT_F32_EPS_FLOOR, OPT_COLSTREAM_CHUNK, OPT_NO_ROWHALF, OPT_PAIR_MAXSIDE, OPT_ROWHALF_MINLG, OPT_NO_PQDCT,
-  OPT_NO_NATIVE, OPT_NATIVE_RATIO, OPT_NATIVE_SHARED, OPT_COUNT
+  OPT_NATIVE, OPT_NATIVE_RATIO, OPT_NATIVE_SHARED, OPT_COUNT
 };
 struct OptVal {
   bool set;
@@ -98,12 +98,13 @@ inline bool opt_set(OptKey k) { return opt(k).set; }
 //           transform): the kernel of a Gaussian filter is negligible beyond E samples (the host measures E on
 //           the actual taps: everything dropped sums to < 1e-14 (f64) / 1e-9 (f32) of sum|h|), so lags -E .. E
 //           suffice, extL = extR = E and L >= n + 2E.
-// Native mode (round 4, gpa_sweep_mr.hip): a smooth length n = 2^a 3^b 5^c 7^d 11^e 13^f that is not a power of two and
-//           whose padded transform would be >= 1.5 n long is transformed at its OWN length on the mixed-radix
-//           LDS-resident engine (gpa_mrfft.h): periodic mode at length n, no extension.  lg / L / ext* keep describing
-//           the padded geometry (the shared-forward kernels derive theirs from it); `native` sends the per-plane pass A
-//           and the per-candidate pass B kernels to their mixed-radix twins, which read natW / natH instead of the
-//           power-of-two twiddles and filter table.
+// Native mode (round 4, gpa_sweep_mr.hip; OPT-IN, option NATIVE): a smooth length n = 2^a 3^b 5^c 7^d 11^e 13^f that is
+//           not a power of two and whose padded transform would be >= NATIVE_RATIO (1.5) n long is transformed at its
+//           OWN length on the mixed-radix LDS-resident engine (gpa_mrfft.h): periodic mode at length n, no extension.
+//           lg / L / ext* keep describing the padded geometry (the shared-forward kernels derive theirs from it);
+//           `native` sends the per-plane pass A and the per-candidate pass B kernels to their mixed-radix twins, which
+//           read natW / natH instead of the power-of-two twiddles and filter table.  Measured SLOWER than the padded
+//           path at every size tried (profiles/r04_native_sweep_rejected.txt), hence not the default.
 struct Axis {
   int n;
   int lg;      // log2(L)

@@ -1,14 +1,15 @@
-"""The lock-in sweep on axes in NATIVE mode (pygpa_amd/csrc/gpa_sweep_mr.hip): a smooth length that is not a power of two is
-transformed at its own length on the mixed-radix engine instead of on a padded power of two.  The reference's filter is
-the circular one of exactly that length (geometric_phase_analysis.py:72-75), so the native kernels are held
+"""The lock-in sweep on axes in NATIVE mode (pygpa_amd/csrc/gpa_sweep_mr.hip, option NATIVE=1): a smooth length that is not
+a power of two is transformed at its own length on the mixed-radix engine instead of on a padded power of two.  The
+reference's filter is the circular one of exactly that length (geometric_phase_analysis.py:72-75), so the native kernels
+are held
 
   * to the oracle (the reference's own arithmetic) at the tolerances of tests/test_gpu_parity.py, kidx bit-exact up to
     amplitude ties, and
-  * to the padded power-of-two path of the same library (NO_NATIVE=1) on every entry point that runs a sweep: all
+  * to the padded power-of-two path of the same library (the default) on every entry point that runs a sweep: all
     lock-ins, best-of-K, the gated selection of wfr4, selection + phase gradient, the fused driver, a stack of frames.
 
-`gpa_plan_axis_native` says which axes the plan runs natively; the golden cases 60^2, 48x80, 63x65 of test_gpu_parity.py
-also run natively now (their lengths are smooth), pinned by the real reference at 1e-11."""
+The mode is OPT-IN: it measured slower than the padded path at every size (profiles/r04_native_sweep_rejected.txt); these
+tests keep the rejected kernels honest.  `gpa_plan_axis_native` says which axes a plan runs natively."""
 import os
 
 import numpy as np
@@ -57,6 +58,7 @@ SHAPES = [((500, 500), (True, True)), ((250, 1000), (True, True)), ((1000, 96), 
 @pytest.mark.parametrize('dtype', DTYPES)
 @pytest.mark.parametrize('shape,native', SHAPES)
 def test_native_sweep_against_oracle_and_padded_path(shape, native, dtype, gpa_option):
+    gpa_option('NATIVE', '1')
     kvecs, img0 = case(shape)
     sigma = 6
     klist = explicit_klists(kvecs, 0.03, 3, 3)[0]
@@ -72,12 +74,12 @@ def test_native_sweep_against_oracle_and_padded_path(shape, native, dtype, gpa_o
     lb = plan.lockin_batch(img0, klist[:3], sigma)
     assert rel(lb, orc.lockin_batch(img0, klist[:3], sigma)) < TOL[dtype]['lock']
     # the padded power-of-two path of the same plan (tables restaged), then native again
-    gpa_option('NO_NATIVE', '1')
+    gpa_option('NATIVE', None)
     lock_p, kidx_p, _ = plan.sweep(img0, kvecs[0], klist, sigma)
     assert (plan.axis_native(0), plan.axis_native(1)) == (False, False)
     same = kidx == kidx_p
     assert same.mean() > 0.999 and rel(lock[same], lock_p[same]) < TOL[dtype]['lock']
-    gpa_option('NO_NATIVE', None)
+    gpa_option('NATIVE', '1')
     lock2, kidx2, _ = plan.sweep(img0, kvecs[0], klist, sigma)
     assert (plan.axis_native(0), plan.axis_native(1)) == native
     assert np.array_equal(kidx2, kidx) and np.array_equal(lock2, lock)
@@ -94,6 +96,7 @@ def test_native_sweep_against_oracle_and_padded_path(shape, native, dtype, gpa_o
 def test_native_gated_and_gradient_modes(dtype, gpa_option):
     """the less travelled selection modes on native axes: wfr4's gated chain and selection + phase gradient
     (geometric_phase_analysis.py:839-862, :763-813) against the oracle and against the padded path"""
+    gpa_option('NATIVE', '1')
     shape = (250, 500)
     kvecs, img0 = case(shape, seed=11)
     sigma = 7
@@ -106,9 +109,9 @@ def test_native_gated_and_gradient_modes(dtype, gpa_option):
     assert plan.axis_native(0) and plan.axis_native(1)
     for mode in (0, 1, 2):
         lock, kidx, grad = plan.sweep(img0, kvecs[0], klist, sigma, want_grad=True, grad_mode=mode)
-        gpa_option('NO_NATIVE', '1')
+        gpa_option('NATIVE', None)
         lock_p, kidx_p, grad_p = plan.sweep(img0, kvecs[0], klist, sigma, want_grad=True, grad_mode=mode)
-        gpa_option('NO_NATIVE', None)
+        gpa_option('NATIVE', '1')
         same = kidx == kidx_p
         assert same.mean() > 0.999
         assert rel(lock[same], lock_p[same]) < TOL[dtype]['lock']
@@ -124,9 +127,9 @@ def test_native_gated_and_gradient_modes(dtype, gpa_option):
         d = np.abs(grad[ok] - grad_p[ok])
         d = np.minimum(d, np.abs(d - np.pi))      # wrapToPi(2 g) / 2: values at +- pi / 2 are the same angle
         assert d.max() < (1e-9 if dtype is np.float64 else 2e-3)
-    gpa_option('NO_NATIVE', '1')
+    gpa_option('NATIVE', None)
     lg_p, kg_p = plan.sweep_gated(img0, kvecs[0], klist, sigma, gate)
-    gpa_option('NO_NATIVE', None)
+    gpa_option('NATIVE', '1')
     same = kg == kg_p
     assert same.mean() > (0.999 if dtype is np.float64 else 0.97)     # f32 amplitude near-ties flip a gated chain
     assert rel(lg[same], lg_p[same]) < TOL[dtype]['lock']
@@ -142,6 +145,7 @@ def test_native_gated_and_gradient_modes(dtype, gpa_option):
 def test_native_fused_driver_against_oracle(shape, dtype, gpa_option):
     """extract_displacement_field (geometric_phase_analysis.py:907-932) on native axes: small K takes the candidate-split
     pass B (PB_PART + merge) at 500^2, the plain per-candidate kernel otherwise; u against the oracle and the padded path"""
+    gpa_option('NATIVE', '1')
     kvecs = hex_kvecs(0.1, 7.0)
     img = hex_moire(shape, kvecs, 0.6 * gaussian_bump_displacement(shape), noise=0.05, seed=3, dtype=dtype)
     klists = np.stack(explicit_klists(kvecs, 0.04, 2, 2))
@@ -152,9 +156,9 @@ def test_native_fused_driver_against_oracle(shape, dtype, gpa_option):
     ref_u = orc.extract_displacement_field(img.astype(np.float64), kvecs, sigma=10, klists=klists, workers=cores)
     bound = 1e-6 if dtype is np.float64 else 0.1          # px: the bounds of tests/test_gpu_configs.py
     assert np.abs(u - ref_u).max() < bound, float(np.abs(u - ref_u).max())
-    gpa_option('NO_NATIVE', '1')
+    gpa_option('NATIVE', None)
     u_p, _, _, iters_p = plan.extract_displacement_field(img, kvecs, klists, 10, 20, kmax=10)
-    gpa_option('NO_NATIVE', None)
+    gpa_option('NATIVE', '1')
     assert np.abs(u - u_p).max() < bound
     # 16 candidates per peak (the per-row loop without the candidate split)
     klists16 = np.stack(explicit_klists(kvecs, 0.04, 4, 4))
@@ -166,8 +170,9 @@ def test_native_fused_driver_against_oracle(shape, dtype, gpa_option):
     plan16.close()
 
 
-def test_native_stack_of_frames_equals_single_images():
+def test_native_stack_of_frames_equals_single_images(gpa_option):
     """a stack of 500^2 frames (blockIdx.z / .y = image in the native kernels) equals the single-image driver"""
+    gpa_option('NATIVE', '1')
     n = 500
     kvecs = hex_kvecs(0.1, 7.0)
     klists = np.stack(explicit_klists(kvecs, 0.04, 2, 2))

@@ -1022,7 +1022,6 @@ def test_compact_padded_axes(shape, dtype, monkeypatch, gpa_option):
     """non-power-of-two axes, narrow spatial kernel: the plan switches to the compact extension (lags -E .. E,
     transform length pow2 >= n + 2E instead of >= 2n - 1) -- same numbers as the oracle and as the full
     extension, and switching sigma on one plan (compact -> full -> compact) restages every table"""
-    gpa_option('NO_NATIVE', '1')    # (this test is about the padded power-of-two path; tests/test_gpu_native_sweep.py has the other)
     kvecs = hex_kvecs(0.11, 4.0)
     img = hex_moire(shape, kvecs, gaussian_bump_displacement(shape), noise=0.2, seed=5)
     img0 = img - img.mean()
