@@ -33,7 +33,7 @@ static const char* const kOptNames[OPT_COUNT] = {
     "PBS_FULLBAND", "USE_GRAPH", "SERIAL_UNWRAP", "NO_WORKER", "NO_KSPLIT", "NO_COMPACT", "NO_SHARED", "SHARED_A",
     "NO_PAIR", "PBS_E8", "TRI_SMALL", "TRI_Q", "NO_MR", "MR_FORCE_BLUESTEIN", "NO_ROWPQ", "COLSOLVE", "NO_LAT",
     "F32_EPS_FLOOR", "COLSTREAM_CHUNK", "NO_ROWHALF", "PAIR_MAXSIDE", "ROWHALF_MINLG", "NO_PQDCT", "NATIVE",
-    "NATIVE_RATIO", "NATIVE_SHARED"};
+    "NATIVE_RATIO", "NATIVE_SHARED", "NO_REORDER"};
 static OptVal g_opts[OPT_COUNT];
 static std::once_flag g_opts_once;
 static void opt_assign(OptVal& o, const char* value) {
@@ -267,6 +267,7 @@ struct gpa_plan {
   bool sh_ok = false;             // this sigma / axis can run it
   bool use_shared = true;         // GPA_NO_SHARED=1 keeps the per-candidate forward transforms
   int sh_epoch = 0, sh_built_epoch = -1, sh_built_K = 0, sh_built_B = 0;   // tables follow sigma and the staged k-list
+  bool sh_built_reorder = true;   // ... and the NO_REORDER option they were built under
   bool sh_built_ok = false;       // the tables of that key are complete and worth using
   bool sh_use = false;            // ... and the staged candidates form runs of >= 2 on an x-plane
   size_t sh_gb_bytes = 0, sh_psi_bytes = 0;
@@ -657,15 +658,53 @@ static int shared_prepare(gpa_plan* p, int P, int K) {
   p->sh_use = false;
   const int B = P * K;
   if (!p->sh_ok || !p->use_shared || K < 2 || (int)p->staged_planeof.size() < B) return GPA_OK;
-  if (p->sh_built_epoch == p->sh_epoch && p->sh_built_K == K && p->sh_built_B == B) {
+  const bool reorder = !opt_set(OPT_NO_REORDER);
+  if (p->sh_built_epoch == p->sh_epoch && p->sh_built_K == K && p->sh_built_B == B && p->sh_built_reorder == reorder) {
     p->sh_use = p->sh_built_ok;
     return GPA_OK;
   }
+  p->sh_built_reorder = reorder;
   // (the cache key is committed only when the tables are complete: a failed allocation below must not leave a key
   //  that sends the next call to the kernel with freed tables -- ADVICE r03)
   p->sh_built_epoch = -1;
   p->sh_built_ok = false;
-  // runs of candidates on one x-plane, in list order; chunks of <= NC candidates per matrix pass
+  // Visiting order of every peak's candidates.  The selection rule is "strictly larger |sf| replaces, in LIST order"
+  // (geometric_phase_analysis.py:679-684) = the first maximum of the list wins.  The kernel stores a winner the moment
+  // it wins, so the order in which it visits the candidates sets how often a pixel is rewritten: in list order the
+  // amplitude climbs towards the grid's centre (4.3 stores per pixel at configs[2]); visiting the candidates nearest
+  // the reference vector first, most later candidates win nowhere in a wavefront and their stores are skipped.  The
+  // candidates of one x-plane stay together (they share the forward transform; a list that interleaves the planes gains
+  // its runs here), planes ordered by their nearest candidate, candidates within a plane by distance, ties by list
+  // position (a stable order: duplicates of a k-vector keep the list's order, so "first maximum" still holds for
+  // them; the reported kidx is the original list position).  Two DIFFERENT candidates whose amplitudes agree bit for
+  // bit at a pixel may now resolve the other way -- the amplitude ties the tests already allow for.
+  std::vector<int> order((size_t)B);
+  for (int pp = 0; pp < P; ++pp) {
+    std::vector<double> d2((size_t)K), pmin;
+    std::vector<int> pfirst;
+    int nplanes = 0;
+    for (int k = 0; k < K; ++k) nplanes = std::max(nplanes, p->staged_planeof[pp * K + k] + 1);
+    pmin.assign((size_t)nplanes, 1e300);
+    pfirst.assign((size_t)nplanes, K);
+    for (int k = 0; k < K; ++k) {
+      const size_t b = (size_t)pp * K + k;
+      const double ex = p->staged_kl[2 * b] - p->staged_kr[2 * b], ey = p->staged_kl[2 * b + 1] - p->staged_kr[2 * b + 1];
+      d2[k] = ex * ex + ey * ey;
+      const int pl = p->staged_planeof[b];
+      pmin[pl] = std::min(pmin[pl], d2[k]);
+      pfirst[pl] = std::min(pfirst[pl], k);
+    }
+    std::vector<int> idx((size_t)K);
+    for (int k = 0; k < K; ++k) idx[k] = k;
+    if (reorder)
+      std::stable_sort(idx.begin(), idx.end(), [&](int a, int b2) {
+        const int pa = p->staged_planeof[pp * K + a], pb = p->staged_planeof[pp * K + b2];
+        if (pa != pb) return pmin[pa] != pmin[pb] ? pmin[pa] < pmin[pb] : pfirst[pa] < pfirst[pb];
+        return d2[a] < d2[b2];
+      });
+    for (int k = 0; k < K; ++k) order[(size_t)pp * K + k] = pp * K + idx[k];
+  }
+  // runs of candidates on one x-plane, in visiting order; chunks of <= NC candidates per matrix pass
   const int NC = p->dtype == 0 ? 4 : 2;
   std::vector<int> desc((size_t)B, 0);
   int runs = 0;
@@ -673,7 +712,7 @@ static int shared_prepare(gpa_plan* p, int P, int K) {
     int k = 0, chunk = 0;
     while (k < K) {
       int e = k + 1;
-      while (e < K && p->staged_planeof[pp * K + e] == p->staged_planeof[pp * K + k]) ++e;
+      while (e < K && p->staged_planeof[order[pp * K + e]] == p->staged_planeof[order[pp * K + k]]) ++e;
       ++runs;
       for (int j = k; j < e; ++j) {
         const int r = j - k, slot = r % NC;
@@ -716,12 +755,12 @@ static int shared_prepare(gpa_plan* p, int P, int K) {
     shifts[pp] = blocks >= EEs ? 0 : sft;
     need = std::max(need, std::min(blocks, EEs));
     for (int k = 0; k < K; ++k)
-      wys[(size_t)pp * K + k] = p->staged_kl[2 * ((size_t)pp * K + k) + 1] + (double)shifts[pp] / EEs;
+      wys[(size_t)pp * K + k] = p->staged_kl[2 * (size_t)order[(size_t)pp * K + k] + 1] + (double)shifts[pp] / EEs;
   }
   p->sh_nbl = opt_set(OPT_PBS_FULLBAND) ? EEs : passB_shared_nbl(p->dtype, need);
   if (p->sh_nbl >= EEs) {   // nothing to gain: no rotation
     for (int pp = 0; pp < P; ++pp) shifts[pp] = 0;
-    for (int bq = 0; bq < B; ++bq) wys[bq] = p->staged_kl[2 * (size_t)bq + 1];
+    for (int bq = 0; bq < B; ++bq) wys[bq] = p->staged_kl[2 * (size_t)order[bq] + 1];
     p->sh_nbl = EEs;
   }
   const size_t gb = (size_t)B * p->ax1s.L * p->rsz, ps = (size_t)B * p->sh_Epad * p->csz;
@@ -744,9 +783,11 @@ static int shared_prepare(gpa_plan* p, int P, int K) {
   if (!p->sh.dyc) TRY(dmalloc(p, &p->sh.dyc, (size_t)p->max_peaks * p->n1 * p->csz));
   if (!p->sh.desc) TRY(dmalloc(p, (void**)&p->sh.desc, (size_t)p->max_batch * sizeof(int)));
   HIP_TRY(hipMemcpyAsync(p->sh.desc, desc.data(), (size_t)B * sizeof(int), hipMemcpyHostToDevice, p->stream));
+  if (!p->sh.order) TRY(dmalloc(p, (void**)&p->sh.order, (size_t)p->max_batch * sizeof(int)));
+  HIP_TRY(hipMemcpyAsync(p->sh.order, order.data(), (size_t)B * sizeof(int), hipMemcpyHostToDevice, p->stream));
   HIP_TRY(launch_shared_tables(p->dtype, p->ax1s, p->d_wys, p->d_kr, p->d_shifts, p->d_taps, p->sh_etab, p->sh_E, p->sh_Epad, B, K,
                                p->sh_nbl, p->sh, p->stream, p->sh_elems));
-  HIP_TRY(hipStreamSynchronize(p->stream));   // `desc` is a local
+  HIP_TRY(hipStreamSynchronize(p->stream));   // `desc`, `order` are locals
   p->sh_built_epoch = p->sh_epoch;
   p->sh_built_K = K;
   p->sh_built_B = B;
@@ -926,7 +967,7 @@ void gpa_plan_destroy(gpa_plan* p) {
   void* bufs[] = {p->tw0, p->tw1, p->Hx, p->Hy, p->Tbuf, p->tb.cxb, p->tb.sx, p->tb.wxw, p->tb.wxr, p->tb.cyb, p->tb.sy, p->tb.wyw, p->tb.wyr, p->tb.planeof, p->d_pw,
                   p->tb.dx, p->tb.dy, p->d_kl, p->d_kr, p->d_image, p->d_mean, p->d_tile_mean, p->d_scratch,
                   p->d_lockin, p->d_kidx, p->d_dudx, p->d_dudy, p->d_wnorm, p->d_u, p->d_kmat, p->d_sf, p->d_grad, p->d_aux0, p->d_aux1,
-                  p->sh.Gb, p->sh.psi, p->sh.dyc, p->sh.gtab, p->sh.desc, p->d_taps, p->tw1s,
+                  p->sh.Gb, p->sh.psi, p->sh.dyc, p->sh.gtab, p->sh.desc, p->sh.order, p->d_taps, p->tw1s,
                   p->tw0s, p->d_taps0, p->shA_gtab, p->shA_Gx, p->shA_psi, p->shA_sx, p->sh.pre, p->sh.rot16, p->d_wys, p->d_shifts};
   for (void* b : bufs)
     if (b) hipFree(b);
@@ -1091,6 +1132,39 @@ static int passB_select(gpa_plan* p, int P, int K, void* lockin, int32_t* kidx) 
   return GPA_OK;
 }
 
+// per-kernel event pairs of a profiled call, summed by name in order of first appearance -> p->kprof_table
+static void collect_kernel_profile(gpa_plan* p) {
+  std::vector<std::string> names;
+  std::vector<int> calls;
+  std::vector<double> total;
+  for (int i = 0; p->kprof && i < p->kprof->n; ++i) {
+    const KernelProfiler::Rec& r = p->kprof->rec[i];
+    float ms = 0.f;
+    if (hipEventElapsedTime(&ms, r.a, r.b) != hipSuccess) continue;
+    size_t j = 0;
+    while (j < names.size() && names[j] != r.name) ++j;
+    if (j == names.size()) { names.push_back(r.name); calls.push_back(0); total.push_back(0.0); }
+    ++calls[j];
+    total[j] += ms;
+  }
+  p->kprof_table.clear();
+  char line[160];
+  for (size_t j = 0; j < names.size(); ++j) {
+    snprintf(line, sizeof(line), "%s %d %.6f\n", names[j].c_str(), calls[j], total[j]);
+    p->kprof_table += line;
+  }
+}
+// installs the plan's profiler on the calling thread for the lifetime of the object (while gpa_set_profiling is on)
+struct ProfInstall {
+  explicit ProfInstall(gpa_plan* p) {
+    if (!p->profiling) return;
+    if (!p->kprof) p->kprof = new KernelProfiler();
+    p->kprof->n = 0;
+    g_kprof = p->kprof;
+  }
+  ~ProfInstall() { g_kprof = nullptr; }
+};
+
 // ---- a3 ----------------------------------------------------------------------
 static int sweep_peaks_dev(gpa_plan* p, const void* image, const void* mean, const double* krefs, int P,
                            const double* klists, int K, double sigma, void* lockin, int32_t* kidx) {
@@ -1161,6 +1235,7 @@ static int sweep_host(gpa_plan* p, const void* image, const double* kref, const 
   if (!p || !image || !kref || !klist || !lockin) return fail(GPA_ERR_ARG, "gpa_sweep: null argument");
   if (K < 1) return fail(GPA_ERR_ARG, "gpa_sweep: K must be >= 1");
   HIP_TRY(hipSetDevice(p->device));
+  ProfInstall prof(p);   // (gpa_set_profiling: which kernels this sweep ran, through gpa_last_kernel_profile)
   const size_t npx = (size_t)p->n0 * p->n1;
   HIP_TRY(hipMemcpyAsync(p->d_image, image, npx * p->rsz, hipMemcpyHostToDevice, p->stream));
   if (grad && !p->d_grad) TRY(dmalloc(p, &p->d_grad, 2 * npx * p->rsz));
@@ -1177,6 +1252,7 @@ static int sweep_host(gpa_plan* p, const void* image, const double* kref, const 
   HIP_TRY(hipMemcpyAsync(lockin, p->d_lockin, npx * p->csz, hipMemcpyDeviceToHost, p->stream));
   if (kidx) HIP_TRY(hipMemcpyAsync(kidx, p->d_kidx, npx * sizeof(int32_t), hipMemcpyDeviceToHost, p->stream));
   HIP_TRY(hipStreamSynchronize(p->stream));
+  if (p->profiling) collect_kernel_profile(p);
   return GPA_OK;
 }
 
@@ -1261,39 +1337,6 @@ int gpa_weighted_lstsq(gpa_plan* p, const void* b, const void* weights, const do
   HIP_TRY(hipStreamSynchronize(p->stream));
   return GPA_OK;
 }
-
-// per-kernel event pairs of a profiled call, summed by name in order of first appearance -> p->kprof_table
-static void collect_kernel_profile(gpa_plan* p) {
-  std::vector<std::string> names;
-  std::vector<int> calls;
-  std::vector<double> total;
-  for (int i = 0; p->kprof && i < p->kprof->n; ++i) {
-    const KernelProfiler::Rec& r = p->kprof->rec[i];
-    float ms = 0.f;
-    if (hipEventElapsedTime(&ms, r.a, r.b) != hipSuccess) continue;
-    size_t j = 0;
-    while (j < names.size() && names[j] != r.name) ++j;
-    if (j == names.size()) { names.push_back(r.name); calls.push_back(0); total.push_back(0.0); }
-    ++calls[j];
-    total[j] += ms;
-  }
-  p->kprof_table.clear();
-  char line[160];
-  for (size_t j = 0; j < names.size(); ++j) {
-    snprintf(line, sizeof(line), "%s %d %.6f\n", names[j].c_str(), calls[j], total[j]);
-    p->kprof_table += line;
-  }
-}
-// installs the plan's profiler on the calling thread for the lifetime of the object (while gpa_set_profiling is on)
-struct ProfInstall {
-  explicit ProfInstall(gpa_plan* p) {
-    if (!p->profiling) return;
-    if (!p->kprof) p->kprof = new KernelProfiler();
-    p->kprof->n = 0;
-    g_kprof = p->kprof;
-  }
-  ~ProfInstall() { g_kprof = nullptr; }
-};
 
 // ---- a7 ----------------------------------------------------------------------
 int gpa_unwrap_prediff_dev(gpa_plan* p, const void* dx, const void* dy, const void* weight, int kmax,

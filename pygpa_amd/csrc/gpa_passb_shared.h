@@ -19,6 +19,9 @@ struct PassBSharedTables {
   void* gtab;   // [2 Epad + 16] T   Hankel taps: gtab[s] = g(s) for 1 <= s <= E, 0 elsewhere
   void* pre;    // [B][Epad] cpx  exp(2 pi i wy'_b j): pre-factor of the end strips (wy' = wy + band rotation)
   void* rot16;  // [P][16] cpx    exp(-2 pi i s_p r / 16): the band rotation of peak p at column r mod 16
+  int* order;   // [B] the kernel visits the candidates of a peak in the order order[pt K + 0 .. K-1] (absolute indices into the
+                //   staged list: x-plane, compensation phasor and the reported kidx are those of the ORIGINAL position);
+                //   every other table here is laid out in visiting order
   int* desc;    // [B] per candidate: bit 0 = first of a run of candidates on one x-plane (read the row, forward
                 //   transform), bit 1 = first of a chunk of <= NC candidates (matrix pass), bits 2-3 = slot in the
                 //   chunk, bits 4-6 = candidates in the chunk, bit 7 = parity of the chunk

@@ -23,9 +23,12 @@
 // On a zero-padded (non-power-of-two) row the same formulas hold with (phi_b - 0): g_b (*) T then contains no
 // wrapped pair at all and the transform length only has to be >= n + E.
 //
-// Selection ("strictly larger |sf| replaces", in list order) keeps only |best|^2 in registers: a winner is stored
-// to `out` the moment it wins and the row is revisited once at the end for the compensation phasor, which frees the
-// registers that the shared spectrum needs.
+// Selection ("strictly larger |sf| replaces", in list order = the first maximum of the list wins) keeps only |best|^2
+// in registers: a winner is stored to `out` the moment it wins and the row is revisited once at the end for the
+// compensation phasor, which frees the registers that the shared spectrum needs.  The candidates of a peak are
+// VISITED nearest-to-the-reference-vector first (host: shared_prepare, PassBSharedTables::order; kidx reports list
+// positions): the maximum does not depend on the order, later candidates then seldom win, and a register none of whose
+// 64 lanes wins issues no store.
 #include <stdlib.h>
 
 #include "gpa_internal.h"
@@ -59,6 +62,9 @@ template <class T> struct upair { T u, v; };
 #endif
 #ifndef GPA_PBS_NOSTORE
 #define GPA_PBS_NOSTORE 0   // diagnosis only: skip the winner stores
+#endif
+#ifndef GPA_PBS_WAVESKIP
+#define GPA_PBS_WAVESKIP 1   // a register with no winning lane in the wavefront issues no store
 #endif
 #ifndef GPA_PBS_NTLOAD
 #define GPA_PBS_NTLOAD 1    // the x-plane row (read once) as a non-temporal load, so that it does not evict the winners' rows from L2 (-2.5 %, L2 hit rate 0.69 -> 0.80)
@@ -187,7 +193,7 @@ __global__ __launch_bounds__((PassBSGeom<T, LG, EE>::THREADS),
                              (EE == 8 ? (sizeof(T) == 8 ? GPA_PBS_E8_F64_WAVES : GPA_PBS_E8_WAVES)
                                       : (sizeof(T) == 8 ? GPA_PBS_F64_WAVES : (LG >= 13 ? GPA_PBS_L13_WAVES : (PADDED ? GPA_PBS_PAD_WAVES : GPA_PBS_F32_WAVES))))) void passB_shared_kernel(
     const cpx<T>* __restrict__ Tin, int n0, int n1, const T* __restrict__ Gb, const cpx<T>* __restrict__ twtab,
-    const int* __restrict__ planeof, const int* __restrict__ desc, const cpx<T>* __restrict__ pre_g,
+    const int* __restrict__ planeof, const int* __restrict__ order, const int* __restrict__ desc, const cpx<T>* __restrict__ pre_g,
     const cpx<T>* __restrict__ psi, const T* __restrict__ gtab, const cpx<T>* __restrict__ dx,
     const cpx<T>* __restrict__ dyc, const cpx<T>* __restrict__ rot16, int K, int E, int Epad, cpx<T>* out,
     int32_t* kidx, int P, int Bx) {
@@ -244,12 +250,13 @@ __global__ __launch_bounds__((PassBSGeom<T, LG, EE>::THREADS),
   const cpx<T> rot_tail = rot16[pt * EE + ((n1 - 1 - (tid < E ? tid : 0)) & (EE - 1))];
   constexpr bool PREFETCH = NBL < EE;
   for (int k = 0; k < K; ++k) {
-    const int b = pt * K + k;
+    const int b = pt * K + k;      // position in visiting order: the candidate tables of this file
+    const int ob = order[b];       // its position in the staged list: x-plane, compensation along x, reported index
     const int d = desc[b];
     if (d & 1) {
       // ---- a new x-plane: read its row once, take the end strips, forward transform -------------------------
-      const cpx<T>* src = Tin + (((size_t)img * Bx + planeof[b]) * n0 + rr) * n1;
-      const cpx<T> cs0 = dx[(size_t)b * n0 + rr];   // exp(-2 pi i (wx - kx) x): the same for every candidate of the plane
+      const cpx<T>* src = Tin + (((size_t)img * Bx + planeof[ob]) * n0 + rr) * n1;
+      const cpx<T> cs0 = dx[(size_t)ob * n0 + rr];   // exp(-2 pi i (wx - kx) x): the same for every candidate of the plane
       const cpx<T> cs = cmul(cs0, rot);              // ... times the band rotation at this thread's columns
       cpx<T> tail = {T(0), T(0)};
       if (tid < E) tail = src[n1 - 1 - tid];
@@ -421,13 +428,19 @@ __global__ __launch_bounds__((PassBSGeom<T, LG, EE>::THREADS),
     if constexpr (PREFETCH) {
       if (k + 1 < K) load_gb<T, TPF, NBL>(h, Gb + (size_t)(b + 1) * (NBL * TPF), tid);
     }
-    // ---- strict '>' in list order; the winner goes to memory at once ----------------------------------------
+    // ---- strict '>' in visiting order; the winner goes to memory at once ------------------------------------
+    // (a register none of whose 64 lanes wins issues no store at all: with the likeliest winners visited first that is
+    //  most registers of most candidates -- GPA_PBS_WAVESKIP=0 restores the sixteen dropped-offset stores per candidate)
+    const int kout = ob - pt * K;
 #pragma unroll
     for (int i = 0; i < EE; ++i) {
       const int yy = tid + TPF * i;
       const T a = y[i].x * y[i].x + y[i].y * y[i].y;
       const bool win = a > ab[i];
       ab[i] = win ? a : ab[i];
+#if GPA_PBS_WAVESKIP
+      if (__builtin_amdgcn_ballot_w64(win) == 0) continue;
+#endif
       // (byte offset; OOB = 0x80000000 stays out of range after the arithmetic shift below, never multiply it)
       // (zero-padded rows: the whole column offset goes into the range-checked voffset, so that the slots beyond
       //  the row are dropped by the descriptor's num_records; soffset is not range checked)
@@ -435,11 +448,11 @@ __global__ __launch_bounds__((PassBSGeom<T, LG, EE>::THREADS),
       constexpr int SOFF = PADDED ? 0 : 1;
 #if GPA_PBS_EXECSTORE
       if (woff != OOB) store_cpx(y[i], orow, woff, SOFF * i * TPF * (int)sizeof(cpx<T>));
-      if (kidx && woff != OOB) __builtin_amdgcn_raw_buffer_store_b32(k, krow, woff >> (sizeof(cpx<T>) == 8 ? 1 : 2), SOFF * i * TPF * 4, 0);
+      if (kidx && woff != OOB) __builtin_amdgcn_raw_buffer_store_b32(kout, krow, woff >> (sizeof(cpx<T>) == 8 ? 1 : 2), SOFF * i * TPF * 4, 0);
 #elif !GPA_PBS_NOSTORE
       store_cpx(y[i], orow, woff, SOFF * i * TPF * (int)sizeof(cpx<T>));
       constexpr int SH = sizeof(cpx<T>) == 8 ? 1 : 2;   // complex byte offset -> int32 byte offset
-      if (kidx) __builtin_amdgcn_raw_buffer_store_b32(k, krow, woff >> SH, SOFF * i * TPF * 4, 0);
+      if (kidx) __builtin_amdgcn_raw_buffer_store_b32(kout, krow, woff >> SH, SOFF * i * TPF * 4, 0);
 #endif
     }
   }
@@ -965,7 +978,7 @@ static hipError_t run_passB_shared(const Axis& a1, int n0, const void* Tbuf, con
   }
   dim3 grid((n0 + G::NF - 1) / G::NF, P * nimg);
   GPA_PROF("passB_shared_kernel", s);
-  kern<<<grid, G::THREADS, lds, s>>>((const cpx<T>*)Tbuf, n0, a1.n, (const T*)st.Gb, (const cpx<T>*)tw1, tb.planeof, st.desc,
+  kern<<<grid, G::THREADS, lds, s>>>((const cpx<T>*)Tbuf, n0, a1.n, (const T*)st.Gb, (const cpx<T>*)tw1, tb.planeof, st.order, st.desc,
                                      (const cpx<T>*)st.pre, (const cpx<T>*)st.psi, (const T*)st.gtab, (const cpx<T>*)tb.dx,
                                      (const cpx<T>*)st.dyc, (const cpx<T>*)st.rot16, K, E, Epad, (cpx<T>*)out, kidx, P, Bx);
   return hipGetLastError();

@@ -86,8 +86,8 @@ def test_shared_passb_wide_and_narrow_kernels(dtype):
 
 @pytest.mark.parametrize('dtype', DTYPES)
 def test_shared_passb_list_orders(dtype):
-    """lists that are not wx-outer grids: a wy-outer list (runs of one candidate per x-plane: nothing to share, the
-    per-candidate kernel runs) and a list with a repeated x-plane run; the first maximum in LIST order wins"""
+    """lists that are not wx-outer grids: a wy-outer list (regrouped by x-plane in the kernel's visiting order since round 4;
+    in list order its runs are one candidate long) and a list with a repeated x-plane run; the first maximum in LIST order wins"""
     shape = (64, 2048)
     img0, kref, klist, sigma = _case(shape, 4, 4, seed=9)
     wy_outer = klist.reshape(4, 4, 2).transpose(1, 0, 2).reshape(-1, 2).copy()
@@ -102,6 +102,49 @@ def test_shared_passb_list_orders(dtype):
             check_kidx(kidx, ref['kidx'], img0, kl, sigma, TOL[dtype]['tie'])
         same = kidx == ref['kidx']
         assert rel(lock[same], ref['lockin'][same]) < TOL[dtype]['lock']
+
+
+@pytest.mark.parametrize('dtype', DTYPES)
+def test_shared_passb_visiting_order(dtype, gpa_option):
+    """the kernel VISITS a peak's candidates nearest-to-the-reference first, planes kept together (fewer rewrites of the
+    winner rows); the maximum does not depend on the order and kidx reports list positions: identical to the run in
+    list order (NO_REORDER=1) and to the oracle, for a plain grid, a wy-outer list (regrouped by x-plane: the shared
+    kernel now runs where list order had runs of one candidate), split runs and a list with duplicated k-vectors (exact
+    amplitude ties: the earlier list position must keep winning)"""
+    shape = (64, 2048)
+    img0, kref, klist, sigma = _case(shape, 4, 4, seed=9)
+    wy_outer = klist.reshape(4, 4, 2).transpose(1, 0, 2).reshape(-1, 2).copy()
+    split_runs = np.concatenate([klist[:2], klist[8:12], klist[2:4], klist[4:8], klist[12:]])
+    dup = np.concatenate([klist, klist[5:7], klist[0:1]])
+    rng = np.random.default_rng(4)
+    shuffled = klist[rng.permutation(len(klist))]
+
+    def run(kl):
+        plan = _lib.Plan(shape, len(kl), dtype)
+        plan.set_profiling(True)
+        lock, kidx, _ = plan.sweep(img0, kref, kl, sigma)
+        prof = plan.last_kernel_profile()
+        plan.close()
+        return lock, kidx, prof
+
+    for name, kl in (('grid', klist), ('wy_outer', wy_outer), ('split_runs', split_runs), ('dup', dup), ('shuffled', shuffled)):
+        ref = orc.sweep(img0, sigma, kl, kref, workers=8)
+        lock, kidx, prof = run(kl)
+        assert 'passB_shared_kernel' in prof, (name, sorted(prof))
+        gpa_option('NO_REORDER', '1')
+        lock_l, kidx_l, prof_l = run(kl)
+        gpa_option('NO_REORDER', None)
+        if name in ('wy_outer', 'shuffled'):
+            assert 'passB_shared_kernel' not in prof_l, (name, sorted(prof_l))     # list order: nothing to share
+        if dtype is np.float64:
+            assert np.array_equal(kidx, ref['kidx']), name
+            assert np.array_equal(kidx, kidx_l), name
+        else:
+            check_kidx(kidx, ref['kidx'], img0, kl, sigma, TOL[dtype]['tie'])
+        same = kidx == ref['kidx']
+        assert rel(lock[same], ref['lockin'][same]) < TOL[dtype]['lock'], name
+        both = kidx == kidx_l
+        assert both.mean() > 0.9999 and rel(lock[both], lock_l[both]) < 2 * TOL[dtype]['lock'], name
 
 
 @pytest.mark.parametrize('dtype', DTYPES)
