@@ -33,7 +33,7 @@ static const char* const kOptNames[OPT_COUNT] = {
     "PBS_FULLBAND", "USE_GRAPH", "SERIAL_UNWRAP", "NO_WORKER", "NO_KSPLIT", "NO_COMPACT", "NO_SHARED", "SHARED_A",
     "NO_PAIR", "PBS_E8", "TRI_SMALL", "TRI_Q", "NO_MR", "MR_FORCE_BLUESTEIN", "NO_ROWPQ", "COLSOLVE", "NO_LAT",
     "F32_EPS_FLOOR", "COLSTREAM_CHUNK", "NO_ROWHALF", "PAIR_MAXSIDE", "ROWHALF_MINLG", "NO_PQDCT", "NATIVE",
-    "NATIVE_RATIO", "NATIVE_SHARED", "NO_REORDER"};
+    "NATIVE_RATIO", "NATIVE_SHARED", "NO_REORDER", "NO_RAW"};
 static OptVal g_opts[OPT_COUNT];
 static std::once_flag g_opts_once;
 static void opt_assign(OptVal& o, const char* value) {
@@ -228,6 +228,7 @@ struct EnqueueWorker {
 struct GraphKey {
   const void* image; void* u; void* lk; int32_t* kidx;
   int P, K, Bx, mask_border, kmax, epoch;
+  int want_lockins, pad_;   // (compensated lock-ins asked for: the captured pass B / set-up launches differ)
 };
 struct GraphEntry {
   GraphKey key;
@@ -268,6 +269,8 @@ struct gpa_plan {
   bool use_shared = true;         // GPA_NO_SHARED=1 keeps the per-candidate forward transforms
   int sh_epoch = 0, sh_built_epoch = -1, sh_built_K = 0, sh_built_B = 0;   // tables follow sigma and the staged k-list
   bool sh_built_reorder = true;   // ... and the NO_REORDER option they were built under
+  double* d_ystep = nullptr;      // [max_peaks] 2 pi frac(ky_p + band rotation_p): phase step along y of the compensation phasor
+  bool lk_raw = false;            // the last passB_select left the lock-ins raw (fused driver): the consumer applies d_ystep
   bool sh_built_ok = false;       // the tables of that key are complete and worth using
   bool sh_use = false;            // ... and the staged candidates form runs of >= 2 on an x-plane
   size_t sh_gb_bytes = 0, sh_psi_bytes = 0;
@@ -780,6 +783,18 @@ static int shared_prepare(gpa_plan* p, int P, int K) {
   if (!p->d_shifts) TRY(dmalloc(p, (void**)&p->d_shifts, (size_t)p->max_peaks * sizeof(int)));
   HIP_TRY(hipMemcpyAsync(p->d_wys, wys.data(), (size_t)B * sizeof(double), hipMemcpyHostToDevice, p->stream));
   HIP_TRY(hipMemcpyAsync(p->d_shifts, shifts.data(), (size_t)P * sizeof(int), hipMemcpyHostToDevice, p->stream));
+  {
+    // raw mode of the kernel: what the winners lack is dyc[p][y] = exp(2 pi i (ky_p + shift_p / EE) y), i.e. this
+    // phase step per column (reduced to (-pi, pi] in double)
+    std::vector<double> ys((size_t)P);
+    for (int pp = 0; pp < P; ++pp) {
+      const double c = p->staged_kr[2 * ((size_t)pp * K) + 1] + (double)shifts[pp] / EEs;
+      ys[pp] = 2.0 * M_PI * (c - rint(c));
+    }
+    if (!p->d_ystep) TRY(dmalloc(p, (void**)&p->d_ystep, (size_t)p->max_peaks * sizeof(double)));
+    HIP_TRY(hipMemcpyAsync(p->d_ystep, ys.data(), (size_t)P * sizeof(double), hipMemcpyHostToDevice, p->stream));
+    HIP_TRY(hipStreamSynchronize(p->stream));   // `ys` is a local
+  }
   if (!p->sh.dyc) TRY(dmalloc(p, &p->sh.dyc, (size_t)p->max_peaks * p->n1 * p->csz));
   if (!p->sh.desc) TRY(dmalloc(p, (void**)&p->sh.desc, (size_t)p->max_batch * sizeof(int)));
   HIP_TRY(hipMemcpyAsync(p->sh.desc, desc.data(), (size_t)B * sizeof(int), hipMemcpyHostToDevice, p->stream));
@@ -968,7 +983,7 @@ void gpa_plan_destroy(gpa_plan* p) {
                   p->tb.dx, p->tb.dy, p->d_kl, p->d_kr, p->d_image, p->d_mean, p->d_tile_mean, p->d_scratch,
                   p->d_lockin, p->d_kidx, p->d_dudx, p->d_dudy, p->d_wnorm, p->d_u, p->d_kmat, p->d_sf, p->d_grad, p->d_aux0, p->d_aux1,
                   p->sh.Gb, p->sh.psi, p->sh.dyc, p->sh.gtab, p->sh.desc, p->sh.order, p->d_taps, p->tw1s,
-                  p->tw0s, p->d_taps0, p->shA_gtab, p->shA_Gx, p->shA_psi, p->shA_sx, p->sh.pre, p->sh.rot16, p->d_wys, p->d_shifts};
+                  p->tw0s, p->d_taps0, p->shA_gtab, p->shA_Gx, p->shA_psi, p->shA_sx, p->sh.pre, p->sh.rot16, p->d_wys, p->d_shifts, p->d_ystep};
   for (void* b : bufs)
     if (b) hipFree(b);
   unwrap_workspace_destroy(&p->uw);
@@ -1104,7 +1119,10 @@ static int run_passA(gpa_plan* p, const void* image, const void* mean, void* Tbu
 // pass B with selection.  A small image has few rows to spread over the 256 CUs and runs its K candidates one after
 // the other in each workgroup (512^2, K = 16: 82 us, a quarter of the image's time): there the candidates are split over
 // up to 4 workgroups per row and merged (launch_passB_split) -- same winners, same values.
-static int passB_select(gpa_plan* p, int P, int K, void* lockin, int32_t* kidx) {
+// raw: the caller's consumer is reconstruct_setup (which takes the compensation's phase step): where the shared kernel
+// runs it then skips its second visit of the winner rows; p->lk_raw says whether it did
+static int passB_select(gpa_plan* p, int P, int K, void* lockin, int32_t* kidx, bool raw = false) {
+  p->lk_raw = false;
   const int rows_wg = (p->n0 + 7) / 8 * P;           // workgroups of the unsplit launch (at least: NF <= 8 rows each)
   int ksplit = 1;
   // (only while the unsplit launch has fewer workgroups than the chip has CUs: at 1024^2, 384 workgroups, the split
@@ -1116,10 +1134,12 @@ static int passB_select(gpa_plan* p, int P, int K, void* lockin, int32_t* kidx) 
     // (a row in native mode: the per-candidate kernel at length n rather than the shared-forward kernel on the
     //  zero-padded power of two, unless NATIVE_SHARED asks for the latter)
     if (p->sh_use && p->ax1.native && !opt_set(OPT_NATIVE_SHARED)) p->sh_use = false;
-    if (p->sh_use)
+    if (p->sh_use) {
+      p->lk_raw = raw && !opt_set(OPT_NO_RAW);
       HIP_TRY(launch_passB_shared(p->dtype, p->ax1s, p->n0, p->Tbuf, p->ax1s.L == p->ax1.L ? p->tw1 : p->tw1s, p->tb,
-                                  p->sh, p->sh_E, p->sh_Epad, P, K, lockin, kidx, p->stream, 1, 0, p->sh_elems, p->sh_nbl));
-    else
+                                  p->sh, p->sh_E, p->sh_Epad, P, K, lockin, kidx, p->stream, 1, 0, p->sh_elems, p->sh_nbl,
+                                  p->lk_raw));
+    } else
       HIP_TRY(launch_passB(p->dtype, p->ax1, p->n0, p->Tbuf, p->Hy, p->tw1, p->tb, P, K, true, lockin, kidx, p->stream));
     return GPA_OK;
   }
@@ -1454,14 +1474,15 @@ static int extract_stage(gpa_plan* p, const double* kvecs, int P, const double* 
 
 // every launch of the driver, nothing else: this is what a hipGraph of the call holds
 static int extract_launch(gpa_plan* p, const void* image, int P, int K, int Bx, int mask_border, int kmax, void* u,
-                          void* lk, int32_t* kidx) {
+                          void* lk, int32_t* kidx, bool want_lockins) {
   const size_t npx = (size_t)p->n0 * p->n1;
   if (p->profiling) HIP_TRY(hipEventRecord(p->stage_ev[0], p->stream));
   HIP_TRY(launch_mean(p->dtype, image, npx, p->d_scratch, p->d_mean, p->stream));
   if (p->profiling) HIP_TRY(hipEventRecord(p->stage_ev[1], p->stream));
   TRY(run_passA(p, image, p->d_mean, p->Tbuf, Bx));
   if (p->profiling) HIP_TRY(hipEventRecord(p->stage_ev[2], p->stream));
-  TRY(passB_select(p, P, K, lk, kidx));
+  TRY(passB_select(p, P, K, lk, kidx, !want_lockins));
+  const double* ystep = p->lk_raw ? p->d_ystep : nullptr;
   if (p->profiling) HIP_TRY(hipEventRecord(p->stage_ev[3], p->stream));
   // phases / weights / per-pixel least squares fused with the unwrap's set-up: the gradient fields never
   // go to HBM, the kernel leaves r0 of both components in the two unwrap workspaces
@@ -1470,7 +1491,7 @@ static int extract_launch(gpa_plan* p, const void* image, int P, int K, int Bx, 
     HIP_TRY(launch_reconstruct_setup(p->dtype, lk, p->d_kmat, P, p->n0, p->n1, mask_border, p->d_wnorm,
                                      unwrap_residual_buffer(&p->uwp, 0), unwrap_residual_buffer(&p->uwp, 1),
                                      unwrap_partials_buffer(&p->uwp, 0), unwrap_partials_buffer(&p->uwp, 1), &nparts,
-                                     p->stream));
+                                     p->stream, 1, 0, 0, ystep));
     hipError_t ep = unwrap_enqueue_prepared(&p->uwp, p->d_wnorm, nparts, kmax, 1e-9, true, u, p->stream);
     if (ep == hipSuccess) ep = unwrap_fetch_iters(&p->uwp, p->h_iters, p->stream);
     if (ep != hipSuccess) return fail(GPA_ERR_HIP, std::string("unwrap: ") + hipGetErrorString(ep));
@@ -1482,7 +1503,8 @@ static int extract_launch(gpa_plan* p, const void* image, int P, int K, int Bx, 
   p->iters_off = 0;
   HIP_TRY(launch_reconstruct_setup(p->dtype, lk, p->d_kmat, P, p->n0, p->n1, mask_border, p->d_wnorm,
                                    unwrap_residual_buffer(&p->uw), unwrap_residual_buffer(&p->uw2),
-                                   unwrap_partials_buffer(&p->uw), unwrap_partials_buffer(&p->uw2), &nparts, p->stream));
+                                   unwrap_partials_buffer(&p->uw), unwrap_partials_buffer(&p->uw2), &nparts, p->stream, 1, 0,
+                                   0, ystep));
   if (p->profiling) HIP_TRY(hipEventRecord(p->stage_ev[4], p->stream));
   HIP_TRY(hipEventRecord(p->ev_fork, p->stream));
   HIP_TRY(hipStreamWaitEvent(p->stream2, p->ev_fork, 0));
@@ -1545,8 +1567,8 @@ static int extract_enqueue(gpa_plan* p, const void* image, const double* kvecs, 
   void* lk = lockins ? lockins : p->d_lockin;
   // per-kernel event pairs while profiling (installed for this thread until the function returns)
   ProfInstall prof(p);
-  if (p->profiling || !p->use_graphs) return extract_launch(p, image, P, K, Bx, mask_border, kmax, u, lk, kidx);
-  const GraphKey key = {image, u, lk, kidx, P, K, Bx, mask_border, kmax, p->tbuf_epoch};
+  if (p->profiling || !p->use_graphs) return extract_launch(p, image, P, K, Bx, mask_border, kmax, u, lk, kidx, lockins != nullptr);
+  const GraphKey key = {image, u, lk, kidx, P, K, Bx, mask_border, kmax, p->tbuf_epoch, lockins != nullptr ? 1 : 0, 0};
   GraphEntry* ent = nullptr;
   for (auto& g : p->graphs)
     if (memcmp(&g.key, &key, sizeof(GraphKey)) == 0) ent = &g;
@@ -1560,17 +1582,17 @@ static int extract_enqueue(gpa_plan* p, const void* image, const double* kvecs, 
     GraphEntry g{};
     g.key = key;
     p->graphs.push_back(g);
-    return extract_launch(p, image, P, K, Bx, mask_border, kmax, u, lk, kidx);
+    return extract_launch(p, image, P, K, Bx, mask_border, kmax, u, lk, kidx, lockins != nullptr);
   }
-  if (ent->failed) return extract_launch(p, image, P, K, Bx, mask_border, kmax, u, lk, kidx);
+  if (ent->failed) return extract_launch(p, image, P, K, Bx, mask_border, kmax, u, lk, kidx, lockins != nullptr);
   // second call: capture
   hipError_t ce = hipStreamBeginCapture(p->stream, hipStreamCaptureModeRelaxed);
   if (ce != hipSuccess) {
     (void)hipGetLastError();
     ent->failed = true;
-    return extract_launch(p, image, P, K, Bx, mask_border, kmax, u, lk, kidx);
+    return extract_launch(p, image, P, K, Bx, mask_border, kmax, u, lk, kidx, lockins != nullptr);
   }
-  const int rc = extract_launch(p, image, P, K, Bx, mask_border, kmax, u, lk, kidx);
+  const int rc = extract_launch(p, image, P, K, Bx, mask_border, kmax, u, lk, kidx, lockins != nullptr);
   hipGraph_t graph = nullptr;
   ce = hipStreamEndCapture(p->stream, &graph);
   if (rc != GPA_OK || ce != hipSuccess || !graph) {
@@ -1578,7 +1600,7 @@ static int extract_enqueue(gpa_plan* p, const void* image, const double* kvecs, 
     if (graph) hipGraphDestroy(graph);
     ent->failed = true;
     if (rc != GPA_OK) return rc;
-    return extract_launch(p, image, P, K, Bx, mask_border, kmax, u, lk, kidx);
+    return extract_launch(p, image, P, K, Bx, mask_border, kmax, u, lk, kidx, lockins != nullptr);
   }
   hipGraphExec_t exec = nullptr;
   ce = hipGraphInstantiate(&exec, graph, nullptr, nullptr, 0);
@@ -1586,7 +1608,7 @@ static int extract_enqueue(gpa_plan* p, const void* image, const double* kvecs, 
     (void)hipGetLastError();
     hipGraphDestroy(graph);
     ent->failed = true;
-    return extract_launch(p, image, P, K, Bx, mask_border, kmax, u, lk, kidx);
+    return extract_launch(p, image, P, K, Bx, mask_border, kmax, u, lk, kidx, lockins != nullptr);
   }
   ent->graph = graph;
   ent->exec = exec;
@@ -1681,9 +1703,11 @@ int gpa_extract_displacement_field_batch_dev(gpa_plan* p, const void* images, in
     const void* image = (const char*)images + (size_t)c0 * npx * p->rsz;
     HIP_TRY(launch_mean(p->dtype, image, npx, p->bScratch, p->bMean, p->stream, nimg));
     TRY(run_passA(p, image, p->bMean, p->bT, Bx, nimg));
+    const bool raw = p->sh_use && !opt_set(OPT_NO_RAW);   // (the stack's lock-ins are never handed out)
     if (p->sh_use)
       HIP_TRY(launch_passB_shared(p->dtype, p->ax1s, p->n0, p->bT, p->ax1s.L == p->ax1.L ? p->tw1 : p->tw1s, p->tb,
-                                  p->sh, p->sh_E, p->sh_Epad, P, K, p->bL, nullptr, p->stream, nimg, Bx, p->sh_elems, p->sh_nbl));
+                                  p->sh, p->sh_E, p->sh_Epad, P, K, p->bL, nullptr, p->stream, nimg, Bx, p->sh_elems, p->sh_nbl,
+                                  raw));
     else
       HIP_TRY(launch_passB(p->dtype, p->ax1, p->n0, p->bT, p->Hy, p->tw1, p->tb, P, K, true, p->bL, nullptr, p->stream, nimg,
                            Bx));
@@ -1691,7 +1715,7 @@ int gpa_extract_displacement_field_batch_dev(gpa_plan* p, const void* images, in
                                      (char*)p->d_wnorm_b + (size_t)c0 * npx * p->rsz,
                                      unwrap_residual_buffer(&p->uwb, 2 * c0), unwrap_residual_buffer(&p->uwb, 2 * c0 + 1),
                                      unwrap_partials_buffer(&p->uwb, 2 * c0), unwrap_partials_buffer(&p->uwb, 2 * c0 + 1),
-                                     &nparts, p->stream, nimg, rstride, pstride));
+                                     &nparts, p->stream, nimg, rstride, pstride, raw ? p->d_ystep : nullptr));
   }
   hipError_t e = unwrap_enqueue_prepared(&p->uwb, p->d_wnorm_b, nparts, kmax, 1e-9, true, u, p->stream);
   if (e == hipSuccess) e = unwrap_fetch_iters(&p->uwb, p->h_iters_b, p->stream);
@@ -1746,7 +1770,7 @@ int gpa_extract_displacement_field(gpa_plan* p, const void* image, const double*
   const size_t npx = (size_t)p->n0 * p->n1;
   HIP_TRY(hipMemcpyAsync(p->d_image, image, npx * p->rsz, hipMemcpyHostToDevice, p->stream));
   TRY(gpa_extract_displacement_field_dev(p, p->d_image, kvecs, P, klists, K, sigma, mask_border, kmax, p->d_u,
-                                         p->d_lockin, kidx ? p->d_kidx : nullptr, iters_out));
+                                         lockins ? p->d_lockin : nullptr, kidx ? p->d_kidx : nullptr, iters_out));
   HIP_TRY(hipMemcpyAsync(u, p->d_u, 2 * npx * p->rsz, hipMemcpyDeviceToHost, p->stream));
   if (lockins) HIP_TRY(hipMemcpyAsync(lockins, p->d_lockin, (size_t)P * npx * p->csz, hipMemcpyDeviceToHost, p->stream));
   if (kidx) HIP_TRY(hipMemcpyAsync(kidx, p->d_kidx, (size_t)P * npx * sizeof(int32_t), hipMemcpyDeviceToHost, p->stream));

@@ -72,7 +72,7 @@ enum OptKey {
   OPT_PBS_FULLBAND, OPT_USE_GRAPH, OPT_SERIAL_UNWRAP, OPT_NO_WORKER, OPT_NO_KSPLIT, OPT_NO_COMPACT, OPT_NO_SHARED,
   OPT_SHARED_A, OPT_NO_PAIR, OPT_PBS_E8, OPT_TRI_SMALL, OPT_TRI_Q, OPT_NO_MR, OPT_MR_FORCE_BLUESTEIN, OPT_NO_ROWPQ,
   OPT_COLSOLVE, OPT_NO_LAT, OPT_F32_EPS_FLOOR, OPT_COLSTREAM_CHUNK, OPT_NO_ROWHALF, OPT_PAIR_MAXSIDE, OPT_ROWHALF_MINLG, OPT_NO_PQDCT,
-  OPT_NATIVE, OPT_NATIVE_RATIO, OPT_NATIVE_SHARED, OPT_NO_REORDER, OPT_COUNT
+  OPT_NATIVE, OPT_NATIVE_RATIO, OPT_NATIVE_SHARED, OPT_NO_REORDER, OPT_NO_RAW, OPT_COUNT
 };
 struct OptVal {
   bool set;
@@ -208,7 +208,8 @@ hipError_t launch_reconstruct(int dtype, const void* lockin, const double* kmat 
 // *nparts partial sums of ||r0||^2 each
 hipError_t launch_reconstruct_setup(int dtype, const void* lockin, const double* kmat, int P, int n0, int n1,
                                     int border, void* wnorm, void* r0, void* r1, double* part0, double* part1,
-                                    int* nparts, hipStream_t s, int nimg = 1, size_t rstride = 0, size_t pstride = 0);
+                                    int* nparts, hipStream_t s, int nimg = 1, size_t rstride = 0, size_t pstride = 0,
+                                    const double* ystep = nullptr /* device [P]: the lock-ins lack exp(i ystep_p y) */);
 
 // pre_diff=True: grads (P x n0 x n1 x 2) are phase gradients along axis 1 ([..., 0]) and axis 0 ([..., 1]):
 // wrap, per-pixel weighted least squares for both, crop to the difference grids

@@ -44,7 +44,9 @@ int passB_shared_nbl(int dtype, int need);
 // a1: the shared kernel's own geometry of the y axis (periodic, or zero-padded to L >= n + E); tw1: twiddles of a1.L
 hipError_t launch_passB_shared(int dtype, const Axis& a1, int n0, const void* Tbuf, const void* tw1, const SweepTables& tb,
                                const PassBSharedTables& st, int E, int Epad, int P, int K, void* out, int32_t* kidx,
-                               hipStream_t s, int nimg = 1, int Bx = 0, int elems = 16, int nbl = 16);
+                               hipStream_t s, int nimg = 1, int Bx = 0, int elems = 16, int nbl = 16, bool raw = false);
+// raw: the winners are left WITHOUT the candidate-independent compensation exp(2 pi i (ky + s_p / 16) y) (no second visit
+// of the rows: 0.8 GB less traffic at 4096^2 x 3); the consumer adds its phase step along y (launch_reconstruct_setup)
 
 // ---- pass A with the forward transform shared by all x-planes of a column (same file) -------------------------------
 // a0: the kernel's own geometry of the x axis (periodic, or zero-padded to L >= n0 + E); tw0: twiddles of a0.L;

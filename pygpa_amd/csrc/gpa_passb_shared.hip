@@ -196,7 +196,7 @@ __global__ __launch_bounds__((PassBSGeom<T, LG, EE>::THREADS),
     const int* __restrict__ planeof, const int* __restrict__ order, const int* __restrict__ desc, const cpx<T>* __restrict__ pre_g,
     const cpx<T>* __restrict__ psi, const T* __restrict__ gtab, const cpx<T>* __restrict__ dx,
     const cpx<T>* __restrict__ dyc, const cpx<T>* __restrict__ rot16, int K, int E, int Epad, cpx<T>* out,
-    int32_t* kidx, int P, int Bx) {
+    int32_t* kidx, int P, int Bx, int raw) {
   using F = WgFFT<T, LG, EE>;
   using G = PassBSGeom<T, LG, EE>;
   using V4 = typename MfmaVec<T>::type;
@@ -457,6 +457,22 @@ __global__ __launch_bounds__((PassBSGeom<T, LG, EE>::THREADS),
     }
   }
   if (!valid) return;
+  if (raw) {
+    // ---- raw mode (the fused driver): the winners stay as stored; the consumer accounts for the missing phasor
+    // exp(2 pi i ky y) as a constant step of the phase along y (reconstruct_setup_kernel).  Only a pixel that nothing
+    // ever won (an all-zero row) still has to be written: 0, winner -1.
+#pragma unroll
+    for (int i = 0; i < EE; ++i) {
+      const int yy = tid + TPF * i;
+      const bool never = !(ab[i] > T(0)) && (!PADDED || yy < n1);
+      if (__builtin_amdgcn_ballot_w64(never) == 0) continue;
+      if (never) {
+        out[obase + yy] = cpx<T>{T(0), T(0)};
+        if (kidx) kidx[obase + yy] = -1;
+      }
+    }
+    return;
+  }
   // ---- compensation to the peak centre: exp(2 pi i ky y), the same for every candidate ---------------------------
   // The winners were stored through the buffer descriptor by this very lane; the stores must have reached L2 before
   // the row is read back (the compiler sees no alias between the descriptor and a plain pointer, and a load may
@@ -962,7 +978,7 @@ hipError_t launch_shared_tables(int dtype, const Axis& a1, const double* wys, co
 template <class T, int LG, bool PADDED, int EE, int NBL>
 static hipError_t run_passB_shared(const Axis& a1, int n0, const void* Tbuf, const void* tw1, const SweepTables& tb,
                                    const PassBSharedTables& st, int E, int Epad, int P, int K, void* out, int32_t* kidx,
-                                   hipStream_t s, int nimg, int Bx) {
+                                   hipStream_t s, int nimg, int Bx, bool raw) {
   using G = PassBSGeom<T, LG, EE>;
   const size_t lds = G::lds_bytes(Epad);
   if (lds > 160 * 1024 || E > G::TPF || Epad > G::TPF) return hipErrorInvalidValue;
@@ -980,7 +996,7 @@ static hipError_t run_passB_shared(const Axis& a1, int n0, const void* Tbuf, con
   GPA_PROF("passB_shared_kernel", s);
   kern<<<grid, G::THREADS, lds, s>>>((const cpx<T>*)Tbuf, n0, a1.n, (const T*)st.Gb, (const cpx<T>*)tw1, tb.planeof, st.order, st.desc,
                                      (const cpx<T>*)st.pre, (const cpx<T>*)st.psi, (const T*)st.gtab, (const cpx<T>*)tb.dx,
-                                     (const cpx<T>*)st.dyc, (const cpx<T>*)st.rot16, K, E, Epad, (cpx<T>*)out, kidx, P, Bx);
+                                     (const cpx<T>*)st.dyc, (const cpx<T>*)st.rot16, K, E, Epad, (cpx<T>*)out, kidx, P, Bx, raw ? 1 : 0);
   return hipGetLastError();
 }
 
@@ -1023,10 +1039,10 @@ int passB_shared_nbl(int dtype, int need) {
 
 hipError_t launch_passB_shared(int dtype, const Axis& a1, int n0, const void* Tbuf, const void* tw1, const SweepTables& tb,
                                const PassBSharedTables& st, int E, int Epad, int P, int K, void* out, int32_t* kidx,
-                               hipStream_t s, int nimg, int Bx, int elems, int nbl) {
+                               hipStream_t s, int nimg, int Bx, int elems, int nbl, bool raw) {
 #define CALL_S(T, LG, EE, NBL) \
-  (a1.padded ? run_passB_shared<T, LG, true, EE, NBL>(a1, n0, Tbuf, tw1, tb, st, E, Epad, P, K, out, kidx, s, nimg, Bx) \
-             : run_passB_shared<T, LG, false, EE, NBL>(a1, n0, Tbuf, tw1, tb, st, E, Epad, P, K, out, kidx, s, nimg, Bx))
+  (a1.padded ? run_passB_shared<T, LG, true, EE, NBL>(a1, n0, Tbuf, tw1, tb, st, E, Epad, P, K, out, kidx, s, nimg, Bx, raw) \
+             : run_passB_shared<T, LG, false, EE, NBL>(a1, n0, Tbuf, tw1, tb, st, E, Epad, P, K, out, kidx, s, nimg, Bx, raw))
 #define CASE_S(LG, EE, NBL) \
   if (a1.lg == LG && elems == EE && nbl == NBL) return dtype == 0 ? CALL_S(float, LG, EE, NBL) : CALL_S(double, LG, EE, NBL);
 #define CASE_F32(LG, EE, NBL) \

@@ -171,7 +171,7 @@ __global__ __launch_bounds__(256) void reconstruct_setup_kernel(const cpx<T>* __
                                                                int border, T* __restrict__ wnorm, T* __restrict__ r0,
                                                                T* __restrict__ r1, double* __restrict__ part0,
                                                                double* __restrict__ part1, int band, size_t rstride,
-                                                               size_t pstride) {
+                                                               size_t pstride, const double* __restrict__ ystep) {
   {
     // image stacks: blockIdx.z = image; its lock-ins / weight follow those of the image before, its two residuals and
     // partial-sum blocks lie rstride elements / pstride doubles behind the previous image's (the batched workspace)
@@ -196,6 +196,12 @@ __global__ __launch_bounds__(256) void reconstruct_setup_kernel(const cpx<T>* __
   T k0[P], k1[P];
 #pragma unroll
   for (int p = 0; p < P; ++p) { k0[p] = (T)kmat[2 * p]; k1[p] = (T)kmat[2 * p + 1]; }
+  // lock-ins handed over WITHOUT the compensation phasor exp(i ystep_p y) of geometric_phase_analysis.py:683 (the shared
+  // pass B in raw mode): a unit phasor that depends on y alone changes no amplitude and no phase difference along x, and
+  // adds the constant ystep_p to every phase difference along y before it is wrapped
+  T cy[P];
+#pragma unroll
+  for (int p = 0; p < P; ++p) cy[p] = ystep ? (T)ystep[p] : T(0);
   auto mask_fac = [&](int x, int y) {
     const bool inside = x >= border && x < n0 - border && y >= border && y < n1 - border;
     return (inside ? T(1) : T(0)) + T(1e-6);
@@ -241,7 +247,7 @@ __global__ __launch_bounds__(256) void reconstruct_setup_kernel(const cpx<T>* __
       const T phr = __shfl_down(phc[p], 1);
       w[p] = ampc[p] * mfac;
       wmax = w[p] > wmax ? w[p] : wmax;
-      bx[p] = has_r ? wrap_phase_diff(phr - phc[p]) : T(0);
+      bx[p] = has_r ? wrap_phase_diff(phr - phc[p] + cy[p]) : T(0);
       by[p] = has_d ? wrap_phase_diff(phn[p] - phc[p]) : T(0);
     }
     const T ws = wmax > T(0) ? T(1) / wmax : T(0);
@@ -303,7 +309,7 @@ __global__ __launch_bounds__(256) void reconstruct_setup_kernel(const cpx<T>* __
 template <class T>
 static hipError_t launch_reconstruct_setup_t(const void* lockin, const double* kmat, int P, int n0, int n1, int border,
                                              void* wnorm, void* r0, void* r1, double* part0, double* part1, int* nparts,
-                                             hipStream_t s, int nimg, size_t rstride, size_t pstride) {
+                                             hipStream_t s, int nimg, size_t rstride, size_t pstride, const double* ystep) {
   // rows per workgroup band: FUSED_ROWS for large images (one halo row per band is recomputed), fewer while the
   // grid would leave most of the 256 CUs idle -- a band is a serial loop of ~1.5 us per row
   int band = FUSED_ROWS;
@@ -315,7 +321,7 @@ static hipError_t launch_reconstruct_setup_t(const void* lockin, const double* k
 #define RS_CASE(PP)                                                                                                   \
   case PP:                                                                                                            \
     reconstruct_setup_kernel<T, PP><<<grid, 256, 0, s>>>((const cpx<T>*)lockin, kmat, n0, n1, border, (T*)wnorm,       \
-                                                         (T*)r0, (T*)r1, part0, part1, band, rstride, pstride);      \
+                                                         (T*)r0, (T*)r1, part0, part1, band, rstride, pstride, ystep); \
     break;
   switch (P) {
     RS_CASE(2) RS_CASE(3) RS_CASE(4) RS_CASE(5) RS_CASE(6) RS_CASE(7) RS_CASE(8)
@@ -327,12 +333,12 @@ static hipError_t launch_reconstruct_setup_t(const void* lockin, const double* k
 
 hipError_t launch_reconstruct_setup(int dtype, const void* lockin, const double* kmat, int P, int n0, int n1,
                                     int border, void* wnorm, void* r0, void* r1, double* part0, double* part1,
-                                    int* nparts, hipStream_t s, int nimg, size_t rstride, size_t pstride) {
+                                    int* nparts, hipStream_t s, int nimg, size_t rstride, size_t pstride, const double* ystep) {
   if (P > MAXP || P < 2) return hipErrorInvalidValue;
   return dtype == 0 ? launch_reconstruct_setup_t<float>(lockin, kmat, P, n0, n1, border, wnorm, r0, r1, part0, part1, nparts, s,
-                                                        nimg, rstride, pstride)
+                                                        nimg, rstride, pstride, ystep)
                     : launch_reconstruct_setup_t<double>(lockin, kmat, P, n0, n1, border, wnorm, r0, r1, part0, part1, nparts, s,
-                                                         nimg, rstride, pstride);
+                                                         nimg, rstride, pstride, ystep);
 }
 
 // per-pixel weighted least squares on given right-hand sides b (P x n0 x n1), the weighted

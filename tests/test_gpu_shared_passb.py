@@ -176,6 +176,39 @@ def test_shared_passb_zero_rows_and_driver(dtype):
 
 
 @pytest.mark.parametrize('dtype', DTYPES)
+@pytest.mark.parametrize('shape', [(1100, 2048), (1600, 3000)])
+def test_raw_winners_in_the_fused_driver(shape, dtype, gpa_option):
+    """the fused driver leaves the winners WITHOUT the compensation phasor exp(2 pi i ky y) of
+    geometric_phase_analysis.py:683 when nobody asked for the lock-ins (no second visit of the winner rows) and the
+    set-up kernel adds the phasor's phase step to the differences along y: same u, same iteration counts and winner
+    indices as the run that compensates (NO_RAW=1), the oracle's u, and the lock-ins handed out on request are the
+    compensated ones; periodic and zero-padded rows, three peaks with different band rotations"""
+    kvecs = hex_kvecs(0.1, 7.0)
+    img = hex_moire(shape, kvecs, gaussian_bump_displacement(shape), noise=0.2, seed=6)
+    kw, sigma, _ = orc.derive_params(kvecs)
+    klists = explicit_klists(kvecs, kw, 4, 4)
+    u_ref, parts = orc.extract_displacement_field(img, kvecs, klists=klists, return_parts=True, workers=8)
+    plan = _lib.Plan(shape, 48, dtype)
+    plan.set_profiling(True)
+    u, _, kidx, it = plan.extract_displacement_field(img, kvecs, np.stack(klists), sigma, 2 * sigma, kmax=10, want_kidx=True)
+    assert 'passB_shared_kernel' in plan.last_kernel_profile()
+    gpa_option('NO_RAW', '1')
+    u_c, _, kidx_c, it_c = plan.extract_displacement_field(img, kvecs, np.stack(klists), sigma, 2 * sigma, kmax=10, want_kidx=True)
+    gpa_option('NO_RAW', None)
+    u_l, lock, kidx_l, it_l = plan.extract_displacement_field(img, kvecs, np.stack(klists), sigma, 2 * sigma, kmax=10,
+                                                              want_lockins=True, want_kidx=True)
+    plan.close()
+    assert np.array_equal(kidx, kidx_c) and np.array_equal(kidx, kidx_l)
+    assert list(it) == list(it_c) == list(it_l)
+    tol = 1e-9 if dtype is np.float64 else 2e-4
+    assert rel(u, u_c) < tol and rel(u_l, u_c) < tol
+    assert rel(u, u_ref) < (1e-8 if dtype is np.float64 else 5e-4)
+    for p in range(3):
+        same = kidx_l[p] == parts['gs'][p]['kidx']
+        assert same.mean() > 0.999 and rel(lock[p][same], parts['gs'][p]['lockin'][same]) < TOL[dtype]['lock']
+
+
+@pytest.mark.parametrize('dtype', DTYPES)
 @pytest.mark.parametrize('shape', [(2048, 96), (4096, 64), (3000, 80), (1500, 72)])
 def test_shared_pass_a_opt_in(shape, dtype, monkeypatch, gpa_option):
     """the shared-forward pass A (GPA_SHARED_A=1: one forward transform per column for all x-planes, end fix of the
