@@ -1187,7 +1187,7 @@ struct ProfInstall {
 
 // ---- a3 ----------------------------------------------------------------------
 static int sweep_peaks_dev(gpa_plan* p, const void* image, const void* mean, const double* krefs, int P,
-                           const double* klists, int K, double sigma, void* lockin, int32_t* kidx) {
+                           const double* klists, int K, double sigma, void* lockin, int32_t* kidx, bool raw = false) {
   const int B = P * K;
   if (B > p->max_batch) return fail(GPA_ERR_STATE, "sweep: P*K exceeds the plan's max_batch");
   TRY(ensure_filters(p, sigma));
@@ -1203,7 +1203,7 @@ static int sweep_peaks_dev(gpa_plan* p, const void* image, const void* mean, con
   if (p->profiling) HIP_TRY(hipEventRecord(p->stage_ev[1], p->stream));
   TRY(run_passA(p, image, mean, p->Tbuf, Bx));
   if (p->profiling) HIP_TRY(hipEventRecord(p->stage_ev[2], p->stream));
-  TRY(passB_select(p, P, K, lockin, kidx));
+  TRY(passB_select(p, P, K, lockin, kidx, raw));
   if (p->profiling) HIP_TRY(hipEventRecord(p->stage_ev[3], p->stream));
   return GPA_OK;
 }
@@ -1789,10 +1789,10 @@ int gpa_extract_gradients(gpa_plan* p, const void* image, const double* kvecs, i
   HIP_TRY(hipMemcpyAsync(p->d_image, image, npx * p->rsz, hipMemcpyHostToDevice, p->stream));
   // no mean subtraction here: a tile must be offset by the mean of the WHOLE image
   // (geometric_phase_analysis.py:919), which only the caller knows
-  TRY(sweep_peaks_dev(p, p->d_image, nullptr, kvecs, P, klists, K, sigma, p->d_lockin, nullptr));
+  TRY(sweep_peaks_dev(p, p->d_image, nullptr, kvecs, P, klists, K, sigma, p->d_lockin, nullptr, true));
   TRY(stage_kmat(p, kvecs, P));
   HIP_TRY(launch_reconstruct(p->dtype, p->d_lockin, p->d_kmat, P, p->n0, p->n1, mask_border, p->d_dudx, p->d_dudy,
-                             p->d_wnorm, p->stream));
+                             p->d_wnorm, p->stream, p->lk_raw ? p->d_ystep : nullptr));
   HIP_TRY(hipMemcpyAsync(dudx, p->d_dudx, (size_t)2 * p->n0 * (p->n1 - 1) * p->rsz, hipMemcpyDeviceToHost, p->stream));
   HIP_TRY(hipMemcpyAsync(dudy, p->d_dudy, (size_t)2 * (p->n0 - 1) * p->n1 * p->rsz, hipMemcpyDeviceToHost, p->stream));
   HIP_TRY(hipMemcpyAsync(wnorm, p->d_wnorm, npx * p->rsz, hipMemcpyDeviceToHost, p->stream));
@@ -1851,10 +1851,10 @@ static int tile_gradients_impl(gpa_plan* p, const void* image, size_t image_pitc
     HIP_TRY(hipStreamSynchronize(st));
     p->tile_mean = mean;
   }
-  TRY(sweep_peaks_dev(p, win, p->d_tile_mean, kvecs, P, klists, K, sigma, p->d_lockin, nullptr));
+  TRY(sweep_peaks_dev(p, win, p->d_tile_mean, kvecs, P, klists, K, sigma, p->d_lockin, nullptr, true));
   TRY(stage_kmat(p, kvecs, P));
   HIP_TRY(launch_reconstruct(p->dtype, p->d_lockin, p->d_kmat, P, n0, n1, mask_border, p->d_dudx, p->d_dudy,
-                             p->d_wnorm, st));
+                             p->d_wnorm, st, p->lk_raw ? p->d_ystep : nullptr));
   // interiors -> destination in ONE launch; the difference fields are one column / row short of the window
   const int wx = std::min(t1, n1 - 1 - j0), hy = std::min(t0, n0 - 1 - i0);
   const void* src[6];

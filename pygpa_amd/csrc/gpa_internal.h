@@ -202,7 +202,7 @@ int spec_index_rt(int lg, int tid, int reg, int elems = 16);   // elems: element
 // ---- reconstruct (gpa_reconstruct.hip) -------------------------------------
 hipError_t launch_reconstruct(int dtype, const void* lockin, const double* kmat /*dev P*2, 2 pi k*/,
                               int P, int n0, int n1, int border, void* dudx, void* dudy,
-                              void* wnorm, hipStream_t s);
+                              void* wnorm, hipStream_t s, const double* ystep = nullptr /* as in launch_reconstruct_setup */);
 
 // fused a5 + a6 + unwrap setup for both components (fused driver): wnorm, r0 of u_x / u_y and
 // *nparts partial sums of ||r0||^2 each

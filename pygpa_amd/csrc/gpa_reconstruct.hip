@@ -68,7 +68,7 @@ template <class T, int P>
 __global__ __launch_bounds__(256) void reconstruct_kernel(const cpx<T>* __restrict__ lockin,
                                                          const double* __restrict__ kmat, int n0, int n1,
                                                          int border, T* __restrict__ dudx, T* __restrict__ dudy,
-                                                         T* __restrict__ wnorm) {
+                                                         T* __restrict__ wnorm, const double* __restrict__ ystep) {
   const int y = blockIdx.x * 256 + threadIdx.x;
   const int x0 = blockIdx.y * REC_ROWS;
   const int x1 = x0 + REC_ROWS < n0 ? x0 + REC_ROWS : n0;
@@ -77,9 +77,9 @@ __global__ __launch_bounds__(256) void reconstruct_kernel(const cpx<T>* __restri
   const int yc = act ? y : n1 - 1;
   const size_t npx = (size_t)n0 * n1;
   const bool has_r = act && yc + 1 < n1;
-  T k0[P], k1[P];
+  T k0[P], k1[P], cy[P];   // cy: phase step along y of a compensation phasor the lock-ins lack (see reconstruct_setup_kernel)
 #pragma unroll
-  for (int p = 0; p < P; ++p) { k0[p] = (T)kmat[2 * p]; k1[p] = (T)kmat[2 * p + 1]; }
+  for (int p = 0; p < P; ++p) { k0[p] = (T)kmat[2 * p]; k1[p] = (T)kmat[2 * p + 1]; cy[p] = ystep ? (T)ystep[p] : T(0); }
   T phc[P], ampc[P], phn[P], ampn[P];
 #pragma unroll
   for (int p = 0; p < P; ++p) {
@@ -114,7 +114,7 @@ __global__ __launch_bounds__(256) void reconstruct_kernel(const cpx<T>* __restri
       w[p] = ampc[p] * mfac;
       wsq += w[p] * w[p];
       wmax = w[p] > wmax ? w[p] : wmax;
-      bx[p] = has_r ? wrap_phase_diff(phr - phc[p]) : T(0);
+      bx[p] = has_r ? wrap_phase_diff(phr - phc[p] + cy[p]) : T(0);
       by[p] = has_d ? wrap_phase_diff(phn[p] - phc[p]) : T(0);
     }
     if (act) {
@@ -595,12 +595,12 @@ hipError_t launch_huber_moments(int dtype, const void* img, int n0, int n1, cons
 
 template <class T>
 static hipError_t launch_reconstruct_t(const void* lockin, const double* kmat, int P, int n0, int n1, int border,
-                                       void* dudx, void* dudy, void* wnorm, hipStream_t s) {
+                                       void* dudx, void* dudy, void* wnorm, hipStream_t s, const double* ystep) {
   dim3 grid((n1 + 255) / 256, (n0 + REC_ROWS - 1) / REC_ROWS);
 #define REC_CASE(PP)                                                                                          \
   case PP:                                                                                                    \
     reconstruct_kernel<T, PP><<<grid, 256, 0, s>>>((const cpx<T>*)lockin, kmat, n0, n1, border, (T*)dudx, (T*)dudy, \
-                                                   (T*)wnorm);                                                \
+                                                   (T*)wnorm, ystep);                                         \
     break;
   switch (P) {
     REC_CASE(2) REC_CASE(3) REC_CASE(4) REC_CASE(5) REC_CASE(6) REC_CASE(7) REC_CASE(8)
@@ -611,10 +611,10 @@ static hipError_t launch_reconstruct_t(const void* lockin, const double* kmat, i
 }
 
 hipError_t launch_reconstruct(int dtype, const void* lockin, const double* kmat, int P, int n0, int n1,
-                              int border, void* dudx, void* dudy, void* wnorm, hipStream_t s) {
+                              int border, void* dudx, void* dudy, void* wnorm, hipStream_t s, const double* ystep) {
   if (P > MAXP || P < 2) return hipErrorInvalidValue;
-  return dtype == 0 ? launch_reconstruct_t<float>(lockin, kmat, P, n0, n1, border, dudx, dudy, wnorm, s)
-                    : launch_reconstruct_t<double>(lockin, kmat, P, n0, n1, border, dudx, dudy, wnorm, s);
+  return dtype == 0 ? launch_reconstruct_t<float>(lockin, kmat, P, n0, n1, border, dudx, dudy, wnorm, s, ystep)
+                    : launch_reconstruct_t<double>(lockin, kmat, P, n0, n1, border, dudx, dudy, wnorm, s, ystep);
 }
 
 }  // namespace gpa

@@ -209,6 +209,26 @@ def test_raw_winners_in_the_fused_driver(shape, dtype, gpa_option):
 
 
 @pytest.mark.parametrize('dtype', DTYPES)
+def test_raw_winners_in_the_gradient_stage(dtype, gpa_option):
+    """the unfused gradient stage (gpa_extract_gradients, the tile pipeline's stage) takes raw winners the same way:
+    gradient fields and weights equal to the compensating run's"""
+    shape = (300, 2048)
+    kvecs = hex_kvecs(0.1, 7.0)
+    img = hex_moire(shape, kvecs, gaussian_bump_displacement(shape), noise=0.2, seed=8, dtype=dtype)
+    kw, sigma, _ = orc.derive_params(kvecs)
+    klists = np.stack(explicit_klists(kvecs, kw, 4, 4))
+    plan = _lib.Plan(shape, 48, dtype)
+    g = plan.extract_gradients(img, kvecs, klists, sigma, 2 * sigma)
+    gpa_option('NO_RAW', '1')
+    g_c = plan.extract_gradients(img, kvecs, klists, sigma, 2 * sigma)
+    plan.close()
+    tol = 1e-10 if dtype is np.float64 else 1e-4
+    for a, b in zip(g, g_c):
+        # (a phase difference that lies on the +-pi seam to rounding may wrap the other way: isolated pixels at most)
+        assert (np.abs(a - b) < tol * max(1.0, np.abs(b).max())).mean() > 0.9999
+
+
+@pytest.mark.parametrize('dtype', DTYPES)
 @pytest.mark.parametrize('shape', [(2048, 96), (4096, 64), (3000, 80), (1500, 72)])
 def test_shared_pass_a_opt_in(shape, dtype, monkeypatch, gpa_option):
     """the shared-forward pass A (GPA_SHARED_A=1: one forward transform per column for all x-planes, end fix of the
