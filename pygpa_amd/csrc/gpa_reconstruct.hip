@@ -34,6 +34,27 @@ __device__ __forceinline__ T wrap_phase_diff(T x) {
   return r - Consts<T>::pi;
 }
 
+// wrap(d + step) for a phase difference d of two atan2 results and a CONSTANT step = hi + lo (raw winners, see
+// reconstruct_setup_kernel), without the systematic rounding that wrap_phase_diff(d + hi) has: d is a multiple of the
+// phases' own spacing (2.4e-7 for |phase| >= 2), so `d + hi + pi` would round the off-grid constant the same way at every
+// pixel -- a bias of up to 1e-7 rad per column, i.e. a ramp across the image.  Here d is wrapped by comparisons (the
+// subtractions are exact), the step is added where the sum is small (d ~ -step: exact or rounded at its own fine
+// spacing), wrapped again the same way (only differences near +-pi get there) and the low part goes on last.
+template <class T>
+__device__ __forceinline__ T wrap_diff_plus_step(T d, T hi, T lo) {
+  const T pi = Consts<T>::pi, two_pi = Consts<T>::two_pi;
+  d = d >= pi ? d - two_pi : (d < -pi ? d + two_pi : d);
+  T x = d + hi;
+  x = x >= pi ? x - two_pi : (x < -pi ? x + two_pi : x);
+  return x + lo;
+}
+
+// circumference of a full turn as this file's phases measure it (atan2 with the precision's own pi constants, wraps by
+// Consts<T>::two_pi) over the true 2 pi: 1 + 2.78e-8 in f32, 1 in f64
+template <class T> __device__ __forceinline__ double unwrap_turn_scale() {
+  return (double)Consts<T>::two_pi / 6.28318530717958647692;
+}
+
 // general argument, fast path for the usual |x| < 2 pi (same arithmetic as wrap_to_pi there)
 template <class T>
 __device__ __forceinline__ T wrap_to_pi_fast(T x) {
@@ -77,9 +98,15 @@ __global__ __launch_bounds__(256) void reconstruct_kernel(const cpx<T>* __restri
   const int yc = act ? y : n1 - 1;
   const size_t npx = (size_t)n0 * n1;
   const bool has_r = act && yc + 1 < n1;
-  T k0[P], k1[P], cy[P];   // cy: phase step along y of a compensation phasor the lock-ins lack (see reconstruct_setup_kernel)
+  T k0[P], k1[P], cy[P], cyl[P];   // cy + cyl: phase step along y of a compensation phasor the lock-ins lack (see reconstruct_setup_kernel)
 #pragma unroll
-  for (int p = 0; p < P; ++p) { k0[p] = (T)kmat[2 * p]; k1[p] = (T)kmat[2 * p + 1]; cy[p] = ystep ? (T)ystep[p] : T(0); }
+  for (int p = 0; p < P; ++p) {
+    k0[p] = (T)kmat[2 * p];
+    k1[p] = (T)kmat[2 * p + 1];
+    const double c = ystep ? ystep[p] * unwrap_turn_scale<T>() : 0.0;
+    cy[p] = (T)c;
+    cyl[p] = (T)(c - (double)cy[p]);
+  }
   T phc[P], ampc[P], phn[P], ampn[P];
 #pragma unroll
   for (int p = 0; p < P; ++p) {
@@ -114,7 +141,7 @@ __global__ __launch_bounds__(256) void reconstruct_kernel(const cpx<T>* __restri
       w[p] = ampc[p] * mfac;
       wsq += w[p] * w[p];
       wmax = w[p] > wmax ? w[p] : wmax;
-      bx[p] = has_r ? wrap_phase_diff(phr - phc[p] + cy[p]) : T(0);
+      bx[p] = has_r ? (ystep ? wrap_diff_plus_step(phr - phc[p], cy[p], cyl[p]) : wrap_phase_diff(phr - phc[p])) : T(0);
       by[p] = has_d ? wrap_phase_diff(phn[p] - phc[p]) : T(0);
     }
     if (act) {
@@ -199,9 +226,20 @@ __global__ __launch_bounds__(256) void reconstruct_setup_kernel(const cpx<T>* __
   // lock-ins handed over WITHOUT the compensation phasor exp(i ystep_p y) of geometric_phase_analysis.py:683 (the shared
   // pass B in raw mode): a unit phasor that depends on y alone changes no amplitude and no phase difference along x, and
   // adds the constant ystep_p to every phase difference along y before it is wrapped
-  T cy[P];
+  // Three details keep this free of SYSTEMATIC f32 error (a constant bias of 1e-8 rad per column is a ramp of 1e-5 .. 1e-4 px
+  // across an image after the unwrap; measured on a 512 x 2048 image, mean error of du/dy: 2e-10 px per column compensated,
+  // 7e-8 with the naive wrap(d + step), 2e-8 .. 4.5e-8 without the first point, 1e-10 with all three -- tools/raw_bias_probe.py):
+  //  * the raw phase turns once every 1 / (ky + s/16) columns, and a full turn of phases that atan2f and the wraps measure
+  //    closes at the f32 value of 2 pi, 1.75e-7 above 2 pi: the step is scaled by that ratio (unwrap_turn_scale);
+  //  * the step is held as hi + lo of the data's precision: one rounded f32 would bias every difference of a peak alike;
+  //  * the constant is added AFTER the difference has been wrapped exactly (wrap_diff_plus_step).
+  T cy[P], cyl[P];
 #pragma unroll
-  for (int p = 0; p < P; ++p) cy[p] = ystep ? (T)ystep[p] : T(0);
+  for (int p = 0; p < P; ++p) {
+    const double c = ystep ? ystep[p] * unwrap_turn_scale<T>() : 0.0;
+    cy[p] = (T)c;
+    cyl[p] = (T)(c - (double)cy[p]);
+  }
   auto mask_fac = [&](int x, int y) {
     const bool inside = x >= border && x < n0 - border && y >= border && y < n1 - border;
     return (inside ? T(1) : T(0)) + T(1e-6);
@@ -247,7 +285,7 @@ __global__ __launch_bounds__(256) void reconstruct_setup_kernel(const cpx<T>* __
       const T phr = __shfl_down(phc[p], 1);
       w[p] = ampc[p] * mfac;
       wmax = w[p] > wmax ? w[p] : wmax;
-      bx[p] = has_r ? wrap_phase_diff(phr - phc[p] + cy[p]) : T(0);
+      bx[p] = has_r ? (ystep ? wrap_diff_plus_step(phr - phc[p], cy[p], cyl[p]) : wrap_phase_diff(phr - phc[p])) : T(0);
       by[p] = has_d ? wrap_phase_diff(phn[p] - phc[p]) : T(0);
     }
     const T ws = wmax > T(0) ? T(1) / wmax : T(0);
