@@ -116,7 +116,7 @@ static hipError_t run_pcg(Impl* w, const void* a, const void* b, const void* wei
       } else {
         // (the last iteration's q is only needed for its <p, q>: the plain stencil)
         npq = pq_partials(w);
-        if ((e = launch_pq(w, pout, weight, it, part_pq, s)) != hipSuccess) return e;
+        if ((e = launch_pq(w, pout, weight, it, part_pq, s, it + 1 < kmax)) != hipSuccess) return e;
       }
     }
     // the flush that ends the solve takes the last step length from the stencil kernel's partial sums and files the

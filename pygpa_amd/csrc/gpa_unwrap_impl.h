@@ -119,7 +119,8 @@ hipError_t dispatch_g_colsolve(const Impl* w, int compat, hipStream_t s);
 hipError_t launch_unwrap_setup(const Impl* w, const void* a, const void* b, const void* weight, bool from_psi, void* phi,
                                hipStream_t s);
 hipError_t launch_scal_init(const Impl* w, int nparts, hipStream_t s);
-hipError_t launch_pq(const Impl* w, const void* p, const void* weight, int it, double* part_pq, hipStream_t s);
+// need_q = false: only the partial sums of <p, q> are wanted (the last iteration of a solve): q is not written
+hipError_t launch_pq(const Impl* w, const void* p, const void* weight, int it, double* part_pq, hipStream_t s, bool need_q = true);
 int pq_partials(const Impl* w);   // partial sums launch_pq writes
 // ring / final_it / init as phi_flush_kernel; commits (flags[2] = flags[0]) unless final_it
 hipError_t launch_phi_flush(const Impl* w, int ring, void* phi, bool phi_unwritten, int final_it, const double* part_pq,

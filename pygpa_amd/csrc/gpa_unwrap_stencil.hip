@@ -213,7 +213,7 @@ __global__ __launch_bounds__(256) void pq_kernel(const T* __restrict__ z, const 
     if (pin) pin += pb * pimg;
     if (pout) pout += pb * pimg;
     if (w) w += (pb >> 1) * pimg;   // the two components of an image share its weight
-    q += pb * pimg;
+    if (q) q += pb * pimg;          // (q == nullptr: the last iteration of a solve needs <p, q> only)
     part += pb * PART_N;
     scal += pb * SCAL_N;
     flags += pb * FLAGS_N;
@@ -305,7 +305,7 @@ __global__ __launch_bounds__(256) void pq_kernel(const T* __restrict__ z, const 
         pq += (double)c * (double)acc;
       }
       if constexpr (!PGIVEN) *reinterpret_cast<VecN<T, V>*>(pout + o) = pc;
-      *reinterpret_cast<VecN<T, V>*>(q + o) = qv;
+      if (q) *reinterpret_cast<VecN<T, V>*>(q + o) = qv;
       pu = pc; wu = wc;
       pc = pd; wc = wd;
     }
@@ -507,7 +507,7 @@ hipError_t setup_t(const Impl* w, const void* a, const void* b, const void* weig
 }
 
 template <class T>
-hipError_t pq_t(const Impl* w, const void* p, const void* weight, int it, double* part_pq, hipStream_t s) {
+hipError_t pq_t(const Impl* w, const void* p, const void* weight, int it, double* part_pq, hipStream_t s, bool need_q) {
   const PqGrid g = pq_grid(w);
   const int n0 = w->n0, n1 = w->n1;
   const size_t npx = (size_t)n0 * n1;
@@ -517,11 +517,11 @@ hipError_t pq_t(const Impl* w, const void* p, const void* weight, int it, double
     if (g.V == 4) pq_small_kernel<T, 4, 4><<<grid, 256, 0, s>>>((const T*)p, (const T*)weight, n0, n1, (T*)w->q, part_pq, w->flags, npx);
     else pq_small_kernel<T, 1, 4><<<grid, 256, 0, s>>>((const T*)p, (const T*)weight, n0, n1, (T*)w->q, part_pq, w->flags, npx);
   } else if (g.V == 4) {
-    pq_kernel<T, true, 4><<<grid, 256, 0, s>>>((const T*)p, nullptr, nullptr, (const T*)weight, n0, n1, (T*)w->q, part_pq,
-                                               w->scal, w->flags, nullptr, 0, it, g.band, npx);
+    pq_kernel<T, true, 4><<<grid, 256, 0, s>>>((const T*)p, nullptr, nullptr, (const T*)weight, n0, n1, need_q ? (T*)w->q : nullptr,
+                                               part_pq, w->scal, w->flags, nullptr, 0, it, g.band, npx);
   } else {
-    pq_kernel<T, true, 1><<<grid, 256, 0, s>>>((const T*)p, nullptr, nullptr, (const T*)weight, n0, n1, (T*)w->q, part_pq,
-                                               w->scal, w->flags, nullptr, 0, it, g.band, npx);
+    pq_kernel<T, true, 1><<<grid, 256, 0, s>>>((const T*)p, nullptr, nullptr, (const T*)weight, n0, n1, need_q ? (T*)w->q : nullptr,
+                                               part_pq, w->scal, w->flags, nullptr, 0, it, g.band, npx);
   }
   return hipGetLastError();
 }
@@ -583,8 +583,8 @@ hipError_t launch_scal_init(const Impl* w, int nparts, hipStream_t s) {
   scal_init_kernel<<<dim3(1, 1, w->nprob), 256, 0, s>>>(w->part, nparts, w->scal, w->flags);
   return hipGetLastError();
 }
-hipError_t launch_pq(const Impl* w, const void* p, const void* weight, int it, double* part_pq, hipStream_t s) {
-  return w->dtype == 0 ? pq_t<float>(w, p, weight, it, part_pq, s) : pq_t<double>(w, p, weight, it, part_pq, s);
+hipError_t launch_pq(const Impl* w, const void* p, const void* weight, int it, double* part_pq, hipStream_t s, bool need_q) {
+  return w->dtype == 0 ? pq_t<float>(w, p, weight, it, part_pq, s, need_q) : pq_t<double>(w, p, weight, it, part_pq, s, need_q);
 }
 hipError_t launch_phi_flush(const Impl* w, int ring, void* phi, bool phi_unwritten, int final_it, const double* part_pq,
                             int npq, hipStream_t s) {
