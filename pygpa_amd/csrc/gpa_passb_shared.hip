@@ -248,7 +248,16 @@ __global__ __launch_bounds__((PassBSGeom<T, LG, EE>::THREADS),
   // column of its tail sample
   const cpx<T> rot = rot16[pt * EE + (tid & (EE - 1))];
   const cpx<T> rot_tail = rot16[pt * EE + ((n1 - 1 - (tid < E ? tid : 0)) & (EE - 1))];
-  constexpr bool PREFETCH = NBL < EE;
+  // (f64: no prefetch since the stores became rare -- visiting order + wave-level skip -- so that loads issued behind them
+  //  no longer wait for sixteen acknowledgements; the 16 registers it frees take the kernel from 68 to 12 bytes of
+  //  scratch: pass B 3.06 -> 2.89 ms.  f32 measured the same either way and keeps it.)
+#ifndef GPA_PBS_PREFETCH_F64
+#define GPA_PBS_PREFETCH_F64 0
+#endif
+#ifndef GPA_PBS_PREFETCH_F32
+#define GPA_PBS_PREFETCH_F32 1
+#endif
+  constexpr bool PREFETCH = NBL < EE && (sizeof(T) == 8 ? GPA_PBS_PREFETCH_F64 : GPA_PBS_PREFETCH_F32);
   for (int k = 0; k < K; ++k) {
     const int b = pt * K + k;      // position in visiting order: the candidate tables of this file
     const int ob = order[b];       // its position in the staged list: x-plane, compensation along x, reported index
