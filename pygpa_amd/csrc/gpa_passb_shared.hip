@@ -145,7 +145,10 @@ struct PassBSGeom {
   // in LDS once per chunk of NC candidates, so that neither the matrix pass nor the fix-up waits on global loads
   // (which queue behind the winner stores in vmcnt).  f64 has no LDS left for that at 4096 points.
   static constexpr bool STAGE = sizeof(T) == 4;
-  static constexpr bool TWL = F::P == 3;                   // pass-1 twiddles from an LDS table (three-pass transforms)
+#ifndef GPA_PBS_TWL
+#define GPA_PBS_TWL 1
+#endif
+  static constexpr bool TWL = GPA_PBS_TWL && F::P == 3;    // pass-1 twiddles from an LDS table (three-pass transforms)
   static constexpr int T1 = TWL ? F::P1_SETS * 6 : 0;      // that table (complex), one per workgroup
   // end strips: f32 keeps the four (end, re/im) forms the matrix pass multiplies directly, f64 (no LDS to spare at
   // 4096 points) the two complex strips and forms them per lane with selects
@@ -221,8 +224,15 @@ __global__ __launch_bounds__((PassBSGeom<T, LG, EE>::THREADS),
 
   // Hankel taps g(1 .. E) (zero beyond) and the pass-1 twiddles: first read after the barriers of the first transform
   for (int i = threadIdx.x; i < 2 * Epad + 16; i += G::THREADS) glds[i] = gtab[i];
-  typename std::conditional<G::TWL, typename F::TwiddlesP1Lds, typename F::Twiddles>::type tw;
-  if constexpr (G::TWL) {
+  // (pass-1 twiddles: from the LDS table where registers are short -- f64, zero-padded rows -- and in registers for
+  //  periodic f32 rows, which have had 20 registers to spare at 3 waves per SIMD since the winner stores became rare:
+  //  1.227 -> 1.203 ms; the table's LDS stays allocated either way, the geometry does not know PADDED)
+#ifndef GPA_PBS_TWREG_F32
+#define GPA_PBS_TWREG_F32 1
+#endif
+  constexpr bool TWLK = G::TWL && !(GPA_PBS_TWREG_F32 && sizeof(T) == 4 && !PADDED);
+  typename std::conditional<TWLK, typename F::TwiddlesP1Lds, typename F::Twiddles>::type tw;
+  if constexpr (TWLK) {
     F::fill_pass1_table(t1, twtab, threadIdx.x, G::THREADS);
     __syncthreads();
     F::load_twiddles(tw, twtab, tid, t1);
