@@ -144,10 +144,7 @@ struct PassBSGeom {
   // f32: the candidate phasors the end fix needs (pre-factors of the strips, post-factors of the results) are staged
   // in LDS once per chunk of NC candidates, so that neither the matrix pass nor the fix-up waits on global loads
   // (which queue behind the winner stores in vmcnt).  f64 has no LDS left for that at 4096 points.
-#ifndef GPA_PBS_STAGE
-#define GPA_PBS_STAGE 1
-#endif
-  static constexpr bool STAGE = GPA_PBS_STAGE && sizeof(T) == 4;
+  static constexpr bool STAGE = sizeof(T) == 4;
 #ifndef GPA_PBS_TWL
 #define GPA_PBS_TWL 1
 #endif
