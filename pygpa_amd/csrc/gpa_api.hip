@@ -33,7 +33,7 @@ static const char* const kOptNames[OPT_COUNT] = {
     "PBS_FULLBAND", "USE_GRAPH", "SERIAL_UNWRAP", "NO_WORKER", "NO_KSPLIT", "NO_COMPACT", "NO_SHARED", "SHARED_A",
     "NO_PAIR", "PBS_E8", "TRI_SMALL", "TRI_Q", "NO_MR", "MR_FORCE_BLUESTEIN", "NO_ROWPQ", "COLSOLVE", "NO_LAT",
     "F32_EPS_FLOOR", "COLSTREAM_CHUNK", "NO_ROWHALF", "PAIR_MAXSIDE", "ROWHALF_MINLG", "NO_PQDCT", "NATIVE",
-    "NATIVE_RATIO", "NATIVE_SHARED", "NO_REORDER", "NO_RAW"};
+    "NATIVE_RATIO", "NATIVE_SHARED", "NO_REORDER", "NO_RAW", "NO_TILEFUSE"};
 static OptVal g_opts[OPT_COUNT];
 static std::once_flag g_opts_once;
 static void opt_assign(OptVal& o, const char* value) {
@@ -1853,6 +1853,16 @@ static int tile_gradients_impl(gpa_plan* p, const void* image, size_t image_pitc
   }
   TRY(sweep_peaks_dev(p, win, p->d_tile_mean, kvecs, P, klists, K, sigma, p->d_lockin, nullptr, true));
   TRY(stage_kmat(p, kvecs, P));
+  if (!opt_set(OPT_NO_TILEFUSE)) {
+    // the least-squares kernel stores the interior pixels straight into the tile blocks (one launch, and neither the
+    // full-window fields nor the copy that cut the interiors out of them: 0.585 -> see profiles per 2048^2 window)
+    void* const dxs[2] = {dx, (char*)dx + dx_plane * rsz};
+    void* const dys[2] = {dy, (char*)dy + dy_plane * rsz};
+    void* const wns[2] = {wn, wn_plane ? (void*)((char*)wn + wn_plane * rsz) : nullptr};
+    HIP_TRY(launch_reconstruct_tile(p->dtype, p->d_lockin, p->d_kmat, P, n0, n1, mask_border, i0, j0, t0, t1, dxs, dx_pitch,
+                                    dys, dy_pitch, wns, wn_pitch, st, p->lk_raw ? p->d_ystep : nullptr));
+    return GPA_OK;
+  }
   HIP_TRY(launch_reconstruct(p->dtype, p->d_lockin, p->d_kmat, P, n0, n1, mask_border, p->d_dudx, p->d_dudy,
                              p->d_wnorm, st, p->lk_raw ? p->d_ystep : nullptr));
   // interiors -> destination in ONE launch; the difference fields are one column / row short of the window

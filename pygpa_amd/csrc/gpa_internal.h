@@ -72,7 +72,7 @@ enum OptKey {
   OPT_PBS_FULLBAND, OPT_USE_GRAPH, OPT_SERIAL_UNWRAP, OPT_NO_WORKER, OPT_NO_KSPLIT, OPT_NO_COMPACT, OPT_NO_SHARED,
   OPT_SHARED_A, OPT_NO_PAIR, OPT_PBS_E8, OPT_TRI_SMALL, OPT_TRI_Q, OPT_NO_MR, OPT_MR_FORCE_BLUESTEIN, OPT_NO_ROWPQ,
   OPT_COLSOLVE, OPT_NO_LAT, OPT_F32_EPS_FLOOR, OPT_COLSTREAM_CHUNK, OPT_NO_ROWHALF, OPT_PAIR_MAXSIDE, OPT_ROWHALF_MINLG, OPT_NO_PQDCT,
-  OPT_NATIVE, OPT_NATIVE_RATIO, OPT_NATIVE_SHARED, OPT_NO_REORDER, OPT_NO_RAW, OPT_COUNT
+  OPT_NATIVE, OPT_NATIVE_RATIO, OPT_NATIVE_SHARED, OPT_NO_REORDER, OPT_NO_RAW, OPT_NO_TILEFUSE, OPT_COUNT
 };
 struct OptVal {
   bool set;
@@ -204,6 +204,13 @@ hipError_t launch_reconstruct(int dtype, const void* lockin, const double* kmat 
                               int P, int n0, int n1, int border, void* dudx, void* dudy,
                               void* wnorm, hipStream_t s, const double* ystep = nullptr /* as in launch_reconstruct_setup */);
 
+// the same, storing only the interior rectangle (origin i0, j0, size t0 x t1) of a halo window straight into the tile
+// blocks of the pipeline: dx[c] / dy[c] = du_c/dx, du_c/dy (the difference fields are clipped to the columns / rows that
+// exist), wn[0] and, if not null, wn[1] the weight; pitches in elements (gpa_tile_gradients_*)
+hipError_t launch_reconstruct_tile(int dtype, const void* lockin, const double* kmat, int P, int n0, int n1, int border,
+                                   int i0, int j0, int t0, int t1, void* const dx[2], size_t dx_pitch, void* const dy[2],
+                                   size_t dy_pitch, void* const wn[2], size_t wn_pitch, hipStream_t s,
+                                   const double* ystep = nullptr);
 // fused a5 + a6 + unwrap setup for both components (fused driver): wnorm, r0 of u_x / u_y and
 // *nparts partial sums of ||r0||^2 each
 hipError_t launch_reconstruct_setup(int dtype, const void* lockin, const double* kmat, int P, int n0, int n1,
