@@ -260,6 +260,52 @@ def make_iterate_case(GPA, pu):
     print('iterate_64     |start+corr-true| = %.2e' % np.abs(start_ks + corr - true_ks).max())
 
 
+C1_STRIDE = 7     # config1_512.npz keeps every 7th pixel (offset 3) of the 512^2 fields + whole-array moments
+
+
+def _c1_pack(a):
+    """subsample + moments of a (..., N, M) field: the full 512^2 outputs would be 6 MB per array"""
+    a = np.asarray(a)
+    return a[..., 3::C1_STRIDE, 3::C1_STRIDE].copy(), np.array([a.sum(), (np.abs(a) ** 2).sum()])
+
+
+def make_config1_case(GPA, pu, only=None):
+    """BASELINE configs[0] at its own size: 512^2, 3 Bragg peaks, a single reference k-vector per peak.
+    (1) iterate_GPA + reconstruct_u_inv (weighted and global), gpa.py:116-154, :157-193;
+    (2) extract_displacement_field with a one-candidate sweep per peak (wfr3 with klist = [pk], :647-666, :907-932).
+    The images are regenerated by the seeded generator in the tests (their moments are stored)."""
+    from pygpa_amd.synthetic import hex_kvecs, hex_moire, gaussian_bump_displacement
+    shape = (512, 512)
+    out = {}
+    # (1) mildly mis-set reference vectors on a clean lattice
+    true_ks = hex_kvecs(0.1, 7.0)
+    start_ks = hex_kvecs(0.1008, 7.35)
+    image = hex_moire(shape, true_ks, None, noise=0.05, seed=21)
+    sigma = 10
+    prs, w, corr = GPA.iterate_GPA(image - image.mean(), start_ks, sigma, edge=5, iters=3)
+    u_w = GPA.reconstruct_u_inv(start_ks + corr, prs, weights=w)
+    u_g = GPA.reconstruct_u_inv(start_ks + corr, prs)
+    out.update(it_true_ks=true_ks, it_start_ks=start_ks, it_sigma=np.int64(sigma), it_corr=corr,
+               it_image_moments=np.array([image.sum(), (image ** 2).sum()]))
+    for name, a in (('it_prs', prs), ('it_w', w), ('it_u_weighted', u_w), ('it_u_global', u_g)):
+        out[name], out[name + '_moments'] = _c1_pack(a)
+    print('config1_512    iterate: |start+corr-true| = %.2e' % np.abs(start_ks + corr - true_ks).max())
+    # (2) K = 1 through the driver
+    kvecs = hex_kvecs(0.1, 7.0)
+    u_true = gaussian_bump_displacement(shape)
+    image = hex_moire(shape, kvecs, u_true, noise=0.1, seed=22)
+
+    def one_candidate(img, sig, kx, ky, kw=None, kstep=None):
+        return GPA.wfr3(img, sig, np.array([[kx, ky]]), np.array([kx, ky]))
+    u, gs = GPA.extract_displacement_field(image, kvecs, wfr_func=one_candidate, return_gs=True)
+    out.update(k1_kvecs=kvecs, k1_image_moments=np.array([image.sum(), (image ** 2).sum()]))
+    out['k1_u'], out['k1_u_moments'] = _c1_pack(u)
+    out['k1_lockin'], out['k1_lockin_moments'] = _c1_pack(np.stack([g['lockin'] for g in gs]))
+    err = np.abs(-u - u_true)[:, 20:-20, 20:-20].max()
+    print('config1_512    K=1 driver: max|-u-u_true| (interior) = %.3f px' % err)
+    np.savez_compressed(os.path.join(OUT, 'config1_512.npz'), **out)
+
+
 def make_unwrap_ramp(pu):
     """The reference's own phase-unwrap test input (tests/test_phase_unwrap.py:13-18)
     evaluated by the reference, at a size small enough to commit."""
@@ -439,12 +485,16 @@ def main():
     os.makedirs(OUT, exist_ok=True)
     GPA, pu = _import_reference()
     sys.path.insert(0, ROOT)
+    if len(sys.argv) > 1 and sys.argv[1] == 'config1':     # only the 512^2 case (minutes: the reference's per-pixel lstsq
+        make_config1_case(GPA, pu)                          # runs as pure Python under the numba stub)
+        return
     make_case(GPA, pu, 'hex_64', (64, 64), 0.15, 7.0, noise=0.0, seed=0, store_w=True)
     make_case(GPA, pu, 'hex_48x80', (48, 80), 0.17, 11.0, noise=0.0, seed=1)
     make_case(GPA, pu, 'hex_63x65', (63, 65), 0.15, 3.0, noise=0.05, seed=2)
     make_case(GPA, pu, 'hex_60', (60, 60), 0.16, 5.0, noise=0.02, seed=4)   # square, 2^2 3 5: mixed-radix rows, ragged recursions
     make_case(GPA, pu, 'hex_128_noise', (128, 128), 0.1, 7.0, noise=0.5, seed=3, full=False, grad=False)
     make_iterate_case(GPA, pu)
+    make_config1_case(GPA, pu)
     make_unwrap_ramp(pu)
     make_warp_case(GPA)
     make_props_case(GPA)

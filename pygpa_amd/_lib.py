@@ -533,6 +533,10 @@ class Plan:
                                             int(tile_pitch), _ptr(int(table_dev_ptr)), int(ntiles), int(t0), int(t1), nf,
                                             ptrs, pitch, rows, cols), 'gpa_stitch_tiles_dev')
 
+    def stream(self):
+        """the plan's main stream (raw hipStream_t as an int)"""
+        return int(self.lib.gpa_plan_stream(self.handle) or 0)
+
     def wait_stream(self, stream):
         """the plan's stream waits for what has been enqueued on `stream` (raw hipStream_t as an int, 0 = default)"""
         check(self.lib.gpa_plan_wait_stream(self.handle, C.c_void_p(int(stream))), 'gpa_plan_wait_stream')

@@ -253,6 +253,12 @@ class HipTileBackend:
         pl.stitch_tiles_dev(tiles.data_ptr(), slot_stride, t0 * t1, t1, table.data_ptr(), ntiles, t0, t1,
                             [(gdx.data_ptr(), n1 - 1, n0, n1 - 1), (gdy.data_ptr(), n1, n0 - 1, n1), (gw.data_ptr(), n1, n0, n1)])
 
+    def stitch_to_tiles(self, c):
+        """the tile plan's stream waits for component c's stitch (one rank: the stitch reads the tile buffer in place, and
+        the NEXT image's tile stage overwrites it -- ADVICE r04).  Called between the stitch and the solve's enqueue, so the
+        tile stage waits for the stitch only, not for the solve behind it on the same stream."""
+        self.plan_c[c].stream_wait(self.plan_w.stream())
+
     def unwrap_start(self, c, gdx, gdy, gw, out, kmax, concurrent=False):
         self._plan(c, concurrent).unwrap_prediff_enqueue_dev(gdx.data_ptr(), gdy.data_ptr(), gw.data_ptr(), out.data_ptr(), kmax=kmax)
 
@@ -567,6 +573,8 @@ class TiledPipeline:
                     gdx, gdy, gw = self._pbuf[buf]
                     self.be.stitch(c, got, 3 * plane, self.table_stream, len(self.tiles), t0, t1, gdx[c], gdy[c], gw[c],
                                    concurrent=both)
+                    if self.world == 1:
+                        self.be.stitch_to_tiles(c)      # `got` IS the tile buffer: the next tile stage must not overwrite it yet
                     self.be.unwrap_start(c, gdx[c], gdy[c], gw[c], self._pu[buf][c], self.kmax, concurrent=both)
             st['gather'] += time.perf_counter() - t
             pending = (i, buf)

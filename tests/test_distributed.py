@@ -288,6 +288,9 @@ class OracleTileBackend:
             gdy[r0:r0 + zy, c0:c0 + z1] = blk[1, :zy, :z1]
             gw[r0:r0 + z0, c0:c0 + z1] = blk[2, :z0, :z1]
 
+    def stitch_to_tiles(self, c):
+        self.stitch_waits = getattr(self, 'stitch_waits', 0) + 1
+
     def unwrap_start(self, c, gdx, gdy, gw, out, kmax, concurrent=False):
         out.copy_(self.torch.from_numpy(self.unwrap(gdx.numpy(), gdy.numpy(), gw.numpy(), kmax)))
         self.iters[c] = kmax

@@ -13,6 +13,7 @@ import numpy as np
 import pytest
 
 from conftest import kidx_mismatch_is_tie
+import tolerances as TOL
 from oracle import gpa_oracle as orc
 from pygpa_amd import _lib
 from pygpa_amd.synthetic import hex_kvecs, gaussian_bump_displacement, hex_moire, explicit_klists
@@ -155,10 +156,98 @@ def test_download_async_pipeline():
     plan.close()
 
 
+# ---- configs[0]: 512^2, 3 Bragg peaks, a single reference k-vector per peak ---------------------------------------
+C1_SL = (Ellipsis, slice(3, None, 7), slice(3, None, 7))      # oracle/make_golden.py: C1_STRIDE
+
+
+def _moments(a):
+    return np.array([a.sum(), (np.abs(a) ** 2).sum()])
+
+
+@pytest.mark.parametrize('dtype', [np.float64, np.float32])
+def test_config1_512_iterate_gpa_route(golden, dtype):
+    """configs[0] on the HIP path at its own size: iterate_GPA (K = 1 lock-in per peak, weighted unwraps with kmax_iter
+    25 / final kmax 200 on the 502^2 cropped maps, Huber plane fits) + reconstruct_u_inv (weighted per-pixel and
+    global), geometric_phase_analysis.py:116-154, :157-193 -- against the REFERENCE's outputs (subsampled fixture
+    tests/golden/config1_512.npz) and against the oracle on every pixel."""
+    import pygpa_amd.geometric_phase_analysis as GPA
+    g = golden('config1_512')
+    shape = (512, 512)
+    image = hex_moire(shape, g['it_true_ks'], None, noise=0.05, seed=21)
+    assert np.array_equal(_moments(image), g['it_image_moments'])          # the fixture's image, regenerated
+    start, sigma = g['it_start_ks'], int(g['it_sigma'])
+    prs_o, w_o, corr_o = orc.iterate_gpa(image - image.mean(), start, sigma)
+    prs, w, corr = GPA.iterate_GPA(image - image.mean(), start, sigma, dtype=dtype)
+    assert prs.shape == (3, 502, 502)
+    # the refined vectors land on the true ones (the reference gets within 3.3e-7)
+    assert np.abs(start + corr - g['it_true_ks']).max() < 1e-6
+    scale = np.abs(g['it_prs']).max()
+    if dtype is np.float64:
+        T = TOL.C1_F64
+        assert np.abs(corr - g['it_corr']).max() < T['corr'] and np.abs(corr - corr_o).max() < T['corr']
+        assert np.abs(prs[C1_SL] - g['it_prs']).max() < T['prs'] and np.abs(prs - prs_o).max() < T['prs']
+        assert np.allclose(w[C1_SL], g['it_w'], rtol=1e-9, atol=1e-12) and np.allclose(w, w_o, rtol=1e-9, atol=1e-12)
+        assert np.allclose(_moments(prs), g['it_prs_moments'], rtol=1e-9)
+    else:
+        T = TOL.C1_F32
+        assert np.abs(corr - g['it_corr']).max() < T['corr']
+        assert np.abs(prs[C1_SL] - g['it_prs']).max() < T['prs_rel'] * scale
+        assert np.abs(prs - prs_o).max() < T['prs_rel'] * scale
+        assert np.allclose(w, w_o, rtol=2e-5, atol=1e-5)
+    _record('config1_512_iterate_%s' % np.dtype(dtype).name,
+            {'corr_err': float(np.abs(corr - g['it_corr']).max()), 'prs_err': float(np.abs(prs - prs_o).max()),
+             'prs_max': float(scale), 'k_err': float(np.abs(start + corr - g['it_true_ks']).max())})
+    # reconstruct_u_inv on the reference's own phases: weighted per-pixel solve on the device, global solve on the host
+    ks = start + g['it_corr']
+    uw = GPA.reconstruct_u_inv(ks, prs_o, weights=w_o, dtype=dtype)
+    ug = GPA.reconstruct_u_inv(ks, prs_o)
+    uw_o = orc.reconstruct_u_inv(ks, prs_o, w_o)
+    tol_u = TOL.C1_F64['u'] if dtype is np.float64 else 2e-5 * max(1.0, np.abs(uw_o).max())
+    assert np.abs(uw - uw_o).max() < tol_u
+    assert np.abs(uw[C1_SL] - g['it_u_weighted']).max() < tol_u + 1e-9
+    assert np.abs(ug[C1_SL] - g['it_u_global']).max() < 1e-9
+
+
+@pytest.mark.parametrize('dtype', [np.float64, np.float32])
+def test_config1_512_single_kvector_driver(golden, dtype):
+    """configs[0] through the driver: extract_displacement_field with ONE candidate per peak (klists=[[pk]]; the
+    reference: wfr3 with klist = [pk] as wfr_func, geometric_phase_analysis.py:647-666, :907-932) at 512^2 -- the
+    K = 1 instantiation of every sweep kernel -- against the reference's u / lock-ins and the oracle's on every pixel."""
+    import pygpa_amd.geometric_phase_analysis as GPA
+    g = golden('config1_512')
+    shape = (512, 512)
+    kvecs = g['k1_kvecs']
+    u_true = gaussian_bump_displacement(shape)
+    image = hex_moire(shape, kvecs, u_true, noise=0.1, seed=22)
+    assert np.array_equal(_moments(image), g['k1_image_moments'])
+    klists = [pk[None] for pk in kvecs]
+    u_o, parts = orc.extract_displacement_field(image, kvecs, klists=klists, return_parts=True)
+    u, gs = GPA.extract_displacement_field(image, kvecs, klists=klists, return_gs=True, dtype=dtype)
+    lock = np.stack([q['lockin'] for q in gs])
+    lock_o = np.stack([q['lockin'] for q in parts['gs']])
+    for pi, q in enumerate(gs):
+        assert np.array_equal(q['kidx'], np.zeros(shape, np.int32))       # index work: the only candidate wins everywhere
+        assert np.array_equal(q['w'][0], np.full(shape, kvecs[pi][0])) and np.array_equal(q['w'][1], np.full(shape, kvecs[pi][1]))
+    err = _px_errors(u, u_o, 20)
+    lrel = float(np.abs(lock - lock_o).max() / np.abs(lock_o).max())
+    _record('config1_512_k1_%s' % np.dtype(dtype).name, dict(err, lockin_rel=lrel, u_max_px=float(np.abs(u_o).max())))
+    if dtype is np.float64:
+        assert err['max_px'] < TOL.C1_F64['u'] and lrel < 1e-11
+        assert np.abs(u[C1_SL] - g['k1_u']).max() < TOL.C1_F64['u']
+        assert np.abs(lock[C1_SL] - g['k1_lockin']).max() < 1e-11 * np.abs(lock_o).max()
+    else:
+        assert err['max_px'] < TOL.C1_F32['u_px'] and lrel < TOL.C1_F32['lockin_rel']
+        d = u[C1_SL] - g['k1_u']
+        assert np.abs(d - d.mean(axis=(1, 2), keepdims=True)).max() < TOL.C1_F32['u_px']
+    # the reference test's own bar for this kind of field (tests/test_geometric_phase_analysis.py:61-66)
+    assert np.all(np.abs(-u - u_true)[:, 20:-20, 20:-20] < 0.9)
+
+
 # ---- configs[1] and configs[2]: measured fp32 accuracy ------------------------------------------------------
 def test_config2_2048_accuracy():
-    """configs[1]: 2048^2, 3 x 8, fp32: device f64 and f32 against the oracle; achieved errors are recorded,
-    the asserted bounds are <= 2x what was measured on MI355X (round 2)"""
+    """configs[1]: 2048^2, 3 x 8, fp32: device f64 and f32 against the oracle.  `f32` is the library default = the
+    reference's stopping test alone (10 + 10 iterations: the mode bench.py's `value` times); `f32_floor` the opt-in
+    F32_EPS_FLOOR=4e-6.  Bounds: tests/tolerances.py (<= 2 x what was measured on MI355X); achieved errors recorded."""
     n = 2048
     kvecs = hex_kvecs(0.1, 7.0)
     img = hex_moire((n, n), kvecs, gaussian_bump_displacement((n, n)), noise=0.1, seed=5)
@@ -171,7 +260,7 @@ def test_config2_2048_accuracy():
     img0 = img - img.mean()
     rec = {'u_max_px': float(np.abs(u_ref).max())}
     out = {}
-    for name, dtype, floor in (('f64', np.float64, None), ('f32', np.float32, None), ('f32_forced10', np.float32, '0')):
+    for name, dtype, floor in (('f64', np.float64, None), ('f32', np.float32, None), ('f32_floor', np.float32, '4e-6')):
         _set_floor(floor)
         plan = _lib.Plan((n, n), 24, dtype)
         u, _, kidx, iters = plan.extract_displacement_field(img, kvecs, klists, sigma, 2 * sigma, want_kidx=True)
@@ -179,11 +268,19 @@ def test_config2_2048_accuracy():
         _set_floor(None)
         out[name] = u
         rec[name] = dict(_px_errors(u, u_ref, 2 * sigma), iters=list(iters))
-        rec[name]['kidx_mismatch'] = _check_kidx_ties(kidx, ref_kidx, img0, klists, sigma, 1e-12 if dtype is np.float64 else 4e-6)
+        rec[name]['kidx_mismatch'] = _check_kidx_ties(kidx, ref_kidx, img0, klists, sigma,
+                                                      TOL.F64['tie_rel'] if dtype is np.float64 else TOL.F32['tie_rel'])
+    rec['f32_forced10'] = rec['f32']          # (the key of rounds 2-4: the same run since the floor became opt-in)
     _record('config2_2048_3x8_vs_oracle', rec)
-    assert rec['f64']['kidx_mismatch'] == 0.0
-    assert rec['f64']['max_px'] < 1e-6
-    assert rec['f32']['interior_max_px'] < 0.02 and rec['f32']['max_px'] < 0.1
+    assert rec['f64']['kidx_mismatch'] == TOL.F64['kidx_frac']
+    assert rec['f64']['max_px'] < TOL.F64['max_px']
+    assert rec['f64']['iters'] == [10, 10]
+    # the headline's mode: the reference's stopping test alone
+    assert rec['f32']['iters'] == [10, 10]
+    assert rec['f32']['kidx_mismatch'] <= TOL.F32['kidx_frac']
+    assert rec['f32']['max_px'] < TOL.F32_C2['max_px'] and rec['f32']['rms_px'] < TOL.F32_C2['rms_px']
+    # the opt-in early stop stays within the general f32 statement
+    assert rec['f32_floor']['max_px'] < TOL.F32['max_px'] and rec['f32_floor']['rms_px'] < TOL.F32['rms_px']
 
 
 @pytest.mark.parametrize('shape', [(1080, 1920), (1000, 1000), (1280, 1024)])
@@ -214,16 +311,17 @@ def test_non_power_of_two_frames_vs_oracle(shape):
 
 
 def test_config3_4096_accuracy_f32_f64_oracle():
-    """configs[2]: 4096^2, 3 x 16 + weighted unwrap.  (1) device f64 against the ORACLE at full size;
-    (2) fp32 against fp64 with the default residual floor (9 + 8 iterations) and with 10 + 10 forced;
-    errors in pixels, recorded.  |u| reaches ~200 px; the reference's own bar for this field is 0.9 px."""
+    """configs[2]: 4096^2, 3 x 16 + weighted unwrap -- the headline workload.  (1) device f64 against the ORACLE at full
+    size; (2) fp32 in the headline's own mode (library default = the reference's stopping test, 10 + 10 iterations)
+    against fp64 AND against the oracle, and with the opt-in residual floor (9 + 8); errors in pixels, recorded.
+    |u| reaches ~155 px; the reference's own bar for this field is 0.9 px.  Bounds: tests/tolerances.py."""
     n = 4096
     kvecs = hex_kvecs(0.1, 7.0)
     img = hex_moire((n, n), kvecs, gaussian_bump_displacement((n, n)), noise=0.1, seed=100)
     kw, sigma, _ = orc.derive_params(kvecs)
     klists = np.stack(explicit_klists(kvecs, kw, 4, 4))
     out, rec = {}, {}
-    for name, dtype, floor in (('f64', np.float64, None), ('f32', np.float32, None), ('f32_forced10', np.float32, '0')):
+    for name, dtype, floor in (('f64', np.float64, None), ('f32', np.float32, None), ('f32_floor', np.float32, '4e-6')):
         _set_floor(floor)
         plan = _lib.Plan((n, n), 48, dtype)
         out[name] = plan.extract_displacement_field(img, kvecs, klists, sigma, 2 * sigma, want_lockins=True, want_kidx=True)
@@ -232,12 +330,13 @@ def test_config3_4096_accuracy_f32_f64_oracle():
     u64, l64, k64, it64 = out['f64']
     assert it64 == (10, 10)
     rec['u_max_px'] = float(np.abs(u64).max())
-    for name in ('f32', 'f32_forced10'):
+    for name in ('f32', 'f32_floor'):
         u32, l32, k32, it32 = out[name]
         rec[name + '_vs_f64'] = dict(_px_errors(u32, u64, 2 * sigma), iters=list(it32),
                                      kidx_mismatch=float((k32 != k64).mean()))
         same = k32 == k64
         rec[name + '_vs_f64']['lockin_rel'] = float(np.abs(l32 - l64)[same].max() / np.abs(l64).max())
+    rec['f32_forced10_vs_f64'] = rec['f32_vs_f64']      # (the key of rounds 2-4)
     del l64
     # (1) the oracle on every host core (candidates through a thread pool)
     cores = os.cpu_count() or 1
@@ -248,14 +347,21 @@ def test_config3_4096_accuracy_f32_f64_oracle():
     ref_kidx = np.stack([g['kidx'] for g in parts['gs']])
     rec['f64_vs_oracle'] = dict(_px_errors(u64, u_ref, 2 * sigma))
     img0 = img - img.mean()
-    rec['f64_vs_oracle']['kidx_mismatch'] = _check_kidx_ties(k64, ref_kidx, img0, klists, sigma, 1e-12)
-    rec['f32_vs_oracle'] = dict(_px_errors(out['f32'][0], u_ref, 2 * sigma))
-    rec['f32_vs_oracle']['kidx_mismatch'] = _check_kidx_ties(out['f32'][2], ref_kidx, img0, klists, sigma, 4e-6)
+    rec['f64_vs_oracle']['kidx_mismatch'] = _check_kidx_ties(k64, ref_kidx, img0, klists, sigma, TOL.F64['tie_rel'])
+    for name in ('f32', 'f32_floor'):
+        rec[name + '_vs_oracle'] = dict(_px_errors(out[name][0], u_ref, 2 * sigma))
+        rec[name + '_vs_oracle']['kidx_mismatch'] = _check_kidx_ties(out[name][2], ref_kidx, img0, klists, sigma, TOL.F32['tie_rel'])
     _record('config3_4096_3x16', rec)
-    assert rec['f64_vs_oracle']['kidx_mismatch'] == 0.0
-    assert rec['f64_vs_oracle']['max_px'] < 1e-5
-    assert rec['f32_vs_f64']['lockin_rel'] < 2e-5
-    assert rec['f32_vs_f64']['interior_max_px'] < 0.05 and rec['f32_vs_f64']['max_px'] < 0.2
+    assert rec['f64_vs_oracle']['kidx_mismatch'] == TOL.F64['kidx_frac']
+    assert rec['f64_vs_oracle']['max_px'] < TOL.F64['max_px']
+    # the headline's mode, against f64 and against the oracle
+    assert rec['f32_vs_f64']['iters'] == [10, 10]
+    assert rec['f32_vs_f64']['lockin_rel'] < TOL.F32['lockin_rel']
+    for key in ('f32_vs_f64', 'f32_vs_oracle'):
+        assert rec[key]['kidx_mismatch'] <= TOL.F32['kidx_frac'], key
+        assert rec[key]['max_px'] < TOL.F32_C3['max_px'] and rec[key]['rms_px'] < TOL.F32_C3['rms_px'], key
+    for key in ('f32_floor_vs_f64', 'f32_floor_vs_oracle'):
+        assert rec[key]['max_px'] < TOL.F32['max_px'] and rec[key]['rms_px'] < TOL.F32['rms_px'], key
 
 
 # ---- configs[3]: 8192^2 in halo tiles --------------------------------------------------------------------
@@ -407,6 +513,27 @@ def test_pipelined_stream_ranks_one_gpu(tmp_path, world):
         assert sorted(np.concatenate([g['seen'] for g in res]).tolist()) == [0, 1, 2, 3, 4]
         for g in res[1:]:
             assert np.array_equal(g['ref0'], res[0]['ref0'])      # step() itself: every rank holds the same field
+
+
+def test_stream_resident_sources_order_tile_stage_after_stitch():
+    """one rank, sources resident (run_stream([img] + [None] * k)): the stitch of image i reads the
+    tile buffer IN PLACE on the component plans' streams while the tile stage of image i + 1 writes it on the tile plan's
+    stream -- the tile plan now waits for the stitches (stitch_to_tiles).  A large stitch (4096^2, 9 windows) beside a
+    short tile stage (2 x 1 candidates): every image of the stream must equal step() bit for bit."""
+    from pygpa_amd import distributed as D
+    n = 4096
+    kvecs = hex_kvecs(0.1, 7.0)
+    img = hex_moire((n, n), kvecs, gaussian_bump_displacement((n, n)), noise=0.05, seed=77, dtype=np.float32)
+    klists = np.stack(explicit_klists(kvecs, 0.04, 2, 1))
+    pipe = D.TiledPipeline((n, n), kvecs, klists, 10, 30, kmax=3, dtype=np.float32, window=(2048, 2048))
+    pipe.load(img)
+    ref = pipe.step().cpu().numpy().copy()
+    got = []
+    iters = pipe.run_stream([None] * 6, on_result=lambda i, u: got.append(u.cpu().numpy().copy()))
+    pipe.close()
+    assert len(got) == 6 and all(it == (3, 3) for it in iters)
+    for i, u in enumerate(got):
+        assert np.array_equal(u, ref), i
 
 
 def test_tiled_two_ranks_one_gpu(tmp_path):

@@ -244,3 +244,30 @@ def test_variants_invert_u_and_prediff(golden):
         u = orc.reconstruct_u_inv_from_phases(g['kvecs'], g['prediff_grads'], g['prediff_weights'], weighted_unwrap=wu,
                                               pre_diff=True, kmax=10 if wu else 100)
         assert np.abs(u - g[key]).max() < 1e-9 * np.abs(g[key]).max(), key
+
+
+def test_config1_512_reference_outputs(golden):
+    """BASELINE configs[0] at its own size (512^2, 3 peaks, one reference k-vector per peak): the oracle's iterate_gpa /
+    reconstruct_u_inv / K = 1 driver against the REFERENCE's outputs (subsampled fixture config1_512.npz made by
+    oracle/make_golden.py from geometric_phase_analysis.py:116-154, :157-193, :647-666, :907-932)."""
+    from pygpa_amd.synthetic import hex_moire, gaussian_bump_displacement
+    g = golden('config1_512')
+    sl = (Ellipsis, slice(3, None, 7), slice(3, None, 7))
+    shape = (512, 512)
+    image = hex_moire(shape, g['it_true_ks'], None, noise=0.05, seed=21)
+    assert np.array_equal(np.array([image.sum(), (image ** 2).sum()]), g['it_image_moments'])
+    prs, w, corr = orc.iterate_gpa(image - image.mean(), g['it_start_ks'], int(g['it_sigma']))
+    assert np.abs(corr - g['it_corr']).max() < 1e-15
+    assert np.abs(prs[sl] - g['it_prs']).max() < 1e-11 and np.abs(w[sl] - g['it_w']).max() < 1e-12
+    assert np.allclose([prs.sum(), (prs ** 2).sum()], g['it_prs_moments'], rtol=1e-12)
+    ks = g['it_start_ks'] + corr
+    assert np.abs(orc.reconstruct_u_inv(ks, prs, w)[sl] - g['it_u_weighted']).max() < 1e-11
+    assert np.abs(orc.reconstruct_u_inv(ks, prs)[sl] - g['it_u_global']).max() < 1e-11
+    kvecs = g['k1_kvecs']
+    image = hex_moire(shape, kvecs, gaussian_bump_displacement(shape), noise=0.1, seed=22)
+    assert np.array_equal(np.array([image.sum(), (image ** 2).sum()]), g['k1_image_moments'])
+    u, parts = orc.extract_displacement_field(image, kvecs, klists=[pk[None] for pk in kvecs], return_parts=True)
+    assert np.abs(u[sl] - g['k1_u']).max() < 1e-11
+    lock = np.stack([q['lockin'] for q in parts['gs']])
+    assert np.abs(lock[sl] - g['k1_lockin']).max() < 1e-13
+    assert np.allclose([u.sum(), (u ** 2).sum()], g['k1_u_moments'], rtol=1e-10)
