@@ -1,0 +1,270 @@
+// C ABI, a9 / f-2 / f-3 / f-4: periodic-component DFT, peak finding, Wiener deconvolution, Jacobian / properties, Huber plane fit.
+#include "gpa_plan.h"
+
+// periodic-component DFT of the image in p->d_image -> p->d_lockin (plane 0)
+int per_dft_staged(gpa_plan* p) {
+  if (!p->bx0.tw) {
+    size_t b = 0;
+    hipError_t e = blue_axis_create(p->dtype, p->n0, p->stream, &p->bx0, &b);
+    if (e == hipSuccess) e = blue_axis_create(p->dtype, p->n1, p->stream, &p->bx1, &b);
+    if (e != hipSuccess) return fail(GPA_ERR_HIP, std::string("gpa_per_dft tables: ") + hipGetErrorString(e));
+    p->ws_bytes += b;
+  }
+  // border-difference vectors: d0 holds n1, d1 holds n0 complex values
+  void* d0 = p->d_aux1;
+  void* d1 = p->d_aux0;
+  HIP_TRY(per_pack(p->dtype, p->d_image, p->n0, p->n1, p->Tbuf, d0, d1, p->stream));
+  HIP_TRY(dft2_inplace(p->dtype, p->bx0, p->bx1, p->Tbuf, p->stream));
+  HIP_TRY(dft_rows_inplace(p->dtype, p->bx1, 1, d0, p->stream));
+  HIP_TRY(dft_rows_inplace(p->dtype, p->bx0, 1, d1, p->stream));
+  HIP_TRY(per_combine(p->dtype, p->Tbuf, d0, d1, p->n0, p->n1, p->d_lockin, p->stream));
+  return GPA_OK;
+}
+
+int gpa_per_dft(gpa_plan* p, const void* image, void* out) {
+  if (!p || !image || !out) return fail(GPA_ERR_ARG, "gpa_per_dft: null argument");
+  HIP_TRY(hipSetDevice(p->device));
+  const size_t npx = (size_t)p->n0 * p->n1;
+  HIP_TRY(hipMemcpyAsync(p->d_image, image, npx * p->rsz, hipMemcpyHostToDevice, p->stream));
+  TRY(per_dft_staged(p));
+  HIP_TRY(hipMemcpyAsync(out, p->d_lockin, npx * p->csz, hipMemcpyDeviceToHost, p->stream));
+  HIP_TRY(hipStreamSynchronize(p->stream));
+  return GPA_OK;
+}
+
+// moisan2011.per in full: inverse_dft == 0 -> (p_hat, s_hat) complex (s_out may be null), != 0 -> (p, s) real
+int gpa_per(gpa_plan* p, const void* image, int inverse_dft, void* p_out, void* s_out) {
+  if (!p || !image || !p_out || (inverse_dft && !s_out)) return fail(GPA_ERR_ARG, "gpa_per: null argument");
+  HIP_TRY(hipSetDevice(p->device));
+  const size_t npx = (size_t)p->n0 * p->n1;
+  HIP_TRY(hipMemcpyAsync(p->d_image, image, npx * p->rsz, hipMemcpyHostToDevice, p->stream));
+  TRY(per_dft_staged(p));   // p_hat in d_lockin, u_hat still in Tbuf
+  if (!inverse_dft) {
+    HIP_TRY(hipMemcpyAsync(p_out, p->d_lockin, npx * p->csz, hipMemcpyDeviceToHost, p->stream));
+    if (s_out) {
+      HIP_TRY(per_smooth_hat(p->dtype, p->Tbuf, p->d_lockin, npx, p->stream));
+      HIP_TRY(hipMemcpyAsync(s_out, p->Tbuf, npx * p->csz, hipMemcpyDeviceToHost, p->stream));
+    }
+  } else {
+    HIP_TRY(per_components(p->dtype, p->bx0, p->bx1, p->d_lockin, p->d_image, p->d_wnorm, p->d_dudx, p->stream));
+    HIP_TRY(hipMemcpyAsync(p_out, p->d_wnorm, npx * p->rsz, hipMemcpyDeviceToHost, p->stream));
+    HIP_TRY(hipMemcpyAsync(s_out, p->d_dudx, npx * p->rsz, hipMemcpyDeviceToHost, p->stream));
+  }
+  HIP_TRY(hipStreamSynchronize(p->stream));
+  return GPA_OK;
+}
+
+// ---- f-3 -------------------------------------------------------------------------
+// scipy.ndimage._filters._gaussian_kernel1d (order 0): exp(-x^2 / 2 sigma^2) / sum, radius int(4 sigma + 0.5)
+int gaussian_weights(double sigma, std::vector<double>& w) {
+  const int R = (int)(4.0 * sigma + 0.5);
+  w.resize(2 * (size_t)R + 1);
+  double sum = 0.0;
+  for (int k = -R; k <= R; ++k) { w[k + R] = exp(-0.5 / (sigma * sigma) * (double)k * k); sum += w[k + R]; }
+  for (double& v : w) v /= sum;
+  return R;
+}
+
+int gpa_find_peaks(gpa_plan* p, const void* image, double sigma, double dog_sigma, double threshold_rel, int max_out,
+                   int32_t* coords, void* values, int* count_out, void* smooth_out) {
+  if (!p || !image || !coords || !values || !count_out) return fail(GPA_ERR_ARG, "gpa_find_peaks: null argument");
+  if (!(sigma > 0.0) || max_out < 1) return fail(GPA_ERR_ARG, "gpa_find_peaks: need sigma > 0, max_out >= 1");
+  if (p->n0 < 3 || p->n1 < 3) return fail(GPA_ERR_STATE, "gpa_find_peaks: image too small");
+  HIP_TRY(hipSetDevice(p->device));
+  const int n0 = p->n0, n1 = p->n1;
+  const size_t npx = (size_t)n0 * n1;
+  // candidates land in d_kidx (max_peaks * npx ints, two per candidate) and d_dudx (2 npx reals)
+  const size_t cap = std::min((size_t)p->max_peaks * npx / 2, 2 * npx);
+  if ((size_t)max_out > cap) max_out = (int)cap;
+  std::vector<double> w1, w2;
+  const int R1 = gaussian_weights(sigma, w1);
+  const int R2 = dog_sigma > 0.0 ? gaussian_weights(dog_sigma, w2) : 0;
+  // d_scratch (4096 doubles): [0, 1024) min/max partials + threshold, [1024, 4096) filter weights
+  if (2 * R1 + 1 > 3072 || 2 * R2 + 1 > 3072) return fail(GPA_ERR_ARG, "gpa_find_peaks: sigma too large (radius > 1535)");
+  hipStream_t st = p->stream;
+  double* d_w = p->d_scratch + 1024;
+  double* d_thr = p->d_scratch + 600;
+  int* d_count = reinterpret_cast<int*>(p->d_scratch + 610);
+  HIP_TRY(hipMemcpyAsync(p->d_image, image, npx * p->rsz, hipMemcpyHostToDevice, st));
+  TRY(per_dft_staged(p));                                                    // p_hat in d_lockin
+  void* fftim = p->d_image;                                                  // the staged image is consumed
+  void* tmp = p->d_wnorm;
+  void* smooth = p->d_u;
+  HIP_TRY(launch_absshift(p->dtype, p->d_lockin, n0, n1, fftim, st));
+  HIP_TRY(hipMemcpyAsync(d_w, w1.data(), w1.size() * sizeof(double), hipMemcpyHostToDevice, st));
+  HIP_TRY(launch_gauss1d(p->dtype, fftim, tmp, n0, n1, 0, d_w, R1, nullptr, st));
+  HIP_TRY(launch_gauss1d(p->dtype, tmp, smooth, n0, n1, 1, d_w, R1, nullptr, st));
+  if (dog_sigma > 0.0) {
+    HIP_TRY(hipStreamSynchronize(st));   // w1 (pageable) and the weight slot are reused
+    HIP_TRY(hipMemcpyAsync(d_w, w2.data(), w2.size() * sizeof(double), hipMemcpyHostToDevice, st));
+    HIP_TRY(launch_gauss1d(p->dtype, fftim, tmp, n0, n1, 0, d_w, R2, nullptr, st));
+    HIP_TRY(launch_gauss1d(p->dtype, tmp, smooth, n0, n1, 1, d_w, R2, smooth, st));
+  }
+  void* d_vals = p->d_dudx;                                                  // 2 npx reals >= max_out values
+  HIP_TRY(launch_localmax(p->dtype, smooth, n0, n1, threshold_rel, p->d_scratch, d_thr, max_out, d_count, p->d_kidx,
+                          d_vals, st));
+  int count = 0;
+  HIP_TRY(hipMemcpyAsync(&count, d_count, sizeof(int), hipMemcpyDeviceToHost, st));
+  HIP_TRY(hipStreamSynchronize(st));
+  const int stored = count < max_out ? count : max_out;
+  if (stored > 0) {
+    HIP_TRY(hipMemcpyAsync(coords, p->d_kidx, (size_t)stored * 2 * sizeof(int32_t), hipMemcpyDeviceToHost, st));
+    HIP_TRY(hipMemcpyAsync(values, d_vals, (size_t)stored * p->rsz, hipMemcpyDeviceToHost, st));
+  }
+  if (smooth_out) HIP_TRY(hipMemcpyAsync(smooth_out, smooth, npx * p->rsz, hipMemcpyDeviceToHost, st));
+  HIP_TRY(hipStreamSynchronize(st));
+  *count_out = count;
+  return GPA_OK;
+}
+
+// ---- f-4 (gaussian_deconvolve) -----------------------------------------------------
+int gpa_gaussian_deconvolve(gpa_plan* p, const void* data, int dr, double sigma, double balance, void* out) {
+  if (!p || !data || !out) return fail(GPA_ERR_ARG, "gpa_gaussian_deconvolve: null argument");
+  if (dr < 0 || !(sigma > 0.0) || !(balance >= 0.0)) return fail(GPA_ERR_ARG, "gpa_gaussian_deconvolve: need dr >= 0, sigma > 0, balance >= 0");
+  const int pad = 2 * dr, n0 = p->n0, n1 = p->n1, m0 = n0 - 2 * pad, m1 = n1 - 2 * pad;
+  if (m0 < 2 || m1 < 2 || pad >= m0 || pad >= m1)
+    return fail(GPA_ERR_STATE, "gpa_gaussian_deconvolve: the plan must have the padded shape (m + 4 dr), with 2 dr < m");
+  HIP_TRY(hipSetDevice(p->device));
+  if (!p->bx0.tw) {
+    size_t b = 0;
+    hipError_t e = blue_axis_create(p->dtype, p->n0, p->stream, &p->bx0, &b);
+    if (e == hipSuccess) e = blue_axis_create(p->dtype, p->n1, p->stream, &p->bx1, &b);
+    if (e != hipSuccess) return fail(GPA_ERR_HIP, std::string("gpa_gaussian_deconvolve tables: ") + hipGetErrorString(e));
+    p->ws_bytes += b;
+  }
+  hipStream_t st = p->stream;
+  // k-space Gaussian factors (doubles)
+  std::vector<double> gx = gaussian_kspace(n0, sigma), gy = gaussian_kspace(n1, sigma);
+  double* d_gx = reinterpret_cast<double*>(p->d_aux0);
+  double* d_gy = reinterpret_cast<double*>(p->d_aux1);
+  HIP_TRY(hipMemcpyAsync(d_gx, gx.data(), (size_t)n0 * sizeof(double), hipMemcpyHostToDevice, st));
+  HIP_TRY(hipMemcpyAsync(d_gy, gy.data(), (size_t)n1 * sizeof(double), hipMemcpyHostToDevice, st));
+  HIP_TRY(hipMemcpyAsync(p->d_image, data, (size_t)m0 * m1 * p->rsz, hipMemcpyHostToDevice, st));
+  HIP_TRY(launch_deconv_pack(p->dtype, p->d_image, m0, m1, pad, p->Tbuf, st));
+  HIP_TRY(dft2_inplace(p->dtype, p->bx0, p->bx1, p->Tbuf, st));
+  HIP_TRY(launch_deconv_filter(p->dtype, p->Tbuf, n0, n1, d_gx, d_gy, balance, st));
+  HIP_TRY(dft2_inplace(p->dtype, p->bx0, p->bx1, p->Tbuf, st));
+  HIP_TRY(launch_deconv_unpack(p->dtype, p->Tbuf, m0, m1, pad, p->d_wnorm, st));
+  HIP_TRY(hipMemcpyAsync(out, p->d_wnorm, (size_t)m0 * m1 * p->rsz, hipMemcpyDeviceToHost, st));
+  HIP_TRY(hipStreamSynchronize(st));   // gx / gy are pageable host vectors
+  return GPA_OK;
+}
+
+// ---- f-2 -------------------------------------------------------------------------
+int gpa_phasegradient2J_dev(gpa_plan* p, const double* kvecs, int P, const void* grads, const void* weights,
+                            double nmperpixel, const double* dks, void* J) {
+  if (!p || !kvecs || !grads || !weights || !J) return fail(GPA_ERR_ARG, "gpa_phasegradient2J: null argument");
+  if (P < 2 || P > p->max_peaks) return fail(GPA_ERR_STATE, "gpa_phasegradient2J: need 2 <= P <= 8 (and P <= max_batch)");
+  if (!(nmperpixel > 0.0)) return fail(GPA_ERR_ARG, "gpa_phasegradient2J: nmperpixel must be positive");
+  HIP_TRY(hipSetDevice(p->device));
+  double kiso[16];
+  for (int i = 0; i < 2 * P; ++i) kiso[i] = kvecs[i] + (dks ? dks[i] : 0.0);
+  TRY(stage_kmat(p, kiso, P));
+  HIP_TRY(launch_jacobian(p->dtype, grads, weights, p->d_kmat, P, (size_t)p->n0 * p->n1, nmperpixel, dks, J, p->stream));
+  return GPA_OK;
+}
+
+int gpa_phasegradient2J(gpa_plan* p, const double* kvecs, int P, const void* grads, const void* weights,
+                        double nmperpixel, const double* dks, void* J) {
+  if (!p || !kvecs || !grads || !weights || !J) return fail(GPA_ERR_ARG, "gpa_phasegradient2J: null argument");
+  if (P < 2 || P > p->max_peaks) return fail(GPA_ERR_STATE, "gpa_phasegradient2J: need 2 <= P <= 8 (and P <= max_batch)");
+  HIP_TRY(hipSetDevice(p->device));
+  const size_t npx = (size_t)p->n0 * p->n1;
+  TRY(ensure_tbuf(p, (P + 1) / 2));
+  void* d_J = nullptr;
+  HIP_TRY(hipMalloc(&d_J, 4 * npx * p->rsz));
+  int rc = GPA_OK;
+  hipError_t e = hipMemcpyAsync(p->d_lockin, grads, (size_t)P * npx * 2 * p->rsz, hipMemcpyHostToDevice, p->stream);
+  if (e == hipSuccess) e = hipMemcpyAsync(p->Tbuf, weights, (size_t)P * npx * p->rsz, hipMemcpyHostToDevice, p->stream);
+  if (e == hipSuccess) rc = gpa_phasegradient2J_dev(p, kvecs, P, p->d_lockin, p->Tbuf, nmperpixel, dks, d_J);
+  if (e == hipSuccess && rc == GPA_OK) e = hipMemcpyAsync(J, d_J, 4 * npx * p->rsz, hipMemcpyDeviceToHost, p->stream);
+  if (e == hipSuccess) e = hipStreamSynchronize(p->stream);
+  hipFree(d_J);
+  if (e != hipSuccess) return fail(GPA_ERR_HIP, std::string("gpa_phasegradient2J: ") + hipGetErrorString(e));
+  return rc;
+}
+
+int gpa_props_from_jac_dev(int device, int dtype, size_t npx, const void* jac, int add_identity, double refangle,
+                           double refscale, int diff, void* props, void* stream) {
+  if (!jac || !props) return fail(GPA_ERR_ARG, "gpa_props_from_jac: null argument");
+  if (dtype != GPA_F32 && dtype != GPA_F64) return fail(GPA_ERR_ARG, "gpa_props_from_jac: dtype must be GPA_F32 or GPA_F64");
+  if (npx == 0) return GPA_OK;
+  HIP_TRY(hipSetDevice(device));
+  HIP_TRY(launch_props(dtype, jac, npx, add_identity, refangle, refscale, diff, props, (hipStream_t)stream));
+  return GPA_OK;
+}
+
+int gpa_props_from_jac(int device, int dtype, size_t npx, const void* jac, int add_identity, double refangle,
+                       double refscale, int diff, void* props) {
+  if (!jac || !props) return fail(GPA_ERR_ARG, "gpa_props_from_jac: null argument");
+  if (dtype != GPA_F32 && dtype != GPA_F64) return fail(GPA_ERR_ARG, "gpa_props_from_jac: dtype must be GPA_F32 or GPA_F64");
+  if (npx == 0) return GPA_OK;
+  int ndev = 0;
+  if (hipGetDeviceCount(&ndev) != hipSuccess || ndev < 1) return fail(GPA_ERR_NODEV, "gpa_props_from_jac: no HIP device");
+  HIP_TRY(hipSetDevice(device));
+  const size_t bytes = 4 * npx * (dtype == GPA_F32 ? 4 : 8);
+  void *d_j = nullptr, *d_p = nullptr;
+  HIP_TRY(hipMalloc(&d_j, bytes));
+  hipError_t e = hipMalloc(&d_p, bytes);
+  int rc = GPA_OK;
+  if (e == hipSuccess) e = hipMemcpy(d_j, jac, bytes, hipMemcpyHostToDevice);
+  if (e == hipSuccess) rc = gpa_props_from_jac_dev(device, dtype, npx, d_j, add_identity, refangle, refscale, diff, d_p, nullptr);
+  if (e == hipSuccess && rc == GPA_OK) e = hipMemcpy(props, d_p, bytes, hipMemcpyDeviceToHost);
+  hipFree(d_j);
+  hipFree(d_p);
+  if (e != hipSuccess) return fail(GPA_ERR_HIP, std::string("gpa_props_from_jac: ") + hipGetErrorString(e));
+  return rc;
+}
+
+// ---- f-4 -------------------------------------------------------------------------
+bool solve3(const double* m /*uu uv u vv v 1*/, const double* b, double* x) {
+  const double A[3][3] = {{m[0], m[1], m[2]}, {m[1], m[3], m[4]}, {m[2], m[4], m[5]}};
+  const double det = A[0][0] * (A[1][1] * A[2][2] - A[1][2] * A[2][1]) - A[0][1] * (A[1][0] * A[2][2] - A[1][2] * A[2][0]) +
+                     A[0][2] * (A[1][0] * A[2][1] - A[1][1] * A[2][0]);
+  if (!(fabs(det) > 0.0)) return false;
+  for (int c = 0; c < 3; ++c) {
+    double M[3][3];
+    for (int i = 0; i < 3; ++i)
+      for (int j = 0; j < 3; ++j) M[i][j] = j == c ? b[i] : A[i][j];
+    x[c] = (M[0][0] * (M[1][1] * M[2][2] - M[1][2] * M[2][1]) - M[0][1] * (M[1][0] * M[2][2] - M[1][2] * M[2][0]) +
+            M[0][2] * (M[1][0] * M[2][1] - M[1][1] * M[2][0])) / det;
+  }
+  return true;
+}
+
+int gpa_fit_plane_dev(gpa_plan* p, const void* image, int max_iter, double tol, double* coef, int* iters_out) {
+  if (!p || !image || !coef) return fail(GPA_ERR_ARG, "gpa_fit_plane: null argument");
+  if (max_iter < 1 || !(tol >= 0.0)) return fail(GPA_ERR_ARG, "gpa_fit_plane: need max_iter >= 1, tol >= 0");
+  HIP_TRY(hipSetDevice(p->device));
+  const int n0 = p->n0, n1 = p->n1;
+  // centred, unit-scaled coordinates keep the normal matrix well conditioned
+  const double cx = 0.5 * (n0 - 1), cy = 0.5 * (n1 - 1), sx = 0.5 * n0, sy = 0.5 * n1;
+  double c[3] = {0.0, 0.0, 0.0};   // start at the zero plane like the reference (x0 = [0, 0, 0])
+  double sums[10];
+  int it = 0;
+  for (; it < max_iter; ++it) {
+    HIP_TRY(launch_huber_moments(p->dtype, image, n0, n1, c, cx, cy, sx, sy, p->d_scratch, p->stream));
+    HIP_TRY(hipMemcpyAsync(sums, p->d_scratch + 2560, sizeof(sums), hipMemcpyDeviceToHost, p->stream));
+    HIP_TRY(hipStreamSynchronize(p->stream));
+    double nc[3];
+    if (!solve3(sums, sums + 6, nc)) return fail(GPA_ERR_STATE, "gpa_fit_plane: singular normal equations");
+    // change of the fitted plane over the image, in units of the data
+    const double step = fabs(nc[0] - c[0]) + fabs(nc[1] - c[1]) + fabs(nc[2] - c[2]);
+    c[0] = nc[0]; c[1] = nc[1]; c[2] = nc[2];
+    if (step <= tol) { ++it; break; }
+  }
+  // back to pixel indices: a0 x + a1 y + a2
+  coef[0] = c[0] / sx;
+  coef[1] = c[1] / sy;
+  coef[2] = c[2] - c[0] * cx / sx - c[1] * cy / sy;
+  if (iters_out) *iters_out = it;
+  return GPA_OK;
+}
+
+int gpa_fit_plane(gpa_plan* p, const void* image, int max_iter, double tol, double* coef, int* iters_out) {
+  if (!p || !image || !coef) return fail(GPA_ERR_ARG, "gpa_fit_plane: null argument");
+  HIP_TRY(hipSetDevice(p->device));
+  HIP_TRY(hipMemcpyAsync(p->d_image, image, (size_t)p->n0 * p->n1 * p->rsz, hipMemcpyHostToDevice, p->stream));
+  return gpa_fit_plane_dev(p, p->d_image, max_iter, tol, coef, iters_out);
+}
+

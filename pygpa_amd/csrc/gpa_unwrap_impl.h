@@ -92,6 +92,11 @@ hipError_t pow2_rowidct_pq(const Impl* w, const void* pin, void* pout, const voi
 // stencil + row transform in one launch (rows of 2048 / 4096 points): D = DCT_rows(A^T W^2 A p) into w->q, partial <p, q>
 bool pow2_pqdct_offered(const Impl* w);
 hipError_t pow2_pqdct(const Impl* w, const void* p, const void* weight, double* part_pq, int* npq, hipStream_t s);
+// persistent, software-pipelined row kernels for 4096-point f32 rows (gpa_unwrap_rowpers.hip; NO_ROWPERS: the one-pair-per-
+// workgroup kernels of gpa_unwrap_rows.hip)
+bool pow2_rowpers_offered(const Impl* w);
+hipError_t pow2_rowidct_p_pers(const Impl* w, const void* pin, void* pout, const double* part_rho, int nrho, int it,
+                               hipStream_t s);
 // columns (gpa_unwrap_cols.hip): every size
 hipError_t dispatch_colsolve(const Impl* w, int compat, hipStream_t s, const double* part_norm, int nnorm, int it,
                              double eps, double* part_rho, int* nrho, const void* zin);

@@ -1033,6 +1033,7 @@ hipError_t pow2_rowidct_p(const Impl* w, const void* pin, void* pout, const doub
                                             : run_rowidct_p_half<double, 13>(w, pin, pout, part_rho, nrho, it, s);
     if (w->lg1 == 14 && w->dtype == 0) return run_rowidct_p_half<float, 14>(w, pin, pout, part_rho, nrho, it, s);
   }
+  if (pow2_rowpers_offered(w)) return pow2_rowidct_p_pers(w, pin, pout, part_rho, nrho, it, s);
 #define CASE(LG) case LG: return w->dtype == 0 ? run_rowidct_p<float, LG>(w, pin, pout, part_rho, nrho, it, s) \
                                                : run_rowidct_p<double, LG>(w, pin, pout, part_rho, nrho, it, s);
   switch (w->lg1) { GPA_FOR_LG(CASE) }

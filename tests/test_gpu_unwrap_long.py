@@ -204,3 +204,35 @@ def test_stack_of_2048_frames_equals_single_images():
         assert np.array_equal(u_b[i], u), (i, float(np.abs(u_b[i] - u).max()))
         assert tuple(it_b[i]) == tuple(iters)
     plan.close()
+
+
+@pytest.mark.parametrize('shape', [(4096, 4096), (2048, 4096), (64, 4096)])
+def test_persistent_row_kernels_equal_per_pair_kernels(shape, gpa_option):
+    """round 5: the persistent, software-pipelined row kernels of gpa_unwrap_rowpers.hip (4096-point f32 rows: LDS-DMA of
+    the next row pair into the other LDS buffer while the current one is transformed) against the one-pair-per-workgroup
+    kernels they replace (NO_ROWPERS): the same arithmetic in the same order -- phi equal BIT FOR BIT, equal iteration
+    counts, over bands of 4 / 2 / 1 row pairs per workgroup, weighted, kmax 10 and kmax 23 (two flushes of the ring);
+    and the oracle's phi at 2048 x 4096."""
+    dx, dy, w = make_problem(shape, seed=shape[0] + 7)
+    dx, dy, w = (np.ascontiguousarray(v, dtype=np.float32) for v in (dx, dy, w))
+    for kmax in (10, 23):
+        gpa_option('NO_ROWPERS', None)
+        plan = _lib.Plan(shape, 1, np.float32)
+        a, it_a = plan.unwrap_prediff(dx, dy, w, kmax=kmax)
+        a2, _ = plan.unwrap_prediff(dx, dy, w, kmax=kmax)
+        plan.close()
+        gpa_option('NO_ROWPERS', '1')
+        plan = _lib.Plan(shape, 1, np.float32)
+        b, it_b = plan.unwrap_prediff(dx, dy, w, kmax=kmax)
+        plan.close()
+        gpa_option('NO_ROWPERS', None)
+        assert np.isfinite(a).all()
+        assert np.array_equal(a, a2)                       # run to run (no race between DMA, reads and exchanges)
+        assert it_a == it_b == kmax
+        assert np.array_equal(a, b), (shape, kmax, float(np.abs(a - b).max()))
+    if shape == (2048, 4096):
+        ref = orc.unwrap_prediff(dx.astype(np.float64), dy.astype(np.float64), w.astype(np.float64), kmax=10, compat=False)
+        plan = _lib.Plan(shape, 1, np.float32)
+        phi, _ = plan.unwrap_prediff(dx, dy, w, kmax=10)
+        plan.close()
+        assert rel(phi, ref) < 5e-5
