@@ -54,6 +54,7 @@ def parse_args():
                          'of the GPU idle between their ~45 dependent kernels; several in flight fill it')
     ap.add_argument('--no-cpu', action='store_true', help='skip the CPU baseline leg')
     ap.add_argument('--no-f64', action='store_true', help='skip the f64 leg')
+    ap.add_argument('--no-config5', action='store_true', help='skip the 16384^2 tile pipeline + Lawler-Fujita leg (config5_single_gpu)')
     ap.add_argument('--window', type=int, default=2048, help='N > 1: side of the (power-of-two) tile windows')
     ap.add_argument('--backend', default='nccl', help='N > 1: torch.distributed backend (gloo stages through the host)')
     ap.add_argument('--share-device', action='store_true', help='N > 1: every rank uses GPU 0 (test aid, with --backend gloo)')
@@ -431,9 +432,120 @@ def single_gpu(args):
         out['small_image_stacks'] = small_image_stacks(kvecs, klists, sigma, args.kmax)
     if not args.no_f64:
         out['host_call'] = host_call(n, knx, kny, np_dt, args.kmax)
+    if not args.no_f64 and not args.no_config5 and args.dtype == 'f32' and n == 4096 and not args.kgrid:
+        try:
+            out['config5_single_gpu'] = config5_single_gpu(knx, kny, np_dt, args.kmax)
+        except Exception as e:      # (an extra leg must not take the headline line with it)
+            out['config5_single_gpu'] = {'error': '%s: %s' % (type(e).__name__, e)}
     if not args.no_cpu:
         out['cpu_baseline'] = cpu_baseline(kvecs, sigma, knx, kny, args.kmax, n)
     print(json.dumps(out), flush=True)
+
+
+def config5_single_gpu(knx, kny, np_dt, kmax, n=16384, window=2048, reps=2):
+    """BASELINE.json configs[4] on ONE GPU, end to end and resident: the 16384^2 image through the tile pipeline (81 halo
+    windows of 2048^2 read in place from the resident image, interiors of the gradient fields written straight into the
+    global fields, two global weighted unwraps) PLUS the Lawler-Fujita undistortion of the image with the field just
+    extracted (gpa_undistort_image_dev: u never leaves HBM).  C ABI only -- no torch in this leg.  Extra key, never `value`."""
+    from pygpa_amd import _lib
+    from pygpa_amd import distributed as D
+    from pygpa_amd.synthetic import hex_kvecs, explicit_klists
+    shape = (n, n)
+    P, K = 3, knx * kny
+    kvecs = hex_kvecs(0.1, 7.0)
+    sigma = int(np.ceil(1 / np.linalg.norm(kvecs, axis=1).min()))
+    kw = np.linalg.norm(kvecs, axis=1).mean() / 2.5
+    klists = np.stack(explicit_klists(kvecs, kw, knx, kny))
+    halo, border = 3 * sigma, 2 * sigma
+    tiles, (t0, t1), wshape = D.tile_plan(shape, None, halo, (window, window))
+    rsz = np.dtype(np_dt).itemsize
+    npx = n * n
+    # the synthetic image, generated in bands of rows (the full-size float64 temporaries would be 2 GB each)
+    t_gen = time.perf_counter()
+    d_img = _lib.DeviceBuffer(npx * rsz)
+    band = 1024
+    y = (np.arange(n) - n // 2)[None, :].astype(np.float64)
+    for r0 in range(0, n, band):
+        x = (np.arange(r0, r0 + band) - n // 2)[:, None].astype(np.float64)
+        ux = 0.5 * x * np.exp(-0.5 * ((x / (n / 8.0)) ** 2 + 1.2 * (y / (n / 6.0)) ** 2))
+        blk = np.zeros((band, n))
+        for kx, ky in kvecs:
+            blk += np.cos(2 * np.pi * (kx * (x + ux) + ky * y))
+        blk += np.random.default_rng([100, r0]).normal(scale=0.05, size=blk.shape)
+        d_img.upload_at(np.ascontiguousarray(blk, dtype=np_dt), r0 * n * rsz)
+    t_gen = time.perf_counter() - t_gen
+    plan_w = _lib.Plan(wshape, P * K, np_dt, device=0)
+    plan_g = _lib.Plan(shape, 1, np_dt, device=0)
+    gdx, gdy = _lib.DeviceBuffer(2 * n * (n - 1) * rsz), _lib.DeviceBuffer(2 * (n - 1) * n * rsz)
+    gw, d_u = _lib.DeviceBuffer(npx * rsz), _lib.DeviceBuffer(2 * npx * rsz)
+    d_rec, d_uinv = _lib.DeviceBuffer(npx * rsz), _lib.DeviceBuffer(2 * npx * rsz)
+    st = {}
+
+    def one_image(record=False):
+        t = time.perf_counter()
+        mean = plan_w.mean_dev(d_img.ptr, npx)                     # (one scalar to the host: the only sync before the end)
+        if record:
+            st['mean'] = time.perf_counter() - t
+            t = time.perf_counter()
+        for (i, j), (w0, w1), (o0, o1), (z0, z1) in tiles:
+            gi, gj = i * t0, j * t1
+            plan_w.tile_gradients_dev(d_img.ptr, n, w0.start, w1.start, mean, kvecs, klists, sigma, border, (o0, o1, z0, z1),
+                                      (gdx.ptr + (gi * (n - 1) + gj) * rsz, n - 1, n * (n - 1)),
+                                      (gdy.ptr + (gi * n + gj) * rsz, n, (n - 1) * n), (gw.ptr + (gi * n + gj) * rsz, n))
+        plan_w.sync()
+        if record:
+            st['tile_stage'] = time.perf_counter() - t
+            t = time.perf_counter()
+        its = [plan_g.unwrap_prediff_dev(gdx.ptr + c * n * (n - 1) * rsz, gdy.ptr + c * (n - 1) * n * rsz, gw.ptr,
+                                         d_u.ptr + c * npx * rsz, kmax=kmax) for c in range(2)]
+        if record:
+            st['global_unwrap'] = time.perf_counter() - t
+            t = time.perf_counter()
+        plan_g.undistort_image_dev(d_img.ptr, d_u.ptr, d_rec.ptr, uinv_ptr=d_uinv.ptr)
+        plan_g.sync()
+        if record:
+            st['lawler_fujita'] = time.perf_counter() - t
+        return its
+
+    one_image()
+    t0_ = time.perf_counter()
+    for _ in range(reps):
+        its = one_image()
+    dt = (time.perf_counter() - t0_) / reps
+    one_image(record=True)
+    plan_g.set_profiling(True)
+    plan_g.undistort_image_dev(d_img.ptr, d_u.ptr, d_rec.ptr, uinv_ptr=d_uinv.ptr)
+    prof = plan_g.last_kernel_profile()
+    plan_g.set_profiling(False)
+    # compulsory HBM bytes of the Lawler-Fujita kernels per launch (DESIGN 2.7): pad / FIR passes read + write one padded
+    # field; the fixed point reads the two coefficient fields once and writes u_inv; the resampling reads coefficients +
+    # u_inv and writes the image.  The 36 rounds x 32 taps per pixel of the fixed point are CACHE traffic (L1 / L2).
+    mpx = (n + 24) * (n + 24)
+    comp = {'pad_edge_kernel': 2 * mpx, 'fir_rows_kernel': 2 * mpx, 'fir_cols_kernel': 2 * mpx, 'invert_kernel': 2 * mpx + 2 * npx,
+            'warp_constant_kernel': 4 * npx}
+    lf = {}
+    for k, (calls, ms) in prof.items():
+        gb = comp.get(k, 0) * rsz / 1e9
+        lf[k] = {'launches': calls, 'total_ms': round(ms, 3), 'compulsory_GB_per_launch': round(gb, 3),
+                 'frac_of_hbm_peak': round(gb * calls / (ms * 1e-3) / HBM_PEAK_GBS, 3) if ms else None}
+    if 'invert_kernel' in lf:
+        ms = lf['invert_kernel']['total_ms']
+        taps = 36 * 32 * npx
+        lf['invert_kernel']['bound'] = ('L1 / texture-address rate of the coefficient gathers: %d rounds x 32 taps per pixel = %.1f G lane-loads '
+                                        'in %.1f ms = %.2f T lane-loads/s (wavefronts leave at their bitwise fixed point, so fewer rounds '
+                                        'run than are counted here); compulsory HBM bytes are 0.0x of the time' % (36, taps / 1e9, ms, taps / ms / 1e9))
+    for b in (d_img, gdx, gdy, gw, d_u, d_rec, d_uinv):
+        b.free()
+    plan_w.close()
+    plan_g.close()
+    return {'workload': '%dx%d synthetic hex moire, 3 x %d k-vectors, %s: %d halo windows of %d^2 (halo %d) read in place -> gradient '
+                        'interiors -> two global weighted unwraps kmax=%d -> Lawler-Fujita undistortion with the extracted field '
+                        '(36 fixed-point rounds + cubic resampling); one GPU, everything resident (BASELINE.json configs[4] end to end)'
+                        % (n, n, K, np.dtype(np_dt).name, len(tiles), window, halo, kmax),
+            'value': round(npx / dt / 1e6, 1), 'unit': 'Mpixels/s', 'ms_per_image': round(dt * 1e3, 2), 'unwrap_iters': list(its),
+            'stage_ms': {k: round(v * 1e3, 2) for k, v in st.items()},
+            'extraction_only_Mpix_s': round(npx / max(dt - st.get('lawler_fujita', 0.0), 1e-9) / 1e6, 1),
+            'lawler_fujita_kernels': lf, 'image_generation_s': round(t_gen, 1)}
 
 
 def host_call(n, knx, kny, np_dt, kmax, reps=5):

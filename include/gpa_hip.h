@@ -292,6 +292,16 @@ int gpa_invert_u(gpa_plan* plan, const void* u, int iters, int edge, void* out);
  * invert_u_overlap passes cval = nan, geometric_phase_analysis.py:297-299).  overlap != 0: invert_u_overlap.      */
 int gpa_invert_u_mode(gpa_plan* plan, const void* u, int iters, int edge, int overlap, int mode, void* out);
 int gpa_undistort_image(gpa_plan* plan, const void* deformed, const void* u, void* out);
+/* The same on device pointers, enqueued on the plan's stream WITHOUT a host synchronisation (gpa_plan_sync, or
+ * gpa_stream_wait_plan for another stream); scratch is kept by the plan.  gpa_invert_u_mode_dev inverts scale * u
+ * (undistort_image passes -u: scale = -1).  rects = nrect x {r0, c0, h, w} (host ints; nrect = 0: the whole grid) restricts
+ * the fixed-point rounds and the resampling to those windows of the output grid -- the tiles a rank owns once it holds the
+ * stitched field; the rest of out_dev is left untouched, the spline prefilter of the whole field runs once per call.
+ * gpa_undistort_image_dev: uinv_dev (2 x n0 x n1, nullable) receives u_inv.                                           */
+int gpa_invert_u_mode_dev(gpa_plan* plan, const void* u_dev, double scale, int iters, int edge, int overlap, int mode,
+                          const int* rects, int nrect, void* out_dev);
+int gpa_undistort_image_dev(gpa_plan* plan, const void* deformed_dev, const void* u_dev, const int* rects, int nrect,
+                            void* uinv_dev, void* out_dev);
 
 /* f-2 -- phase gradient -> Jacobian -> lattice properties.
  * gpa_phasegradient2J: J[n,m,i,j] = (per-pixel weighted least squares of grads[:,n,m,j] against

@@ -42,6 +42,8 @@ SIGNATURES = {
     'gpa_reconstruct_prediff': (_i, [_vp, _vp, _vp, _vp, _i, _vp, _vp, _vp]),
     'gpa_invert_u': (_i, [_vp, _vp, _i, _i, _vp]),
     'gpa_invert_u_mode': (_i, [_vp, _vp, _i, _i, _i, _i, _vp]),
+    'gpa_invert_u_mode_dev': (_i, [_vp, _vp, _d, _i, _i, _i, _i, _vp, _i, _vp]),
+    'gpa_undistort_image_dev': (_i, [_vp, _vp, _vp, _vp, _i, _vp, _vp]),
     'gpa_reconstruct_grad': (_i, [_vp, _vp, _vp, _i, _i, _vp, _vp, _vp]),
     'gpa_reconstruct_grad_dev': (_i, [_vp, _vp, _vp, _i, _i, _vp, _vp, _vp]),
     'gpa_weighted_lstsq': (_i, [_vp, _vp, _vp, _vp, _i, _vp]),
@@ -325,6 +327,31 @@ class Plan:
         out = np.empty(self.shape, dtype=self.rdtype)
         check(self.lib.gpa_undistort_image(self.handle, _ptr(deformed), _ptr(u), _ptr(out)), 'gpa_undistort_image')
         return out
+
+    @staticmethod
+    def _rects(rects):
+        """None, one (r0, c0, h, w) or a list of them -> (ctypes int array or None, count)"""
+        if rects is None:
+            return None, 0
+        flat = np.asarray(rects, dtype=np.int64).reshape(-1)
+        if flat.size % 4:
+            raise ValueError('rects: (r0, c0, h, w) per window')
+        return (C.c_int * flat.size)(*[int(v) for v in flat]), flat.size // 4
+
+    def invert_u_dev(self, u_ptr, out_ptr, scale=1.0, iters=35, edge=0, overlap=True, mode='nearest', rects=None):
+        """invert_u_overlap / invert_u of scale * u on device pointers, enqueued on the plan's stream (no host sync);
+        rects = (r0, c0, h, w) or a list of such windows: only those parts of the output grid are computed"""
+        arr, n = self._rects(rects)
+        check(self.lib.gpa_invert_u_mode_dev(self.handle, _ptr(int(u_ptr)), float(scale), int(iters), int(edge), int(bool(overlap)),
+                                             self._WARP_MODES[mode], arr, n, _ptr(int(out_ptr))), 'gpa_invert_u_mode_dev')
+
+    def undistort_image_dev(self, deformed_ptr, u_ptr, out_ptr, uinv_ptr=None, rects=None):
+        """undistort_image on device pointers, enqueued on the plan's stream (no host sync); uinv_ptr (2 x n0 x n1) receives
+        u_inv = invert_u_overlap(-u); rects = (r0, c0, h, w) or a list: only those windows of the outputs are computed"""
+        arr, n = self._rects(rects)
+        check(self.lib.gpa_undistort_image_dev(self.handle, _ptr(int(deformed_ptr)), _ptr(int(u_ptr)), arr, n,
+                                               _ptr(None if uinv_ptr is None else int(uinv_ptr)), _ptr(int(out_ptr))),
+              'gpa_undistort_image_dev')
 
     def phasegradient2J(self, kvecs, grads, weights, nmperpixel, dks=None):
         kvecs = _f64(kvecs).reshape(-1, 2)
@@ -744,6 +771,15 @@ class DeviceBuffer:
         host = np.ascontiguousarray(host)
         self._select()
         if self._hip.hipMemcpy(C.c_void_p(self.ptr), host.ctypes.data_as(C.c_void_p), C.c_size_t(host.nbytes), 1) != 0:
+            raise GPAError('hipMemcpy H2D failed')
+
+    def upload_at(self, host, byte_offset):
+        """H2D of `host` to ptr + byte_offset (a large buffer filled piece by piece)"""
+        host = np.ascontiguousarray(host)
+        if byte_offset < 0 or byte_offset + host.nbytes > self.nbytes:
+            raise ValueError('upload_at: outside the buffer')
+        self._select()
+        if self._hip.hipMemcpy(C.c_void_p(self.ptr + int(byte_offset)), host.ctypes.data_as(C.c_void_p), C.c_size_t(host.nbytes), 1) != 0:
             raise GPAError('hipMemcpy H2D failed')
 
     def download(self, shape, dtype):

@@ -13,7 +13,7 @@ static const char* const kOptNames[OPT_COUNT] = {
     "PBS_FULLBAND", "USE_GRAPH", "SERIAL_UNWRAP", "NO_WORKER", "NO_KSPLIT", "NO_COMPACT", "NO_SHARED", "SHARED_A",
     "NO_PAIR", "PBS_E8", "TRI_SMALL", "TRI_Q", "NO_MR", "MR_FORCE_BLUESTEIN", "NO_ROWPQ", "COLSOLVE", "NO_LAT",
     "F32_EPS_FLOOR", "COLSTREAM_CHUNK", "NO_ROWHALF", "PAIR_MAXSIDE", "ROWHALF_MINLG", "NO_PQDCT", "NATIVE",
-    "NATIVE_RATIO", "NATIVE_SHARED", "NO_REORDER", "NO_RAW", "NO_TILEFUSE", "NO_ROWPERS", "ROW_STAGGER"};
+    "NATIVE_RATIO", "NATIVE_SHARED", "NO_REORDER", "NO_RAW", "NO_TILEFUSE", "NO_ROWPERS", "NO_PQPERS"};
 static OptVal g_opts[OPT_COUNT];
 static std::once_flag g_opts_once;
 static void opt_assign(OptVal& o, const char* value) {
@@ -261,6 +261,7 @@ void gpa_plan_destroy(gpa_plan* p) {
   if (p->ev_x) hipEventDestroy(p->ev_x);
   if (p->d_tsum_part) (void)hipFree(p->d_tsum_part);
   if (p->d_ticket) (void)hipFree(p->d_ticket);
+  warp_ws_free(&p->warp);
   blue_axis_destroy(&p->bx0);
   blue_axis_destroy(&p->bx1);
   if (p->h_k) hipHostFree(p->h_k);

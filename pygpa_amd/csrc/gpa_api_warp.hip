@@ -1,37 +1,80 @@
 // C ABI, f-1: Lawler-Fujita undistortion (geometric_phase_analysis.py:248-300, :935-974).
+//
+// The _dev entry points take device pointers, enqueue on the plan's stream and return without a host synchronisation
+// (gpa_plan_sync / gpa_stream_wait_plan order later work); scratch and prefilter taps live in the plan (p->warp, grown
+// on first use).  `rects` = nrect x {r0, c0, h, w} restricts the heavy kernels -- the fixed-point rounds, the final resampling --
+// to windows of the output grid: the tiles a rank owns after the stitched field has been handed to it.
+// The host-pointer entry points of rounds 1-4 are these plus the copies.
 #include "gpa_plan.h"
 
-int invert_u_host(gpa_plan* p, const void* u, int iters, int edge, int shift, void* out, int mode, bool overlap) {
+static int check_invert_args(gpa_plan* p, const void* u, void* out, int iters, int edge, int mode) {
   if (!p || !u || !out) return fail(GPA_ERR_ARG, "gpa_invert_u: null argument");
   if (iters < 1 || edge < 0) return fail(GPA_ERR_ARG, "gpa_invert_u: need iters >= 1, edge >= 0");
-  HIP_TRY(hipSetDevice(p->device));
-  const size_t npx = (size_t)p->n0 * p->n1, nout = (size_t)(p->n0 + 2 * edge) * (p->n1 + 2 * edge);
-  void* d_out = nullptr;
-  HIP_TRY(hipMalloc(&d_out, 2 * nout * p->rsz));
-  hipError_t e = hipMemcpyAsync(p->d_u, u, 2 * npx * p->rsz, hipMemcpyHostToDevice, p->stream);
-  if (e == hipSuccess) e = warp_invert_u(p->dtype, p->d_u, p->n0, p->n1, 1.0, iters, edge, shift, d_out, p->stream, mode, overlap ? 1 : 0);
-  if (e == hipSuccess) e = hipMemcpyAsync(out, d_out, 2 * nout * p->rsz, hipMemcpyDeviceToHost, p->stream);
-  if (e == hipSuccess) e = hipStreamSynchronize(p->stream);
-  hipFree(d_out);
-  if (e != hipSuccess) return fail(GPA_ERR_HIP, std::string("gpa_invert_u: ") + hipGetErrorString(e));
+  if (mode != 0 && mode != 1) return fail(GPA_ERR_ARG, "gpa_invert_u_mode: mode must be 0 (nearest) or 1 (constant)");
   return GPA_OK;
 }
 
+// invert_u_overlap (overlap != 0: out is 2 x (n0 + 2 edge) x (n1 + 2 edge)) or invert_u (out 2 x n0 x n1, every round
+// after the first sampled at r + u_it(r) - edge) of scale * u, all on the device
+int gpa_invert_u_mode_dev(gpa_plan* p, const void* u_dev, double scale, int iters, int edge, int overlap, int mode,
+                          const int* rects, int nrect, void* out_dev) {
+  TRY(check_invert_args(p, u_dev, out_dev, iters, edge, mode));
+  if (nrect < 0 || (nrect > 0 && !rects)) return fail(GPA_ERR_ARG, "gpa_invert_u_mode_dev: nrect windows need rects");
+  HIP_TRY(hipSetDevice(p->device));
+  ProfInstall prof(p);
+  const hipError_t e = overlap ? warp_invert_u(p->dtype, u_dev, p->n0, p->n1, scale, iters, edge, 0, out_dev, p->stream, mode, 1, &p->warp, rects, nrect)
+                               : warp_invert_u(p->dtype, u_dev, p->n0, p->n1, scale, iters, 0, edge, out_dev, p->stream, mode, 0, &p->warp, rects, nrect);
+  if (e != hipSuccess) return fail(GPA_ERR_HIP, std::string("gpa_invert_u_mode_dev: ") + hipGetErrorString(e));
+  if (p->profiling) { HIP_TRY(hipStreamSynchronize(p->stream)); collect_kernel_profile(p); }
+  return GPA_OK;
+}
+
+// undistort_image (geometric_phase_analysis.py:935-974): u_inv = invert_u_overlap(-u) (35 rounds, mode 'nearest', no
+// edge) into uinv_dev (2 x n0 x n1; null: plan scratch), then deformed resampled at r + u_inv(r) (order 3, 'constant')
+int gpa_undistort_image_dev(gpa_plan* p, const void* deformed_dev, const void* u_dev, const int* rects, int nrect,
+                            void* uinv_dev, void* out_dev) {
+  if (!p || !deformed_dev || !u_dev || !out_dev) return fail(GPA_ERR_ARG, "gpa_undistort_image_dev: null argument");
+  if (nrect < 0 || (nrect > 0 && !rects)) return fail(GPA_ERR_ARG, "gpa_undistort_image_dev: nrect windows need rects");
+  HIP_TRY(hipSetDevice(p->device));
+  ProfInstall prof(p);
+  void* uinv = uinv_dev ? uinv_dev : p->d_dudx;   // (2 planes of n0 x n1 fit)
+  HIP_TRY(warp_invert_u(p->dtype, u_dev, p->n0, p->n1, -1.0, 35, 0, 0, uinv, p->stream, 0, 1, &p->warp, rects, nrect));
+  HIP_TRY(warp_image(p->dtype, deformed_dev, uinv, p->n0, p->n1, out_dev, p->stream, &p->warp, rects, nrect));
+  if (p->profiling) { HIP_TRY(hipStreamSynchronize(p->stream)); collect_kernel_profile(p); }
+  return GPA_OK;
+}
+
+static int invert_u_host(gpa_plan* p, const void* u, int iters, int edge, int overlap, int mode, void* out) {
+  TRY(check_invert_args(p, u, out, iters, edge, mode));
+  HIP_TRY(hipSetDevice(p->device));
+  const int e2 = overlap ? edge : 0;
+  const size_t npx = (size_t)p->n0 * p->n1, nout = (size_t)(p->n0 + 2 * e2) * (p->n1 + 2 * e2);
+  void* d_out = nullptr;
+  HIP_TRY(hipMalloc(&d_out, 2 * nout * p->rsz));
+  int rc = GPA_OK;
+  hipError_t e = hipMemcpyAsync(p->d_u, u, 2 * npx * p->rsz, hipMemcpyHostToDevice, p->stream);
+  if (e == hipSuccess) rc = gpa_invert_u_mode_dev(p, p->d_u, 1.0, iters, edge, overlap, mode, nullptr, 0, d_out);
+  if (e == hipSuccess && rc == GPA_OK) e = hipMemcpyAsync(out, d_out, 2 * nout * p->rsz, hipMemcpyDeviceToHost, p->stream);
+  if (e == hipSuccess) e = hipStreamSynchronize(p->stream);
+  (void)hipFree(d_out);
+  if (e != hipSuccess) return fail(GPA_ERR_HIP, std::string("gpa_invert_u: ") + hipGetErrorString(e));
+  return rc;
+}
+
 int gpa_invert_u_overlap(gpa_plan* p, const void* u, int iters, int edge, void* out) {
-  return invert_u_host(p, u, iters, edge, 0, out, 0, true);
+  return invert_u_host(p, u, iters, edge, 1, 0, out);
 }
 
 // invert_u (geometric_phase_analysis.py:248-259): the image's own grid, one sampling at r and then `iters` rounds
 // at r + u_it(r) - edge
 int gpa_invert_u(gpa_plan* p, const void* u, int iters, int edge, void* out) {
-  return invert_u_host(p, u, iters, 0, edge, out, 0, false);
+  return invert_u_host(p, u, iters, edge, 0, 0, out);
 }
 
 // the two with scipy's boundary mode as an argument: 0 = 'nearest', 1 = 'constant' (the `mode=` keyword of
 // geometric_phase_analysis.py:248, :262); overlap != 0 = invert_u_overlap
 int gpa_invert_u_mode(gpa_plan* p, const void* u, int iters, int edge, int overlap, int mode, void* out) {
-  if (mode != 0 && mode != 1) return fail(GPA_ERR_ARG, "gpa_invert_u_mode: mode must be 0 (nearest) or 1 (constant)");
-  return overlap ? invert_u_host(p, u, iters, edge, 0, out, mode, true) : invert_u_host(p, u, iters, 0, edge, out, mode, false);
+  return invert_u_host(p, u, iters, edge, overlap ? 1 : 0, mode, out);
 }
 
 int gpa_undistort_image(gpa_plan* p, const void* deformed, const void* u, void* out) {
@@ -40,11 +83,8 @@ int gpa_undistort_image(gpa_plan* p, const void* deformed, const void* u, void* 
   const size_t npx = (size_t)p->n0 * p->n1;
   HIP_TRY(hipMemcpyAsync(p->d_u, u, 2 * npx * p->rsz, hipMemcpyHostToDevice, p->stream));
   HIP_TRY(hipMemcpyAsync(p->d_image, deformed, npx * p->rsz, hipMemcpyHostToDevice, p->stream));
-  // u_inv = invert_u_overlap(-u) (35 rounds, no overlap edge) lands in dudx (2 planes of n0*n1 fit)
-  HIP_TRY(warp_invert_u(p->dtype, p->d_u, p->n0, p->n1, -1.0, 35, 0, 0, p->d_dudx, p->stream));
-  HIP_TRY(warp_image(p->dtype, p->d_image, p->d_dudx, p->n0, p->n1, p->d_wnorm, p->stream));
+  TRY(gpa_undistort_image_dev(p, p->d_image, p->d_u, nullptr, 0, nullptr, p->d_wnorm));
   HIP_TRY(hipMemcpyAsync(out, p->d_wnorm, npx * p->rsz, hipMemcpyDeviceToHost, p->stream));
   HIP_TRY(hipStreamSynchronize(p->stream));
   return GPA_OK;
 }
-

@@ -72,7 +72,7 @@ enum OptKey {
   OPT_PBS_FULLBAND, OPT_USE_GRAPH, OPT_SERIAL_UNWRAP, OPT_NO_WORKER, OPT_NO_KSPLIT, OPT_NO_COMPACT, OPT_NO_SHARED,
   OPT_SHARED_A, OPT_NO_PAIR, OPT_PBS_E8, OPT_TRI_SMALL, OPT_TRI_Q, OPT_NO_MR, OPT_MR_FORCE_BLUESTEIN, OPT_NO_ROWPQ,
   OPT_COLSOLVE, OPT_NO_LAT, OPT_F32_EPS_FLOOR, OPT_COLSTREAM_CHUNK, OPT_NO_ROWHALF, OPT_PAIR_MAXSIDE, OPT_ROWHALF_MINLG, OPT_NO_PQDCT,
-  OPT_NATIVE, OPT_NATIVE_RATIO, OPT_NATIVE_SHARED, OPT_NO_REORDER, OPT_NO_RAW, OPT_NO_TILEFUSE, OPT_NO_ROWPERS, OPT_ROW_STAGGER, OPT_COUNT
+  OPT_NATIVE, OPT_NATIVE_RATIO, OPT_NATIVE_SHARED, OPT_NO_REORDER, OPT_NO_RAW, OPT_NO_TILEFUSE, OPT_NO_ROWPERS, OPT_NO_PQPERS, OPT_COUNT
 };
 struct OptVal {
   bool set;
@@ -267,8 +267,19 @@ hipError_t launch_stitch(int dtype, const void* tiles, size_t slot_stride, size_
 // ---- f-1 Lawler-Fujita (gpa_warp.hip); both synchronise the stream before returning -----------
 // mode: 0 = scipy 'nearest' (the reference's default), 1 = 'constant'; nan_last (mode 1 only): the last round samples
 // with cval = NaN as invert_u_overlap does (geometric_phase_analysis.py:296-299), invert_u never does (:255-258)
+// scratch + prefilter taps of the warp kernels, kept by the plan: no allocation and no host synchronisation per call
+struct WarpWs {
+  void* buf = nullptr;
+  size_t cap = 0;
+  void* taps = nullptr;
+  int taps_dtype = -1;
+};
+void warp_ws_free(WarpWs* ws);
+// rects = nrect x {r0, c0, h, w}: the windows of the output grid that are computed (nrect = 0: all of it) -- the tiles a
+// rank owns; the prefilter of the whole field runs once per call
 hipError_t warp_invert_u(int dtype, const void* d_u, int n0, int n1, double scale, int iters, int edge, int shift,
-                         void* d_out, hipStream_t s, int mode = 0, int nan_last = 0);
-hipError_t warp_image(int dtype, const void* d_img, const void* d_uinv, int n0, int n1, void* d_out, hipStream_t s);
+                         void* d_out, hipStream_t s, int mode, int nan_last, WarpWs* ws, const int* rects = nullptr, int nrect = 0);
+hipError_t warp_image(int dtype, const void* d_img, const void* d_uinv, int n0, int n1, void* d_out, hipStream_t s, WarpWs* ws,
+                      const int* rects = nullptr, int nrect = 0);
 
 }  // namespace gpa

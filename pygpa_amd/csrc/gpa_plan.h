@@ -201,6 +201,7 @@ struct gpa_plan {
   hipStream_t stream2 = nullptr;
   hipEvent_t ev_fork = nullptr, ev_join = nullptr;
   BlueAxis bx0{}, bx1{};          // Bluestein tables for gpa_per_dft, built on first use
+  WarpWs warp{};                  // scratch + taps of the Lawler-Fujita kernels (gpa_warp.hip), grown on first use
   // timing
   hipEvent_t ev0 = nullptr, ev1 = nullptr;
   bool profiling = false;
@@ -261,7 +262,6 @@ int tile_gradients_impl(gpa_plan* p, const void* image, size_t image_pitch, int 
                                int mask_border, int i0, int j0, int t0, int t1, void* dx, size_t dx_pitch, size_t dx_plane,
                                void* dy, size_t dy_pitch, size_t dy_plane, void* wn, size_t wn_pitch, size_t wn_plane);
 int plan_event(gpa_plan* p);
-int invert_u_host(gpa_plan* p, const void* u, int iters, int edge, int shift, void* out, int mode, bool overlap);
 int per_dft_staged(gpa_plan* p);
 int gaussian_weights(double sigma, std::vector<double>& w);
 bool solve3(const double* m /*uu uv u vv v 1*/, const double* b, double* x);

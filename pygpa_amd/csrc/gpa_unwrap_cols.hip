@@ -117,11 +117,13 @@ __global__ __launch_bounds__((ColGeom<T, LG, LAT>::THREADS)) void colsolve_kerne
     // fused path: the update of iteration it-1 was applied by this iteration's row kernel;
     // every workgroup evaluates the reference's stopping test (phase_unwrap.py:348) on it
     const double tot = block_sum(norm_part, shn);
-    const bool stop = sqrt(tot) < eps * sqrt(norm0) || tot == 0.0 || !(tot == tot) || tot > 1e4 * best;
+    double stall;
+    const bool stop = sqrt(tot) < eps * sqrt(norm0) || tot == 0.0 || pcg_breakdown(tot, best, norm0, sizeof(T) == 4, scal[SC_STALL + ((it - 1) & 1)], &stall);
     if (blockIdx.x == 0 && threadIdx.x == 0) {
       flags[0] = it;                                   // updates completed
       scal[6] = tot;
       scal[10 + (it & 1)] = tot < best ? tot : best;
+      scal[SC_STALL + (it & 1)] = stall;
       if (stop) flags[1] = 1;
     }
     if (stop) return;
@@ -302,11 +304,13 @@ __global__ __launch_bounds__(1024) void colsolve_tri_kernel(const T* __restrict_
     // the reference's stopping test (phase_unwrap.py:348) on the update the row kernel has just applied
     const double tot = reduce_partials(part_norm, nnorm, shn);
     const double best = scal[10 + ((it - 1) & 1)];
-    const bool stop = sqrt(tot) < eps * sqrt(scal[5]) || tot == 0.0 || !(tot == tot) || tot > 1e4 * best;
+    double stall;
+    const bool stop = sqrt(tot) < eps * sqrt(scal[5]) || tot == 0.0 || pcg_breakdown(tot, best, scal[5], sizeof(T) == 4, scal[SC_STALL + ((it - 1) & 1)], &stall);
     if (blockIdx.x == 0 && threadIdx.x == 0) {
       flags[0] = it;
       scal[6] = tot;
       scal[10 + (it & 1)] = tot < best ? tot : best;
+      scal[SC_STALL + (it & 1)] = stall;
       if (stop) flags[1] = 1;
     }
     if (stop) return;

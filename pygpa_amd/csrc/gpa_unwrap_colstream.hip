@@ -180,7 +180,7 @@ __global__ __launch_bounds__(64 * G) void colstream_scan_kernel(int n0, int n1, 
                                                                double* __restrict__ carP, double* __restrict__ carZ, double* __restrict__ col0,
                                                                int* flags, const double* part_norm, int nnorm, int it, double eps,
                                                                double* scal, double* part_rho, int rho_slot, size_t pimg,
-                                                               size_t pagg) {
+                                                               size_t pagg, int f32) {
   {
     const size_t pb = blockIdx.z;
     agg += pb * pagg;
@@ -225,11 +225,13 @@ __global__ __launch_bounds__(64 * G) void colstream_scan_kernel(int n0, int n1, 
     // the reference's stopping test (phase_unwrap.py:348) on the update the row kernel has just applied, evaluated by
     // every workgroup of this launch; the other two launches of the solve read the flag
     const double tot = block_sum(norm_part, shn);
-    const bool stop = sqrt(tot) < eps * sqrt(norm0) || tot == 0.0 || !(tot == tot) || tot > 1e4 * best;
+    double stall;
+    const bool stop = sqrt(tot) < eps * sqrt(norm0) || tot == 0.0 || pcg_breakdown(tot, best, norm0, f32 != 0, scal[SC_STALL + ((it - 1) & 1)], &stall);
     if (blockIdx.x == 0 && threadIdx.x == 0) {
       flags[0] = it;
       scal[6] = tot;
       scal[10 + (it & 1)] = tot < best ? tot : best;
+      scal[SC_STALL + (it & 1)] = stall;
       if (stop) flags[1] = 1;
     }
     if (stop) return;
@@ -488,7 +490,7 @@ hipError_t run_stream(const Impl* w, int compat, hipStream_t s, const double* pa
 #define GPA_SCAN(GG, MM)                                                                                                   \
   colstream_scan_kernel<GG, MM><<<gs, 64 * GG, 0, s>>>(n0, n1, C, S, (const StreamCol*)w->strtab, (const double2*)w->stragg, \
                                                           agg0, carP, carZ, col0, w->flags, part_norm, nnorm, it, eps, w->scal, \
-                                                          part_rho, nparts, pimg, pagg)
+                                                          part_rho, nparts, pimg, pagg, w->dtype == 0 ? 1 : 0)
     if (S <= 16) GPA_SCAN(4, 4);
     else if (S <= 32) GPA_SCAN(8, 4);
     else if (S <= 64) GPA_SCAN(8, 8);

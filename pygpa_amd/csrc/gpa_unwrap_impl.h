@@ -97,6 +97,7 @@ hipError_t pow2_pqdct(const Impl* w, const void* p, const void* weight, double* 
 bool pow2_rowpers_offered(const Impl* w);
 hipError_t pow2_rowidct_p_pers(const Impl* w, const void* pin, void* pout, const double* part_rho, int nrho, int it,
                                hipStream_t s);
+hipError_t pow2_pqdct_pers(const Impl* w, const void* p, const void* weight, double* part_pq, int* npq, hipStream_t s);
 // columns (gpa_unwrap_cols.hip): every size
 hipError_t dispatch_colsolve(const Impl* w, int compat, hipStream_t s, const double* part_norm, int nnorm, int it,
                              double eps, double* part_rho, int* nrho, const void* zin);
@@ -195,6 +196,8 @@ __device__ __forceinline__ bool solve_init(const double* __restrict__ part0, int
     scal[7] = tot;   // smallest ||r||^2 seen
     scal[10] = tot;
     scal[11] = tot;
+    scal[SC_ALPHA + RING_MAX] = 0.0;       // SC_STALL (defined below): iterations since the last new minimum
+    scal[SC_ALPHA + RING_MAX + 1] = 0.0;
     scal[1] = 0.0;
     flags[0] = 0;
     flags[2] = 0;
@@ -202,6 +205,25 @@ __device__ __forceinline__ bool solve_init(const double* __restrict__ part0, int
     flags[1] = tot == 0.0 ? 1 : 0;
   }
   return tot != 0.0;
+}
+
+// Breakdown guard of the stopping test (not in the reference, which iterates in f64 only).
+//  (1) NaN, or a residual 100 x above the smallest one seen: CG has lost conjugacy and would iterate into garbage.
+//  (2) f32 only, and only once the residual is at the f32 rounding floor (||r|| < 1e-5 ||r0||): PCG_STALL consecutive
+//      iterations without a new smallest residual.  An f32 iteration cannot improve further there, and pushed on it DRIFTS:
+//      rounding feeds the near-null low modes of the weighted Laplacian, which the residual does not see (measured: 2 % of
+//      |phi| at kmax = 100 on the 63 x 65 golden case, where the f64 reference converges after 15 iterations).
+// While the residual keeps falling -- the whole of a kmax = 10 solve of the benchmark image -- neither acts and the
+// reference's test (phase_unwrap.py:348) decides alone.  stall_prev / *stall_new: iterations since the last new minimum
+// (scal[SC_STALL + parity], double-buffered like the minimum itself).
+constexpr int SC_STALL = SC_ALPHA + RING_MAX;   // two slots
+constexpr double PCG_STALL = 2.0;
+__device__ __forceinline__ bool pcg_breakdown(double tot, double best, double norm0, bool f32, double stall_prev,
+                                              double* stall_new) {
+  const double st = tot < best ? 0.0 : stall_prev + 1.0;
+  *stall_new = st;
+  if (!(tot == tot) || tot > 1e4 * best) return true;
+  return f32 && best < 1e-10 * norm0 && st >= PCG_STALL;
 }
 
 // Scalars of the fused power-of-two path (single writer = block 0 of the named kernel;

@@ -311,11 +311,13 @@ __global__ __launch_bounds__(MAXT) void mr_colsolve_kernel(
     // the reference's stopping test (phase_unwrap.py:348), evaluated identically by every workgroup
     const double tot = reduce_partials(part_norm, nnorm, sh);
     const double best = scal[10 + ((it - 1) & 1)];
-    const bool stop = sqrt(tot) < eps * sqrt(scal[5]) || tot == 0.0 || !(tot == tot) || tot > 1e4 * best;
+    double stall;
+    const bool stop = sqrt(tot) < eps * sqrt(scal[5]) || tot == 0.0 || pcg_breakdown(tot, best, scal[5], sizeof(T) == 4, scal[SC_STALL + ((it - 1) & 1)], &stall);
     if (blockIdx.x == 0 && threadIdx.x == 0) {
       flags[0] = it;
       scal[6] = tot;
       scal[10 + (it & 1)] = tot < best ? tot : best;
+      scal[SC_STALL + (it & 1)] = stall;
       if (stop) flags[1] = 1;
     }
     if (stop) return;

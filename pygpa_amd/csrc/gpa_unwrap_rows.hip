@@ -1012,6 +1012,7 @@ inline bool use_row_half(const Impl* w) {
 
 bool pow2_pqdct_offered(const Impl* w) { return !w->generic && (w->lg1 == 11 || w->lg1 == 12) && (w->n0 % 2) == 0; }
 hipError_t pow2_pqdct(const Impl* w, const void* p, const void* weight, double* part_pq, int* npq, hipStream_t s) {
+  if (pow2_rowpers_offered(w) && w->n0 >= 16 && !opt_set(OPT_NO_PQPERS)) return pow2_pqdct_pers(w, p, weight, part_pq, npq, s);
   if (w->lg1 == 11) return w->dtype == 0 ? run_pqdct<float, 11>(w, p, weight, part_pq, npq, s) : run_pqdct<double, 11>(w, p, weight, part_pq, npq, s);
   if (w->lg1 == 12) return w->dtype == 0 ? run_pqdct<float, 12>(w, p, weight, part_pq, npq, s) : run_pqdct<double, 12>(w, p, weight, part_pq, npq, s);
   return hipErrorInvalidValue;

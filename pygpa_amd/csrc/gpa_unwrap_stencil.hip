@@ -106,6 +106,8 @@ __global__ void scal_init_kernel(const double* part, int nparts, double* scal, i
     scal[7] = tot;   // smallest ||r||^2 seen
     scal[10] = tot;
     scal[11] = tot;
+    scal[SC_STALL] = 0.0;
+    scal[SC_STALL + 1] = 0.0;
     scal[1] = 0.0;
     flags[0] = 0;
     flags[2] = 0;
@@ -136,7 +138,7 @@ __global__ void scal_alpha_kernel(const double* part, int nparts, double* scal, 
     scal[1] = scal[0];             // rho_prev
   }
 }
-__global__ void scal_stop_kernel(const double* part, int nparts, double* scal, int* flags, int kmax, double eps) {
+__global__ void scal_stop_kernel(const double* part, int nparts, double* scal, int* flags, int kmax, double eps, int f32) {
   if (flags[1]) return;
   __shared__ double sh[256];
   double acc = 0;
@@ -150,7 +152,9 @@ __global__ void scal_stop_kernel(const double* part, int nparts, double* scal, i
     // breakdown guard (not in the reference, which iterates in f64 only): once the
     // residual has bottomed out at the working precision CG loses conjugacy and the
     // residual grows again; stop instead of iterating into garbage.
-    if (!(tot == tot) || tot > 1e4 * scal[7]) flags[1] = 1;
+    double stall;
+    if (pcg_breakdown(tot, scal[7], scal[5], f32 != 0, scal[SC_STALL], &stall)) flags[1] = 1;
+    scal[SC_STALL] = stall;
     if (tot < scal[7]) scal[7] = tot;
   }
 }
@@ -565,7 +569,7 @@ hipError_t plain_tail_t(const Impl* w, const void* weight, void* phi, int nrow, 
   { GPA_PROF("update_kernel", s);
     update_kernel<T><<<gl, 256, 0, s>>>((const T*)pcur, (const T*)w->q, (T*)phi, (T*)w->r, npx, w->scal,
                                         w->part + 2 * MAXPART, w->flags); }
-  scal_stop_kernel<<<1, 256, 0, s>>>(w->part + 2 * MAXPART, gl, w->scal, w->flags, kmax, eps);
+  scal_stop_kernel<<<1, 256, 0, s>>>(w->part + 2 * MAXPART, gl, w->scal, w->flags, kmax, eps, w->dtype == 0 ? 1 : 0);
   return hipGetLastError();
 }
 }  // namespace

@@ -269,6 +269,15 @@ class HipTileBackend:
         """torch's current stream waits for component c's plan (its field is about to be sent / handed out)"""
         self.plan_c[c].stream_wait(self._torch_stream())
 
+    def undistort_tiles(self, image, u, out, uinv, rects):
+        """Lawler-Fujita on the global plan (gpa_undistort_image_dev): u_inv = invert_u_overlap(-u) and the deformed image
+        resampled at r + u_inv, for the output windows `rects` only (None: everywhere); ordered after torch's stream (the
+        broadcast that delivered u), and torch's stream after it"""
+        pl = self._plan(0)
+        pl.wait_stream(self._torch_stream())
+        pl.undistort_image_dev(image.data_ptr(), u.data_ptr(), out.data_ptr(), uinv_ptr=uinv.data_ptr(), rects=rects)
+        pl.stream_wait(self._torch_stream())
+
     def sync_device(self):
         self.torch.cuda.synchronize(self.device)
 
@@ -435,6 +444,40 @@ class TiledPipeline:
             self._broadcast(self.u[c], c % self.world)
         return self.u
 
+    # ---- Lawler-Fujita undistortion of the stitched field, sharded over the tiles ------------------------------------
+    def undistort(self, image, u=None):
+        """undistort_image (geometric_phase_analysis.py:935-974) with the field this pipeline produced: every rank holds u
+        (step() broadcasts it; pass another (2, N, M) device tensor otherwise) and is given the whole deformed `image`
+        (host array or device tensor -- every rank the same, as for load()).  The fixed-point inversion (35 + 1 rounds of two
+        cubic-spline interpolations per pixel) and the final resampling are independent per output pixel: rank r computes
+        them for the interiors of the tiles it owns (gpa_undistort_image_dev with those windows; the spline prefilter of the
+        whole field, ~3 % of the work, runs on every rank), and one all_reduce of the zero-filled outputs hands every rank
+        the whole undistorted image and u_inv.  Returns (undistorted (N, M), u_inv (2, N, M)) as device tensors.  No host
+        round trip of u."""
+        torch = self.torch
+        u = self.u if u is None else u
+        t_dt = torch.float32 if self.dtype == np.float32 else torch.float64
+        if not torch.is_tensor(image):
+            image = torch.from_numpy(np.ascontiguousarray(image, dtype=self.dtype))
+        image = image.to(device=self.dev, dtype=t_dt).contiguous()
+        if getattr(self, '_lf', None) is None:
+            self._lf = (torch.zeros(self.shape, dtype=t_dt, device=self.dev), torch.zeros((2,) + self.shape, dtype=t_dt, device=self.dev))
+        out, uinv = self._lf
+        if self.world == 1:
+            self.be.undistort_tiles(image, u, out, uinv, None)
+            return out, uinv
+        t0, t1 = self.tshape
+        rects = [(self.tiles[idx][0][0] * t0, self.tiles[idx][0][1] * t1, self.tiles[idx][3][0], self.tiles[idx][3][1]) for idx in self.mine]
+        out.zero_()
+        uinv.zero_()
+        if rects:
+            self.be.undistort_tiles(image, u, out, uinv, rects)
+        for t in (out, uinv):
+            if self._host_staged():
+                self.be.sync_device()
+            self._all_reduce_sum(t)      # every pixel has ONE non-zero contributor: the sum is exact
+        return out, uinv
+
     # ---- image-pipelined schedule ---------------------------------------------------------------------------
     # step() leaves N - 2 of N GPUs idle during the global unwrap (54 % of single-GPU time).  For a STREAM of images
     # the unwrap of image i therefore runs on a rotating pair of ranks -- component c of image i on rank
@@ -586,7 +629,7 @@ class TiledPipeline:
     def close(self):
         if getattr(self, 'be', None) is not None:
             self.be.close()
-        for name in ('wins', 'local', 'gathered', 'gdx', 'gdy', 'gw', 'u', '_pbuf', '_pu', '_rx', 'rects', 'table_step',
+        for name in ('wins', 'local', 'gathered', 'gdx', 'gdy', 'gw', 'u', '_pbuf', '_pu', '_rx', '_lf', 'rects', 'table_step',
                      'table_stream'):
             setattr(self, name, None)
 

@@ -288,6 +288,19 @@ class OracleTileBackend:
             gdy[r0:r0 + zy, c0:c0 + z1] = blk[1, :zy, :z1]
             gw[r0:r0 + z0, c0:c0 + z1] = blk[2, :z0, :z1]
 
+    def undistort_tiles(self, image, u, out, uinv, rects):
+        """the oracle's undistort_image (scipy.ndimage.map_coordinates, the reference's calls) on the whole field, of which
+        only the given windows are handed out -- what gpa_undistort_image_dev does with its rects"""
+        from oracle import gpa_oracle as orc
+        un, ui = image.numpy().astype(np.float64), u.numpy().astype(np.float64)
+        full_inv = orc.invert_u_overlap(-ui)
+        full = orc.undistort_image(un, ui)
+        t = self.torch.from_numpy
+        n0, n1 = un.shape
+        for r0, c0, h, w in (rects if rects is not None else [(0, 0, n0, n1)]):
+            out[r0:r0 + h, c0:c0 + w] = t(full[r0:r0 + h, c0:c0 + w])
+            uinv[:, r0:r0 + h, c0:c0 + w] = t(full_inv[:, r0:r0 + h, c0:c0 + w])
+
     def stitch_to_tiles(self, c):
         self.stitch_waits = getattr(self, 'stitch_waits', 0) + 1
 
@@ -359,3 +372,43 @@ def test_pipelined_stream_equals_step(tmp_path, world):
         mp.spawn(_stream_worker, args=(world, _free_port(), out), nprocs=world, join=True)
     seen = np.concatenate([np.load(out % r) for r in range(world)])
     assert sorted(seen.tolist()) == [0, 1, 2, 3]      # every image's field arrived exactly once
+
+
+def _undistort_worker(rank, world, port, out_path):
+    sys.path.insert(0, ROOT)
+    if world > 1:
+        import torch.distributed as dist
+        dist.init_process_group('gloo', init_method='tcp://127.0.0.1:%d' % port, rank=rank, world_size=world)
+    from oracle import gpa_oracle as orc
+    from pygpa_amd import distributed as D
+    _, kvecs, klists = _case()
+    img = _stream_images(2)[1]
+    pipe = D.TiledPipeline(img.shape, kvecs, np.stack(klists), 6, 20, kmax=10, dtype=np.float64, grid=(2, 3),
+                           backend=OracleTileBackend())
+    pipe.load(img)
+    u = pipe.step().clone().numpy()
+    rec, uinv = pipe.undistort(img)
+    ref_rec, ref_inv = orc.undistort_image(img, u), orc.invert_u_overlap(-u)
+    assert np.array_equal(rec.numpy(), ref_rec), 'undistorted image differs from the whole-image call'
+    assert np.array_equal(uinv.numpy(), ref_inv)
+    np.save(out_path % rank, rec.numpy())
+    pipe.close()
+    if world > 1:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+@pytest.mark.parametrize('world', [1, 2, 3])
+def test_tile_sharded_undistort_equals_whole_image(tmp_path, world):
+    """configs[4]'s Lawler-Fujita stage inside the tile pipeline (TiledPipeline.undistort): every rank inverts / resamples the
+    interiors of its own tiles (6 tiles over 1, 2, 3 ranks) from the broadcast field, one all_reduce assembles them -- the
+    result on EVERY rank equals the whole-image undistort_image of the oracle bit for bit"""
+    import torch.multiprocessing as mp
+    out = str(tmp_path / 'rec_rank%d.npy')
+    if world == 1:
+        _undistort_worker(0, 1, 0, out)
+    else:
+        mp.spawn(_undistort_worker, args=(world, _free_port(), out), nprocs=world, join=True)
+    recs = [np.load(out % r) for r in range(world)]
+    for r in recs[1:]:
+        assert np.array_equal(r, recs[0])

@@ -364,6 +364,56 @@ class DeviceArray:
             pass
 
 
+@pytest.mark.parametrize('dtype', DTYPES)
+def test_f1_device_entry_points_equal_host_entry_points(dtype):
+    """round 5: gpa_invert_u_mode_dev / gpa_undistort_image_dev (device pointers, enqueued on the plan's stream, scratch
+    kept by the plan, no host round trip of u) against the host-pointer entry points they now back: BIT-identical fields,
+    both boundary modes, overlap and plain variant, the scale argument (undistort_image inverts -u); and the window
+    argument: four windows of the output grid, computed one after the other, assemble the whole-grid result."""
+    shape = (200, 168)
+    rng = np.random.default_rng(5)
+    ks = hex_kvecs(0.1, 7.0)
+    u = (0.6 * gaussian_bump_displacement(shape) + 0.05 * rng.normal(size=(2,) + shape)).astype(dtype)
+    deformed = hex_moire(shape, ks, u.astype(np.float64)).astype(dtype)
+    plan = _lib.Plan(shape, 1, dtype)
+    d_u, d_img = DeviceArray(u), DeviceArray(deformed)
+    for overlap, edge, mode in ((True, 0, 'nearest'), (True, 6, 'nearest'), (False, 3, 'nearest'), (True, 4, 'constant'), (False, 0, 'constant')):
+        host = plan.invert_u_overlap(u, iters=7, edge=edge, mode=mode) if overlap else plan.invert_u(u, iters=7, edge=edge, mode=mode)
+        d_out = DeviceArray(np.zeros_like(host))
+        plan.invert_u_dev(d_u.ptr, d_out.ptr, scale=1.0, iters=7, edge=edge, overlap=overlap, mode=mode)
+        plan.sync()
+        assert np.array_equal(d_out.get(), host, equal_nan=True), (overlap, edge, mode)
+        # scale = -1 on the device = the host call on -u
+        host_neg = plan.invert_u_overlap(-u, iters=7, edge=edge, mode=mode) if overlap else plan.invert_u(-u, iters=7, edge=edge, mode=mode)
+        plan.invert_u_dev(d_u.ptr, d_out.ptr, scale=-1.0, iters=7, edge=edge, overlap=overlap, mode=mode)
+        plan.sync()
+        assert np.array_equal(d_out.get(), host_neg, equal_nan=True), (overlap, edge, mode)
+    # undistort_image: whole grid, then as four windows (ragged split) into a poisoned buffer
+    rec_host = plan.undistort_image(deformed, u)
+    uinv_host = plan.invert_u_overlap(-u)
+    d_rec, d_uinv = DeviceArray(np.full(shape, -7.0, dtype)), DeviceArray(np.full((2,) + shape, -7.0, dtype))
+    plan.undistort_image_dev(d_img.ptr, d_u.ptr, d_rec.ptr, uinv_ptr=d_uinv.ptr)
+    plan.sync()
+    assert np.array_equal(d_rec.get(), rec_host) and np.array_equal(d_uinv.get(), uinv_host)
+    d_rec2, d_uinv2 = DeviceArray(np.full(shape, -7.0, dtype)), DeviceArray(np.full((2,) + shape, -7.0, dtype))
+    r_split, c_split = 77, 100
+    plan.undistort_image_dev(d_img.ptr, d_u.ptr, d_rec2.ptr, uinv_ptr=d_uinv2.ptr, rects=(0, 0, r_split, c_split))
+    plan.sync()
+    part = d_rec2.get()
+    assert np.array_equal(part[:r_split, :c_split], rec_host[:r_split, :c_split])
+    assert np.all(part[r_split:] == -7.0) and np.all(part[:, c_split:] == -7.0)      # nothing outside the window is touched
+    plan.undistort_image_dev(d_img.ptr, d_u.ptr, d_rec2.ptr, uinv_ptr=d_uinv2.ptr,          # three windows behind one prefilter
+                             rects=[(0, c_split, r_split, shape[1] - c_split), (r_split, 0, shape[0] - r_split, c_split),
+                                    (r_split, c_split, shape[0] - r_split, shape[1] - c_split)])
+    plan.sync()
+    assert np.array_equal(d_rec2.get(), rec_host) and np.array_equal(d_uinv2.get(), uinv_host)
+    # against the oracle (scipy.ndimage.map_coordinates, the reference's calls)
+    if dtype is np.float64:      # (f32: a sample a few ulps from the 'constant' border may land on its other side, see above)
+        ref = orc.undistort_image(deformed, u)
+        assert np.abs(rec_host - ref).max() < 1e-9 * np.abs(ref).max()
+    plan.close()
+
+
 def test_async_driver_and_plan_reuse():
     """gpa_extract_displacement_field_async on two plans (device pointers via torch), results equal
     to the synchronous host-pointer call; repeated calls with the same k-lists reuse the staged

@@ -206,7 +206,7 @@ def test_stack_of_2048_frames_equals_single_images():
     plan.close()
 
 
-@pytest.mark.parametrize('shape', [(4096, 4096), (2048, 4096), (64, 4096)])
+@pytest.mark.parametrize('shape', [(4096, 4096), (2048, 4096), (64, 4096), (2048, 2048)])
 def test_persistent_row_kernels_equal_per_pair_kernels(shape, gpa_option):
     """round 5: the persistent, software-pipelined row kernels of gpa_unwrap_rowpers.hip (4096-point f32 rows: LDS-DMA of
     the next row pair into the other LDS buffer while the current one is transformed) against the one-pair-per-workgroup
@@ -226,6 +226,12 @@ def test_persistent_row_kernels_equal_per_pair_kernels(shape, gpa_option):
         b, it_b = plan.unwrap_prediff(dx, dy, w, kmax=kmax)
         plan.close()
         gpa_option('NO_ROWPERS', None)
+        gpa_option('NO_PQPERS', '1')                        # persistent rowidct_p with the per-pair stencil + transform kernel
+        plan = _lib.Plan(shape, 1, np.float32)
+        c, it_c = plan.unwrap_prediff(dx, dy, w, kmax=kmax)
+        plan.close()
+        gpa_option('NO_PQPERS', None)
+        assert it_c == kmax and np.array_equal(a, c), (shape, kmax, float(np.abs(a - c).max()))
         assert np.isfinite(a).all()
         assert np.array_equal(a, a2)                       # run to run (no race between DMA, reads and exchanges)
         assert it_a == it_b == kmax
