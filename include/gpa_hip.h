@@ -67,10 +67,6 @@ void* gpa_plan_stream(const gpa_plan* plan);
 /* FFT lengths used along each axis (== n for powers of two, else the next power
  * of two >= 2n-1; the circular Gaussian convolution is evaluated exactly either way) */
 int gpa_plan_fft_len(const gpa_plan* plan, int axis);
-/* 1 when the sweep kernels transform this axis at its own length n on the mixed-radix engine (opt-in: option NATIVE;
- * n smooth, not a power of two, padded transform >= NATIVE_RATIO n; decided per sigma by the last call that took
- * one) -- gpa_plan_fft_len keeps reporting the padded geometry, which the shared-forward kernels still use */
-int gpa_plan_axis_native(const gpa_plan* plan, int axis);
 
 /* a1/a2 -- batched spatial lock-in
  *   out[b] = ifft2( fft2(image * exp(2 pi i (x kx_b + y ky_b))) * G_sigma )

@@ -31,7 +31,6 @@ SIGNATURES = {
     'gpa_plan_workspace_bytes': (_sz, [_vp]),
     'gpa_plan_stream': (_vp, [_vp]),
     'gpa_plan_fft_len': (_i, [_vp, _i]),
-    'gpa_plan_axis_native': (_i, [_vp, _i]),
     'gpa_lockin_batch': (_i, [_vp, _vp, _vp, _i, _d, _vp]),
     'gpa_lockin_batch_dev': (_i, [_vp, _vp, _vp, _i, _d, _vp]),
     'gpa_sweep': (_i, [_vp, _vp, _vp, _vp, _i, _d, _vp, _vp, _vp]),
@@ -131,27 +130,44 @@ def check(code, what):
         raise GPAError('%s failed (%d): %s' % (what, code, last_error()))
 
 
+_OPTION_VALUES = {}     # what this process has set through set_option (name -> str); a name that is absent follows the
+#                         library's start-up value, i.e. the GPA_<NAME> environment variable read once
+
+
 def set_option(name, value):
     """gpa_set_option: a diagnostic / test switch of the library ('NO_LAT', 'COLSOLVE', 'F32_EPS_FLOOR', ...; the
     names of INTEGRATION.md).  value None clears it.  The library reads the GPA_<NAME> environment variables once, when
     it is first used; afterwards only this call changes a switch."""
     check(load().gpa_set_option(str(name).encode(), None if value is None else str(value).encode()), 'gpa_set_option')
+    _OPTION_VALUES[str(name)] = None if value is None else str(value)
+
+
+def get_option(name):
+    """the value a switch currently has as far as this process can know: what set_option last gave it, else the GPA_<NAME>
+    environment variable the library read at start-up (None: unset)"""
+    name = str(name)
+    if name in _OPTION_VALUES:
+        return _OPTION_VALUES[name]
+    return os.environ.get('GPA_' + name)
 
 
 class options:
-    """with options(NO_LAT=1, COLSOLVE='tri'): ...  -- switches set for the block and cleared after it"""
+    """with options(NO_LAT=1, COLSOLVE='tri'): ...  -- switches set for the block; afterwards every one of them is back at the
+    value it had before (an outer options() block's, the environment's, or unset), not simply cleared"""
 
     def __init__(self, **kw):
         self.kw = kw
+        self.prev = {}
 
     def __enter__(self):
         for k, v in self.kw.items():
+            self.prev[k] = get_option(k)
             set_option(k, v)
         return self
 
     def __exit__(self, *exc):
         for k in self.kw:
-            set_option(k, None)
+            set_option(k, self.prev.get(k))
         return False
 
 
@@ -213,10 +229,6 @@ class Plan:
 
     def fft_len(self, axis):
         return self.lib.gpa_plan_fft_len(self.handle, axis)
-
-    def axis_native(self, axis):
-        """True when the sweep runs this axis at its own length on the mixed-radix engine (after a call that took sigma)"""
-        return bool(self.lib.gpa_plan_axis_native(self.handle, axis))
 
     def sync(self):
         check(self.lib.gpa_plan_sync(self.handle), 'gpa_plan_sync')

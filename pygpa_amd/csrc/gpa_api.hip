@@ -10,10 +10,10 @@ int gpa_fail(int code, const std::string& msg) {
 // ---- run-time options -------------------------------------------------------------------------
 namespace gpa {
 static const char* const kOptNames[OPT_COUNT] = {
-    "PBS_FULLBAND", "USE_GRAPH", "SERIAL_UNWRAP", "NO_WORKER", "NO_KSPLIT", "NO_COMPACT", "NO_SHARED", "SHARED_A",
+    "PBS_FULLBAND", "SERIAL_UNWRAP", "NO_WORKER", "NO_KSPLIT", "NO_COMPACT", "NO_SHARED",
     "NO_PAIR", "PBS_E8", "TRI_SMALL", "TRI_Q", "NO_MR", "MR_FORCE_BLUESTEIN", "NO_ROWPQ", "COLSOLVE", "NO_LAT",
-    "F32_EPS_FLOOR", "COLSTREAM_CHUNK", "NO_ROWHALF", "PAIR_MAXSIDE", "ROWHALF_MINLG", "NO_PQDCT", "NATIVE",
-    "NATIVE_RATIO", "NATIVE_SHARED", "NO_REORDER", "NO_RAW", "NO_TILEFUSE", "NO_ROWPERS", "NO_PQPERS"};
+    "F32_EPS_FLOOR", "COLSTREAM_CHUNK", "NO_ROWHALF", "PAIR_MAXSIDE", "ROWHALF_MINLG", "NO_PQDCT",
+    "NO_REORDER", "NO_RAW", "NO_TILEFUSE", "NO_ROWPERS"};
 static OptVal g_opts[OPT_COUNT];
 static std::once_flag g_opts_once;
 static void opt_assign(OptVal& o, const char* value) {
@@ -51,9 +51,6 @@ Axis make_axis(int n) {
   a.L = 1 << lg;
   a.extL = a.padded ? n - 1 : 0;
   a.extR = 0;
-  a.native = false;
-  a.pl = MrPlan{};
-  a.natW = a.natH = nullptr;
   return a;
 }
 
@@ -110,7 +107,7 @@ int plan_build(gpa_plan* p) {
   // start with what the non-sweep users need (<= 8 real planes) and grow in ensure_tbuf()
   p->tbuf_planes = B < 4 ? B : 4;
   TRY(dmalloc(p, &p->Tbuf, (size_t)p->tbuf_planes * npx * p->csz));
-  // (carrier base tables: one entry per thread of a transform -- L / 16, or up to 256 for an axis in native mode)
+  // (carrier base tables: one entry per thread of a transform, L / 16)
   TRY(dmalloc(p, &p->tb.cxb, (size_t)B * std::max(p->ax0.L / 16, 256) * p->csz));
   TRY(dmalloc(p, &p->tb.sx, (size_t)B * 16 * p->csz));
   TRY(dmalloc(p, &p->tb.wxw, (size_t)B * p->csz));
@@ -207,7 +204,6 @@ gpa_plan* gpa_plan_create(int device, int n0, int n1, int max_batch, int dtype) 
   p->csz = 2 * p->rsz;
   p->ax0 = p->ax0_full = make_axis(n0);
   p->ax1 = p->ax1_full = make_axis(n1);
-  p->use_graphs = opt_set(OPT_USE_GRAPH);
   p->serial_unwrap = opt_set(OPT_SERIAL_UNWRAP);
   p->use_worker = !opt_set(OPT_NO_WORKER);
   p->no_ksplit = opt_set(OPT_NO_KSPLIT);
@@ -235,16 +231,11 @@ void gpa_plan_destroy(gpa_plan* p) {
   delete p->worker;
   p->worker = nullptr;
   if (p->stream) hipStreamSynchronize(p->stream);
-  for (auto& g : p->graphs) {
-    if (g.exec) hipGraphExecDestroy(g.exec);
-    if (g.graph) hipGraphDestroy(g.graph);
-  }
-  p->graphs.clear();
   void* bufs[] = {p->tw0, p->tw1, p->Hx, p->Hy, p->Tbuf, p->tb.cxb, p->tb.sx, p->tb.wxw, p->tb.wxr, p->tb.cyb, p->tb.sy, p->tb.wyw, p->tb.wyr, p->tb.planeof, p->d_pw,
                   p->tb.dx, p->tb.dy, p->d_kl, p->d_kr, p->d_image, p->d_mean, p->d_tile_mean, p->d_scratch,
                   p->d_lockin, p->d_kidx, p->d_dudx, p->d_dudy, p->d_wnorm, p->d_u, p->d_kmat, p->d_sf, p->d_grad, p->d_aux0, p->d_aux1,
                   p->sh.Gb, p->sh.psi, p->sh.dyc, p->sh.gtab, p->sh.desc, p->sh.order, p->d_taps, p->tw1s,
-                  p->tw0s, p->d_taps0, p->shA_gtab, p->shA_Gx, p->shA_psi, p->shA_sx, p->sh.pre, p->sh.rot16, p->d_wys, p->d_shifts, p->d_ystep};
+                  p->sh.pre, p->sh.rot16, p->d_wys, p->d_shifts, p->d_ystep};
   for (void* b : bufs)
     if (b) hipFree(b);
   unwrap_workspace_destroy(&p->uw);
@@ -260,7 +251,6 @@ void gpa_plan_destroy(gpa_plan* p) {
   if (p->ev_join) hipEventDestroy(p->ev_join);
   if (p->ev_x) hipEventDestroy(p->ev_x);
   if (p->d_tsum_part) (void)hipFree(p->d_tsum_part);
-  if (p->d_ticket) (void)hipFree(p->d_ticket);
   warp_ws_free(&p->warp);
   blue_axis_destroy(&p->bx0);
   blue_axis_destroy(&p->bx1);
@@ -294,10 +284,6 @@ void* gpa_plan_stream(const gpa_plan* p) { return p ? (void*)p->stream : nullptr
 int gpa_plan_fft_len(const gpa_plan* p, int axis) {
   if (!p) return 0;
   return axis == 0 ? p->ax0.L : p->ax1.L;
-}
-int gpa_plan_axis_native(const gpa_plan* p, int axis) {
-  if (!p) return 0;
-  return (axis == 0 ? p->ax0.native : p->ax1.native) ? 1 : 0;
 }
 
 // ---- timing --------------------------------------------------------------------

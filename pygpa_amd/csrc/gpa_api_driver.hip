@@ -84,7 +84,7 @@ int extract_launch(gpa_plan* p, const void* image, int P, int K, int Bx, int mas
   HIP_TRY(hipEventRecord(p->ev_fork, p->stream));
   HIP_TRY(hipStreamWaitEvent(p->stream2, p->ev_fork, 0));
   // the second component's launches go out from the plan's helper thread while this thread enqueues the first
-  // (not while profiling -- the per-kernel event pairs belong to this thread -- or capturing a graph)
+  // (not while profiling: the per-kernel event pairs belong to this thread)
   hipStreamCaptureStatus cap = hipStreamCaptureStatusNone;
   (void)hipStreamIsCapturing(p->stream, &cap);
   const bool threaded = p->use_worker && !p->profiling && !p->serial_unwrap && cap == hipStreamCaptureStatusNone;
@@ -113,23 +113,10 @@ int extract_launch(gpa_plan* p, const void* image, int P, int K, int Bx, int mas
   return GPA_OK;
 }
 
-void drop_graphs(gpa_plan* p) {
-  if (p->graphs.empty()) return;
-  (void)hipStreamSynchronize(p->stream);   // an executable graph may still be running
-  for (auto& g : p->graphs) {
-    if (g.exec) hipGraphExecDestroy(g.exec);
-    if (g.graph) hipGraphDestroy(g.graph);
-  }
-  p->graphs.clear();
-}
-
-// enqueue the whole driver on the plan's streams without any host synchronisation.
-// A call is ~110 kernel launches.  They depend only on (pointers, P, K, x-planes, border, kmax) -- the tables
-// the kernels read are restaged in place by extract_stage -- so with GPA_USE_GRAPH=1 the second call with one
-// key captures them into a hipGraph (both streams) and later calls replay it.  Measured on MI355X / ROCm 7.2
-// (profiles/r02_graph_vs_eager.txt) the replay is NOT faster than eager launches at any size (512^2: 0.65 vs
-// 0.60 ms; 4096^2: equal) and it serialises with the copy stream of gpa_download_async (9.4 vs 6.75 ms with
-// the D2H of u in the step), so eager launching is the default.
+// enqueue the whole driver on the plan's streams without any host synchronisation: ~110 eager kernel launches.
+// (Rounds 2-4 could capture them into a hipGraph -- USE_GRAPH=1 -- and replay it: measured NOT faster than eager launches at
+// any size on MI355X / ROCm 7.2, 512^2 0.65 against 0.60 ms, 4096^2 equal, and it serialised with the copy stream of
+// gpa_download_async: profiles/r02_graph_vs_eager.txt.  Removed in round 5; git history has it.)
 int extract_enqueue(gpa_plan* p, const void* image, const double* kvecs, int P, const double* klists, int K,
                            double sigma, int mask_border, int kmax, void* u, void* lockins, int32_t* kidx) {
   if (!p || !image || !kvecs || !klists || !u) return fail(GPA_ERR_ARG, "gpa_extract_displacement_field: null argument");
@@ -142,53 +129,7 @@ int extract_enqueue(gpa_plan* p, const void* image, const double* kvecs, int P, 
   void* lk = lockins ? lockins : p->d_lockin;
   // per-kernel event pairs while profiling (installed for this thread until the function returns)
   ProfInstall prof(p);
-  if (p->profiling || !p->use_graphs) return extract_launch(p, image, P, K, Bx, mask_border, kmax, u, lk, kidx, lockins != nullptr);
-  const GraphKey key = {image, u, lk, kidx, P, K, Bx, mask_border, kmax, p->tbuf_epoch, lockins != nullptr ? 1 : 0, 0};
-  GraphEntry* ent = nullptr;
-  for (auto& g : p->graphs)
-    if (memcmp(&g.key, &key, sizeof(GraphKey)) == 0) ent = &g;
-  if (ent && ent->exec) {
-    HIP_TRY(hipGraphLaunch(ent->exec, p->stream));
-    return GPA_OK;
-  }
-  if (!ent) {
-    // first call with this key: run eagerly (lazy allocations and function attributes happen here)
-    if (p->graphs.size() >= 8) drop_graphs(p);
-    GraphEntry g{};
-    g.key = key;
-    p->graphs.push_back(g);
-    return extract_launch(p, image, P, K, Bx, mask_border, kmax, u, lk, kidx, lockins != nullptr);
-  }
-  if (ent->failed) return extract_launch(p, image, P, K, Bx, mask_border, kmax, u, lk, kidx, lockins != nullptr);
-  // second call: capture
-  hipError_t ce = hipStreamBeginCapture(p->stream, hipStreamCaptureModeRelaxed);
-  if (ce != hipSuccess) {
-    (void)hipGetLastError();
-    ent->failed = true;
-    return extract_launch(p, image, P, K, Bx, mask_border, kmax, u, lk, kidx, lockins != nullptr);
-  }
-  const int rc = extract_launch(p, image, P, K, Bx, mask_border, kmax, u, lk, kidx, lockins != nullptr);
-  hipGraph_t graph = nullptr;
-  ce = hipStreamEndCapture(p->stream, &graph);
-  if (rc != GPA_OK || ce != hipSuccess || !graph) {
-    (void)hipGetLastError();
-    if (graph) hipGraphDestroy(graph);
-    ent->failed = true;
-    if (rc != GPA_OK) return rc;
-    return extract_launch(p, image, P, K, Bx, mask_border, kmax, u, lk, kidx, lockins != nullptr);
-  }
-  hipGraphExec_t exec = nullptr;
-  ce = hipGraphInstantiate(&exec, graph, nullptr, nullptr, 0);
-  if (ce != hipSuccess || !exec) {
-    (void)hipGetLastError();
-    hipGraphDestroy(graph);
-    ent->failed = true;
-    return extract_launch(p, image, P, K, Bx, mask_border, kmax, u, lk, kidx, lockins != nullptr);
-  }
-  ent->graph = graph;
-  ent->exec = exec;
-  HIP_TRY(hipGraphLaunch(exec, p->stream));
-  return GPA_OK;
+  return extract_launch(p, image, P, K, Bx, mask_border, kmax, u, lk, kidx, lockins != nullptr);
 }
 
 int gpa_extract_displacement_field_async(gpa_plan* p, const void* image, const double* kvecs, int P,
@@ -269,7 +210,6 @@ int gpa_extract_displacement_field_batch_dev(gpa_plan* p, const void* images, in
     p->b_chunk = chunk;
   }
   TRY(shared_prepare(p, P, K));
-  if (p->sh_use && p->ax1.native && !opt_set(OPT_NATIVE_SHARED)) p->sh_use = false;   // (as in passB_select)
   int nparts = 0;
   const size_t rstride = 2 * npx;                                                     // residual slices per image
   const size_t pstride = (size_t)(unwrap_partials_buffer(&p->uwb, 2) - unwrap_partials_buffer(&p->uwb, 0));

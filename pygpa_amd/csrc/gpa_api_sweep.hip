@@ -31,51 +31,9 @@ int gpa_lockin_batch(gpa_plan* p, const void* image, const double* kvecs, int B,
   return GPA_OK;
 }
 
-// per-plane tables of the shared-forward pass A for the staged x-planes: rebuilt when sigma or the k-list changed
-int sharedA_prepare(gpa_plan* p, int Bx, bool* use) {
-  *use = false;
-  // Opt-in (GPA_SHARED_A=1).  Measured at 4096^2, 3 x 4 planes, f32 (profiles/r03_passA_shared.txt): 1.0 - 1.2 ms against
-  // the per-plane kernel's 0.815 ms although its transforms alone take 0.43 ms against 0.51 ms: pass A is bound by
-  // the drain of its 32-byte-segment stores (~0.6 - 0.75 ms for 1.6 GB), which the per-plane kernel hides behind the
-  // forward transform of the NEXT plane (it needs nothing from memory), while the shared kernel's next plane starts
-  // with table loads that queue behind those stores.  Kept for the record and for the tests that pin its parity.
-  if (!p->shA_ok || !p->use_shared || Bx < 2 || !opt_set(OPT_SHARED_A)) return GPA_OK;
-  if (p->shA_built_epoch == p->sh_epoch && p->shA_built_Bx == Bx) { *use = true; return GPA_OK; }
-  p->shA_built_epoch = -1;   // committed again only when the tables are complete
-  HIP_TRY(hipStreamSynchronize(p->stream));
-  const size_t gx = (size_t)Bx * p->ax0s.L * p->rsz, ps = (size_t)Bx * p->shA_Epad * p->csz;
-  if (gx > p->shA_gx_bytes) {
-    if (p->shA_Gx) { (void)hipFree(p->shA_Gx); p->ws_bytes -= p->shA_gx_bytes; p->shA_Gx = nullptr; p->shA_gx_bytes = 0; }
-    TRY(dmalloc(p, &p->shA_Gx, gx));
-    p->shA_gx_bytes = gx;
-  }
-  if (ps > p->shA_psi_bytes) {
-    if (p->shA_psi) { (void)hipFree(p->shA_psi); p->ws_bytes -= p->shA_psi_bytes; p->shA_psi = nullptr; p->shA_psi_bytes = 0; }
-    TRY(dmalloc(p, &p->shA_psi, ps));
-    p->shA_psi_bytes = ps;
-  }
-  if (!p->shA_sx) TRY(dmalloc(p, &p->shA_sx, (size_t)p->max_batch * 16 * p->csz));
-  HIP_TRY(launch_sharedA_tables(p->dtype, p->ax0s, p->d_pw, p->d_taps0, p->shA_etab, p->shA_E, p->shA_Epad, Bx, p->shA_Gx,
-                                p->shA_psi, p->shA_sx, p->stream));
-  p->shA_built_epoch = p->sh_epoch;
-  p->shA_built_Bx = Bx;
-  *use = true;
-  return GPA_OK;
-}
-
-// pass A over the staged x-planes: one forward transform per column for all planes where the axis allows it
-// (gpa_passb_shared.h), the per-plane forward transforms otherwise
+// pass A over the staged x-planes (per-plane forward transforms, the image tile kept in registers)
 int run_passA(gpa_plan* p, const void* image, const void* mean, void* Tbuf, int Bx, int nimg) {
-  bool shared = false;
-  TRY(sharedA_prepare(p, Bx, &shared));
-  if (shared) {
-    SweepTables tb = p->tb;
-    tb.sx = p->shA_sx;     // stride factors of the kernel's own transform length
-    HIP_TRY(launch_passA_shared(p->dtype, p->ax0s, p->n1, image, mean, tb, p->ax0.L / 16, p->shA_Gx, p->shA_psi, p->shA_gtab,
-                                p->ax0s.L == p->ax0.L ? p->tw0 : p->tw0s, p->shA_E, p->shA_Epad, Tbuf, Bx, p->stream, nimg));
-  } else {
-    HIP_TRY(launch_passA(p->dtype, p->ax0, p->n1, image, mean, p->tb, p->Hx, p->tw0, Tbuf, Bx, p->stream, nimg));
-  }
+  HIP_TRY(launch_passA(p->dtype, p->ax0, p->n1, image, mean, p->tb, p->Hx, p->tw0, Tbuf, Bx, p->stream, nimg));
   return GPA_OK;
 }
 
@@ -94,11 +52,8 @@ int passB_select(gpa_plan* p, int P, int K, void* lockin, int32_t* kidx, bool ra
     while (ksplit < 4 && ksplit * 2 <= K && rows_wg * ksplit < 1024) ksplit *= 2;
   if (ksplit == 1) {
     TRY(shared_prepare(p, P, K));
-    // (a row in native mode: the per-candidate kernel at length n rather than the shared-forward kernel on the
-    //  zero-padded power of two, unless NATIVE_SHARED asks for the latter)
-    if (p->sh_use && p->ax1.native && !opt_set(OPT_NATIVE_SHARED)) p->sh_use = false;
     if (p->sh_use) {
-      p->lk_raw = raw && !opt_set(OPT_NO_RAW);
+      p->lk_raw = raw && !opt_set(OPT_NO_RAW) && p->sh_one_kref;
       HIP_TRY(launch_passB_shared(p->dtype, p->ax1s, p->n0, p->Tbuf, p->ax1s.L == p->ax1.L ? p->tw1 : p->tw1s, p->tb,
                                   p->sh, p->sh_E, p->sh_Epad, P, K, lockin, kidx, p->stream, 1, 0, p->sh_elems, p->sh_nbl,
                                   p->lk_raw));

@@ -122,10 +122,7 @@ void build_filter_table(const Axis& ax, const std::vector<double>& g, const std:
 
 int ensure_filters(gpa_plan* p, double sigma) {
   if (!(sigma > 0)) return fail(GPA_ERR_ARG, "sigma must be positive");
-  // NATIVE=1 (opt-in, measured slower: Axis::native): an axis that is not a power of two long runs at its own length on
-  // the mixed-radix engine when the padded transform would be at least NATIVE_RATIO (default 1.5) times as long
-  const double natkey = !opt_set(OPT_NATIVE) ? -1.0 : (opt_set(OPT_NATIVE_RATIO) ? opt(OPT_NATIVE_RATIO).num : 1.5);
-  if (sigma == p->sigma_cached && natkey == p->natkey_cached) return GPA_OK;
+  if (sigma == p->sigma_cached) return GPA_OK;
   HIP_TRY(hipStreamSynchronize(p->stream));   // the tables may still be read by an earlier asynchronous call
   p->sigma_cached = -1.0;   // a failure below must not leave half-switched tables behind a matching sigma
   for (int axis = 0; axis < 2; ++axis) {
@@ -137,87 +134,16 @@ int ensure_filters(gpa_plan* p, double sigma) {
       hsp = spatial_kernel(full.n, g);
       if (!p->no_compact) want = compact_axis(full, kernel_support(hsp, p->dtype == 0 ? 1e-9 : 1e-14));
     }
-    {
-      MrPlan pl{};
-      want.native = natkey > 0 && full.padded && full.n >= 48 && mr_make_plan(full.n, &pl) && pl.T <= 256 &&
-                    (double)want.L >= natkey * (double)full.n;
-      if (want.native) {
-        want.pl = pl;
-        void** Wd = axis == 0 ? &p->natW0 : &p->natW1;
-        void** Hd = axis == 0 ? &p->natH0 : &p->natH1;
-        if (!*Wd) {
-          TRY(dmalloc(p, Wd, (size_t)mr_lds_elems(full.n) * p->csz));
-          TRY(dmalloc(p, Hd, (size_t)full.n * p->rsz));
-          std::vector<double> t((size_t)2 * mr_lds_elems(full.n), 0.0);   // entry k at mr_pad(k), see mr_store()
-          for (int k = 0; k < full.n; ++k) {
-            t[2 * (size_t)mr_pad(k)] = cos(-2.0 * M_PI * k / full.n);
-            t[2 * (size_t)mr_pad(k) + 1] = sin(-2.0 * M_PI * k / full.n);
-          }
-          TRY(upload_real_table(p, *Wd, t));
-        }
-        std::vector<double> hn((size_t)full.n);
-        for (int k = 0; k < full.n; ++k) hn[k] = g[k] / (double)full.n;
-        TRY(upload_real_table(p, *Hd, hn));
-        want.natW = *Wd;
-        want.natH = *Hd;
-      }
-    }
-    if (want.lg != cur.lg || want.extR != cur.extR || want.extL != cur.extL || want.native != cur.native) {
+    if (want.lg != cur.lg || want.extR != cur.extR || want.extL != cur.extL) {
       // another transform length for this sigma: twiddles of that length, and the carrier tables (laid out per
       // L / 16 threads) have to be staged again
       TRY(upload_twiddles(p, axis == 0 ? p->tw0 : p->tw1, want.L));
       p->staged_kl.clear();
       p->staged_kr.clear();
-      drop_graphs(p);
       cur = want;
     }
     build_filter_table(cur, g, hsp, table);
     TRY(upload_real_table(p, axis == 0 ? p->Hx : p->Hy, table));
-    if (axis == 0) {
-      // shared-forward pass A: taps, support and (for lengths that are not powers of two) the zero-padded geometry
-      // of the x axis, exactly as for the y axis below
-      p->shA_ok = false;
-      const int n = cur.n;
-      int mmax = (int)ceil(10.0 * sigma) + 16;
-      if (p->use_shared && mmax < n / 2 && mmax <= 1024) {
-        std::vector<double> taps = spatial_taps(n, g, mmax);
-        double total = fabs(taps[0]), tail = 0;
-        for (int m = 1; m <= mmax; ++m) total += 2 * fabs(taps[m]);
-        int E = 1;
-        const double tol = p->dtype == 0 ? 1e-9 : 1e-14;
-        for (int m = mmax; m >= 1; --m) {
-          tail += 2 * fabs(taps[m]);
-          if (tail > tol * total) { E = m; break; }
-        }
-        Axis sa = cur;
-        if (cur.padded) {
-          sa.lg = 6;
-          while ((1 << sa.lg) < n + E) ++sa.lg;
-          sa.L = 1 << sa.lg;
-          sa.extL = sa.extR = 0;
-        }
-        if (passA_shared_supports(p->dtype, sa, E)) {
-          const int Epad = (E + 15) & ~15;
-          if (sa.L != cur.L && p->tw0s_L != sa.L) {
-            if (!p->tw0s) TRY(dmalloc(p, &p->tw0s, (size_t)4096 * p->csz));
-            TRY(upload_twiddles(p, p->tw0s, sa.L));
-            p->tw0s_L = sa.L;
-          }
-          p->ax0s = sa;
-          if (!p->d_taps0) TRY(dmalloc(p, (void**)&p->d_taps0, 1025 * sizeof(double)));
-          if (!p->shA_gtab) TRY(dmalloc(p, &p->shA_gtab, (2 * 256 + 16) * p->rsz));
-          HIP_TRY(hipMemcpyAsync(p->d_taps0, taps.data(), ((size_t)mmax + 1) * sizeof(double), hipMemcpyHostToDevice, p->stream));
-          HIP_TRY(hipStreamSynchronize(p->stream));
-          std::vector<double> gt((size_t)2 * Epad + 16, 0.0);
-          for (int m = 1; m <= E; ++m) gt[m] = taps[m];
-          TRY(upload_real_table(p, p->shA_gtab, gt));
-          p->shA_etab = mmax;
-          p->shA_E = E;
-          p->shA_Epad = Epad;
-          p->shA_ok = true;
-        }
-      }
-    }
     if (axis == 1) {
       // shared-forward pass B: the taps of this axis' filter out to where they are rounding noise, the support E
       // beyond which they are dropped from the end fix (the same criterion as the compact extension above)
@@ -270,7 +196,6 @@ int ensure_filters(gpa_plan* p, double sigma) {
     }
   }
   p->sigma_cached = sigma;
-  p->natkey_cached = natkey;
   return GPA_OK;
 }
 
@@ -406,9 +331,14 @@ int shared_prepare(gpa_plan* p, int P, int K) {
     // raw mode of the kernel: what the winners lack is dyc[p][y] = exp(2 pi i (ky_p + shift_p / EE) y), i.e. this
     // phase step per column (reduced to (-pi, pi] in double)
     std::vector<double> ys((size_t)P);
+    p->sh_one_kref = true;
     for (int pp = 0; pp < P; ++pp) {
       const double c = p->staged_kr[2 * ((size_t)pp * K) + 1] + (double)shifts[pp] / EEs;
       ys[pp] = 2.0 * M_PI * (c - rint(c));
+      //  the step is ONE number per peak: every candidate of a peak must share the reference vector, as
+      // stage_kvectors' callers stage them today; a list that does not keeps the compensating pass B (passB_select)
+      for (int k = 1; k < K; ++k)
+        if (p->staged_kr[2 * ((size_t)pp * K + k) + 1] != p->staged_kr[2 * ((size_t)pp * K) + 1]) p->sh_one_kref = false;
     }
     if (!p->d_ystep) TRY(dmalloc(p, (void**)&p->d_ystep, (size_t)p->max_peaks * sizeof(double)));
     HIP_TRY(hipMemcpyAsync(p->d_ystep, ys.data(), (size_t)P * sizeof(double), hipMemcpyHostToDevice, p->stream));
@@ -484,7 +414,6 @@ int ensure_tbuf(gpa_plan* p, int planes) {
   p->tbuf_planes = 0;
   TRY(dmalloc(p, &p->Tbuf, (size_t)planes * npx * p->csz));
   p->tbuf_planes = planes;
-  ++p->tbuf_epoch;   // captured graphs hold the old pointer
   return GPA_OK;
 }
 

@@ -116,19 +116,15 @@ int gpa_tile_sums_dev(gpa_plan* p, const void* wins, size_t win_stride, size_t w
     return fail(GPA_ERR_ARG, "gpa_tile_sums_dev: bad argument");
   HIP_TRY(hipSetDevice(p->device));
   const size_t need = (size_t)ntiles * tile_sums_bands(max_rows);
-  if (need > p->tsum_cap || !p->d_ticket) {
+  if (need > p->tsum_cap) {
     HIP_TRY(hipStreamSynchronize(p->stream));
-    if (p->d_tsum_part) (void)hipFree(p->d_tsum_part);
+    if (p->d_tsum_part) { (void)hipFree(p->d_tsum_part); p->ws_bytes -= p->tsum_cap * sizeof(double); }
     p->d_tsum_part = nullptr;
-    HIP_TRY(hipMalloc((void**)&p->d_tsum_part, need * sizeof(double)));
+    p->tsum_cap = 0;
+    TRY(dmalloc(p, (void**)&p->d_tsum_part, need * sizeof(double)));
     p->tsum_cap = need;
-    if (!p->d_ticket) {
-      HIP_TRY(hipMalloc((void**)&p->d_ticket, 16));
-      HIP_TRY(hipMemsetAsync(p->d_ticket, 0, 16, p->stream));
-    }
   }
-  HIP_TRY(launch_tile_sums(p->dtype, wins, win_stride, win_pitch, rects_dev, ntiles, max_rows, p->d_tsum_part, p->d_ticket,
-                           sum_dev, p->stream));
+  HIP_TRY(launch_tile_sums(p->dtype, wins, win_stride, win_pitch, rects_dev, ntiles, max_rows, p->d_tsum_part, sum_dev, p->stream));
   return GPA_OK;
 }
 

@@ -69,10 +69,10 @@ inline hipError_t set_dynamic_lds_once(const void* kern, int bytes, unsigned& do
 // library first looks at it and changed afterwards only through gpa_set_option(): no getenv() on any call path.
 // A switch is "set" when it has a value at all (GPA_NO_LAT=0 is set, as it always was); num = atof(value).
 enum OptKey {
-  OPT_PBS_FULLBAND, OPT_USE_GRAPH, OPT_SERIAL_UNWRAP, OPT_NO_WORKER, OPT_NO_KSPLIT, OPT_NO_COMPACT, OPT_NO_SHARED,
-  OPT_SHARED_A, OPT_NO_PAIR, OPT_PBS_E8, OPT_TRI_SMALL, OPT_TRI_Q, OPT_NO_MR, OPT_MR_FORCE_BLUESTEIN, OPT_NO_ROWPQ,
+  OPT_PBS_FULLBAND, OPT_SERIAL_UNWRAP, OPT_NO_WORKER, OPT_NO_KSPLIT, OPT_NO_COMPACT, OPT_NO_SHARED,
+  OPT_NO_PAIR, OPT_PBS_E8, OPT_TRI_SMALL, OPT_TRI_Q, OPT_NO_MR, OPT_MR_FORCE_BLUESTEIN, OPT_NO_ROWPQ,
   OPT_COLSOLVE, OPT_NO_LAT, OPT_F32_EPS_FLOOR, OPT_COLSTREAM_CHUNK, OPT_NO_ROWHALF, OPT_PAIR_MAXSIDE, OPT_ROWHALF_MINLG, OPT_NO_PQDCT,
-  OPT_NATIVE, OPT_NATIVE_RATIO, OPT_NATIVE_SHARED, OPT_NO_REORDER, OPT_NO_RAW, OPT_NO_TILEFUSE, OPT_NO_ROWPERS, OPT_NO_PQPERS, OPT_COUNT
+  OPT_NO_REORDER, OPT_NO_RAW, OPT_NO_TILEFUSE, OPT_NO_ROWPERS, OPT_COUNT
 };
 struct OptVal {
   bool set;
@@ -98,26 +98,17 @@ inline bool opt_set(OptKey k) { return opt(k).set; }
 //           transform): the kernel of a Gaussian filter is negligible beyond E samples (the host measures E on
 //           the actual taps: everything dropped sums to < 1e-14 (f64) / 1e-9 (f32) of sum|h|), so lags -E .. E
 //           suffice, extL = extR = E and L >= n + 2E.
-// Native mode (round 4, gpa_sweep_mr.hip; OPT-IN, option NATIVE): a smooth length n = 2^a 3^b 5^c 7^d 11^e 13^f that is
-//           not a power of two and whose padded transform would be >= NATIVE_RATIO (1.5) n long is transformed at its
-//           OWN length on the mixed-radix LDS-resident engine (gpa_mrfft.h): periodic mode at length n, no extension.
-//           lg / L / ext* keep describing the padded geometry (the shared-forward kernels derive theirs from it);
-//           `native` sends the per-plane pass A and the per-candidate pass B kernels to their mixed-radix twins, which
-//           read natW / natH instead of the power-of-two twiddles and filter table.  Measured SLOWER than the padded
-//           path at every size tried (profiles/r04_native_sweep_rejected.txt), hence not the default.
+// (Round 4's opt-in native-length mode of the sweep -- pass A / per-candidate pass B on the mixed-radix engine at the axis' own
+//  length -- measured slower at every size (profiles/r04_native_sweep_rejected.txt) and was removed in round 5; git history.)
 struct Axis {
   int n;
   int lg;      // log2(L)
   int L;
   bool padded;
   int extL, extR;
-  bool native;        // per-plane / per-candidate kernels run the length-n transform `pl`
-  MrPlan pl;
-  const void* natW;   // device: w_n^i at mr_pad(i), cpx of the plan dtype
-  const void* natH;   // device: g[k] / n, k < n in natural order, reals of the plan dtype
 };
 // threads a transform of the axis is spread over = entries per candidate of the carrier base table
-inline int axis_tpf(const Axis& a) { return a.native ? a.pl.T : a.L / 16; }
+inline int axis_tpf(const Axis& a) { return a.L / 16; }
 
 // source sample of FFT slot m (-1: zero padding)
 GPA_HD int axis_src(int m, int n, int L, bool padded, int extL, int extR) {
@@ -184,13 +175,6 @@ hipError_t launch_passB_ext(int dtype, const Axis& a1, int n0, const void* Tbuf,
 hipError_t launch_passB_split(int dtype, const Axis& a1, int n0, const void* Tbuf, const void* Hy, const void* tw1,
                               const SweepTables& tb, int P, int K, int ksplit, void* part, int32_t* pidx, void* out,
                               int32_t* kidx, hipStream_t s);
-// the same passes on an axis in native mode (gpa_sweep_mr.hip); mode = PB_ALL / PB_SELECT / PB_GATED / PB_PHASES / PB_PART
-// of gpa_passb.h, ksplit > 1 only with PB_PART (grid.z), out / kidx then the slabs of launch_passB_split
-hipError_t launch_passA_mr(int dtype, const Axis& a0, int n1, const void* image, const void* mean, const SweepTables& tb,
-                           void* Tbuf, int Bx, hipStream_t s, int nimg);
-hipError_t launch_passB_mr(int dtype, const Axis& a1, int n0, const void* Tbuf, const SweepTables& tb, int P, int K, int mode,
-                           void* out, int32_t* kidx, const uint8_t* gate, void* psi, hipStream_t s, int ksplit, int nimg,
-                           int Bx);
 // a4: phase gradient of the winner from the per-candidate phases (mode 0 np.gradient, 1 forward differences with
 // NaN at the end, 2 the same with swapped components)
 hipError_t launch_phasegrad(int dtype, const void* psi, int K, const int32_t* kidx, int n0, int n1, const double* kl,
@@ -253,7 +237,7 @@ hipError_t launch_deconv_unpack(int dtype, const void* Z, int m0, int m1, int pa
 // sum over the interior rectangles rects_dev[t] = (o0, o1, z0, z1) of ntiles windows (win_stride / pitch in elements);
 // part: >= ntiles * tile_sums_bands(max_rows) doubles, ticket: one zeroed unsigned, out: one double
 hipError_t launch_tile_sums(int dtype, const void* wins, size_t win_stride, size_t pitch, const int* rects_dev, int ntiles,
-                            int max_rows, double* part, unsigned* ticket, double* out, hipStream_t s);
+                            int max_rows, double* part, double* out, hipStream_t s);
 int tile_sums_bands(int max_rows);
 hipError_t launch_set_mean(int dtype, const double* sum, double scale, void* mean_out, hipStream_t s);
 // nf <= 6 rectangular copies (rows x cols elements, pitches in elements) in one launch

@@ -48,15 +48,7 @@ hipError_t launch_passB_shared(int dtype, const Axis& a1, int n0, const void* Tb
 // raw: the winners are left WITHOUT the candidate-independent compensation exp(2 pi i (ky + s_p / 16) y) (no second visit
 // of the rows: 0.8 GB less traffic at 4096^2 x 3); the consumer adds its phase step along y (launch_reconstruct_setup)
 
-// ---- pass A with the forward transform shared by all x-planes of a column (same file) -------------------------------
-// a0: the kernel's own geometry of the x axis (periodic, or zero-padded to L >= n0 + E); tw0: twiddles of a0.L;
-// Gx [Bx][L] / psix [Bx][Epad] from launch_sharedA_tables (pw: device doubles, the distinct wx); gtab: Hankel taps of
-// the x axis; cxb_stride: entries per plane of tb.cxb.  tb.sx must hold exp(2 pi i wx (a0.L / 16) i): the sxs table of launch_sharedA_tables.
-bool passA_shared_supports(int dtype, const Axis& a0, int E);
-hipError_t launch_sharedA_tables(int dtype, const Axis& a0, const double* pw, const double* taps, int Etab, int E, int Epad,
-                                 int Bx, void* Gx, void* psix, void* sxs /*[Bx][16] stride factors for a0.L*/, hipStream_t s);
-hipError_t launch_passA_shared(int dtype, const Axis& a0, int n1, const void* image, const void* mean, const SweepTables& tb,
-                               int cxb_stride, const void* Gx, const void* psix, const void* gtab, const void* tw0, int E,
-                               int Epad, void* Tbuf, int B, hipStream_t s, int nimg = 1);
+// (Round 3's opt-in pass A with the forward transform shared by all x-planes of a column -- measured slower, 1.0-1.2 against
+//  0.815 ms: profiles/r03_passA_shared.txt -- was removed in round 5; git history has it.)
 
 }  // namespace gpa

@@ -524,398 +524,6 @@ __device__ __forceinline__ cpx<T> unit_phasor_s(double cycles) {
   return {(T)c, (T)s};
 }
 
-// ===============================================================================================================
-// Pass A with the forward transform shared by ALL x-planes of a column.
-//
-// The same identity along x: T_q(x) = C_x(img cx_q)(x) = exp(2 pi i wx_q x) [ (g_q (*) img)(x) + fix_q(x) ], with the
-// image itself -- no carrier -- under the forward transform.  A column is transformed ONCE for all the planes of all
-// peaks (13 transforms per column for 3 x 4 planes instead of 24), each plane multiplies its shifted real Gaussian
-// G(f + wx_q), transforms back, adds the end fix of the first / last E rows (the Hankel contraction again: per plane
-// 16 columns = 2 ends x C image columns x (re, im) -- one matrix tile wide at 4096 points) and applies the phasor.
-// The image is real, so the strips are real and the candidate phasor enters the contraction's B operand directly.
-// ===============================================================================================================
-template <class T, int LG>
-struct PassASGeom {
-  using F = WgFFT<T, LG>;
-  static_assert(F::P == 3, "three-pass transforms only");
-  static constexpr int TPF = F::TPF;
-  // columns per workgroup: as many as fit 1024 threads and the LDS left beside ~16 KB of fix-up tables
-  static constexpr int cols() {
-    int c = 16;
-    while (c > 1 && (c * TPF > 1024 || (size_t)c * (F::LDS_ELEMS + 32) * sizeof(cpx<T>) > 144 * 1024)) c /= 2;
-    return c;
-  }
-  static constexpr int C = cols();
-  static constexpr int NT = (sizeof(T) == 4 && C >= 2) ? 2 : 1;   // transforms per thread (adjacent columns)
-  static constexpr int CT = C / NT;
-  static constexpr int REGION = CT * F::LDS_ELEMS;
-  static constexpr int THREADS = CT * TPF;
-  static_assert(THREADS % 64 == 0, "whole wavefronts");
-  static constexpr int NWAVES = THREADS / 64;
-  static constexpr int NCOL = 4 * C;                               // matrix columns of one plane: (end, column, re / im)
-  static constexpr int NTILES = NCOL >= 16 ? NCOL / 16 : 1;
-  static constexpr int T1 = F::P1_SETS * 6;
-  // LDS beside the transform image, in reals: strips [2][C][ES] | results [2][C][ES] complex | phasors + post-factors
-  // of the plane [2 buffers][2][ES] complex | Hankel taps | pass-1 twiddles
-  __host__ __device__ static size_t extra_reals(int Epad) {
-    const size_t ES = (size_t)Epad + 4;
-    return 2 * C * ES + 2 * (2 * C * ES) + 2 * (2 * 2 * ES) * 2 + (2 * (size_t)Epad + 16) + 2 * T1;
-  }
-  __host__ __device__ static size_t lds_bytes(int Epad) {
-    return (size_t)NT * REGION * sizeof(cpx<T>) + extra_reals(Epad) * sizeof(T);
-  }
-};
-
-template <class T, int LG, bool PADDED>
-__global__ __launch_bounds__((PassASGeom<T, LG>::THREADS)) void passA_shared_kernel(
-    const T* __restrict__ image, const T* __restrict__ mean, int n0, int n1, const T* __restrict__ Gx,
-    const cpx<T>* __restrict__ twtab, const cpx<T>* __restrict__ cxb, const cpx<T>* __restrict__ sx,
-    const cpx<T>* __restrict__ psix, const T* __restrict__ gtab, int cxb_stride, int E, int Epad,
-    cpx<T>* __restrict__ Tout, int B, int bchunk) {
-  using F = WgFFT<T, LG>;
-  using G = PassASGeom<T, LG>;
-  using V4 = typename MfmaVec<T>::type;
-  constexpr int CT = G::CT, NT = G::NT, TPF = F::TPF, L = F::L, C = G::C;
-  extern __shared__ __attribute__((aligned(16))) char smem[];
-  const int c = threadIdx.x % CT, t = threadIdx.x / CT;
-  cpx<T>* lds = reinterpret_cast<cpx<T>*>(smem) + c;
-  const int ES = Epad + 4;
-  T* strip = reinterpret_cast<T*>(reinterpret_cast<cpx<T>*>(smem) + (size_t)NT * G::REGION);   // [2][C][ES]
-  cpx<T>* fixb = reinterpret_cast<cpx<T>*>(strip + 2 * C * ES);                                  // [2][C][ES]
-  cpx<T>* ptab = fixb + 2 * C * ES;                                                              // [2][2][ES]: trig, psi
-  T* glds = reinterpret_cast<T*>(ptab + 2 * 2 * ES);
-  cpx<T>* t1 = reinterpret_cast<cpx<T>*>(glds + 2 * Epad + 16);
-  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-  const int tile = xcd_tile(blockIdx.x, gridDim.x);
-  const int y0 = tile * C + c * NT;
-  image += (size_t)blockIdx.z * n0 * n1;
-  Tout += (size_t)blockIdx.z * B * n0 * n1;
-  const T m = mean ? mean[blockIdx.z] : T(0);
-
-  for (int i = threadIdx.x; i < 2 * Epad + 16; i += G::THREADS) glds[i] = gtab[i];
-  F::fill_pass1_table(t1, twtab, threadIdx.x, G::THREADS);
-
-  // ---- the columns, once: registers -> end strips (real) -> forward transform ------------------------------------
-  cpx<T> X[NT][16];
-#pragma unroll
-  for (int n = 0; n < NT; ++n) {
-    const int y = y0 + n;
-#pragma unroll
-    for (int i = 0; i < 16; ++i) {
-      const int xs = t + TPF * i;
-      X[n][i] = {(y < n1 && (!PADDED || xs < n0)) ? image[(size_t)xs * n1 + y] - m : T(0), T(0)};
-    }
-  }
-  if (t < Epad) {
-#pragma unroll
-    for (int n = 0; n < NT; ++n) {
-      const int y = y0 + n, col = c * NT + n;
-      const bool in = t < E && y < n1;
-      strip[(0 * C + col) * ES + t] = in ? X[n][0].x : T(0);                                   // img(j), j = t
-      strip[(1 * C + col) * ES + t] = in ? image[(size_t)(n0 - 1 - t) * n1 + y] - m : T(0);   // img(n0 - 1 - j)
-    }
-  }
-  __syncthreads();
-#ifndef GPA_PAS_TWMEM
-#define GPA_PAS_TWMEM 1     // twiddles read from the table where used: with them in registers the f32 kernel spills (112 B)
-#endif
-#ifndef GPA_PAS_NOFIX
-#define GPA_PAS_NOFIX 0     // diagnosis only
-#endif
-#ifndef GPA_PAS_GSTORE
-#define GPA_PAS_GSTORE 0    // experiment: plain global stores instead of the buffer descriptor
-#endif
-#ifndef GPA_PAS_NOSTORE
-#define GPA_PAS_NOSTORE 0   // diagnosis only
-#endif
-#if GPA_PAS_TWMEM
-  typename F::TwiddlesMem tw;
-  F::load_twiddles(tw, twtab, t);
-#else
-  typename F::TwiddlesP1Lds tw;
-  F::load_twiddles(tw, twtab, t, t1);
-#endif
-  F::template forward_multi<NT, CT>(X, lds, G::REGION, t, tw);
-
-  const int iA = PADDED ? (n0 - E) / TPF : 15, iB = PADDED ? (n0 - 1) / TPF : 15;
-  const int b0 = blockIdx.y * bchunk;
-  const int b1 = (b0 + bchunk < B) ? b0 + bchunk : B;
-  for (int b = b0; b < b1; ++b) {
-    F::refresh(tw);
-    const int par = b & 1;
-    // phasors exp(2 pi i wx j) and post-factors of this plane into LDS (double-buffered: the previous plane's
-    // fix-up may still be reading its copy)
-    cpx<T>* trig = ptab + (par * 2 + 0) * ES;
-    cpx<T>* psl = ptab + (par * 2 + 1) * ES;
-    if (!GPA_PAS_NOFIX) for (int j = threadIdx.x; j < Epad; j += G::THREADS) {
-      trig[j] = cxb[(size_t)b * cxb_stride + j];
-      psl[j] = psix[(size_t)b * Epad + j];
-    }
-    cpx<T> y[NT][16];
-    {
-      using gscalar = const __attribute__((address_space(1))) T;
-      gscalar* gq = (gscalar*)(Gx + (size_t)b * L);
-#pragma unroll
-      for (int i = 0; i < 16; ++i) {
-        const T h = gq[i * TPF + t];
-#pragma unroll
-        for (int n = 0; n < NT; ++n) y[n][i] = {X[n][i].x * h, X[n][i].y * h};
-      }
-    }
-#pragma unroll
-    for (int n = 0; n < NT; ++n) { F::template inv_phase<0, CT>(y[n], lds + n * G::REGION, t, tw); if (NT > 1) __builtin_amdgcn_sched_barrier(0); }
-    __syncthreads();
-    if (!GPA_PAS_NOFIX) {
-      // end-fix contraction of this plane: D[a][col] = sum_j g(a + 1 + j) img_end(j, column) trig(j), matrix column
-      // = (end, image column, re / im); work items (row tile, column tile) dealt over the wavefronts
-      const int Mt = (E + 15) >> 4;
-      const int kq = lane >> 4;
-      for (int w = wave; w < Mt * G::NTILES; w += G::NWAVES) {
-        const int mt = w / G::NTILES, nt = w % G::NTILES;
-        const int ncol = (nt * 16 + (lane & 15)) % G::NCOL;
-        const int reim = ncol & 1, col = (ncol >> 1) % C, end = (ncol >> 1) / C;
-        const T* sp = strip + (end * C + col) * ES;
-        // real / imaginary part of exp(+-2 pi i wx j): end 0 takes +, end 1 the conjugate
-        const T sgn = (reim && end) ? T(-1) : T(1);
-        V4 acc0 = {T(0), T(0), T(0), T(0)}, acc1 = {T(0), T(0), T(0), T(0)};
-        int ns = ((E - 16 * mt - 1) >> 2) + 1;
-        if (ns > (Epad >> 2)) ns = Epad >> 2;
-        const T* ga = glds + 16 * mt + (lane & 15) + kq + 1;
-        for (int s = 0; s < ns; s += 4) {
-          T sv[4], av[4];
-          cpx<T> tv[4];
-#pragma unroll
-          for (int u = 0; u < 4; ++u) {
-            int j = 4 * (s + u) + kq;
-            j = j < Epad ? j : Epad - 1;
-            sv[u] = sp[j];
-            tv[u] = trig[j];
-            av[u] = ga[4 * (s + u)];
-          }
-#pragma unroll
-          for (int u = 0; u < 4; ++u) {
-            const T bv = sv[u] * (reim ? sgn * tv[u].y : tv[u].x);
-            if (u & 1) acc1 = mfma16(av[u], bv, acc1);
-            else acc0 = mfma16(av[u], bv, acc0);
-          }
-        }
-        if (nt * 16 + (lane & 15) < G::NCOL) {
-#pragma unroll
-          for (int r = 0; r < 4; ++r) {
-            const int a0 = 16 * mt + mfma_row<T>(kq, r);
-            reinterpret_cast<T*>(fixb + (end * C + col) * ES + a0)[reim] = acc0[r] + acc1[r];
-          }
-        }
-      }
-    }
-#pragma unroll
-    for (int n = 0; n < NT; ++n) { F::template inv_phase<1, CT>(y[n], lds + n * G::REGION, t, tw); if (NT > 1) __builtin_amdgcn_sched_barrier(0); }
-    __syncthreads();
-#pragma unroll
-    for (int n = 0; n < NT; ++n) { F::template inv_phase<2, CT>(y[n], lds + n * G::REGION, t, tw); if (NT > 1) __builtin_amdgcn_sched_barrier(0); }
-    // ---- the first / last E rows get their wrapped pairs ------------------------------------------------------------
-#pragma unroll
-    for (int n = 0; n < NT && !GPA_PAS_NOFIX; ++n) {
-      const int col = c * NT + n;
-      if (t < E) {
-        const cpx<T> tt = cmulc(fixb[(1 * C + col) * ES + t], psl[t]);
-        y[n][0].x += tt.x;
-        y[n][0].y += tt.y;
-      }
-      if constexpr (!PADDED) {
-        const int a0 = TPF - 1 - t;
-        if (a0 < E) {
-          const cpx<T> tt = cmul(fixb[(0 * C + col) * ES + a0], psl[a0]);
-          y[n][15].x += tt.x;
-          y[n][15].y += tt.y;
-        }
-      } else {
-        const int aA = n0 - 1 - (t + TPF * iA), aB = aA - TPF;
-        const bool inA = aA >= 0 && aA < E, inB = aB >= 0 && aB < E && iB != iA;
-        const int qa = inA ? aA : 0, qb = inB ? aB : 0;
-        const cpx<T> ta = cmul(fixb[(0 * C + col) * ES + qa], psl[qa]), tb2 = cmul(fixb[(0 * C + col) * ES + qb], psl[qb]);
-        const cpx<T> fA = {inA ? ta.x : T(0), inA ? ta.y : T(0)}, fB = {inB ? tb2.x : T(0), inB ? tb2.y : T(0)};
-#pragma unroll
-        for (int i = 0; i < 16; ++i) {
-          if (i == iA) { y[n][i].x += fA.x; y[n][i].y += fA.y; }
-          if (i == iB && iB != iA) { y[n][i].x += fB.x; y[n][i].y += fB.y; }
-        }
-      }
-    }
-    // ---- the plane's phasor exp(2 pi i wx x), then out (two adjacent columns of a row as one 16-byte store) ----------
-    {
-      const cpx<T> base = cxb[(size_t)b * cxb_stride + t];
-#pragma unroll
-      for (int i = 0; i < 16; ++i) {
-        const cpx<T> ph = cmul(base, sx[b * 16 + i]);
-#pragma unroll
-        for (int n = 0; n < NT; ++n) y[n][i] = cmul(y[n][i], ph);
-      }
-    }
-    // out through a buffer descriptor of the plane: one 32-bit lane offset (row t of the thread's first column) plus a
-    // scalar offset per register -- no 64-bit address arithmetic, no address registers kept across the transforms
-    {
-      const __amdgpu_buffer_rsrc_t prow = __builtin_amdgcn_make_buffer_rsrc((void*)(Tout + (size_t)b * n0 * n1), 0,
-                                                                            (int)((size_t)n0 * n1 * sizeof(cpx<T>)), 0x00020000);
-      constexpr int OOB = (int)0x80000000;
-      const int rowb = n1 * (int)sizeof(cpx<T>);
-      bool paired = false;
-#if GPA_PAS_GSTORE
-      if constexpr (NT == 2) {
-        if (y0 + 1 < n1 && (n1 & 1) == 0) {
-          paired = true;
-#pragma unroll
-          for (int i = 0; i < 16; ++i) {
-            const int slot = t + TPF * i;
-            if (!PADDED || slot < n0) {
-              struct alignas(2 * sizeof(cpx<T>)) Pair { cpx<T> a, b; };
-              Pair pr = {y[0][i], y[1][i]};
-              *reinterpret_cast<Pair*>(&Tout[((size_t)b * n0 + slot) * n1 + y0]) = pr;
-            }
-          }
-        }
-      }
-#endif
-      if constexpr (NT == 2 && !GPA_PAS_GSTORE) {
-        if (y0 + 1 < n1 && (n1 & 1) == 0) {
-          paired = true;
-          const int v0 = t * rowb + y0 * (int)sizeof(cpx<T>);
-#pragma unroll
-          for (int i = 0; i < 16; ++i) {
-            const int voff = ((!PADDED || t + TPF * i < n0) && !(GPA_PAS_NOSTORE && i > 0)) ? v0 : OOB;
-            store_pair(y[0][i], y[1][i], prow, voff, i * TPF * rowb);
-          }
-        }
-      }
-      if (!paired) {
-#pragma unroll
-        for (int n = 0; n < NT; ++n) {
-          const int yy = y0 + n;
-          const int v0 = t * rowb + yy * (int)sizeof(cpx<T>);
-#pragma unroll
-          for (int i = 0; i < 16; ++i) {
-            const int voff = (yy < n1 && (!PADDED || t + TPF * i < n0)) ? v0 : OOB;
-            store_cpx(y[n][i], prow, voff, i * TPF * rowb);
-          }
-        }
-      }
-    }
-  }
-}
-
-// tables of the shared pass A: shifted Gaussian of every x-plane (spectral layout, / L) and its post-factors
-template <class T, int LG>
-__global__ __launch_bounds__(256) void sharedA_tables_kernel(const double* __restrict__ pw, const double* __restrict__ taps,
-                                                            int Etab, int n0, int E, int Epad, int wrapped,
-                                                            T* __restrict__ Gx, cpx<T>* __restrict__ psix,
-                                                            cpx<T>* __restrict__ sxs) {
-  using F = WgFFT<T, LG>;
-  constexpr int L = F::L, TPF = F::TPF;
-  const int b = blockIdx.y;
-  const int idx = blockIdx.x * 256 + threadIdx.x;
-  const double wx = pw[b];
-  if (idx < L) {
-    const int i = idx / TPF, t = idx % TPF;
-    const double fq = wx + (double)F::spec_index(t, i) / (double)L;
-    double acc = 0;
-    for (int m = Etab; m >= 1; --m) {
-      const double ph = fq * (double)m;
-      acc += taps[m] * cospi(2.0 * (ph - rint(ph)));
-    }
-    Gx[(size_t)b * L + idx] = (T)((taps[0] + 2.0 * acc) / (double)L);
-  }
-  if (idx < Epad) {
-    double ps, pc, qs, qc;
-    const double c0 = -wx * (double)n0, c1 = wx * (double)(idx + 1);
-    sincospi(2.0 * (c0 - rint(c0)), &ps, &pc);
-    sincospi(2.0 * (c1 - rint(c1)), &qs, &qc);
-    pc -= wrapped ? 1.0 : 0.0;
-    cpx<T> v = {(T)(pc * qc - ps * qs), (T)(pc * qs + ps * qc)};
-    if (idx >= E) v = {T(0), T(0)};
-    psix[(size_t)b * Epad + idx] = v;
-  }
-  // stride factors of the output phasor for THIS transform length: exp(2 pi i wx (L / 16) i)
-  if (idx < 16) sxs[b * 16 + idx] = unit_phasor_s<T>(wx * (double)TPF * (double)idx);
-}
-
-hipError_t launch_sharedA_tables(int dtype, const Axis& a0, const double* pw, const double* taps, int Etab, int E, int Epad,
-                                 int Bx, void* Gx, void* psix, void* sxs, hipStream_t s) {
-  int len = a0.L > Epad ? a0.L : Epad;
-  dim3 grid((len + 255) / 256, Bx);
-#define CASE_TA(LG)                                                                                                      \
-  case LG:                                                                                                               \
-    if (dtype == 0) sharedA_tables_kernel<float, LG><<<grid, 256, 0, s>>>(pw, taps, Etab, a0.n, E, Epad, a0.padded ? 0 : 1, \
-                                                                          (float*)Gx, (cpx<float>*)psix, (cpx<float>*)sxs); \
-    else sharedA_tables_kernel<double, LG><<<grid, 256, 0, s>>>(pw, taps, Etab, a0.n, E, Epad, a0.padded ? 0 : 1,          \
-                                                                (double*)Gx, (cpx<double>*)psix, (cpx<double>*)sxs);     \
-    return hipGetLastError();
-  switch (a0.lg) { CASE_TA(10) CASE_TA(11) CASE_TA(12) }
-#undef CASE_TA
-  return hipErrorInvalidValue;
-}
-
-template <class T, int LG, bool PADDED>
-static hipError_t run_passA_shared(const Axis& a0, int n1, const void* image, const void* mean, const SweepTables& tb,
-                                   int cxb_stride, const void* Gx, const void* psix, const void* gtab, const void* tw0, int E,
-                                   int Epad, void* Tbuf, int B, hipStream_t s, int nimg) {
-  using G = PassASGeom<T, LG>;
-  const size_t lds = G::lds_bytes(Epad);
-  if (lds > 160 * 1024 || Epad > G::TPF) return hipErrorInvalidValue;
-  auto kern = passA_shared_kernel<T, LG, PADDED>;
-  static int lds_set[32] = {0};
-  int dev = 0;
-  (void)hipGetDevice(&dev);
-  if (lds_set[dev & 31] < (int)lds) {
-    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-    if (e != hipSuccess) return e;
-    lds_set[dev & 31] = (int)lds;
-  }
-  const int tiles = (n1 + G::C - 1) / G::C;
-  // few column tiles (small images): split the planes over grid.y -- each part repeats the forward transform
-  int ysplit = 1;
-  while (tiles * ysplit < 512 && ysplit < B) ysplit *= 2;
-  if (ysplit > B) ysplit = B;
-  const int bchunk = (B + ysplit - 1) / ysplit;
-  dim3 grid(tiles, (B + bchunk - 1) / bchunk, nimg);
-  GPA_PROF("passA_shared_kernel", s);
-  kern<<<grid, G::THREADS, lds, s>>>((const T*)image, (const T*)mean, a0.n, n1, (const T*)Gx, (const cpx<T>*)tw0,
-                                     (const cpx<T>*)tb.cxb, (const cpx<T>*)tb.sx, (const cpx<T>*)psix, (const T*)gtab,
-                                     cxb_stride, E, Epad, (cpx<T>*)Tbuf, B, bchunk);
-  return hipGetLastError();
-}
-
-template <class T, int LG>
-static bool passA_shared_fits(int Epad) {
-  using G = PassASGeom<T, LG>;
-  return G::lds_bytes(Epad) <= 160 * 1024 && Epad <= G::TPF;
-}
-
-bool passA_shared_supports(int dtype, const Axis& a0, int E) {
-  const int Epad = (E + 15) & ~15;
-  if (E < 1 || 2 * E > a0.n) return false;
-  if (a0.padded && a0.n + E > a0.L) return false;
-  // (sx / the phasor factorisation assume L / 16 threads per transform of the SAME length as the plan's tables)
-  switch (a0.lg) {
-    case 11: return dtype == 0 ? passA_shared_fits<float, 11>(Epad) : passA_shared_fits<double, 11>(Epad);
-    case 12: return dtype == 0 ? passA_shared_fits<float, 12>(Epad) : passA_shared_fits<double, 12>(Epad);
-  }
-  return false;
-}
-
-hipError_t launch_passA_shared(int dtype, const Axis& a0, int n1, const void* image, const void* mean, const SweepTables& tb,
-                               int cxb_stride, const void* Gx, const void* psix, const void* gtab, const void* tw0, int E,
-                               int Epad, void* Tbuf, int B, hipStream_t s, int nimg) {
-#define CALL_AS(T, LG)                                                                                                        \
-  (a0.padded ? run_passA_shared<T, LG, true>(a0, n1, image, mean, tb, cxb_stride, Gx, psix, gtab, tw0, E, Epad, Tbuf, B, s, nimg) \
-             : run_passA_shared<T, LG, false>(a0, n1, image, mean, tb, cxb_stride, Gx, psix, gtab, tw0, E, Epad, Tbuf, B, s, nimg))
-#define CASE_AS(LG) \
-  case LG: return dtype == 0 ? CALL_AS(float, LG) : CALL_AS(double, LG);
-  switch (a0.lg) { CASE_AS(11) CASE_AS(12) }
-#undef CASE_AS
-#undef CALL_AS
-  return hipErrorInvalidValue;
-}
-
 // ---------------------------------------------------------------------------------------------------------------
 // tables: the shifted Gaussian of every candidate in the spectral register layout, the post-factors of the end fix
 // and the compensation phasor of every peak, all evaluated in double

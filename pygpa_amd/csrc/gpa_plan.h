@@ -86,25 +86,10 @@ struct EnqueueWorker {
   }
 };
 
-struct GraphKey {
-  const void* image; void* u; void* lk; int32_t* kidx;
-  int P, K, Bx, mask_border, kmax, epoch;
-  int want_lockins, pad_;   // (compensated lock-ins asked for: the captured pass B / set-up launches differ)
-};
-struct GraphEntry {
-  GraphKey key;
-  hipGraph_t graph;
-  hipGraphExec_t exec;
-  bool failed;
-};
-
 struct gpa_plan {
   int device = 0, dtype = 0, n0 = 0, n1 = 0, max_batch = 0;
   Axis ax0{}, ax1{};              // the geometry in use (depends on sigma for non-power-of-two axes)
   Axis ax0_full{}, ax1_full{};    // the plan's largest geometry (L >= 2n - 1): what the tables are sized for
-  // native mode of an axis (gpa_sweep_mr.hip): the length-n twiddles (uploaded once) and the filter table of the cached sigma
-  void *natW0 = nullptr, *natW1 = nullptr, *natH0 = nullptr, *natH1 = nullptr;
-  double natkey_cached = -2.0;    // the NO_NATIVE / NATIVE_RATIO options the cached geometry was chosen under
   hipStream_t stream = nullptr;
   size_t rsz = 4, csz = 8;        // bytes per real / complex element
   size_t ws_bytes = 0;
@@ -131,21 +116,12 @@ struct gpa_plan {
   int sh_epoch = 0, sh_built_epoch = -1, sh_built_K = 0, sh_built_B = 0;   // tables follow sigma and the staged k-list
   bool sh_built_reorder = true;   // ... and the NO_REORDER option they were built under
   double* d_ystep = nullptr;      // [max_peaks] 2 pi frac(ky_p + band rotation_p): phase step along y of the compensation phasor
+  bool sh_one_kref = true;        // every candidate of a peak shares its reference vector (what d_ystep assumes)
   bool lk_raw = false;            // the last passB_select left the lock-ins raw (fused driver): the consumer applies d_ystep
   bool sh_built_ok = false;       // the tables of that key are complete and worth using
   bool sh_use = false;            // ... and the staged candidates form runs of >= 2 on an x-plane
   size_t sh_gb_bytes = 0, sh_psi_bytes = 0;
   std::vector<int> staged_planeof;
-  // shared-forward pass A: the same for the x axis (tables per x-plane)
-  bool shA_ok = false;
-  int shA_etab = 0, shA_E = 0, shA_Epad = 0;
-  Axis ax0s{};
-  void* tw0s = nullptr;
-  int tw0s_L = 0;
-  double* d_taps0 = nullptr;
-  void *shA_gtab = nullptr, *shA_Gx = nullptr, *shA_psi = nullptr, *shA_sx = nullptr;
-  size_t shA_gx_bytes = 0, shA_psi_bytes = 0;
-  int shA_built_epoch = -1, shA_built_Bx = 0;
   void* Tbuf = nullptr;           // [tbuf_planes][n0][n1] complex: one plane per DISTINCT wx (x-plane), grown on demand
   int tbuf_planes = 0;
   SweepTables tb{};
@@ -166,9 +142,8 @@ struct gpa_plan {
   void* d_image = nullptr;        // staging for host-pointer entry points
   void* d_mean = nullptr;
   void* d_tile_mean = nullptr;    // whole-image mean of the tile path (gpa_tile_gradients_dev)
-  double* d_tsum_part = nullptr;  // partial sums + ticket of gpa_tile_sums_dev, grown on demand
+  double* d_tsum_part = nullptr;  // partial sums of gpa_tile_sums_dev, grown on demand
   size_t tsum_cap = 0;
-  unsigned* d_ticket = nullptr;
   hipEvent_t ev_x = nullptr;      // stream-to-stream ordering (gpa_plan_wait_stream / gpa_stream_wait_plan)
   double tile_mean = std::numeric_limits<double>::quiet_NaN();
   void* d_sf = nullptr;           // [K][n0][n1] complex, grown on demand (a4 gradient path)
@@ -209,9 +184,7 @@ struct gpa_plan {
   float stage_ms[5] = {0, 0, 0, 0, 0};
   EnqueueWorker* worker = nullptr;   // second enqueueing thread of the fused driver
   bool use_worker = true, no_ksplit = false, no_compact = false;
-  std::vector<GraphEntry> graphs;    // captured fused-driver calls (extract_enqueue)
-  bool use_graphs = true, serial_unwrap = false;
-  int tbuf_epoch = 0;                // bumped when a buffer baked into the graphs is reallocated
+  bool serial_unwrap = false;
   KernelProfiler* kprof = nullptr;   // per-kernel event pairs of the last profiled driver call
   std::string kprof_table;           // "name calls total_ms" lines of that call
   // downloads overlapped with the next call (gpa_download_async)
@@ -241,7 +214,6 @@ int stage_kvectors(gpa_plan* p, const double* kl, const double* kr_per_b, int B,
 int ensure_tbuf(gpa_plan* p, int planes);
 int ensure_sf(gpa_plan* p, size_t bytes);
 int stage_kmat(gpa_plan* p, const double* kvecs, int P);
-int sharedA_prepare(gpa_plan* p, int Bx, bool* use);
 int run_passA(gpa_plan* p, const void* image, const void* mean, void* Tbuf, int Bx, int nimg = 1);
 int passB_select(gpa_plan* p, int P, int K, void* lockin, int32_t* kidx, bool raw = false);
 void collect_kernel_profile(gpa_plan* p);
@@ -254,7 +226,6 @@ int sweep_host(gpa_plan* p, const void* image, const double* kref, const double*
 int extract_stage(gpa_plan* p, const double* kvecs, int P, const double* klists, int K, double sigma, int* Bx);
 int extract_launch(gpa_plan* p, const void* image, int P, int K, int Bx, int mask_border, int kmax, void* u,
                           void* lk, int32_t* kidx, bool want_lockins);
-void drop_graphs(gpa_plan* p);
 int extract_enqueue(gpa_plan* p, const void* image, const double* kvecs, int P, const double* klists, int K,
                            double sigma, int mask_border, int kmax, void* u, void* lockins, int32_t* kidx);
 int tile_gradients_impl(gpa_plan* p, const void* image, size_t image_pitch, int r0, int c0, bool mean_on_device,

@@ -61,7 +61,6 @@ __global__ void tables_kernel(const double* __restrict__ kl, const double* __res
 hipError_t launch_tables(int dtype, const Axis& a0, const Axis& a1, const double* kl,
                          const double* kr, int B, const double* pw, int Bx, const SweepTables& tb,
                          hipStream_t s) {
-  // (a native axis: one base entry per thread of its mixed-radix transform, stride factors in steps of that count)
   const int tpf0 = axis_tpf(a0), tpf1 = axis_tpf(a1);
   int len = a0.n > a1.n ? a0.n : a1.n;
   if (len < tpf0) len = tpf0;
@@ -337,7 +336,6 @@ static hipError_t run_passA(const Axis& a0, int n1, const void* image, const voi
 hipError_t launch_passA(int dtype, const Axis& a0, int n1, const void* image, const void* mean,
                         const SweepTables& tb, const void* Hx, const void* tw0, void* Tbuf,
                         int B, hipStream_t s, int nimg) {
-  if (a0.native) return launch_passA_mr(dtype, a0, n1, image, mean, tb, Tbuf, B, s, nimg);
 #define CASE_A(LG)                                                                                \
   case LG:                                                                                        \
     if (dtype == 0)                                                                               \
@@ -354,8 +352,6 @@ hipError_t launch_passA(int dtype, const Axis& a0, int n1, const void* image, co
 hipError_t launch_passB(int dtype, const Axis& a1, int n0, const void* Tbuf, const void* Hy,
                         const void* tw1, const SweepTables& tb, int P, int K, bool select,
                         void* out, int32_t* kidx, hipStream_t s, int nimg, int Bx) {
-  if (a1.native)
-    return launch_passB_mr(dtype, a1, n0, Tbuf, tb, P, K, select ? PB_SELECT : PB_ALL, out, kidx, nullptr, nullptr, s, 1, nimg, Bx);
 #define CALL_B(T, LG, PD)                                                                                                   \
   (select ? run_passB<T, LG, PD, PB_SELECT>(a1, n0, Tbuf, Hy, tw1, tb, P, K, out, kidx, nullptr, nullptr, s, 1, nimg, Bx)    \
           : run_passB<T, LG, PD, PB_ALL>(a1, n0, Tbuf, Hy, tw1, tb, P, K, out, kidx, nullptr, nullptr, s, 1, nimg, Bx))

@@ -109,9 +109,7 @@ hipError_t launch_passB_split(int dtype, const Axis& a1, int n0, const void* Tbu
                               const SweepTables& tb, int P, int K, int ksplit, void* part, int32_t* pidx, void* out,
                               int32_t* kidx, hipStream_t s) {
   hipError_t e = hipErrorInvalidValue;
-  if (a1.native) {
-    e = launch_passB_mr(dtype, a1, n0, Tbuf, tb, P, K, PB_PART, part, pidx, nullptr, nullptr, s, ksplit, 1, 0);
-  } else {
+  {
 #define CALL_P(T, LG, PD) run_passB<T, LG, PD, PB_PART>(a1, n0, Tbuf, Hy, tw1, tb, P, K, part, pidx, nullptr, nullptr, s, ksplit)
 #define CASE_P(LG)                                                                                  \
   case LG:                                                                                          \
@@ -137,8 +135,6 @@ hipError_t launch_passB_split(int dtype, const Axis& a1, int n0, const void* Tbu
 hipError_t launch_passB_ext(int dtype, const Axis& a1, int n0, const void* Tbuf, const void* Hy, const void* tw1,
                             const SweepTables& tb, int K, int mode, void* out, int32_t* kidx, const uint8_t* gate,
                             void* psi, hipStream_t s) {
-  if (a1.native && (mode == PB_GATED || mode == PB_PHASES))
-    return launch_passB_mr(dtype, a1, n0, Tbuf, tb, 1, K, mode, out, kidx, gate, psi, s, 1, 1, 0);
 #define CALL_X(T, LG, PD)                                                                                        \
   (mode == PB_GATED ? run_passB<T, LG, PD, PB_GATED>(a1, n0, Tbuf, Hy, tw1, tb, 1, K, out, kidx, gate, psi, s)   \
                     : run_passB<T, LG, PD, PB_PHASES>(a1, n0, Tbuf, Hy, tw1, tb, 1, K, out, kidx, gate, psi, s))

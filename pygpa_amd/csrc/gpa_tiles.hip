@@ -132,7 +132,7 @@ __global__ __launch_bounds__(256) void stitch_kernel(const T* __restrict__ tiles
 }  // namespace
 
 hipError_t launch_tile_sums(int dtype, const void* wins, size_t win_stride, size_t pitch, const int* rects_dev, int ntiles,
-                            int max_rows, double* part, unsigned* ticket, double* out, hipStream_t s) {
+                            int max_rows, double* part, double* out, hipStream_t s) {
   const int nbands = (max_rows + TS_ROWS - 1) / TS_ROWS;
   GPA_PROF("tile_sums_kernel", s);
   if (dtype == 0)
@@ -140,7 +140,6 @@ hipError_t launch_tile_sums(int dtype, const void* wins, size_t win_stride, size
   else
     tile_sums_kernel<double><<<dim3(nbands, ntiles), 256, 0, s>>>((const double*)wins, win_stride, pitch, rects_dev, nbands, part);
   tile_sums_final_kernel<<<1, 256, 0, s>>>(part, nbands * ntiles, out);
-  (void)ticket;
   return hipGetLastError();
 }
 int tile_sums_bands(int max_rows) { return (max_rows + TS_ROWS - 1) / TS_ROWS; }

@@ -1,7 +1,9 @@
 // Shared between the translation units of the weighted unwrap (a7): the workspace (Impl), the scalar / flag / partial-sum
 // conventions of the fused iteration, the block reductions every kernel uses, and the launch entry points each
 // translation unit offers to the PCG driver (gpa_unwrap.hip):
-//   gpa_unwrap_rows.hip     row kernels of the power-of-two fused iteration (rowdct_fused, rowidct_p, rowidct_pq)
+//   gpa_unwrap_rows.hip     row kernels of the power-of-two fused iteration (rowdct_fused, rowidct_p, rowidct_pq);
+//   gpa_unwrap_rowhalf.hip  the same for rows of 8192 points and more (half-length transforms); gpa_unwrap_pqdct.hip the
+//                           stencil + forward transform in one launch; gpa_unwrap_rowpers.hip the persistent rowidct_p
 //   gpa_unwrap_cols.hip     column solves (DCT kernel, transform-free recursion, streamed recursion)
 //   gpa_unwrap_stencil.hip  set-up, stencil (pq), phi flush, the scalar / elementwise kernels of the plain scheme
 //   gpa_unwrap_generic.hip  sizes that are not powers of two: mixed-radix fused kernels (gpa_unwrap_mr.h), Bluestein kernels
@@ -92,12 +94,16 @@ hipError_t pow2_rowidct_pq(const Impl* w, const void* pin, void* pout, const voi
 // stencil + row transform in one launch (rows of 2048 / 4096 points): D = DCT_rows(A^T W^2 A p) into w->q, partial <p, q>
 bool pow2_pqdct_offered(const Impl* w);
 hipError_t pow2_pqdct(const Impl* w, const void* p, const void* weight, double* part_pq, int* npq, hipStream_t s);
-// persistent, software-pipelined row kernels for 4096-point f32 rows (gpa_unwrap_rowpers.hip; NO_ROWPERS: the one-pair-per-
-// workgroup kernels of gpa_unwrap_rows.hip)
+// long rows: one row per half-length transform (gpa_unwrap_rowhalf.hip)
+bool rowhalf_offered(const Impl* w);
+hipError_t rowhalf_rowdct(const Impl* w, const void* q, int ring, const double* part_pq, int npq, double* part_norm, int it,
+                          int* nnorm, int init, hipStream_t s);
+hipError_t rowhalf_rowidct_p(const Impl* w, const void* pin, void* pout, const double* part_rho, int nrho, int it, hipStream_t s);
+// persistent, software-pipelined rowidct_p for 4096-point f32 rows (gpa_unwrap_rowpers.hip; NO_ROWPERS: the one-pair-per-
+// workgroup kernel of gpa_unwrap_rows.hip)
 bool pow2_rowpers_offered(const Impl* w);
 hipError_t pow2_rowidct_p_pers(const Impl* w, const void* pin, void* pout, const double* part_rho, int nrho, int it,
                                hipStream_t s);
-hipError_t pow2_pqdct_pers(const Impl* w, const void* p, const void* weight, double* part_pq, int* npq, hipStream_t s);
 // columns (gpa_unwrap_cols.hip): every size
 hipError_t dispatch_colsolve(const Impl* w, int compat, hipStream_t s, const double* part_norm, int nnorm, int it,
                              double eps, double* part_rho, int* nrho, const void* zin);

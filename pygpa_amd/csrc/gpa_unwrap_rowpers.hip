@@ -1,5 +1,7 @@
-// a7, PERSISTENT row kernels of the fused PCG iteration on 4096-point f32 rows (round 5; phase_unwrap.py:326-349, the
-// preconditioner's row DCT-III :95-103 and the search-direction update :332-340).
+// a7, PERSISTENT row kernel of the fused PCG iteration on 4096-point f32 rows (round 5; phase_unwrap.py:326-349, the
+// preconditioner's row DCT-III :95-103 and the search-direction update :332-340): rowidct_p.  (The same treatment of the
+// stencil + forward-transform kernel pqdct measured SLOWER -- 69 against 58 us -- and is not in the tree:
+// profiles/r05_pqdct_persistent_rejected.txt.)
 //
 // The one-row-pair-per-workgroup kernels of gpa_unwrap_rows.hip run 2048 workgroups as two rounds of the chip: the four
 // workgroups of a CU load, transform and store IN STEP, so the memory system idles while they compute and the SIMDs idle
@@ -177,221 +179,6 @@ __global__ __launch_bounds__(256, 2) void rowidct_p_pers_kernel(
   }
 }
 
-// ---------------------------------------------------------------------------------------------------------------------
-// pqdct, persistent: D = DCT-II_rows(A^T W^2 A p) and the partial <p, q> (pqdct_kernel of gpa_unwrap_rows.hip; the stencil
-// phase_unwrap.py:118-132, the transform :84-92) with the loads of row pair j + 1 in flight while pair j is worked on:
-//   * the pair's own rows of p (the ones whose left / right neighbours the stencil needs) land in the other LDS buffer by
-//     LDS-DMA; the rows above and below it and the four rows of w are requested into registers one iteration ahead
-//     (16-byte loads, 112 VGPRs in flight across the transform -- what two workgroups per CU leave room for);
-//   * the landing zone is read out (own rows + their neighbours' edge pixels), then receives q of the pair as the packed
-//     transform's input and serves as its exchange buffer.
-// A workgroup walks a contiguous band of pairs, bands in XCD-aware order (the rows above / below a band are its neighbour
-// bands' rows: same L2).  Arithmetic, its order and the indices of the partial sums are pqdct_kernel's: D, <p, q> and
-// with them phi are equal bit for bit.
-// ---------------------------------------------------------------------------------------------------------------------
-__device__ __forceinline__ int xcd_tile_inv(int t, int grid) {   // the workgroup index b with xcd_tile(b, grid) == t
-  const int base = grid >> 3, rem = grid & 7;
-  int x, idx;
-  if (t < rem * (base + 1)) { x = t / (base + 1); idx = t - x * (base + 1); }
-  else { const int t2 = t - rem * (base + 1); x = rem + t2 / base; idx = t2 - (t2 / base) * base; }
-  return idx * 8 + x;
-}
-
-template <int NQ>
-struct PqPrefetch {   // what the stencil of one row pair needs from global memory besides the pair's own rows of p
-  Vec4<float> wu[NQ], wa[NQ], wb[NQ], wd[NQ], pu[NQ], pd[NQ];
-  float wla[NQ], wra[NQ], wlb[NQ], wrb[NQ];
-};
-
-template <int LG>
-__device__ __forceinline__ void pq_prefetch(PqPrefetch<PersGeom<LG>::NQ>& f, const float* __restrict__ p,
-                                            const float* __restrict__ wgt, int pr, int n0, int tid, int lane) {
-  using G = PersGeom<LG>;
-  constexpr int N = G::N, TPF = G::TPF, NQ = G::NQ;
-  const int xa = 2 * pr, xb = xa + 1;
-  const bool up = xa > 0, dn = xb + 1 < n0;
-  const size_t oa = (size_t)xa * N, ob = oa + N;
-#pragma unroll
-  for (int v = 0; v < NQ; ++v) {
-    const int c0 = 4 * (tid + TPF * v);
-    // (halo rows outside the image are never used: their address is clamped to a row of the pair)
-    f.pu[v] = *reinterpret_cast<const Vec4<float>*>(p + (up ? oa - N : oa) + c0);
-    f.pd[v] = *reinterpret_cast<const Vec4<float>*>(p + (dn ? ob + N : ob) + c0);
-    if (wgt) {
-      f.wu[v] = *reinterpret_cast<const Vec4<float>*>(wgt + (up ? oa - N : oa) + c0);
-      f.wa[v] = *reinterpret_cast<const Vec4<float>*>(wgt + oa + c0);
-      f.wb[v] = *reinterpret_cast<const Vec4<float>*>(wgt + ob + c0);
-      f.wd[v] = *reinterpret_cast<const Vec4<float>*>(wgt + (dn ? ob + N : ob) + c0);
-    }
-    f.wla[v] = f.wlb[v] = f.wra[v] = f.wrb[v] = 1.0f;
-    if (wgt) {
-      if (lane == 0 && c0 > 0) { f.wla[v] = wgt[oa + c0 - 1]; f.wlb[v] = wgt[ob + c0 - 1]; }
-      if (lane == 63 && c0 + 4 < N) { f.wra[v] = wgt[oa + c0 + 4]; f.wrb[v] = wgt[ob + c0 + 4]; }
-    }
-  }
-  if (!wgt) {
-#pragma unroll
-    for (int v = 0; v < NQ; ++v)
-#pragma unroll
-      for (int j = 0; j < 4; ++j) f.wu[v].v[j] = f.wa[v].v[j] = f.wb[v].v[j] = f.wd[v].v[j] = 1.0f;
-  }
-}
-
-template <int LG>
-__global__ __launch_bounds__(256, 2) void pqdct_pers_kernel(const float* __restrict__ p, const float* __restrict__ wgt,
-                                                           float* __restrict__ Dout, int n0, const cpx<float>* __restrict__ twtab,
-                                                           const cpx<float>* __restrict__ wk, const int* flags, double* part_pq,
-                                                           size_t pimg) {
-  using T = float;
-  using G = PersGeom<LG>;
-  using F = typename G::F;
-  using D = typename G::D;
-  constexpr int TPF = G::TPF, N = G::N, E = G::E, NQ = G::NQ;
-  {
-    const size_t pb = blockIdx.z;
-    p += pb * pimg;
-    Dout += pb * pimg;
-    if (wgt) wgt += (pb >> 1) * pimg;   // the two components of an image share its weight
-    flags += pb * FLAGS_N;
-    part_pq += pb * PART_N;
-  }
-  if (flags[1]) return;
-  extern __shared__ __attribute__((aligned(16))) char smem[];
-  __shared__ double shw[8];
-  __shared__ cpx<T> t1s[G::T1N];
-  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-  const int npairs = n0 / 2, nwg = (int)gridDim.x;
-  const int band = xcd_tile((int)blockIdx.x, nwg);
-  const int p0 = (int)((long long)band * npairs / nwg), p1 = (int)((long long)(band + 1) * npairs / nwg);
-  if (p0 >= p1) return;
-  const unsigned buf0 = lds_addr(smem);
-  dma_pair<LG>(p + (size_t)2 * p0 * N, buf0, wave, lane);
-  PqPrefetch<NQ> pf;
-  pq_prefetch<LG>(pf, p, wgt, p0, n0, tid, lane);
-  typename G::TW tw;
-  F::fill_pass1_table(t1s, twtab, tid, TPF);
-  __syncthreads();   // (t1s)
-  F::load_twiddles(tw, twtab, tid, t1s);
-  // (loop-invariant registers settled before the loop: see rowidct_p_pers_kernel)
-#pragma unroll
-  for (int q = 0; q < F::GMAX; ++q)
-#pragma unroll
-    for (int c = 0; c < 3; ++c) { settle(tw.lo[q][c].x); settle(tw.lo[q][c].y); settle(tw.hi[q][c].x); settle(tw.hi[q][c].y); }
-  for (int pr = p0; pr < p1; ++pr) {
-    const int cur = (pr - p0) & 1;
-    char* bcur = smem + cur * G::BUF_BYTES;
-    cpx<T>* lds = reinterpret_cast<cpx<T>*>(bcur);
-    const T* st = reinterpret_cast<const T*>(bcur);
-    const int xa = 2 * pr, xb = xa + 1;
-    const bool up = xa > 0, dn = xb + 1 < n0;
-    const size_t oa = (size_t)xa * N, ob = oa + N;
-    // the pair's rows have landed: everything older than the previous pair's E * 2 stores of D is done
-    asm volatile("s_waitcnt vmcnt(%0)" ::"n"(2 * E) : "memory");
-    GPA_PBAR();
-    // ---- this pair's own rows (and the edge pixels of their neighbours) out of the landing zone
-    Vec4<T> Pa[NQ], Pb[NQ];
-    T pla[NQ], pra[NQ], plb[NQ], prb[NQ];
-#pragma unroll
-    for (int v = 0; v < NQ; ++v) {
-      const int c0 = 4 * (tid + TPF * v);
-      Pa[v] = *reinterpret_cast<const Vec4<T>*>(st + c0);
-      Pb[v] = *reinterpret_cast<const Vec4<T>*>(st + N + c0);
-      pla[v] = st[c0 > 0 ? c0 - 1 : 0];
-      plb[v] = st[N + (c0 > 0 ? c0 - 1 : 0)];
-      pra[v] = st[c0 + 4 < N ? c0 + 4 : c0];
-      prb[v] = st[N + (c0 + 4 < N ? c0 + 4 : c0)];
-    }
-    GPA_PBAR();   // the landing zone is read out: it becomes the transform's input / exchange buffer
-    // ---- the next pair's own rows: DMA into the other buffer (its last reader was the previous transform)
-    if (pr + 1 < p1) dma_pair<LG>(p + (size_t)2 * (pr + 1) * N, buf0 + (cur ^ 1) * G::BUF_BYTES, wave, lane);
-    Vec4<T>(&Pu)[NQ] = pf.pu, (&Pd)[NQ] = pf.pd, (&Wu)[NQ] = pf.wu, (&Wa)[NQ] = pf.wa, (&Wb)[NQ] = pf.wb, (&Wd)[NQ] = pf.wd;
-    T(&wla)[NQ] = pf.wla, (&wra)[NQ] = pf.wra, (&wlb)[NQ] = pf.wlb, (&wrb)[NQ] = pf.wrb;
-    // ---- q = A^T W^2 A p of the two rows (edge order: right, left, down, up -- pq_kernel's), into the exchange buffer
-    double pq = 0;
-#pragma unroll
-    for (int v = 0; v < NQ; ++v) {
-      const int c0 = 4 * (tid + TPF * v);
-      const bool hasl = c0 > 0, hasr = c0 + 4 < N;
-      if (wgt) {
-#pragma unroll
-        for (int j = 0; j < 4; ++j) { Wu[v].v[j] *= Wu[v].v[j]; Wa[v].v[j] *= Wa[v].v[j]; Wb[v].v[j] *= Wb[v].v[j]; Wd[v].v[j] *= Wd[v].v[j]; }
-        wla[v] *= wla[v]; wlb[v] *= wlb[v]; wra[v] *= wra[v]; wrb[v] *= wrb[v];
-      }
-      T xla = __shfl_up(Wa[v].v[3], 1), xra = __shfl_down(Wa[v].v[0], 1), xlb = __shfl_up(Wb[v].v[3], 1), xrb = __shfl_down(Wb[v].v[0], 1);
-      if (lane == 0) { xla = wla[v]; xlb = wlb[v]; }
-      if (lane == 63) { xra = wra[v]; xrb = wrb[v]; }
-#pragma unroll
-      for (int j = 0; j < 4; ++j) {
-        T qa, qb;
-        {
-          const T c = Pa[v].v[j], wj = Wa[v].v[j];
-          T acc = T(0);
-          if (j < 3) { const T wn = Wa[v].v[j + 1]; acc += (wn < wj ? wn : wj) * (Pa[v].v[j + 1] - c); }
-          else if (hasr) acc += (xra < wj ? xra : wj) * (pra[v] - c);
-          if (j > 0) { const T wn = Wa[v].v[j - 1]; acc += (wn < wj ? wn : wj) * (Pa[v].v[j - 1] - c); }
-          else if (hasl) acc += (xla < wj ? xla : wj) * (pla[v] - c);
-          { const T wn = Wb[v].v[j]; acc += (wn < wj ? wn : wj) * (Pb[v].v[j] - c); }
-          if (up) { const T wn = Wu[v].v[j]; acc += (wn < wj ? wn : wj) * (Pu[v].v[j] - c); }
-          qa = acc;
-          pq += (double)c * (double)acc;
-        }
-        {
-          const T c = Pb[v].v[j], wj = Wb[v].v[j];
-          T acc = T(0);
-          if (j < 3) { const T wn = Wb[v].v[j + 1]; acc += (wn < wj ? wn : wj) * (Pb[v].v[j + 1] - c); }
-          else if (hasr) acc += (xrb < wj ? xrb : wj) * (prb[v] - c);
-          if (j > 0) { const T wn = Wb[v].v[j - 1]; acc += (wn < wj ? wn : wj) * (Pb[v].v[j - 1] - c); }
-          else if (hasl) acc += (xlb < wj ? xlb : wj) * (plb[v] - c);
-          if (dn) { const T wn = Wd[v].v[j]; acc += (wn < wj ? wn : wj) * (Pd[v].v[j] - c); }
-          { const T wn = Wa[v].v[j]; acc += (wn < wj ? wn : wj) * (Pa[v].v[j] - c); }
-          qb = acc;
-          pq += (double)c * (double)acc;
-        }
-        lds[F::pad(c0 + j)] = {qa, qb};
-      }
-      __builtin_amdgcn_sched_barrier(0);   // (one group of 4 columns after the other: interleaved they overrun the registers)
-    }
-    // ---- the next pair's other inputs into the registers this stencil has just released: in flight across the transform
-    asm volatile("" ::: "memory");   // (not earlier: requested ahead of the stencil they would double its registers)
-    __builtin_amdgcn_sched_barrier(0);
-    if (pr + 1 < p1) pq_prefetch<LG>(pf, p, wgt, pr + 1, n0, tid, lane);
-    __builtin_amdgcn_sched_barrier(0);
-    // the pair's <p, q>: wavefront sums now, combined by thread 0 in block_sum's order behind the next barrier
-    pq = wave_sum(pq);
-    if (lane == 0) shw[wave] = pq;
-    GPA_PBAR();
-    if (tid == 0) {
-      double t = 0;
-      for (int i = 0; i < TPF / 64; ++i) t += shw[i];
-      part_pq[xcd_tile_inv(pr, npairs)] = t;   // (pqdct_kernel files pair xcd_tile(b) under its workgroup index b)
-    }
-    // (the transform's LDS addresses are recomputed from an opaque copy of the thread index every iteration: hoisted out
-    //  of the loop they are ~85 registers the kernel does not have, i.e. scratch reloads that queue IN ORDER behind the
-    //  prefetch in flight)
-    int tt = tid;
-    asm volatile("" : "+v"(tt));
-    cpx<T> x[E];
-#pragma unroll
-    for (int i = 0; i < E; ++i) x[i] = lds[F::pad(makhoul_src(tt + TPF * i, N))];
-    GPA_PBAR();
-    F::template fwd_phase<0>(x, lds, tt, tw);
-    GPA_PBAR();
-    F::template fwd_phase<1>(x, lds, tt, tw);
-    GPA_PBAR();
-    F::template fwd_phase<2>(x, lds, tt, tw);
-    GPA_PBAR();
-    D::fwd_scatter(x, lds, tt);
-    GPA_PBAR();
-    D::fwd_gather(x, lds, tt, wk);
-#pragma unroll
-    for (int i = 0; i < E; ++i) {
-      const int k = tt + TPF * i;
-      Dout[oa + k] = x[i].x;
-      Dout[ob + k] = x[i].y;
-    }
-  }
-}
-
 int pers_workgroups() {
   static int n = 0;
   if (!n) {
@@ -407,23 +194,6 @@ int pers_workgroups() {
 
 bool pow2_rowpers_offered(const Impl* w) {
   return !w->generic && w->dtype == 0 && w->lg1 == 12 && (w->n0 % 2) == 0 && w->n0 >= 64 && !opt_set(OPT_NO_ROWPERS);
-}
-
-hipError_t pow2_pqdct_pers(const Impl* w, const void* p, const void* weight, double* part_pq, int* npq, hipStream_t s) {
-  using G = PersGeom<12>;
-  auto kern = pqdct_pers_kernel<12>;
-  static unsigned lds_set = 0;
-  hipError_t e = set_dynamic_lds_once(reinterpret_cast<const void*>(kern), (int)G::LDS_BYTES, lds_set);
-  if (e != hipSuccess) return e;
-  const int npairs = w->n0 / 2;
-  if (npairs > MAXPART) return hipErrorInvalidValue;
-  *npq = npairs;
-  const int grid = npairs < pers_workgroups() ? npairs : pers_workgroups();
-  GPA_PROF("pqdct_kernel", s);
-  kern<<<dim3(grid, 1, w->nprob), G::TPF, G::LDS_BYTES, s>>>((const float*)p, (const float*)weight, (float*)w->q, w->n0,
-                                                            (const cpx<float>*)w->tw1, (const cpx<float>*)w->wk1, w->flags, part_pq,
-                                                            (size_t)w->n0 * w->n1);
-  return hipGetLastError();
 }
 
 hipError_t pow2_rowidct_p_pers(const Impl* w, const void* pin, void* pout, const double* part_rho, int nrho, int it,

@@ -45,14 +45,15 @@ def kidx_mismatch_is_tie(amp_stack, kidx_a, kidx_b, rtol):
 
 @pytest.fixture
 def gpa_option():
-    """set diagnostic switches of the library (gpa_set_option) for one test; whatever was set is cleared afterwards"""
+    """set diagnostic switches of the library (gpa_set_option) for one test; afterwards every switch touched is back at the
+    value it had before the test (the GPA_<NAME> environment variable's, or unset)"""
     from pygpa_amd import _lib
-    touched = set()
+    before = {}
 
     def setter(name, value):
-        touched.add(name)
+        before.setdefault(name, _lib.get_option(name))
         _lib.set_option(name, value)
 
     yield setter
-    for name in touched:
-        _lib.set_option(name, None)
+    for name, value in before.items():
+        _lib.set_option(name, value)

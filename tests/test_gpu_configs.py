@@ -1,5 +1,5 @@
 """BASELINE.json configs at their full sizes, the measured fp32 accuracy, the multi-rank device path and the
-hipGraph / table-staging machinery of the fused driver.  Run with `-m gpu` on an MI355X.
+table-staging machinery of the fused driver.  Run with `-m gpu` on an MI355X.
 
 Accuracy numbers are written to gpurun_out/r02_accuracy.json (copied to profiles/ when committed)."""
 import json
@@ -93,36 +93,6 @@ def test_sweep_tables_survive_spectral_calls():
     GPA.gaussian_deconvolve(np.zeros((2,) + shape), 10, dr=20)
     b = plan.sweep(imgp, kvecs[1], klist, 10)
     assert np.array_equal(a[0], b[0])
-
-
-# ---- hipGraph replay of the fused driver -------------------------------------------------------------------
-@pytest.mark.parametrize('dtype', [np.float64, np.float32])
-def test_graph_replay_equals_eager(dtype):
-    """the 2nd call with one key captures the launches, later calls replay them: same bits as the eager
-    plan, also after the k-lists changed (tables restaged under an existing graph) and for a second buffer"""
-    from test_gpu_parity import DeviceArray
-    shape = (256, 512)
-    kvecs = hex_kvecs(0.1, 7.0)
-    img = hex_moire(shape, kvecs, gaussian_bump_displacement(shape), noise=0.1, seed=8)
-    img2 = hex_moire(shape, kvecs, gaussian_bump_displacement(shape), noise=0.3, seed=9)
-    kl_a = np.stack(explicit_klists(kvecs, 0.04, 2, 2))
-    kl_b = np.stack(explicit_klists(kvecs, 0.03, 2, 2))          # same K and x-plane count, other values
-    eager = _lib.Plan(shape, 12, dtype)
-    ref = {(i, k): eager.extract_displacement_field(im, kvecs, kl, 10, 20)[0]
-           for i, im in enumerate((img, img2)) for k, kl in (('a', kl_a), ('b', kl_b))}
-    eager.close()
-    _lib.set_option('USE_GRAPH', '1')          # read when the plan is created (opt-in: not faster on ROCm 7.2)
-    plan = _lib.Plan(shape, 12, dtype)
-    _lib.set_option('USE_GRAPH', None)
-    d_img = [DeviceArray(img.astype(dtype)), DeviceArray(img2.astype(dtype))]
-    outs = [DeviceArray(np.zeros((2,) + shape, dtype=dtype)) for _ in range(2)]
-    seq = [(0, 'a', 0), (0, 'a', 0), (0, 'a', 0), (0, 'b', 0), (0, 'a', 0), (1, 'a', 1), (1, 'a', 1), (1, 'b', 1),
-           (1, 'a', 1), (0, 'a', 0), (0, 'b', 0)]
-    for i, k, j in seq:
-        plan.extract_displacement_field_async(d_img[i].ptr, kvecs, kl_a if k == 'a' else kl_b, 10, 20, 10, outs[j].ptr)
-        plan.sync()
-        assert np.array_equal(outs[j].get(), ref[(i, k)]), (i, k, j)
-    plan.close()
 
 
 def test_download_async_pipeline():

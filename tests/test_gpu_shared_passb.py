@@ -228,35 +228,6 @@ def test_raw_winners_in_the_gradient_stage(dtype, gpa_option):
         assert (np.abs(a - b) < tol * max(1.0, np.abs(b).max())).mean() > 0.9999
 
 
-@pytest.mark.parametrize('dtype', DTYPES)
-@pytest.mark.parametrize('shape', [(2048, 96), (4096, 64), (3000, 80), (1500, 72)])
-def test_shared_pass_a_opt_in(shape, dtype, monkeypatch, gpa_option):
-    """the shared-forward pass A (GPA_SHARED_A=1: one forward transform per column for all x-planes, end fix of the
-    first / last rows on the matrix cores) -- measured slower than the per-plane kernel and therefore off by default,
-    its numbers pinned all the same: oracle's lock-ins (all of them, gpa_lockin_batch, and the sweep's winners), the
-    first / last 3 sigma ROWS on their own, periodic and zero-padded columns"""
-    gpa_option('SHARED_A', '1')
-    kvecs = hex_kvecs(0.1, 7.0)
-    img = hex_moire(shape, kvecs, gaussian_bump_displacement(shape), noise=0.2, seed=6)
-    img0 = img - img.mean()
-    kw, sigma, _ = orc.derive_params(kvecs)
-    klist = explicit_klists(kvecs, kw, 4, 2)[2]
-    plan = _lib.Plan(shape, len(klist), dtype)
-    out = plan.lockin_batch(img0, klist, sigma)
-    ref = orc.lockin_batch(img0, klist, sigma)
-    sc = np.abs(ref).max()
-    e3 = int(3 * sigma)
-    d = np.abs(out - ref) / sc
-    assert d.max() < TOL[dtype]['lock']
-    assert max(d[:, :e3, :].max(), d[:, -e3:, :].max()) < TOL[dtype]['lock']
-    refs = orc.sweep(img0, sigma, klist, kvecs[2], workers=8)
-    lock, kidx, _ = plan.sweep(img0, kvecs[2], klist, sigma)
-    plan.close()
-    check_kidx(kidx, refs['kidx'], img0, klist, sigma, TOL[dtype]['tie'])
-    same = kidx == refs['kidx']
-    assert same.mean() > 0.999 and rel(lock[same], refs['lockin'][same]) < TOL[dtype]['lock']
-
-
 def test_shared_passb_random_rows():
     """seeded random draws of the row length (960 ... 4096: periodic 2048 / 4096-point rows and every zero-padded length
     between them, including the ones that fall back to the per-candidate kernel), sigma (support of the end fix,
