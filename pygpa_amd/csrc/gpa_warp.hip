@@ -122,18 +122,36 @@ __global__ __launch_bounds__(256) void fir_cols_kernel(const T* __restrict__ in,
   }
 }
 
+// cubic B-spline weights as scipy.ndimage evaluates them (ni_splines.c: get_spline_interpolation_weights, order 3).
+// f64: the divisions by 6 as written (pinned to SciPy at 4e-15); f32: times 1/6 -- one instruction where an IEEE
+// division takes ten, six times per round of the fixed point, and 0.5 ulp of f32 either way
+template <class T>
+__device__ __forceinline__ T sixth(T v) {
+  if constexpr (sizeof(T) == 4) return v * T(0.16666666666666666);
+  else return v / T(6);
+}
 template <class T>
 __device__ __forceinline__ void bspline_weights(T t, T (&w)[4]) {
   const T z = T(1) - t;
-  w[1] = (t * t * (t - T(2)) * T(3) + T(4)) / T(6);
-  w[2] = (z * z * (z - T(2)) * T(3) + T(4)) / T(6);
-  w[0] = z * z * z / T(6);
+  w[1] = sixth(t * t * (t - T(2)) * T(3) + T(4));
+  w[2] = sixth(z * z * (z - T(2)) * T(3) + T(4));
+  w[0] = sixth(z * z * z);
   w[3] = T(1) - w[0] - w[1] - w[2];
 }
+// index type of the coefficient gathers: 32-bit element offsets from a uniform base (one address instruction per tap,
+// shared by the two components) while the field is below 2^32 bytes, 64-bit beyond
+template <bool WIDE> struct GatherIdx { typedef unsigned type; };
+template <> struct GatherIdx<true> { typedef size_t type; };
+// element `o` of a field: as base + 32-bit BYTE offset (the form the scalar-base global loads take) or a 64-bit index
+template <class T> __device__ __forceinline__ T gather(const T* __restrict__ base, unsigned o) {
+  return *reinterpret_cast<const T*>(reinterpret_cast<const char*>(base) + (unsigned)(o * (unsigned)sizeof(T)));
+}
+template <class T> __device__ __forceinline__ T gather(const T* __restrict__ base, size_t o) { return base[o]; }
 
 // mode='nearest': coordinate (already shifted by npad) unclamped, tap indices clamped
-template <class T, int NC>
+template <class T, int NC, bool WIDE = false>
 __device__ __forceinline__ void interp_nearest(const T* const (&coef)[NC], int m0, int m1, T x, T y, T (&out)[NC]) {
+  typedef typename GatherIdx<WIDE>::type I;
   // keep floor() finite for wild coordinates: everything beyond one sample outside reads the edge
   x = x < T(-2) ? T(-2) : (x > T(m0 + 1) ? T(m0 + 1) : x);
   y = y < T(-2) ? T(-2) : (y > T(m1 + 1) ? T(m1 + 1) : y);
@@ -151,18 +169,20 @@ __device__ __forceinline__ void interp_nearest(const T* const (&coef)[NC], int m
   for (int a = 0; a < 4; ++a) {
     int i = ix + a;
     i = i < 0 ? 0 : (i >= m0 ? m0 - 1 : i);
-    const size_t row = (size_t)i * m1;
+    const I row = (I)i * (I)m1;
+    const I o0 = row + (I)cy[0], o1 = row + (I)cy[1], o2 = row + (I)cy[2], o3 = row + (I)cy[3];
 #pragma unroll
     for (int n = 0; n < NC; ++n) {
-      const T* cr = coef[n] + row;
-      out[n] += wx[a] * (wy[0] * cr[cy[0]] + wy[1] * cr[cy[1]] + wy[2] * cr[cy[2]] + wy[3] * cr[cy[3]]);
+      const T* cr = coef[n];
+      out[n] += wx[a] * (wy[0] * gather(cr, o0) + wy[1] * gather(cr, o1) + wy[2] * gather(cr, o2) + wy[3] * gather(cr, o3));
     }
   }
 }
 
 // mode='constant': whole-sample mirrored taps, `cval` where the coordinate leaves [0, n-1] (NaN coordinates too)
-template <class T, int NC>
+template <class T, int NC, bool WIDE = false>
 __device__ __forceinline__ void interp_constant(const T* const (&coef)[NC], int n0, int n1, T x, T y, T cval, T (&out)[NC]) {
+  typedef typename GatherIdx<WIDE>::type I;
   if (!(x >= T(0) && x <= T(n0 - 1) && y >= T(0) && y <= T(n1 - 1))) {
 #pragma unroll
     for (int n = 0; n < NC; ++n) out[n] = cval;
@@ -180,18 +200,19 @@ __device__ __forceinline__ void interp_constant(const T* const (&coef)[NC], int 
   for (int n = 0; n < NC; ++n) out[n] = T(0);
 #pragma unroll
   for (int a = 0; a < 4; ++a) {
-    const size_t row = (size_t)ext_index(ix + a, n0, EXT_MIRROR) * n1;
+    const I row = (I)ext_index(ix + a, n0, EXT_MIRROR) * (I)n1;
+    const I o0 = row + (I)cy[0], o1 = row + (I)cy[1], o2 = row + (I)cy[2], o3 = row + (I)cy[3];
 #pragma unroll
     for (int n = 0; n < NC; ++n) {
-      const T* cr = coef[n] + row;
-      out[n] += wx[a] * (wy[0] * cr[cy[0]] + wy[1] * cr[cy[1]] + wy[2] * cr[cy[2]] + wy[3] * cr[cy[3]]);
+      const T* cr = coef[n];
+      out[n] += wx[a] * (wy[0] * gather(cr, o0) + wy[1] * gather(cr, o1) + wy[2] * gather(cr, o2) + wy[3] * gather(cr, o3));
     }
   }
 }
 
 // the same fixed point with scipy's mode='constant' (geometric_phase_analysis.py:248, :262 `mode=`): coefficients of the
 // unpadded field, 0 outside it in every round but the last of the overlap variant, which passes cval=nan (:297-299)
-template <class T>
+template <class T, bool WIDE>
 __global__ __launch_bounds__(256) void invert_constant_kernel(const T* __restrict__ c0, const T* __restrict__ c1, int n0, int n1,
                                                              int edge, int shift, int iters, int nan_last,
                                                              T* __restrict__ out, int wr0, int wc0, int wc1) {
@@ -201,13 +222,13 @@ __global__ __launch_bounds__(256) void invert_constant_kernel(const T* __restric
   const T* const coef[2] = {c0, c1};
   const T xb = T(i - edge), yb = T(j - edge);
   T v[2];
-  interp_constant<T, 2>(coef, n0, n1, xb, yb, T(0), v);
+  interp_constant<T, 2, WIDE>(coef, n0, n1, xb, yb, T(0), v);
   const T xs = xb - T(shift), ys = yb - T(shift);
   for (int it = 0; it < iters; ++it) {
     T nv[2];
     const bool last_nan = nan_last && it == iters - 1;
     const T cval = last_nan ? (T)__builtin_nan("") : T(0);
-    interp_constant<T, 2>(coef, n0, n1, xs + v[0], ys + v[1], cval, nv);
+    interp_constant<T, 2, WIDE>(coef, n0, n1, xs + v[0], ys + v[1], cval, nv);
     // a round that reproduces its input bit for bit is a fixed point: every later round returns the same numbers, so the
     // wavefront leaves once all its pixels are there (the same result as running all rounds; f32 fields settle after
     // ~15 of the reference's 36 rounds).  The cval = NaN round of invert_u_overlap is a different function: still run.
@@ -215,7 +236,7 @@ __global__ __launch_bounds__(256) void invert_constant_kernel(const T* __restric
     v[0] = nv[0];
     v[1] = nv[1];
     if (__all(fixed)) {
-      if (nan_last && !last_nan) interp_constant<T, 2>(coef, n0, n1, xs + v[0], ys + v[1], (T)__builtin_nan(""), v);
+      if (nan_last && !last_nan) interp_constant<T, 2, WIDE>(coef, n0, n1, xs + v[0], ys + v[1], (T)__builtin_nan(""), v);
       break;
     }
   }
@@ -224,7 +245,7 @@ __global__ __launch_bounds__(256) void invert_constant_kernel(const T* __restric
 }
 
 // u_it(r) <- u(r + u_it(r)), all rounds for one pixel (geometric_phase_analysis.py:291-299)
-template <class T>
+template <class T, bool WIDE>
 __global__ __launch_bounds__(256) void invert_kernel(const T* __restrict__ c0, const T* __restrict__ c1, int m0, int m1,
                                                     int n0, int n1, int edge, int shift, int iters, T* __restrict__ out,
                                                     int wr0, int wc0, int wc1) {
@@ -234,12 +255,12 @@ __global__ __launch_bounds__(256) void invert_kernel(const T* __restrict__ c0, c
   const T* const coef[2] = {c0, c1};
   const T xb = T(i - edge + NPAD), yb = T(j - edge + NPAD);
   T v[2];
-  interp_nearest<T, 2>(coef, m0, m1, xb, yb, v);
+  interp_nearest<T, 2, WIDE>(coef, m0, m1, xb, yb, v);
   // (shift != 0: invert_u, which samples every later round at r + u_it - shift, geometric_phase_analysis.py:258)
   const T xs = xb - T(shift), ys = yb - T(shift);
   for (int it = 0; it < iters; ++it) {
     T nv[2];
-    interp_nearest<T, 2>(coef, m0, m1, xs + v[0], ys + v[1], nv);
+    interp_nearest<T, 2, WIDE>(coef, m0, m1, xs + v[0], ys + v[1], nv);
     // bitwise fixed point of every pixel of the wavefront: all later rounds return the same numbers (see above)
     const bool fixed = nv[0] == v[0] && nv[1] == v[1];
     v[0] = nv[0];
@@ -360,8 +381,12 @@ hipError_t invert_constant_t(const T* d_u, int n0, int n1, T scale, int iters, i
     // cval (:255-258) and keeps 0 outside -- said by the caller, not guessed from the geometry (invert_u with its
     // default edge = 0 has shift == 0 too)
     GPA_PROF("invert_kernel", s);
-    invert_constant_kernel<T><<<dim3((v.w + 255) / 256, v.h), 256, 0, s>>>(c0, c1, n0, n1, edge, shift, iters, nan_last ? 1 : 0, d_out,
-                                                                          v.r0, v.c0, v.c0 + v.w);
+    if (npx * sizeof(T) < ((size_t)1 << 32))
+      invert_constant_kernel<T, false><<<dim3((v.w + 255) / 256, v.h), 256, 0, s>>>(c0, c1, n0, n1, edge, shift, iters, nan_last ? 1 : 0, d_out,
+                                                                                   v.r0, v.c0, v.c0 + v.w);
+    else
+      invert_constant_kernel<T, true><<<dim3((v.w + 255) / 256, v.h), 256, 0, s>>>(c0, c1, n0, n1, edge, shift, iters, nan_last ? 1 : 0, d_out,
+                                                                                  v.r0, v.c0, v.c0 + v.w);
     }
     e = hipGetLastError();
   }
@@ -392,7 +417,10 @@ hipError_t invert_t(const T* d_u, int n0, int n1, T scale, int iters, int edge, 
       const Win v = window(nrect > 0 ? rects + 4 * q : nullptr, o0, o1);
       if (v.h <= 0 || v.w <= 0) continue;
       GPA_PROF("invert_kernel", s);
-      invert_kernel<T><<<dim3((v.w + 255) / 256, v.h), 256, 0, s>>>(c0, c1, m0, m1, n0, n1, edge, shift, iters, d_out, v.r0, v.c0, v.c0 + v.w);
+      if (mp * sizeof(T) < ((size_t)1 << 32))
+        invert_kernel<T, false><<<dim3((v.w + 255) / 256, v.h), 256, 0, s>>>(c0, c1, m0, m1, n0, n1, edge, shift, iters, d_out, v.r0, v.c0, v.c0 + v.w);
+      else
+        invert_kernel<T, true><<<dim3((v.w + 255) / 256, v.h), 256, 0, s>>>(c0, c1, m0, m1, n0, n1, edge, shift, iters, d_out, v.r0, v.c0, v.c0 + v.w);
     }
     e = hipGetLastError();
   }
