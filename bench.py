@@ -54,6 +54,7 @@ def parse_args():
                          'of the GPU idle between their ~45 dependent kernels; several in flight fill it')
     ap.add_argument('--no-cpu', action='store_true', help='skip the CPU baseline leg')
     ap.add_argument('--no-f64', action='store_true', help='skip the f64 leg')
+    ap.add_argument('--no-lf', action='store_true', help='N > 1: skip the tile-sharded Lawler-Fujita diagnostic after the timed region')
     ap.add_argument('--no-config5', action='store_true', help='skip the 16384^2 tile pipeline + Lawler-Fujita leg (config5_single_gpu)')
     ap.add_argument('--window', type=int, default=2048, help='N > 1: side of the (power-of-two) tile windows')
     ap.add_argument('--backend', default='nccl', help='N > 1: torch.distributed backend (gloo stages through the host)')
@@ -380,9 +381,28 @@ def kernel_table(n, L0, L1, P, K, Bx, s, iters, kern, stage, res_s):
     out['whole_step'] = {'algorithmic_GBps': round(step_alg / res_s / 1e9, 1),
                          'counter_GBps': round(step_hbm / res_s / 1e9, 1) if step_hbm else None,
                          'counter_frac_of_hbm_peak': round(step_hbm / res_s / 1e9 / HBM_PEAK_GBS, 4) if step_hbm else None,
-                         'survey_model_GBps': round(survey_bytes(n, n, P, K, s, iters)['total'] / res_s / 1e9, 1),
-                         'note': 'over the resident-only step time; survey_model = SURVEY.md 8(d) bytes of the reference '
-                                 'algorithm (2-D FFT pairs, 19 arrays per PCG iteration), which this build does not move'}
+                         'note': 'over the resident-only step time.  (SURVEY.md 8(d)\'s byte model of the REFERENCE algorithm -- 2-D FFT '
+                                 'pairs, 19 arrays per PCG iteration -- is obsolete as a yardstick: this build does not move those bytes, and '
+                                 'divided by this step time the model exceeds the HBM peak; dropped from the line in round 5.)'}
+    # ---- the unwrap as a group: one working PCG iteration = its five launches (stencil-fused iteration) or four; bytes of the
+    #      iteration over the sum of the per-launch times (serial clock: the two components run one after the other while profiling)
+    it_kernels = [k for k in ('pqdct_kernel', 'colstream_agg_kernel', 'colstream_scan_kernel', 'colstream_apply_kernel', 'rowidct_p_kernel',
+                              'rowdct_fused_kernel', 'colsolve_kernel', 'colsolve_tri_kernel', 'pq_kernel', 'rowidct_pq_kernel') if k in table]
+    if it_kernels and sum(iters) > 0:
+        fused = 'pqdct_kernel' in table and 'colstream_agg_kernel' in table
+        names = (['pqdct_kernel', 'colstream_agg_kernel', 'colstream_scan_kernel', 'colstream_apply_kernel', 'rowidct_p_kernel'] if fused
+                 else [k for k in it_kernels if k not in ('pqdct_kernel',)])
+        per_launch_us = {k: table[k]['total_ms'] / max(table[k]['working_launches'], 1) * 1e3 for k in names if k in table}
+        it_us = sum(per_launch_us.values())
+        it_bytes = (44 if fused else 48) * s // 4 * n * n     # 44 bytes per sample and iteration (f32), 48 unfused
+        unwrap_ms = sum(table[k]['total_ms'] for k in it_kernels + ['phi_flush_kernel'] if k in table)
+        out['roofline_unwrap'] = {'bound': 'hbm', 'group': names, 'us_per_iteration': round(it_us, 1), 'per_launch_us': {k: round(v, 1) for k, v in per_launch_us.items()},
+                                  'algorithmic_bytes_per_iteration': int(it_bytes), 'achieved': round(it_bytes / (it_us * 1e-6) / 1e9, 1),
+                                  'peak': HBM_PEAK_GBS, 'unit': 'GB/s', 'frac': round(it_bytes / (it_us * 1e-6) / 1e9 / HBM_PEAK_GBS, 4),
+                                  'unwrap_serial_ms_both_components': round(unwrap_ms, 4),
+                                  'share_of_serial_step': round(unwrap_ms / max(sum(table[k]['total_ms'] for k in table), 1e-9), 3),
+                                  'note': 'one working PCG iteration as a group: its launches one after the other (HIP events) over its algorithmic '
+                                          'bytes; in the timed step the two components run on two streams and overlap'}
     return out
 
 
@@ -410,7 +430,7 @@ def single_gpu(args):
         'resident_only': {'value': m['resident_value'], 'ms_per_step': m['resident_ms'],
                           'note': 'same loop with u left in HBM (round-1 definition)'},
     }
-    for key in ('early_stop', 'kernels', 'stage_ms', 'roofline', 'whole_step'):
+    for key in ('early_stop', 'kernels', 'stage_ms', 'roofline', 'roofline_unwrap', 'whole_step'):
         if key in m:
             out[key] = m[key]
 
@@ -711,6 +731,23 @@ def multi_gpu(args, world, rank, local_rank):
         t = t.to(dev)
     dist.all_reduce(t, op=dist.ReduceOp.MAX)
     dt = float(t.item())
+    # ---- diagnostics for the scaling line (after the timed region): what the backend says the world is, and per-rank
+    #      stage times -- host times of the timed stream (enqueueing + waits) and DEVICE-inclusive times of one unpipelined
+    #      step with the device drained after every stage
+    dev_ms = {}
+    pipe.step(timings=dev_ms)
+    lf_ms = None
+    if not args.no_lf:
+        torch.cuda.synchronize(dev)
+        t_lf = time.perf_counter()
+        full = torch.zeros(shape, dtype=torch.float32 if np_dt is np.float32 else torch.float64, device=dev)
+        pipe.undistort(full)          # (the rounds depend on u, not on the image: a zero image times the same kernels)
+        torch.cuda.synchronize(dev)
+        lf_ms = (time.perf_counter() - t_lf) * 1e3
+    mine = {'rank': rank, 'tiles': len(pipe.mine), 'stream_host_ms_per_image': {k: round(v / max(args.steps, 1) * 1e3, 3) for k, v in pipe.stage_s.items()} if stream else None,
+            'step_device_ms': {k: round(v, 3) for k, v in dev_ms.items()}, 'undistort_tile_sharded_ms': None if lf_ms is None else round(lf_ms, 2)}
+    per_rank = [None] * world
+    dist.all_gather_object(per_rank, mine)
     if rank == 0:
         npx = shape[0] * shape[1]
         cfg = {4: 'BASELINE.json configs[3]', 8: 'BASELINE.json configs[4]: the 16384^2 image, WITHOUT the Lawler-Fujita '
@@ -747,6 +784,13 @@ def multi_gpu(args, world, rank, local_rank):
                        'pixels_per_gpu': shape[0] * shape[1] // world, 'schedule': args.schedule,
                        'unwrap_iters': iters_rep, 'backend': args.backend, 'collectives': coll,
                        'stage_ms_per_image_rank0': stages},
+            'ranks': {'world_size_reported_by_backend': dist.get_world_size(), 'backend': dist.get_backend(),
+                      'rccl_version': list(torch.cuda.nccl.version()) if args.backend == 'nccl' else None,
+                      'devices_visible': torch.cuda.device_count(), 'per_rank': per_rank,
+                      'note': 'stream_host_ms = host time of the timed image stream per stage (enqueueing and waits); step_device_ms = one '
+                              'unpipelined step() after the timed region with the device drained after every stage; '
+                              'undistort_tile_sharded_ms = TiledPipeline.undistort (Lawler-Fujita of the stitched field, every rank its own '
+                              'tiles, one all_reduce), first call, after the timed region -- NOT part of `value`'},
         }
         # roofline of the tile stage's dominant kernel (pass B on one window), measured on this rank AFTER the timed
         # region on a whole-image call of the window's shape: the same kernel instantiation on the same rows

@@ -40,35 +40,38 @@ __device__ __forceinline__ int ext_index(int i, int n, int ext) {
   return i >= n ? p - i : i;
 }
 
-template <class T>
-__global__ __launch_bounds__(256) void pad_edge_kernel(const T* __restrict__ in, int n0, int n1, int npad, T scale,
-                                                      T* __restrict__ out) {
-  const int m1 = n1 + 2 * npad;
-  const int y = blockIdx.x * 256 + threadIdx.x, x = blockIdx.y;
-  if (y >= m1) return;
-  int sx = x - npad, sy = y - npad;
-  sx = sx < 0 ? 0 : (sx >= n0 ? n0 - 1 : sx);
-  sy = sy < 0 ? 0 : (sy >= n1 ? n1 - 1 : sy);
-  out[(size_t)x * m1 + y] = scale * in[(size_t)sx * n1 + sy];
-}
-
 // FIR along rows (axis 1): one workgroup = FR_OUT consecutive outputs of one row, a thread computes FPT consecutive ones
 // from a register window of FPT + 2 KT inputs (read from the LDS tile once: ~10 LDS reads per output where the
 // one-output-per-thread form of rounds 1-4 made 130; the taps are uniform and come through the scalar cache).  Same
 // sum, same order of additions per output.
 constexpr int FPT = 8;                 // outputs per thread
 constexpr int FR_OUT = 256 * FPT;      // outputs per workgroup (rows)
-template <class T>
+// PADSRC: `in` is the UNPADDED sn0 x sn1 field and the m0 x m1 array this pass filters is its edge-replicated padding by npad
+// samples, scaled: element (x, y) = scale * in[clamp(x - npad)][clamp(y - npad)] is formed while the tile is loaded -- what
+// pad_edge_kernel used to write to memory and this kernel to read back (2 x 1.2 ms at 16384^2)
+template <class T, bool PADSRC>
 __global__ __launch_bounds__(256) void fir_rows_kernel(const T* __restrict__ in, int m0, int m1, int ext,
-                                                      const T* __restrict__ h, T* __restrict__ out) {
+                                                      const T* __restrict__ h, T* __restrict__ out, int npad, int sn0, int sn1,
+                                                      T scale) {
   __shared__ T tile[FR_OUT + 2 * KT];
   const int x = blockIdx.y, y0 = blockIdx.x * FR_OUT;
-  const T* row = in + (size_t)x * m1;
-  const bool interior = y0 - KT >= 0 && y0 + FR_OUT + KT <= m1;
-  if (interior) {
-    for (int i = threadIdx.x; i < FR_OUT + 2 * KT; i += 256) tile[i] = row[y0 - KT + i];
+  if constexpr (PADSRC) {
+    int sx = x - npad;
+    sx = sx < 0 ? 0 : (sx >= sn0 ? sn0 - 1 : sx);
+    const T* row = in + (size_t)sx * sn1;
+    for (int i = threadIdx.x; i < FR_OUT + 2 * KT; i += 256) {
+      int sy = ext_index(y0 - KT + i, m1, ext) - npad;
+      sy = sy < 0 ? 0 : (sy >= sn1 ? sn1 - 1 : sy);
+      tile[i] = scale * row[sy];
+    }
   } else {
-    for (int i = threadIdx.x; i < FR_OUT + 2 * KT; i += 256) tile[i] = row[ext_index(y0 - KT + i, m1, ext)];
+    const T* row = in + (size_t)x * m1;
+    const bool interior = y0 - KT >= 0 && y0 + FR_OUT + KT <= m1;
+    if (interior) {
+      for (int i = threadIdx.x; i < FR_OUT + 2 * KT; i += 256) tile[i] = row[y0 - KT + i];
+    } else {
+      for (int i = threadIdx.x; i < FR_OUT + 2 * KT; i += 256) tile[i] = row[ext_index(y0 - KT + i, m1, ext)];
+    }
   }
   __syncthreads();
   const int t0 = threadIdx.x * FPT;
@@ -86,6 +89,20 @@ __global__ __launch_bounds__(256) void fir_rows_kernel(const T* __restrict__ in,
     for (int o = 0; o < FPT; ++o) acc[o] += hk * win[o + k];
   }
   T* orow = out + (size_t)x * m1 + y0 + t0;
+  if ((m1 & 3) == 0 && y0 + t0 + FPT <= m1) {
+    // whole 16-byte (f32: two 16-byte) stores: eight scalar stores per thread, 32 bytes apart between lanes, used a quarter of
+    // every line they touched
+    struct alignas(16) V { T v[16 / sizeof(T)]; };
+    constexpr int PER = 16 / sizeof(T);
+#pragma unroll
+    for (int o = 0; o < FPT; o += PER) {
+      V q;
+#pragma unroll
+      for (int e = 0; e < PER; ++e) q.v[e] = acc[o + e];
+      *reinterpret_cast<V*>(orow + o) = q;
+    }
+    return;
+  }
 #pragma unroll
   for (int o = 0; o < FPT; ++o)
     if (y0 + t0 + o < m1) orow[o] = acc[o];
@@ -132,11 +149,23 @@ __device__ __forceinline__ T sixth(T v) {
 }
 template <class T>
 __device__ __forceinline__ void bspline_weights(T t, T (&w)[4]) {
+#pragma clang fp contract(off)   // (the same bits at every call site; SciPy's C evaluates these without fused operations too)
   const T z = T(1) - t;
   w[1] = sixth(t * t * (t - T(2)) * T(3) + T(4));
   w[2] = sixth(z * z * (z - T(2)) * T(3) + T(4));
   w[0] = sixth(z * z * z);
   w[3] = T(1) - w[0] - w[1] - w[2];
+}
+// one row of the 4 x 4 tap sum, and its accumulation: explicit fused multiply-adds in ONE fixed order, so that the same taps
+// give the same bits whichever kernel or code path gathers them (from L1 / L2, or from the LDS window of invert_tile_kernel)
+template <class T>
+__device__ __forceinline__ T tap_row(const T (&wy)[4], T t0, T t1, T t2, T t3) {
+#pragma clang fp contract(off)
+  T r = wy[0] * t0;
+  r = fma(wy[1], t1, r);
+  r = fma(wy[2], t2, r);
+  r = fma(wy[3], t3, r);
+  return r;
 }
 // index type of the coefficient gathers: 32-bit element offsets from a uniform base (one address instruction per tap,
 // shared by the two components) while the field is below 2^32 bytes, 64-bit beyond
@@ -174,7 +203,7 @@ __device__ __forceinline__ void interp_nearest(const T* const (&coef)[NC], int m
 #pragma unroll
     for (int n = 0; n < NC; ++n) {
       const T* cr = coef[n];
-      out[n] += wx[a] * (wy[0] * gather(cr, o0) + wy[1] * gather(cr, o1) + wy[2] * gather(cr, o2) + wy[3] * gather(cr, o3));
+      out[n] = fma(wx[a], tap_row(wy, gather(cr, o0), gather(cr, o1), gather(cr, o2), gather(cr, o3)), out[n]);
     }
   }
 }
@@ -205,7 +234,7 @@ __device__ __forceinline__ void interp_constant(const T* const (&coef)[NC], int 
 #pragma unroll
     for (int n = 0; n < NC; ++n) {
       const T* cr = coef[n];
-      out[n] += wx[a] * (wy[0] * gather(cr, o0) + wy[1] * gather(cr, o1) + wy[2] * gather(cr, o2) + wy[3] * gather(cr, o3));
+      out[n] = fma(wx[a], tap_row(wy, gather(cr, o0), gather(cr, o1), gather(cr, o2), gather(cr, o3)), out[n]);
     }
   }
 }
@@ -271,6 +300,109 @@ __global__ __launch_bounds__(256) void invert_kernel(const T* __restrict__ c0, c
   out[(size_t)o0 * o1 + (size_t)i * o1 + j] = v[1];
 }
 
+// The same fixed point on 16 x 16 pixel tiles with the coefficient window of the LATER rounds staged in LDS (round 5).
+// Every round gathers 2 x 16 coefficients per pixel around r + u_it(r); the kernel above is bound by those gathers (L1 /
+// texture-address rate and the dependent chain of rounds: 200 instructions per round issue in a quarter of the time a round
+// takes).  The iterates of a tile move by hundreds of pixels in the first rounds where |u| is large, but contract by
+// |grad u| per round; once no pixel of the tile moved by more than 2 samples in a round, the bounding box of the tile's
+// sample points (+ spline support + a margin for what movement is left) is loaded into LDS ONCE -- both components
+// interleaved, tap indices clamped while loading, exactly as mode='nearest' clamps them -- and the remaining rounds read
+// their taps with ds_read_b64 (a lane whose 4 x 4 footprint leaves the window falls back to global memory for that round).
+// The arithmetic per tap and its order are interp_nearest's: the results are bit-identical to invert_kernel's.
+constexpr int LT = 16;        // tile side
+constexpr int LW = 48;        // window side (samples): tile stretched by up to 1.5 + footprint 4 + margin 2 x 4
+constexpr int LWP = LW + 1;   // row pitch (odd: the four rows of a wavefront start on different banks)
+constexpr int LMARG = 4;
+template <class T> struct T2 { T a, b; };
+
+template <class T>
+__device__ __forceinline__ bool interp_window(const T2<T>* __restrict__ win, int wx0, int wy0, int m0, int m1, T x, T y, T (&out)[2]) {
+  x = x < T(-2) ? T(-2) : (x > T(m0 + 1) ? T(m0 + 1) : x);
+  y = y < T(-2) ? T(-2) : (y > T(m1 + 1) ? T(m1 + 1) : y);
+  const T fx = floor(x), fy = floor(y);
+  const int rx = (int)fx - 1 - wx0, ry = (int)fy - 1 - wy0;     // window coordinates of the first tap
+  if (!(rx >= 0 && ry >= 0 && rx + 3 < LW && ry + 3 < LW)) return false;    // (NaN coordinates: false as well)
+  T wx[4], wy[4];
+  bspline_weights(x - fx, wx);
+  bspline_weights(y - fy, wy);
+  out[0] = out[1] = T(0);
+#pragma unroll
+  for (int a = 0; a < 4; ++a) {
+    const T2<T>* cr = win + (rx + a) * LWP + ry;
+    const T2<T> t0 = cr[0], t1 = cr[1], t2 = cr[2], t3 = cr[3];
+    out[0] = fma(wx[a], tap_row(wy, t0.a, t1.a, t2.a, t3.a), out[0]);
+    out[1] = fma(wx[a], tap_row(wy, t0.b, t1.b, t2.b, t3.b), out[1]);
+  }
+  return true;
+}
+
+template <class T, bool WIDE>
+__global__ __launch_bounds__(256) void invert_tile_kernel(const T* __restrict__ c0, const T* __restrict__ c1, int m0, int m1,
+                                                         int n0, int n1, int edge, int shift, int iters, T* __restrict__ out,
+                                                         int wr0, int wc0, int wr1, int wc1) {
+  __shared__ T2<T> win[LW * LWP];
+  __shared__ int box[4];                                   // min x, min y, max x, max y of the first taps
+  const int o1 = n1 + 2 * edge, o0 = n0 + 2 * edge;
+  const int ti = threadIdx.x >> 4, tj = threadIdx.x & 15;
+  const int i_raw = wr0 + blockIdx.y * LT + ti, j_raw = wc0 + blockIdx.x * LT + tj;
+  const bool valid = i_raw < wr1 && j_raw < wc1;
+  const int i = i_raw < wr1 ? i_raw : wr1 - 1, j = j_raw < wc1 ? j_raw : wc1 - 1;   // (lanes beyond the window shadow its last pixel)
+  const T* const coef[2] = {c0, c1};
+  const T xb = T(i - edge + NPAD), yb = T(j - edge + NPAD);
+  T v[2];
+  interp_nearest<T, 2, WIDE>(coef, m0, m1, xb, yb, v);
+  const T xs = xb - T(shift), ys = yb - T(shift);
+  int state = 0;        // 0: rounds from global memory, the workgroup still deciding; 1: window staged; 2: no window (does not fit)
+  int wx0 = 0, wy0 = 0;
+  for (int it = 0; it < iters; ++it) {
+    T nv[2];
+    const T x = xs + v[0], y = ys + v[1];
+    if (state != 1 || !interp_window<T>(win, wx0, wy0, m0, m1, x, y, nv)) interp_nearest<T, 2, WIDE>(coef, m0, m1, x, y, nv);
+    const bool fixed = nv[0] == v[0] && nv[1] == v[1];
+    const bool moving = !(fabs(nv[0] - v[0]) <= T(2) && fabs(nv[1] - v[1]) <= T(2));   // (NaN: moving)
+    v[0] = nv[0];
+    v[1] = nv[1];
+    if (state == 0) {
+      // workgroup-uniform decision (every wavefront is still in the loop: none leaves before the decision is made)
+      if (it == 0 && threadIdx.x < 4) box[threadIdx.x] = threadIdx.x < 2 ? 0x7fffffff : (int)0x80000000;
+      if (!__syncthreads_or(moving ? 1 : 0)) {
+        T xn = xs + v[0], yn = ys + v[1];
+        xn = xn < T(-2) ? T(-2) : (xn > T(m0 + 1) ? T(m0 + 1) : xn);
+        yn = yn < T(-2) ? T(-2) : (yn > T(m1 + 1) ? T(m1 + 1) : yn);
+        const int fx = (int)floor(xn) - 1, fy = (int)floor(yn) - 1;
+        atomicMin(&box[0], fx);
+        atomicMin(&box[1], fy);
+        atomicMax(&box[2], fx);
+        atomicMax(&box[3], fy);
+        __syncthreads();
+        const int bx0 = box[0], by0 = box[1], bx1 = box[2], by1 = box[3];
+        if (bx1 - bx0 + 4 + 2 * LMARG <= LW && by1 - by0 + 4 + 2 * LMARG <= LW) {
+          // centre the box in the window; tap indices clamped while loading = mode 'nearest' clamping them at use
+          wx0 = bx0 - (LW - (bx1 - bx0 + 4)) / 2;
+          wy0 = by0 - (LW - (by1 - by0 + 4)) / 2;
+          for (int e = threadIdx.x; e < LW * LW; e += 256) {
+            const int r = e / LW, c = e - r * LW;
+            int gi = wx0 + r, gj = wy0 + c;
+            gi = gi < 0 ? 0 : (gi >= m0 ? m0 - 1 : gi);
+            gj = gj < 0 ? 0 : (gj >= m1 ? m1 - 1 : gj);
+            const size_t o = (size_t)gi * m1 + gj;
+            win[r * LWP + c] = T2<T>{c0[o], c1[o]};
+          }
+          state = 1;
+        } else {
+          state = 2;
+        }
+        __syncthreads();
+      }
+      continue;      // (no wavefront leaves while the workgroup may still meet at a barrier)
+    }
+    if (__all(fixed)) break;
+  }
+  if (!valid) return;
+  out[(size_t)i * o1 + j] = v[0];
+  out[(size_t)o0 * o1 + (size_t)i * o1 + j] = v[1];
+}
+
 // final resampling, map_coordinates defaults: order 3, mode='constant', cval = 0
 template <class T>
 __global__ __launch_bounds__(256) void warp_constant_kernel(const T* __restrict__ coef, int n0, int n1,
@@ -331,12 +463,16 @@ hipError_t reserve(WarpWs* ws, size_t bytes, hipStream_t s) {
   return hipSuccess;
 }
 
-// coefficients of `in` (m0 x m1, already padded if the mode wants it); tmp: same size
+// coefficients of `in` (m0 x m1); tmp: same size.  npad >= 0: `in` is the unpadded (m0 - 2 npad) x (m1 - 2 npad) field, padded
+// by edge replication and scaled on the fly (fir_rows_kernel<PADSRC>)
 template <class T>
-hipError_t prefilter(const T* in, int m0, int m1, int ext, const T* d_h, T* tmp, T* out, hipStream_t s) {
+hipError_t prefilter(const T* in, int m0, int m1, int ext, const T* d_h, T* tmp, T* out, hipStream_t s, int npad = -1,
+                     T scale = T(1)) {
   {
     GPA_PROF("fir_rows_kernel", s);
-    fir_rows_kernel<T><<<dim3((m1 + FR_OUT - 1) / FR_OUT, m0), 256, 0, s>>>(in, m0, m1, ext, d_h, tmp);
+    const dim3 grid((m1 + FR_OUT - 1) / FR_OUT, m0);
+    if (npad >= 0) fir_rows_kernel<T, true><<<grid, 256, 0, s>>>(in, m0, m1, ext, d_h, tmp, npad, m0 - 2 * npad, m1 - 2 * npad, scale);
+    else fir_rows_kernel<T, false><<<grid, 256, 0, s>>>(in, m0, m1, ext, d_h, tmp, 0, m0, m1, T(1));
   }
   {
     GPA_PROF("fir_cols_kernel", s);
@@ -367,11 +503,9 @@ hipError_t invert_constant_t(const T* d_u, int n0, int n1, T scale, int iters, i
   if (e != hipSuccess) return e;
   T* buf = (T*)ws->buf;
   const T* d_h = (const T*)ws->taps;
-  T *cp = buf, *tmp = buf + npx, *c0 = buf + 2 * npx, *c1 = buf + 3 * npx;
-  for (int c = 0; c < 2 && e == hipSuccess; ++c) {
-    pad_edge_kernel<T><<<dim3((n1 + 255) / 256, n0), 256, 0, s>>>(d_u + (size_t)c * npx, n0, n1, 0, scale, cp);
-    e = prefilter<T>(cp, n0, n1, EXT_MIRROR, d_h, tmp, c == 0 ? c0 : c1, s);
-  }
+  T *tmp = buf + npx, *c0 = buf + 2 * npx, *c1 = buf + 3 * npx;
+  for (int c = 0; c < 2 && e == hipSuccess; ++c)
+    e = prefilter<T>(d_u + (size_t)c * npx, n0, n1, EXT_MIRROR, d_h, tmp, c == 0 ? c0 : c1, s, 0, scale);
   if (e == hipSuccess) {
     const int o1 = n1 + 2 * edge, o0 = n0 + 2 * edge;
     for (int q = 0; q < (nrect > 0 ? nrect : 1); ++q) {
@@ -403,21 +537,24 @@ hipError_t invert_t(const T* d_u, int n0, int n1, T scale, int iters, int edge, 
   if (e != hipSuccess) return e;
   T* buf = (T*)ws->buf;
   const T* d_h = (const T*)ws->taps;
-  T *pad = buf, *tmp = buf + mp, *c0 = buf + 2 * mp, *c1 = buf + 3 * mp;
-  for (int c = 0; c < 2 && e == hipSuccess; ++c) {
-    {
-      GPA_PROF("pad_edge_kernel", s);
-      pad_edge_kernel<T><<<dim3((m1 + 255) / 256, m0), 256, 0, s>>>(d_u + (size_t)c * n0 * n1, n0, n1, NPAD, scale, pad);
-    }
-    e = prefilter<T>(pad, m0, m1, EXT_REFLECT, d_h, tmp, c == 0 ? c0 : c1, s);
-  }
+  T *tmp = buf + mp, *c0 = buf + 2 * mp, *c1 = buf + 3 * mp;
+  // (scaling and the 12-sample edge padding of mode 'nearest' happen while the row pass loads its tiles)
+  for (int c = 0; c < 2 && e == hipSuccess; ++c)
+    e = prefilter<T>(d_u + (size_t)c * n0 * n1, m0, m1, EXT_REFLECT, d_h, tmp, c == 0 ? c0 : c1, s, NPAD, scale);
   if (e == hipSuccess) {
     const int o1 = n1 + 2 * edge, o0 = n0 + 2 * edge;
     for (int q = 0; q < (nrect > 0 ? nrect : 1); ++q) {
       const Win v = window(nrect > 0 ? rects + 4 * q : nullptr, o0, o1);
       if (v.h <= 0 || v.w <= 0) continue;
       GPA_PROF("invert_kernel", s);
-      if (mp * sizeof(T) < ((size_t)1 << 32))
+      if (!opt_set(OPT_NO_LFTILE)) {
+        // 16 x 16 tiles, the later rounds from an LDS window (NO_LFTILE: the row-segment kernel, every round from L1 / L2)
+        const dim3 grid((v.w + LT - 1) / LT, (v.h + LT - 1) / LT);
+        if (mp * sizeof(T) < ((size_t)1 << 32))
+          invert_tile_kernel<T, false><<<grid, 256, 0, s>>>(c0, c1, m0, m1, n0, n1, edge, shift, iters, d_out, v.r0, v.c0, v.r0 + v.h, v.c0 + v.w);
+        else
+          invert_tile_kernel<T, true><<<grid, 256, 0, s>>>(c0, c1, m0, m1, n0, n1, edge, shift, iters, d_out, v.r0, v.c0, v.r0 + v.h, v.c0 + v.w);
+      } else if (mp * sizeof(T) < ((size_t)1 << 32))
         invert_kernel<T, false><<<dim3((v.w + 255) / 256, v.h), 256, 0, s>>>(c0, c1, m0, m1, n0, n1, edge, shift, iters, d_out, v.r0, v.c0, v.c0 + v.w);
       else
         invert_kernel<T, true><<<dim3((v.w + 255) / 256, v.h), 256, 0, s>>>(c0, c1, m0, m1, n0, n1, edge, shift, iters, d_out, v.r0, v.c0, v.c0 + v.w);

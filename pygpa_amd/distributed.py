@@ -420,12 +420,29 @@ class TiledPipeline:
             self.be.tile_gradients(self.wins[slot], self.wshape[1], self.kvecs, self.klists, self.sigma, self.border,
                                    (o0, o1, z0, z1), self.local, slot)
 
-    def step(self):
+    def step(self, timings=None):
+        """one image through the unpipelined schedule.  timings: a dict that receives the DEVICE-inclusive milliseconds of
+        every stage on this rank (the device is drained after each stage: a diagnostic pass, not a timed one)"""
+        import time
         n0, n1 = self.shape
         t0, t1 = self.tshape
         plane = t0 * t1
+        tick = [time.perf_counter()]
+
+        def mark(name):
+            if timings is not None:
+                self.be.sync_device()
+                now = time.perf_counter()
+                timings[name] = timings.get(name, 0.0) + (now - tick[0]) * 1e3
+                tick[0] = now
+
+        if timings is not None:
+            self.be.sync_device()
+            tick[0] = time.perf_counter()
         self.image_mean()
+        mark('mean')
         self._tile_stage()
+        mark('tile_stage')
         # --- collective 1 (RCCL all_gather over xGMI): the tile blocks of every rank (one rank: read in place)
         self.be.tiles_to_torch(self._host_staged())
         if self.world > 1:
@@ -433,6 +450,7 @@ class TiledPipeline:
             src = self.gathered
         else:
             src = self.local
+        mark('all_gather')
         # --- stitch + global unwrap, component c on rank c % world; collective 2 hands each component to everybody
         for c in self.unwrappers:
             comp = src[0, c] if self.world > 1 else src[c]
@@ -440,8 +458,10 @@ class TiledPipeline:
                            self.gdx[c], self.gdy[c], self.gw)
             self.be.unwrap_start(c, self.gdx[c], self.gdy[c], self.gw, self.u[c], self.kmax)
             self.iters[c] = self.be.unwrap_wait(c)
+        mark('stitch+unwrap')
         for c in range(2):
             self._broadcast(self.u[c], c % self.world)
+        mark('broadcast')
         return self.u
 
     # ---- Lawler-Fujita undistortion of the stitched field, sharded over the tiles ------------------------------------
