@@ -31,8 +31,9 @@ kstats 2048_c2 --size 2048 --kgrid 4x2
 kstats 512_f32 --size 512
 unset GPA_SERIAL_UNWRAP
 # one unwrap component at 8192^2 / 16384^2 and the tile pipeline's image stream at 16384^2 (-> gpurun_out/kstats/)
-WHAT="unwrap8192 unwrap16384 tiles16384" bash $ROOT/tools/gpu_kstats.sh > $out/kstats_long.log 2>&1; tail -3 $out/kstats_long.log | cut -c1-150
-cp $ROOT/gpurun_out/kstats/kernel_stats_unwrap_8192.csv $ROOT/gpurun_out/kstats/kernel_stats_unwrap_16384.csv $ROOT/gpurun_out/kstats/kernel_stats_tiles_16384.csv $out/ 2>/dev/null
+WHAT="unwrap8192 unwrap16384 tiles16384 lf16384" bash $ROOT/tools/gpu_kstats.sh > $out/kstats_long.log 2>&1; tail -3 $out/kstats_long.log | cut -c1-150
+cp $ROOT/gpurun_out/kstats/kernel_stats_unwrap_8192.csv $ROOT/gpurun_out/kstats/kernel_stats_unwrap_16384.csv $ROOT/gpurun_out/kstats/kernel_stats_tiles_16384.csv $ROOT/gpurun_out/kstats/kernel_stats_lf_16384.csv $out/ 2>/dev/null
+cd $ROOT && timeout 600 python3 tools/lf_times.py --sizes 2048 4096 8192 16384 > $out/lf_times.txt 2>&1; GPA_NO_LFTILE=1 timeout 600 python3 tools/lf_times.py --sizes 4096 16384 > $out/lf_times_rowkernel.txt 2>&1; cd /tmp
 cp $ROOT/gpurun_out/stage_times.json $out/ 2>/dev/null
 cd $ROOT && timeout 600 bash tools/gpu_unwrap_sizes.sh > /dev/null 2>&1; cp gpurun_out/unwrap_sizes.txt $out/ 2>/dev/null
 SIZES="256 500 512 1000 1024 1500 2000 2048 3000 4096 8192 16384" timeout 900 bash tools/gpu_sizes.sh > /dev/null 2>&1; cp gpurun_out/sizes.txt $out/ 2>/dev/null
@@ -51,6 +52,14 @@ done
 cd $ROOT
 COMMIT=${COMMIT:-unknown} python3 tools/make_counters.py $out/counters.json $out/pmc_[0-9] > /dev/null; head -c 900 $out/counters.json; echo
 cp $out/counters.json $ROOT/profiles/counters.json
+# HBM traffic of the Lawler-Fujita kernels at 16384^2 (one pass per counter, as above)
+j=0
+for set in "FETCH_SIZE" "WRITE_SIZE"; do
+  timeout 300 rocprofv3 --pmc $set --output-format csv -d $out/pmclf_$j -- python3 $ROOT/tools/lf_times.py --sizes 16384 --reps 1 > $out/pmclf_$j.log 2>&1
+  j=$((j+1))
+done
+python3 tools/pmc_summary.py $out/pmclf_[0-9] > $out/lf_pmc_16384.txt 2>&1
+rm -rf $out/pmclf_[0-9]
 # f64 traffic of the sweep (18.2 GB moved for 4 GB needed)
 j=0
 for set in "FETCH_SIZE" "WRITE_SIZE"; do
