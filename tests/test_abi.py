@@ -109,3 +109,22 @@ def test_device_buffer_selects_its_device_first(monkeypatch):
     assert all(c[2] == 3 for c in calls if c[0] == 'set')
     # the worker thread made its own selections
     assert {c[1] for c in calls[2:8]} != {calls[0][1]}
+
+
+def test_options_restore_previous_values(monkeypatch):
+    """`options()` (and the gpa_option fixture) put every switch back to the value it had -- an outer block's, the
+    GPA_<NAME> environment variable's, or unset -- instead of clearing it"""
+    _ensure_built()
+    monkeypatch.setenv('GPA_TRI_Q', '2')
+    _lib._OPTION_VALUES.pop('TRI_Q', None)
+    _lib._OPTION_VALUES.pop('COLSOLVE', None)
+    with _lib.options(TRI_Q=None, COLSOLVE='tri'):
+        assert _lib.get_option('TRI_Q') is None and _lib.get_option('COLSOLVE') == 'tri'
+        with _lib.options(COLSOLVE='fft'):
+            assert _lib.get_option('COLSOLVE') == 'fft'
+        assert _lib.get_option('COLSOLVE') == 'tri'
+    assert _lib.get_option('TRI_Q') == '2' and _lib.get_option('COLSOLVE') is None
+    _lib.set_option('TRI_Q', None)
+    with pytest.raises(_lib.GPAError):
+        _lib.set_option('NO_SUCH_SWITCH', '1')
+    _lib._OPTION_VALUES.pop('NO_SUCH_SWITCH', None)

@@ -19,8 +19,9 @@ acc = collections.defaultdict(lambda: collections.defaultdict(list))
 for d in sys.argv[2:]:
     for f in glob.glob(os.path.join(d, '**', '*counter_collection.csv'), recursive=True):
         for r in csv.DictReader(open(f)):
+            kname = r['Kernel_Name'].replace('rowidct_p_pers_kernel', 'rowidct_p_kernel')   # (the persistent form files under the profiler's name)
             for s in SHORT:
-                if s in r['Kernel_Name']:
+                if s in kname:
                     if s in ('passB_kernel', 'passB_shared_kernel') and 'float' not in r['Kernel_Name']:
                         continue
                     acc[s][r['Counter_Name']].append(float(r['Counter_Value']))
