@@ -19,6 +19,34 @@ namespace {
 // forms q of its two rows in registers exactly as pq_kernel does (same edge order: right, left, down, up), parks them
 // in LDS as the packed pair's transform input, and runs rowdct_fused_kernel's transform.
 // ---------------------------------------------------------------------------
+// the value the neighbouring lane holds (lane - 1 / lane + 1 of the wavefront; lanes 0 / 63 get 0 and take theirs from
+// memory): one DPP move per dword instead of the ds_bpermute of __shfl_up / __shfl_down (an LDS-crossbar round trip and
+// its address arithmetic, 16 times per row pair)
+#ifndef GPA_PQ_PLAIN
+__device__ __forceinline__ float from_lane_below(float x) {
+  return __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(x), 0x138 /* wave_shr:1 */, 0xf, 0xf, false));
+}
+__device__ __forceinline__ float from_lane_above(float x) {
+  return __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(x), 0x130 /* wave_shl:1 */, 0xf, 0xf, false));
+}
+__device__ __forceinline__ double from_lane_below(double x) {
+  const int lo = __builtin_amdgcn_update_dpp(0, __double2loint(x), 0x138, 0xf, 0xf, false);
+  const int hi = __builtin_amdgcn_update_dpp(0, __double2hiint(x), 0x138, 0xf, 0xf, false);
+  return __hiloint2double(hi, lo);
+}
+__device__ __forceinline__ double from_lane_above(double x) {
+  const int lo = __builtin_amdgcn_update_dpp(0, __double2loint(x), 0x130, 0xf, 0xf, false);
+  const int hi = __builtin_amdgcn_update_dpp(0, __double2hiint(x), 0x130, 0xf, 0xf, false);
+  return __hiloint2double(hi, lo);
+}
+// min of two weights: one v_min instead of compare + select (the same value for everything but NaN)
+__device__ __forceinline__ float wmin(float a, float b) { return fminf(a, b); }
+__device__ __forceinline__ double wmin(double a, double b) { return fmin(a, b); }
+#else
+template <class T> __device__ __forceinline__ T from_lane_below(T x) { return __shfl_up(x, 1); }
+template <class T> __device__ __forceinline__ T from_lane_above(T x) { return __shfl_down(x, 1); }
+template <class T> __device__ __forceinline__ T wmin(T a, T b) { return a < b ? a : b; }
+#endif
 #ifndef GPA_PQDCT_WAVES
 #define GPA_PQDCT_WAVES 4
 #endif
@@ -99,8 +127,8 @@ __global__ __launch_bounds__((RowGeom<T, LG>::THREADS), (sizeof(T) == 8 ? GPA_F6
         for (int j = 0; j < 4; ++j) { W.u[v].v[j] *= W.u[v].v[j]; W.a[v].v[j] *= W.a[v].v[j]; W.b[v].v[j] *= W.b[v].v[j]; W.d[v].v[j] *= W.d[v].v[j]; }
         EW.la[v] *= EW.la[v]; EW.lb[v] *= EW.lb[v]; EW.ra[v] *= EW.ra[v]; EW.rb[v] *= EW.rb[v];
       }
-      T pla = __shfl_up(P.a[v].v[3], 1), pra = __shfl_down(P.a[v].v[0], 1), plb = __shfl_up(P.b[v].v[3], 1), prb = __shfl_down(P.b[v].v[0], 1);
-      T wla = __shfl_up(W.a[v].v[3], 1), wra = __shfl_down(W.a[v].v[0], 1), wlb = __shfl_up(W.b[v].v[3], 1), wrb = __shfl_down(W.b[v].v[0], 1);
+      T pla = from_lane_below(P.a[v].v[3]), pra = from_lane_above(P.a[v].v[0]), plb = from_lane_below(P.b[v].v[3]), prb = from_lane_above(P.b[v].v[0]);
+      T wla = from_lane_below(W.a[v].v[3]), wra = from_lane_above(W.a[v].v[0]), wlb = from_lane_below(W.b[v].v[3]), wrb = from_lane_above(W.b[v].v[0]);
       if (lane == 0) { pla = EP.la[v]; plb = EP.lb[v]; wla = EW.la[v]; wlb = EW.lb[v]; }
       if (lane == 63) { pra = EP.ra[v]; prb = EP.rb[v]; wra = EW.ra[v]; wrb = EW.rb[v]; }
 #pragma unroll
@@ -110,24 +138,24 @@ __global__ __launch_bounds__((RowGeom<T, LG>::THREADS), (sizeof(T) == 8 ? GPA_F6
         {
           const T c = P.a[v].v[j], wj = W.a[v].v[j];
           T acc = T(0);
-          if (j < 3) { const T wn = W.a[v].v[j + 1]; acc += (wn < wj ? wn : wj) * (P.a[v].v[j + 1] - c); }
-          else if (hasr) acc += (wra < wj ? wra : wj) * (pra - c);
-          if (j > 0) { const T wn = W.a[v].v[j - 1]; acc += (wn < wj ? wn : wj) * (P.a[v].v[j - 1] - c); }
-          else if (hasl) acc += (wla < wj ? wla : wj) * (pla - c);
-          { const T wn = W.b[v].v[j]; acc += (wn < wj ? wn : wj) * (P.b[v].v[j] - c); }
-          if (up) { const T wn = W.u[v].v[j]; acc += (wn < wj ? wn : wj) * (P.u[v].v[j] - c); }
+          if (j < 3) { const T wn = W.a[v].v[j + 1]; acc += wmin(wn, wj) * (P.a[v].v[j + 1] - c); }
+          else if (hasr) acc += wmin(wra, wj) * (pra - c);
+          if (j > 0) { const T wn = W.a[v].v[j - 1]; acc += wmin(wn, wj) * (P.a[v].v[j - 1] - c); }
+          else if (hasl) acc += wmin(wla, wj) * (pla - c);
+          { const T wn = W.b[v].v[j]; acc += wmin(wn, wj) * (P.b[v].v[j] - c); }
+          if (up) { const T wn = W.u[v].v[j]; acc += wmin(wn, wj) * (P.u[v].v[j] - c); }
           qa = acc;
           pq += (double)c * (double)acc;
         }
         {
           const T c = P.b[v].v[j], wj = W.b[v].v[j];
           T acc = T(0);
-          if (j < 3) { const T wn = W.b[v].v[j + 1]; acc += (wn < wj ? wn : wj) * (P.b[v].v[j + 1] - c); }
-          else if (hasr) acc += (wrb < wj ? wrb : wj) * (prb - c);
-          if (j > 0) { const T wn = W.b[v].v[j - 1]; acc += (wn < wj ? wn : wj) * (P.b[v].v[j - 1] - c); }
-          else if (hasl) acc += (wlb < wj ? wlb : wj) * (plb - c);
-          if (dn) { const T wn = W.d[v].v[j]; acc += (wn < wj ? wn : wj) * (P.d[v].v[j] - c); }
-          { const T wn = W.a[v].v[j]; acc += (wn < wj ? wn : wj) * (P.a[v].v[j] - c); }
+          if (j < 3) { const T wn = W.b[v].v[j + 1]; acc += wmin(wn, wj) * (P.b[v].v[j + 1] - c); }
+          else if (hasr) acc += wmin(wrb, wj) * (prb - c);
+          if (j > 0) { const T wn = W.b[v].v[j - 1]; acc += wmin(wn, wj) * (P.b[v].v[j - 1] - c); }
+          else if (hasl) acc += wmin(wlb, wj) * (plb - c);
+          if (dn) { const T wn = W.d[v].v[j]; acc += wmin(wn, wj) * (P.d[v].v[j] - c); }
+          { const T wn = W.a[v].v[j]; acc += wmin(wn, wj) * (P.a[v].v[j] - c); }
           qb = acc;
           pq += (double)c * (double)acc;
         }
