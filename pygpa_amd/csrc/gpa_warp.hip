@@ -4,7 +4,7 @@
 // SciPy itself before this was written:
 //   prefilter   : cubic B-spline coefficients = two-sided exponential filter
 //                 h_k = (-6 z / (1 - z^2)) z^|k|, z = sqrt(3) - 2, along both axes;
-//                 evaluated here as a 2*KT+1 tap FIR (|z|^KT < 1e-18) instead of SciPy's
+//                 evaluated here as a 2*KT+1 tap FIR (f64: KT = 32, |z|^KT < 1e-18; f32: KT = 16, 7e-10) instead of SciPy's
 //                 causal/anticausal recursion: same numbers, but every output is independent.
 //   mode nearest : pad the image by 12 edge-replicated samples, filter with HALF-sample
 //                  symmetric extension, interpolate with the coordinate left unclamped and
@@ -21,7 +21,9 @@ namespace gpa {
 
 namespace {
 
-constexpr int KT = 32;       // taps on each side of the prefilter
+// taps on each side of the prefilter: the pole is z = sqrt(3) - 2, |z|^k falls below the precision's rounding of the
+// centre tap at k = 16 in f32 (|z|^16 = 7e-10 against 2^-24 = 6e-8) and at k = 28 in f64 (1e-16; 32 kept: |z|^32 = 5e-19)
+template <class T> struct TapHalf { static constexpr int value = sizeof(T) == 4 ? 16 : 32; };
 constexpr int NPAD = 12;     // SciPy's pre-padding for mode='nearest'
 
 enum Ext { EXT_REFLECT = 0, EXT_MIRROR = 1 };
@@ -53,6 +55,7 @@ template <class T, bool PADSRC>
 __global__ __launch_bounds__(256) void fir_rows_kernel(const T* __restrict__ in, int m0, int m1, int ext,
                                                       const T* __restrict__ h, T* __restrict__ out, int npad, int sn0, int sn1,
                                                       T scale) {
+  constexpr int KT = TapHalf<T>::value;
   __shared__ T tile[FR_OUT + 2 * KT];
   const int x = blockIdx.y, y0 = blockIdx.x * FR_OUT;
   if constexpr (PADSRC) {
@@ -113,6 +116,7 @@ __global__ __launch_bounds__(256) void fir_rows_kernel(const T* __restrict__ in,
 template <class T>
 __global__ __launch_bounds__(256) void fir_cols_kernel(const T* __restrict__ in, int m0, int m1, int ext,
                                                       const T* __restrict__ h, T* __restrict__ out) {
+  constexpr int KT = TapHalf<T>::value;
   __shared__ T tile[(32 + 2 * KT) * 64];
   const int y0 = blockIdx.x * 64, x0 = blockIdx.y * 32;
   const int c = threadIdx.x & 63, g = threadIdx.x >> 6;
@@ -222,14 +226,20 @@ __device__ __forceinline__ void interp_constant(const T* const (&coef)[NC], int 
   bspline_weights(x - fx, wx);
   bspline_weights(y - fy, wy);
   const int ix = (int)fx - 1, iy = (int)fy - 1;
-  int cy[4];
+  int cy[4], cx[4];
+  if (ix >= 0 && iy >= 0 && ix + 3 < n0 && iy + 3 < n1) {
+    // (the 4 x 4 footprint inside the field -- all but a frame of pixels: no mirror arithmetic, eight integer remainders)
 #pragma unroll
-  for (int b = 0; b < 4; ++b) cy[b] = ext_index(iy + b, n1, EXT_MIRROR);
+    for (int b = 0; b < 4; ++b) { cy[b] = iy + b; cx[b] = ix + b; }
+  } else {
+#pragma unroll
+    for (int b = 0; b < 4; ++b) { cy[b] = ext_index(iy + b, n1, EXT_MIRROR); cx[b] = ext_index(ix + b, n0, EXT_MIRROR); }
+  }
 #pragma unroll
   for (int n = 0; n < NC; ++n) out[n] = T(0);
 #pragma unroll
   for (int a = 0; a < 4; ++a) {
-    const I row = (I)ext_index(ix + a, n0, EXT_MIRROR) * (I)n1;
+    const I row = (I)cx[a] * (I)n1;
     const I o0 = row + (I)cy[0], o1 = row + (I)cy[1], o2 = row + (I)cy[2], o3 = row + (I)cy[3];
 #pragma unroll
     for (int n = 0; n < NC; ++n) {
@@ -403,34 +413,21 @@ __global__ __launch_bounds__(256) void invert_tile_kernel(const T* __restrict__ 
   out[(size_t)o0 * o1 + (size_t)i * o1 + j] = v[1];
 }
 
-// final resampling, map_coordinates defaults: order 3, mode='constant', cval = 0
-template <class T>
+// final resampling, map_coordinates defaults: order 3, mode='constant', cval = 0 (geometric_phase_analysis.py:969-973): out(r) =
+// image(r + u_inv(r)).  One row of 256 pixels per workgroup: u_inv is smooth, so a wavefront's 64 x 16 taps are four runs of
+// ~67 adjacent coefficients per tap row -- coalesced as they are.  (A 16 x 16 tile form with the coefficient window staged in
+// LDS, as invert_tile_kernel has it, measured 2.5 x SLOWER here: one evaluation per pixel does not pay for the window.)
+template <class T, bool WIDE>
 __global__ __launch_bounds__(256) void warp_constant_kernel(const T* __restrict__ coef, int n0, int n1,
                                                            const T* __restrict__ uinv, T cval, T* __restrict__ out,
                                                            int wr0, int wc0, int wc1) {
   const int j = wc0 + blockIdx.x * 256 + threadIdx.x, i = wr0 + blockIdx.y;
   if (j >= wc1) return;
   const size_t o = (size_t)i * n1 + j, npx = (size_t)n0 * n1;
-  const T x = T(i) + uinv[o], y = T(j) + uinv[npx + o];
-  if (!(x >= T(0) && x <= T(n0 - 1) && y >= T(0) && y <= T(n1 - 1))) {   // also catches NaN
-    out[o] = cval;
-    return;
-  }
-  const T fx = floor(x), fy = floor(y);
-  T wx[4], wy[4];
-  bspline_weights(x - fx, wx);
-  bspline_weights(y - fy, wy);
-  const int ix = (int)fx - 1, iy = (int)fy - 1;
-  T acc = T(0);
-#pragma unroll
-  for (int a = 0; a < 4; ++a) {
-    const T* cr = coef + (size_t)ext_index(ix + a, n0, EXT_MIRROR) * n1;
-    T r = T(0);
-#pragma unroll
-    for (int b = 0; b < 4; ++b) r += wy[b] * cr[ext_index(iy + b, n1, EXT_MIRROR)];
-    acc += wx[a] * r;
-  }
-  out[o] = acc;
+  const T* const cf[1] = {coef};
+  T r[1];
+  interp_constant<T, 1, WIDE>(cf, n0, n1, T(i) + uinv[o], T(j) + uinv[npx + o], cval, r);
+  out[o] = r[0];
 }
 
 // the prefilter's taps, uploaded once per workspace and precision (pinned staging is not worth it: 65 values)
@@ -438,11 +435,12 @@ template <class T>
 hipError_t ensure_taps(WarpWs* ws, hipStream_t s) {
   const int want = sizeof(T) == 4 ? 0 : 1;
   if (ws->taps && ws->taps_dtype == want) return hipSuccess;
+  constexpr int KT = TapHalf<T>::value;
   const double z = sqrt(3.0) - 2.0;
   T h[2 * KT + 1];
   for (int k = -KT; k <= KT; ++k) h[k + KT] = (T)((-6.0 * z / (1.0 - z * z)) * pow(z, abs(k)));
   hipError_t e = hipSuccess;
-  if (!ws->taps) e = hipMalloc(&ws->taps, (2 * KT + 1) * sizeof(double));
+  if (!ws->taps) e = hipMalloc(&ws->taps, (2 * TapHalf<double>::value + 1) * sizeof(double));
   if (e != hipSuccess) return e;
   e = hipMemcpyAsync(ws->taps, h, sizeof(h), hipMemcpyHostToDevice, s);
   if (e != hipSuccess) return e;
@@ -580,7 +578,11 @@ hipError_t warp_t(const T* d_img, const T* d_uinv, int n0, int n1, T* d_out, hip
       const Win v = window(nrect > 0 ? rects + 4 * q : nullptr, n0, n1);
       if (v.h <= 0 || v.w <= 0) continue;
       GPA_PROF("warp_constant_kernel", s);
-      warp_constant_kernel<T><<<dim3((v.w + 255) / 256, v.h), 256, 0, s>>>(buf + npx, n0, n1, d_uinv, T(0), d_out, v.r0, v.c0, v.c0 + v.w);
+      const dim3 grid((v.w + 255) / 256, v.h);
+      if (npx * sizeof(T) < ((size_t)1 << 32))
+        warp_constant_kernel<T, false><<<grid, 256, 0, s>>>(buf + npx, n0, n1, d_uinv, T(0), d_out, v.r0, v.c0, v.c0 + v.w);
+      else
+        warp_constant_kernel<T, true><<<grid, 256, 0, s>>>(buf + npx, n0, n1, d_uinv, T(0), d_out, v.r0, v.c0, v.c0 + v.w);
     }
     e = hipGetLastError();
   }
