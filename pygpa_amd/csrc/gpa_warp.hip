@@ -180,6 +180,16 @@ template <class T> __device__ __forceinline__ T gather(const T* __restrict__ bas
   return *reinterpret_cast<const T*>(reinterpret_cast<const char*>(base) + (unsigned)(o * (unsigned)sizeof(T)));
 }
 template <class T> __device__ __forceinline__ T gather(const T* __restrict__ base, size_t o) { return base[o]; }
+// four ADJACENT elements from element `o` on: one 16-byte (f64: 32-byte) load -- global memory takes it at 4-byte alignment --
+// where four scalar gathers cost the texture-address unit four wave-instructions (the gathers of a round are bound by that
+// unit, not by bytes)
+template <class T> struct Tap4 { T v[4]; };
+template <class T> __device__ __forceinline__ Tap4<T> gather4(const T* __restrict__ base, unsigned o) {
+  return *reinterpret_cast<const Tap4<T>*>(reinterpret_cast<const char*>(base) + (unsigned)(o * (unsigned)sizeof(T)));
+}
+template <class T> __device__ __forceinline__ Tap4<T> gather4(const T* __restrict__ base, size_t o) {
+  return *reinterpret_cast<const Tap4<T>*>(base + o);
+}
 
 // mode='nearest': coordinate (already shifted by npad) unclamped, tap indices clamped
 template <class T, int NC, bool WIDE = false>
@@ -198,6 +208,8 @@ __device__ __forceinline__ void interp_nearest(const T* const (&coef)[NC], int m
   for (int b = 0; b < 4; ++b) { const int j = iy + b; cy[b] = j < 0 ? 0 : (j >= m1 ? m1 - 1 : j); }
 #pragma unroll
   for (int n = 0; n < NC; ++n) out[n] = T(0);
+  // (four scalar gathers per tap row, not one 16-byte load as interp_constant's interior path: measured, the fixed point
+  //  got slower with it -- 13.3 -> 14.5 ms at 16384^2 -- its rounds are bound by instruction issue, not by the gathers)
 #pragma unroll
   for (int a = 0; a < 4; ++a) {
     int i = ix + a;
@@ -226,20 +238,28 @@ __device__ __forceinline__ void interp_constant(const T* const (&coef)[NC], int 
   bspline_weights(x - fx, wx);
   bspline_weights(y - fy, wy);
   const int ix = (int)fx - 1, iy = (int)fy - 1;
-  int cy[4], cx[4];
-  if (ix >= 0 && iy >= 0 && ix + 3 < n0 && iy + 3 < n1) {
-    // (the 4 x 4 footprint inside the field -- all but a frame of pixels: no mirror arithmetic, eight integer remainders)
-#pragma unroll
-    for (int b = 0; b < 4; ++b) { cy[b] = iy + b; cx[b] = ix + b; }
-  } else {
-#pragma unroll
-    for (int b = 0; b < 4; ++b) { cy[b] = ext_index(iy + b, n1, EXT_MIRROR); cx[b] = ext_index(ix + b, n0, EXT_MIRROR); }
-  }
 #pragma unroll
   for (int n = 0; n < NC; ++n) out[n] = T(0);
+  if (ix >= 0 && iy >= 0 && ix + 3 < n0 && iy + 3 < n1) {
+    // the 4 x 4 footprint inside the field -- all but a frame of pixels: no mirror arithmetic (eight integer remainders), the
+    // four taps of a row in one load
+#pragma unroll
+    for (int a = 0; a < 4; ++a) {
+      const I o = (I)(ix + a) * (I)n1 + (I)iy;
+#pragma unroll
+      for (int n = 0; n < NC; ++n) {
+        const Tap4<T> q = gather4(coef[n], o);
+        out[n] = fma(wx[a], tap_row(wy, q.v[0], q.v[1], q.v[2], q.v[3]), out[n]);
+      }
+    }
+    return;
+  }
+  int cy[4];
+#pragma unroll
+  for (int b = 0; b < 4; ++b) cy[b] = ext_index(iy + b, n1, EXT_MIRROR);
 #pragma unroll
   for (int a = 0; a < 4; ++a) {
-    const I row = (I)cx[a] * (I)n1;
+    const I row = (I)ext_index(ix + a, n0, EXT_MIRROR) * (I)n1;
     const I o0 = row + (I)cy[0], o1 = row + (I)cy[1], o2 = row + (I)cy[2], o3 = row + (I)cy[3];
 #pragma unroll
     for (int n = 0; n < NC; ++n) {
@@ -254,7 +274,7 @@ __device__ __forceinline__ void interp_constant(const T* const (&coef)[NC], int 
 template <class T, bool WIDE>
 __global__ __launch_bounds__(256) void invert_constant_kernel(const T* __restrict__ c0, const T* __restrict__ c1, int n0, int n1,
                                                              int edge, int shift, int iters, int nan_last,
-                                                             T* __restrict__ out, int wr0, int wc0, int wc1) {
+                                                             T* __restrict__ out, int wr0, int wc0, int wc1, int all_rounds) {
   const int o1 = n1 + 2 * edge, o0 = n0 + 2 * edge;
   const int j = wc0 + blockIdx.x * 256 + threadIdx.x, i = wr0 + blockIdx.y;
   if (j >= wc1) return;
@@ -263,6 +283,7 @@ __global__ __launch_bounds__(256) void invert_constant_kernel(const T* __restric
   T v[2];
   interp_constant<T, 2, WIDE>(coef, n0, n1, xb, yb, T(0), v);
   const T xs = xb - T(shift), ys = yb - T(shift);
+  T pv[2] = {(T)__builtin_nan(""), (T)__builtin_nan("")};   // the iterate before v
   for (int it = 0; it < iters; ++it) {
     T nv[2];
     const bool last_nan = nan_last && it == iters - 1;
@@ -270,14 +291,25 @@ __global__ __launch_bounds__(256) void invert_constant_kernel(const T* __restric
     interp_constant<T, 2, WIDE>(coef, n0, n1, xs + v[0], ys + v[1], cval, nv);
     // a round that reproduces its input bit for bit is a fixed point: every later round returns the same numbers, so the
     // wavefront leaves once all its pixels are there (the same result as running all rounds; f32 fields settle after
-    // ~15 of the reference's 36 rounds).  The cval = NaN round of invert_u_overlap is a different function: still run.
+    // ~15 of the reference's 36 rounds).  So is a CYCLE OF TWO: a few per cent of the pixels of an f32 field never reach a
+    // bitwise fixed point but alternate between two neighbouring values (x_(k+1) = x_(k-1) bit for bit: the map is
+    // deterministic, so the sequence alternates from there on), and one such pixel kept its whole wavefront in the loop
+    // for all rounds -- 43 % of the wavefronts at 4096^2 (tools/lf_rounds.py).  A wavefront leaves once every pixel is at a
+    // fixed point or in a cycle of two; the member of the cycle that the full count of rounds ends on follows from the
+    // parity of the rounds left.  Longer cycles run to the end.  The cval = NaN round of invert_u_overlap is a
+    // different function: still run, on the iterate the full count of rounds would hand it.
     const bool fixed = nv[0] == v[0] && nv[1] == v[1];
-    v[0] = nv[0];
-    v[1] = nv[1];
-    if (__all(fixed)) {
-      if (nan_last && !last_nan) interp_constant<T, 2, WIDE>(coef, n0, n1, xs + v[0], ys + v[1], (T)__builtin_nan(""), v);
+    const bool cyc2 = nv[0] == pv[0] && nv[1] == pv[1];
+    if (!last_nan && !all_rounds && __all(fixed || cyc2)) {
+      const int plain_left = (nan_last ? iters - 2 : iters - 1) - it;   // plain rounds the full count would still run
+      if (!(plain_left & 1)) { v[0] = nv[0]; v[1] = nv[1]; }          // (odd: the cycle's other member, v itself)
+      if (nan_last) interp_constant<T, 2, WIDE>(coef, n0, n1, xs + v[0], ys + v[1], (T)__builtin_nan(""), v);
       break;
     }
+    pv[0] = v[0];
+    pv[1] = v[1];
+    v[0] = nv[0];
+    v[1] = nv[1];
   }
   out[(size_t)i * o1 + j] = v[0];
   out[(size_t)o0 * o1 + (size_t)i * o1 + j] = v[1];
@@ -287,7 +319,7 @@ __global__ __launch_bounds__(256) void invert_constant_kernel(const T* __restric
 template <class T, bool WIDE>
 __global__ __launch_bounds__(256) void invert_kernel(const T* __restrict__ c0, const T* __restrict__ c1, int m0, int m1,
                                                     int n0, int n1, int edge, int shift, int iters, T* __restrict__ out,
-                                                    int wr0, int wc0, int wc1) {
+                                                    int wr0, int wc0, int wc1, int all_rounds) {
   const int o1 = n1 + 2 * edge, o0 = n0 + 2 * edge;
   const int j = wc0 + blockIdx.x * 256 + threadIdx.x, i = wr0 + blockIdx.y;
   if (j >= wc1) return;
@@ -297,14 +329,21 @@ __global__ __launch_bounds__(256) void invert_kernel(const T* __restrict__ c0, c
   interp_nearest<T, 2, WIDE>(coef, m0, m1, xb, yb, v);
   // (shift != 0: invert_u, which samples every later round at r + u_it - shift, geometric_phase_analysis.py:258)
   const T xs = xb - T(shift), ys = yb - T(shift);
+  T pv[2] = {(T)__builtin_nan(""), (T)__builtin_nan("")};
   for (int it = 0; it < iters; ++it) {
     T nv[2];
     interp_nearest<T, 2, WIDE>(coef, m0, m1, xs + v[0], ys + v[1], nv);
-    // bitwise fixed point of every pixel of the wavefront: all later rounds return the same numbers (see above)
+    // every pixel of the wavefront at a bitwise fixed point or in a cycle of two: the later rounds are known (see above)
     const bool fixed = nv[0] == v[0] && nv[1] == v[1];
+    const bool cyc2 = nv[0] == pv[0] && nv[1] == pv[1];
+    if (!all_rounds && __all(fixed || cyc2)) {
+      if (!((iters - 1 - it) & 1)) { v[0] = nv[0]; v[1] = nv[1]; }
+      break;
+    }
+    pv[0] = v[0];
+    pv[1] = v[1];
     v[0] = nv[0];
     v[1] = nv[1];
-    if (__all(fixed)) break;
   }
   out[(size_t)i * o1 + j] = v[0];
   out[(size_t)o0 * o1 + (size_t)i * o1 + j] = v[1];
@@ -349,9 +388,9 @@ __device__ __forceinline__ bool interp_window(const T2<T>* __restrict__ win, int
 template <class T, bool WIDE>
 __global__ __launch_bounds__(256) void invert_tile_kernel(const T* __restrict__ c0, const T* __restrict__ c1, int m0, int m1,
                                                          int n0, int n1, int edge, int shift, int iters, T* __restrict__ out,
-                                                         int wr0, int wc0, int wr1, int wc1) {
+                                                         int wr0, int wc0, int wr1, int wc1, int all_rounds) {
   __shared__ T2<T> win[LW * LWP];
-  __shared__ int box[4];                                   // min x, min y, max x, max y of the first taps
+  __shared__ int box[4][4];                                // per wavefront: min x, min y, max x, max y of the first taps
   const int o1 = n1 + 2 * edge, o0 = n0 + 2 * edge;
   const int ti = threadIdx.x >> 4, tj = threadIdx.x & 15;
   const int i_raw = wr0 + blockIdx.y * LT + ti, j_raw = wc0 + blockIdx.x * LT + tj;
@@ -364,39 +403,70 @@ __global__ __launch_bounds__(256) void invert_tile_kernel(const T* __restrict__ 
   const T xs = xb - T(shift), ys = yb - T(shift);
   int state = 0;        // 0: rounds from global memory, the workgroup still deciding; 1: window staged; 2: no window (does not fit)
   int wx0 = 0, wy0 = 0;
+  T pv[2] = {(T)__builtin_nan(""), (T)__builtin_nan("")};   // the iterate before v
   for (int it = 0; it < iters; ++it) {
     T nv[2];
     const T x = xs + v[0], y = ys + v[1];
     if (state != 1 || !interp_window<T>(win, wx0, wy0, m0, m1, x, y, nv)) interp_nearest<T, 2, WIDE>(coef, m0, m1, x, y, nv);
     const bool fixed = nv[0] == v[0] && nv[1] == v[1];
+    const bool cyc2 = nv[0] == pv[0] && nv[1] == pv[1];
     const bool moving = !(fabs(nv[0] - v[0]) <= T(2) && fabs(nv[1] - v[1]) <= T(2));   // (NaN: moving)
+    if (state != 0 && !all_rounds && __all(fixed || cyc2)) {
+      // every pixel of the wavefront has settled; a cycle's member after the full count of rounds follows from the parity
+      if (!((iters - 1 - it) & 1)) { v[0] = nv[0]; v[1] = nv[1]; }
+#ifdef GPA_LF_ROUNDS_DEBUG
+      v[0] = T(it);
+      v[1] = fixed ? T(1) : T(0);
+#endif
+      break;
+    }
+    pv[0] = v[0];
+    pv[1] = v[1];
     v[0] = nv[0];
     v[1] = nv[1];
     if (state == 0) {
       // workgroup-uniform decision (every wavefront is still in the loop: none leaves before the decision is made)
-      if (it == 0 && threadIdx.x < 4) box[threadIdx.x] = threadIdx.x < 2 ? 0x7fffffff : (int)0x80000000;
       if (!__syncthreads_or(moving ? 1 : 0)) {
         T xn = xs + v[0], yn = ys + v[1];
         xn = xn < T(-2) ? T(-2) : (xn > T(m0 + 1) ? T(m0 + 1) : xn);
         yn = yn < T(-2) ? T(-2) : (yn > T(m1 + 1) ? T(m1 + 1) : yn);
         const int fx = (int)floor(xn) - 1, fy = (int)floor(yn) - 1;
-        atomicMin(&box[0], fx);
-        atomicMin(&box[1], fy);
-        atomicMax(&box[2], fx);
-        atomicMax(&box[3], fy);
+        // bounding box of the tile's first taps: a shuffle tree per wavefront, the four wavefronts' results through LDS.
+        // (atomicMin / atomicMax on one LDS word were what hipcc turns into a loop over the 64 lanes, readlane by readlane:
+        //  ~1500 scalar instructions per wavefront, more than the kernel's vector instructions -- rocprofv3 SQ_INSTS_SALU)
+        int lo_x = fx, lo_y = fy, hi_x = fx, hi_y = fy;
+#pragma unroll
+        for (int m = 32; m > 0; m >>= 1) {
+          lo_x = min(lo_x, __shfl_xor(lo_x, m));
+          lo_y = min(lo_y, __shfl_xor(lo_y, m));
+          hi_x = max(hi_x, __shfl_xor(hi_x, m));
+          hi_y = max(hi_y, __shfl_xor(hi_y, m));
+        }
+        if ((threadIdx.x & 63) == 0) {
+          int* b = box[threadIdx.x >> 6];
+          b[0] = lo_x; b[1] = lo_y; b[2] = hi_x; b[3] = hi_y;
+        }
         __syncthreads();
-        const int bx0 = box[0], by0 = box[1], bx1 = box[2], by1 = box[3];
+        const int bx0 = min(min(box[0][0], box[1][0]), min(box[2][0], box[3][0])), by0 = min(min(box[0][1], box[1][1]), min(box[2][1], box[3][1]));
+        const int bx1 = max(max(box[0][2], box[1][2]), max(box[2][2], box[3][2])), by1 = max(max(box[0][3], box[1][3]), max(box[2][3], box[3][3]));
         if (bx1 - bx0 + 4 + 2 * LMARG <= LW && by1 - by0 + 4 + 2 * LMARG <= LW) {
           // centre the box in the window; tap indices clamped while loading = mode 'nearest' clamping them at use
           wx0 = bx0 - (LW - (bx1 - bx0 + 4)) / 2;
           wy0 = by0 - (LW - (by1 - by0 + 4)) / 2;
-          for (int e = threadIdx.x; e < LW * LW; e += 256) {
-            const int r = e / LW, c = e - r * LW;
-            int gi = wx0 + r, gj = wy0 + c;
-            gi = gi < 0 ? 0 : (gi >= m0 ? m0 - 1 : gi);
+          // (192 of the 256 threads: a thread keeps its column and walks down the rows four at a time -- no division, one
+          //  clamp and one multiply per element; the loop over e = thread + 256 k with e / LW, e % LW was a fifth of the
+          //  kernel's instructions)
+          if (threadIdx.x < 4 * LW) {
+            const int r0w = (int)threadIdx.x / LW, c = (int)threadIdx.x - r0w * LW;
+            int gj = wy0 + c;
             gj = gj < 0 ? 0 : (gj >= m1 ? m1 - 1 : gj);
-            const size_t o = (size_t)gi * m1 + gj;
-            win[r * LWP + c] = T2<T>{c0[o], c1[o]};
+#pragma unroll 4
+            for (int r = r0w; r < LW; r += 4) {
+              int gi = wx0 + r;
+              gi = gi < 0 ? 0 : (gi >= m0 ? m0 - 1 : gi);
+              const size_t o = (size_t)gi * m1 + gj;
+              win[r * LWP + c] = T2<T>{c0[o], c1[o]};
+            }
           }
           state = 1;
         } else {
@@ -406,7 +476,9 @@ __global__ __launch_bounds__(256) void invert_tile_kernel(const T* __restrict__ 
       }
       continue;      // (no wavefront leaves while the workgroup may still meet at a barrier)
     }
-    if (__all(fixed)) break;
+#ifdef GPA_LF_ROUNDS_DEBUG
+    if (it == iters - 1) { v[0] = T(it + 1); v[1] = fixed ? T(1) : T(0); }
+#endif
   }
   if (!valid) return;
   out[(size_t)i * o1 + j] = v[0];
@@ -506,6 +578,7 @@ hipError_t invert_constant_t(const T* d_u, int n0, int n1, T scale, int iters, i
     e = prefilter<T>(d_u + (size_t)c * npx, n0, n1, EXT_MIRROR, d_h, tmp, c == 0 ? c0 : c1, s, 0, scale);
   if (e == hipSuccess) {
     const int o1 = n1 + 2 * edge, o0 = n0 + 2 * edge;
+    const int allr = opt_set(OPT_LF_ALL_ROUNDS) ? 1 : 0;   // (diagnostic: every round of the fixed point, no early exit)
     for (int q = 0; q < (nrect > 0 ? nrect : 1); ++q) {
     const Win v = window(nrect > 0 ? rects + 4 * q : nullptr, o0, o1);
     if (v.h <= 0 || v.w <= 0) continue;
@@ -515,10 +588,10 @@ hipError_t invert_constant_t(const T* d_u, int n0, int n1, T scale, int iters, i
     GPA_PROF("invert_kernel", s);
     if (npx * sizeof(T) < ((size_t)1 << 32))
       invert_constant_kernel<T, false><<<dim3((v.w + 255) / 256, v.h), 256, 0, s>>>(c0, c1, n0, n1, edge, shift, iters, nan_last ? 1 : 0, d_out,
-                                                                                   v.r0, v.c0, v.c0 + v.w);
+                                                                                   v.r0, v.c0, v.c0 + v.w, allr);
     else
       invert_constant_kernel<T, true><<<dim3((v.w + 255) / 256, v.h), 256, 0, s>>>(c0, c1, n0, n1, edge, shift, iters, nan_last ? 1 : 0, d_out,
-                                                                                  v.r0, v.c0, v.c0 + v.w);
+                                                                                  v.r0, v.c0, v.c0 + v.w, allr);
     }
     e = hipGetLastError();
   }
@@ -541,6 +614,7 @@ hipError_t invert_t(const T* d_u, int n0, int n1, T scale, int iters, int edge, 
     e = prefilter<T>(d_u + (size_t)c * n0 * n1, m0, m1, EXT_REFLECT, d_h, tmp, c == 0 ? c0 : c1, s, NPAD, scale);
   if (e == hipSuccess) {
     const int o1 = n1 + 2 * edge, o0 = n0 + 2 * edge;
+    const int allr = opt_set(OPT_LF_ALL_ROUNDS) ? 1 : 0;   // (diagnostic: every round of the fixed point, no early exit)
     for (int q = 0; q < (nrect > 0 ? nrect : 1); ++q) {
       const Win v = window(nrect > 0 ? rects + 4 * q : nullptr, o0, o1);
       if (v.h <= 0 || v.w <= 0) continue;
@@ -549,13 +623,13 @@ hipError_t invert_t(const T* d_u, int n0, int n1, T scale, int iters, int edge, 
         // 16 x 16 tiles, the later rounds from an LDS window (NO_LFTILE: the row-segment kernel, every round from L1 / L2)
         const dim3 grid((v.w + LT - 1) / LT, (v.h + LT - 1) / LT);
         if (mp * sizeof(T) < ((size_t)1 << 32))
-          invert_tile_kernel<T, false><<<grid, 256, 0, s>>>(c0, c1, m0, m1, n0, n1, edge, shift, iters, d_out, v.r0, v.c0, v.r0 + v.h, v.c0 + v.w);
+          invert_tile_kernel<T, false><<<grid, 256, 0, s>>>(c0, c1, m0, m1, n0, n1, edge, shift, iters, d_out, v.r0, v.c0, v.r0 + v.h, v.c0 + v.w, allr);
         else
-          invert_tile_kernel<T, true><<<grid, 256, 0, s>>>(c0, c1, m0, m1, n0, n1, edge, shift, iters, d_out, v.r0, v.c0, v.r0 + v.h, v.c0 + v.w);
+          invert_tile_kernel<T, true><<<grid, 256, 0, s>>>(c0, c1, m0, m1, n0, n1, edge, shift, iters, d_out, v.r0, v.c0, v.r0 + v.h, v.c0 + v.w, allr);
       } else if (mp * sizeof(T) < ((size_t)1 << 32))
-        invert_kernel<T, false><<<dim3((v.w + 255) / 256, v.h), 256, 0, s>>>(c0, c1, m0, m1, n0, n1, edge, shift, iters, d_out, v.r0, v.c0, v.c0 + v.w);
+        invert_kernel<T, false><<<dim3((v.w + 255) / 256, v.h), 256, 0, s>>>(c0, c1, m0, m1, n0, n1, edge, shift, iters, d_out, v.r0, v.c0, v.c0 + v.w, allr);
       else
-        invert_kernel<T, true><<<dim3((v.w + 255) / 256, v.h), 256, 0, s>>>(c0, c1, m0, m1, n0, n1, edge, shift, iters, d_out, v.r0, v.c0, v.c0 + v.w);
+        invert_kernel<T, true><<<dim3((v.w + 255) / 256, v.h), 256, 0, s>>>(c0, c1, m0, m1, n0, n1, edge, shift, iters, d_out, v.r0, v.c0, v.c0 + v.w, allr);
     }
     e = hipGetLastError();
   }

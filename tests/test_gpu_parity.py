@@ -368,6 +368,37 @@ class DeviceArray:
 
 
 @pytest.mark.parametrize('dtype', DTYPES)
+def test_f1_early_exit_equals_every_round(dtype, gpa_option):
+    """The fixed point u_it(r) <- u(r + u_it(r)) (geometric_phase_analysis.py:291-299, :255-258) leaves a wavefront's loop once
+    every pixel is at a bitwise fixed point or alternates between two values, and picks the member of such a cycle by the
+    parity of the rounds left: BIT-identical to running every round (LF_ALL_ROUNDS=1), for even and odd round counts, both
+    boundary modes, overlap (with its final cval = NaN round) and plain variant, the tile and the row kernel.  The field is
+    large and rough enough that cycles occur (asserted: an even and an odd count differ somewhere in f32)."""
+    shape = (600, 520)
+    rng = np.random.default_rng(11)
+    u = (2.0 * gaussian_bump_displacement(shape) + 0.02 * rng.normal(size=(2,) + shape)).astype(dtype)
+    plan = _lib.Plan(shape, 1, dtype)
+    got = {}
+    for lftile in (None, '1'):
+        for overlap, edge, mode in ((True, 0, 'nearest'), (False, 3, 'nearest'), (True, 4, 'constant'), (False, 0, 'constant')):
+            for iters in (35, 36):
+                gpa_option('NO_LFTILE', lftile)
+                gpa_option('LF_ALL_ROUNDS', None)
+                fn = plan.invert_u_overlap if overlap else plan.invert_u
+                a = fn(u, iters=iters, edge=edge, mode=mode)
+                gpa_option('LF_ALL_ROUNDS', '1')
+                b = fn(u, iters=iters, edge=edge, mode=mode)
+                gpa_option('LF_ALL_ROUNDS', None)
+                assert np.array_equal(a, b, equal_nan=True), (lftile, overlap, edge, mode, iters, int((a != b).sum()))
+                got[(lftile, overlap, edge, mode, iters)] = a
+    gpa_option('NO_LFTILE', None)
+    if dtype is np.float32:
+        k35, k36 = (None, False, 3, 'nearest', 35), (None, False, 3, 'nearest', 36)
+        assert not np.array_equal(got[k35], got[k36])      # cycles exist in this field: the parity matters
+    plan.close()
+
+
+@pytest.mark.parametrize('dtype', DTYPES)
 def test_f1_device_entry_points_equal_host_entry_points(dtype):
     """round 5: gpa_invert_u_mode_dev / gpa_undistort_image_dev (device pointers, enqueued on the plan's stream, scratch
     kept by the plan, no host round trip of u) against the host-pointer entry points they now back: BIT-identical fields,
