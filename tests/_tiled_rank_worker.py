@@ -34,7 +34,10 @@ def main():
     pipe.load(img)
     pipe.step()
     u2 = pipe.step().cpu().numpy()
-    np.savez(out_prefix + '_rank%d.npz' % rank, u=u, u2=u2, tiles=len(pipe.mine), iters=np.array(pipe.iters))
+    # Lawler-Fujita with the field just extracted, sharded over the tiles (every rank its own windows, one all_reduce)
+    lf, uinv = pipe.undistort(img)
+    np.savez(out_prefix + '_rank%d.npz' % rank, u=u, u2=u2, tiles=len(pipe.mine), iters=np.array(pipe.iters),
+             lf=lf.cpu().numpy(), uinv=uinv.cpu().numpy())
     pipe.close()
     dist.barrier()
     dist.destroy_process_group()

@@ -537,6 +537,15 @@ def test_tiled_two_ranks_one_gpu(tmp_path):
         assert ntiles == 4
         g0, g1 = (np.load(prefix + '_rank%d.npz' % r) for r in range(2))
         assert np.array_equal(g0['u'], g1['u']) and np.array_equal(g0['u2'], g1['u2'])
+        # the tile-sharded Lawler-Fujita stage (TiledPipeline.undistort: every rank the windows of its own tiles, one
+        # all_reduce of the zero-filled outputs): both ranks hold what ONE whole-grid call makes of the same field, bit for bit
+        plan = _lib.Plan(img.shape, 1, np.dtype(dtype))
+        ref_lf = plan.undistort_image(img.astype(dtype), g0['u2'])
+        ref_uinv = plan.invert_u_overlap(-g0['u2'])
+        plan.close()
+        for g in (g0, g1):
+            assert np.array_equal(g['lf'], ref_lf, equal_nan=True), dtype
+            assert np.array_equal(g['uinv'], ref_uinv, equal_nan=True), dtype
 
 
 def test_tiled_nccl_single_rank(tmp_path):
