@@ -553,11 +553,10 @@ def config5_single_gpu(knx, kny, np_dt, kmax, n=16384, window=2048, reps=2):
         lf[k] = {'launches': calls, 'total_ms': round(ms, 3), 'compulsory_GB_per_launch': round(gb, 3),
                  'frac_of_hbm_peak': round(gb * calls / (ms * 1e-3) / HBM_PEAK_GBS, 3) if ms else None}
     if 'invert_kernel' in lf:
-        ms = lf['invert_kernel']['total_ms']
-        taps = 36 * 32 * npx
-        lf['invert_kernel']['bound'] = ('L1 / texture-address rate of the coefficient gathers: %d rounds x 32 taps per pixel = %.1f G lane-loads '
-                                        'in %.1f ms = %.2f T lane-loads/s (wavefronts leave at their bitwise fixed point, so fewer rounds '
-                                        'run than are counted here); compulsory HBM bytes are 0.0x of the time' % (36, taps / 1e9, ms, taps / ms / 1e9))
+        lf['invert_kernel']['bound'] = ('instruction issue, not bytes: the reference runs 36 rounds of 2 x 16-tap cubic interpolations per pixel; a '
+                                        'wavefront leaves once every pixel is at a bitwise fixed point or in a cycle of two (mean ~5 rounds, same '
+                                        'bits), the first rounds gather from L1 / L2 and the later ones from a 48 x 48 LDS window per 16 x 16 tile: '
+                                        '~1400 vector instructions per wavefront (tools/lf_pmc.sh); compulsory HBM bytes are a few percent of the time')
     for b in (d_img, gdx, gdy, gw, d_u, d_rec, d_uinv):
         b.free()
     plan_w.close()
