@@ -27,6 +27,12 @@ struct RowHalfGeom {
   static constexpr size_t LDS_BYTES = (size_t)F::LDS_ELEMS * sizeof(cpx<T>);
 };
 
+// four reals at the alignment of ONE (global memory takes 16-byte accesses at 4-byte alignment): the partner bins N - k
+template <class T> struct alignas(sizeof(T)) Vec4U {
+  T v[4];
+  __device__ __forceinline__ operator Vec4<T>() const { Vec4<T> r; r.v[0] = v[0]; r.v[1] = v[1]; r.v[2] = v[2]; r.v[3] = v[3]; return r; }
+  __device__ __forceinline__ Vec4U& operator=(const Vec4<T>& o) { v[0] = o.v[0]; v[1] = o.v[1]; v[2] = o.v[2]; v[3] = o.v[3]; return *this; }
+};
 // (f32 rows of 16384 points: two 512-thread workgroups per CU, i.e. 4 waves per SIMD and at most 128 registers)
 #ifndef GPA_ROWHALF14_WAVES
 #define GPA_ROWHALF14_WAVES 4
@@ -78,13 +84,26 @@ __global__ __launch_bounds__((RowHalfGeom<T, LG>::THREADS), (sizeof(T) == 4 && L
 #define GPA_ROWHALF_LATE_R (sizeof(T) == 4 && LG == 14)
 #endif
   constexpr bool LATE_R = GPA_ROWHALF_LATE_R;
-  T rlo[E], rhi[E];
+  // The post-processing owns its bins in BLOCKS OF FOUR: thread t, block v holds k = 4 (t + TPF v) + e, e = 0 .. 3, and their
+  // partners N - k -- so the kept spectrum comes in and goes out as 16-byte accesses (the partners' vector starts at N - k0 - 3:
+  // 4-byte aligned, which global memory takes) and the two tables as 32 bytes per block.  (Rounds 3-5 owned k = t + TPF i:
+  // 64 dword accesses per thread and row where there are 16 vectors now; the memory pipeline issued four times the
+  // instructions for the same bytes.)  Bin 0's partner is bin N/2, stored at HN: block 0 of thread 0 goes element by element.
+  constexpr int NB = E / 4;
+  Vec4<T> rlo[NB], rhi[NB];     // rhi[v].v[3 - e] = R[N - k0 - e]
   auto load_kept = [&]() {
 #pragma unroll
-    for (int i = 0; i < E; ++i) {
-      const int k = tid + TPF * i;
-      rlo[i] = r[o + k];
-      rhi[i] = r[o + (k == 0 ? HN : N - k)];
+    for (int v = 0; v < NB; ++v) {
+      const int k0 = 4 * (tid + TPF * v);
+      rlo[v] = *reinterpret_cast<const Vec4<T>*>(r + o + k0);
+      if (k0 == 0) {
+        rhi[v].v[3] = r[o + HN];
+        rhi[v].v[2] = r[o + N - 1];
+        rhi[v].v[1] = r[o + N - 2];
+        rhi[v].v[0] = r[o + N - 3];
+      } else {
+        rhi[v] = *reinterpret_cast<const Vec4U<T>*>(r + o + N - k0 - 3);
+      }
     }
   };
   if (it > 0 && !LATE_R) load_kept();
@@ -107,29 +126,47 @@ __global__ __launch_bounds__((RowHalfGeom<T, LG>::THREADS), (sizeof(T) == 4 && L
   __syncthreads();
   double sq = 0;
 #pragma unroll
-  for (int i = 0; i < E; ++i) {
-    const int k = tid + TPF * i;
-    const cpx<T> zk = lds[F::pad(k)], zm = lds[F::pad((HN - k) & (HN - 1))];
-    T xlo, xhi;
-    if (k == 0) {
-      xlo = T(2) * (zk.x + zk.y);
-      xhi = T(1.41421356237309504880) * (zk.x - zk.y);
+  for (int v = 0; v < NB; ++v) {
+    const int k0 = 4 * (tid + TPF * v);
+    struct alignas(16) C2 { cpx<T> a, b; };
+    const C2 tn01 = *reinterpret_cast<const C2*>(twn + k0), tn23 = *reinterpret_cast<const C2*>(twn + k0 + 2);
+    const C2 wk01 = *reinterpret_cast<const C2*>(wk + k0), wk23 = *reinterpret_cast<const C2*>(wk + k0 + 2);
+    const cpx<T> tn[4] = {tn01.a, tn01.b, tn23.a, tn23.b}, wv[4] = {wk01.a, wk01.b, wk23.a, wk23.b};
+    Vec4<T> olo, ohi;
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+      const int k = k0 + e;
+      const cpx<T> zk = lds[F::pad(k)], zm = lds[F::pad((HN - k) & (HN - 1))];
+      T xlo, xhi;
+      if (k == 0) {
+        xlo = T(2) * (zk.x + zk.y);
+        xhi = T(1.41421356237309504880) * (zk.x - zk.y);
+      } else {
+        const cpx<T> ve = {T(0.5) * (zk.x + zm.x), T(0.5) * (zk.y - zm.y)};   // (T_k + conj T_m) / 2
+        const cpx<T> vo = {T(0.5) * (zk.y + zm.y), T(-0.5) * (zk.x - zm.x)};  // -i (T_k - conj T_m) / 2
+        const cpx<T> V = ve + cmul(tn[e], vo);
+        const cpx<T> U = cmul(wv[e], V);
+        xlo = T(2) * U.x;
+        xhi = T(-2) * U.y;
+      }
+      if (it > 0) {
+        xlo = rlo[v].v[e] - alpha * xlo;
+        xhi = rhi[v].v[3 - e] - alpha * xhi;
+        // sum_n r^2 = (1 / 2N) sum_k c_k R_k^2, c_0 = 1/2 (SciPy's unnormalised DCT-II)
+        sq += (k == 0 ? 0.5 : 1.0) * (double)xlo * (double)xlo + (double)xhi * (double)xhi;
+      }
+      olo.v[e] = xlo;
+      ohi.v[3 - e] = xhi;
+    }
+    *reinterpret_cast<Vec4<T>*>(r + o + k0) = olo;
+    if (k0 == 0) {
+      r[o + HN] = ohi.v[3];
+      r[o + N - 1] = ohi.v[2];
+      r[o + N - 2] = ohi.v[1];
+      r[o + N - 3] = ohi.v[0];
     } else {
-      const cpx<T> ve = {T(0.5) * (zk.x + zm.x), T(0.5) * (zk.y - zm.y)};   // (T_k + conj T_m) / 2
-      const cpx<T> vo = {T(0.5) * (zk.y + zm.y), T(-0.5) * (zk.x - zm.x)};  // -i (T_k - conj T_m) / 2
-      const cpx<T> V = ve + cmul(twn[k], vo);
-      const cpx<T> U = cmul(wk[k], V);
-      xlo = T(2) * U.x;
-      xhi = T(-2) * U.y;
+      *reinterpret_cast<Vec4U<T>*>(r + o + N - k0 - 3) = ohi;
     }
-    if (it > 0) {
-      xlo = rlo[i] - alpha * xlo;
-      xhi = rhi[i] - alpha * xhi;
-      // sum_n r^2 = (1 / 2N) sum_k c_k R_k^2, c_0 = 1/2 (SciPy's unnormalised DCT-II)
-      sq += (k == 0 ? 0.5 : 1.0) * (double)xlo * (double)xlo + (double)xhi * (double)xhi;
-    }
-    r[o + k] = xlo;
-    r[o + (k == 0 ? HN : N - k)] = xhi;
   }
   if (it > 0) {
     const double tot = block_sum(sq, sh);

@@ -353,7 +353,7 @@ __global__ __launch_bounds__(256) void invert_kernel(const T* __restrict__ c0, c
 // Every round gathers 2 x 16 coefficients per pixel around r + u_it(r); the kernel above is bound by those gathers (L1 /
 // texture-address rate and the dependent chain of rounds: 200 instructions per round issue in a quarter of the time a round
 // takes).  The iterates of a tile move by hundreds of pixels in the first rounds where |u| is large, but contract by
-// |grad u| per round; once no pixel of the tile moved by more than 2 samples in a round, the bounding box of the tile's
+// |grad u| per round; once no pixel of the tile moved by more than LMOVE = 8 samples in a round, the bounding box of the tile's
 // sample points (+ spline support + a margin for what movement is left) is loaded into LDS ONCE -- both components
 // interleaved, tap indices clamped while loading, exactly as mode='nearest' clamps them -- and the remaining rounds read
 // their taps with ds_read_b64 (a lane whose 4 x 4 footprint leaves the window falls back to global memory for that round).
@@ -362,6 +362,14 @@ constexpr int LT = 16;        // tile side
 constexpr int LW = 48;        // window side (samples): tile stretched by up to 1.5 + footprint 4 + margin 2 x 4
 constexpr int LWP = LW + 1;   // row pitch (odd: the four rows of a wavefront start on different banks)
 constexpr int LMARG = 4;
+// the window is staged once no pixel of the tile moved by more than LMOVE samples in a round: with the iterates contracting
+// by c = |grad u| per round what is left to move is <= LMOVE c / (1 - c) -- inside the margin for c <= 1/3 (a lane that does
+// leave the window gathers from global memory for that round, same bits).  2 / 4 / 8 / 16: 8.42 / 8.01 / 7.74 / 7.36 ms at
+// 16384^2 on the benchmark field (one global round fewer per step); 8 keeps the margin honest for rougher fields.
+#ifndef GPA_LF_LMOVE
+#define GPA_LF_LMOVE 8
+#endif
+constexpr int LMOVE = GPA_LF_LMOVE;
 template <class T> struct T2 { T a, b; };
 
 template <class T>
@@ -410,7 +418,7 @@ __global__ __launch_bounds__(256) void invert_tile_kernel(const T* __restrict__ 
     if (state != 1 || !interp_window<T>(win, wx0, wy0, m0, m1, x, y, nv)) interp_nearest<T, 2, WIDE>(coef, m0, m1, x, y, nv);
     const bool fixed = nv[0] == v[0] && nv[1] == v[1];
     const bool cyc2 = nv[0] == pv[0] && nv[1] == pv[1];
-    const bool moving = !(fabs(nv[0] - v[0]) <= T(2) && fabs(nv[1] - v[1]) <= T(2));   // (NaN: moving)
+    const bool moving = !(fabs(nv[0] - v[0]) <= T(LMOVE) && fabs(nv[1] - v[1]) <= T(LMOVE));   // (NaN: moving)
     if (state != 0 && !all_rounds && __all(fixed || cyc2)) {
       // every pixel of the wavefront has settled; a cycle's member after the full count of rounds follows from the parity
       if (!((iters - 1 - it) & 1)) { v[0] = nv[0]; v[1] = nv[1]; }
