@@ -338,11 +338,19 @@ int gpa_fit_plane_dev(gpa_plan* plan, const void* image, int max_iter, double to
  * (m0 + 4 dr) x (m1 + 4 dr); data, out: m0 x m1 (host).                                       */
 int gpa_gaussian_deconvolve(gpa_plan* plan, const void* data, int dr, double sigma, double balance,
                             void* out);
+/* the same on device pointers (d_data, d_out: m0 x m1 reals), on the plan's stream; returns after the stream has drained */
+int gpa_gaussian_deconvolve_dev(gpa_plan* plan, const void* d_data, int dr, double sigma, double balance,
+                                void* d_out);
 
 /* a9 -- DFT of the periodic component of Moisan's periodic+smooth decomposition
  * (third-party moisan2011.per(image, inverse_dft=False)[0], call site
  * geometric_phase_analysis.py:429).  out: n0 x n1 complex.                    */
 int gpa_per_dft(gpa_plan* plan, const void* image, void* out);
+/* the same on device pointers, enqueued on the plan's stream (no host synchronisation); d_image is not modified.
+ * Image sizes: every axis length 1 ... 65536 in both precisions (gpa_dft.h: a power of two up to 16384 (f32) / 8192 (f64)
+ * runs the register FFT at its own length, other lengths a chirp-z transform, in one workgroup while 2n - 1 <= 16384 / 8192
+ * and as a two-level transform through HBM beyond).                                                                        */
+int gpa_per_dft_dev(gpa_plan* plan, const void* d_image, void* d_out);
 
 /* a9, the whole of moisan2011.per(image, inverse_dft) (the reference imports it at
  * geometric_phase_analysis.py:9 and calls it at :429 with inverse_dft=False):
@@ -362,6 +370,11 @@ int gpa_per(gpa_plan* plan, const void* image, int inverse_dft, void* p_out, voi
 int gpa_find_peaks(gpa_plan* plan, const void* image, double sigma, double dog_sigma,
                    double threshold_rel, int max_out, int32_t* coords, void* values,
                    int* count_out, void* smooth_out);
+/* the same with the image (not modified) and the optional smooth_out on the device; coords, values, count_out stay host
+ * arrays (a handful of entries).  Synchronises the plan's stream (the count decides what is copied).                    */
+int gpa_find_peaks_dev(gpa_plan* plan, const void* d_image, double sigma, double dog_sigma,
+                       double threshold_rel, int max_out, int32_t* coords, void* values,
+                       int* count_out, void* d_smooth_out);
 
 /* timing hooks used by bench.py: elapsed milliseconds between two recorded
  * events on the plan's stream (HIP events, so it measures the stream the

@@ -78,9 +78,12 @@ SIGNATURES = {
     'gpa_fit_plane': (_i, [_vp, _vp, _i, _d, _dp, _ip]),
     'gpa_fit_plane_dev': (_i, [_vp, _vp, _i, _d, _dp, _ip]),
     'gpa_per_dft': (_i, [_vp, _vp, _vp]),
+    'gpa_per_dft_dev': (_i, [_vp, _vp, _vp]),
     'gpa_per': (_i, [_vp, _vp, _i, _vp, _vp]),
     'gpa_gaussian_deconvolve': (_i, [_vp, _vp, _i, _d, _d, _vp]),
+    'gpa_gaussian_deconvolve_dev': (_i, [_vp, _vp, _i, _d, _d, _vp]),
     'gpa_find_peaks': (_i, [_vp, _vp, _d, _d, _d, _i, _vp, _vp, _ip, _vp]),
+    'gpa_find_peaks_dev': (_i, [_vp, _vp, _d, _d, _d, _i, _vp, _vp, _ip, _vp]),
     'gpa_timer_start': (_i, [_vp]),
     'gpa_timer_stop': (_i, [_vp, _vp]),
     'gpa_set_profiling': (_i, [_vp, _i]),
@@ -406,6 +409,29 @@ class Plan:
         order = np.lexsort((coords[:, 1], coords[:, 0], -vals))
         out = (coords[order].astype(np.intp), vals[order])
         return out + (smooth,) if want_smooth else out
+
+    def find_peaks_dev(self, image_ptr, sigma, dog_sigma, threshold_rel, smooth_ptr=None, max_out=4096):
+        """find_peaks on a device image (not modified); the candidate list comes back to the host, the smoothed spectrum
+        (optional) stays on the device"""
+        coords = np.empty((max_out, 2), dtype=np.int32)
+        vals = np.empty(max_out, dtype=self.rdtype)
+        count = C.c_int(0)
+        check(self.lib.gpa_find_peaks_dev(self.handle, _ptr(int(image_ptr)), float(sigma), float(dog_sigma),
+                                          float(threshold_rel), int(max_out), _ptr(coords), _ptr(vals), C.byref(count),
+                                          _ptr(None if smooth_ptr is None else int(smooth_ptr))), 'gpa_find_peaks_dev')
+        n = min(count.value, max_out)
+        coords, vals = coords[:n], vals[:n]
+        order = np.lexsort((coords[:, 1], coords[:, 0], -vals))
+        return coords[order].astype(np.intp), vals[order]
+
+    def per_dft_dev(self, image_ptr, out_ptr):
+        """per_dft on device pointers (n0 x n1 reals in, n0 x n1 complex out), enqueued on the plan's stream"""
+        check(self.lib.gpa_per_dft_dev(self.handle, _ptr(int(image_ptr)), _ptr(int(out_ptr))), 'gpa_per_dft_dev')
+
+    def gaussian_deconvolve_dev(self, data_ptr, dr, sigma, balance, out_ptr):
+        """gaussian_deconvolve of one m0 x m1 device field (this plan: the padded shape); out_ptr may equal data_ptr"""
+        check(self.lib.gpa_gaussian_deconvolve_dev(self.handle, _ptr(int(data_ptr)), int(dr), float(sigma), float(balance),
+                                                   _ptr(int(out_ptr))), 'gpa_gaussian_deconvolve_dev')
 
     def gaussian_deconvolve(self, data, dr, sigma, balance):
         """one m0 x m1 field; this plan has the padded shape (m0 + 4 dr, m1 + 4 dr)"""

@@ -13,7 +13,7 @@ static const char* const kOptNames[OPT_COUNT] = {
     "PBS_FULLBAND", "SERIAL_UNWRAP", "NO_WORKER", "NO_KSPLIT", "NO_COMPACT", "NO_SHARED",
     "NO_PAIR", "PBS_E8", "TRI_SMALL", "TRI_Q", "NO_MR", "MR_FORCE_BLUESTEIN", "NO_ROWPQ", "COLSOLVE", "NO_LAT",
     "F32_EPS_FLOOR", "COLSTREAM_CHUNK", "NO_ROWHALF", "PAIR_MAXSIDE", "ROWHALF_MINLG", "NO_PQDCT",
-    "NO_REORDER", "NO_RAW", "NO_TILEFUSE", "NO_ROWPERS", "NO_LFTILE", "LF_ALL_ROUNDS"};
+    "NO_REORDER", "NO_RAW", "NO_TILEFUSE", "NO_ROWPERS", "NO_LFTILE", "LF_ALL_ROUNDS", "DFT_ENGINE"};
 static OptVal g_opts[OPT_COUNT];
 static std::once_flag g_opts_once;
 static void opt_assign(OptVal& o, const char* value) {
@@ -138,7 +138,7 @@ int plan_build(gpa_plan* p) {
   TRY(dmalloc(p, &p->d_wnorm, npx * p->rsz));
   TRY(dmalloc(p, &p->d_u, 2 * npx * p->rsz));
   TRY(dmalloc(p, (void**)&p->d_kmat, (size_t)p->max_peaks * 2 * sizeof(double)));
-  {
+  if (!p->spectral_only) {
     size_t before = 0;
     hipError_t e = unwrap_workspace_create(p->dtype, p->n0, p->n1, p->stream, &p->uw, &before);
     if (e != hipSuccess) return fail(GPA_ERR_HIP, std::string("unwrap workspace: ") + hipGetErrorString(e));
@@ -210,12 +210,13 @@ gpa_plan* gpa_plan_create(int device, int n0, int n1, int max_batch, int dtype) 
   p->no_compact = opt_set(OPT_NO_COMPACT);
   p->use_shared = !opt_set(OPT_NO_SHARED);
   const int maxlg = dtype == GPA_F32 ? 14 : 13;
-  if (p->ax0.lg > maxlg || p->ax1.lg > maxlg) {
-    fail(GPA_ERR_ARG, "gpa_plan_create: axis too long for an LDS-resident transform "
-                      "(f32: 16384 pow2 / 8192 other; f64: 8192 pow2 / 4096 other)");
+  if (n0 > 65536 || n1 > 65536) {
+    fail(GPA_ERR_ARG, "gpa_plan_create: axis longer than 65536");
     delete p;
     return nullptr;
   }
+  // beyond an LDS-resident transform (f32: 16384 pow2 / 8192 other; f64: 8192 pow2 / 4096 other) the plan has no sweep / unwrap
+  p->spectral_only = p->ax0.lg > maxlg || p->ax1.lg > maxlg;
   if (plan_build(p) != GPA_OK) {
     std::string keep = g_err;
     gpa_plan_destroy(p);
@@ -252,8 +253,9 @@ void gpa_plan_destroy(gpa_plan* p) {
   if (p->ev_x) hipEventDestroy(p->ev_x);
   if (p->d_tsum_part) (void)hipFree(p->d_tsum_part);
   warp_ws_free(&p->warp);
-  blue_axis_destroy(&p->bx0);
-  blue_axis_destroy(&p->bx1);
+  dft_axis_destroy(&p->bx0);
+  dft_axis_destroy(&p->bx1);
+  dft_work_free(&p->dftw);
   if (p->h_k) hipHostFree(p->h_k);
   if (p->h_iters) hipHostFree(p->h_iters);
   if (p->kprof) {

@@ -1,23 +1,48 @@
 // C ABI, a9 / f-2 / f-3 / f-4: periodic-component DFT, peak finding, Wiener deconvolution, Jacobian / properties, Huber plane fit.
 #include "gpa_plan.h"
 
-// periodic-component DFT of the image in p->d_image -> p->d_lockin (plane 0)
-int per_dft_staged(gpa_plan* p) {
-  if (!p->bx0.tw) {
-    size_t b = 0;
-    hipError_t e = blue_axis_create(p->dtype, p->n0, p->stream, &p->bx0, &b);
-    if (e == hipSuccess) e = blue_axis_create(p->dtype, p->n1, p->stream, &p->bx1, &b);
-    if (e != hipSuccess) return fail(GPA_ERR_HIP, std::string("gpa_per_dft tables: ") + hipGetErrorString(e));
-    p->ws_bytes += b;
+// the two axes of the plain 2-D DFT, built on first use (DFT_ENGINE=chirpz | chirpz2 forces an engine: tests)
+int dft_axes(gpa_plan* p) {
+  if (p->bx0.kind != DFT_NONE) return GPA_OK;
+  int force = 0;
+  if (opt_set(OPT_DFT_ENGINE)) {
+    const char* v = opt(OPT_DFT_ENGINE).str;
+    force = !strcmp(v, "chirpz2") ? DFT_BIG : !strcmp(v, "chirpz") ? DFT_BLUE : 0;
   }
+  size_t b = 0;
+  p->dftw.counted = &p->ws_bytes;
+  hipError_t e = dft_axis_create(p->dtype, p->n0, p->stream, &p->bx0, &b, force);
+  if (e == hipSuccess) e = dft_axis_create(p->dtype, p->n1, p->stream, &p->bx1, &b, force);
+  if (e != hipSuccess) {
+    dft_axis_destroy(&p->bx0);
+    dft_axis_destroy(&p->bx1);
+    return fail(GPA_ERR_HIP, std::string("DFT tables (axis lengths 1 ... 65536): ") + hipGetErrorString(e));
+  }
+  p->ws_bytes += b;
+  return GPA_OK;
+}
+
+// periodic-component DFT of the device image -> p->d_lockin (plane 0); u_hat stays in p->Tbuf
+int per_dft_staged(gpa_plan* p, const void* d_image) {
+  TRY(dft_axes(p));
   // border-difference vectors: d0 holds n1, d1 holds n0 complex values
   void* d0 = p->d_aux1;
   void* d1 = p->d_aux0;
-  HIP_TRY(per_pack(p->dtype, p->d_image, p->n0, p->n1, p->Tbuf, d0, d1, p->stream));
-  HIP_TRY(dft2_inplace(p->dtype, p->bx0, p->bx1, p->Tbuf, p->stream));
-  HIP_TRY(dft_rows_inplace(p->dtype, p->bx1, 1, d0, p->stream));
-  HIP_TRY(dft_rows_inplace(p->dtype, p->bx0, 1, d1, p->stream));
+  HIP_TRY(per_borders(p->dtype, d_image, p->n0, p->n1, d0, d1, p->stream));
+  HIP_TRY(dft2_forward_real(p->dtype, p->bx0, p->bx1, d_image, p->Tbuf, &p->dftw, p->stream));
+  HIP_TRY(dft_rows_inplace(p->dtype, p->bx1, 1, d0, &p->dftw, p->stream));
+  HIP_TRY(dft_rows_inplace(p->dtype, p->bx0, 1, d1, &p->dftw, p->stream));
   HIP_TRY(per_combine(p->dtype, p->Tbuf, d0, d1, p->n0, p->n1, p->d_lockin, p->stream));
+  return GPA_OK;
+}
+
+int gpa_per_dft_dev(gpa_plan* p, const void* d_image, void* d_out) {
+  if (!p || !d_image || !d_out) return fail(GPA_ERR_ARG, "gpa_per_dft_dev: null argument");
+  HIP_TRY(hipSetDevice(p->device));
+  ProfInstall prof(p);
+  TRY(per_dft_staged(p, d_image));
+  HIP_TRY(hipMemcpyAsync(d_out, p->d_lockin, (size_t)p->n0 * p->n1 * p->csz, hipMemcpyDeviceToDevice, p->stream));
+  if (p->profiling) { HIP_TRY(hipStreamSynchronize(p->stream)); collect_kernel_profile(p); }
   return GPA_OK;
 }
 
@@ -26,7 +51,7 @@ int gpa_per_dft(gpa_plan* p, const void* image, void* out) {
   HIP_TRY(hipSetDevice(p->device));
   const size_t npx = (size_t)p->n0 * p->n1;
   HIP_TRY(hipMemcpyAsync(p->d_image, image, npx * p->rsz, hipMemcpyHostToDevice, p->stream));
-  TRY(per_dft_staged(p));
+  TRY(per_dft_staged(p, p->d_image));
   HIP_TRY(hipMemcpyAsync(out, p->d_lockin, npx * p->csz, hipMemcpyDeviceToHost, p->stream));
   HIP_TRY(hipStreamSynchronize(p->stream));
   return GPA_OK;
@@ -38,7 +63,7 @@ int gpa_per(gpa_plan* p, const void* image, int inverse_dft, void* p_out, void* 
   HIP_TRY(hipSetDevice(p->device));
   const size_t npx = (size_t)p->n0 * p->n1;
   HIP_TRY(hipMemcpyAsync(p->d_image, image, npx * p->rsz, hipMemcpyHostToDevice, p->stream));
-  TRY(per_dft_staged(p));   // p_hat in d_lockin, u_hat still in Tbuf
+  TRY(per_dft_staged(p, p->d_image));   // p_hat in d_lockin, u_hat still in Tbuf
   if (!inverse_dft) {
     HIP_TRY(hipMemcpyAsync(p_out, p->d_lockin, npx * p->csz, hipMemcpyDeviceToHost, p->stream));
     if (s_out) {
@@ -46,7 +71,7 @@ int gpa_per(gpa_plan* p, const void* image, int inverse_dft, void* p_out, void* 
       HIP_TRY(hipMemcpyAsync(s_out, p->Tbuf, npx * p->csz, hipMemcpyDeviceToHost, p->stream));
     }
   } else {
-    HIP_TRY(per_components(p->dtype, p->bx0, p->bx1, p->d_lockin, p->d_image, p->d_wnorm, p->d_dudx, p->stream));
+    HIP_TRY(per_components(p->dtype, p->bx0, p->bx1, p->d_lockin, p->d_image, p->d_wnorm, p->d_dudx, &p->dftw, p->stream));
     HIP_TRY(hipMemcpyAsync(p_out, p->d_wnorm, npx * p->rsz, hipMemcpyDeviceToHost, p->stream));
     HIP_TRY(hipMemcpyAsync(s_out, p->d_dudx, npx * p->rsz, hipMemcpyDeviceToHost, p->stream));
   }
@@ -65,16 +90,18 @@ int gaussian_weights(double sigma, std::vector<double>& w) {
   return R;
 }
 
-int gpa_find_peaks(gpa_plan* p, const void* image, double sigma, double dog_sigma, double threshold_rel, int max_out,
-                   int32_t* coords, void* values, int* count_out, void* smooth_out) {
-  if (!p || !image || !coords || !values || !count_out) return fail(GPA_ERR_ARG, "gpa_find_peaks: null argument");
+// image: device pointer (not modified); coords / values / count_out: host; d_smooth_out: device, may be null
+int gpa_find_peaks_dev(gpa_plan* p, const void* d_image, double sigma, double dog_sigma, double threshold_rel, int max_out,
+                       int32_t* coords, void* values, int* count_out, void* d_smooth_out) {
+  if (!p || !d_image || !coords || !values || !count_out) return fail(GPA_ERR_ARG, "gpa_find_peaks: null argument");
   if (!(sigma > 0.0) || max_out < 1) return fail(GPA_ERR_ARG, "gpa_find_peaks: need sigma > 0, max_out >= 1");
   if (p->n0 < 3 || p->n1 < 3) return fail(GPA_ERR_STATE, "gpa_find_peaks: image too small");
   HIP_TRY(hipSetDevice(p->device));
+  ProfInstall prof(p);
   const int n0 = p->n0, n1 = p->n1;
   const size_t npx = (size_t)n0 * n1;
-  // candidates land in d_kidx (max_peaks * npx ints, two per candidate) and d_dudx (2 npx reals)
-  const size_t cap = std::min((size_t)p->max_peaks * npx / 2, 2 * npx);
+  // candidates land in d_kidx (max_peaks * npx ints, two per candidate) and d_dudy (2 (n0 - 1) n1 reals)
+  const size_t cap = std::min((size_t)p->max_peaks * npx / 2, 2 * (size_t)(n0 - 1) * n1);
   if ((size_t)max_out > cap) max_out = (int)cap;
   std::vector<double> w1, w2;
   const int R1 = gaussian_weights(sigma, w1);
@@ -85,10 +112,9 @@ int gpa_find_peaks(gpa_plan* p, const void* image, double sigma, double dog_sigm
   double* d_w = p->d_scratch + 1024;
   double* d_thr = p->d_scratch + 600;
   int* d_count = reinterpret_cast<int*>(p->d_scratch + 610);
-  HIP_TRY(hipMemcpyAsync(p->d_image, image, npx * p->rsz, hipMemcpyHostToDevice, st));
-  TRY(per_dft_staged(p));                                                    // p_hat in d_lockin
-  void* fftim = p->d_image;                                                  // the staged image is consumed
-  void* tmp = p->d_wnorm;
+  TRY(per_dft_staged(p, d_image));                                           // p_hat in d_lockin
+  void* fftim = p->d_wnorm;
+  void* tmp = p->d_dudx;
   void* smooth = p->d_u;
   HIP_TRY(launch_absshift(p->dtype, p->d_lockin, n0, n1, fftim, st));
   HIP_TRY(hipMemcpyAsync(d_w, w1.data(), w1.size() * sizeof(double), hipMemcpyHostToDevice, st));
@@ -100,7 +126,7 @@ int gpa_find_peaks(gpa_plan* p, const void* image, double sigma, double dog_sigm
     HIP_TRY(launch_gauss1d(p->dtype, fftim, tmp, n0, n1, 0, d_w, R2, nullptr, st));
     HIP_TRY(launch_gauss1d(p->dtype, tmp, smooth, n0, n1, 1, d_w, R2, smooth, st));
   }
-  void* d_vals = p->d_dudx;                                                  // 2 npx reals >= max_out values
+  void* d_vals = p->d_dudy;
   HIP_TRY(launch_localmax(p->dtype, smooth, n0, n1, threshold_rel, p->d_scratch, d_thr, max_out, d_count, p->d_kidx,
                           d_vals, st));
   int count = 0;
@@ -111,27 +137,38 @@ int gpa_find_peaks(gpa_plan* p, const void* image, double sigma, double dog_sigm
     HIP_TRY(hipMemcpyAsync(coords, p->d_kidx, (size_t)stored * 2 * sizeof(int32_t), hipMemcpyDeviceToHost, st));
     HIP_TRY(hipMemcpyAsync(values, d_vals, (size_t)stored * p->rsz, hipMemcpyDeviceToHost, st));
   }
-  if (smooth_out) HIP_TRY(hipMemcpyAsync(smooth_out, smooth, npx * p->rsz, hipMemcpyDeviceToHost, st));
+  if (d_smooth_out) HIP_TRY(hipMemcpyAsync(d_smooth_out, smooth, npx * p->rsz, hipMemcpyDeviceToDevice, st));
   HIP_TRY(hipStreamSynchronize(st));
+  if (p->profiling) collect_kernel_profile(p);
   *count_out = count;
   return GPA_OK;
 }
 
+int gpa_find_peaks(gpa_plan* p, const void* image, double sigma, double dog_sigma, double threshold_rel, int max_out,
+                   int32_t* coords, void* values, int* count_out, void* smooth_out) {
+  if (!p || !image) return fail(GPA_ERR_ARG, "gpa_find_peaks: null argument");
+  HIP_TRY(hipSetDevice(p->device));
+  const size_t npx = (size_t)p->n0 * p->n1;
+  HIP_TRY(hipMemcpyAsync(p->d_image, image, npx * p->rsz, hipMemcpyHostToDevice, p->stream));
+  TRY(gpa_find_peaks_dev(p, p->d_image, sigma, dog_sigma, threshold_rel, max_out, coords, values, count_out, nullptr));
+  if (smooth_out) {
+    HIP_TRY(hipMemcpyAsync(smooth_out, p->d_u, npx * p->rsz, hipMemcpyDeviceToHost, p->stream));
+    HIP_TRY(hipStreamSynchronize(p->stream));
+  }
+  return GPA_OK;
+}
+
 // ---- f-4 (gaussian_deconvolve) -----------------------------------------------------
-int gpa_gaussian_deconvolve(gpa_plan* p, const void* data, int dr, double sigma, double balance, void* out) {
-  if (!p || !data || !out) return fail(GPA_ERR_ARG, "gpa_gaussian_deconvolve: null argument");
+// d_data: m0 x m1 reals on the device (m = plan shape - 4 dr), d_out likewise
+int gpa_gaussian_deconvolve_dev(gpa_plan* p, const void* d_data, int dr, double sigma, double balance, void* d_out) {
+  if (!p || !d_data || !d_out) return fail(GPA_ERR_ARG, "gpa_gaussian_deconvolve: null argument");
   if (dr < 0 || !(sigma > 0.0) || !(balance >= 0.0)) return fail(GPA_ERR_ARG, "gpa_gaussian_deconvolve: need dr >= 0, sigma > 0, balance >= 0");
   const int pad = 2 * dr, n0 = p->n0, n1 = p->n1, m0 = n0 - 2 * pad, m1 = n1 - 2 * pad;
   if (m0 < 2 || m1 < 2 || pad >= m0 || pad >= m1)
     return fail(GPA_ERR_STATE, "gpa_gaussian_deconvolve: the plan must have the padded shape (m + 4 dr), with 2 dr < m");
   HIP_TRY(hipSetDevice(p->device));
-  if (!p->bx0.tw) {
-    size_t b = 0;
-    hipError_t e = blue_axis_create(p->dtype, p->n0, p->stream, &p->bx0, &b);
-    if (e == hipSuccess) e = blue_axis_create(p->dtype, p->n1, p->stream, &p->bx1, &b);
-    if (e != hipSuccess) return fail(GPA_ERR_HIP, std::string("gpa_gaussian_deconvolve tables: ") + hipGetErrorString(e));
-    p->ws_bytes += b;
-  }
+  ProfInstall prof(p);
+  TRY(dft_axes(p));
   hipStream_t st = p->stream;
   // k-space Gaussian factors (doubles)
   std::vector<double> gx = gaussian_kspace(n0, sigma), gy = gaussian_kspace(n1, sigma);
@@ -139,14 +176,26 @@ int gpa_gaussian_deconvolve(gpa_plan* p, const void* data, int dr, double sigma,
   double* d_gy = reinterpret_cast<double*>(p->d_aux1);
   HIP_TRY(hipMemcpyAsync(d_gx, gx.data(), (size_t)n0 * sizeof(double), hipMemcpyHostToDevice, st));
   HIP_TRY(hipMemcpyAsync(d_gy, gy.data(), (size_t)n1 * sizeof(double), hipMemcpyHostToDevice, st));
-  HIP_TRY(hipMemcpyAsync(p->d_image, data, (size_t)m0 * m1 * p->rsz, hipMemcpyHostToDevice, st));
-  HIP_TRY(launch_deconv_pack(p->dtype, p->d_image, m0, m1, pad, p->Tbuf, st));
-  HIP_TRY(dft2_inplace(p->dtype, p->bx0, p->bx1, p->Tbuf, st));
+  HIP_TRY(launch_deconv_pack(p->dtype, d_data, m0, m1, pad, p->Tbuf, st));
+  HIP_TRY(dft2_inplace(p->dtype, p->bx0, p->bx1, p->Tbuf, &p->dftw, st));
   HIP_TRY(launch_deconv_filter(p->dtype, p->Tbuf, n0, n1, d_gx, d_gy, balance, st));
-  HIP_TRY(dft2_inplace(p->dtype, p->bx0, p->bx1, p->Tbuf, st));
-  HIP_TRY(launch_deconv_unpack(p->dtype, p->Tbuf, m0, m1, pad, p->d_wnorm, st));
-  HIP_TRY(hipMemcpyAsync(out, p->d_wnorm, (size_t)m0 * m1 * p->rsz, hipMemcpyDeviceToHost, st));
+  HIP_TRY(dft2_inplace(p->dtype, p->bx0, p->bx1, p->Tbuf, &p->dftw, st));
+  HIP_TRY(launch_deconv_unpack(p->dtype, p->Tbuf, m0, m1, pad, d_out, st));
   HIP_TRY(hipStreamSynchronize(st));   // gx / gy are pageable host vectors
+  if (p->profiling) collect_kernel_profile(p);
+  return GPA_OK;
+}
+
+int gpa_gaussian_deconvolve(gpa_plan* p, const void* data, int dr, double sigma, double balance, void* out) {
+  if (!p || !data || !out) return fail(GPA_ERR_ARG, "gpa_gaussian_deconvolve: null argument");
+  const int pad = 2 * dr, m0 = p->n0 - 2 * pad, m1 = p->n1 - 2 * pad;
+  if (dr < 0 || m0 < 2 || m1 < 2)
+    return fail(GPA_ERR_STATE, "gpa_gaussian_deconvolve: the plan must have the padded shape (m + 4 dr), with 2 dr < m");
+  HIP_TRY(hipSetDevice(p->device));
+  HIP_TRY(hipMemcpyAsync(p->d_image, data, (size_t)m0 * m1 * p->rsz, hipMemcpyHostToDevice, p->stream));
+  TRY(gpa_gaussian_deconvolve_dev(p, p->d_image, dr, sigma, balance, p->d_wnorm));
+  HIP_TRY(hipMemcpyAsync(out, p->d_wnorm, (size_t)m0 * m1 * p->rsz, hipMemcpyDeviceToHost, p->stream));
+  HIP_TRY(hipStreamSynchronize(p->stream));
   return GPA_OK;
 }
 

@@ -122,6 +122,7 @@ void build_filter_table(const Axis& ax, const std::vector<double>& g, const std:
 
 int ensure_filters(gpa_plan* p, double sigma) {
   if (!(sigma > 0)) return fail(GPA_ERR_ARG, "sigma must be positive");
+  NEED_UNWRAP(p, "lock-in sweep");
   if (sigma == p->sigma_cached) return GPA_OK;
   HIP_TRY(hipStreamSynchronize(p->stream));   // the tables may still be read by an earlier asynchronous call
   p->sigma_cached = -1.0;   // a failure below must not leave half-switched tables behind a matching sigma

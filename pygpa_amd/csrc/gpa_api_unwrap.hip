@@ -71,6 +71,7 @@ int gpa_unwrap_prediff_dev(gpa_plan* p, const void* dx, const void* dy, const vo
                            double eps, int compat, void* phi, int* iters_out) {
   if (!p || !dx || !dy || !phi) return fail(GPA_ERR_ARG, "gpa_unwrap_prediff: null argument");
   if (kmax < 1) return fail(GPA_ERR_ARG, "gpa_unwrap_prediff: kmax must be >= 1");
+  NEED_UNWRAP(p, "gpa_unwrap_prediff");
   HIP_TRY(hipSetDevice(p->device));
   int iters = 0;
   ProfInstall prof(p);   // (gpa_set_profiling: per-kernel times of this solve through gpa_last_kernel_profile)
@@ -85,6 +86,7 @@ int gpa_unwrap_prediff_enqueue_dev(gpa_plan* p, const void* dx, const void* dy, 
                                    int compat, void* phi) {
   if (!p || !dx || !dy || !phi) return fail(GPA_ERR_ARG, "gpa_unwrap_prediff_enqueue: null argument");
   if (kmax < 1) return fail(GPA_ERR_ARG, "gpa_unwrap_prediff_enqueue: kmax must be >= 1");
+  NEED_UNWRAP(p, "gpa_unwrap_prediff_enqueue");
   HIP_TRY(hipSetDevice(p->device));
   hipError_t e = unwrap_enqueue(&p->uw, dx, dy, weight, false, kmax, eps, compat != 0, phi, p->stream);
   if (e != hipSuccess) return fail(GPA_ERR_HIP, std::string("unwrap: ") + hipGetErrorString(e));
@@ -93,6 +95,7 @@ int gpa_unwrap_prediff_enqueue_dev(gpa_plan* p, const void* dx, const void* dy, 
 
 int gpa_unwrap_finish(gpa_plan* p, int* iters_out) {
   if (!p) return fail(GPA_ERR_ARG, "gpa_unwrap_finish: null plan");
+  NEED_UNWRAP(p, "gpa_unwrap_finish");
   HIP_TRY(hipSetDevice(p->device));
   int iters = 0;
   hipError_t e = unwrap_finish(&p->uw, &iters, p->stream);
@@ -121,6 +124,7 @@ int gpa_unwrap(gpa_plan* p, const void* psi, const void* weight, int kmax, doubl
                int* iters_out) {
   if (!p || !psi || !phi) return fail(GPA_ERR_ARG, "gpa_unwrap: null argument");
   if (kmax < 1) return fail(GPA_ERR_ARG, "gpa_unwrap: kmax must be >= 1");
+  NEED_UNWRAP(p, "gpa_unwrap");
   HIP_TRY(hipSetDevice(p->device));
   const size_t npx = (size_t)p->n0 * p->n1;
   HIP_TRY(hipMemcpyAsync(p->d_image, psi, npx * p->rsz, hipMemcpyHostToDevice, p->stream));

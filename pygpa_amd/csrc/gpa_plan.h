@@ -20,6 +20,7 @@
 #include "gpa_internal.h"
 #include "gpa_passb_shared.h"
 #include "gpa_unwrap.h"
+#include "gpa_dft.h"
 
 using namespace gpa;
 
@@ -31,6 +32,14 @@ static inline int fail(int code, const std::string& msg) { return gpa_fail(code,
     hipError_t _e = (expr);                                                                   \
     if (_e != hipSuccess)                                                                     \
       return fail(GPA_ERR_HIP, std::string(#expr) + ": " + hipGetErrorString(_e));            \
+  } while (0)
+
+#define NEED_UNWRAP(p, what)                                                                                     \
+  do {                                                                                                             \
+    if (!(p)->uw.impl)                                                                                             \
+      return fail(GPA_ERR_STATE, std::string(what) + ": this plan's image is too large for the sweep / unwrap kernels " \
+                                 "(an axis above 16384 pow2 / 8192 other in f32, 8192 / 4096 in f64); it serves per, "  \
+                                 "find_peaks, gaussian_deconvolve and the per-pixel entry points only");                 \
   } while (0)
 
 #define TRY(expr)            \
@@ -88,6 +97,10 @@ struct EnqueueWorker {
 
 struct gpa_plan {
   int device = 0, dtype = 0, n0 = 0, n1 = 0, max_batch = 0;
+  // an axis beyond what one workgroup transforms (f32: 16384 pow2 / 8192 other; f64: 8192 pow2 / 4096 other): no sweep and no
+  // unwrap workspace -- the plan serves the plain-DFT rows (per, find_peaks, gaussian_deconvolve: any axis up to 65536) and
+  // the per-pixel kernels (reconstruct, Lawler-Fujita, Jacobian / properties, plane fit)
+  bool spectral_only = false;
   Axis ax0{}, ax1{};              // the geometry in use (depends on sigma for non-power-of-two axes)
   Axis ax0_full{}, ax1_full{};    // the plan's largest geometry (L >= 2n - 1): what the tables are sized for
   hipStream_t stream = nullptr;
@@ -175,7 +188,8 @@ struct gpa_plan {
   UnwrapWorkspace uw2{};          // second workspace + stream: the two components of u unwrap concurrently
   hipStream_t stream2 = nullptr;
   hipEvent_t ev_fork = nullptr, ev_join = nullptr;
-  BlueAxis bx0{}, bx1{};          // Bluestein tables for gpa_per_dft, built on first use
+  DftAxis bx0{}, bx1{};           // the two axes of the plain 2-D DFT (a9, f-3, f-4: gpa_dft.h), built on first use
+  DftWork dftw{};                 // scratch of its through-HBM engine, grown on demand
   WarpWs warp{};                  // scratch + taps of the Lawler-Fujita kernels (gpa_warp.hip), grown on first use
   // timing
   hipEvent_t ev0 = nullptr, ev1 = nullptr;
@@ -233,7 +247,8 @@ int tile_gradients_impl(gpa_plan* p, const void* image, size_t image_pitch, int 
                                int mask_border, int i0, int j0, int t0, int t1, void* dx, size_t dx_pitch, size_t dx_plane,
                                void* dy, size_t dy_pitch, size_t dy_plane, void* wn, size_t wn_pitch, size_t wn_plane);
 int plan_event(gpa_plan* p);
-int per_dft_staged(gpa_plan* p);
+int dft_axes(gpa_plan* p);
+int per_dft_staged(gpa_plan* p, const void* d_image);
 int gaussian_weights(double sigma, std::vector<double>& w);
 bool solve3(const double* m /*uu uv u vv v 1*/, const double* b, double* x);
 Axis make_axis(int n);

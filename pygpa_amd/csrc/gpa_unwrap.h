@@ -27,26 +27,6 @@ hipError_t unwrap_run(UnwrapWorkspace* ws, const void* a, const void* b, const v
                       bool from_psi, int kmax, double eps, bool axes_compat, void* phi,
                       int* iters_out, hipStream_t s);
 
-// ---- arbitrary-size forward 2-D DFT (Bluestein on the workgroup FFT), used by a9 ------------
-struct BlueAxis {
-  int n = 0, lg = 0;
-  void *tw = nullptr, *chirp = nullptr, *bspec = nullptr;
-};
-hipError_t blue_axis_create(int dtype, int n, hipStream_t s, BlueAxis* out, size_t* bytes);
-void blue_axis_destroy(BlueAxis* a);
-// in-place forward DFT of a complex n0 x n1 array (natural order in and out)
-hipError_t dft2_inplace(int dtype, const BlueAxis& a0, const BlueAxis& a1, void* Z, hipStream_t s);
-hipError_t dft_rows_inplace(int dtype, const BlueAxis& a, int rows, void* Z, hipStream_t s);
-// a9 (Moisan 2011 periodic + smooth decomposition): per_pack writes Z = u as complex and the two
-// border-difference vectors d0 (length n1), d1 (length n0); per_combine forms
-// P^ = U^ - V^ / (2 cos(2 pi q / n0) + 2 cos(2 pi r / n1) - 4) with V^ from D0 = DFT(d0), D1 = DFT(d1)
-hipError_t per_pack(int dtype, const void* image, int n0, int n1, void* Z, void* d0, void* d1, hipStream_t s);
-hipError_t per_smooth_hat(int dtype, void* Uhat_inout, const void* Phat, size_t n, hipStream_t s);
-hipError_t per_components(int dtype, const BlueAxis& a0, const BlueAxis& a1, void* Phat_destroyed, const void* image,
-                          void* p_out, void* s_out, hipStream_t s);
-hipError_t per_combine(int dtype, const void* Uhat, const void* D0, const void* D1, int n0, int n1, void* out,
-                       hipStream_t s);
-
 // the two halves of unwrap_run, for callers that overlap several unwraps on different streams:
 // enqueue everything without synchronising, then fetch the iteration count (synchronises s)
 hipError_t unwrap_enqueue(UnwrapWorkspace* ws, const void* a, const void* b, const void* weight, bool from_psi,

@@ -314,47 +314,4 @@ void unwrap_workspace_destroy(UnwrapWorkspace* ws) {
   delete w;
   ws->impl = nullptr;
 }
-// ---------------------------------------------------------------------------
-// arbitrary-size 2-D DFT + a9 helpers (exported)
-// ---------------------------------------------------------------------------
-hipError_t blue_axis_create(int dtype, int n, hipStream_t s, BlueAxis* out, size_t* bytes) {
-  int lgb = 6;
-  while ((1 << lgb) < 2 * n - 1) ++lgb;
-  if (lgb > (dtype == 0 ? 14 : 13)) return hipErrorInvalidValue;
-  const int L = 1 << lgb, tpf = L / 16;
-  out->n = n;
-  out->lg = lgb;
-  std::vector<double> t((size_t)2 * L), ch((size_t)2 * n), bre((size_t)L, 0.0), bim((size_t)L, 0.0);
-  for (int k = 0; k < L; ++k) { t[2 * k] = cos(-2.0 * M_PI * k / L); t[2 * k + 1] = sin(-2.0 * M_PI * k / L); }
-  for (int m = 0; m < n; ++m) {
-    const long long mm = ((long long)m * m) % (2LL * n);
-    const double cr = cos(M_PI * (double)mm / n), ci = sin(M_PI * (double)mm / n);
-    ch[2 * m] = cr; ch[2 * m + 1] = ci;
-    bre[m] = cr; bim[m] = ci;
-    if (m > 0) { bre[L - m] = cr; bim[L - m] = ci; }
-  }
-  host_fft(bre, bim);
-  std::vector<double> bs((size_t)2 * L);
-  for (int i = 0; i < 16; ++i)
-    for (int tt = 0; tt < tpf; ++tt) {
-      const int k = spec_index_rt(lgb, tt, i);
-      bs[2 * ((size_t)i * tpf + tt)] = bre[k] / L;
-      bs[2 * ((size_t)i * tpf + tt) + 1] = bim[k] / L;
-    }
-  size_t b = 0;
-  hipError_t e;
-  if ((e = upload(dtype, &out->tw, t, &b, s)) != hipSuccess) return e;
-  if ((e = upload(dtype, &out->chirp, ch, &b, s)) != hipSuccess) return e;
-  if ((e = upload(dtype, &out->bspec, bs, &b, s)) != hipSuccess) return e;
-  if (bytes) *bytes += b;
-  return hipSuccess;
-}
-
-void blue_axis_destroy(BlueAxis* a) {
-  if (a->tw) hipFree(a->tw);
-  if (a->chirp) hipFree(a->chirp);
-  if (a->bspec) hipFree(a->bspec);
-  a->tw = a->chirp = a->bspec = nullptr;
-}
-
 }  // namespace gpa

@@ -22,5 +22,6 @@ for w in ${WHAT:-bench4096 unwrap8192 unwrap16384 tiles16384}; do
     unwrap*) n=${w#unwrap}; run unwrap_$n $ROOT/tools/unwrap_sizes.py --sizes $n --modes default --reps 2 ;;
     tiles*) n=${w#tiles}; run tiles_$n $ROOT/tools/stage_times.py --sizes $n ;;
     lf*) n=${w#lf}; run lf_$n $ROOT/tools/lf_times.py --sizes $n --reps 2 ;;
+    next*) n=${w#next}; run next_$n $ROOT/tools/next_rows.py --sizes $n ${NEXT_ARGS:-} ;;
   esac
 done
