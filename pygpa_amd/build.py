@@ -18,7 +18,7 @@ CSRC = os.path.join(HERE, 'csrc')
 BUILD = os.path.join(CSRC, '_build')
 LIB = os.path.join(HERE, 'libgpa_hip.so')
 SOURCES = ['gpa_sweep.hip', 'gpa_passb_shared.hip', 'gpa_sweep_ext.hip', 'gpa_reconstruct.hip', 'gpa_unwrap.hip', 'gpa_unwrap_rows.hip', 'gpa_unwrap_rowhalf.hip', 'gpa_unwrap_pqdct.hip', 'gpa_unwrap_rowpers.hip', 'gpa_unwrap_cols.hip', 'gpa_unwrap_colstream.hip', 'gpa_unwrap_stencil.hip', 'gpa_unwrap_generic.hip',
-           'gpa_unwrap_tables.hip', 'gpa_dft2.hip', 'gpa_warp.hip', 'gpa_tiles.hip', 'gpa_peaks.hip', 'gpa_api.hip', 'gpa_api_tables.hip', 'gpa_api_sweep.hip', 'gpa_api_unwrap.hip', 'gpa_api_driver.hip',
+           'gpa_unwrap_tables.hip', 'gpa_dft2.hip', 'gpa_gaussfft.hip', 'gpa_warp.hip', 'gpa_tiles.hip', 'gpa_peaks.hip', 'gpa_api.hip', 'gpa_api_tables.hip', 'gpa_api_sweep.hip', 'gpa_api_unwrap.hip', 'gpa_api_driver.hip',
            'gpa_api_tiles.hip', 'gpa_api_warp.hip', 'gpa_api_spectral.hip']
 ARCH = 'gfx950'
 FLAGS = ['-O3', '-std=c++17', '-fPIC', '--offload-arch=' + ARCH, '-fno-gpu-rdc',

@@ -13,7 +13,7 @@ static const char* const kOptNames[OPT_COUNT] = {
     "PBS_FULLBAND", "SERIAL_UNWRAP", "NO_WORKER", "NO_KSPLIT", "NO_COMPACT", "NO_SHARED",
     "NO_PAIR", "PBS_E8", "TRI_SMALL", "TRI_Q", "NO_MR", "MR_FORCE_BLUESTEIN", "NO_ROWPQ", "COLSOLVE", "NO_LAT",
     "F32_EPS_FLOOR", "COLSTREAM_CHUNK", "NO_ROWHALF", "PAIR_MAXSIDE", "ROWHALF_MINLG", "NO_PQDCT",
-    "NO_REORDER", "NO_RAW", "NO_TILEFUSE", "NO_ROWPERS", "NO_LFTILE", "LF_ALL_ROUNDS", "DFT_ENGINE"};
+    "NO_REORDER", "NO_RAW", "NO_TILEFUSE", "NO_ROWPERS", "NO_LFTILE", "LF_ALL_ROUNDS", "DFT_ENGINE", "GAUSS_FFT_MINR", "NO_GAUSS2D", "NO_DFT_HALF"};
 static OptVal g_opts[OPT_COUNT];
 static std::once_flag g_opts_once;
 static void opt_assign(OptVal& o, const char* value) {
@@ -256,6 +256,13 @@ void gpa_plan_destroy(gpa_plan* p) {
   dft_axis_destroy(&p->bx0);
   dft_axis_destroy(&p->bx1);
   dft_work_free(&p->dftw);
+  for (auto& ax : p->gft)
+    for (auto& g : ax) {
+      if (g.H) (void)hipFree(g.H);
+      if (g.tw) (void)hipFree(g.tw);
+    }
+  if (p->d_pertab) (void)hipFree(p->d_pertab);
+  if (p->d_peakws) (void)hipFree(p->d_peakws);
   if (p->h_k) hipHostFree(p->h_k);
   if (p->h_iters) hipHostFree(p->h_iters);
   if (p->kprof) {

@@ -22,17 +22,26 @@ int dft_axes(gpa_plan* p) {
   return GPA_OK;
 }
 
-// periodic-component DFT of the device image -> p->d_lockin (plane 0); u_hat stays in p->Tbuf
-int per_dft_staged(gpa_plan* p, const void* d_image) {
+// periodic-component DFT of the device image -> p->d_lockin (plane 0), or (abs_out) |fftshift| of it as reals -> abs_out;
+// u_hat stays in p->Tbuf
+int per_dft_staged(gpa_plan* p, const void* d_image, void* abs_out) {
   TRY(dft_axes(p));
+  if (!p->d_pertab) {
+    TRY(dmalloc(p, &p->d_pertab, per_tables_bytes(p->dtype, p->n0, p->n1)));
+    HIP_TRY(per_tables_fill(p->dtype, p->n0, p->n1, p->d_pertab, p->stream));
+  }
   // border-difference vectors: d0 holds n1, d1 holds n0 complex values
   void* d0 = p->d_aux1;
   void* d1 = p->d_aux0;
   HIP_TRY(per_borders(p->dtype, d_image, p->n0, p->n1, d0, d1, p->stream));
-  HIP_TRY(dft2_forward_real(p->dtype, p->bx0, p->bx1, d_image, p->Tbuf, &p->dftw, p->stream));
+  // |P^| is symmetric under (q, r) -> (-q, -r): for abs_out half of u_hat is enough (power-of-two rows; NO_DFT_HALF: tests)
+  const size_t hp = abs_out && !opt_set(OPT_NO_DFT_HALF) ? dft2_half_pitch(p->bx1) : 0;
+  if (hp) HIP_TRY(dft2_forward_real_half(p->dtype, p->bx0, p->bx1, d_image, p->Tbuf, &p->dftw, p->stream));
+  else HIP_TRY(dft2_forward_real(p->dtype, p->bx0, p->bx1, d_image, p->Tbuf, &p->dftw, p->stream));
   HIP_TRY(dft_rows_inplace(p->dtype, p->bx1, 1, d0, &p->dftw, p->stream));
   HIP_TRY(dft_rows_inplace(p->dtype, p->bx0, 1, d1, &p->dftw, p->stream));
-  HIP_TRY(per_combine(p->dtype, p->Tbuf, d0, d1, p->n0, p->n1, p->d_lockin, p->stream));
+  HIP_TRY(per_combine(p->dtype, p->Tbuf, d0, d1, p->n0, p->n1, p->d_pertab, abs_out != nullptr,
+                      abs_out ? abs_out : p->d_lockin, p->stream, hp));
   return GPA_OK;
 }
 
@@ -40,7 +49,7 @@ int gpa_per_dft_dev(gpa_plan* p, const void* d_image, void* d_out) {
   if (!p || !d_image || !d_out) return fail(GPA_ERR_ARG, "gpa_per_dft_dev: null argument");
   HIP_TRY(hipSetDevice(p->device));
   ProfInstall prof(p);
-  TRY(per_dft_staged(p, d_image));
+  TRY(per_dft_staged(p, d_image, nullptr));
   HIP_TRY(hipMemcpyAsync(d_out, p->d_lockin, (size_t)p->n0 * p->n1 * p->csz, hipMemcpyDeviceToDevice, p->stream));
   if (p->profiling) { HIP_TRY(hipStreamSynchronize(p->stream)); collect_kernel_profile(p); }
   return GPA_OK;
@@ -51,7 +60,7 @@ int gpa_per_dft(gpa_plan* p, const void* image, void* out) {
   HIP_TRY(hipSetDevice(p->device));
   const size_t npx = (size_t)p->n0 * p->n1;
   HIP_TRY(hipMemcpyAsync(p->d_image, image, npx * p->rsz, hipMemcpyHostToDevice, p->stream));
-  TRY(per_dft_staged(p, p->d_image));
+  TRY(per_dft_staged(p, p->d_image, nullptr));
   HIP_TRY(hipMemcpyAsync(out, p->d_lockin, npx * p->csz, hipMemcpyDeviceToHost, p->stream));
   HIP_TRY(hipStreamSynchronize(p->stream));
   return GPA_OK;
@@ -63,7 +72,7 @@ int gpa_per(gpa_plan* p, const void* image, int inverse_dft, void* p_out, void* 
   HIP_TRY(hipSetDevice(p->device));
   const size_t npx = (size_t)p->n0 * p->n1;
   HIP_TRY(hipMemcpyAsync(p->d_image, image, npx * p->rsz, hipMemcpyHostToDevice, p->stream));
-  TRY(per_dft_staged(p, p->d_image));   // p_hat in d_lockin, u_hat still in Tbuf
+  TRY(per_dft_staged(p, p->d_image, nullptr));   // p_hat in d_lockin, u_hat still in Tbuf
   if (!inverse_dft) {
     HIP_TRY(hipMemcpyAsync(p_out, p->d_lockin, npx * p->csz, hipMemcpyDeviceToHost, p->stream));
     if (s_out) {
@@ -90,6 +99,71 @@ int gaussian_weights(double sigma, std::vector<double>& w) {
   return R;
 }
 
+// device tables of the FFT form of one axis' filter: transfer function + twiddles of the segment length, two sigmas kept per axis
+static int gauss_tables(gpa_plan* p, int axis, double sigma, int lg, const std::vector<double>& w, const void** H, const void** tw) {
+  gpa_plan::GaussTab* slot = nullptr;
+  for (auto& g : p->gft[axis])
+    if (g.sigma == sigma && g.lg == lg) slot = &g;
+  if (!slot) {
+    slot = p->gft[axis][0].stamp <= p->gft[axis][1].stamp ? &p->gft[axis][0] : &p->gft[axis][1];
+    HIP_TRY(hipStreamSynchronize(p->stream));   // an earlier call may still read the tables being replaced
+    slot->sigma = -1.0;
+    const size_t L = (size_t)1 << lg;
+    if (slot->cap_lg < lg) {
+      if (slot->H) { (void)hipFree(slot->H); p->ws_bytes -= ((size_t)1 << slot->cap_lg) * p->rsz; }
+      if (slot->tw) { (void)hipFree(slot->tw); p->ws_bytes -= ((size_t)1 << slot->cap_lg) * p->csz; }
+      slot->H = slot->tw = nullptr;
+      slot->cap_lg = 0;
+      TRY(dmalloc(p, &slot->H, L * p->rsz));
+      TRY(dmalloc(p, &slot->tw, L * p->csz));
+      slot->cap_lg = lg;
+    }
+    TRY(upload_real_table(p, slot->H, gaussfft_table(lg, w)));
+    TRY(upload_twiddles(p, slot->tw, (int)L));
+    slot->sigma = sigma;
+    slot->lg = lg;
+  }
+  slot->stamp = ++p->gft_clock;
+  *H = slot->H;
+  *tw = slot->tw;
+  return GPA_OK;
+}
+
+// out = [minuend -] scipy.ndimage.gaussian_filter(in, sigma) (axis 0 first, then axis 1; `tmp` holds the intermediate).
+// Kernels of radius >= GAUSS_FFT_MINR (default 12) run as overlap-save FFT convolutions (gpa_gaussfft.hip), shorter ones as
+// direct sums in double (gauss1d_kernel); the filter weights of the direct form live in d_scratch[1024 ...].
+int gaussian_filter_dev(gpa_plan* p, const void* in, void* tmp, void* out, double sigma, const void* minuend) {
+  std::vector<double> w;
+  const int R = gaussian_weights(sigma, w), n0 = p->n0, n1 = p->n1;
+  hipStream_t st = p->stream;
+  const int minr = opt_set(OPT_GAUSS_FFT_MINR) ? (int)opt(OPT_GAUSS_FFT_MINR).num : 12;
+  int lg0 = 0, lg1 = 0;
+  if (R >= minr) {
+    lg0 = gaussfft_choose_lg(p->dtype, n0, R, true);
+    lg1 = gaussfft_choose_lg(p->dtype, n1, R, false);
+  }
+  if (lg0 && lg1) {
+    const void *H0, *H1, *tw0, *tw1;
+    TRY(gauss_tables(p, 0, sigma, lg0, w, &H0, &tw0));
+    TRY(gauss_tables(p, 1, sigma, lg1, w, &H1, &tw1));
+    HIP_TRY(launch_gaussfft(p->dtype, lg0, 0, in, tmp, n0, n1, R, H0, tw0, nullptr, st));
+    HIP_TRY(launch_gaussfft(p->dtype, lg1, 1, tmp, out, n0, n1, R, H1, tw1, minuend, st));
+    return GPA_OK;
+  }
+  if (2 * R + 1 > 3072) return fail(GPA_ERR_ARG, "gaussian filter: sigma too large for this image (radius > 1535 and no FFT length fits)");
+  double* d_w = p->d_scratch + 1024;
+  HIP_TRY(hipStreamSynchronize(st));   // the weight slot may still be read by an earlier filter
+  HIP_TRY(hipMemcpyAsync(d_w, w.data(), w.size() * sizeof(double), hipMemcpyHostToDevice, st));
+  if (gauss2d_small_ok(R) && !opt_set(OPT_NO_GAUSS2D)) {
+    HIP_TRY(launch_gauss2d_small(p->dtype, in, out, n0, n1, d_w, R, minuend, st));
+  } else {
+    HIP_TRY(launch_gauss1d(p->dtype, in, tmp, n0, n1, 0, d_w, R, nullptr, st));
+    HIP_TRY(launch_gauss1d(p->dtype, tmp, out, n0, n1, 1, d_w, R, minuend, st));
+  }
+  HIP_TRY(hipStreamSynchronize(st));   // w is a pageable host vector
+  return GPA_OK;
+}
+
 // image: device pointer (not modified); coords / values / count_out: host; d_smooth_out: device, may be null
 int gpa_find_peaks_dev(gpa_plan* p, const void* d_image, double sigma, double dog_sigma, double threshold_rel, int max_out,
                        int32_t* coords, void* values, int* count_out, void* d_smooth_out) {
@@ -103,31 +177,18 @@ int gpa_find_peaks_dev(gpa_plan* p, const void* d_image, double sigma, double do
   // candidates land in d_kidx (max_peaks * npx ints, two per candidate) and d_dudy (2 (n0 - 1) n1 reals)
   const size_t cap = std::min((size_t)p->max_peaks * npx / 2, 2 * (size_t)(n0 - 1) * n1);
   if ((size_t)max_out > cap) max_out = (int)cap;
-  std::vector<double> w1, w2;
-  const int R1 = gaussian_weights(sigma, w1);
-  const int R2 = dog_sigma > 0.0 ? gaussian_weights(dog_sigma, w2) : 0;
-  // d_scratch (4096 doubles): [0, 1024) min/max partials + threshold, [1024, 4096) filter weights
-  if (2 * R1 + 1 > 3072 || 2 * R2 + 1 > 3072) return fail(GPA_ERR_ARG, "gpa_find_peaks: sigma too large (radius > 1535)");
   hipStream_t st = p->stream;
-  double* d_w = p->d_scratch + 1024;
-  double* d_thr = p->d_scratch + 600;
-  int* d_count = reinterpret_cast<int*>(p->d_scratch + 610);
-  TRY(per_dft_staged(p, d_image));                                           // p_hat in d_lockin
+  if (!p->d_peakws) TRY(dmalloc(p, (void**)&p->d_peakws, (2 * PEAK_PARTS + 16) * sizeof(double)));
+  double* d_thr = p->d_peakws + 2 * PEAK_PARTS;
+  int* d_count = reinterpret_cast<int*>(p->d_peakws + 2 * PEAK_PARTS + 8);
   void* fftim = p->d_wnorm;
   void* tmp = p->d_dudx;
   void* smooth = p->d_u;
-  HIP_TRY(launch_absshift(p->dtype, p->d_lockin, n0, n1, fftim, st));
-  HIP_TRY(hipMemcpyAsync(d_w, w1.data(), w1.size() * sizeof(double), hipMemcpyHostToDevice, st));
-  HIP_TRY(launch_gauss1d(p->dtype, fftim, tmp, n0, n1, 0, d_w, R1, nullptr, st));
-  HIP_TRY(launch_gauss1d(p->dtype, tmp, smooth, n0, n1, 1, d_w, R1, nullptr, st));
-  if (dog_sigma > 0.0) {
-    HIP_TRY(hipStreamSynchronize(st));   // w1 (pageable) and the weight slot are reused
-    HIP_TRY(hipMemcpyAsync(d_w, w2.data(), w2.size() * sizeof(double), hipMemcpyHostToDevice, st));
-    HIP_TRY(launch_gauss1d(p->dtype, fftim, tmp, n0, n1, 0, d_w, R2, nullptr, st));
-    HIP_TRY(launch_gauss1d(p->dtype, tmp, smooth, n0, n1, 1, d_w, R2, smooth, st));
-  }
+  TRY(per_dft_staged(p, d_image, fftim));                                    // |fftshift(p_hat)|, DC = 0
+  TRY(gaussian_filter_dev(p, fftim, tmp, smooth, sigma, nullptr));
+  if (dog_sigma > 0.0) TRY(gaussian_filter_dev(p, fftim, tmp, smooth, dog_sigma, smooth));
   void* d_vals = p->d_dudy;
-  HIP_TRY(launch_localmax(p->dtype, smooth, n0, n1, threshold_rel, p->d_scratch, d_thr, max_out, d_count, p->d_kidx,
+  HIP_TRY(launch_localmax(p->dtype, smooth, n0, n1, threshold_rel, p->d_peakws, d_thr, max_out, d_count, p->d_kidx,
                           d_vals, st));
   int count = 0;
   HIP_TRY(hipMemcpyAsync(&count, d_count, sizeof(int), hipMemcpyDeviceToHost, st));

@@ -46,6 +46,10 @@ hipError_t dft2_inplace(int dtype, const DftAxis& a0, const DftAxis& a1, void* Z
 // forward DFT of a REAL n0 x n1 image into the complex array Z
 hipError_t dft2_forward_real(int dtype, const DftAxis& a0, const DftAxis& a1, const void* image, void* Z, DftWork* w,
                              hipStream_t s);
+// the same, bins [0, n1/2] of every row only, row pitch dft2_half_pitch(a1) (0: this axis' engine cannot; power-of-two rows can)
+size_t dft2_half_pitch(const DftAxis& a1);
+hipError_t dft2_forward_real_half(int dtype, const DftAxis& a0, const DftAxis& a1, const void* image, void* Z, DftWork* w,
+                                  hipStream_t s);
 // forward DFT of `rows` contiguous complex rows of length a.n, in place
 hipError_t dft_rows_inplace(int dtype, const DftAxis& a, int rows, void* Z, DftWork* w, hipStream_t s);
 
@@ -56,7 +60,12 @@ hipError_t per_borders(int dtype, const void* image, int n0, int n1, void* d0, v
 hipError_t per_smooth_hat(int dtype, void* Uhat_inout, const void* Phat, size_t n, hipStream_t s);
 hipError_t per_components(int dtype, const DftAxis& a0, const DftAxis& a1, void* Phat_destroyed, const void* image,
                           void* p_out, void* s_out, DftWork* w, hipStream_t s);
-hipError_t per_combine(int dtype, const void* Uhat, const void* D0, const void* D1, int n0, int n1, void* out,
-                       hipStream_t s);
+// `tab`: per_tables_bytes() of device memory filled once by per_tables_fill (the per-axis factors, in double).
+// abs_shift: out = |fftshift(P^)| as reals with the DC bin exactly 0 (what f-3 smooths) instead of P^ itself
+size_t per_tables_bytes(int dtype, int n0, int n1);
+hipError_t per_tables_fill(int dtype, int n0, int n1, void* tab, hipStream_t s);
+// half_pitch != 0 (abs_shift only): Uhat holds bins 0 ... n1/2 of every row with that row pitch (dft2_forward_real_half)
+hipError_t per_combine(int dtype, const void* Uhat, const void* D0, const void* D1, int n0, int n1, const void* tab,
+                       bool abs_shift, void* out, hipStream_t s, size_t half_pitch = 0);
 
 }  // namespace gpa

@@ -22,9 +22,12 @@ namespace {
 //   A_k = (Z_k + conj Z_{-k}) / 2,  B_k = (Z_k - conj Z_{-k}) / 2i  -- both full rows leave from one transform.
 // The forward transform leaves the spectrum digit-scrambled in registers; one more trip through LDS (scatter to the bin's own
 // slot, read back in the natural layout) makes the stores coalesced and gives every thread the partner bin -k.
-template <class T, int LG, bool REAL_IN>
+// HALF (real input only): bins 0 ... L/2 of every row, row pitch `opitch` -- the other half of a real image's spectrum is its
+// mirror image, U^[-q, -r] = conj U^[q, r], and a consumer that wants |U^| (f-3) never needs it.
+template <class T, int LG, bool REAL_IN, bool HALF = false>
 __global__ __launch_bounds__((GenGeom<T, LG>::THREADS)) void p2_rows_kernel(const void* __restrict__ in_, cpx<T>* __restrict__ out,
-                                                                          int nrows, const cpx<T>* __restrict__ twtab) {
+                                                                          int nrows, const cpx<T>* __restrict__ twtab,
+                                                                          size_t opitch) {
   using F = WgFFT<T, LG>;
   using G = GenGeom<T, LG>;
   constexpr int TPF = F::TPF, L = F::L;
@@ -58,18 +61,19 @@ __global__ __launch_bounds__((GenGeom<T, LG>::THREADS)) void p2_rows_kernel(cons
   if constexpr (REAL_IN) {
     const int ra = 2 * g, rb = 2 * g + 1;
     if (ra >= nrows) return;
-    cpx<T>* oa = out + (size_t)ra * L;
-    cpx<T>* ob = out + (size_t)(rb < nrows ? rb : ra) * L;
+    cpx<T>* oa = out + (size_t)ra * opitch;
+    cpx<T>* ob = out + (size_t)(rb < nrows ? rb : ra) * opitch;
 #pragma unroll
     for (int i = 0; i < 16; ++i) {
       const int k = tid + TPF * i;
+      if (HALF && k > L / 2) continue;
       const cpx<T> zk = lds[F::pad(k)], zm = lds[F::pad((L - k) & (L - 1))];
       oa[k] = {T(0.5) * (zk.x + zm.x), T(0.5) * (zk.y - zm.y)};
       if (rb < nrows) ob[k] = {T(0.5) * (zk.y + zm.y), T(-0.5) * (zk.x - zm.x)};
     }
   } else {
     if (g >= nrows) return;
-    cpx<T>* o = out + (size_t)g * L;
+    cpx<T>* o = out + (size_t)g * opitch;
 #pragma unroll
     for (int i = 0; i < 16; ++i) o[tid + TPF * i] = lds[F::pad(tid + TPF * i)];
   }
@@ -187,7 +191,7 @@ __global__ __launch_bounds__((GenGeom<T, LG>::THREADS)) void g_rowdft_kernel(
 
 template <class T, int LG>
 __global__ __launch_bounds__((GenGeom<T, LG>::THREADS)) void g_coldft_kernel(
-    cpx<T>* __restrict__ Z, int n, int n1, const cpx<T>* __restrict__ twtab, const cpx<T>* __restrict__ chirp,
+    cpx<T>* __restrict__ Z, int n, int n1, size_t pitch, const cpx<T>* __restrict__ twtab, const cpx<T>* __restrict__ chirp,
     const cpx<T>* __restrict__ bspec) {
   using F = WgFFT<T, LG>;
   using B = WgBluestein<T, LG>;
@@ -204,14 +208,14 @@ __global__ __launch_bounds__((GenGeom<T, LG>::THREADS)) void g_coldft_kernel(
 #pragma unroll
   for (int i = 0; i < 16; ++i) {
     const int slot = tid + TPF * i;
-    x[i] = (valid && slot < n) ? Z[(size_t)slot * n1 + col] : cpx<T>{T(0), T(0)};
+    x[i] = (valid && slot < n) ? Z[(size_t)slot * pitch + col] : cpx<T>{T(0), T(0)};
   }
   B::dft(x, lds, tid, n, chirp, bspec, tw);
   if (!valid) return;
 #pragma unroll
   for (int i = 0; i < 16; ++i) {
     const int slot = tid + TPF * i;
-    if (slot < n) Z[(size_t)slot * n1 + col] = x[i];
+    if (slot < n) Z[(size_t)slot * pitch + col] = x[i];
   }
 }
 
@@ -368,48 +372,81 @@ __global__ __launch_bounds__(256) void per_borders_kernel(const T* __restrict__ 
   if (j < n0) d1[j] = {u[(size_t)j * n1 + n1 - 1] - u[(size_t)j * n1], T(0)};
 }
 
+// per-axis factors of the border image's spectrum, in double once per plan: e[j] = 1 - exp(2 pi i j / n) (real part as
+// 2 sin^2(pi j / n): no cancellation), s[j] = sin^2(pi j / n).  Layout of the table: s0[n0], s1[n1] doubles, e0[n0], e1[n1] complex.
 template <class T>
+__global__ __launch_bounds__(256) void per_tables_kernel(int n0, int n1, double* __restrict__ s0, double* __restrict__ s1,
+                                                        cpx<T>* __restrict__ e0, cpx<T>* __restrict__ e1) {
+  const int j = blockIdx.x * 256 + threadIdx.x;
+  for (int ax = 0; ax < 2; ++ax) {
+    const int n = ax ? n1 : n0;
+    if (j >= n) continue;
+    const double sh = sinpi((double)j / n);
+    double sn, cs;
+    sincospi(2.0 * (double)j / n, &sn, &cs);
+    (ax ? s1 : s0)[j] = sh * sh;
+    (ax ? e1 : e0)[j] = {(T)(2.0 * sh * sh), (T)(-sn)};
+  }
+}
+
+// P^ = U^ - V^ / (2 cos(2 pi q / n0) + 2 cos(2 pi r / n1) - 4), 2 cos a + 2 cos b - 4 = -4 (sin^2(a/2) + sin^2(b/2)).
+// ABS: what f-3 wants of it, |fftshift(P^)| with the DC bin exactly 0 (geometric_phase_analysis.py:427-430), in ONE pass:
+// the thread of output pixel (si, sj) reads bin (si - n0/2, sj - n1/2) mod (n0, n1).
+template <class T, bool ABS>
 __global__ __launch_bounds__(256) void per_combine_kernel(const cpx<T>* __restrict__ Uh, const cpx<T>* __restrict__ D0,
                                                          const cpx<T>* __restrict__ D1, int n0, int n1,
-                                                         cpx<T>* __restrict__ out) {
-  const int r = blockIdx.x * 256 + threadIdx.x, q = blockIdx.y;
-  if (r >= n1) return;
-  const cpx<T> U = Uh[(size_t)q * n1 + r];
-  cpx<T> S = {T(0), T(0)};
-  if (q != 0 || r != 0) {
-    double sq, cq, sr, cr;
-    sincospi(2.0 * (double)q / n0, &sq, &cq);
-    sincospi(2.0 * (double)r / n1, &sr, &cr);
-    const cpx<T> fq = {(T)(1.0 - cq), (T)(-sq)}, fr = {(T)(1.0 - cr), (T)(-sr)};
-    const cpx<T> V = cmul(D0[r], fq) + cmul(D1[q], fr);
-    // 2 cos a + 2 cos b - 4 = -4 (sin^2(a/2) + sin^2(b/2))
-    const double sa = sinpi((double)q / n0), sb = sinpi((double)r / n1);
-    const T inv = (T)(1.0 / (-4.0 * (sa * sa + sb * sb)));
-    S = {V.x * inv, V.y * inv};
+                                                         const double* __restrict__ s0, const double* __restrict__ s1,
+                                                         const cpx<T>* __restrict__ e0, const cpx<T>* __restrict__ e1,
+                                                         void* __restrict__ out_, size_t upitch, int half) {
+  const int oj = blockIdx.x * 256 + threadIdx.x, oi = blockIdx.y;
+  if (oj >= n1) return;
+  int q = oi, r = oj;
+  if constexpr (ABS) {
+    q = oi + n0 - n0 / 2;
+    q = q >= n0 ? q - n0 : q;
+    r = oj + n1 - n1 / 2;
+    r = r >= n1 ? r - n1 : r;
+    // u_hat holds columns 0 ... n1/2 only: |P^[q, r]| = |P^[-q, -r]|
+    if (half && r > n1 / 2) { r = n1 - r; q = q ? n0 - q : 0; }
   }
-  out[(size_t)q * n1 + r] = {U.x - S.x, U.y - S.y};
+  const cpx<T> U = Uh[(size_t)q * upitch + r];
+  cpx<T> P = {T(0), T(0)};
+  if (q != 0 || r != 0) {
+    const cpx<T> V = cmul(D0[r], e0[q]) + cmul(D1[q], e1[r]);
+    const T inv = T(-0.25) / (T)(s0[q] + s1[r]);
+    P = {U.x - V.x * inv, U.y - V.y * inv};
+  } else if (!ABS) {
+    P = U;
+  }
+  if constexpr (ABS) {
+    // (f32: the bins of a 4096^2 image stay below 1e8, far from where x^2 + y^2 leaves the f32 range)
+    if constexpr (sizeof(T) == 4) static_cast<T*>(out_)[(size_t)oi * n1 + oj] = sqrtf(P.x * P.x + P.y * P.y);
+    else static_cast<T*>(out_)[(size_t)oi * n1 + oj] = hypot(P.x, P.y);
+  }
+  else static_cast<cpx<T>*>(out_)[(size_t)oi * n1 + oj] = P;
 }
 
 // ---------------------------------------------------------------------------------------------------------------------
 // launchers
 // ---------------------------------------------------------------------------------------------------------------------
-template <class T, int LG, bool REAL_IN>
-hipError_t run_p2_rows(const DftAxis& a, int nrows, const void* in, void* out, hipStream_t s) {
+template <class T, int LG, bool REAL_IN, bool HALF = false>
+hipError_t run_p2_rows(const DftAxis& a, int nrows, const void* in, void* out, hipStream_t s, size_t opitch = 0) {
   using G = GenGeom<T, LG>;
   if constexpr (!G::FITS) return hipErrorInvalidValue;
   else {
-    auto kern = p2_rows_kernel<T, LG, REAL_IN>;
+    auto kern = p2_rows_kernel<T, LG, REAL_IN, HALF>;
     static unsigned lds_set = 0;
     hipError_t e = set_dynamic_lds_once(reinterpret_cast<const void*>(kern), (int)G::LDS_BYTES, lds_set);
     if (e != hipSuccess) return e;
     const int ntr = REAL_IN ? (nrows + 1) / 2 : nrows;
     GPA_PROF(REAL_IN ? "dft_rows_r2c_kernel" : "dft_rows_kernel", s);
-    kern<<<(ntr + G::NF - 1) / G::NF, G::THREADS, G::LDS_BYTES, s>>>(in, (cpx<T>*)out, nrows, (const cpx<T>*)a.tw);
+    kern<<<(ntr + G::NF - 1) / G::NF, G::THREADS, G::LDS_BYTES, s>>>(in, (cpx<T>*)out, nrows, (const cpx<T>*)a.tw,
+                                                                     opitch ? opitch : (size_t)a.n);
     return hipGetLastError();
   }
 }
 template <class T, int LG>
-hipError_t run_p2_cols(const DftAxis& a, int n1, void* Z, hipStream_t s) {
+hipError_t run_p2_cols(const DftAxis& a, int n1, size_t pitch, void* Z, hipStream_t s) {
   using G = ColGeom<T, LG>;
   if constexpr (!G::FITS) return hipErrorInvalidValue;
   else {
@@ -418,7 +455,7 @@ hipError_t run_p2_cols(const DftAxis& a, int n1, void* Z, hipStream_t s) {
     hipError_t e = set_dynamic_lds_once(reinterpret_cast<const void*>(kern), (int)G::LDS_BYTES, lds_set);
     if (e != hipSuccess) return e;
     GPA_PROF("dft_cols_kernel", s);
-    kern<<<(n1 + G::C - 1) / G::C, G::THREADS, G::LDS_BYTES, s>>>((cpx<T>*)Z, n1, (size_t)n1, (const cpx<T>*)a.tw);
+    kern<<<(n1 + G::C - 1) / G::C, G::THREADS, G::LDS_BYTES, s>>>((cpx<T>*)Z, n1, pitch, (const cpx<T>*)a.tw);
     return hipGetLastError();
   }
 }
@@ -438,7 +475,7 @@ hipError_t run_rowdft(const DftAxis& a, int n0, void* Z, hipStream_t s) {
   }
 }
 template <class T, int LG>
-hipError_t run_coldft(const DftAxis& a, int n1, void* Z, hipStream_t s) {
+hipError_t run_coldft(const DftAxis& a, int n1, size_t pitch, void* Z, hipStream_t s) {
   using G = GenGeom<T, LG>;
   if constexpr (!G::FITS) return hipErrorInvalidValue;
   else {
@@ -447,7 +484,7 @@ hipError_t run_coldft(const DftAxis& a, int n1, void* Z, hipStream_t s) {
     hipError_t e = set_dynamic_lds_once(reinterpret_cast<const void*>(kern), (int)G::LDS_BYTES, lds_set);
     if (e != hipSuccess) return e;
     GPA_PROF("dft_cols_chirpz_kernel", s);
-    kern<<<(n1 + G::NF - 1) / G::NF, G::THREADS, G::LDS_BYTES, s>>>((cpx<T>*)Z, a.n, n1, (const cpx<T>*)a.tw,
+    kern<<<(n1 + G::NF - 1) / G::NF, G::THREADS, G::LDS_BYTES, s>>>((cpx<T>*)Z, a.n, n1, pitch, (const cpx<T>*)a.tw,
                                                                      (const cpx<T>*)a.chirp, (const cpx<T>*)a.bspec);
     return hipGetLastError();
   }
@@ -554,22 +591,23 @@ hipError_t rows_inplace(int dtype, const DftAxis& a, int rows, void* Z, DftWork*
   return e;
 }
 
-hipError_t cols_inplace(int dtype, const DftAxis& a, int n1, void* Z, DftWork* w, hipStream_t s) {
+// `n1` columns of a row-major array with row pitch `pitch` (complex elements)
+hipError_t cols_inplace(int dtype, const DftAxis& a, int n1, size_t pitch, void* Z, DftWork* w, hipStream_t s) {
   hipError_t e = hipErrorInvalidValue;
   switch (a.kind) {
     case DFT_POW2:
-#define CASE(LG) case LG: e = dtype == 0 ? run_p2_cols<float, LG>(a, n1, Z, s) : run_p2_cols<double, LG>(a, n1, Z, s); break;
+#define CASE(LG) case LG: e = dtype == 0 ? run_p2_cols<float, LG>(a, n1, pitch, Z, s) : run_p2_cols<double, LG>(a, n1, pitch, Z, s); break;
       switch (a.lg) { GPA_FOR_LG(CASE) }
 #undef CASE
       break;
     case DFT_BLUE:
-#define CASE(LG) case LG: e = dtype == 0 ? run_coldft<float, LG>(a, n1, Z, s) : run_coldft<double, LG>(a, n1, Z, s); break;
+#define CASE(LG) case LG: e = dtype == 0 ? run_coldft<float, LG>(a, n1, pitch, Z, s) : run_coldft<double, LG>(a, n1, pitch, Z, s); break;
       switch (a.lg) { GPA_FOR_LG(CASE) }
 #undef CASE
       break;
     case DFT_BIG:
-      e = dtype == 0 ? big_run<float>(a, true, (cpx<float>*)Z, (size_t)n1, n1, w, s)
-                     : big_run<double>(a, true, (cpx<double>*)Z, (size_t)n1, n1, w, s);
+      e = dtype == 0 ? big_run<float>(a, true, (cpx<float>*)Z, pitch, n1, w, s)
+                     : big_run<double>(a, true, (cpx<double>*)Z, pitch, n1, w, s);
       break;
   }
   return e;
@@ -714,7 +752,7 @@ void dft_work_free(DftWork* w) {
 hipError_t dft2_inplace(int dtype, const DftAxis& a0, const DftAxis& a1, void* Z, DftWork* w, hipStream_t s) {
   hipError_t e = rows_inplace(dtype, a1, a0.n, Z, w, s);
   if (e != hipSuccess) return e;
-  return cols_inplace(dtype, a0, a1.n, Z, w, s);
+  return cols_inplace(dtype, a0, a1.n, (size_t)a1.n, Z, w, s);
 }
 
 hipError_t dft_rows_inplace(int dtype, const DftAxis& a, int rows, void* Z, DftWork* w, hipStream_t s) {
@@ -740,7 +778,21 @@ hipError_t dft2_forward_real(int dtype, const DftAxis& a0, const DftAxis& a1, co
     e = rows_inplace(dtype, a1, a0.n, Z, w, s);
   }
   if (e != hipSuccess) return e;
-  return cols_inplace(dtype, a0, a1.n, Z, w, s);
+  return cols_inplace(dtype, a0, a1.n, (size_t)a1.n, Z, w, s);
+}
+
+// bins [0, n1/2] of every row only (row pitch dft2_half_pitch): half the column transforms and half the traffic
+size_t dft2_half_pitch(const DftAxis& a1) { return a1.kind == DFT_POW2 ? (size_t)(a1.n / 2 + 2) : 0; }
+hipError_t dft2_forward_real_half(int dtype, const DftAxis& a0, const DftAxis& a1, const void* image, void* Z, DftWork* w,
+                                  hipStream_t s) {
+  const size_t hp = dft2_half_pitch(a1);
+  if (!hp) return hipErrorInvalidValue;
+  hipError_t e = hipErrorInvalidValue;
+#define CASE(LG) case LG: e = dtype == 0 ? run_p2_rows<float, LG, true, true>(a1, a0.n, image, Z, s, hp) : run_p2_rows<double, LG, true, true>(a1, a0.n, image, Z, s, hp); break;
+  switch (a1.lg) { GPA_FOR_LG(CASE) }
+#undef CASE
+  if (e != hipSuccess) return e;
+  return cols_inplace(dtype, a0, a1.n / 2 + 1, hp, Z, w, s);
 }
 
 hipError_t per_borders(int dtype, const void* image, int n0, int n1, void* d0, void* d1, hipStream_t s) {
@@ -799,14 +851,30 @@ hipError_t per_components(int dtype, const DftAxis& a0, const DftAxis& a1, void*
     per_real_kernel<double><<<grid, 256, 0, s>>>((const cpx<double>*)Phat_destroyed, (const double*)image, scale, (double*)p_out, (double*)s_out, n);
   return hipGetLastError();
 }
-hipError_t per_combine(int dtype, const void* Uhat, const void* D0, const void* D1, int n0, int n1, void* out,
-                       hipStream_t s) {
+size_t per_tables_bytes(int dtype, int n0, int n1) { return (size_t)(n0 + n1) * (sizeof(double) + (dtype == 0 ? 8 : 16)); }
+hipError_t per_tables_fill(int dtype, int n0, int n1, void* tab, hipStream_t s) {
+  double* s0 = static_cast<double*>(tab);
+  double* s1 = s0 + n0;
+  void* e0 = s1 + n1;
+  const int len = n0 > n1 ? n0 : n1;
+  if (dtype == 0) per_tables_kernel<float><<<(len + 255) / 256, 256, 0, s>>>(n0, n1, s0, s1, (cpx<float>*)e0, (cpx<float>*)e0 + n0);
+  else per_tables_kernel<double><<<(len + 255) / 256, 256, 0, s>>>(n0, n1, s0, s1, (cpx<double>*)e0, (cpx<double>*)e0 + n0);
+  return hipGetLastError();
+}
+hipError_t per_combine(int dtype, const void* Uhat, const void* D0, const void* D1, int n0, int n1, const void* tab,
+                       bool abs_shift, void* out, hipStream_t s, size_t half_pitch) {
+  if (half_pitch && !abs_shift) return hipErrorInvalidValue;
   dim3 grid((n1 + 255) / 256, n0);
-  GPA_PROF("per_combine_kernel", s);
-  if (dtype == 0)
-    per_combine_kernel<float><<<grid, 256, 0, s>>>((const cpx<float>*)Uhat, (const cpx<float>*)D0, (const cpx<float>*)D1, n0, n1, (cpx<float>*)out);
-  else
-    per_combine_kernel<double><<<grid, 256, 0, s>>>((const cpx<double>*)Uhat, (const cpx<double>*)D0, (const cpx<double>*)D1, n0, n1, (cpx<double>*)out);
+  const double* s0 = static_cast<const double*>(tab);
+  const double* s1 = s0 + n0;
+  const void* e0 = s1 + n1;
+  GPA_PROF(abs_shift ? "per_absshift_kernel" : "per_combine_kernel", s);
+#define CALL(T, ABS) per_combine_kernel<T, ABS><<<grid, 256, 0, s>>>((const cpx<T>*)Uhat, (const cpx<T>*)D0, (const cpx<T>*)D1, n0, n1, \
+                                                                      s0, s1, (const cpx<T>*)e0, (const cpx<T>*)e0 + n0, out, \
+                                                                      half_pitch ? half_pitch : (size_t)n1, half_pitch ? 1 : 0)
+  if (dtype == 0) { if (abs_shift) CALL(float, true); else CALL(float, false); }
+  else { if (abs_shift) CALL(double, true); else CALL(double, false); }
+#undef CALL
   return hipGetLastError();
 }
 

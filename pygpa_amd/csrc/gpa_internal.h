@@ -72,7 +72,7 @@ enum OptKey {
   OPT_PBS_FULLBAND, OPT_SERIAL_UNWRAP, OPT_NO_WORKER, OPT_NO_KSPLIT, OPT_NO_COMPACT, OPT_NO_SHARED,
   OPT_NO_PAIR, OPT_PBS_E8, OPT_TRI_SMALL, OPT_TRI_Q, OPT_NO_MR, OPT_MR_FORCE_BLUESTEIN, OPT_NO_ROWPQ,
   OPT_COLSOLVE, OPT_NO_LAT, OPT_F32_EPS_FLOOR, OPT_COLSTREAM_CHUNK, OPT_NO_ROWHALF, OPT_PAIR_MAXSIDE, OPT_ROWHALF_MINLG, OPT_NO_PQDCT,
-  OPT_NO_REORDER, OPT_NO_RAW, OPT_NO_TILEFUSE, OPT_NO_ROWPERS, OPT_NO_LFTILE, OPT_LF_ALL_ROUNDS, OPT_DFT_ENGINE, OPT_COUNT
+  OPT_NO_REORDER, OPT_NO_RAW, OPT_NO_TILEFUSE, OPT_NO_ROWPERS, OPT_NO_LFTILE, OPT_LF_ALL_ROUNDS, OPT_DFT_ENGINE, OPT_GAUSS_FFT_MINR, OPT_NO_GAUSS2D, OPT_NO_DFT_HALF, OPT_COUNT
 };
 struct OptVal {
   bool set;
@@ -221,7 +221,10 @@ hipError_t launch_huber_moments(int dtype, const void* img, int n0, int n1, cons
                                 double sx, double sy, double* scratch, hipStream_t s);
 
 // ---- f-3 peak candidates (gpa_peaks.hip) --------------------------------------------------------
-hipError_t launch_absshift(int dtype, const void* phat, int n0, int n1, void* out, hipStream_t s);
+constexpr int PEAK_PARTS = 1024;   // workgroups of the min / max reduction (2 doubles each)
+bool gauss2d_small_ok(int R);
+hipError_t launch_gauss2d_small(int dtype, const void* in, void* out, int n0, int n1, const double* w, int R,
+                                const void* minuend, hipStream_t s);
 hipError_t launch_gauss1d(int dtype, const void* in, void* out, int n0, int n1, int axis, const double* w, int R,
                           const void* minuend, hipStream_t s);
 hipError_t launch_localmax(int dtype, const void* smooth, int n0, int n1, double rel, double* part, double* thr,

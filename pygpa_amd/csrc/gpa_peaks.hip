@@ -14,19 +14,6 @@
 namespace gpa {
 namespace {
 
-template <class T>
-__global__ __launch_bounds__(256) void absshift_kernel(const cpx<T>* __restrict__ phat, int n0, int n1,
-                                                      T* __restrict__ out) {
-  const size_t o = (size_t)blockIdx.x * 256 + threadIdx.x;
-  if (o >= (size_t)n0 * n1) return;
-  const int i = (int)(o / n1), j = (int)(o - (size_t)i * n1);
-  // DC of (image - mean) is zero; the reference holds its rounding residue there
-  const cpx<T> v = phat[o];
-  const T a = o == 0 ? T(0) : (T)hypot((double)v.x, (double)v.y);
-  const int si = (i + n0 / 2) % n0, sj = (j + n1 / 2) % n1;   // np.fft.fftshift
-  out[(size_t)si * n1 + sj] = a;
-}
-
 __device__ __forceinline__ int reflect_index(int i, int n) {
   // scipy 'reflect': (d c b a | a b c d | d c b a), period 2n
   const int p = 2 * n;
@@ -57,18 +44,75 @@ __global__ __launch_bounds__(256) void gauss1d_kernel(const T* __restrict__ in, 
   out[o] = minuend ? (T)((double)minuend[o] - acc) : (T)acc;
 }
 
+// both axes of a SHORT kernel (radius <= GAUSS2D_RMAX) in one pass over the image: a 32 x 64 output tile, its halo loaded
+// once into LDS through the reflection of both axes, axis 0 first (the intermediate is rounded to the array's type exactly
+// where scipy stores it), then axis 1 -- the same sums in the same order as two launches of gauss1d_kernel, bit for bit,
+// with one read and one write of the image instead of two each
+constexpr int GAUSS2D_RMAX = 11, G2_TH = 32, G2_TW = 64;
+template <class T>
+__global__ __launch_bounds__(256) void gauss2d_small_kernel(const T* __restrict__ in, T* out, int n0, int n1,
+                                                           const double* __restrict__ w, int R, const T* minuend) {
+  extern __shared__ __attribute__((aligned(16))) char g2_smem[];
+  const int PW = G2_TW + 2 * R, PH = G2_TH + 2 * R;
+  T* tin = reinterpret_cast<T*>(g2_smem);          // [PH][PW]
+  T* mid = tin + PH * PW;                          // [G2_TH][PW]
+  const int i0 = blockIdx.y * G2_TH, j0 = blockIdx.x * G2_TW;
+  for (int e = threadIdx.x; e < PH * PW; e += 256) {
+    const int a = e / PW, b = e - a * PW;
+    tin[e] = in[(size_t)reflect_index(i0 - R + a, n0) * n1 + reflect_index(j0 - R + b, n1)];
+  }
+  __syncthreads();
+  for (int e = threadIdx.x; e < G2_TH * PW; e += 256) {
+    const int a = e / PW, b = e - a * PW;
+    const T* col = tin + (a + R) * PW + b;
+    double acc = (double)col[0] * w[R];
+    for (int k = R; k >= 1; --k) acc += ((double)col[-k * PW] + (double)col[k * PW]) * w[R - k];
+    mid[e] = (T)acc;
+  }
+  __syncthreads();
+  for (int e = threadIdx.x; e < G2_TH * G2_TW; e += 256) {
+    const int a = e / G2_TW, b = e - a * G2_TW;
+    const int i = i0 + a, j = j0 + b;
+    if (i >= n0 || j >= n1) continue;
+    const T* row = mid + a * PW + b + R;
+    double acc = (double)row[0] * w[R];
+    for (int k = R; k >= 1; --k) acc += ((double)row[-k] + (double)row[k]) * w[R - k];
+    const size_t o = (size_t)i * n1 + j;
+    out[o] = minuend ? (T)((double)minuend[o] - acc) : (T)acc;
+  }
+}
+
+// grid-stride min / max with 16-byte loads and two independent chains per thread (64 MB in ~15 us; the round-5 kernel ran 256
+// workgroups of scalar loads: 72 us)
 template <class T>
 __global__ __launch_bounds__(256) void minmax_partial_kernel(const T* __restrict__ a, size_t count,
                                                             double* __restrict__ part) {
   __shared__ double smin[256], smax[256];
-  double lo = 1e300, hi = -1e300;
-  for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < count; i += (size_t)gridDim.x * 256) {
-    const double v = (double)a[i];
-    lo = v < lo ? v : lo;
-    hi = v > hi ? v : hi;
+  constexpr int W = 16 / sizeof(T);
+  struct alignas(16) Vec { T v[W]; };
+  T lo = a[0], hi = a[0];
+  const size_t nv = (reinterpret_cast<size_t>(a) & 15) == 0 ? count / W : 0, step = (size_t)gridDim.x * 256;
+  const Vec* av = reinterpret_cast<const Vec*>(a);
+  T lo2 = lo, hi2 = hi;
+  size_t i = (size_t)blockIdx.x * 256 + threadIdx.x;
+  for (; i + step < nv; i += 2 * step) {
+    const Vec u = av[i], w = av[i + step];
+#pragma unroll
+    for (int k = 0; k < W; ++k) {
+      lo = u.v[k] < lo ? u.v[k] : lo; hi = u.v[k] > hi ? u.v[k] : hi;
+      lo2 = w.v[k] < lo2 ? w.v[k] : lo2; hi2 = w.v[k] > hi2 ? w.v[k] : hi2;
+    }
   }
-  smin[threadIdx.x] = lo;
-  smax[threadIdx.x] = hi;
+  if (i < nv) {
+    const Vec u = av[i];
+#pragma unroll
+    for (int k = 0; k < W; ++k) { lo = u.v[k] < lo ? u.v[k] : lo; hi = u.v[k] > hi ? u.v[k] : hi; }
+  }
+  for (size_t j = nv * W + (size_t)blockIdx.x * 256 + threadIdx.x; j < count; j += step) {
+    lo = a[j] < lo ? a[j] : lo; hi = a[j] > hi ? a[j] : hi;
+  }
+  smin[threadIdx.x] = (double)(lo2 < lo ? lo2 : lo);
+  smax[threadIdx.x] = (double)(hi2 > hi ? hi2 : hi);
   __syncthreads();
   for (int s = 128; s > 0; s >>= 1) {
     if (threadIdx.x < s) {
@@ -202,18 +246,25 @@ hipError_t launch_deconv_unpack(int dtype, const void* Z, int m0, int m1, int pa
   return hipGetLastError();
 }
 
-hipError_t launch_absshift(int dtype, const void* phat, int n0, int n1, void* out, hipStream_t s) {
-  const unsigned grid = (unsigned)(((size_t)n0 * n1 + 255) / 256);
+// gaussian_filter with a kernel of radius R <= GAUSS2D_RMAX, both axes in one launch
+bool gauss2d_small_ok(int R) { return R <= GAUSS2D_RMAX; }
+hipError_t launch_gauss2d_small(int dtype, const void* in, void* out, int n0, int n1, const double* w, int R,
+                                const void* minuend, hipStream_t s) {
+  const dim3 grid((n1 + G2_TW - 1) / G2_TW, (n0 + G2_TH - 1) / G2_TH);
+  const size_t elems = (size_t)(G2_TH + 2 * R) * (G2_TW + 2 * R) + (size_t)G2_TH * (G2_TW + 2 * R);
+  GPA_PROF("gauss2d_small_kernel", s);
   if (dtype == 0)
-    absshift_kernel<float><<<grid, 256, 0, s>>>((const cpx<float>*)phat, n0, n1, (float*)out);
+    gauss2d_small_kernel<float><<<grid, 256, elems * sizeof(float), s>>>((const float*)in, (float*)out, n0, n1, w, R, (const float*)minuend);
   else
-    absshift_kernel<double><<<grid, 256, 0, s>>>((const cpx<double>*)phat, n0, n1, (double*)out);
+    gauss2d_small_kernel<double><<<grid, 256, elems * sizeof(double), s>>>((const double*)in, (double*)out, n0, n1, w, R,
+                                                                          (const double*)minuend);
   return hipGetLastError();
 }
 
 hipError_t launch_gauss1d(int dtype, const void* in, void* out, int n0, int n1, int axis, const double* w, int R,
                           const void* minuend, hipStream_t s) {
   const unsigned grid = (unsigned)(((size_t)n0 * n1 + 255) / 256);
+  GPA_PROF("gauss1d_kernel", s);
   if (dtype == 0)
     gauss1d_kernel<float><<<grid, 256, 0, s>>>((const float*)in, (float*)out, n0, n1, axis, w, R, (const float*)minuend);
   else
@@ -222,16 +273,22 @@ hipError_t launch_gauss1d(int dtype, const void* in, void* out, int n0, int n1, 
   return hipGetLastError();
 }
 
-// part: >= 512 doubles; thr: 3 doubles; count: 1 int (cleared)
+// part: >= 2 * PEAK_PARTS doubles; thr: 3 doubles; count: 1 int (cleared)
 hipError_t launch_localmax(int dtype, const void* smooth, int n0, int n1, double rel, double* part, double* thr,
                            int max_out, int* count, int32_t* coords, void* vals, hipStream_t s) {
   const size_t npx = (size_t)n0 * n1;
   const unsigned grid = (unsigned)((npx + 255) / 256);
-  if (dtype == 0)
-    minmax_partial_kernel<float><<<256, 256, 0, s>>>((const float*)smooth, npx, part);
-  else
-    minmax_partial_kernel<double><<<256, 256, 0, s>>>((const double*)smooth, npx, part);
-  threshold_kernel<<<1, 256, 0, s>>>(part, 256, rel, thr, count);
+  const size_t want = npx / 8192;
+  const int nparts = want > PEAK_PARTS ? PEAK_PARTS : (want < 32 ? 32 : (int)want);
+  {
+    GPA_PROF("minmax_kernels", s);
+    if (dtype == 0)
+      minmax_partial_kernel<float><<<nparts, 256, 0, s>>>((const float*)smooth, npx, part);
+    else
+      minmax_partial_kernel<double><<<nparts, 256, 0, s>>>((const double*)smooth, npx, part);
+    threshold_kernel<<<1, 256, 0, s>>>(part, nparts, rel, thr, count);
+  }
+  GPA_PROF("localmax_kernel", s);
   if (dtype == 0)
     localmax_kernel<float><<<grid, 256, 0, s>>>((const float*)smooth, n0, n1, thr, max_out, count, coords, (float*)vals);
   else

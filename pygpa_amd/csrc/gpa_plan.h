@@ -21,6 +21,7 @@
 #include "gpa_passb_shared.h"
 #include "gpa_unwrap.h"
 #include "gpa_dft.h"
+#include "gpa_gaussfft.h"
 
 using namespace gpa;
 
@@ -190,6 +191,12 @@ struct gpa_plan {
   hipEvent_t ev_fork = nullptr, ev_join = nullptr;
   DftAxis bx0{}, bx1{};           // the two axes of the plain 2-D DFT (a9, f-3, f-4: gpa_dft.h), built on first use
   DftWork dftw{};                 // scratch of its through-HBM engine, grown on demand
+  void* d_pertab = nullptr;       // a9: per-axis factors 1 - e^(2 pi i j / n) and sin^2(pi j / n) (per_tables_create)
+  // f-3: tables of the FFT form of gaussian_filter (gpa_gaussfft.h), two sigmas per axis (difference of Gaussians)
+  struct GaussTab { double sigma = -1.0; int lg = 0; void* H = nullptr; void* tw = nullptr; int cap_lg = 0; unsigned stamp = 0; };
+  GaussTab gft[2][2];
+  unsigned gft_clock = 0;
+  double* d_peakws = nullptr;     // f-3: min / max partials (2 x 2048), threshold, candidate counter
   WarpWs warp{};                  // scratch + taps of the Lawler-Fujita kernels (gpa_warp.hip), grown on first use
   // timing
   hipEvent_t ev0 = nullptr, ev1 = nullptr;
@@ -248,7 +255,8 @@ int tile_gradients_impl(gpa_plan* p, const void* image, size_t image_pitch, int 
                                void* dy, size_t dy_pitch, size_t dy_plane, void* wn, size_t wn_pitch, size_t wn_plane);
 int plan_event(gpa_plan* p);
 int dft_axes(gpa_plan* p);
-int per_dft_staged(gpa_plan* p, const void* d_image);
+int per_dft_staged(gpa_plan* p, const void* d_image, void* abs_out);
+int gaussian_filter_dev(gpa_plan* p, const void* in, void* tmp, void* out, double sigma, const void* minuend);
 int gaussian_weights(double sigma, std::vector<double>& w);
 bool solve3(const double* m /*uu uv u vv v 1*/, const double* b, double* x);
 Axis make_axis(int n);

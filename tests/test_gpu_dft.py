@@ -205,3 +205,39 @@ def test_gaussian_deconvolve_largest_sizes():
         ref = orc.gaussian_deconvolve(u.astype(np.float64), 10.0, dr=20, balance=5000)
         assert rel(out, ref) < (1e-9 if dtype is np.float64 else 2e-4)
         del out, ref
+
+
+@pytest.mark.parametrize('dtype', DTYPES)
+@pytest.mark.parametrize('shape,sigma,dog', [((2048, 2048), 1.0, 50.0), ((1000, 1500), 3.0, 50.0), ((700, 96), 6.5, 20.0),
+                                             ((333, 4100), 1.0, 50.0), ((301, 1024), 2.0, 50.0), ((128, 64), 0.8, 50.0)])
+def test_smoothed_spectrum_fft_filter_vs_oracle(shape, sigma, dog, dtype, gpa_option):
+    """f-3's smoothing as overlap-save FFT convolutions (pygpa_amd/csrc/gpa_gaussfft.hip; kernels of radius >= 12) against
+    SciPy's gaussian_filter (the oracle), and against the direct sums of rounds 2-5 (GAUSS_FFT_MINR above every radius):
+    several segments per axis, segments that reflect at both ends, a 96-pixel axis under a radius-80 kernel"""
+    kvecs = hex_kvecs(0.12, 17.0)
+    img = hex_moire(shape, kvecs, noise=0.5, seed=8)
+    plan = _lib.Plan(shape, 1, dtype)
+    coords, vals, smooth = plan.find_peaks(img, sigma, dog, 0.05, want_smooth=True)
+    ref = orc.smoothed_spectrum(img, sigma, DoG=True) if dog == 50.0 else None
+    if ref is None:
+        import scipy.ndimage as ndi
+        pd, _ = orc.per(img - img.mean(), inverse_dft=False)
+        fftim = np.abs(np.fft.fftshift(pd))
+        ref = ndi.gaussian_filter(fftim, sigma=sigma) - ndi.gaussian_filter(fftim, sigma=dog)
+    tol = 2e-5 if dtype == np.float32 else 1e-11
+    assert rel(smooth, ref) < tol
+    gpa_option('GAUSS_FFT_MINR', '100000')
+    _, _, direct = plan.find_peaks(img, sigma, dog, 0.05, want_smooth=True)
+    assert rel(direct, ref) < tol
+    assert rel(smooth, direct) < tol
+    # the short kernel's two axes in one launch (gauss2d_small_kernel) are the two launches of gauss1d_kernel bit for bit
+    gpa_option('NO_GAUSS2D', '1')
+    _, _, two = plan.find_peaks(img, sigma, dog, 0.05, want_smooth=True)
+    assert np.array_equal(two, direct)
+    gpa_option('NO_GAUSS2D', None)
+    gpa_option('GAUSS_FFT_MINR', None)
+    # the spectrum from half of u_hat (power-of-two rows) against the full transform: the same field up to rounding
+    gpa_option('NO_DFT_HALF', '1')
+    _, _, full = plan.find_peaks(img, sigma, dog, 0.05, want_smooth=True)
+    assert rel(full, ref) < tol and rel(smooth, full) < tol
+    plan.close()
