@@ -55,6 +55,8 @@ def parse_args():
     ap.add_argument('--no-cpu', action='store_true', help='skip the CPU baseline leg')
     ap.add_argument('--no-f64', action='store_true', help='skip the f64 leg')
     ap.add_argument('--no-lf', action='store_true', help='N > 1: skip the tile-sharded Lawler-Fujita diagnostic after the timed region')
+    ap.add_argument('--no-pipeline', action='store_true', help='skip the image -> k-vectors -> u -> undistortion -> properties leg (pipeline_end_to_end)')
+    ap.add_argument('--only-pipeline', action='store_true', help='run that leg alone and print its object (tools / profiles)')
     ap.add_argument('--no-config5', action='store_true', help='skip the 16384^2 tile pipeline + Lawler-Fujita leg (config5_single_gpu)')
     ap.add_argument('--window', type=int, default=2048, help='N > 1: side of the (power-of-two) tile windows')
     ap.add_argument('--backend', default='nccl', help='N > 1: torch.distributed backend (gloo stages through the host)')
@@ -410,6 +412,9 @@ def single_gpu(args):
     n = args.size
     knx, kny = (int(v) for v in args.kgrid.split('x')) if args.kgrid else (args.kside, args.kside)
     np_dt = np.float32 if args.dtype == 'f32' else np.float64
+    if args.only_pipeline:
+        print(json.dumps({'pipeline_end_to_end': pipeline_end_to_end(n, knx, kny, np_dt, args.kmax)}), flush=True)
+        return
     m = measure(n, knx, kny, np_dt, args.kmax, args.steps, args.warmup, depth=args.inflight)
     P, K, sigma, kvecs, klists = m['P'], m['K'], m['sigma'], m['kvecs'], m['klists']
     out = {
@@ -457,6 +462,11 @@ def single_gpu(args):
             out['config5_single_gpu'] = config5_single_gpu(knx, kny, np_dt, args.kmax)
         except Exception as e:      # (an extra leg must not take the headline line with it)
             out['config5_single_gpu'] = {'error': '%s: %s' % (type(e).__name__, e)}
+    if not args.no_f64 and not args.no_pipeline:
+        try:
+            out['pipeline_end_to_end'] = pipeline_end_to_end(n, knx, kny, np_dt, args.kmax)
+        except Exception as e:      # (an extra leg must not take the headline line with it)
+            out['pipeline_end_to_end'] = {'error': '%s: %s' % (type(e).__name__, e)}
     if not args.no_cpu:
         out['cpu_baseline'] = cpu_baseline(kvecs, sigma, knx, kny, args.kmax, n)
     print(json.dumps(out), flush=True)
@@ -570,6 +580,148 @@ def config5_single_gpu(knx, kny, np_dt, kmax, n=16384, window=2048, reps=2):
             'stage_ms': {k: round(v * 1e3, 2) for k, v in st.items()},
             'extraction_only_Mpix_s': round(npx / max(dt - st.get('lawler_fujita', 0.0), 1e-9) / 1e6, 1),
             'lawler_fujita_kernels': lf, 'image_generation_s': round(t_gen, 1)}
+
+
+# compulsory HBM words (reals of the plan dtype) per pixel and launch of the kernels either side of the hot path that are pure
+# streams (P = 3 peaks): what the fraction of the HBM peak in `pipeline_end_to_end` is measured against
+PIPE_WORDS = {
+    'dft_rows_r2c_kernel': 2.0,      # image in, bins 0 ... n/2 of every row out (half of u_hat: |P^| is symmetric)
+    'dft_cols_kernel': 2.0,          # that half in place: in + out
+    'per_absshift_kernel': 2.0,      # half of u_hat in, |fftshift(P^)| out
+    'gauss2d_small_kernel': 2.0,     # in, out
+    'gauss_fft_cols_kernel': 2.0,    # in, out (overlap-save re-reads 2R rows per segment from L2)
+    'gauss_fft_rows_kernel': 3.0,    # in, minuend, out
+    'minmax_kernels': 1.0, 'localmax_kernel': 1.0,
+    'lockin_abs_kernel': 9.0,        # 3 complex lock-ins in, 3 weights out
+    'jacobian_kernel': 13.0,         # 3 gradient pairs + 3 weights in, J (2 x 2) out
+    'props_kernel': 8.0,             # J in, 4 properties out
+    'fir_rows_kernel': 2.0, 'fir_cols_kernel': 2.0, 'warp_constant_kernel': 4.0,
+}
+
+
+def pipeline_end_to_end(n, knx, kny, np_dt, kmax, reps=3):
+    """What a user of the reference runs around the hot path, resident on one GPU at the headline's size:
+    extract_primary_ks (geometric_phase_analysis.py:397-505) -> extract_displacement_field with the k-vectors just found
+    (:907-932) -> undistort_image (:935-974) -> wfr2_grad_opt per peak (:763-813) + phasegradient2J + props_from_Jac
+    (property_extract.py:69-101, :137-178).  Per stage: wall clock around the calls with one stream sync; per kernel: HIP
+    events on the launch stream (gpa_set_profiling), and for the pure streams the fraction of the HBM peak on their compulsory
+    bytes.  Extra key, never `value`."""
+    from pygpa_amd import _lib
+    import pygpa_amd.geometric_phase_analysis as GPA
+    from pygpa_amd.synthetic import hex_kvecs, explicit_klists, gaussian_bump_displacement, hex_moire
+    P, K = 3, knx * kny
+    true_ks = hex_kvecs(0.1, 7.0)
+    img = hex_moire((n, n), true_ks, gaussian_bump_displacement((n, n)), noise=0.1, seed=100, dtype=np.float64)
+    img = (img - img.mean()).astype(np_dt)          # the callers of wfr2_grad_opt subtract the mean (:919)
+    s = np.dtype(np_dt).itemsize
+    npx = n * n
+    plan = _lib.Plan((n, n), P * K, np_dt, device=0)
+    bufs = {k: _lib.DeviceBuffer(v * npx * s) for k, v in dict(img=1, u=2, rec=1, uinv=2, lock=2 * P, grad=2 * P, w=P, J=4, props=4).items()}
+    bufs['img'].upload(img)
+    st = {}
+
+    def stage_ks(profile=None):
+        if profile is not None:      # every evaluation of the relaxation loop is one library call with its own kernel profile
+            def recording(fn):
+                def call(*a, **k):
+                    r = fn(*a, **k)
+                    for name, (c, ms) in plan.last_kernel_profile().items():
+                        c0, t0 = profile.get(name, (0, 0.0))
+                        profile[name] = (c0 + c, t0 + ms)
+                    profile['(library calls)'] = (profile.get('(library calls)', (0, 0.0))[0] + 1, 0.0)
+                    return r
+                return call
+            plan.find_peaks_dev, plan.find_peaks_again = recording(plan.find_peaks_dev), recording(plan.find_peaks_again)
+        try:
+            ks, _ = GPA.extract_primary_ks_dev(plan, bufs['img'].ptr, pix_norm_range=(2, 0.2 * n))
+        finally:
+            if profile is not None:
+                del plan.find_peaks_dev, plan.find_peaks_again
+        return ks
+
+    ks = stage_ks()
+    sigma = int(np.ceil(1 / np.linalg.norm(ks, axis=1).min()))
+    kw = np.linalg.norm(ks, axis=1).mean() / 2.5
+    klists = np.stack(explicit_klists(ks, kw, knx, kny))
+
+    def stage_extract():
+        plan.extract_displacement_field_dev(bufs['img'].ptr, ks, klists, sigma, 2 * sigma, kmax, bufs['u'].ptr)
+
+    def stage_undistort():
+        plan.undistort_image_dev(bufs['img'].ptr, bufs['u'].ptr, bufs['rec'].ptr, uinv_ptr=bufs['uinv'].ptr)
+
+    def stage_props(profile=None):
+        def note():
+            if profile is not None:
+                for name, (c, ms) in plan.last_kernel_profile().items():
+                    c0, t0 = profile.get(name, (0, 0.0))
+                    profile[name] = (c0 + c, t0 + ms)
+        for p_ in range(P):
+            plan.sweep_grad_dev(bufs['img'].ptr, ks[p_], klists[p_], sigma, bufs['lock'].ptr + p_ * 2 * npx * s,
+                                bufs['grad'].ptr + p_ * 2 * npx * s)
+            note()
+        plan.lockin_weights_dev(bufs['lock'].ptr, P, bufs['w'].ptr)
+        note()
+        plan.phasegradient2J_dev(ks, bufs['grad'].ptr, bufs['w'].ptr, 1.0, bufs['J'].ptr)
+        note()
+        plan.timer_start()
+        plan.props_from_jac_dev(bufs['J'].ptr, bufs['props'].ptr, add_identity=True)
+        ms = plan.timer_stop()
+        if profile is not None:
+            profile['props_kernel'] = (1, ms)
+
+    stages = [('extract_primary_ks', stage_ks), ('extract_displacement_field', stage_extract), ('undistort_image', stage_undistort),
+              ('wfr2_grad_opt_x3+phasegradient2J+props_from_Jac', stage_props)]
+    for _, f in stages:
+        f()
+    plan.sync()
+    t_all = time.perf_counter()
+    for _ in range(reps):
+        for name, f in stages:
+            t = time.perf_counter()
+            f()
+            plan.sync()
+            st[name] = st.get(name, 0.0) + (time.perf_counter() - t) / reps
+    t_all = (time.perf_counter() - t_all) / reps
+    # per-kernel HIP-event times of one profiled pass
+    plan.set_profiling(True)
+    kern = {}
+    for name, f in stages:
+        prof = {}
+        if name.startswith('wfr2') or name == 'extract_primary_ks':
+            f(prof)
+        else:
+            f()
+            plan.sync()
+            prof = plan.last_kernel_profile()
+        kern[name] = prof
+    plan.set_profiling(False)
+    table = {}
+    for stage, prof in kern.items():
+        rows = {}
+        for k, (calls, ms) in prof.items():
+            row = {'launches': calls, 'total_ms': round(ms, 4)}
+            if k in PIPE_WORDS and ms > 0:
+                gb = PIPE_WORDS[k] * s * npx * calls / 1e9
+                row['compulsory_GB'] = round(gb, 3)
+                row['frac_of_hbm_peak'] = round(gb / (ms * 1e-3) / HBM_PEAK_GBS, 3)
+            rows[k] = row
+        table[stage] = rows
+    err = float(np.abs(np.minimum(np.linalg.norm(ks[:, None] - true_ks[None], axis=2), np.linalg.norm(ks[:, None] + true_ks[None], axis=2)).min(axis=1)).max())
+    for b in bufs.values():
+        b.free()
+    plan.close()
+    return {'workload': '%dx%d synthetic hex moire resident in HBM, %s: extract_primary_ks (DoG, threshold relaxation on the host) -> '
+                        'extract_displacement_field (3 x %d k-vectors around the k-vectors FOUND, kmax=%d) -> undistort_image '
+                        '(Lawler-Fujita with the extracted field) -> wfr2_grad_opt per peak + phasegradient2J + props_from_Jac; '
+                        'nothing but the candidate lists leaves the device' % (n, n, np.dtype(np_dt).name, K, kmax),
+            'value': round(npx / t_all / 1e6, 1), 'unit': 'Mpixels/s', 'ms_per_image': round(t_all * 1e3, 3),
+            'stage_ms': {k: round(v * 1e3, 3) for k, v in st.items()},
+            'found_kvectors_max_error_cycles_per_px': err, 'reference_bar': 1.5 / n,
+            'kernels': table,
+            'note': 'stage_ms: host wall clock with one stream synchronisation per stage; kernels: HIP events of one profiled pass of '
+                    'each stage (the last evaluation of extract_primary_ks\' relaxation loop); frac_of_hbm_peak on the compulsory '
+                    'bytes of PIPE_WORDS, for the pure streams only'}
 
 
 def host_call(n, knx, kny, np_dt, kmax, reps=5):

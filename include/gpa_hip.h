@@ -316,6 +316,9 @@ int gpa_phasegradient2J(gpa_plan* plan, const double* kvecs, int P, const void* 
                         const void* weights, double nmperpixel, const double* dks, void* J);
 int gpa_phasegradient2J_dev(gpa_plan* plan, const double* kvecs, int P, const void* grads,
                             const void* weights, double nmperpixel, const double* dks, void* J);
+/* np.abs of P lock-ins (P x n0 x n1 complex -> P x n0 x n1 real), the `weights` the reference's callers hand to
+ * phasegradient2J (property_extract.py:69); device pointers, on the plan's stream.                              */
+int gpa_lockin_weights_dev(gpa_plan* plan, const void* lockins, int P, void* weights);
 int gpa_props_from_jac(int device, int dtype, size_t npx, const void* jac, int add_identity,
                        double refangle, double refscale, int diff, void* props);
 int gpa_props_from_jac_dev(int device, int dtype, size_t npx, const void* jac, int add_identity,
@@ -375,6 +378,12 @@ int gpa_find_peaks(gpa_plan* plan, const void* image, double sigma, double dog_s
 int gpa_find_peaks_dev(gpa_plan* plan, const void* d_image, double sigma, double dog_sigma,
                        double threshold_rel, int max_out, int32_t* coords, void* values,
                        int* count_out, void* d_smooth_out);
+/* peak_local_max at another threshold_rel of the smoothed spectrum that the last gpa_find_peaks / gpa_find_peaks_dev call
+ * of this plan computed (the plan keeps it): the re-evaluations of extract_primary_ks' parameter relaxation
+ * (geometric_phase_analysis.py:447-467) while sigma and DoG stay the same cost one threshold + maxima pass instead of the
+ * transforms and filters.  GPA_ERR_STATE before the first gpa_find_peaks call.                                           */
+int gpa_find_peaks_again(gpa_plan* plan, double threshold_rel, int max_out, int32_t* coords, void* values,
+                         int* count_out);
 
 /* timing hooks used by bench.py: elapsed milliseconds between two recorded
  * events on the plan's stream (HIP events, so it measures the stream the

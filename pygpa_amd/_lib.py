@@ -73,6 +73,7 @@ SIGNATURES = {
     'gpa_undistort_image': (_i, [_vp, _vp, _vp, _vp]),
     'gpa_phasegradient2J': (_i, [_vp, _vp, _i, _vp, _vp, _d, _vp, _vp]),
     'gpa_phasegradient2J_dev': (_i, [_vp, _vp, _i, _vp, _vp, _d, _vp, _vp]),
+    'gpa_lockin_weights_dev': (_i, [_vp, _vp, _i, _vp]),
     'gpa_props_from_jac': (_i, [_i, _i, _sz, _vp, _i, _d, _d, _i, _vp]),
     'gpa_props_from_jac_dev': (_i, [_i, _i, _sz, _vp, _i, _d, _d, _i, _vp, _vp]),
     'gpa_fit_plane': (_i, [_vp, _vp, _i, _d, _dp, _ip]),
@@ -84,6 +85,7 @@ SIGNATURES = {
     'gpa_gaussian_deconvolve_dev': (_i, [_vp, _vp, _i, _d, _d, _vp]),
     'gpa_find_peaks': (_i, [_vp, _vp, _d, _d, _d, _i, _vp, _vp, _ip, _vp]),
     'gpa_find_peaks_dev': (_i, [_vp, _vp, _d, _d, _d, _i, _vp, _vp, _ip, _vp]),
+    'gpa_find_peaks_again': (_i, [_vp, _d, _i, _vp, _vp, _ip]),
     'gpa_timer_start': (_i, [_vp]),
     'gpa_timer_stop': (_i, [_vp, _vp]),
     'gpa_set_profiling': (_i, [_vp, _i]),
@@ -380,6 +382,42 @@ class Plan:
                                            float(nmperpixel), _ptr(dks), _ptr(J)), 'gpa_phasegradient2J')
         return J
 
+    # ---- device-pointer forms of the rows after the path (f-2, f-4): nothing leaves HBM -----------------------------
+    def sweep_grad_dev(self, image_ptr, kref, klist, sigma, lockin_ptr, grad_ptr, kidx_ptr=None, grad_mode=0):
+        """wfr2_grad_opt of one peak on device pointers: lockin (n0 x n1 complex), grad (n0 x n1 x 2), optional kidx"""
+        kref = _f64(kref).reshape(2)
+        klist = _f64(klist).reshape(-1, 2)
+        check(self.lib.gpa_sweep_grad_dev(self.handle, _ptr(int(image_ptr)), _ptr(kref), _ptr(klist), len(klist), float(sigma),
+                                          int(grad_mode), _ptr(int(lockin_ptr)),
+                                          _ptr(None if kidx_ptr is None else int(kidx_ptr)), _ptr(int(grad_ptr))),
+              'gpa_sweep_grad_dev')
+
+    def lockin_weights_dev(self, lockins_ptr, P, weights_ptr):
+        """np.abs of P lock-ins on the device"""
+        check(self.lib.gpa_lockin_weights_dev(self.handle, _ptr(int(lockins_ptr)), int(P), _ptr(int(weights_ptr))),
+              'gpa_lockin_weights_dev')
+
+    def phasegradient2J_dev(self, kvecs, grads_ptr, weights_ptr, nmperpixel, J_ptr, dks=None):
+        """phasegradient2J on device pointers: grads (P x n0 x n1 x 2), weights (P x n0 x n1) -> J (n0 x n1 x 2 x 2)"""
+        kvecs = _f64(kvecs).reshape(-1, 2)
+        dks = None if dks is None else _f64(dks).reshape(len(kvecs), 2)
+        check(self.lib.gpa_phasegradient2J_dev(self.handle, _ptr(kvecs), len(kvecs), _ptr(int(grads_ptr)),
+                                               _ptr(int(weights_ptr)), float(nmperpixel), _ptr(dks), _ptr(int(J_ptr))),
+              'gpa_phasegradient2J_dev')
+
+    def props_from_jac_dev(self, jac_ptr, props_ptr, add_identity=False, refangle=0., refscale=1., diff=False):
+        """props_from_Jac on device pointers (n0 x n1 x 2 x 2 -> 4 x n0 x n1), on the plan's stream"""
+        check(self.lib.gpa_props_from_jac_dev(self.device, self.code, self.shape[0] * self.shape[1], _ptr(int(jac_ptr)),
+                                              int(bool(add_identity)), float(refangle), float(refscale), int(bool(diff)),
+                                              _ptr(int(props_ptr)), _ptr(self.stream())), 'gpa_props_from_jac_dev')
+
+    def fit_plane_dev(self, image_ptr, max_iter=200, tol=1e-12):
+        coef = (C.c_double * 3)()
+        iters = C.c_int(0)
+        check(self.lib.gpa_fit_plane_dev(self.handle, _ptr(int(image_ptr)), int(max_iter), float(tol), coef, C.byref(iters)),
+              'gpa_fit_plane_dev')
+        return np.array(coef[:]), iters.value
+
     def fit_plane(self, image, max_iter=200, tol=1e-12):
         image = self._img(image)
         coef = (C.c_double * 3)()
@@ -419,6 +457,23 @@ class Plan:
         check(self.lib.gpa_find_peaks_dev(self.handle, _ptr(int(image_ptr)), float(sigma), float(dog_sigma),
                                           float(threshold_rel), int(max_out), _ptr(coords), _ptr(vals), C.byref(count),
                                           _ptr(None if smooth_ptr is None else int(smooth_ptr))), 'gpa_find_peaks_dev')
+        n = min(count.value, max_out)
+        coords, vals = coords[:n], vals[:n]
+        order = np.lexsort((coords[:, 1], coords[:, 0], -vals))
+        return coords[order].astype(np.intp), vals[order]
+
+    def find_peaks_again(self, threshold_rel, max_out=4096):
+        """the candidates of the smoothed spectrum of the LAST find_peaks / find_peaks_dev call at another threshold"""
+        tried_full = False
+        while True:
+            coords = np.empty((max_out, 2), dtype=np.int32)
+            vals = np.empty(max_out, dtype=self.rdtype)
+            count = C.c_int(0)
+            check(self.lib.gpa_find_peaks_again(self.handle, float(threshold_rel), int(max_out), _ptr(coords), _ptr(vals),
+                                                C.byref(count)), 'gpa_find_peaks_again')
+            if count.value <= max_out or tried_full:
+                break
+            max_out, tried_full = count.value, True
         n = min(count.value, max_out)
         coords, vals = coords[:n], vals[:n]
         order = np.lexsort((coords[:, 1], coords[:, 0], -vals))

@@ -127,7 +127,7 @@ int plan_build(gpa_plan* p) {
   TRY(dmalloc(p, &p->d_image, npx * p->rsz));
   TRY(dmalloc(p, &p->d_mean, 16));
   TRY(dmalloc(p, &p->d_tile_mean, 16));
-  TRY(dmalloc(p, (void**)&p->d_scratch, 4096 * sizeof(double)));
+  TRY(dmalloc(p, (void**)&p->d_scratch, 16384 * sizeof(double)));
   TRY(dmalloc(p, &p->d_aux0, (size_t)p->n0 * 2 * sizeof(double)));
   TRY(dmalloc(p, &p->d_aux1, (size_t)p->n1 * 2 * sizeof(double)));
   p->max_peaks = B < 8 ? B : 8;
@@ -263,6 +263,7 @@ void gpa_plan_destroy(gpa_plan* p) {
     }
   if (p->d_pertab) (void)hipFree(p->d_pertab);
   if (p->d_peakws) (void)hipFree(p->d_peakws);
+  if (p->d_peaksmooth) (void)hipFree(p->d_peaksmooth);
   if (p->h_k) hipHostFree(p->h_k);
   if (p->h_iters) hipHostFree(p->h_iters);
   if (p->kprof) {

@@ -164,6 +164,31 @@ int gaussian_filter_dev(gpa_plan* p, const void* in, void* tmp, void* out, doubl
   return GPA_OK;
 }
 
+// threshold + 3x3 maxima of the smoothed spectrum in p->d_peaksmooth -> host lists (synchronises the stream: the count decides the copy)
+static int peaks_collect(gpa_plan* p, double threshold_rel, int max_out, int32_t* coords, void* values, int* count_out) {
+  const int n0 = p->n0, n1 = p->n1;
+  const size_t npx = (size_t)n0 * n1;
+  hipStream_t st = p->stream;
+  // candidates land in d_kidx (max_peaks * npx ints, two per candidate) and d_dudy (2 (n0 - 1) n1 reals)
+  const size_t cap = std::min((size_t)p->max_peaks * npx / 2, 2 * (size_t)(n0 - 1) * n1);
+  if ((size_t)max_out > cap) max_out = (int)cap;
+  double* d_thr = p->d_peakws + 2 * PEAK_PARTS;
+  int* d_count = reinterpret_cast<int*>(p->d_peakws + 2 * PEAK_PARTS + 8);
+  void* d_vals = p->d_dudy;
+  HIP_TRY(launch_localmax(p->dtype, p->d_peaksmooth, n0, n1, threshold_rel, p->d_peakws, d_thr, max_out, d_count, p->d_kidx, d_vals, st));
+  int count = 0;
+  HIP_TRY(hipMemcpyAsync(&count, d_count, sizeof(int), hipMemcpyDeviceToHost, st));
+  HIP_TRY(hipStreamSynchronize(st));
+  const int stored = count < max_out ? count : max_out;
+  if (stored > 0) {
+    HIP_TRY(hipMemcpyAsync(coords, p->d_kidx, (size_t)stored * 2 * sizeof(int32_t), hipMemcpyDeviceToHost, st));
+    HIP_TRY(hipMemcpyAsync(values, d_vals, (size_t)stored * p->rsz, hipMemcpyDeviceToHost, st));
+    HIP_TRY(hipStreamSynchronize(st));
+  }
+  *count_out = count;
+  return GPA_OK;
+}
+
 // image: device pointer (not modified); coords / values / count_out: host; d_smooth_out: device, may be null
 int gpa_find_peaks_dev(gpa_plan* p, const void* d_image, double sigma, double dog_sigma, double threshold_rel, int max_out,
                        int32_t* coords, void* values, int* count_out, void* d_smooth_out) {
@@ -174,34 +199,36 @@ int gpa_find_peaks_dev(gpa_plan* p, const void* d_image, double sigma, double do
   ProfInstall prof(p);
   const int n0 = p->n0, n1 = p->n1;
   const size_t npx = (size_t)n0 * n1;
-  // candidates land in d_kidx (max_peaks * npx ints, two per candidate) and d_dudy (2 (n0 - 1) n1 reals)
-  const size_t cap = std::min((size_t)p->max_peaks * npx / 2, 2 * (size_t)(n0 - 1) * n1);
-  if ((size_t)max_out > cap) max_out = (int)cap;
   hipStream_t st = p->stream;
+  p->peaks_smooth_valid = false;
   if (!p->d_peakws) TRY(dmalloc(p, (void**)&p->d_peakws, (2 * PEAK_PARTS + 16) * sizeof(double)));
-  double* d_thr = p->d_peakws + 2 * PEAK_PARTS;
-  int* d_count = reinterpret_cast<int*>(p->d_peakws + 2 * PEAK_PARTS + 8);
   void* fftim = p->d_wnorm;
   void* tmp = p->d_dudx;
-  void* smooth = p->d_u;
+  if (!p->d_peaksmooth) TRY(dmalloc(p, &p->d_peaksmooth, npx * p->rsz));   // its own buffer: stays valid for gpa_find_peaks_again
+  void* smooth = p->d_peaksmooth;
   TRY(per_dft_staged(p, d_image, fftim));                                    // |fftshift(p_hat)|, DC = 0
   TRY(gaussian_filter_dev(p, fftim, tmp, smooth, sigma, nullptr));
   if (dog_sigma > 0.0) TRY(gaussian_filter_dev(p, fftim, tmp, smooth, dog_sigma, smooth));
-  void* d_vals = p->d_dudy;
-  HIP_TRY(launch_localmax(p->dtype, smooth, n0, n1, threshold_rel, p->d_peakws, d_thr, max_out, d_count, p->d_kidx,
-                          d_vals, st));
-  int count = 0;
-  HIP_TRY(hipMemcpyAsync(&count, d_count, sizeof(int), hipMemcpyDeviceToHost, st));
-  HIP_TRY(hipStreamSynchronize(st));
-  const int stored = count < max_out ? count : max_out;
-  if (stored > 0) {
-    HIP_TRY(hipMemcpyAsync(coords, p->d_kidx, (size_t)stored * 2 * sizeof(int32_t), hipMemcpyDeviceToHost, st));
-    HIP_TRY(hipMemcpyAsync(values, d_vals, (size_t)stored * p->rsz, hipMemcpyDeviceToHost, st));
+  p->peaks_smooth_valid = true;
+  TRY(peaks_collect(p, threshold_rel, max_out, coords, values, count_out));
+  if (d_smooth_out) {
+    HIP_TRY(hipMemcpyAsync(d_smooth_out, smooth, npx * p->rsz, hipMemcpyDeviceToDevice, st));
+    HIP_TRY(hipStreamSynchronize(st));
   }
-  if (d_smooth_out) HIP_TRY(hipMemcpyAsync(d_smooth_out, smooth, npx * p->rsz, hipMemcpyDeviceToDevice, st));
-  HIP_TRY(hipStreamSynchronize(st));
   if (p->profiling) collect_kernel_profile(p);
-  *count_out = count;
+  return GPA_OK;
+}
+
+// peak_local_max of the smoothed spectrum that the last gpa_find_peaks[_dev] call left in the plan, at another threshold: what
+// the parameter relaxation of extract_primary_ks (geometric_phase_analysis.py:447-467) re-evaluates while sigma stays the same
+int gpa_find_peaks_again(gpa_plan* p, double threshold_rel, int max_out, int32_t* coords, void* values, int* count_out) {
+  if (!p || !coords || !values || !count_out) return fail(GPA_ERR_ARG, "gpa_find_peaks_again: null argument");
+  if (max_out < 1) return fail(GPA_ERR_ARG, "gpa_find_peaks_again: max_out must be >= 1");
+  if (!p->peaks_smooth_valid) return fail(GPA_ERR_STATE, "gpa_find_peaks_again: no smoothed spectrum in the plan (call gpa_find_peaks first)");
+  HIP_TRY(hipSetDevice(p->device));
+  ProfInstall prof(p);
+  TRY(peaks_collect(p, threshold_rel, max_out, coords, values, count_out));
+  if (p->profiling) collect_kernel_profile(p);
   return GPA_OK;
 }
 
@@ -213,7 +240,7 @@ int gpa_find_peaks(gpa_plan* p, const void* image, double sigma, double dog_sigm
   HIP_TRY(hipMemcpyAsync(p->d_image, image, npx * p->rsz, hipMemcpyHostToDevice, p->stream));
   TRY(gpa_find_peaks_dev(p, p->d_image, sigma, dog_sigma, threshold_rel, max_out, coords, values, count_out, nullptr));
   if (smooth_out) {
-    HIP_TRY(hipMemcpyAsync(smooth_out, p->d_u, npx * p->rsz, hipMemcpyDeviceToHost, p->stream));
+    HIP_TRY(hipMemcpyAsync(smooth_out, p->d_peaksmooth, npx * p->rsz, hipMemcpyDeviceToHost, p->stream));
     HIP_TRY(hipStreamSynchronize(p->stream));
   }
   return GPA_OK;
@@ -267,10 +294,23 @@ int gpa_phasegradient2J_dev(gpa_plan* p, const double* kvecs, int P, const void*
   if (P < 2 || P > p->max_peaks) return fail(GPA_ERR_STATE, "gpa_phasegradient2J: need 2 <= P <= 8 (and P <= max_batch)");
   if (!(nmperpixel > 0.0)) return fail(GPA_ERR_ARG, "gpa_phasegradient2J: nmperpixel must be positive");
   HIP_TRY(hipSetDevice(p->device));
+  ProfInstall prof(p);
   double kiso[16];
   for (int i = 0; i < 2 * P; ++i) kiso[i] = kvecs[i] + (dks ? dks[i] : 0.0);
   TRY(stage_kmat(p, kiso, P));
   HIP_TRY(launch_jacobian(p->dtype, grads, weights, p->d_kmat, P, (size_t)p->n0 * p->n1, nmperpixel, dks, J, p->stream));
+  if (p->profiling) { HIP_TRY(hipStreamSynchronize(p->stream)); collect_kernel_profile(p); }
+  return GPA_OK;
+}
+
+// weights of the lock-ins as the reference's callers form them, np.abs(g['lockin']) (P x n0 x n1 complex -> P x n0 x n1 real)
+int gpa_lockin_weights_dev(gpa_plan* p, const void* lockins, int P, void* weights) {
+  if (!p || !lockins || !weights) return fail(GPA_ERR_ARG, "gpa_lockin_weights: null argument");
+  if (P < 1) return fail(GPA_ERR_ARG, "gpa_lockin_weights: P must be >= 1");
+  HIP_TRY(hipSetDevice(p->device));
+  ProfInstall prof(p);
+  HIP_TRY(launch_cabs(p->dtype, lockins, (size_t)P * p->n0 * p->n1, weights, p->stream));
+  if (p->profiling) { HIP_TRY(hipStreamSynchronize(p->stream)); collect_kernel_profile(p); }
   return GPA_OK;
 }
 
@@ -346,6 +386,7 @@ int gpa_fit_plane_dev(gpa_plan* p, const void* image, int max_iter, double tol, 
   if (!p || !image || !coef) return fail(GPA_ERR_ARG, "gpa_fit_plane: null argument");
   if (max_iter < 1 || !(tol >= 0.0)) return fail(GPA_ERR_ARG, "gpa_fit_plane: need max_iter >= 1, tol >= 0");
   HIP_TRY(hipSetDevice(p->device));
+  ProfInstall prof(p);
   const int n0 = p->n0, n1 = p->n1;
   // centred, unit-scaled coordinates keep the normal matrix well conditioned
   const double cx = 0.5 * (n0 - 1), cy = 0.5 * (n1 - 1), sx = 0.5 * n0, sy = 0.5 * n1;
@@ -354,7 +395,7 @@ int gpa_fit_plane_dev(gpa_plan* p, const void* image, int max_iter, double tol, 
   int it = 0;
   for (; it < max_iter; ++it) {
     HIP_TRY(launch_huber_moments(p->dtype, image, n0, n1, c, cx, cy, sx, sy, p->d_scratch, p->stream));
-    HIP_TRY(hipMemcpyAsync(sums, p->d_scratch + 2560, sizeof(sums), hipMemcpyDeviceToHost, p->stream));
+    HIP_TRY(hipMemcpyAsync(sums, p->d_scratch + huber_sums_offset(), sizeof(sums), hipMemcpyDeviceToHost, p->stream));
     HIP_TRY(hipStreamSynchronize(p->stream));
     double nc[3];
     if (!solve3(sums, sums + 6, nc)) return fail(GPA_ERR_STATE, "gpa_fit_plane: singular normal equations");
@@ -367,6 +408,7 @@ int gpa_fit_plane_dev(gpa_plan* p, const void* image, int max_iter, double tol, 
   coef[0] = c[0] / sx;
   coef[1] = c[1] / sy;
   coef[2] = c[2] - c[0] * cx / sx - c[1] * cy / sy;
+  if (p->profiling) collect_kernel_profile(p);
   if (iters_out) *iters_out = it;
   return GPA_OK;
 }

@@ -138,6 +138,8 @@ int gpa_sweep_grad_dev(gpa_plan* p, const void* image, const double* kref, const
   if (K < 1) return fail(GPA_ERR_ARG, "gpa_sweep_grad: K must be >= 1");
   if (grad_mode < 0 || grad_mode > 2) return fail(GPA_ERR_ARG, "gpa_sweep_grad: grad_mode must be 0, 1 or 2");
   HIP_TRY(hipSetDevice(p->device));
+  const bool top = g_kprof == nullptr;   // (called directly, not from sweep_host: this call owns the profile)
+  ProfInstallIf prof(p, top);
   // a4: the winner is selected in registers by pass B as in the plain sweep; what the gradient stencil needs from
   // the OTHER candidates is only the phase of the winner's candidate at the four neighbours, so pass B also writes
   // one real per pixel and candidate (K reals instead of the K complex lock-ins of the first build)
@@ -146,6 +148,7 @@ int gpa_sweep_grad_dev(gpa_plan* p, const void* image, const double* kref, const
   int32_t* ki = kidx ? kidx : p->d_kidx;
   TRY(sweep_one_peak(p, image, kref, klist, K, sigma, 3, lockin, ki, nullptr, p->d_sf));
   HIP_TRY(launch_phasegrad(p->dtype, p->d_sf, K, ki, p->n0, p->n1, p->d_kl, p->d_kr, grad_mode, grad, p->stream));
+  if (top && p->profiling) { HIP_TRY(hipStreamSynchronize(p->stream)); collect_kernel_profile(p); }
   return GPA_OK;
 }
 

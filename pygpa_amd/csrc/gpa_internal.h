@@ -213,10 +213,12 @@ hipError_t launch_wlstsq(int dtype, const void* b, const void* w, const double* 
 // f-2: grads (P x npx x 2) + weights (P x npx) -> J (npx x 2 x 2); Jac (+I) -> props (4 x npx)
 hipError_t launch_jacobian(int dtype, const void* grads, const void* w, const double* kmat, int P, size_t npx,
                            double nmperpixel, const double* dks /*host P x 2 or null*/, void* J, hipStream_t s);
+hipError_t launch_cabs(int dtype, const void* z, size_t count, void* out, hipStream_t s);
 hipError_t launch_props(int dtype, const void* jac, size_t npx, int add_identity, double refangle, double refscale,
                         int diff, void* out, hipStream_t s);
 
-// f-4: one IRLS pass of the Huber plane fit; ten sums at scratch + 2560 (scratch >= 2570 doubles)
+// f-4: one IRLS pass of the Huber plane fit; ten sums at scratch + huber_sums_offset() (scratch: 10 more doubles than that)
+int huber_sums_offset();
 hipError_t launch_huber_moments(int dtype, const void* img, int n0, int n1, const double* coef, double cx, double cy,
                                 double sx, double sy, double* scratch, hipStream_t s);
 

@@ -163,7 +163,7 @@ struct gpa_plan {
   void* d_sf = nullptr;           // [K][n0][n1] complex, grown on demand (a4 gradient path)
   size_t sf_bytes = 0;
   void* d_grad = nullptr;         // n0 x n1 x 2 staging for the host-pointer a4 call
-  double* d_scratch = nullptr;    // 4096 doubles
+  double* d_scratch = nullptr;    // 16384 doubles (mean partials, Gaussian weights at + 1024, Huber partials: 10 x 1024 + 10)
   void* d_aux0 = nullptr;         // n0 / n1 complex doubles: border-difference spectra (a9), Gaussian factors (f-4);
   void* d_aux1 = nullptr;         // NOT the sweep's compensation tables, which stay valid across those calls
   void* d_lockin = nullptr;       // [P<=max_peaks][n0][n1] complex (staging / fused driver)
@@ -197,6 +197,8 @@ struct gpa_plan {
   GaussTab gft[2][2];
   unsigned gft_clock = 0;
   double* d_peakws = nullptr;     // f-3: min / max partials (2 x 2048), threshold, candidate counter
+  void* d_peaksmooth = nullptr;   // f-3: the smoothed spectrum of the last gpa_find_peaks call, n0 x n1 reals (gpa_find_peaks_again)
+  bool peaks_smooth_valid = false;
   WarpWs warp{};                  // scratch + taps of the Lawler-Fujita kernels (gpa_warp.hip), grown on first use
   // timing
   hipEvent_t ev0 = nullptr, ev1 = nullptr;
@@ -267,6 +269,17 @@ int plan_build(gpa_plan* p);
 int upload_twiddles(gpa_plan* p, void* dst, int L);
 
 // installs the plan's profiler on the calling thread for the lifetime of the object (while gpa_set_profiling is on)
+// the same, only when `own` (an entry point that may also be called from inside another profiled one)
+struct ProfInstallIf {
+  bool own;
+  ProfInstallIf(gpa_plan* p, bool own_) : own(own_ && p->profiling) {
+    if (!own) return;
+    if (!p->kprof) p->kprof = new KernelProfiler();
+    p->kprof->n = 0;
+    g_kprof = p->kprof;
+  }
+  ~ProfInstallIf() { if (own) g_kprof = nullptr; }
+};
 struct ProfInstall {
   explicit ProfInstall(gpa_plan* p) {
     if (!p->profiling) return;

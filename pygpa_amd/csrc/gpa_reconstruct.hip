@@ -567,6 +567,27 @@ __global__ __launch_bounds__(256) void props_kernel(const Quad<T>* __restrict__ 
   out[3 * npx + o] = s0 / s1;
 }
 
+// |z| of a complex array (np.abs of the lock-ins: the weights of phasegradient2J), two values per thread
+template <class T>
+__global__ __launch_bounds__(256) void cabs_kernel(const cpx<T>* __restrict__ z, size_t count, T* __restrict__ out) {
+  const size_t i = 2 * ((size_t)blockIdx.x * 256 + threadIdx.x);
+  if (i + 1 < count) {
+    struct alignas(2 * sizeof(cpx<T>)) Two { cpx<T> a, b; };
+    struct alignas(2 * sizeof(T)) Out { T a, b; };
+    const Two v = *reinterpret_cast<const Two*>(z + i);
+    *reinterpret_cast<Out*>(out + i) = Out{(T)hypot(v.a.x, v.a.y), (T)hypot(v.b.x, v.b.y)};
+  } else if (i < count) {
+    out[i] = (T)hypot(z[i].x, z[i].y);
+  }
+}
+hipError_t launch_cabs(int dtype, const void* z, size_t count, void* out, hipStream_t s) {
+  const unsigned grid = (unsigned)((count / 2 + 256) / 256);
+  GPA_PROF("lockin_abs_kernel", s);
+  if (dtype == 0) cabs_kernel<float><<<grid, 256, 0, s>>>((const cpx<float>*)z, count, (float*)out);
+  else cabs_kernel<double><<<grid, 256, 0, s>>>((const cpx<double>*)z, count, (double*)out);
+  return hipGetLastError();
+}
+
 hipError_t launch_jacobian(int dtype, const void* grads, const void* w, const double* kmat, int P, size_t npx,
                            double nmperpixel, const double* dks, void* J, hipStream_t s) {
   if (P > MAXP || P < 2) return hipErrorInvalidValue;
@@ -574,6 +595,7 @@ hipError_t launch_jacobian(int dtype, const void* grads, const void* w, const do
   GradShift shift{};
   shift.on = dks != nullptr;
   for (int i = 0; dks && i < 2 * P; ++i) shift.v[i] = 6.283185307179586476925 * dks[i];
+  GPA_PROF("jacobian_kernel", s);
   if (dtype == 0)
     jacobian_kernel<float><<<grid, 256, 0, s>>>((const Pair2<float>*)grads, (const float*)w, kmat, P, npx,
                                                 (float)(1.0 / nmperpixel), shift, (Quad<float>*)J);
@@ -586,6 +608,7 @@ hipError_t launch_jacobian(int dtype, const void* grads, const void* w, const do
 hipError_t launch_props(int dtype, const void* jac, size_t npx, int add_identity, double refangle, double refscale,
                         int diff, void* out, hipStream_t s) {
   const unsigned grid = (unsigned)((npx + 255) / 256);
+  GPA_PROF("props_kernel", s);
   if (dtype == 0)
     props_kernel<float><<<grid, 256, 0, s>>>((const Quad<float>*)jac, npx, add_identity ? 1.f : 0.f, (float)refangle,
                                              (float)refscale, diff, (float*)out);
@@ -602,6 +625,9 @@ hipError_t launch_props(int dtype, const void* jac, size_t npx, int add_identity
 // One pass over the image per iteration accumulates the weighted normal equations in centred, scaled
 // coordinates (u = (x - cx) / sx, v = (y - cy) / sy) in double; the 3x3 solve is the host's.
 // sums: 0..5 = w*(uu, uv, u, vv, v, 1), 6..8 = w*(u z, v z, z), 9 = cost = sum 0.5 rho
+// (round 6: workgroup b takes rows b, b + grid, ...: the row index and its coordinate are wave-uniform, no 64-bit division per
+//  pixel, up to 1024 workgroups instead of 256 -- 124 -> ~20 us per pass at 4096^2; the sums keep a fixed order)
+constexpr int HUBER_PARTS = 1024;
 template <class T>
 __global__ __launch_bounds__(256) void huber_moments_kernel(const T* __restrict__ img, int n0, int n1, double a0,
                                                            double a1, double a2, double cx, double cy, double isx,
@@ -609,15 +635,20 @@ __global__ __launch_bounds__(256) void huber_moments_kernel(const T* __restrict_
   double acc[10];
 #pragma unroll
   for (int k = 0; k < 10; ++k) acc[k] = 0.0;
-  const size_t npx = (size_t)n0 * n1;
-  for (size_t o = (size_t)blockIdx.x * 256 + threadIdx.x; o < npx; o += (size_t)gridDim.x * 256) {
-    const int x = (int)(o / n1), y = (int)(o - (size_t)x * n1);
-    const double u = (x - cx) * isx, v = (y - cy) * isy, z = (double)img[o];
-    const double r = z - (a0 * u + a1 * v + a2), ar = fabs(r);
-    const double w = ar <= 1.0 ? 1.0 : 1.0 / ar;
-    acc[0] += w * u * u; acc[1] += w * u * v; acc[2] += w * u; acc[3] += w * v * v; acc[4] += w * v; acc[5] += w;
-    acc[6] += w * u * z; acc[7] += w * v * z; acc[8] += w * z;
-    acc[9] += ar <= 1.0 ? 0.5 * r * r : ar - 0.5;
+  for (int x = blockIdx.x; x < n0; x += gridDim.x) {
+    const double u = (x - cx) * isx, pu = a0 * u + a2;
+    const T* row = img + (size_t)x * n1;
+    double su = 0.0, sw = 0.0, suz = 0.0;   // sums that carry the row's constant u: multiplied in once per row
+    for (int y = threadIdx.x; y < n1; y += 256) {
+      const double v = (y - cy) * isy, z = (double)row[y];
+      const double r = z - (a1 * v + pu), ar = fabs(r);
+      const double w = ar <= 1.0 ? 1.0 : 1.0 / ar;
+      sw += w; su += w * v; suz += w * z;
+      acc[3] += w * v * v; acc[7] += w * v * z;
+      acc[9] += ar <= 1.0 ? 0.5 * r * r : ar - 0.5;
+    }
+    acc[0] += sw * u * u; acc[1] += su * u; acc[2] += sw * u; acc[4] += su; acc[5] += sw;
+    acc[6] += suz * u; acc[8] += suz;
   }
   __shared__ double sh[256];
   for (int k = 0; k < 10; ++k) {
@@ -649,17 +680,19 @@ __global__ __launch_bounds__(256) void huber_final_kernel(const double* __restri
   }
 }
 
-// scratch: >= 10 * 256 + 10 doubles; the ten sums land at scratch + 2560
+// scratch: >= 10 * HUBER_PARTS + 10 doubles; the ten sums land at scratch + 10 * HUBER_PARTS
+int huber_sums_offset() { return 10 * HUBER_PARTS; }
 hipError_t launch_huber_moments(int dtype, const void* img, int n0, int n1, const double* coef, double cx, double cy,
                                 double sx, double sy, double* scratch, hipStream_t s) {
-  const int nparts = 256;
+  const int nparts = n0 < HUBER_PARTS ? n0 : HUBER_PARTS;
+  GPA_PROF("huber_moments_kernels", s);
   if (dtype == 0)
     huber_moments_kernel<float><<<nparts, 256, 0, s>>>((const float*)img, n0, n1, coef[0], coef[1], coef[2], cx, cy,
                                                        1.0 / sx, 1.0 / sy, scratch);
   else
     huber_moments_kernel<double><<<nparts, 256, 0, s>>>((const double*)img, n0, n1, coef[0], coef[1], coef[2], cx, cy,
                                                         1.0 / sx, 1.0 / sy, scratch);
-  huber_final_kernel<<<1, 256, 0, s>>>(scratch, nparts, scratch + 10 * nparts);
+  huber_final_kernel<<<1, 256, 0, s>>>(scratch, nparts, scratch + 10 * HUBER_PARTS);
   return hipGetLastError();
 }
 

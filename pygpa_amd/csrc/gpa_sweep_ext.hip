@@ -55,6 +55,7 @@ __global__ __launch_bounds__(256) void phasegrad_kernel(const T* __restrict__ ps
 hipError_t launch_phasegrad(int dtype, const void* psi, int K, const int32_t* kidx, int n0, int n1, const double* kl,
                             const double* kr, int mode, void* grad, hipStream_t s) {
   dim3 grid((n1 + 255) / 256, n0);
+  GPA_PROF("phasegrad_kernel", s);
   if (dtype == 0)
     phasegrad_kernel<float><<<grid, 256, 0, s>>>((const float*)psi, K, kidx, n0, n1, kl, kr, mode, (float*)grad);
   else

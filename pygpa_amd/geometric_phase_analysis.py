@@ -241,15 +241,16 @@ def select_closest_to_triangle(ks):
     return ks[list(best)]
 
 
-def _peak_candidates(plan, image, sigma, dog, threshold, pix_norm_range):
-    """One evaluation of the array work of extract_primary_ks (device: gpa_find_peaks) plus the ring
-    selection and the +k / -k merge: (all_ks, pixel radii of the selected peaks, their heights)."""
-    peaks, heights = plan.find_peaks(image, sigma, 50.0 if dog else 0.0, threshold)
-    offset = peaks - np.array(image.shape) // 2
+def _peak_candidates(find, shape, sigma, dog, threshold, pix_norm_range):
+    """One evaluation of the array work of extract_primary_ks (device: gpa_find_peaks; `find(sigma, dog_sigma,
+    threshold)` -> (peaks, heights)) plus the ring selection and the +k / -k merge: (all_ks, pixel radii of the
+    selected peaks, their heights)."""
+    peaks, heights = find(sigma, 50.0 if dog else 0.0, threshold)
+    offset = peaks - np.array(shape) // 2
     radius = np.sqrt((offset * offset).sum(axis=1))
     ring = (radius > pix_norm_range[0]) & (radius < pix_norm_range[1])
     peaks, radius, heights = peaks[ring], radius[ring], heights[ring]
-    freq = [fftbounds(n) for n in image.shape]
+    freq = [fftbounds(n) for n in shape]
     ks = np.stack([freq[0][peaks[:, 0]], freq[1][peaks[:, 1]]], axis=1) if len(peaks) else np.zeros((0, 2))
     return remove_negative_duplicates(ks), radius, heights
 
@@ -285,9 +286,36 @@ def extract_primary_ks(image, plot=False, threshold=0.7, pix_norm_range=(2, 200)
     triangle, fewer are returned as found.  ``plot`` only enables progress messages (no figure)."""
     image = np.asarray(image)
     plan = _plan(image, 1, dtype)
+    return _primary_ks(_reusing(plan, lambda s, d, t: plan.find_peaks(image, s, d, t)), image.shape, plot, threshold,
+                       pix_norm_range, sigma, DoG)
+
+
+def extract_primary_ks_dev(plan, image_ptr, plot=False, threshold=0.7, pix_norm_range=(2, 200), sigma=1, DoG=True):
+    """extract_primary_ks of an image that is resident on the device (`plan`: a _lib.Plan of its shape, `image_ptr`: device
+    pointer to n0 x n1 reals of the plan's dtype; not modified): only the candidate lists -- a handful of (row, column,
+    height) entries per evaluation -- come to the host."""
+    return _primary_ks(_reusing(plan, lambda s, d, t: plan.find_peaks_dev(image_ptr, s, d, t)), plan.shape, plot, threshold,
+                       pix_norm_range, sigma, DoG)
+
+
+def _reusing(plan, find):
+    """`find` for one image: an evaluation that differs from the previous one in the threshold only takes the smoothed spectrum
+    the plan still holds (gpa_find_peaks_again: one threshold + maxima pass instead of transforms and filters)"""
+    last = []
+
+    def evaluate(sigma, dog_sigma, threshold):
+        if last == [sigma, dog_sigma] and hasattr(plan, 'find_peaks_again'):
+            return plan.find_peaks_again(threshold)
+        out = find(sigma, dog_sigma, threshold)
+        last[:] = [sigma, dog_sigma]
+        return out
+    return evaluate
+
+
+def _primary_ks(find, shape, plot, threshold, pix_norm_range, sigma, DoG):
     dog = bool(DoG)
     while True:
-        all_ks, radius, heights = _peak_candidates(plan, image, sigma, dog, threshold, pix_norm_range)
+        all_ks, radius, heights = _peak_candidates(find, shape, sigma, dog, threshold, pix_norm_range)
         if len(all_ks) >= 3:
             break
         step = _relaxed_parameters(len(all_ks), radius, heights, threshold, sigma)

@@ -241,3 +241,23 @@ def test_smoothed_spectrum_fft_filter_vs_oracle(shape, sigma, dog, dtype, gpa_op
     _, _, full = plan.find_peaks(img, sigma, dog, 0.05, want_smooth=True)
     assert rel(full, ref) < tol and rel(smooth, full) < tol
     plan.close()
+
+
+@pytest.mark.parametrize('dtype', DTYPES)
+def test_find_peaks_again_equals_a_fresh_evaluation(dtype):
+    """gpa_find_peaks_again (the threshold relaxation of extract_primary_ks without recomputing the spectrum) returns exactly
+    what a full evaluation at that threshold returns; on the device image as on the host image"""
+    shape = (300, 256)
+    img = hex_moire(shape, hex_kvecs(0.12, 17.0), noise=0.5, seed=9)
+    plan = _lib.Plan(shape, 1, dtype)
+    c0, v0 = plan.find_peaks(img, 1.0, 50.0, 0.7)
+    for thr in (0.35, 0.05, 0.9):
+        ca, va = plan.find_peaks_again(thr)
+        cf, vf = _lib.Plan(shape, 1, dtype).find_peaks(img, 1.0, 50.0, thr)
+        assert np.array_equal(ca, cf) and np.array_equal(va, vf)
+    buf = _lib.DeviceBuffer(img.size * np.dtype(dtype).itemsize)
+    buf.upload(np.ascontiguousarray(img, dtype=dtype))
+    cd, vd = plan.find_peaks_dev(buf.ptr, 1.0, 50.0, 0.7)
+    assert np.array_equal(cd, c0) and np.array_equal(vd, v0)
+    buf.free()
+    plan.close()
