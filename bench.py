@@ -535,7 +535,7 @@ def config5_single_gpu(knx, kny, np_dt, kmax, n=16384, window=2048, reps=2):
         if record:
             st['global_unwrap'] = time.perf_counter() - t
             t = time.perf_counter()
-        plan_g.undistort_image_dev(d_img.ptr, d_u.ptr, d_rec.ptr, uinv_ptr=d_uinv.ptr)
+        plan_g.undistort_image_dev(d_img.ptr, d_u.ptr, d_rec.ptr, uinv_ptr=d_uinv.ptr, scale=-1.0)   # (extracted field = -displacement)
         plan_g.sync()
         if record:
             st['lawler_fujita'] = time.perf_counter() - t
@@ -548,7 +548,7 @@ def config5_single_gpu(knx, kny, np_dt, kmax, n=16384, window=2048, reps=2):
     dt = (time.perf_counter() - t0_) / reps
     one_image(record=True)
     plan_g.set_profiling(True)
-    plan_g.undistort_image_dev(d_img.ptr, d_u.ptr, d_rec.ptr, uinv_ptr=d_uinv.ptr)
+    plan_g.undistort_image_dev(d_img.ptr, d_u.ptr, d_rec.ptr, uinv_ptr=d_uinv.ptr, scale=-1.0)
     prof = plan_g.last_kernel_profile()
     plan_g.set_profiling(False)
     # compulsory HBM bytes of the Lawler-Fujita kernels per launch: pad / FIR passes read + write one padded
@@ -648,7 +648,8 @@ def pipeline_end_to_end(n, knx, kny, np_dt, kmax, reps=3):
         plan.extract_displacement_field_dev(bufs['img'].ptr, ks, klists, sigma, 2 * sigma, kmax, bufs['u'].ptr)
 
     def stage_undistort():
-        plan.undistort_image_dev(bufs['img'].ptr, bufs['u'].ptr, bufs['rec'].ptr, uinv_ptr=bufs['uinv'].ptr)
+        # (the extracted field is MINUS the displacement, tests/test_geometric_phase_analysis.py:63: undistort with -u)
+        plan.undistort_image_dev(bufs['img'].ptr, bufs['u'].ptr, bufs['rec'].ptr, uinv_ptr=bufs['uinv'].ptr, scale=-1.0)
 
     def stage_props(profile=None):
         def note():

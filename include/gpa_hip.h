@@ -298,6 +298,11 @@ int gpa_invert_u_mode_dev(gpa_plan* plan, const void* u_dev, double scale, int i
                           const int* rects, int nrect, void* out_dev);
 int gpa_undistort_image_dev(gpa_plan* plan, const void* deformed_dev, const void* u_dev, const int* rects, int nrect,
                             void* uinv_dev, void* out_dev);
+/* undistort_image(deformed, scale * u) on device pointers: scale = -1 undistorts with the field exactly as
+ * extract_displacement_field returns it (the reference's tests recover the true displacement as MINUS that field,
+ * tests/test_geometric_phase_analysis.py:63, and undistort with the true one, :76).                                   */
+int gpa_undistort_image_scaled_dev(gpa_plan* plan, const void* deformed_dev, const void* u_dev, double scale,
+                                   const int* rects, int nrect, void* uinv_dev, void* out_dev);
 
 /* f-2 -- phase gradient -> Jacobian -> lattice properties.
  * gpa_phasegradient2J: J[n,m,i,j] = (per-pixel weighted least squares of grads[:,n,m,j] against

@@ -509,18 +509,56 @@ def reconstruct_u_inv(kvecs, b, weights=None):
 # --------------------------------------------------------------------------
 # f-1: Lawler-Fujita undistortion
 # --------------------------------------------------------------------------
-def invert_u_overlap(us, iters=35, edge=0, mode='nearest'):
+class _Resampler:
+    """scipy.ndimage.map_coordinates(field, coords, order=3, mode=mode[, cval]) for MANY coordinate sets of ONE field: the
+    cubic-spline prefilter of the field runs once instead of once per call.  map_coordinates itself is
+    `padded, npad = _prepad_for_spline_filter(input, mode, cval); filtered = spline_filter(padded, 3, float64, mode);
+    _nd_image.geometric_transform(filtered, None, coords, None, None, output, 3, mode_code, cval, npad, None, None)`
+    (scipy/ndimage/_interpolation.py); this class keeps `filtered` and repeats the last call -- the same C routine with the
+    same arguments, so the numbers are map_coordinates' bit for bit (tests/test_oracle_golden.py holds it to that).  If
+    SciPy's private layout ever changes, `fast` is False and every sample is a plain map_coordinates call."""
+
+    def __init__(self, field, mode):
+        import scipy.ndimage as ndi
+        self.field = np.asarray(field, dtype=np.float64)
+        self.mode = mode
+        self.fast = False
+        try:
+            from scipy.ndimage import _interpolation as _ip, _nd_image, _ni_support
+            padded, self.npad = _ip._prepad_for_spline_filter(self.field, mode, 0.0)
+            self.filtered = ndi.spline_filter(padded, 3, output=np.float64, mode=mode)
+            self.code = _ni_support._extend_mode_to_code(mode)
+            self._gt = _nd_image.geometric_transform
+            self.fast = True
+        except Exception:
+            pass
+
+    def __call__(self, coords, cval=0.0):
+        import scipy.ndimage as ndi
+        coords = np.asarray(coords, dtype=np.float64)
+        if not self.fast:
+            return ndi.map_coordinates(self.field, coords, mode=self.mode, cval=cval)
+        out = np.zeros(coords.shape[1:], dtype=np.float64)
+        self._gt(self.filtered, None, coords, None, None, out, 3, self.code, cval, self.npad, None, None)
+        return out
+
+
+def invert_u_overlap(us, iters=35, edge=0, mode='nearest', rows=None):
     """Fixed-point inversion of a displacement field: u_it(r) <- u(r + u_it(r)), `iters` rounds of
     cubic-spline resampling (scipy.ndimage.map_coordinates, order 3) on the grid extended by
     `edge` pixels; the last round is called with cval=nan.  Follows invert_u_overlap
-    (gpa.py:262-300)."""
-    import scipy.ndimage as ndi
+    (gpa.py:262-300).
+    rows (test aid for large fields): a 1-D array of row indices of the output grid; the iterate of a pixel depends on the
+    field alone, never on the other pixels' iterates, so those rows come out exactly as in the full call (result: (2, len(rows), M))."""
     us = np.asarray(us, dtype=np.float64)
     xx, yy = np.mgrid[-edge:us.shape[1] + edge, -edge:us.shape[2] + edge]
-    u_it = [ndi.map_coordinates(u, [xx, yy], mode=mode) for u in us]
+    if rows is not None:
+        xx, yy = xx[np.asarray(rows)], yy[np.asarray(rows)]
+    sample = [_Resampler(u, mode) for u in us]
+    u_it = [f([xx, yy]) for f in sample]
     for _ in range(iters - 1):
-        u_it = [ndi.map_coordinates(u, [xx + u_it[0], yy + u_it[1]], mode=mode) for u in us]
-    u_it = [ndi.map_coordinates(u, [xx + u_it[0], yy + u_it[1]], mode=mode, cval=np.nan) for u in us]
+        u_it = [f([xx + u_it[0], yy + u_it[1]]) for f in sample]
+    u_it = [f([xx + u_it[0], yy + u_it[1]], cval=np.nan) for f in sample]
     return np.stack(u_it)
 
 
@@ -536,14 +574,16 @@ def invert_u(us, iters=35, edge=0, mode='nearest'):
     return np.stack(u_it)
 
 
-def undistort_image(deformed, u):
+def undistort_image(deformed, u, rows=None):
     """Resample `deformed` at r + u_inv(r), u_inv = invert_u_overlap(-u); the resampling uses
     map_coordinates' defaults (order 3, mode='constant', cval=0).  Follows undistort_image
-    (gpa.py:935-974)."""
+    (gpa.py:935-974).  rows: as in invert_u_overlap (those rows of the result)."""
     import scipy.ndimage as ndi
     u = np.asarray(u, dtype=np.float64)
-    u_inv = invert_u_overlap(-u)
+    u_inv = invert_u_overlap(-u, rows=rows)
     xx, yy = np.mgrid[:u.shape[1], :u.shape[2]]
+    if rows is not None:
+        xx, yy = xx[np.asarray(rows)], yy[np.asarray(rows)]
     return ndi.map_coordinates(np.asarray(deformed, dtype=np.float64), [xx + u_inv[0], yy + u_inv[1]])
 
 

@@ -43,6 +43,7 @@ SIGNATURES = {
     'gpa_invert_u_mode': (_i, [_vp, _vp, _i, _i, _i, _i, _vp]),
     'gpa_invert_u_mode_dev': (_i, [_vp, _vp, _d, _i, _i, _i, _i, _vp, _i, _vp]),
     'gpa_undistort_image_dev': (_i, [_vp, _vp, _vp, _vp, _i, _vp, _vp]),
+    'gpa_undistort_image_scaled_dev': (_i, [_vp, _vp, _vp, _d, _vp, _i, _vp, _vp]),
     'gpa_reconstruct_grad': (_i, [_vp, _vp, _vp, _i, _i, _vp, _vp, _vp]),
     'gpa_reconstruct_grad_dev': (_i, [_vp, _vp, _vp, _i, _i, _vp, _vp, _vp]),
     'gpa_weighted_lstsq': (_i, [_vp, _vp, _vp, _vp, _i, _vp]),
@@ -362,12 +363,13 @@ class Plan:
         check(self.lib.gpa_invert_u_mode_dev(self.handle, _ptr(int(u_ptr)), float(scale), int(iters), int(edge), int(bool(overlap)),
                                              self._WARP_MODES[mode], arr, n, _ptr(int(out_ptr))), 'gpa_invert_u_mode_dev')
 
-    def undistort_image_dev(self, deformed_ptr, u_ptr, out_ptr, uinv_ptr=None, rects=None):
-        """undistort_image on device pointers, enqueued on the plan's stream (no host sync); uinv_ptr (2 x n0 x n1) receives
-        u_inv = invert_u_overlap(-u); rects = (r0, c0, h, w) or a list: only those windows of the outputs are computed"""
+    def undistort_image_dev(self, deformed_ptr, u_ptr, out_ptr, uinv_ptr=None, rects=None, scale=1.0):
+        """undistort_image(deformed, scale * u) on device pointers, enqueued on the plan's stream (no host sync); uinv_ptr
+        (2 x n0 x n1) receives u_inv = invert_u_overlap(-scale * u); rects = (r0, c0, h, w) or a list: only those windows of the
+        outputs are computed.  scale = -1: u is the field as extract_displacement_field returns it (minus the displacement)"""
         arr, n = self._rects(rects)
-        check(self.lib.gpa_undistort_image_dev(self.handle, _ptr(int(deformed_ptr)), _ptr(int(u_ptr)), arr, n,
-                                               _ptr(None if uinv_ptr is None else int(uinv_ptr)), _ptr(int(out_ptr))),
+        check(self.lib.gpa_undistort_image_scaled_dev(self.handle, _ptr(int(deformed_ptr)), _ptr(int(u_ptr)), float(scale), arr, n,
+                                                      _ptr(None if uinv_ptr is None else int(uinv_ptr)), _ptr(int(out_ptr))),
               'gpa_undistort_image_dev')
 
     def phasegradient2J(self, kvecs, grads, weights, nmperpixel, dks=None):

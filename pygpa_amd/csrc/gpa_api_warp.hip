@@ -33,12 +33,20 @@ int gpa_invert_u_mode_dev(gpa_plan* p, const void* u_dev, double scale, int iter
 // edge) into uinv_dev (2 x n0 x n1; null: plan scratch), then deformed resampled at r + u_inv(r) (order 3, 'constant')
 int gpa_undistort_image_dev(gpa_plan* p, const void* deformed_dev, const void* u_dev, const int* rects, int nrect,
                             void* uinv_dev, void* out_dev) {
+  return gpa_undistort_image_scaled_dev(p, deformed_dev, u_dev, 1.0, rects, nrect, uinv_dev, out_dev);
+}
+
+// undistort_image(deformed, scale * u).  The reference's tests recover the true displacement as MINUS the extracted field
+// (tests/test_geometric_phase_analysis.py:63) and undistort with the true one (:76): a caller that keeps the extracted field on
+// the device undistorts with scale = -1 instead of negating 2 n0 n1 values first.
+int gpa_undistort_image_scaled_dev(gpa_plan* p, const void* deformed_dev, const void* u_dev, double scale, const int* rects,
+                                   int nrect, void* uinv_dev, void* out_dev) {
   if (!p || !deformed_dev || !u_dev || !out_dev) return fail(GPA_ERR_ARG, "gpa_undistort_image_dev: null argument");
   if (nrect < 0 || (nrect > 0 && !rects)) return fail(GPA_ERR_ARG, "gpa_undistort_image_dev: nrect windows need rects");
   HIP_TRY(hipSetDevice(p->device));
   ProfInstall prof(p);
   void* uinv = uinv_dev ? uinv_dev : p->d_dudx;   // (2 planes of n0 x n1 fit)
-  HIP_TRY(warp_invert_u(p->dtype, u_dev, p->n0, p->n1, -1.0, 35, 0, 0, uinv, p->stream, 0, 1, &p->warp, rects, nrect));
+  HIP_TRY(warp_invert_u(p->dtype, u_dev, p->n0, p->n1, -scale, 35, 0, 0, uinv, p->stream, 0, 1, &p->warp, rects, nrect));
   HIP_TRY(warp_image(p->dtype, deformed_dev, uinv, p->n0, p->n1, out_dev, p->stream, &p->warp, rects, nrect));
   if (p->profiling) { HIP_TRY(hipStreamSynchronize(p->stream)); collect_kernel_profile(p); }
   return GPA_OK;

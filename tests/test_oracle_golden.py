@@ -271,3 +271,29 @@ def test_config1_512_reference_outputs(golden):
     lock = np.stack([q['lockin'] for q in parts['gs']])
     assert np.abs(lock[sl] - g['k1_lockin']).max() < 1e-13
     assert np.allclose([u.sum(), (u ** 2).sum()], g['k1_u_moments'], rtol=1e-10)
+
+
+def test_f1_oracle_resampler_is_map_coordinates_bit_for_bit():
+    """oracle._Resampler (one spline prefilter per field instead of one per round; the GPU tests at 4096^2 need it) repeats
+    map_coordinates' own last call: bit-identical to the literal sequence of map_coordinates calls of
+    geometric_phase_analysis.py:262-300, for both modes, with and without the overlap edge, and on a subset of rows"""
+    import scipy.ndimage as ndi
+    from pygpa_amd.synthetic import gaussian_bump_displacement
+    us = gaussian_bump_displacement((96, 120)) * 3 + 0.1 * np.random.default_rng(3).normal(size=(2, 96, 120))
+
+    def literal(us, iters=35, edge=0, mode='nearest'):
+        xx, yy = np.mgrid[-edge:us.shape[1] + edge, -edge:us.shape[2] + edge]
+        u_it = [ndi.map_coordinates(u, [xx, yy], mode=mode) for u in us]
+        for _ in range(iters - 1):
+            u_it = [ndi.map_coordinates(u, [xx + u_it[0], yy + u_it[1]], mode=mode) for u in us]
+        u_it = [ndi.map_coordinates(u, [xx + u_it[0], yy + u_it[1]], mode=mode, cval=np.nan) for u in us]
+        return np.stack(u_it)
+
+    assert orc._Resampler(us[0], 'nearest').fast, 'SciPy moved its private entry points: the oracle falls back to plain calls'
+    for mode in ('nearest', 'constant'):
+        for edge in (0, 5):
+            assert np.array_equal(orc.invert_u_overlap(us, edge=edge, mode=mode), literal(us, edge=edge, mode=mode), equal_nan=True)
+    rows = np.r_[2:9, 40:71]
+    assert np.array_equal(orc.invert_u_overlap(us, rows=rows), literal(us)[:, rows], equal_nan=True)
+    img = np.random.default_rng(4).normal(size=us.shape[1:])
+    assert np.array_equal(orc.undistort_image(img, us, rows=rows), orc.undistort_image(img, us)[rows])

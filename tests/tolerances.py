@@ -24,3 +24,12 @@ F32_C3 = dict(rms_px=6.6e-6, max_px=0.0181)                   # configs[2], 4096
 # reference's own outputs (tests/golden/config1_512.npz); |u| up to 19 px, phases up to ~20 rad
 C1_F64 = dict(corr=1e-12, prs=1e-8, u=1e-9)
 C1_F32 = dict(corr=2e-7, prs_rel=2e-5, u_px=2e-3, lockin_rel=2e-6)
+# configs[3]'s image (8192^2, 3 x 16, |u| up to 310 px) through the WHOLE-IMAGE driver against the oracle at full size
+# (round 6, tests/test_gpu_pins.py): measured rms 8.7e-6 px, max 0.0041 px, 2 winner flips in 67 M pixels (3e-8)
+F32_C4 = dict(rms_px=1.8e-5, max_px=0.0083, kidx_frac=2.5e-7)
+# Lawler-Fujita at the benchmark's displacement (4096^2, |u| up to 155 px) against the oracle: u_inv in px, the undistorted
+# image relative to its maximum; measured f64 2.7e-13 / 2.4e-13, f32 1.2e-4 / 8.8e-5
+LF_4096 = {'float64': dict(u_inv_px=1e-9, rec_rel=1e-9), 'float32': dict(u_inv_px=2.5e-4, rec_rel=1.8e-4)}
+# ... and at 16384^2 with |u| up to 621 px in f32 against the equation that defines the inverse: sample coordinates up to
+# 16384 carry an f32 ulp of 9.8e-4 px; measured residual 7.6e-4 px, reconstruction within 0.014 of a lattice of amplitude 3
+LF_16384_F32 = dict(residual_px=2e-3, rec_abs=0.03)
