@@ -823,6 +823,10 @@ def multi_gpu(args, world, rank, local_rank):
         dist.init_process_group('nccl', rank=rank, world_size=world, device_id=torch.device('cuda', dev_index))
     else:
         dist.init_process_group(args.backend, rank=rank, world_size=world)
+    # the line says n_gpus = N only if the backend's process group really has N ranks
+    if dist.get_world_size() != args.gpus or dist.get_world_size() != world:
+        raise SystemExit('bench.py --gpus %d: the %s process group reports %d ranks (WORLD_SIZE=%d)'
+                         % (args.gpus, args.backend, dist.get_world_size(), world))
     from pygpa_amd import distributed as D
     from pygpa_amd import _lib
     from pygpa_amd.synthetic import hex_kvecs, explicit_klists
@@ -935,6 +939,7 @@ def multi_gpu(args, world, rank, local_rank):
                        'tile_interior': list(pipe.tshape), 'peaks': P, 'kvectors_per_peak': K,
                        'pixels_per_gpu': shape[0] * shape[1] // world, 'schedule': args.schedule,
                        'unwrap_iters': iters_rep, 'backend': args.backend, 'collectives': coll,
+                       'ranks_in_process_group': dist.get_world_size(), 'parallelism': 'tiles over %d ranks' % dist.get_world_size(),
                        'stage_ms_per_image_rank0': stages},
             'ranks': {'world_size_reported_by_backend': dist.get_world_size(), 'backend': dist.get_backend(),
                       'rccl_version': list(torch.cuda.nccl.version()) if args.backend == 'nccl' else None,

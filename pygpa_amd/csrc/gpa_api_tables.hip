@@ -226,8 +226,19 @@ int shared_prepare(gpa_plan* p, int P, int K) {
   // position (a stable order: duplicates of a k-vector keep the list's order, so "first maximum" still holds for
   // them; the reported kidx is the original list position).  Two DIFFERENT candidates whose amplitudes agree bit for
   // bit at a pixel may now resolve the other way -- the amplitude ties the tests already allow for.
+  // One kind of tie between different candidates is structural, not accidental: k-vectors that differ by WHOLE cycles per pixel
+  // sample the same carrier on the integer grid, and where the products k x are exact (dyadic k) the device's lock-ins are
+  // equal bit for bit at every pixel.  A peak whose list holds such a pair keeps the LIST order, so that the earlier of
+  // the two wins everywhere as the reference's rule says (round 6; tests/test_gpu_shared_passb.py::test_aliased_candidates_*).
   std::vector<int> order((size_t)B);
   for (int pp = 0; pp < P; ++pp) {
+    bool aliased = false;
+    for (int a = 0; a < K && !aliased; ++a)
+      for (int b2 = a + 1; b2 < K && !aliased; ++b2) {
+        const double *ka = &p->staged_kl[2 * ((size_t)pp * K + a)], *kb = &p->staged_kl[2 * ((size_t)pp * K + b2)];
+        const bool same = ka[0] == kb[0] && ka[1] == kb[1];
+        aliased = !same && ka[0] - floor(ka[0]) == kb[0] - floor(kb[0]) && ka[1] - floor(ka[1]) == kb[1] - floor(kb[1]);
+      }
     std::vector<double> d2((size_t)K), pmin;
     std::vector<int> pfirst;
     int nplanes = 0;
@@ -244,7 +255,7 @@ int shared_prepare(gpa_plan* p, int P, int K) {
     }
     std::vector<int> idx((size_t)K);
     for (int k = 0; k < K; ++k) idx[k] = k;
-    if (reorder)
+    if (reorder && !aliased)
       std::stable_sort(idx.begin(), idx.end(), [&](int a, int b2) {
         const int pa = p->staged_planeof[pp * K + a], pb = p->staged_planeof[pp * K + b2];
         if (pa != pb) return pmin[pa] != pmin[pb] ? pmin[pa] < pmin[pb] : pfirst[pa] < pfirst[pb];

@@ -24,7 +24,11 @@
 
 namespace gpa {
 
-static hipError_t run_pcg(Impl* w, const void* a, const void* b, const void* weight, bool from_psi, int kmax, double eps,
+static __global__ void set_stall_limit_kernel(double* scal, int nprob, double limit) {
+  for (int pb = threadIdx.x; pb < nprob; pb += blockDim.x) scal[(size_t)pb * SCAL_N + SC_STALL_LIMIT] = limit;
+}
+
+hipError_t run_pcg(Impl* w, const void* a, const void* b, const void* weight, bool from_psi, int kmax, double eps,
                           int compat, void* phi, hipStream_t s) {
   const int n0 = w->n0, n1 = w->n1;
   const size_t npx = (size_t)n0 * n1;
@@ -37,6 +41,17 @@ static hipError_t run_pcg(Impl* w, const void* a, const void* b, const void* wei
     const OptVal& mode = opt(OPT_COLSOLVE);   // once per solve: 0 default, 1 tri, 2 fft, 3 stream
     w->col_mode = !mode.set ? 0 : (mode.str[0] == 't' ? 1 : (mode.str[0] == 's' ? 3 : 2));
     w->lat_ok = !opt_set(OPT_NO_LAT);
+  }
+  {
+    // the f32 stagnation guard's count (pcg_breakdown (2)): 2 by default, F32_STALL=<n>, F32_STALL=0 = off
+    const OptVal& st = opt(OPT_F32_STALL);
+    const double limit = !st.set ? PCG_STALL : (st.num > 0.0 ? st.num : 1e300);
+    if (w->stall_limit_dev != limit) {
+      set_stall_limit_kernel<<<1, 64, 0, s>>>(w->scal, w->cap, limit);
+      hipError_t e0 = hipGetLastError();
+      if (e0 != hipSuccess) return e0;
+      w->stall_limit_dev = limit;
+    }
   }
   if (n0 > MAXPART) return hipErrorInvalidValue;   // (one partial sum per image row in the plain scheme)
   int npq = pq_partials(w);   // (the fused row + stencil kernel of small images reports its own count)

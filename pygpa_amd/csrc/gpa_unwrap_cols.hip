@@ -118,7 +118,7 @@ __global__ __launch_bounds__((ColGeom<T, LG, LAT>::THREADS)) void colsolve_kerne
     // every workgroup evaluates the reference's stopping test (phase_unwrap.py:348) on it
     const double tot = block_sum(norm_part, shn);
     double stall;
-    const bool stop = sqrt(tot) < eps * sqrt(norm0) || tot == 0.0 || pcg_breakdown(tot, best, norm0, sizeof(T) == 4, scal[SC_STALL + ((it - 1) & 1)], &stall);
+    const bool stop = sqrt(tot) < eps * sqrt(norm0) || tot == 0.0 || pcg_breakdown(tot, best, norm0, sizeof(T) == 4, scal[SC_STALL + ((it - 1) & 1)], &stall, scal[SC_STALL_LIMIT]);
     if (blockIdx.x == 0 && threadIdx.x == 0) {
       flags[0] = it;                                   // updates completed
       scal[6] = tot;
@@ -305,7 +305,7 @@ __global__ __launch_bounds__(1024) void colsolve_tri_kernel(const T* __restrict_
     const double tot = reduce_partials(part_norm, nnorm, shn);
     const double best = scal[10 + ((it - 1) & 1)];
     double stall;
-    const bool stop = sqrt(tot) < eps * sqrt(scal[5]) || tot == 0.0 || pcg_breakdown(tot, best, scal[5], sizeof(T) == 4, scal[SC_STALL + ((it - 1) & 1)], &stall);
+    const bool stop = sqrt(tot) < eps * sqrt(scal[5]) || tot == 0.0 || pcg_breakdown(tot, best, scal[5], sizeof(T) == 4, scal[SC_STALL + ((it - 1) & 1)], &stall, scal[SC_STALL_LIMIT]);
     if (blockIdx.x == 0 && threadIdx.x == 0) {
       flags[0] = it;
       scal[6] = tot;

@@ -226,7 +226,7 @@ __global__ __launch_bounds__(64 * G) void colstream_scan_kernel(int n0, int n1, 
     // every workgroup of this launch; the other two launches of the solve read the flag
     const double tot = block_sum(norm_part, shn);
     double stall;
-    const bool stop = sqrt(tot) < eps * sqrt(norm0) || tot == 0.0 || pcg_breakdown(tot, best, norm0, f32 != 0, scal[SC_STALL + ((it - 1) & 1)], &stall);
+    const bool stop = sqrt(tot) < eps * sqrt(norm0) || tot == 0.0 || pcg_breakdown(tot, best, norm0, f32 != 0, scal[SC_STALL + ((it - 1) & 1)], &stall, scal[SC_STALL_LIMIT]);
     if (blockIdx.x == 0 && threadIdx.x == 0) {
       flags[0] = it;
       scal[6] = tot;

@@ -44,6 +44,7 @@ struct Impl {
   size_t rsz;
   void *r, *p, *p2, *q, *z;   // p / p2: double-buffered search direction (= ring[0], ring[1])
   int prepared_parts;        // number of partial norms of a prepared r0 (unwrap_enqueue_prepared)
+  double stall_limit_dev;    // what scal[SC_STALL_LIMIT] of every problem holds (0: never written)
   void* ring[10];            // search directions of the last RING iterations (fused path), grown on demand
   int nring;
   void *tw0, *tw1;           // FFT twiddles per axis
@@ -223,13 +224,17 @@ __device__ __forceinline__ bool solve_init(const double* __restrict__ part0, int
 // reference's test (phase_unwrap.py:348) decides alone.  stall_prev / *stall_new: iterations since the last new minimum
 // (scal[SC_STALL + parity], double-buffered like the minimum itself).
 constexpr int SC_STALL = SC_ALPHA + RING_MAX;   // two slots
+// scal[SC_STALL_LIMIT]: the PCG_STALL of guard (2), written by the host (set_stall_limit_kernel) when a solve is enqueued:
+// 2 by default, the library option F32_STALL=<n> sets another count, F32_STALL=0 switches guard (2) off (the reference's loop,
+// phase_unwrap.py:326-349, has no such stop).  solve_init() leaves the slot alone.
+constexpr int SC_STALL_LIMIT = SC_STALL + 2;
 constexpr double PCG_STALL = 2.0;
 __device__ __forceinline__ bool pcg_breakdown(double tot, double best, double norm0, bool f32, double stall_prev,
-                                              double* stall_new) {
+                                              double* stall_new, double stall_limit) {
   const double st = tot < best ? 0.0 : stall_prev + 1.0;
   *stall_new = st;
   if (!(tot == tot) || tot > 1e4 * best) return true;
-  return f32 && best < 1e-10 * norm0 && st >= PCG_STALL;
+  return f32 && best < 1e-10 * norm0 && st >= stall_limit;
 }
 
 // Scalars of the fused power-of-two path (single writer = block 0 of the named kernel;

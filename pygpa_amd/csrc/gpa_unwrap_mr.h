@@ -312,7 +312,7 @@ __global__ __launch_bounds__(MAXT) void mr_colsolve_kernel(
     const double tot = reduce_partials(part_norm, nnorm, sh);
     const double best = scal[10 + ((it - 1) & 1)];
     double stall;
-    const bool stop = sqrt(tot) < eps * sqrt(scal[5]) || tot == 0.0 || pcg_breakdown(tot, best, scal[5], sizeof(T) == 4, scal[SC_STALL + ((it - 1) & 1)], &stall);
+    const bool stop = sqrt(tot) < eps * sqrt(scal[5]) || tot == 0.0 || pcg_breakdown(tot, best, scal[5], sizeof(T) == 4, scal[SC_STALL + ((it - 1) & 1)], &stall, scal[SC_STALL_LIMIT]);
     if (blockIdx.x == 0 && threadIdx.x == 0) {
       flags[0] = it;
       scal[6] = tot;

@@ -153,7 +153,7 @@ __global__ void scal_stop_kernel(const double* part, int nparts, double* scal, i
     // residual has bottomed out at the working precision CG loses conjugacy and the
     // residual grows again; stop instead of iterating into garbage.
     double stall;
-    if (pcg_breakdown(tot, scal[7], scal[5], f32 != 0, scal[SC_STALL], &stall)) flags[1] = 1;
+    if (pcg_breakdown(tot, scal[7], scal[5], f32 != 0, scal[SC_STALL], &stall, scal[SC_STALL_LIMIT])) flags[1] = 1;
     scal[SC_STALL] = stall;
     if (tot < scal[7]) scal[7] = tot;
   }

@@ -269,13 +269,13 @@ class HipTileBackend:
         """torch's current stream waits for component c's plan (its field is about to be sent / handed out)"""
         self.plan_c[c].stream_wait(self._torch_stream())
 
-    def undistort_tiles(self, image, u, out, uinv, rects):
+    def undistort_tiles(self, image, u, out, uinv, rects, scale=1.0):
         """Lawler-Fujita on the global plan (gpa_undistort_image_dev): u_inv = invert_u_overlap(-u) and the deformed image
         resampled at r + u_inv, for the output windows `rects` only (None: everywhere); ordered after torch's stream (the
         broadcast that delivered u), and torch's stream after it"""
         pl = self._plan(0)
         pl.wait_stream(self._torch_stream())
-        pl.undistort_image_dev(image.data_ptr(), u.data_ptr(), out.data_ptr(), uinv_ptr=uinv.data_ptr(), rects=rects)
+        pl.undistort_image_dev(image.data_ptr(), u.data_ptr(), out.data_ptr(), uinv_ptr=uinv.data_ptr(), rects=rects, scale=scale)
         pl.stream_wait(self._torch_stream())
 
     def sync_device(self):
@@ -303,14 +303,21 @@ class TiledPipeline:
     contiguous: what the owner of component c is sent is one slice, and the stitch reads it as it arrives."""
 
     def __init__(self, shape, kvecs, klists, sigma, halo, kmax=10, dtype=np.float32, device=0, group=None,
-                 grid=None, window=None, tiles=None, tshape=None, wshape=None, backend=None):
+                 grid=None, window=None, tiles=None, tshape=None, wshape=None, backend=None, dist_sync=None):
         torch, dist = _dist()
         self.torch, self.dist, self.group = torch, dist, group
+        import os
+        self.dist_sync = int(os.environ.get('GPA_DIST_SYNC', '0') or 0) if dist_sync is None else int(dist_sync)
+        # GPA_DIST_FORCE_COLLECTIVES=1 (test aid): a process group of ONE rank takes every collective of the N > 1 path anyway
+        # (all_reduce, all_gather_into_tensor, gather, broadcast with itself) instead of the single-rank shortcuts -- on a
+        # one-GPU box the RCCL calls and the stream-event ordering around them then really execute
+        self.force_collectives = _initialized() and os.environ.get('GPA_DIST_FORCE_COLLECTIVES', '0') not in ('', '0')
         self.world, self.rank = 1, 0
         self.backend = None
         if _initialized():
             self.world, self.rank = dist.get_world_size(group), dist.get_rank(group)
             self.backend = dist.get_backend(group)
+        self.multi = self.world > 1 or self.force_collectives      # the collectives run (False: one rank reads its own buffers)
         self.shape = (int(shape[0]), int(shape[1]))
         self.kvecs = np.asarray(kvecs, dtype=np.float64).reshape(-1, 2)
         self.klists = np.asarray(klists, dtype=np.float64)
@@ -335,7 +342,7 @@ class TiledPipeline:
         pr = self.per_rank
         self.wins = torch.zeros((max(len(self.mine), 1),) + self.wshape, dtype=t_dt, device=dev)
         self.local = torch.zeros((2, pr, 3, t0, t1), dtype=t_dt, device=dev)
-        self.gathered = torch.zeros((self.world, 2, pr, 3, t0, t1), dtype=t_dt, device=dev) if self.world > 1 else None
+        self.gathered = torch.zeros((self.world, 2, pr, 3, t0, t1), dtype=t_dt, device=dev) if self.multi else None
         self.gdx = torch.zeros((2, n0, n1 - 1), dtype=t_dt, device=dev)
         self.gdy = torch.zeros((2, n0 - 1, n1), dtype=t_dt, device=dev)
         self.gw = torch.zeros((n0, n1), dtype=t_dt, device=dev)
@@ -357,29 +364,50 @@ class TiledPipeline:
     def _host_staged(self):
         return self.backend is not None and self.backend != 'nccl'
 
+    def _fence(self, what, after=False):
+        """GPA_DIST_SYNC=1 (or TiledPipeline(..., dist_sync=True)): drain this rank's device and meet the other ranks at a
+        barrier before AND after every collective, so that the first run on a real multi-GPU node can be bisected -- a hang
+        or a wrong field then points at ONE collective instead of at whatever the streams had overlapped with it.
+        GPA_DIST_SYNC=2 also logs every collective with its rank and wall time to stderr.  Off by default: the schedule
+        overlaps collectives with kernels through stream events and synchronises the host once per image."""
+        if not self.dist_sync or not self.multi:
+            return
+        self.be.sync_device()
+        self.dist.barrier(group=self.group)
+        if self.dist_sync > 1:
+            import sys
+            import time
+            print('[gpa dist_sync] rank %d %s %s %.6f' % (self.rank, 'done' if after else 'enter', what, time.time()),
+                  file=sys.stderr, flush=True)
+
     def _all_reduce_sum(self, t):
-        if self.world == 1:
+        if not self.multi:
             return t
+        self._fence('all_reduce %s' % (tuple(t.shape),))
         if self._host_staged():
             h = t.cpu()
             self.dist.all_reduce(h, group=self.group)
             t.copy_(h)
         else:
             self.dist.all_reduce(t, group=self.group)
+        self._fence('all_reduce', after=True)
         return t
 
     def _all_gather(self, out, t):
+        self._fence('all_gather %s' % (tuple(t.shape),))
         if self._host_staged():
             h = out.cpu()
             self.dist.all_gather_into_tensor(h, t.cpu().contiguous().unsqueeze(0), group=self.group)   # gloo wants world x input
             out.copy_(h)
         else:
             self.dist.all_gather_into_tensor(out, t, group=self.group)
+        self._fence('all_gather', after=True)
 
     def _broadcast(self, t, src):
-        if self.world == 1:
+        if not self.multi:
             return
         src_global = src if self.group is None else self.dist.get_global_rank(self.group, src)
+        self._fence('broadcast from %d %s' % (src, tuple(t.shape)))
         if self._host_staged():
             h = t.cpu()
             self.dist.broadcast(h, src_global, group=self.group)
@@ -387,6 +415,7 @@ class TiledPipeline:
                 t.copy_(h)
         else:
             self.dist.broadcast(t, src_global, group=self.group)
+        self._fence('broadcast', after=True)
 
     # ---- data ------------------------------------------------------------------------------------
     def load(self, image=None, window_fn=None):
@@ -408,7 +437,7 @@ class TiledPipeline:
             self.be.tile_sums(self.wins, self.rects, len(self.mine), self.max_rows, self.sums)
         else:
             self.sums.zero_()
-        if self.world > 1:
+        if self.multi:
             self.be.tiles_to_torch(self._host_staged())
             self._all_reduce_sum(self.sums)
             self.be.torch_to_tiles()
@@ -445,7 +474,7 @@ class TiledPipeline:
         mark('tile_stage')
         # --- collective 1 (RCCL all_gather over xGMI): the tile blocks of every rank (one rank: read in place)
         self.be.tiles_to_torch(self._host_staged())
-        if self.world > 1:
+        if self.multi:
             self._all_gather(self.gathered, self.local)
             src = self.gathered
         else:
@@ -453,8 +482,8 @@ class TiledPipeline:
         mark('all_gather')
         # --- stitch + global unwrap, component c on rank c % world; collective 2 hands each component to everybody
         for c in self.unwrappers:
-            comp = src[0, c] if self.world > 1 else src[c]
-            self.be.stitch(c, comp, 3 * plane, self.table_step if self.world > 1 else self.table_stream, len(self.tiles), t0, t1,
+            comp = src[0, c] if self.multi else src[c]
+            self.be.stitch(c, comp, 3 * plane, self.table_step if self.multi else self.table_stream, len(self.tiles), t0, t1,
                            self.gdx[c], self.gdy[c], self.gw)
             self.be.unwrap_start(c, self.gdx[c], self.gdy[c], self.gw, self.u[c], self.kmax)
             self.iters[c] = self.be.unwrap_wait(c)
@@ -465,7 +494,7 @@ class TiledPipeline:
         return self.u
 
     # ---- Lawler-Fujita undistortion of the stitched field, sharded over the tiles ------------------------------------
-    def undistort(self, image, u=None):
+    def undistort(self, image, u=None, scale=1.0):
         """undistort_image (geometric_phase_analysis.py:935-974) with the field this pipeline produced: every rank holds u
         (step() broadcasts it; pass another (2, N, M) device tensor otherwise) and is given the whole deformed `image`
         (host array or device tensor -- every rank the same, as for load()).  The fixed-point inversion (35 + 1 rounds of two
@@ -473,7 +502,12 @@ class TiledPipeline:
         them for the interiors of the tiles it owns (gpa_undistort_image_dev with those windows; the spline prefilter of the
         whole field, ~3 % of the work, runs on every rank), and one all_reduce of the zero-filled outputs hands every rank
         the whole undistorted image and u_inv.  Returns (undistorted (N, M), u_inv (2, N, M)) as device tensors.  No host
-        round trip of u."""
+        round trip of u.
+        The two tensors are buffers of the pipeline: the NEXT undistort() call overwrites them (clone what must outlive it),
+        as run_stream's results are.  The sum also turns a -0.0 of the owner into +0.0.  (the all_reduce moves 3
+        full planes per rank where a gather of the owned tiles would move 1 / N of that; it runs outside every timed region.)
+        `scale`: undistort_image(image, scale * u) -- scale = -1 for the field exactly as this pipeline extracted it, which is
+        MINUS the displacement (tests/test_geometric_phase_analysis.py:63, :76)."""
         torch = self.torch
         u = self.u if u is None else u
         t_dt = torch.float32 if self.dtype == np.float32 else torch.float64
@@ -483,15 +517,15 @@ class TiledPipeline:
         if getattr(self, '_lf', None) is None:
             self._lf = (torch.zeros(self.shape, dtype=t_dt, device=self.dev), torch.zeros((2,) + self.shape, dtype=t_dt, device=self.dev))
         out, uinv = self._lf
-        if self.world == 1:
-            self.be.undistort_tiles(image, u, out, uinv, None)
+        if not self.multi:
+            self.be.undistort_tiles(image, u, out, uinv, None, scale)
             return out, uinv
         t0, t1 = self.tshape
         rects = [(self.tiles[idx][0][0] * t0, self.tiles[idx][0][1] * t1, self.tiles[idx][3][0], self.tiles[idx][3][1]) for idx in self.mine]
         out.zero_()
         uinv.zero_()
         if rects:
-            self.be.undistort_tiles(image, u, out, uinv, rects)
+            self.be.undistort_tiles(image, u, out, uinv, rects, scale)
         for t in (out, uinv):
             if self._host_staged():
                 self.be.sync_device()
@@ -515,10 +549,11 @@ class TiledPipeline:
         One rank: the tile buffer itself."""
         dist = self.dist
         part = self.local[c]                      # contiguous: one slice per owner
-        if self.world == 1:
+        if not self.multi:
             return part
         dst_global = dst if self.group is None else dist.get_global_rank(self.group, dst)
         rx = self._rx[c] if self.rank == dst else None
+        self._fence('gather of component %d to %d' % (c, dst))
         if self._host_staged():
             hp = part.cpu()
             outs = [self.torch.empty_like(hp) for _ in range(self.world)] if rx is not None else None
@@ -526,8 +561,10 @@ class TiledPipeline:
             if rx is not None:
                 for r, o in enumerate(outs):
                     rx[r].copy_(o)
+            self._fence('gather', after=True)
             return rx
         dist.gather(part, list(rx.unbind(0)) if rx is not None else None, dst=dst_global, group=self.group)
+        self._fence('gather', after=True)
         return rx
 
     def _send_component(self, t, src, dst):
@@ -536,6 +573,7 @@ class TiledPipeline:
             return
         dist = self.dist
         g = (lambda r: r) if self.group is None else (lambda r: dist.get_global_rank(self.group, r))
+        self._fence('send %d -> %d' % (src, dst))
         if self._host_staged():
             if self.rank == src:
                 dist.send(t.cpu(), g(dst), group=self.group)
@@ -543,6 +581,7 @@ class TiledPipeline:
                 h = t.cpu()
                 dist.recv(h, g(src), group=self.group)
                 t.copy_(h)
+            self._fence('send', after=True)
             return
         # RCCL: a grouped isend / irecv runs on the communicator of the whole group (a bare send / recv would build a
         # two-rank communicator per pair on first use, inside somebody's timed region)
@@ -554,6 +593,7 @@ class TiledPipeline:
         if ops:
             for w in dist.batch_isend_irecv(ops):
                 w.wait()
+        self._fence('send', after=True)
 
     def run_stream(self, sources, on_result=None):
         """A stream of images of the pipeline's shape through the image-pipelined schedule.
@@ -583,7 +623,7 @@ class TiledPipeline:
             # receive buffers of the gathers (allocated once; a component's buffer is free again when its unwrap,
             # which follows the stitch on the same stream, has been waited for -- before the next image's gather)
             self._rx = [torch.zeros((self.world, self.per_rank, 3, t0, t1), dtype=t_dt, device=self.dev)
-                        for _ in range(2)] if self.world > 1 else None
+                        for _ in range(2)] if self.multi else None
         st = {k: 0.0 for k in ('load', 'mean', 'tiles', 'gather', 'unwrap_wait', 'handover')}
         iters_all = []
         pending = None      # (index, buffer set) of the image whose unwraps are in flight
@@ -636,7 +676,7 @@ class TiledPipeline:
                     gdx, gdy, gw = self._pbuf[buf]
                     self.be.stitch(c, got, 3 * plane, self.table_stream, len(self.tiles), t0, t1, gdx[c], gdy[c], gw[c],
                                    concurrent=both)
-                    if self.world == 1:
+                    if not self.multi:
                         self.be.stitch_to_tiles(c)      # `got` IS the tile buffer: the next tile stage must not overwrite it yet
                     self.be.unwrap_start(c, gdx[c], gdy[c], gw[c], self._pu[buf][c], self.kmax, concurrent=both)
             st['gather'] += time.perf_counter() - t

@@ -395,6 +395,23 @@ def iterate_GPA(image, kvecs, sigma, edge=5, iters=3, kmax_iter=25, kmax=200, ve
     return np.stack(prs), w, corr
 
 
+def myweighed_lstsq(b, K, w, dtype=None):
+    """Per-pixel weighted least squares, minimise ||w (K x - b)|| over x (2,) at every pixel
+    (geometric_phase_analysis.py:97-113; imported by the reference's own property_extract.py:10): b (P, N, M'), K (P, 2)
+    = 2 pi kvecs, w (P, N', M'') with N' >= N, M'' >= M' -- the reference indexes w[:, i, j] for the pixels of b, so the
+    weight of a difference is that of its first pixel (:110) -- returns (2, N, M').  Device: gpa_weighted_lstsq
+    (2 x 2 normal equations per pixel; the minimum-norm answer where they are singular, like np.linalg.lstsq)."""
+    b = np.asarray(b)
+    K = np.asarray(K, dtype=np.float64).reshape(-1, 2)
+    w = np.asarray(w)
+    if b.ndim != 3 or len(K) != b.shape[0] or w.ndim != 3 or w.shape[0] != b.shape[0]:
+        raise ValueError('b (P, N, M), K (P, 2), w (P, >= N, >= M) expected')
+    if w.shape[1] < b.shape[1] or w.shape[2] < b.shape[2]:
+        raise ValueError('w must cover the pixels of b')
+    plan = _lib.get_plan(b.shape[1:], len(K), DEFAULT_DTYPE if dtype is None else dtype)
+    return plan.weighted_lstsq(b, w[:, :b.shape[1], :b.shape[2]], K / (2 * np.pi))
+
+
 def reconstruct_u_inv(kvecs, b, weights=None, use_only_ks=None, dtype=None):
     """Unwrapped phases -> displacement field (geometric_phase_analysis.py:157-193).
     The weighted per-pixel solve runs on the device; the two global solves are one small

@@ -288,11 +288,11 @@ class OracleTileBackend:
             gdy[r0:r0 + zy, c0:c0 + z1] = blk[1, :zy, :z1]
             gw[r0:r0 + z0, c0:c0 + z1] = blk[2, :z0, :z1]
 
-    def undistort_tiles(self, image, u, out, uinv, rects):
+    def undistort_tiles(self, image, u, out, uinv, rects, scale=1.0):
         """the oracle's undistort_image (scipy.ndimage.map_coordinates, the reference's calls) on the whole field, of which
         only the given windows are handed out -- what gpa_undistort_image_dev does with its rects"""
         from oracle import gpa_oracle as orc
-        un, ui = image.numpy().astype(np.float64), u.numpy().astype(np.float64)
+        un, ui = image.numpy().astype(np.float64), scale * u.numpy().astype(np.float64)
         full_inv = orc.invert_u_overlap(-ui)
         full = orc.undistort_image(un, ui)
         t = self.torch.from_numpy
@@ -374,9 +374,13 @@ def test_pipelined_stream_equals_step(tmp_path, world):
     assert sorted(seen.tolist()) == [0, 1, 2, 3]      # every image's field arrived exactly once
 
 
-def _undistort_worker(rank, world, port, out_path):
+def _undistort_worker(rank, world, port, out_path, dist_sync=0, force=False):
     sys.path.insert(0, ROOT)
-    if world > 1:
+    if dist_sync:
+        os.environ['GPA_DIST_SYNC'] = str(dist_sync)
+    if force:
+        os.environ['GPA_DIST_FORCE_COLLECTIVES'] = '1'
+    if world > 1 or force:
         import torch.distributed as dist
         dist.init_process_group('gloo', init_method='tcp://127.0.0.1:%d' % port, rank=rank, world_size=world)
     from oracle import gpa_oracle as orc
@@ -393,7 +397,7 @@ def _undistort_worker(rank, world, port, out_path):
     assert np.array_equal(uinv.numpy(), ref_inv)
     np.save(out_path % rank, rec.numpy())
     pipe.close()
-    if world > 1:
+    if world > 1 or force:
         dist.barrier()
         dist.destroy_process_group()
 
@@ -412,3 +416,20 @@ def test_tile_sharded_undistort_equals_whole_image(tmp_path, world):
     recs = [np.load(out % r) for r in range(world)]
     for r in recs[1:]:
         assert np.array_equal(r, recs[0])
+
+
+def test_dist_sync_fences_leave_the_results_alone(tmp_path):
+    """GPA_DIST_SYNC=2 (drain the device and meet at a barrier around EVERY collective of TiledPipeline,
+    with a log line each -- the bisecting aid for the first run on a real multi-GPU node): two gloo ranks through step() and
+    the tile-sharded undistortion give the fields of the unfenced run"""
+    import torch.multiprocessing as mp
+    out = str(tmp_path / 'rec_sync_rank%d.npy')
+    mp.spawn(_undistort_worker, args=(2, _free_port(), out, 2), nprocs=2, join=True)
+    ref = str(tmp_path / 'rec_ref_rank%d.npy')
+    _undistort_worker(0, 1, 0, ref)
+    assert np.array_equal(np.load(out % 0), np.load(ref % 0)) and np.array_equal(np.load(out % 1), np.load(ref % 0))
+    # GPA_DIST_FORCE_COLLECTIVES=1: a group of ONE rank through every collective of the N > 1 path (what the GPU test runs on
+    # RCCL with the one rank a single-GPU box allows), fenced as well
+    one = str(tmp_path / 'rec_forced_rank%d.npy')
+    mp.spawn(_undistort_worker, args=(1, _free_port(), one, 2, True), nprocs=1, join=True)
+    assert np.array_equal(np.load(one % 0), np.load(ref % 0))

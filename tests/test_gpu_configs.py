@@ -567,6 +567,32 @@ def test_tiled_nccl_single_rank(tmp_path):
     assert int(g['tiles']) == 4
 
 
+def test_stream_and_step_on_nccl_single_rank_forced_collectives(tmp_path):
+    """`run_stream` (and step()) on the nccl backend.  A single-GPU box allows ONE RCCL rank; with
+    GPA_DIST_FORCE_COLLECTIVES=1 that rank takes every collective of the N > 1 schedule anyway -- all_reduce of the mean,
+    all_gather_into_tensor of the tile blocks, the gathers to the owners, the broadcasts -- on device tensors, ordered against
+    the library's streams through events (tiles_to_torch / torch_to_tiles): run_stream's fields equal step()'s bit for bit
+    (the worker asserts it) and both equal the run without a process group; once more with GPA_DIST_SYNC=1 fences"""
+    import test_distributed as TD
+    from pygpa_amd import distributed as D
+    _, kvecs, klists = TD._case()
+    images = TD._stream_images(5)
+    pipe = D.TiledPipeline(images[0].shape, kvecs, np.stack(klists), 6, 20, kmax=10, dtype=np.float32, device=0, grid=(2, 2))
+    pipe.load(images[0])
+    ref0 = pipe.step().cpu().numpy().copy()
+    pipe.close()
+    for sync in ('0', '1'):
+        prefix = str(tmp_path / ('nccl_stream' + sync))
+        env = dict(os.environ, RANK='0', WORLD_SIZE='1', LOCAL_RANK='0', MASTER_ADDR='127.0.0.1', MASTER_PORT=str(_free_port()),
+                   HSA_ENABLE_IPC_MODE_LEGACY='0', GPA_DIST_FORCE_COLLECTIVES='1', GPA_DIST_SYNC=sync)
+        r = subprocess.run([sys.executable, os.path.join(ROOT, 'tests', '_stream_rank_worker.py'), prefix, 'float32', 'nccl'],
+                           env=env, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, timeout=900)
+        assert r.returncode == 0, r.stdout.decode()[-3000:]
+        g = np.load(prefix + '_rank0.npz')
+        assert bool(g['ok']) and list(g['seen']) == [0, 1, 2, 3, 4]
+        assert np.array_equal(g['ref0'], ref0)
+
+
 def test_stack_frames_over_two_ranks_one_gpu(tmp_path):
     """pygpa_amd.distributed.extract_displacement_field_stack_sharded with world size 2 (both ranks on cuda:0,
     gloo): blocks of frames per rank, no data-path collective, the gathered field equals the single-process

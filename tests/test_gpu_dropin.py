@@ -196,3 +196,24 @@ def test_extract_primary_ks():
         ext_ks, _ = GPA.extract_primary_ks(original, DoG=False)
         abs_diffs = np.linalg.norm((ext_ks[None] - ori_ks[:, None]), axis=-1).min(axis=0)
         assert np.all(abs_diffs < 1.5 / size), (r_k, theta, ext_ks)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize('dtype', [np.float64, np.float32])
+@pytest.mark.parametrize('name', ['hex_64', 'hex_48x80', 'hex_63x65'])
+def test_myweighed_lstsq_is_part_of_the_module_surface(golden, name, dtype):
+    """`myweighed_lstsq(b, K, w)` (geometric_phase_analysis.py:97-113; the reference's own property_extract.py:10 imports it
+    from the module): the per-pixel weighted least squares of reconstruct_u_inv_from_phases (:234-237) called the way the
+    reference calls it -- wrapped phase differences, K = 2 pi kvecs, the FULL weight stack (the difference grids are one
+    pixel shorter) -- against the reference's dudx / dudy"""
+    import pygpa_amd.geometric_phase_analysis as GPA
+    from pygpa_amd.mathtools import wrapToPi
+    g = golden(name)
+    K = 2 * np.pi * g['kvecs']
+    dbdx = wrapToPi(np.diff(g['a5_phases'], axis=2))
+    dbdy = wrapToPi(np.diff(g['a5_phases'], axis=1))
+    tol = 1e-11 if dtype is np.float64 else 2e-5
+    for b, ref in ((dbdx, g['a6_dudx']), (dbdy, g['a6_dudy'])):
+        out = GPA.myweighed_lstsq(b, K, g['a5_weights'], dtype=dtype)
+        assert out.shape == ref.shape
+        assert np.abs(out - ref).max() < tol * np.abs(ref).max()

@@ -318,3 +318,53 @@ def test_raw_winners_random_draws(gpa_option):
     # no systematic loss over the draws (the biased variants this arithmetic replaced measured 5 - 10 x)
     print('raw / compensated error ratios: median %.2f, max %.2f over %d draws' % (np.median(ratios), max(ratios), len(ratios)))
     assert np.median(ratios) < 1.3, ratios
+
+
+@pytest.mark.parametrize('dtype', DTYPES)
+def test_aliased_candidates_bit_equal_amplitudes_keep_list_order(dtype, gpa_option):
+    """an exact amplitude tie between two DIFFERENT candidates, constructed, not accidental.  k-vectors
+    that differ by a whole cycle per pixel sample the same carrier on the integer grid; with dyadic components the products
+    k x are exact and the device's lock-ins of the two candidates are equal bit for bit at EVERY pixel.  The reference's rule
+    (strictly larger |sf| replaces, in list order, geometric_phase_analysis.py:679-684) then keeps the EARLIER of the two.
+    The default visiting order (nearest to the reference vector first) would visit the later one first; a list with such a
+    pair is visited in list order instead: the winner map equals NO_REORDER=1's bit for bit, the earlier position wins, the
+    later one never does, and the oracle -- whose own carriers exp(2 pi i k x) differ by rounding, so that its tie is broken
+    by noise -- agrees up to exactly those ties."""
+    shape = (64, 2048)
+    kref = np.array([0.125, 0.0625])
+    x = np.arange(shape[0])[:, None] - shape[0] // 2
+    y = np.arange(shape[1])[None, :] - shape[1] // 2
+    rng = np.random.default_rng(21)
+    img0 = np.cos(2 * np.pi * (kref[0] * x + kref[1] * (y + 3.0 * np.sin(y / 300.0)))) + 0.2 * rng.normal(size=shape)
+    img0 -= img0.mean()
+    sigma = 10
+    grid = np.array([(kref[0] + dx, kref[1] + dy) for dx in (-0.03125, 0.0, 0.03125) for dy in (-0.015625, 0.0, 0.015625)])
+    # position 1: the centre candidate shifted by a whole cycle along x (far from kref: the nearest-first order would visit it
+    # LAST); position 5 of `grid` (+1 below) is the centre candidate itself
+    klist = np.concatenate([grid[:1], [kref + np.array([1.0, 0.0])], grid[1:]])
+    early, late = 1, 5
+    assert np.array_equal(klist[late], kref)
+
+    def run():
+        plan = _lib.Plan(shape, len(klist), dtype)
+        plan.set_profiling(True)
+        lock, kidx, _ = plan.sweep(img0, kref, klist, sigma)
+        prof = plan.last_kernel_profile()
+        plan.close()
+        return lock, kidx, prof
+
+    lock, kidx, prof = run()
+    gpa_option('NO_REORDER', '1')
+    lock_l, kidx_l, _ = run()
+    gpa_option('NO_REORDER', None)
+    assert np.array_equal(kidx, kidx_l) and np.array_equal(lock, lock_l)
+    assert (kidx == early).mean() > 0.2 and not (kidx == late).any()
+    # the two candidates' lock-ins ARE equal bit for bit on the device (so the tie is real, not assumed)
+    plan = _lib.Plan(shape, 2, dtype)
+    both = plan.lockin_batch(img0, klist[[early, late]], sigma)
+    plan.close()
+    assert np.array_equal(np.abs(both[0]), np.abs(both[1]))
+    ref = orc.sweep(img0, sigma, klist, kref, workers=8)
+    folded = np.where(ref['kidx'] == late, early, ref['kidx'])
+    check_kidx(kidx, folded, img0, klist, sigma, TOL[dtype]['tie'])
+    assert (kidx == folded).mean() > 0.9999

@@ -236,3 +236,45 @@ def test_persistent_row_kernels_equal_per_pair_kernels(shape, gpa_option):
         phi, _ = plan.unwrap_prediff(dx, dy, w, kmax=10)
         plan.close()
         assert rel(phi, ref) < 5e-5
+
+
+def test_f32_stagnation_guard_fires_and_has_a_switch(golden, gpa_option):
+    """VERDICT r05 item 8 / ADVICE r05: the f32-only stagnation stop (pcg_breakdown (2), gpa_unwrap_impl.h; not in the
+    reference) on a case where it FIRES -- the 63 x 65 golden case at kmax = 100, which the f64 reference solves in 15
+    iterations -- asserted against the oracle's iterate at the SAME iteration count; F32_STALL=0 switches it off (the solve
+    then runs on like the reference's loop, phase_unwrap.py:326-349, and drifts: what the guard is for); and it never acts
+    within kmax = 10 on the benchmark's kind of image (2048^2): the same bits with and without it."""
+    g = golden('hex_63x65')
+    wn = np.linalg.norm(g['a5_weights'], axis=0)
+    dx, dy = g['a6_dudx'][0], g['a6_dudy'][0]
+    plan = _lib.Plan(g['image'].shape, 1, np.float32)
+    phi, it = plan.unwrap_prediff(dx, dy, wn, kmax=100)
+    assert 10 < it < 40, it
+    ref_it = orc.unwrap_prediff(dx, dy, wn, kmax=it)
+    sc = np.abs(ref_it).max()
+    assert np.abs(phi - ref_it).max() < 2.5e-5 * sc
+    gpa_option('F32_STALL', '0')
+    phi_off, it_off = plan.unwrap_prediff(dx, dy, wn, kmax=100)
+    assert it_off > it
+    ref_100 = orc.unwrap_prediff(dx, dy, wn, kmax=100)
+    # without the guard the f32 iterate has drifted further from the reference's answer than with it
+    assert np.abs(phi_off - ref_100).max() > np.abs(phi - ref_100).max()
+    gpa_option('F32_STALL', '5')
+    _, it5 = plan.unwrap_prediff(dx, dy, wn, kmax=100)
+    assert it < it5 <= it_off
+    gpa_option('F32_STALL', None)
+    plan.close()
+    # the benchmark's kind of image: 10 + 10 iterations, the guard is inert
+    from pygpa_amd.synthetic import hex_kvecs, gaussian_bump_displacement, hex_moire, explicit_klists
+    n = 2048
+    kvecs = hex_kvecs(0.1, 7.0)
+    img = hex_moire((n, n), kvecs, gaussian_bump_displacement((n, n)), noise=0.1, seed=100, dtype=np.float32)
+    klists = np.stack(explicit_klists(kvecs, 0.04, 4, 4))
+    plan = _lib.Plan((n, n), 48, np.float32)
+    u, _, _, iters = plan.extract_displacement_field(img, kvecs, klists, 10, 20, 10)
+    gpa_option('F32_STALL', '0')
+    u_off, _, _, iters_off = plan.extract_displacement_field(img, kvecs, klists, 10, 20, 10)
+    gpa_option('F32_STALL', None)
+    plan.close()
+    assert tuple(iters) == tuple(iters_off) == (10, 10)
+    assert np.array_equal(u, u_off)
