@@ -36,6 +36,7 @@ sys.path.insert(0, ROOT)
 
 HBM_PEAK_GBS = 8000.0        # MI355X HBM3E spec peak (MI355X_MICROARCH.md: 8.0 TB/s spec, ~6.3 achievable)
 VALU_PEAK_TFLOPS = 157.3     # f32 vector peak: 1024 SIMD-32 x 2 flop x 2.4 GHz (same guide)
+VALU_PEAK_TFLOPS_F64 = 78.6  # f64 vector peak (same guide): half the f32 rate
 VALU_ISSUE_PEAK = 1024 * 2.4e9 / 2   # wave64 VALU instructions / s: one per 2 cycles per SIMD
 
 
@@ -299,6 +300,7 @@ def kernel_table(n, L0, L1, P, K, Bx, s, iters, kern, stage, res_s):
     roofline object of the dominant kernel; whole-step traffic figures"""
     out = {}
     models = kernel_models(n, n, L0, L1, P, K, Bx, s, iters)
+    valu_peak = VALU_PEAK_TFLOPS if s == 4 else VALU_PEAK_TFLOPS_F64     # the vector peak of the precision the path computes in
     counters = load_counters()
     stale = counters.pop('_stale', None)
     meta = counters.get('_meta', {})
@@ -338,7 +340,7 @@ def kernel_table(n, L0, L1, P, K, Bx, s, iters, kern, stage, res_s):
         if c.get('valu_insts'):
             row['valu_issue_frac'] = round(c['valu_insts'] / per / VALU_ISSUE_PEAK, 4)
         fr = {'hbm': row.get('hbm_frac', (m['bytes'] / per / 1e9 / HBM_PEAK_GBS) if m.get('bytes') else 0.0),
-              'valu': row.get('valu_issue_frac', ((m.get('executed_flops') or m['flops']) / per / 1e12 / VALU_PEAK_TFLOPS) if m.get('flops') else 0.0)}
+              'valu': row.get('valu_issue_frac', ((m.get('executed_flops') or m['flops']) / per / 1e12 / valu_peak) if m.get('flops') else 0.0)}
         row['bound'] = max(fr, key=fr.get)
         table[name] = row
     out['kernels'] = table
@@ -358,16 +360,16 @@ def kernel_table(n, L0, L1, P, K, Bx, s, iters, kern, stage, res_s):
     if drow['bound'] == 'valu' and dm.get('flops'):
         ex = dm.get('executed_flops', dm['flops'])
         out['roofline'] = {'bound': 'valu', 'kernel': dom, 'achieved': round(ex / dsec / 1e12, 2),
-                           'peak': VALU_PEAK_TFLOPS, 'unit': 'TFLOP/s', 'frac': round(ex / dsec / 1e12 / VALU_PEAK_TFLOPS, 4),
+                           'peak': valu_peak, 'unit': 'TFLOP/s', 'frac': round(ex / dsec / 1e12 / valu_peak, 4),
                            'traffic': dc.get('hbm_bytes'), 'kernel_ms': round(dsec * 1e3, 4),
                            'executed_flops_per_launch': ex,
                            'algorithmic_flops_per_launch': dm['flops'],
                            'algorithmic_TFLOPs': round(dm['flops'] / dsec / 1e12, 2),
-                           'algorithmic_frac': round(dm['flops'] / dsec / 1e12 / VALU_PEAK_TFLOPS, 4),
+                           'algorithmic_frac': round(dm['flops'] / dsec / 1e12 / valu_peak, 4),
                            'algorithmic_bytes_per_launch': dm.get('bytes'),
                            'valu_issue_frac': drow.get('valu_issue_frac'), 'source': src,
                            'note': 'frac = EXECUTED flops over peak: the transforms the kernel performs (one forward per x-plane row, one '
-                                   'inverse per candidate, nominal 5 L log2 L each) over the HIP-event time, against the f32 vector peak; '
+                                   'inverse per candidate, nominal 5 L log2 L each) over the HIP-event time, against the vector peak of the precision of the plan (f32 157.3, f64 78.6 TFLOP/s); '
                                    'algorithmic_* credits the reference algorithm\'s work instead (a forward AND an inverse transform per '
                                    'candidate and row), which the shared-forward kernel does not perform; valu_issue_frac = counted VALU '
                                    'wave-instructions / (1024 SIMDs x 1 per 2 cycles x 2.4 GHz); a small MFMA contraction (the row-end fix) '
@@ -441,9 +443,14 @@ def single_gpu(args):
 
     if not args.no_f64 and args.dtype == 'f32':
         k64 = max(3, args.steps // 4)
-        m64 = measure(n, knx, kny, np.float64, args.kmax, k64, 1, profile=False)
+        m64 = measure(n, knx, kny, np.float64, args.kmax, k64, 1, profile=True)
         out['f64'] = {'value': m64['value'], 'unit': 'Mpixels/s', 'ms_per_step': m64['ms_per_step'],
-                      'steps': k64, 'unwrap_iters': m64['iters'], 'note': 'the reference computes in complex128; same step, D2H of u included'}
+                      'resident_only': m64['resident_value'], 'steps': k64, 'unwrap_iters': m64['iters'],
+                      'note': 'the reference computes in complex128 and the mirror defaults to float64: the same step in f64, D2H of u '
+                              'included, with its own per-kernel table and rooflines (VERDICT r05 item 6)'}
+        for key in ('kernels', 'stage_ms', 'roofline', 'roofline_unwrap', 'whole_step'):
+            if key in m64:
+                out['f64'][key] = m64[key]
     if not args.no_f64 and args.dtype == 'f32' and n == 4096 and not args.kgrid:
         # BASELINE.json configs[1] (2048^2, 3 peaks x 8 k-vectors as the survey's 4 x 2 list, f32) in the same run
         # (a 2048^2 step is 1.4 ms: three times the steps of the headline, so that one slow D2H does not move the leg by 4 %)

@@ -126,7 +126,9 @@ __global__ __launch_bounds__(256, 2) void rowidct_p_pers_kernel(
     cpx<T>* lds = reinterpret_cast<cpx<T>*>(bcur);
     const T* st = reinterpret_cast<const T*>(bcur);
     const size_t oa = (size_t)2 * pr * N, ob = oa + N;
-    // this wave's pieces of pair pr have landed (everything older than the previous pair's NQ * 2 stores is done)
+    // this wave's pieces of pair pr have landed (everything older than the previous pair's NQ * 2 stores is done).  The count
+    // holds only while the youngest vector-memory operations of an iteration are exactly those stores -- no split stores, no
+    // scratch accesses in the loop: tests/test_isa_invariants.py checks the compiled loop for precisely that.
     asm volatile("s_waitcnt vmcnt(%0)" ::"n"(2 * NQ) : "memory");
     GPA_PBAR();   // ... and everybody else's; the other buffer's last reads (previous gather) are done
     if (pr + 1 < p1) dma_pair<LG>(Z + (size_t)2 * (pr + 1) * N, buf0 + (cur ^ 1) * G::BUF_BYTES, wave, lane);
@@ -179,15 +181,18 @@ __global__ __launch_bounds__(256, 2) void rowidct_p_pers_kernel(
   }
 }
 
+// two resident workgroups per CU of the CURRENT device (one slot per device index, like set_dynamic_lds_once: ADVICE r05)
 int pers_workgroups() {
-  static int n = 0;
-  if (!n) {
-    int dev = 0, cus = 0;
-    (void)hipGetDevice(&dev);
+  static int n[32] = {};
+  int dev = 0;
+  (void)hipGetDevice(&dev);
+  int& slot = n[dev & 31];
+  if (!slot) {
+    int cus = 0;
     if (hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || cus <= 0) cus = 256;
-    n = 2 * cus;
+    slot = 2 * cus;
   }
-  return n;
+  return slot;
 }
 
 }  // namespace
