@@ -267,20 +267,17 @@ def measure(n, knx, kny, np_dt, kmax, steps, warmup, depth=1, profile=True):
     # The timed step runs the REFERENCE's stopping test alone (phase_unwrap.py:348: k >= kmax or ||r|| < 1e-9 ||r0||) --
     # the library default in both precisions since round 5.  The opt-in f32 residual floor (F32_EPS_FLOOR=4e-6)
     # ends the benchmark image's solves after 9 + 8 iterations instead of 10 + 10; it is reported as `early_stop`.
-    try:
-        dt = g.timed(steps, warmup, download=True)
-        iters = g.plan.last_iters()
-        dt_res = g.timed(steps, 1, download=False)
-        res = {'n': n, 'P': P, 'K': K, 'Bx': int(Bx), 'sigma': sigma, 'kvecs': kvecs, 'klists': klists, 'iters': list(iters),
-               'value': round(n * n * steps / dt / 1e6, 2), 'ms_per_step': round(dt / steps * 1e3, 4),
-               'resident_value': round(n * n * steps / dt_res / 1e6, 2), 'resident_ms': round(dt_res / steps * 1e3, 4),
-               'depth': g.depth}
-        if profile:
-            stage, kern = g.profile()
-            L0, L1 = g.plan.fft_len(0), g.plan.fft_len(1)
-            res.update(kernel_table(n, L0, L1, P, K, Bx, s, iters, kern, stage, dt_res / steps))
-    finally:
-        pass
+    dt = g.timed(steps, warmup, download=True)
+    iters = g.plan.last_iters()
+    dt_res = g.timed(steps, 1, download=False)
+    res = {'n': n, 'P': P, 'K': K, 'Bx': int(Bx), 'sigma': sigma, 'kvecs': kvecs, 'klists': klists, 'iters': list(iters),
+           'value': round(n * n * steps / dt / 1e6, 2), 'ms_per_step': round(dt / steps * 1e3, 4),
+           'resident_value': round(n * n * steps / dt_res / 1e6, 2), 'resident_ms': round(dt_res / steps * 1e3, 4),
+           'depth': g.depth}
+    if profile:
+        stage, kern = g.profile()
+        L0, L1 = g.plan.fft_len(0), g.plan.fft_len(1)
+        res.update(kernel_table(n, L0, L1, P, K, Bx, s, iters, kern, stage, dt_res / steps))
     if np_dt is np.float32:
         _lib.set_option('F32_EPS_FLOOR', '4e-6')
         try:
@@ -745,21 +742,18 @@ def host_call(n, knx, kny, np_dt, kmax, reps=5):
     img = hex_moire((n, n), kvecs, gaussian_bump_displacement((n, n)), noise=0.1, seed=100, dtype=np_dt)
     plan = _lib.Plan((n, n), 3 * knx * kny, np_dt, device=0)
     out = {}
-    try:
-        for kind in ('pageable', 'pinned'):
-            if kind == 'pinned':
-                src, dst = _lib.pinned_empty((n, n), np_dt), _lib.pinned_empty((2, n, n), np_dt)
-                src[...] = img
-            else:
-                src, dst = img, np.empty((2, n, n), np_dt)
+    for kind in ('pageable', 'pinned'):
+        if kind == 'pinned':
+            src, dst = _lib.pinned_empty((n, n), np_dt), _lib.pinned_empty((2, n, n), np_dt)
+            src[...] = img
+        else:
+            src, dst = img, np.empty((2, n, n), np_dt)
+        plan.extract_displacement_field(src, kvecs, klists, sigma, 2 * sigma, kmax=kmax, out=dst)
+        t0 = time.perf_counter()
+        for _ in range(reps):
             plan.extract_displacement_field(src, kvecs, klists, sigma, 2 * sigma, kmax=kmax, out=dst)
-            t0 = time.perf_counter()
-            for _ in range(reps):
-                plan.extract_displacement_field(src, kvecs, klists, sigma, 2 * sigma, kmax=kmax, out=dst)
-            dt = (time.perf_counter() - t0) / reps
-            out[kind] = {'value': round(n * n / dt / 1e6, 1), 'ms_per_call': round(dt * 1e3, 3)}
-    finally:
-        pass
+        dt = (time.perf_counter() - t0) / reps
+        out[kind] = {'value': round(n * n / dt / 1e6, 1), 'ms_per_call': round(dt * 1e3, 3)}
     plan.close()
     out['unit'] = 'Mpixels/s'
     out['note'] = ('one synchronous host-array call per image: H2D of the image + the step + D2H of u inside the timed call, nothing '

@@ -32,6 +32,10 @@
 #ifdef __cplusplus
 extern "C" {
 #endif
+/* the library is built with -fvisibility=hidden: these declarations are its whole dynamic symbol table (tests/test_abi.py) */
+#if defined(__GNUC__)
+#pragma GCC visibility push(default)
+#endif
 
 #define GPA_F32 0
 #define GPA_F64 1
@@ -53,7 +57,7 @@ int gpa_device_count(void);
  * the environment variables GPA_<NAME> as they were when the library was first used; after that
  * only this call changes them (the library never reads the environment on a call path).
  * Switches read at plan creation (NO_SHARED, NO_COMPACT, NO_KSPLIT, NO_MR, MR_FORCE_BLUESTEIN,
- * USE_GRAPH, SERIAL_UNWRAP, NO_WORKER) apply to plans created afterwards.  Process-wide.        */
+ * SERIAL_UNWRAP, NO_WORKER, DFT_ENGINE) apply to plans created afterwards.  Process-wide.        */
 int gpa_set_option(const char* name, const char* value);
 
 /* One plan = one device + one stream + workspace for images of shape (n0, n1)
@@ -416,6 +420,9 @@ int gpa_last_kernel_profile(gpa_plan* plan, char* out, size_t cap);
 int gpa_download_async(gpa_plan* plan, void* host_dst, const void* dev_src, size_t bytes, int slot);
 int gpa_download_wait(gpa_plan* plan, int slot);
 
+#if defined(__GNUC__)
+#pragma GCC visibility pop
+#endif
 #ifdef __cplusplus
 }
 #endif

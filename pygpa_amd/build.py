@@ -21,7 +21,9 @@ SOURCES = ['gpa_sweep.hip', 'gpa_passb_shared.hip', 'gpa_sweep_ext.hip', 'gpa_re
            'gpa_unwrap_tables.hip', 'gpa_dft2.hip', 'gpa_gaussfft.hip', 'gpa_warp.hip', 'gpa_tiles.hip', 'gpa_peaks.hip', 'gpa_api.hip', 'gpa_api_tables.hip', 'gpa_api_sweep.hip', 'gpa_api_unwrap.hip', 'gpa_api_driver.hip',
            'gpa_api_tiles.hip', 'gpa_api_warp.hip', 'gpa_api_spectral.hip']
 ARCH = 'gfx950'
-FLAGS = ['-O3', '-std=c++17', '-fPIC', '--offload-arch=' + ARCH, '-fno-gpu-rdc',
+# -fvisibility=hidden: the dynamic symbol table is the C ABI of include/gpa_hip.h (its declarations sit inside a visibility
+# pragma) and nothing else -- the helpers the entry-point files share cannot be interposed by another library of the process
+FLAGS = ['-O3', '-std=c++17', '-fPIC', '--offload-arch=' + ARCH, '-fno-gpu-rdc', '-fvisibility=hidden',
          '-Wno-unused-result', '-Wno-unused-value', '-ffp-contract=fast', '-fno-slp-vectorize']
 
 

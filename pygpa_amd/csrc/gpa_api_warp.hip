@@ -7,6 +7,20 @@
 // The host-pointer entry points of rounds 1-4 are these plus the copies.
 #include "gpa_plan.h"
 
+// windows of the output grid: every rect must have a positive size and touch the grid (a window that lies outside entirely is a
+// caller's mistake, not an empty request: ADVICE r05); windows that stick out are clipped by the kernels' launchers
+static int check_rects(const int* rects, int nrect, int o0, int o1, const char* who) {
+  if (nrect < 0 || (nrect > 0 && !rects)) return fail(GPA_ERR_ARG, std::string(who) + ": nrect windows need rects");
+  for (int q = 0; q < nrect; ++q) {
+    const int *r = rects + 4 * q;
+    if (r[2] <= 0 || r[3] <= 0 || r[0] >= o0 || r[1] >= o1 || r[0] + r[2] <= 0 || r[1] + r[3] <= 0)
+      return fail(GPA_ERR_ARG, std::string(who) + ": window " + std::to_string(q) + " {" + std::to_string(r[0]) + ", " + std::to_string(r[1]) +
+                                   ", " + std::to_string(r[2]) + ", " + std::to_string(r[3]) + "} is empty or outside the " +
+                                   std::to_string(o0) + " x " + std::to_string(o1) + " output grid");
+  }
+  return GPA_OK;
+}
+
 static int check_invert_args(gpa_plan* p, const void* u, void* out, int iters, int edge, int mode) {
   if (!p || !u || !out) return fail(GPA_ERR_ARG, "gpa_invert_u: null argument");
   if (iters < 1 || edge < 0) return fail(GPA_ERR_ARG, "gpa_invert_u: need iters >= 1, edge >= 0");
@@ -19,8 +33,9 @@ static int check_invert_args(gpa_plan* p, const void* u, void* out, int iters, i
 int gpa_invert_u_mode_dev(gpa_plan* p, const void* u_dev, double scale, int iters, int edge, int overlap, int mode,
                           const int* rects, int nrect, void* out_dev) {
   TRY(check_invert_args(p, u_dev, out_dev, iters, edge, mode));
-  if (nrect < 0 || (nrect > 0 && !rects)) return fail(GPA_ERR_ARG, "gpa_invert_u_mode_dev: nrect windows need rects");
+  TRY(check_rects(rects, nrect, p->n0 + (overlap ? 2 * edge : 0), p->n1 + (overlap ? 2 * edge : 0), "gpa_invert_u_mode_dev"));
   HIP_TRY(hipSetDevice(p->device));
+  p->warp.counted = &p->ws_bytes;
   ProfInstall prof(p);
   const hipError_t e = overlap ? warp_invert_u(p->dtype, u_dev, p->n0, p->n1, scale, iters, edge, 0, out_dev, p->stream, mode, 1, &p->warp, rects, nrect)
                                : warp_invert_u(p->dtype, u_dev, p->n0, p->n1, scale, iters, 0, edge, out_dev, p->stream, mode, 0, &p->warp, rects, nrect);
@@ -42,9 +57,13 @@ int gpa_undistort_image_dev(gpa_plan* p, const void* deformed_dev, const void* u
 int gpa_undistort_image_scaled_dev(gpa_plan* p, const void* deformed_dev, const void* u_dev, double scale, const int* rects,
                                    int nrect, void* uinv_dev, void* out_dev) {
   if (!p || !deformed_dev || !u_dev || !out_dev) return fail(GPA_ERR_ARG, "gpa_undistort_image_dev: null argument");
-  if (nrect < 0 || (nrect > 0 && !rects)) return fail(GPA_ERR_ARG, "gpa_undistort_image_dev: nrect windows need rects");
+  TRY(check_rects(rects, nrect, p->n0, p->n1, "gpa_undistort_image_dev"));
   HIP_TRY(hipSetDevice(p->device));
   ProfInstall prof(p);
+  // one reservation for the inversion AND the resampling (the first call used to grow the scratch twice, with a stream
+  // synchronisation and a free in between); counted in gpa_plan_workspace_bytes
+  p->warp.counted = &p->ws_bytes;
+  HIP_TRY(warp_reserve_undistort(p->dtype, p->n0, p->n1, &p->warp, p->stream));
   void* uinv = uinv_dev ? uinv_dev : p->d_dudx;   // (2 planes of n0 x n1 fit)
   HIP_TRY(warp_invert_u(p->dtype, u_dev, p->n0, p->n1, -scale, 35, 0, 0, uinv, p->stream, 0, 1, &p->warp, rects, nrect));
   HIP_TRY(warp_image(p->dtype, deformed_dev, uinv, p->n0, p->n1, out_dev, p->stream, &p->warp, rects, nrect));

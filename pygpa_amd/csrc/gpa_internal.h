@@ -262,8 +262,11 @@ struct WarpWs {
   size_t cap = 0;
   void* taps = nullptr;
   int taps_dtype = -1;
+  size_t* counted = nullptr;   // where the owner accounts the scratch (gpa_plan::ws_bytes), may be null
 };
 void warp_ws_free(WarpWs* ws);
+// scratch of one undistort_image call on an n0 x n1 grid (inversion + resampling): reserved in ONE allocation up front
+hipError_t warp_reserve_undistort(int dtype, int n0, int n1, WarpWs* ws, hipStream_t s);
 // rects = nrect x {r0, c0, h, w}: the windows of the output grid that are computed (nrect = 0: all of it) -- the tiles a
 // rank owns; the prefilter of the whole field runs once per call
 hipError_t warp_invert_u(int dtype, const void* d_u, int n0, int n1, double scale, int iters, int edge, int shift,

@@ -533,11 +533,13 @@ hipError_t reserve(WarpWs* ws, size_t bytes, hipStream_t s) {
   hipError_t e = hipStreamSynchronize(s);
   if (e != hipSuccess) return e;
   if (ws->buf) (void)hipFree(ws->buf);
+  if (ws->counted) *ws->counted -= ws->cap;
   ws->buf = nullptr;
   ws->cap = 0;
   e = hipMalloc(&ws->buf, bytes);
   if (e != hipSuccess) return e;
   ws->cap = bytes;
+  if (ws->counted) *ws->counted += bytes;
   return hipSuccess;
 }
 
@@ -673,10 +675,18 @@ hipError_t warp_t(const T* d_img, const T* d_uinv, int n0, int n1, T* d_out, hip
 
 }  // namespace
 
+hipError_t warp_reserve_undistort(int dtype, int n0, int n1, WarpWs* ws, hipStream_t s) {
+  const size_t rs = dtype == 0 ? 4 : 8;
+  return reserve(ws, 4 * (size_t)(n0 + 2 * NPAD) * (n1 + 2 * NPAD) * rs + 2 * (size_t)n0 * n1 * rs, s);
+}
+
 void warp_ws_free(WarpWs* ws) {
   if (ws->buf) (void)hipFree(ws->buf);
+  if (ws->buf && ws->counted) *ws->counted -= ws->cap;
   if (ws->taps) (void)hipFree(ws->taps);
+  size_t* counted = ws->counted;
   *ws = WarpWs{};
+  ws->counted = counted;
 }
 
 // d_u: 2 x n0 x n1 (device); the field that is inverted is scale * u; d_out: 2 x (n0+2e) x (n1+2e).  Enqueued on s, no

@@ -28,6 +28,20 @@ def test_header_symbols_exported():
         assert hasattr(lib, n), 'symbol %s declared in gpa_hip.h is not exported' % n
         assert n in _lib.SIGNATURES, 'symbol %s has no ctypes prototype' % n
     assert sorted(_lib.SIGNATURES) == names
+    # ... and nothing else: the library is built with -fvisibility=hidden, its dynamic symbol table is the header
+    import shutil
+    import subprocess
+    nm = shutil.which('nm') or shutil.which('llvm-nm') or '/opt/rocm/lib/llvm/bin/llvm-nm'
+    if os.path.exists(nm):
+        out = subprocess.run([nm, '-D', '--defined-only', _lib.LIB_PATH], capture_output=True, text=True).stdout
+        exported = sorted({ln.split()[-1] for ln in out.splitlines() if ln.split() and ln.split()[-2] in ('T', 'W', 'D', 'B', 'V')})
+        own = [e for e in exported if not e.startswith('__hip') and not e.startswith('_fini') and not e.startswith('_init')]
+        # (hipcc gives the host-side handles of __global__ kernels default visibility whatever the flag: mangled *_kernel names)
+        kernels = [e for e in own if e.startswith('_Z') and 'kernel' in e]
+        # (... and libstdc++'s own templates are declared with default visibility by its headers: weak std:: instantiations)
+        std = [e for e in own if re.match(r'_Z(Z?N?K?St|N9__gnu_cxx|T[ISV]|GV)', e)]
+        rest = sorted(set(own) - set(kernels) - set(std))
+        assert rest == names, sorted(set(rest) ^ set(names))[:20]
 
 
 def test_version_and_error_string():

@@ -441,6 +441,16 @@ def test_f1_device_entry_points_equal_host_entry_points(dtype):
                                     (r_split, c_split, shape[0] - r_split, shape[1] - c_split)])
     plan.sync()
     assert np.array_equal(d_rec2.get(), rec_host) and np.array_equal(d_uinv2.get(), uinv_host)
+    # a window that is empty or lies outside the grid is refused, not silently skipped; one that sticks out is clipped
+    before = plan.workspace_bytes
+    for bad in ((0, 0, 0, 5), (0, 0, 5, -1), (shape[0], 0, 4, 4), (0, shape[1] + 3, 4, 4), (-9, 0, 9, 4)):
+        with pytest.raises(_lib.GPAError):
+            plan.undistort_image_dev(d_img.ptr, d_u.ptr, d_rec2.ptr, uinv_ptr=d_uinv2.ptr, rects=bad)
+    plan.undistort_image_dev(d_img.ptr, d_u.ptr, d_rec2.ptr, uinv_ptr=d_uinv2.ptr, rects=(shape[0] - 10, shape[1] - 10, 50, 50))
+    plan.sync()
+    assert np.array_equal(d_rec2.get(), rec_host)
+    # the Lawler-Fujita scratch is part of the plan's reported workspace and does not grow from call to call
+    assert plan.workspace_bytes == before > 6 * u[0].nbytes
     # against the oracle (scipy.ndimage.map_coordinates, the reference's calls)
     if dtype is np.float64:      # (f32: a sample a few ulps from the 'constant' border may land on its other side, see above)
         ref = orc.undistort_image(deformed, u)

@@ -1,6 +1,6 @@
 #!/usr/bin/env python
 """Static instruction counts (total / VALU / LDS / VMEM / SALU / barriers) of the functions of one translation unit.
-usage: python tools/isa_counts.py gpa_sweep_mr [substring ...]   (substrings select demangled names)"""
+usage: python tools/isa_counts.py gpa_sweep [substring ...]   (substrings select demangled names)"""
 import os
 import re
 import subprocess

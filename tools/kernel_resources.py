@@ -1,6 +1,6 @@
 #!/usr/bin/env python
 """VGPRs / scratch / occupancy / LDS of every kernel of one translation unit, from hipcc's kernel-resource-usage remarks.
-usage: python tools/kernel_resources.py gpa_sweep_mr [filter-substring] [extra hipcc flags...]"""
+usage: python tools/kernel_resources.py gpa_sweep [filter-substring] [extra hipcc flags...]"""
 import re
 import subprocess
 import sys
