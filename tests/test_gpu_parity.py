@@ -491,7 +491,15 @@ def test_error_paths_and_extreme_shapes():
     with pytest.raises(_lib.GPAError):
         _lib.Plan((2, 64), 1, np.float32)                 # axis shorter than 4
     with pytest.raises(_lib.GPAError):
-        _lib.Plan((64, 20000), 1, np.float32)             # axis too long for an LDS-resident transform
+        _lib.Plan((64, 70000), 1, np.float32)             # axis longer than 65536
+    # an axis too long for an LDS-resident transform (round 6): the plan exists, for the plain-DFT rows and the per-pixel
+    # kernels; its sweep and unwrap entry points refuse with the reason
+    big = _lib.Plan((64, 20000), 1, np.float32)
+    with pytest.raises(_lib.GPAError, match='too large for the sweep'):
+        big.lockin_batch(np.zeros((64, 20000), dtype=np.float32), np.zeros((1, 2)), 5.0)
+    with pytest.raises(_lib.GPAError, match='too large for the sweep'):
+        big.unwrap(np.zeros((64, 20000), dtype=np.float32))
+    big.close()
     plan = _lib.Plan((64, 64), 2, np.float32)
     img = np.zeros((64, 64), dtype=np.float32)
     with pytest.raises(_lib.GPAError):
