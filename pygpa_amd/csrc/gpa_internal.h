@@ -72,7 +72,7 @@ enum OptKey {
   OPT_PBS_FULLBAND, OPT_SERIAL_UNWRAP, OPT_NO_WORKER, OPT_NO_KSPLIT, OPT_NO_COMPACT, OPT_NO_SHARED,
   OPT_NO_PAIR, OPT_PBS_E8, OPT_TRI_SMALL, OPT_TRI_Q, OPT_NO_MR, OPT_MR_FORCE_BLUESTEIN, OPT_NO_ROWPQ,
   OPT_COLSOLVE, OPT_NO_LAT, OPT_F32_EPS_FLOOR, OPT_COLSTREAM_CHUNK, OPT_NO_ROWHALF, OPT_PAIR_MAXSIDE, OPT_ROWHALF_MINLG, OPT_NO_PQDCT,
-  OPT_NO_REORDER, OPT_NO_RAW, OPT_NO_TILEFUSE, OPT_NO_ROWPERS, OPT_NO_LFTILE, OPT_LF_ALL_ROUNDS, OPT_DFT_ENGINE, OPT_GAUSS_FFT_MINR, OPT_NO_GAUSS2D, OPT_NO_DFT_HALF, OPT_F32_STALL, OPT_COUNT
+  OPT_NO_REORDER, OPT_NO_RAW, OPT_NO_TILEFUSE, OPT_NO_ROWPERS, OPT_NO_LFTILE, OPT_LF_ALL_ROUNDS, OPT_DFT_ENGINE, OPT_GAUSS_FFT_MINR, OPT_NO_GAUSS2D, OPT_NO_DFT_HALF, OPT_F32_STALL, OPT_PBS_LDS_PAD, OPT_COUNT
 };
 struct OptVal {
   bool set;

@@ -607,8 +607,11 @@ static hipError_t run_passB_shared(const Axis& a1, int n0, const void* Tbuf, con
                                    const PassBSharedTables& st, int E, int Epad, int P, int K, void* out, int32_t* kidx,
                                    hipStream_t s, int nimg, int Bx, bool raw) {
   using G = PassBSGeom<T, LG, EE>;
-  const size_t lds = G::lds_bytes(Epad);
+  size_t lds = G::lds_bytes(Epad);
   if (lds > 160 * 1024 || E > G::TPF || Epad > G::TPF) return hipErrorInvalidValue;
+  // (experiment switch PBS_LDS_PAD=<bytes>: extra dynamic LDS per workgroup, i.e. fewer rows per CU, so that kernels of other
+  //  streams -- the unwrap of the previous image, bench.py --inflight 2 -- can share the CUs with this one)
+  if (opt_set(OPT_PBS_LDS_PAD)) lds = std::min<size_t>(160 * 1024, lds + (size_t)opt(OPT_PBS_LDS_PAD).num);
   auto kern = passB_shared_kernel<T, LG, PADDED, EE, NBL>;
   // (the dynamic LDS size depends on Epad: raise the limit whenever a larger one comes along)
   static int lds_set[32] = {0};

@@ -261,3 +261,22 @@ def test_find_peaks_again_equals_a_fresh_evaluation(dtype):
     assert np.array_equal(cd, c0) and np.array_equal(vd, v0)
     buf.free()
     plan.close()
+
+
+@pytest.mark.parametrize('dtype', DTYPES)
+def test_per_dft_random_shapes_every_engine(dtype, gpa_option):
+    """seeded random shapes 4 ... 700 per axis (powers of two, smooth and prime lengths, odd row counts) through the engine the
+    library picks and through each forced chirp-z engine: the same oracle, the engine's tolerance"""
+    rng = np.random.default_rng(2026)
+    lengths = [4, 5, 7, 31, 64, 97, 128, 200, 256, 257, 360, 509, 512, 640, 700]
+    for draw in range(12):
+        shape = (int(rng.choice(lengths)), int(rng.choice(lengths)))
+        img = make_image(shape, seed=100 + draw)
+        for engine in (None, 'chirpz', 'chirpz2'):
+            gpa_option('DFT_ENGINE', engine)
+            plan = _lib.Plan(shape, 1, dtype)
+            phat = plan.per_dft(img)
+            plan.close()
+            picked = 'pow2' if engine is None and is_pow2(shape[0]) and is_pow2(shape[1]) else 'chirpz'
+            check_phat(phat, img, dtype, shape, picked)
+    gpa_option('DFT_ENGINE', None)

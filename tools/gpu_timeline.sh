@@ -2,14 +2,14 @@
 # usage (GPU box): tools/gpu_timeline.sh [size]  -> gpurun_out/timeline/timeline_<n>.txt
 # kernel timeline of the benchmark step (rocprofv3 --kernel-trace, the two unwrap streams as they really run): GPU-busy time
 # (union of the kernel intervals), time with >= 2 kernels in flight, the idle gaps, per-phase walls
-n=${1:-4096}
+n=${1:-4096}; dt=${2:-f32}
 out=gpurun_out/timeline; mkdir -p $out
 ROOT=$PWD
 cd /tmp && export TMPDIR=/tmp
-rocprofv3 --kernel-trace --output-format csv -d $ROOT/$out/kt -- python3 $ROOT/bench.py --size $n --steps 8 --warmup 2 --no-cpu --no-f64 > $ROOT/$out/log 2>&1
+rocprofv3 --kernel-trace --output-format csv -d $ROOT/$out/kt -- python3 $ROOT/bench.py --size $n --dtype $dt --steps 8 --warmup 2 --no-cpu --no-f64 --no-pipeline > $ROOT/$out/log 2>&1
 cd $ROOT
 f=$(ls $out/kt/*/*kernel_trace.csv | head -1)
-python3 - $f > $out/timeline_$n.txt <<'PY'
+python3 - $f > $out/timeline_${n}_$dt.txt <<'PY'
 import csv, sys, re, collections
 rows = list(csv.DictReader(open(sys.argv[1])))
 rows.sort(key=lambda r: int(r['Start_Timestamp']))
@@ -48,4 +48,4 @@ for k in range(mid, mid + 3):
             print('      %-28s n=%3d total %8.1f us  median %7.2f' % (nme, len(v), sum(v), sorted(v)[len(v) // 2]))
 PY
 rm -rf $out/kt
-cat $out/timeline_$n.txt
+cat $out/timeline_${n}_$dt.txt
