@@ -43,8 +43,10 @@ VALU_ISSUE_PEAK = 1024 * 2.4e9 / 2   # wave64 VALU instructions / s: one per 2 c
 def parse_args():
     ap = argparse.ArgumentParser()
     ap.add_argument('--gpus', type=int, default=1)
-    ap.add_argument('--steps', type=int, default=20)
-    ap.add_argument('--warmup', type=int, default=3)
+    # (defaults: the timed loop ends with the pipeline's drain -- the last image's D2H of u, 2.6 ms, overlaps nothing -- which
+    #  100 steps amortise to 0.5 % of a step where 20 steps left 2.4 %: tools/ab_steps.sh; the whole default run stays under a minute)
+    ap.add_argument('--steps', type=int, default=100)
+    ap.add_argument('--warmup', type=int, default=5)
     ap.add_argument('--size', type=int, default=4096)
     ap.add_argument('--kside', type=int, default=4, help='k-vectors per peak = kside^2')
     ap.add_argument('--kgrid', default=None, help='NXxNY candidate grid per peak (e.g. 4x2 for BASELINE config 2)')

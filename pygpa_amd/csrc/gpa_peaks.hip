@@ -57,24 +57,35 @@ __global__ __launch_bounds__(256) void gauss2d_small_kernel(const T* __restrict_
   T* tin = reinterpret_cast<T*>(g2_smem);          // [PH][PW]
   T* mid = tin + PH * PW;                          // [G2_TH][PW]
   const int i0 = blockIdx.y * G2_TH, j0 = blockIdx.x * G2_TW;
-  for (int e = threadIdx.x; e < PH * PW; e += 256) {
-    const int a = e / PW, b = e - a * PW;
-    tin[e] = in[(size_t)reflect_index(i0 - R + a, n0) * n1 + reflect_index(j0 - R + b, n1)];
+  // threads as 4 rows x 64 columns: no division by a run-time width anywhere, the row's reflection once per wavefront
+  const int tx = threadIdx.x & 63, ty = threadIdx.x >> 6;
+  int jc[2];
+#pragma unroll
+  for (int q = 0; q < 2; ++q) jc[q] = reflect_index(j0 - R + tx + 64 * q, n1);
+  for (int a = ty; a < PH; a += 4) {
+    const T* row = in + (size_t)reflect_index(i0 - R + a, n0) * n1;
+#pragma unroll
+    for (int q = 0; q < 2; ++q)
+      if (tx + 64 * q < PW) tin[a * PW + tx + 64 * q] = row[jc[q]];
   }
   __syncthreads();
-  for (int e = threadIdx.x; e < G2_TH * PW; e += 256) {
-    const int a = e / PW, b = e - a * PW;
-    const T* col = tin + (a + R) * PW + b;
-    double acc = (double)col[0] * w[R];
-    for (int k = R; k >= 1; --k) acc += ((double)col[-k * PW] + (double)col[k * PW]) * w[R - k];
-    mid[e] = (T)acc;
+  for (int a = ty; a < G2_TH; a += 4) {
+#pragma unroll
+    for (int q = 0; q < 2; ++q) {
+      const int b2 = tx + 64 * q;
+      if (b2 >= PW) continue;
+      const T* col = tin + (a + R) * PW + b2;
+      double acc = (double)col[0] * w[R];
+      for (int k = R; k >= 1; --k) acc += ((double)col[-k * PW] + (double)col[k * PW]) * w[R - k];
+      mid[a * PW + b2] = (T)acc;
+    }
   }
   __syncthreads();
-  for (int e = threadIdx.x; e < G2_TH * G2_TW; e += 256) {
-    const int a = e / G2_TW, b = e - a * G2_TW;
-    const int i = i0 + a, j = j0 + b;
+  const int j = j0 + tx;
+  for (int a = ty; a < G2_TH; a += 4) {
+    const int i = i0 + a;
     if (i >= n0 || j >= n1) continue;
-    const T* row = mid + a * PW + b + R;
+    const T* row = mid + a * PW + tx + R;
     double acc = (double)row[0] * w[R];
     for (int k = R; k >= 1; --k) acc += ((double)row[-k] + (double)row[k]) * w[R - k];
     const size_t o = (size_t)i * n1 + j;

@@ -35,6 +35,15 @@ WHAT="unwrap8192 unwrap16384 tiles16384 lf16384" bash $ROOT/tools/gpu_kstats.sh 
 cp $ROOT/gpurun_out/kstats/kernel_stats_unwrap_8192.csv $ROOT/gpurun_out/kstats/kernel_stats_unwrap_16384.csv $ROOT/gpurun_out/kstats/kernel_stats_tiles_16384.csv $ROOT/gpurun_out/kstats/kernel_stats_lf_16384.csv $out/ 2>/dev/null
 cd $ROOT && timeout 600 python3 tools/lf_times.py --sizes 2048 4096 8192 16384 > $out/lf_times.txt 2>&1; GPA_NO_LFTILE=1 timeout 600 python3 tools/lf_times.py --sizes 4096 16384 > $out/lf_times_rowkernel.txt 2>&1; cd /tmp
 cp $ROOT/gpurun_out/stage_times.json $out/ 2>/dev/null
+# round 6: the rows either side of the path -- the resident image -> k-vectors -> u -> undistortion -> properties leg with its
+# rocprofv3 summary, the same in f64, the NumPy-in / NumPy-out calls of a9 / f-2 / f-3 / f-4 under rocprofv3, the step's timeline
+cd $ROOT && bash tools/gpu_pipeline.sh 4096 f32 > $out/pipeline_4096_f32.txt 2>&1; bash tools/gpu_pipeline.sh 4096 f64 > $out/pipeline_4096_f64.txt 2>&1
+cp gpurun_out/pipeline/kernel_stats_pipeline_4096_f32.csv gpurun_out/pipeline/kernel_stats_pipeline_4096_f64.csv gpurun_out/pipeline/pipeline_4096_f32.json gpurun_out/pipeline/pipeline_4096_f64.json $out/ 2>/dev/null
+WHAT="next4096 next2048 next16384" NEXT_ARGS="--what per peaks deconv plane" bash tools/gpu_kstats.sh > $out/kstats_next.log 2>&1
+cp gpurun_out/kstats/kernel_stats_next_4096.csv gpurun_out/kstats/kernel_stats_next_2048.csv gpurun_out/kstats/kernel_stats_next_16384.csv $out/ 2>/dev/null
+grep -h "\^2 f" gpurun_out/kstats/ks_next_*.log > $out/next_rows_host_calls.txt 2>/dev/null
+bash tools/gpu_timeline.sh 4096 f32 > /dev/null 2>&1; bash tools/gpu_timeline.sh 4096 f64 > /dev/null 2>&1; cp gpurun_out/timeline/timeline_4096_f32.txt gpurun_out/timeline/timeline_4096_f64.txt $out/ 2>/dev/null
+cd /tmp
 cd $ROOT && timeout 600 bash tools/gpu_unwrap_sizes.sh > /dev/null 2>&1; cp gpurun_out/unwrap_sizes.txt $out/ 2>/dev/null
 SIZES="256 500 512 1000 1024 1500 2000 2048 3000 4096 8192 16384" timeout 900 bash tools/gpu_sizes.sh > /dev/null 2>&1; cp gpurun_out/sizes.txt $out/ 2>/dev/null
 cd /tmp
