@@ -146,8 +146,35 @@ int gpa_sweep_grad_dev(gpa_plan* p, const void* image, const double* kref, const
   const size_t npx = (size_t)p->n0 * p->n1;
   TRY(ensure_sf(p, (size_t)K * npx * p->rsz));
   int32_t* ki = kidx ? kidx : p->d_kidx;
-  TRY(sweep_one_peak(p, image, kref, klist, K, sigma, 3, lockin, ki, nullptr, p->d_sf));
-  HIP_TRY(launch_phasegrad(p->dtype, p->d_sf, K, ki, p->n0, p->n1, p->d_kl, p->d_kr, grad_mode, grad, p->stream));
+  // rows the shared-forward pass B takes (2048- / 4096- / f32 8192-point classes, lists with runs on their x-planes): one
+  // forward transform per x-plane row instead of one per candidate, the phases written by that kernel (round 6; NO_SHARED or
+  // NO_SHARED_PHASES keep the per-candidate kernel: the same gradient up to rounding, tests/test_gpu_shared_passb.py)
+  bool shared = false;
+  if (K <= p->max_batch && p->use_shared && !opt_set(OPT_NO_SHARED_PHASES)) {
+    TRY(ensure_filters(p, sigma));
+    std::vector<double> kr((size_t)K * 2);
+    for (int k = 0; k < K; ++k) { kr[2 * k] = kref[0]; kr[2 * k + 1] = kref[1]; }
+    int Bx = 0;
+    TRY(stage_kvectors(p, klist, kr.data(), K, &Bx));
+    TRY(shared_prepare(p, 1, K));
+    if (p->sh_use && p->sh_one_kref) {
+      TRY(ensure_tbuf(p, Bx));
+      TRY(run_passA(p, image, nullptr, p->Tbuf, Bx));
+      const hipError_t e = launch_passB_shared_phases(p->dtype, p->ax1s, p->n0, p->Tbuf, p->ax1s.L == p->ax1.L ? p->tw1 : p->tw1s,
+                                                      p->tb, p->sh, p->sh_E, p->sh_Epad, 1, K, lockin, ki, p->d_sf, p->stream, 0,
+                                                      p->sh_elems, p->sh_nbl);
+      if (e == hipSuccess) {
+        shared = true;
+        HIP_TRY(launch_phasegrad(p->dtype, p->d_sf, K, ki, p->n0, p->n1, p->d_kl, p->d_kr, grad_mode, grad, p->stream, p->d_ystep));
+      } else if (e != hipErrorInvalidValue) {
+        return fail(GPA_ERR_HIP, std::string("shared pass B (phases): ") + hipGetErrorString(e));
+      }
+    }
+  }
+  if (!shared) {
+    TRY(sweep_one_peak(p, image, kref, klist, K, sigma, 3, lockin, ki, nullptr, p->d_sf));
+    HIP_TRY(launch_phasegrad(p->dtype, p->d_sf, K, ki, p->n0, p->n1, p->d_kl, p->d_kr, grad_mode, grad, p->stream));
+  }
   if (top && p->profiling) { HIP_TRY(hipStreamSynchronize(p->stream)); collect_kernel_profile(p); }
   return GPA_OK;
 }

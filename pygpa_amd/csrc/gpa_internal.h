@@ -72,7 +72,7 @@ enum OptKey {
   OPT_PBS_FULLBAND, OPT_SERIAL_UNWRAP, OPT_NO_WORKER, OPT_NO_KSPLIT, OPT_NO_COMPACT, OPT_NO_SHARED,
   OPT_NO_PAIR, OPT_PBS_E8, OPT_TRI_SMALL, OPT_TRI_Q, OPT_NO_MR, OPT_MR_FORCE_BLUESTEIN, OPT_NO_ROWPQ,
   OPT_COLSOLVE, OPT_NO_LAT, OPT_F32_EPS_FLOOR, OPT_COLSTREAM_CHUNK, OPT_NO_ROWHALF, OPT_PAIR_MAXSIDE, OPT_ROWHALF_MINLG, OPT_NO_PQDCT,
-  OPT_NO_REORDER, OPT_NO_RAW, OPT_NO_TILEFUSE, OPT_NO_ROWPERS, OPT_NO_LFTILE, OPT_LF_ALL_ROUNDS, OPT_DFT_ENGINE, OPT_GAUSS_FFT_MINR, OPT_NO_GAUSS2D, OPT_NO_DFT_HALF, OPT_F32_STALL, OPT_PBS_LDS_PAD, OPT_COUNT
+  OPT_NO_REORDER, OPT_NO_RAW, OPT_NO_TILEFUSE, OPT_NO_ROWPERS, OPT_NO_LFTILE, OPT_LF_ALL_ROUNDS, OPT_DFT_ENGINE, OPT_GAUSS_FFT_MINR, OPT_NO_GAUSS2D, OPT_NO_DFT_HALF, OPT_F32_STALL, OPT_PBS_LDS_PAD, OPT_NO_SHARED_PHASES, OPT_COUNT
 };
 struct OptVal {
   bool set;
@@ -177,8 +177,10 @@ hipError_t launch_passB_split(int dtype, const Axis& a1, int n0, const void* Tbu
                               int32_t* kidx, hipStream_t s);
 // a4: phase gradient of the winner from the per-candidate phases (mode 0 np.gradient, 1 forward differences with
 // NaN at the end, 2 the same with swapped components)
+// ystep (device, one double) != null: psi holds the phases of the shared pass B (compensated along x, lacking the phasor
+// exp(i ystep y)): no 2 pi (w - k) is added, ystep is subtracted from the differences along y
 hipError_t launch_phasegrad(int dtype, const void* psi, int K, const int32_t* kidx, int n0, int n1, const double* kl,
-                            const double* kr, int mode, void* grad, hipStream_t s);
+                            const double* kr, int mode, void* grad, hipStream_t s, const double* ystep = nullptr);
 int passA_cols(int dtype, int lg);
 // frequency bin held by (thread, register) after the forward transform of length 2^lg
 int spec_index_rt(int lg, int tid, int reg, int elems = 16);   // elems: elements per thread of the transform (16 or 8)

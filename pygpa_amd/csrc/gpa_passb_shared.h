@@ -45,6 +45,9 @@ int passB_shared_nbl(int dtype, int need);
 hipError_t launch_passB_shared(int dtype, const Axis& a1, int n0, const void* Tbuf, const void* tw1, const SweepTables& tb,
                                const PassBSharedTables& st, int E, int Epad, int P, int K, void* out, int32_t* kidx,
                                hipStream_t s, int nimg = 1, int Bx = 0, int elems = 16, int nbl = 16, bool raw = false);
+hipError_t launch_passB_shared_phases(int dtype, const Axis& a1, int n0, const void* Tbuf, const void* tw1, const SweepTables& tb,
+                                      const PassBSharedTables& st, int E, int Epad, int P, int K, void* out, int32_t* kidx,
+                                      void* psi_out, hipStream_t s, int Bx, int elems, int nbl);
 // raw: the winners are left WITHOUT the candidate-independent compensation exp(2 pi i (ky + s_p / 16) y) (no second visit
 // of the rows: 0.8 GB less traffic at 4096^2 x 3); the consumer adds its phase step along y (launch_reconstruct_setup)
 

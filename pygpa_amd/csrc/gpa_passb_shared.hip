@@ -191,7 +191,11 @@ struct PassBSGeom {
 #ifndef GPA_PBS_L13_WAVES
 #define GPA_PBS_L13_WAVES 3   // 8192-point rows: one workgroup of 8 wavefronts per CU whatever the register budget
 #endif
-template <class T, int LG, bool PADDED, int EE, int NBL>
+// PSI (a4, round 6): -angle of EVERY candidate's row goes out as one real per pixel (psi_out[list position][row][y]) for the
+// phase-gradient stencil of wfr2_grad_opt (geometric_phase_analysis.py:763-813).  The values in registers are the lock-ins
+// WITHOUT the candidate-independent phasor exp(2 pi i (ky + s / 16) y) -- compensation along x included --, so the stencil
+// subtracts that phasor's phase step per column and needs no 2 pi (w - k) (launch_phasegrad, compensated form).
+template <class T, int LG, bool PADDED, int EE, int NBL, bool PSI = false>
 __global__ __launch_bounds__((PassBSGeom<T, LG, EE>::THREADS),
                              (EE == 8 ? (sizeof(T) == 8 ? GPA_PBS_E8_F64_WAVES : GPA_PBS_E8_WAVES)
                                       : (sizeof(T) == 8 ? GPA_PBS_F64_WAVES : (LG >= 13 ? GPA_PBS_L13_WAVES : (PADDED ? GPA_PBS_PAD_WAVES : GPA_PBS_F32_WAVES))))) void passB_shared_kernel(
@@ -199,7 +203,7 @@ __global__ __launch_bounds__((PassBSGeom<T, LG, EE>::THREADS),
     const int* __restrict__ planeof, const int* __restrict__ order, const int* __restrict__ desc, const cpx<T>* __restrict__ pre_g,
     const cpx<T>* __restrict__ psi, const T* __restrict__ gtab, const cpx<T>* __restrict__ dx,
     const cpx<T>* __restrict__ dyc, const cpx<T>* __restrict__ rot16, int K, int E, int Epad, cpx<T>* out,
-    int32_t* kidx, int P, int Bx, int raw) {
+    int32_t* kidx, int P, int Bx, int raw, T* __restrict__ psi_out) {
   using F = WgFFT<T, LG, EE>;
   using G = PassBSGeom<T, LG, EE>;
   using V4 = typename MfmaVec<T>::type;
@@ -447,10 +451,20 @@ __global__ __launch_bounds__((PassBSGeom<T, LG, EE>::THREADS),
     if constexpr (PREFETCH) {
       if (k + 1 < K) load_gb<T, TPF, NBL>(h, Gb + (size_t)(b + 1) * (NBL * TPF), tid);
     }
+    const int kout = ob - pt * K;
+    if constexpr (PSI) {
+      if (valid) {
+        T* prow = psi_out + ((size_t)(p * K + kout) * n0 + rr) * n1;
+#pragma unroll
+        for (int i = 0; i < EE; ++i) {
+          const int yy = tid + TPF * i;
+          if (!PADDED || yy < n1) prow[yy] = -atan2(y[i].y, y[i].x);
+        }
+      }
+    }
     // ---- strict '>' in visiting order; the winner goes to memory at once ------------------------------------
     // (a register none of whose 64 lanes wins issues no store at all: with the likeliest winners visited first that is
     //  most registers of most candidates -- GPA_PBS_WAVESKIP=0 restores the sixteen dropped-offset stores per candidate)
-    const int kout = ob - pt * K;
 #pragma unroll
     for (int i = 0; i < EE; ++i) {
       const int yy = tid + TPF * i;
@@ -602,17 +616,17 @@ hipError_t launch_shared_tables(int dtype, const Axis& a1, const double* wys, co
   return hipErrorInvalidValue;
 }
 
-template <class T, int LG, bool PADDED, int EE, int NBL>
+template <class T, int LG, bool PADDED, int EE, int NBL, bool PSI = false>
 static hipError_t run_passB_shared(const Axis& a1, int n0, const void* Tbuf, const void* tw1, const SweepTables& tb,
                                    const PassBSharedTables& st, int E, int Epad, int P, int K, void* out, int32_t* kidx,
-                                   hipStream_t s, int nimg, int Bx, bool raw) {
+                                   hipStream_t s, int nimg, int Bx, bool raw, void* psi_out = nullptr) {
   using G = PassBSGeom<T, LG, EE>;
   size_t lds = G::lds_bytes(Epad);
   if (lds > 160 * 1024 || E > G::TPF || Epad > G::TPF) return hipErrorInvalidValue;
   // (experiment switch PBS_LDS_PAD=<bytes>: extra dynamic LDS per workgroup, i.e. fewer rows per CU, so that kernels of other
   //  streams -- the unwrap of the previous image, bench.py --inflight 2 -- can share the CUs with this one)
   if (opt_set(OPT_PBS_LDS_PAD)) lds = std::min<size_t>(160 * 1024, lds + (size_t)opt(OPT_PBS_LDS_PAD).num);
-  auto kern = passB_shared_kernel<T, LG, PADDED, EE, NBL>;
+  auto kern = passB_shared_kernel<T, LG, PADDED, EE, NBL, PSI>;
   // (the dynamic LDS size depends on Epad: raise the limit whenever a larger one comes along)
   static int lds_set[32] = {0};
   int dev = 0;
@@ -623,10 +637,10 @@ static hipError_t run_passB_shared(const Axis& a1, int n0, const void* Tbuf, con
     lds_set[dev & 31] = (int)lds;
   }
   dim3 grid((n0 + G::NF - 1) / G::NF, P * nimg);
-  GPA_PROF("passB_shared_kernel", s);
+  GPA_PROF(PSI ? "passB_shared_phases_kernel" : "passB_shared_kernel", s);
   kern<<<grid, G::THREADS, lds, s>>>((const cpx<T>*)Tbuf, n0, a1.n, (const T*)st.Gb, (const cpx<T>*)tw1, tb.planeof, st.order, st.desc,
                                      (const cpx<T>*)st.pre, (const cpx<T>*)st.psi, (const T*)st.gtab, (const cpx<T>*)tb.dx,
-                                     (const cpx<T>*)st.dyc, (const cpx<T>*)st.rot16, K, E, Epad, (cpx<T>*)out, kidx, P, Bx, raw ? 1 : 0);
+                                     (const cpx<T>*)st.dyc, (const cpx<T>*)st.rot16, K, E, Epad, (cpx<T>*)out, kidx, P, Bx, raw ? 1 : 0, (T*)psi_out);
   return hipGetLastError();
 }
 
@@ -665,6 +679,27 @@ int passB_shared_nbl(int dtype, int need) {
   if (dtype == 0 && need <= 6) return 6;
   if (need <= 8) return 8;
   return 16;
+}
+
+// the a4 form: the same sweep, and -angle of every candidate's lock-in (without the candidate-independent phasor along y) into
+// psi_out [P][K (list positions)][n0][n1] reals.  Instantiated for the row classes the pipeline uses (2048 / 4096 / f32 8192).
+hipError_t launch_passB_shared_phases(int dtype, const Axis& a1, int n0, const void* Tbuf, const void* tw1, const SweepTables& tb,
+                                      const PassBSharedTables& st, int E, int Epad, int P, int K, void* out, int32_t* kidx,
+                                      void* psi_out, hipStream_t s, int Bx, int elems, int nbl) {
+  if (!psi_out || !kidx) return hipErrorInvalidValue;
+#define CALL_P(T, LG, EE, NBL) \
+  (a1.padded ? run_passB_shared<T, LG, true, EE, NBL, true>(a1, n0, Tbuf, tw1, tb, st, E, Epad, P, K, out, kidx, s, 1, Bx, false, psi_out) \
+             : run_passB_shared<T, LG, false, EE, NBL, true>(a1, n0, Tbuf, tw1, tb, st, E, Epad, P, K, out, kidx, s, 1, Bx, false, psi_out))
+#define CASE_P(LG, EE, NBL) \
+  if (a1.lg == LG && elems == EE && nbl == NBL) return dtype == 0 ? CALL_P(float, LG, EE, NBL) : CALL_P(double, LG, EE, NBL);
+#define CASE_PF32(LG, EE, NBL) \
+  if (a1.lg == LG && elems == EE && nbl == NBL && dtype == 0) return CALL_P(float, LG, EE, NBL);
+  CASE_PF32(11, 16, 6) CASE_PF32(12, 16, 6) CASE_PF32(13, 16, 6) CASE_PF32(13, 16, 8) CASE_PF32(13, 16, 16)
+  CASE_P(11, 16, 8) CASE_P(12, 16, 8) CASE_P(11, 16, 16) CASE_P(12, 16, 16)
+#undef CASE_PF32
+#undef CASE_P
+#undef CALL_P
+  return hipErrorInvalidValue;
 }
 
 hipError_t launch_passB_shared(int dtype, const Axis& a1, int n0, const void* Tbuf, const void* tw1, const SweepTables& tb,

@@ -21,7 +21,8 @@ namespace gpa {
 template <class T>
 __global__ __launch_bounds__(256) void phasegrad_kernel(const T* __restrict__ psi, int K, const int32_t* __restrict__ kidx,
                                                        int n0, int n1, const double* __restrict__ kl,
-                                                       const double* __restrict__ kr, int mode, T* __restrict__ grad) {
+                                                       const double* __restrict__ kr, int mode, T* __restrict__ grad,
+                                                       const double* __restrict__ ystep) {
   const int y = blockIdx.x * 256 + threadIdx.x, x = blockIdx.y;
   if (y >= n1) return;
   const size_t npx = (size_t)n0 * n1, o = (size_t)x * n1 + y;
@@ -41,8 +42,14 @@ __global__ __launch_bounds__(256) void phasegrad_kernel(const T* __restrict__ ps
       g1 = y + 1 < n1 ? pl[o + 1] - c : nan;
     }
     const T two_pi = T(6.28318530717958647692), pi = T(3.14159265358979323846);
-    g0 += (T)(6.28318530717958647692 * (kl[2 * bi] - kr[2 * bi]));
-    g1 += (T)(6.28318530717958647692 * (kl[2 * bi + 1] - kr[2 * bi + 1]));
+    if (ystep) {
+      // compensated form (the shared pass B's phases): psi is -angle of the lock-in compensated along x and lacking only the
+      // candidate-independent phasor exp(i ystep y): the compensated phase differs by -ystep per column, and 2 pi (w - k) is in it
+      g1 = (T)((double)g1 - ystep[0]);
+    } else {
+      g0 += (T)(6.28318530717958647692 * (kl[2 * bi] - kr[2 * bi]));
+      g1 += (T)(6.28318530717958647692 * (kl[2 * bi + 1] - kr[2 * bi + 1]));
+    }
     // wrapToPi(2 g) / 2 with the floored modulo of mathtools.py:72-75
     const T t0 = T(2) * g0 + pi, t1 = T(2) * g1 + pi;
     g0 = T(0.5) * (t0 - two_pi * floor(t0 / two_pi) - pi);
@@ -53,13 +60,13 @@ __global__ __launch_bounds__(256) void phasegrad_kernel(const T* __restrict__ ps
 }
 
 hipError_t launch_phasegrad(int dtype, const void* psi, int K, const int32_t* kidx, int n0, int n1, const double* kl,
-                            const double* kr, int mode, void* grad, hipStream_t s) {
+                            const double* kr, int mode, void* grad, hipStream_t s, const double* ystep) {
   dim3 grid((n1 + 255) / 256, n0);
   GPA_PROF("phasegrad_kernel", s);
   if (dtype == 0)
-    phasegrad_kernel<float><<<grid, 256, 0, s>>>((const float*)psi, K, kidx, n0, n1, kl, kr, mode, (float*)grad);
+    phasegrad_kernel<float><<<grid, 256, 0, s>>>((const float*)psi, K, kidx, n0, n1, kl, kr, mode, (float*)grad, ystep);
   else
-    phasegrad_kernel<double><<<grid, 256, 0, s>>>((const double*)psi, K, kidx, n0, n1, kl, kr, mode, (double*)grad);
+    phasegrad_kernel<double><<<grid, 256, 0, s>>>((const double*)psi, K, kidx, n0, n1, kl, kr, mode, (double*)grad, ystep);
   return hipGetLastError();
 }
 

@@ -368,3 +368,51 @@ def test_aliased_candidates_bit_equal_amplitudes_keep_list_order(dtype, gpa_opti
     folded = np.where(ref['kidx'] == late, early, ref['kidx'])
     check_kidx(kidx, folded, img0, klist, sigma, TOL[dtype]['tie'])
     assert (kidx == folded).mean() > 0.9999
+
+
+@pytest.mark.parametrize('dtype', DTYPES)
+@pytest.mark.parametrize('shape,grid', [((64, 2048), (4, 4)), ((48, 4096), (4, 4)), ((40, 3000), (3, 3)), ((36, 8192), (4, 2))])
+def test_a4_gradient_through_the_shared_forward_kernel(shape, grid, dtype, gpa_option):
+    """round 6: wfr2_grad_opt (geometric_phase_analysis.py:763-813) on rows the shared-forward pass B takes -- the phases of
+    every candidate written by that kernel (one forward transform per x-plane row instead of one per candidate), the stencil
+    on phases that lack only the candidate-independent phasor along y -- against the oracle (modulo the pi-periodic wrap of
+    wrapToPi(2 g) / 2), against the per-candidate kernel (NO_SHARED_PHASES=1), for np.gradient and the two 'diff' spellings;
+    which kernel ran is asserted from the kernel profile"""
+    if dtype is np.float64 and shape[1] > 4096:
+        pytest.skip('f64 rows of the 8192-point class stay on the per-candidate kernel')
+    img0, kref, klist, sigma = _case(shape, *grid, seed=12)
+    ref = orc.sweep(img0, sigma, klist, kref, want_grad=True, workers=8)
+
+    def run(mode):
+        plan = _lib.Plan(shape, len(klist), dtype)
+        plan.set_profiling(True)
+        out = plan.sweep(img0, kref, klist, sigma, want_grad=True, grad_mode=mode)
+        prof = plan.last_kernel_profile()
+        plan.close()
+        return out, prof
+
+    (lock, kidx, grad), prof = run(0)
+    assert 'passB_shared_phases_kernel' in prof, sorted(prof)
+    check_kidx(kidx, ref['kidx'], img0, klist, sigma, TOL[dtype]['tie'])
+    same = kidx == ref['kidx']
+    assert same.mean() > 0.9999
+    assert rel(lock[same], ref['lockin'][same]) < TOL[dtype]['lock']
+    amp = np.abs(ref['lockin'])
+    ok = same & (amp > 1e-3 * amp.max())
+    d = orc.wrap_to_pi(2 * (grad.astype(np.float64) - ref['grad'])) / 2
+    assert np.abs(d[ok]).max() < (1e-9 if dtype is np.float64 else 2e-3)
+    gpa_option('NO_SHARED_PHASES', '1')
+    for mode in (0, 1, 2):
+        (lock_p, kidx_p, grad_p), prof_p = run(mode)
+        assert 'passB_shared_phases_kernel' not in prof_p and 'passB_kernel' in prof_p
+        gpa_option('NO_SHARED_PHASES', None)
+        (lock_s, kidx_s, grad_s), _ = run(mode)
+        gpa_option('NO_SHARED_PHASES', '1')
+        both = (kidx_s == kidx_p) & (amp > 1e-3 * amp.max())
+        assert (kidx_s == kidx_p).mean() > 0.9999
+        ds = orc.wrap_to_pi(2 * (grad_s.astype(np.float64) - grad_p.astype(np.float64))) / 2
+        if mode:      # forward differences: NaN in the last row / column of the matching component, in both
+            assert np.array_equal(np.isnan(grad_s), np.isnan(grad_p))
+            both &= ~np.isnan(ds).any(axis=-1)
+        assert np.abs(ds[both]).max() < (1e-9 if dtype is np.float64 else 4e-3), mode
+    gpa_option('NO_SHARED_PHASES', None)
