@@ -237,11 +237,12 @@ def csrc_sha256():
     return h.hexdigest()[:16]
 
 
-def load_counters():
-    """per-launch PMC figures of the committed rocprofv3 passes (profiles/counters.json): HBM bytes
-    (FETCH_SIZE doubled per the microarch guide + WRITE_SIZE) and VALU wave-instructions per kernel.
+def load_counters(name='counters.json'):
+    """per-launch PMC figures of the committed rocprofv3 passes (profiles/counters.json; the f64 leg: counters_f64.json,
+    FETCH_SIZE / WRITE_SIZE only): HBM bytes (FETCH_SIZE doubled per the microarch guide + WRITE_SIZE) and VALU
+    wave-instructions per kernel.
     REFUSED (empty: traffic null) when the file was measured on other kernel sources than this tree's."""
-    path = os.path.join(ROOT, 'profiles', 'counters.json')
+    path = os.path.join(ROOT, 'profiles', name)
     try:
         c = json.load(open(path))
     except Exception:
@@ -300,7 +301,7 @@ def kernel_table(n, L0, L1, P, K, Bx, s, iters, kern, stage, res_s):
     out = {}
     models = kernel_models(n, n, L0, L1, P, K, Bx, s, iters)
     valu_peak = VALU_PEAK_TFLOPS if s == 4 else VALU_PEAK_TFLOPS_F64     # the vector peak of the precision the path computes in
-    counters = load_counters()
+    counters = load_counters('counters.json' if s == 4 else 'counters_f64.json')
     stale = counters.pop('_stale', None)
     meta = counters.get('_meta', {})
     same_cfg = meta.get('config', {'n': 4096, 'K': 16, 'dtype': 'f32'}) == {'n': n, 'K': K, 'dtype': 'f32' if s == 4 else 'f64'}

@@ -76,5 +76,6 @@ for set in "FETCH_SIZE" "WRITE_SIZE"; do
   j=$((j+1))
 done
 COMMIT=${COMMIT:-unknown} PMC_DTYPE=f64 python3 tools/make_counters.py $out/counters_f64.json $out/pmc64_[0-9] > /dev/null
+cp $out/counters_f64.json $ROOT/profiles/counters_f64.json
 rm -rf $out/pmc_[0-9] $out/pmc64_[0-9]
 bench_line
