@@ -13,7 +13,7 @@ static const char* const kOptNames[OPT_COUNT] = {
     "PBS_FULLBAND", "SERIAL_UNWRAP", "NO_WORKER", "NO_KSPLIT", "NO_COMPACT", "NO_SHARED",
     "NO_PAIR", "PBS_E8", "TRI_SMALL", "TRI_Q", "NO_MR", "MR_FORCE_BLUESTEIN", "NO_ROWPQ", "COLSOLVE", "NO_LAT",
     "F32_EPS_FLOOR", "COLSTREAM_CHUNK", "NO_ROWHALF", "PAIR_MAXSIDE", "ROWHALF_MINLG", "NO_PQDCT",
-    "NO_REORDER", "NO_RAW", "NO_TILEFUSE", "NO_ROWPERS", "NO_LFTILE", "LF_ALL_ROUNDS", "DFT_ENGINE", "GAUSS_FFT_MINR", "NO_GAUSS2D", "NO_DFT_HALF", "F32_STALL", "PBS_LDS_PAD", "NO_SHARED_PHASES"};
+    "NO_REORDER", "NO_RAW", "NO_TILEFUSE", "NO_ROWPERS", "NO_LFTILE", "LF_ALL_ROUNDS", "DFT_ENGINE", "GAUSS_FFT_MINR", "NO_GAUSS2D", "NO_DFT_HALF", "F32_STALL", "PBS_LDS_PAD", "NO_SHARED_PHASES", "PA_STAG", "PA_STAG_TICKS", "PA_ROT"};
 static OptVal g_opts[OPT_COUNT];
 static std::once_flag g_opts_once;
 static void opt_assign(OptVal& o, const char* value) {

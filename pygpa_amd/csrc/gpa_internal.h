@@ -64,6 +64,20 @@ inline hipError_t set_dynamic_lds_once(const void* kern, int bytes, unsigned& do
   return e;
 }
 
+// compute units of the current device (one slot per device index)
+inline int device_cus() {
+  static int n[32] = {};
+  int dev = 0;
+  (void)hipGetDevice(&dev);
+  int& slot = n[dev & 31];
+  if (!slot) {
+    int cus = 0;
+    if (hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || cus <= 0) cus = 256;
+    slot = cus;
+  }
+  return slot;
+}
+
 // ---- run-time options (gpa_set_option, include/gpa_hip.h) ---------------------------------------
 // Diagnostic / test switches of the library.  The table is filled ONCE from the environment (GPA_<NAME>) when the
 // library first looks at it and changed afterwards only through gpa_set_option(): no getenv() on any call path.
@@ -72,7 +86,7 @@ enum OptKey {
   OPT_PBS_FULLBAND, OPT_SERIAL_UNWRAP, OPT_NO_WORKER, OPT_NO_KSPLIT, OPT_NO_COMPACT, OPT_NO_SHARED,
   OPT_NO_PAIR, OPT_PBS_E8, OPT_TRI_SMALL, OPT_TRI_Q, OPT_NO_MR, OPT_MR_FORCE_BLUESTEIN, OPT_NO_ROWPQ,
   OPT_COLSOLVE, OPT_NO_LAT, OPT_F32_EPS_FLOOR, OPT_COLSTREAM_CHUNK, OPT_NO_ROWHALF, OPT_PAIR_MAXSIDE, OPT_ROWHALF_MINLG, OPT_NO_PQDCT,
-  OPT_NO_REORDER, OPT_NO_RAW, OPT_NO_TILEFUSE, OPT_NO_ROWPERS, OPT_NO_LFTILE, OPT_LF_ALL_ROUNDS, OPT_DFT_ENGINE, OPT_GAUSS_FFT_MINR, OPT_NO_GAUSS2D, OPT_NO_DFT_HALF, OPT_F32_STALL, OPT_PBS_LDS_PAD, OPT_NO_SHARED_PHASES, OPT_COUNT
+  OPT_NO_REORDER, OPT_NO_RAW, OPT_NO_TILEFUSE, OPT_NO_ROWPERS, OPT_NO_LFTILE, OPT_LF_ALL_ROUNDS, OPT_DFT_ENGINE, OPT_GAUSS_FFT_MINR, OPT_NO_GAUSS2D, OPT_NO_DFT_HALF, OPT_F32_STALL, OPT_PBS_LDS_PAD, OPT_NO_SHARED_PHASES, OPT_PA_STAG, OPT_PA_STAG_TICKS, OPT_PA_ROT, OPT_COUNT
 };
 struct OptVal {
   bool set;

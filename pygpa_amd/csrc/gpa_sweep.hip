@@ -201,7 +201,8 @@ __global__ __launch_bounds__((PassAGeom<T, LG>::THREADS)) void passA_kernel(
     const cpx<T>* __restrict__ cxb, const cpx<T>* __restrict__ sx, const cpx<T>* __restrict__ wxw,
     const cpx<T>* __restrict__ wxr, int extL, int extR,
     const typename HType<PADDED, T>::type* __restrict__ H,
-    const cpx<T>* __restrict__ twtab, cpx<T>* __restrict__ Tout, int B, int bchunk) {
+    const cpx<T>* __restrict__ twtab, cpx<T>* __restrict__ Tout, int B, int bchunk, int stag_phases, int stag_ticks,
+    int stag_first, int rot_mul) {
   using F = WgFFT<T, LG>;
   using G = PassAGeom<T, LG>;
   constexpr int CT = G::CT, NT = G::NT, TPF = F::TPF, L = F::L;
@@ -214,7 +215,14 @@ __global__ __launch_bounds__((PassAGeom<T, LG>::THREADS)) void passA_kernel(
   // XCD-aware tile order: workgroups b, b+8, b+16, ... share an XCD (round-robin
   // dispatch), so give each XCD a contiguous run of column tiles -- the tiles that
   // share a 128-byte line of the output then meet in one L2 and leave it as whole lines.
-  const int tile = xcd_tile(blockIdx.x, gridDim.x);
+  int tile = xcd_tile(blockIdx.x, gridDim.x);
+  if (stag_phases < 0) {
+    // experiment (PA_STAG=-q): groups of q lines' worth of tiles dealt round-robin over the XCDs instead of one contiguous run
+    // of tiles per XCD (the column strip an XCD writes then spans the whole row instead of 1 KB of it)
+    constexpr int TPL0 = (128 / (int)(G::C * sizeof(cpx<T>))) > 0 ? (128 / (int)(G::C * sizeof(cpx<T>))) : 1;
+    const int g = TPL0 * -stag_phases, x = blockIdx.x & 7, idx = blockIdx.x >> 3;
+    if (gridDim.x % (8 * g) == 0) tile = ((idx / g) * 8 + x) * g + idx % g;
+  }
   const int y0 = tile * G::C + c * NT;
   // image stacks: blockIdx.z = image, its B planes behind those of the image before
   image += (size_t)blockIdx.z * n0 * n1;
@@ -236,10 +244,31 @@ __global__ __launch_bounds__((PassAGeom<T, LG>::THREADS)) void passA_kernel(
   }
   typename F::KTw tw;
   F::load_twiddles(tw, twtab, t);
+  if (stag_phases > 1 && (int)blockIdx.x < stag_first) {
+    // phase stagger (PA_STAG): the workgroups that assemble one 128-byte line of an x-plane stay in step, but the lines'
+    // owners start their plane loops 1/phases of a plane period apart, so that the drain of one group of CUs meets the
+    // transforms of another instead of the whole chip storing -- and then computing -- at once.  Only the first wave of
+    // workgroups waits; the later ones inherit the phase of the workgroup whose CU they take over.
+    constexpr int TPL = (128 / (int)(G::C * sizeof(cpx<T>))) > 0 ? (128 / (int)(G::C * sizeof(cpx<T>))) : 1;
+    const int ph = (tile / TPL) % stag_phases;
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    if (ph) {
+      const unsigned long long t0 = wall_clock64(), wait = (unsigned long long)ph * (unsigned)stag_ticks;
+      while (wall_clock64() - t0 < wait) __builtin_amdgcn_s_sleep(4);
+    }
+    __syncthreads();
+  }
 
   const int b0 = blockIdx.y * bchunk;
   const int b1 = (b0 + bchunk < B) ? b0 + bchunk : B;
-  for (int b = b0; b < b1; ++b) {
+  // plane rotation (PA_ROT=<m>, default 1 for transforms of 4096 points and more, 0 = off): the owners of line q start their
+  // plane loop at plane (q m) mod nb.  The workgroups of this kernel run in step (one per CU, same work), so without it the whole
+  // chip stores 32-byte row pieces of ONE plane at a time, 32 KB apart; spread over the planes (128 MB apart) the same stores
+  // drain in 3.5 instead of 6.2 us per plane: 0.81 -> 0.68 ms at 4096^2 f32, 1.77 -> 1.61 f64 (profiles/r06_passA_rotation.txt).
+  // Every plane is computed exactly as before; only the order differs.
+  const int nb = b1 - b0;
+  int b = b0 + (nb > 0 ? (int)(((unsigned)(tile * G::C * (int)sizeof(cpx<T>) / 128) * (unsigned)rot_mul) % (unsigned)nb) : 0);
+  for (int j = 0; j < nb; ++j, b = (b + 1 < b1 ? b + 1 : b0)) {
     F::refresh(tw);
     const cpx<T> base = cxb[(size_t)b * TPF + t];
     cpx<T> x[NT][16];
@@ -271,16 +300,21 @@ __global__ __launch_bounds__((PassAGeom<T, LG>::THREADS)) void passA_kernel(
       // when the row pitch keeps that store naturally aligned
       if (y0 + 1 < n1 && (n1 & 1) == 0) {
         paired = true;
-#pragma unroll
-        for (int i = 0; i < 16; ++i) {
+        struct alignas(2 * sizeof(cpx<T>)) Pair { cpx<T> a, b; };
+        auto put = [&](int i) {
           const int slot = t + TPF * i;
-#ifdef GPA_PA_NOSTORE
-          if (i > 0) continue;   // diagnosis only
-#endif
           if (!PADDED || slot < n0) {
-            struct alignas(2 * sizeof(cpx<T>)) Pair { cpx<T> a, b; };
             Pair pr = {x[0][i], x[1][i]};
             *reinterpret_cast<Pair*>(&Tout[((size_t)b * n0 + slot) * n1 + y0]) = pr;
+          }
+        };
+        {
+#pragma unroll
+          for (int i = 0; i < 16; ++i) {
+#ifdef GPA_PA_NOSTORE
+            if (i > 0) continue;   // diagnosis only
+#endif
+            put(i);
           }
         }
       }
@@ -323,11 +357,15 @@ static hipError_t run_passA(const Axis& a0, int n1, const void* image, const voi
     if (ysplit > B) ysplit = B;
     const int bchunk = (B + ysplit - 1) / ysplit;
     dim3 grid(tiles, (B + bchunk - 1) / bchunk, nimg);
+    // PA_STAG=<phases> [PA_STAG_TICKS=<10-ns ticks per phase step>]: see the kernel
+    const int stag = opt_set(OPT_PA_STAG) ? (int)opt(OPT_PA_STAG).num : 0;
+    const int stag_ticks = opt_set(OPT_PA_STAG_TICKS) ? (int)opt(OPT_PA_STAG_TICKS).num : 800 / (stag > 1 ? stag : 1);
     GPA_PROF("passA_kernel", s);
     kern<<<grid, G::THREADS, G::LDS_BYTES, s>>>(
         (const T*)image, (const T*)mean, a0.n, n1, (const cpx<T>*)tb.cxb, (const cpx<T>*)tb.sx,
         (const cpx<T>*)tb.wxw, (const cpx<T>*)tb.wxr, a0.extL, a0.extR,
-        (const typename HType<PADDED, T>::type*)Hx, (const cpx<T>*)tw0, (cpx<T>*)Tbuf, B, bchunk);
+        (const typename HType<PADDED, T>::type*)Hx, (const cpx<T>*)tw0, (cpx<T>*)Tbuf, B, bchunk, stag,
+        stag_ticks, device_cus(), opt_set(OPT_PA_ROT) ? (int)opt(OPT_PA_ROT).num : (LG >= 12 ? 1 : 0));
     return hipGetLastError();
   }
 }
