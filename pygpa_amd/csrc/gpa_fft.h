@@ -375,6 +375,79 @@ struct WgFFT {
   }
   GPA_HD static void refresh(TwiddlesP1Lds&) {}
 
+  // The general form of TwiddlesP1Lds for three- and four-pass transforms: pass 0 in registers, EVERY later twiddled pass from
+  // a small LDS table (pass p: [S_p][6] complex, S_p = distinct m0 of the pass; 8192 points: 64 + 8 sets = 3.4 KB).  What a
+  // kernel at its register limit wants: the persistent 16384-point row kernels keep two phase tables in registers instead.
+  struct TwiddlesLds {
+    cpx<T> lo[GMAX][3], hi[GMAX][3];
+    const cpx<T>* t;   // tables of passes 1 .. P-2, one after the other
+    int tid;
+  };
+  static constexpr int pass_sets(int p) { return 1 << (lg_len(p) - bits(p)); }
+  static constexpr int lds_table_offset(int p) {   // in complex elements, p >= 1
+    int o = 0;
+    for (int q = 1; q < p; ++q) o += pass_sets(q) * 6;
+    return o;
+  }
+  static constexpr int LDS_TABLE_ELEMS = P > 2 ? lds_table_offset(P - 1) : 1;
+  GPA_HD static void fill_lds_tables(cpx<T>* t, const cpx<T>* __restrict__ table, int thread, int nthreads) {
+    static_assert(P >= 3, "TwiddlesLds: three- and four-pass transforms");
+    fill_one_table<1>(t, table, thread, nthreads);
+    if constexpr (P > 3) fill_one_table<2>(t, table, thread, nthreads);
+  }
+  template <int p>
+  GPA_HD static void fill_one_table(cpx<T>* t, const cpx<T>* __restrict__ table, int thread, int nthreads) {
+    constexpr int lgLp = lg_len(p), r = 1 << bits(p);
+    cpx<T>* tp = t + lds_table_offset(p);
+    for (int e = thread; e < pass_sets(p) * 6; e += nthreads) {
+      const int m0 = e / 6, c = e % 6;
+      const int u = m0 << (LOG2L - lgLp);
+      const int ex = c < 3 ? c + 1 : 4 * (c - 2);
+      tp[e] = ex < r ? table[u * ex] : cpx<T>{T(1), T(0)};
+    }
+  }
+  GPA_HD static void load_twiddles(TwiddlesLds& tw, const cpx<T>* __restrict__ table, int tid, const cpx<T>* t) {
+    constexpr int b = bits(0), r = 1 << b, g = E / r, lgS = LOG2L - b;
+#pragma unroll
+    for (int q = 0; q < g; ++q) {
+      const int G = tid + TPF * q;
+      const int u = G & ((1 << lgS) - 1);
+#pragma unroll
+      for (int c = 0; c < 3; ++c) {
+        if ((c + 1) < r) tw.lo[q][c] = table[u * (c + 1)];
+        if (4 * (c + 1) < r) tw.hi[q][c] = table[u * 4 * (c + 1)];
+      }
+    }
+    tw.t = t;
+    tw.tid = tid;
+  }
+  template <int p, int r, bool INV>
+  GPA_HD static void twiddle(cpx<T>* v, const TwiddlesLds& tw, int q) {
+    cpx<T> lo[3], hi[3];
+    if constexpr (p == 0) {
+#pragma unroll
+      for (int c = 0; c < 3; ++c) { lo[c] = tw.lo[q][c]; hi[c] = tw.hi[q][c]; }
+    } else {
+      constexpr int lgS = lg_len(p) - bits(p);
+      const int m0 = (tw.tid + TPF * q) & ((1 << lgS) - 1);
+      const cpx<T>* t = tw.t + lds_table_offset(p) + m0 * 6;
+#pragma unroll
+      for (int c = 0; c < 3; ++c) {
+        if ((c + 1) < r) lo[c] = t[c];
+        if (4 * (c + 1) < r) hi[c] = t[3 + c];
+      }
+    }
+#pragma unroll
+    for (int k = 1; k < r; ++k) {
+      const int a = k >> 2, b = k & 3;
+      cpx<T> t = v[k];
+      if (a > 0) t = cmul_maybe_conj<INV>(t, hi[a - 1]);
+      if (b > 0) t = cmul_maybe_conj<INV>(t, lo[b - 1]);
+      v[k] = t;
+    }
+  }
+  GPA_HD static void refresh(TwiddlesLds&) {}
+
   // one pass of butterflies on the thread's 16 registers (q and j loops are
   // fully unrolled, so every register index is static)
   template <int p, bool INV, class TW>

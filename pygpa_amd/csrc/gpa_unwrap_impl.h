@@ -102,6 +102,11 @@ hipError_t rowhalf_rowdct(const Impl* w, const void* q, int ring, const double* 
 hipError_t rowhalf_rowidct_p(const Impl* w, const void* pin, void* pout, const double* part_rho, int nrho, int it, hipStream_t s);
 // persistent, software-pipelined rowidct_p for 4096-point f32 rows (gpa_unwrap_rowpers.hip; NO_ROWPERS: the one-pair-per-
 // workgroup kernel of gpa_unwrap_rows.hip)
+// gpa_unwrap_rowhalfpers.hip: the persistent, LDS-DMA-pipelined forms of the half-length kernels (f32, 8192 / 16384 points)
+bool rowhalfpers_offered(const Impl* w);
+hipError_t rowhalfpers_rowdct(const Impl* w, const void* q, int ring, const double* part_pq, int npq, double* part_norm, int it,
+                              int* nnorm, int init, hipStream_t s);
+hipError_t rowhalfpers_rowidct_p(const Impl* w, const void* pin, void* pout, const double* part_rho, int nrho, int it, hipStream_t s);
 bool pow2_rowpers_offered(const Impl* w);
 hipError_t pow2_rowidct_p_pers(const Impl* w, const void* pin, void* pout, const double* part_rho, int nrho, int it,
                                hipStream_t s);

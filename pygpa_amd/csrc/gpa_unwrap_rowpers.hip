@@ -16,26 +16,10 @@
 //     after it; the new one leaves as 16-byte stores that the next iteration does not wait for (counted vmcnt).
 // Barriers are raw s_barrier + lgkmcnt(0): __syncthreads() would drain the DMA in flight (vmcnt(0)).
 // Same arithmetic as rowidct_p_kernel, same order of operations per value: bit-identical p.
-#include "gpa_unwrap_impl.h"
+#include "gpa_unwrap_pers.h"
 
 namespace gpa {
 namespace {
-
-__device__ __forceinline__ unsigned lds_addr(const void* p) {
-  return (unsigned)(unsigned long long)(const __attribute__((address_space(3))) char*)p;
-}
-// one LDS-DMA wave-instruction: lane l copies 16 bytes from its own `gsrc` to LDS byte lds_dst + 16 l (lds_dst wave-uniform)
-__device__ __forceinline__ void glds16(const void* gsrc, unsigned lds_dst) {
-  unsigned keep;
-  asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, off\n\ts_mov_b32 m0, %0"
-               : "=&s"(keep)
-               : "v"(gsrc), "s"(lds_dst)
-               : "memory");
-}
-// opaque use of a register: whatever load produces it has been waited for when this returns
-__device__ __forceinline__ void settle(float& v) { asm volatile("" : "+v"(v)); }
-// workgroup barrier that leaves vector-memory operations (the DMA, the stores) in flight
-#define GPA_PBAR() asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory")
 
 template <int LG>
 struct PersGeom {

@@ -547,7 +547,8 @@ hipError_t pow2_rowidct_pq(const Impl* w, const void* pin, void* pout, const voi
 }
 hipError_t pow2_rowidct_p(const Impl* w, const void* pin, void* pout, const double* part_rho, int nrho, int it,
                           hipStream_t s) {
-  if (use_row_half(w) && rowhalf_offered(w)) return rowhalf_rowidct_p(w, pin, pout, part_rho, nrho, it, s);
+  if (use_row_half(w) && rowhalf_offered(w))
+    return rowhalfpers_offered(w) ? rowhalfpers_rowidct_p(w, pin, pout, part_rho, nrho, it, s) : rowhalf_rowidct_p(w, pin, pout, part_rho, nrho, it, s);
   if (pow2_rowpers_offered(w)) return pow2_rowidct_p_pers(w, pin, pout, part_rho, nrho, it, s);
 #define CASE(LG) case LG: return w->dtype == 0 ? run_rowidct_p<float, LG>(w, pin, pout, part_rho, nrho, it, s) \
                                                : run_rowidct_p<double, LG>(w, pin, pout, part_rho, nrho, it, s);
@@ -562,7 +563,9 @@ hipError_t pow2_rowdct_fused(const Impl* w, const void* q, int ring, const doubl
   // loses, 95 -> 126, and stays packed)
   if (w->dtype == 1 && w->lg1 == 12 && w->tw1h && !opt_set(OPT_NO_ROWHALF) && !opt_set(OPT_ROWHALF_MINLG))
     return rowhalf_rowdct(w, q, ring, part_pq, npq, part_norm, it, nnorm, init, s);
-  if (use_row_half(w) && rowhalf_offered(w)) return rowhalf_rowdct(w, q, ring, part_pq, npq, part_norm, it, nnorm, init, s);
+  if (use_row_half(w) && rowhalf_offered(w))
+    return rowhalfpers_offered(w) ? rowhalfpers_rowdct(w, q, ring, part_pq, npq, part_norm, it, nnorm, init, s)
+                                  : rowhalf_rowdct(w, q, ring, part_pq, npq, part_norm, it, nnorm, init, s);
 #define CASE(LG) case LG: return w->dtype == 0 ? run_rowdct_fused<float, LG>(w, q, ring, part_pq, npq, part_norm, it, nnorm, init, s) \
                                                : run_rowdct_fused<double, LG>(w, q, ring, part_pq, npq, part_norm, it, nnorm, init, s);
   switch (w->lg1) { GPA_FOR_LG(CASE) }

@@ -50,8 +50,10 @@ def solve_profiled(shape, dtype, dx, dy, w, kmax):
 
 # f32 tolerance by the longest axis: the Poisson preconditioner divides the lowest modes by eigenvalues ~ (pi / N)^2, i.e.
 # multiplies the f32 rounding of a row transform (~1e-7 per pass) by up to N^2 / pi^2 = 2.7e7 at N = 16384; the iteration
-# corrects most of it, what is left is a smooth offset of a few 1e-4 of |phi| at 16384 points (measured 4.0e-4)
-F32_TOL = {8192: 3e-4, 16384: 1e-3}
+# corrects most of it, what is left is a smooth offset whose size is a matter of the rounding's luck: over 12 problems (seeds) the
+# error at 64 x 16384 is 3e-4 .. 2.7e-3 of max|phi| (median 7e-4), at 128 x 8192 4e-5 .. 3.3e-4 (median 8e-5) -- the same
+# distribution for the one-row-per-workgroup and the persistent row kernels (tools/dbg/halfpers_seeds.py, round 6)
+F32_TOL = {8192: 6e-4, 16384: 4e-3}
 
 
 # (both sides powers of two: the power-of-two kernels; 96 x 8192 / 8192 x 96 run the same long axes on the mixed-radix
@@ -206,13 +208,14 @@ def test_stack_of_2048_frames_equals_single_images():
     plan.close()
 
 
-@pytest.mark.parametrize('shape', [(4096, 4096), (2048, 4096), (64, 4096)])
+@pytest.mark.parametrize('shape', [(4096, 4096), (2048, 4096), (64, 4096), (1024, 8192), (512, 16384)])
 def test_persistent_row_kernels_equal_per_pair_kernels(shape, gpa_option):
     """round 5: the persistent, software-pipelined rowidct_p kernel of gpa_unwrap_rowpers.hip (4096-point f32 rows: LDS-DMA of
     the next row pair into the other LDS buffer while the current one is transformed) against the one-pair-per-workgroup
     kernel it replaces (NO_ROWPERS): the same arithmetic in the same order -- phi equal BIT FOR BIT, equal iteration
     counts, over bands of 4 / 2 / 1 row pairs per workgroup, weighted, kmax 10 and kmax 23 (two flushes of the ring);
-    and the oracle's phi at 2048 x 4096."""
+    and the oracle's phi at 2048 x 4096.  Round 6: the same for the persistent half-length kernels of 8192- and 16384-point
+    rows (gpa_unwrap_rowhalfpers.hip; bands of 2 / 1-2 rows per workgroup) against the one-row-per-workgroup kernels."""
     dx, dy, w = make_problem(shape, seed=shape[0] + 7)
     dx, dy, w = (np.ascontiguousarray(v, dtype=np.float32) for v in (dx, dy, w))
     for kmax in (10, 23):

@@ -69,3 +69,42 @@ def test_persistent_row_kernel_vmcnt_invariant(tmp_path):
     assert head_ops.count('global_load_dwordx4') == 2 * NQ
     # in program order the DMA precedes the loads, and nothing but the loads and the stores is younger than it
     assert head_ops.index('global_load_dwordx4') > max(i for i, o in enumerate(head_ops) if o == 'global_load_lds_dwordx4')
+
+
+@pytest.mark.parametrize('kernel', ['rowidct_p_halfpers_kernelILi13E', 'rowidct_p_halfpers_kernelILi14E',
+                                    'rowdct_halfpers_kernelILi13E', 'rowdct_halfpers_kernelILi14E'])
+def test_persistent_half_length_kernels_vmcnt_invariant(kernel, tmp_path):
+    """round 6: the persistent half-length row kernels (gpa_unwrap_rowhalfpers.hip) guard their LDS landing zone the same way --
+    `s_waitcnt vmcnt(8)` at the top of the row loop, i.e. "everything older than the previous row's (at least) eight stores is
+    done".  What must hold: no scratch anywhere in the kernel (a spill inside the loop would be a vector-memory operation the
+    count does not know), the hand-written wait is the first instruction of the loop, the LDS-DMA of the next row is requested
+    before every other vector-memory operation of the iteration (hipcc's own waits for those then never fall short of the DMA),
+    and an iteration ends in at least eight stores with nothing but stores after the last load."""
+    global FLAGS
+    saved = FLAGS
+    FLAGS = [f for f in FLAGS if not f.startswith('-ffp-contract')] + ['-ffp-contract=off']   # as pygpa_amd/build.py compiles it
+    try:
+        text = _isa('gpa_unwrap_rowhalfpers', tmp_path)
+    finally:
+        FLAGS = saved
+    name, lines, desc = _function(text, kernel)
+    assert re.search(r'\.amdhsa_private_segment_fixed_size\s+0\b', desc), 'the kernel uses scratch: spills count in vmcnt'
+    assert not any('scratch_' in ln for ln in lines)
+    hdr = [i for i, ln in enumerate(lines) if re.match(r'^\.LBB\d+_\d+:.*Loop Header', ln)
+           and any('global_load_lds_dwordx4' in x for x in lines[i:i + 120])]
+    assert len(hdr) == 1, 'expected ONE loop around the LDS-DMA, found %d' % len(hdr)
+    h = hdr[0]
+    # (the loop opens with a register copy -- the opaque thread index; the wait must come before any barrier or memory operation)
+    first = next(ln for ln in lines[h + 1:] if VM.match(ln) or re.match(r'\s*(s_barrier|s_waitcnt vmcnt)', ln))
+    assert re.match(r'\s*s_waitcnt vmcnt\(8\)', first), first
+    # program order of the vector-memory operations from the loop header to the end of the function (the loop is the last thing
+    # the kernel does): DMA first, then loads, then only stores
+    ops = [VM.match(ln).group(1) for ln in lines[h:] if VM.match(ln)]
+    dma = [i for i, o in enumerate(ops) if o == 'global_load_lds_dwordx4']
+    loads = [i for i, o in enumerate(ops) if o.startswith('global_load') and o != 'global_load_lds_dwordx4']
+    stores = [i for i, o in enumerate(ops) if o.startswith('global_store')]
+    assert len(dma) == 8 and dma == list(range(8)), ops[:12]
+    assert stores and (not loads or min(stores) > max(loads)), ops
+    # (hipcc rotates the loop: the block that ends an iteration may sit in front of the header; count over the whole kernel)
+    allops = [VM.match(ln).group(1) for ln in lines if VM.match(ln)]
+    assert sum(o in ('global_store_dwordx4', 'global_store_dword') for o in allops) >= 8, allops
