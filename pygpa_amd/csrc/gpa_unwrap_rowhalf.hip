@@ -226,11 +226,7 @@ __global__ __launch_bounds__((RowHalfGeom<T, LG>::THREADS)) void rowidct_p_half_
       x[i] = {T(0.5) * zlo[i], T(0)};
       vh = T(0.70710678118654752440) * zhi[i];
     } else {
-#ifdef GPA_ROWHALF_NOTAB
-      x[i] = cmulc(cpx<T>{T(0.5) * zlo[i], T(-0.5) * zhi[i]}, wk[tid]);   // diagnosis only (wrong numbers)
-#else
       x[i] = cmulc(cpx<T>{T(0.5) * zlo[i], T(-0.5) * zhi[i]}, wk[k]);
-#endif
     }
     lds[F::pad(k)] = x[i];
   }
@@ -245,11 +241,7 @@ __global__ __launch_bounds__((RowHalfGeom<T, LG>::THREADS)) void rowidct_p_half_
       const cpx<T> vm = lds[F::pad(HN - k)];
       const cpx<T> ve = {T(0.5) * (x[i].x + vm.x), T(0.5) * (x[i].y - vm.y)};       // (V_k + conj V_m) / 2
       const cpx<T> d = {x[i].x - vm.x, x[i].y + vm.y};                              // V_k - conj V_m
-#ifdef GPA_ROWHALF_NOTAB
-      const cpx<T> vo = cscale(cmulc(d, twn[tid]), T(0.5));
-#else
       const cpx<T> vo = cscale(cmulc(d, twn[k]), T(0.5));                           // conj(E_k) (.) / 2
-#endif
       Tk = {ve.x - vo.y, ve.y + vo.x};                                              // Ve + i Vo
     }
     x[i] = {Tk.x, -Tk.y};                                                           // IFFT = conj(FFT(conj .))
