@@ -416,3 +416,30 @@ def test_a4_gradient_through_the_shared_forward_kernel(shape, grid, dtype, gpa_o
             both &= ~np.isnan(ds).any(axis=-1)
         assert np.abs(ds[both]).max() < (1e-9 if dtype is np.float64 else 4e-3), mode
     gpa_option('NO_SHARED_PHASES', None)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize('dtype', [np.float32, np.float64])
+def test_pass_a_plane_rotation_is_order_only(dtype, gpa_option):
+    """round 6: pass A's plane rotation (PA_ROT, default at 4096-point transforms and more: the owners of a 128-byte line of the
+    x-planes start their plane loop at a different plane) and the experiment switches beside it (PA_STAG phases / XCD map) change
+    the ORDER in which a workgroup computes its planes and nothing else: lock-ins of a 12-plane batch at 4096 x 1024 equal bit for
+    bit with the rotation off, on, with another multiplier, with the XCD map and with a stagger."""
+    from pygpa_amd.synthetic import hex_kvecs, gaussian_bump_displacement, hex_moire, explicit_klists
+    shape = (4096, 1024)
+    kvecs = hex_kvecs(0.1, 7.0)
+    img = hex_moire(shape, kvecs, 0.5 * gaussian_bump_displacement(shape), noise=0.05, seed=3, dtype=dtype)
+    img0 = img - img.mean()
+    ks = np.concatenate([k for k in explicit_klists(kvecs, 0.04, 2, 2)])[:12]
+    outs = []
+    for opts in ({'PA_ROT': '0'}, {}, {'PA_ROT': '5'}, {'PA_STAG': '-1'}, {'PA_STAG': '3', 'PA_STAG_TICKS': '200'}):
+        for k in ('PA_ROT', 'PA_STAG', 'PA_STAG_TICKS'):
+            gpa_option(k, opts.get(k))
+        plan = _lib.Plan(shape, 12, dtype)
+        outs.append(plan.lockin_batch(img0, ks, 10))
+        plan.close()
+    for k in ('PA_ROT', 'PA_STAG', 'PA_STAG_TICKS'):
+        gpa_option(k, None)
+    assert np.isfinite(outs[0]).all() and np.abs(outs[0]).max() > 0
+    for o in outs[1:]:
+        assert np.array_equal(o, outs[0])
