@@ -339,6 +339,9 @@ def kernel_table(n, L0, L1, P, K, Bx, s, iters, kern, stage, res_s):
             row['executed_TFLOPs'] = round(m['executed_flops'] / per / 1e12, 2)
         if c.get('valu_insts'):
             row['valu_issue_frac'] = round(c['valu_insts'] / per / VALU_ISSUE_PEAK, 4)
+            # the same count priced at what a SIMD with 2-3 resident waves retires (one wave64 instruction per ~4 cycles; the
+            # 2-cycle peak needs 8 waves: tools/ubench/pkfma.hip 7.2 / 4.1 / 3.2 / 2.8 cycles at 1 / 2 / 4 / 8 waves)
+            row['valu_busy_frac_4cycle'] = round(c['valu_insts'] * 4 / (1024 * 2.4e9) / per, 4)
         fr = {'hbm': row.get('hbm_frac', (m['bytes'] / per / 1e9 / HBM_PEAK_GBS) if m.get('bytes') else 0.0),
               'valu': row.get('valu_issue_frac', ((m.get('executed_flops') or m['flops']) / per / 1e12 / valu_peak) if m.get('flops') else 0.0)}
         row['bound'] = max(fr, key=fr.get)
@@ -367,13 +370,16 @@ def kernel_table(n, L0, L1, P, K, Bx, s, iters, kern, stage, res_s):
                            'algorithmic_TFLOPs': round(dm['flops'] / dsec / 1e12, 2),
                            'algorithmic_frac': round(dm['flops'] / dsec / 1e12 / valu_peak, 4),
                            'algorithmic_bytes_per_launch': dm.get('bytes'),
-                           'valu_issue_frac': drow.get('valu_issue_frac'), 'source': src,
+                           'valu_issue_frac': drow.get('valu_issue_frac'),
+                           'valu_busy_frac_4cycle': drow.get('valu_busy_frac_4cycle'), 'source': src,
                            'note': 'frac = EXECUTED flops over peak: the transforms the kernel performs (one forward per x-plane row, one '
                                    'inverse per candidate, nominal 5 L log2 L each) over the HIP-event time, against the vector peak of the precision of the plan (f32 157.3, f64 78.6 TFLOP/s); '
                                    'algorithmic_* credits the reference algorithm\'s work instead (a forward AND an inverse transform per '
                                    'candidate and row), which the shared-forward kernel does not perform; valu_issue_frac = counted VALU '
-                                   'wave-instructions / (1024 SIMDs x 1 per 2 cycles x 2.4 GHz); a small MFMA contraction (the row-end fix) '
-                                   'runs beside the vector pipe'}
+                                   'wave-instructions / (1024 SIMDs x 1 per 2 cycles x 2.4 GHz) -- a rate a SIMD reaches with 8 resident waves; '
+                                   'valu_busy_frac_4cycle prices the same count at one instruction per 4 cycles, what a SIMD retires with the 2-3 '
+                                   'waves this kernel\'s LDS and registers allow (profiles/r06_passA_rotation.txt section 7): on that clock the kernel '
+                                   'is VALU-bound outright; a small MFMA contraction (the row-end fix) runs beside the vector pipe'}
     else:
         ach = (dc.get('hbm_bytes') or dm.get('bytes') or 0) / dsec / 1e9
         out['roofline'] = {'bound': 'hbm', 'kernel': dom, 'achieved': round(ach, 1), 'peak': HBM_PEAK_GBS, 'unit': 'GB/s',

@@ -1,6 +1,6 @@
 #!/usr/bin/env python3
 """Predicted per-image time and Mpixels/s of the tile pipeline on 1 / 2 / 4 / 8 MI355X from MEASURED single-GPU stage
-times (profiles/r04_stage_times.json, tools/stage_times.py) and a per-link xGMI model -- the curve a SCALE run of
+times (profiles/r06_stage_times.json, tools/stage_times.py) and a per-link xGMI model -- the curve a SCALE run of
 `bench.py --gpus N` is to be compared with (no multi-GPU box was available to this build).
 
 Model, per image in the steady state of TiledPipeline.run_stream (every rank carries the same load over a rotation):
@@ -20,7 +20,7 @@ import os
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 LINK = 153e9 / 2
-st = json.load(open(os.path.join(ROOT, 'profiles', 'r04_stage_times.json')))
+st = json.load(open(os.path.join(ROOT, 'profiles', 'r06_stage_times.json')))
 T_LAT = 30e-6
 shapes = {1: 4096, 2: None, 4: 8192, 8: 16384}
 tw = st['4096']['alone']['tile_stage_s_per_window_alone']
