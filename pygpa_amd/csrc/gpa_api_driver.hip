@@ -69,7 +69,7 @@ int extract_launch(gpa_plan* p, const void* image, int P, int K, int Bx, int mas
                                      p->stream, 1, 0, 0, ystep));
     hipError_t ep = unwrap_enqueue_prepared(&p->uwp, p->d_wnorm, nparts, kmax, 1e-9, true, u, p->stream);
     if (ep == hipSuccess) ep = unwrap_fetch_iters(&p->uwp, p->h_iters, p->stream);
-    if (ep != hipSuccess) return fail(GPA_ERR_HIP, std::string("unwrap: ") + hipGetErrorString(ep));
+    if (ep != hipSuccess) return unwrap_fail(ep);
     p->iters_stride = 4;
     p->iters_off = unwrap_iters_slot(&p->uwp);
     return GPA_OK;
@@ -106,7 +106,7 @@ int extract_launch(gpa_plan* p, const void* image, int P, int K, int Bx, int mas
   if (e == hipSuccess) e = unwrap_fetch_iters(&p->uw, &p->h_iters[0], p->stream);
   if (threaded) p->worker->wait(); else second();
   if (e == hipSuccess) e = e2;
-  if (e != hipSuccess) return fail(GPA_ERR_HIP, std::string("unwrap: ") + hipGetErrorString(e));
+  if (e != hipSuccess) return unwrap_fail(e);
   HIP_TRY(hipEventRecord(p->ev_join, p->stream2));
   HIP_TRY(hipStreamWaitEvent(p->stream, p->ev_join, 0));
   if (p->profiling) HIP_TRY(hipEventRecord(p->stage_ev[5], p->stream));

@@ -76,7 +76,7 @@ int gpa_unwrap_prediff_dev(gpa_plan* p, const void* dx, const void* dy, const vo
   int iters = 0;
   ProfInstall prof(p);   // (gpa_set_profiling: per-kernel times of this solve through gpa_last_kernel_profile)
   hipError_t e = unwrap_run(&p->uw, dx, dy, weight, false, kmax, eps, compat != 0, phi, &iters, p->stream);
-  if (e != hipSuccess) return fail(GPA_ERR_HIP, std::string("unwrap: ") + hipGetErrorString(e));
+  if (e != hipSuccess) return unwrap_fail(e);
   if (p->profiling) collect_kernel_profile(p);
   if (iters_out) *iters_out = iters;
   return GPA_OK;
@@ -89,7 +89,7 @@ int gpa_unwrap_prediff_enqueue_dev(gpa_plan* p, const void* dx, const void* dy, 
   NEED_UNWRAP(p, "gpa_unwrap_prediff_enqueue");
   HIP_TRY(hipSetDevice(p->device));
   hipError_t e = unwrap_enqueue(&p->uw, dx, dy, weight, false, kmax, eps, compat != 0, phi, p->stream);
-  if (e != hipSuccess) return fail(GPA_ERR_HIP, std::string("unwrap: ") + hipGetErrorString(e));
+  if (e != hipSuccess) return unwrap_fail(e);
   return GPA_OK;
 }
 
@@ -99,7 +99,7 @@ int gpa_unwrap_finish(gpa_plan* p, int* iters_out) {
   HIP_TRY(hipSetDevice(p->device));
   int iters = 0;
   hipError_t e = unwrap_finish(&p->uw, &iters, p->stream);
-  if (e != hipSuccess) return fail(GPA_ERR_HIP, std::string("unwrap: ") + hipGetErrorString(e));
+  if (e != hipSuccess) return unwrap_fail(e);
   if (iters_out) *iters_out = iters;
   return GPA_OK;
 }
@@ -132,7 +132,7 @@ int gpa_unwrap(gpa_plan* p, const void* psi, const void* weight, int kmax, doubl
   int iters = 0;
   hipError_t e = unwrap_run(&p->uw, p->d_image, nullptr, weight ? p->d_wnorm : nullptr, true, kmax, eps,
                             compat != 0, p->d_u, &iters, p->stream);
-  if (e != hipSuccess) return fail(GPA_ERR_HIP, std::string("unwrap: ") + hipGetErrorString(e));
+  if (e != hipSuccess) return unwrap_fail(e);
   if (iters_out) *iters_out = iters;
   HIP_TRY(hipMemcpyAsync(phi, p->d_u, npx * p->rsz, hipMemcpyDeviceToHost, p->stream));
   HIP_TRY(hipStreamSynchronize(p->stream));

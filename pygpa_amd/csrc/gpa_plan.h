@@ -265,6 +265,13 @@ Axis make_axis(int n);
 Axis compact_axis(const Axis& full, int E);
 int upload_real_table(gpa_plan* p, void* dst, const std::vector<double>& v);
 int dmalloc(gpa_plan* p, void** ptr, size_t bytes);
+// an unwrap that did not start: hipErrorNotSupported is the workspace's "this shape has no kernels" (gpa_unwrap_tables.hip)
+inline int unwrap_fail(hipError_t e) {
+  if (e == hipErrorNotSupported)
+    return fail(GPA_ERR_STATE, "unwrap: no kernels for this shape -- an image with an axis that is not a power of two needs both axes <= 8192 "
+                               "(f32) / 4096 (f64); powers of two go to 16384 / 8192 per axis (INTEGRATION.md, size limits)");
+  return fail(GPA_ERR_HIP, std::string("unwrap: ") + hipGetErrorString(e));
+}
 int plan_build(gpa_plan* p);
 int upload_twiddles(gpa_plan* p, void* dst, int L);
 

@@ -281,3 +281,21 @@ def test_f32_stagnation_guard_fires_and_has_a_switch(golden, gpa_option):
     plan.close()
     assert tuple(iters) == tuple(iters_off) == (10, 10)
     assert np.array_equal(u, u_off)
+
+
+def test_shapes_without_unwrap_kernels_say_so():
+    """the unwrap's size limits: a 16384-point axis beside an axis that is not a power of two has no kernels in
+    f32 (the mixed-radix engine stops at 8192 points), nor has 300 x 8192 in f64 -- the call fails with GPA_ERR_STATE and names the
+    limit instead of a bare HIP error string; 300 x 8192 in f32 runs."""
+    rng = np.random.default_rng(1)
+    for shape, dt, ok in (((300, 16384), np.float32, False), ((300, 8192), np.float64, False), ((300, 8192), np.float32, True)):
+        dx = (0.1 * rng.standard_normal((shape[0], shape[1] - 1))).astype(dt)
+        dy = (0.1 * rng.standard_normal((shape[0] - 1, shape[1]))).astype(dt)
+        plan = _lib.Plan(shape, 1, dt)
+        if ok:
+            phi, it = plan.unwrap_prediff(dx, dy, None, kmax=2)
+            assert np.isfinite(phi).all() and it == 2
+        else:
+            with pytest.raises(_lib.GPAError, match='no kernels for this shape'):
+                plan.unwrap_prediff(dx, dy, None, kmax=2)
+        plan.close()
