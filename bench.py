@@ -900,18 +900,26 @@ def multi_gpu(args, world, rank, local_rank):
     # ---- diagnostics for the scaling line (after the timed region): what the backend says the world is, and per-rank
     #      stage times -- host times of the timed stream (enqueueing + waits) and DEVICE-inclusive times of one unpipelined
     #      step with the device drained after every stage
-    dev_ms = {}
-    pipe.step(timings=dev_ms)
+    #      (the timed value is complete at this point: a diagnostic that fails on every rank alike is reported, not fatal)
+    dev_ms, diag_err = {}, None
+    try:
+        pipe.step(timings=dev_ms)
+    except Exception as e:
+        diag_err = 'step(timings): %s: %s' % (type(e).__name__, e)
     lf_ms = None
-    if not args.no_lf:
-        torch.cuda.synchronize(dev)
-        t_lf = time.perf_counter()
-        full = torch.zeros(shape, dtype=torch.float32 if np_dt is np.float32 else torch.float64, device=dev)
-        pipe.undistort(full)          # (the rounds depend on u, not on the image: a zero image times the same kernels)
-        torch.cuda.synchronize(dev)
-        lf_ms = (time.perf_counter() - t_lf) * 1e3
+    if not args.no_lf and diag_err is None:
+        try:
+            torch.cuda.synchronize(dev)
+            t_lf = time.perf_counter()
+            full = torch.zeros(shape, dtype=torch.float32 if np_dt is np.float32 else torch.float64, device=dev)
+            pipe.undistort(full)          # (the rounds depend on u, not on the image: a zero image times the same kernels)
+            torch.cuda.synchronize(dev)
+            lf_ms = (time.perf_counter() - t_lf) * 1e3
+        except Exception as e:
+            diag_err = 'undistort: %s: %s' % (type(e).__name__, e)
     mine = {'rank': rank, 'tiles': len(pipe.mine), 'stream_host_ms_per_image': {k: round(v / max(args.steps, 1) * 1e3, 3) for k, v in pipe.stage_s.items()} if stream else None,
-            'step_device_ms': {k: round(v, 3) for k, v in dev_ms.items()}, 'undistort_tile_sharded_ms': None if lf_ms is None else round(lf_ms, 2)}
+            'step_device_ms': {k: round(v, 3) for k, v in dev_ms.items()}, 'undistort_tile_sharded_ms': None if lf_ms is None else round(lf_ms, 2),
+            'diagnostic_error': diag_err}
     per_rank = [None] * world
     dist.all_gather_object(per_rank, mine)
     if rank == 0:
